@@ -1,0 +1,772 @@
+// mhx_api.hip -- host side of libmhx.so: the C ABI of include/mhx.h, device memory ownership,
+// kernel selection (pre-built register kernel / hiprtc-specialised kernel / generic kernel) and
+// the mcmcsample-equivalent launch schedule.  No torch types, no C++ types across the boundary.
+#include "../../include/mhx.h"
+
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "mhx_rwmh_kernels.h"
+#include "mhx_emcee_kernels.h"
+#include "mhx_ram_kernels.h"
+#include "mhx_diag_kernels.h"
+#include "mhx_jit_embed.inc"   // generated: the device headers as string literals for hiprtc
+
+// ---------------------------------------------------------------------------------------------
+// errors
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...)
+{
+    char buf[2048];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return fail(MHX_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,  \
+                        __LINE__);                                                                  \
+    } while (0)
+
+extern "C" int mhx_version(void) { return MHX_VERSION; }
+extern "C" const char* mhx_last_error(void) { return g_err.c_str(); }
+
+// ---------------------------------------------------------------------------------------------
+// pre-built kernels (hipcc, gfx950)
+template <int D, int TK, int PK>
+__global__ void __launch_bounds__(64)
+k_rwmh_reg(const mhx_rwmh_args a, const float* __restrict__ tparams, const float* __restrict__ pvec)
+{
+    mhx_rwmh_reg_body<D, TK, PK>(a, tparams, pvec);
+}
+__global__ void __launch_bounds__(256)
+k_rwmh_generic(const mhx_rwmh_args a, const float* __restrict__ tparams, const float* __restrict__ pvec)
+{
+    mhx_rwmh_generic_body<MHX_TARGET_DYNAMIC>(a, tparams, pvec);
+}
+__global__ void __launch_bounds__(256)
+k_rwmh_init(const mhx_rwmh_args a, const float* __restrict__ tparams, const float* __restrict__ pvec, const int draw)
+{
+    mhx_rwmh_init_body<MHX_TARGET_DYNAMIC>(a, tparams, pvec, draw);
+}
+__global__ void __launch_bounds__(256)
+k_target_eval(const float* __restrict__ x, float* __restrict__ lp, const int n, const int d, const int kind,
+              const float* __restrict__ tparams, const int ntparams, const float tconst)
+{
+    mhx_target_eval_body<MHX_TARGET_DYNAMIC>(x, lp, n, d, kind, tparams, ntparams, tconst);
+}
+__global__ void __launch_bounds__(256)
+k_record_state(const float* __restrict__ x, const float* __restrict__ lp, const unsigned char* __restrict__ last_acc,
+               float* samples, unsigned char* accepted, const int n, const long ld, const int d, const long slot)
+{
+    mhx_record_state_body(x, lp, last_acc, samples, accepted, n, ld, d, slot);
+}
+
+struct prebuilt_reg { int D, TK, PK; void (*fn)(const mhx_rwmh_args, const float*, const float*); };
+static const prebuilt_reg k_prebuilt_reg[] = {
+    {100, MHX_TARGET_ISO_GAUSS, MHX_PROP_ISO, k_rwmh_reg<100, MHX_TARGET_ISO_GAUSS, MHX_PROP_ISO>},
+    {2, MHX_TARGET_IID_NORMAL, MHX_PROP_ISO, k_rwmh_reg<2, MHX_TARGET_IID_NORMAL, MHX_PROP_ISO>},
+};
+
+// ---------------------------------------------------------------------------------------------
+// context + JIT cache
+struct jit_module {
+    hipModule_t mod = nullptr;
+    std::map<std::string, hipFunction_t> fns;
+};
+
+struct mhx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::map<std::string, std::unique_ptr<jit_module>> jit;
+    ~mhx_ctx()
+    {
+        for (auto& kv : jit)
+            if (kv.second && kv.second->mod) (void)hipModuleUnload(kv.second->mod);
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+extern "C" int mhx_ctx_create(int device, mhx_ctx** out)
+{
+    if (!out) return fail(MHX_EINVAL, "mhx_ctx_create: out is NULL");
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(MHX_EINVAL, "mhx_ctx_create: device %d of %d", device, n);
+    HIP_TRY(hipSetDevice(device));
+    std::unique_ptr<mhx_ctx> c(new mhx_ctx);
+    c->device = device;
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&c->ev0));
+    HIP_TRY(hipEventCreate(&c->ev1));
+    *out = c.release();
+    return MHX_OK;
+}
+
+extern "C" int mhx_ctx_destroy(mhx_ctx* ctx)
+{
+    if (!ctx) return MHX_OK;
+    (void)hipSetDevice(ctx->device);
+    delete ctx;
+    return MHX_OK;
+}
+
+// compile `source` (which #includes the embedded device headers) with hiprtc for gfx950
+static int jit_compile(mhx_ctx* ctx, const std::string& key, const std::string& source,
+                       const std::vector<std::string>& defines, jit_module** out)
+{
+    auto it = ctx->jit.find(key);
+    if (it != ctx->jit.end()) { *out = it->second.get(); return MHX_OK; }
+    hiprtcProgram prog = nullptr;
+    const char* hdr_src[] = {k_src_mhx_device_math_h, k_src_mhx_targets_h, k_src_mhx_rwmh_kernels_h,
+                             k_src_mhx_emcee_kernels_h, k_src_mhx_ram_kernels_h};
+    const char* hdr_name[] = {"mhx_device_math.h", "mhx_targets.h", "mhx_rwmh_kernels.h",
+                              "mhx_emcee_kernels.h", "mhx_ram_kernels.h"};
+    hiprtcResult r = hiprtcCreateProgram(&prog, source.c_str(), "mhx_jit.hip", 5, hdr_src, hdr_name);
+    if (r != HIPRTC_SUCCESS) return fail(MHX_EJIT, "hiprtcCreateProgram: %s", hiprtcGetErrorString(r));
+    std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
+    for (auto& d : defines) opts.push_back("-D" + d);
+    std::vector<const char*> copts;
+    for (auto& o : opts) copts.push_back(o.c_str());
+    r = hiprtcCompileProgram(prog, (int)copts.size(), copts.data());
+    if (r != HIPRTC_SUCCESS) {
+        size_t ls = 0;
+        hiprtcGetProgramLogSize(prog, &ls);
+        std::string log(ls, '\0');
+        if (ls) hiprtcGetProgramLog(prog, &log[0]);
+        hiprtcDestroyProgram(&prog);
+        if (log.size() > 1800) log.resize(1800);
+        return fail(MHX_EJIT, "hiprtc compile failed (%s): %s", hiprtcGetErrorString(r), log.c_str());
+    }
+    size_t cs = 0;
+    hiprtcGetCodeSize(prog, &cs);
+    std::vector<char> code(cs);
+    hiprtcGetCode(prog, code.data());
+    hiprtcDestroyProgram(&prog);
+    std::unique_ptr<jit_module> m(new jit_module);
+    hipError_t e = hipModuleLoadData(&m->mod, code.data());
+    if (e != hipSuccess) return fail(MHX_EJIT, "hipModuleLoadData: %s", hipGetErrorString(e));
+    *out = m.get();
+    ctx->jit[key] = std::move(m);
+    return MHX_OK;
+}
+
+static int jit_function(jit_module* m, const char* name, hipFunction_t* fn)
+{
+    auto it = m->fns.find(name);
+    if (it != m->fns.end()) { *fn = it->second; return MHX_OK; }
+    hipError_t e = hipModuleGetFunction(fn, m->mod, name);
+    if (e != hipSuccess) return fail(MHX_EJIT, "hipModuleGetFunction(%s): %s", name, hipGetErrorString(e));
+    m->fns[name] = *fn;
+    return MHX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// targets
+struct mhx_target {
+    mhx_ctx* ctx = nullptr;
+    int kind = 0, dim = 0, nparams = 0;
+    float cst = 0.0f;
+    float* dparams = nullptr;
+    std::string user_src;        // MHX_TARGET_USER
+    std::string user_key;        // hash of the source, for the JIT cache
+    ~mhx_target() { if (dparams) (void)hipFree(dparams); }
+};
+
+static float target_const(int kind, int dim, const float* p)
+{
+    const double LOG_2PI = 1.8378770664093454835606594728112;
+    double c = -0.5 * (double)dim * LOG_2PI;
+    switch (kind) {
+    case MHX_TARGET_CORR_GAUSS: {
+        size_t off = 0;
+        for (int i = 0; i < dim; ++i) { c += std::log((double)p[off + i]); off += (size_t)i + 1; }
+        break;
+    }
+    case MHX_TARGET_BANANA: c -= 0.5 * std::log(100.0); break;
+    case MHX_TARGET_FUNNEL: c -= std::log(3.0); break;
+    case MHX_TARGET_IID_NORMAL:
+    case MHX_TARGET_USER: c = 0.0; break;
+    default: break;
+    }
+    return (float)c;
+}
+
+static int target_upload(mhx_target* t, const float* params, size_t nparams)
+{
+    t->nparams = (int)nparams;
+    // one dummy element keeps the pointer valid for kinds without parameters
+    const size_t n = nparams ? nparams : 1;
+    HIP_TRY(hipMalloc(&t->dparams, n * sizeof(float)));
+    if (nparams) HIP_TRY(hipMemcpy(t->dparams, params, nparams * sizeof(float), hipMemcpyHostToDevice));
+    else HIP_TRY(hipMemset(t->dparams, 0, sizeof(float)));
+    return MHX_OK;
+}
+
+extern "C" int mhx_target_builtin(mhx_ctx* ctx, int kind, int dim, const float* params, size_t nparams,
+                                  mhx_target** out)
+{
+    if (!ctx || !out) return fail(MHX_EINVAL, "mhx_target_builtin: NULL argument");
+    if (dim <= 0) return fail(MHX_EINVAL, "mhx_target_builtin: dim must be positive, got %d", dim);
+    if (nparams && !params) return fail(MHX_EINVAL, "mhx_target_builtin: params is NULL");
+    const size_t tri = (size_t)dim * ((size_t)dim + 1) / 2;
+    switch (kind) {
+    case MHX_TARGET_ISO_GAUSS:
+        if (nparams) return fail(MHX_EINVAL, "ISO_GAUSS takes no parameters");
+        break;
+    case MHX_TARGET_CORR_GAUSS:
+        if (nparams != tri) return fail(MHX_EINVAL, "CORR_GAUSS needs %zu packed-lower parameters, got %zu", tri, nparams);
+        for (int i = 0; i < dim; ++i)
+            if (!(params[(size_t)i * (i + 1) / 2 + i] > 0.0f))
+                return fail(MHX_ENOTPD, "CORR_GAUSS: diagonal %d of inv(chol(Sigma)) is not positive", i);
+        break;
+    case MHX_TARGET_IID_NORMAL:
+        if (dim != 2) return fail(MHX_EINVAL, "IID_NORMAL is a 2-parameter (mu, sigma) model, dim=%d", dim);
+        if (nparams < 1) return fail(MHX_EINVAL, "IID_NORMAL needs at least one data point");
+        break;
+    case MHX_TARGET_BANANA:
+        if (dim < 2 || nparams != 1) return fail(MHX_EINVAL, "BANANA needs dim >= 2 and params = {b}");
+        break;
+    case MHX_TARGET_FUNNEL:
+        if (dim < 2 || nparams != 0) return fail(MHX_EINVAL, "FUNNEL needs dim >= 2 and no parameters");
+        break;
+    default:
+        return fail(MHX_EINVAL, "mhx_target_builtin: unknown kind %d", kind);
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::unique_ptr<mhx_target> t(new mhx_target);
+    t->ctx = ctx;
+    t->kind = kind;
+    t->dim = dim;
+    t->cst = target_const(kind, dim, params);
+    int rc = target_upload(t.get(), params, nparams);
+    if (rc) return rc;
+    *out = t.release();
+    return MHX_OK;
+}
+
+static std::string fnv_hex(const std::string& s)
+{
+    unsigned long long h = 1469598103934665603ull;
+    for (unsigned char ch : s) { h ^= ch; h *= 1099511628211ull; }
+    char b[32];
+    snprintf(b, sizeof b, "%016llx", h);
+    return b;
+}
+
+static std::string jit_source(const mhx_target* t, const char* family_header)
+{
+    std::string s = "#include \"mhx_device_math.h\"\n";
+    if (t->kind == MHX_TARGET_USER) {
+        s += "#line 1 \"user_logdensity.hip\"\n";
+        s += t->user_src;
+        s += "\n#define MHX_HAVE_USER_TARGET 1\n";
+    }
+    s += "#include \"";
+    s += family_header;
+    s += "\"\n";
+    return s;
+}
+
+static int jit_generic_rwmh(const mhx_target* t, jit_module** m)
+{
+    const std::string key = "rwmh_generic/tk=" + std::to_string(t->kind) + "/" + t->user_key;
+    return jit_compile(t->ctx, key, jit_source(t, "mhx_rwmh_kernels.h"),
+                       {"MHX_JIT_RWMH_GENERIC=1", "MHX_JIT_TK=" + std::to_string(t->kind)}, m);
+}
+
+extern "C" int mhx_target_from_hip_source(mhx_ctx* ctx, const char* src, int dim, const float* data,
+                                          size_t ndata, mhx_target** out)
+{
+    if (!ctx || !src || !out) return fail(MHX_EINVAL, "mhx_target_from_hip_source: NULL argument");
+    if (dim <= 0) return fail(MHX_EINVAL, "mhx_target_from_hip_source: dim must be positive");
+    if (ndata && !data) return fail(MHX_EINVAL, "mhx_target_from_hip_source: data is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::unique_ptr<mhx_target> t(new mhx_target);
+    t->ctx = ctx;
+    t->kind = MHX_TARGET_USER;
+    t->dim = dim;
+    t->cst = 0.0f;
+    t->user_src = src;
+    t->user_key = fnv_hex(t->user_src);
+    int rc = target_upload(t.get(), data, ndata);
+    if (rc) return rc;
+    // compile now so that a bad source is reported at model construction, like a MethodError would be
+    jit_module* m = nullptr;
+    rc = jit_generic_rwmh(t.get(), &m);
+    if (rc) return rc;
+    *out = t.release();
+    return MHX_OK;
+}
+
+extern "C" int mhx_target_destroy(mhx_target* t)
+{
+    if (!t) return MHX_OK;
+    (void)hipSetDevice(t->ctx->device);
+    delete t;
+    return MHX_OK;
+}
+
+static int launch_module(hipFunction_t fn, unsigned grid, unsigned block, hipStream_t s, void** params)
+{
+    HIP_TRY(hipModuleLaunchKernel(fn, grid, 1, 1, block, 1, 1, 0, s, params, nullptr));
+    return MHX_OK;
+}
+
+extern "C" int mhx_target_eval(mhx_ctx* ctx, const mhx_target* t, const float* x, int n, float* lp)
+{
+    if (!ctx || !t || !x || !lp || n <= 0) return fail(MHX_EINVAL, "mhx_target_eval: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    float *dx = nullptr, *dlp = nullptr;
+    const size_t nx = (size_t)t->dim * (size_t)n;
+    HIP_TRY(hipMalloc(&dx, nx * sizeof(float)));
+    HIP_TRY(hipMalloc(&dlp, (size_t)n * sizeof(float)));
+    int rc = MHX_OK;
+    do {
+        if (hipMemcpy(dx, x, nx * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { rc = fail(MHX_EHIP, "H2D copy failed"); break; }
+        const unsigned grid = (unsigned)((n + 255) / 256);
+        int d = t->dim, kind = t->kind, np = t->nparams;
+        float cst = t->cst;
+        const float* tp = t->dparams;
+        if (t->kind == MHX_TARGET_USER) {
+            jit_module* m = nullptr;
+            hipFunction_t fn;
+            if ((rc = jit_generic_rwmh(t, &m))) break;
+            if ((rc = jit_function(m, "mhx_jit_target_eval", &fn))) break;
+            void* params[] = {&dx, &dlp, &n, &d, &kind, &tp, &np, &cst};
+            if ((rc = launch_module(fn, grid, 256, ctx->stream, params))) break;
+        } else {
+            hipLaunchKernelGGL(k_target_eval, dim3(grid), dim3(256), 0, ctx->stream, dx, dlp, n, d, kind, tp, np, cst);
+        }
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) { rc = fail(MHX_EHIP, "target_eval kernel failed"); break; }
+        if (hipMemcpy(lp, dlp, (size_t)n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(MHX_EHIP, "D2H copy failed"); break; }
+    } while (0);
+    (void)hipFree(dx);
+    (void)hipFree(dlp);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// runs
+enum run_kind { RUN_RWMH = 0, RUN_EMCEE = 1, RUN_RAM = 2 };
+
+struct mhx_run {
+    mhx_ctx* ctx = nullptr;
+    const mhx_target* target = nullptr;
+    int kind = RUN_RWMH;
+    int dim = 0, n = 0;                  // n = chains / walkers
+    uint64_t seed = 0, first_id = 0;
+    int flags = 0;
+    bool initialised = false;
+    uint64_t tau = 0;                    // transitions done so far (RNG step counter)
+    // rwmh
+    int prop_kind = 0;
+    float prop_scale = 1.0f;
+    float* d_pvec = nullptr;
+    // emcee
+    float stretch = 2.0f;
+    // ram
+    mhx_ram_cfg ramcfg{};
+    float *d_S = nullptr, *d_S2 = nullptr;       // packed factors (current / scratch), [n][tri] each
+    unsigned char* d_Ssel = nullptr;             // which buffer holds chain c's current factor
+    unsigned char* d_status = nullptr;
+    float *d_dmin = nullptr, *d_dmax = nullptr;  // [dim][n]
+    float* d_eta = nullptr;                      // adaptation step sizes of the current launch
+    size_t eta_cap = 0;
+    // state
+    float *d_x = nullptr, *d_lp = nullptr, *d_ybuf = nullptr;
+    uint32_t* d_acc = nullptr;
+    unsigned char* d_last = nullptr;
+    unsigned long long* d_acc_total = nullptr;
+    // sample buffer of the last mhx_run_sample
+    float* d_samples = nullptr;
+    unsigned char* d_accepted = nullptr;
+    size_t samples_cap = 0, accepted_cap = 0;
+    int64_t n_saved = 0;
+    // kernel choice
+    int variant = 0;
+    void (*reg_fn)(const mhx_rwmh_args, const float*, const float*) = nullptr;
+    hipFunction_t jit_step = nullptr, jit_init = nullptr;
+    mhx_stats stats{};
+
+    ~mhx_run()
+    {
+        void* ptrs[] = {d_pvec, d_S, d_S2, d_Ssel, d_status, d_dmin, d_dmax, d_eta, d_x, d_lp, d_ybuf,
+                        d_acc, d_last, d_acc_total, d_samples, d_accepted};
+        for (void* p : ptrs) if (p) (void)hipFree(p);
+    }
+};
+
+static int run_alloc_state(mhx_run* r)
+{
+    const size_t n = (size_t)r->n, d = (size_t)r->dim;
+    HIP_TRY(hipMalloc(&r->d_x, d * n * sizeof(float)));
+    HIP_TRY(hipMalloc(&r->d_lp, n * sizeof(float)));
+    HIP_TRY(hipMalloc(&r->d_acc, n * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&r->d_last, n));
+    HIP_TRY(hipMalloc(&r->d_acc_total, sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(r->d_acc, 0, n * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(r->d_last, 0, n));
+    HIP_TRY(hipMemset(r->d_acc_total, 0, sizeof(unsigned long long)));
+    return MHX_OK;
+}
+
+static mhx_rwmh_args rwmh_args(const mhx_run* r)
+{
+    mhx_rwmh_args a;
+    memset(&a, 0, sizeof a);
+    a.x = r->d_x; a.lp = r->d_lp; a.acc_count = r->d_acc; a.acc_total = r->d_acc_total;
+    a.samples = r->d_samples; a.accepted = r->d_accepted; a.last_acc = r->d_last; a.ybuf = r->d_ybuf;
+    a.seed = r->seed; a.first_chain = r->first_id;
+    a.nchains = r->n; a.ld = r->n; a.dim = r->dim;
+    a.target_kind = r->target->kind; a.ntparams = r->target->nparams; a.tconst = r->target->cst;
+    a.prop_kind = r->prop_kind; a.pscale = r->prop_scale;
+    a.save_next = MHX_NO_SAVE; a.thinning = 1;
+    return a;
+}
+
+#define MHX_REG_MAX_DIM 160
+#define MHX_REG_MAX_DIM_DENSE 96
+
+extern "C" int mhx_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, mhx_run** out)
+{
+    if (!ctx || !t || !cfg || !out) return fail(MHX_EINVAL, "mhx_rwmh_create: NULL argument");
+    if (cfg->dim != t->dim)
+        return fail(MHX_EINVAL, "mhx_rwmh_create: proposal dim %d != model dim %d", cfg->dim, t->dim);
+    if (cfg->nchains <= 0) return fail(MHX_EINVAL, "mhx_rwmh_create: nchains must be positive");
+    const int d = cfg->dim;
+    size_t nvec = 0;
+    switch (cfg->proposal_kind) {
+    case MHX_PROP_ISO:
+        if (!(cfg->proposal_scale > 0.0f)) return fail(MHX_EINVAL, "ISO proposal needs a positive scale");
+        break;
+    case MHX_PROP_DIAG: nvec = (size_t)d; break;
+    case MHX_PROP_DENSE: nvec = (size_t)d * ((size_t)d + 1) / 2; break;
+    default: return fail(MHX_EINVAL, "mhx_rwmh_create: unknown proposal kind %d", cfg->proposal_kind);
+    }
+    if (nvec && !cfg->proposal_vec) return fail(MHX_EINVAL, "mhx_rwmh_create: proposal_vec is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::unique_ptr<mhx_run> r(new mhx_run);
+    r->ctx = ctx; r->target = t; r->kind = RUN_RWMH;
+    r->dim = d; r->n = cfg->nchains; r->seed = cfg->seed; r->first_id = cfg->first_chain;
+    r->flags = cfg->flags;
+    r->prop_kind = cfg->proposal_kind; r->prop_scale = cfg->proposal_scale;
+    HIP_TRY(hipMalloc(&r->d_pvec, (nvec ? nvec : 1) * sizeof(float)));
+    if (nvec) HIP_TRY(hipMemcpy(r->d_pvec, cfg->proposal_vec, nvec * sizeof(float), hipMemcpyHostToDevice));
+    int rc = run_alloc_state(r.get());
+    if (rc) return rc;
+
+    // ---- kernel choice
+    r->variant = 0;
+    const int tk = t->kind, pk = r->prop_kind;
+    const int regmax = pk == MHX_PROP_DENSE ? MHX_REG_MAX_DIM_DENSE : MHX_REG_MAX_DIM;
+    if (!(r->flags & MHX_FLAG_GENERIC)) {
+        if (tk != MHX_TARGET_USER)
+            for (const auto& pb : k_prebuilt_reg)
+                if (pb.D == d && pb.TK == tk && pb.PK == pk) { r->reg_fn = pb.fn; r->variant = 1; }
+        if (!r->variant && !(r->flags & MHX_FLAG_NO_JIT) && d <= regmax &&
+            !(tk == MHX_TARGET_CORR_GAUSS && d > 64) && !(tk == MHX_TARGET_IID_NORMAL && t->nparams > 4096)) {
+            jit_module* m = nullptr;
+            const std::string key = "rwmh_reg/d=" + std::to_string(d) + "/tk=" + std::to_string(tk) + "/pk=" +
+                                    std::to_string(pk) + "/" + t->user_key;
+            rc = jit_compile(ctx, key, jit_source(t, "mhx_rwmh_kernels.h"),
+                             {"MHX_JIT_RWMH_REG=1", "MHX_JIT_DIM=" + std::to_string(d),
+                              "MHX_JIT_TK=" + std::to_string(tk), "MHX_JIT_PK=" + std::to_string(pk)}, &m);
+            if (rc == MHX_OK) rc = jit_function(m, "mhx_jit_rwmh_reg", &r->jit_step);
+            if (rc == MHX_OK) r->variant = 2;
+            else if (tk == MHX_TARGET_USER) return rc;      // no pre-built kernel can run a user source
+            // built-in target: the generic kernel below computes the same chain; keep the message
+        }
+    }
+    if (tk == MHX_TARGET_USER) {
+        jit_module* m = nullptr;
+        if ((rc = jit_generic_rwmh(t, &m))) return rc;
+        if ((rc = jit_function(m, "mhx_jit_rwmh_init", &r->jit_init))) return rc;
+        if (r->variant == 0 && (rc = jit_function(m, "mhx_jit_rwmh_generic", &r->jit_step))) return rc;
+    }
+    if (r->variant == 0) HIP_TRY(hipMalloc(&r->d_ybuf, (size_t)d * (size_t)r->n * sizeof(float)));
+    *out = r.release();
+    return MHX_OK;
+}
+
+// ---- emcee / ram creation, init and stepping live in their own sections below
+static int emcee_init(mhx_run* r, const float* init);
+static int emcee_advance(mhx_run* r, uint64_t nsteps, uint32_t save_next, int save_slot, int thinning);
+static int ram_init(mhx_run* r, const float* init);
+static int ram_advance(mhx_run* r, uint64_t nsteps, uint64_t n_adapt, uint32_t save_next, int save_slot, int thinning);
+
+static int rwmh_init(mhx_run* r, const float* init)
+{
+    mhx_ctx* ctx = r->ctx;
+    const size_t nx = (size_t)r->dim * (size_t)r->n;
+    if (init) HIP_TRY(hipMemcpyAsync(r->d_x, init, nx * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    mhx_rwmh_args a = rwmh_args(r);
+    const float* tp = r->target->dparams;
+    const float* pv = r->d_pvec;
+    int draw = init ? 0 : 1;
+    const unsigned grid = (unsigned)((r->n + 255) / 256);
+    if (r->target->kind == MHX_TARGET_USER) {
+        void* params[] = {&a, &tp, &pv, &draw};
+        int rc = launch_module(r->jit_init, grid, 256, ctx->stream, params);
+        if (rc) return rc;
+    } else {
+        hipLaunchKernelGGL(k_rwmh_init, dim3(grid), dim3(256), 0, ctx->stream, a, tp, pv, draw);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MHX_OK;
+}
+
+#define MHX_MAX_STEPS_PER_LAUNCH 65536ull
+
+static int rwmh_advance(mhx_run* r, uint64_t nsteps, uint32_t save_next, int save_slot, int thinning)
+{
+    mhx_ctx* ctx = r->ctx;
+    const float* tp = r->target->dparams;
+    const float* pv = r->d_pvec;
+    uint64_t done = 0;
+    while (done < nsteps) {
+        const uint64_t chunk = std::min<uint64_t>(nsteps - done, MHX_MAX_STEPS_PER_LAUNCH);
+        mhx_rwmh_args a = rwmh_args(r);
+        a.step0 = (uint32_t)(r->tau + 1);
+        a.nsteps = (int)chunk;
+        a.save_next = save_next;
+        a.save_slot = save_slot;
+        a.thinning = thinning;
+        if (r->variant == 1) {
+            const unsigned grid = (unsigned)((r->n + 63) / 64);
+            hipLaunchKernelGGL(r->reg_fn, dim3(grid), dim3(64), 0, ctx->stream, a, tp, pv);
+        } else if (r->variant == 2) {
+            const unsigned grid = (unsigned)((r->n + 63) / 64);
+            void* params[] = {&a, &tp, &pv};
+            int rc = launch_module(r->jit_step, grid, 64, ctx->stream, params);
+            if (rc) return rc;
+        } else if (r->target->kind == MHX_TARGET_USER) {
+            const unsigned grid = (unsigned)((r->n + 255) / 256);
+            void* params[] = {&a, &tp, &pv};
+            int rc = launch_module(r->jit_step, grid, 256, ctx->stream, params);
+            if (rc) return rc;
+        } else {
+            const unsigned grid = (unsigned)((r->n + 255) / 256);
+            hipLaunchKernelGGL(k_rwmh_generic, dim3(grid), dim3(256), 0, ctx->stream, a, tp, pv);
+        }
+        HIP_TRY(hipGetLastError());
+        r->stats.launches++;
+        // advance the save cursor past this chunk
+        if (save_next != MHX_NO_SAVE) {
+            const uint64_t last = r->tau + chunk;
+            if ((uint64_t)save_next <= last) {
+                const uint64_t k = (last - save_next) / (uint64_t)thinning + 1;
+                save_next += (uint32_t)(k * (uint64_t)thinning);
+                save_slot += (int)k;
+            }
+        }
+        r->tau += chunk;
+        done += chunk;
+    }
+    return MHX_OK;
+}
+
+extern "C" int mhx_run_init(mhx_run* r, const float* initial_params)
+{
+    if (!r) return fail(MHX_EINVAL, "mhx_run_init: run is NULL");
+    HIP_TRY(hipSetDevice(r->ctx->device));
+    int rc;
+    switch (r->kind) {
+    case RUN_RWMH: rc = rwmh_init(r, initial_params); break;
+    case RUN_EMCEE: rc = emcee_init(r, initial_params); break;
+    default: rc = ram_init(r, initial_params); break;
+    }
+    if (rc) return rc;
+    r->initialised = true;
+    r->tau = 0;
+    HIP_TRY(hipMemset(r->d_acc_total, 0, sizeof(unsigned long long)));
+    return MHX_OK;
+}
+
+// [upstream AbstractMCMC.mcmcsample, restated from memory]: see DESIGN.md section 5
+static void schedule_counts(const mhx_schedule* s, uint64_t* n_transitions, uint64_t* n_adapt)
+{
+    const int64_t N = s->n_samples, di = s->discard_initial, th = s->thinning, nw = s->num_warmup;
+    const int64_t dfw = nw < di ? nw : di;
+    const int64_t kfw = nw - dfw;
+    const int64_t k = kfw < N ? kfw : N;
+    *n_transitions = (uint64_t)(di + (N - 1) * th);
+    *n_adapt = (uint64_t)(dfw + (k >= 2 ? (k - 1) * th : 0));
+}
+
+static int ensure_buffer(void** p, size_t* cap, size_t need)
+{
+    if (*cap >= need && *p) return MHX_OK;
+    if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
+    hipError_t e = hipMalloc(p, need);
+    if (e != hipSuccess) return fail(MHX_ENOMEM, "sample buffer of %zu bytes: %s", need, hipGetErrorString(e));
+    *cap = need;
+    return MHX_OK;
+}
+
+extern "C" int mhx_run_sample(mhx_run* r, const mhx_schedule* s, int save_samples)
+{
+    if (!r || !s) return fail(MHX_EINVAL, "mhx_run_sample: NULL argument");
+    if (!r->initialised) return fail(MHX_ESTATE, "mhx_run_sample: call mhx_run_init first");
+    if (s->n_samples < 1 || s->thinning < 1 || s->discard_initial < 0 || s->num_warmup < 0)
+        return fail(MHX_EINVAL, "mhx_run_sample: bad schedule (N=%d discard=%d thinning=%d warmup=%d)",
+                    s->n_samples, s->discard_initial, s->thinning, s->num_warmup);
+    mhx_ctx* ctx = r->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    uint64_t nT = 0, nA = 0;
+    schedule_counts(s, &nT, &nA);
+    if (r->tau + nT >= 0xffffffffull) return fail(MHX_EINVAL, "step counter would exceed 2^32-1; start a new seed");
+    const auto t0 = std::chrono::steady_clock::now();
+    r->stats = mhx_stats{};
+    r->stats.kernel_variant = r->variant;
+    unsigned long long acc_before = 0;
+    HIP_TRY(hipMemcpy(&acc_before, r->d_acc_total, sizeof acc_before, hipMemcpyDeviceToHost));
+
+    uint32_t save_next = MHX_NO_SAVE;
+    int save_slot = 0;
+    r->n_saved = 0;
+    if (save_samples) {
+        const size_t N = (size_t)s->n_samples, n = (size_t)r->n, d1 = (size_t)r->dim + 1;
+        int rc = ensure_buffer((void**)&r->d_samples, &r->samples_cap, N * d1 * n * sizeof(float));
+        if (rc) return rc;
+        rc = ensure_buffer((void**)&r->d_accepted, &r->accepted_cap, N * n);
+        if (rc) return rc;
+        r->n_saved = s->n_samples;
+        if (s->discard_initial == 0) {
+            // sample 1 is the current state itself (test/runtests.jl:203-213: chain[1].params == initial_params)
+            const unsigned grid = (unsigned)((r->n + 255) / 256);
+            hipLaunchKernelGGL(k_record_state, dim3(grid), dim3(256), 0, ctx->stream, r->d_x, r->d_lp, r->d_last,
+                               r->d_samples, r->d_accepted, r->n, (long)r->n, r->dim, 0L);
+            HIP_TRY(hipGetLastError());
+            save_slot = 1;
+            save_next = s->n_samples > 1 ? (uint32_t)(r->tau + (uint64_t)s->thinning) : MHX_NO_SAVE;
+        } else {
+            save_slot = 0;
+            save_next = (uint32_t)(r->tau + (uint64_t)s->discard_initial);
+        }
+    }
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    int rc = MHX_OK;
+    if (nT) {
+        switch (r->kind) {
+        case RUN_RWMH: rc = rwmh_advance(r, nT, save_next, save_slot, s->thinning); break;
+        case RUN_EMCEE: rc = emcee_advance(r, nT, save_next, save_slot, s->thinning); break;
+        default: rc = ram_advance(r, nT, nA, save_next, save_slot, s->thinning); break;
+        }
+    }
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    unsigned long long acc_after = 0;
+    HIP_TRY(hipMemcpy(&acc_after, r->d_acc_total, sizeof acc_after, hipMemcpyDeviceToHost));
+    r->stats.kernel_ms = ms;
+    r->stats.transitions = nT * (uint64_t)r->n;
+    r->stats.accepted = acc_after - acc_before;
+    r->stats.wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return MHX_OK;
+}
+
+extern "C" int mhx_run_get_samples(mhx_run* r, float* samples, uint8_t* accepted)
+{
+    if (!r) return fail(MHX_EINVAL, "mhx_run_get_samples: run is NULL");
+    if (r->n_saved <= 0) return fail(MHX_ESTATE, "mhx_run_get_samples: the last mhx_run_sample saved nothing");
+    HIP_TRY(hipSetDevice(r->ctx->device));
+    const size_t N = (size_t)r->n_saved, n = (size_t)r->n, d1 = (size_t)r->dim + 1;
+    if (samples) HIP_TRY(hipMemcpy(samples, r->d_samples, N * d1 * n * sizeof(float), hipMemcpyDeviceToHost));
+    if (accepted) HIP_TRY(hipMemcpy(accepted, r->d_accepted, N * n, hipMemcpyDeviceToHost));
+    return MHX_OK;
+}
+
+extern "C" int mhx_run_device_samples(mhx_run* r, void** samples, void** accepted, int64_t* n_samples)
+{
+    if (!r) return fail(MHX_EINVAL, "mhx_run_device_samples: run is NULL");
+    if (samples) *samples = r->d_samples;
+    if (accepted) *accepted = r->d_accepted;
+    if (n_samples) *n_samples = r->n_saved;
+    return MHX_OK;
+}
+
+extern "C" int mhx_run_get_state(mhx_run* r, float* x, float* lp, uint32_t* accept_counts)
+{
+    if (!r) return fail(MHX_EINVAL, "mhx_run_get_state: run is NULL");
+    if (!r->initialised) return fail(MHX_ESTATE, "mhx_run_get_state: run is not initialised");
+    HIP_TRY(hipSetDevice(r->ctx->device));
+    const size_t n = (size_t)r->n, d = (size_t)r->dim;
+    if (x) HIP_TRY(hipMemcpy(x, r->d_x, d * n * sizeof(float), hipMemcpyDeviceToHost));
+    if (lp) HIP_TRY(hipMemcpy(lp, r->d_lp, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (accept_counts) HIP_TRY(hipMemcpy(accept_counts, r->d_acc, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return MHX_OK;
+}
+
+extern "C" int mhx_run_set_state(mhx_run* r, const float* x)
+{
+    if (!r || !x) return fail(MHX_EINVAL, "mhx_run_set_state: NULL argument");
+    if (!r->initialised) return fail(MHX_ESTATE, "mhx_run_set_state: run is not initialised");
+    mhx_ctx* ctx = r->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t n = (size_t)r->n, d = (size_t)r->dim;
+    HIP_TRY(hipMemcpy(r->d_x, x, d * n * sizeof(float), hipMemcpyHostToDevice));
+    // lp is a cache of logdensity(model, x) (src/AdvancedMH.jl:75): recompute it
+    const unsigned grid = (unsigned)((r->n + 255) / 256);
+    int nn = r->n, dd = r->dim, kind = r->target->kind, np = r->target->nparams;
+    float cst = r->target->cst;
+    const float* tp = r->target->dparams;
+    const float* dx = r->d_x;
+    float* dlp = r->d_lp;
+    if (kind == MHX_TARGET_USER) {
+        jit_module* m = nullptr;
+        hipFunction_t fn;
+        int rc = jit_generic_rwmh(r->target, &m);
+        if (rc) return rc;
+        if ((rc = jit_function(m, "mhx_jit_target_eval", &fn))) return rc;
+        void* params[] = {&dx, &dlp, &nn, &dd, &kind, &tp, &np, &cst};
+        if ((rc = launch_module(fn, grid, 256, ctx->stream, params))) return rc;
+    } else {
+        hipLaunchKernelGGL(k_target_eval, dim3(grid), dim3(256), 0, ctx->stream, dx, dlp, nn, dd, kind, tp, np, cst);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MHX_OK;
+}
+
+extern "C" int mhx_run_stats(mhx_run* r, mhx_stats* out)
+{
+    if (!r || !out) return fail(MHX_EINVAL, "mhx_run_stats: NULL argument");
+    *out = r->stats;
+    return MHX_OK;
+}
+
+extern "C" int mhx_run_destroy(mhx_run* r)
+{
+    if (!r) return MHX_OK;
+    (void)hipSetDevice(r->ctx->device);
+    delete r;
+    return MHX_OK;
+}
+
+#include "mhx_api_emcee.inc"
+#include "mhx_api_ram.inc"
+#include "mhx_api_diag.inc"

@@ -1,0 +1,226 @@
+// mhx_device_math.h -- device-side arithmetic of the MHX engine (gfx950, wave64).
+//
+// Everything a lane needs to turn (seed, chain id, step) into proposal noise and an accept
+// threshold: Philox4x32-10, uniform conversions, and fp32 log / exp / sincos(2*pi*k/2^32) written
+// as explicit fmaf polynomials.  The translation unit is compiled with
+// -ffp-contract=off, so the only fused operations are the __builtin_fmaf calls below and every
+// other +,*,/ and sqrt rounds once (IEEE, correctly rounded) -- that is what makes a chain's
+// trajectory a pure function of (seed, chain id) that a host restatement can reproduce bit for bit.
+//
+// This header is compiled twice: by hipcc into libmhx.so (pre-built kernels) and by hiprtc at run
+// time (specialised kernels, user log-densities); keep it free of host headers.
+#pragma once
+
+#ifndef __HIPCC_RTC__
+#include <hip/hip_runtime.h>
+#endif
+
+#define MHX_DEV __device__ __forceinline__
+
+typedef unsigned int mhx_u32;
+typedef unsigned long long mhx_u64;
+
+// signature of a user log-density in HIP source form (see include/mhx.h, mhx_target_from_hip_source)
+#define MHX_LOGDENSITY(x, d, data, ndata)                                                          \
+    template <class MHX_X>                                                                          \
+    MHX_DEV float mhx_user_logdensity(const MHX_X& x, const int d, const float* __restrict__ data, \
+                                      const int ndata)
+
+// RNG stream tags: counter word 3 = tag << 28 | block
+#define MHX_STREAM_PROPOSAL 0u
+#define MHX_STREAM_ACCEPT   1u
+#define MHX_STREAM_INIT     2u
+#define MHX_STREAM_EMCEE    3u
+
+struct mhx_u32x4 { mhx_u32 x, y, z, w; };
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10.  The key schedule (seed + r * Weyl) is wave-uniform and lives in SGPRs; the two
+// 32x32->64 products per round are the only slow-rate VALU ops.
+struct mhx_philox_key { mhx_u32 k0[10], k1[10]; };
+
+MHX_DEV mhx_philox_key mhx_philox_schedule(mhx_u64 seed)
+{
+    mhx_philox_key ks;
+    mhx_u32 a = (mhx_u32)seed, b = (mhx_u32)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) { ks.k0[r] = a; ks.k1[r] = b; a += 0x9E3779B9u; b += 0xBB67AE85u; }
+    return ks;
+}
+
+MHX_DEV mhx_u32x4 mhx_philox(const mhx_philox_key& ks, mhx_u32 c0, mhx_u32 c1, mhx_u32 c2, mhx_u32 c3)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const mhx_u64 p0 = (mhx_u64)0xD2511F53u * c0;
+        const mhx_u64 p1 = (mhx_u64)0xCD9E8D57u * c2;
+        const mhx_u32 n0 = (mhx_u32)(p1 >> 32) ^ c1 ^ ks.k0[r];
+        const mhx_u32 n2 = (mhx_u32)(p0 >> 32) ^ c3 ^ ks.k1[r];
+        c1 = (mhx_u32)p1; c3 = (mhx_u32)p0; c0 = n0; c2 = n2;
+    }
+    mhx_u32x4 o; o.x = c0; o.y = c1; o.z = c2; o.w = c3;
+    return o;
+}
+
+// ---------------------------------------------------------------------------------------------
+MHX_DEV mhx_u32 mhx_f2u(float f) { return __builtin_bit_cast(mhx_u32, f); }
+MHX_DEV float   mhx_u2f(mhx_u32 u) { return __builtin_bit_cast(float, u); }
+MHX_DEV float   mhx_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+#define MHX_LN2_HI 0x1.62e4p-1f
+#define MHX_LN2_LO 0x1.7f7d1cp-20f
+#define MHX_LOG2E  0x1.715476p+0f
+#define MHX_INF    __builtin_inff()
+#define MHX_NAN    __builtin_nanf("")
+
+// log for a positive, normal, finite argument (every uniform we draw): no special cases
+MHX_DEV float mhx_log_pos(float x)
+{
+    const mhx_u32 ix = mhx_f2u(x);
+    const mhx_u32 t = ix - 0x3f2aaaabu;
+    const int e = (int)t >> 23;
+    const float m = mhx_u2f(ix - ((mhx_u32)e << 23));
+    const float f = m - 1.0f;
+    const float ef = (float)e;
+    float q = -0x1.04cba2p-3f;
+    q = mhx_fma(q, f, 0x1.19bbe2p-3f);
+    q = mhx_fma(q, f, -0x1.f483fap-4f);
+    q = mhx_fma(q, f, 0x1.1fd494p-3f);
+    q = mhx_fma(q, f, -0x1.55913ep-3f);
+    q = mhx_fma(q, f, 0x1.99bffep-3f);
+    q = mhx_fma(q, f, -0x1.ffff28p-3f);
+    q = mhx_fma(q, f, 0x1.55552cp-2f);
+    q = mhx_fma(q, f, -0.5f);
+    const float f2 = f * f;
+    float r = mhx_fma(f2, q, f);
+    r = mhx_fma(ef, MHX_LN2_LO, r);
+    r = mhx_fma(ef, MHX_LN2_HI, r);
+    return r;
+}
+
+// full-range log (user log-densities, emcee's log z)
+MHX_DEV float mhx_log(float x)
+{
+    mhx_u32 ix = mhx_f2u(x);
+    if ((ix << 1) == 0u) return -MHX_INF;
+    if (ix >> 31) return MHX_NAN;
+    if (ix >= 0x7f800000u) return x;
+    float adj = 0.0f;
+    if (ix < 0x00800000u) { x = x * 0x1p23f; adj = -23.0f; }
+    // same polynomial as mhx_log_pos; the exponent correction is folded in before the conversion
+    ix = mhx_f2u(x);
+    const mhx_u32 t = ix - 0x3f2aaaabu;
+    const int e = (int)t >> 23;
+    const float m = mhx_u2f(ix - ((mhx_u32)e << 23));
+    const float f = m - 1.0f;
+    const float ef = (float)(e + (int)adj);
+    float q = -0x1.04cba2p-3f;
+    q = mhx_fma(q, f, 0x1.19bbe2p-3f);
+    q = mhx_fma(q, f, -0x1.f483fap-4f);
+    q = mhx_fma(q, f, 0x1.1fd494p-3f);
+    q = mhx_fma(q, f, -0x1.55913ep-3f);
+    q = mhx_fma(q, f, 0x1.99bffep-3f);
+    q = mhx_fma(q, f, -0x1.ffff28p-3f);
+    q = mhx_fma(q, f, 0x1.55552cp-2f);
+    q = mhx_fma(q, f, -0.5f);
+    const float f2 = f * f;
+    float r = mhx_fma(f2, q, f);
+    r = mhx_fma(ef, MHX_LN2_LO, r);
+    r = mhx_fma(ef, MHX_LN2_HI, r);
+    return r;
+}
+
+MHX_DEV float mhx_exp(float x)
+{
+    if (x != x) return x;
+    if (x > 0x1.62e42ep+6f) return MHX_INF;
+    if (x < -0x1.9fe368p+6f) return 0.0f;
+    const float n = __builtin_rintf(x * MHX_LOG2E);
+    float r = mhx_fma(n, -MHX_LN2_HI, x);
+    r = mhx_fma(n, -MHX_LN2_LO, r);
+    float p = 0x1.a1517cp-13f;
+    p = mhx_fma(p, r, 0x1.6d4328p-10f);
+    p = mhx_fma(p, r, 0x1.1110c6p-7f);
+    p = mhx_fma(p, r, 0x1.5554eap-5f);
+    p = mhx_fma(p, r, 0x1.555556p-3f);
+    p = mhx_fma(p, r, 0.5f);
+    const float r2 = r * r;
+    float y = mhx_fma(r2, p, r) + 1.0f;
+    const int ni = (int)n;
+    const int n1 = ni / 2;
+    const int n2 = ni - n1;
+    y = y * mhx_u2f((mhx_u32)(n1 + 127) << 23);
+    y = y * mhx_u2f((mhx_u32)(n2 + 127) << 23);
+    return y;
+}
+
+MHX_DEV float mhx_sqrt(float x) { return __builtin_sqrtf(x); }   // correctly rounded (default HIP lowering)
+
+// sin/cos of 2*pi*k/2^32: integer quadrant reduction, degree-4 polynomials in r^2 on |r| <= 1/8 turn
+MHX_DEV void mhx_sincos2pi_u32(mhx_u32 k, float& s, float& c)
+{
+    const mhx_u32 kk = k + 0x20000000u;
+    const mhx_u32 q = kk >> 30;
+    const int ri = (int)(kk & 0x3fffffffu) - 0x20000000;
+    const float r = (float)ri * 0x1p-32f;
+    const float r2 = r * r;
+    float sp = 0x1.4bc87cp+5f;
+    sp = mhx_fma(sp, r2, -0x1.32ca9ep+6f);
+    sp = mhx_fma(sp, r2, 0x1.466bbap+6f);
+    sp = mhx_fma(sp, r2, -0x1.4abbcep+5f);
+    sp = mhx_fma(sp, r2, 0x1.921fb6p+2f);
+    sp = sp * r;
+    float cp = 0x1.d9c326p+5f;
+    cp = mhx_fma(cp, r2, -0x1.55c57ap+6f);
+    cp = mhx_fma(cp, r2, 0x1.03c1dcp+6f);
+    cp = mhx_fma(cp, r2, -0x1.3bd3ccp+4f);
+    cp = mhx_fma(cp, r2, 1.0f);
+    const bool odd = (q & 1u) != 0u;
+    float ss = odd ? cp : sp;
+    float cc = odd ? sp : cp;
+    // sign flips as integer xors on the sign bit: q in {2,3} negates sin, q in {1,2} negates cos
+    const mhx_u32 sneg = (q & 2u) << 30;
+    const mhx_u32 cneg = ((q + 1u) & 2u) << 30;
+    s = mhx_u2f(mhx_f2u(ss) ^ sneg);
+    c = mhx_u2f(mhx_f2u(cc) ^ cneg);
+}
+
+MHX_DEV float mhx_u01_open(mhx_u32 k) { return mhx_fma((float)k, 0x1p-32f, 0x1p-33f); }   // (0,1]
+MHX_DEV float mhx_u01_half(mhx_u32 k) { return (float)(k >> 8) * 0x1p-24f; }               // [0,1)
+
+// Box-Muller: radius from k0, angle from k1
+MHX_DEV void mhx_normal_pair(mhx_u32 k0, mhx_u32 k1, float& n0, float& n1)
+{
+    const float l = mhx_log_pos(mhx_u01_open(k0));
+    const float rad = mhx_sqrt(-2.0f * l);
+    float s, c;
+    mhx_sincos2pi_u32(k1, s, c);
+    n0 = rad * c;
+    n1 = rad * s;
+}
+
+// the 4 standard normals 4b..4b+3 of (id, step, stream)
+MHX_DEV void mhx_normal4(const mhx_philox_key& ks, mhx_u32 id_lo, mhx_u32 id_hi, mhx_u32 step,
+                         mhx_u32 stream, mhx_u32 block, float n[4])
+{
+    const mhx_u32x4 w = mhx_philox(ks, id_lo, id_hi, step, (stream << 28) | block);
+    mhx_normal_pair(w.x, w.y, n[0], n[1]);
+    mhx_normal_pair(w.z, w.w, n[2], n[3]);
+}
+
+// log of the accept uniform of `step`: one Philox block serves 4 consecutive steps.
+// `cache` holds the block of step>>2; refresh it when a new group starts.
+struct mhx_accept_cache { mhx_u32x4 w; mhx_u32 group; };
+
+MHX_DEV float mhx_accept_logu(const mhx_philox_key& ks, mhx_u32 id_lo, mhx_u32 id_hi, mhx_u32 step,
+                              mhx_accept_cache& cache)
+{
+    const mhx_u32 g = step >> 2;
+    if (g != cache.group) {                           // wave-uniform
+        cache.w = mhx_philox(ks, id_lo, id_hi, g, MHX_STREAM_ACCEPT << 28);
+        cache.group = g;
+    }
+    const mhx_u32 j = step & 3u;                      // wave-uniform select
+    const mhx_u32 k = j == 0u ? cache.w.x : (j == 1u ? cache.w.y : (j == 2u ? cache.w.z : cache.w.w));
+    return mhx_log_pos(mhx_u01_open(k));
+}

@@ -1,0 +1,101 @@
+// mhx_targets.h -- log-density catalogue evaluated per lane (one lane = one chain / walker).
+//
+// A target is a function of an indexable `x` (x[k] -> float): a register array in the
+// compile-time-dimension kernels, a strided view of the [dim][nchains] HBM state in the generic
+// ones.  Parameters (`p`) are wave-uniform and read through the scalar cache.  The summation
+// order of every target is part of the arithmetic spec: sequential fmaf
+// accumulation in ascending index order.
+//
+// Replaces DensityModel(f) / logdensity(model, x) of the reference (src/AdvancedMH.jl:52-54, :74).
+#pragma once
+#include "mhx_device_math.h"
+
+#define MHX_TARGET_ISO_GAUSS  0
+#define MHX_TARGET_CORR_GAUSS 1
+#define MHX_TARGET_IID_NORMAL 2
+#define MHX_TARGET_BANANA     3
+#define MHX_TARGET_FUNNEL     4
+#define MHX_TARGET_USER       100
+
+#define MHX_HALF_LOG_2PI 0x1.d67f1cp-1f
+
+// strided view of one chain's parameters inside a [dim][ld] array
+struct mhx_strided_x {
+    const float* base;   // &array[0][chain]
+    long ld;
+    MHX_DEV float operator[](int k) const { return base[(long)k * ld]; }
+};
+
+// A user log-density supplied as HIP source (mhx_target_from_hip_source) is placed by the JIT
+// between mhx_device_math.h and this header; it defines mhx_user_logdensity via MHX_LOGDENSITY
+// and the JIT defines MHX_HAVE_USER_TARGET.
+
+// KIND is a compile-time constant in specialised kernels and MHX_TARGET_DYNAMIC (-1) in the
+// generic pre-built kernel, where `kind` is a wave-uniform run-time switch.
+#define MHX_TARGET_DYNAMIC (-1)
+
+template <int KIND, class X>
+MHX_DEV float mhx_target_eval(int kind, const X& x, const int d, const float* __restrict__ p,
+                              const int np, const float cst)
+{
+    const int k_ = (KIND == MHX_TARGET_DYNAMIC) ? kind : KIND;
+    switch (k_) {
+    case MHX_TARGET_ISO_GAUSS: {
+        float q = 0.0f;
+#pragma unroll
+        for (int k = 0; k < d; ++k) { const float v = x[k]; q = mhx_fma(v, v, q); }
+        return mhx_fma(-0.5f, q, cst);
+    }
+    case MHX_TARGET_CORR_GAUSS: {
+        float q = 0.0f;
+        int off = 0;
+#pragma unroll
+        for (int i = 0; i < d; ++i) {
+            float w = 0.0f;
+#pragma unroll
+            for (int j = 0; j <= i; ++j) w = mhx_fma(p[off + j], x[j], w);
+            q = mhx_fma(w, w, q);
+            off += i + 1;
+        }
+        return mhx_fma(-0.5f, q, cst);
+    }
+    case MHX_TARGET_IID_NORMAL: {
+        const float mu = x[0], sigma = x[1];
+        if (!(sigma > 0.0f)) return -MHX_INF;         // theta[2] >= 0 support, and logpdf = -Inf at sigma == 0
+        float acc = 0.0f;
+        for (int i = 0; i < np; ++i) {
+            const float z = (p[i] - mu) / sigma;
+            acc = mhx_fma(z, z, acc);
+        }
+        const float tt = mhx_log(sigma) + MHX_HALF_LOG_2PI;
+        return mhx_fma(-0.5f, acc, -((float)np * tt));
+    }
+    case MHX_TARGET_BANANA: {
+        const float b = p[0];
+        const float x0 = x[0];
+        float q = (x0 * x0) * 0.01f;
+        const float u = mhx_fma(b, mhx_fma(x0, x0, -100.0f), x[1]);
+        q = mhx_fma(u, u, q);
+#pragma unroll
+        for (int k = 2; k < d; ++k) { const float v = x[k]; q = mhx_fma(v, v, q); }
+        return mhx_fma(-0.5f, q, cst);
+    }
+    case MHX_TARGET_FUNNEL: {
+        const float v = x[0];
+        float q = 0.0f;
+#pragma unroll
+        for (int k = 1; k < d; ++k) { const float xk = x[k]; q = mhx_fma(xk, xk, q); }
+        const float ev = mhx_exp(-v);
+        float r = (v * v) * 0x1.c71c72p-5f;
+        r = mhx_fma(0.5f * (float)(d - 1), v, r);
+        r = mhx_fma(0.5f * ev, q, r);
+        return cst - r;
+    }
+#ifdef MHX_HAVE_USER_TARGET
+    case MHX_TARGET_USER:
+        return mhx_user_logdensity(x, d, p, np);
+#endif
+    default:
+        return MHX_NAN;
+    }
+}

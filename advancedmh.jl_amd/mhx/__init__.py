@@ -1,0 +1,9 @@
+"""mhx -- Python host mirror of the AdvancedMH.jl API over libmhx.so (MI355X / gfx950 HIP kernels)."""
+from ._lib import (ArgumentError, Context, MhxError, PosDefException, FLAG_GENERIC, FLAG_NO_JIT, LIB_PATH,
+                   EXPORTS, lib)
+from .api import (I, Banana, Chains, CorrGaussian, DensityModel, Ensemble, Funnel, HipLogDensity, IIDNormal,
+                  InverseGamma, IsoGaussian, MetropolisHastings, MvNormal, Normal, RandomWalkProposal,
+                  RobustAdaptiveMetropolis, Run, RWMH, StretchProposal, SymmetricRandomWalkProposal, Transition,
+                  logdensity, pack_lower, sample, unpack_lower, zeros)
+
+__all__ = [n for n in dir() if not n.startswith("_")]

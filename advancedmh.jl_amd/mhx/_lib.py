@@ -1,0 +1,161 @@
+"""ctypes binding of libmhx.so (include/mhx.h).  This is the only way the Python host mirror reaches
+the device: there is no CPU fallback -- if the HIP library is missing or fails, calls raise."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_PKG), "libmhx.so")
+
+MHX_OK, MHX_EINVAL, MHX_ENOMEM, MHX_EHIP, MHX_EJIT, MHX_ENOTPD, MHX_ESTATE = 0, -1, -2, -3, -4, -5, -6
+
+TARGET_ISO_GAUSS, TARGET_CORR_GAUSS, TARGET_IID_NORMAL, TARGET_BANANA, TARGET_FUNNEL = 0, 1, 2, 3, 4
+TARGET_USER = 100
+PROP_ISO, PROP_DIAG, PROP_DENSE = 0, 1, 2
+FLAG_NO_JIT, FLAG_GENERIC = 1, 2
+
+
+class MhxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libmhx error %d: %s" % (code, msg))
+        self.code = code
+
+
+class ArgumentError(MhxError, ValueError):
+    """MHX_EINVAL -- where the reference throws ArgumentError / MethodError."""
+
+
+class PosDefException(MhxError):
+    """MHX_ENOTPD -- LinearAlgebra.PosDefException of the reference."""
+
+
+class Schedule(C.Structure):
+    _fields_ = [("n_samples", C.c_int32), ("discard_initial", C.c_int32), ("thinning", C.c_int32),
+                ("num_warmup", C.c_int32)]
+
+
+class RwmhCfg(C.Structure):
+    _fields_ = [("dim", C.c_int32), ("nchains", C.c_int32), ("seed", C.c_uint64), ("first_chain", C.c_uint64),
+                ("proposal_kind", C.c_int32), ("proposal_scale", C.c_float),
+                ("proposal_vec", C.POINTER(C.c_float)), ("flags", C.c_int32)]
+
+
+class EmceeCfg(C.Structure):
+    _fields_ = [("dim", C.c_int32), ("nwalkers", C.c_int32), ("seed", C.c_uint64), ("ensemble_id", C.c_uint64),
+                ("stretch", C.c_float), ("flags", C.c_int32)]
+
+
+class RamCfg(C.Structure):
+    _fields_ = [("dim", C.c_int32), ("nchains", C.c_int32), ("seed", C.c_uint64), ("first_chain", C.c_uint64),
+                ("alpha", C.c_float), ("gamma", C.c_float), ("eig_lo", C.c_float), ("eig_hi", C.c_float),
+                ("flags", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("transitions", C.c_uint64), ("accepted", C.c_uint64), ("kernel_ms", C.c_double),
+                ("wall_ms", C.c_double), ("kernel_variant", C.c_int32), ("launches", C.c_int32)]
+
+
+class DiagCfg(C.Structure):
+    _fields_ = [("max_lag", C.c_int32)]
+
+
+EXPORTS = [
+    "mhx_version", "mhx_last_error", "mhx_ctx_create", "mhx_ctx_destroy", "mhx_target_builtin",
+    "mhx_target_from_hip_source", "mhx_target_destroy", "mhx_target_eval", "mhx_rwmh_create",
+    "mhx_emcee_create", "mhx_ram_create", "mhx_ram_set_factor", "mhx_ram_get_factor",
+    "mhx_ram_get_diag_range", "mhx_run_init", "mhx_run_sample", "mhx_run_get_samples",
+    "mhx_run_get_state", "mhx_run_set_state", "mhx_run_stats", "mhx_run_device_samples",
+    "mhx_run_destroy", "mhx_run_diagnostics",
+]
+
+_lib = None
+
+
+def lib():
+    """Load libmhx.so (built in-tree by __graft_entry__.build()).  Fails loudly when absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libmhx.so not found at %s -- run `python __graft_entry__.py` (build()) first; "
+                              "there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        L.mhx_last_error.restype = C.c_char_p
+        vp, fp, u8p, u32p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_uint32)
+        dp = C.POINTER(C.c_double)
+        L.mhx_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+        L.mhx_ctx_destroy.argtypes = [vp]
+        L.mhx_target_builtin.argtypes = [vp, C.c_int, C.c_int, fp, C.c_size_t, C.POINTER(vp)]
+        L.mhx_target_from_hip_source.argtypes = [vp, C.c_char_p, C.c_int, fp, C.c_size_t, C.POINTER(vp)]
+        L.mhx_target_destroy.argtypes = [vp]
+        L.mhx_target_eval.argtypes = [vp, vp, fp, C.c_int, fp]
+        L.mhx_rwmh_create.argtypes = [vp, vp, C.POINTER(RwmhCfg), C.POINTER(vp)]
+        L.mhx_emcee_create.argtypes = [vp, vp, C.POINTER(EmceeCfg), C.POINTER(vp)]
+        L.mhx_ram_create.argtypes = [vp, vp, C.POINTER(RamCfg), C.POINTER(vp)]
+        L.mhx_ram_set_factor.argtypes = [vp, fp]
+        L.mhx_ram_get_factor.argtypes = [vp, fp, u8p]
+        L.mhx_ram_get_diag_range.argtypes = [vp, fp, fp]
+        L.mhx_run_init.argtypes = [vp, fp]
+        L.mhx_run_sample.argtypes = [vp, C.POINTER(Schedule), C.c_int]
+        L.mhx_run_get_samples.argtypes = [vp, fp, u8p]
+        L.mhx_run_get_state.argtypes = [vp, fp, fp, u32p]
+        L.mhx_run_set_state.argtypes = [vp, fp]
+        L.mhx_run_stats.argtypes = [vp, C.POINTER(Stats)]
+        L.mhx_run_device_samples.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int64)]
+        L.mhx_run_destroy.argtypes = [vp]
+        L.mhx_run_diagnostics.argtypes = [vp, C.POINTER(DiagCfg), dp, dp, dp, dp]
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc == MHX_OK:
+        return
+    msg = lib().mhx_last_error().decode("utf-8", "replace")
+    if rc == MHX_EINVAL:
+        raise ArgumentError(rc, msg)
+    if rc == MHX_ENOTPD:
+        raise PosDefException(rc, msg)
+    raise MhxError(rc, msg)
+
+
+def fptr(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def u8ptr(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def u32ptr(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Context:
+    """mhx_ctx: one per GPU."""
+
+    _default = {}
+
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        check(lib().mhx_ctx_create(device, C.byref(self.h)))
+        self.device = device
+
+    @classmethod
+    def default(cls, device=None):
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0")) if os.environ.get("MHX_DEVICE") is None else int(
+                os.environ["MHX_DEVICE"])
+        if device not in cls._default:
+            cls._default[device] = cls(device)
+        return cls._default[device]
+
+    def close(self):
+        if self.h:
+            lib().mhx_ctx_destroy(self.h)
+            self.h = C.c_void_p()

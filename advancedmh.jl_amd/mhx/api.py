@@ -1,0 +1,529 @@
+"""Host mirror of the AdvancedMH.jl API surface for the GPU hot path.
+
+Same names and keyword meaning as the reference so that its tests read the same:
+
+    model   = DensityModel(IsoGaussian(100))                      # src/AdvancedMH.jl:52-54
+    spl     = RWMH(MvNormal(zeros(100), 0.238**2 * I))            # src/mh-core.jl:50-51
+    chain   = sample(model, spl, 1000, 65536; discard_initial=1000)  # AbstractMCMC.sample (re-export, src/AdvancedMH.jl:30)
+
+Every call goes through the C ABI of libmhx.so (include/mhx.h); nothing here computes a sample on
+the CPU.  A Python callable cannot be lowered to the device: DensityModel takes one of the
+catalogue log-densities below or HipLogDensity(source) (hiprtc-compiled, inlined per lane).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib as L
+
+# ------------------------------------------------------------------------------------------------
+# distributions (the subset of Distributions.jl the GPU path accepts)
+
+
+class _Identity:
+    """LinearAlgebra.I; supports `s * I`."""
+
+    def __init__(self, scale=1.0):
+        self.scale = float(scale)
+
+    def __rmul__(self, s):
+        return _Identity(self.scale * float(s))
+
+    __mul__ = __rmul__
+
+
+I = _Identity()
+
+
+def zeros(d):
+    return np.zeros(int(d))
+
+
+class Normal:
+    def __init__(self, mu=0.0, sigma=1.0):
+        self.mu, self.sigma = float(mu), float(sigma)
+
+    def rand(self, rng):
+        return self.mu + self.sigma * rng.standard_normal()
+
+
+class InverseGamma:
+    def __init__(self, shape, scale):
+        self.shape, self.scale = float(shape), float(scale)
+
+    def rand(self, rng):
+        return self.scale / rng.gamma(self.shape)
+
+
+class MvNormal:
+    """MvNormal(mean, cov): cov may be `s*I`, a vector of variances (diagonal) or a dense PD matrix."""
+
+    def __init__(self, mean, cov=I):
+        self.mean = np.asarray(mean, dtype=np.float64)
+        self.dim = int(self.mean.size)
+        if isinstance(cov, _Identity):
+            self.kind, self.scale, self.vec = L.PROP_ISO, math.sqrt(cov.scale), None
+        else:
+            cov = np.asarray(cov, dtype=np.float64)
+            if cov.ndim == 1:
+                if cov.size != self.dim:
+                    raise L.ArgumentError(L.MHX_EINVAL, "MvNormal: mean and covariance dimensions differ")
+                self.kind, self.scale, self.vec = L.PROP_DIAG, 1.0, np.sqrt(cov)
+            else:
+                if cov.shape != (self.dim, self.dim):
+                    raise L.ArgumentError(L.MHX_EINVAL, "MvNormal: mean and covariance dimensions differ")
+                try:
+                    chol = np.linalg.cholesky(cov)
+                except np.linalg.LinAlgError as e:
+                    raise L.PosDefException(L.MHX_ENOTPD, "MvNormal: covariance is not positive definite") from e
+                self.kind, self.scale, self.vec = L.PROP_DENSE, 1.0, pack_lower(chol)
+
+    def rand(self, rng):
+        z = rng.standard_normal(self.dim)
+        if self.kind == L.PROP_ISO:
+            return self.mean + self.scale * z
+        if self.kind == L.PROP_DIAG:
+            return self.mean + self.vec * z
+        return self.mean + unpack_lower(self.vec, self.dim) @ z
+
+
+def pack_lower(M):
+    M = np.asarray(M)
+    return np.concatenate([M[i, :i + 1] for i in range(M.shape[0])]).astype(np.float32)
+
+
+def unpack_lower(p, d):
+    M = np.zeros((d, d), dtype=np.asarray(p).dtype)
+    o = 0
+    for i in range(d):
+        M[i, :i + 1] = p[o:o + i + 1]
+        o += i + 1
+    return M
+
+
+def _as_mvnormal(dist):
+    """RWMH accepts MvNormal, a vector of univariate Normals (src/proposal.jl:26-28) or an Int."""
+    if isinstance(dist, (int, np.integer)):
+        return MvNormal(zeros(dist), I)                           # src/mh-core.jl:51
+    if isinstance(dist, MvNormal):
+        return dist
+    if isinstance(dist, (list, tuple)) and all(isinstance(p, Normal) for p in dist):
+        mv = MvNormal([p.mu for p in dist], np.array([p.sigma ** 2 for p in dist]))
+        return mv
+    raise L.ArgumentError(L.MHX_EINVAL, "the GPU path supports MvNormal / vector-of-Normal random-walk proposals; "
+                          "got %r (static, function and NamedTuple proposals stay on the CPU reference)" % (dist,))
+
+
+# ------------------------------------------------------------------------------------------------
+# log-densities that can live on the device
+
+
+class _TargetSpec:
+    kind = None
+    dim = 0
+    params = None
+
+    def build(self, ctx):
+        h = C.c_void_p()
+        p = None if self.params is None else L.f32(self.params)
+        L.check(L.lib().mhx_target_builtin(ctx.h, self.kind, self.dim, L.fptr(p), 0 if p is None else p.size,
+                                           C.byref(h)))
+        return h
+
+
+class IsoGaussian(_TargetSpec):
+    """logpdf(MvNormal(zeros(d), I), x)"""
+    kind = L.TARGET_ISO_GAUSS
+
+    def __init__(self, d):
+        self.dim = int(d)
+
+
+class CorrGaussian(_TargetSpec):
+    """logpdf(MvNormal(zeros(d), Sigma), x); stored as inv(chol(Sigma)) packed lower."""
+    kind = L.TARGET_CORR_GAUSS
+
+    def __init__(self, Sigma):
+        Sigma = np.asarray(Sigma, dtype=np.float64)
+        self.dim = Sigma.shape[0]
+        try:
+            A = np.linalg.inv(np.linalg.cholesky(Sigma))
+        except np.linalg.LinAlgError as e:
+            raise L.PosDefException(L.MHX_ENOTPD, "CorrGaussian: Sigma is not positive definite") from e
+        self.params = pack_lower(A)
+
+
+class IIDNormal(_TargetSpec):
+    """theta = (mu, sigma):  sigma >= 0 ? sum(logpdf.(Normal(mu, sigma), data)) : -Inf   (README.md:29-31)"""
+    kind = L.TARGET_IID_NORMAL
+    dim = 2
+
+    def __init__(self, data):
+        self.params = L.f32(data).ravel()
+
+
+class Banana(_TargetSpec):
+    kind = L.TARGET_BANANA
+
+    def __init__(self, d, b=0.03):
+        self.dim = int(d)
+        self.params = np.array([b], dtype=np.float32)
+
+
+class Funnel(_TargetSpec):
+    kind = L.TARGET_FUNNEL
+
+    def __init__(self, d):
+        self.dim = int(d)
+
+
+class HipLogDensity(_TargetSpec):
+    """A user log-density as HIP source:  MHX_LOGDENSITY(x, d, data, ndata) { ...; return lp; }"""
+    kind = L.TARGET_USER
+
+    def __init__(self, source, dim, data=None):
+        self.source, self.dim = source, int(dim)
+        self.params = None if data is None else L.f32(data).ravel()
+
+    def build(self, ctx):
+        h = C.c_void_p()
+        p = self.params
+        L.check(L.lib().mhx_target_from_hip_source(ctx.h, self.source.encode(), self.dim, L.fptr(p),
+                                                   0 if p is None else p.size, C.byref(h)))
+        return h
+
+
+class DensityModel:
+    """DensityModel(logdensity) -- src/AdvancedMH.jl:52-54."""
+
+    def __init__(self, logdensity):
+        if callable(logdensity) and not isinstance(logdensity, _TargetSpec):
+            raise L.ArgumentError(L.MHX_EINVAL, "a Python callable cannot be lowered to the GPU; pass a catalogue "
+                                  "log-density or HipLogDensity(source, dim)")
+        if not isinstance(logdensity, _TargetSpec):
+            raise L.ArgumentError(L.MHX_EINVAL, "DensityModel: unsupported log-density %r" % (logdensity,))
+        self.logdensity = logdensity
+        self._handles = {}
+
+    @property
+    def dim(self):
+        return self.logdensity.dim
+
+    def handle(self, ctx):
+        if ctx not in self._handles:
+            self._handles[ctx] = self.logdensity.build(ctx)
+        return self._handles[ctx]
+
+
+def logdensity(model, x, ctx=None):
+    """logdensity(model, params) for one point (d,) or a batch (d, n) -- src/AdvancedMH.jl:74."""
+    if isinstance(x, Transition):
+        return x.lp                                              # cached, src/AdvancedMH.jl:75
+    ctx = ctx or L.Context.default()
+    x = L.f32(x)
+    single = x.ndim == 1
+    xb = x.reshape(model.dim, -1)
+    if xb.shape[0] != model.dim:
+        raise L.ArgumentError(L.MHX_EINVAL, "logdensity: x has the wrong dimension")
+    xb = np.ascontiguousarray(xb)
+    lp = np.empty(xb.shape[1], dtype=np.float32)
+    L.check(L.lib().mhx_target_eval(ctx.h, model.handle(ctx), L.fptr(xb), xb.shape[1], L.fptr(lp)))
+    return float(lp[0]) if single else lp
+
+
+class Transition:
+    """Transition(params, lp, accepted) -- src/AdvancedMH.jl:61-65."""
+
+    def __init__(self, params, lp, accepted):
+        self.params, self.lp, self.accepted = params, lp, accepted
+
+
+# ------------------------------------------------------------------------------------------------
+# samplers
+
+
+class RandomWalkProposal:
+    """RandomWalkProposal{issymmetric}(dist) -- src/proposal.jl:13-21."""
+
+    def __init__(self, proposal, issymmetric=False):
+        self.proposal = _as_mvnormal(proposal)
+        self.issymmetric = issymmetric
+        if np.any(self.proposal.mean != 0):
+            # src/proposal.jl:58-64: a non-zero-mean random walk has a non-zero Hastings ratio;
+            # the device path implements the zero-mean (ratio == 0) case only.
+            raise L.ArgumentError(L.MHX_EINVAL, "random-walk proposals on the GPU path must be zero-mean")
+
+
+def SymmetricRandomWalkProposal(proposal):
+    return RandomWalkProposal(proposal, True)
+
+
+class MetropolisHastings:
+    """MetropolisHastings(proposal) -- src/mh-core.jl:44-46."""
+
+    def __init__(self, proposal):
+        if not isinstance(proposal, RandomWalkProposal):
+            raise L.ArgumentError(L.MHX_EINVAL, "the GPU path implements RandomWalkProposal only")
+        self.proposal = proposal
+
+
+def RWMH(d):
+    """RWMH(d) / RWMH(d::Int) -- src/mh-core.jl:50-51."""
+    return MetropolisHastings(RandomWalkProposal(d))
+
+
+class StretchProposal:
+    """StretchProposal(prior, a = 2.0) -- src/emcee.jl:63-68."""
+
+    def __init__(self, proposal, stretch_length=2.0):
+        self.proposal, self.stretch_length = proposal, float(stretch_length)
+
+    def rand_initial(self, rng):
+        p = self.proposal
+        if isinstance(p, (list, tuple)):
+            return np.array([q.rand(rng) for q in p])
+        return np.asarray(p.rand(rng))
+
+
+class Ensemble:
+    """Ensemble(n_walkers, proposal) -- src/emcee.jl:1-4."""
+
+    def __init__(self, n_walkers, proposal):
+        if not isinstance(proposal, StretchProposal):
+            raise L.ArgumentError(L.MHX_EINVAL, "Ensemble: only StretchProposal is implemented (as in the reference)")
+        self.n_walkers, self.proposal = int(n_walkers), proposal
+
+
+class RobustAdaptiveMetropolis:
+    """RobustAdaptiveMetropolis(; α=0.234, γ=0.6, S=nothing, eigenvalue_lower_bound=0, eigenvalue_upper_bound=Inf)
+    -- src/RobustAdaptiveMetropolis.jl:75-87."""
+
+    def __init__(self, α=0.234, γ=0.6, S=None, eigenvalue_lower_bound=0.0, eigenvalue_upper_bound=float("inf"),
+                 alpha=None, gamma=None):
+        self.α = float(alpha if alpha is not None else α)
+        self.γ = float(gamma if gamma is not None else γ)
+        self.S = None if S is None else np.asarray(S, dtype=np.float64)
+        self.eigenvalue_lower_bound = float(eigenvalue_lower_bound)
+        self.eigenvalue_upper_bound = float(eigenvalue_upper_bound)
+
+
+# ------------------------------------------------------------------------------------------------
+# chains container (the part of MCMCChains.Chains the reference tests touch)
+
+
+class Chains:
+    """value[iteration, parameter, chain]; the last parameter is the internal `lp`
+    (ext/AdvancedMHMCMCChainsExt.jl:36, :96-118)."""
+
+    def __init__(self, value, names, start, thin, accepted=None, stats=None, state=None):
+        self.value = value
+        self.names = list(names)
+        self.start, self.thin = int(start), int(thin)
+        self.accepted = accepted
+        self.stats = stats or {}
+        self.state = state
+        self.internals = ["lp"]
+
+    def range(self):
+        n = self.value.shape[0]
+        return range(self.start, self.start + self.thin * n, self.thin)
+
+    def __getitem__(self, name):
+        if isinstance(name, str):
+            return self.value[:, self.names.index(name), :]
+        return self.value[name]
+
+    def __len__(self):
+        return self.value.shape[0]
+
+    @property
+    def nchains(self):
+        return self.value.shape[2]
+
+    def mean(self, name):
+        return float(np.mean(self[name], dtype=np.float64))
+
+    def params(self):
+        return [n for n in self.names if n not in self.internals]
+
+
+# ------------------------------------------------------------------------------------------------
+# a live run (what AbstractMCMC's `state` is for the reference)
+
+
+class Run:
+    def __init__(self, model, sampler, nchains=1, seed=0, first_chain=0, ctx=None, flags=0):
+        self.ctx = ctx or L.Context.default()
+        self.model, self.sampler = model, sampler
+        self.h = C.c_void_p()
+        lib = L.lib()
+        d = model.dim
+        self._keep = []
+        if isinstance(sampler, MetropolisHastings):
+            mv = sampler.proposal.proposal
+            if mv.dim != d:
+                raise L.ArgumentError(L.MHX_EINVAL, "proposal dimension %d != model dimension %d" % (mv.dim, d))
+            vec = None if mv.vec is None else L.f32(mv.vec)
+            self._keep.append(vec)
+            cfg = L.RwmhCfg(d, nchains, seed, first_chain, mv.kind, mv.scale, L.fptr(vec), flags)
+            L.check(lib.mhx_rwmh_create(self.ctx.h, model.handle(self.ctx), C.byref(cfg), C.byref(self.h)))
+            self.n = nchains
+            self.kind = "rwmh"
+        elif isinstance(sampler, Ensemble):
+            cfg = L.EmceeCfg(d, sampler.n_walkers, seed, first_chain, sampler.proposal.stretch_length, flags)
+            L.check(lib.mhx_emcee_create(self.ctx.h, model.handle(self.ctx), C.byref(cfg), C.byref(self.h)))
+            self.n = sampler.n_walkers
+            self.kind = "emcee"
+        elif isinstance(sampler, RobustAdaptiveMetropolis):
+            if sampler.S is not None and sampler.S.shape != (d, d):
+                # src/RobustAdaptiveMetropolis.jl:202-204
+                raise L.ArgumentError(L.MHX_EINVAL, "The provided `S` has the wrong dimensionality.")
+            cfg = L.RamCfg(d, nchains, seed, first_chain, sampler.α, sampler.γ, sampler.eigenvalue_lower_bound,
+                           sampler.eigenvalue_upper_bound, flags)
+            L.check(lib.mhx_ram_create(self.ctx.h, model.handle(self.ctx), C.byref(cfg), C.byref(self.h)))
+            self.n = nchains
+            self.kind = "ram"
+            if sampler.S is not None:
+                S = np.tile(pack_lower(np.tril(sampler.S)), (nchains, 1))
+                L.check(lib.mhx_ram_set_factor(self.h, L.fptr(L.f32(S))))
+        else:
+            raise L.ArgumentError(L.MHX_EINVAL, "unsupported sampler %r" % (sampler,))
+        self.dim = d
+        self.seed = seed
+
+    # -- initial AbstractMCMC.step
+    def init(self, initial_params=None):
+        ip = None
+        if initial_params is not None:
+            ip = np.asarray(initial_params, dtype=np.float32)
+            if self.kind == "emcee" and ip.ndim == 2 and ip.shape == (self.n, self.dim) and self.n != self.dim:
+                ip = ip.T                                       # vector-of-walkers form
+            if ip.ndim == 1:
+                if ip.size != self.dim:
+                    raise L.ArgumentError(L.MHX_EINVAL, "initial_params has the wrong dimension")
+                ip = np.repeat(ip.reshape(self.dim, 1), self.n, axis=1)
+            if ip.shape != (self.dim, self.n):
+                raise L.ArgumentError(L.MHX_EINVAL, "initial_params must be (dim,) or (dim, nchains)")
+            ip = L.f32(ip)
+        elif self.kind == "emcee":
+            # src/emcee.jl:29-34: W draws from the wrapped prior; a one-off host draw (numpy Generator
+            # seeded from the run seed), the device takes over from the first sweep.
+            rng = np.random.default_rng([self.seed, 0xE3CEE])
+            ip = L.f32(np.stack([self.sampler.proposal.rand_initial(rng) for _ in range(self.n)], axis=1))
+        L.check(L.lib().mhx_run_init(self.h, L.fptr(ip)))
+
+    def sample(self, n_samples, discard_initial=0, thinning=1, num_warmup=0, save=True):
+        s = L.Schedule(n_samples, discard_initial, thinning, num_warmup)
+        L.check(L.lib().mhx_run_sample(self.h, C.byref(s), 1 if save else 0))
+
+    def samples(self, want_accepted=True):
+        n_saved = C.c_int64()
+        L.check(L.lib().mhx_run_device_samples(self.h, None, None, C.byref(n_saved)))
+        N = int(n_saved.value)
+        out = np.empty((N, self.dim + 1, self.n), dtype=np.float32)
+        acc = np.empty((N, self.n), dtype=np.uint8) if want_accepted else None
+        L.check(L.lib().mhx_run_get_samples(self.h, L.fptr(out), L.u8ptr(acc)))
+        return out, acc
+
+    def state(self):
+        x = np.empty((self.dim, self.n), dtype=np.float32)
+        lp = np.empty(self.n, dtype=np.float32)
+        cnt = np.empty(self.n, dtype=np.uint32)
+        L.check(L.lib().mhx_run_get_state(self.h, L.fptr(x), L.fptr(lp), L.u32ptr(cnt)))
+        return x, lp, cnt
+
+    def set_params(self, x):
+        """AbstractMCMC.setparams!! (src/AdvancedMH.jl:150-157): replaces params, lp is re-evaluated."""
+        x = L.f32(x)
+        if x.shape != (self.dim, self.n):
+            raise L.ArgumentError(L.MHX_EINVAL, "set_params: x must be (dim, nchains)")
+        L.check(L.lib().mhx_run_set_state(self.h, L.fptr(x)))
+
+    def factor(self):
+        nS = self.dim * (self.dim + 1) // 2
+        S = np.empty((self.n, nS), dtype=np.float32)
+        st = np.empty(self.n, dtype=np.uint8)
+        L.check(L.lib().mhx_ram_get_factor(self.h, L.fptr(S), L.u8ptr(st)))
+        return S, st
+
+    def diag_range(self):
+        lo = np.empty((self.dim, self.n), dtype=np.float32)
+        hi = np.empty((self.dim, self.n), dtype=np.float32)
+        L.check(L.lib().mhx_ram_get_diag_range(self.h, L.fptr(lo), L.fptr(hi)))
+        return lo, hi
+
+    def stats(self):
+        st = L.Stats()
+        L.check(L.lib().mhx_run_stats(self.h, C.byref(st)))
+        return dict(transitions=st.transitions, accepted=st.accepted, kernel_ms=st.kernel_ms, wall_ms=st.wall_ms,
+                    kernel_variant=st.kernel_variant, launches=st.launches)
+
+    def diagnostics(self, max_lag=64):
+        d1 = self.dim + 1
+        arrs = [np.zeros(d1, dtype=np.float64) for _ in range(4)]
+        cfg = L.DiagCfg(max_lag)
+        ptrs = [a.ctypes.data_as(C.POINTER(C.c_double)) for a in arrs]
+        L.check(L.lib().mhx_run_diagnostics(self.h, C.byref(cfg), *ptrs))
+        return dict(sum_m=arrs[0], sum_m2=arrs[1], sum_v=arrs[2], ess=arrs[3])
+
+    def close(self):
+        if self.h:
+            L.lib().mhx_run_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def sample(model, sampler, N, nchains=1, *, initial_params=None, discard_initial=None, thinning=1, num_warmup=0,
+           param_names=None, chain_type=Chains, seed=0, first_chain=0, callback=None, ctx=None, flags=0,
+           progress=False):
+    """sample(model, sampler, N[, nchains]; kwargs...) -- AbstractMCMC.sample as re-exported by the
+    reference (src/AdvancedMH.jl:30).  All chains advance together on the GPU (what
+    `sample(model, spl, MCMCThreads(), N, nchains)` does with one task per chain, README.md:141-147).
+
+    discard_initial defaults to num_warmup [upstream]; `callback(run, i)` is called after each saved
+    sample (the reference signature callback(rng, model, sampler, sample, state, i) carries objects
+    that live on the device here -- the Run gives access to them)."""
+    if discard_initial is None:
+        discard_initial = num_warmup
+    run = Run(model, sampler, nchains=nchains, seed=seed, first_chain=first_chain, ctx=ctx, flags=flags)
+    run.init(initial_params)
+    if callback is None:
+        run.sample(N, discard_initial, thinning, num_warmup)
+        value, acc = run.samples()
+    else:
+        # one saved sample per call, so that the callback can look at every state
+        chunks, accs = [], []
+        dfw = min(num_warmup, discard_initial)
+        kfw = num_warmup - dfw
+        run.sample(1, discard_initial, 1, dfw)
+        v, a = run.samples()
+        chunks.append(v), accs.append(a)
+        callback(run, 1)
+        for i in range(2, N + 1):
+            warm = thinning if i <= kfw else 0
+            # `thinning` transitions, the last one saved: discard = thinning - 1 ... expressed as
+            # N=1, discard_initial=thinning (sample 1 = state after `thinning` transitions)
+            run.sample(1, thinning, 1, warm)
+            v, a = run.samples()
+            chunks.append(v), accs.append(a)
+            callback(run, i)
+        value, acc = np.concatenate(chunks, axis=0), np.concatenate(accs, axis=0)
+    d = model.dim
+    if param_names is None:
+        names = ["param_%d" % (i + 1) for i in range(d)]           # src/AdvancedMH.jl:91
+    else:
+        names = [str(p) for p in param_names]
+        if len(names) != d:
+            raise L.ArgumentError(L.MHX_EINVAL, "param_names has the wrong length")
+    names = names + ["lp"]
+    if chain_type is Chains:
+        return Chains(value, names, discard_initial + 1, thinning, accepted=acc, stats=run.stats(), state=run)
+    if chain_type is np.ndarray:
+        return value
+    raise L.ArgumentError(L.MHX_EINVAL, "chain_type must be Chains or numpy.ndarray")

@@ -1,0 +1,193 @@
+/*
+ * mhx.h -- C ABI of libmhx.so, the MI355X (gfx950) many-chain Metropolis-Hastings engine.
+ *
+ * The reference (TuringLang/AdvancedMH.jl v0.8.8) is pure Julia and has no FFI today; its operator
+ * API for this path is the AbstractMCMC interface.  Each entry point below names the reference
+ * interface it replaces (file:line under the reference tree).  A Julia maintainer binds these with
+ * `ccall` (advancedmh.jl_amd/julia/AdvancedMHHIP.jl); the executable host mirror in
+ * this repo is the Python package advancedmh.jl_amd/mhx (ctypes).
+ *
+ * Conventions
+ *   - every function returns MHX_OK (0) or a negative mhx_status; mhx_last_error() gives the
+ *     message for the calling thread.  Nothing throws across the boundary.
+ *   - the caller owns every host buffer; the library owns device memory behind opaque handles.
+ *   - calls are blocking: the device work they enqueue has completed when they return.
+ *   - host tensor layouts are C order with the CHAIN index fastest:
+ *       x        [dim][nchains]
+ *       samples  [n_samples][dim + 1][nchains]   (row `dim` is lp; cf. ext/AdvancedMHMCMCChainsExt.jl:96-105)
+ *       accepted [n_samples][nchains]            (Transition.accepted, src/AdvancedMH.jl:61-65)
+ *       S        [nchains][dim*(dim+1)/2]        packed lower triangle, row-major (RAM factor)
+ *   - a handle is not thread-safe; distinct contexts (one per GPU) may be driven concurrently.
+ *   - chains carry GLOBAL ids first_chain .. first_chain+nchains-1 in their RNG counters, so a run
+ *     sharded over several GPUs/processes is bit-identical to the unsharded run.
+ */
+#ifndef MHX_H
+#define MHX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MHX_VERSION 100 /* 0.1.0 */
+
+typedef enum {
+    MHX_OK = 0,
+    MHX_EINVAL = -1,   /* bad argument: dim mismatch, non-zero-mean RW proposal, missing initial_params ... */
+    MHX_ENOMEM = -2,
+    MHX_EHIP = -3,     /* HIP runtime error */
+    MHX_EJIT = -4,     /* hiprtc failed to compile a user log-density / specialised kernel */
+    MHX_ENOTPD = -5,   /* replaces LinearAlgebra.PosDefException of lowrankdowndate (reported, never thrown) */
+    MHX_ESTATE = -6    /* call out of order (e.g. sampling before init) */
+} mhx_status;
+
+typedef struct mhx_ctx mhx_ctx;       /* one per GPU: device, stream, JIT cache */
+typedef struct mhx_target mhx_target; /* a log-density on the device  == DensityModel (src/AdvancedMH.jl:52-54) */
+typedef struct mhx_run mhx_run;       /* device-resident chains of one sampler + their sample buffer */
+
+int mhx_version(void);
+const char *mhx_last_error(void);
+
+int mhx_ctx_create(int device, mhx_ctx **out);
+int mhx_ctx_destroy(mhx_ctx *ctx);
+
+/* ---------------------------------------------------------------------------------------------
+ * Targets.  Replaces DensityModel(f) / logdensity(model, x) (src/AdvancedMH.jl:52-54, :74-77). */
+typedef enum {
+    MHX_TARGET_ISO_GAUSS = 0,  /* logpdf(MvNormal(zeros(d), I), x);            params: none               */
+    MHX_TARGET_CORR_GAUSS = 1, /* logpdf(MvNormal(zeros(d), Sigma), x);        params: inv(chol(Sigma)) packed lower */
+    MHX_TARGET_IID_NORMAL = 2, /* README.md:29-31: theta=(mu,sigma), sum logpdf(Normal(mu,sigma), data); params: data */
+    MHX_TARGET_BANANA = 3,     /* twisted Gaussian N(0, diag(100,1,...)) with x2 += b(x1^2-100); params: {b}   */
+    MHX_TARGET_FUNNEL = 4,     /* Neal's funnel: x1~N(0,9), xk~N(0,exp(x1));  params: none               */
+    MHX_TARGET_USER = 100      /* hiprtc-compiled user source                                              */
+} mhx_target_kind;
+
+int mhx_target_builtin(mhx_ctx *ctx, int kind, int dim, const float *params, size_t nparams,
+                       mhx_target **out);
+/* `src` must define   MHX_LOGDENSITY(x, d, data, ndata) { ... return lp; }   using x[k] and the
+ * mhx_fma / mhx_log / mhx_exp / mhx_sqrt device functions; it is compiled by hiprtc and inlined
+ * into the sampler kernels (the "JIT-lowered user log-density" of the design). */
+int mhx_target_from_hip_source(mhx_ctx *ctx, const char *src, int dim, const float *data, size_t ndata,
+                               mhx_target **out);
+int mhx_target_destroy(mhx_target *t);
+/* logdensity(model, x) for a batch: x [dim][n] (host) -> lp [n] (host).  src/AdvancedMH.jl:74 */
+int mhx_target_eval(mhx_ctx *ctx, const mhx_target *t, const float *x, int n, float *lp);
+
+/* ---------------------------------------------------------------------------------------------
+ * Schedule.  Replaces the kwargs of AbstractMCMC.sample/mcmcsample [upstream]: N, discard_initial,
+ * thinning, num_warmup.  Sample 1 is the state after `discard_initial` transitions from the
+ * initial state; sample i is `thinning` transitions after sample i-1. */
+typedef struct {
+    int32_t n_samples;
+    int32_t discard_initial;
+    int32_t thinning;   /* >= 1 */
+    int32_t num_warmup; /* RAM: transitions that adapt (step_warmup) */
+} mhx_schedule;
+
+/* ---------------------------------------------------------------------------------------------
+ * Random-walk Metropolis-Hastings.  Replaces MetropolisHastings{RandomWalkProposal{_, <:MvNormal}}
+ * (src/mh-core.jl:44-51, src/proposal.jl:13-25) and its step methods (src/mh-core.jl:76-117). */
+typedef enum { MHX_PROP_ISO = 0, MHX_PROP_DIAG = 1, MHX_PROP_DENSE = 2 } mhx_proposal_kind;
+
+typedef struct {
+    int32_t dim;
+    int32_t nchains;
+    uint64_t seed;
+    uint64_t first_chain;   /* global id of chain 0 of this shard */
+    int32_t proposal_kind;  /* mhx_proposal_kind; proposals are zero-mean (src/proposal.jl:49-64) */
+    float proposal_scale;   /* ISO: sigma of N(0, sigma^2 I) */
+    const float *proposal_vec; /* DIAG: sigma_k [dim]; DENSE: chol(Sigma) packed lower [dim(dim+1)/2] */
+    int32_t flags;          /* MHX_FLAG_* */
+} mhx_rwmh_cfg;
+
+#define MHX_FLAG_NO_JIT 1 /* never specialise with hiprtc; use the pre-built kernels only */
+#define MHX_FLAG_GENERIC 2 /* force the generic (state-in-HBM) kernel even when a register kernel exists */
+
+int mhx_rwmh_create(mhx_ctx *ctx, const mhx_target *t, const mhx_rwmh_cfg *cfg, mhx_run **out);
+
+/* ---------------------------------------------------------------------------------------------
+ * Affine-invariant ensemble.  Replaces Ensemble{StretchProposal} (src/emcee.jl:1-4, :63-68), its
+ * step (:14-24), sweep (:39-58) and stretch move (:70-102).  The device sweep is the parallel
+ * half-split of the walker set, not the reference's sequential loop. */
+typedef struct {
+    int32_t dim;
+    int32_t nwalkers;
+    uint64_t seed;
+    uint64_t ensemble_id;
+    float stretch;          /* a = 2.0 */
+    int32_t flags;
+} mhx_emcee_cfg;
+
+int mhx_emcee_create(mhx_ctx *ctx, const mhx_target *t, const mhx_emcee_cfg *cfg, mhx_run **out);
+
+/* ---------------------------------------------------------------------------------------------
+ * Robust adaptive Metropolis.  Replaces RobustAdaptiveMetropolis (src/RobustAdaptiveMetropolis.jl:75-87),
+ * its state (:99-114) and step / step_warmup (:175-278). */
+typedef struct {
+    int32_t dim;
+    int32_t nchains;
+    uint64_t seed;
+    uint64_t first_chain;
+    float alpha;            /* 0.234 */
+    float gamma;            /* 0.6 */
+    float eig_lo, eig_hi;   /* eigenvalue (diagonal) bounds, 0 and +inf */
+    int32_t flags;
+} mhx_ram_cfg;
+
+int mhx_ram_create(mhx_ctx *ctx, const mhx_target *t, const mhx_ram_cfg *cfg, mhx_run **out);
+/* in/out Cholesky factors, [nchains][dim(dim+1)/2]; S == NULL on set means identity */
+int mhx_ram_set_factor(mhx_run *run, const float *S);
+int mhx_ram_get_factor(mhx_run *run, float *S, uint8_t *status /* [nchains] or NULL */);
+/* running min / max of diag(S) over every adapted state so far, [dim][nchains] each */
+int mhx_ram_get_diag_range(mhx_run *run, float *diag_min, float *diag_max);
+
+/* ---------------------------------------------------------------------------------------------
+ * Running chains.  mhx_run_init == the initial AbstractMCMC.step (src/mh-core.jl:76-86,
+ * src/emcee.jl:29-34, src/RobustAdaptiveMetropolis.jl:175-214): x0 = initial_params if given, else
+ * a draw (RWMH: from the proposal; RAM: randn(d); Ensemble: initial walkers are required).
+ * mhx_run_sample == the mcmcsample loop + bundle_samples into the device sample buffer.  It may be
+ * called repeatedly; each call continues the chains (counter-based RNG => resumable). */
+int mhx_run_init(mhx_run *run, const float *initial_params /* host [dim][nchains] or NULL */);
+int mhx_run_sample(mhx_run *run, const mhx_schedule *sched, int save_samples);
+
+/* copy the sample buffer of the last mhx_run_sample to the host (either pointer may be NULL) */
+int mhx_run_get_samples(mhx_run *run, float *samples, uint8_t *accepted);
+/* getparams / setparams!! (src/AdvancedMH.jl:146-157, src/RobustAdaptiveMetropolis.jl:116-121) */
+int mhx_run_get_state(mhx_run *run, float *x, float *lp, uint32_t *accept_counts);
+int mhx_run_set_state(mhx_run *run, const float *x /* lp is recomputed */);
+
+typedef struct {
+    uint64_t transitions;      /* chain-steps executed by the last mhx_run_sample (all chains)         */
+    uint64_t accepted;         /* accepted proposals among them (wavefront ballot + popcount reduction) */
+    double kernel_ms;          /* device time of the sampler kernels (hipEvent)                         */
+    double wall_ms;            /* host wall time of the call                                            */
+    int32_t kernel_variant;    /* 0 generic (HBM state), 1 pre-built register kernel, 2 hiprtc-specialised */
+    int32_t launches;
+} mhx_stats;
+int mhx_run_stats(mhx_run *run, mhx_stats *out);
+
+/* device pointers of the sample buffer of the last mhx_run_sample (for zero-copy consumers on the
+ * same HIP runtime, e.g. diagnostics or a torch tensor view); valid until the next sample/destroy */
+int mhx_run_device_samples(mhx_run *run, void **samples, void **accepted, int64_t *n_samples);
+
+int mhx_run_destroy(mhx_run *run);
+
+/* ---------------------------------------------------------------------------------------------
+ * Diagnostics on the device sample buffer (what MCMCChains prints for the reference, README.md:59-63).
+ * Per-parameter chain statistics, [dim+1] each: between/within-chain R-hat inputs and ESS.
+ *   mean_of_means, var_of_means (B/n), mean_of_vars (W), ess (sum over chains of per-chain
+ *   initial-positive-sequence ESS with max_lag cut-off).
+ * The sums are returned un-normalised as well (sum_m, sum_m2, sum_v) so that shards on several
+ * GPUs can be combined with ONE all-reduce. */
+typedef struct {
+    int32_t max_lag;
+} mhx_diag_cfg;
+int mhx_run_diagnostics(mhx_run *run, const mhx_diag_cfg *cfg, double *sum_m, double *sum_m2,
+                        double *sum_v, double *ess /* each [dim+1] */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MHX_H */

@@ -1,0 +1,122 @@
+/*
+ * mhx_oracle.h -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+ *
+ * A plain-C restatement of the AdvancedMH.jl hot path (reference @ /root/reference, v0.8.8):
+ *   src/mh-core.jl:76-117                      RWMH initial step + propose/logdensity/accept step
+ *   src/proposal.jl:13-25,41-64,190-196        RandomWalkProposal draw / Hastings ratio (== 0)
+ *   src/emcee.jl:1-102                         Ensemble sweep + stretch move
+ *   src/RobustAdaptiveMetropolis.jl:123-278    RAM inner step, rank-1 Cholesky adapt, step/step_warmup
+ *   ext/AdvancedMHMCMCChainsExt.jl:80-121      sample tensor layout (iterations x (params.., lp) x chains)
+ * plus the upstream pieces the package calls (AbstractMCMC.mcmcsample schedule, Distributions
+ * MvNormal rand/logpdf, LinearAlgebra.lowrankupdate/lowrankdowndate) restated from their
+ * published algorithms -- marked [upstream, restated] where they occur.
+ *
+ * PARITY STATUS: "parity unpinned" at bit level versus the Julia reference: the reference is
+ * pure Julia, no julia binary exists in this image, and its tests hold no golden vectors (all
+ * are statistical).  Julia's Xoshiro256++/ziggurat stream is replaced here by Philox4x32-10 with
+ * the arithmetic spec of DESIGN.md section 3.  What IS pinned: Philox against the Random123
+ * known-answer vectors, the transcendental polynomials against libm, the target log-densities
+ * against scipy, the rank-1 Cholesky up/downdate against numpy.linalg.cholesky, and the samplers
+ * against every analytic known answer the reference's own tests use (tests/test_oracle_*.py).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ */
+#ifndef MHX_ORACLE_H
+#define MHX_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- arithmetic spec primitives (exported so tests can pin them) ---- */
+void  orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+float orc_logf(float x);
+float orc_expf(float x);
+void  orc_sincos2pi_u32(uint32_t k, float *s, float *c);
+float orc_u01_open(uint32_t k);      /* (0,1]  : fmaf((float)k, 2^-32, 2^-33) */
+float orc_u01_half(uint32_t k);      /* [0,1)  : (k>>8) * 2^-24               */
+void  orc_normal_pair(uint32_t k0, uint32_t k1, float *n0, float *n1);
+/* d standard normals of (seed, chain, step, stream) -- the proposal noise of one chain-step */
+void  orc_normals(uint64_t seed, uint64_t chain, uint32_t step, uint32_t stream, int d, float *out);
+float orc_accept_logu(uint64_t seed, uint64_t chain, uint32_t step);
+
+/* RNG stream tags (c3 = tag<<28 | block) */
+enum { ORC_STREAM_PROPOSAL = 0, ORC_STREAM_ACCEPT = 1, ORC_STREAM_INIT = 2, ORC_STREAM_EMCEE = 3 };
+
+/* ---- targets ---- */
+enum {
+    ORC_TARGET_ISO_GAUSS   = 0,  /* params: none                                                  */
+    ORC_TARGET_CORR_GAUSS  = 1,  /* params: A = inv(chol(Sigma)) packed lower row-major, d(d+1)/2 */
+    ORC_TARGET_IID_NORMAL  = 2,  /* theta=(mu,sigma); params: n data points                       */
+    ORC_TARGET_BANANA      = 3,  /* params: {b}                                                   */
+    ORC_TARGET_FUNNEL      = 4,  /* params: none                                                  */
+    ORC_TARGET_CALLBACK    = 100 /* user function pointer (DensityModel(f))                       */
+};
+typedef float (*orc_logdensity_fn)(const float *x, int d, const void *data);
+
+typedef struct {
+    int kind;
+    int dim;
+    const float *params;     /* kind-specific, see above */
+    int nparams;
+    orc_logdensity_fn fn;    /* ORC_TARGET_CALLBACK */
+    const void *fn_data;
+} orc_target;
+
+float orc_target_eval(const orc_target *t, const float *x);
+
+/* ---- proposals (RandomWalkProposal{_, <:MvNormal}, zero mean) ---- */
+enum { ORC_PROP_ISO = 0, ORC_PROP_DIAG = 1, ORC_PROP_DENSE = 2 };
+typedef struct {
+    int kind;
+    float scale;          /* ISO: sigma                                  */
+    const float *vec;     /* DIAG: sigma_k[d]; DENSE: packed lower L     */
+} orc_proposal;
+
+/* ---- schedule [upstream AbstractMCMC.mcmcsample, restated] ---- */
+typedef struct {
+    int n_samples;        /* N                      */
+    int discard_initial;
+    int thinning;
+    int num_warmup;
+} orc_schedule;
+/* total transitions after the initial state, and how many leading ones are warm-up (adapting) */
+void orc_schedule_counts(const orc_schedule *s, int64_t *n_transitions, int64_t *n_adapt);
+
+/* ---- samplers.  Output tensors: samples[N][d+1][C] (chain fastest, lp last row),
+ *      accepted[N][C].  chains are global ids first_chain .. first_chain+C-1. ---- */
+int orc_rwmh(const orc_target *t, const orc_proposal *p, const orc_schedule *s,
+             uint64_t seed, uint64_t first_chain, int nchains,
+             const float *init /* [d][C] or NULL */, float *samples, uint8_t *accepted,
+             float *final_x /* [d][C] */, float *final_lp, uint32_t *accept_counts);
+
+/* Ensemble(W, StretchProposal(prior, a)). mode 0 = reference-faithful sequential sweep
+ * (src/emcee.jl:39-58), mode 1 = parallel half-split (what the HIP kernel runs). */
+int orc_emcee(const orc_target *t, float a, int mode, const orc_schedule *s,
+              uint64_t seed, uint64_t ensemble_id, int nwalkers,
+              const float *init /* [d][W], required */, float *samples, uint8_t *accepted,
+              float *final_x, float *final_lp, uint32_t *accept_counts);
+
+typedef struct {
+    float alpha;          /* target acceptance, 0.234 */
+    float gamma;          /* 0.6 */
+    float eig_lo, eig_hi; /* 0, +inf */
+} orc_ram_cfg;
+/* S: packed lower row-major [C][d(d+1)/2], in = initial factor (NULL -> identity), out = final.
+ * logalpha_trace (optional) [n_transitions][C]. status[C]: bit0 = a downdate hit s^2>1. */
+int orc_ram(const orc_target *t, const orc_ram_cfg *cfg, const orc_schedule *s,
+            uint64_t seed, uint64_t first_chain, int nchains,
+            const float *init /* [d][C] or NULL -> randn */, const float *S_in, float *S_out,
+            float *samples, uint8_t *accepted, float *final_x, float *final_lp,
+            uint32_t *accept_counts, uint8_t *status, float *diag_min, float *diag_max);
+
+/* rank-1 Cholesky update (sign=+1) / downdate (sign=-1) of a packed lower factor, in place.
+ * returns 0, or i+1 if the downdate failed at column i (S is then partially modified). */
+int orc_chol_rank1(float *S, float *w, int d, int sign);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

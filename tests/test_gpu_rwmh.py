@@ -1,0 +1,63 @@
+"""GPU parity: HIP RWMH kernels (through the C ABI) vs the CPU oracle, bit for bit.
+Reference behaviour under test: src/mh-core.jl:76-117, src/proposal.jl:41-56."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def _same(a, b, what):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    assert a.shape == b.shape, what
+    if a.dtype == np.float32:
+        bad = np.argwhere(_bits(a) != _bits(b))
+    else:
+        bad = np.argwhere(a != b)
+    assert len(bad) == 0, "%s: %d mismatches, first at %s: %r vs %r" % (
+        what, len(bad), bad[0], a[tuple(bad[0])], b[tuple(bad[0])])
+
+
+S = float(np.float32(0.238))
+
+
+@pytest.mark.parametrize("flags_name", ["auto", "generic"])
+@pytest.mark.parametrize("d,C,N", [(100, 130, 40), (2, 5, 64), (7, 64, 33), (33, 257, 17)])
+def test_iso_gauss_rwmh_bit_exact(mhx, oracle, d, C, N, flags_name):
+    flags = mhx.FLAG_GENERIC if flags_name == "generic" else 0
+    seed = 0xC0FFEE + d
+    model = mhx.DensityModel(mhx.IsoGaussian(d))
+    spl = mhx.RWMH(mhx.MvNormal(mhx.zeros(d), S * S * mhx.I))
+    chain = mhx.sample(model, spl, N, C, seed=seed, first_chain=7, flags=flags)
+    ref = oracle.rwmh(oracle.iso_gauss(d), oracle.Proposal(oracle.PROP_ISO, S), oracle.schedule(N), seed, 7, C)
+    _same(chain.value, ref["samples"], "samples")
+    _same(chain.accepted, ref["accepted"], "accepted")
+    x, lp, cnt = chain.state.state()
+    _same(x, ref["final_x"], "final x")
+    _same(lp, ref["final_lp"], "final lp")
+    _same(cnt, ref["accept_counts"], "accept counts")
+    assert chain.stats["accepted"] == int(ref["accept_counts"].sum())
+    if flags_name == "auto":
+        assert chain.stats["kernel_variant"] in (1, 2)
+    else:
+        assert chain.stats["kernel_variant"] == 0
+
+
+def test_schedule_discard_thinning_and_initial_params(mhx, oracle):
+    d, C, N = 4, 70, 25
+    init = np.random.default_rng(1).normal(size=(d, C)).astype(np.float32)
+    model = mhx.DensityModel(mhx.IsoGaussian(d))
+    spl = mhx.RWMH(mhx.MvNormal(mhx.zeros(d), np.array([0.5, 1.0, 0.25, 2.0]) ** 2))
+    chain = mhx.sample(model, spl, N, C, seed=5, initial_params=init, discard_initial=25, thinning=4)
+    assert chain.range() == range(26, 26 + 4 * N, 4)          # test/runtests.jl:129
+    prop = oracle.Proposal(oracle.PROP_DIAG, vec=np.array([0.5, 1.0, 0.25, 2.0], dtype=np.float32))
+    ref = oracle.rwmh(oracle.iso_gauss(d), prop, oracle.schedule(N, 25, 4), 5, 0, C, init=init)
+    _same(chain.value, ref["samples"], "samples")
+    _same(chain.accepted, ref["accepted"], "accepted")
+    # first sample == initial_params when nothing is discarded (test/runtests.jl:203-213)
+    chain0 = mhx.sample(model, spl, 3, C, seed=5, initial_params=init)
+    _same(chain0.value[0, :d, :], init, "sample 1")
+    assert not chain0.accepted[0].any()
