@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: MH steps/sec (all chains) on the isotropic 100-dim Gaussian,
+RWMH, 65 536 chains per GPU (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch: ONE mhx_run_sample launch that advances all
+65 536 chains of this rank by `--inner` (default 250) Metropolis-Hastings transitions and records
+every state (the save-all semantics of the reference's `sample`) into the HBM-resident sample
+tensor [inner][d+1][chains].  Inputs (chain state) and outputs (samples) stay in HBM; nothing
+crosses PCIe inside the timed region.  Chains are sharded over ranks by global chain id
+(first_chain = rank * chains), no data-path collective; scaling is weak.
+
+Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel against HBM with the
+algorithmic bytes of DESIGN.md section 7; `cpu_baseline` is the CPU oracle (a port of the
+reference algorithm, oracle/) timed on this host on a bounded sample -- rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "advancedmh.jl_amd"))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s achievable)
+D = 100
+CHAINS = 65536
+
+
+def algorithmic_bytes_per_launch(d, chains, inner):
+    """sample record 4(d+1)+1 B per chain-step (save-all) + one state
+    round trip per launch (read x, lp, accept count, last flag; write them back)."""
+    record = 4 * (d + 1) + 1
+    state = 2 * (4 * d + 4 + 4 + 1)
+    return chains * (inner * record + state)
+
+
+def cpu_baseline(d, inner, seed, target_seconds=10.0):
+    """The oracle (same algorithm, same Philox streams, scalar loop per chain) on all host cores:
+    chains statically partitioned over threads (the MCMCThreads analogue).  Bounded sample."""
+    import concurrent.futures as cf
+    import numpy as np
+    from oracle import oracle as O
+    O.build()
+    s = float(np.float32(2.38 / d ** 0.5))
+    cores = os.cpu_count() or 1
+    tgt = O.iso_gauss(d)
+
+    def work(first, n, steps):
+        O.rwmh(tgt, O.Proposal(O.PROP_ISO, s), O.schedule(steps + 1), seed, first, n, save=True)
+
+    def pool(per_thread, steps):
+        t0 = time.perf_counter()
+        with cf.ThreadPoolExecutor(cores) as ex:
+            list(ex.map(lambda i: work(i * per_thread, per_thread, steps), range(cores)))
+        return time.perf_counter() - t0
+
+    t0 = time.perf_counter()
+    work(0, 8, 100)                                   # single-thread rate (the `sample(model, spl, N)` analogue)
+    rate1 = 800 / (time.perf_counter() - t0)
+    rate_all = cores * 8 * 100 / pool(8, 100)         # calibration on all cores
+    per_thread = max(1, int(rate_all * target_seconds / (inner * cores)))
+    dt = pool(per_thread, inner)
+    total = cores * per_thread * inner
+    return {"value": total / dt, "unit": "MH steps/s", "cores": cores, "kind": "port",
+            "sample": "%d chains x %d transitions of the same d=%d workload (oracle/mhx_oracle.c, %d threads, %.1f s); "
+                      "single-thread %.3g steps/s" % (cores * per_thread, inner, d, cores, dt, rate1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--inner", type=int, default=250, help="MH transitions per chain per step (launch)")
+    ap.add_argument("--chains", type=int, default=CHAINS, help="chains per GPU")
+    ap.add_argument("--dim", type=int, default=D)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ess", action="store_true", help="also report ESS/sec from the device diagnostics")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1 or os.environ.get("MHX_BENCH_FORCE_DIST"):      # the env knob exercises the RCCL path on 1 GPU
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import numpy as np
+    import mhx
+
+    d, C, inner = args.dim, args.chains, args.inner
+    s = float(np.float32(2.38 / d ** 0.5))
+    ctx = mhx.Context(local_rank)
+    model = mhx.DensityModel(mhx.IsoGaussian(d))
+    spl = mhx.RWMH(mhx.MvNormal(mhx.zeros(d), s * s * mhx.I))
+    run = mhx.Run(model, spl, nchains=C, seed=0xC0FFEE, first_chain=rank * C, ctx=ctx)
+    run.init(None)                                    # x0 ~ proposal draw (src/mh-core.jl:83), on the device
+
+    def step():
+        # N=inner saved samples, the first one being the state after 1 transition: inner transitions
+        run.sample(inner, 1, 1, 0, save=True)
+        return run.stats()
+
+    def sync():
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    kernel_ms, accepted, transitions = 0.0, 0, 0
+    for _ in range(args.steps):
+        st = step()                                   # blocking: the stream is synchronised on return
+        kernel_ms += st["kernel_ms"]
+        accepted += st["accepted"]
+        transitions += st["transitions"]
+    sync()
+    dt = time.perf_counter() - t0
+    variant = st["kernel_variant"]
+
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        tot = torch.tensor([float(accepted), float(transitions)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tot)                          # the only collective: global acceptance statistic
+        accepted, transitions_all = float(tot[0].item()), float(tot[1].item())
+    else:
+        transitions_all = float(transitions)
+
+    if rank == 0:
+        total_steps = float(C) * inner * args.steps * world
+        value = total_steps / dt
+        launch_s = kernel_ms * 1e-3 / args.steps
+        bytes_launch = algorithmic_bytes_per_launch(d, C, inner)
+        achieved = bytes_launch / launch_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                key = "rwmh_d%d_c%d_inner%d" % (d, C, inner)
+                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "MH steps/sec (all chains)", "value": value, "unit": "MH steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "RWMH, isotropic %d-dim standard MvNormal target, %d chains per GPU, proposal "
+                                   "N(0,(2.38/sqrt(d))^2 I), %d transitions per launch, every state recorded" % (d, C, inner),
+                       "chains_per_gpu": C, "dim": d, "transitions_per_step": inner,
+                       "kernel_variant": {0: "generic", 1: "prebuilt-register", 2: "hiprtc-register"}[variant],
+                       "sharding": "chains by global id, no data-path collective"},
+            "acceptance_rate": accepted / transitions_all,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "mhx_rwmh_reg<100,iso,iso>", "avg_launch_ms": launch_s * 1e3,
+                         "algorithmic_bytes_per_launch": bytes_launch,
+                         "note": "VALU-bound kernel (Philox + Box-Muller polynomials, ~6.1k lane-ops per chain-step); "
+                                 "HBM sees only the sample records"},
+        }
+        if args.ess:
+            try:
+                dg = run.diagnostics()
+                out["ess_per_sec"] = float(np.median(dg["ess"][:d])) * world / (dt / args.steps)
+            except Exception as e:          # diagnostics are optional for the headline line
+                out["ess_per_sec"] = None
+                out["ess_error"] = str(e)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(d, inner, 0xC0FFEE)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
