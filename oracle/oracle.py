@@ -120,8 +120,9 @@ def accept_logu(seed, chain, step):
 class Target:
     """kind + params, or a Python callable f(x: np.ndarray) -> float (DensityModel(f))."""
 
-    def __init__(self, kind, dim, params=None, fn=None):
+    def __init__(self, kind, dim, params=None, fn=None, fn_data=None):
         self.kind, self.dim = kind, dim
+        self._fn_data = fn_data             # keep-alive for a ctypes object passed as void*
         self.params = None if params is None else np.ascontiguousarray(params, dtype=np.float32)
         self._cb = None
         self._fn_addr = None
@@ -141,7 +142,7 @@ class Target:
             self.c.fn = self._cb
         elif self._fn_addr is not None:
             self.c.fn = C.cast(self._fn_addr, LOGDENSITY_FN)
-        self.c.fn_data = None
+        self.c.fn_data = None if fn_data is None else C.cast(C.pointer(fn_data), C.c_void_p)
 
     def __call__(self, x):
         x = np.ascontiguousarray(x, dtype=np.float32)

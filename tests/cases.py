@@ -1,0 +1,70 @@
+"""Seeded parity cases shared by the CPU tests (oracle vs committed golden traces) and the GPU
+tests (HIP kernels vs oracle / golden traces).  Each case returns the oracle's result dict."""
+import numpy as np
+
+S238 = float(np.float32(0.238))
+
+
+def sigma_ar1(d, rho):
+    i = np.arange(d)
+    return rho ** np.abs(i[:, None] - i[None, :])
+
+
+def case_rwmh_iso(O):
+    return O.rwmh(O.iso_gauss(5), O.Proposal(O.PROP_ISO, 0.5), O.schedule(32), 11, 3, 8)
+
+
+def case_rwmh_dense_corr(O):
+    d = 4
+    L = np.linalg.cholesky(0.3 * sigma_ar1(d, 0.5))
+    prop = O.Proposal(O.PROP_DENSE, vec=O.pack_lower(L))
+    return O.rwmh(O.corr_gauss_from_cov(sigma_ar1(d, 0.8)), prop, O.schedule(20, 3, 2), 12, 0, 6)
+
+
+def case_rwmh_funnel(O):
+    return O.rwmh(O.Target(O.TARGET_FUNNEL, 6), O.Proposal(O.PROP_ISO, 0.4), O.schedule(24), 13, 100, 7)
+
+
+def case_rwmh_banana(O):
+    t = O.Target(O.TARGET_BANANA, 5, params=[0.03])
+    return O.rwmh(t, O.Proposal(O.PROP_DIAG, vec=[2.0, 0.5, 1.0, 1.0, 1.0]), O.schedule(24), 14, 0, 7)
+
+
+def emcee_init(d, W, seed):
+    return np.random.default_rng(seed).normal(size=(d, W)).astype(np.float32)
+
+
+def case_emcee_split(O):
+    d, W = 3, 10
+    return O.emcee(O.corr_gauss_from_cov(sigma_ar1(d, 0.9)), 2.0, 1, O.schedule(16), 21, 0, W, emcee_init(d, W, 5))
+
+
+def case_emcee_seq(O):
+    d, W = 3, 10
+    return O.emcee(O.corr_gauss_from_cov(sigma_ar1(d, 0.9)), 2.0, 0, O.schedule(16), 21, 0, W, emcee_init(d, W, 5))
+
+
+def case_ram(O):
+    d = 4
+    r = O.ram(O.corr_gauss_from_cov(sigma_ar1(d, 0.7)), O.schedule(24, 0, 1, 16), 31, 2, 6,
+              init=np.zeros((d, 6), dtype=np.float32))
+    return r
+
+
+def case_ram_bounds(O):
+    d = 2
+    Sig = np.array([[10.0, 5.0], [5.0, 10.0]])
+    return O.ram(O.corr_gauss_from_cov(Sig), O.schedule(40, 0, 1, 40), 32, 0, 5, init=np.zeros((d, 5), dtype=np.float32),
+                 gamma=0.51, eig_lo=0.9, eig_hi=1.1)
+
+
+TRACE_CASES = {
+    "rwmh_iso": case_rwmh_iso,
+    "rwmh_dense_corr": case_rwmh_dense_corr,
+    "rwmh_funnel": case_rwmh_funnel,
+    "rwmh_banana": case_rwmh_banana,
+    "emcee_split": case_emcee_split,
+    "emcee_seq": case_emcee_seq,
+    "ram": case_ram,
+    "ram_bounds": case_ram_bounds,
+}

@@ -1,0 +1,140 @@
+"""CPU: the oracle's samplers against the committed golden traces (drift pin) and against every
+analytic known answer the reference's own tests use."""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import user_targets
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def traces():
+    return np.load(os.path.join(GOLD, "traces.npz"))
+
+
+@pytest.mark.parametrize("name", sorted(cases.TRACE_CASES))
+def test_oracle_reproduces_golden_traces(oracle, traces, name):
+    res = cases.TRACE_CASES[name](oracle)
+    for k, v in res.items():
+        want = traces["%s/%s" % (name, k)]
+        assert v.shape == want.shape
+        assert np.array_equal(v.view(np.uint8), want.view(np.uint8)), "%s/%s drifted" % (name, k)
+
+
+def test_rwmh_normal_model_known_answer(oracle):
+    """test/runtests.jl:76-94: RWMH(MvNormal(zeros(2), I)) on the Normal(mu, sigma) likelihood of 300
+    N(0,1) points; posterior mean mu ~ 0, sigma ~ 1 (atol 0.1).  100 000 draws, one chain, as README.md:40."""
+    data = np.load(os.path.join(GOLD, "c1_normal_data.npy"))
+    t = oracle.Target(oracle.TARGET_IID_NORMAL, 2, params=data)
+    r = oracle.rwmh(t, oracle.Proposal(oracle.PROP_ISO, 1.0), oracle.schedule(100000), 1234, 0, 1,
+                    init=np.array([[0.0], [1.0]], dtype=np.float32))
+    mu, sig = r["samples"][:, 0, 0].astype(np.float64), r["samples"][:, 1, 0].astype(np.float64)
+    assert abs(mu.mean() - data.mean()) < 0.1 and abs(mu.mean()) < 0.1
+    assert abs(sig.mean() - 1.0) < 0.1
+    assert (sig >= 0).all()                                   # never leaves the support
+    acc = r["accepted"][1:, 0].mean()
+    assert 0.001 < acc < 0.2                                   # unit-scale proposal on a sharp posterior (sd ~ 0.06)
+
+
+def test_rwmh_first_sample_and_schedule(oracle):
+    init = np.random.default_rng(0).normal(size=(3, 4)).astype(np.float32)
+    r = oracle.rwmh(oracle.iso_gauss(3), oracle.Proposal(oracle.PROP_ISO, 0.7), oracle.schedule(6), 9, 0, 4, init=init)
+    assert np.array_equal(r["samples"][0, :3, :], init) and not r["accepted"][0].any()   # test/runtests.jl:203-213
+    # thinning/discard pick the same states out of the same chain
+    full = oracle.rwmh(oracle.iso_gauss(3), oracle.Proposal(oracle.PROP_ISO, 0.7), oracle.schedule(40), 9, 0, 4, init=init)
+    thin = oracle.rwmh(oracle.iso_gauss(3), oracle.Proposal(oracle.PROP_ISO, 0.7), oracle.schedule(5, 7, 4), 9, 0, 4, init=init)
+    assert np.array_equal(thin["samples"], full["samples"][7:7 + 4 * 5:4])
+    # global chain ids: a shard equals the matching slice of the whole
+    part = oracle.rwmh(oracle.iso_gauss(3), oracle.Proposal(oracle.PROP_ISO, 0.7), oracle.schedule(40), 9, 2, 2, init=init[:, 2:])
+    assert np.array_equal(part["samples"], full["samples"][:, :, 2:])
+
+
+def test_rwmh_edge_cases(oracle):
+    # lp = -inf at the start and a finite candidate: +inf log-ratio => accept
+    t = oracle.Target(oracle.TARGET_IID_NORMAL, 2, params=np.zeros(5, dtype=np.float32))
+    r = oracle.rwmh(t, oracle.Proposal(oracle.PROP_ISO, 0.5), oracle.schedule(200), 3, 0, 8,
+                    init=np.tile(np.array([[0.0], [-0.2]], dtype=np.float32), (1, 8)))
+    assert np.isneginf(r["samples"][0, 2, :]).all()
+    later = r["samples"][-1, 2, :]
+    fin0 = np.isfinite(r["samples"][:, 2, :])
+    assert np.isfinite(later).all()                          # every chain escaped the -inf start
+    # candidates outside the support are always rejected
+    # once finite, lp never returns to -inf (a -inf candidate is always rejected)
+    assert (np.diff(fin0.astype(int), axis=0) >= 0).all()
+    fin = np.isfinite(r["samples"][:, 2, :])
+    assert (r["samples"][:, 1, :][fin] > 0).all()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_emcee_nig_known_answer_untransformed(oracle, mode):
+    """test/emcee.jl:3-42: E[s] = 49/24, E[m] = 7/6 (atol 0.1); Ensemble(1000, StretchProposal(...)), 1000 iterations.
+    mode 0 = the reference's sequential sweep, mode 1 = the parallel half-split the GPU runs."""
+    t = user_targets.host_target(oracle, user_targets.NIG_UNTRANSFORMED, 2)
+    rng = np.random.default_rng(100)
+    W = 1000
+    init = np.stack([3.0 / rng.gamma(2.0, size=W), rng.normal(size=W)]).astype(np.float32)   # [InverseGamma(2,3), Normal(0,1)]
+    r = oracle.emcee(t, 2.0, mode, oracle.schedule(1000), 100, 0, W, init)
+    s, m = r["samples"][:, 0, :].astype(np.float64), r["samples"][:, 1, :].astype(np.float64)
+    assert abs(s.mean() - 49 / 24) < 0.1
+    assert abs(m.mean() - 7 / 6) < 0.1
+    assert (s > 0).all()
+    r2 = oracle.emcee(t, 2.0, mode, oracle.schedule(200, 25, 4), 100, 0, W, init)
+    assert np.array_equal(r2["samples"], r["samples"][25:25 + 4 * 200:4])     # test/emcee.jl:39 index arithmetic
+
+
+def test_emcee_nig_known_answer_transformed(oracle):
+    """test/emcee.jl:44-83 (log-transformed space, initial walkers ~ MvNormal(zeros(2), I))."""
+    t = user_targets.host_target(oracle, user_targets.NIG_TRANSFORMED, 2)
+    W = 1000
+    init = np.random.default_rng(100).normal(size=(2, W)).astype(np.float32)
+    r = oracle.emcee(t, 2.0, 1, oracle.schedule(1000), 101, 0, W, init)
+    logs, m = r["samples"][:, 0, :].astype(np.float64), r["samples"][:, 1, :].astype(np.float64)
+    assert abs(np.exp(logs).mean() - 49 / 24) < 0.1
+    assert abs(m.mean() - 7 / 6) < 0.1
+
+
+def test_emcee_partner_is_never_self_and_initial_sample(oracle):
+    d, W = 2, 6
+    init = cases.emcee_init(d, W, 1)
+    for mode in (0, 1):
+        r = oracle.emcee(oracle.iso_gauss(d), 2.0, mode, oracle.schedule(50), 5, 0, W, init)
+        assert np.array_equal(r["samples"][0, :d, :], init) and not r["accepted"][0].any()
+        # a stretch move keeps the walker on the line through its partner: accepted moves changed x
+        moved = (np.diff(r["samples"][:, 0, :], axis=0) != 0)
+        assert np.array_equal(moved, r["accepted"][1:].astype(bool))
+
+
+@pytest.mark.parametrize("var", [10.0, 0.01])
+def test_ram_eigenvalue_bounds(oracle, var):
+    """test/RobustAdaptiveMetropolis.jl:30-72: diag(S) stays within [0.9, 1.1] and saturates the relevant bound."""
+    Sig = np.array([[var, var / 2], [var / 2, var]])
+    C = 8
+    r = oracle.ram(oracle.corr_gauss_from_cov(Sig), oracle.schedule(1000, 0, 1, 1000), 7, 0, C,
+                   init=np.zeros((2, C), dtype=np.float32), gamma=0.51, eig_lo=0.9, eig_hi=1.1)
+    assert (r["diag_min"] >= 0.9).all() and (r["diag_max"] <= 1.1).all()
+    if var < 0.5:
+        assert np.abs(r["diag_min"] - 0.9).max() < 0.05
+    else:
+        assert np.abs(r["diag_max"] - 1.1).max() < 0.05
+    assert r["accepted"][0].all()                             # initial Transition(x, lp, true), RAM.jl:213
+
+
+def test_ram_doctest_covariance(oracle):
+    """src/RobustAdaptiveMetropolis.jl:17-70: 2-d Gaussian, correlation 0.5; 10 000 warm-up + 10 000 draws from
+    zeros(2): cov(chain) ~ Sigma (rtol 0.2); with bounds [0.1, 2.0]: |cov - Sigma| < 0.2."""
+    Sig = np.array([[1.0, 0.5], [0.5, 1.0]])
+    C = 4
+    for kw in ({}, dict(eig_lo=0.1, eig_hi=2.0)):
+        r = oracle.ram(oracle.corr_gauss_from_cov(Sig), oracle.schedule(10000, 10000, 1, 10000), 42, 0, C,
+                       init=np.zeros((2, C), dtype=np.float32), **kw)
+        for c in range(C):
+            cov = np.cov(r["samples"][:, :2, c].astype(np.float64).T)
+            assert np.linalg.norm(cov - Sig) < 0.2 * np.linalg.norm(Sig) + 0.05
+        # the adapted factor approximates a scaled chol(Sigma): acceptance near the 0.234 target afterwards
+        acc = r["accepted"].mean()
+        assert 0.12 < acc < 0.4
+        assert (r["status"] & 1).sum() == 0
