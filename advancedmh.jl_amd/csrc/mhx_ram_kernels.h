@@ -1,3 +1,381 @@
-// mhx_ram_kernels.h -- robust adaptive Metropolis kernels.  (filled in below)
+// mhx_ram_kernels.h -- Robust Adaptive Metropolis (Vihola 2012), one WAVEFRONT per chain.
+//
+// Replaces ram_step_inner (src/RobustAdaptiveMetropolis.jl:123-151), ram_adapt (:153-173),
+// valid_eigenvalues (:239-245) and the step / step_warmup methods (:216-278).
+//
+// Every chain owns a lower-triangular factor S (d(d+1)/2 floats: 80 KB at d = 200), so a lane
+// cannot own a chain.  A 64-lane wave owns one: lane t holds rows t, t+64, ... of x, U, v, w.  S is
+// stored per chain as a PACKED COLUMN-MAJOR lower triangle (column i = rows i..d-1, contiguous), so
+// that both passes over it are column sweeps with coalesced row-segment loads:
+//   pass A  x' = S U + x      v_j += S_ji U_i, columns i ascending  == row-dot in ascending order
+//   pass B  rank-1 update     for column i: rotation (c,s) from (S_ii, w_i), then every row j > i
+//                             independently -- the upstream lowrankupdate/lowrankdowndate sweep
+// The update is written to the chain's SECOND factor buffer and a per-chain selector flips only if
+// the new factor is valid (downdate stayed positive definite, diagonal inside the eigenvalue bounds
+// -- RAM.jl:259-264 keeps the old S otherwise), so a rejected update costs no copy.
+// HBM traffic per adapting step: 2 reads + 1 write of S.
 #pragma once
 #include "mhx_targets.h"
+
+#define MHX_RAM_CHUNK 8
+
+struct mhx_ram_args {
+    float* x;                 // [dim][ld]  (ABI layout; touched once per launch)
+    float* lp;                // [ld]
+    mhx_u32* acc_count;
+    mhx_u64* acc_total;
+    float* samples;           // [slots][dim+1][ld] or null
+    unsigned char* accepted;
+    unsigned char* last_acc;
+    float* S0;                // [nchains][tri] packed column-major lower
+    float* S1;                // second buffer
+    unsigned char* sel;       // [nchains] which buffer is current
+    unsigned char* status;    // [nchains] bit0: a downdate left the PD cone, bit1: NaN log-ratio
+    float* dmin;              // [nchains][dim] running min of diag(S)
+    float* dmax;
+    const float* eta;         // [nsteps] adaptation step sizes iteration^-gamma of this launch
+    const float* acol;        // CORR_GAUSS target: inv(chol(Sigma)) packed column-major lower
+    mhx_u64 seed;
+    mhx_u64 first_chain;
+    int nchains;
+    int ld;
+    int dim;
+    int target_kind;
+    int ntparams;
+    float tconst;
+    float alpha;
+    float eig_lo, eig_hi;
+    int default_bounds;
+    mhx_u32 step0;
+    int nsteps;
+    int n_adapt;              // the first n_adapt steps of this launch adapt S (step_warmup)
+    mhx_u32 save_next;
+    int save_slot;
+    int thinning;
+};
+
+// x accessor over LDS (broadcast reads: every lane evaluates the target redundantly)
+struct mhx_lds_x {
+    const float* p;
+    MHX_DEV float operator[](int k) const { return p[k]; }
+};
+
+MHX_DEV long mhx_ram_col_off(int i, int d) { return (long)i * d - ((long)i * (i - 1)) / 2; }
+
+// R = rows per lane (dim <= 64 R)
+template <int R, int TK>
+MHX_DEV void mhx_ram_body(const mhx_ram_args& a, const float* __restrict__ tparams, float* lds)
+{
+    // XCD-aware chain mapping: blocks b, b+8, ... run on one XCD; give them consecutive chains
+    const int nb = gridDim.x;
+    const int per = (nb + 7) >> 3;
+    const int c = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+    if (c >= a.nchains) return;
+    const int t = threadIdx.x;
+    const int d = a.dim;
+    const long ld = a.ld;
+    const long tri = (long)d * (d + 1) / 2;
+    const mhx_u64 id = a.first_chain + (mhx_u64)c;
+    const mhx_u32 id_lo = (mhx_u32)id, id_hi = (mhx_u32)(id >> 32);
+    const mhx_philox_key ks = mhx_philox_schedule(a.seed);
+    float* Ush = lds;            // [d] proposal noise, later the rank-1 vector / target scratch
+    float* ysh = lds + d;        // [d] candidate
+
+    float x[R], dmn[R], dmx[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int row = t + 64 * r;
+        x[r] = row < d ? a.x[(long)row * ld + c] : 0.0f;
+        dmn[r] = row < d ? a.dmin[(long)c * d + row] : 0.0f;
+        dmx[r] = row < d ? a.dmax[(long)c * d + row] : 0.0f;
+    }
+    float lp = a.lp[c];
+    mhx_u32 nacc = a.acc_count[c];
+    mhx_u32 wave_acc = 0;
+    bool last = a.last_acc[c] != 0;
+    int sel = a.sel[c];
+    unsigned st = a.status[c];
+    mhx_accept_cache ac;
+    ac.group = 0xffffffffu;
+    ac.w.x = ac.w.y = ac.w.z = ac.w.w = 0u;
+    mhx_u32 save_next = a.save_next;
+    long slot = a.save_slot;
+    const int nblk = (d + 3) >> 2;
+
+    for (int it = 0; it < a.nsteps; ++it) {
+        const mhx_u32 step = a.step0 + (mhx_u32)it;
+        const float* Scur = (sel ? a.S1 : a.S0) + (long)c * tri;
+        float* Snew = (sel ? a.S0 : a.S1) + (long)c * tri;
+
+        // ---- U = randn(d)  (RAM.jl:135): lane b draws Philox block b
+        for (int b = t; b < nblk; b += 64) {
+            float n[4];
+            mhx_normal4(ks, id_lo, id_hi, step, MHX_STREAM_PROPOSAL, (mhx_u32)b, n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (4 * b + j < d) Ush[4 * b + j] = n[j];
+        }
+        __syncthreads();
+        float nn = 0.0f;                                   // |U|^2, ascending order (every lane)
+        for (int j = 0; j < d; ++j) { const float u = Ush[j]; nn = mhx_fma(u, u, nn); }
+
+        // ---- pass A: v = S U, x' = v + x   (RAM.jl:136 muladd(S, U, x))
+        float v[R], y[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = 0.0f;
+        for (int i0 = 0; i0 < d; i0 += MHX_RAM_CHUNK) {
+            float col[MHX_RAM_CHUNK][R];
+#pragma unroll
+            for (int cc = 0; cc < MHX_RAM_CHUNK; ++cc) {
+                const int i = i0 + cc;
+                const long off = mhx_ram_col_off(i, d) - i;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int row = t + 64 * r;
+                    col[cc][r] = (i < d && row >= i && row < d) ? Scur[off + row] : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int cc = 0; cc < MHX_RAM_CHUNK; ++cc) {
+                const int i = i0 + cc;
+                if (i < d) {
+                    const float ui = Ush[i];
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        if (t + 64 * r >= i) v[r] = mhx_fma(col[cc][r], ui, v[r]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = t + 64 * r;
+            y[r] = v[r] + x[r];
+            if (row < d) ysh[row] = y[r];
+        }
+        __syncthreads();
+
+        // ---- lp' = logdensity(x')  (RAM.jl:140)
+        float lpy;
+        const int kind = (TK == MHX_TARGET_DYNAMIC) ? a.target_kind : TK;
+        if (kind == MHX_TARGET_CORR_GAUSS) {
+            // cooperative column sweep over A = inv(chol(Sigma)): w_j += A_ji y_i, i ascending
+            float wv[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) wv[r] = 0.0f;
+            for (int i0 = 0; i0 < d; i0 += MHX_RAM_CHUNK) {
+                float col[MHX_RAM_CHUNK][R];
+#pragma unroll
+                for (int cc = 0; cc < MHX_RAM_CHUNK; ++cc) {
+                    const int i = i0 + cc;
+                    const long off = mhx_ram_col_off(i, d) - i;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int row = t + 64 * r;
+                        col[cc][r] = (i < d && row >= i && row < d) ? a.acol[off + row] : 0.0f;
+                    }
+                }
+#pragma unroll
+                for (int cc = 0; cc < MHX_RAM_CHUNK; ++cc) {
+                    const int i = i0 + cc;
+                    if (i < d) {
+                        const float yi = ysh[i];
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+                            if (t + 64 * r >= i) wv[r] = mhx_fma(col[cc][r], yi, wv[r]);
+                    }
+                }
+            }
+            __syncthreads();                               // all lanes are done reading Ush (nn) -> reuse it
+#pragma unroll
+            for (int r = 0; r < R; ++r) if (t + 64 * r < d) Ush[t + 64 * r] = wv[r];
+            __syncthreads();
+            float q = 0.0f;
+            for (int j = 0; j < d; ++j) { const float w = Ush[j]; q = mhx_fma(w, w, q); }
+            lpy = mhx_fma(-0.5f, q, a.tconst);
+            __syncthreads();
+        } else {
+            mhx_lds_x yv;
+            yv.p = ysh;
+            lpy = mhx_target_eval<TK>(kind, yv, d, tparams, a.ntparams, a.tconst);
+        }
+
+        // ---- accept (RAM.jl:147-148): loga = min(lp' - lp, 0); accept iff randexp > -loga
+        const float diff = lpy - lp;
+        const float loga = (diff != diff) ? diff : (diff < 0.0f ? diff : 0.0f);
+        const float logu = mhx_accept_logu(ks, id_lo, id_hi, step, ac);
+        const bool acc = logu < loga;
+
+        // ---- adapt (RAM.jl:153-173, :259-264) during warm-up
+        if (it < a.n_adapt) {
+            const float da = mhx_exp(loga) - a.alpha;                    // :159
+            if (da == da) {
+                const float eta = a.eta[it];                             // :162 iteration^-gamma
+                const float coef = mhx_sqrt(eta * __builtin_fabsf(da)) / mhx_sqrt(nn);   // :163
+                float w[R], nd[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) { w[r] = v[r] * coef; nd[r] = 0.0f; }
+                const bool up = da > 0.0f;                               // :165 sign(da) == 1
+                bool ok = true;
+                for (int i0 = 0; i0 < d && ok; i0 += MHX_RAM_CHUNK) {
+                    float col[MHX_RAM_CHUNK][R];
+#pragma unroll
+                    for (int cc = 0; cc < MHX_RAM_CHUNK; ++cc) {
+                        const int i = i0 + cc;
+                        const long off = mhx_ram_col_off(i, d) - i;
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            const int row = t + 64 * r;
+                            col[cc][r] = (i < d && row >= i && row < d) ? Scur[off + row] : 0.0f;
+                        }
+                    }
+#pragma unroll
+                    for (int cc = 0; cc < MHX_RAM_CHUNK; ++cc) {
+                        const int i = i0 + cc;
+                        if (i < d && ok) {
+                            const int il = i & 63, ir = i >> 6;
+                            float aii = 0.0f, bi = 0.0f;
+#pragma unroll
+                            for (int r = 0; r < R; ++r)
+                                if (r == ir) {
+                                    aii = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, col[cc][r]), il));
+                                    bi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w[r]), il));
+                                }
+                            float cs, sn, diag;
+                            if (up) {
+                                const float rr = mhx_sqrt(mhx_fma(bi, bi, aii * aii));
+                                cs = aii / rr;
+                                sn = bi / rr;
+                                diag = rr;
+                            } else {
+                                sn = bi / aii;
+                                const float s2 = sn * sn;
+                                if (s2 > 1.0f) { ok = false; st |= 1u; }      // PosDefException upstream
+                                cs = mhx_sqrt(1.0f - s2);
+                                diag = cs * aii;
+                            }
+                            if (ok) {
+                                const long off = mhx_ram_col_off(i, d) - i;
+#pragma unroll
+                                for (int r = 0; r < R; ++r) {
+                                    const int row = t + 64 * r;
+                                    if (row < d && row >= i) {
+                                        float out;
+                                        if (row == i) {
+                                            out = diag;
+                                            nd[r] = diag;
+                                        } else if (up) {
+                                            const float Aji = col[cc][r], vj = w[r];
+                                            out = mhx_fma(cs, Aji, sn * vj);
+                                            w[r] = mhx_fma(cs, vj, -(sn * Aji));
+                                        } else {
+                                            const float vj = w[r];
+                                            out = (col[cc][r] - sn * vj) / cs;
+                                            w[r] = mhx_fma(cs, vj, -(sn * out));
+                                        }
+                                        Snew[off + row] = out;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+                // valid_eigenvalues (RAM.jl:239-245): every diagonal entry inside [lo, hi]
+                if (ok && !a.default_bounds) {
+                    bool bad = false;
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        if (t + 64 * r < d && !(a.eig_lo <= nd[r] && nd[r] <= a.eig_hi)) bad = true;
+                    if (__ballot(bad) != 0ull) ok = false;
+                }
+                if (ok) {
+                    sel ^= 1;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        dmn[r] = nd[r] < dmn[r] ? nd[r] : dmn[r];
+                        dmx[r] = nd[r] > dmx[r] ? nd[r] : dmx[r];
+                    }
+                }
+            } else {
+                st |= 2u;
+            }
+        }
+
+        // ---- state select (RAM.jl:267-277)
+#pragma unroll
+        for (int r = 0; r < R; ++r) x[r] = acc ? y[r] : x[r];
+        lp = acc ? lpy : lp;
+        nacc += acc ? 1u : 0u;
+        last = acc;
+        wave_acc += acc ? 1u : 0u;
+        if (step == save_next) {
+            float* rowp = a.samples + slot * (long)(d + 1) * ld + c;
+#pragma unroll
+            for (int r = 0; r < R; ++r) if (t + 64 * r < d) rowp[(long)(t + 64 * r) * ld] = x[r];
+            if (t == 0) {
+                rowp[(long)d * ld] = lp;
+                a.accepted[slot * ld + c] = acc ? 1 : 0;
+            }
+            save_next += (mhx_u32)a.thinning;
+            ++slot;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int row = t + 64 * r;
+        if (row < d) {
+            a.x[(long)row * ld + c] = x[r];
+            a.dmin[(long)c * d + row] = dmn[r];
+            a.dmax[(long)c * d + row] = dmx[r];
+        }
+    }
+    if (t == 0) {
+        a.lp[c] = lp;
+        a.acc_count[c] = nacc;
+        a.last_acc[c] = last ? 1 : 0;
+        a.sel[c] = (unsigned char)sel;
+        a.status[c] = (unsigned char)st;
+        atomicAdd(a.acc_total, (mhx_u64)wave_acc);
+    }
+}
+
+// initial state (RAM.jl:175-214): x0 = initial_params or randn(d); lp0; accepted = true (:213)
+template <int TK>
+MHX_DEV void mhx_ram_init_body(const mhx_ram_args& a, const float* __restrict__ tparams, const int draw)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.nchains) return;
+    const long ld = a.ld;
+    const int d = a.dim;
+    float* xs = a.x + c;
+    if (draw) {
+        const mhx_u64 id = a.first_chain + (mhx_u64)c;
+        const mhx_philox_key ks = mhx_philox_schedule(a.seed);
+        const int nblk = (d + 3) >> 2;
+        for (int b = 0; b < nblk; ++b) {
+            float n[4];
+            mhx_normal4(ks, (mhx_u32)id, (mhx_u32)(id >> 32), 0u, MHX_STREAM_INIT, (mhx_u32)b, n);
+            for (int j = 0; j < 4; ++j) if (4 * b + j < d) xs[(long)(4 * b + j) * ld] = n[j];
+        }
+    }
+    mhx_strided_x xv;
+    xv.base = xs;
+    xv.ld = ld;
+    a.lp[c] = mhx_target_eval<TK>(a.target_kind, xv, d, tparams, a.ntparams, a.tconst);
+    a.acc_count[c] = 0u;
+    a.last_acc[c] = 1;
+    a.status[c] = 0;
+}
+
+#ifdef MHX_JIT_RAM
+extern "C" __global__ void __launch_bounds__(64)
+mhx_jit_ram(const mhx_ram_args a, const float* __restrict__ tparams)
+{
+    extern __shared__ float mhx_ram_lds[];
+    mhx_ram_body<MHX_JIT_R, MHX_JIT_TK>(a, tparams, mhx_ram_lds);
+}
+extern "C" __global__ void __launch_bounds__(256)
+mhx_jit_ram_init(const mhx_ram_args a, const float* __restrict__ tparams, const int draw)
+{
+    mhx_ram_init_body<MHX_JIT_TK>(a, tparams, draw);
+}
+#endif
