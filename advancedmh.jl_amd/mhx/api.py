@@ -459,13 +459,24 @@ class Run:
         return dict(transitions=st.transitions, accepted=st.accepted, kernel_ms=st.kernel_ms, wall_ms=st.wall_ms,
                     kernel_variant=st.kernel_variant, launches=st.launches)
 
-    def diagnostics(self, max_lag=64):
+    def diagnostics(self, max_lag=0, ess_chains=256):
+        """Sums for R-hat / between-chain ESS (all chains) and, if max_lag > 0, the Geyer ESS from
+        chain-averaged autocovariances.  See include/mhx.h (mhx_run_diagnostics)."""
         d1 = self.dim + 1
         arrs = [np.zeros(d1, dtype=np.float64) for _ in range(4)]
-        cfg = L.DiagCfg(max_lag)
+        cfg = L.DiagCfg(max_lag, ess_chains)
         ptrs = [a.ctypes.data_as(C.POINTER(C.c_double)) for a in arrs]
+        if max_lag <= 0:
+            ptrs[3] = None
         L.check(L.lib().mhx_run_diagnostics(self.h, C.byref(cfg), *ptrs))
-        return dict(sum_m=arrs[0], sum_m2=arrs[1], sum_v=arrs[2], ess=arrs[3])
+        n_saved = C.c_int64()
+        L.check(L.lib().mhx_run_device_samples(self.h, None, None, C.byref(n_saved)))
+        out = dict(sum_m=arrs[0], sum_m2=arrs[1], sum_v=arrs[2], n_chains=self.n, n_samples=int(n_saved.value))
+        if max_lag > 0:
+            out["ess_geyer"] = np.abs(arrs[3])
+            out["ess_geyer_truncated"] = arrs[3] < 0
+        out.update(combine_diagnostics(out["sum_m"], out["sum_m2"], out["sum_v"], self.n, out["n_samples"]))
+        return out
 
     def close(self):
         if self.h:
@@ -477,6 +488,22 @@ class Run:
             self.close()
         except Exception:
             pass
+
+
+def combine_diagnostics(sum_m, sum_m2, sum_v, n_chains, n_samples):
+    """R-hat and between-chain ESS from the (all-reduced) per-parameter sums; see include/mhx.h."""
+    Cn, N = float(n_chains), float(n_samples)
+    mean = sum_m / Cn
+    W = sum_v / Cn
+    out = dict(mean=mean, W=W)
+    if n_chains > 1:
+        Vm = np.maximum((sum_m2 - sum_m * sum_m / Cn) / (Cn - 1.0), 0.0)
+        varp = (N - 1.0) / N * W + Vm
+        with np.errstate(divide="ignore", invalid="ignore"):
+            out["rhat"] = np.sqrt(varp / W)
+            out["ess_between"] = Cn * varp / Vm
+        out["var_plus"] = varp
+    return out
 
 
 def sample(model, sampler, N, nchains=1, *, initial_params=None, discard_initial=None, thinning=1, num_warmup=0,

@@ -175,17 +175,23 @@ int mhx_run_device_samples(mhx_run *run, void **samples, void **accepted, int64_
 int mhx_run_destroy(mhx_run *run);
 
 /* ---------------------------------------------------------------------------------------------
- * Diagnostics on the device sample buffer (what MCMCChains prints for the reference, README.md:59-63).
- * Per-parameter chain statistics, [dim+1] each: between/within-chain R-hat inputs and ESS.
- *   mean_of_means, var_of_means (B/n), mean_of_vars (W), ess (sum over chains of per-chain
- *   initial-positive-sequence ESS with max_lag cut-off).
- * The sums are returned un-normalised as well (sum_m, sum_m2, sum_v) so that shards on several
- * GPUs can be combined with ONE all-reduce. */
+ * Diagnostics on the device sample buffer of the last mhx_run_sample (what MCMCChains prints for the
+ * reference, README.md:59-63).  Per parameter p (dim parameters, then lp), each array [dim+1]:
+ *   sum_m  = sum_c m_c        sum_m2 = sum_c m_c^2        sum_v = sum_c s2_c
+ * with m_c / s2_c the mean / unbiased variance of chain c over the N draws.  They are returned
+ * un-normalised so that shards on several GPUs combine with ONE all-reduce of 3(dim+1)+1 doubles
+ * (DESIGN.md section 8); R-hat and the between-chain ESS follow on the host:
+ *   W = sum_v/C, Vm = (sum_m2 - sum_m^2/C)/(C-1), var+ = (N-1)/N W + Vm,
+ *   R-hat = sqrt(var+/W), ESS_between = C var+/Vm.
+ * ess[p] (optional) = C N / tau_p with tau_p from Geyer's initial monotone sequence on the
+ * autocovariances (lags 0..max_lag) averaged over the first `ess_chains` chains; it is returned
+ * NEGATED when the sequence was still positive at max_lag (|ess| is then an upper bound). */
 typedef struct {
-    int32_t max_lag;
+    int32_t max_lag;    /* 0: skip the autocovariance ESS (ess[] = NaN) */
+    int32_t ess_chains; /* chains used for the autocovariances, 0 = all */
 } mhx_diag_cfg;
 int mhx_run_diagnostics(mhx_run *run, const mhx_diag_cfg *cfg, double *sum_m, double *sum_m2,
-                        double *sum_v, double *ess /* each [dim+1] */);
+                        double *sum_v, double *ess /* each [dim+1], any may be NULL */);
 
 #ifdef __cplusplus
 }

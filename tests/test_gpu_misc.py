@@ -1,0 +1,174 @@
+"""GPU: catalogue targets, JIT-specialised vs generic kernels, C1 plumbing, large-d streaming path,
+shard invariance, diagnostics, error behaviour -- all through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import user_targets
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _same(a, b, what):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    assert a.shape == b.shape, what
+    bad = np.argwhere(a.view(np.uint32) != b.view(np.uint32)) if a.dtype == np.float32 else np.argwhere(a != b)
+    assert len(bad) == 0, "%s: %d mismatches, first at %s: %r vs %r" % (
+        what, len(bad), bad[0], a[tuple(bad[0])], b[tuple(bad[0])])
+
+
+def test_logdensity_batch_matches_oracle(mhx, oracle):
+    rng = np.random.default_rng(0)
+    d, n = 9, 300
+    x = rng.normal(size=(d, n)).astype(np.float32)
+    Sig = cases.sigma_ar1(d, 0.6)
+    specs = [
+        (mhx.IsoGaussian(d), oracle.iso_gauss(d)),
+        (mhx.CorrGaussian(Sig), oracle.corr_gauss_from_cov(Sig)),
+        (mhx.Banana(d, 0.03), oracle.Target(oracle.TARGET_BANANA, d, params=[0.03])),
+        (mhx.Funnel(d), oracle.Target(oracle.TARGET_FUNNEL, d)),
+        (mhx.HipLogDensity(user_targets.SHIFTED_GAUSS, d, data=np.r_[np.arange(d), 1 + np.arange(d)]),
+         user_targets.host_target(oracle, user_targets.SHIFTED_GAUSS, d, data=np.r_[np.arange(d), 1 + np.arange(d)])),
+    ]
+    for spec, ot in specs:
+        lp = mhx.logdensity(mhx.DensityModel(spec), x)
+        want = np.array([ot(x[:, i]) for i in range(n)], dtype=np.float32)
+        _same(lp, want, type(spec).__name__)
+    data = rng.normal(size=30).astype(np.float32)
+    th = np.stack([rng.normal(size=n), rng.normal(size=n) + 1.0]).astype(np.float32)   # some sigma < 0
+    lp = mhx.logdensity(mhx.DensityModel(mhx.IIDNormal(data)), th)
+    ot = oracle.Target(oracle.TARGET_IID_NORMAL, 2, params=data)
+    _same(lp, np.array([ot(th[:, i]) for i in range(n)], dtype=np.float32), "IIDNormal")
+    assert np.isneginf(lp[th[1] < 0]).all()
+
+
+@pytest.mark.parametrize("flags_name", ["auto", "nojit", "generic"])
+@pytest.mark.parametrize("name", ["rwmh_iso", "rwmh_dense_corr", "rwmh_funnel", "rwmh_banana"])
+def test_rwmh_golden_traces_all_kernel_variants(mhx, name, flags_name):
+    tr = np.load(os.path.join(GOLD, "traces.npz"))
+    flags = {"auto": 0, "nojit": mhx.FLAG_NO_JIT, "generic": mhx.FLAG_GENERIC}[flags_name]
+    if name == "rwmh_iso":
+        chain = mhx.sample(mhx.DensityModel(mhx.IsoGaussian(5)), mhx.RWMH(mhx.MvNormal(mhx.zeros(5), 0.25 * mhx.I)), 32, 8,
+                           seed=11, first_chain=3, flags=flags)
+    elif name == "rwmh_dense_corr":
+        d = 4
+        chain = mhx.sample(mhx.DensityModel(mhx.CorrGaussian(cases.sigma_ar1(d, 0.8))),
+                           mhx.RWMH(mhx.MvNormal(mhx.zeros(d), 0.3 * cases.sigma_ar1(d, 0.5))), 20, 6, seed=12,
+                           discard_initial=3, thinning=2, flags=flags)
+    elif name == "rwmh_funnel":
+        chain = mhx.sample(mhx.DensityModel(mhx.Funnel(6)), mhx.RWMH(mhx.MvNormal(mhx.zeros(6), 0.16 * mhx.I)), 24, 7,
+                           seed=13, first_chain=100, flags=flags)
+    else:
+        chain = mhx.sample(mhx.DensityModel(mhx.Banana(5, 0.03)),
+                           mhx.RWMH([mhx.Normal(0, 2.0), mhx.Normal(0, 0.5), mhx.Normal(0, 1), mhx.Normal(0, 1), mhx.Normal(0, 1)]),
+                           24, 7, seed=14, flags=flags)
+    _same(chain.value, tr[name + "/samples"], "samples")
+    _same(chain.accepted, tr[name + "/accepted"], "accepted")
+    want_variant = {"auto": 2, "nojit": 0, "generic": 0}[flags_name]
+    assert chain.stats["kernel_variant"] == want_variant
+
+
+def test_c1_readme_plumbing(mhx, oracle):
+    """BASELINE config 1 / README.md:25-40: Normal(mu, sigma) DensityModel, RWMH(MvNormal(zeros(2), I)),
+    100 000 steps, ONE chain -- GPU result identical to the CPU oracle and close to the data's moments."""
+    data = np.load(os.path.join(GOLD, "c1_normal_data.npy"))[:30]
+    model = mhx.DensityModel(mhx.IIDNormal(data))
+    chain = mhx.sample(model, mhx.RWMH(mhx.MvNormal(mhx.zeros(2), mhx.I)), 100000, 1, seed=1234,
+                       initial_params=np.array([0.0, 1.0]), param_names=["μ", "σ"])
+    t = oracle.Target(oracle.TARGET_IID_NORMAL, 2, params=data)
+    ref = oracle.rwmh(t, oracle.Proposal(oracle.PROP_ISO, 1.0), oracle.schedule(100000), 1234, 0, 1,
+                      init=np.array([[0.0], [1.0]], dtype=np.float32))
+    _same(chain.value, ref["samples"], "samples")
+    assert chain.names == ["μ", "σ", "lp"]
+    assert abs(chain.mean("μ") - data.mean()) < 0.1 and abs(chain.mean("σ") - data.std()) < 0.15
+    assert chain.stats["kernel_variant"] == 1                   # the pre-built (2, iid-normal, iso) register kernel
+    d = chain.state.diagnostics(max_lag=2000, ess_chains=1)
+    ess = d["ess_geyer"][:2]
+    assert (ess > 1000).all() and (ess < 30000).all()           # README.md:59-63 shows ESS ~ 3.9e3 of 1e5 draws
+
+
+def test_large_dim_streaming_kernel(mhx, oracle):
+    """BASELINE config 5 shape: 1000-dim funnel / banana, state streamed from HBM (generic kernel)."""
+    d, C, N = 1000, 96, 6
+    s = float(np.float32(2.38 / d ** 0.5))
+    for spec, ot in ((mhx.Funnel(d), oracle.Target(oracle.TARGET_FUNNEL, d)),
+                     (mhx.Banana(d, 0.03), oracle.Target(oracle.TARGET_BANANA, d, params=[0.03]))):
+        chain = mhx.sample(mhx.DensityModel(spec), mhx.RWMH(mhx.MvNormal(mhx.zeros(d), s * s * mhx.I)), N, C, seed=55,
+                           first_chain=1 << 33)
+        ref = oracle.rwmh(ot, oracle.Proposal(oracle.PROP_ISO, s), oracle.schedule(N), 55, 1 << 33, C)
+        _same(chain.value, ref["samples"], "samples")
+        assert chain.stats["kernel_variant"] == 0
+
+
+def test_shard_invariance_and_resume(mhx):
+    """chains carry global ids: two shards == one run; a run continued in pieces == one long run."""
+    d, C, N = 6, 200, 30
+    model = mhx.DensityModel(mhx.IsoGaussian(d))
+    spl = mhx.RWMH(mhx.MvNormal(mhx.zeros(d), 0.3 * mhx.I))
+    whole = mhx.sample(model, spl, N, C, seed=9)
+    a = mhx.sample(model, spl, N, 120, seed=9, first_chain=0)
+    b = mhx.sample(model, spl, N, 80, seed=9, first_chain=120)
+    _same(np.concatenate([a.value, b.value], axis=2), whole.value, "shards")
+    run = mhx.Run(model, spl, nchains=C, seed=9)
+    run.init(None)
+    run.sample(10, 0, 1, 0)
+    p1, _ = run.samples()
+    run.sample(20, 1, 1, 0)
+    p2, _ = run.samples()
+    _same(np.concatenate([p1, p2], axis=0), whole.value, "resume")
+    # setparams!! (src/AdvancedMH.jl:150-157): replace params, lp re-evaluated
+    x, lp, _ = run.state()
+    run.set_params(np.zeros_like(x))
+    x2, lp2, _ = run.state()
+    assert (x2 == 0).all() and np.allclose(lp2, -0.5 * d * np.log(2 * np.pi), atol=1e-5)
+
+
+def test_diagnostics_match_numpy(mhx):
+    d, C, N = 3, 300, 400
+    model = mhx.DensityModel(mhx.IsoGaussian(d))
+    chain = mhx.sample(model, mhx.RWMH(mhx.MvNormal(mhx.zeros(d), 1.0 * mhx.I)), N, C, seed=3, discard_initial=200)
+    dg = chain.state.diagnostics(max_lag=100, ess_chains=0)
+    v = chain.value.astype(np.float64)
+    m, s2 = v.mean(axis=0), v.var(axis=0, ddof=1)               # [d+1][C]
+    assert np.allclose(dg["sum_m"], m.sum(axis=1), rtol=1e-9, atol=1e-7)
+    assert np.allclose(dg["sum_m2"], (m * m).sum(axis=1), rtol=1e-9, atol=1e-7)
+    assert np.allclose(dg["sum_v"], s2.sum(axis=1), rtol=1e-9)
+    # Geyer ESS from chain-averaged autocovariances, recomputed in numpy
+    for p in range(d):
+        xc = v[:, p, :] - m[p]
+        ac = np.array([(xc[:N - k] * xc[k:]).sum() for k in range(100)])
+        rho = ac / ac[0]
+        tau, prev = -1.0, np.inf
+        for j in range(50):
+            pm = rho[2 * j] + rho[2 * j + 1]
+            if pm <= 0:
+                break
+            pm = min(pm, prev)
+            prev = pm
+            tau += 2 * pm
+        assert abs(dg["ess_geyer"][p] - C * N / tau) / (C * N / tau) < 1e-3
+    assert (np.abs(dg["rhat"][:d] - 1) < 0.05).all()
+    # between-chain ESS agrees with the autocovariance ESS for stationary replicas
+    assert (np.abs(dg["ess_between"][:d] / dg["ess_geyer"][:d] - 1) < 0.25).all()
+
+
+def test_error_behaviour(mhx):
+    with pytest.raises(mhx.ArgumentError):                      # dim mismatch
+        mhx.sample(mhx.DensityModel(mhx.IsoGaussian(3)), mhx.RWMH(4), 5)
+    with pytest.raises(mhx.ArgumentError):                      # non-zero-mean RW proposal (Hastings ratio != 0)
+        mhx.RWMH(mhx.MvNormal(np.ones(3), mhx.I))
+    with pytest.raises(mhx.ArgumentError):                      # a Python closure cannot be lowered
+        mhx.DensityModel(lambda x: -0.5 * (x ** 2).sum())
+    with pytest.raises(mhx.MhxError) as ei:                     # bad user source -> compile error at model construction
+        mhx.logdensity(mhx.DensityModel(mhx.HipLogDensity("MHX_LOGDENSITY(x, d, data, n) { return undefined_symbol; }", 2)),
+                       np.zeros(2))
+    assert ei.value.code == -4 and "undefined_symbol" in str(ei.value)
+    with pytest.raises(mhx.PosDefException):
+        mhx.MvNormal(mhx.zeros(2), np.array([[1.0, 2.0], [2.0, 1.0]]))
+    with pytest.raises(mhx.ArgumentError):                      # ensemble of one walker
+        mhx.sample(mhx.DensityModel(mhx.IsoGaussian(2)), mhx.Ensemble(1, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(2), mhx.I))), 3)
+    with pytest.raises(mhx.ArgumentError):                      # bad schedule
+        mhx.sample(mhx.DensityModel(mhx.IsoGaussian(2)), mhx.RWMH(2), 5, thinning=0)
