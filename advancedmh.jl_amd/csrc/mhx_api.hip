@@ -68,9 +68,9 @@ k_rwmh_init(const mhx_rwmh_args a, const float* __restrict__ tparams, const floa
 }
 __global__ void __launch_bounds__(256)
 k_target_eval(const float* __restrict__ x, float* __restrict__ lp, const int n, const int d, const int kind,
-              const float* __restrict__ tparams, const int ntparams, const float tconst)
+              const float* __restrict__ tparams, const int ntparams, const float tconst, const int lanes)
 {
-    mhx_target_eval_body<MHX_TARGET_DYNAMIC>(x, lp, n, d, kind, tparams, ntparams, tconst);
+    mhx_target_eval_body<MHX_TARGET_DYNAMIC>(x, lp, n, d, kind, tparams, ntparams, tconst, lanes);
 }
 __global__ void __launch_bounds__(256)
 k_record_state(const float* __restrict__ x, const float* __restrict__ lp, const unsigned char* __restrict__ last_acc,
@@ -78,6 +78,22 @@ k_record_state(const float* __restrict__ x, const float* __restrict__ lp, const 
 {
     mhx_record_state_body(x, lp, last_acc, samples, accepted, n, ld, d, slot);
 }
+
+// occupancy target of the cooperative kernel: its point is >= 2 waves per SIMD
+#define MHX_COOP_WAVES(NBL) ((NBL) <= 5 ? 4 : ((NBL) <= 13 ? 2 : 1))
+template <int L, int NBL, int TK, int PK>
+__global__ void __launch_bounds__(256, MHX_COOP_WAVES(NBL))
+k_rwmh_coop(const mhx_rwmh_args a, const float* __restrict__ tparams, const float* __restrict__ pvec)
+{
+    mhx_rwmh_coop_body<L, NBL, TK, PK>(a, tparams, pvec);
+}
+
+struct prebuilt_coop { int L, NBL, TK, PK; void (*fn)(const mhx_rwmh_args, const float*, const float*); };
+static const prebuilt_coop k_prebuilt_coop[] = {
+    {2, 13, MHX_TARGET_ISO_GAUSS, MHX_PROP_ISO, k_rwmh_coop<2, 13, MHX_TARGET_ISO_GAUSS, MHX_PROP_ISO>},
+    {64, 4, MHX_TARGET_FUNNEL, MHX_PROP_ISO, k_rwmh_coop<64, 4, MHX_TARGET_FUNNEL, MHX_PROP_ISO>},
+    {64, 4, MHX_TARGET_BANANA, MHX_PROP_ISO, k_rwmh_coop<64, 4, MHX_TARGET_BANANA, MHX_PROP_ISO>},
+};
 
 struct prebuilt_reg { int D, TK, PK; void (*fn)(const mhx_rwmh_args, const float*, const float*); };
 static const prebuilt_reg k_prebuilt_reg[] = {
@@ -345,7 +361,7 @@ extern "C" int mhx_target_eval(mhx_ctx* ctx, const mhx_target* t, const float* x
     do {
         if (hipMemcpy(dx, x, nx * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { rc = fail(MHX_EHIP, "H2D copy failed"); break; }
         const unsigned grid = (unsigned)((n + 255) / 256);
-        int d = t->dim, kind = t->kind, np = t->nparams;
+        int d = t->dim, kind = t->kind, np = t->nparams, lanes = 1;
         float cst = t->cst;
         const float* tp = t->dparams;
         if (t->kind == MHX_TARGET_USER) {
@@ -353,10 +369,10 @@ extern "C" int mhx_target_eval(mhx_ctx* ctx, const mhx_target* t, const float* x
             hipFunction_t fn;
             if ((rc = jit_generic_rwmh(t, &m))) break;
             if ((rc = jit_function(m, "mhx_jit_target_eval", &fn))) break;
-            void* params[] = {&dx, &dlp, &n, &d, &kind, &tp, &np, &cst};
+            void* params[] = {&dx, &dlp, &n, &d, &kind, &tp, &np, &cst, &lanes};
             if ((rc = launch_module(fn, grid, 256, ctx->stream, params))) break;
         } else {
-            hipLaunchKernelGGL(k_target_eval, dim3(grid), dim3(256), 0, ctx->stream, dx, dlp, n, d, kind, tp, np, cst);
+            hipLaunchKernelGGL(k_target_eval, dim3(grid), dim3(256), 0, ctx->stream, dx, dlp, n, d, kind, tp, np, cst, lanes);
         }
         if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) { rc = fail(MHX_EHIP, "target_eval kernel failed"); break; }
         if (hipMemcpy(lp, dlp, (size_t)n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(MHX_EHIP, "D2H copy failed"); break; }
@@ -404,6 +420,7 @@ struct mhx_run {
     size_t samples_cap = 0, accepted_cap = 0;
     int64_t n_saved = 0;
     // kernel choice
+    int coop_L = 1;                      // lanes per chain (reduction shape of the separable targets)
     int variant = 0;
     void (*reg_fn)(const mhx_rwmh_args, const float*, const float*) = nullptr;
     hipFunction_t jit_step = nullptr, jit_init = nullptr;
@@ -442,6 +459,7 @@ static mhx_rwmh_args rwmh_args(const mhx_run* r)
     a.target_kind = r->target->kind; a.ntparams = r->target->nparams; a.tconst = r->target->cst;
     a.prop_kind = r->prop_kind; a.pscale = r->prop_scale;
     a.save_next = MHX_NO_SAVE; a.thinning = 1;
+    a.reduce_lanes = r->coop_L;
     return a;
 }
 
@@ -476,11 +494,48 @@ extern "C" int mhx_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh
     int rc = run_alloc_state(r.get());
     if (rc) return rc;
 
+    // the register / cooperative kernels address a [dim+1][nchains] slab with 32-bit byte offsets
+    if (((uint64_t)d + 1) * (uint64_t)r->n * 4ull >= (1ull << 32)) r->flags |= MHX_FLAG_GENERIC;
     // ---- kernel choice
     r->variant = 0;
     const int tk = t->kind, pk = r->prop_kind;
     const int regmax = pk == MHX_PROP_DENSE ? MHX_REG_MAX_DIM_DENSE : MHX_REG_MAX_DIM;
-    if (!(r->flags & MHX_FLAG_GENERIC)) {
+    const int nblk = (d + 3) / 4;
+    const bool separable = tk == MHX_TARGET_ISO_GAUSS || tk == MHX_TARGET_BANANA || tk == MHX_TARGET_FUNNEL;
+    // lanes per chain: cfg->reduce_lanes, or (auto) the smallest power of two that (a) keeps a lane's
+    // blocks in registers (<= 13 blocks = 104 VGPRs of state) and (b) gives the chip >= 2 waves per SIMD
+    int L = 1;
+    if (separable && pk != MHX_PROP_DENSE && !(r->flags & MHX_FLAG_GENERIC)) {
+        if (cfg->reduce_lanes > 0) {
+            L = cfg->reduce_lanes;
+            if (L > 64 || (L & (L - 1))) return fail(MHX_EINVAL, "reduce_lanes must be a power of two <= 64, got %d", L);
+        } else {
+            while (L < 64 && (nblk + L - 1) / L > 13) L *= 2;
+            while (L < 64 && 2 * L <= nblk && (long)r->n * L / 64 < 2048) L *= 2;
+        }
+    } else if (cfg->reduce_lanes > 1) {
+        return fail(MHX_EINVAL, "reduce_lanes > 1 needs a separable catalogue target and an ISO/DIAG proposal");
+    }
+    if (L > 1) {
+        const int NBL = (nblk + L - 1) / L;
+        if (NBL > 16) return fail(MHX_EINVAL, "reduce_lanes=%d leaves %d blocks per lane (max 16)", L, NBL);
+        for (const auto& pb : k_prebuilt_coop)
+            if (pb.L == L && pb.NBL == NBL && pb.TK == tk && pb.PK == pk) { r->reg_fn = pb.fn; r->variant = 3; }
+        if (!r->variant && !(r->flags & MHX_FLAG_NO_JIT)) {
+            jit_module* m = nullptr;
+            const std::string key = "rwmh_coop/l=" + std::to_string(L) + "/nbl=" + std::to_string(NBL) + "/tk=" +
+                                    std::to_string(tk) + "/pk=" + std::to_string(pk);
+            rc = jit_compile(ctx, key, jit_source(t, "mhx_rwmh_kernels.h"),
+                             {"MHX_JIT_RWMH_COOP=1", "MHX_JIT_L=" + std::to_string(L), "MHX_JIT_NBL=" + std::to_string(NBL),
+                              "MHX_JIT_TK=" + std::to_string(tk), "MHX_JIT_PK=" + std::to_string(pk)}, &m);
+            if (rc == MHX_OK) rc = jit_function(m, "mhx_jit_rwmh_coop", &r->jit_step);
+            if (rc == MHX_OK) r->variant = 4;
+            else if (cfg->reduce_lanes > 1) return rc;      // the caller asked for this shape explicitly
+        }
+        if (r->variant) r->coop_L = L;
+        else if (cfg->reduce_lanes > 1) return fail(MHX_EINVAL, "reduce_lanes=%d: no pre-built kernel and JIT disabled", L);
+    }
+    if (!r->variant && !(r->flags & MHX_FLAG_GENERIC)) {
         if (tk != MHX_TARGET_USER)
             for (const auto& pb : k_prebuilt_reg)
                 if (pb.D == d && pb.TK == tk && pb.PK == pk) { r->reg_fn = pb.fn; r->variant = 1; }
@@ -553,7 +608,17 @@ static int rwmh_advance(mhx_run* r, uint64_t nsteps, uint32_t save_next, int sav
         a.save_next = save_next;
         a.save_slot = save_slot;
         a.thinning = thinning;
-        if (r->variant == 1) {
+        if (r->variant == 3 || r->variant == 4) {
+            const long threads = (((long)r->n + (64 / r->coop_L) - 1) / (64 / r->coop_L)) * 64;   // whole waves
+            const unsigned grid = (unsigned)((threads + 255) / 256);
+            if (r->variant == 3) {
+                hipLaunchKernelGGL(r->reg_fn, dim3(grid), dim3(256), 0, ctx->stream, a, tp, pv);
+            } else {
+                void* params[] = {&a, &tp, &pv};
+                int rc = launch_module(r->jit_step, grid, 256, ctx->stream, params);
+                if (rc) return rc;
+            }
+        } else if (r->variant == 1) {
             const unsigned grid = (unsigned)((r->n + 63) / 64);
             hipLaunchKernelGGL(r->reg_fn, dim3(grid), dim3(64), 0, ctx->stream, a, tp, pv);
         } else if (r->variant == 2) {
@@ -640,6 +705,7 @@ extern "C" int mhx_run_sample(mhx_run* r, const mhx_schedule* s, int save_sample
     const auto t0 = std::chrono::steady_clock::now();
     r->stats = mhx_stats{};
     r->stats.kernel_variant = r->variant;
+    r->stats.reduce_lanes = r->coop_L;
     unsigned long long acc_before = 0;
     HIP_TRY(hipMemcpy(&acc_before, r->d_acc_total, sizeof acc_before, hipMemcpyDeviceToHost));
 
@@ -731,7 +797,7 @@ extern "C" int mhx_run_set_state(mhx_run* r, const float* x)
     HIP_TRY(hipMemcpy(r->d_x, x, d * n * sizeof(float), hipMemcpyHostToDevice));
     // lp is a cache of logdensity(model, x) (src/AdvancedMH.jl:75): recompute it
     const unsigned grid = (unsigned)((r->n + 255) / 256);
-    int nn = r->n, dd = r->dim, kind = r->target->kind, np = r->target->nparams;
+    int nn = r->n, dd = r->dim, kind = r->target->kind, np = r->target->nparams, lanes = r->coop_L;
     float cst = r->target->cst;
     const float* tp = r->target->dparams;
     const float* dx = r->d_x;
@@ -742,10 +808,10 @@ extern "C" int mhx_run_set_state(mhx_run* r, const float* x)
         int rc = jit_generic_rwmh(r->target, &m);
         if (rc) return rc;
         if ((rc = jit_function(m, "mhx_jit_target_eval", &fn))) return rc;
-        void* params[] = {&dx, &dlp, &nn, &dd, &kind, &tp, &np, &cst};
+        void* params[] = {&dx, &dlp, &nn, &dd, &kind, &tp, &np, &cst, &lanes};
         if ((rc = launch_module(fn, grid, 256, ctx->stream, params))) return rc;
     } else {
-        hipLaunchKernelGGL(k_target_eval, dim3(grid), dim3(256), 0, ctx->stream, dx, dlp, nn, dd, kind, tp, np, cst);
+        hipLaunchKernelGGL(k_target_eval, dim3(grid), dim3(256), 0, ctx->stream, dx, dlp, nn, dd, kind, tp, np, cst, lanes);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -19,12 +19,34 @@
 
 typedef unsigned int mhx_u32;
 typedef unsigned long long mhx_u64;
+__device__ __forceinline__ mhx_u32 mhx_f2u_fwd(float f) { return __builtin_bit_cast(mhx_u32, f); }
 
 // signature of a user log-density in HIP source form (see include/mhx.h, mhx_target_from_hip_source)
 #define MHX_LOGDENSITY(x, d, data, ndata)                                                          \
     template <class MHX_X>                                                                          \
     MHX_DEV float mhx_user_logdensity(const MHX_X& x, const int d, const float* __restrict__ data, \
                                       const int ndata)
+
+// wave-uniform base pointer + 32-bit per-lane BYTE offset: lowers to the scalar-base addressing mode
+// (global_load/store v_off, ..., s[base:base+1]) instead of a 64-bit vector address per access
+MHX_DEV float mhx_ld_off(const float* base, mhx_u32 byte_off)
+{
+    return *(const float*)((const char*)base + byte_off);
+}
+MHX_DEV void mhx_st_off(float* base, mhx_u32 byte_off, float v) { *(float*)((char*)base + byte_off) = v; }
+
+// A [rows][ld] fp32 slab addressed through a buffer descriptor: wave-uniform base in the SRD, the row
+// offset in an SGPR (soffset), the lane's column offset in one VGPR (voffset) -- no per-access 64-bit
+// vector address arithmetic.  `bytes` bounds the slab (hardware range check).
+typedef __amdgpu_buffer_rsrc_t mhx_srd;
+MHX_DEV mhx_srd mhx_make_srd(const void* base, mhx_u32 bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)bytes, 0x00020000);
+}
+MHX_DEV void mhx_srd_store(mhx_srd srd, mhx_u32 lane_byte_off, mhx_u32 row_byte_off, float v)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(mhx_f2u_fwd(v), srd, (int)lane_byte_off, (int)row_byte_off, 0);
+}
 
 // RNG stream tags: counter word 3 = tag << 28 | block
 #define MHX_STREAM_PROPOSAL 0u

@@ -48,6 +48,7 @@ struct mhx_rwmh_args {
     mhx_u32 save_next;        // first transition >= step0 whose state is recorded (MHX_NO_SAVE: none)
     int save_slot;            // its slot in `samples`
     int thinning;
+    int reduce_lanes;         // reduction shape of the separable targets (lanes per chain), >= 1
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -63,8 +64,9 @@ MHX_DEV void mhx_rwmh_reg_body(const mhx_rwmh_args& a, const float* __restrict__
     const long ld = a.ld;
 
     float x[D], y[D];
+    const mhx_u32 cu = (mhx_u32)c * 4u;  // row pointers are wave-uniform (scalar), the lane adds c * 4 bytes
 #pragma unroll
-    for (int k = 0; k < D; ++k) x[k] = a.x[(long)k * ld + c];
+    for (int k = 0; k < D; ++k) x[k] = mhx_ld_off(a.x + (long)k * ld, cu);
     float lp = a.lp[c];
     mhx_u32 nacc = a.acc_count[c];
     mhx_u32 wave_acc = 0;
@@ -120,17 +122,19 @@ MHX_DEV void mhx_rwmh_reg_body(const mhx_rwmh_args& a, const float* __restrict__
         wave_acc += (mhx_u32)__popcll(__ballot(acc));
         // ---- record (ext/AdvancedMHMCMCChainsExt.jl:96-105 layout, chain fastest)
         if (step == save_next) {
-            float* row = a.samples + slot * (long)(D + 1) * ld + c;
+            float* slotp = a.samples + slot * (long)(D + 1) * ld;
+            const mhx_srd srd = mhx_make_srd(slotp, (mhx_u32)(D + 1) * (mhx_u32)ld * 4u);
+            const mhx_u32 ldb = (mhx_u32)ld * 4u;
 #pragma unroll
-            for (int k = 0; k < D; ++k) row[(long)k * ld] = x[k];
-            row[(long)D * ld] = lp;
+            for (int k = 0; k < D; ++k) mhx_srd_store(srd, cu, (mhx_u32)k * ldb, x[k]);
+            mhx_srd_store(srd, cu, (mhx_u32)D * ldb, lp);
             a.accepted[slot * ld + c] = acc ? 1 : 0;
             save_next += (mhx_u32)a.thinning;
             ++slot;
         }
     }
 #pragma unroll
-    for (int k = 0; k < D; ++k) a.x[(long)k * ld + c] = x[k];
+    for (int k = 0; k < D; ++k) mhx_st_off(a.x + (long)k * ld, cu, x[k]);
     a.lp[c] = lp;
     a.acc_count[c] = nacc;
     a.last_acc[c] = last ? 1 : 0;
@@ -225,6 +229,164 @@ MHX_DEV void mhx_rwmh_generic_body(const mhx_rwmh_args& a, const float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------
+// Cooperative kernel: L lanes share one chain (L = 2 .. 64, a power of two; 64/L chains per wave).
+// Lane l owns the Philox blocks b = l, l+L, ... (4 dimensions each), i.e. NBL blocks of state
+// x[NBL][4] and candidate y[NBL][4] in VGPRs.  Used for the separable catalogue targets
+// (iso-Gaussian, banana, funnel), whose log-density is a sum over dimensions: every lane reduces its
+// own blocks sequentially, the L partial sums meet in an xor-butterfly (offsets 1, 2, 4, ... in
+// units of 64/L lanes) and every lane of the chain ends up with the same lp and takes the same
+// accept decision.  Two regimes:
+//   - few chains, moderate d (65 536 x 100): L = 2 doubles the wave count to 2 per SIMD, which is
+//     what a CDNA4 SIMD needs to reach its VALU issue rate (one wave alone issues every ~5 cycles);
+//   - large d (1000): L = 64 is wave-per-chain, the whole state (4 VGPRs per 256 dimensions) stays
+//     in registers across a launch and nothing is streamed from HBM but the recorded samples.
+// The reduction shape L is part of the arithmetic spec (the oracle takes the same L).
+template <int L, int NBL, int TK, int PK>
+MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const float* __restrict__ tparams,
+                                const float* __restrict__ pvec)
+{
+    constexpr int CPW = 64 / L;                    // chains per wave
+    const int lane = threadIdx.x & 63;
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int cw = lane & (CPW - 1);
+    const int l = lane / CPW;
+    const long c_raw = wave * CPW + cw;
+    const bool valid = c_raw < a.nchains;
+    const long c = valid ? c_raw : (long)a.nchains - 1;      // idle lanes shadow the last chain (loads only)
+    const mhx_u64 id = a.first_chain + (mhx_u64)c;
+    const mhx_u32 id_lo = (mhx_u32)id, id_hi = (mhx_u32)(id >> 32);
+    const mhx_philox_key ks = mhx_philox_schedule(a.seed);
+    const long ld = a.ld;
+    const int d = a.dim;
+    // Element (i, j) of this lane is dimension k = 4 (l + L i) + j.  Its address in a [dim][ld] array is
+    //   base + ((4 L i + j) ld) * 4  [wave-uniform, scalar]  +  (4 l ld + c) * 4  [one VGPR for all (i, j)]
+    // (the host guarantees (dim + 1) * ld * 4 < 2^32).  Only a lane's LAST block (i == NBL-1) can lie
+    // past the end of the vector; every earlier block is complete for every lane.
+    const mhx_u32 lane_off = ((mhx_u32)(4 * l) * (mhx_u32)ld + (mhx_u32)c) * 4u;     // bytes
+    const int k_last = 4 * (l + L * (NBL - 1));               // first dimension of the last block
+
+    float x[NBL][4], y[NBL][4];
+#pragma unroll
+    for (int i = 0; i < NBL; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float* col = a.x + (long)(4 * L * i + j) * ld;
+            if (i < NBL - 1) x[i][j] = mhx_ld_off(col, lane_off);
+            else x[i][j] = (k_last + j < d) ? mhx_ld_off(col, lane_off) : 0.0f;
+            y[i][j] = 0.0f;
+        }
+    float lp = a.lp[c];
+    mhx_u32 nacc = a.acc_count[c];
+    mhx_u32 wave_acc = 0;
+    bool last = a.last_acc[c] != 0;
+    mhx_accept_cache ac;
+    ac.group = 0xffffffffu;
+    ac.w.x = ac.w.y = ac.w.z = ac.w.w = 0u;
+    mhx_u32 save_next = a.save_next;
+    long slot = a.save_slot;
+
+    for (int it = 0; it < a.nsteps; ++it) {
+        const mhx_u32 step = a.step0 + (mhx_u32)it;
+        // Branch-free over the lane's blocks: a last block past the end of the vector (and the padding
+        // dimensions of the final block) computes on zeros -- y = 0 there, and fma(0, 0, q) == q bit for
+        // bit, so the partial sums need no predication.
+        float q = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NBL; ++i) {
+            const int b = l + L * i;
+            float n[4];
+            mhx_normal4(ks, id_lo, id_hi, step, MHX_STREAM_PROPOSAL, (mhx_u32)b, n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float sc = a.pscale;
+                if (PK != MHX_PROP_ISO) {
+                    const int k = 4 * b + j;
+                    sc = pvec[(i < NBL - 1 || k < d) ? k : 0];
+                }
+                float yk = mhx_fma(sc, n[j], x[i][j]);
+                if (i == NBL - 1) yk = (k_last + j < d) ? yk : 0.0f;
+                y[i][j] = yk;
+                const float sq = mhx_fma(yk, yk, q);
+                if (TK == MHX_TARGET_BANANA && i == 0 && j == 0) {
+                    q = l == 0 ? (yk * yk) * 0.01f : sq;           // x1 ~ N(0, 100)
+                } else if (TK == MHX_TARGET_BANANA && i == 0 && j == 1) {
+                    const float y0 = y[0][0];
+                    const float u = mhx_fma(tparams[0], mhx_fma(y0, y0, -100.0f), yk);
+                    q = l == 0 ? mhx_fma(u, u, q) : sq;
+                } else if (TK == MHX_TARGET_FUNNEL && i == 0 && j == 0) {
+                    q = l == 0 ? q : sq;                           // x1 is the funnel's scale, not a summand
+                } else {
+                    q = sq;
+                }
+            }
+            // keep the blocks in program order: with >= 2 waves per SIMD the other wave provides the
+            // latency hiding, and interleaving blocks only inflates the live register set
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int off = 1; off < L; off <<= 1) q = q + __shfl_xor(q, off * CPW, 64);
+        float lpy;
+        if (TK == MHX_TARGET_FUNNEL) {
+            const float v = __shfl(y[0][0], cw, 64);           // x1 lives in lane l == 0 of the chain
+            const float ev = mhx_exp(-v);
+            float r = (v * v) * 0x1.c71c72p-5f;
+            r = mhx_fma(0.5f * (float)(d - 1), v, r);
+            r = mhx_fma(0.5f * ev, q, r);
+            lpy = a.tconst - r;
+        } else {
+            lpy = mhx_fma(-0.5f, q, a.tconst);
+        }
+        const float logu = mhx_accept_logu(ks, id_lo, id_hi, step, ac);
+        const bool acc = logu < (lpy - lp);
+#pragma unroll
+        for (int i = 0; i < NBL; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[i][j] = acc ? y[i][j] : x[i][j];
+        lp = acc ? lpy : lp;
+        nacc += acc ? 1u : 0u;
+        last = acc;
+        wave_acc += (mhx_u32)__popcll(__ballot(acc && valid && l == 0));
+        if (step == save_next) {
+            if (valid) {
+                float* slotp = a.samples + slot * (long)(d + 1) * ld;
+                const mhx_srd srd = mhx_make_srd(slotp, (mhx_u32)(d + 1) * (mhx_u32)ld * 4u);
+                const mhx_u32 ldb = (mhx_u32)ld * 4u;
+#pragma unroll
+                for (int i = 0; i < NBL; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const mhx_u32 rowb = (mhx_u32)(4 * L * i + j) * ldb;     // wave-uniform -> soffset
+                        if (i < NBL - 1) mhx_srd_store(srd, lane_off, rowb, x[i][j]);
+                        else if (k_last + j < d) mhx_srd_store(srd, lane_off, rowb, x[i][j]);
+                    }
+                if (l == 0) {
+                    slotp[(long)d * ld + c] = lp;
+                    a.accepted[slot * ld + c] = acc ? 1 : 0;
+                }
+            }
+            save_next += (mhx_u32)a.thinning;
+            ++slot;
+        }
+    }
+    if (valid) {
+#pragma unroll
+        for (int i = 0; i < NBL; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float* col = a.x + (long)(4 * L * i + j) * ld;
+                if (i < NBL - 1) mhx_st_off(col, lane_off, x[i][j]);
+                else if (k_last + j < d) mhx_st_off(col, lane_off, x[i][j]);
+            }
+        if (l == 0) {
+            a.lp[c] = lp;
+            a.acc_count[c] = nacc;
+            a.last_acc[c] = last ? 1 : 0;
+        }
+    }
+    if (lane == 0) atomicAdd(a.acc_total, (mhx_u64)wave_acc);
+}
+
+// ---------------------------------------------------------------------------------------------
 // initial state (src/mh-core.jl:83-84): x0 = initial_params, or a bare proposal draw
 // (src/proposal.jl:41-47) from Philox stream INIT; lp0 = logdensity(model, x0).
 template <int TK>
@@ -264,7 +426,7 @@ MHX_DEV void mhx_rwmh_init_body(const mhx_rwmh_args& a, const float* __restrict_
     mhx_strided_x xv;
     xv.base = xs;
     xv.ld = ld;
-    a.lp[c] = mhx_target_eval<TK>(a.target_kind, xv, d, tparams, a.ntparams, a.tconst);
+    a.lp[c] = mhx_target_eval_lanes<TK>(a.target_kind, xv, d, tparams, a.ntparams, a.tconst, a.reduce_lanes);
     a.acc_count[c] = 0u;
     a.last_acc[c] = 0;          // Transition(params, lp, false), src/mh-core.jl:84
 }
@@ -274,14 +436,14 @@ MHX_DEV void mhx_rwmh_init_body(const mhx_rwmh_args& a, const float* __restrict_
 template <int TK>
 MHX_DEV void mhx_target_eval_body(const float* __restrict__ x, float* __restrict__ lp, const int n,
                                   const int d, const int kind, const float* __restrict__ tparams,
-                                  const int ntparams, const float tconst)
+                                  const int ntparams, const float tconst, const int lanes)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
     mhx_strided_x xv;
     xv.base = x + c;
     xv.ld = n;
-    lp[c] = mhx_target_eval<TK>(kind, xv, d, tparams, ntparams, tconst);
+    lp[c] = mhx_target_eval_lanes<TK>(kind, xv, d, tparams, ntparams, tconst, lanes);
 }
 
 // record the current state into sample slot `slot` (sample 1 of a run with discard_initial == 0)
@@ -306,6 +468,13 @@ mhx_jit_rwmh_reg(const mhx_rwmh_args a, const float* __restrict__ tparams, const
     mhx_rwmh_reg_body<MHX_JIT_DIM, MHX_JIT_TK, MHX_JIT_PK>(a, tparams, pvec);
 }
 #endif
+#ifdef MHX_JIT_RWMH_COOP
+extern "C" __global__ void __launch_bounds__(256, (MHX_JIT_NBL) <= 5 ? 4 : ((MHX_JIT_NBL) <= 13 ? 2 : 1))
+mhx_jit_rwmh_coop(const mhx_rwmh_args a, const float* __restrict__ tparams, const float* __restrict__ pvec)
+{
+    mhx_rwmh_coop_body<MHX_JIT_L, MHX_JIT_NBL, MHX_JIT_TK, MHX_JIT_PK>(a, tparams, pvec);
+}
+#endif
 #ifdef MHX_JIT_RWMH_GENERIC
 extern "C" __global__ void __launch_bounds__(256)
 mhx_jit_rwmh_generic(const mhx_rwmh_args a, const float* __restrict__ tparams, const float* __restrict__ pvec)
@@ -320,8 +489,9 @@ mhx_jit_rwmh_init(const mhx_rwmh_args a, const float* __restrict__ tparams, cons
 }
 extern "C" __global__ void __launch_bounds__(256)
 mhx_jit_target_eval(const float* __restrict__ x, float* __restrict__ lp, const int n, const int d,
-                    const int kind, const float* __restrict__ tparams, const int ntparams, const float tconst)
+                    const int kind, const float* __restrict__ tparams, const int ntparams, const float tconst,
+                    const int lanes)
 {
-    mhx_target_eval_body<MHX_JIT_TK>(x, lp, n, d, kind, tparams, ntparams, tconst);
+    mhx_target_eval_body<MHX_JIT_TK>(x, lp, n, d, kind, tparams, ntparams, tconst, lanes);
 }
 #endif

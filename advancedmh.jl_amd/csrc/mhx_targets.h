@@ -99,3 +99,48 @@ MHX_DEV float mhx_target_eval(int kind, const X& x, const int d, const float* __
         return MHX_NAN;
     }
 }
+
+// The separable targets evaluated with the L-lane reduction shape of the cooperative kernels, by ONE
+// lane (initial state, setparams): lane l of the shape owns the Philox blocks b = l, l+L, ...; the L
+// partial sums meet in an xor-butterfly with offsets 1, 2, 4, ...  Same arithmetic as
+// mhx_rwmh_coop_body, serialised.
+template <int KIND, class X>
+MHX_DEV float mhx_target_eval_lanes(int kind, const X& x, const int d, const float* __restrict__ p,
+                                    const int np, const float cst, const int L)
+{
+    const int k_ = (KIND == MHX_TARGET_DYNAMIC) ? kind : KIND;
+    const bool separable = k_ == MHX_TARGET_ISO_GAUSS || k_ == MHX_TARGET_BANANA || k_ == MHX_TARGET_FUNNEL;
+    if (L <= 1 || !separable) return mhx_target_eval<KIND>(kind, x, d, p, np, cst);
+    const int nblk = (d + 3) >> 2;
+    float part[64];
+    for (int l = 0; l < L; ++l) {
+        float q = 0.0f;
+        for (int b = l; b < nblk; b += L)
+            for (int j = 0; j < 4; ++j) {
+                const int k = 4 * b + j;
+                if (k >= d) break;
+                const float v = x[k];
+                if (k_ == MHX_TARGET_BANANA && k == 0) q = (v * v) * 0.01f;
+                else if (k_ == MHX_TARGET_BANANA && k == 1) {
+                    const float x0 = x[0];
+                    const float u = mhx_fma(p[0], mhx_fma(x0, x0, -100.0f), v);
+                    q = mhx_fma(u, u, q);
+                } else if (k_ == MHX_TARGET_FUNNEL && k == 0) {
+                } else q = mhx_fma(v, v, q);
+            }
+        part[l] = q;
+    }
+    for (int off = 1; off < L; off <<= 1) {
+        float nxt[64];
+        for (int l = 0; l < L; ++l) nxt[l] = part[l] + part[l ^ off];
+        for (int l = 0; l < L; ++l) part[l] = nxt[l];
+    }
+    const float q = part[0];
+    if (k_ != MHX_TARGET_FUNNEL) return mhx_fma(-0.5f, q, cst);
+    const float v = x[0];
+    const float ev = mhx_exp(-v);
+    float r = (v * v) * 0x1.c71c72p-5f;
+    r = mhx_fma(0.5f * (float)(d - 1), v, r);
+    r = mhx_fma(0.5f * ev, q, r);
+    return cst - r;
+}

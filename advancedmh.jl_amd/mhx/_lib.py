@@ -38,7 +38,7 @@ class Schedule(C.Structure):
 class RwmhCfg(C.Structure):
     _fields_ = [("dim", C.c_int32), ("nchains", C.c_int32), ("seed", C.c_uint64), ("first_chain", C.c_uint64),
                 ("proposal_kind", C.c_int32), ("proposal_scale", C.c_float),
-                ("proposal_vec", C.POINTER(C.c_float)), ("flags", C.c_int32)]
+                ("proposal_vec", C.POINTER(C.c_float)), ("flags", C.c_int32), ("reduce_lanes", C.c_int32)]
 
 
 class EmceeCfg(C.Structure):
@@ -54,7 +54,8 @@ class RamCfg(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("transitions", C.c_uint64), ("accepted", C.c_uint64), ("kernel_ms", C.c_double),
-                ("wall_ms", C.c_double), ("kernel_variant", C.c_int32), ("launches", C.c_int32)]
+                ("wall_ms", C.c_double), ("kernel_variant", C.c_int32), ("launches", C.c_int32),
+                ("reduce_lanes", C.c_int32)]
 
 
 class DiagCfg(C.Structure):

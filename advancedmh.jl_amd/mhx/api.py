@@ -353,7 +353,7 @@ class Chains:
 
 
 class Run:
-    def __init__(self, model, sampler, nchains=1, seed=0, first_chain=0, ctx=None, flags=0):
+    def __init__(self, model, sampler, nchains=1, seed=0, first_chain=0, ctx=None, flags=0, reduce_lanes=0):
         self.ctx = ctx or L.Context.default()
         self.model, self.sampler = model, sampler
         self.h = C.c_void_p()
@@ -366,7 +366,7 @@ class Run:
                 raise L.ArgumentError(L.MHX_EINVAL, "proposal dimension %d != model dimension %d" % (mv.dim, d))
             vec = None if mv.vec is None else L.f32(mv.vec)
             self._keep.append(vec)
-            cfg = L.RwmhCfg(d, nchains, seed, first_chain, mv.kind, mv.scale, L.fptr(vec), flags)
+            cfg = L.RwmhCfg(d, nchains, seed, first_chain, mv.kind, mv.scale, L.fptr(vec), flags, reduce_lanes)
             L.check(lib.mhx_rwmh_create(self.ctx.h, model.handle(self.ctx), C.byref(cfg), C.byref(self.h)))
             self.n = nchains
             self.kind = "rwmh"
@@ -457,7 +457,7 @@ class Run:
         st = L.Stats()
         L.check(L.lib().mhx_run_stats(self.h, C.byref(st)))
         return dict(transitions=st.transitions, accepted=st.accepted, kernel_ms=st.kernel_ms, wall_ms=st.wall_ms,
-                    kernel_variant=st.kernel_variant, launches=st.launches)
+                    kernel_variant=st.kernel_variant, launches=st.launches, reduce_lanes=st.reduce_lanes)
 
     def diagnostics(self, max_lag=0, ess_chains=256):
         """Sums for R-hat / between-chain ESS (all chains) and, if max_lag > 0, the Geyer ESS from
@@ -508,7 +508,7 @@ def combine_diagnostics(sum_m, sum_m2, sum_v, n_chains, n_samples):
 
 def sample(model, sampler, N, nchains=1, *, initial_params=None, discard_initial=None, thinning=1, num_warmup=0,
            param_names=None, chain_type=Chains, seed=0, first_chain=0, callback=None, ctx=None, flags=0,
-           progress=False):
+           reduce_lanes=0, progress=False):
     """sample(model, sampler, N[, nchains]; kwargs...) -- AbstractMCMC.sample as re-exported by the
     reference (src/AdvancedMH.jl:30).  All chains advance together on the GPU (what
     `sample(model, spl, MCMCThreads(), N, nchains)` does with one task per chain, README.md:141-147).
@@ -518,7 +518,8 @@ def sample(model, sampler, N, nchains=1, *, initial_params=None, discard_initial
     that live on the device here -- the Run gives access to them)."""
     if discard_initial is None:
         discard_initial = num_warmup
-    run = Run(model, sampler, nchains=nchains, seed=seed, first_chain=first_chain, ctx=ctx, flags=flags)
+    run = Run(model, sampler, nchains=nchains, seed=seed, first_chain=first_chain, ctx=ctx, flags=flags,
+              reduce_lanes=reduce_lanes)
     run.init(initial_params)
     if callback is None:
         run.sample(N, discard_initial, thinning, num_warmup)

@@ -100,6 +100,10 @@ typedef struct {
     float proposal_scale;   /* ISO: sigma of N(0, sigma^2 I) */
     const float *proposal_vec; /* DIAG: sigma_k [dim]; DENSE: chol(Sigma) packed lower [dim(dim+1)/2] */
     int32_t flags;          /* MHX_FLAG_* */
+    int32_t reduce_lanes;   /* lanes that share one chain (power of two <= 64) for the separable catalogue
+                               targets; 0 = let the engine choose from nchains and dim, 1 = one lane per chain.
+                               The value in effect is reported in mhx_stats.reduce_lanes: it fixes the
+                               summation order of the log-density and therefore the exact chain. */
 } mhx_rwmh_cfg;
 
 #define MHX_FLAG_NO_JIT 1 /* never specialise with hiprtc; use the pre-built kernels only */
@@ -163,8 +167,10 @@ typedef struct {
     uint64_t accepted;         /* accepted proposals among them (wavefront ballot + popcount reduction) */
     double kernel_ms;          /* device time of the sampler kernels (hipEvent)                         */
     double wall_ms;            /* host wall time of the call                                            */
-    int32_t kernel_variant;    /* 0 generic (HBM state), 1 pre-built register kernel, 2 hiprtc-specialised */
+    int32_t kernel_variant;    /* 0 generic (HBM state), 1 pre-built register kernel, 2 hiprtc-specialised register
+                                  kernel, 3 pre-built cooperative kernel, 4 hiprtc-specialised cooperative kernel */
     int32_t launches;
+    int32_t reduce_lanes;      /* lanes per chain in effect (1 unless a cooperative kernel runs) */
 } mhx_stats;
 int mhx_run_stats(mhx_run *run, mhx_stats *out);
 

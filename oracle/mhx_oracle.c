@@ -186,9 +186,56 @@ static float target_const(const orc_target *t)
     return (float)c;
 }
 
+/* sum of squares of a separable target with the L-lane reduction shape:
+ * `first` elements are handled by the caller-supplied head (lane 0, block 0). */
+static float butterfly(float *p, int L)
+{
+    float tmp[64];
+    for (int off = 1; off < L; off <<= 1) {
+        for (int l = 0; l < L; ++l) tmp[l] = p[l] + p[l ^ off];
+        memcpy(p, tmp, sizeof(float) * (size_t)L);
+    }
+    return p[0];
+}
+
+static float split_sum_squares(const orc_target *t, const float *x)
+{
+    const int d = t->dim, L = t->reduce_lanes, nblk = (d + 3) / 4;
+    float p[64];
+    for (int l = 0; l < L; ++l) {
+        float q = 0.0f;
+        for (int b = l; b < nblk; b += L)
+            for (int j = 0; j < 4; ++j) {
+                const int k = 4 * b + j;
+                if (k >= d) break;
+                if (t->kind == ORC_TARGET_BANANA && k == 0) { q = (x[0] * x[0]) * 0.01f; continue; }
+                if (t->kind == ORC_TARGET_BANANA && k == 1) {
+                    float u = fmaf(t->params[0], fmaf(x[0], x[0], -100.0f), x[1]);
+                    q = fmaf(u, u, q);
+                    continue;
+                }
+                if (t->kind == ORC_TARGET_FUNNEL && k == 0) continue;
+                q = fmaf(x[k], x[k], q);
+            }
+        p[l] = q;
+    }
+    return butterfly(p, L);
+}
+
 float orc_target_eval(const orc_target *t, const float *x)
 {
     const int d = t->dim;
+    if (t->reduce_lanes > 1 && (t->kind == ORC_TARGET_ISO_GAUSS || t->kind == ORC_TARGET_BANANA ||
+                                t->kind == ORC_TARGET_FUNNEL)) {
+        const float q = split_sum_squares(t, x);
+        if (t->kind != ORC_TARGET_FUNNEL) return fmaf(-0.5f, q, target_const(t));
+        const float v = x[0];
+        float ev = orc_expf(-v);
+        float r = (v * v) * 0x1.c71c72p-5f;
+        r = fmaf(0.5f * (float)(d - 1), v, r);
+        r = fmaf(0.5f * ev, q, r);
+        return target_const(t) - r;
+    }
     switch (t->kind) {
     case ORC_TARGET_ISO_GAUSS: {                       /* logpdf(MvNormal(zeros(d), I), x) */
         float q = 0.0f;

@@ -63,6 +63,10 @@ typedef struct {
     int nparams;
     orc_logdensity_fn fn;    /* ORC_TARGET_CALLBACK */
     const void *fn_data;
+    /* reduction shape of the separable targets (ISO_GAUSS, BANANA, FUNNEL): L lanes per chain.
+     * lane l accumulates the Philox blocks b = l, l+L, ... (4 dimensions each) sequentially, the L
+     * partial sums are combined by an xor-butterfly (offsets 1, 2, 4, ...).  0 or 1 = sequential. */
+    int reduce_lanes;
 } orc_target;
 
 float orc_target_eval(const orc_target *t, const float *x);

@@ -21,7 +21,7 @@ LOGDENSITY_FN = C.CFUNCTYPE(C.c_float, C.POINTER(C.c_float), C.c_int, C.c_void_p
 
 class _Target(C.Structure):
     _fields_ = [("kind", C.c_int), ("dim", C.c_int), ("params", C.POINTER(C.c_float)),
-                ("nparams", C.c_int), ("fn", LOGDENSITY_FN), ("fn_data", C.c_void_p)]
+                ("nparams", C.c_int), ("fn", LOGDENSITY_FN), ("fn_data", C.c_void_p), ("reduce_lanes", C.c_int)]
 
 
 class _Proposal(C.Structure):
@@ -120,7 +120,7 @@ def accept_logu(seed, chain, step):
 class Target:
     """kind + params, or a Python callable f(x: np.ndarray) -> float (DensityModel(f))."""
 
-    def __init__(self, kind, dim, params=None, fn=None, fn_data=None):
+    def __init__(self, kind, dim, params=None, fn=None, fn_data=None, reduce_lanes=0):
         self.kind, self.dim = kind, dim
         self._fn_data = fn_data             # keep-alive for a ctypes object passed as void*
         self.params = None if params is None else np.ascontiguousarray(params, dtype=np.float32)
@@ -143,14 +143,20 @@ class Target:
         elif self._fn_addr is not None:
             self.c.fn = C.cast(self._fn_addr, LOGDENSITY_FN)
         self.c.fn_data = None if fn_data is None else C.cast(C.pointer(fn_data), C.c_void_p)
+        self.c.reduce_lanes = int(reduce_lanes)
+
+    def with_lanes(self, L):
+        """the same target with the L-lane reduction shape of the cooperative kernels"""
+        self.c.reduce_lanes = int(L)
+        return self
 
     def __call__(self, x):
         x = np.ascontiguousarray(x, dtype=np.float32)
         return lib().orc_target_eval(C.byref(self.c), _fp(x))
 
 
-def iso_gauss(d):
-    return Target(TARGET_ISO_GAUSS, d)
+def iso_gauss(d, reduce_lanes=0):
+    return Target(TARGET_ISO_GAUSS, d, reduce_lanes=reduce_lanes)
 
 
 def corr_gauss_from_cov(Sigma):

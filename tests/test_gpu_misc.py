@@ -45,14 +45,14 @@ def test_logdensity_batch_matches_oracle(mhx, oracle):
     assert np.isneginf(lp[th[1] < 0]).all()
 
 
-@pytest.mark.parametrize("flags_name", ["auto", "nojit", "generic"])
+@pytest.mark.parametrize("flags_name", ["auto", "nojit", "generic"])   # golden traces use the sequential (1-lane) shape
 @pytest.mark.parametrize("name", ["rwmh_iso", "rwmh_dense_corr", "rwmh_funnel", "rwmh_banana"])
 def test_rwmh_golden_traces_all_kernel_variants(mhx, name, flags_name):
     tr = np.load(os.path.join(GOLD, "traces.npz"))
     flags = {"auto": 0, "nojit": mhx.FLAG_NO_JIT, "generic": mhx.FLAG_GENERIC}[flags_name]
     if name == "rwmh_iso":
         chain = mhx.sample(mhx.DensityModel(mhx.IsoGaussian(5)), mhx.RWMH(mhx.MvNormal(mhx.zeros(5), 0.25 * mhx.I)), 32, 8,
-                           seed=11, first_chain=3, flags=flags)
+                           seed=11, first_chain=3, flags=flags, reduce_lanes=1)
     elif name == "rwmh_dense_corr":
         d = 4
         chain = mhx.sample(mhx.DensityModel(mhx.CorrGaussian(cases.sigma_ar1(d, 0.8))),
@@ -60,11 +60,11 @@ def test_rwmh_golden_traces_all_kernel_variants(mhx, name, flags_name):
                            discard_initial=3, thinning=2, flags=flags)
     elif name == "rwmh_funnel":
         chain = mhx.sample(mhx.DensityModel(mhx.Funnel(6)), mhx.RWMH(mhx.MvNormal(mhx.zeros(6), 0.16 * mhx.I)), 24, 7,
-                           seed=13, first_chain=100, flags=flags)
+                           seed=13, first_chain=100, flags=flags, reduce_lanes=1)
     else:
         chain = mhx.sample(mhx.DensityModel(mhx.Banana(5, 0.03)),
                            mhx.RWMH([mhx.Normal(0, 2.0), mhx.Normal(0, 0.5), mhx.Normal(0, 1), mhx.Normal(0, 1), mhx.Normal(0, 1)]),
-                           24, 7, seed=14, flags=flags)
+                           24, 7, seed=14, flags=flags, reduce_lanes=1)
     _same(chain.value, tr[name + "/samples"], "samples")
     _same(chain.accepted, tr[name + "/accepted"], "accepted")
     want_variant = {"auto": 2, "nojit": 0, "generic": 0}[flags_name]
@@ -96,11 +96,16 @@ def test_large_dim_streaming_kernel(mhx, oracle):
     s = float(np.float32(2.38 / d ** 0.5))
     for spec, ot in ((mhx.Funnel(d), oracle.Target(oracle.TARGET_FUNNEL, d)),
                      (mhx.Banana(d, 0.03), oracle.Target(oracle.TARGET_BANANA, d, params=[0.03]))):
-        chain = mhx.sample(mhx.DensityModel(spec), mhx.RWMH(mhx.MvNormal(mhx.zeros(d), s * s * mhx.I)), N, C, seed=55,
-                           first_chain=1 << 33)
-        ref = oracle.rwmh(ot, oracle.Proposal(oracle.PROP_ISO, s), oracle.schedule(N), 55, 1 << 33, C)
-        _same(chain.value, ref["samples"], "samples")
-        assert chain.stats["kernel_variant"] == 0
+        for lanes, flags in ((0, 0), (1, 0), (16, 0), (0, mhx.FLAG_GENERIC)):
+            chain = mhx.sample(mhx.DensityModel(spec), mhx.RWMH(mhx.MvNormal(mhx.zeros(d), s * s * mhx.I)), N, C, seed=55,
+                               first_chain=1 << 33, reduce_lanes=lanes, flags=flags)
+            L = chain.stats["reduce_lanes"]
+            ref = oracle.rwmh(ot.with_lanes(L), oracle.Proposal(oracle.PROP_ISO, s), oracle.schedule(N), 55, 1 << 33, C)
+            _same(chain.value, ref["samples"], "samples L=%d" % L)
+            if lanes == 0 and flags == 0:
+                assert L == 64 and chain.stats["kernel_variant"] == 3      # wave per chain, pre-built
+            if lanes == 1 or flags:
+                assert L == 1 and chain.stats["kernel_variant"] == 0       # state streamed from HBM
 
 
 def test_shard_invariance_and_resume(mhx):
@@ -108,11 +113,11 @@ def test_shard_invariance_and_resume(mhx):
     d, C, N = 6, 200, 30
     model = mhx.DensityModel(mhx.IsoGaussian(d))
     spl = mhx.RWMH(mhx.MvNormal(mhx.zeros(d), 0.3 * mhx.I))
-    whole = mhx.sample(model, spl, N, C, seed=9)
-    a = mhx.sample(model, spl, N, 120, seed=9, first_chain=0)
-    b = mhx.sample(model, spl, N, 80, seed=9, first_chain=120)
+    whole = mhx.sample(model, spl, N, C, seed=9, reduce_lanes=2)
+    a = mhx.sample(model, spl, N, 120, seed=9, first_chain=0, reduce_lanes=2)
+    b = mhx.sample(model, spl, N, 80, seed=9, first_chain=120, reduce_lanes=2)
     _same(np.concatenate([a.value, b.value], axis=2), whole.value, "shards")
-    run = mhx.Run(model, spl, nchains=C, seed=9)
+    run = mhx.Run(model, spl, nchains=C, seed=9, reduce_lanes=2)
     run.init(None)
     run.sample(10, 0, 1, 0)
     p1, _ = run.samples()

@@ -24,15 +24,20 @@ def _same(a, b, what):
 S = float(np.float32(0.238))
 
 
-@pytest.mark.parametrize("flags_name", ["auto", "generic"])
+@pytest.mark.parametrize("flags_name,lanes", [("auto", 1), ("generic", 0), ("auto", 0), ("auto", 2), ("auto", 8)])
 @pytest.mark.parametrize("d,C,N", [(100, 130, 40), (2, 5, 64), (7, 64, 33), (33, 257, 17)])
-def test_iso_gauss_rwmh_bit_exact(mhx, oracle, d, C, N, flags_name):
+def test_iso_gauss_rwmh_bit_exact(mhx, oracle, d, C, N, flags_name, lanes):
     flags = mhx.FLAG_GENERIC if flags_name == "generic" else 0
+    if lanes > 1 and lanes > (d + 3) // 4:
+        pytest.skip("more lanes than Philox blocks")
     seed = 0xC0FFEE + d
     model = mhx.DensityModel(mhx.IsoGaussian(d))
     spl = mhx.RWMH(mhx.MvNormal(mhx.zeros(d), S * S * mhx.I))
-    chain = mhx.sample(model, spl, N, C, seed=seed, first_chain=7, flags=flags)
-    ref = oracle.rwmh(oracle.iso_gauss(d), oracle.Proposal(oracle.PROP_ISO, S), oracle.schedule(N), seed, 7, C)
+    chain = mhx.sample(model, spl, N, C, seed=seed, first_chain=7, flags=flags, reduce_lanes=lanes)
+    if lanes == 1:
+        assert chain.stats["reduce_lanes"] == 1
+    L = chain.stats["reduce_lanes"]
+    ref = oracle.rwmh(oracle.iso_gauss(d, reduce_lanes=L), oracle.Proposal(oracle.PROP_ISO, S), oracle.schedule(N), seed, 7, C)
     _same(chain.value, ref["samples"], "samples")
     _same(chain.accepted, ref["accepted"], "accepted")
     x, lp, cnt = chain.state.state()
@@ -40,10 +45,14 @@ def test_iso_gauss_rwmh_bit_exact(mhx, oracle, d, C, N, flags_name):
     _same(lp, ref["final_lp"], "final lp")
     _same(cnt, ref["accept_counts"], "accept counts")
     assert chain.stats["accepted"] == int(ref["accept_counts"].sum())
-    if flags_name == "auto":
+    if flags_name == "generic":
+        assert chain.stats["kernel_variant"] == 0 and L == 1
+    elif lanes == 1:
         assert chain.stats["kernel_variant"] in (1, 2)
+    elif lanes > 1:
+        assert chain.stats["kernel_variant"] in (3, 4) and L == lanes
     else:
-        assert chain.stats["kernel_variant"] == 0
+        assert chain.stats["kernel_variant"] in (1, 2, 3, 4)
 
 
 def test_schedule_discard_thinning_and_initial_params(mhx, oracle):
@@ -51,13 +60,13 @@ def test_schedule_discard_thinning_and_initial_params(mhx, oracle):
     init = np.random.default_rng(1).normal(size=(d, C)).astype(np.float32)
     model = mhx.DensityModel(mhx.IsoGaussian(d))
     spl = mhx.RWMH(mhx.MvNormal(mhx.zeros(d), np.array([0.5, 1.0, 0.25, 2.0]) ** 2))
-    chain = mhx.sample(model, spl, N, C, seed=5, initial_params=init, discard_initial=25, thinning=4)
+    chain = mhx.sample(model, spl, N, C, seed=5, initial_params=init, discard_initial=25, thinning=4, reduce_lanes=1)
     assert chain.range() == range(26, 26 + 4 * N, 4)          # test/runtests.jl:129
     prop = oracle.Proposal(oracle.PROP_DIAG, vec=np.array([0.5, 1.0, 0.25, 2.0], dtype=np.float32))
     ref = oracle.rwmh(oracle.iso_gauss(d), prop, oracle.schedule(N, 25, 4), 5, 0, C, init=init)
     _same(chain.value, ref["samples"], "samples")
     _same(chain.accepted, ref["accepted"], "accepted")
     # first sample == initial_params when nothing is discarded (test/runtests.jl:203-213)
-    chain0 = mhx.sample(model, spl, 3, C, seed=5, initial_params=init)
+    chain0 = mhx.sample(model, spl, 3, C, seed=5, initial_params=init, reduce_lanes=1)
     _same(chain0.value[0, :d, :], init, "sample 1")
     assert not chain0.accepted[0].any()
