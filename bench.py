@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark: MH steps/sec (all chains) on the isotropic 100-dim Gaussian,
-RWMH, 65 536 chains per GPU (BASELINE.json configs[1]).
+"""bench.py -- headline benchmark: MH steps/sec (all chains) + ESS/sec on the isotropic 100-dim
+Gaussian, RWMH, 65 536 chains per GPU (BASELINE.json configs[1]).
 
     python bench.py --gpus N --steps K --warmup W
 
@@ -28,6 +28,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s achievable)
 D = 100
 CHAINS = 65536
+VARIANTS = {0: "generic", 1: "prebuilt-register", 2: "hiprtc-register", 3: "prebuilt-cooperative",
+            4: "hiprtc-cooperative"}
 
 
 def algorithmic_bytes_per_launch(d, chains, inner):
@@ -78,8 +80,8 @@ def main():
     ap.add_argument("--inner", type=int, default=250, help="MH transitions per chain per step (launch)")
     ap.add_argument("--chains", type=int, default=CHAINS, help="chains per GPU")
     ap.add_argument("--dim", type=int, default=D)
+    ap.add_argument("--lanes", type=int, default=0, help="lanes per chain (0 = engine's choice)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--ess", action="store_true", help="also report ESS/sec from the device diagnostics")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -102,7 +104,7 @@ def main():
     ctx = mhx.Context(local_rank)
     model = mhx.DensityModel(mhx.IsoGaussian(d))
     spl = mhx.RWMH(mhx.MvNormal(mhx.zeros(d), s * s * mhx.I))
-    run = mhx.Run(model, spl, nchains=C, seed=0xC0FFEE, first_chain=rank * C, ctx=ctx)
+    run = mhx.Run(model, spl, nchains=C, seed=0xC0FFEE, first_chain=rank * C, ctx=ctx, reduce_lanes=args.lanes)
     run.init(None)                                    # x0 ~ proposal draw (src/mh-core.jl:83), on the device
 
     def step():
@@ -130,16 +132,19 @@ def main():
     dt = time.perf_counter() - t0
     variant = st["kernel_variant"]
 
+    # Diagnostics of the LAST launch's sample tensor (outside the timed region): per-shard sums for R-hat
+    # and the between-chain ESS; across GPUs they combine with the one small all-reduce the design has.
+    diag = run.diagnostics(max_lag=0)
     if dist is not None:
         import torch
+        from mhx.dist import allreduce_stats
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        tot = torch.tensor([float(accepted), float(transitions)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tot)                          # the only collective: global acceptance statistic
-        accepted, transitions_all = float(tot[0].item()), float(tot[1].item())
+        diag = allreduce_stats(diag, accepted, transitions, device=torch.device("cuda", local_rank))   # RCCL over xGMI
+        acc_rate = diag["acceptance_rate"]
     else:
-        transitions_all = float(transitions)
+        acc_rate = accepted / float(transitions)
 
     if rank == 0:
         total_steps = float(C) * inner * args.steps * world
@@ -152,35 +157,34 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                key = "rwmh_d%d_c%d_inner%d" % (d, C, inner)
-                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+                traffic = tj.get("rwmh_d%d_c%d_inner%d" % (d, C, inner), {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        essb = np.asarray(diag["ess_between"][:d], dtype=np.float64)
         out = {
-            "metric": "MH steps/sec (all chains)", "value": value, "unit": "MH steps/s",
+            "metric": "MH steps/sec (all chains) + ESS/sec", "value": value, "unit": "MH steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "RWMH, isotropic %d-dim standard MvNormal target, %d chains per GPU, proposal "
                                    "N(0,(2.38/sqrt(d))^2 I), %d transitions per launch, every state recorded" % (d, C, inner),
                        "chains_per_gpu": C, "dim": d, "transitions_per_step": inner,
-                       "kernel_variant": {0: "generic", 1: "prebuilt-register", 2: "hiprtc-register"}[variant],
+                       "kernel_variant": VARIANTS[variant], "lanes_per_chain": st["reduce_lanes"],
                        "sharding": "chains by global id, no data-path collective"},
-            "acceptance_rate": accepted / transitions_all,
+            "acceptance_rate": acc_rate,
+            # ESS/sec: total effective sample size of ONE step's draws (median over the d parameters; between-chain
+            # estimator C * var+ / Var_c(chain means), include/mhx.h) divided by the wall time of one step
+            "ess_per_sec": float(np.median(essb)) / (dt / args.steps),
+            "ess": {"estimator": "between-chain, last step's %d draws x %d chains" % (inner, C * world),
+                    "median": float(np.median(essb)), "min": float(essb.min()),
+                    "rhat_max": float(np.max(diag["rhat"][:d]))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "mhx_rwmh_reg<100,iso,iso>", "avg_launch_ms": launch_s * 1e3,
-                         "algorithmic_bytes_per_launch": bytes_launch,
-                         "note": "VALU-bound kernel (Philox + Box-Muller polynomials, ~6.1k lane-ops per chain-step); "
-                                 "HBM sees only the sample records"},
+                         "kernel": "k_rwmh_coop<2,13,iso,iso>" if variant == 3 else "rwmh variant %d" % variant,
+                         "avg_launch_ms": launch_s * 1e3, "algorithmic_bytes_per_launch": bytes_launch,
+                         "note": "VALU-bound kernel (Philox4x32-10 + Box-Muller polynomials, ~4.8k wave-instructions "
+                                 "per 64 chain-steps); HBM sees only the sample records"},
         }
-        if args.ess:
-            try:
-                dg = run.diagnostics()
-                out["ess_per_sec"] = float(np.median(dg["ess"][:d])) * world / (dt / args.steps)
-            except Exception as e:          # diagnostics are optional for the headline line
-                out["ess_per_sec"] = None
-                out["ess_error"] = str(e)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(d, inner, 0xC0FFEE)
         print(json.dumps(out))
