@@ -13,11 +13,14 @@
 // The update is written to the chain's SECOND factor buffer and a per-chain selector flips only if
 // the new factor is valid (downdate stayed positive definite, diagonal inside the eigenvalue bounds
 // -- RAM.jl:259-264 keeps the old S otherwise), so a rejected update costs no copy.
-// HBM traffic per adapting step: 2 reads + 1 write of S.
+// HBM traffic per adapting step: 1 read + 1 write of S -- the read pass of the NEXT step's mat-vec is
+// fused into the update sweep (its noise is recomputable from the counter RNG); 1 read when S is fixed.
 #pragma once
 #include "mhx_targets.h"
 
-#define MHX_RAM_CHUNK 8
+#ifndef MHX_RAM_NV
+#define MHX_RAM_NV 2           // 16-byte loads in flight per lane and chunk (chunk = NV KiB per wave); measured best of 2/4/8
+#endif
 
 struct mhx_ram_args {
     float* x;                 // [dim][ld]  (ABI layout; touched once per launch)
@@ -27,7 +30,7 @@ struct mhx_ram_args {
     float* samples;           // [slots][dim+1][ld] or null
     unsigned char* accepted;
     unsigned char* last_acc;
-    float* S0;                // [nchains][tri] packed column-major lower
+    float* S0;                // [nchains][tri_pad] packed column-major lower (tri padded to a multiple of 4)
     float* S1;                // second buffer
     unsigned char* sel;       // [nchains] which buffer is current
     unsigned char* status;    // [nchains] bit0: a downdate left the PD cone, bit1: NaN log-ratio
@@ -62,6 +65,177 @@ struct mhx_lds_x {
 
 MHX_DEV long mhx_ram_col_off(int i, int d) { return (long)i * d - ((long)i * (i - 1)) / 2; }
 
+// ---------------------------------------------------------------------------------------------
+// Streaming a packed factor.  A chain's factor is ONE contiguous array, so it is pulled through the
+// wave in full-width pieces -- MHX_RAM_NV x (64 lanes x 16 B) = one "chunk" per round, every lane
+// active, 16-byte aligned -- and parked in a two-chunk LDS ring; the column logic then reads its row
+// segments from LDS.  While the columns of chunk k are processed, the loads of chunk k+1 are already
+// in flight in VGPRs: 4 VGPRs hold 1 KiB in flight (per-column masked dword loads held ~0.4 KiB).
+// A column that straddles two chunks is processed once its tail has arrived.
+#define MHX_RAM_CHF (MHX_RAM_NV * 256)          // floats per chunk
+#define MHX_RAM_RING (2 * MHX_RAM_CHF)          // floats in the ring (power of two)
+
+typedef float mhx_f4 __attribute__((ext_vector_type(4)));
+
+template <class F>
+MHX_DEV void mhx_ram_stream_columns(const float* __restrict__ S, const int d, const int t, float* ring, F&& f)
+{
+    const long tri = (long)d * (d + 1) / 2;
+    const long nvec = (tri + 3) >> 2;                       // the host pads every factor to a multiple of 4 floats
+    const mhx_f4* __restrict__ src = (const mhx_f4*)S;
+    mhx_f4* ring4 = (mhx_f4*)ring;
+    const int nchunks = (int)((tri + MHX_RAM_CHF - 1) / MHX_RAM_CHF);
+    mhx_f4 regs[MHX_RAM_NV];
+    const mhx_f4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int v = 0; v < MHX_RAM_NV; ++v) {
+        const long i4 = (long)v * 64 + t;
+        regs[v] = i4 < nvec ? src[i4] : zero4;
+    }
+#pragma unroll
+    for (int v = 0; v < MHX_RAM_NV; ++v) ring4[v * 64 + t] = regs[v];
+    __syncthreads();
+    int col = 0;
+    long off = 0;                                           // linear offset of column `col`
+    for (int k = 0; k < nchunks; ++k) {
+        const bool more = k + 1 < nchunks;
+        if (more) {
+#pragma unroll
+            for (int v = 0; v < MHX_RAM_NV; ++v) {
+                const long i4 = (long)(k + 1) * (MHX_RAM_NV * 64) + v * 64 + t;
+                regs[v] = i4 < nvec ? src[i4] : zero4;
+            }
+        }
+        const long avail = (long)(k + 1) * MHX_RAM_CHF < tri ? (long)(k + 1) * MHX_RAM_CHF : tri;
+        while (col < d && off + (d - col) <= avail) {
+            if (!f(col, off)) return;
+            off += d - col;
+            ++col;
+        }
+        if (more) {
+            __syncthreads();
+#pragma unroll
+            for (int v = 0; v < MHX_RAM_NV; ++v)
+                ring4[(((k + 1) & 1) * (MHX_RAM_NV * 64)) + v * 64 + t] = regs[v];
+            __syncthreads();
+        }
+    }
+}
+
+// rows of column i owned by this lane, from the ring
+template <int R>
+MHX_DEV void mhx_ram_ring_col(const float* ring, const int i, const long off, const int d, const int t, float (&col)[R])
+{
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int row = t + 64 * r;
+        col[r] = (row >= i && row < d) ? ring[(off + (row - i)) & (MHX_RAM_RING - 1)] : 0.0f;
+    }
+}
+
+// v = S u: column sweep (columns ascending == the row-dot's ascending j order)
+template <int R>
+MHX_DEV void mhx_ram_matvec(const float* __restrict__ S, const float* ush, const int d, const int t, float* ring,
+                            float (&v)[R])
+{
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = 0.0f;
+    mhx_ram_stream_columns(S, d, t, ring, [&](const int i, const long off) {
+        float col[R];
+        mhx_ram_ring_col<R>(ring, i, off, d, t, col);
+        const float ui = ush[i];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (t + 64 * r >= i) v[r] = mhx_fma(col[r], ui, v[r]);
+        return true;
+    });
+}
+
+// draw U = randn(d) of `step` into LDS (lane b draws Philox block b) and return |U|^2 (ascending order)
+MHX_DEV float mhx_ram_draw(const mhx_philox_key& ks, mhx_u32 id_lo, mhx_u32 id_hi, mhx_u32 step, const int d,
+                           const int t, float* ush)
+{
+    const int nblk = (d + 3) >> 2;
+    for (int b = t; b < nblk; b += 64) {
+        float n[4];
+        mhx_normal4(ks, id_lo, id_hi, step, MHX_STREAM_PROPOSAL, (mhx_u32)b, n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (4 * b + j < d) ush[4 * b + j] = n[j];
+    }
+    __syncthreads();
+    float nn = 0.0f;
+    for (int j = 0; j < d; ++j) { const float u = ush[j]; nn = mhx_fma(u, u, nn); }
+    return nn;
+}
+
+// state of the rank-1 sweep that is carried across columns
+template <int R>
+struct mhx_ram_sweep {
+    float w[R];        // the rank-1 vector, rotated column by column
+    float nd[R];       // new diagonal entries of the rows this lane owns
+    float vo[R];       // next step's S_old U'   (fused mat-vec, see below)
+    float vn[R];       // next step's S_new U'
+    bool ok;
+    unsigned st;
+};
+
+// rank-1 update (up) / downdate of one column, written to Snew; if `fuse`, the NEXT step's proposal
+// mat-vec is accumulated on the fly for both the old and the new factor (the next U is recomputable
+// from the counter RNG), which removes that step's separate read pass over S.
+template <int R>
+MHX_DEV bool mhx_ram_sweep_col(const float (&col)[R], float* __restrict__ Snew, const float* unext, const int i,
+                               const long off, const int d, const int t, const bool up, const bool fuse,
+                               mhx_ram_sweep<R>& sw)
+{
+    const int il = i & 63, ir = i >> 6;
+    float aii = 0.0f, bi = 0.0f;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (r == ir) {
+            aii = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, col[r]), il));
+            bi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sw.w[r]), il));
+        }
+    float cs, sn, diag;
+    if (up) {
+        const float rr = mhx_sqrt(mhx_fma(bi, bi, aii * aii));
+        cs = aii / rr;
+        sn = bi / rr;
+        diag = rr;
+    } else {
+        sn = bi / aii;
+        const float s2 = sn * sn;
+        if (s2 > 1.0f) { sw.ok = false; sw.st |= 1u; return false; }      // PosDefException upstream
+        cs = mhx_sqrt(1.0f - s2);
+        diag = cs * aii;
+    }
+    const float un = fuse ? unext[i] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int row = t + 64 * r;
+        if (row < d && row >= i) {
+            float out;
+            if (row == i) {
+                out = diag;
+                sw.nd[r] = diag;
+            } else if (up) {
+                const float Aji = col[r], vj = sw.w[r];
+                out = mhx_fma(cs, Aji, sn * vj);
+                sw.w[r] = mhx_fma(cs, vj, -(sn * Aji));
+            } else {
+                const float vj = sw.w[r];
+                out = (col[r] - sn * vj) / cs;
+                sw.w[r] = mhx_fma(cs, vj, -(sn * out));
+            }
+            Snew[off + (row - i)] = out;
+            if (fuse) {
+                sw.vo[r] = mhx_fma(col[r], un, sw.vo[r]);
+                sw.vn[r] = mhx_fma(out, un, sw.vn[r]);
+            }
+        }
+    }
+    return true;
+}
+
 // R = rows per lane (dim <= 64 R)
 template <int R, int TK>
 MHX_DEV void mhx_ram_body(const mhx_ram_args& a, const float* __restrict__ tparams, float* lds)
@@ -75,11 +249,14 @@ MHX_DEV void mhx_ram_body(const mhx_ram_args& a, const float* __restrict__ tpara
     const int d = a.dim;
     const long ld = a.ld;
     const long tri = (long)d * (d + 1) / 2;
+    const long tri_pad = (tri + 3) & ~3L;                    // per-chain stride of the factor buffers
     const mhx_u64 id = a.first_chain + (mhx_u64)c;
     const mhx_u32 id_lo = (mhx_u32)id, id_hi = (mhx_u32)(id >> 32);
     const mhx_philox_key ks = mhx_philox_schedule(a.seed);
-    float* Ush = lds;            // [d] proposal noise, later the rank-1 vector / target scratch
-    float* ysh = lds + d;        // [d] candidate
+    float* ring = lds;                          // [MHX_RAM_RING] streaming ring (16-byte aligned: first in LDS)
+    float* ucur = lds + MHX_RAM_RING;           // [d] noise of the current step (dead after its mat-vec: target scratch)
+    float* unxt = ucur + d;                     // [d] noise of the next step (fused mat-vec)
+    float* ysh = unxt + d;                      // [d] candidate
 
     float x[R], dmn[R], dmx[R];
 #pragma unroll
@@ -100,51 +277,22 @@ MHX_DEV void mhx_ram_body(const mhx_ram_args& a, const float* __restrict__ tpara
     ac.w.x = ac.w.y = ac.w.z = ac.w.w = 0u;
     mhx_u32 save_next = a.save_next;
     long slot = a.save_slot;
-    const int nblk = (d + 3) >> 2;
+    bool have_v = false;         // v = S U of this step (and nn = |U|^2) already produced by the previous sweep
+    float v[R], nn = 0.0f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = 0.0f;
 
     for (int it = 0; it < a.nsteps; ++it) {
         const mhx_u32 step = a.step0 + (mhx_u32)it;
-        const float* Scur = (sel ? a.S1 : a.S0) + (long)c * tri;
-        float* Snew = (sel ? a.S0 : a.S1) + (long)c * tri;
+        const float* Scur = (sel ? a.S1 : a.S0) + (long)c * tri_pad;
+        float* Snew = (sel ? a.S0 : a.S1) + (long)c * tri_pad;
 
-        // ---- U = randn(d)  (RAM.jl:135): lane b draws Philox block b
-        for (int b = t; b < nblk; b += 64) {
-            float n[4];
-            mhx_normal4(ks, id_lo, id_hi, step, MHX_STREAM_PROPOSAL, (mhx_u32)b, n);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) if (4 * b + j < d) Ush[4 * b + j] = n[j];
+        // ---- U = randn(d), v = S U, x' = v + x   (RAM.jl:135-136)
+        if (!have_v) {
+            nn = mhx_ram_draw(ks, id_lo, id_hi, step, d, t, ucur);
+            mhx_ram_matvec<R>(Scur, ucur, d, t, ring, v);
         }
-        __syncthreads();
-        float nn = 0.0f;                                   // |U|^2, ascending order (every lane)
-        for (int j = 0; j < d; ++j) { const float u = Ush[j]; nn = mhx_fma(u, u, nn); }
-
-        // ---- pass A: v = S U, x' = v + x   (RAM.jl:136 muladd(S, U, x))
-        float v[R], y[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) v[r] = 0.0f;
-        for (int i0 = 0; i0 < d; i0 += MHX_RAM_CHUNK) {
-            float col[MHX_RAM_CHUNK][R];
-#pragma unroll
-            for (int cc = 0; cc < MHX_RAM_CHUNK; ++cc) {
-                const int i = i0 + cc;
-                const long off = mhx_ram_col_off(i, d) - i;
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int row = t + 64 * r;
-                    col[cc][r] = (i < d && row >= i && row < d) ? Scur[off + row] : 0.0f;
-                }
-            }
-#pragma unroll
-            for (int cc = 0; cc < MHX_RAM_CHUNK; ++cc) {
-                const int i = i0 + cc;
-                if (i < d) {
-                    const float ui = Ush[i];
-#pragma unroll
-                    for (int r = 0; r < R; ++r)
-                        if (t + 64 * r >= i) v[r] = mhx_fma(col[cc][r], ui, v[r]);
-                }
-            }
-        }
+        float y[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int row = t + 64 * r;
@@ -159,39 +307,14 @@ MHX_DEV void mhx_ram_body(const mhx_ram_args& a, const float* __restrict__ tpara
         if (kind == MHX_TARGET_CORR_GAUSS) {
             // cooperative column sweep over A = inv(chol(Sigma)): w_j += A_ji y_i, i ascending
             float wv[R];
+            mhx_ram_matvec<R>(a.acol, ysh, d, t, ring, wv);
+            __syncthreads();
 #pragma unroll
-            for (int r = 0; r < R; ++r) wv[r] = 0.0f;
-            for (int i0 = 0; i0 < d; i0 += MHX_RAM_CHUNK) {
-                float col[MHX_RAM_CHUNK][R];
-#pragma unroll
-                for (int cc = 0; cc < MHX_RAM_CHUNK; ++cc) {
-                    const int i = i0 + cc;
-                    const long off = mhx_ram_col_off(i, d) - i;
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const int row = t + 64 * r;
-                        col[cc][r] = (i < d && row >= i && row < d) ? a.acol[off + row] : 0.0f;
-                    }
-                }
-#pragma unroll
-                for (int cc = 0; cc < MHX_RAM_CHUNK; ++cc) {
-                    const int i = i0 + cc;
-                    if (i < d) {
-                        const float yi = ysh[i];
-#pragma unroll
-                        for (int r = 0; r < R; ++r)
-                            if (t + 64 * r >= i) wv[r] = mhx_fma(col[cc][r], yi, wv[r]);
-                    }
-                }
-            }
-            __syncthreads();                               // all lanes are done reading Ush (nn) -> reuse it
-#pragma unroll
-            for (int r = 0; r < R; ++r) if (t + 64 * r < d) Ush[t + 64 * r] = wv[r];
+            for (int r = 0; r < R; ++r) if (t + 64 * r < d) ucur[t + 64 * r] = wv[r];
             __syncthreads();
             float q = 0.0f;
-            for (int j = 0; j < d; ++j) { const float w = Ush[j]; q = mhx_fma(w, w, q); }
+            for (int j = 0; j < d; ++j) { const float w = ucur[j]; q = mhx_fma(w, w, q); }
             lpy = mhx_fma(-0.5f, q, a.tconst);
-            __syncthreads();
         } else {
             mhx_lds_x yv;
             yv.p = ysh;
@@ -205,94 +328,53 @@ MHX_DEV void mhx_ram_body(const mhx_ram_args& a, const float* __restrict__ tpara
         const bool acc = logu < loga;
 
         // ---- adapt (RAM.jl:153-173, :259-264) during warm-up
+        have_v = false;
         if (it < a.n_adapt) {
             const float da = mhx_exp(loga) - a.alpha;                    // :159
             if (da == da) {
                 const float eta = a.eta[it];                             // :162 iteration^-gamma
                 const float coef = mhx_sqrt(eta * __builtin_fabsf(da)) / mhx_sqrt(nn);   // :163
-                float w[R], nd[R];
+                mhx_ram_sweep<R> sw;
 #pragma unroll
-                for (int r = 0; r < R; ++r) { w[r] = v[r] * coef; nd[r] = 0.0f; }
+                for (int r = 0; r < R; ++r) { sw.w[r] = v[r] * coef; sw.nd[r] = 0.0f; sw.vo[r] = 0.0f; sw.vn[r] = 0.0f; }
+                sw.ok = true;
+                sw.st = 0u;
                 const bool up = da > 0.0f;                               // :165 sign(da) == 1
-                bool ok = true;
-                for (int i0 = 0; i0 < d && ok; i0 += MHX_RAM_CHUNK) {
-                    float col[MHX_RAM_CHUNK][R];
-#pragma unroll
-                    for (int cc = 0; cc < MHX_RAM_CHUNK; ++cc) {
-                        const int i = i0 + cc;
-                        const long off = mhx_ram_col_off(i, d) - i;
-#pragma unroll
-                        for (int r = 0; r < R; ++r) {
-                            const int row = t + 64 * r;
-                            col[cc][r] = (i < d && row >= i && row < d) ? Scur[off + row] : 0.0f;
-                        }
-                    }
-#pragma unroll
-                    for (int cc = 0; cc < MHX_RAM_CHUNK; ++cc) {
-                        const int i = i0 + cc;
-                        if (i < d && ok) {
-                            const int il = i & 63, ir = i >> 6;
-                            float aii = 0.0f, bi = 0.0f;
-#pragma unroll
-                            for (int r = 0; r < R; ++r)
-                                if (r == ir) {
-                                    aii = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, col[cc][r]), il));
-                                    bi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w[r]), il));
-                                }
-                            float cs, sn, diag;
-                            if (up) {
-                                const float rr = mhx_sqrt(mhx_fma(bi, bi, aii * aii));
-                                cs = aii / rr;
-                                sn = bi / rr;
-                                diag = rr;
-                            } else {
-                                sn = bi / aii;
-                                const float s2 = sn * sn;
-                                if (s2 > 1.0f) { ok = false; st |= 1u; }      // PosDefException upstream
-                                cs = mhx_sqrt(1.0f - s2);
-                                diag = cs * aii;
-                            }
-                            if (ok) {
-                                const long off = mhx_ram_col_off(i, d) - i;
-#pragma unroll
-                                for (int r = 0; r < R; ++r) {
-                                    const int row = t + 64 * r;
-                                    if (row < d && row >= i) {
-                                        float out;
-                                        if (row == i) {
-                                            out = diag;
-                                            nd[r] = diag;
-                                        } else if (up) {
-                                            const float Aji = col[cc][r], vj = w[r];
-                                            out = mhx_fma(cs, Aji, sn * vj);
-                                            w[r] = mhx_fma(cs, vj, -(sn * Aji));
-                                        } else {
-                                            const float vj = w[r];
-                                            out = (col[cc][r] - sn * vj) / cs;
-                                            w[r] = mhx_fma(cs, vj, -(sn * out));
-                                        }
-                                        Snew[off + row] = out;
-                                    }
-                                }
-                            }
-                        }
-                    }
-                }
+                const bool fuse = it + 1 < a.nsteps;                     // a next step exists in this launch
+                float nn_next = 0.0f;
+                __syncthreads();                                         // every lane is done with ucur / ysh
+                if (fuse) nn_next = mhx_ram_draw(ks, id_lo, id_hi, step + 1u, d, t, unxt);
+                mhx_ram_stream_columns(Scur, d, t, ring, [&](const int i, const long off) {
+                    float col[R];
+                    mhx_ram_ring_col<R>(ring, i, off, d, t, col);
+                    return mhx_ram_sweep_col<R>(col, Snew, unxt, i, off, d, t, up, fuse, sw);
+                });
+                st |= sw.st;
+                bool ok = sw.ok;
+                const bool swept = sw.ok;                                // the sweep reached the last column
                 // valid_eigenvalues (RAM.jl:239-245): every diagonal entry inside [lo, hi]
                 if (ok && !a.default_bounds) {
                     bool bad = false;
 #pragma unroll
                     for (int r = 0; r < R; ++r)
-                        if (t + 64 * r < d && !(a.eig_lo <= nd[r] && nd[r] <= a.eig_hi)) bad = true;
+                        if (t + 64 * r < d && !(a.eig_lo <= sw.nd[r] && sw.nd[r] <= a.eig_hi)) bad = true;
                     if (__ballot(bad) != 0ull) ok = false;
                 }
                 if (ok) {
                     sel ^= 1;
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
-                        dmn[r] = nd[r] < dmn[r] ? nd[r] : dmn[r];
-                        dmx[r] = nd[r] > dmx[r] ? nd[r] : dmx[r];
+                        dmn[r] = sw.nd[r] < dmn[r] ? sw.nd[r] : dmn[r];
+                        dmx[r] = sw.nd[r] > dmx[r] ? sw.nd[r] : dmx[r];
                     }
+                }
+                if (fuse && swept) {
+                    // the next step's mat-vec is done: S_{t+1} = new factor if it was kept, else the old one
+#pragma unroll
+                    for (int r = 0; r < R; ++r) v[r] = ok ? sw.vn[r] : sw.vo[r];
+                    nn = nn_next;
+                    have_v = true;
+                    float* sp = ucur; ucur = unxt; unxt = sp;
                 }
             } else {
                 st |= 2u;

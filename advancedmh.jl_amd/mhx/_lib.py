@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_PKG), "libmhx.so")
+LIB_PATH = os.environ.get("MHX_LIB") or os.path.join(os.path.dirname(_PKG), "libmhx.so")
 
 MHX_OK, MHX_EINVAL, MHX_ENOMEM, MHX_EHIP, MHX_EJIT, MHX_ENOTPD, MHX_ESTATE = 0, -1, -2, -3, -4, -5, -6
 
