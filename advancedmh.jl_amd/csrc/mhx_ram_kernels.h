@@ -195,17 +195,20 @@ MHX_DEV bool mhx_ram_sweep_col(const float (&col)[R], float* __restrict__ Snew, 
             aii = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, col[r]), il));
             bi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sw.w[r]), il));
         }
-    float cs, sn, diag;
+    // one reciprocal per column; the per-element divisions of the upstream sweep become multiplications
+    float cs, sn, diag, rcs = 0.0f;
     if (up) {
         const float rr = mhx_sqrt(mhx_fma(bi, bi, aii * aii));
-        cs = aii / rr;
-        sn = bi / rr;
+        const float rinv = 1.0f / rr;
+        cs = aii * rinv;
+        sn = bi * rinv;
         diag = rr;
     } else {
         sn = bi / aii;
         const float s2 = sn * sn;
         if (s2 > 1.0f) { sw.ok = false; sw.st |= 1u; return false; }      // PosDefException upstream
         cs = mhx_sqrt(1.0f - s2);
+        rcs = 1.0f / cs;
         diag = cs * aii;
     }
     const float un = fuse ? unext[i] : 0.0f;
@@ -223,7 +226,7 @@ MHX_DEV bool mhx_ram_sweep_col(const float (&col)[R], float* __restrict__ Snew, 
                 sw.w[r] = mhx_fma(cs, vj, -(sn * Aji));
             } else {
                 const float vj = sw.w[r];
-                out = (col[r] - sn * vj) / cs;
+                out = (col[r] - sn * vj) * rcs;
                 sw.w[r] = mhx_fma(cs, vj, -(sn * out));
             }
             Snew[off + (row - i)] = out;

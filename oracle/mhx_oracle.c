@@ -521,7 +521,8 @@ int orc_chol_rank1(float *S, float *w, int d, int sign)
         float c, sn;
         if (sign > 0) {
             float r = sqrtf(fmaf(b, b, a * a));
-            c = a / r; sn = b / r;
+            float rinv = 1.0f / r;                       /* one reciprocal per column (spec 3.9) */
+            c = a * rinv; sn = b * rinv;
             S[SIDX(i, i)] = r;
             for (int j = i + 1; j < d; ++j) {
                 float Aji = S[SIDX(j, i)], vj = w[j];
@@ -533,10 +534,11 @@ int orc_chol_rank1(float *S, float *w, int d, int sign)
             float s2 = sn * sn;
             if (s2 > 1.0f) return i + 1;                 /* PosDefException(i) upstream */
             c = sqrtf(1.0f - s2);
+            const float rc = 1.0f / c;
             S[SIDX(i, i)] = c * a;
             for (int j = i + 1; j < d; ++j) {
                 float vj = w[j];
-                float Aji = (S[SIDX(j, i)] - sn * vj) / c;
+                float Aji = (S[SIDX(j, i)] - sn * vj) * rc;
                 S[SIDX(j, i)] = Aji;
                 w[j] = fmaf(c, vj, -(sn * Aji));
             }

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Usage: tools/profile_cmd.sh <tag> <command...>   -- kernel trace + HBM + SQ counters for any command
+set -u
+TAG=$1; shift
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$REPO/gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+CMD="$*"
+echo "== unprofiled"; (cd $REPO && $CMD) 2>&1 | tail -6 | tee $OUT/run.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktrace -o bench -- bash -c "cd $REPO && $CMD" > $OUT/ktrace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- bash -c "cd $REPO && $CMD" > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- bash -c "cd $REPO && $CMD" > $OUT/pmc_write.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU --output-format csv -d $OUT/pmc_sq -o bench -- bash -c "cd $REPO && $CMD" > $OUT/pmc_sq.log 2>&1
+rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_SMEM --output-format csv -d $OUT/pmc_sq2 -o bench -- bash -c "cd $REPO && $CMD" > $OUT/pmc_sq2.log 2>&1
+python $REPO/tools/summarize_profile.py $OUT > $OUT/summary.txt 2>&1; grep -v "__amd_rocclr\|k_ram_init\|k_ram_repack\|k_ram_unit\|k_ram_diag" $OUT/summary.txt

@@ -22,7 +22,7 @@ for f in find("ktrace", "*kernel_stats.csv"):
         print("  %-70s calls=%s avg_ns=%s total_ns=%s pct=%s" % (r.get("Name", "")[:70], r.get("Calls"),
               r.get("AverageNs"), r.get("TotalDurationNs"), r.get("Percentage")))
     rep["kernel_stats"] = rows[:12]
-for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
     for f in find(sub, "*counter_collection.csv"):
         agg = defaultdict(lambda: defaultdict(list))
         for r in csv.DictReader(open(f)):
