@@ -95,6 +95,19 @@ static const prebuilt_coop k_prebuilt_coop[] = {
     {64, 4, MHX_TARGET_BANANA, MHX_PROP_ISO, k_rwmh_coop<64, 4, MHX_TARGET_BANANA, MHX_PROP_ISO>},
 };
 
+// sum of a u32 array into a u64 (one atomic per block)
+__global__ void __launch_bounds__(256)
+k_sum_u32(const unsigned* __restrict__ v, const long n, unsigned long long* out)
+{
+    __shared__ unsigned long long red[4];
+    unsigned long long s = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s += v[i];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
 struct prebuilt_reg { int D, TK, PK; void (*fn)(const mhx_rwmh_args, const float*, const float*); };
 static const prebuilt_reg k_prebuilt_reg[] = {
     {100, MHX_TARGET_ISO_GAUSS, MHX_PROP_ISO, k_rwmh_reg<100, MHX_TARGET_ISO_GAUSS, MHX_PROP_ISO>},
@@ -706,8 +719,18 @@ extern "C" int mhx_run_sample(mhx_run* r, const mhx_schedule* s, int save_sample
     r->stats = mhx_stats{};
     r->stats.kernel_variant = r->variant;
     r->stats.reduce_lanes = r->coop_L;
+    auto total_accepts = [&](unsigned long long* out) -> int {
+        if (r->kind == RUN_EMCEE) {            // per-walker counts summed on demand (no atomics in the half-step kernels)
+            HIP_TRY(hipMemsetAsync(r->d_acc_total, 0, sizeof(unsigned long long), ctx->stream));
+            hipLaunchKernelGGL(k_sum_u32, dim3(64), dim3(256), 0, ctx->stream, (const unsigned*)r->d_acc, (long)r->n, r->d_acc_total);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        }
+        HIP_TRY(hipMemcpy(out, r->d_acc_total, sizeof *out, hipMemcpyDeviceToHost));
+        return MHX_OK;
+    };
     unsigned long long acc_before = 0;
-    HIP_TRY(hipMemcpy(&acc_before, r->d_acc_total, sizeof acc_before, hipMemcpyDeviceToHost));
+    { int rc0 = total_accepts(&acc_before); if (rc0) return rc0; }
 
     uint32_t save_next = MHX_NO_SAVE;
     int save_slot = 0;
@@ -747,7 +770,7 @@ extern "C" int mhx_run_sample(mhx_run* r, const mhx_schedule* s, int save_sample
     float ms = 0.0f;
     HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     unsigned long long acc_after = 0;
-    HIP_TRY(hipMemcpy(&acc_after, r->d_acc_total, sizeof acc_after, hipMemcpyDeviceToHost));
+    { int rc1 = total_accepts(&acc_after); if (rc1) return rc1; }
     r->stats.kernel_ms = ms;
     r->stats.transitions = nT * (uint64_t)r->n;
     r->stats.accepted = acc_after - acc_before;

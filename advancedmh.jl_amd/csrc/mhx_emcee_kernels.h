@@ -36,6 +36,7 @@ struct mhx_emcee_args {
     mhx_u32 sweep;            // RNG step counter of this sweep
     int half;                 // 0: walkers [0, W/2) move; 1: walkers [W/2, W) move
     long save_slot;           // slot to record this sweep into, or -1
+    int reduce_lanes;         // lanes per walker (cooperative kernel), >= 1
 };
 
 // D > 0: compile-time dimension, candidate in registers.  D == 0: run-time dimension, candidate
@@ -113,9 +114,8 @@ MHX_DEV void mhx_emcee_half_body(const mhx_emcee_args& a, const float* __restric
         row[(long)d * ld] = acc ? lpy : lpi;
         a.accepted[a.save_slot * ld + i] = acc ? 1 : 0;
     }
-    const mhx_u64 b = __ballot(acc);
-    if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u)
-        atomicAdd(a.acc_total, (mhx_u64)__popcll(b));
+    // the all-walker accept count is summed from acc_count by the host after the run (see the
+    // cooperative kernel below for why there is no per-wave atomic in these short launches)
 }
 
 // initial walkers (src/emcee.jl:6-8): W log-density evaluations, accepted = false
@@ -127,16 +127,120 @@ MHX_DEV void mhx_emcee_init_body(const mhx_emcee_args& a, const float* __restric
     mhx_strided_x xv;
     xv.base = a.x + i;
     xv.ld = a.nwalkers;
-    a.lp[i] = mhx_target_eval<TK>(a.target_kind, xv, a.dim, tparams, a.ntparams, a.tconst);
+    a.lp[i] = mhx_target_eval_lanes<TK>(a.target_kind, xv, a.dim, tparams, a.ntparams, a.tconst, a.reduce_lanes);
     a.acc_count[i] = 0u;
     a.last_acc[i] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cooperative stretch move for the dense-Gaussian target: L lanes share one walker (64/L walkers per
+// wave).  A half-step of a 16 384-walker ensemble is only 128 waves of lane-per-walker work, each
+// walking the 1275 entries of inv(chol(Sigma)) serially; with L = 8 it is 1024 waves (one per SIMD)
+// and every lane owns D/L dimensions of the move and D/L rows of A y.  The candidate is exchanged
+// through LDS (broadcast reads within a walker's lane group); the L partial sums of squares meet in
+// an xor-butterfly -- the reduction shape is part of the arithmetic spec (oracle: reduce_lanes = L).
+template <int D, int L>
+MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const float* __restrict__ A, float* ysh)
+{
+    constexpr int CPW = 64 / L;                  // walkers per wave
+    constexpr int NK = (D + L - 1) / L;          // dimensions (and rows) per lane
+    constexpr int DP = D | 1;                    // odd LDS row pitch: the CPW walkers hit distinct banks
+    const int W = a.nwalkers;
+    const int halfW = W / 2;
+    const int lo = a.half ? halfW : 0;
+    const int cnt = a.half ? W - halfW : halfW;
+    const int lane = threadIdx.x & 63;
+    const int cw = lane & (CPW - 1);
+    const int l = lane / CPW;
+    const int t_raw = blockIdx.x * CPW + cw;     // one wave per block
+    const bool valid = t_raw < cnt;
+    const int i = lo + (valid ? t_raw : cnt - 1);
+    const int ostart = a.half ? 0 : halfW;
+    const int osize = a.half ? halfW : W - halfW;
+    const long ld = W;
+
+    const mhx_philox_key ks = mhx_philox_schedule(a.seed);
+    const mhx_u32x4 w4 = mhx_philox(ks, (mhx_u32)i, (mhx_u32)a.ensemble_id, a.sweep, MHX_STREAM_EMCEE << 28);
+    const int j = ostart + (int)(((mhx_u64)w4.x * (mhx_u64)(mhx_u32)osize) >> 32);
+    const float u = mhx_u01_half(w4.y);
+    const float tt = mhx_fma(a.stretch - 1.0f, u, 1.0f);
+    const float z = (tt * tt) / a.stretch;                               // src/emcee.jl:81
+    const float alphamult = (float)(D - 1) * mhx_log(z);                 // :82
+
+    float xs[NK], ysl[NK];
+    float* yrow = ysh + cw * DP;
+#pragma unroll
+    for (int m = 0; m < NK; ++m) {
+        const int k = l + L * m;
+        if (k < D) {
+            const float xi = a.x[(long)k * ld + i];
+            const float xj = a.x[(long)k * ld + j];
+            xs[m] = xi;
+            ysl[m] = mhx_fma(z, xi - xj, xj);                            // :85
+            yrow[k] = ysl[m];
+        } else {
+            xs[m] = 0.0f;
+            ysl[m] = 0.0f;
+        }
+    }
+    __syncthreads();
+    float q = 0.0f;
+#pragma unroll
+    for (int m = 0; m < NK; ++m) {
+        const int r = l + L * m;                                         // this lane's row of A y
+        const int rmax = (L * m + L - 1) < (D - 1) ? (L * m + L - 1) : (D - 1);   // wave-uniform trip count
+        const int rc = r < D ? r : 0;                                    // rows past the end shadow row 0 (masked below)
+        const float* Ar = A + (long)rc * (rc + 1) / 2;
+        // unconditional, index-clamped loads: all of a row's entries are in flight together (L1/L2 hits)
+        float av[D];
+#pragma unroll
+        for (int jj = 0; jj <= rmax; ++jj) av[jj] = Ar[jj <= rc ? jj : rc];
+        float w = 0.0f;
+#pragma unroll
+        for (int jj = 0; jj <= rmax; ++jj) {
+            const float yv = yrow[jj];
+            w = (r < D && jj <= r) ? mhx_fma(av[jj], yv, w) : w;
+        }
+        q = r < D ? mhx_fma(w, w, q) : q;
+    }
+#pragma unroll
+    for (int off = 1; off < L; off <<= 1) q = q + __shfl_xor(q, off * CPW, 64);
+    const float lpy = mhx_fma(-0.5f, q, a.tconst);
+    const float lpi = a.lp[i];
+    const float alpha = (alphamult + lpy) - lpi;                         // :91
+    const float logu = mhx_log_pos(mhx_u01_open(w4.z));
+    const bool acc = logu <= alpha;                                      // :93
+    if (valid) {
+        if (acc) {
+#pragma unroll
+            for (int m = 0; m < NK; ++m) { const int k = l + L * m; if (k < D) a.x[(long)k * ld + i] = ysl[m]; }
+            if (l == 0) { a.lp[i] = lpy; a.acc_count[i] += 1u; }
+        }
+        if (l == 0) a.last_acc[i] = acc ? 1 : 0;
+        if (a.save_slot >= 0) {
+            float* row = a.samples + a.save_slot * (long)(D + 1) * ld + i;
+#pragma unroll
+            for (int m = 0; m < NK; ++m) { const int k = l + L * m; if (k < D) row[(long)k * ld] = acc ? ysl[m] : xs[m]; }
+            if (l == 0) {
+                row[(long)D * ld] = acc ? lpy : lpi;
+                a.accepted[a.save_slot * ld + i] = acc ? 1 : 0;
+            }
+        }
+    }
+    // no per-wave atomic here: a half-step is one short launch of ~1000 waves, and 1000 atomics on one
+    // address (~12 ns each) would cost more than the move; the host sums acc_count after the run.
 }
 
 #ifdef MHX_JIT_EMCEE
 extern "C" __global__ void __launch_bounds__(64)
 mhx_jit_emcee_half(const mhx_emcee_args a, const float* __restrict__ tparams)
 {
+#if MHX_JIT_L > 1
+    __shared__ float ysh[(64 / MHX_JIT_L) * (MHX_JIT_DIM | 1)];
+    mhx_emcee_coop_body<MHX_JIT_DIM, MHX_JIT_L>(a, tparams, ysh);
+#else
     mhx_emcee_half_body<MHX_JIT_DIM, MHX_JIT_TK>(a, tparams);
+#endif
 }
 extern "C" __global__ void __launch_bounds__(256)
 mhx_jit_emcee_init(const mhx_emcee_args a, const float* __restrict__ tparams)

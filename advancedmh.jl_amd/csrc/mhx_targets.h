@@ -110,9 +110,28 @@ MHX_DEV float mhx_target_eval_lanes(int kind, const X& x, const int d, const flo
 {
     const int k_ = (KIND == MHX_TARGET_DYNAMIC) ? kind : KIND;
     const bool separable = k_ == MHX_TARGET_ISO_GAUSS || k_ == MHX_TARGET_BANANA || k_ == MHX_TARGET_FUNNEL;
-    if (L <= 1 || !separable) return mhx_target_eval<KIND>(kind, x, d, p, np, cst);
-    const int nblk = (d + 3) >> 2;
+    if (L <= 1 || !(separable || k_ == MHX_TARGET_CORR_GAUSS)) return mhx_target_eval<KIND>(kind, x, d, p, np, cst);
     float part[64];
+    if (k_ == MHX_TARGET_CORR_GAUSS) {
+        // shape of the cooperative ensemble kernel: lane l owns rows i = l, l+L, ... of A x
+        for (int l = 0; l < L; ++l) {
+            float q = 0.0f;
+            for (int i = l; i < d; i += L) {
+                const float* Ar = p + (long)i * (i + 1) / 2;
+                float w = 0.0f;
+                for (int j = 0; j <= i; ++j) w = mhx_fma(Ar[j], x[j], w);
+                q = mhx_fma(w, w, q);
+            }
+            part[l] = q;
+        }
+        for (int off = 1; off < L; off <<= 1) {
+            float nxt[64];
+            for (int l = 0; l < L; ++l) nxt[l] = part[l] + part[l ^ off];
+            for (int l = 0; l < L; ++l) part[l] = nxt[l];
+        }
+        return mhx_fma(-0.5f, part[0], cst);
+    }
+    const int nblk = (d + 3) >> 2;
     for (int l = 0; l < L; ++l) {
         float q = 0.0f;
         for (int b = l; b < nblk; b += L)

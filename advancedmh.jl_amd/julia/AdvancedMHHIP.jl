@@ -36,7 +36,7 @@ struct RwmhCfg
     proposal_kind::Int32; proposal_scale::Cfloat; proposal_vec::Ptr{Cfloat}; flags::Int32; reduce_lanes::Int32
 end
 struct EmceeCfg
-    dim::Int32; nwalkers::Int32; seed::UInt64; ensemble_id::UInt64; stretch::Cfloat; flags::Int32
+    dim::Int32; nwalkers::Int32; seed::UInt64; ensemble_id::UInt64; stretch::Cfloat; flags::Int32; reduce_lanes::Int32
 end
 struct RamCfg
     dim::Int32; nchains::Int32; seed::UInt64; first_chain::UInt64
@@ -122,7 +122,7 @@ function AbstractMCMC.sample(
         end
     elseif sampler isa AdvancedMH.Ensemble
         n = sampler.n_walkers
-        cfg = EmceeCfg(d, n, seed, ens.first_chain, Float32(sampler.proposal.stretch_length), 0)
+        cfg = EmceeCfg(d, n, seed, ens.first_chain, Float32(sampler.proposal.stretch_length), 0, 0)
         check(ccall((:mhx_emcee_create, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{EmceeCfg}, Ref{Ptr{Cvoid}}),
                     ctx[], tgt, cfg, run))
         if initial_params === nothing                                       # src/emcee.jl:29-34

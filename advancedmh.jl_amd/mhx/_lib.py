@@ -43,7 +43,7 @@ class RwmhCfg(C.Structure):
 
 class EmceeCfg(C.Structure):
     _fields_ = [("dim", C.c_int32), ("nwalkers", C.c_int32), ("seed", C.c_uint64), ("ensemble_id", C.c_uint64),
-                ("stretch", C.c_float), ("flags", C.c_int32)]
+                ("stretch", C.c_float), ("flags", C.c_int32), ("reduce_lanes", C.c_int32)]
 
 
 class RamCfg(C.Structure):

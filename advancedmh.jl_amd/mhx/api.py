@@ -371,7 +371,7 @@ class Run:
             self.n = nchains
             self.kind = "rwmh"
         elif isinstance(sampler, Ensemble):
-            cfg = L.EmceeCfg(d, sampler.n_walkers, seed, first_chain, sampler.proposal.stretch_length, flags)
+            cfg = L.EmceeCfg(d, sampler.n_walkers, seed, first_chain, sampler.proposal.stretch_length, flags, reduce_lanes)
             L.check(lib.mhx_emcee_create(self.ctx.h, model.handle(self.ctx), C.byref(cfg), C.byref(self.h)))
             self.n = sampler.n_walkers
             self.kind = "emcee"

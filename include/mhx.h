@@ -122,6 +122,7 @@ typedef struct {
     uint64_t ensemble_id;
     float stretch;          /* a = 2.0 */
     int32_t flags;
+    int32_t reduce_lanes;   /* lanes per walker (dense-Gaussian target): 0 = engine's choice, 1 = one lane per walker */
 } mhx_emcee_cfg;
 
 int mhx_emcee_create(mhx_ctx *ctx, const mhx_target *t, const mhx_emcee_cfg *cfg, mhx_run **out);

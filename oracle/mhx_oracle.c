@@ -225,6 +225,23 @@ static float split_sum_squares(const orc_target *t, const float *x)
 float orc_target_eval(const orc_target *t, const float *x)
 {
     const int d = t->dim;
+    if (t->reduce_lanes > 1 && t->kind == ORC_TARGET_CORR_GAUSS) {
+        /* rows i = l, l+L, ... on lane l (each row-dot sequential), partial sums of squares in a butterfly */
+        const float *A = t->params;
+        const int L = t->reduce_lanes;
+        float p[64];
+        for (int l = 0; l < L; ++l) {
+            float q = 0.0f;
+            for (int i = l; i < d; i += L) {
+                const size_t off = (size_t)i * ((size_t)i + 1) / 2;
+                float w = 0.0f;
+                for (int j = 0; j <= i; ++j) w = fmaf(A[off + j], x[j], w);
+                q = fmaf(w, w, q);
+            }
+            p[l] = q;
+        }
+        return fmaf(-0.5f, butterfly(p, L), target_const(t));
+    }
     if (t->reduce_lanes > 1 && (t->kind == ORC_TARGET_ISO_GAUSS || t->kind == ORC_TARGET_BANANA ||
                                 t->kind == ORC_TARGET_FUNNEL)) {
         const float q = split_sum_squares(t, x);

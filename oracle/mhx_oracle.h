@@ -65,7 +65,8 @@ typedef struct {
     const void *fn_data;
     /* reduction shape of the separable targets (ISO_GAUSS, BANANA, FUNNEL): L lanes per chain.
      * lane l accumulates the Philox blocks b = l, l+L, ... (4 dimensions each) sequentially, the L
-     * partial sums are combined by an xor-butterfly (offsets 1, 2, 4, ...).  0 or 1 = sequential. */
+     * partial sums are combined by an xor-butterfly (offsets 1, 2, 4, ...).  0 or 1 = sequential.
+     * CORR_GAUSS (cooperative ensemble kernel): lane l owns the rows i = l, l+L, ... of A x. */
     int reduce_lanes;
 } orc_target;
 

@@ -159,11 +159,11 @@ def iso_gauss(d, reduce_lanes=0):
     return Target(TARGET_ISO_GAUSS, d, reduce_lanes=reduce_lanes)
 
 
-def corr_gauss_from_cov(Sigma):
+def corr_gauss_from_cov(Sigma, reduce_lanes=0):
     """params = inv(chol(Sigma)) packed lower row-major, computed in float64 then rounded."""
     Sigma = np.asarray(Sigma, dtype=np.float64)
     A = np.linalg.inv(np.linalg.cholesky(Sigma))
-    return Target(TARGET_CORR_GAUSS, Sigma.shape[0], pack_lower(A))
+    return Target(TARGET_CORR_GAUSS, Sigma.shape[0], pack_lower(A), reduce_lanes=reduce_lanes)
 
 
 def pack_lower(M):

@@ -18,24 +18,32 @@ def _same(a, b, what):
     assert len(bad) == 0, "%s: %d mismatches, first at %s" % (what, len(bad), bad[0])
 
 
-@pytest.mark.parametrize("flags_name", ["auto", "generic"])
-@pytest.mark.parametrize("d,W,N", [(3, 10, 16), (50, 130, 12), (5, 257, 20)])
-def test_emcee_corr_gauss_bit_exact(mhx, oracle, d, W, N, flags_name):
+@pytest.mark.parametrize("flags_name,lanes", [("auto", 1), ("generic", 0), ("auto", 0), ("auto", 4), ("auto", 16)])
+@pytest.mark.parametrize("d,W,N", [(3, 10, 16), (50, 130, 12), (5, 257, 20), (17, 64, 9)])
+def test_emcee_corr_gauss_bit_exact(mhx, oracle, d, W, N, flags_name, lanes):
     flags = mhx.FLAG_GENERIC if flags_name == "generic" else 0
+    if lanes > d:
+        pytest.skip("more lanes than dimensions")
     Sig = cases.sigma_ar1(d, 0.9)
     init = cases.emcee_init(d, W, 5)
     model = mhx.DensityModel(mhx.CorrGaussian(Sig))
     spl = mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I)))
     chain = mhx.sample(model, spl, N, seed=21, first_chain=3, initial_params=init, discard_initial=2, thinning=3,
-                       flags=flags)
-    ref = oracle.emcee(oracle.corr_gauss_from_cov(Sig), 2.0, 1, oracle.schedule(N, 2, 3), 21, 3, W, init)
+                       flags=flags, reduce_lanes=lanes)
+    Lx = chain.stats["reduce_lanes"]
+    if lanes >= 1:
+        assert Lx == lanes
+    ref = oracle.emcee(oracle.corr_gauss_from_cov(Sig, reduce_lanes=Lx), 2.0, 1, oracle.schedule(N, 2, 3), 21, 3, W, init)
     _same(chain.value, ref["samples"], "samples")
     _same(chain.accepted, ref["accepted"], "accepted")
     x, lp, cnt = chain.state.state()
     _same(x, ref["final_x"], "final x")
     _same(lp, ref["final_lp"], "final lp")
     _same(cnt, ref["accept_counts"], "accept counts")
-    assert chain.stats["kernel_variant"] == (0 if flags_name == "generic" else 2)
+    if flags_name == "generic":
+        assert chain.stats["kernel_variant"] == 0 and Lx == 1
+    else:
+        assert chain.stats["kernel_variant"] == (4 if Lx > 1 else 2)
 
 
 def test_emcee_golden_trace(mhx):
@@ -43,7 +51,7 @@ def test_emcee_golden_trace(mhx):
     d, W = 3, 10
     model = mhx.DensityModel(mhx.CorrGaussian(cases.sigma_ar1(d, 0.9)))
     spl = mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I)))
-    chain = mhx.sample(model, spl, 16, seed=21, first_chain=0, initial_params=cases.emcee_init(d, W, 5))
+    chain = mhx.sample(model, spl, 16, seed=21, first_chain=0, initial_params=cases.emcee_init(d, W, 5), reduce_lanes=1)
     _same(chain.value, tr["emcee_split/samples"], "samples")
     _same(chain.accepted, tr["emcee_split/accepted"], "accepted")
 
