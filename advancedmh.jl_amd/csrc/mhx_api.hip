@@ -248,7 +248,7 @@ static int target_upload(mhx_target* t, const float* params, size_t nparams)
     const size_t n = nparams ? nparams : 1;
     HIP_TRY(hipMalloc(&t->dparams, n * sizeof(float)));
     if (nparams) HIP_TRY(hipMemcpy(t->dparams, params, nparams * sizeof(float), hipMemcpyHostToDevice));
-    else HIP_TRY(hipMemset(t->dparams, 0, sizeof(float)));
+    else HIP_TRY(hipMemsetAsync(t->dparams, 0, sizeof(float), t->ctx->stream));
     return MHX_OK;
 }
 
@@ -455,9 +455,9 @@ static int run_alloc_state(mhx_run* r)
     HIP_TRY(hipMalloc(&r->d_acc, n * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&r->d_last, n));
     HIP_TRY(hipMalloc(&r->d_acc_total, sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(r->d_acc, 0, n * sizeof(uint32_t)));
-    HIP_TRY(hipMemset(r->d_last, 0, n));
-    HIP_TRY(hipMemset(r->d_acc_total, 0, sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(r->d_acc, 0, n * sizeof(uint32_t), r->ctx->stream));
+    HIP_TRY(hipMemsetAsync(r->d_last, 0, n, r->ctx->stream));
+    HIP_TRY(hipMemsetAsync(r->d_acc_total, 0, sizeof(unsigned long long), r->ctx->stream));
     return MHX_OK;
 }
 
@@ -678,7 +678,7 @@ extern "C" int mhx_run_init(mhx_run* r, const float* initial_params)
     if (rc) return rc;
     r->initialised = true;
     r->tau = 0;
-    HIP_TRY(hipMemset(r->d_acc_total, 0, sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(r->d_acc_total, 0, sizeof(unsigned long long), r->ctx->stream));
     return MHX_OK;
 }
 

@@ -45,6 +45,19 @@ def test_ram_bit_exact(mhx, oracle, d, C, N, warm):
     _same(st, ref["status"], "status")
 
 
+def test_ram_long_run_spans_several_launches(mhx, oracle):
+    """9 000 transitions = three launches; adaptation stops inside the second one."""
+    d, C = 3, 5
+    Sig = cases.sigma_ar1(d, 0.5)
+    init = np.zeros((d, C), dtype=np.float32)
+    chain, S, st, lo, hi, x, lp, cnt = _run(mhx, mhx.DensityModel(mhx.CorrGaussian(Sig)), mhx.RobustAdaptiveMetropolis(),
+                                            3000, C, 5, 0, init, num_warmup=6000, discard_initial=6000)
+    ref = oracle.ram(oracle.corr_gauss_from_cov(Sig), oracle.schedule(3000, 6000, 1, 6000), 5, 0, C, init=init)
+    _same(S, ref["S"], "S")
+    _same(chain.value, ref["samples"], "samples")
+    _same(cnt, ref["accept_counts"], "accept counts")
+
+
 def test_ram_iso_target_random_init_and_custom_factor(mhx, oracle):
     d, C, N = 5, 7, 30
     rng = np.random.default_rng(3)
