@@ -122,14 +122,21 @@ MHX_DEV void mhx_ram_stream_columns(const float* __restrict__ S, const int d, co
     }
 }
 
-// rows of column i owned by this lane, from the ring
+// rows of column i owned by this lane, from the ring.  Row slots entirely above the diagonal
+// (64 (r+1) <= i) are skipped by a wave-uniform test; inside a slot the read is unconditional and the
+// rows above the diagonal are zeroed by a select -- no divergent branches in the column loops.
 template <int R>
 MHX_DEV void mhx_ram_ring_col(const float* ring, const int i, const long off, const int d, const int t, float (&col)[R])
 {
+    const int base = (int)(off & (MHX_RAM_RING - 1)) + (t - i);        // ring index of row t (may be negative: masked)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int row = t + 64 * r;
-        col[r] = (row >= i && row < d) ? ring[(off + (row - i)) & (MHX_RAM_RING - 1)] : 0.0f;
+        col[r] = 0.0f;
+        if (64 * (r + 1) > i) {                                        // wave-uniform
+            const int row = t + 64 * r;
+            const float v = ring[(base + 64 * r) & (MHX_RAM_RING - 1)];
+            col[r] = (row >= i && row < d) ? v : 0.0f;
+        }
     }
 }
 
@@ -146,7 +153,11 @@ MHX_DEV void mhx_ram_matvec(const float* __restrict__ S, const float* ush, const
         const float ui = ush[i];
 #pragma unroll
         for (int r = 0; r < R; ++r)
-            if (t + 64 * r >= i) v[r] = mhx_fma(col[r], ui, v[r]);
+            if (64 * (r + 1) > i) {                                    // wave-uniform
+                // rows above the diagonal carry col == 0: fma(0, u, v) == v bit for bit (v is finite or NaN)
+                const float nv = mhx_fma(col[r], ui, v[r]);
+                v[r] = (t + 64 * r >= i) ? nv : v[r];
+            }
         return true;
     });
 }
@@ -179,25 +190,24 @@ struct mhx_ram_sweep {
     unsigned st;
 };
 
-// rank-1 update (up) / downdate of one column, written to Snew; if `fuse`, the NEXT step's proposal
+// rank-1 update (UP) / downdate of one column, written to Snew; if `fuse`, the NEXT step's proposal
 // mat-vec is accumulated on the fly for both the old and the new factor (the next U is recomputable
 // from the counter RNG), which removes that step's separate read pass over S.
-template <int R>
+template <int R, bool UP>
 MHX_DEV bool mhx_ram_sweep_col(const float (&col)[R], float* __restrict__ Snew, const float* unext, const int i,
-                               const long off, const int d, const int t, const bool up, const bool fuse,
-                               mhx_ram_sweep<R>& sw)
+                               const long off, const int d, const int t, const bool fuse, mhx_ram_sweep<R>& sw)
 {
     const int il = i & 63, ir = i >> 6;
     float aii = 0.0f, bi = 0.0f;
 #pragma unroll
     for (int r = 0; r < R; ++r)
-        if (r == ir) {
+        if (r == ir) {                                                 // wave-uniform
             aii = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, col[r]), il));
             bi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sw.w[r]), il));
         }
     // one reciprocal per column; the per-element divisions of the upstream sweep become multiplications
     float cs, sn, diag, rcs = 0.0f;
-    if (up) {
+    if (UP) {
         const float rr = mhx_sqrt(mhx_fma(bi, bi, aii * aii));
         const float rinv = 1.0f / rr;
         cs = aii * rinv;
@@ -206,32 +216,35 @@ MHX_DEV bool mhx_ram_sweep_col(const float (&col)[R], float* __restrict__ Snew, 
     } else {
         sn = bi / aii;
         const float s2 = sn * sn;
-        if (s2 > 1.0f) { sw.ok = false; sw.st |= 1u; return false; }      // PosDefException upstream
+        if (s2 > 1.0f) { sw.ok = false; sw.st |= 1u; return false; }      // PosDefException upstream (wave-uniform)
         cs = mhx_sqrt(1.0f - s2);
         rcs = 1.0f / cs;
         diag = cs * aii;
     }
     const float un = fuse ? unext[i] : 0.0f;
+    float* dst = Snew + (off - i);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int row = t + 64 * r;
-        if (row < d && row >= i) {
-            float out;
-            if (row == i) {
-                out = diag;
-                sw.nd[r] = diag;
-            } else if (up) {
-                const float Aji = col[r], vj = sw.w[r];
-                out = mhx_fma(cs, Aji, sn * vj);
-                sw.w[r] = mhx_fma(cs, vj, -(sn * Aji));
+        if (64 * (r + 1) > i) {                                        // wave-uniform: slot has rows >= i
+            const int row = t + 64 * r;
+            const bool below = row > i && row < d;
+            const bool ondiag = row == i;
+            const float Aji = col[r], vj = sw.w[r];
+            float oe, wn;
+            if (UP) {
+                oe = mhx_fma(cs, Aji, sn * vj);
+                wn = mhx_fma(cs, vj, -(sn * Aji));
             } else {
-                const float vj = sw.w[r];
-                out = (col[r] - sn * vj) * rcs;
-                sw.w[r] = mhx_fma(cs, vj, -(sn * out));
+                oe = (Aji - sn * vj) * rcs;
+                wn = mhx_fma(cs, vj, -(sn * oe));
             }
-            Snew[off + (row - i)] = out;
+            const float out = ondiag ? diag : (below ? oe : 0.0f);
+            sw.w[r] = below ? wn : vj;
+            sw.nd[r] = ondiag ? diag : sw.nd[r];
+            if (below || ondiag) dst[row] = out;
             if (fuse) {
-                sw.vo[r] = mhx_fma(col[r], un, sw.vo[r]);
+                // rows above the diagonal contribute fma(0, un, v) == v
+                sw.vo[r] = mhx_fma(Aji, un, sw.vo[r]);
                 sw.vn[r] = mhx_fma(out, un, sw.vn[r]);
             }
         }
@@ -347,11 +360,19 @@ MHX_DEV void mhx_ram_body(const mhx_ram_args& a, const float* __restrict__ tpara
                 float nn_next = 0.0f;
                 __syncthreads();                                         // every lane is done with ucur / ysh
                 if (fuse) nn_next = mhx_ram_draw(ks, id_lo, id_hi, step + 1u, d, t, unxt);
-                mhx_ram_stream_columns(Scur, d, t, ring, [&](const int i, const long off) {
-                    float col[R];
-                    mhx_ram_ring_col<R>(ring, i, off, d, t, col);
-                    return mhx_ram_sweep_col<R>(col, Snew, unxt, i, off, d, t, up, fuse, sw);
-                });
+                if (up) {
+                    mhx_ram_stream_columns(Scur, d, t, ring, [&](const int i, const long off) {
+                        float col[R];
+                        mhx_ram_ring_col<R>(ring, i, off, d, t, col);
+                        return mhx_ram_sweep_col<R, true>(col, Snew, unxt, i, off, d, t, fuse, sw);
+                    });
+                } else {
+                    mhx_ram_stream_columns(Scur, d, t, ring, [&](const int i, const long off) {
+                        float col[R];
+                        mhx_ram_ring_col<R>(ring, i, off, d, t, col);
+                        return mhx_ram_sweep_col<R, false>(col, Snew, unxt, i, off, d, t, fuse, sw);
+                    });
+                }
                 st |= sw.st;
                 bool ok = sw.ok;
                 const bool swept = sw.ok;                                // the sweep reached the last column
