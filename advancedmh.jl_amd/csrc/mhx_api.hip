@@ -81,18 +81,31 @@ k_record_state(const float* __restrict__ x, const float* __restrict__ lp, const 
 
 // occupancy target of the cooperative kernel: its point is >= 2 waves per SIMD
 #define MHX_COOP_WAVES(NBL) ((NBL) <= 5 ? 4 : ((NBL) <= 13 ? 2 : 1))
-template <int L, int NBL, int TK, int PK>
+template <int L, int NBL, int TK, int PK, bool MOM>
 __global__ void __launch_bounds__(256, MHX_COOP_WAVES(NBL))
 k_rwmh_coop(const mhx_rwmh_args a, const float* __restrict__ tparams, const float* __restrict__ pvec)
 {
-    mhx_rwmh_coop_body<L, NBL, TK, PK>(a, tparams, pvec);
+    mhx_rwmh_coop_body<L, NBL, TK, PK, MOM>(a, tparams, pvec);
+}
+__global__ void __launch_bounds__(256)
+k_moments_first(const float* __restrict__ x, const float* __restrict__ lp, float* mean, float* m2, const int n,
+                const long ld, const int d)
+{
+    mhx_moments_first_body(x, lp, mean, m2, n, ld, d);
 }
 
-struct prebuilt_coop { int L, NBL, TK, PK; void (*fn)(const mhx_rwmh_args, const float*, const float*); };
+// `fn` records samples, `fn_mom` keeps running moments instead (null: specialised by hiprtc on demand)
+struct prebuilt_coop {
+    int L, NBL, TK, PK;
+    void (*fn)(const mhx_rwmh_args, const float*, const float*);
+    void (*fn_mom)(const mhx_rwmh_args, const float*, const float*);
+};
 static const prebuilt_coop k_prebuilt_coop[] = {
-    {2, 13, MHX_TARGET_ISO_GAUSS, MHX_PROP_ISO, k_rwmh_coop<2, 13, MHX_TARGET_ISO_GAUSS, MHX_PROP_ISO>},
-    {64, 4, MHX_TARGET_FUNNEL, MHX_PROP_ISO, k_rwmh_coop<64, 4, MHX_TARGET_FUNNEL, MHX_PROP_ISO>},
-    {64, 4, MHX_TARGET_BANANA, MHX_PROP_ISO, k_rwmh_coop<64, 4, MHX_TARGET_BANANA, MHX_PROP_ISO>},
+    {2, 13, MHX_TARGET_ISO_GAUSS, MHX_PROP_ISO, k_rwmh_coop<2, 13, MHX_TARGET_ISO_GAUSS, MHX_PROP_ISO, false>, nullptr},
+    {32, 8, MHX_TARGET_FUNNEL, MHX_PROP_ISO, k_rwmh_coop<32, 8, MHX_TARGET_FUNNEL, MHX_PROP_ISO, false>,
+     k_rwmh_coop<32, 8, MHX_TARGET_FUNNEL, MHX_PROP_ISO, true>},
+    {32, 8, MHX_TARGET_BANANA, MHX_PROP_ISO, k_rwmh_coop<32, 8, MHX_TARGET_BANANA, MHX_PROP_ISO, false>,
+     k_rwmh_coop<32, 8, MHX_TARGET_BANANA, MHX_PROP_ISO, true>},
 };
 
 // sum of a u32 array into a u64 (one atomic per block)
@@ -432,6 +445,15 @@ struct mhx_run {
     unsigned char* d_accepted = nullptr;
     size_t samples_cap = 0, accepted_cap = 0;
     int64_t n_saved = 0;
+    // running moments of the last mhx_run_sample(save = 2)
+    float *d_mom_mean = nullptr, *d_mom_m2 = nullptr;
+    size_t mom_cap = 0, mom_cap2 = 0;
+    uint64_t mom_n = 0;                  // states folded in so far
+    bool moments_mode = false;
+    void (*reg_fn_mom)(const mhx_rwmh_args, const float*, const float*) = nullptr;
+    hipFunction_t jit_step_mom = nullptr;
+    std::string coop_key;                // JIT key / defines of the cooperative kernel (for its moments twin)
+    std::vector<std::string> coop_defs;
     // kernel choice
     int coop_L = 1;                      // lanes per chain (reduction shape of the separable targets)
     int variant = 0;
@@ -442,7 +464,7 @@ struct mhx_run {
     ~mhx_run()
     {
         void* ptrs[] = {d_pvec, d_S, d_S2, d_Ssel, d_status, d_dmin, d_dmax, d_eta, d_x, d_lp, d_ybuf,
-                        d_acc, d_last, d_acc_total, d_samples, d_accepted};
+                        d_acc, d_last, d_acc_total, d_samples, d_accepted, d_mom_mean, d_mom_m2};
         for (void* p : ptrs) if (p) (void)hipFree(p);
     }
 };
@@ -473,6 +495,7 @@ static mhx_rwmh_args rwmh_args(const mhx_run* r)
     a.prop_kind = r->prop_kind; a.pscale = r->prop_scale;
     a.save_next = MHX_NO_SAVE; a.thinning = 1;
     a.reduce_lanes = r->coop_L;
+    if (r->moments_mode) { a.mom_mean = r->d_mom_mean; a.mom_m2 = r->d_mom_m2; a.mom_n0 = (mhx_u32)r->mom_n; }
     return a;
 }
 
@@ -533,20 +556,25 @@ extern "C" int mhx_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh
         const int NBL = (nblk + L - 1) / L;
         if (NBL > 16) return fail(MHX_EINVAL, "reduce_lanes=%d leaves %d blocks per lane (max 16)", L, NBL);
         for (const auto& pb : k_prebuilt_coop)
-            if (pb.L == L && pb.NBL == NBL && pb.TK == tk && pb.PK == pk) { r->reg_fn = pb.fn; r->variant = 3; }
+            if (pb.L == L && pb.NBL == NBL && pb.TK == tk && pb.PK == pk) { r->reg_fn = pb.fn; r->reg_fn_mom = pb.fn_mom; r->variant = 3; }
         if (!r->variant && !(r->flags & MHX_FLAG_NO_JIT)) {
             jit_module* m = nullptr;
             const std::string key = "rwmh_coop/l=" + std::to_string(L) + "/nbl=" + std::to_string(NBL) + "/tk=" +
                                     std::to_string(tk) + "/pk=" + std::to_string(pk);
-            rc = jit_compile(ctx, key, jit_source(t, "mhx_rwmh_kernels.h"),
+            rc = jit_compile(ctx, key + "/mom=0", jit_source(t, "mhx_rwmh_kernels.h"),
                              {"MHX_JIT_RWMH_COOP=1", "MHX_JIT_L=" + std::to_string(L), "MHX_JIT_NBL=" + std::to_string(NBL),
-                              "MHX_JIT_TK=" + std::to_string(tk), "MHX_JIT_PK=" + std::to_string(pk)}, &m);
+                              "MHX_JIT_TK=" + std::to_string(tk), "MHX_JIT_PK=" + std::to_string(pk), "MHX_JIT_MOM=0"}, &m);
             if (rc == MHX_OK) rc = jit_function(m, "mhx_jit_rwmh_coop", &r->jit_step);
             if (rc == MHX_OK) r->variant = 4;
             else if (cfg->reduce_lanes > 1) return rc;      // the caller asked for this shape explicitly
         }
-        if (r->variant) r->coop_L = L;
-        else if (cfg->reduce_lanes > 1) return fail(MHX_EINVAL, "reduce_lanes=%d: no pre-built kernel and JIT disabled", L);
+        if (r->variant) {
+            r->coop_L = L;
+            r->coop_key = "rwmh_coop/l=" + std::to_string(L) + "/nbl=" + std::to_string(NBL) + "/tk=" + std::to_string(tk) +
+                          "/pk=" + std::to_string(pk);
+            r->coop_defs = {"MHX_JIT_RWMH_COOP=1", "MHX_JIT_L=" + std::to_string(L), "MHX_JIT_NBL=" + std::to_string(NBL),
+                            "MHX_JIT_TK=" + std::to_string(tk), "MHX_JIT_PK=" + std::to_string(pk), "MHX_JIT_MOM=1"};
+        } else if (cfg->reduce_lanes > 1) return fail(MHX_EINVAL, "reduce_lanes=%d: no pre-built kernel and JIT disabled", L);
     }
     if (!r->variant && !(r->flags & MHX_FLAG_GENERIC)) {
         if (tk != MHX_TARGET_USER)
@@ -624,7 +652,13 @@ static int rwmh_advance(mhx_run* r, uint64_t nsteps, uint32_t save_next, int sav
         if (r->variant == 3 || r->variant == 4) {
             const long threads = (((long)r->n + (64 / r->coop_L) - 1) / (64 / r->coop_L)) * 64;   // whole waves
             const unsigned grid = (unsigned)((threads + 255) / 256);
-            if (r->variant == 3) {
+            if (r->moments_mode && r->reg_fn_mom) {
+                hipLaunchKernelGGL(r->reg_fn_mom, dim3(grid), dim3(256), 0, ctx->stream, a, tp, pv);
+            } else if (r->moments_mode) {
+                void* params[] = {&a, &tp, &pv};
+                int rc = launch_module(r->jit_step_mom, grid, 256, ctx->stream, params);
+                if (rc) return rc;
+            } else if (r->variant == 3) {
                 hipLaunchKernelGGL(r->reg_fn, dim3(grid), dim3(256), 0, ctx->stream, a, tp, pv);
             } else {
                 void* params[] = {&a, &tp, &pv};
@@ -657,6 +691,7 @@ static int rwmh_advance(mhx_run* r, uint64_t nsteps, uint32_t save_next, int sav
                 const uint64_t k = (last - save_next) / (uint64_t)thinning + 1;
                 save_next += (uint32_t)(k * (uint64_t)thinning);
                 save_slot += (int)k;
+                if (r->moments_mode) r->mom_n += k;
             }
         }
         r->tau += chunk;
@@ -735,7 +770,37 @@ extern "C" int mhx_run_sample(mhx_run* r, const mhx_schedule* s, int save_sample
     uint32_t save_next = MHX_NO_SAVE;
     int save_slot = 0;
     r->n_saved = 0;
-    if (save_samples) {
+    r->moments_mode = false;
+    if (save_samples == MHX_SAVE_MOMENTS) {
+        // running moments instead of a sample tensor
+        if (r->kind != RUN_RWMH || (r->variant != 0 && r->variant != 3 && r->variant != 4))
+            return fail(MHX_EINVAL, "running moments need an RWMH run on the cooperative or the generic kernel "
+                                    "(separable target, or MHX_FLAG_GENERIC); this run uses kernel variant %d", r->variant);
+        if (((r->variant == 3 && !r->reg_fn_mom) || r->variant == 4) && !r->jit_step_mom) {
+            jit_module* m = nullptr;
+            int rcj = jit_compile(ctx, r->coop_key + "/mom=1", jit_source(r->target, "mhx_rwmh_kernels.h"), r->coop_defs, &m);
+            if (rcj == MHX_OK) rcj = jit_function(m, "mhx_jit_rwmh_coop", &r->jit_step_mom);
+            if (rcj) return rcj;
+        }
+        const size_t bytes = ((size_t)r->dim + 1) * (size_t)r->n * sizeof(float);
+        int rc = ensure_buffer((void**)&r->d_mom_mean, &r->mom_cap, bytes);
+        if (rc) return rc;
+        rc = ensure_buffer((void**)&r->d_mom_m2, &r->mom_cap2, bytes);
+        if (rc) return rc;
+        r->moments_mode = true;
+        r->mom_n = 0;
+        r->n_saved = s->n_samples;
+        if (s->discard_initial == 0) {
+            const unsigned grid = (unsigned)((r->n + 255) / 256);
+            hipLaunchKernelGGL(k_moments_first, dim3(grid), dim3(256), 0, ctx->stream, r->d_x, r->d_lp, r->d_mom_mean,
+                               r->d_mom_m2, r->n, (long)r->n, r->dim);
+            HIP_TRY(hipGetLastError());
+            r->mom_n = 1;
+            save_next = s->n_samples > 1 ? (uint32_t)(r->tau + (uint64_t)s->thinning) : MHX_NO_SAVE;
+        } else {
+            save_next = (uint32_t)(r->tau + (uint64_t)s->discard_initial);
+        }
+    } else if (save_samples) {
         const size_t N = (size_t)s->n_samples, n = (size_t)r->n, d1 = (size_t)r->dim + 1;
         int rc = ensure_buffer((void**)&r->d_samples, &r->samples_cap, N * d1 * n * sizeof(float));
         if (rc) return rc;
@@ -781,7 +846,8 @@ extern "C" int mhx_run_sample(mhx_run* r, const mhx_schedule* s, int save_sample
 extern "C" int mhx_run_get_samples(mhx_run* r, float* samples, uint8_t* accepted)
 {
     if (!r) return fail(MHX_EINVAL, "mhx_run_get_samples: run is NULL");
-    if (r->n_saved <= 0) return fail(MHX_ESTATE, "mhx_run_get_samples: the last mhx_run_sample saved nothing");
+    if (r->n_saved <= 0 || r->moments_mode)
+        return fail(MHX_ESTATE, "mhx_run_get_samples: the last mhx_run_sample kept no sample tensor");
     HIP_TRY(hipSetDevice(r->ctx->device));
     const size_t N = (size_t)r->n_saved, n = (size_t)r->n, d1 = (size_t)r->dim + 1;
     if (samples) HIP_TRY(hipMemcpy(samples, r->d_samples, N * d1 * n * sizeof(float), hipMemcpyDeviceToHost));

@@ -66,3 +66,29 @@ MHX_DEV void mhx_diag_autocov_body(const float* __restrict__ samples, const long
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     if (threadIdx.x == 0) atomicAdd(&acov[k * d1 + p], acc);
 }
+
+// the same three sums from running moments (runs that kept no sample tensor): m_c = mean, s2_c = M2/(n-1)
+MHX_DEV void mhx_diag_from_moments_body(const float* __restrict__ mom_mean, const float* __restrict__ mom_m2,
+                                        const long nsamp, const int d1, const long C, double* __restrict__ sums,
+                                        double* red)
+{
+    const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int p = blockIdx.y;
+    double m = 0.0, v = 0.0;
+    if (c < C) {
+        m = (double)mom_mean[(long)p * C + c];
+        v = nsamp > 1 ? (double)mom_m2[(long)p * C + c] / (double)(nsamp - 1) : 0.0;
+    }
+    double vals[3] = {c < C ? m : 0.0, c < C ? m * m : 0.0, c < C ? v : 0.0};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        double x = vals[q];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if ((threadIdx.x & 63) == 0) red[q * 4 + (threadIdx.x >> 6)] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const double x = red[threadIdx.x * 4] + red[threadIdx.x * 4 + 1] + red[threadIdx.x * 4 + 2] + red[threadIdx.x * 4 + 3];
+        atomicAdd(&sums[(long)threadIdx.x * d1 + p], x);
+    }
+}

@@ -49,7 +49,20 @@ struct mhx_rwmh_args {
     int save_slot;            // its slot in `samples`
     int thinning;
     int reduce_lanes;         // reduction shape of the separable targets (lanes per chain), >= 1
+    // running moments instead of a sample tensor (runs too large to store): per chain and parameter the
+    // Welford mean / M2 over the states the schedule would have recorded
+    float* mom_mean;          // [dim+1][ld] or null
+    float* mom_m2;            // [dim+1][ld]
+    mhx_u32 mom_n0;           // states already folded in before this launch
 };
+
+// one Welford step with the wave-uniform 1/n
+MHX_DEV void mhx_welford(float x, float rn, float& mean, float& m2)
+{
+    const float delta = x - mean;
+    mean = mhx_fma(delta, rn, mean);
+    m2 = mhx_fma(delta, x - mean, m2);
+}
 
 // ---------------------------------------------------------------------------------------------
 template <int D, int TK, int PK>
@@ -166,6 +179,7 @@ MHX_DEV void mhx_rwmh_generic_body(const mhx_rwmh_args& a, const float* __restri
     ac.w.x = ac.w.y = ac.w.z = ac.w.w = 0u;
     mhx_u32 save_next = a.save_next;
     long slot = a.save_slot;
+    mhx_u32 mom_n = a.mom_n0;
     const int nblk = (d + 3) >> 2;
 
     for (int i = 0; i < a.nsteps; ++i) {
@@ -206,7 +220,27 @@ MHX_DEV void mhx_rwmh_generic_body(const mhx_rwmh_args& a, const float* __restri
         nacc += acc ? 1u : 0u;
         last = acc;
         wave_acc += (mhx_u32)__popcll(__ballot(acc));
-        if (step == save_next) {
+        if (a.mom_mean && step == save_next) {
+            // running moments kept in HBM (this kernel's state lives there anyway)
+            ++mom_n;
+            const float rn = 1.0f / (float)mom_n;
+            const bool first = mom_n == 1u;
+            for (int k = 0; k <= d; ++k) {
+                float v;
+                if (k < d) {
+                    v = acc ? ys[(long)k * ld] : xs[(long)k * ld];
+                    if (acc) xs[(long)k * ld] = v;
+                } else {
+                    v = lp;
+                }
+                float mean = first ? 0.0f : a.mom_mean[(long)k * ld + c];
+                float m2v = first ? 0.0f : a.mom_m2[(long)k * ld + c];
+                mhx_welford(v, rn, mean, m2v);
+                a.mom_mean[(long)k * ld + c] = mean;
+                a.mom_m2[(long)k * ld + c] = m2v;
+            }
+            save_next += (mhx_u32)a.thinning;
+        } else if (step == save_next) {
             float* row = a.samples + slot * (long)(d + 1) * ld + c;
             for (int k = 0; k < d; ++k) {
                 const float v = acc ? ys[(long)k * ld] : xs[(long)k * ld];
@@ -241,7 +275,7 @@ MHX_DEV void mhx_rwmh_generic_body(const mhx_rwmh_args& a, const float* __restri
 //   - large d (1000): L = 64 is wave-per-chain, the whole state (4 VGPRs per 256 dimensions) stays
 //     in registers across a launch and nothing is streamed from HBM but the recorded samples.
 // The reduction shape L is part of the arithmetic spec (the oracle takes the same L).
-template <int L, int NBL, int TK, int PK>
+template <int L, int NBL, int TK, int PK, bool MOM>
 MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const float* __restrict__ tparams,
                                 const float* __restrict__ pvec)
 {
@@ -284,6 +318,21 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const float* __restrict_
     ac.w.x = ac.w.y = ac.w.z = ac.w.w = 0u;
     mhx_u32 save_next = a.save_next;
     long slot = a.save_slot;
+    // running moments (MOM): continue the Welford recursion of the previous launches
+    float mm[MOM ? NBL : 1][4], m2[MOM ? NBL : 1][4], lpm = 0.0f, lpm2 = 0.0f;
+    mhx_u32 mom_n = a.mom_n0;
+    if (MOM) {
+#pragma unroll
+        for (int i = 0; i < NBL; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool in = (i < NBL - 1) || (k_last + j < d);
+                const long e = (long)(4 * L * i + j) * ld;
+                mm[i][j] = (in && mom_n) ? mhx_ld_off(a.mom_mean + e, lane_off) : 0.0f;
+                m2[i][j] = (in && mom_n) ? mhx_ld_off(a.mom_m2 + e, lane_off) : 0.0f;
+            }
+        if (mom_n) { lpm = a.mom_mean[(long)d * ld + c]; lpm2 = a.mom_m2[(long)d * ld + c]; }
+    }
 
     for (int it = 0; it < a.nsteps; ++it) {
         const mhx_u32 step = a.step0 + (mhx_u32)it;
@@ -346,7 +395,16 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const float* __restrict_
         nacc += acc ? 1u : 0u;
         last = acc;
         wave_acc += (mhx_u32)__popcll(__ballot(acc && valid && l == 0));
-        if (step == save_next) {
+        if (MOM && step == save_next) {
+            ++mom_n;
+            const float rn = 1.0f / (float)mom_n;
+#pragma unroll
+            for (int i = 0; i < NBL; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mhx_welford(x[i][j], rn, mm[i][j], m2[i][j]);
+            mhx_welford(lp, rn, lpm, lpm2);
+            save_next += (mhx_u32)a.thinning;
+        } else if (step == save_next) {
             if (valid) {
                 float* slotp = a.samples + slot * (long)(d + 1) * ld;
                 const mhx_srd srd = mhx_make_srd(slotp, (mhx_u32)(d + 1) * (mhx_u32)ld * 4u);
@@ -381,6 +439,17 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const float* __restrict_
             a.lp[c] = lp;
             a.acc_count[c] = nacc;
             a.last_acc[c] = last ? 1 : 0;
+        }
+        if (MOM) {
+#pragma unroll
+            for (int i = 0; i < NBL; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool in = (i < NBL - 1) || (k_last + j < d);
+                    const long e = (long)(4 * L * i + j) * ld;
+                    if (in) { mhx_st_off(a.mom_mean + e, lane_off, mm[i][j]); mhx_st_off(a.mom_m2 + e, lane_off, m2[i][j]); }
+                }
+            if (l == 0) { a.mom_mean[(long)d * ld + c] = lpm; a.mom_m2[(long)d * ld + c] = lpm2; }
         }
     }
     if (lane == 0) atomicAdd(a.acc_total, (mhx_u64)wave_acc);
@@ -460,6 +529,17 @@ MHX_DEV void mhx_record_state_body(const float* __restrict__ x, const float* __r
     accepted[slot * ld + c] = last_acc[c];
 }
 
+// first folded sample = the current state (discard_initial == 0): mean = state, M2 = 0
+MHX_DEV void mhx_moments_first_body(const float* __restrict__ x, const float* __restrict__ lp, float* mean, float* m2,
+                                    const int n, const long ld, const int d)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    for (int k = 0; k < d; ++k) { mean[(long)k * ld + c] = x[(long)k * ld + c]; m2[(long)k * ld + c] = 0.0f; }
+    mean[(long)d * ld + c] = lp[c];
+    m2[(long)d * ld + c] = 0.0f;
+}
+
 // JIT entry points: hiprtc compiles this header with the specialisation macros defined
 #ifdef MHX_JIT_RWMH_REG
 extern "C" __global__ void __launch_bounds__(64)
@@ -472,7 +552,7 @@ mhx_jit_rwmh_reg(const mhx_rwmh_args a, const float* __restrict__ tparams, const
 extern "C" __global__ void __launch_bounds__(256, (MHX_JIT_NBL) <= 5 ? 4 : ((MHX_JIT_NBL) <= 13 ? 2 : 1))
 mhx_jit_rwmh_coop(const mhx_rwmh_args a, const float* __restrict__ tparams, const float* __restrict__ pvec)
 {
-    mhx_rwmh_coop_body<MHX_JIT_L, MHX_JIT_NBL, MHX_JIT_TK, MHX_JIT_PK>(a, tparams, pvec);
+    mhx_rwmh_coop_body<MHX_JIT_L, MHX_JIT_NBL, MHX_JIT_TK, MHX_JIT_PK, (MHX_JIT_MOM != 0)>(a, tparams, pvec);
 }
 #endif
 #ifdef MHX_JIT_RWMH_GENERIC

@@ -414,8 +414,10 @@ class Run:
         L.check(L.lib().mhx_run_init(self.h, L.fptr(ip)))
 
     def sample(self, n_samples, discard_initial=0, thinning=1, num_warmup=0, save=True):
+        """save: True/1 sample tensor, False/0 nothing, "moments"/2 running moments only (mhx.h)."""
         s = L.Schedule(n_samples, discard_initial, thinning, num_warmup)
-        L.check(L.lib().mhx_run_sample(self.h, C.byref(s), 1 if save else 0))
+        mode = 2 if (isinstance(save, str) and save == "moments") or (save is not True and save == 2) else (1 if save else 0)
+        L.check(L.lib().mhx_run_sample(self.h, C.byref(s), mode))
 
     def samples(self, want_accepted=True):
         n_saved = C.c_int64()

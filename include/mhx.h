@@ -155,6 +155,13 @@ int mhx_ram_get_diag_range(mhx_run *run, float *diag_min, float *diag_max);
  * mhx_run_sample == the mcmcsample loop + bundle_samples into the device sample buffer.  It may be
  * called repeatedly; each call continues the chains (counter-based RNG => resumable). */
 int mhx_run_init(mhx_run *run, const float *initial_params /* host [dim][nchains] or NULL */);
+/* save_samples: 0 = keep nothing, 1 = sample tensor, 2 = running moments only (per chain and parameter the
+ * mean / M2 of the states the schedule selects; for runs whose sample tensor would not fit, e.g.
+ * 262 144 chains x 1000 dims -- mhx_run_diagnostics then works from the moments; RWMH on the cooperative or
+ * generic kernel) */
+#define MHX_SAVE_NONE 0
+#define MHX_SAVE_SAMPLES 1
+#define MHX_SAVE_MOMENTS 2
 int mhx_run_sample(mhx_run *run, const mhx_schedule *sched, int save_samples);
 
 /* copy the sample buffer of the last mhx_run_sample to the host (either pointer may be NULL) */
