@@ -533,32 +533,24 @@ int orc_emcee(const orc_target *t, float a, int mode, const orc_schedule *s,
 #define SIDX(i, j) ((size_t)(i) * ((size_t)(i) + 1) / 2 + (size_t)(j))
 int orc_chol_rank1(float *S, float *w, int d, int sign)
 {
+    /* One sweep for both signs (the textbook rank-one modification; for sigma = -1 it is the upstream
+     * lowrankdowndate! loop, for sigma = +1 it equals the upstream Givens form algebraically):
+     *   s = w_i / S_ii,  c = sqrt(1 + sigma s^2),  S_ii <- c S_ii,
+     *   S_ji <- (S_ji + sigma s w_j) / c,  w_j <- c w_j - s S_ji(new)            (spec 3.9) */
+    const float sg = sign > 0 ? 1.0f : -1.0f;
     for (int i = 0; i < d; ++i) {
         const float a = S[SIDX(i, i)], b = w[i];
-        float c, sn;
-        if (sign > 0) {
-            float r = sqrtf(fmaf(b, b, a * a));
-            float rinv = 1.0f / r;                       /* one reciprocal per column (spec 3.9) */
-            c = a * rinv; sn = b * rinv;
-            S[SIDX(i, i)] = r;
-            for (int j = i + 1; j < d; ++j) {
-                float Aji = S[SIDX(j, i)], vj = w[j];
-                S[SIDX(j, i)] = fmaf(c, Aji, sn * vj);
-                w[j] = fmaf(c, vj, -(sn * Aji));
-            }
-        } else {
-            sn = b / a;
-            float s2 = sn * sn;
-            if (s2 > 1.0f) return i + 1;                 /* PosDefException(i) upstream */
-            c = sqrtf(1.0f - s2);
-            const float rc = 1.0f / c;
-            S[SIDX(i, i)] = c * a;
-            for (int j = i + 1; j < d; ++j) {
-                float vj = w[j];
-                float Aji = (S[SIDX(j, i)] - sn * vj) * rc;
-                S[SIDX(j, i)] = Aji;
-                w[j] = fmaf(c, vj, -(sn * Aji));
-            }
+        const float sn = b / a;
+        if (sign < 0 && sn * sn > 1.0f) return i + 1;   /* PosDefException(i) upstream */
+        const float ss = sg * sn;
+        const float c = sqrtf(fmaf(ss, sn, 1.0f));
+        const float rc = 1.0f / c;                        /* one reciprocal per column */
+        S[SIDX(i, i)] = c * a;
+        for (int j = i + 1; j < d; ++j) {
+            const float vj = w[j];
+            const float Aji = fmaf(ss, vj, S[SIDX(j, i)]) * rc;
+            S[SIDX(j, i)] = Aji;
+            w[j] = fmaf(c, vj, -(sn * Aji));
         }
     }
     return 0;
