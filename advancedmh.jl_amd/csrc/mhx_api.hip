@@ -20,6 +20,7 @@
 #include "mhx_rwmh_kernels.h"
 #include "mhx_emcee_kernels.h"
 #include "mhx_ram_kernels.h"
+#include "mhx_mala_kernels.h"
 #include "mhx_diag_kernels.h"
 #include "mhx_jit_embed.inc"   // generated: the device headers as string literals for hiprtc
 
@@ -182,10 +183,10 @@ static int jit_compile(mhx_ctx* ctx, const std::string& key, const std::string& 
     if (it != ctx->jit.end()) { *out = it->second.get(); return MHX_OK; }
     hiprtcProgram prog = nullptr;
     const char* hdr_src[] = {k_src_mhx_device_math_h, k_src_mhx_targets_h, k_src_mhx_rwmh_kernels_h,
-                             k_src_mhx_emcee_kernels_h, k_src_mhx_ram_kernels_h};
+                             k_src_mhx_emcee_kernels_h, k_src_mhx_ram_kernels_h, k_src_mhx_mala_kernels_h};
     const char* hdr_name[] = {"mhx_device_math.h", "mhx_targets.h", "mhx_rwmh_kernels.h",
-                              "mhx_emcee_kernels.h", "mhx_ram_kernels.h"};
-    hiprtcResult r = hiprtcCreateProgram(&prog, source.c_str(), "mhx_jit.hip", 5, hdr_src, hdr_name);
+                              "mhx_emcee_kernels.h", "mhx_ram_kernels.h", "mhx_mala_kernels.h"};
+    hiprtcResult r = hiprtcCreateProgram(&prog, source.c_str(), "mhx_jit.hip", 6, hdr_src, hdr_name);
     if (r != HIPRTC_SUCCESS) return fail(MHX_EJIT, "hiprtcCreateProgram: %s", hiprtcGetErrorString(r));
     std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
     for (auto& d : defines) opts.push_back("-D" + d);
@@ -411,7 +412,7 @@ extern "C" int mhx_target_eval(mhx_ctx* ctx, const mhx_target* t, const float* x
 
 // ---------------------------------------------------------------------------------------------
 // runs
-enum run_kind { RUN_RWMH = 0, RUN_EMCEE = 1, RUN_RAM = 2 };
+enum run_kind { RUN_RWMH = 0, RUN_EMCEE = 1, RUN_RAM = 2, RUN_MALA = 3 };
 
 struct mhx_run {
     mhx_ctx* ctx = nullptr;
@@ -428,6 +429,9 @@ struct mhx_run {
     float* d_pvec = nullptr;
     // emcee
     float stretch = 2.0f;
+    // mala
+    float mala_sigma = 1.0f;
+    float *d_gx = nullptr, *d_gy = nullptr, *d_z = nullptr;
     // ram
     mhx_ram_cfg ramcfg{};
     float *d_S = nullptr, *d_S2 = nullptr;       // packed factors (current / scratch), [n][tri] each
@@ -465,7 +469,7 @@ struct mhx_run {
     ~mhx_run()
     {
         void* ptrs[] = {d_pvec, d_S, d_S2, d_Ssel, d_status, d_dmin, d_dmax, d_eta, d_x, d_lp, d_ybuf,
-                        d_acc, d_last, d_acc_total, d_samples, d_accepted, d_mom_mean, d_mom_m2};
+                        d_acc, d_last, d_acc_total, d_samples, d_accepted, d_mom_mean, d_mom_m2, d_gx, d_gy, d_z};
         for (void* p : ptrs) if (p) (void)hipFree(p);
     }
 };
@@ -611,6 +615,9 @@ static int emcee_init(mhx_run* r, const float* init);
 static int emcee_advance(mhx_run* r, uint64_t nsteps, uint32_t save_next, int save_slot, int thinning);
 static int ram_init(mhx_run* r, const float* init);
 static int ram_advance(mhx_run* r, uint64_t nsteps, uint64_t n_adapt, uint32_t save_next, int save_slot, int thinning);
+static int mala_init(mhx_run* r, const float* init);
+static int mala_eval_state(mhx_run* r, int reset_counts);
+static int mala_advance(mhx_run* r, uint64_t nsteps, uint32_t save_next, int save_slot, int thinning);
 
 static int rwmh_init(mhx_run* r, const float* init)
 {
@@ -709,6 +716,7 @@ extern "C" int mhx_run_init(mhx_run* r, const float* initial_params)
     switch (r->kind) {
     case RUN_RWMH: rc = rwmh_init(r, initial_params); break;
     case RUN_EMCEE: rc = emcee_init(r, initial_params); break;
+    case RUN_MALA: rc = mala_init(r, initial_params); break;
     default: rc = ram_init(r, initial_params); break;
     }
     if (rc) return rc;
@@ -827,6 +835,7 @@ extern "C" int mhx_run_sample(mhx_run* r, const mhx_schedule* s, int save_sample
         switch (r->kind) {
         case RUN_RWMH: rc = rwmh_advance(r, nT, save_next, save_slot, s->thinning); break;
         case RUN_EMCEE: rc = emcee_advance(r, nT, save_next, save_slot, s->thinning); break;
+        case RUN_MALA: rc = mala_advance(r, nT, save_next, save_slot, s->thinning); break;
         default: rc = ram_advance(r, nT, nA, save_next, save_slot, s->thinning); break;
         }
     }
@@ -885,6 +894,7 @@ extern "C" int mhx_run_set_state(mhx_run* r, const float* x)
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t n = (size_t)r->n, d = (size_t)r->dim;
     HIP_TRY(hipMemcpy(r->d_x, x, d * n * sizeof(float), hipMemcpyHostToDevice));
+    if (r->kind == RUN_MALA) return mala_eval_state(r, 0);   // src/MALA.jl:27-35: lp and gradient are recomputed
     // lp is a cache of logdensity(model, x) (src/AdvancedMH.jl:75): recompute it
     const unsigned grid = (unsigned)((r->n + 255) / 256);
     int nn = r->n, dd = r->dim, kind = r->target->kind, np = r->target->nparams, lanes = r->coop_L;
@@ -925,4 +935,5 @@ extern "C" int mhx_run_destroy(mhx_run* r)
 
 #include "mhx_api_emcee.inc"
 #include "mhx_api_ram.inc"
+#include "mhx_api_mala.inc"
 #include "mhx_api_diag.inc"

@@ -27,6 +27,12 @@ __device__ __forceinline__ mhx_u32 mhx_f2u_fwd(float f) { return __builtin_bit_c
     MHX_DEV float mhx_user_logdensity(const MHX_X& x, const int d, const float* __restrict__ data, \
                                       const int ndata)
 
+// a user gradient in HIP source form: writes g.set(k, dlp/dx_k) and returns lp
+#define MHX_LOGDENSITY_AND_GRADIENT(x, g, d, data, ndata)                                                       \
+    template <class MHX_X, class MHX_G>                                                                         \
+    MHX_DEV float mhx_user_logdensity_and_gradient(const MHX_X& x, const MHX_G& g, const int d,                 \
+                                                   const float* __restrict__ data, const int ndata)
+
 // wave-uniform base pointer + 32-bit per-lane BYTE offset: lowers to the scalar-base addressing mode
 // (global_load/store v_off, ..., s[base:base+1]) instead of a 64-bit vector address per access
 MHX_DEV float mhx_ld_off(const float* base, mhx_u32 byte_off)

@@ -1,0 +1,240 @@
+// mhx_mala_kernels.h -- Metropolis-adjusted Langevin, one wavefront lane per chain.
+//
+// Replaces MALA's step (src/MALA.jl:54-93) with the standard Langevin proposal
+// g -> MvNormal((sigma2/2) g, sigma2 I) used by the reference's tests (test/runtests.jl:291,352):
+//   y = x + (sigma2/2) grad(x) + sigma z
+//   logratio = q(prop(grad y), x, y) - q(prop(grad x), y, x) = 1/2 |z|^2 - 1/2 |z + (sigma/2)(grad x + grad y)|^2
+//   accept iff -randexp < lp(y) - lp(x) + logratio
+// The gradient the reference gets from ForwardDiff / LogDensityProblems (ext/AdvancedMHForwardDiffExt.jl,
+// src/MALA.jl:100-105) is analytic here for the catalogue targets, and supplied as HIP source
+// (MHX_LOGDENSITY_AND_GRADIENT) for user models.  State x and grad(x) live in HBM as [dim][nchains]
+// (chain fastest, coalesced); candidate, its gradient and the noise go through scratch slabs.
+#pragma once
+#include "mhx_targets.h"
+
+// read/write view of one chain's column inside a [dim][ld] slab
+struct mhx_strided_rw {
+    float* base;
+    long ld;
+    MHX_DEV float operator[](int k) const { return base[(long)k * ld]; }
+    MHX_DEV void set(int k, float v) const { base[(long)k * ld] = v; }
+};
+
+// value and gradient of the catalogue targets; same accumulation order as mhx_target_eval
+template <int KIND, class X, class GO>
+MHX_DEV float mhx_target_grad(int kind, const X& x, const GO& g, const int d, const float* __restrict__ p,
+                              const int np, const float cst)
+{
+    const int k_ = (KIND == MHX_TARGET_DYNAMIC) ? kind : KIND;
+    switch (k_) {
+    case MHX_TARGET_ISO_GAUSS: {
+        float q = 0.0f;
+        for (int k = 0; k < d; ++k) { const float v = x[k]; q = mhx_fma(v, v, q); g.set(k, -v); }
+        return mhx_fma(-0.5f, q, cst);
+    }
+    case MHX_TARGET_CORR_GAUSS: {                      // grad = -A^T (A x)
+        float q = 0.0f;
+        int off = 0;
+        for (int i = 0; i < d; ++i) {                  // w = A x, parked in g
+            float w = 0.0f;
+            for (int j = 0; j <= i; ++j) w = mhx_fma(p[off + j], x[j], w);
+            g.set(i, w);
+            q = mhx_fma(w, w, q);
+            off += i + 1;
+        }
+        for (int j = 0; j < d; ++j) {                  // g_j = -sum_{i>=j} A_ij w_i (ascending i), in place
+            float acc = 0.0f;
+            for (int i = j; i < d; ++i) acc = mhx_fma(p[(long)i * (i + 1) / 2 + j], g[i], acc);
+            g.set(j, -acc);
+        }
+        return mhx_fma(-0.5f, q, cst);
+    }
+    case MHX_TARGET_IID_NORMAL: {
+        const float mu = x[0], sigma = x[1];
+        if (!(sigma > 0.0f)) { g.set(0, 0.0f); g.set(1, 0.0f); return -MHX_INF; }
+        const float inv = 1.0f / sigma;
+        float acc = 0.0f, s1 = 0.0f;
+        for (int i = 0; i < np; ++i) {
+            const float z = (p[i] - mu) / sigma;
+            acc = mhx_fma(z, z, acc);
+            s1 = s1 + z;
+        }
+        const float nf = (float)np;
+        g.set(0, s1 * inv);
+        g.set(1, (acc - nf) * inv);
+        const float tt = mhx_log(sigma) + MHX_HALF_LOG_2PI;
+        return mhx_fma(-0.5f, acc, -(nf * tt));
+    }
+    case MHX_TARGET_BANANA: {
+        const float b = p[0];
+        const float x0 = x[0];
+        float q = (x0 * x0) * 0.01f;
+        const float u = mhx_fma(b, mhx_fma(x0, x0, -100.0f), x[1]);
+        q = mhx_fma(u, u, q);
+        g.set(0, -(mhx_fma(x0, 0.01f, (2.0f * b) * (u * x0))));
+        g.set(1, -u);
+        for (int k = 2; k < d; ++k) { const float v = x[k]; q = mhx_fma(v, v, q); g.set(k, -v); }
+        return mhx_fma(-0.5f, q, cst);
+    }
+    case MHX_TARGET_FUNNEL: {
+        const float v = x[0];
+        float q = 0.0f;
+        for (int k = 1; k < d; ++k) { const float xk = x[k]; q = mhx_fma(xk, xk, q); }
+        const float ev = mhx_exp(-v);
+        float r = (v * v) * 0x1.c71c72p-5f;
+        r = mhx_fma(0.5f * (float)(d - 1), v, r);
+        r = mhx_fma(0.5f * ev, q, r);
+        g.set(0, mhx_fma(0.5f * ev, q, -(mhx_fma(v, 0x1.c71c72p-4f, 0.5f * (float)(d - 1)))));
+        for (int k = 1; k < d; ++k) g.set(k, -(ev * x[k]));
+        return cst - r;
+    }
+#ifdef MHX_HAVE_USER_TARGET
+    case MHX_TARGET_USER:
+        return mhx_user_logdensity_and_gradient(x, g, d, p, np);
+#endif
+    default:
+        return MHX_NAN;
+    }
+}
+
+struct mhx_mala_args {
+    float* x;                 // [dim][ld]
+    float* gx;                // [dim][ld] gradient at x (GradientTransition.gradient, src/MALA.jl:14-19)
+    float* lp;
+    mhx_u32* acc_count;
+    mhx_u64* acc_total;
+    float* samples;
+    unsigned char* accepted;
+    unsigned char* last_acc;
+    float* ybuf;              // [dim][ld] candidate
+    float* gybuf;             // [dim][ld] gradient at the candidate
+    float* zbuf;              // [dim][ld] proposal noise
+    mhx_u64 seed;
+    mhx_u64 first_chain;
+    int nchains;
+    int ld;
+    int dim;
+    int target_kind;
+    int ntparams;
+    float tconst;
+    float sigma;              // sqrt(sigma2)
+    float h;                  // sigma2 / 2
+    float hs;                 // sigma / 2
+    mhx_u32 step0;
+    int nsteps;
+    mhx_u32 save_next;
+    int save_slot;
+    int thinning;
+};
+
+template <int TK>
+MHX_DEV void mhx_mala_body(const mhx_mala_args& a, const float* __restrict__ tparams)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.nchains) return;
+    const mhx_u64 id = a.first_chain + (mhx_u64)c;
+    const mhx_u32 id_lo = (mhx_u32)id, id_hi = (mhx_u32)(id >> 32);
+    const mhx_philox_key ks = mhx_philox_schedule(a.seed);
+    const long ld = a.ld;
+    const int d = a.dim;
+    float* xs = a.x + c;
+    float* gs = a.gx + c;
+    float* ys = a.ybuf + c;
+    float* zs = a.zbuf + c;
+    mhx_strided_rw gy;
+    gy.base = a.gybuf + c;
+    gy.ld = ld;
+    mhx_strided_x yv;
+    yv.base = ys;
+    yv.ld = ld;
+
+    float lp = a.lp[c];
+    mhx_u32 nacc = a.acc_count[c];
+    mhx_u32 wave_acc = 0;
+    bool last = a.last_acc[c] != 0;
+    mhx_accept_cache ac;
+    ac.group = 0xffffffffu;
+    ac.w.x = ac.w.y = ac.w.z = ac.w.w = 0u;
+    mhx_u32 save_next = a.save_next;
+    long slot = a.save_slot;
+    const int nblk = (d + 3) >> 2;
+
+    for (int it = 0; it < a.nsteps; ++it) {
+        const mhx_u32 step = a.step0 + (mhx_u32)it;
+        // ---- propose (src/MALA.jl:70): y = x + (sigma2/2) grad(x) + sigma z
+        float fwd = 0.0f;
+        for (int b = 0; b < nblk; ++b) {
+            float n[4];
+            mhx_normal4(ks, id_lo, id_hi, step, MHX_STREAM_PROPOSAL, (mhx_u32)b, n);
+            for (int j = 0; j < 4; ++j) {
+                const int k = 4 * b + j;
+                if (k < d) {
+                    const float z = n[j];
+                    ys[(long)k * ld] = mhx_fma(a.sigma, z, mhx_fma(a.h, gs[(long)k * ld], xs[(long)k * ld]));
+                    zs[(long)k * ld] = z;
+                    fwd = mhx_fma(z, z, fwd);
+                }
+            }
+        }
+        // ---- value and gradient at the candidate (:73-75)
+        const float lpy = mhx_target_grad<TK>(a.target_kind, yv, gy, d, tparams, a.ntparams, a.tconst);
+        // ---- log ratio of the proposal densities (:78-80)
+        float bwd = 0.0f;
+        for (int k = 0; k < d; ++k) {
+            const float tk = mhx_fma(a.hs, gs[(long)k * ld] + gy[k], zs[(long)k * ld]);
+            bwd = mhx_fma(tk, tk, bwd);
+        }
+        const float loga = (lpy - lp) + 0.5f * (fwd - bwd);              // :83
+        const float logu = mhx_accept_logu(ks, id_lo, id_hi, step, ac);
+        const bool acc = logu < loga;                                    // :86 (strict)
+        if (acc) {
+            for (int k = 0; k < d; ++k) { xs[(long)k * ld] = ys[(long)k * ld]; gs[(long)k * ld] = gy[k]; }
+            lp = lpy;
+        }
+        nacc += acc ? 1u : 0u;
+        last = acc;
+        wave_acc += (mhx_u32)__popcll(__ballot(acc));
+        if (step == save_next) {
+            float* row = a.samples + slot * (long)(d + 1) * ld + c;
+            for (int k = 0; k < d; ++k) row[(long)k * ld] = xs[(long)k * ld];
+            row[(long)d * ld] = lp;
+            a.accepted[slot * ld + c] = acc ? 1 : 0;
+            save_next += (mhx_u32)a.thinning;
+            ++slot;
+        }
+    }
+    a.lp[c] = lp;
+    a.acc_count[c] = nacc;
+    a.last_acc[c] = last ? 1 : 0;
+    if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u)
+        atomicAdd(a.acc_total, (mhx_u64)wave_acc);
+}
+
+// initial GradientTransition (src/MALA.jl:38-40): lp and gradient at the given initial_params
+template <int TK>
+MHX_DEV void mhx_mala_init_body(const mhx_mala_args& a, const float* __restrict__ tparams, const int reset_counts)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.nchains) return;
+    mhx_strided_x xv;
+    xv.base = a.x + c;
+    xv.ld = a.ld;
+    mhx_strided_rw g;
+    g.base = a.gx + c;
+    g.ld = a.ld;
+    a.lp[c] = mhx_target_grad<TK>(a.target_kind, xv, g, a.dim, tparams, a.ntparams, a.tconst);
+    if (reset_counts) { a.acc_count[c] = 0u; a.last_acc[c] = 0; }
+}
+
+#ifdef MHX_JIT_MALA
+extern "C" __global__ void __launch_bounds__(256)
+mhx_jit_mala(const mhx_mala_args a, const float* __restrict__ tparams)
+{
+    mhx_mala_body<MHX_JIT_TK>(a, tparams);
+}
+extern "C" __global__ void __launch_bounds__(256)
+mhx_jit_mala_init(const mhx_mala_args a, const float* __restrict__ tparams, const int reset_counts)
+{
+    mhx_mala_init_body<MHX_JIT_TK>(a, tparams, reset_counts);
+}
+#endif

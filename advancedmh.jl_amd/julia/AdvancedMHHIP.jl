@@ -38,6 +38,17 @@ end
 struct EmceeCfg
     dim::Int32; nwalkers::Int32; seed::UInt64; ensemble_id::UInt64; stretch::Cfloat; flags::Int32; reduce_lanes::Int32
 end
+struct MalaCfg
+    dim::Int32; nchains::Int32; seed::UInt64; first_chain::UInt64; sigma2::Cfloat; flags::Int32
+end
+"""
+    LangevinProposal(σ²)
+
+Stands for the reference's `g -> MvNormal((σ² / 2) .* g, σ² * I)` (test/runtests.jl:291): `MALA(LangevinProposal(σ²))`
+dispatches to the device; a general closure keeps running on the CPU path.
+"""
+struct LangevinProposal; sigma2::Float64; end
+(p::LangevinProposal)(g) = MvNormal((p.sigma2 / 2) .* g, p.sigma2 * I)
 struct RamCfg
     dim::Int32; nchains::Int32; seed::UInt64; first_chain::UInt64
     alpha::Cfloat; gamma::Cfloat; eig_lo::Cfloat; eig_hi::Cfloat; flags::Int32
@@ -128,6 +139,13 @@ function AbstractMCMC.sample(
         if initial_params === nothing                                       # src/emcee.jl:29-34
             initial_params = reduce(hcat, [rand(rng, sampler.proposal.proposal) for _ in 1:n])
         end
+    elseif sampler isa AdvancedMH.MALA
+        prop = sampler.proposal.proposal
+        prop isa LangevinProposal || throw(ArgumentError("the GPU path implements MALA(LangevinProposal(σ²)) only"))
+        initial_params === nothing && error("please specify initial parameters")   # src/MALA.jl:37
+        cfg = MalaCfg(d, n, seed, ens.first_chain, prop.sigma2, 0)
+        check(ccall((:mhx_mala_create, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{MalaCfg}, Ref{Ptr{Cvoid}}),
+                    ctx[], tgt, cfg, run))
     elseif sampler isa AdvancedMH.RobustAdaptiveMetropolis
         cfg = RamCfg(d, n, seed, ens.first_chain, sampler.α, sampler.γ,
                      sampler.eigenvalue_lower_bound, sampler.eigenvalue_upper_bound, 0)
@@ -173,5 +191,5 @@ AbstractMCMC.sample(model::AdvancedMH.DensityModel{<:DeviceLogDensity}, sampler:
                     ens::MCMCHIP, N::Integer, nchains::Integer = 1; kwargs...) =
     AbstractMCMC.sample(Random.default_rng(), model, sampler, ens, N, nchains; kwargs...)
 
-export MCMCHIP, IsoGaussian, CorrGaussian, IIDNormal, Banana, Funnel, HipSource
+export MCMCHIP, LangevinProposal, IsoGaussian, CorrGaussian, IIDNormal, Banana, Funnel, HipSource
 end # module

@@ -52,6 +52,11 @@ class RamCfg(C.Structure):
                 ("flags", C.c_int32)]
 
 
+class MalaCfg(C.Structure):
+    _fields_ = [("dim", C.c_int32), ("nchains", C.c_int32), ("seed", C.c_uint64), ("first_chain", C.c_uint64),
+                ("sigma2", C.c_float), ("flags", C.c_int32)]
+
+
 class Stats(C.Structure):
     _fields_ = [("transitions", C.c_uint64), ("accepted", C.c_uint64), ("kernel_ms", C.c_double),
                 ("wall_ms", C.c_double), ("kernel_variant", C.c_int32), ("launches", C.c_int32),
@@ -65,7 +70,7 @@ class DiagCfg(C.Structure):
 EXPORTS = [
     "mhx_version", "mhx_last_error", "mhx_ctx_create", "mhx_ctx_destroy", "mhx_target_builtin",
     "mhx_target_from_hip_source", "mhx_target_destroy", "mhx_target_eval", "mhx_rwmh_create",
-    "mhx_emcee_create", "mhx_ram_create", "mhx_ram_set_factor", "mhx_ram_get_factor",
+    "mhx_emcee_create", "mhx_ram_create", "mhx_mala_create", "mhx_ram_set_factor", "mhx_ram_get_factor",
     "mhx_ram_get_diag_range", "mhx_run_init", "mhx_run_sample", "mhx_run_get_samples",
     "mhx_run_get_state", "mhx_run_set_state", "mhx_run_stats", "mhx_run_device_samples",
     "mhx_run_destroy", "mhx_run_diagnostics",
@@ -94,6 +99,7 @@ def lib():
         L.mhx_rwmh_create.argtypes = [vp, vp, C.POINTER(RwmhCfg), C.POINTER(vp)]
         L.mhx_emcee_create.argtypes = [vp, vp, C.POINTER(EmceeCfg), C.POINTER(vp)]
         L.mhx_ram_create.argtypes = [vp, vp, C.POINTER(RamCfg), C.POINTER(vp)]
+        L.mhx_mala_create.argtypes = [vp, vp, C.POINTER(MalaCfg), C.POINTER(vp)]
         L.mhx_ram_set_factor.argtypes = [vp, fp]
         L.mhx_ram_get_factor.argtypes = [vp, fp, u8p]
         L.mhx_ram_get_diag_range.argtypes = [vp, fp, fp]

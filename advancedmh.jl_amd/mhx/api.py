@@ -308,6 +308,18 @@ class RobustAdaptiveMetropolis:
         self.eigenvalue_upper_bound = float(eigenvalue_upper_bound)
 
 
+class MALA:
+    """MALA(sigma2): the reference's `MALA(g -> MvNormal((sigma2 / 2) .* g, sigma2 * I))` (src/MALA.jl:1-11,
+    test/runtests.jl:291).  Only this standard Langevin proposal is lowered to the device; a general
+    gradient -> Distribution closure stays on the CPU reference."""
+
+    def __init__(self, sigma2):
+        if callable(sigma2):
+            raise L.ArgumentError(L.MHX_EINVAL, "MALA on the GPU path takes sigma2, i.e. the proposal "
+                                  "g -> MvNormal((sigma2/2) g, sigma2 I); an arbitrary closure cannot be lowered")
+        self.sigma2 = float(sigma2)
+
+
 # ------------------------------------------------------------------------------------------------
 # chains container (the part of MCMCChains.Chains the reference tests touch)
 
@@ -375,6 +387,11 @@ class Run:
             L.check(lib.mhx_emcee_create(self.ctx.h, model.handle(self.ctx), C.byref(cfg), C.byref(self.h)))
             self.n = sampler.n_walkers
             self.kind = "emcee"
+        elif isinstance(sampler, MALA):
+            cfg = L.MalaCfg(d, nchains, seed, first_chain, sampler.sigma2, flags)
+            L.check(lib.mhx_mala_create(self.ctx.h, model.handle(self.ctx), C.byref(cfg), C.byref(self.h)))
+            self.n = nchains
+            self.kind = "mala"
         elif isinstance(sampler, RobustAdaptiveMetropolis):
             if sampler.S is not None and sampler.S.shape != (d, d):
                 # src/RobustAdaptiveMetropolis.jl:202-204

@@ -149,6 +149,24 @@ int mhx_ram_get_factor(mhx_run *run, float *S, uint8_t *status /* [nchains] or N
 int mhx_ram_get_diag_range(mhx_run *run, float *diag_min, float *diag_max);
 
 /* ---------------------------------------------------------------------------------------------
+ * Metropolis-adjusted Langevin.  Replaces MALA (src/MALA.jl:1-11), GradientTransition (:14-19) and its step
+ * (:54-93) for the standard proposal  g -> MvNormal((sigma2/2) g, sigma2 I)  of the reference's tests
+ * (test/runtests.jl:291,352).  Gradients are analytic for the catalogue targets; a user source must also
+ * define  MHX_LOGDENSITY_AND_GRADIENT(x, g, d, data, ndata) { ... g.set(k, dlp_dxk); ... return lp; }
+ * (the reference throws in check_capabilities, src/MALA.jl:42-52, when no gradient is available).
+ * mhx_run_init requires initial_params (src/MALA.jl:37). */
+typedef struct {
+    int32_t dim;
+    int32_t nchains;
+    uint64_t seed;
+    uint64_t first_chain;
+    float sigma2;
+    int32_t flags;
+} mhx_mala_cfg;
+
+int mhx_mala_create(mhx_ctx *ctx, const mhx_target *t, const mhx_mala_cfg *cfg, mhx_run **out);
+
+/* ---------------------------------------------------------------------------------------------
  * Running chains.  mhx_run_init == the initial AbstractMCMC.step (src/mh-core.jl:76-86,
  * src/emcee.jl:29-34, src/RobustAdaptiveMetropolis.jl:175-214): x0 = initial_params if given, else
  * a draw (RWMH: from the proposal; RAM: randn(d); Ensemble: initial walkers are required).

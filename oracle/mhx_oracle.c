@@ -642,3 +642,132 @@ int orc_ram(const orc_target *t, const orc_ram_cfg *cfg, const orc_schedule *s,
     free(x); free(S); free(Sn);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* gradients of the catalogue targets (what ForwardDiff / LogDensityProblems.logdensity_and_gradient
+ * supply to the reference's MALA, src/MALA.jl:73-75, ext/AdvancedMHForwardDiffExt.jl:13-17)     */
+float orc_target_grad(const orc_target *t, const float *x, float *g, orc_logdensity_grad_fn user)
+{
+    const int d = t->dim;
+    switch (t->kind) {
+    case ORC_TARGET_ISO_GAUSS:
+        for (int k = 0; k < d; ++k) g[k] = -x[k];
+        return orc_target_eval(t, x);
+    case ORC_TARGET_CORR_GAUSS: {                      /* grad = -A^T (A x) */
+        const float *A = t->params;
+        float q = 0.0f;
+        size_t off = 0;
+        for (int i = 0; i < d; ++i) {                  /* w = A x, kept in g */
+            float w = 0.0f;
+            for (int j = 0; j <= i; ++j) w = fmaf(A[off + j], x[j], w);
+            g[i] = w;
+            q = fmaf(w, w, q);
+            off += (size_t)i + 1;
+        }
+        for (int j = 0; j < d; ++j) {                  /* g_j = -sum_{i>=j} A_ij w_i, ascending i, in place */
+            float acc = 0.0f;
+            for (int i = j; i < d; ++i) acc = fmaf(A[SIDX(i, j)], g[i], acc);
+            g[j] = -acc;
+        }
+        return fmaf(-0.5f, q, target_const(t));
+    }
+    case ORC_TARGET_IID_NORMAL: {
+        const float mu = x[0], sigma = x[1];
+        if (!(sigma > 0.0f)) { g[0] = 0.0f; g[1] = 0.0f; return -INFINITY; }
+        const float inv = 1.0f / sigma;
+        float acc = 0.0f, s1 = 0.0f;
+        for (int i = 0; i < t->nparams; ++i) {
+            const float z = (t->params[i] - mu) / sigma;
+            acc = fmaf(z, z, acc);
+            s1 = s1 + z;
+        }
+        const float nf = (float)t->nparams;
+        g[0] = s1 * inv;                               /* sum (y-mu)/sigma^2 */
+        g[1] = (acc - nf) * inv;                       /* -n/sigma + sum (y-mu)^2/sigma^3 */
+        const float tt = orc_logf(sigma) + HALF_LOG_2PI_F;
+        return fmaf(-0.5f, acc, -(nf * tt));
+    }
+    case ORC_TARGET_BANANA: {
+        const float b = t->params[0];
+        const float x0 = x[0];
+        float q = (x0 * x0) * 0.01f;
+        const float u = fmaf(b, fmaf(x0, x0, -100.0f), x[1]);
+        q = fmaf(u, u, q);
+        g[0] = -(fmaf(x0, 0.01f, (2.0f * b) * (u * x0)));
+        g[1] = -u;
+        for (int k = 2; k < d; ++k) { q = fmaf(x[k], x[k], q); g[k] = -x[k]; }
+        return fmaf(-0.5f, q, target_const(t));
+    }
+    case ORC_TARGET_FUNNEL: {
+        const float v = x[0];
+        float q = 0.0f;
+        for (int k = 1; k < d; ++k) q = fmaf(x[k], x[k], q);
+        const float ev = orc_expf(-v);
+        float r = (v * v) * 0x1.c71c72p-5f;
+        r = fmaf(0.5f * (float)(d - 1), v, r);
+        r = fmaf(0.5f * ev, q, r);
+        g[0] = fmaf(0.5f * ev, q, -(fmaf(v, 0x1.c71c72p-4f, 0.5f * (float)(d - 1))));   /* -v/9 - (d-1)/2 + e^-v q/2 */
+        for (int k = 1; k < d; ++k) g[k] = -(ev * x[k]);
+        return target_const(t) - r;
+    }
+    case ORC_TARGET_CALLBACK:
+        return user ? user(x, g, d, t->fn_data) : NAN;
+    default:
+        return NAN;
+    }
+}
+
+/* MALA: src/MALA.jl:54-93 with the standard Langevin proposal g -> MvNormal((sigma2/2) g, sigma2 I)
+ * (the form of the reference's tests, test/runtests.jl:291,352):
+ *   y = x + (sigma2/2) grad(x) + sigma z                                     (:70, proposal.jl:49-56)
+ *   logratio = q(prop(grad y), x, y) - q(prop(grad x), y, x)                 (:78-80)
+ *            = 1/2 |z|^2 - 1/2 |z + (sigma/2)(grad x + grad y)|^2
+ *   accept iff -randexp < lp(y) - lp(x) + logratio                           (:83-86)            */
+int orc_mala(const orc_target *t, orc_logdensity_grad_fn user, float sigma2, const orc_schedule *s,
+             uint64_t seed, uint64_t first_chain, int nchains, const float *init,
+             float *samples, uint8_t *accepted, float *final_x, float *final_lp, uint32_t *accept_counts)
+{
+    const int d = t->dim, C = nchains;
+    if (!init) return -1;                                /* :37 "please specify initial parameters" */
+    int64_t nT, nA;
+    orc_schedule_counts(s, &nT, &nA);
+    const float sigma = sqrtf(sigma2);
+    const float h = (sigma * sigma) * 0.5f;              /* drift step sigma2/2 */
+    const float hs = 0.5f * sigma;
+    float *x = malloc(sizeof(float) * (size_t)d * 5);
+    float *gx = x + d, *y = gx + d, *gy = y + d, *z = gy + d;
+    for (int c = 0; c < C; ++c) {
+        const uint64_t id = first_chain + (uint64_t)c;
+        for (int k = 0; k < d; ++k) x[k] = init[(size_t)k * C + c];
+        float lp = orc_target_grad(t, x, gx, user);      /* :38-40 GradientTransition(params, lp, grad, false) */
+        uint32_t nacc = 0;
+        int64_t slot = save_slot(s, 0);
+        if (slot >= 0) record(samples, accepted, slot, d, C, c, x, lp, 0);
+        for (int64_t tau = 1; tau <= nT; ++tau) {
+            const uint32_t step = (uint32_t)tau;
+            orc_normals(seed, id, step, ORC_STREAM_PROPOSAL, d, z);
+            float fwd = 0.0f;
+            for (int k = 0; k < d; ++k) {
+                y[k] = fmaf(sigma, z[k], fmaf(h, gx[k], x[k]));
+                fwd = fmaf(z[k], z[k], fwd);
+            }
+            const float lpy = orc_target_grad(t, y, gy, user);
+            float bwd = 0.0f;
+            for (int k = 0; k < d; ++k) {
+                const float tk = fmaf(hs, gx[k] + gy[k], z[k]);
+                bwd = fmaf(tk, tk, bwd);
+            }
+            const float loga = (lpy - lp) + 0.5f * (fwd - bwd);
+            const float logu = orc_accept_logu(seed, id, step);
+            const int acc = logu < loga;
+            if (acc) { memcpy(x, y, sizeof(float) * (size_t)d); memcpy(gx, gy, sizeof(float) * (size_t)d); lp = lpy; ++nacc; }
+            slot = save_slot(s, tau);
+            if (slot >= 0) record(samples, accepted, slot, d, C, c, x, lp, acc);
+        }
+        if (final_x) for (int k = 0; k < d; ++k) final_x[(size_t)k * C + c] = x[k];
+        if (final_lp) final_lp[c] = lp;
+        if (accept_counts) accept_counts[c] = nacc;
+    }
+    free(x);
+    return 0;
+}

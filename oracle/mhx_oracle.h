@@ -117,6 +117,16 @@ int orc_ram(const orc_target *t, const orc_ram_cfg *cfg, const orc_schedule *s,
             float *samples, uint8_t *accepted, float *final_x, float *final_lp,
             uint32_t *accept_counts, uint8_t *status, float *diag_min, float *diag_max);
 
+/* value and gradient of a catalogue target (MALA); g[d] out.  CALLBACK targets: fn_grad in `t->fn_data`
+ * is not supported -- user gradients are exercised through gcc-built sources in tests/user_targets.py. */
+typedef float (*orc_logdensity_grad_fn)(const float *x, float *g, int d, const void *data);
+float orc_target_grad(const orc_target *t, const float *x, float *g, orc_logdensity_grad_fn user);
+
+/* MALA(g -> MvNormal((sigma2/2) g, sigma2 I)): src/MALA.jl:54-93.  init [d][C] is required (:37). */
+int orc_mala(const orc_target *t, orc_logdensity_grad_fn user, float sigma2, const orc_schedule *s,
+             uint64_t seed, uint64_t first_chain, int nchains, const float *init,
+             float *samples, uint8_t *accepted, float *final_x, float *final_lp, uint32_t *accept_counts);
+
 /* rank-1 Cholesky update (sign=+1) / downdate (sign=-1) of a packed lower factor, in place.
  * returns 0, or i+1 if the downdate failed at column i (S is then partially modified). */
 int orc_chol_rank1(float *S, float *w, int d, int sign);

@@ -257,6 +257,35 @@ def ram(target, sched, seed, first_chain, nchains, init=None, S_in=None, alpha=0
                 status=status, S=S_out, diag_min=dmin, diag_max=dmax)
 
 
+GRAD_FN = C.CFUNCTYPE(C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_void_p)
+
+
+def target_grad(target, x, user_grad_addr=None):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    g = np.empty_like(x)
+    L = lib()
+    L.orc_target_grad.restype = C.c_float
+    ug = C.cast(user_grad_addr, GRAD_FN) if user_grad_addr else C.cast(None, GRAD_FN)
+    lp = L.orc_target_grad(C.byref(target.c), _fp(x), _fp(g), ug)
+    return lp, g
+
+
+def mala(target, sigma2, sched, seed, first_chain, nchains, init, user_grad_addr=None, save=True):
+    d, N, Cn = target.dim, sched.n_samples, nchains
+    samples = np.empty((N, d + 1, Cn), dtype=np.float32) if save else None
+    accepted = np.empty((N, Cn), dtype=np.uint8) if save else None
+    fx = np.empty((d, Cn), dtype=np.float32)
+    flp = np.empty(Cn, dtype=np.float32)
+    cnt = np.empty(Cn, dtype=np.uint32)
+    init = np.ascontiguousarray(init, dtype=np.float32)
+    assert init.shape == (d, Cn)
+    ug = C.cast(user_grad_addr, GRAD_FN) if user_grad_addr else C.cast(None, GRAD_FN)
+    rc = lib().orc_mala(C.byref(target.c), ug, C.c_float(sigma2), C.byref(sched), C.c_uint64(seed),
+                        C.c_uint64(first_chain), Cn, _fp(init), _fp(samples), _u8p(accepted), _fp(fx), _fp(flp), _u32p(cnt))
+    assert rc == 0
+    return dict(samples=samples, accepted=accepted, final_x=fx, final_lp=flp, accept_counts=cnt)
+
+
 def chol_rank1(S_packed, w, sign):
     S = np.ascontiguousarray(S_packed, dtype=np.float32).copy()
     w = np.ascontiguousarray(w, dtype=np.float32).copy()

@@ -1,0 +1,82 @@
+"""GPU parity: HIP MALA kernel vs the oracle (bit exact) and the reference's MALA tests.
+Reference: src/MALA.jl:54-93, test/runtests.jl:288-366."""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import user_targets
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _same(a, b, what):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    assert a.shape == b.shape, what
+    bad = np.argwhere(a.view(np.uint32) != b.view(np.uint32)) if a.dtype == np.float32 else np.argwhere(a != b)
+    assert len(bad) == 0, "%s: %d mismatches, first at %s: %r vs %r" % (
+        what, len(bad), bad[0], a[tuple(bad[0])], b[tuple(bad[0])])
+
+
+@pytest.mark.parametrize("name", ["iso", "corr", "banana", "funnel", "iid"])
+def test_mala_bit_exact(mhx, oracle, name):
+    rng = np.random.default_rng(4)
+    d, C, N = 7, 70, 30
+    if name == "iso":
+        spec, ot = mhx.IsoGaussian(d), oracle.iso_gauss(d)
+    elif name == "corr":
+        Sig = cases.sigma_ar1(d, 0.6)
+        spec, ot = mhx.CorrGaussian(Sig), oracle.corr_gauss_from_cov(Sig)
+    elif name == "banana":
+        spec, ot = mhx.Banana(d, 0.03), oracle.Target(oracle.TARGET_BANANA, d, params=[0.03])
+    elif name == "funnel":
+        spec, ot = mhx.Funnel(d), oracle.Target(oracle.TARGET_FUNNEL, d)
+    else:
+        d = 2
+        data = np.load(os.path.join(GOLD, "c1_normal_data.npy"))[:40]
+        spec, ot = mhx.IIDNormal(data), oracle.Target(oracle.TARGET_IID_NORMAL, 2, params=data)
+    init = (rng.normal(size=(d, C)) * 0.3 + 1.0).astype(np.float32)
+    chain = mhx.sample(mhx.DensityModel(spec), mhx.MALA(0.05), N, C, seed=8, first_chain=5, initial_params=init,
+                       discard_initial=3, thinning=2)
+    ref = oracle.mala(ot, np.float32(0.05), oracle.schedule(N, 3, 2), 8, 5, C, init)
+    _same(chain.value, ref["samples"], "samples")
+    _same(chain.accepted, ref["accepted"], "accepted")
+    x, lp, cnt = chain.state.state()
+    _same(x, ref["final_x"], "final x")
+    _same(cnt, ref["accept_counts"], "accept counts")
+
+
+def test_mala_reference_tests(mhx, oracle):
+    """test/runtests.jl:288-332 (basic) and :334-365 (issue #95)."""
+    data = np.load(os.path.join(GOLD, "c1_normal_data.npy"))
+    model = mhx.DensityModel(mhx.IIDNormal(data))
+    spl1 = mhx.MALA(1e-3)
+    with pytest.raises(mhx.MhxError) as ei:                     # "please specify initial parameters", src/MALA.jl:37
+        mhx.sample(model, spl1, 1000, discard_initial=100)
+    assert "initial parameters" in str(ei.value)
+    chain1 = mhx.sample(model, spl1, 1000, 16, initial_params=np.ones(2), param_names=["μ", "σ"], discard_initial=100, seed=3)
+    assert abs(chain1.mean("μ") - data.mean()) < 0.1 and abs(chain1.mean("σ") - 1.0) < 0.1
+    Sig = np.array([[1.5, 0.35], [0.35, 1.0]])
+    A = np.linalg.inv(Sig).astype(np.float32)
+    umodel = mhx.DensityModel(mhx.HipLogDensity(user_targets.QUADRATIC_WITH_GRADIENT, 2, data=A.ravel()))
+    chain = mhx.sample(umodel, mhx.MALA(0.5), 20000, 32, initial_params=np.ones(2), seed=1)
+    v = chain.value[:, :2, :].astype(np.float64)
+    assert np.abs(v.mean(axis=(0, 2))).max() < 0.1
+    assert np.abs(np.cov(v.transpose(1, 0, 2).reshape(2, -1)) - Sig).max() < 0.2
+    # bit-exact against the oracle running the same source (value and gradient) compiled for the host
+    ut = user_targets.host_target(oracle, user_targets.QUADRATIC_WITH_GRADIENT, 2, data=A.ravel())
+    ref = oracle.mala(ut, 0.5, oracle.schedule(200), 1, 0, 32, np.ones((2, 32), dtype=np.float32), user_grad_addr=ut.grad_addr)
+    _same(chain.value[:200], ref["samples"], "samples")
+    # a user source without a gradient cannot run MALA (check_capabilities, src/MALA.jl:42-52)
+    nograd = mhx.DensityModel(mhx.HipLogDensity(user_targets.SHIFTED_GAUSS, 2, data=[0, 0, 1, 1]))
+    with pytest.raises(mhx.MhxError) as ei:
+        mhx.sample(nograd, mhx.MALA(0.5), 10, initial_params=np.ones(2))
+    assert ei.value.code == -4
+    # setparams!! recomputes lp and the gradient (src/MALA.jl:27-35)
+    run = chain1.state
+    x, lp, _ = run.state()
+    run.set_params(np.ones_like(x))
+    x2, lp2, _ = run.state()
+    assert (x2 == 1).all() and np.allclose(lp2, lp2[0])

@@ -138,3 +138,40 @@ def test_ram_doctest_covariance(oracle):
         acc = r["accepted"].mean()
         assert 0.12 < acc < 0.4
         assert (r["status"] & 1).sum() == 0
+
+
+def test_mala_known_answers(oracle):
+    """test/runtests.jl:288-366.  basic: the Normal(mu, sigma) model with sigma2 = 1e-3 from ones(2): means ~ (0, 1);
+    issue #95: 2-d Gaussian Sigma = [1.5 .35; .35 1], sigma2 = 0.5: mean ~ 0 (atol .1), cov ~ Sigma (atol .2)."""
+    data = np.load(os.path.join(GOLD, "c1_normal_data.npy"))
+    t = oracle.Target(oracle.TARGET_IID_NORMAL, 2, params=data)
+    r = oracle.mala(t, 1e-3, oracle.schedule(1000, 100), 3, 0, 8, np.ones((2, 8), dtype=np.float32))
+    v = r["samples"].astype(np.float64)
+    assert abs(v[:, 0, :].mean() - data.mean()) < 0.1 and abs(v[:, 1, :].mean() - 1.0) < 0.1
+    Sig = np.array([[1.5, 0.35], [0.35, 1.0]])
+    r = oracle.mala(oracle.corr_gauss_from_cov(Sig), 0.5, oracle.schedule(100000), 1, 0, 4, np.ones((2, 4), dtype=np.float32))
+    v = r["samples"][:, :2, :].astype(np.float64)
+    assert np.abs(v.mean(axis=(0, 2))).max() < 0.1
+    assert np.abs(np.cov(v.transpose(1, 0, 2).reshape(2, -1)) - Sig).max() < 0.2
+    assert np.array_equal(r["samples"][0, :2, :], np.ones((2, 4), dtype=np.float32)) and not r["accepted"][0].any()
+    # same model through a user source with its own gradient (TheNormalLogDensity(inv(Sigma)))
+    A = np.linalg.inv(Sig).astype(np.float32)
+    ut = user_targets.host_target(oracle, user_targets.QUADRATIC_WITH_GRADIENT, 2, data=A.ravel())
+    r2 = oracle.mala(ut, 0.5, oracle.schedule(50000), 1, 0, 4, np.ones((2, 4), dtype=np.float32), user_grad_addr=ut.grad_addr)
+    v2 = r2["samples"][:, :2, :].astype(np.float64)
+    assert np.abs(np.cov(v2.transpose(1, 0, 2).reshape(2, -1)) - Sig).max() < 0.2
+
+
+def test_catalogue_gradients_against_finite_differences(oracle):
+    rng = np.random.default_rng(0)
+    d = 6
+    x = rng.normal(size=d).astype(np.float32)
+    Sig = cases.sigma_ar1(d, 0.7)
+    for t in (oracle.iso_gauss(d), oracle.corr_gauss_from_cov(Sig), oracle.Target(oracle.TARGET_BANANA, d, params=[0.03]),
+              oracle.Target(oracle.TARGET_FUNNEL, d)):
+        lp, g = oracle.target_grad(t, x)
+        assert lp == t(x)
+        for k in range(d):
+            e = np.zeros(d, dtype=np.float32)
+            e[k] = 1e-3
+            assert abs(g[k] - (t(x + e) - t(x - e)) / 2e-3) < 2e-3 * max(1.0, abs(g[k]))

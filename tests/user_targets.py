@@ -59,6 +59,31 @@ MHX_LOGDENSITY(x, d, data, ndata)
 }
 """
 
+# test/runtests.jl:334-365 (issue #95): TheNormalLogDensity(A): lp = -x'Ax/2, gradient = -Ax; data = A row-major
+QUADRATIC_WITH_GRADIENT = r"""
+MHX_LOGDENSITY(x, d, data, ndata)
+{
+    float q = 0.0f;
+    for (int i = 0; i < d; ++i) {
+        float r = 0.0f;
+        for (int j = 0; j < d; ++j) r = mhx_fma(data[i * d + j], x[j], r);
+        q = mhx_fma(x[i], r, q);
+    }
+    return -0.5f * q;
+}
+MHX_LOGDENSITY_AND_GRADIENT(x, g, d, data, ndata)
+{
+    float q = 0.0f;
+    for (int i = 0; i < d; ++i) {
+        float r = 0.0f;
+        for (int j = 0; j < d; ++j) r = mhx_fma(data[i * d + j], x[j], r);
+        q = mhx_fma(x[i], r, q);
+        g.set(i, -r);
+    }
+    return -0.5f * q;
+}
+"""
+
 _PRELUDE = r"""
 #include <math.h>
 #include <string.h>
@@ -71,6 +96,18 @@ static inline float mhx_sqrt(float x) { return sqrtf(x); }
 #define MHX_NAN NAN
 #define MHX_LOGDENSITY(x, d, data, ndata) \
     template <class MHX_X> static inline float mhx_user_logdensity(const MHX_X& x, const int d, const float* data, const int ndata)
+#define MHX_LOGDENSITY_AND_GRADIENT(x, g, d, data, ndata) \
+    template <class MHX_X, class MHX_G> static inline float mhx_user_logdensity_and_gradient(const MHX_X& x, const MHX_G& g, const int d, const float* data, const int ndata)
+struct host_grad_out { float* p; void set(int k, float v) const { p[k] = v; } float operator[](int k) const { return p[k]; } };
+"""
+
+_EPILOGUE_GRAD = r"""
+extern "C" float user_logdensity_and_gradient(const float* x, float* g, int d, const void* data)
+{
+    const user_data* D = (const user_data*)data;
+    host_grad_out go = { g };
+    return mhx_user_logdensity_and_gradient(x, go, d, D ? D->p : (const float*)0, D ? D->n : 0);
+}
 """
 
 _EPILOGUE = r"""
@@ -92,11 +129,13 @@ def host_target(oracle, source, dim, data=None, cache_dir="/tmp/mhx_user_targets
     import numpy as np
     oracle.build()
     os.makedirs(cache_dir, exist_ok=True)
-    tag = hashlib.sha1((_PRELUDE + source + _EPILOGUE).encode()).hexdigest()[:16]
+    has_grad = "MHX_LOGDENSITY_AND_GRADIENT" in source
+    epilogue = _EPILOGUE + (_EPILOGUE_GRAD if has_grad else "")
+    tag = hashlib.sha1((_PRELUDE + source + epilogue).encode()).hexdigest()[:16]
     so = os.path.join(cache_dir, "user_%s.so" % tag)
     if not os.path.exists(so):
         cpp = os.path.join(cache_dir, "user_%s.cpp" % tag)
-        open(cpp, "w").write(_PRELUDE + source + _EPILOGUE)
+        open(cpp, "w").write(_PRELUDE + source + epilogue)
         odir = os.path.join(ROOT, "oracle")
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
                                "-mfma", "-mavx2", "-o", so, cpp, "-L" + odir, "-lmhx_oracle", "-Wl,-rpath," + odir])
@@ -109,4 +148,5 @@ def host_target(oracle, source, dim, data=None, cache_dir="/tmp/mhx_user_targets
         ud = _UserData(arr.ctypes.data_as(C.POINTER(C.c_float)), arr.size)
     t = oracle.Target(oracle.TARGET_CALLBACK, dim, fn=addr, fn_data=ud)
     t._keep = (lib, arr, ud)
+    t.grad_addr = C.cast(lib.user_logdensity_and_gradient, C.c_void_p).value if has_grad else None
     return t
