@@ -1,0 +1,98 @@
+"""GPU, at BASELINE.json's FULL sizes: the HIP path on the whole workload, checked (a) bit for bit against the
+oracle on subsets of chains (chains are independent and carry global ids, so any subset is reproducible on the
+CPU in seconds) and (b) through size-independent properties (shard concatenation, acceptance statistics,
+every walker of an ensemble against the full-ensemble oracle)."""
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b, what):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    assert a.shape == b.shape, what
+    bad = np.argwhere(a.view(np.uint32) != b.view(np.uint32)) if a.dtype == np.float32 else np.argwhere(a != b)
+    assert len(bad) == 0, "%s: %d mismatches, first at %s" % (what, len(bad), bad[0])
+
+
+def test_c2_full_size_rwmh(mhx, oracle):
+    """configs[1]: isotropic 100-dim Gaussian, RWMH, 65 536 chains."""
+    d, C, N = 100, 65536, 40
+    s = float(np.float32(2.38 / d ** 0.5))
+    model = mhx.DensityModel(mhx.IsoGaussian(d))
+    spl = mhx.RWMH(mhx.MvNormal(mhx.zeros(d), s * s * mhx.I))
+    chain = mhx.sample(model, spl, N, C, seed=0xC0FFEE)
+    L = chain.stats["reduce_lanes"]
+    assert chain.stats["kernel_variant"] == 3 and L == 2          # the pre-built cooperative kernel
+    for first in (0, 31337, C - 64):                               # three subsets of 64 chains
+        ref = oracle.rwmh(oracle.iso_gauss(d, reduce_lanes=L), oracle.Proposal(oracle.PROP_ISO, s), oracle.schedule(N),
+                          0xC0FFEE, first, 64)
+        _same(chain.value[:, :, first:first + 64], ref["samples"], "samples of chains %d.." % first)
+        _same(chain.accepted[:, first:first + 64], ref["accepted"], "accepted")
+    # lp column is the log-density of the recorded state for every chain
+    x = chain.value[-1, :d, :].astype(np.float64)
+    lp = -0.5 * (x * x).sum(axis=0) - 0.5 * d * np.log(2 * np.pi)
+    assert np.abs(chain.value[-1, d, :] - lp).max() < 2e-3
+    # accepted flag <=> the state changed; the device total equals the sum of the flags
+    moved = (np.diff(chain.value[:, 0, :], axis=0) != 0)
+    assert np.array_equal(moved, chain.accepted[1:].astype(bool))
+    assert chain.stats["accepted"] == int(chain.accepted[1:].sum())
+    # two half-size shards reproduce the whole
+    half = mhx.sample(model, spl, 8, C // 2, seed=0xC0FFEE, first_chain=C // 2, reduce_lanes=L)
+    _same(half.value, chain.value[:8, :, C // 2:], "upper shard")
+
+
+def test_c3_full_size_emcee(mhx, oracle):
+    """configs[2]: Ensemble(16 384, StretchProposal), 50-dim correlated Gaussian -- the whole ensemble against the oracle."""
+    d, W, N = 50, 16384, 4
+    Sig = cases.sigma_ar1(d, 0.9)
+    init = cases.emcee_init(d, W, 11)
+    chain = mhx.sample(mhx.DensityModel(mhx.CorrGaussian(Sig)), mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I))),
+                       N, seed=3, initial_params=init)
+    L = chain.stats["reduce_lanes"]
+    assert L > 1 and chain.stats["kernel_variant"] == 4
+    ref = oracle.emcee(oracle.corr_gauss_from_cov(Sig, reduce_lanes=L), 2.0, 1, oracle.schedule(N), 3, 0, W, init)
+    _same(chain.value, ref["samples"], "samples")
+    _same(chain.accepted, ref["accepted"], "accepted")
+    assert chain.stats["accepted"] == int(ref["accept_counts"].sum())
+
+
+def test_c4_full_size_ram(mhx, oracle):
+    """configs[3]: RobustAdaptiveMetropolis, 200-dim Gaussian with kappa = 1e3, 32 768 chains (5.3 GB of factors)."""
+    d, C, N = 200, 32768, 6
+    rng = np.random.default_rng(7)
+    Q, _ = np.linalg.qr(rng.normal(size=(d, d)))
+    Sig = (Q * 1e3 ** (np.arange(d) / (d - 1.0))) @ Q.T
+    model = mhx.DensityModel(mhx.CorrGaussian(Sig))
+    run = mhx.Run(model, mhx.RobustAdaptiveMetropolis(), nchains=C, seed=4)
+    run.init(np.zeros(d))
+    run.sample(N, 0, 1, 4)                                         # 4 adapting + 1 fixed transition
+    val, acc = run.samples()
+    S, status = run.factor()
+    assert (status == 0).all()
+    ot = oracle.corr_gauss_from_cov(Sig)
+    for first in (0, C - 16):
+        ref = oracle.ram(ot, oracle.schedule(N, 0, 1, 4), 4, first, 16, init=np.zeros((d, 16), dtype=np.float32))
+        _same(val[:, :, first:first + 16], ref["samples"], "samples of chains %d.." % first)
+        _same(S[first:first + 16], ref["S"], "factors")
+    # every chain's factor stays lower-triangular positive: packed diagonal entries > 0
+    diag_idx = np.array([i * (i + 1) // 2 + i for i in range(d)])
+    assert (S[:, diag_idx] > 0).all()
+    run.close()
+
+
+def test_c5_shard_size_rwmh(mhx, oracle):
+    """configs[4], one GPU's shard: 1000-dim funnel, 32 768 chains with global ids of shard 5 of 8."""
+    d, C, N = 1000, 32768, 5
+    s = float(np.float32(2.38 / d ** 0.5))
+    first = 5 * C
+    chain = mhx.sample(mhx.DensityModel(mhx.Funnel(d)), mhx.RWMH(mhx.MvNormal(mhx.zeros(d), s * s * mhx.I)), N, C, seed=5,
+                       first_chain=first)
+    L = chain.stats["reduce_lanes"]
+    assert chain.stats["kernel_variant"] == 3 and L == 32
+    ot = oracle.Target(oracle.TARGET_FUNNEL, d).with_lanes(L)
+    for off in (0, C - 32):
+        ref = oracle.rwmh(ot, oracle.Proposal(oracle.PROP_ISO, s), oracle.schedule(N), 5, first + off, 32)
+        _same(chain.value[:, :, off:off + 32], ref["samples"], "samples of chains %d.." % (first + off))

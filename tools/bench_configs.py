@@ -32,7 +32,8 @@ def report(name, st, extra):
 if "c3" in which:
     d, W, sweeps = 50, 16384, 500
     model = mhx.DensityModel(mhx.CorrGaussian(sigma_ar1(d, 0.9)))
-    run = mhx.Run(model, mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I))), seed=3)
+    run = mhx.Run(model, mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I))), seed=3,
+                  reduce_lanes=int(os.environ.get("C3_LANES", 0)))
     run.init(None)
     run.sample(20, 1, 1, 0, save=True)
     for save in (True, False):
@@ -41,7 +42,7 @@ if "c3" in which:
         else:
             run.sample(1, sweeps, 1, 0, save=False)
         st = run.stats()
-        report("C3 emcee d=50 W=16384 save=%s" % save, st,
+        report("C3 emcee d=50 W=16384 save=%s lanes=%d" % (save, st["reduce_lanes"]), st,
                dict(bytes_per_move=813, achieved_GBs=813 * st["transitions"] / (st["kernel_ms"] * 1e-3) / 1e9))
     run.close()
 
