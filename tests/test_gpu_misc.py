@@ -207,3 +207,36 @@ def test_error_behaviour(mhx):
         mhx.sample(mhx.DensityModel(mhx.IsoGaussian(2)), mhx.Ensemble(1, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(2), mhx.I))), 3)
     with pytest.raises(mhx.ArgumentError):                      # bad schedule
         mhx.sample(mhx.DensityModel(mhx.IsoGaussian(2)), mhx.RWMH(2), 5, thinning=0)
+
+
+@pytest.mark.parametrize("flags_name", ["auto", "generic"])
+def test_infinite_and_nan_log_ratios(mhx, oracle, flags_name):
+    """src/mh-core.jl:104-108 edge cases: lp = -Inf at the start with a finite candidate (+Inf ratio => accept), a
+    candidate outside the support (-Inf => reject), -Inf vs -Inf (NaN => reject) -- identical decisions on the GPU."""
+    flags = mhx.FLAG_GENERIC if flags_name == "generic" else 0
+    data = np.zeros(5, dtype=np.float32)
+    C = 70
+    init = np.tile(np.array([[0.0], [-0.2]], dtype=np.float32), (1, C))      # sigma < 0: outside the support
+    chain = mhx.sample(mhx.DensityModel(mhx.IIDNormal(data)), mhx.RWMH(mhx.MvNormal(mhx.zeros(2), 0.25 * mhx.I)), 300, C, seed=3,
+                       initial_params=init, flags=flags)
+    ref = oracle.rwmh(oracle.Target(oracle.TARGET_IID_NORMAL, 2, params=data), oracle.Proposal(oracle.PROP_ISO, 0.5),
+                      oracle.schedule(300), 3, 0, C, init=init)
+    _same(chain.value, ref["samples"], "samples")
+    _same(chain.accepted, ref["accepted"], "accepted")
+    assert np.isneginf(chain.value[0, 2, :]).all() and np.isfinite(chain.value[-1, 2, :]).all()
+
+
+def test_ram_nan_log_ratio_skips_adaptation(mhx, oracle):
+    """RAM from a point of zero density towards more zero density: lp' - lp = NaN, the step is rejected and the
+    factor is left alone (status bit 1), exactly as the oracle does."""
+    data = np.zeros(4, dtype=np.float32)
+    C = 6
+    init = np.tile(np.array([[0.0], [-50.0]], dtype=np.float32), (1, C))    # far outside the support
+    chain = mhx.sample(mhx.DensityModel(mhx.IIDNormal(data)), mhx.RobustAdaptiveMetropolis(), 12, C, seed=2, initial_params=init,
+                       num_warmup=12, discard_initial=0)
+    S, st = chain.state.factor()
+    ref = oracle.ram(oracle.Target(oracle.TARGET_IID_NORMAL, 2, params=data), oracle.schedule(12, 0, 1, 12), 2, 0, C, init=init)
+    _same(chain.value, ref["samples"], "samples")
+    _same(S, ref["S"], "S")
+    _same(st, ref["status"], "status")
+    assert (st & 2).all()
