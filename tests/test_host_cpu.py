@@ -116,3 +116,22 @@ def test_two_rank_statistics_allreduce_gloo(oracle):
         assert np.allclose(rhat, want["rhat"], rtol=1e-12)
         assert np.allclose(essb, want["ess_between"], rtol=1e-9)
         assert abs(accrate - r["accept_counts"].sum() / (total * (N - 1 + 50))) < 1e-12
+
+
+def test_product_path_never_touches_the_oracle_or_a_cpu_fallback():
+    """The oracle is test infrastructure: nothing under advancedmh.jl_amd/ (kernels, C ABI, host mirror) may
+    import, include or link it; and the package ships no compatibility layer."""
+    pkg = os.path.join(ROOT, "advancedmh.jl_amd")
+    bad = []
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if not f.endswith((".py", ".h", ".hip", ".inc", ".jl", "Makefile")) or f == "mhx_jit_embed.inc":
+                continue
+            text = open(os.path.join(dirpath, f), errors="replace").read()
+            for needle in ("mhx_oracle", "from oracle", "import oracle", "oracle/", "__HIP_PLATFORM", "hipify", "triton"):
+                if needle in text:
+                    bad.append((os.path.relpath(os.path.join(dirpath, f), ROOT), needle))
+    assert not bad, bad
+    # bench.py may use the oracle only in its cpu_baseline leg
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    assert bench.count("from oracle import oracle") == 1 and "def cpu_baseline" in bench
