@@ -2,7 +2,7 @@
 from ._lib import (ArgumentError, Context, MhxError, PosDefException, FLAG_GENERIC, FLAG_NO_JIT, LIB_PATH,
                    EXPORTS, lib)
 from .api import (I, Banana, Chains, CorrGaussian, DensityModel, Ensemble, Funnel, HipLogDensity, IIDNormal,
-                  InverseGamma, IsoGaussian, MALA, MetropolisHastings, MvNormal, Normal, RandomWalkProposal,
+                  InverseGamma, IsoGaussian, MALA, MCMCDistributed, MCMCHIP, MCMCSerial, MCMCThreads, MetropolisHastings, MvNormal, Normal, RandomWalkProposal,
                   RobustAdaptiveMetropolis, Run, RWMH, combine_diagnostics, StretchProposal, SymmetricRandomWalkProposal, Transition,
                   logdensity, pack_lower, sample, unpack_lower, zeros)
 

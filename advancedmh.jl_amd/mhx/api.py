@@ -525,7 +525,29 @@ def combine_diagnostics(sum_m, sum_m2, sum_v, n_chains, n_samples):
     return out
 
 
-def sample(model, sampler, N, nchains=1, *, initial_params=None, discard_initial=None, thinning=1, num_warmup=0,
+class _ParallelTag:
+    """MCMCSerial() / MCMCThreads() / MCMCDistributed() of AbstractMCMC (re-exported, src/AdvancedMH.jl:30) and the
+    MCMCHIP() of the Julia glue: accepted as the third positional argument of `sample` for drop-in call sites
+    (README.md:141-147, test/runtests.jl:99-108).  On this engine every form runs all chains together on the GPU."""
+
+
+class MCMCSerial(_ParallelTag):
+    pass
+
+
+class MCMCThreads(_ParallelTag):
+    pass
+
+
+class MCMCDistributed(_ParallelTag):
+    pass
+
+
+class MCMCHIP(_ParallelTag):
+    pass
+
+
+def sample(model, sampler, N, nchains=1, *more, initial_params=None, discard_initial=None, thinning=1, num_warmup=0,
            param_names=None, chain_type=Chains, seed=0, first_chain=0, callback=None, ctx=None, flags=0,
            reduce_lanes=0, progress=False):
     """sample(model, sampler, N[, nchains]; kwargs...) -- AbstractMCMC.sample as re-exported by the
@@ -535,6 +557,12 @@ def sample(model, sampler, N, nchains=1, *, initial_params=None, discard_initial
     discard_initial defaults to num_warmup [upstream]; `callback(run, i)` is called after each saved
     sample (the reference signature callback(rng, model, sampler, sample, state, i) carries objects
     that live on the device here -- the Run gives access to them)."""
+    if isinstance(N, _ParallelTag):                 # sample(model, spl, MCMCThreads(), N, nchains)
+        if not more:
+            raise L.ArgumentError(L.MHX_EINVAL, "sample(model, sampler, parallel, N, nchains): nchains is missing")
+        N, nchains = nchains, more[0]
+    elif more:
+        raise L.ArgumentError(L.MHX_EINVAL, "sample: too many positional arguments")
     if discard_initial is None:
         discard_initial = num_warmup
     run = Run(model, sampler, nchains=nchains, seed=seed, first_chain=first_chain, ctx=ctx, flags=flags,

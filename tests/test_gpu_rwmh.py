@@ -70,3 +70,18 @@ def test_schedule_discard_thinning_and_initial_params(mhx, oracle):
     chain0 = mhx.sample(model, spl, 3, C, seed=5, initial_params=init, reduce_lanes=1)
     _same(chain0.value[0, :d, :], init, "sample 1")
     assert not chain0.accepted[0].any()
+
+
+def test_parallel_sampling_call_forms(mhx):
+    """test/runtests.jl:96-110: sample(model, spl, MCMCThreads(), 10 000, 4) -- the parallel tags are accepted and
+    every form runs the chains together on the GPU; same moments check as the reference (atol 0.1)."""
+    import os
+    data = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c1_normal_data.npy"))
+    model = mhx.DensityModel(mhx.IIDNormal(data))
+    spl = mhx.RWMH(mhx.MvNormal(mhx.zeros(2), 0.01 * mhx.I))
+    a = mhx.sample(model, spl, mhx.MCMCThreads(), 10000, 4, param_names=["μ", "σ"], seed=2, initial_params=np.array([0.0, 1.0]))
+    b = mhx.sample(model, spl, 10000, 4, param_names=["μ", "σ"], seed=2, initial_params=np.array([0.0, 1.0]))
+    assert a.value.shape == (10000, 3, 4) and np.array_equal(a.value, b.value)
+    assert abs(a.mean("μ") - data.mean()) < 0.1 and abs(a.mean("σ") - 1.0) < 0.1
+    c = mhx.sample(model, spl, mhx.MCMCDistributed(), 100, 4, seed=2, initial_params=np.array([0.0, 1.0]))
+    assert np.array_equal(c.value, b.value[:100])
