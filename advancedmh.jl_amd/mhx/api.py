@@ -108,6 +108,8 @@ def _as_mvnormal(dist):
         return MvNormal(zeros(dist), I)                           # src/mh-core.jl:51
     if isinstance(dist, MvNormal):
         return dist
+    if isinstance(dist, Normal):                                      # scalar parameter: RandomWalkProposal(Normal(0, 1))
+        return MvNormal([dist.mu], np.array([dist.sigma ** 2]))
     if isinstance(dist, (list, tuple)) and all(isinstance(p, Normal) for p in dist):
         mv = MvNormal([p.mu for p in dist], np.array([p.sigma ** 2 for p in dist]))
         return mv

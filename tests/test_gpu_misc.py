@@ -240,3 +240,22 @@ def test_ram_nan_log_ratio_skips_adaptation(mhx, oracle):
     _same(S, ref["S"], "S")
     _same(st, ref["status"], "status")
     assert (st & 2).all()
+
+
+def test_symmetric_random_walk_on_a_scalar_model(mhx):
+    """test/runtests.jl:215-259: target Normal(5, 0.7) as a user log-density, SymmetricRandomWalkProposal(Normal(0, 1)),
+    100 000 draws: mean and std within 0.05 (the symmetric flag only skips a Hastings ratio that is 0 anyway)."""
+    src = """
+    MHX_LOGDENSITY(x, d, data, ndata)
+    {
+        const float z = (x[0] - 5.0f) / 0.7f;
+        return -0.5f * (z * z) - 0x1.d67f1cp-1f - mhx_log(0.7f);
+    }
+    """
+    m1 = mhx.DensityModel(mhx.HipLogDensity(src, 1))
+    p2 = mhx.SymmetricRandomWalkProposal(mhx.Normal(0, 1))
+    assert p2.issymmetric and not mhx.RandomWalkProposal(mhx.Normal(0, 1)).issymmetric
+    chain1 = mhx.sample(m1, mhx.MetropolisHastings(p2), 100000, param_names=["x"], seed=11)
+    x = chain1["x"].astype(np.float64)
+    assert abs(x.mean() - 5.0) < 0.05 and abs(x.std() - 0.7) < 0.05
+    assert chain1.stats["kernel_variant"] == 2                    # hiprtc-specialised register kernel, D = 1
