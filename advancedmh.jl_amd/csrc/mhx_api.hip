@@ -429,6 +429,7 @@ struct mhx_run {
     float* d_pvec = nullptr;
     // emcee
     float stretch = 2.0f;
+    float* d_pmean = nullptr;            // drifting walk: mu[dim] then 2 L^-1 mu [dim]
     // mala
     float mala_sigma = 1.0f;
     float *d_gx = nullptr, *d_gy = nullptr, *d_z = nullptr;
@@ -469,7 +470,7 @@ struct mhx_run {
     ~mhx_run()
     {
         void* ptrs[] = {d_pvec, d_S, d_S2, d_Ssel, d_status, d_dmin, d_dmax, d_eta, d_x, d_lp, d_ybuf,
-                        d_acc, d_last, d_acc_total, d_samples, d_accepted, d_mom_mean, d_mom_m2, d_gx, d_gy, d_z};
+                        d_acc, d_last, d_acc_total, d_samples, d_accepted, d_mom_mean, d_mom_m2, d_gx, d_gy, d_z, d_pmean};
         for (void* p : ptrs) if (p) (void)hipFree(p);
     }
 };
@@ -501,6 +502,7 @@ static mhx_rwmh_args rwmh_args(const mhx_run* r)
     a.save_next = MHX_NO_SAVE; a.thinning = 1;
     a.reduce_lanes = r->coop_L;
     if (r->moments_mode) { a.mom_mean = r->d_mom_mean; a.mom_m2 = r->d_mom_m2; a.mom_n0 = (mhx_u32)r->mom_n; }
+    a.pmean = r->d_pmean;
     return a;
 }
 
@@ -534,6 +536,32 @@ extern "C" int mhx_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh
     if (nvec) HIP_TRY(hipMemcpy(r->d_pvec, cfg->proposal_vec, nvec * sizeof(float), hipMemcpyHostToDevice));
     int rc = run_alloc_state(r.get());
     if (rc) return rc;
+    // drifting random walk: keep mu and 2 L^-1 mu (double arithmetic on the host, rounded once) and use the
+    // generic kernel, the only one that evaluates the Hastings ratio
+    bool drift = false;
+    if (cfg->proposal_mean)
+        for (int k = 0; k < d; ++k) drift = drift || cfg->proposal_mean[k] != 0.0f;
+    if (drift) {
+        std::vector<float> pm(2 * (size_t)d);
+        std::vector<double> m((size_t)d);
+        size_t off = 0;
+        for (int i = 0; i < d; ++i) {
+            double acc = (double)cfg->proposal_mean[i];
+            if (cfg->proposal_kind == MHX_PROP_ISO) m[i] = acc / (double)cfg->proposal_scale;
+            else if (cfg->proposal_kind == MHX_PROP_DIAG) m[i] = acc / (double)cfg->proposal_vec[i];
+            else {
+                for (int j = 0; j < i; ++j) acc -= (double)cfg->proposal_vec[off + j] * m[j];
+                m[i] = acc / (double)cfg->proposal_vec[off + i];
+                off += (size_t)i + 1;
+            }
+            pm[i] = cfg->proposal_mean[i];
+            pm[(size_t)d + i] = (float)(2.0 * m[i]);
+        }
+        HIP_TRY(hipMalloc(&r->d_pmean, pm.size() * sizeof(float)));
+        HIP_TRY(hipMemcpy(r->d_pmean, pm.data(), pm.size() * sizeof(float), hipMemcpyHostToDevice));
+        if (cfg->reduce_lanes > 1) return fail(MHX_EINVAL, "a drifting random walk runs on the generic kernel: reduce_lanes must be 0 or 1");
+        r->flags |= MHX_FLAG_GENERIC;
+    }
 
     // the register / cooperative kernels address a [dim+1][nchains] slab with 32-bit byte offsets
     if (((uint64_t)d + 1) * (uint64_t)r->n * 4ull >= (1ull << 32)) r->flags |= MHX_FLAG_GENERIC;

@@ -54,6 +54,8 @@ struct mhx_rwmh_args {
     float* mom_mean;          // [dim+1][ld] or null
     float* mom_m2;            // [dim+1][ld]
     mhx_u32 mom_n0;           // states already folded in before this launch
+    // drifting random walk (non-zero proposal mean; generic kernel only): mu[dim] followed by 2 L^-1 mu [dim]
+    const float* pmean;       // null = zero mean (the Hastings ratio is then exactly 0 and is not computed)
 };
 
 // one Welford step with the wave-uniform 1/n
@@ -184,18 +186,27 @@ MHX_DEV void mhx_rwmh_generic_body(const mhx_rwmh_args& a, const float* __restri
 
     for (int i = 0; i < a.nsteps; ++i) {
         const mhx_u32 step = a.step0 + (mhx_u32)i;
+        // a drifting walk (proposal mean mu != 0) keeps |z|^2 and |z + 2 L^-1 mu|^2 for its Hastings ratio
+        const float* mu = a.pmean;
+        float fwd = 0.0f, bwd = 0.0f;
         if (a.prop_kind == MHX_PROP_DENSE) {
             for (int b = 0; b < nblk; ++b) {
                 float n[4];
                 mhx_normal4(ks, id_lo, id_hi, step, MHX_STREAM_PROPOSAL, (mhx_u32)b, n);
-                for (int j = 0; j < 4; ++j) if (4 * b + j < d) ys[(long)(4 * b + j) * ld] = n[j];
+                for (int j = 0; j < 4; ++j) {
+                    const int k = 4 * b + j;
+                    if (k < d) {
+                        ys[(long)k * ld] = n[j];
+                        if (mu) { fwd = mhx_fma(n[j], n[j], fwd); const float tk = n[j] + mu[d + k]; bwd = mhx_fma(tk, tk, bwd); }
+                    }
+                }
             }
             // y_r = x_r + sum_{j<=r} L_rj z_j ; rows in descending order so z can be overwritten in place
             for (int r = d - 1; r >= 0; --r) {
                 const float* Lr = pvec + (long)r * (r + 1) / 2;
                 float w = 0.0f;
                 for (int j = 0; j <= r; ++j) w = mhx_fma(Lr[j], ys[(long)j * ld], w);
-                ys[(long)r * ld] = xs[(long)r * ld] + w;
+                ys[(long)r * ld] = mu ? xs[(long)r * ld] + (mu[r] + w) : xs[(long)r * ld] + w;
             }
         } else {
             for (int b = 0; b < nblk; ++b) {
@@ -205,7 +216,14 @@ MHX_DEV void mhx_rwmh_generic_body(const mhx_rwmh_args& a, const float* __restri
                     const int k = 4 * b + j;
                     if (k < d) {
                         const float s = a.prop_kind == MHX_PROP_ISO ? a.pscale : pvec[k];
-                        ys[(long)k * ld] = mhx_fma(s, n[j], xs[(long)k * ld]);
+                        if (mu) {
+                            ys[(long)k * ld] = xs[(long)k * ld] + mhx_fma(s, n[j], mu[k]);
+                            fwd = mhx_fma(n[j], n[j], fwd);
+                            const float tk = n[j] + mu[d + k];
+                            bwd = mhx_fma(tk, tk, bwd);
+                        } else {
+                            ys[(long)k * ld] = mhx_fma(s, n[j], xs[(long)k * ld]);
+                        }
                     }
                 }
             }
@@ -215,7 +233,9 @@ MHX_DEV void mhx_rwmh_generic_body(const mhx_rwmh_args& a, const float* __restri
         yv.ld = ld;
         const float lpy = mhx_target_eval<TK>(a.target_kind, yv, d, tparams, a.ntparams, a.tconst);
         const float logu = mhx_accept_logu(ks, id_lo, id_hi, step, ac);
-        const bool acc = logu < (lpy - lp);
+        // src/mh-core.jl:104-105 with logratio_proposal_density (src/proposal.jl:190-192) when the walk drifts
+        const float loga = mu ? (lpy - lp) + 0.5f * (fwd - bwd) : (lpy - lp);
+        const bool acc = logu < loga;
         lp = acc ? lpy : lp;
         nacc += acc ? 1u : 0u;
         last = acc;
@@ -479,6 +499,7 @@ MHX_DEV void mhx_rwmh_init_body(const mhx_rwmh_args& a, const float* __restrict_
                 const int k = 4 * b + j;
                 if (k < d) {
                     if (a.prop_kind == MHX_PROP_DENSE) xs[(long)k * ld] = n[j];
+                    else if (a.pmean) xs[(long)k * ld] = 0.0f + mhx_fma(a.prop_kind == MHX_PROP_ISO ? a.pscale : pvec[k], n[j], a.pmean[k]);
                     else xs[(long)k * ld] = mhx_fma(a.prop_kind == MHX_PROP_ISO ? a.pscale : pvec[k], n[j], 0.0f);
                 }
             }
@@ -488,7 +509,7 @@ MHX_DEV void mhx_rwmh_init_body(const mhx_rwmh_args& a, const float* __restrict_
                 const float* Lr = pvec + (long)r * (r + 1) / 2;
                 float w = 0.0f;
                 for (int j = 0; j <= r; ++j) w = mhx_fma(Lr[j], xs[(long)j * ld], w);
-                xs[(long)r * ld] = 0.0f + w;
+                xs[(long)r * ld] = a.pmean ? 0.0f + (a.pmean[r] + w) : 0.0f + w;
             }
         }
     }

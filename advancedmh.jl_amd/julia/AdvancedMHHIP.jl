@@ -33,7 +33,8 @@ struct Schedule
 end
 struct RwmhCfg
     dim::Int32; nchains::Int32; seed::UInt64; first_chain::UInt64
-    proposal_kind::Int32; proposal_scale::Cfloat; proposal_vec::Ptr{Cfloat}; flags::Int32; reduce_lanes::Int32
+    proposal_kind::Int32; proposal_scale::Cfloat; proposal_vec::Ptr{Cfloat}; flags::Int32
+    proposal_mean::Ptr{Cfloat}; reduce_lanes::Int32
 end
 struct EmceeCfg
     dim::Int32; nwalkers::Int32; seed::UInt64; ensemble_id::UInt64; stretch::Cfloat; flags::Int32; reduce_lanes::Int32
@@ -95,9 +96,8 @@ function target(ctx::Ptr{Cvoid}, t::DeviceLogDensity)
     return h[], dim
 end
 
-# MvNormal -> (kind, scale, vec); zero mean only (src/proposal.jl:58-64: otherwise the Hastings ratio is not 0)
+# MvNormal -> (kind, scale, vec); a non-zero mean is passed separately (drifting walk, Hastings ratio on the device)
 function proposal_spec(d::MvNormal)
-    all(iszero, mean(d)) || throw(ArgumentError("random-walk proposals on the GPU path must be zero-mean"))
     Σ = cov(d)
     if Σ ≈ Σ[1, 1] * I
         return Int32(0), Float32(sqrt(Σ[1, 1])), Float32[]
@@ -126,8 +126,10 @@ function AbstractMCMC.sample(
         prop = sampler.proposal
         prop isa AdvancedMH.RandomWalkProposal || throw(ArgumentError("the GPU path implements RandomWalkProposal only"))
         kind, scale, vec = proposal_spec(prop.proposal)
-        GC.@preserve vec begin
-            cfg = RwmhCfg(d, n, seed, ens.first_chain, kind, scale, pointer(vec), 0, 0)
+        μ = Float32.(mean(prop.proposal))
+        GC.@preserve vec μ begin
+            cfg = RwmhCfg(d, n, seed, ens.first_chain, kind, scale, pointer(vec), 0,
+                          all(iszero, μ) ? Ptr{Cfloat}(C_NULL) : pointer(μ), 0)
             check(ccall((:mhx_rwmh_create, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{RwmhCfg}, Ref{Ptr{Cvoid}}),
                         ctx[], tgt, cfg, run))
         end

@@ -38,7 +38,8 @@ class Schedule(C.Structure):
 class RwmhCfg(C.Structure):
     _fields_ = [("dim", C.c_int32), ("nchains", C.c_int32), ("seed", C.c_uint64), ("first_chain", C.c_uint64),
                 ("proposal_kind", C.c_int32), ("proposal_scale", C.c_float),
-                ("proposal_vec", C.POINTER(C.c_float)), ("flags", C.c_int32), ("reduce_lanes", C.c_int32)]
+                ("proposal_vec", C.POINTER(C.c_float)), ("flags", C.c_int32),
+                ("proposal_mean", C.POINTER(C.c_float)), ("reduce_lanes", C.c_int32)]
 
 
 class EmceeCfg(C.Structure):

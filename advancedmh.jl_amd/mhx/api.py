@@ -251,10 +251,10 @@ class RandomWalkProposal:
     def __init__(self, proposal, issymmetric=False):
         self.proposal = _as_mvnormal(proposal)
         self.issymmetric = issymmetric
-        if np.any(self.proposal.mean != 0):
-            # src/proposal.jl:58-64: a non-zero-mean random walk has a non-zero Hastings ratio;
-            # the device path implements the zero-mean (ratio == 0) case only.
-            raise L.ArgumentError(L.MHX_EINVAL, "random-walk proposals on the GPU path must be zero-mean")
+        # a non-zero mean makes the walk drift; its Hastings ratio (src/proposal.jl:58-64,190-192) is then
+        # evaluated on the device (generic kernel).  Declaring such a proposal symmetric would skip it.
+        if issymmetric and np.any(self.proposal.mean != 0):
+            raise L.ArgumentError(L.MHX_EINVAL, "a random-walk proposal with a non-zero mean is not symmetric")
 
 
 def SymmetricRandomWalkProposal(proposal):
@@ -379,8 +379,9 @@ class Run:
             if mv.dim != d:
                 raise L.ArgumentError(L.MHX_EINVAL, "proposal dimension %d != model dimension %d" % (mv.dim, d))
             vec = None if mv.vec is None else L.f32(mv.vec)
-            self._keep.append(vec)
-            cfg = L.RwmhCfg(d, nchains, seed, first_chain, mv.kind, mv.scale, L.fptr(vec), flags, reduce_lanes)
+            mean = L.f32(mv.mean) if np.any(mv.mean != 0) else None
+            self._keep += [vec, mean]
+            cfg = L.RwmhCfg(d, nchains, seed, first_chain, mv.kind, mv.scale, L.fptr(vec), flags, L.fptr(mean), reduce_lanes)
             L.check(lib.mhx_rwmh_create(self.ctx.h, model.handle(self.ctx), C.byref(cfg), C.byref(self.h)))
             self.n = nchains
             self.kind = "rwmh"

@@ -96,10 +96,13 @@ typedef struct {
     int32_t nchains;
     uint64_t seed;
     uint64_t first_chain;   /* global id of chain 0 of this shard */
-    int32_t proposal_kind;  /* mhx_proposal_kind; proposals are zero-mean (src/proposal.jl:49-64) */
+    int32_t proposal_kind;  /* one of mhx_proposal_kind; src/proposal.jl:49-64 */
     float proposal_scale;   /* ISO: sigma of N(0, sigma^2 I) */
     const float *proposal_vec; /* DIAG: sigma_k [dim]; DENSE: chol(Sigma) packed lower [dim(dim+1)/2] */
     int32_t flags;          /* MHX_FLAG_* */
+    const float *proposal_mean; /* NULL = zero mean.  mu[dim]: a drifting random walk x + mu + L z; its Hastings ratio
+                               q(x | y) - q(y | x) (src/proposal.jl:58-64,190-192) is then non-zero and is computed.
+                               Runs on the generic kernel. */
     int32_t reduce_lanes;   /* lanes that share one chain (power of two <= 64) for the separable catalogue
                                targets; 0 = let the engine choose from nchains and dim, 1 = one lane per chain.
                                The value in effect is reported in mhx_stats.reduce_lanes: it fixes the

@@ -314,23 +314,44 @@ float orc_target_eval(const orc_target *t, const float *x)
  * reference call sites: src/proposal.jl:24-25 (rand), :41-47 (initial), :49-56 (t + rand).   */
 static void propose_from(const orc_proposal *p, int d, const float *z, const float *x, float *y)
 {
+    const float *mu = p->mean;
     switch (p->kind) {
     case ORC_PROP_ISO:
-        for (int k = 0; k < d; ++k) y[k] = fmaf(p->scale, z[k], x[k]);
+        for (int k = 0; k < d; ++k) y[k] = mu ? x[k] + fmaf(p->scale, z[k], mu[k]) : fmaf(p->scale, z[k], x[k]);
         break;
     case ORC_PROP_DIAG:
-        for (int k = 0; k < d; ++k) y[k] = fmaf(p->vec[k], z[k], x[k]);
+        for (int k = 0; k < d; ++k) y[k] = mu ? x[k] + fmaf(p->vec[k], z[k], mu[k]) : fmaf(p->vec[k], z[k], x[k]);
         break;
     default: {
         size_t off = 0;
         for (int i = 0; i < d; ++i) {
             float w = 0.0f;
             for (int j = 0; j <= i; ++j) w = fmaf(p->vec[off + j], z[j], w);
-            y[i] = x[i] + w;
+            y[i] = mu ? x[i] + (mu[i] + w) : x[i] + w;
             off += (size_t)i + 1;
         }
     }
     }
+}
+
+/* twice the whitened mean 2 L^-1 mu (host arithmetic in double, rounded once): with it the Hastings ratio of a
+ * drifting random walk is  logq(x|y) - logq(y|x) = 1/2 |z|^2 - 1/2 |z + 2 L^-1 mu|^2   (src/proposal.jl:58-64,190-192) */
+static void whitened_mean2(const orc_proposal *p, int d, float *tm)
+{
+    double *m = malloc(sizeof(double) * (size_t)d);
+    size_t off = 0;
+    for (int i = 0; i < d; ++i) {
+        double acc = (double)p->mean[i];
+        if (p->kind == ORC_PROP_ISO) m[i] = acc / (double)p->scale;
+        else if (p->kind == ORC_PROP_DIAG) m[i] = acc / (double)p->vec[i];
+        else {
+            for (int j = 0; j < i; ++j) acc -= (double)p->vec[off + j] * m[j];
+            m[i] = acc / (double)p->vec[off + i];
+            off += (size_t)i + 1;
+        }
+        tm[i] = (float)(2.0 * m[i]);
+    }
+    free(m);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -377,8 +398,9 @@ int orc_rwmh(const orc_target *t, const orc_proposal *p, const orc_schedule *s,
     const int d = t->dim, C = nchains;
     int64_t nT, nA;
     orc_schedule_counts(s, &nT, &nA);
-    float *x = malloc(sizeof(float) * (size_t)d * 3);
-    float *y = x + d, *z = y + d;
+    float *x = malloc(sizeof(float) * (size_t)d * 4);
+    float *y = x + d, *z = y + d, *tm = z + d;
+    if (p->mean) whitened_mean2(p, d, tm);
     for (int c = 0; c < C; ++c) {
         const uint64_t id = first_chain + (uint64_t)c;
         /* mh-core.jl:83  params = initial_params === nothing ? propose(rng, sampler, model) : initial_params
@@ -400,6 +422,15 @@ int orc_rwmh(const orc_target *t, const orc_proposal *p, const orc_schedule *s,
             propose_from(p, d, z, x, y);                /* mh-core.jl:100 */
             float lpy = orc_target_eval(t, y);          /* :103 */
             float loga = lpy - lp;                      /* :104-105, Hastings ratio of a zero-mean RW == 0 */
+            if (p->mean) {                              /* :105,119-123 -> proposal.jl:190-192 */
+                float fwd = 0.0f, bwd = 0.0f;
+                for (int k = 0; k < d; ++k) {
+                    fwd = fmaf(z[k], z[k], fwd);
+                    const float tk = z[k] + tm[k];
+                    bwd = fmaf(tk, tk, bwd);
+                }
+                loga = (lpy - lp) + 0.5f * (fwd - bwd);
+            }
             float logu = orc_accept_logu(seed, id, step);
             int acc = logu < loga;                      /* :108  -randexp(rng) < loga (strict; NaN -> reject) */
             if (acc) { memcpy(x, y, sizeof(float) * (size_t)d); lp = lpy; ++nacc; }

@@ -78,6 +78,8 @@ typedef struct {
     int kind;
     float scale;          /* ISO: sigma                                  */
     const float *vec;     /* DIAG: sigma_k[d]; DENSE: packed lower L     */
+    const float *mean;    /* NULL = zero mean; else mu[d]: the random walk drifts and the Hastings ratio
+                             q(x | y) - q(y | x) of src/proposal.jl:58-64,190-192 is no longer zero */
 } orc_proposal;
 
 /* ---- schedule [upstream AbstractMCMC.mcmcsample, restated] ---- */

@@ -25,7 +25,7 @@ class _Target(C.Structure):
 
 
 class _Proposal(C.Structure):
-    _fields_ = [("kind", C.c_int), ("scale", C.c_float), ("vec", C.POINTER(C.c_float))]
+    _fields_ = [("kind", C.c_int), ("scale", C.c_float), ("vec", C.POINTER(C.c_float)), ("mean", C.POINTER(C.c_float))]
 
 
 class _Schedule(C.Structure):
@@ -182,9 +182,10 @@ def unpack_lower(p, d):
 
 
 class Proposal:
-    def __init__(self, kind, scale=1.0, vec=None):
+    def __init__(self, kind, scale=1.0, vec=None, mean=None):
         self.vec = None if vec is None else np.ascontiguousarray(vec, dtype=np.float32)
-        self.c = _Proposal(kind, float(scale), _fp(self.vec))
+        self.mean = None if mean is None else np.ascontiguousarray(mean, dtype=np.float32)
+        self.c = _Proposal(kind, float(scale), _fp(self.vec), _fp(self.mean))
 
 
 def schedule(n_samples, discard_initial=0, thinning=1, num_warmup=0):

@@ -193,8 +193,8 @@ def test_running_moments_match_sample_statistics(mhx, flags_name, d, C, lanes):
 def test_error_behaviour(mhx):
     with pytest.raises(mhx.ArgumentError):                      # dim mismatch
         mhx.sample(mhx.DensityModel(mhx.IsoGaussian(3)), mhx.RWMH(4), 5)
-    with pytest.raises(mhx.ArgumentError):                      # non-zero-mean RW proposal (Hastings ratio != 0)
-        mhx.RWMH(mhx.MvNormal(np.ones(3), mhx.I))
+    with pytest.raises(mhx.ArgumentError):                      # a drifting walk declared symmetric
+        mhx.SymmetricRandomWalkProposal(mhx.MvNormal(np.ones(3), mhx.I))
     with pytest.raises(mhx.ArgumentError):                      # a Python closure cannot be lowered
         mhx.DensityModel(lambda x: -0.5 * (x ** 2).sum())
     with pytest.raises(mhx.MhxError) as ei:                     # bad user source -> compile error at model construction
@@ -259,3 +259,30 @@ def test_symmetric_random_walk_on_a_scalar_model(mhx):
     x = chain1["x"].astype(np.float64)
     assert abs(x.mean() - 5.0) < 0.05 and abs(x.std() - 0.7) < 0.05
     assert chain1.stats["kernel_variant"] == 2                    # hiprtc-specialised register kernel, D = 1
+
+
+@pytest.mark.parametrize("kind", ["iso", "diag", "dense"])
+def test_drifting_random_walk_hastings_ratio(mhx, oracle, kind):
+    """RandomWalkProposal(MvNormal(mu != 0, Sigma)): the walk drifts and logratio_proposal_density
+    (src/proposal.jl:58-64,190-192) is no longer 0 -- evaluated on the device, bit-exact against the oracle, and the
+    chain still targets the model (the ratio cancels the drift)."""
+    d, C, N = 3, 96, 60
+    mean = np.array([0.3, -0.2, 0.1])
+    if kind == "iso":
+        cov, oprop = 0.64 * mhx.I, oracle.Proposal(oracle.PROP_ISO, 0.8, mean=mean)
+    elif kind == "diag":
+        sd = np.array([0.5, 1.0, 0.25])
+        cov, oprop = sd ** 2, oracle.Proposal(oracle.PROP_DIAG, vec=sd, mean=mean)
+    else:
+        Sg = 0.5 * np.array([[1, .3, 0], [.3, 1, .2], [0, .2, 1.0]])
+        cov, oprop = Sg, oracle.Proposal(oracle.PROP_DENSE, vec=oracle.pack_lower(np.linalg.cholesky(Sg)), mean=mean)
+    model = mhx.DensityModel(mhx.IsoGaussian(d))
+    spl = mhx.RWMH(mhx.MvNormal(mean, cov))
+    chain = mhx.sample(model, spl, N, C, seed=5, first_chain=2)
+    assert chain.stats["kernel_variant"] == 0
+    ref = oracle.rwmh(oracle.iso_gauss(d), oprop, oracle.schedule(N), 5, 2, C)
+    _same(chain.value, ref["samples"], "samples")
+    _same(chain.accepted, ref["accepted"], "accepted")
+    long = mhx.sample(model, spl, 4000, 256, seed=6, discard_initial=500)
+    v = long.value[:, :d, :].astype(np.float64)
+    assert np.abs(v.mean(axis=(0, 2))).max() < 0.05 and np.abs(v.var(axis=(0, 2)) - 1).max() < 0.05

@@ -32,8 +32,9 @@ def test_no_gpu_fails_loudly_not_silently(mhx):
 
 
 def test_host_side_argument_errors(mhx):
-    with pytest.raises(mhx.ArgumentError):
-        mhx.RWMH(mhx.MvNormal(np.ones(3), mhx.I))               # non-zero mean (src/proposal.jl:58-64)
+    assert mhx.RWMH(mhx.MvNormal(np.ones(3), mhx.I)).proposal.proposal.mean.sum() == 3   # a drifting walk is allowed ...
+    with pytest.raises(mhx.ArgumentError):                      # ... but it is not symmetric (src/proposal.jl:195)
+        mhx.SymmetricRandomWalkProposal(mhx.MvNormal(np.ones(3), mhx.I))
     with pytest.raises(mhx.ArgumentError):
         mhx.DensityModel(lambda x: 0.0)
     with pytest.raises(mhx.ArgumentError):

@@ -175,3 +175,12 @@ def test_catalogue_gradients_against_finite_differences(oracle):
             e = np.zeros(d, dtype=np.float32)
             e[k] = 1e-3
             assert abs(g[k] - (t(x + e) - t(x - e)) / 2e-3) < 2e-3 * max(1.0, abs(g[k]))
+
+
+def test_drifting_walk_is_corrected_by_the_hastings_ratio(oracle):
+    """src/proposal.jl:58-64,190-192: with a non-zero proposal mean the ratio q(x|y) - q(y|x) is what keeps the target invariant."""
+    d = 3
+    mean = np.array([0.3, -0.2, 0.1], dtype=np.float32)
+    r = oracle.rwmh(oracle.iso_gauss(d), oracle.Proposal(oracle.PROP_ISO, 0.8, mean=mean), oracle.schedule(40000, 1000), 5, 0, 8)
+    v = r["samples"][:, :d, :].astype(np.float64)
+    assert np.abs(v.mean(axis=(0, 2))).max() < 0.03 and np.abs(v.var(axis=(0, 2)) - 1).max() < 0.03
