@@ -435,7 +435,7 @@ struct mhx_run {
     float *d_gx = nullptr, *d_gy = nullptr, *d_z = nullptr;
     // ram
     mhx_ram_cfg ramcfg{};
-    float *d_S = nullptr, *d_S2 = nullptr;       // packed factors (current / scratch), [n][tri] each
+    float* d_S = nullptr;                        // packed factors [n][2][tri_pad]: both buffers of a chain side by side
     unsigned char* d_Ssel = nullptr;             // which buffer holds chain c's current factor
     unsigned char* d_status = nullptr;
     float *d_dmin = nullptr, *d_dmax = nullptr;  // [dim][n]
@@ -469,7 +469,7 @@ struct mhx_run {
 
     ~mhx_run()
     {
-        void* ptrs[] = {d_pvec, d_S, d_S2, d_Ssel, d_status, d_dmin, d_dmax, d_eta, d_x, d_lp, d_ybuf,
+        void* ptrs[] = {d_pvec, d_S, d_Ssel, d_status, d_dmin, d_dmax, d_eta, d_x, d_lp, d_ybuf,
                         d_acc, d_last, d_acc_total, d_samples, d_accepted, d_mom_mean, d_mom_m2, d_gx, d_gy, d_z, d_pmean};
         for (void* p : ptrs) if (p) (void)hipFree(p);
     }

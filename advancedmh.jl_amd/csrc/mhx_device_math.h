@@ -16,6 +16,7 @@
 #endif
 
 #define MHX_DEV __device__ __forceinline__
+#define MHX_HD __host__ __device__ __forceinline__
 
 typedef unsigned int mhx_u32;
 typedef unsigned long long mhx_u64;
