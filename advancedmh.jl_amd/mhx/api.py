@@ -396,7 +396,7 @@ class Run:
             self.n = nchains
             self.kind = "mala"
         elif isinstance(sampler, RobustAdaptiveMetropolis):
-            if sampler.S is not None and sampler.S.shape != (d, d):
+            if sampler.S is not None and sampler.S.shape != (d, d) and sampler.S.shape != (nchains, d, d):
                 # src/RobustAdaptiveMetropolis.jl:202-204
                 raise L.ArgumentError(L.MHX_EINVAL, "The provided `S` has the wrong dimensionality.")
             cfg = L.RamCfg(d, nchains, seed, first_chain, sampler.α, sampler.γ, sampler.eigenvalue_lower_bound,
@@ -405,7 +405,10 @@ class Run:
             self.n = nchains
             self.kind = "ram"
             if sampler.S is not None:
-                S = np.tile(pack_lower(np.tril(sampler.S)), (nchains, 1))
+                if sampler.S.ndim == 3:                      # one factor per chain (the C ABI's native form)
+                    S = np.stack([pack_lower(np.tril(sampler.S[c])) for c in range(nchains)])
+                else:
+                    S = np.tile(pack_lower(np.tril(sampler.S)), (nchains, 1))
                 L.check(lib.mhx_ram_set_factor(self.h, L.fptr(L.f32(S))))
         else:
             raise L.ArgumentError(L.MHX_EINVAL, "unsupported sampler %r" % (sampler,))

@@ -128,3 +128,43 @@ def test_ram_doctest_covariance(mhx):
             assert np.linalg.norm(cov - Sig) < 0.2 * np.linalg.norm(Sig) + 0.05
         allcov = np.cov(v.transpose(1, 0, 2).reshape(2, -1))
         assert np.abs(allcov - Sig).max() < 0.05
+
+
+# one dimension per pre-built kernel shape (lanes per chain x rows per lane): 16x{1,2,4}, 32x{3..8},
+# 64x{5,6,7,8,12,16}; odd chain counts leave idle lane groups in the last wave
+@pytest.mark.parametrize("d", [16, 30, 50, 64, 90, 128, 150, 190, 224, 250, 300, 380, 448, 500, 700, 1000])
+def test_ram_every_kernel_shape(mhx, oracle, d):
+    C, N, warm = 5, 5, 4
+    Sig = cases.sigma_ar1(d, 0.6)
+    init = np.zeros((d, C), dtype=np.float32)
+    chain, S, st, lo, hi, x, lp, cnt = _run(mhx, mhx.DensityModel(mhx.CorrGaussian(Sig)), mhx.RobustAdaptiveMetropolis(),
+                                            N, C, 900 + d, 1, init, num_warmup=warm, discard_initial=0)
+    ref = oracle.ram(oracle.corr_gauss_from_cov(Sig), oracle.schedule(N, 0, 1, warm), 900 + d, 1, C, init=init)
+    _same(chain.value, ref["samples"], "samples")
+    _same(S, ref["S"], "S")
+    _same(x, ref["final_x"], "final x")
+    _same(lo, ref["diag_min"], "diag min")
+    _same(hi, ref["diag_max"], "diag max")
+    _same(st, ref["status"], "status")
+
+
+def test_ram_chains_of_one_wave_fail_independently(mhx, oracle):
+    """Chains that share a wave (16-lane groups at d = 6) take different paths: one starts at NaN (its
+    adaptation is skipped every step, status bit 1 -- RAM.jl:159); with a GROWING step size (gamma = -1,
+    eta = iteration) the downdates of the others leave the PD cone at different steps (status bit 0, the
+    old factor is kept -- RAM.jl:259-264) while their updates still go through."""
+    d, C, N = 6, 7, 12
+    init = np.zeros((d, C), dtype=np.float32)
+    init[:, 2] = np.nan
+    L = np.tile(np.eye(d, dtype=np.float32), (C, 1, 1))
+    L[5] *= 40.0
+    Sin = np.stack([oracle.pack_lower(L[c]) for c in range(C)])
+    model = mhx.DensityModel(mhx.IsoGaussian(d))
+    spl = mhx.RobustAdaptiveMetropolis(γ=-1.0, S=L)
+    chain, S, st, lo, hi, x, lp, cnt = _run(mhx, model, spl, N, C, 41, 0, init, num_warmup=N, discard_initial=0)
+    ref = oracle.ram(oracle.iso_gauss(d), oracle.schedule(N, 0, 1, N), 41, 0, C, init=init, S_in=Sin, gamma=-1.0)
+    _same(st, ref["status"], "status")
+    _same(S, ref["S"], "S")
+    _same(chain.value, ref["samples"], "samples")
+    _same(lo, ref["diag_min"], "diag min")
+    assert st[2] == 2 and (st[[0, 1, 3, 4, 5, 6]] & 1).all()
