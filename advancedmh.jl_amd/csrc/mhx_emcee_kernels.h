@@ -139,12 +139,18 @@ MHX_DEV void mhx_emcee_init_body(const mhx_emcee_args& a, const float* __restric
 // and every lane owns D/L dimensions of the move and D/L rows of A y.  The candidate is exchanged
 // through LDS (broadcast reads within a walker's lane group); the L partial sums of squares meet in
 // an xor-butterfly -- the reduction shape is part of the arithmetic spec (oracle: reduce_lanes = L).
+#define MHX_EMCEE_COOP_WAVES 4                   // waves per block: they share the LDS copy of the factor
 template <int D, int L>
-MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const float* __restrict__ A, float* ysh)
+MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const float* __restrict__ A, float* ysh_all, float* Ash)
 {
     constexpr int CPW = 64 / L;                  // walkers per wave
     constexpr int NK = (D + L - 1) / L;          // dimensions (and rows) per lane
     constexpr int DP = D | 1;                    // odd LDS row pitch: the CPW walkers hit distinct banks
+    constexpr int NA = D * (D + 1) / 2;
+    // the packed factor, once per block, coalesced (a lane's row reads are scattered: from LDS, not L2)
+    for (int e = threadIdx.x; e < NA; e += 64 * MHX_EMCEE_COOP_WAVES) Ash[e] = A[e];
+    const int wave = threadIdx.x >> 6;
+    float* ysh = ysh_all + wave * (CPW * DP);
     const int W = a.nwalkers;
     const int halfW = W / 2;
     const int lo = a.half ? halfW : 0;
@@ -152,7 +158,7 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const float* __restric
     const int lane = threadIdx.x & 63;
     const int cw = lane & (CPW - 1);
     const int l = lane / CPW;
-    const int t_raw = blockIdx.x * CPW + cw;     // one wave per block
+    const int t_raw = (blockIdx.x * MHX_EMCEE_COOP_WAVES + wave) * CPW + cw;
     const bool valid = t_raw < cnt;
     const int i = lo + (valid ? t_raw : cnt - 1);
     const int ostart = a.half ? 0 : halfW;
@@ -190,16 +196,13 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const float* __restric
         const int r = l + L * m;                                         // this lane's row of A y
         const int rmax = (L * m + L - 1) < (D - 1) ? (L * m + L - 1) : (D - 1);   // wave-uniform trip count
         const int rc = r < D ? r : 0;                                    // rows past the end shadow row 0 (masked below)
-        const float* Ar = A + (long)rc * (rc + 1) / 2;
-        // unconditional, index-clamped loads: all of a row's entries are in flight together (L1/L2 hits)
-        float av[D];
-#pragma unroll
-        for (int jj = 0; jj <= rmax; ++jj) av[jj] = Ar[jj <= rc ? jj : rc];
+        const float* Ar = Ash + rc * (rc + 1) / 2;
         float w = 0.0f;
 #pragma unroll
         for (int jj = 0; jj <= rmax; ++jj) {
+            const float av = Ar[jj <= rc ? jj : rc];                     // index-clamped: no divergent reads
             const float yv = yrow[jj];
-            w = (r < D && jj <= r) ? mhx_fma(av[jj], yv, w) : w;
+            w = (r < D && jj <= r) ? mhx_fma(av, yv, w) : w;
         }
         q = r < D ? mhx_fma(w, w, q) : q;
     }
@@ -232,12 +235,17 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const float* __restric
 }
 
 #ifdef MHX_JIT_EMCEE
+#if MHX_JIT_L > 1
+extern "C" __global__ void __launch_bounds__(64 * MHX_EMCEE_COOP_WAVES)
+#else
 extern "C" __global__ void __launch_bounds__(64)
+#endif
 mhx_jit_emcee_half(const mhx_emcee_args a, const float* __restrict__ tparams)
 {
 #if MHX_JIT_L > 1
-    __shared__ float ysh[(64 / MHX_JIT_L) * (MHX_JIT_DIM | 1)];
-    mhx_emcee_coop_body<MHX_JIT_DIM, MHX_JIT_L>(a, tparams, ysh);
+    __shared__ float ysh[MHX_EMCEE_COOP_WAVES * (64 / MHX_JIT_L) * (MHX_JIT_DIM | 1)];
+    __shared__ float Ash[MHX_JIT_DIM * (MHX_JIT_DIM + 1) / 2];
+    mhx_emcee_coop_body<MHX_JIT_DIM, MHX_JIT_L>(a, tparams, ysh, Ash);
 #else
     mhx_emcee_half_body<MHX_JIT_DIM, MHX_JIT_TK>(a, tparams);
 #endif
