@@ -188,7 +188,7 @@ static int jit_compile(mhx_ctx* ctx, const std::string& key, const std::string& 
                               "mhx_emcee_kernels.h", "mhx_ram_kernels.h", "mhx_mala_kernels.h"};
     hiprtcResult r = hiprtcCreateProgram(&prog, source.c_str(), "mhx_jit.hip", 6, hdr_src, hdr_name);
     if (r != HIPRTC_SUCCESS) return fail(MHX_EJIT, "hiprtcCreateProgram: %s", hiprtcGetErrorString(r));
-    std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
+    std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize"};
     for (auto& d : defines) opts.push_back("-D" + d);
     std::vector<const char*> copts;
     for (auto& o : opts) copts.push_back(o.c_str());

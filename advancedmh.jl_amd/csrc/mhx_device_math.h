@@ -77,14 +77,17 @@ MHX_DEV mhx_philox_key mhx_philox_schedule(mhx_u64 seed)
     return ks;
 }
 
+// a ^ b ^ c in one instruction (v_bitop3_b32, truth table 0x96); hipcc leaves it as two v_xor_b32
+MHX_DEV mhx_u32 mhx_xor3(mhx_u32 a, mhx_u32 b, mhx_u32 c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+
 MHX_DEV mhx_u32x4 mhx_philox(const mhx_philox_key& ks, mhx_u32 c0, mhx_u32 c1, mhx_u32 c2, mhx_u32 c3)
 {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const mhx_u64 p0 = (mhx_u64)0xD2511F53u * c0;
         const mhx_u64 p1 = (mhx_u64)0xCD9E8D57u * c2;
-        const mhx_u32 n0 = (mhx_u32)(p1 >> 32) ^ c1 ^ ks.k0[r];
-        const mhx_u32 n2 = (mhx_u32)(p0 >> 32) ^ c3 ^ ks.k1[r];
+        const mhx_u32 n0 = mhx_xor3((mhx_u32)(p1 >> 32), c1, ks.k0[r]);
+        const mhx_u32 n2 = mhx_xor3((mhx_u32)(p0 >> 32), c3, ks.k1[r]);
         c1 = (mhx_u32)p1; c3 = (mhx_u32)p0; c0 = n0; c2 = n2;
     }
     mhx_u32x4 o; o.x = c0; o.y = c1; o.z = c2; o.w = c3;
@@ -185,6 +188,19 @@ MHX_DEV float mhx_exp(float x)
 
 MHX_DEV float mhx_sqrt(float x) { return __builtin_sqrtf(x); }   // correctly rounded (default HIP lowering)
 
+// Correctly rounded sqrt for x that is +-0 or a NORMAL positive number: the hardware estimate (1 ulp) and
+// the same two-residual fix-up hipcc emits, without its denormal pre-scaling and class test (7 of 17
+// instructions).  The Box-Muller radius argument -2 ln u is 0 or >= 1.19e-7.
+MHX_DEV float mhx_sqrt_normal(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = mhx_u2f(mhx_f2u(s) - 1u), sp = mhx_u2f(mhx_f2u(s) + 1u);
+    const float rm = mhx_fma(-sm, s, x), rp = mhx_fma(-sp, s, x);
+    float r = (0.0f >= rm) ? sm : s;
+    r = (0.0f < rp) ? sp : r;
+    return r;
+}
+
 // sin/cos of 2*pi*k/2^32: integer quadrant reduction, degree-4 polynomials in r^2 on |r| <= 1/8 turn
 MHX_DEV void mhx_sincos2pi_u32(mhx_u32 k, float& s, float& c)
 {
@@ -221,7 +237,7 @@ MHX_DEV float mhx_u01_half(mhx_u32 k) { return (float)(k >> 8) * 0x1p-24f; }    
 MHX_DEV void mhx_normal_pair(mhx_u32 k0, mhx_u32 k1, float& n0, float& n1)
 {
     const float l = mhx_log_pos(mhx_u01_open(k0));
-    const float rad = mhx_sqrt(-2.0f * l);
+    const float rad = mhx_sqrt_normal(-2.0f * l);
     float s, c;
     mhx_sincos2pi_u32(k1, s, c);
     n0 = rad * c;
