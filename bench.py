@@ -26,6 +26,7 @@ sys.path.insert(0, os.path.join(ROOT, "advancedmh.jl_amd"))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s achievable)
+VALU_PEAK = 256 * 4 * 2.4e9 / 4.0   # wave64 VALU instructions per second: 16-lane SIMDs, 4 cycles per instruction
 D = 100
 CHAINS = 65536
 VARIANTS = {0: "generic", 1: "prebuilt-register", 2: "hiprtc-register", 3: "prebuilt-cooperative",
@@ -152,14 +153,20 @@ def main():
         launch_s = kernel_ms * 1e-3 / args.steps
         bytes_launch = algorithmic_bytes_per_launch(d, C, inner)
         achieved = bytes_launch / launch_s / 1e9
-        traffic = None
+        traffic, valu = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                tj = json.load(open(tpath))
-                traffic = tj.get("rwmh_d%d_c%d_inner%d" % (d, C, inner), {}).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath)).get("rwmh_d%d_c%d_inner%d" % (d, C, inner), {})
+                traffic = tj.get("hbm_bytes_per_launch")
+                if tj.get("valu_insts_per_launch"):
+                    # what actually bounds the kernel: wave-instructions (PMC SQ_INSTS_VALU) per second against
+                    # 256 CUs x 4 SIMDs x one wave64 VALU instruction per 4 cycles at 2.4 GHz
+                    rate = tj["valu_insts_per_launch"] / launch_s
+                    valu = {"wave_insts_per_launch": tj["valu_insts_per_launch"], "achieved_per_s": rate,
+                            "peak_per_s": VALU_PEAK, "frac": rate / VALU_PEAK}
             except Exception:
-                traffic = None
+                traffic, valu = None, None
         essb = np.asarray(diag["ess_between"][:d], dtype=np.float64)
         out = {
             "metric": "MH steps/sec (all chains) + ESS/sec", "value": value, "unit": "MH steps/s",
@@ -182,8 +189,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_rwmh_coop<2,13,iso,iso>" if variant == 3 else "rwmh variant %d" % variant,
                          "avg_launch_ms": launch_s * 1e3, "algorithmic_bytes_per_launch": bytes_launch,
-                         "note": "VALU-bound kernel (Philox4x32-10 + Box-Muller polynomials, ~4.8k wave-instructions "
-                                 "per 64 chain-steps); HBM sees only the sample records"},
+                         "valu": valu,
+                         "note": "VALU-issue-bound kernel (Philox4x32-10 + Box-Muller polynomials, 64 wave-instructions "
+                                 "per chain-step, PMC SQ_INSTS_VALU); HBM sees only the sample records"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(d, inner, 0xC0FFEE)
