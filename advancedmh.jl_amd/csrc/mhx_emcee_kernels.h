@@ -140,17 +140,48 @@ MHX_DEV void mhx_emcee_init_body(const mhx_emcee_args& a, const float* __restric
 // through LDS (broadcast reads within a walker's lane group); the L partial sums of squares meet in
 // an xor-butterfly -- the reduction shape is part of the arithmetic spec (oracle: reduce_lanes = L).
 #define MHX_EMCEE_COOP_WAVES 4                   // waves per block: they share the LDS copy of the factor
+
+typedef float mhx_e4 __attribute__((ext_vector_type(4)));
+
+// LDS image of the packed factor for L lanes per walker.  Lane l owns rows l, l+L, ...; row set m
+// (rows L m .. L m + L - 1) is stored as LEN4(m) groups of L float4 -- group jj4 holds columns
+// 4 jj4 .. 4 jj4 + 3 of the L rows, so a lane group reads L consecutive float4 (no bank conflicts) --
+// zero-filled above the diagonal: fma(0, y, w) == w, the row dot needs no masks.
 template <int D, int L>
-MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const float* __restrict__ A, float* ysh_all, float* Ash)
+struct mhx_emcee_geom {
+    static constexpr int NK = (D + L - 1) / L;
+    static constexpr int DP4 = ((D + 3) & ~3) + 4;           // y row pitch: 16-byte aligned, spread over the banks
+    MHX_HD static constexpr int len4(int m) { return ((L * (m + 1) < D ? L * (m + 1) : D) + 3) / 4; }
+    MHX_HD static constexpr int off4(int m) { int o = 0; for (int k = 0; k < m; ++k) o += len4(k) * L; return o; }
+    static constexpr int TOTAL4 = off4(NK);
+};
+
+template <int D, int L>
+MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const float* __restrict__ A, float* ysh_all, mhx_e4* Ash4)
 {
+    typedef mhx_emcee_geom<D, L> GEO;
     constexpr int CPW = 64 / L;                  // walkers per wave
-    constexpr int NK = (D + L - 1) / L;          // dimensions (and rows) per lane
-    constexpr int DP = D | 1;                    // odd LDS row pitch: the CPW walkers hit distinct banks
-    constexpr int NA = D * (D + 1) / 2;
-    // the packed factor, once per block, coalesced (a lane's row reads are scattered: from LDS, not L2)
-    for (int e = threadIdx.x; e < NA; e += 64 * MHX_EMCEE_COOP_WAVES) Ash[e] = A[e];
+    constexpr int NK = GEO::NK;                  // dimensions (and rows) per lane
+    constexpr int DP4 = GEO::DP4;
+    // the factor, once per block (a lane's row reads are scattered: from LDS, not L2)
+#pragma unroll
+    for (int m = 0; m < NK; ++m) {
+        constexpr int dummy = 0; (void)dummy;
+        const int n4 = GEO::len4(m) * L;
+        for (int g = threadIdx.x; g < n4; g += 64 * MHX_EMCEE_COOP_WAVES) {
+            const int jj4 = g / L, rl = g % L;
+            const int r = rl + L * m;
+            const float* Ar = A + (r < D ? r * (r + 1) / 2 : 0);
+            mhx_e4 v;
+            v.x = (r < D && 4 * jj4 + 0 <= r) ? Ar[4 * jj4 + 0] : 0.0f;
+            v.y = (r < D && 4 * jj4 + 1 <= r) ? Ar[4 * jj4 + 1] : 0.0f;
+            v.z = (r < D && 4 * jj4 + 2 <= r) ? Ar[4 * jj4 + 2] : 0.0f;
+            v.w = (r < D && 4 * jj4 + 3 <= r) ? Ar[4 * jj4 + 3] : 0.0f;
+            Ash4[GEO::off4(m) + g] = v;
+        }
+    }
     const int wave = threadIdx.x >> 6;
-    float* ysh = ysh_all + wave * (CPW * DP);
+    float* ysh = ysh_all + wave * (CPW * DP4);
     const int W = a.nwalkers;
     const int halfW = W / 2;
     const int lo = a.half ? halfW : 0;
@@ -174,7 +205,7 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const float* __restric
     const float alphamult = (float)(D - 1) * mhx_log(z);                 // :82
 
     float xs[NK], ysl[NK];
-    float* yrow = ysh + cw * DP;
+    float* yrow = ysh + cw * DP4;
 #pragma unroll
     for (int m = 0; m < NK; ++m) {
         const int k = l + L * m;
@@ -187,22 +218,25 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const float* __restric
         } else {
             xs[m] = 0.0f;
             ysl[m] = 0.0f;
+            if (k < DP4) yrow[k] = 0.0f;                                 // the pad multiplies zeros of the factor
         }
     }
+    if (NK * L < DP4) { for (int k = NK * L + l; k < DP4; k += L) yrow[k] = 0.0f; }
     __syncthreads();
+    const mhx_e4* yrow4 = (const mhx_e4*)yrow;
     float q = 0.0f;
 #pragma unroll
     for (int m = 0; m < NK; ++m) {
         const int r = l + L * m;                                         // this lane's row of A y
-        const int rmax = (L * m + L - 1) < (D - 1) ? (L * m + L - 1) : (D - 1);   // wave-uniform trip count
-        const int rc = r < D ? r : 0;                                    // rows past the end shadow row 0 (masked below)
-        const float* Ar = Ash + rc * (rc + 1) / 2;
         float w = 0.0f;
 #pragma unroll
-        for (int jj = 0; jj <= rmax; ++jj) {
-            const float av = Ar[jj <= rc ? jj : rc];                     // index-clamped: no divergent reads
-            const float yv = yrow[jj];
-            w = (r < D && jj <= r) ? mhx_fma(av, yv, w) : w;
+        for (int jj4 = 0; jj4 < GEO::len4(m); ++jj4) {
+            const mhx_e4 av = Ash4[GEO::off4(m) + jj4 * L + l];
+            const mhx_e4 yv = yrow4[jj4];
+            w = mhx_fma(av.x, yv.x, w);
+            w = mhx_fma(av.y, yv.y, w);
+            w = mhx_fma(av.z, yv.z, w);
+            w = mhx_fma(av.w, yv.w, w);
         }
         q = r < D ? mhx_fma(w, w, q) : q;
     }
@@ -243,9 +277,9 @@ extern "C" __global__ void __launch_bounds__(64)
 mhx_jit_emcee_half(const mhx_emcee_args a, const float* __restrict__ tparams)
 {
 #if MHX_JIT_L > 1
-    __shared__ float ysh[MHX_EMCEE_COOP_WAVES * (64 / MHX_JIT_L) * (MHX_JIT_DIM | 1)];
-    __shared__ float Ash[MHX_JIT_DIM * (MHX_JIT_DIM + 1) / 2];
-    mhx_emcee_coop_body<MHX_JIT_DIM, MHX_JIT_L>(a, tparams, ysh, Ash);
+    __shared__ mhx_e4 ysh4[MHX_EMCEE_COOP_WAVES * (64 / MHX_JIT_L) * mhx_emcee_geom<MHX_JIT_DIM, MHX_JIT_L>::DP4 / 4];
+    __shared__ mhx_e4 Ash4[mhx_emcee_geom<MHX_JIT_DIM, MHX_JIT_L>::TOTAL4];
+    mhx_emcee_coop_body<MHX_JIT_DIM, MHX_JIT_L>(a, tparams, (float*)ysh4, Ash4);
 #else
     mhx_emcee_half_body<MHX_JIT_DIM, MHX_JIT_TK>(a, tparams);
 #endif
