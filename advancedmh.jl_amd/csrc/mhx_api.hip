@@ -430,6 +430,7 @@ struct mhx_run {
     // emcee
     float stretch = 2.0f;
     float* d_pmean = nullptr;            // drifting walk: mu[dim] then 2 L^-1 mu [dim]
+    float* d_qx = nullptr;               // static proposal: logpdf of the proposal at each chain's state (up to its constant)
     // mala
     float mala_sigma = 1.0f;
     float *d_gx = nullptr, *d_gy = nullptr, *d_z = nullptr;
@@ -470,7 +471,7 @@ struct mhx_run {
     ~mhx_run()
     {
         void* ptrs[] = {d_pvec, d_S, d_Ssel, d_status, d_dmin, d_dmax, d_eta, d_x, d_lp, d_ybuf,
-                        d_acc, d_last, d_acc_total, d_samples, d_accepted, d_mom_mean, d_mom_m2, d_gx, d_gy, d_z, d_pmean};
+                        d_acc, d_last, d_acc_total, d_samples, d_accepted, d_mom_mean, d_mom_m2, d_gx, d_gy, d_z, d_pmean, d_qx};
         for (void* p : ptrs) if (p) (void)hipFree(p);
     }
 };
@@ -503,7 +504,24 @@ static mhx_rwmh_args rwmh_args(const mhx_run* r)
     a.reduce_lanes = r->coop_L;
     if (r->moments_mode) { a.mom_mean = r->d_mom_mean; a.mom_m2 = r->d_mom_m2; a.mom_n0 = (mhx_u32)r->mom_n; }
     a.pmean = r->d_pmean;
+    a.qx = r->d_qx;
     return a;
+}
+
+__global__ void __launch_bounds__(256)
+k_rwmh_whiten(const mhx_rwmh_args a, const float* __restrict__ pvec)
+{
+    mhx_rwmh_whiten_body(a, pvec);
+}
+// logpdf of a static proposal at the current states (after init / set_state)
+static int rwmh_whiten(mhx_run* r)
+{
+    if (!r->d_qx) return MHX_OK;
+    mhx_rwmh_args a = rwmh_args(r);
+    hipLaunchKernelGGL(k_rwmh_whiten, dim3((unsigned)((r->n + 255) / 256)), dim3(256), 0, r->ctx->stream, a, r->d_pvec);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(r->ctx->stream));
+    return MHX_OK;
 }
 
 #define MHX_REG_MAX_DIM 160
@@ -560,6 +578,12 @@ extern "C" int mhx_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh
         HIP_TRY(hipMalloc(&r->d_pmean, pm.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(r->d_pmean, pm.data(), pm.size() * sizeof(float), hipMemcpyHostToDevice));
         if (cfg->reduce_lanes > 1) return fail(MHX_EINVAL, "a drifting random walk runs on the generic kernel: reduce_lanes must be 0 or 1");
+        r->flags |= MHX_FLAG_GENERIC;
+    }
+    // static (independence) proposal, src/proposal.jl:9-11,66-83: generic kernel, one more float of state per chain
+    if (cfg->flags & MHX_FLAG_STATIC_PROPOSAL) {
+        if (cfg->reduce_lanes > 1) return fail(MHX_EINVAL, "a static proposal runs on the generic kernel: reduce_lanes must be 0 or 1");
+        HIP_TRY(hipMalloc(&r->d_qx, (size_t)r->n * sizeof(float)));
         r->flags |= MHX_FLAG_GENERIC;
     }
 
@@ -666,7 +690,7 @@ static int rwmh_init(mhx_run* r, const float* init)
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return MHX_OK;
+    return rwmh_whiten(r);
 }
 
 #define MHX_MAX_STEPS_PER_LAUNCH 65536ull
@@ -943,7 +967,7 @@ extern "C" int mhx_run_set_state(mhx_run* r, const float* x)
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return MHX_OK;
+    return r->kind == RUN_RWMH ? rwmh_whiten(r) : MHX_OK;
 }
 
 extern "C" int mhx_run_stats(mhx_run* r, mhx_stats* out)

@@ -56,6 +56,8 @@ struct mhx_rwmh_args {
     mhx_u32 mom_n0;           // states already folded in before this launch
     // drifting random walk (non-zero proposal mean; generic kernel only): mu[dim] followed by 2 L^-1 mu [dim]
     const float* pmean;       // null = zero mean (the Hastings ratio is then exactly 0 and is not computed)
+    // static (independence) proposal, generic kernel only: q(x) = -1/2 |L^-1 (x - mu)|^2 of each chain's state
+    float* qx;                // [ld] or null = random walk
 };
 
 // one Welford step with the wave-uniform 1/n
@@ -183,11 +185,13 @@ MHX_DEV void mhx_rwmh_generic_body(const mhx_rwmh_args& a, const float* __restri
     long slot = a.save_slot;
     mhx_u32 mom_n = a.mom_n0;
     const int nblk = (d + 3) >> 2;
+    float qxc = a.qx ? a.qx[c] : 0.0f;
 
     for (int i = 0; i < a.nsteps; ++i) {
         const mhx_u32 step = a.step0 + (mhx_u32)i;
         // a drifting walk (proposal mean mu != 0) keeps |z|^2 and |z + 2 L^-1 mu|^2 for its Hastings ratio
         const float* mu = a.pmean;
+        const bool stat = a.qx != nullptr;             // StaticProposal: the candidate ignores x (src/proposal.jl:66-72)
         float fwd = 0.0f, bwd = 0.0f;
         if (a.prop_kind == MHX_PROP_DENSE) {
             for (int b = 0; b < nblk; ++b) {
@@ -197,7 +201,8 @@ MHX_DEV void mhx_rwmh_generic_body(const mhx_rwmh_args& a, const float* __restri
                     const int k = 4 * b + j;
                     if (k < d) {
                         ys[(long)k * ld] = n[j];
-                        if (mu) { fwd = mhx_fma(n[j], n[j], fwd); const float tk = n[j] + mu[d + k]; bwd = mhx_fma(tk, tk, bwd); }
+                        if (mu || stat) fwd = mhx_fma(n[j], n[j], fwd);
+                        if (mu && !stat) { const float tk = n[j] + mu[d + k]; bwd = mhx_fma(tk, tk, bwd); }
                     }
                 }
             }
@@ -206,7 +211,8 @@ MHX_DEV void mhx_rwmh_generic_body(const mhx_rwmh_args& a, const float* __restri
                 const float* Lr = pvec + (long)r * (r + 1) / 2;
                 float w = 0.0f;
                 for (int j = 0; j <= r; ++j) w = mhx_fma(Lr[j], ys[(long)j * ld], w);
-                ys[(long)r * ld] = mu ? xs[(long)r * ld] + (mu[r] + w) : xs[(long)r * ld] + w;
+                const float xr = stat ? 0.0f : xs[(long)r * ld];
+                ys[(long)r * ld] = mu ? xr + (mu[r] + w) : xr + w;
             }
         } else {
             for (int b = 0; b < nblk; ++b) {
@@ -216,13 +222,15 @@ MHX_DEV void mhx_rwmh_generic_body(const mhx_rwmh_args& a, const float* __restri
                     const int k = 4 * b + j;
                     if (k < d) {
                         const float s = a.prop_kind == MHX_PROP_ISO ? a.pscale : pvec[k];
+                        const float xk = stat ? 0.0f : xs[(long)k * ld];
                         if (mu) {
-                            ys[(long)k * ld] = xs[(long)k * ld] + mhx_fma(s, n[j], mu[k]);
+                            ys[(long)k * ld] = xk + mhx_fma(s, n[j], mu[k]);
                             fwd = mhx_fma(n[j], n[j], fwd);
                             const float tk = n[j] + mu[d + k];
                             bwd = mhx_fma(tk, tk, bwd);
                         } else {
-                            ys[(long)k * ld] = mhx_fma(s, n[j], xs[(long)k * ld]);
+                            ys[(long)k * ld] = mhx_fma(s, n[j], xk);
+                            if (stat) fwd = mhx_fma(n[j], n[j], fwd);
                         }
                     }
                 }
@@ -234,9 +242,12 @@ MHX_DEV void mhx_rwmh_generic_body(const mhx_rwmh_args& a, const float* __restri
         const float lpy = mhx_target_eval<TK>(a.target_kind, yv, d, tparams, a.ntparams, a.tconst);
         const float logu = mhx_accept_logu(ks, id_lo, id_hi, step, ac);
         // src/mh-core.jl:104-105 with logratio_proposal_density (src/proposal.jl:190-192) when the walk drifts
-        const float loga = mu ? (lpy - lp) + 0.5f * (fwd - bwd) : (lpy - lp);
+        // static proposal: logpdf(p, x) - logpdf(p, y) (src/proposal.jl:74-83), q(y) = -1/2 |z|^2
+        const float qy = -0.5f * fwd;
+        const float loga = stat ? (lpy - lp) + (qxc - qy) : (mu ? (lpy - lp) + 0.5f * (fwd - bwd) : (lpy - lp));
         const bool acc = logu < loga;
         lp = acc ? lpy : lp;
+        qxc = (stat && acc) ? qy : qxc;
         nacc += acc ? 1u : 0u;
         last = acc;
         wave_acc += (mhx_u32)__popcll(__ballot(acc));
@@ -276,10 +287,40 @@ MHX_DEV void mhx_rwmh_generic_body(const mhx_rwmh_args& a, const float* __restri
         }
     }
     a.lp[c] = lp;
+    if (a.qx) a.qx[c] = qxc;
     a.acc_count[c] = nacc;
     a.last_acc[c] = last ? 1 : 0;
     if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u)
         atomicAdd(a.acc_total, (mhx_u64)wave_acc);
+}
+
+// q(x) = -1/2 |L^-1 (x - mu)|^2 of every chain's current state: the static proposal's logpdf up to its
+// constant (src/proposal.jl:31-35); forward substitution with the whitened vector in the scratch slab
+MHX_DEV void mhx_rwmh_whiten_body(const mhx_rwmh_args& a, const float* __restrict__ pvec)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.nchains) return;
+    const long ld = a.ld;
+    const int d = a.dim;
+    const float* xs = a.x + c;
+    float* ts = a.ybuf + c;
+    const float* mu = a.pmean;
+    float q = 0.0f;
+    for (int i = 0; i < d; ++i) {
+        const float r = mu ? xs[(long)i * ld] - mu[i] : xs[(long)i * ld];
+        float t;
+        if (a.prop_kind == MHX_PROP_ISO) t = r / a.pscale;
+        else if (a.prop_kind == MHX_PROP_DIAG) t = r / pvec[i];
+        else {
+            const float* Li = pvec + (long)i * (i + 1) / 2;
+            float acc = 0.0f;
+            for (int j = 0; j < i; ++j) acc = mhx_fma(Li[j], ts[(long)j * ld], acc);
+            t = (r - acc) / Li[i];
+        }
+        ts[(long)i * ld] = t;
+        q = mhx_fma(t, t, q);
+    }
+    a.qx[c] = -0.5f * q;
 }
 
 // ---------------------------------------------------------------------------------------------

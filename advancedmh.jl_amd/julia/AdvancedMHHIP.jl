@@ -124,11 +124,13 @@ function AbstractMCMC.sample(
     n = nchains
     if sampler isa AdvancedMH.MetropolisHastings
         prop = sampler.proposal
-        prop isa AdvancedMH.RandomWalkProposal || throw(ArgumentError("the GPU path implements RandomWalkProposal only"))
+        prop isa Union{AdvancedMH.RandomWalkProposal, AdvancedMH.StaticProposal} ||
+            throw(ArgumentError("the GPU path implements RandomWalkProposal and StaticProposal over (Mv)Normal only"))
         kind, scale, vec = proposal_spec(prop.proposal)
         μ = Float32.(mean(prop.proposal))
+        flags = prop isa AdvancedMH.StaticProposal ? Int32(4) : Int32(0)    # MHX_FLAG_STATIC_PROPOSAL
         GC.@preserve vec μ begin
-            cfg = RwmhCfg(d, n, seed, ens.first_chain, kind, scale, pointer(vec), 0,
+            cfg = RwmhCfg(d, n, seed, ens.first_chain, kind, scale, pointer(vec), flags,
                           all(iszero, μ) ? Ptr{Cfloat}(C_NULL) : pointer(μ), 0)
             check(ccall((:mhx_rwmh_create, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{RwmhCfg}, Ref{Ptr{Cvoid}}),
                         ctx[], tgt, cfg, run))

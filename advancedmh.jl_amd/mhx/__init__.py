@@ -3,7 +3,8 @@ from ._lib import (ArgumentError, Context, MhxError, PosDefException, FLAG_GENER
                    EXPORTS, lib)
 from .api import (I, Banana, Chains, CorrGaussian, DensityModel, Ensemble, Funnel, HipLogDensity, IIDNormal,
                   InverseGamma, IsoGaussian, MALA, MCMCDistributed, MCMCHIP, MCMCSerial, MCMCThreads, MetropolisHastings, MvNormal, Normal, RandomWalkProposal,
-                  RobustAdaptiveMetropolis, Run, RWMH, combine_diagnostics, StretchProposal, SymmetricRandomWalkProposal, Transition,
+                  RobustAdaptiveMetropolis, Run, RWMH, StaticMH, StaticProposal, combine_diagnostics, StretchProposal,
+                  SymmetricRandomWalkProposal, Transition,
                   logdensity, pack_lower, sample, unpack_lower, zeros)
 
 __all__ = [n for n in dir() if not n.startswith("_")]

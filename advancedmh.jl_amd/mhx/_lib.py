@@ -14,6 +14,7 @@ TARGET_ISO_GAUSS, TARGET_CORR_GAUSS, TARGET_IID_NORMAL, TARGET_BANANA, TARGET_FU
 TARGET_USER = 100
 PROP_ISO, PROP_DIAG, PROP_DENSE = 0, 1, 2
 FLAG_NO_JIT, FLAG_GENERIC = 1, 2
+MHX_FLAG_STATIC_PROPOSAL = 4
 
 
 class MhxError(RuntimeError):

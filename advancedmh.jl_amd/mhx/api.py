@@ -261,13 +261,30 @@ def SymmetricRandomWalkProposal(proposal):
     return RandomWalkProposal(proposal, True)
 
 
+class StaticProposal:
+    """StaticProposal(dist) -- src/proposal.jl:9-11: every candidate is a fresh draw from `dist`, whatever the
+    current state (independence sampler); the acceptance ratio carries logpdf(dist, x) - logpdf(dist, y)
+    (src/proposal.jl:66-83).  `dist`: Normal / list of Normals / MvNormal."""
+
+    issymmetric = False
+
+    def __init__(self, proposal):
+        self.proposal = _as_mvnormal(proposal)
+
+
 class MetropolisHastings:
     """MetropolisHastings(proposal) -- src/mh-core.jl:44-46."""
 
     def __init__(self, proposal):
-        if not isinstance(proposal, RandomWalkProposal):
-            raise L.ArgumentError(L.MHX_EINVAL, "the GPU path implements RandomWalkProposal only")
+        if not isinstance(proposal, (RandomWalkProposal, StaticProposal)):
+            raise L.ArgumentError(L.MHX_EINVAL, "the GPU path implements RandomWalkProposal and StaticProposal "
+                                  "over (Mv)Normal distributions only")
         self.proposal = proposal
+
+
+def StaticMH(d):
+    """StaticMH(d) -- src/mh-core.jl:48."""
+    return MetropolisHastings(StaticProposal(d))
 
 
 def RWMH(d):
@@ -381,6 +398,8 @@ class Run:
             vec = None if mv.vec is None else L.f32(mv.vec)
             mean = L.f32(mv.mean) if np.any(mv.mean != 0) else None
             self._keep += [vec, mean]
+            if isinstance(sampler.proposal, StaticProposal):
+                flags |= L.MHX_FLAG_STATIC_PROPOSAL
             cfg = L.RwmhCfg(d, nchains, seed, first_chain, mv.kind, mv.scale, L.fptr(vec), flags, L.fptr(mean), reduce_lanes)
             L.check(lib.mhx_rwmh_create(self.ctx.h, model.handle(self.ctx), C.byref(cfg), C.byref(self.h)))
             self.n = nchains

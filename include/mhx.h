@@ -111,6 +111,9 @@ typedef struct {
 
 #define MHX_FLAG_NO_JIT 1 /* never specialise with hiprtc; use the pre-built kernels only */
 #define MHX_FLAG_GENERIC 2 /* force the generic (state-in-HBM) kernel even when a register kernel exists */
+#define MHX_FLAG_STATIC_PROPOSAL 4 /* RWMH runs only: the proposal is a StaticProposal (src/proposal.jl:9-11,66-83) --
+                                      the candidate is a draw mean + L z that ignores the current state (independence
+                                      sampler) and the ratio is logpdf(p, x) - logpdf(p, y) */
 
 int mhx_rwmh_create(mhx_ctx *ctx, const mhx_target *t, const mhx_rwmh_cfg *cfg, mhx_run **out);
 

@@ -334,6 +334,28 @@ static void propose_from(const orc_proposal *p, int d, const float *z, const flo
     }
 }
 
+/* q(x) = -1/2 |L^-1 (x - mu)|^2: logpdf of the proposal at x up to its constant (src/proposal.jl:31-35);
+ * forward substitution, every sum in ascending order */
+static float static_logq(const orc_proposal *p, int d, const float *x, float *t)
+{
+    const float *mu = p->mean;
+    size_t off = 0;
+    float q = 0.0f;
+    for (int i = 0; i < d; ++i) {
+        const float r = mu ? x[i] - mu[i] : x[i];
+        if (p->kind == ORC_PROP_ISO) t[i] = r / p->scale;
+        else if (p->kind == ORC_PROP_DIAG) t[i] = r / p->vec[i];
+        else {
+            float acc = 0.0f;
+            for (int j = 0; j < i; ++j) acc = fmaf(p->vec[off + j], t[j], acc);
+            t[i] = (r - acc) / p->vec[off + i];
+            off += (size_t)i + 1;
+        }
+        q = fmaf(t[i], t[i], q);
+    }
+    return -0.5f * q;
+}
+
 /* twice the whitened mean 2 L^-1 mu (host arithmetic in double, rounded once): with it the Hastings ratio of a
  * drifting random walk is  logq(x|y) - logq(y|x) = 1/2 |z|^2 - 1/2 |z + 2 L^-1 mu|^2   (src/proposal.jl:58-64,190-192) */
 static void whitened_mean2(const orc_proposal *p, int d, float *tm)
@@ -398,9 +420,10 @@ int orc_rwmh(const orc_target *t, const orc_proposal *p, const orc_schedule *s,
     const int d = t->dim, C = nchains;
     int64_t nT, nA;
     orc_schedule_counts(s, &nT, &nA);
-    float *x = malloc(sizeof(float) * (size_t)d * 4);
-    float *y = x + d, *z = y + d, *tm = z + d;
-    if (p->mean) whitened_mean2(p, d, tm);
+    float *x = malloc(sizeof(float) * (size_t)d * 5);
+    float *y = x + d, *z = y + d, *tm = z + d, *zero = tm + d;
+    if (p->mean && !p->is_static) whitened_mean2(p, d, tm);
+    for (int k = 0; k < d; ++k) zero[k] = 0.0f;
     for (int c = 0; c < C; ++c) {
         const uint64_t id = first_chain + (uint64_t)c;
         /* mh-core.jl:83  params = initial_params === nothing ? propose(rng, sampler, model) : initial_params
@@ -413,16 +436,23 @@ int orc_rwmh(const orc_target *t, const orc_proposal *p, const orc_schedule *s,
             propose_from(p, d, z, y, x);
         }
         float lp = orc_target_eval(t, x);               /* mh-core.jl:84 transition(..., false) */
+        float qx = p->is_static ? static_logq(p, d, x, y) : 0.0f;
         uint32_t nacc = 0;
         int64_t slot = save_slot(s, 0);
         if (slot >= 0) record(samples, accepted, slot, d, C, c, x, lp, 0);
         for (int64_t tau = 1; tau <= nT; ++tau) {
             const uint32_t step = (uint32_t)tau;
             orc_normals(seed, id, step, ORC_STREAM_PROPOSAL, d, z);
-            propose_from(p, d, z, x, y);                /* mh-core.jl:100 */
+            propose_from(p, d, z, p->is_static ? zero : x, y);   /* mh-core.jl:100; static: proposal.jl:66-72 */
             float lpy = orc_target_eval(t, y);          /* :103 */
             float loga = lpy - lp;                      /* :104-105, Hastings ratio of a zero-mean RW == 0 */
-            if (p->mean) {                              /* :105,119-123 -> proposal.jl:190-192 */
+            float qy = 0.0f;
+            if (p->is_static) {                         /* proposal.jl:74-83: q = logpdf(proposal, t) */
+                float fwd = 0.0f;
+                for (int k = 0; k < d; ++k) fwd = fmaf(z[k], z[k], fwd);
+                qy = -0.5f * fwd;
+                loga = (lpy - lp) + (qx - qy);
+            } else if (p->mean) {                       /* :105,119-123 -> proposal.jl:190-192 */
                 float fwd = 0.0f, bwd = 0.0f;
                 for (int k = 0; k < d; ++k) {
                     fwd = fmaf(z[k], z[k], fwd);
@@ -433,7 +463,7 @@ int orc_rwmh(const orc_target *t, const orc_proposal *p, const orc_schedule *s,
             }
             float logu = orc_accept_logu(seed, id, step);
             int acc = logu < loga;                      /* :108  -randexp(rng) < loga (strict; NaN -> reject) */
-            if (acc) { memcpy(x, y, sizeof(float) * (size_t)d); lp = lpy; ++nacc; }
+            if (acc) { memcpy(x, y, sizeof(float) * (size_t)d); lp = lpy; qx = qy; ++nacc; }
             slot = save_slot(s, tau);
             if (slot >= 0) record(samples, accepted, slot, d, C, c, x, lp, acc);
         }

@@ -80,6 +80,8 @@ typedef struct {
     const float *vec;     /* DIAG: sigma_k[d]; DENSE: packed lower L     */
     const float *mean;    /* NULL = zero mean; else mu[d]: the random walk drifts and the Hastings ratio
                              q(x | y) - q(y | x) of src/proposal.jl:58-64,190-192 is no longer zero */
+    int is_static;        /* StaticProposal (src/proposal.jl:9-11,66-83): the candidate is a draw mu + L z that
+                             ignores the current state; ratio = logpdf(p, x) - logpdf(p, y)            */
 } orc_proposal;
 
 /* ---- schedule [upstream AbstractMCMC.mcmcsample, restated] ---- */

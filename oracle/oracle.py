@@ -25,7 +25,8 @@ class _Target(C.Structure):
 
 
 class _Proposal(C.Structure):
-    _fields_ = [("kind", C.c_int), ("scale", C.c_float), ("vec", C.POINTER(C.c_float)), ("mean", C.POINTER(C.c_float))]
+    _fields_ = [("kind", C.c_int), ("scale", C.c_float), ("vec", C.POINTER(C.c_float)), ("mean", C.POINTER(C.c_float)),
+                ("is_static", C.c_int)]
 
 
 class _Schedule(C.Structure):
@@ -182,10 +183,10 @@ def unpack_lower(p, d):
 
 
 class Proposal:
-    def __init__(self, kind, scale=1.0, vec=None, mean=None):
+    def __init__(self, kind, scale=1.0, vec=None, mean=None, static=False):
         self.vec = None if vec is None else np.ascontiguousarray(vec, dtype=np.float32)
         self.mean = None if mean is None else np.ascontiguousarray(mean, dtype=np.float32)
-        self.c = _Proposal(kind, float(scale), _fp(self.vec), _fp(self.mean))
+        self.c = _Proposal(kind, float(scale), _fp(self.vec), _fp(self.mean), 1 if static else 0)
 
 
 def schedule(n_samples, discard_initial=0, thinning=1, num_warmup=0):

@@ -286,3 +286,63 @@ def test_drifting_random_walk_hastings_ratio(mhx, oracle, kind):
     long = mhx.sample(model, spl, 4000, 256, seed=6, discard_initial=500)
     v = long.value[:, :d, :].astype(np.float64)
     assert np.abs(v.mean(axis=(0, 2))).max() < 0.05 and np.abs(v.var(axis=(0, 2)) - 1).max() < 0.05
+
+
+# ---- StaticProposal / StaticMH: the independence sampler of src/proposal.jl:9-11,66-83 --------------------
+@pytest.mark.parametrize("kind", ["iso", "diag", "dense", "dense_mean", "iso_mean"])
+def test_static_proposal_bit_exact(mhx, oracle, kind):
+    d, C, N = 5, 7, 40
+    rng = np.random.default_rng(11)
+    mean = None
+    if kind.startswith("iso"):
+        prop, op = mhx.MvNormal(mhx.zeros(d), 1.3 ** 2 * mhx.I), dict(kind=oracle.PROP_ISO, scale=float(np.float32(1.3)))
+        if kind == "iso_mean":
+            mean = rng.normal(size=d) * 0.3
+            prop = mhx.MvNormal(mean, 1.3 ** 2 * mhx.I)
+    elif kind == "diag":
+        s = 0.5 + rng.random(d)
+        prop, op = [mhx.Normal(0.0, float(v)) for v in s], dict(kind=oracle.PROP_DIAG, vec=s.astype(np.float32))
+    else:
+        A = rng.normal(size=(d, d)) * 0.3
+        Sig = A @ A.T + np.eye(d)
+        if kind == "dense_mean":
+            mean = rng.normal(size=d) * 0.3
+        prop = mhx.MvNormal(mhx.zeros(d) if mean is None else mean, Sig)
+        op = dict(kind=oracle.PROP_DENSE, vec=oracle.pack_lower(np.linalg.cholesky(Sig)))
+    Sig_t = cases.sigma_ar1(d, 0.5)
+    model = mhx.DensityModel(mhx.CorrGaussian(Sig_t))
+    spl = mhx.StaticMH(prop)
+    for init in (None, (rng.normal(size=(d, C)) * 0.5).astype(np.float32)):
+        chain = mhx.sample(model, spl, N, C, seed=5, first_chain=3, initial_params=init, discard_initial=2, thinning=3)
+        ref = oracle.rwmh(oracle.corr_gauss_from_cov(Sig_t), oracle.Proposal(mean=mean, static=True, **op),
+                          oracle.schedule(N, 2, 3), 5, 3, C, init=init)
+        assert np.array_equal(chain.value.view(np.uint32), ref["samples"].view(np.uint32))
+        assert np.array_equal(chain.accepted, ref["accepted"])
+        assert 0.02 < chain.accepted[1:].mean() < 0.98
+
+
+def test_static_mh_posterior_of_the_readme_model(mhx):
+    """test/runtests.jl:56-74 (StaticMH testset): the Normal(mu, sigma) model of the README under static proposals
+    [Normal(0,1), Normal(0,1)] and MvNormal(zeros(2), I); posterior mean of mu ~ mean(data), sigma ~ std(data)."""
+    data = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c1_normal_data.npy"))
+    model = mhx.DensityModel(mhx.IIDNormal(data))
+    for prop in ([mhx.Normal(0.0, 1.0), mhx.Normal(0.0, 1.0)], mhx.MvNormal(mhx.zeros(2), mhx.I)):
+        chain = mhx.sample(model, mhx.StaticMH(prop), 400, 2048, seed=9, discard_initial=200)
+        mu, sig = chain.value[:, 0, :].mean(), chain.value[:, 1, :].mean()
+        assert abs(mu - data.mean()) < 0.1 and abs(sig - data.std()) < 0.1, (mu, sig)
+
+
+def test_static_proposal_survives_setparams(mhx, oracle):
+    """setparams!! replaces the state: the proposal's logpdf at the new state is recomputed with it."""
+    d, C = 3, 4
+    model = mhx.DensityModel(mhx.IsoGaussian(d))
+    spl = mhx.StaticMH(mhx.MvNormal(mhx.zeros(d), 4.0 * mhx.I))
+    run = mhx.Run(model, spl, nchains=C, seed=2)
+    x0 = np.full((d, C), 0.25, dtype=np.float32)
+    run.init(np.zeros((d, C), dtype=np.float32))
+    run.set_params(x0)
+    run.sample(6, 0, 1, 0, save=True)
+    got = run.samples()[0]
+    ref = oracle.rwmh(oracle.iso_gauss(d), oracle.Proposal(oracle.PROP_ISO, 2.0, static=True), oracle.schedule(6), 2, 0, C, init=x0)
+    assert np.array_equal(got.view(np.uint32), ref["samples"].view(np.uint32))
+    run.close()
