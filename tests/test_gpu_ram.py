@@ -168,3 +168,22 @@ def test_ram_chains_of_one_wave_fail_independently(mhx, oracle):
     _same(chain.value, ref["samples"], "samples")
     _same(lo, ref["diag_min"], "diag min")
     assert st[2] == 2 and (st[[0, 1, 3, 4, 5, 6]] & 1).all()
+
+
+@pytest.mark.parametrize("d", [3, 40, 100])
+def test_ram_user_log_density(mhx, oracle, d):
+    """A user log-density given as HIP source (hiprtc) under RAM, in 16- and 32-lane groups: independent Gaussians
+    with per-dimension mean / std passed as data; the oracle evaluates the same source compiled for the host."""
+    import user_targets
+    C, N, warm = 6, 10, 8
+    rng = np.random.default_rng(d)
+    data = np.concatenate([rng.normal(size=d), 0.5 + rng.random(d)]).astype(np.float32)
+    model = mhx.DensityModel(mhx.HipLogDensity(user_targets.SHIFTED_GAUSS, d, data=data))
+    ut = user_targets.host_target(oracle, user_targets.SHIFTED_GAUSS, d, data=data)
+    init = np.zeros((d, C), dtype=np.float32)
+    chain, S, st, lo, hi, x, lp, cnt = _run(mhx, model, mhx.RobustAdaptiveMetropolis(), N, C, 17, 0, init,
+                                            num_warmup=warm, discard_initial=0)
+    ref = oracle.ram(ut, oracle.schedule(N, 0, 1, warm), 17, 0, C, init=init)
+    _same(chain.value, ref["samples"], "samples")
+    _same(S, ref["S"], "S")
+    _same(cnt, ref["accept_counts"], "accept counts")
