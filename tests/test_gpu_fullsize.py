@@ -83,6 +83,25 @@ def test_c4_full_size_ram(mhx, oracle):
     run.close()
 
 
+def test_c4_full_size_is_deterministic_under_load(mhx):
+    """The sweep stores whole row slots and relies on a wave's stores to one address landing in program order
+    (DESIGN.md 6.3); the spot-checked chains above could miss a rare reordering under full load, so the whole
+    2.6 GB of factors of two identical runs must agree bit for bit, and every factor must be finite."""
+    d, C = 200, 32768
+    model = mhx.DensityModel(mhx.CorrGaussian(cases.sigma_ar1(d, 0.9)))
+    out = []
+    for rep in range(2):
+        run = mhx.Run(model, mhx.RobustAdaptiveMetropolis(), nchains=C, seed=8)
+        run.init(np.zeros((d, C), dtype=np.float32))
+        run.sample(1, 12, 1, 12, save=False)
+        S, st = run.factor()
+        out.append((S.copy(), st.copy()))
+        run.close()
+    assert np.isfinite(out[0][0]).all()
+    assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
+    assert np.array_equal(out[0][1], out[1][1])
+
+
 def test_c5_shard_size_rwmh(mhx, oracle):
     """configs[4], one GPU's shard: 1000-dim funnel, 32 768 chains with global ids of shard 5 of 8."""
     d, C, N = 1000, 32768, 5
