@@ -195,7 +195,14 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(d, inner, 0xC0FFEE)
-        print(json.dumps(out))
+        # RCCL writes its version banner to the C stdout buffer: push it out first so the JSON line is the last one
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
