@@ -76,8 +76,9 @@ def cpu_baseline(d, inner, seed, target_seconds=10.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=30,
+                    help="untimed launches; the first ~20 run below the steady clock (8.0e9 vs 9.2e9 steps/s)")
     ap.add_argument("--inner", type=int, default=250, help="MH transitions per chain per step (launch)")
     ap.add_argument("--chains", type=int, default=CHAINS, help="chains per GPU")
     ap.add_argument("--dim", type=int, default=D)
