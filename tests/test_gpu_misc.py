@@ -346,3 +346,33 @@ def test_static_proposal_survives_setparams(mhx, oracle):
     ref = oracle.rwmh(oracle.iso_gauss(d), oracle.Proposal(oracle.PROP_ISO, 2.0, static=True), oracle.schedule(6), 2, 0, C, init=x0)
     assert np.array_equal(got.view(np.uint32), ref["samples"].view(np.uint32))
     run.close()
+
+
+def test_runs_release_their_device_memory(mhx):
+    """create / init / sample / diagnostics / destroy cycles over every sampler leave the free-memory count unchanged."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        f, t = C.c_size_t(), C.c_size_t()
+        assert hip.hipMemGetInfo(C.byref(f), C.byref(t)) == 0
+        return f.value
+
+    d = 20
+    ctx = mhx.Context(0)
+    models = [mhx.DensityModel(mhx.IsoGaussian(d)), mhx.DensityModel(mhx.CorrGaussian(cases.sigma_ar1(d, 0.5)))]
+
+    def cycle():
+        for m in models:
+            for spl in (mhx.RWMH(mhx.MvNormal(mhx.zeros(d), 0.3 * mhx.I)), mhx.RobustAdaptiveMetropolis(), mhx.MALA(0.1),
+                        mhx.StaticMH(mhx.MvNormal(mhx.zeros(d), 2.0 * mhx.I)),
+                        mhx.Ensemble(64, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I)))):
+                ch = mhx.sample(m, spl, 20, 512, seed=1, ctx=ctx, initial_params=np.zeros(d), num_warmup=5)
+                ch.state.diagnostics(max_lag=5)
+                ch.state.close()
+
+    cycle()                                              # JIT modules and the context's caches are allocated once
+    before = free_bytes()
+    for _ in range(5):
+        cycle()
+    assert before - free_bytes() < (1 << 20), "device memory leaked: %d bytes" % (before - free_bytes())
