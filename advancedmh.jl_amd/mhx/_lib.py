@@ -66,7 +66,7 @@ class Stats(C.Structure):
 
 
 class DiagCfg(C.Structure):
-    _fields_ = [("max_lag", C.c_int32), ("ess_chains", C.c_int32)]
+    _fields_ = [("max_lag", C.c_int32), ("ess_chains", C.c_int32), ("split", C.c_int32)]
 
 
 EXPORTS = [

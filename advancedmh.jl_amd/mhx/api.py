@@ -503,23 +503,25 @@ class Run:
         return dict(transitions=st.transitions, accepted=st.accepted, kernel_ms=st.kernel_ms, wall_ms=st.wall_ms,
                     kernel_variant=st.kernel_variant, launches=st.launches, reduce_lanes=st.reduce_lanes)
 
-    def diagnostics(self, max_lag=0, ess_chains=256):
-        """Sums for R-hat / between-chain ESS (all chains) and, if max_lag > 0, the Geyer ESS from
-        chain-averaged autocovariances.  See include/mhx.h (mhx_run_diagnostics)."""
+    def diagnostics(self, max_lag=0, ess_chains=256, split=False):
+        """Sums for R-hat / between-chain ESS (all chains) and, if max_lag > 0, the Geyer ESS from the multi-chain
+        autocorrelations.  split=True: every chain counts as two half-chains (split R-hat).  See include/mhx.h
+        (mhx_run_diagnostics)."""
         d1 = self.dim + 1
         arrs = [np.zeros(d1, dtype=np.float64) for _ in range(4)]
-        cfg = L.DiagCfg(max_lag, ess_chains)
+        cfg = L.DiagCfg(max_lag, ess_chains, 1 if split else 0)
         ptrs = [a.ctypes.data_as(C.POINTER(C.c_double)) for a in arrs]
         if max_lag <= 0:
             ptrs[3] = None
         L.check(L.lib().mhx_run_diagnostics(self.h, C.byref(cfg), *ptrs))
         n_saved = C.c_int64()
         L.check(L.lib().mhx_run_device_samples(self.h, None, None, C.byref(n_saved)))
-        out = dict(sum_m=arrs[0], sum_m2=arrs[1], sum_v=arrs[2], n_chains=self.n, n_samples=int(n_saved.value))
+        parts = 2 if split else 1
+        out = dict(sum_m=arrs[0], sum_m2=arrs[1], sum_v=arrs[2], n_chains=self.n * parts, n_samples=int(n_saved.value) // parts)
         if max_lag > 0:
             out["ess_geyer"] = np.abs(arrs[3])
             out["ess_geyer_truncated"] = arrs[3] < 0
-        out.update(combine_diagnostics(out["sum_m"], out["sum_m2"], out["sum_v"], self.n, out["n_samples"]))
+        out.update(combine_diagnostics(out["sum_m"], out["sum_m2"], out["sum_v"], out["n_chains"], out["n_samples"]))
         return out
 
     def close(self):

@@ -221,12 +221,16 @@ int mhx_run_destroy(mhx_run *run);
  * (DESIGN.md section 8); R-hat and the between-chain ESS follow on the host:
  *   W = sum_v/C, Vm = (sum_m2 - sum_m^2/C)/(C-1), var+ = (N-1)/N W + Vm,
  *   R-hat = sqrt(var+/W), ESS_between = C var+/Vm.
- * ess[p] (optional) = C N / tau_p with tau_p from Geyer's initial monotone sequence on the
- * autocovariances (lags 0..max_lag) averaged over the first `ess_chains` chains; it is returned
- * NEGATED when the sequence was still positive at max_lag (|ess| is then an upper bound). */
+ * ess[p] (optional) = C N / tau_p with tau_p from Geyer's initial monotone sequence on the multi-chain
+ * autocorrelations rho_t = 1 - (W' - A_t)/var+ (Vehtari et al. 2021, eq. 10: A_t the lag-t autocovariance
+ * averaged over the first `ess_chains` chains, W' = A_0, var+ from all chains; one chain: A_t/A_0), lags
+ * 0..max_lag; it is returned NEGATED when the sequence was still positive at max_lag (|ess| is then an upper
+ * bound).  With cfg.split every chain is two half-chains: C -> 2C, N -> floor(N/2) in all of the above. */
 typedef struct {
     int32_t max_lag;    /* 0: skip the autocovariance ESS (ess[] = NaN) */
     int32_t ess_chains; /* chains used for the autocovariances, 0 = all */
+    int32_t split;      /* 1: every chain counts as two half-chains of floor(N/2) draws (split R-hat, Vehtari et al.
+                           2021): the sums then run over 2 nchains chains, and so do the autocovariances */
 } mhx_diag_cfg;
 int mhx_run_diagnostics(mhx_run *run, const mhx_diag_cfg *cfg, double *sum_m, double *sum_m2,
                         double *sum_v, double *ess /* each [dim+1], any may be NULL */);

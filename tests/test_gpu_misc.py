@@ -141,20 +141,36 @@ def test_diagnostics_match_numpy(mhx):
     assert np.allclose(dg["sum_m"], m.sum(axis=1), rtol=1e-9, atol=1e-7)
     assert np.allclose(dg["sum_m2"], (m * m).sum(axis=1), rtol=1e-9, atol=1e-7)
     assert np.allclose(dg["sum_v"], s2.sum(axis=1), rtol=1e-9)
-    # Geyer ESS from chain-averaged autocovariances, recomputed in numpy
-    for p in range(d):
-        xc = v[:, p, :] - m[p]
-        ac = np.array([(xc[:N - k] * xc[k:]).sum() for k in range(100)])
-        rho = ac / ac[0]
+    # Geyer ESS from the multi-chain autocorrelations rho_t = 1 - (W - A_t)/var+, recomputed in numpy
+    def ess_numpy(vv, nlag):
+        Nn, Cc = vv.shape
+        mm = vv.mean(axis=0)
+        xc = vv - mm
+        A = np.array([(xc[:Nn - k] * xc[k:]).sum() for k in range(nlag)]) / (Cc * (Nn - 1.0))
+        W = vv.var(axis=0, ddof=1).mean()
+        varp = (Nn - 1.0) / Nn * W + mm.var(ddof=1)
+        rho = 1.0 - (A[0] - A) / varp
         tau, prev = -1.0, np.inf
-        for j in range(50):
+        for j in range(nlag // 2):
             pm = rho[2 * j] + rho[2 * j + 1]
             if pm <= 0:
                 break
             pm = min(pm, prev)
             prev = pm
             tau += 2 * pm
-        assert abs(dg["ess_geyer"][p] - C * N / tau) / (C * N / tau) < 1e-3
+        return Cc * Nn / tau, np.sqrt(varp / W)
+
+    for p in range(d):
+        want, _ = ess_numpy(v[:, p, :], 100)
+        assert abs(dg["ess_geyer"][p] - want) / want < 1e-3
+    # split chains (Vehtari et al. 2021): 2C half-chains of N/2 draws
+    ds = chain.state.diagnostics(max_lag=100, ess_chains=0, split=True)
+    assert ds["n_chains"] == 2 * C and ds["n_samples"] == N // 2
+    for p in range(d):
+        halves = np.concatenate([v[:N // 2, p, :], v[N // 2:, p, :]], axis=1)
+        want, rhat = ess_numpy(halves, 100)
+        assert abs(ds["ess_geyer"][p] - want) / want < 1e-3
+        assert abs(ds["rhat"][p] - rhat) < 1e-6
     assert (np.abs(dg["rhat"][:d] - 1) < 0.05).all()
     # between-chain ESS agrees with the autocovariance ESS for stationary replicas
     assert (np.abs(dg["ess_between"][:d] / dg["ess_geyer"][:d] - 1) < 0.25).all()
