@@ -429,6 +429,7 @@ struct mhx_run {
     float* d_pvec = nullptr;
     // emcee
     float stretch = 2.0f;
+    float* d_xw = nullptr;               // walker-major copy [W][round4(dim)]: the state while the cooperative kernel runs
     float* d_pmean = nullptr;            // drifting walk: mu[dim] then 2 L^-1 mu [dim]
     float* d_qx = nullptr;               // static proposal: logpdf of the proposal at each chain's state (up to its constant)
     // mala
@@ -471,7 +472,7 @@ struct mhx_run {
     ~mhx_run()
     {
         void* ptrs[] = {d_pvec, d_S, d_Ssel, d_status, d_dmin, d_dmax, d_eta, d_x, d_lp, d_ybuf,
-                        d_acc, d_last, d_acc_total, d_samples, d_accepted, d_mom_mean, d_mom_m2, d_gx, d_gy, d_z, d_pmean, d_qx};
+                        d_acc, d_last, d_acc_total, d_samples, d_accepted, d_mom_mean, d_mom_m2, d_gx, d_gy, d_z, d_pmean, d_qx, d_xw};
         for (void* p : ptrs) if (p) (void)hipFree(p);
     }
 };
@@ -664,6 +665,7 @@ extern "C" int mhx_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh
 
 // ---- emcee / ram creation, init and stepping live in their own sections below
 static int emcee_init(mhx_run* r, const float* init);
+static int emcee_sync_state(mhx_run* r, int to_abi);
 static int emcee_advance(mhx_run* r, uint64_t nsteps, uint32_t save_next, int save_slot, int thinning);
 static int ram_init(mhx_run* r, const float* init);
 static int ram_advance(mhx_run* r, uint64_t nsteps, uint64_t n_adapt, uint32_t save_next, int save_slot, int thinning);
@@ -932,6 +934,7 @@ extern "C" int mhx_run_get_state(mhx_run* r, float* x, float* lp, uint32_t* acce
     if (!r->initialised) return fail(MHX_ESTATE, "mhx_run_get_state: run is not initialised");
     HIP_TRY(hipSetDevice(r->ctx->device));
     const size_t n = (size_t)r->n, d = (size_t)r->dim;
+    if (x && r->kind == RUN_EMCEE) { int rc = emcee_sync_state(r, 1); if (rc) return rc; }
     if (x) HIP_TRY(hipMemcpy(x, r->d_x, d * n * sizeof(float), hipMemcpyDeviceToHost));
     if (lp) HIP_TRY(hipMemcpy(lp, r->d_lp, n * sizeof(float), hipMemcpyDeviceToHost));
     if (accept_counts) HIP_TRY(hipMemcpy(accept_counts, r->d_acc, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -946,6 +949,7 @@ extern "C" int mhx_run_set_state(mhx_run* r, const float* x)
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t n = (size_t)r->n, d = (size_t)r->dim;
     HIP_TRY(hipMemcpy(r->d_x, x, d * n * sizeof(float), hipMemcpyHostToDevice));
+    if (r->kind == RUN_EMCEE) { int rc = emcee_sync_state(r, 0); if (rc) return rc; }
     if (r->kind == RUN_MALA) return mala_eval_state(r, 0);   // src/MALA.jl:27-35: lp and gradient are recomputed
     // lp is a cache of logdensity(model, x) (src/AdvancedMH.jl:75): recompute it
     const unsigned grid = (unsigned)((r->n + 255) / 256);

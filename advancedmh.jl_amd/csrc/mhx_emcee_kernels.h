@@ -12,12 +12,15 @@
 //
 // One launch = one half-step; consecutive launches on the stream order the halves.  Walkers are
 // stored [dim][W] (walker fastest): own reads/writes are coalesced, the partner gather is a
-// scattered 4-byte read per dimension served by L2 (16 384 x 50 floats = 3.3 MB).
+// scattered 4-byte read per dimension served by L2 (16 384 x 50 floats = 3.3 MB).  The cooperative kernel
+// keeps the walkers in a walker-major copy instead ([W][round4(dim)]): a walker and its partner are then
+// one contiguous row each (4 cache lines at d = 50 instead of 50), read and written as float4.
 #pragma once
 #include "mhx_targets.h"
 
 struct mhx_emcee_args {
-    float* x;                 // [dim][W]
+    float* x;                 // [dim][W]   (ABI layout; the lane-per-walker kernels work on it)
+    float* xw;                // [W][round4(dim)] walker-major copy, zero padded: the state of the cooperative kernel
     float* lp;                // [W]
     mhx_u32* acc_count;       // [W]
     mhx_u64* acc_total;
@@ -150,10 +153,16 @@ typedef float mhx_e4 __attribute__((ext_vector_type(4)));
 template <int D, int L>
 struct mhx_emcee_geom {
     static constexpr int NK = (D + L - 1) / L;
-    static constexpr int DP4 = ((D + 3) & ~3) + 4;           // y row pitch: 16-byte aligned, spread over the banks
+    static constexpr int XP = (D + 3) & ~3;                   // pitch of a walker's row in the walker-major state
+    static constexpr int NQ = XP / 4;                         // float4 per walker
+    static constexpr int NQL = (NQ + 1 + L - 1) / L;          // float4 slots per lane (incl. the zero tail of the y row)
+    static constexpr int DP4 = XP + 4;                        // y row pitch: 16-byte aligned, spread over the banks
     MHX_HD static constexpr int len4(int m) { return ((L * (m + 1) < D ? L * (m + 1) : D) + 3) / 4; }
     MHX_HD static constexpr int off4(int m) { int o = 0; for (int k = 0; k < m; ++k) o += len4(k) * L; return o; }
     static constexpr int TOTAL4 = off4(NK);
+    static constexpr int THREADS = 64 * MHX_EMCEE_COOP_WAVES;
+    MHX_HD static constexpr int nit(int m) { return (len4(m) * L + THREADS - 1) / THREADS; }   // float4 per thread of row set m
+    MHX_HD static constexpr int maxit() { int x = 1; for (int k = 0; k < NK; ++k) x = nit(k) > x ? nit(k) : x; return x; }
 };
 
 template <int D, int L>
@@ -163,21 +172,27 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const float* __restric
     constexpr int CPW = 64 / L;                  // walkers per wave
     constexpr int NK = GEO::NK;                  // dimensions (and rows) per lane
     constexpr int DP4 = GEO::DP4;
-    // the factor, once per block (a lane's row reads are scattered: from LDS, not L2)
+    // The factor goes to LDS once per block (a lane's row reads are scattered: from LDS, not L2).  Its loads
+    // are unconditional (index-clamped, zero selected afterwards) so that hipcc puts ALL of them in flight
+    // at once, together with the walker gathers below: the launch is a chain of memory latencies.
+    mhx_e4 areg[NK][GEO::maxit()];
 #pragma unroll
     for (int m = 0; m < NK; ++m) {
-        constexpr int dummy = 0; (void)dummy;
-        const int n4 = GEO::len4(m) * L;
-        for (int g = threadIdx.x; g < n4; g += 64 * MHX_EMCEE_COOP_WAVES) {
-            const int jj4 = g / L, rl = g % L;
-            const int r = rl + L * m;
-            const float* Ar = A + (r < D ? r * (r + 1) / 2 : 0);
-            mhx_e4 v;
-            v.x = (r < D && 4 * jj4 + 0 <= r) ? Ar[4 * jj4 + 0] : 0.0f;
-            v.y = (r < D && 4 * jj4 + 1 <= r) ? Ar[4 * jj4 + 1] : 0.0f;
-            v.z = (r < D && 4 * jj4 + 2 <= r) ? Ar[4 * jj4 + 2] : 0.0f;
-            v.w = (r < D && 4 * jj4 + 3 <= r) ? Ar[4 * jj4 + 3] : 0.0f;
-            Ash4[GEO::off4(m) + g] = v;
+#pragma unroll
+        for (int it = 0; it < GEO::nit(m); ++it) {
+            const int g = threadIdx.x + GEO::THREADS * it;
+            const bool ok = g < GEO::len4(m) * L;
+            const int gg = ok ? g : 0;
+            const int jj4 = gg / L, r = gg % L + L * m;
+            const int base = r < D ? r * (r + 1) / 2 : 0;
+            float e[4];
+#pragma unroll
+            for (int cidx = 0; cidx < 4; ++cidx) {
+                const bool in = ok && r < D && 4 * jj4 + cidx <= r;
+                const float a0 = A[in ? base + 4 * jj4 + cidx : 0];
+                e[cidx] = in ? a0 : 0.0f;
+            }
+            areg[m][it].x = e[0]; areg[m][it].y = e[1]; areg[m][it].z = e[2]; areg[m][it].w = e[3];
         }
     }
     const int wave = threadIdx.x >> 6;
@@ -204,24 +219,38 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const float* __restric
     const float z = (tt * tt) / a.stretch;                               // src/emcee.jl:81
     const float alphamult = (float)(D - 1) * mhx_log(z);                 // :82
 
-    float xs[NK], ysl[NK];
+    // the move, element-wise on float4 slices of the two rows (lane l: float4 l, l+L, ...); the zero pad of
+    // the rows gives the zero pad of y that multiplies the zeros of the factor image
+    constexpr int NQ = GEO::NQ, NQL = GEO::NQL;
+    mhx_e4 xs[NQL], ysl[NQL];
     float* yrow = ysh + cw * DP4;
+    mhx_e4* xrow_i = (mhx_e4*)(a.xw + (long)i * GEO::XP);
+    const mhx_e4* xrow_j = (const mhx_e4*)(a.xw + (long)j * GEO::XP);
+#pragma unroll
+    for (int m = 0; m < NQL; ++m) {
+        const int q4 = l + L * m;
+        const mhx_e4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+        xs[m] = zero4;
+        ysl[m] = zero4;
+        if (q4 < NQ) {
+            const mhx_e4 xi = xrow_i[q4];
+            const mhx_e4 xj = xrow_j[q4];
+            xs[m] = xi;
+            ysl[m].x = mhx_fma(z, xi.x - xj.x, xj.x);                    // :85
+            ysl[m].y = mhx_fma(z, xi.y - xj.y, xj.y);
+            ysl[m].z = mhx_fma(z, xi.z - xj.z, xj.z);
+            ysl[m].w = mhx_fma(z, xi.w - xj.w, xj.w);
+        }
+        if (q4 < DP4 / 4) ((mhx_e4*)yrow)[q4] = ysl[m];
+    }
 #pragma unroll
     for (int m = 0; m < NK; ++m) {
-        const int k = l + L * m;
-        if (k < D) {
-            const float xi = a.x[(long)k * ld + i];
-            const float xj = a.x[(long)k * ld + j];
-            xs[m] = xi;
-            ysl[m] = mhx_fma(z, xi - xj, xj);                            // :85
-            yrow[k] = ysl[m];
-        } else {
-            xs[m] = 0.0f;
-            ysl[m] = 0.0f;
-            if (k < DP4) yrow[k] = 0.0f;                                 // the pad multiplies zeros of the factor
+#pragma unroll
+        for (int it = 0; it < GEO::nit(m); ++it) {
+            const int g = threadIdx.x + GEO::THREADS * it;
+            if (g < GEO::len4(m) * L) Ash4[GEO::off4(m) + g] = areg[m][it];
         }
     }
-    if (NK * L < DP4) { for (int k = NK * L + l; k < DP4; k += L) yrow[k] = 0.0f; }
     __syncthreads();
     const mhx_e4* yrow4 = (const mhx_e4*)yrow;
     float q = 0.0f;
@@ -250,14 +279,23 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const float* __restric
     if (valid) {
         if (acc) {
 #pragma unroll
-            for (int m = 0; m < NK; ++m) { const int k = l + L * m; if (k < D) a.x[(long)k * ld + i] = ysl[m]; }
+            for (int m = 0; m < NQL; ++m) { const int q4 = l + L * m; if (q4 < NQ) xrow_i[q4] = ysl[m]; }
             if (l == 0) { a.lp[i] = lpy; a.acc_count[i] += 1u; }
         }
         if (l == 0) a.last_acc[i] = acc ? 1 : 0;
         if (a.save_slot >= 0) {
+            // the record is [dim+1][W] (walker fastest): 16-byte runs per dimension from this wave's walkers
+            // (staging it through LDS for 64-byte runs measured no faster)
             float* row = a.samples + a.save_slot * (long)(D + 1) * ld + i;
 #pragma unroll
-            for (int m = 0; m < NK; ++m) { const int k = l + L * m; if (k < D) row[(long)k * ld] = acc ? ysl[m] : xs[m]; }
+            for (int m = 0; m < NQL; ++m) {
+                const int k = 4 * (l + L * m);
+                const mhx_e4 v = acc ? ysl[m] : xs[m];
+                if (k + 0 < D) row[(long)(k + 0) * ld] = v.x;
+                if (k + 1 < D) row[(long)(k + 1) * ld] = v.y;
+                if (k + 2 < D) row[(long)(k + 2) * ld] = v.z;
+                if (k + 3 < D) row[(long)(k + 3) * ld] = v.w;
+            }
             if (l == 0) {
                 row[(long)D * ld] = acc ? lpy : lpi;
                 a.accepted[a.save_slot * ld + i] = acc ? 1 : 0;
