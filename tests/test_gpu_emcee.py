@@ -83,3 +83,21 @@ def test_emcee_transformed_space(mhx):
     chain = mhx.sample(model, spl, 1000, seed=101, param_names=["logs", "m"])
     assert abs(np.exp(chain["logs"].astype(np.float64)).mean() - 49 / 24) < 0.1
     assert abs(chain.mean("m") - 7 / 6) < 0.1
+
+
+@pytest.mark.parametrize("d,W,N,lanes", [(128, 40, 4, 16), (128, 37, 3, 2), (100, 33, 4, 8), (126, 18, 3, 16), (33, 9, 5, 32)])
+def test_emcee_cooperative_kernel_large_dimensions(mhx, oracle, d, W, N, lanes):
+    """The cooperative kernel at its largest factor images (several float4 of the factor per thread, several
+    float4 of a walker per lane), dimensions that are not multiples of 4, odd ensemble sizes, recorded sweeps."""
+    Sig = cases.sigma_ar1(d, 0.8)
+    init = cases.emcee_init(d, W, 9)
+    model = mhx.DensityModel(mhx.CorrGaussian(Sig))
+    spl = mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I)))
+    chain = mhx.sample(model, spl, N, seed=4, first_chain=1, initial_params=init, reduce_lanes=lanes)
+    assert chain.stats["reduce_lanes"] == lanes and chain.stats["kernel_variant"] == 4
+    ref = oracle.emcee(oracle.corr_gauss_from_cov(Sig, reduce_lanes=lanes), 2.0, 1, oracle.schedule(N), 4, 1, W, init)
+    _same(chain.value, ref["samples"], "samples")
+    _same(chain.accepted, ref["accepted"], "accepted")
+    x, lp, cnt = chain.state.state()
+    _same(x, ref["final_x"], "final x")
+    _same(lp, ref["final_lp"], "final lp")
