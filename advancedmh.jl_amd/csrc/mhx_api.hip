@@ -17,6 +17,8 @@
 #include <string>
 #include <vector>
 
+#include <rocprim/rocprim.hpp>   // device radix sort for the rank-normalised ESS (after <cstring>: it calls memset)
+
 #include "mhx_rwmh_kernels.h"
 #include "mhx_emcee_kernels.h"
 #include "mhx_ram_kernels.h"

@@ -75,7 +75,7 @@ EXPORTS = [
     "mhx_emcee_create", "mhx_ram_create", "mhx_mala_create", "mhx_ram_set_factor", "mhx_ram_get_factor",
     "mhx_ram_get_diag_range", "mhx_run_init", "mhx_run_sample", "mhx_run_get_samples",
     "mhx_run_get_state", "mhx_run_set_state", "mhx_run_stats", "mhx_run_device_samples",
-    "mhx_run_destroy", "mhx_run_diagnostics",
+    "mhx_run_destroy", "mhx_run_diagnostics", "mhx_run_ess_bulk_tail",
 ]
 
 _lib = None
@@ -114,6 +114,7 @@ def lib():
         L.mhx_run_device_samples.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int64)]
         L.mhx_run_destroy.argtypes = [vp]
         L.mhx_run_diagnostics.argtypes = [vp, C.POINTER(DiagCfg), dp, dp, dp, dp]
+        L.mhx_run_ess_bulk_tail.argtypes = [vp, C.POINTER(DiagCfg), C.POINTER(C.c_int32), C.c_int32, dp, dp]
         _lib = L
     return _lib
 

@@ -524,6 +524,23 @@ class Run:
         out.update(combine_diagnostics(out["sum_m"], out["sum_m2"], out["sum_v"], out["n_chains"], out["n_samples"]))
         return out
 
+    def ess_bulk_tail(self, params=None, max_lag=0, ess_chains=256, split=True):
+        """Rank-normalised bulk ESS and tail ESS (Vehtari et al. 2021; MCMCChains' ess_bulk / ess_tail) of the given
+        parameter rows (default: all, lp included) of the last sample buffer, sorted and scored on the device.
+        max_lag = 0: half the draws of a (half-)chain.  Negative values: upper bounds (see include/mhx.h)."""
+        n_saved = C.c_int64()
+        L.check(L.lib().mhx_run_device_samples(self.h, None, None, C.byref(n_saved)))
+        N = int(n_saved.value) // (2 if split else 1)
+        if max_lag <= 0:
+            max_lag = max(2, N // 2)
+        idx = np.arange(self.dim + 1, dtype=np.int32) if params is None else np.ascontiguousarray(params, dtype=np.int32)
+        bulk, tail = np.zeros(len(idx)), np.zeros(len(idx))
+        cfg = L.DiagCfg(max_lag, ess_chains, 1 if split else 0)
+        dp = C.POINTER(C.c_double)
+        L.check(L.lib().mhx_run_ess_bulk_tail(self.h, C.byref(cfg), idx.ctypes.data_as(C.POINTER(C.c_int32)), len(idx),
+                                              bulk.ctypes.data_as(dp), tail.ctypes.data_as(dp)))
+        return dict(params=idx, ess_bulk=np.abs(bulk), ess_tail=np.abs(tail), bulk_truncated=bulk < 0, tail_truncated=tail < 0)
+
     def close(self):
         if self.h:
             L.lib().mhx_run_destroy(self.h)

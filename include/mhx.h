@@ -235,6 +235,14 @@ typedef struct {
 int mhx_run_diagnostics(mhx_run *run, const mhx_diag_cfg *cfg, double *sum_m, double *sum_m2,
                         double *sum_v, double *ess /* each [dim+1], any may be NULL */);
 
+/* Rank-normalised bulk ESS and tail ESS (Vehtari et al. 2021, sections 4.1-4.3; what MCMCChains / ArviZ print as
+ * ess_bulk, ess_tail) of the parameters params[0..nparams) (indices into the dim+1 rows, lp = dim) of the sample
+ * buffer: the draws of one parameter are sorted on the device, replaced by the normal scores of their ranks (bulk)
+ * and by the indicators of the 5 % / 95 % quantiles (tail: the smaller of the two), and the multi-chain ESS above
+ * (cfg.max_lag, cfg.ess_chains, cfg.split) is taken of those series.  Negated values: as for ess[] above. */
+int mhx_run_ess_bulk_tail(mhx_run *run, const mhx_diag_cfg *cfg, const int32_t *params, int32_t nparams,
+                          double *ess_bulk, double *ess_tail /* each [nparams], either may be NULL */);
+
 #ifdef __cplusplus
 }
 #endif

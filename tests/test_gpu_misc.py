@@ -392,3 +392,50 @@ def test_runs_release_their_device_memory(mhx):
     for _ in range(5):
         cycle()
     assert before - free_bytes() < (1 << 20), "device memory leaked: %d bytes" % (before - free_bytes())
+
+
+def test_bulk_and_tail_ess_match_numpy(mhx):
+    """Rank-normalised bulk ESS and tail ESS (Vehtari et al. 2021) against a numpy / scipy restatement."""
+    from scipy.stats import norm
+    d, C, N = 2, 64, 600
+    model = mhx.DensityModel(mhx.CorrGaussian(np.array([[1.0, 0.8], [0.8, 1.0]])))
+    chain = mhx.sample(model, mhx.RWMH(mhx.MvNormal(mhx.zeros(d), 0.6 * mhx.I)), N, C, seed=12, discard_initial=300)
+    got = chain.state.ess_bulk_tail(max_lag=120, ess_chains=0, split=True)
+    v = chain.value.astype(np.float64)
+
+    def ess(series, nlag):                                   # series [N][C]: multi-chain Geyer ESS on split chains
+        h = series.shape[0] // 2
+        s = np.concatenate([series[:h], series[h:2 * h]], axis=1)
+        Nn, Cc = s.shape
+        mm = s.mean(axis=0)
+        xc = s - mm
+        A = np.array([(xc[:Nn - k] * xc[k:]).sum() for k in range(nlag)]) / (Cc * (Nn - 1.0))
+        W = s.var(axis=0, ddof=1).mean()
+        varp = (Nn - 1.0) / Nn * W + mm.var(ddof=1)
+        rho = 1.0 - (A[0] - A) / varp
+        tau, prev = -1.0, np.inf
+        for j in range(nlag // 2):
+            pm = rho[2 * j] + rho[2 * j + 1]
+            if pm <= 0:
+                break
+            pm = min(pm, prev)
+            prev = pm
+            tau += 2 * pm
+        return Cc * Nn / tau
+
+    for p in range(d + 1):
+        x = v[:, p, :]
+        S = x.size
+        order = np.argsort(x.ravel(), kind="stable")
+        ranks = np.empty(S)
+        ranks[order] = np.arange(1, S + 1)
+        z = norm.ppf((ranks - 0.375) / (S + 0.25)).reshape(x.shape).astype(np.float32).astype(np.float64)
+        srt = np.sort(x.ravel())
+        q05, q95 = srt[int(0.05 * (S - 1))], srt[int(0.95 * (S - 1))]
+        want_bulk = ess(z, 120)
+        want_tail = min(ess((x <= q05).astype(np.float64), 120), ess((x <= q95).astype(np.float64), 120))
+        assert abs(got["ess_bulk"][p] - want_bulk) / want_bulk < 2e-3, (p, got["ess_bulk"][p], want_bulk)
+        assert abs(got["ess_tail"][p] - want_tail) / want_tail < 2e-3, (p, got["ess_tail"][p], want_tail)
+    # a Gaussian target: the bulk ESS agrees with the plain ESS of the same draws
+    plain = chain.state.diagnostics(max_lag=120, ess_chains=0, split=True)["ess_geyer"]
+    assert (np.abs(got["ess_bulk"][:d] / plain[:d] - 1) < 0.15).all()
