@@ -42,8 +42,12 @@ struct mhx_emcee_args {
     int reduce_lanes;         // lanes per walker (cooperative kernel), >= 1
 };
 
-// D > 0: compile-time dimension, candidate in registers.  D == 0: run-time dimension, candidate
-// staged in ybuf.
+typedef float mhx_e4 __attribute__((ext_vector_type(4)));
+
+// D > 0: compile-time dimension, candidate in registers; the walkers are read from the walker-major copy
+// [W][round4(D)] (a.xw): a walker and its partner are one contiguous row each, float4 loads, 4 cache lines
+// at d = 50 where the [dim][W] layout touches 50 per partner.  D == 0: run-time dimension, [dim][W] state,
+// candidate staged in ybuf.
 template <int D, int TK>
 MHX_DEV void mhx_emcee_half_body(const mhx_emcee_args& a, const float* __restrict__ tparams)
 {
@@ -70,14 +74,19 @@ MHX_DEV void mhx_emcee_half_body(const mhx_emcee_args& a, const float* __restric
     const float alphamult = (float)(d - 1) * mhx_log(z);                // :82
 
     float lpy;
-    float yreg[D > 0 ? D : 1];
+    constexpr int XP = D > 0 ? ((D + 3) & ~3) : 4;
+    float yreg[XP];
     float* ys = a.ybuf + i;
+    mhx_e4* xrow_i = D > 0 ? (mhx_e4*)(a.xw + (long)i * XP) : nullptr;
     if (D > 0) {
+        const mhx_e4* xrow_j = (const mhx_e4*)(a.xw + (long)j * XP);
 #pragma unroll
-        for (int k = 0; k < D; ++k) {
-            const float xi = a.x[(long)k * ld + i];
-            const float xj = a.x[(long)k * ld + j];
-            yreg[k] = mhx_fma(z, xi - xj, xj);                          // :85
+        for (int q = 0; q < XP / 4; ++q) {
+            const mhx_e4 xi = xrow_i[q], xj = xrow_j[q];                  // the zero pad of the rows stays zero
+            yreg[4 * q + 0] = mhx_fma(z, xi.x - xj.x, xj.x);              // :85
+            yreg[4 * q + 1] = mhx_fma(z, xi.y - xj.y, xj.y);
+            yreg[4 * q + 2] = mhx_fma(z, xi.z - xj.z, xj.z);
+            yreg[4 * q + 3] = mhx_fma(z, xi.w - xj.w, xj.w);
         }
         lpy = mhx_target_eval<TK>(TK, yreg, D, tparams, a.ntparams, a.tconst);
     } else {
@@ -98,7 +107,11 @@ MHX_DEV void mhx_emcee_half_body(const mhx_emcee_args& a, const float* __restric
     if (acc) {
         if (D > 0) {
 #pragma unroll
-            for (int k = 0; k < D; ++k) a.x[(long)k * ld + i] = yreg[k];
+            for (int q = 0; q < XP / 4; ++q) {
+                mhx_e4 v;
+                v.x = yreg[4 * q + 0]; v.y = yreg[4 * q + 1]; v.z = yreg[4 * q + 2]; v.w = yreg[4 * q + 3];
+                xrow_i[q] = v;
+            }
         } else {
             for (int k = 0; k < d; ++k) a.x[(long)k * ld + i] = ys[(long)k * ld];
         }
@@ -110,7 +123,7 @@ MHX_DEV void mhx_emcee_half_body(const mhx_emcee_args& a, const float* __restric
         float* row = a.samples + a.save_slot * (long)(d + 1) * ld + i;
         if (D > 0) {
 #pragma unroll
-            for (int k = 0; k < D; ++k) row[(long)k * ld] = acc ? yreg[k] : a.x[(long)k * ld + i];
+            for (int k = 0; k < D; ++k) row[(long)k * ld] = acc ? yreg[k] : a.xw[(long)i * XP + k];
         } else {
             for (int k = 0; k < d; ++k) row[(long)k * ld] = a.x[(long)k * ld + i];
         }
@@ -143,8 +156,6 @@ MHX_DEV void mhx_emcee_init_body(const mhx_emcee_args& a, const float* __restric
 // through LDS (broadcast reads within a walker's lane group); the L partial sums of squares meet in
 // an xor-butterfly -- the reduction shape is part of the arithmetic spec (oracle: reduce_lanes = L).
 #define MHX_EMCEE_COOP_WAVES 4                   // waves per block: they share the LDS copy of the factor
-
-typedef float mhx_e4 __attribute__((ext_vector_type(4)));
 
 // LDS image of the packed factor for L lanes per walker.  Lane l owns rows l, l+L, ...; row set m
 // (rows L m .. L m + L - 1) is stored as LEN4(m) groups of L float4 -- group jj4 holds columns
