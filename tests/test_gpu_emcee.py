@@ -101,3 +101,24 @@ def test_emcee_cooperative_kernel_large_dimensions(mhx, oracle, d, W, N, lanes):
     x, lp, cnt = chain.state.state()
     _same(x, ref["final_x"], "final x")
     _same(lp, ref["final_lp"], "final lp")
+
+
+@pytest.mark.parametrize("d,W", [(7, 37), (50, 64), (64, 10)])
+def test_emcee_user_log_density_walker_major_rows(mhx, oracle, d, W):
+    """The register kernel (user log-density in HIP source) on walker-major rows: dimensions with and without
+    padding, recorded sweeps with thinning, state read back in the ABI layout."""
+    rng = np.random.default_rng(d)
+    data = np.concatenate([rng.normal(size=d), 0.5 + rng.random(d)]).astype(np.float32)
+    model = mhx.DensityModel(mhx.HipLogDensity(user_targets.SHIFTED_GAUSS, d, data=data))
+    ut = user_targets.host_target(oracle, user_targets.SHIFTED_GAUSS, d, data=data)
+    init = cases.emcee_init(d, W, 2)
+    spl = mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I)))
+    chain = mhx.sample(model, spl, 9, seed=6, first_chain=2, initial_params=init, discard_initial=1, thinning=2)
+    assert chain.stats["kernel_variant"] == 2
+    ref = oracle.emcee(ut, 2.0, 1, oracle.schedule(9, 1, 2), 6, 2, W, init)
+    _same(chain.value, ref["samples"], "samples")
+    _same(chain.accepted, ref["accepted"], "accepted")
+    x, lp, cnt = chain.state.state()
+    _same(x, ref["final_x"], "final x")
+    _same(lp, ref["final_lp"], "final lp")
+    _same(cnt, ref["accept_counts"], "accept counts")
