@@ -17,7 +17,9 @@
  * the arithmetic spec of DESIGN.md section 3.  What IS pinned: Philox against the Random123
  * known-answer vectors, the transcendental polynomials against libm, the target log-densities
  * against scipy, the rank-1 Cholesky up/downdate against numpy.linalg.cholesky, and the samplers
- * against every analytic known answer the reference's own tests use (tests/test_oracle_*.py).
+ * against every analytic known answer the reference's own tests use (tests/test_oracle_*.py) and, step
+ * by step, against a second float64 numpy / scipy restatement of the reference's formulas
+ * (tests/test_reference_restatement.py).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
  */
