@@ -23,6 +23,7 @@
 #include "mhx_emcee_kernels.h"
 #include "mhx_ram_kernels.h"
 #include "mhx_mala_kernels.h"
+#include "mhx_rwmh_dense_kernels.h"
 #include "mhx_diag_kernels.h"
 #include "mhx_jit_embed.inc"   // generated: the device headers as string literals for hiprtc
 
@@ -185,10 +186,12 @@ static int jit_compile(mhx_ctx* ctx, const std::string& key, const std::string& 
     if (it != ctx->jit.end()) { *out = it->second.get(); return MHX_OK; }
     hiprtcProgram prog = nullptr;
     const char* hdr_src[] = {k_src_mhx_device_math_h, k_src_mhx_targets_h, k_src_mhx_rwmh_kernels_h,
-                             k_src_mhx_emcee_kernels_h, k_src_mhx_ram_kernels_h, k_src_mhx_mala_kernels_h};
+                             k_src_mhx_emcee_kernels_h, k_src_mhx_ram_kernels_h, k_src_mhx_mala_kernels_h,
+                             k_src_mhx_rwmh_dense_kernels_h};
     const char* hdr_name[] = {"mhx_device_math.h", "mhx_targets.h", "mhx_rwmh_kernels.h",
-                              "mhx_emcee_kernels.h", "mhx_ram_kernels.h", "mhx_mala_kernels.h"};
-    hiprtcResult r = hiprtcCreateProgram(&prog, source.c_str(), "mhx_jit.hip", 6, hdr_src, hdr_name);
+                              "mhx_emcee_kernels.h", "mhx_ram_kernels.h", "mhx_mala_kernels.h",
+                              "mhx_rwmh_dense_kernels.h"};
+    hiprtcResult r = hiprtcCreateProgram(&prog, source.c_str(), "mhx_jit.hip", 7, hdr_src, hdr_name);
     if (r != HIPRTC_SUCCESS) return fail(MHX_EJIT, "hiprtcCreateProgram: %s", hiprtcGetErrorString(r));
     std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize"};
     for (auto& d : defines) opts.push_back("-D" + d);
@@ -529,6 +532,7 @@ static int rwmh_whiten(mhx_run* r)
 
 #define MHX_REG_MAX_DIM 160
 #define MHX_REG_MAX_DIM_DENSE 96
+#define MHX_DENSE_COOP_MAX_DIM 128           // the float4 factor image must fit the 64 KB of static LDS
 
 extern "C" int mhx_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, mhx_run** out)
 {
@@ -609,8 +613,28 @@ extern "C" int mhx_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh
             while (L < 64 && (nblk + L - 1) / L > 13) L *= 2;
             while (L < 64 && 2 * L <= nblk && (long)r->n * L / 64 < 2048) L *= 2;
         }
+    } else if (tk == MHX_TARGET_CORR_GAUSS && pk != MHX_PROP_DENSE && !(r->flags & (MHX_FLAG_GENERIC | MHX_FLAG_NO_JIT)) &&
+               d >= 2 && d <= MHX_DENSE_COOP_MAX_DIM && (cfg->reduce_lanes > 1 || (cfg->reduce_lanes == 0 && d >= 16))) {
+        // dense Gaussian target: the cooperative kernel of mhx_rwmh_dense_kernels.h (L lanes per chain, factor image
+        // in LDS).  Lanes per chain by default: at most 12.5 rows of A y per lane (measured at 65 536 chains: d = 32 /
+        // 50 / 64 / 100 / 128 run 1.8e10 / 8.5e9 / 6.8e9 / 2.9e9 / 2.0e9 steps/s; the lane-per-chain register kernel
+        // 1.4e10 / 7.2e9 / 4.9e9 / - / -; more rows per lane than ~16 spill)
+        L = 2;
+        if (cfg->reduce_lanes > 1) L = cfg->reduce_lanes;
+        else while (2 * d > 25 * L) L *= 2;
+        if (L > 64 || (L & (L - 1)) || L > d) return fail(MHX_EINVAL, "reduce_lanes must be a power of two <= min(64, dim), got %d", L);
+        jit_module* m = nullptr;
+        const std::string key = "rwmh_dense/d=" + std::to_string(d) + "/l=" + std::to_string(L) + "/pk=" + std::to_string(pk);
+        rc = jit_compile(ctx, key, jit_source(t, "mhx_rwmh_dense_kernels.h"),
+                         {"MHX_JIT_RWMH_DENSE=1", "MHX_JIT_DIM=" + std::to_string(d), "MHX_JIT_L=" + std::to_string(L),
+                          "MHX_JIT_PK=" + std::to_string(pk)}, &m);
+        if (rc == MHX_OK) rc = jit_function(m, "mhx_jit_rwmh_dense", &r->jit_step);
+        if (rc == MHX_OK) { r->variant = 5; r->coop_L = L; }
+        else if (cfg->reduce_lanes > 1) return rc;
+        L = 1;                                                        // not the separable cooperative path below
     } else if (cfg->reduce_lanes > 1) {
-        return fail(MHX_EINVAL, "reduce_lanes > 1 needs a separable catalogue target and an ISO/DIAG proposal");
+        return fail(MHX_EINVAL, "reduce_lanes > 1 needs a separable catalogue target or the dense Gaussian target "
+                                "(dim <= 128, JIT), and an ISO/DIAG proposal");
     }
     if (L > 1) {
         const int NBL = (nblk + L - 1) / L;
@@ -729,6 +753,12 @@ static int rwmh_advance(mhx_run* r, uint64_t nsteps, uint32_t save_next, int sav
                 int rc = launch_module(r->jit_step, grid, 256, ctx->stream, params);
                 if (rc) return rc;
             }
+        } else if (r->variant == 5) {
+            const long per_block = (64 / r->coop_L) * MHX_EMCEE_COOP_WAVES;          // chains per block
+            const unsigned grid = (unsigned)(((long)r->n + per_block - 1) / per_block);
+            void* params[] = {&a, &tp, &pv};
+            int rc = launch_module(r->jit_step, grid, 64 * MHX_EMCEE_COOP_WAVES, ctx->stream, params);
+            if (rc) return rc;
         } else if (r->variant == 1) {
             const unsigned grid = (unsigned)((r->n + 63) / 64);
             hipLaunchKernelGGL(r->reg_fn, dim3(grid), dim3(64), 0, ctx->stream, a, tp, pv);

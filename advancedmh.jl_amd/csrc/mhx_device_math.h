@@ -18,6 +18,9 @@
 #define MHX_DEV __device__ __forceinline__
 #define MHX_HD __host__ __device__ __forceinline__
 
+// ordering of ONE wave's LDS traffic (data that only the lanes of a wave exchange: no s_barrier needed)
+#define MHX_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
 typedef unsigned int mhx_u32;
 typedef unsigned long long mhx_u64;
 __device__ __forceinline__ mhx_u32 mhx_f2u_fwd(float f) { return __builtin_bit_cast(mhx_u32, f); }

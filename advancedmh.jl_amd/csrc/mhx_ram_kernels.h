@@ -86,8 +86,6 @@ typedef float mhx_f4 __attribute__((ext_vector_type(4)));
 #define MHX_RAM_FIXED_FLOATS(G, R) ((64 / (G)) * (MHX_RAM_RING(G, R) + MHX_RAM_MIRF(G, R)))
 #define MHX_RAM_LDS_FLOATS(G, R, d) (MHX_RAM_FIXED_FLOATS(G, R) + (64 / (G)) * 3 * (d))
 
-// ordering of one wave's LDS traffic (the block is one wave: no s_barrier needed)
-#define MHX_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
 // Streaming a packed factor: GS lanes pull one contiguous array in full-width pieces -- NV x (GS lanes
 // x 16 B) = one chunk per round, every lane active -- and park it in a two-chunk LDS ring; the column

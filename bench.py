@@ -30,7 +30,7 @@ VALU_PEAK = 256 * 4 * 2.4e9 / 4.0   # wave64 VALU instructions per second: 16-la
 D = 100
 CHAINS = 65536
 VARIANTS = {0: "generic", 1: "prebuilt-register", 2: "hiprtc-register", 3: "prebuilt-cooperative",
-            4: "hiprtc-cooperative"}
+            4: "hiprtc-cooperative", 5: "hiprtc-dense-cooperative"}
 
 
 def algorithmic_bytes_per_launch(d, chains, inner):

@@ -200,7 +200,8 @@ typedef struct {
     double kernel_ms;          /* device time of the sampler kernels (hipEvent)                         */
     double wall_ms;            /* host wall time of the call                                            */
     int32_t kernel_variant;    /* 0 generic (HBM state), 1 pre-built register kernel, 2 hiprtc-specialised register
-                                  kernel, 3 pre-built cooperative kernel, 4 hiprtc-specialised cooperative kernel */
+                                  kernel, 3 pre-built cooperative kernel, 4 hiprtc-specialised cooperative kernel,
+                                  5 hiprtc-specialised cooperative kernel for the dense Gaussian target (RWMH) */
     int32_t launches;
     int32_t reduce_lanes;      /* lanes per chain in effect (1 unless a cooperative kernel runs) */
 } mhx_stats;

@@ -85,3 +85,44 @@ def test_parallel_sampling_call_forms(mhx):
     assert abs(a.mean("μ") - data.mean()) < 0.1 and abs(a.mean("σ") - 1.0) < 0.1
     c = mhx.sample(model, spl, mhx.MCMCDistributed(), 100, 4, seed=2, initial_params=np.array([0.0, 1.0]))
     assert np.array_equal(c.value, b.value[:100])
+
+
+@pytest.mark.parametrize("d,C,lanes,prop", [(100, 70, 0, "iso"), (128, 33, 16, "diag"), (70, 9, 8, "iso"), (5, 37, 2, "diag"),
+                                            (50, 40, 4, "iso"), (99, 17, 32, "diag")])
+def test_dense_gaussian_target_cooperative_kernel(mhx, oracle, d, C, lanes, prop):
+    """RWMH on the dense Gaussian target with L lanes per chain (mhx_rwmh_dense_kernels.h): the default above 64
+    dimensions, on request below; ISO and DIAG proposals, random initial states, a schedule with discard and
+    thinning, a second call that resumes the run."""
+    import cases
+    seed = 77 + d
+    Sig = cases.sigma_ar1(d, 0.6)
+    model = mhx.DensityModel(mhx.CorrGaussian(Sig))
+    if prop == "iso":
+        s = float(np.float32(1.7 / d ** 0.5))
+        spl, op = mhx.RWMH(mhx.MvNormal(mhx.zeros(d), s * s * mhx.I)), oracle.Proposal(oracle.PROP_ISO, s)
+    else:
+        sv = (np.float32(1.7 / d ** 0.5) * (0.5 + np.random.default_rng(d).random(d))).astype(np.float32)
+        spl, op = mhx.RWMH([mhx.Normal(0.0, float(v)) for v in sv]), oracle.Proposal(oracle.PROP_DIAG, vec=sv)
+    run = mhx.Run(model, spl, nchains=C, seed=seed, first_chain=11, reduce_lanes=lanes)
+    run.init(None)
+    run.sample(6, 3, 2, 0)
+    p1, a1 = run.samples()
+    st = run.stats()
+    L = st["reduce_lanes"]
+    assert st["kernel_variant"] == 5 and (L == lanes if lanes else L == 8)      # d = 100: at most 12.5 rows per lane
+    run.sample(5, 1, 1, 0)
+    p2, a2 = run.samples()
+    x, lp, cnt = run.state()
+    # the same chain in one go: 3 discarded, 6 samples 2 apart (13 transitions), then 5 more 1 apart
+    ot = oracle.corr_gauss_from_cov(Sig, reduce_lanes=L)
+    ref = oracle.rwmh(ot, op, oracle.schedule(19, 0, 1), seed, 11, C)
+    idx1 = [3 + 2 * i for i in range(6)]
+    idx2 = [idx1[-1] + 1 + i for i in range(5)]
+    _same(p1, ref["samples"][idx1], "first call")
+    _same(p2, ref["samples"][idx2], "resumed call")
+    _same(a2, ref["accepted"][idx2], "accept flags")
+    _same(x, ref["final_x"], "final x")
+    _same(lp, ref["final_lp"], "final lp")
+    _same(cnt, ref["accept_counts"], "accept counts")
+    assert 0.02 < ref["accepted"][1:].mean() < 0.9
+    run.close()
