@@ -140,6 +140,17 @@ def main():
     # Diagnostics of the LAST launch's sample tensor (outside the timed region): per-shard sums for R-hat
     # and the between-chain ESS; across GPUs they combine with the one small all-reduce the design has.
     diag = run.diagnostics(max_lag=0)
+    bulk = None
+    if world == 1:
+        try:                                          # rank-normalised bulk ESS of three parameters (device sort), for reference
+            b = run.ess_bulk_tail(params=[0, d // 2, d - 1], split=True)
+            bulk = {"params": [int(v) for v in b["params"]], "ess_bulk": [float(v) for v in b["ess_bulk"]],
+                    "upper_bound_only": [bool(v) for v in b["bulk_truncated"]],
+                    "note": "split chains, Geyer truncation; 250 draws per chain are shorter than the autocorrelation time, "
+                            "so the sequence is still positive at the last lag and the value is an upper bound -- "
+                            "ess_per_sec uses the between-chain estimator"}
+        except Exception as e:                        # never let a diagnostic break the bench line
+            bulk = {"error": str(e)}
     if dist is not None:
         import torch
         from mhx.dist import allreduce_stats
@@ -188,7 +199,7 @@ def main():
             "ess_per_sec": float(np.median(essb)) / (dt / args.steps),
             "ess": {"estimator": "between-chain, last step's %d draws x %d chains" % (inner, C * world),
                     "median": float(np.median(essb)), "min": float(essb.min()),
-                    "rhat_max": float(np.max(diag["rhat"][:d]))},
+                    "rhat_max": float(np.max(diag["rhat"][:d])), "bulk": bulk},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_rwmh_coop<2,13,iso,iso>" if variant == 3 else "rwmh variant %d" % variant,
