@@ -176,19 +176,14 @@ struct mhx_emcee_geom {
     MHX_HD static constexpr int maxit() { int x = 1; for (int k = 0; k < NK; ++k) x = nit(k) > x ? nit(k) : x; return x; }
 };
 
+// this thread's float4 of the factor image, straight from the packed factor: unconditional, index-clamped
+// loads (zero selected afterwards), so that hipcc puts ALL of them in flight at once
 template <int D, int L>
-MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const float* __restrict__ A, float* ysh_all, mhx_e4* Ash4)
+MHX_DEV void mhx_dense_image_load(const float* __restrict__ A, mhx_e4 (&areg)[mhx_emcee_geom<D, L>::NK][mhx_emcee_geom<D, L>::maxit()])
 {
     typedef mhx_emcee_geom<D, L> GEO;
-    constexpr int CPW = 64 / L;                  // walkers per wave
-    constexpr int NK = GEO::NK;                  // dimensions (and rows) per lane
-    constexpr int DP4 = GEO::DP4;
-    // The factor goes to LDS once per block (a lane's row reads are scattered: from LDS, not L2).  Its loads
-    // are unconditional (index-clamped, zero selected afterwards) so that hipcc puts ALL of them in flight
-    // at once, together with the walker gathers below: the launch is a chain of memory latencies.
-    mhx_e4 areg[NK][GEO::maxit()];
 #pragma unroll
-    for (int m = 0; m < NK; ++m) {
+    for (int m = 0; m < GEO::NK; ++m) {
 #pragma unroll
         for (int it = 0; it < GEO::nit(m); ++it) {
             const int g = threadIdx.x + GEO::THREADS * it;
@@ -206,6 +201,56 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const float* __restric
             areg[m][it].x = e[0]; areg[m][it].y = e[1]; areg[m][it].z = e[2]; areg[m][it].w = e[3];
         }
     }
+}
+template <int D, int L>
+MHX_DEV void mhx_dense_image_store(const mhx_e4 (&areg)[mhx_emcee_geom<D, L>::NK][mhx_emcee_geom<D, L>::maxit()], mhx_e4* Ash4)
+{
+    typedef mhx_emcee_geom<D, L> GEO;
+#pragma unroll
+    for (int m = 0; m < GEO::NK; ++m) {
+#pragma unroll
+        for (int it = 0; it < GEO::nit(m); ++it) {
+            const int g = threadIdx.x + GEO::THREADS * it;
+            if (g < GEO::len4(m) * L) Ash4[GEO::off4(m) + g] = areg[m][it];
+        }
+    }
+}
+// lane l's share of |A y|^2: rows l, l+L, ... of A y from the LDS image and the candidate row (ascending
+// columns, one fmaf chain per row), summed in ascending row order; the L shares meet in the caller's butterfly
+template <int D, int L>
+MHX_DEV float mhx_dense_rows_sq(const mhx_e4* Ash4, const mhx_e4* yrow4, const int l)
+{
+    typedef mhx_emcee_geom<D, L> GEO;
+    float q = 0.0f;
+#pragma unroll
+    for (int m = 0; m < GEO::NK; ++m) {
+        const int r = l + L * m;
+        float w = 0.0f;
+#pragma unroll
+        for (int jj4 = 0; jj4 < GEO::len4(m); ++jj4) {
+            const mhx_e4 av = Ash4[GEO::off4(m) + jj4 * L + l];
+            const mhx_e4 yv = yrow4[jj4];
+            w = mhx_fma(av.x, yv.x, w);
+            w = mhx_fma(av.y, yv.y, w);
+            w = mhx_fma(av.z, yv.z, w);
+            w = mhx_fma(av.w, yv.w, w);
+        }
+        q = r < D ? mhx_fma(w, w, q) : q;
+    }
+    return q;
+}
+
+template <int D, int L>
+MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const float* __restrict__ A, float* ysh_all, mhx_e4* Ash4)
+{
+    typedef mhx_emcee_geom<D, L> GEO;
+    constexpr int CPW = 64 / L;                  // walkers per wave
+    constexpr int NK = GEO::NK;                  // dimensions (and rows) per lane
+    constexpr int DP4 = GEO::DP4;
+    // The factor goes to LDS once per block (a lane's row reads are scattered: from LDS, not L2); its loads fly
+    // together with the walker rows below: the launch is a chain of memory latencies.
+    mhx_e4 areg[NK][GEO::maxit()];
+    mhx_dense_image_load<D, L>(A, areg);
     const int wave = threadIdx.x >> 6;
     float* ysh = ysh_all + wave * (CPW * DP4);
     const int W = a.nwalkers;
@@ -254,32 +299,9 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const float* __restric
         }
         if (q4 < DP4 / 4) ((mhx_e4*)yrow)[q4] = ysl[m];
     }
-#pragma unroll
-    for (int m = 0; m < NK; ++m) {
-#pragma unroll
-        for (int it = 0; it < GEO::nit(m); ++it) {
-            const int g = threadIdx.x + GEO::THREADS * it;
-            if (g < GEO::len4(m) * L) Ash4[GEO::off4(m) + g] = areg[m][it];
-        }
-    }
+    mhx_dense_image_store<D, L>(areg, Ash4);
     __syncthreads();
-    const mhx_e4* yrow4 = (const mhx_e4*)yrow;
-    float q = 0.0f;
-#pragma unroll
-    for (int m = 0; m < NK; ++m) {
-        const int r = l + L * m;                                         // this lane's row of A y
-        float w = 0.0f;
-#pragma unroll
-        for (int jj4 = 0; jj4 < GEO::len4(m); ++jj4) {
-            const mhx_e4 av = Ash4[GEO::off4(m) + jj4 * L + l];
-            const mhx_e4 yv = yrow4[jj4];
-            w = mhx_fma(av.x, yv.x, w);
-            w = mhx_fma(av.y, yv.y, w);
-            w = mhx_fma(av.z, yv.z, w);
-            w = mhx_fma(av.w, yv.w, w);
-        }
-        q = r < D ? mhx_fma(w, w, q) : q;
-    }
+    float q = mhx_dense_rows_sq<D, L>(Ash4, (const mhx_e4*)yrow, l);
 #pragma unroll
     for (int off = 1; off < L; off <<= 1) q = q + __shfl_xor(q, off * CPW, 64);
     const float lpy = mhx_fma(-0.5f, q, a.tconst);

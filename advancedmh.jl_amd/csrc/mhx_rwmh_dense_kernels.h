@@ -21,27 +21,11 @@ MHX_DEV void mhx_rwmh_dense_coop_body(const mhx_rwmh_args& a, const float* __res
     typedef mhx_emcee_geom<D, L> GEO;
     constexpr int CPW = 64 / L;                  // chains per wave
     constexpr int NK = GEO::NK, NQ = GEO::NQ, NQL = GEO::NQL, DP4 = GEO::DP4;
-    // ---- the factor image, once per launch (unconditional index-clamped loads: all in flight together)
-#pragma unroll
-    for (int m = 0; m < NK; ++m) {
-#pragma unroll
-        for (int it = 0; it < GEO::nit(m); ++it) {
-            const int g = threadIdx.x + GEO::THREADS * it;
-            const bool ok = g < GEO::len4(m) * L;
-            const int gg = ok ? g : 0;
-            const int jj4 = gg / L, r = gg % L + L * m;
-            const int base = r < D ? r * (r + 1) / 2 : 0;
-            mhx_e4 v;
-            float e[4];
-#pragma unroll
-            for (int cidx = 0; cidx < 4; ++cidx) {
-                const bool in = ok && r < D && 4 * jj4 + cidx <= r;
-                const float a0 = A[in ? base + 4 * jj4 + cidx : 0];
-                e[cidx] = in ? a0 : 0.0f;
-            }
-            v.x = e[0]; v.y = e[1]; v.z = e[2]; v.w = e[3];
-            if (ok) Ash4[GEO::off4(m) + g] = v;
-        }
+    // ---- the factor image, once per launch
+    {
+        mhx_e4 areg[NK][GEO::maxit()];
+        mhx_dense_image_load<D, L>(A, areg);
+        mhx_dense_image_store<D, L>(areg, Ash4);
     }
     __syncthreads();
 
@@ -104,23 +88,7 @@ MHX_DEV void mhx_rwmh_dense_coop_body(const mhx_rwmh_args& a, const float* __res
         }
         MHX_WAVE_SYNC();
         // ---- lp' = -1/2 |A y|^2 + const: rows l, l+L, ... by this lane, butterfly over the chain's lanes
-        const mhx_e4* yrow4 = (const mhx_e4*)yrow;
-        float q = 0.0f;
-#pragma unroll
-        for (int m = 0; m < NK; ++m) {
-            const int r = l + L * m;
-            float w = 0.0f;
-#pragma unroll
-            for (int jj4 = 0; jj4 < GEO::len4(m); ++jj4) {
-                const mhx_e4 av = Ash4[GEO::off4(m) + jj4 * L + l];
-                const mhx_e4 yv = yrow4[jj4];
-                w = mhx_fma(av.x, yv.x, w);
-                w = mhx_fma(av.y, yv.y, w);
-                w = mhx_fma(av.z, yv.z, w);
-                w = mhx_fma(av.w, yv.w, w);
-            }
-            q = r < D ? mhx_fma(w, w, q) : q;
-        }
+        float q = mhx_dense_rows_sq<D, L>(Ash4, (const mhx_e4*)yrow, l);
 #pragma unroll
         for (int off = 1; off < L; off <<= 1) q = q + __shfl_xor(q, off * CPW, 64);
         const float lpy = mhx_fma(-0.5f, q, a.tconst);
