@@ -1,0 +1,122 @@
+"""GPU parity on randomly drawn (but reproducible) configurations: sampler x target x proposal x dimension x chain
+count x schedule, each compared with the oracle bit for bit.  The hand-picked cases elsewhere pin the known edges;
+this sweeps the combinations between them (odd sizes, d = 1, one chain, N = 1, thinning, resumed runs)."""
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b, what):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    bad = np.argwhere(a.view(np.uint32) != b.view(np.uint32)) if a.dtype == np.float32 else np.argwhere(a != b)
+    assert len(bad) == 0, "%s: %d mismatches, first at %s" % (what, len(bad), bad[0])
+
+
+def _schedule(rng):
+    N = int(rng.integers(1, 9))
+    di = int(rng.integers(0, 4))
+    th = int(rng.integers(1, 4))
+    return N, di, th
+
+
+@pytest.mark.parametrize("case", range(60))
+def test_rwmh_random_configurations(mhx, oracle, case):
+    rng = np.random.default_rng(1000 + case)
+    d = int(rng.choice([1, 2, 3, 5, 8, 13, 17, 31, 40, 66, 97]))
+    C = int(rng.choice([1, 2, 7, 63, 64, 65, 130]))
+    N, di, th = _schedule(rng)
+    tname = str(rng.choice(["iso", "corr", "banana", "funnel"])) if d >= 2 else "iso"
+    pname = str(rng.choice(["iso", "diag", "dense"]))
+    static = bool(rng.integers(0, 4) == 0)
+    drift = (not static) and bool(rng.integers(0, 5) == 0)
+    Sig = cases.sigma_ar1(d, 0.5)
+    if tname == "iso":
+        tgt, ot = mhx.IsoGaussian(d), (lambda L: oracle.iso_gauss(d, reduce_lanes=L))
+    elif tname == "corr":
+        tgt, ot = mhx.CorrGaussian(Sig), (lambda L: oracle.corr_gauss_from_cov(Sig, reduce_lanes=L))
+    elif tname == "banana":
+        tgt, ot = mhx.Banana(d, 0.03), (lambda L: oracle.Target(oracle.TARGET_BANANA, d, params=[0.03], reduce_lanes=L))
+    else:
+        tgt, ot = mhx.Funnel(d), (lambda L: oracle.Target(oracle.TARGET_FUNNEL, d, reduce_lanes=L))
+    mean = (rng.normal(size=d) * 0.2).astype(np.float32).astype(np.float64) if (drift or (static and rng.integers(0, 2))) else None
+    mu = mhx.zeros(d) if mean is None else mean
+    if pname == "iso":
+        s = float(np.float32(0.3 + rng.random()))
+        dist, op = mhx.MvNormal(mu, s * s * mhx.I), dict(kind=oracle.PROP_ISO, scale=s)
+    elif pname == "diag":
+        sv = (0.3 + rng.random(d)).astype(np.float32)
+        dist, op = mhx.MvNormal(mu, sv.astype(np.float64) ** 2), dict(kind=oracle.PROP_DIAG, vec=sv)   # a vector of variances
+    else:
+        A = rng.normal(size=(d, d)) * 0.2
+        Sp = A @ A.T + 0.3 * np.eye(d)
+        dist, op = mhx.MvNormal(mu, Sp), dict(kind=oracle.PROP_DENSE, vec=oracle.pack_lower(np.linalg.cholesky(Sp)))
+        if d == 1:
+            op = dict(kind=oracle.PROP_ISO, scale=float(np.float32(np.sqrt(Sp[0, 0]))))
+    spl = mhx.StaticMH(dist) if static else mhx.RWMH(dist)
+    init = None if rng.integers(0, 2) else (rng.normal(size=(d, C)) * 0.5).astype(np.float32)
+    seed, first = int(rng.integers(1, 1 << 40)), int(rng.integers(0, 1 << 33))
+    chain = mhx.sample(mhx.DensityModel(tgt), spl, N, C, seed=seed, first_chain=first, initial_params=init,
+                       discard_initial=di, thinning=th)
+    L = chain.stats["reduce_lanes"]
+    ref = oracle.rwmh(ot(L), oracle.Proposal(mean=mean, static=static, **op), oracle.schedule(N, di, th), seed, first, C, init=init)
+    what = "case %d: d=%d C=%d %s/%s static=%s mean=%s variant=%d L=%d" % (case, d, C, tname, pname, static, mean is not None,
+                                                                        chain.stats["kernel_variant"], L)
+    _same(chain.value, ref["samples"], what)
+    _same(chain.accepted, ref["accepted"], what)
+    x, lp, cnt = chain.state.state()
+    _same(x, ref["final_x"], what)
+    _same(cnt, ref["accept_counts"], what)
+
+
+@pytest.mark.parametrize("case", range(25))
+def test_emcee_random_configurations(mhx, oracle, case):
+    rng = np.random.default_rng(2000 + case)
+    d = int(rng.choice([1, 2, 3, 6, 11, 20, 33, 64, 90]))
+    W = int(rng.choice([2, 3, 10, 65, 128, 131]))
+    N, di, th = _schedule(rng)
+    corr = bool(rng.integers(0, 2)) and d >= 2
+    Sig = cases.sigma_ar1(d, 0.8)
+    tgt, ot = (mhx.CorrGaussian(Sig), lambda L: oracle.corr_gauss_from_cov(Sig, reduce_lanes=L)) if corr else \
+              (mhx.IsoGaussian(d), lambda L: oracle.iso_gauss(d))
+    a = float(np.float32(1.5 + rng.random()))
+    init = cases.emcee_init(d, W, case)
+    seed, ens = int(rng.integers(1, 1 << 40)), int(rng.integers(0, 1000))
+    spl = mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I), a))
+    chain = mhx.sample(mhx.DensityModel(tgt), spl, N, seed=seed, first_chain=ens, initial_params=init, discard_initial=di, thinning=th)
+    L = chain.stats["reduce_lanes"]
+    ref = oracle.emcee(ot(L), a, 1, oracle.schedule(N, di, th), seed, ens, W, init)
+    what = "case %d: d=%d W=%d corr=%s variant=%d L=%d" % (case, d, W, corr, chain.stats["kernel_variant"], L)
+    _same(chain.value, ref["samples"], what)
+    _same(chain.accepted, ref["accepted"], what)
+    x, lp, cnt = chain.state.state()
+    _same(x, ref["final_x"], what)
+    _same(lp, ref["final_lp"], what)
+
+
+@pytest.mark.parametrize("case", range(25))
+def test_ram_random_configurations(mhx, oracle, case):
+    rng = np.random.default_rng(3000 + case)
+    d = int(rng.choice([1, 2, 4, 9, 16, 17, 33, 47, 65, 100]))
+    C = int(rng.choice([1, 3, 4, 5, 9, 33]))
+    N = int(rng.integers(2, 9))
+    warm = int(rng.integers(0, N + 2))
+    corr = bool(rng.integers(0, 2)) and d >= 2
+    Sig = cases.sigma_ar1(d, 0.6)
+    tgt, ot = (mhx.CorrGaussian(Sig), oracle.corr_gauss_from_cov(Sig)) if corr else (mhx.IsoGaussian(d), oracle.iso_gauss(d))
+    bounds = (0.0, float("inf")) if rng.integers(0, 2) else (0.8, 1.3)
+    gamma = float(np.float32(0.51 + 0.4 * rng.random()))
+    init = None if rng.integers(0, 2) else (rng.normal(size=(d, C)) * 0.3).astype(np.float32)
+    seed, first = int(rng.integers(1, 1 << 40)), int(rng.integers(0, 1 << 20))
+    spl = mhx.RobustAdaptiveMetropolis(γ=gamma, eigenvalue_lower_bound=bounds[0], eigenvalue_upper_bound=bounds[1])
+    chain = mhx.sample(mhx.DensityModel(tgt), spl, N, C, seed=seed, first_chain=first, initial_params=init, num_warmup=warm,
+                       discard_initial=0)
+    ref = oracle.ram(ot, oracle.schedule(N, 0, 1, warm), seed, first, C, init=init, gamma=gamma, eig_lo=bounds[0], eig_hi=bounds[1])
+    what = "case %d: d=%d C=%d corr=%s warm=%d bounds=%s" % (case, d, C, corr, warm, bounds)
+    _same(chain.value, ref["samples"], what)
+    S, st = chain.state.factor()
+    _same(S, ref["S"], what)
+    _same(st, ref["status"], what)
