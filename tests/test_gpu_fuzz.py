@@ -120,3 +120,30 @@ def test_ram_random_configurations(mhx, oracle, case):
     S, st = chain.state.factor()
     _same(S, ref["S"], what)
     _same(st, ref["status"], what)
+
+
+@pytest.mark.parametrize("case", range(16))
+def test_mala_random_configurations(mhx, oracle, case):
+    rng = np.random.default_rng(4000 + case)
+    d = int(rng.choice([1, 2, 3, 7, 16, 33, 70]))
+    C = int(rng.choice([1, 3, 64, 65, 200]))
+    N, di, th = _schedule(rng)
+    tname = str(rng.choice(["iso", "corr", "banana", "funnel"])) if d >= 2 else "iso"
+    Sig = cases.sigma_ar1(d, 0.4)
+    if tname == "iso":
+        tgt, ot = mhx.IsoGaussian(d), oracle.iso_gauss(d)
+    elif tname == "corr":
+        tgt, ot = mhx.CorrGaussian(Sig), oracle.corr_gauss_from_cov(Sig)
+    elif tname == "banana":
+        tgt, ot = mhx.Banana(d, 0.03), oracle.Target(oracle.TARGET_BANANA, d, params=[0.03])
+    else:
+        tgt, ot = mhx.Funnel(d), oracle.Target(oracle.TARGET_FUNNEL, d)
+    s2 = float(np.float32(0.05 + 0.3 * rng.random()))
+    init = (rng.normal(size=(d, C)) * 0.4).astype(np.float32)
+    seed, first = int(rng.integers(1, 1 << 40)), int(rng.integers(0, 1 << 20))
+    chain = mhx.sample(mhx.DensityModel(tgt), mhx.MALA(s2), N, C, seed=seed, first_chain=first, initial_params=init,
+                       discard_initial=di, thinning=th)
+    ref = oracle.mala(ot, s2, oracle.schedule(N, di, th), seed, first, C, init)
+    what = "case %d: d=%d C=%d %s" % (case, d, C, tname)
+    _same(chain.value, ref["samples"], what)
+    _same(chain.accepted, ref["accepted"], what)
