@@ -533,6 +533,17 @@ static int rwmh_whiten(mhx_run* r)
 #define MHX_REG_MAX_DIM 160
 #define MHX_REG_MAX_DIM_DENSE 96
 #define MHX_DENSE_COOP_MAX_DIM 128           // the float4 factor image must fit the 64 KB of static LDS
+// lanes per chain of the dense cooperative kernel: at most 12.5 rows of a factor per lane
+static int dense_coop_lanes(int d) { int L = 2; while (2 * d > 25 * L) L *= 2; return L; }
+// do `nimages` factor images plus the candidate rows of a 4-wave block fit the 64 KB of static LDS?
+static bool dense_coop_fits(int d, int L, int nimages)
+{
+    if (L < 2 || L > 64 || (L & (L - 1)) || L > d) return true;      // let the caller report the bad shape
+    long total4 = 0;
+    for (int m = 0; m * L < d; ++m) total4 += (long)((std::min(L * (m + 1), d) + 3) / 4) * L;
+    const long rows = 4L * (64 / L) * (((d + 3) & ~3) + 4) * 4;
+    return nimages * total4 * 16 + rows + 64 <= 65536;
+}
 
 extern "C" int mhx_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, mhx_run** out)
 {
@@ -613,21 +624,24 @@ extern "C" int mhx_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh
             while (L < 64 && (nblk + L - 1) / L > 13) L *= 2;
             while (L < 64 && 2 * L <= nblk && (long)r->n * L / 64 < 2048) L *= 2;
         }
-    } else if (tk == MHX_TARGET_CORR_GAUSS && pk != MHX_PROP_DENSE && !(r->flags & (MHX_FLAG_GENERIC | MHX_FLAG_NO_JIT)) &&
-               d >= 2 && d <= MHX_DENSE_COOP_MAX_DIM && (cfg->reduce_lanes > 1 || (cfg->reduce_lanes == 0 && d >= 16))) {
-        // dense Gaussian target: the cooperative kernel of mhx_rwmh_dense_kernels.h (L lanes per chain, factor image
-        // in LDS).  Lanes per chain by default: at most 12.5 rows of A y per lane (measured at 65 536 chains: d = 32 /
-        // 50 / 64 / 100 / 128 run 1.8e10 / 8.5e9 / 6.8e9 / 2.9e9 / 2.0e9 steps/s; the lane-per-chain register kernel
-        // 1.4e10 / 7.2e9 / 4.9e9 / - / -; more rows per lane than ~16 spill)
-        L = 2;
-        if (cfg->reduce_lanes > 1) L = cfg->reduce_lanes;
-        else while (2 * d > 25 * L) L *= 2;
+    } else if (((tk == MHX_TARGET_CORR_GAUSS) || (tk == MHX_TARGET_ISO_GAUSS && pk == MHX_PROP_DENSE)) &&
+               !(r->flags & (MHX_FLAG_GENERIC | MHX_FLAG_NO_JIT)) && d >= 2 && d <= MHX_DENSE_COOP_MAX_DIM &&
+               (cfg->reduce_lanes > 1 || (cfg->reduce_lanes == 0 && d >= 16)) &&
+               dense_coop_fits(d, cfg->reduce_lanes > 1 ? cfg->reduce_lanes : dense_coop_lanes(d),
+                               (tk == MHX_TARGET_CORR_GAUSS ? 1 : 0) + (pk == MHX_PROP_DENSE ? 1 : 0))) {
+        // a dense factor in play (dense Gaussian target, dense proposal, or both): the cooperative kernel of
+        // mhx_rwmh_dense_kernels.h (L lanes per chain, factor images in LDS).  Lanes per chain by default: at most
+        // 12.5 rows per lane (measured at 65 536 chains, dense target: d = 32 / 50 / 64 / 100 / 128 run 1.8e10 /
+        // 8.5e9 / 6.8e9 / 2.9e9 / 2.0e9 steps/s; the lane-per-chain register kernel 1.4e10 / 7.2e9 / 4.9e9 / - / -;
+        // more rows per lane than ~16 spill)
+        L = cfg->reduce_lanes > 1 ? cfg->reduce_lanes : dense_coop_lanes(d);
         if (L > 64 || (L & (L - 1)) || L > d) return fail(MHX_EINVAL, "reduce_lanes must be a power of two <= min(64, dim), got %d", L);
         jit_module* m = nullptr;
-        const std::string key = "rwmh_dense/d=" + std::to_string(d) + "/l=" + std::to_string(L) + "/pk=" + std::to_string(pk);
+        const std::string key = "rwmh_dense/d=" + std::to_string(d) + "/l=" + std::to_string(L) + "/pk=" + std::to_string(pk) +
+                                "/tk=" + std::to_string(tk);
         rc = jit_compile(ctx, key, jit_source(t, "mhx_rwmh_dense_kernels.h"),
                          {"MHX_JIT_RWMH_DENSE=1", "MHX_JIT_DIM=" + std::to_string(d), "MHX_JIT_L=" + std::to_string(L),
-                          "MHX_JIT_PK=" + std::to_string(pk)}, &m);
+                          "MHX_JIT_PK=" + std::to_string(pk), "MHX_JIT_TK=" + std::to_string(tk)}, &m);
         if (rc == MHX_OK) rc = jit_function(m, "mhx_jit_rwmh_dense", &r->jit_step);
         if (rc == MHX_OK) { r->variant = 5; r->coop_L = L; }
         else if (cfg->reduce_lanes > 1) return rc;

@@ -215,28 +215,37 @@ MHX_DEV void mhx_dense_image_store(const mhx_e4 (&areg)[mhx_emcee_geom<D, L>::NK
         }
     }
 }
-// lane l's share of |A y|^2: rows l, l+L, ... of A y from the LDS image and the candidate row (ascending
-// columns, one fmaf chain per row), summed in ascending row order; the L shares meet in the caller's butterfly
+// rows l, l+L, ... of (lower-triangular image) x (row vector in LDS): ascending columns, one fmaf chain per row
+template <int D, int L>
+MHX_DEV void mhx_dense_rows(const mhx_e4* img4, const mhx_e4* row4, const int l, float (&w)[mhx_emcee_geom<D, L>::NK])
+{
+    typedef mhx_emcee_geom<D, L> GEO;
+#pragma unroll
+    for (int m = 0; m < GEO::NK; ++m) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int jj4 = 0; jj4 < GEO::len4(m); ++jj4) {
+            const mhx_e4 av = img4[GEO::off4(m) + jj4 * L + l];
+            const mhx_e4 yv = row4[jj4];
+            acc = mhx_fma(av.x, yv.x, acc);
+            acc = mhx_fma(av.y, yv.y, acc);
+            acc = mhx_fma(av.z, yv.z, acc);
+            acc = mhx_fma(av.w, yv.w, acc);
+        }
+        w[m] = acc;
+    }
+}
+// lane l's share of |A y|^2: its rows of A y squared and summed in ascending row order; the L shares meet in the
+// caller's butterfly
 template <int D, int L>
 MHX_DEV float mhx_dense_rows_sq(const mhx_e4* Ash4, const mhx_e4* yrow4, const int l)
 {
     typedef mhx_emcee_geom<D, L> GEO;
+    float w[GEO::NK];
+    mhx_dense_rows<D, L>(Ash4, yrow4, l, w);
     float q = 0.0f;
 #pragma unroll
-    for (int m = 0; m < GEO::NK; ++m) {
-        const int r = l + L * m;
-        float w = 0.0f;
-#pragma unroll
-        for (int jj4 = 0; jj4 < GEO::len4(m); ++jj4) {
-            const mhx_e4 av = Ash4[GEO::off4(m) + jj4 * L + l];
-            const mhx_e4 yv = yrow4[jj4];
-            w = mhx_fma(av.x, yv.x, w);
-            w = mhx_fma(av.y, yv.y, w);
-            w = mhx_fma(av.z, yv.z, w);
-            w = mhx_fma(av.w, yv.w, w);
-        }
-        q = r < D ? mhx_fma(w, w, q) : q;
-    }
+    for (int m = 0; m < GEO::NK; ++m) q = (l + L * m) < D ? mhx_fma(w[m], w[m], q) : q;
     return q;
 }
 

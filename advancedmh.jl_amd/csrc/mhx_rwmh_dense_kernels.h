@@ -1,6 +1,6 @@
-// mhx_rwmh_dense_kernels.h -- random-walk Metropolis on the dense Gaussian target (CORR_GAUSS), L lanes per
-// chain, for the dimensions whose fully unrolled lane-per-chain kernel no longer fits (d > 64) and for
-// chain counts that leave a lane-per-chain grid at one wave per SIMD.
+// mhx_rwmh_dense_kernels.h -- random-walk Metropolis with a dense factor in play -- the dense Gaussian target
+// (CORR_GAUSS), a dense (Cholesky) proposal, or both -- L lanes per chain: for the dimensions whose fully unrolled
+// lane-per-chain kernel no longer fits and for chain counts that leave a lane-per-chain grid at one wave per SIMD.
 //
 // Same step as mhx_rwmh_reg_body (src/mh-core.jl:92-117) and the same mat-vec machinery as the cooperative
 // stretch move (mhx_emcee_kernels.h): the packed factor A = inv(chol(Sigma)) sits in LDS as a zero-padded
@@ -14,18 +14,28 @@
 #include "mhx_rwmh_kernels.h"
 #include "mhx_emcee_kernels.h"
 
-template <int D, int L, int PK>
+// TK: MHX_TARGET_CORR_GAUSS (factor image A) or MHX_TARGET_ISO_GAUSS; PK: ISO / DIAG scales, or DENSE -- the
+// proposal's Cholesky factor as a second image: xi = L z is a row product like A y, and y = x + xi.
+template <int D, int L, int PK, int TK>
 MHX_DEV void mhx_rwmh_dense_coop_body(const mhx_rwmh_args& a, const float* __restrict__ A,
-                                      const float* __restrict__ pvec, float* ysh_all, mhx_e4* Ash4)
+                                      const float* __restrict__ pvec, float* ysh_all, mhx_e4* Ash4, mhx_e4* Lsh4)
 {
     typedef mhx_emcee_geom<D, L> GEO;
+    constexpr bool CORR = TK == MHX_TARGET_CORR_GAUSS;
+    constexpr bool DENSEP = PK == MHX_PROP_DENSE;
     constexpr int CPW = 64 / L;                  // chains per wave
     constexpr int NK = GEO::NK, NQ = GEO::NQ, NQL = GEO::NQL, DP4 = GEO::DP4;
-    // ---- the factor image, once per launch
+    // ---- the factor images, once per launch
     {
         mhx_e4 areg[NK][GEO::maxit()];
-        mhx_dense_image_load<D, L>(A, areg);
-        mhx_dense_image_store<D, L>(areg, Ash4);
+        if (CORR) {
+            mhx_dense_image_load<D, L>(A, areg);
+            mhx_dense_image_store<D, L>(areg, Ash4);
+        }
+        if (DENSEP) {
+            mhx_dense_image_load<D, L>(pvec, areg);
+            mhx_dense_image_store<D, L>(areg, Lsh4);
+        }
     }
     __syncthreads();
 
@@ -41,10 +51,11 @@ MHX_DEV void mhx_rwmh_dense_coop_body(const mhx_rwmh_args& a, const float* __res
     const mhx_u32 id_lo = (mhx_u32)id, id_hi = (mhx_u32)(id >> 32);
     const mhx_philox_key ks = mhx_philox_schedule(a.seed);
     float* yrow = ysh_all + (wave * CPW + cw) * DP4;
+    mhx_e4* yrow4 = (mhx_e4*)yrow;
 
     // ---- state: float4 slices l, l+L, ... of x (ABI layout [dim][ld], touched once per launch)
     mhx_e4 xs[NQL];
-    float sc[NQL][4];                            // proposal scales of the owned dimensions (0 in the pad)
+    float sc[NQL][4];                            // ISO / DIAG: scales of the owned dimensions; DENSE: 1 (0 in the pad)
 #pragma unroll
     for (int m = 0; m < NQL; ++m) {
         const int q4 = l + L * m;
@@ -52,8 +63,9 @@ MHX_DEV void mhx_rwmh_dense_coop_body(const mhx_rwmh_args& a, const float* __res
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int k = 4 * q4 + j;
-            e[j] = (q4 < NQ && k < D) ? a.x[(long)k * ld + c] : 0.0f;
-            sc[m][j] = (q4 < NQ && k < D) ? (PK == MHX_PROP_ISO ? a.pscale : pvec[k]) : 0.0f;
+            const bool in = q4 < NQ && k < D;
+            e[j] = in ? a.x[(long)k * ld + c] : 0.0f;
+            sc[m][j] = in ? (PK == MHX_PROP_ISO ? a.pscale : (DENSEP ? 1.0f : pvec[k])) : 0.0f;
         }
         xs[m].x = e[0]; xs[m].y = e[1]; xs[m].z = e[2]; xs[m].w = e[3];
     }
@@ -69,30 +81,69 @@ MHX_DEV void mhx_rwmh_dense_coop_body(const mhx_rwmh_args& a, const float* __res
 
     for (int it = 0; it < a.nsteps; ++it) {
         const mhx_u32 step = a.step0 + (mhx_u32)it;
-        // ---- candidate: y = x + sigma z (src/proposal.jl:49-56); the pad of the row stays zero (scale 0, x 0)
+        // ---- candidate (src/proposal.jl:49-56).  ISO / DIAG: y = fma(sigma, z, x) on the owned slices.  DENSE: the
+        // slices of z go to the chain's LDS row, xi = L z comes back by rows, is handed over through the same row
+        // and y = x + xi.  The pad of every row stays zero (scale 0, x 0).
         mhx_e4 ys[NQL];
 #pragma unroll
         for (int m = 0; m < NQL; ++m) {
             const int q4 = l + L * m;
             const mhx_e4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
             ys[m] = zero4;
-            if (q4 < NQ) {                                               // wave-uniform per m except the last slice
+            if (q4 < NQ) {
                 float n[4];
                 mhx_normal4(ks, id_lo, id_hi, step, MHX_STREAM_PROPOSAL, (mhx_u32)q4, n);
-                ys[m].x = mhx_fma(sc[m][0], n[0], xs[m].x);
-                ys[m].y = mhx_fma(sc[m][1], n[1], xs[m].y);
-                ys[m].z = mhx_fma(sc[m][2], n[2], xs[m].z);
-                ys[m].w = mhx_fma(sc[m][3], n[3], xs[m].w);
+                if (DENSEP) {
+                    ys[m].x = sc[m][0] * n[0]; ys[m].y = sc[m][1] * n[1]; ys[m].z = sc[m][2] * n[2]; ys[m].w = sc[m][3] * n[3];
+                } else {
+                    ys[m].x = mhx_fma(sc[m][0], n[0], xs[m].x);
+                    ys[m].y = mhx_fma(sc[m][1], n[1], xs[m].y);
+                    ys[m].z = mhx_fma(sc[m][2], n[2], xs[m].z);
+                    ys[m].w = mhx_fma(sc[m][3], n[3], xs[m].w);
+                }
             }
-            if (q4 < DP4 / 4) ((mhx_e4*)yrow)[q4] = ys[m];
+            if (q4 < DP4 / 4) yrow4[q4] = ys[m];
         }
         MHX_WAVE_SYNC();
-        // ---- lp' = -1/2 |A y|^2 + const: rows l, l+L, ... by this lane, butterfly over the chain's lanes
-        float q = mhx_dense_rows_sq<D, L>(Ash4, (const mhx_e4*)yrow, l);
+        if (DENSEP) {
+            float xi[NK];
+            mhx_dense_rows<D, L>(Lsh4, yrow4, l, xi);                    // xi_r = sum_{j<=r} L_rj z_j, ascending j
+            MHX_WAVE_SYNC();                                             // every lane has read z
+#pragma unroll
+            for (int m = 0; m < NK; ++m) { const int r = l + L * m; if (r < D) yrow[r] = xi[m]; }
+            MHX_WAVE_SYNC();
+#pragma unroll
+            for (int m = 0; m < NQL; ++m) {
+                const int q4 = l + L * m;
+                if (q4 < NQ) {
+                    const mhx_e4 w4 = yrow4[q4];                          // the pad still holds the zeros of z
+                    ys[m].x = xs[m].x + w4.x; ys[m].y = xs[m].y + w4.y; ys[m].z = xs[m].z + w4.z; ys[m].w = xs[m].w + w4.w;
+                }
+            }
+            MHX_WAVE_SYNC();
+#pragma unroll
+            for (int m = 0; m < NQL; ++m) { const int q4 = l + L * m; if (q4 < NQ) yrow4[q4] = ys[m]; }
+            MHX_WAVE_SYNC();
+        }
+        // ---- lp': dense Gaussian -1/2 |A y|^2 + const (rows l, l+L, ... by this lane); isotropic -1/2 |y|^2 + const
+        // (the lane's slices in ascending order); butterfly over the chain's lanes
+        float q = 0.0f;
+        if (CORR) {
+            q = mhx_dense_rows_sq<D, L>(Ash4, yrow4, l);
+        } else {
+#pragma unroll
+            for (int m = 0; m < NQL; ++m) {
+                const int k = 4 * (l + L * m);
+                if (k + 0 < D) q = mhx_fma(ys[m].x, ys[m].x, q);
+                if (k + 1 < D) q = mhx_fma(ys[m].y, ys[m].y, q);
+                if (k + 2 < D) q = mhx_fma(ys[m].z, ys[m].z, q);
+                if (k + 3 < D) q = mhx_fma(ys[m].w, ys[m].w, q);
+            }
+        }
 #pragma unroll
         for (int off = 1; off < L; off <<= 1) q = q + __shfl_xor(q, off * CPW, 64);
         const float lpy = mhx_fma(-0.5f, q, a.tconst);
-        MHX_WAVE_SYNC();                                             // the row is free for the next candidate
+        MHX_WAVE_SYNC();                                                 // the row is free for the next candidate
         // ---- accept (src/mh-core.jl:104-114); a zero-mean random walk has no Hastings term
         const float logu = mhx_accept_logu(ks, id_lo, id_hi, step, ac);
         const bool acc = logu < (lpy - lp);
@@ -145,7 +196,9 @@ extern "C" __global__ void __launch_bounds__(64 * MHX_EMCEE_COOP_WAVES)
 mhx_jit_rwmh_dense(const mhx_rwmh_args a, const float* __restrict__ tparams, const float* __restrict__ pvec)
 {
     __shared__ mhx_e4 ysh4[MHX_EMCEE_COOP_WAVES * (64 / MHX_JIT_L) * mhx_emcee_geom<MHX_JIT_DIM, MHX_JIT_L>::DP4 / 4];
-    __shared__ mhx_e4 Ash4[mhx_emcee_geom<MHX_JIT_DIM, MHX_JIT_L>::TOTAL4];
-    mhx_rwmh_dense_coop_body<MHX_JIT_DIM, MHX_JIT_L, MHX_JIT_PK>(a, tparams, pvec, (float*)ysh4, Ash4);
+    // one image per factor in use: the target's (dense Gaussian) and the proposal's (dense proposal)
+    __shared__ mhx_e4 Ash4[MHX_JIT_TK == MHX_TARGET_CORR_GAUSS ? mhx_emcee_geom<MHX_JIT_DIM, MHX_JIT_L>::TOTAL4 : 1];
+    __shared__ mhx_e4 Lsh4[MHX_JIT_PK == MHX_PROP_DENSE ? mhx_emcee_geom<MHX_JIT_DIM, MHX_JIT_L>::TOTAL4 : 1];
+    mhx_rwmh_dense_coop_body<MHX_JIT_DIM, MHX_JIT_L, MHX_JIT_PK, MHX_JIT_TK>(a, tparams, pvec, (float*)ysh4, Ash4, Lsh4);
 }
 #endif

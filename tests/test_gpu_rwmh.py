@@ -88,7 +88,8 @@ def test_parallel_sampling_call_forms(mhx):
 
 
 @pytest.mark.parametrize("d,C,lanes,prop", [(100, 70, 0, "iso"), (128, 33, 16, "diag"), (70, 9, 8, "iso"), (5, 37, 2, "diag"),
-                                            (50, 40, 4, "iso"), (99, 17, 32, "diag")])
+                                            (50, 40, 4, "iso"), (99, 17, 32, "diag"), (100, 21, 0, "dense"), (37, 66, 4, "dense"),
+                                            (96, 5, 8, "dense"), (100, 13, 0, "dense_iso_target"), (18, 130, 0, "dense_iso_target")])
 def test_dense_gaussian_target_cooperative_kernel(mhx, oracle, d, C, lanes, prop):
     """RWMH on the dense Gaussian target with L lanes per chain (mhx_rwmh_dense_kernels.h): the default above 64
     dimensions, on request below; ISO and DIAG proposals, random initial states, a schedule with discard and
@@ -96,10 +97,15 @@ def test_dense_gaussian_target_cooperative_kernel(mhx, oracle, d, C, lanes, prop
     import cases
     seed = 77 + d
     Sig = cases.sigma_ar1(d, 0.6)
-    model = mhx.DensityModel(mhx.CorrGaussian(Sig))
+    iso_target = prop.endswith("iso_target")
+    model = mhx.DensityModel(mhx.IsoGaussian(d) if iso_target else mhx.CorrGaussian(Sig))
     if prop == "iso":
         s = float(np.float32(1.7 / d ** 0.5))
         spl, op = mhx.RWMH(mhx.MvNormal(mhx.zeros(d), s * s * mhx.I)), oracle.Proposal(oracle.PROP_ISO, s)
+    elif prop.startswith("dense"):
+        Sp = (1.7 ** 2 / d) * cases.sigma_ar1(d, 0.4)
+        spl = mhx.RWMH(mhx.MvNormal(mhx.zeros(d), Sp))
+        op = oracle.Proposal(oracle.PROP_DENSE, vec=oracle.pack_lower(np.linalg.cholesky(Sp)))
     else:
         sv = (np.float32(1.7 / d ** 0.5) * (0.5 + np.random.default_rng(d).random(d))).astype(np.float32)
         spl, op = mhx.RWMH([mhx.Normal(0.0, float(v)) for v in sv]), oracle.Proposal(oracle.PROP_DIAG, vec=sv)
@@ -109,12 +115,12 @@ def test_dense_gaussian_target_cooperative_kernel(mhx, oracle, d, C, lanes, prop
     p1, a1 = run.samples()
     st = run.stats()
     L = st["reduce_lanes"]
-    assert st["kernel_variant"] == 5 and (L == lanes if lanes else L == 8)      # d = 100: at most 12.5 rows per lane
+    assert st["kernel_variant"] == 5 and (L == lanes if lanes else L == (8 if d == 100 else 2))   # <= 12.5 rows per lane
     run.sample(5, 1, 1, 0)
     p2, a2 = run.samples()
     x, lp, cnt = run.state()
     # the same chain in one go: 3 discarded, 6 samples 2 apart (13 transitions), then 5 more 1 apart
-    ot = oracle.corr_gauss_from_cov(Sig, reduce_lanes=L)
+    ot = oracle.iso_gauss(d, reduce_lanes=L) if iso_target else oracle.corr_gauss_from_cov(Sig, reduce_lanes=L)
     ref = oracle.rwmh(ot, op, oracle.schedule(19, 0, 1), seed, 11, C)
     idx1 = [3 + 2 * i for i in range(6)]
     idx2 = [idx1[-1] + 1 + i for i in range(5)]
