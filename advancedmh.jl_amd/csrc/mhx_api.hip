@@ -434,6 +434,7 @@ struct mhx_run {
     float* d_pvec = nullptr;
     // emcee
     float stretch = 2.0f;
+    size_t dense_lds = 0;                // dynamic LDS bytes of the dense cooperative RWMH kernel
     float* d_xw = nullptr;               // walker-major copy [W][round4(dim)]: the state while the cooperative kernel runs
     float* d_pmean = nullptr;            // drifting walk: mu[dim] then 2 L^-1 mu [dim]
     float* d_qx = nullptr;               // static proposal: logpdf of the proposal at each chain's state (up to its constant)
@@ -532,17 +533,22 @@ static int rwmh_whiten(mhx_run* r)
 
 #define MHX_REG_MAX_DIM 160
 #define MHX_REG_MAX_DIM_DENSE 96
-#define MHX_DENSE_COOP_MAX_DIM 128           // the float4 factor image must fit the 64 KB of static LDS
+#define MHX_DENSE_COOP_MAX_DIM 256
+#define MHX_LDS_PER_BLOCK 163840             // gfx950: 160 KB of LDS, all of it available to one block
 // lanes per chain of the dense cooperative kernel: at most 12.5 rows of a factor per lane
 static int dense_coop_lanes(int d) { int L = 2; while (2 * d > 25 * L) L *= 2; return L; }
-// do `nimages` factor images plus the candidate rows of a 4-wave block fit the 64 KB of static LDS?
+// dynamic LDS of the dense cooperative kernel: the candidate rows of a 4-wave block + `nimages` factor images
+static size_t dense_coop_lds_bytes(int d, int L, int nimages)
+{
+    long total4 = 0;
+    for (int m = 0; m * L < d; ++m) total4 += (long)((std::min(L * (m + 1), d) + 3) / 4) * L;
+    const long rows4 = (long)MHX_EMCEE_COOP_WAVES * (64 / L) * ((((d + 3) & ~3) + 4) / 4);
+    return (size_t)(rows4 + nimages * total4) * 16;
+}
 static bool dense_coop_fits(int d, int L, int nimages)
 {
     if (L < 2 || L > 64 || (L & (L - 1)) || L > d) return true;      // let the caller report the bad shape
-    long total4 = 0;
-    for (int m = 0; m * L < d; ++m) total4 += (long)((std::min(L * (m + 1), d) + 3) / 4) * L;
-    const long rows = 4L * (64 / L) * (((d + 3) & ~3) + 4) * 4;
-    return nimages * total4 * 16 + rows + 64 <= 65536;
+    return dense_coop_lds_bytes(d, L, nimages) <= MHX_LDS_PER_BLOCK;
 }
 
 extern "C" int mhx_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, mhx_run** out)
@@ -643,6 +649,11 @@ extern "C" int mhx_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh
                          {"MHX_JIT_RWMH_DENSE=1", "MHX_JIT_DIM=" + std::to_string(d), "MHX_JIT_L=" + std::to_string(L),
                           "MHX_JIT_PK=" + std::to_string(pk), "MHX_JIT_TK=" + std::to_string(tk)}, &m);
         if (rc == MHX_OK) rc = jit_function(m, "mhx_jit_rwmh_dense", &r->jit_step);
+        if (rc == MHX_OK) {
+            r->dense_lds = dense_coop_lds_bytes(d, L, (tk == MHX_TARGET_CORR_GAUSS ? 1 : 0) + (pk == MHX_PROP_DENSE ? 1 : 0));
+            if (hipFuncSetAttribute((const void*)r->jit_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->dense_lds) != hipSuccess)
+                rc = fail(MHX_EHIP, "dense cooperative kernel: %zu bytes of LDS refused", r->dense_lds);
+        }
         if (rc == MHX_OK) { r->variant = 5; r->coop_L = L; }
         else if (cfg->reduce_lanes > 1) return rc;
         L = 1;                                                        // not the separable cooperative path below
@@ -771,8 +782,8 @@ static int rwmh_advance(mhx_run* r, uint64_t nsteps, uint32_t save_next, int sav
             const long per_block = (64 / r->coop_L) * MHX_EMCEE_COOP_WAVES;          // chains per block
             const unsigned grid = (unsigned)(((long)r->n + per_block - 1) / per_block);
             void* params[] = {&a, &tp, &pv};
-            int rc = launch_module(r->jit_step, grid, 64 * MHX_EMCEE_COOP_WAVES, ctx->stream, params);
-            if (rc) return rc;
+            HIP_TRY(hipModuleLaunchKernel(r->jit_step, grid, 1, 1, 64 * MHX_EMCEE_COOP_WAVES, 1, 1, (unsigned)r->dense_lds,
+                                          ctx->stream, params, nullptr));
         } else if (r->variant == 1) {
             const unsigned grid = (unsigned)((r->n + 63) / 64);
             hipLaunchKernelGGL(r->reg_fn, dim3(grid), dim3(64), 0, ctx->stream, a, tp, pv);

@@ -215,6 +215,52 @@ MHX_DEV void mhx_dense_image_store(const mhx_e4 (&areg)[mhx_emcee_geom<D, L>::NK
         }
     }
 }
+// the whole image, in batches of row sets that keep at most 16 float4 of staging registers per thread (one
+// batch up to d = 128; a persistent kernel pays the extra round trips of a larger image once per launch)
+template <int D, int L>
+MHX_DEV void mhx_dense_image_fill(const float* __restrict__ A, mhx_e4* img4)
+{
+    typedef mhx_emcee_geom<D, L> GEO;
+    constexpr int GB = GEO::maxit() >= 16 ? 1 : 16 / GEO::maxit();          // row sets per batch
+#pragma unroll
+    for (int m0 = 0; m0 < GEO::NK; m0 += GB) {
+        mhx_e4 regs[GB][GEO::maxit()];
+#pragma unroll
+        for (int i = 0; i < GB; ++i) {
+            const int m = m0 + i;
+            if (m < GEO::NK) {
+#pragma unroll
+                for (int it = 0; it < GEO::nit(m); ++it) {
+                    const int g = threadIdx.x + GEO::THREADS * it;
+                    const bool ok = g < GEO::len4(m) * L;
+                    const int gg = ok ? g : 0;
+                    const int jj4 = gg / L, r = gg % L + L * m;
+                    const int base = r < D ? r * (r + 1) / 2 : 0;
+                    float e[4];
+#pragma unroll
+                    for (int cidx = 0; cidx < 4; ++cidx) {
+                        const bool in = ok && r < D && 4 * jj4 + cidx <= r;
+                        const float a0 = A[in ? base + 4 * jj4 + cidx : 0];
+                        e[cidx] = in ? a0 : 0.0f;
+                    }
+                    regs[i][it].x = e[0]; regs[i][it].y = e[1]; regs[i][it].z = e[2]; regs[i][it].w = e[3];
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < GB; ++i) {
+            const int m = m0 + i;
+            if (m < GEO::NK) {
+#pragma unroll
+                for (int it = 0; it < GEO::nit(m); ++it) {
+                    const int g = threadIdx.x + GEO::THREADS * it;
+                    if (g < GEO::len4(m) * L) img4[GEO::off4(m) + g] = regs[i][it];
+                }
+            }
+        }
+    }
+}
+
 // rows l, l+L, ... of (lower-triangular image) x (row vector in LDS): ascending columns, one fmaf chain per row
 template <int D, int L>
 MHX_DEV void mhx_dense_rows(const mhx_e4* img4, const mhx_e4* row4, const int l, float (&w)[mhx_emcee_geom<D, L>::NK])

@@ -26,17 +26,8 @@ MHX_DEV void mhx_rwmh_dense_coop_body(const mhx_rwmh_args& a, const float* __res
     constexpr int CPW = 64 / L;                  // chains per wave
     constexpr int NK = GEO::NK, NQ = GEO::NQ, NQL = GEO::NQL, DP4 = GEO::DP4;
     // ---- the factor images, once per launch
-    {
-        mhx_e4 areg[NK][GEO::maxit()];
-        if (CORR) {
-            mhx_dense_image_load<D, L>(A, areg);
-            mhx_dense_image_store<D, L>(areg, Ash4);
-        }
-        if (DENSEP) {
-            mhx_dense_image_load<D, L>(pvec, areg);
-            mhx_dense_image_store<D, L>(areg, Lsh4);
-        }
-    }
+    if (CORR) mhx_dense_image_fill<D, L>(A, Ash4);
+    if (DENSEP) mhx_dense_image_fill<D, L>(pvec, Lsh4);
     __syncthreads();
 
     const int wave = threadIdx.x >> 6;
@@ -192,13 +183,15 @@ MHX_DEV void mhx_rwmh_dense_coop_body(const mhx_rwmh_args& a, const float* __res
 }
 
 #ifdef MHX_JIT_RWMH_DENSE
+// dynamic LDS (up to 160 KB per block on gfx950): [candidate rows][target image][proposal image]
 extern "C" __global__ void __launch_bounds__(64 * MHX_EMCEE_COOP_WAVES)
 mhx_jit_rwmh_dense(const mhx_rwmh_args a, const float* __restrict__ tparams, const float* __restrict__ pvec)
 {
-    __shared__ mhx_e4 ysh4[MHX_EMCEE_COOP_WAVES * (64 / MHX_JIT_L) * mhx_emcee_geom<MHX_JIT_DIM, MHX_JIT_L>::DP4 / 4];
-    // one image per factor in use: the target's (dense Gaussian) and the proposal's (dense proposal)
-    __shared__ mhx_e4 Ash4[MHX_JIT_TK == MHX_TARGET_CORR_GAUSS ? mhx_emcee_geom<MHX_JIT_DIM, MHX_JIT_L>::TOTAL4 : 1];
-    __shared__ mhx_e4 Lsh4[MHX_JIT_PK == MHX_PROP_DENSE ? mhx_emcee_geom<MHX_JIT_DIM, MHX_JIT_L>::TOTAL4 : 1];
-    mhx_rwmh_dense_coop_body<MHX_JIT_DIM, MHX_JIT_L, MHX_JIT_PK, MHX_JIT_TK>(a, tparams, pvec, (float*)ysh4, Ash4, Lsh4);
+    typedef mhx_emcee_geom<MHX_JIT_DIM, MHX_JIT_L> GEO;
+    extern __shared__ mhx_e4 mhx_dense_lds[];
+    constexpr int YS4 = MHX_EMCEE_COOP_WAVES * (64 / MHX_JIT_L) * GEO::DP4 / 4;
+    mhx_e4* Ash4 = mhx_dense_lds + YS4;
+    mhx_e4* Lsh4 = Ash4 + (MHX_JIT_TK == MHX_TARGET_CORR_GAUSS ? GEO::TOTAL4 : 0);
+    mhx_rwmh_dense_coop_body<MHX_JIT_DIM, MHX_JIT_L, MHX_JIT_PK, MHX_JIT_TK>(a, tparams, pvec, (float*)mhx_dense_lds, Ash4, Lsh4);
 }
 #endif
