@@ -304,8 +304,10 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const float* __restric
     constexpr int DP4 = GEO::DP4;
     // The factor goes to LDS once per block (a lane's row reads are scattered: from LDS, not L2); its loads fly
     // together with the walker rows below: the launch is a chain of memory latencies.
-    mhx_e4 areg[NK][GEO::maxit()];
-    mhx_dense_image_load<D, L>(A, areg);
+    // (images of more than 16 float4 per thread are filled in batches further down instead)
+    constexpr bool ONE_BATCH = NK * GEO::maxit() <= 16;
+    mhx_e4 areg[ONE_BATCH ? NK : 1][GEO::maxit()];
+    if constexpr (ONE_BATCH) mhx_dense_image_load<D, L>(A, areg);
     const int wave = threadIdx.x >> 6;
     float* ysh = ysh_all + wave * (CPW * DP4);
     const int W = a.nwalkers;
@@ -354,7 +356,8 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const float* __restric
         }
         if (q4 < DP4 / 4) ((mhx_e4*)yrow)[q4] = ysl[m];
     }
-    mhx_dense_image_store<D, L>(areg, Ash4);
+    if constexpr (ONE_BATCH) mhx_dense_image_store<D, L>(areg, Ash4);
+    else mhx_dense_image_fill<D, L>(A, Ash4);
     __syncthreads();
     float q = mhx_dense_rows_sq<D, L>(Ash4, (const mhx_e4*)yrow, l);
 #pragma unroll
@@ -403,9 +406,10 @@ extern "C" __global__ void __launch_bounds__(64)
 mhx_jit_emcee_half(const mhx_emcee_args a, const float* __restrict__ tparams)
 {
 #if MHX_JIT_L > 1
-    __shared__ mhx_e4 ysh4[MHX_EMCEE_COOP_WAVES * (64 / MHX_JIT_L) * mhx_emcee_geom<MHX_JIT_DIM, MHX_JIT_L>::DP4 / 4];
-    __shared__ mhx_e4 Ash4[mhx_emcee_geom<MHX_JIT_DIM, MHX_JIT_L>::TOTAL4];
-    mhx_emcee_coop_body<MHX_JIT_DIM, MHX_JIT_L>(a, tparams, (float*)ysh4, Ash4);
+    // dynamic LDS (up to 160 KB per block on gfx950): [candidate rows][factor image]
+    extern __shared__ mhx_e4 mhx_emcee_lds[];
+    constexpr int YS4 = MHX_EMCEE_COOP_WAVES * (64 / MHX_JIT_L) * mhx_emcee_geom<MHX_JIT_DIM, MHX_JIT_L>::DP4 / 4;
+    mhx_emcee_coop_body<MHX_JIT_DIM, MHX_JIT_L>(a, tparams, (float*)mhx_emcee_lds, mhx_emcee_lds + YS4);
 #else
     mhx_emcee_half_body<MHX_JIT_DIM, MHX_JIT_TK>(a, tparams);
 #endif

@@ -85,7 +85,8 @@ def test_emcee_transformed_space(mhx):
     assert abs(chain.mean("m") - 7 / 6) < 0.1
 
 
-@pytest.mark.parametrize("d,W,N,lanes", [(128, 40, 4, 16), (128, 37, 3, 2), (100, 33, 4, 8), (126, 18, 3, 16), (33, 9, 5, 32)])
+@pytest.mark.parametrize("d,W,N,lanes", [(128, 40, 4, 16), (128, 37, 3, 2), (100, 33, 4, 8), (126, 18, 3, 16), (33, 9, 5, 32),
+                                         (200, 21, 3, 16), (256, 10, 3, 32), (190, 12, 3, 64)])
 def test_emcee_cooperative_kernel_large_dimensions(mhx, oracle, d, W, N, lanes):
     """The cooperative kernel at its largest factor images (several float4 of the factor per thread, several
     float4 of a walker per lane), dimensions that are not multiples of 4, odd ensemble sizes, recorded sweeps."""
