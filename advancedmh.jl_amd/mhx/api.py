@@ -378,6 +378,36 @@ class Chains:
     def params(self):
         return [n for n in self.names if n not in self.internals]
 
+    def summarystats(self, max_lag=0):
+        """The table MCMCChains prints for the reference's chains (README.md:59-63): mean, std, ess_bulk, ess_tail
+        and (split) rhat per parameter, computed on the device from the run's sample buffer (mhx_run_diagnostics,
+        mhx_run_ess_bulk_tail); internals (lp) are left out as MCMCChains does."""
+        if self.state is None:
+            raise L.ArgumentError(L.MHX_EINVAL, "summarystats needs the live run (chain.state)")
+        idx = [i for i, n in enumerate(self.names) if n not in self.internals]
+        dg = self.state.diagnostics(max_lag=0, split=True)
+        et = self.state.ess_bulk_tail(params=idx, max_lag=max_lag, split=True)
+        full = self.state.diagnostics(max_lag=0, split=False)
+        std = np.sqrt(np.maximum(full.get("var_plus", full["W"]), 0.0))
+        return dict(parameters=[self.names[i] for i in idx], mean=full["mean"][idx], std=std[idx],
+                    ess_bulk=et["ess_bulk"], ess_tail=et["ess_tail"],
+                    rhat=dg["rhat"][idx] if "rhat" in dg else np.full(len(idx), np.nan))
+
+    def __repr__(self):
+        head = "Chains MCMC chain (%dx%dx%d Array{Float32, 3}), iterations %d:%d:%d" % (
+            self.value.shape[0], self.value.shape[1], self.value.shape[2], self.start, self.thin, self.range()[-1])
+        try:
+            st = self.summarystats()
+        except Exception:
+            return head
+        lines = [head, "  parameters        mean       std   ess_bulk   ess_tail      rhat"]
+        for i, n in enumerate(st["parameters"][:20]):
+            lines.append("  %-12s %9.4f %9.4f %10.1f %10.1f %9.4f" % (n, st["mean"][i], st["std"][i], st["ess_bulk"][i],
+                                                                   st["ess_tail"][i], st["rhat"][i]))
+        if len(st["parameters"]) > 20:
+            lines.append("  ... %d more" % (len(st["parameters"]) - 20))
+        return "\n".join(lines)
+
 
 # ------------------------------------------------------------------------------------------------
 # a live run (what AbstractMCMC's `state` is for the reference)

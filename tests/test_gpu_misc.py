@@ -439,3 +439,19 @@ def test_bulk_and_tail_ess_match_numpy(mhx):
     # a Gaussian target: the bulk ESS agrees with the plain ESS of the same draws
     plain = chain.state.diagnostics(max_lag=120, ess_chains=0, split=True)["ess_geyer"]
     assert (np.abs(got["ess_bulk"][:d] / plain[:d] - 1) < 0.15).all()
+
+
+def test_chains_summary_statistics(mhx):
+    """chain.summarystats(): the MCMCChains table (README.md:59-63) from the device diagnostics; README model."""
+    data = np.load(os.path.join(GOLD, "c1_normal_data.npy"))
+    model = mhx.DensityModel(mhx.IIDNormal(data))
+    chain = mhx.sample(model, mhx.RWMH(mhx.MvNormal(mhx.zeros(2), 0.05 * mhx.I)), 2000, 64, seed=1, discard_initial=500,
+                       param_names=["mu", "sigma"], initial_params=np.array([0.0, 1.0]))
+    st = chain.summarystats()
+    assert st["parameters"] == ["mu", "sigma"]
+    assert abs(st["mean"][0] - data.mean()) < 0.05 and abs(st["mean"][1] - data.std()) < 0.05
+    v = chain.value.astype(np.float64)
+    assert np.allclose(st["std"], v[:, :2, :].std(axis=(0, 2)), rtol=0.02)
+    assert (st["rhat"] < 1.05).all() and (st["ess_bulk"] > 1000).all() and (st["ess_tail"] > 500).all()
+    text = repr(chain)
+    assert "ess_bulk" in text and "mu" in text and "sigma" in text
