@@ -455,3 +455,12 @@ def test_chains_summary_statistics(mhx):
     assert (st["rhat"] < 1.05).all() and (st["ess_bulk"] > 1000).all() and (st["ess_tail"] > 500).all()
     text = repr(chain)
     assert "ess_bulk" in text and "mu" in text and "sigma" in text
+
+
+def test_readme_example_runs():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "examples", "readme_model.py")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "ess_bulk" in out.stdout and "sigma" in out.stdout
