@@ -10,11 +10,13 @@
 // swap.  Same stationary distribution, different Markov kernel -- the oracle implements both
 // (mode 0 sequential, mode 1 split) and the HIP kernel is bit-exact against mode 1.
 //
-// One launch = one half-step; consecutive launches on the stream order the halves.  Walkers are
-// stored [dim][W] (walker fastest): own reads/writes are coalesced, the partner gather is a
-// scattered 4-byte read per dimension served by L2 (16 384 x 50 floats = 3.3 MB).  The cooperative kernel
-// keeps the walkers in a walker-major copy instead ([W][round4(dim)]): a walker and its partner are then
-// one contiguous row each (4 cache lines at d = 50 instead of 50), read and written as float4.
+// One launch = one half-step; consecutive launches on the stream order the halves.  The ABI layout of
+// the walkers is [dim][W] (walker fastest) and the run-time-dimension kernel works on it directly (own
+// accesses coalesced, the partner gather a scattered 4-byte read per dimension).  The compile-time-
+// dimension kernels -- lane per walker in registers, and the cooperative one below -- keep the walkers in
+// a walker-major copy instead ([W][round4(dim)], refreshed from / written back to the ABI layout by the
+// host side): a walker and its partner are then one contiguous row each (4 cache lines at d = 50
+// instead of 50 per partner), read and written as float4.
 #pragma once
 #include "mhx_targets.h"
 
@@ -151,10 +153,12 @@ MHX_DEV void mhx_emcee_init_body(const mhx_emcee_args& a, const float* __restric
 // ---------------------------------------------------------------------------------------------
 // Cooperative stretch move for the dense-Gaussian target: L lanes share one walker (64/L walkers per
 // wave).  A half-step of a 16 384-walker ensemble is only 128 waves of lane-per-walker work, each
-// walking the 1275 entries of inv(chol(Sigma)) serially; with L = 8 it is 1024 waves (one per SIMD)
-// and every lane owns D/L dimensions of the move and D/L rows of A y.  The candidate is exchanged
-// through LDS (broadcast reads within a walker's lane group); the L partial sums of squares meet in
-// an xor-butterfly -- the reduction shape is part of the arithmetic spec (oracle: reduce_lanes = L).
+// walking the 1275 entries of inv(chol(Sigma)) serially; with L = 16 it is 2048 waves (two per SIMD):
+// every lane owns float4 slices of the move and D/L rows of A y.  The candidate is exchanged through
+// LDS (broadcast reads within a walker's lane group); the L partial sums of squares meet in an
+// xor-butterfly -- the reduction shape is part of the arithmetic spec (oracle: reduce_lanes = L).
+// The same image / row-product machinery serves random-walk Metropolis on dense factors
+// (mhx_rwmh_dense_kernels.h).
 #define MHX_EMCEE_COOP_WAVES 4                   // waves per block: they share the LDS copy of the factor
 
 // LDS image of the packed factor for L lanes per walker.  Lane l owns rows l, l+L, ...; row set m
