@@ -56,6 +56,8 @@ if "c4" in which:
     run = mhx.Run(model, mhx.RobustAdaptiveMetropolis(), nchains=C, seed=4)
     run.init(np.zeros(d))
     phases = (("warm-up (adapting)", (200, 200)), ("fixed S", (100, 0)))
+    if os.environ.get("C4_FULL"):                   # 2 000 warm-up + 500 fixed steps
+        phases = (("warm-up (adapting), 2000 steps", (2000, 2000)), ("fixed S, 500 steps", (500, 0)))
     if os.environ.get("C4_ONLY") == "adapt":
         phases = phases[:1]
     for nm, (n, warm) in phases:
