@@ -42,6 +42,8 @@ struct mhx_emcee_args {
     int half;                 // 0: walkers [0, W/2) move; 1: walkers [W/2, W) move
     long save_slot;           // slot to record this sweep into, or -1
     int reduce_lanes;         // lanes per walker (cooperative kernel), >= 1
+    int t_begin, t_count;     // the slice of the moving half this launch moves (an ensemble sharded over GPUs moves
+                              // one slice per rank and exchanges the slices; a single GPU moves [0, size of the half))
 };
 
 typedef float mhx_e4 __attribute__((ext_vector_type(4)));
@@ -57,8 +59,8 @@ MHX_DEV void mhx_emcee_half_body(const mhx_emcee_args& a, const float* __restric
     const int halfW = W / 2;
     const int lo = a.half ? halfW : 0;
     const int cnt = a.half ? W - halfW : halfW;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= cnt) return;
+    const int t = a.t_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= cnt || t >= a.t_begin + a.t_count) return;
     const int i = lo + t;
     const int ostart = a.half ? 0 : halfW;
     const int osize = a.half ? halfW : W - halfW;
@@ -321,8 +323,8 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const float* __restric
     const int lane = threadIdx.x & 63;
     const int cw = lane & (CPW - 1);
     const int l = lane / CPW;
-    const int t_raw = (blockIdx.x * MHX_EMCEE_COOP_WAVES + wave) * CPW + cw;
-    const bool valid = t_raw < cnt;
+    const int t_raw = a.t_begin + (blockIdx.x * MHX_EMCEE_COOP_WAVES + wave) * CPW + cw;
+    const bool valid = t_raw < cnt && t_raw < a.t_begin + a.t_count;
     const int i = lo + (valid ? t_raw : cnt - 1);
     const int ostart = a.half ? 0 : halfW;
     const int osize = a.half ? halfW : W - halfW;

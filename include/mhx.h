@@ -236,6 +236,17 @@ typedef struct {
 int mhx_run_diagnostics(mhx_run *run, const mhx_diag_cfg *cfg, double *sum_m, double *sum_m2,
                         double *sum_v, double *ess /* each [dim+1], any may be NULL */);
 
+/* ---- building blocks of ONE ensemble sharded over several GPUs (src/emcee.jl:14-24, parallel half-split form).
+ * Every rank holds the whole ensemble; for each half h of a sweep every rank moves its own slice
+ * [begin, begin + count) of the moving half with mhx_emcee_half_step and the ranks then exchange the slices (an
+ * all-gather of the walker-major rows and the lp / accept arrays that mhx_emcee_device_state exposes -- device
+ * pointers, valid for the life of the run; pitch = floats per walker row); mhx_emcee_end_sweep advances the RNG
+ * sweep counter after both halves.  Walkers carry their global index in the RNG counter, so any partition moves
+ * exactly the walkers a single GPU would (advancedmh.jl_amd/mhx/dist.py: ShardedEnsemble). */
+int mhx_emcee_half_step(mhx_run *run, int half, int begin, int count);
+int mhx_emcee_end_sweep(mhx_run *run);
+int mhx_emcee_device_state(mhx_run *run, float **xw, int32_t *pitch, float **lp, uint32_t **acc_count, uint8_t **last_acc);
+
 /* Rank-normalised bulk ESS and tail ESS (Vehtari et al. 2021, sections 4.1-4.3; what MCMCChains / ArviZ print as
  * ess_bulk, ess_tail) of the parameters params[0..nparams) (indices into the dim+1 rows, lp = dim) of the sample
  * buffer: the draws of one parameter are sorted on the device, replaced by the normal scores of their ranks (bulk)

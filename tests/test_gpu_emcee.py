@@ -123,3 +123,74 @@ def test_emcee_user_log_density_walker_major_rows(mhx, oracle, d, W):
     _same(x, ref["final_x"], "final x")
     _same(lp, ref["final_lp"], "final lp")
     _same(cnt, ref["accept_counts"], "accept counts")
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("d,W,user", [(50, 100, False), (7, 33, True), (20, 64, False)])
+def test_sharded_ensemble_slices_reproduce_the_single_gpu_run(mhx, oracle, d, W, user, world):
+    """An ensemble sharded over `world` ranks (mhx.dist.ShardedEnsemble): every rank moves one slice of the moving
+    half per half-step.  Emulated on one device -- the slices run one after the other on the same state, which is what
+    the all-gather of the multi-GPU run reconstructs on every rank -- the result must be the oracle's sweep."""
+    from mhx.dist import ShardedEnsemble
+    if user:
+        rng = np.random.default_rng(d)
+        data = np.concatenate([rng.normal(size=d), 0.5 + rng.random(d)]).astype(np.float32)
+        model = mhx.DensityModel(mhx.HipLogDensity(user_targets.SHIFTED_GAUSS, d, data=data))
+        ot = user_targets.host_target(oracle, user_targets.SHIFTED_GAUSS, d, data=data)
+    else:
+        Sig = cases.sigma_ar1(d, 0.8)
+        model = mhx.DensityModel(mhx.CorrGaussian(Sig))
+        ot = None
+    init = cases.emcee_init(d, W, 4)
+    run = mhx.Run(model, mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I))), seed=8, first_chain=5)
+    run.init(init)
+    sh = ShardedEnsemble(run, world=world, exchange=None)
+    sh.sweep(6)
+    x, lp, cnt = run.state()
+    if not user:                                             # the lanes-per-walker choice is the engine's
+        ot = oracle.corr_gauss_from_cov(Sig, reduce_lanes=_lanes_of(mhx, model, W))
+    ref = oracle.emcee(ot, 2.0, 1, oracle.schedule(7), 8, 5, W, init)
+    _same(x, ref["final_x"], "final x")
+    _same(lp, ref["final_lp"], "final lp")
+    _same(cnt, ref["accept_counts"], "accept counts")
+    run.close()
+
+
+def _lanes_of(mhx, model, W):
+    """lanes per walker the engine picks for this model / ensemble size (reported by a throw-away run)"""
+    d = model.dim
+    probe = mhx.Run(model, mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I))), seed=1)
+    probe.init(cases.emcee_init(d, W, 1))
+    probe.sample(2, 0, 1, 0)
+    L = probe.stats()["reduce_lanes"]
+    probe.close()
+    return L
+
+
+def test_sharded_ensemble_over_rccl_single_rank(mhx, oracle):
+    """The collective path of ShardedEnsemble (torch.distributed, backend nccl = RCCL) with the one rank this box has:
+    the device state is wrapped zero-copy and all-gathered in place after every half-step."""
+    torch = pytest.importorskip("torch")
+    import torch.distributed as dist
+    from mhx.dist import ShardedEnsemble
+    d, W = 12, 40
+    Sig = cases.sigma_ar1(d, 0.7)
+    model = mhx.DensityModel(mhx.CorrGaussian(Sig))
+    init = cases.emcee_init(d, W, 6)
+    run = mhx.Run(model, mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I))), seed=3, first_chain=1)
+    run.init(init)
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+    try:
+        sh = ShardedEnsemble(run, rank=0, world=1, exchange="torch")
+        sh.sweep(4)
+    finally:
+        if created:
+            dist.destroy_process_group()
+    x, lp, cnt = run.state()
+    ref = oracle.emcee(oracle.corr_gauss_from_cov(Sig, reduce_lanes=_lanes_of(mhx, model, W)), 2.0, 1, oracle.schedule(5), 3, 1, W, init)
+    _same(x, ref["final_x"], "final x")
+    _same(lp, ref["final_lp"], "final lp")
+    run.close()

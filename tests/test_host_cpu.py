@@ -136,3 +136,19 @@ def test_product_path_never_touches_the_oracle_or_a_cpu_fallback():
     # bench.py may use the oracle only in its cpu_baseline leg
     bench = open(os.path.join(ROOT, "bench.py")).read()
     assert bench.count("from oracle import oracle") == 1 and "def cpu_baseline" in bench
+
+
+def test_sharded_ensemble_slices_partition_a_half():
+    """mhx.dist.ShardedEnsemble.slices: contiguous, equal-sized (last ones possibly shorter or empty), covering the half."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "advancedmh.jl_amd"))
+    from mhx.dist import ShardedEnsemble
+    for cnt in (1, 2, 7, 8, 50, 8192, 8193):
+        for world in (1, 2, 3, 4, 8):
+            sl = ShardedEnsemble.slices(cnt, world)
+            assert len(sl) == world and sum(c for _, c in sl) == cnt
+            pos = 0
+            for b, c in sl:
+                assert c >= 0 and (c == 0 or b == pos)
+                pos += c
+            assert max(c for _, c in sl) == (cnt + world - 1) // world
