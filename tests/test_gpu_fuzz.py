@@ -147,3 +147,39 @@ def test_mala_random_configurations(mhx, oracle, case):
     what = "case %d: d=%d C=%d %s" % (case, d, C, tname)
     _same(chain.value, ref["samples"], what)
     _same(chain.accepted, ref["accepted"], what)
+
+
+def test_dimensions_beyond_the_specialised_kernels(mhx, oracle):
+    """Sizes past every specialised kernel's range fall back to the cooperative / run-time-dimension / generic kernels
+    and stay bit-exact: RWMH d = 4000 (64 lanes per chain), emcee d = 300 (isotropic and dense target), RAM d = 1024,
+    MALA d = 500, RWMH on a dense target at d = 300."""
+    def same(a, b, what):
+        _same(a, b, what)
+    d, C = 4000, 96
+    s = float(np.float32(2.38 / d ** 0.5))
+    ch = mhx.sample(mhx.DensityModel(mhx.IsoGaussian(d)), mhx.RWMH(mhx.MvNormal(mhx.zeros(d), s * s * mhx.I)), 4, C, seed=3)
+    L = ch.stats["reduce_lanes"]
+    assert L == 64
+    same(ch.value, oracle.rwmh(oracle.iso_gauss(d, reduce_lanes=L), oracle.Proposal(oracle.PROP_ISO, s), oracle.schedule(4), 3, 0, C)["samples"], "rwmh d=4000")
+    d, W = 300, 500
+    init = cases.emcee_init(d, W, 1)
+    spl = mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I)))
+    ch = mhx.sample(mhx.DensityModel(mhx.IsoGaussian(d)), spl, 3, seed=2, initial_params=init)
+    same(ch.value, oracle.emcee(oracle.iso_gauss(d), 2.0, 1, oracle.schedule(3), 2, 0, W, init)["samples"], "emcee d=300")
+    Sig = cases.sigma_ar1(d, 0.5)
+    ch = mhx.sample(mhx.DensityModel(mhx.CorrGaussian(Sig)), spl, 3, seed=2, initial_params=init)
+    assert ch.stats["kernel_variant"] == 0
+    same(ch.value, oracle.emcee(oracle.corr_gauss_from_cov(Sig), 2.0, 1, oracle.schedule(3), 2, 0, W, init)["samples"], "emcee dense d=300")
+    ch = mhx.sample(mhx.DensityModel(mhx.CorrGaussian(Sig)), mhx.RWMH(mhx.MvNormal(mhx.zeros(d), 0.01 * mhx.I)), 4, 40, seed=7)
+    assert ch.stats["kernel_variant"] == 0
+    same(ch.value, oracle.rwmh(oracle.corr_gauss_from_cov(Sig), oracle.Proposal(oracle.PROP_ISO, float(np.float32(0.1))),
+                               oracle.schedule(4), 7, 0, 40)["samples"], "rwmh dense d=300")
+    d, C = 1024, 6
+    ch = mhx.sample(mhx.DensityModel(mhx.IsoGaussian(d)), mhx.RobustAdaptiveMetropolis(), 4, C, seed=5, num_warmup=4, initial_params=np.zeros(d))
+    ref = oracle.ram(oracle.iso_gauss(d), oracle.schedule(4, 4, 1, 4), 5, 0, C, init=np.zeros((d, C), dtype=np.float32))
+    same(ch.value, ref["samples"], "ram d=1024")
+    same(ch.state.factor()[0], ref["S"], "ram d=1024 factor")
+    d, C = 500, 100
+    init = (np.random.default_rng(1).normal(size=(d, C)) * 0.1).astype(np.float32)
+    ch = mhx.sample(mhx.DensityModel(mhx.IsoGaussian(d)), mhx.MALA(0.01), 4, C, seed=6, initial_params=init)
+    same(ch.value, oracle.mala(oracle.iso_gauss(d), 0.01, oracle.schedule(4), 6, 0, C, init)["samples"], "mala d=500")
