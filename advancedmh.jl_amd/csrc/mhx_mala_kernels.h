@@ -210,6 +210,94 @@ MHX_DEV void mhx_mala_body(const mhx_mala_args& a, const float* __restrict__ tpa
         atomicAdd(a.acc_total, (mhx_u64)wave_acc);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Compile-time dimension D (hiprtc): x, grad(x), the candidate, its gradient and the noise all live in
+// registers (5 D floats per lane) for the steps of a launch; HBM sees the state once per launch and the
+// recorded samples.  Same arithmetic as mhx_mala_body, statement for statement.
+template <int D>
+struct mhx_reg_rw {
+    float* v;                                        // a lane-private array that full unrolling turns into registers
+    MHX_DEV float operator[](int k) const { return v[k]; }
+    MHX_DEV void set(int k, float x) const { v[k] = x; }
+};
+
+template <int D, int TK>
+MHX_DEV void mhx_mala_reg_body(const mhx_mala_args& a, const float* __restrict__ tparams)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.nchains) return;
+    const mhx_u64 id = a.first_chain + (mhx_u64)c;
+    const mhx_u32 id_lo = (mhx_u32)id, id_hi = (mhx_u32)(id >> 32);
+    const mhx_philox_key ks = mhx_philox_schedule(a.seed);
+    const long ld = a.ld;
+    float x[D], g[D], y[D], gyv[D], z[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) { x[k] = a.x[(long)k * ld + c]; g[k] = a.gx[(long)k * ld + c]; }
+    mhx_reg_rw<D> gy;
+    gy.v = gyv;
+    float lp = a.lp[c];
+    mhx_u32 nacc = a.acc_count[c];
+    mhx_u32 wave_acc = 0;
+    bool last = a.last_acc[c] != 0;
+    mhx_accept_cache ac;
+    ac.group = 0xffffffffu;
+    ac.w.x = ac.w.y = ac.w.z = ac.w.w = 0u;
+    mhx_u32 save_next = a.save_next;
+    long slot = a.save_slot;
+    constexpr int nblk = (D + 3) >> 2;
+
+    for (int it = 0; it < a.nsteps; ++it) {
+        const mhx_u32 step = a.step0 + (mhx_u32)it;
+        float fwd = 0.0f;
+#pragma unroll
+        for (int b = 0; b < nblk; ++b) {
+            float n[4];
+            mhx_normal4(ks, id_lo, id_hi, step, MHX_STREAM_PROPOSAL, (mhx_u32)b, n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 4 * b + j;
+                if (k < D) {
+                    z[k] = n[j];
+                    y[k] = mhx_fma(a.sigma, n[j], mhx_fma(a.h, g[k], x[k]));      // src/MALA.jl:70
+                    fwd = mhx_fma(n[j], n[j], fwd);
+                }
+            }
+        }
+        const float lpy = mhx_target_grad<TK>(TK, y, gy, D, tparams, a.ntparams, a.tconst);   // :73-75
+        float bwd = 0.0f;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const float tk = mhx_fma(a.hs, g[k] + gyv[k], z[k]);
+            bwd = mhx_fma(tk, tk, bwd);
+        }
+        const float loga = (lpy - lp) + 0.5f * (fwd - bwd);              // :78-83
+        const float logu = mhx_accept_logu(ks, id_lo, id_hi, step, ac);
+        const bool acc = logu < loga;                                    // :86 (strict)
+#pragma unroll
+        for (int k = 0; k < D; ++k) { x[k] = acc ? y[k] : x[k]; g[k] = acc ? gyv[k] : g[k]; }
+        lp = acc ? lpy : lp;
+        nacc += acc ? 1u : 0u;
+        last = acc;
+        wave_acc += (mhx_u32)__popcll(__ballot(acc));
+        if (step == save_next) {
+            float* row = a.samples + slot * (long)(D + 1) * ld + c;
+#pragma unroll
+            for (int k = 0; k < D; ++k) row[(long)k * ld] = x[k];
+            row[(long)D * ld] = lp;
+            a.accepted[slot * ld + c] = acc ? 1 : 0;
+            save_next += (mhx_u32)a.thinning;
+            ++slot;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < D; ++k) { a.x[(long)k * ld + c] = x[k]; a.gx[(long)k * ld + c] = g[k]; }
+    a.lp[c] = lp;
+    a.acc_count[c] = nacc;
+    a.last_acc[c] = last ? 1 : 0;
+    if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u)
+        atomicAdd(a.acc_total, (mhx_u64)wave_acc);
+}
+
 // initial GradientTransition (src/MALA.jl:38-40): lp and gradient at the given initial_params
 template <int TK>
 MHX_DEV void mhx_mala_init_body(const mhx_mala_args& a, const float* __restrict__ tparams, const int reset_counts)
@@ -230,7 +318,11 @@ MHX_DEV void mhx_mala_init_body(const mhx_mala_args& a, const float* __restrict_
 extern "C" __global__ void __launch_bounds__(256)
 mhx_jit_mala(const mhx_mala_args a, const float* __restrict__ tparams)
 {
+#if MHX_JIT_DIM > 0
+    mhx_mala_reg_body<MHX_JIT_DIM, MHX_JIT_TK>(a, tparams);
+#else
     mhx_mala_body<MHX_JIT_TK>(a, tparams);
+#endif
 }
 extern "C" __global__ void __launch_bounds__(256)
 mhx_jit_mala_init(const mhx_mala_args a, const float* __restrict__ tparams, const int reset_counts)
