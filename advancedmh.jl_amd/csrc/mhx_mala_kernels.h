@@ -7,8 +7,9 @@
 //   accept iff -randexp < lp(y) - lp(x) + logratio
 // The gradient the reference gets from ForwardDiff / LogDensityProblems (ext/AdvancedMHForwardDiffExt.jl,
 // src/MALA.jl:100-105) is analytic here for the catalogue targets, and supplied as HIP source
-// (MHX_LOGDENSITY_AND_GRADIENT) for user models.  State x and grad(x) live in HBM as [dim][nchains]
-// (chain fastest, coalesced); candidate, its gradient and the noise go through scratch slabs.
+// (MHX_LOGDENSITY_AND_GRADIENT) for user models.  Run-time dimension: state x and grad(x) live in HBM as
+// [dim][nchains] (chain fastest, coalesced); candidate, its gradient and the noise go through scratch slabs.
+// Compile-time dimension (hiprtc, d <= 48): all five vectors are registers (mhx_mala_reg_body).
 #pragma once
 #include "mhx_targets.h"
 
