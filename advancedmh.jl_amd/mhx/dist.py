@@ -107,7 +107,9 @@ class ShardedEnsemble:
         import torch.distributed as dist
         per = sl[0][1]
         t = self._tensors()
-        torch.cuda.synchronize()
+        on_gpu = t["xw"].is_cuda
+        if on_gpu:
+            torch.cuda.synchronize()
         for name in ("xw", "lp", "acc", "last"):
             full = t[name][lo:lo + cnt]
             if per * self.world == cnt:                      # equal slices: gather straight into the state
@@ -120,4 +122,5 @@ class ShardedEnsemble:
                 out = torch.empty((per * self.world,) + tuple(full.shape[1:]), dtype=full.dtype, device=full.device)
                 dist.all_gather_into_tensor(out, piece, group=self.group)
                 full.copy_(out[:cnt])
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()

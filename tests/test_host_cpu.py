@@ -93,6 +93,62 @@ def _rank_main(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _gather_rank_main(rank, world, port, q):
+    """Each rank changes its own slice of the moving half of a fake ensemble state (CPU tensors standing in for the
+    device state) and runs ShardedEnsemble's exchange; afterwards every rank must hold all the slices."""
+    import sys
+    import torch
+    import torch.distributed as dist
+    for p in (ROOT, os.path.join(ROOT, "advancedmh.jl_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from mhx.dist import ShardedEnsemble
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    W, P = 23, 8                                           # odd ensemble: halves of 11 and 12, ragged slices
+    sh = ShardedEnsemble.__new__(ShardedEnsemble)
+    sh.rank, sh.world, sh.group, sh.W, sh.pitch = rank, world, None, W, P
+    sh._t = dict(xw=torch.zeros(W, P), lp=torch.zeros(W), acc=torch.zeros(W, dtype=torch.int32), last=torch.zeros(W, dtype=torch.uint8))
+    for h in (0, 1):
+        lo, cnt = (W // 2, W - W // 2) if h else (0, W // 2)
+        sl = ShardedEnsemble.slices(cnt, world)
+        b, c = sl[rank]
+        for w in range(lo + b, lo + b + c):                  # "move" the walkers of this rank's slice
+            sh._t["xw"][w] = float(100 * (rank + 1) + w)
+            sh._t["lp"][w] = float(-w)
+            sh._t["acc"][w] = w + 1
+            sh._t["last"][w] = 1
+        sh._all_gather(lo, cnt, sl)
+    q.put((rank, sh._t["xw"][:, 0].tolist(), sh._t["lp"].tolist(), sh._t["acc"].tolist(), sh._t["last"].tolist()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_ensemble_exchange_gloo(world):
+    """The all-gather of mhx.dist.ShardedEnsemble on gloo with 2 and 3 ranks, equal and ragged slices."""
+    import torch.multiprocessing as mp
+    from mhx.dist import ShardedEnsemble
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_rank_main, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    W = 23
+    owner = np.zeros(W, dtype=int)
+    for h in (0, 1):
+        lo, cnt = (W // 2, W - W // 2) if h else (0, W // 2)
+        for r, (b, c) in enumerate(ShardedEnsemble.slices(cnt, world)):
+            owner[lo + b:lo + b + c] = r
+    want_x = [float(100 * (owner[w] + 1) + w) for w in range(W)]
+    for rank, x0, lp, acc, last in res:
+        assert x0 == want_x and lp == [float(-w) for w in range(W)]
+        assert acc == [w + 1 for w in range(W)] and last == [1] * W
+
+
 def test_two_rank_statistics_allreduce_gloo(oracle):
     """world_size 2 on gloo: per-shard sums all-reduced == the single-process result over all chains."""
     import torch.multiprocessing as mp
