@@ -1031,6 +1031,88 @@ extern "C" int mhx_run_set_state(mhx_run* r, const float* x)
     return r->kind == RUN_RWMH ? rwmh_whiten(r) : MHX_OK;
 }
 
+// ---- checkpoint / resume: the complete state of a run as one host blob ------------------------------------------
+struct ckpt_header {
+    uint32_t magic, version;
+    int32_t kind, dim, n, pad;
+    uint64_t tau, seed, first_id;
+};
+static const uint32_t k_ckpt_magic = 0x5848484du;          // "MHXX"
+struct ckpt_part { void* dev; size_t bytes; };
+// the device arrays that make up the state, in blob order
+static std::vector<ckpt_part> ckpt_parts(mhx_run* r)
+{
+    const size_t n = (size_t)r->n, d = (size_t)r->dim;
+    std::vector<ckpt_part> p = {{r->d_x, d * n * sizeof(float)}, {r->d_lp, n * sizeof(float)},
+                                {r->d_acc, n * sizeof(uint32_t)}, {r->d_last, n}};
+    if (r->kind == RUN_RAM) {
+        const size_t trip = (size_t)mhx_ram_tri_pad(r->dim);
+        p.push_back({r->d_S, 2 * trip * n * sizeof(float)});
+        p.push_back({r->d_Ssel, n});
+        p.push_back({r->d_status, n});
+        p.push_back({r->d_dmin, d * n * sizeof(float)});
+        p.push_back({r->d_dmax, d * n * sizeof(float)});
+    }
+    if (r->kind == RUN_MALA) p.push_back({r->d_gx, d * n * sizeof(float)});
+    if (r->d_qx) p.push_back({r->d_qx, n * sizeof(float)});
+    return p;
+}
+extern "C" int mhx_run_state_size(mhx_run* r, size_t* bytes)
+{
+    if (!r || !bytes) return fail(MHX_EINVAL, "mhx_run_state_size: NULL argument");
+    size_t total = sizeof(ckpt_header);
+    for (const auto& p : ckpt_parts(r)) total += p.bytes;
+    *bytes = total;
+    return MHX_OK;
+}
+extern "C" int mhx_run_save_state(mhx_run* r, void* blob, size_t bytes)
+{
+    if (!r || !blob) return fail(MHX_EINVAL, "mhx_run_save_state: NULL argument");
+    if (!r->initialised) return fail(MHX_ESTATE, "mhx_run_save_state: run is not initialised");
+    size_t need = 0;
+    mhx_run_state_size(r, &need);
+    if (bytes < need) return fail(MHX_EINVAL, "mhx_run_save_state: the blob holds %zu bytes, the state needs %zu", bytes, need);
+    HIP_TRY(hipSetDevice(r->ctx->device));
+    if (r->kind == RUN_EMCEE) { int rc = emcee_sync_state(r, 1); if (rc) return rc; }      // walker-major -> ABI layout
+    HIP_TRY(hipStreamSynchronize(r->ctx->stream));
+    ckpt_header h = {k_ckpt_magic, 1u, (int32_t)r->kind, r->dim, r->n, 0, r->tau, r->seed, r->first_id};
+    char* out = (char*)blob;
+    memcpy(out, &h, sizeof h);
+    out += sizeof h;
+    for (const auto& p : ckpt_parts(r)) {
+        HIP_TRY(hipMemcpy(out, p.dev, p.bytes, hipMemcpyDeviceToHost));
+        out += p.bytes;
+    }
+    return MHX_OK;
+}
+extern "C" int mhx_run_load_state(mhx_run* r, const void* blob, size_t bytes)
+{
+    if (!r || !blob) return fail(MHX_EINVAL, "mhx_run_load_state: NULL argument");
+    size_t need = 0;
+    mhx_run_state_size(r, &need);
+    ckpt_header h;
+    if (bytes < sizeof h) return fail(MHX_EINVAL, "mhx_run_load_state: the blob is too short");
+    memcpy(&h, blob, sizeof h);
+    if (h.magic != k_ckpt_magic || h.version != 1u) return fail(MHX_EINVAL, "mhx_run_load_state: not a state blob of this library");
+    if (h.kind != (int32_t)r->kind || h.dim != r->dim || h.n != r->n || bytes < need)
+        return fail(MHX_EINVAL, "mhx_run_load_state: the blob is a state of sampler kind %d, dim %d, %d chains (%zu bytes); "
+                                "this run is kind %d, dim %d, %d chains (%zu bytes)", h.kind, h.dim, h.n, bytes, (int)r->kind, r->dim, r->n, need);
+    HIP_TRY(hipSetDevice(r->ctx->device));
+    const char* in = (const char*)blob + sizeof h;
+    for (const auto& p : ckpt_parts(r)) {
+        HIP_TRY(hipMemcpy(p.dev, in, p.bytes, hipMemcpyHostToDevice));
+        in += p.bytes;
+    }
+    // the counter-based streams continue where the saved run stopped: same seed, same global ids, same step counter
+    r->seed = h.seed; r->first_id = h.first_id; r->tau = h.tau;
+    r->initialised = true;
+    r->n_saved = 0;
+    HIP_TRY(hipMemsetAsync(r->d_acc_total, 0, sizeof(unsigned long long), r->ctx->stream));
+    if (r->kind == RUN_EMCEE) { int rc = emcee_sync_state(r, 0); if (rc) return rc; }      // ABI layout -> walker-major
+    HIP_TRY(hipStreamSynchronize(r->ctx->stream));
+    return MHX_OK;
+}
+
 extern "C" int mhx_run_stats(mhx_run* r, mhx_stats* out)
 {
     if (!r || !out) return fail(MHX_EINVAL, "mhx_run_stats: NULL argument");

@@ -76,7 +76,7 @@ EXPORTS = [
     "mhx_ram_get_diag_range", "mhx_run_init", "mhx_run_sample", "mhx_run_get_samples",
     "mhx_run_get_state", "mhx_run_set_state", "mhx_run_stats", "mhx_run_device_samples",
     "mhx_run_destroy", "mhx_run_diagnostics", "mhx_run_ess_bulk_tail", "mhx_emcee_half_step", "mhx_emcee_end_sweep",
-    "mhx_emcee_device_state",
+    "mhx_emcee_device_state", "mhx_run_state_size", "mhx_run_save_state", "mhx_run_load_state",
 ]
 
 _lib = None
@@ -115,6 +115,9 @@ def lib():
         L.mhx_run_device_samples.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int64)]
         L.mhx_run_destroy.argtypes = [vp]
         L.mhx_run_diagnostics.argtypes = [vp, C.POINTER(DiagCfg), dp, dp, dp, dp]
+        L.mhx_run_state_size.argtypes = [vp, C.POINTER(C.c_size_t)]
+        L.mhx_run_save_state.argtypes = [vp, C.c_void_p, C.c_size_t]
+        L.mhx_run_load_state.argtypes = [vp, C.c_void_p, C.c_size_t]
         L.mhx_emcee_half_step.argtypes = [vp, C.c_int, C.c_int, C.c_int]
         L.mhx_emcee_end_sweep.argtypes = [vp]
         L.mhx_emcee_device_state.argtypes = [vp, C.POINTER(fp), C.POINTER(C.c_int32), C.POINTER(fp), C.POINTER(u32p), C.POINTER(u8p)]

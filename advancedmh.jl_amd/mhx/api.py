@@ -554,6 +554,20 @@ class Run:
         out.update(combine_diagnostics(out["sum_m"], out["sum_m2"], out["sum_v"], out["n_chains"], out["n_samples"]))
         return out
 
+    def save_state(self):
+        """The complete state of the run as bytes (checkpoint; upstream's `state` of step / `initial_state`)."""
+        nb = C.c_size_t()
+        L.check(L.lib().mhx_run_state_size(self.h, C.byref(nb)))
+        buf = np.empty(nb.value, dtype=np.uint8)
+        L.check(L.lib().mhx_run_save_state(self.h, buf.ctypes.data_as(C.c_void_p), nb.value))
+        return buf.tobytes()
+
+    def load_state(self, blob):
+        """Continue a saved run: same sampler, model, dim and chain count; seed, global ids and the RNG step counter come
+        from the blob, so the continuation is the uninterrupted run bit for bit."""
+        buf = np.frombuffer(blob, dtype=np.uint8)
+        L.check(L.lib().mhx_run_load_state(self.h, buf.ctypes.data_as(C.c_void_p), buf.size))
+
     def ess_bulk_tail(self, params=None, max_lag=0, ess_chains=256, split=True):
         """Rank-normalised bulk ESS and tail ESS (Vehtari et al. 2021; MCMCChains' ess_bulk / ess_tail) of the given
         parameter rows (default: all, lp included) of the last sample buffer, sorted and scored on the device.

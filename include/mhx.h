@@ -194,6 +194,16 @@ int mhx_run_get_samples(mhx_run *run, float *samples, uint8_t *accepted);
 int mhx_run_get_state(mhx_run *run, float *x, float *lp, uint32_t *accept_counts);
 int mhx_run_set_state(mhx_run *run, const float *x /* lp is recomputed */);
 
+/* Checkpoint / resume -- the `state` half of AbstractMCMC's (sample, state) = step(...) and of upstream's
+ * `initial_state` keyword (src/mh-core.jl:92-117, src/emcee.jl:14-24, src/RobustAdaptiveMetropolis.jl:99-114): the
+ * complete state of a run -- positions, cached log-densities, accept bookkeeping, the RNG step counter with its
+ * seed and global ids, and per sampler the RAM factors / selectors / diagonal ranges, the MALA gradients, the
+ * static proposal's log-densities -- as one host blob.  A run created with the same sampler, model, dim and chain
+ * count continues the saved one bit for bit after mhx_run_load_state (its own seed / first_chain are replaced). */
+int mhx_run_state_size(mhx_run *run, size_t *bytes);
+int mhx_run_save_state(mhx_run *run, void *blob, size_t bytes);
+int mhx_run_load_state(mhx_run *run, const void *blob, size_t bytes);
+
 typedef struct {
     uint64_t transitions;      /* chain-steps executed by the last mhx_run_sample (all chains)         */
     uint64_t accepted;         /* accepted proposals among them (wavefront ballot + popcount reduction) */

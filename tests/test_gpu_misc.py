@@ -464,3 +464,60 @@ def test_readme_example_runs():
     out = subprocess.run([sys.executable, os.path.join(root, "examples", "readme_model.py")], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "ess_bulk" in out.stdout and "sigma" in out.stdout
+
+
+@pytest.mark.parametrize("kind", ["rwmh_coop", "rwmh_dense", "rwmh_static", "emcee_coop", "emcee_user", "ram", "mala"])
+def test_checkpoint_and_resume(mhx, kind):
+    """mhx_run_save_state / mhx_run_load_state: a NEW run (created with another seed) that loads the blob continues the
+    saved run bit for bit -- samples, accept flags, final state, RAM factors."""
+    d, C = (40, 70) if kind != "emcee_user" else (6, 30)
+    Sig = cases.sigma_ar1(d, 0.5)
+    init = None
+    if kind == "rwmh_coop":
+        model, spl = mhx.DensityModel(mhx.IsoGaussian(d)), mhx.RWMH(mhx.MvNormal(mhx.zeros(d), 0.1 * mhx.I))
+    elif kind == "rwmh_dense":
+        model, spl = mhx.DensityModel(mhx.CorrGaussian(Sig)), mhx.RWMH(mhx.MvNormal(mhx.zeros(d), 0.05 * Sig))
+    elif kind == "rwmh_static":
+        model, spl = mhx.DensityModel(mhx.CorrGaussian(Sig)), mhx.StaticMH(mhx.MvNormal(mhx.zeros(d), 1.2 * mhx.I))
+    elif kind == "emcee_coop":
+        model, spl = mhx.DensityModel(mhx.CorrGaussian(Sig)), mhx.Ensemble(C, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I)))
+        init = cases.emcee_init(d, C, 3)
+    elif kind == "emcee_user":
+        data = np.concatenate([np.zeros(d), np.ones(d)]).astype(np.float32)
+        model = mhx.DensityModel(mhx.HipLogDensity(user_targets.SHIFTED_GAUSS, d, data=data))
+        spl = mhx.Ensemble(C, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I)))
+        init = cases.emcee_init(d, C, 3)
+    elif kind == "ram":
+        model, spl = mhx.DensityModel(mhx.CorrGaussian(Sig)), mhx.RobustAdaptiveMetropolis()
+        init = np.zeros((d, C), dtype=np.float32)
+    else:
+        model, spl = mhx.DensityModel(mhx.CorrGaussian(Sig)), mhx.MALA(0.05)
+        init = np.zeros((d, C), dtype=np.float32)
+    warm = 30 if kind == "ram" else 0                        # the warm-up spans the checkpoint
+
+    def new_run(seed):
+        return mhx.Run(model, spl, nchains=C, seed=seed, first_chain=4)
+
+    a = new_run(11)
+    a.init(init)
+    a.sample(5, 2, 1, warm)
+    blob = a.save_state()
+    a.sample(7, 1, 2, max(0, warm - 6))
+    want, want_acc = a.samples()
+    want_state = a.state()
+    b = new_run(999)                                         # another seed: the blob's takes over
+    b.load_state(blob)
+    b.sample(7, 1, 2, max(0, warm - 6))
+    got, got_acc = b.samples()
+    _same(got, want, "samples after the checkpoint")
+    _same(got_acc, want_acc, "accept flags")
+    for u, v, what in zip(b.state(), want_state, ("x", "lp", "accept counts")):
+        _same(u, v, what)
+    if kind == "ram":
+        _same(b.factor()[0], a.factor()[0], "factors")
+        _same(b.diag_range()[0], a.diag_range()[0], "diag min")
+    with pytest.raises(mhx.ArgumentError):                   # a blob of another shape is refused
+        other = mhx.Run(mhx.DensityModel(mhx.IsoGaussian(3)), mhx.RWMH(3), nchains=2, seed=1)
+        other.load_state(blob)
+    a.close()
+    b.close()
