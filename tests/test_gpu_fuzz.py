@@ -8,6 +8,9 @@ import cases
 
 pytestmark = pytest.mark.gpu
 
+import os
+SEED_OFFSET = int(os.environ.get("MHX_FUZZ_SEED", "0"))          # another slice of the configuration space per value
+
 
 def _same(a, b, what):
     a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
@@ -25,7 +28,7 @@ def _schedule(rng):
 
 @pytest.mark.parametrize("case", range(60))
 def test_rwmh_random_configurations(mhx, oracle, case):
-    rng = np.random.default_rng(1000 + case)
+    rng = np.random.default_rng(1000 + case + 100000 * SEED_OFFSET)
     d = int(rng.choice([1, 2, 3, 5, 8, 13, 17, 31, 40, 66, 97]))
     C = int(rng.choice([1, 2, 7, 63, 64, 65, 130]))
     N, di, th = _schedule(rng)
@@ -54,8 +57,6 @@ def test_rwmh_random_configurations(mhx, oracle, case):
         A = rng.normal(size=(d, d)) * 0.2
         Sp = A @ A.T + 0.3 * np.eye(d)
         dist, op = mhx.MvNormal(mu, Sp), dict(kind=oracle.PROP_DENSE, vec=oracle.pack_lower(np.linalg.cholesky(Sp)))
-        if d == 1:
-            op = dict(kind=oracle.PROP_ISO, scale=float(np.float32(np.sqrt(Sp[0, 0]))))
     spl = mhx.StaticMH(dist) if static else mhx.RWMH(dist)
     init = None if rng.integers(0, 2) else (rng.normal(size=(d, C)) * 0.5).astype(np.float32)
     seed, first = int(rng.integers(1, 1 << 40)), int(rng.integers(0, 1 << 33))
@@ -74,7 +75,7 @@ def test_rwmh_random_configurations(mhx, oracle, case):
 
 @pytest.mark.parametrize("case", range(25))
 def test_emcee_random_configurations(mhx, oracle, case):
-    rng = np.random.default_rng(2000 + case)
+    rng = np.random.default_rng(2000 + case + 100000 * SEED_OFFSET)
     d = int(rng.choice([1, 2, 3, 6, 11, 20, 33, 64, 90]))
     W = int(rng.choice([2, 3, 10, 65, 128, 131]))
     N, di, th = _schedule(rng)
@@ -99,7 +100,7 @@ def test_emcee_random_configurations(mhx, oracle, case):
 
 @pytest.mark.parametrize("case", range(25))
 def test_ram_random_configurations(mhx, oracle, case):
-    rng = np.random.default_rng(3000 + case)
+    rng = np.random.default_rng(3000 + case + 100000 * SEED_OFFSET)
     d = int(rng.choice([1, 2, 4, 9, 16, 17, 33, 47, 65, 100]))
     C = int(rng.choice([1, 3, 4, 5, 9, 33]))
     N = int(rng.integers(2, 9))
@@ -124,7 +125,7 @@ def test_ram_random_configurations(mhx, oracle, case):
 
 @pytest.mark.parametrize("case", range(16))
 def test_mala_random_configurations(mhx, oracle, case):
-    rng = np.random.default_rng(4000 + case)
+    rng = np.random.default_rng(4000 + case + 100000 * SEED_OFFSET)
     d = int(rng.choice([1, 2, 3, 7, 16, 33, 70]))
     C = int(rng.choice([1, 3, 64, 65, 200]))
     N, di, th = _schedule(rng)
