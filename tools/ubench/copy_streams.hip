@@ -75,6 +75,42 @@ __global__ void __launch_bounds__(64) k_stream_dma(const f4* __restrict__ in, f4
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 }
+// write-only: what the sample recorder of the RWMH kernel asks of HBM (one-shot flat float4 stores)
+__global__ void __launch_bounds__(256) k_fill(f4* __restrict__ out, long n4)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const f4 v = {1.0f, 2.0f, 3.0f, (float)i};
+    if (i < n4) out[i] = v;
+}
+// the recorder's own shape: a wave writes 128-byte row segments, rows `ld` floats apart
+__global__ void __launch_bounds__(256) k_fill_rows(float* __restrict__ out, int rows, long ld)
+{
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;               // chain
+    for (int r = 0; r < rows; ++r) out[(long)r * ld + c] = (float)r;
+}
+static void run_fill(f4* out, long n4)
+{
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const int grid = (int)((n4 + 255) / 256);
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(k_fill, dim3(grid), dim3(256), 0, 0, out, n4);
+    hipEventRecord(e0);
+    const int reps = 10;
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_fill, dim3(grid), dim3(256), 0, 0, out, n4);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("write-only flat float4 fill          %.1f GB/s\n", (double)n4 * 16.0 * reps / (ms * 1e-3) / 1e9);
+    const long ld = 65536; const int rows = (int)(n4 * 4 / ld);
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(k_fill_rows, dim3(ld / 256), dim3(256), 0, 0, (float*)out, rows, ld);
+    hipEventRecord(e0);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_fill_rows, dim3(ld / 256), dim3(256), 0, 0, (float*)out, rows, ld);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("write-only rows of 65536 floats, a lane per column   %.1f GB/s\n", (double)rows * ld * 4.0 * reps / (ms * 1e-3) / 1e9);
+}
+
 template <int NV>
 static void run_dma(f4* in, f4* out, int nseg, int nvec, long stride4)
 {
@@ -147,6 +183,7 @@ int main()
     run_dma<1>(in, out, nseg, nvec, stride4);
     run_dma<2>(in, out, nseg, nvec, stride4);
     run_dma<4>(in, out, nseg, nvec, stride4);
+    run_fill(out, (long)nseg * stride4);
     run_flat(in, out, (long)nseg * stride4, 2048);
     run_flat(in, out, (long)nseg * stride4, 8192);
     run_flat(in, out, (long)nseg * stride4, (int)(((long)nseg * stride4 + 255) / 256));
