@@ -50,6 +50,14 @@ static int fail(int code, const char* fmt, ...)
                         __LINE__);                                                                  \
     } while (0)
 
+// Every copy that touches run / target state goes through the context's stream (created non-blocking: the null stream
+// does not order against it) and is waited for, so that all accesses to device state are ordered on ONE stream.
+#define COPY_SYNC(stream, dst, src, bytes, kind)                                                    \
+    do {                                                                                            \
+        HIP_TRY(hipMemcpyAsync((dst), (src), (bytes), (kind), (stream)));                           \
+        HIP_TRY(hipStreamSynchronize(stream));                                                      \
+    } while (0)
+
 extern "C" int mhx_version(void) { return MHX_VERSION; }
 extern "C" const char* mhx_last_error(void) { return g_err.c_str(); }
 
@@ -267,7 +275,7 @@ static int target_upload(mhx_target* t, const float* params, size_t nparams)
     // one dummy element keeps the pointer valid for kinds without parameters
     const size_t n = nparams ? nparams : 1;
     HIP_TRY(hipMalloc(&t->dparams, n * sizeof(float)));
-    if (nparams) HIP_TRY(hipMemcpy(t->dparams, params, nparams * sizeof(float), hipMemcpyHostToDevice));
+    if (nparams) COPY_SYNC(t->ctx->stream, t->dparams, params, nparams * sizeof(float), hipMemcpyHostToDevice);
     else HIP_TRY(hipMemsetAsync(t->dparams, 0, sizeof(float), t->ctx->stream));
     return MHX_OK;
 }
@@ -392,7 +400,7 @@ extern "C" int mhx_target_eval(mhx_ctx* ctx, const mhx_target* t, const float* x
     HIP_TRY(hipMalloc(&dlp, (size_t)n * sizeof(float)));
     int rc = MHX_OK;
     do {
-        if (hipMemcpy(dx, x, nx * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { rc = fail(MHX_EHIP, "H2D copy failed"); break; }
+        if (hipMemcpyAsync(dx, x, nx * sizeof(float), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { rc = fail(MHX_EHIP, "H2D copy failed"); break; }
         const unsigned grid = (unsigned)((n + 255) / 256);
         int d = t->dim, kind = t->kind, np = t->nparams, lanes = 1;
         float cst = t->cst;
@@ -408,7 +416,7 @@ extern "C" int mhx_target_eval(mhx_ctx* ctx, const mhx_target* t, const float* x
             hipLaunchKernelGGL(k_target_eval, dim3(grid), dim3(256), 0, ctx->stream, dx, dlp, n, d, kind, tp, np, cst, lanes);
         }
         if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) { rc = fail(MHX_EHIP, "target_eval kernel failed"); break; }
-        if (hipMemcpy(lp, dlp, (size_t)n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(MHX_EHIP, "D2H copy failed"); break; }
+        if (hipMemcpyAsync(lp, dlp, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = fail(MHX_EHIP, "D2H copy failed"); break; }
     } while (0);
     (void)hipFree(dx);
     (void)hipFree(dlp);
@@ -575,7 +583,7 @@ extern "C" int mhx_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh
     r->flags = cfg->flags;
     r->prop_kind = cfg->proposal_kind; r->prop_scale = cfg->proposal_scale;
     HIP_TRY(hipMalloc(&r->d_pvec, (nvec ? nvec : 1) * sizeof(float)));
-    if (nvec) HIP_TRY(hipMemcpy(r->d_pvec, cfg->proposal_vec, nvec * sizeof(float), hipMemcpyHostToDevice));
+    if (nvec) COPY_SYNC(ctx->stream, r->d_pvec, cfg->proposal_vec, nvec * sizeof(float), hipMemcpyHostToDevice);
     int rc = run_alloc_state(r.get());
     if (rc) return rc;
     // drifting random walk: keep mu and 2 L^-1 mu (double arithmetic on the host, rounded once) and use the
@@ -600,7 +608,7 @@ extern "C" int mhx_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh
             pm[(size_t)d + i] = (float)(2.0 * m[i]);
         }
         HIP_TRY(hipMalloc(&r->d_pmean, pm.size() * sizeof(float)));
-        HIP_TRY(hipMemcpy(r->d_pmean, pm.data(), pm.size() * sizeof(float), hipMemcpyHostToDevice));
+        COPY_SYNC(ctx->stream, r->d_pmean, pm.data(), pm.size() * sizeof(float), hipMemcpyHostToDevice);
         if (cfg->reduce_lanes > 1) return fail(MHX_EINVAL, "a drifting random walk runs on the generic kernel: reduce_lanes must be 0 or 1");
         r->flags |= MHX_FLAG_GENERIC;
     }
@@ -881,7 +889,7 @@ extern "C" int mhx_run_sample(mhx_run* r, const mhx_schedule* s, int save_sample
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(ctx->stream));
         }
-        HIP_TRY(hipMemcpy(out, r->d_acc_total, sizeof *out, hipMemcpyDeviceToHost));
+        COPY_SYNC(r->ctx->stream, out, r->d_acc_total, sizeof *out, hipMemcpyDeviceToHost);
         return MHX_OK;
     };
     unsigned long long acc_before = 0;
@@ -929,6 +937,8 @@ extern "C" int mhx_run_sample(mhx_run* r, const mhx_schedule* s, int save_sample
         r->n_saved = s->n_samples;
         if (s->discard_initial == 0) {
             // sample 1 is the current state itself (test/runtests.jl:203-213: chain[1].params == initial_params)
+            // an ensemble on the register / cooperative kernels lives in its walker-major copy: bring d_x up to date
+            if (r->kind == RUN_EMCEE) { int rcs = emcee_sync_state(r, 1); if (rcs) return rcs; }
             const unsigned grid = (unsigned)((r->n + 255) / 256);
             hipLaunchKernelGGL(k_record_state, dim3(grid), dim3(256), 0, ctx->stream, r->d_x, r->d_lp, r->d_last,
                                r->d_samples, r->d_accepted, r->n, (long)r->n, r->dim, 0L);
@@ -971,8 +981,8 @@ extern "C" int mhx_run_get_samples(mhx_run* r, float* samples, uint8_t* accepted
         return fail(MHX_ESTATE, "mhx_run_get_samples: the last mhx_run_sample kept no sample tensor");
     HIP_TRY(hipSetDevice(r->ctx->device));
     const size_t N = (size_t)r->n_saved, n = (size_t)r->n, d1 = (size_t)r->dim + 1;
-    if (samples) HIP_TRY(hipMemcpy(samples, r->d_samples, N * d1 * n * sizeof(float), hipMemcpyDeviceToHost));
-    if (accepted) HIP_TRY(hipMemcpy(accepted, r->d_accepted, N * n, hipMemcpyDeviceToHost));
+    if (samples) COPY_SYNC(r->ctx->stream, samples, r->d_samples, N * d1 * n * sizeof(float), hipMemcpyDeviceToHost);
+    if (accepted) COPY_SYNC(r->ctx->stream, accepted, r->d_accepted, N * n, hipMemcpyDeviceToHost);
     return MHX_OK;
 }
 
@@ -992,9 +1002,9 @@ extern "C" int mhx_run_get_state(mhx_run* r, float* x, float* lp, uint32_t* acce
     HIP_TRY(hipSetDevice(r->ctx->device));
     const size_t n = (size_t)r->n, d = (size_t)r->dim;
     if (x && r->kind == RUN_EMCEE) { int rc = emcee_sync_state(r, 1); if (rc) return rc; }
-    if (x) HIP_TRY(hipMemcpy(x, r->d_x, d * n * sizeof(float), hipMemcpyDeviceToHost));
-    if (lp) HIP_TRY(hipMemcpy(lp, r->d_lp, n * sizeof(float), hipMemcpyDeviceToHost));
-    if (accept_counts) HIP_TRY(hipMemcpy(accept_counts, r->d_acc, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (x) COPY_SYNC(r->ctx->stream, x, r->d_x, d * n * sizeof(float), hipMemcpyDeviceToHost);
+    if (lp) COPY_SYNC(r->ctx->stream, lp, r->d_lp, n * sizeof(float), hipMemcpyDeviceToHost);
+    if (accept_counts) COPY_SYNC(r->ctx->stream, accept_counts, r->d_acc, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
     return MHX_OK;
 }
 
@@ -1005,7 +1015,7 @@ extern "C" int mhx_run_set_state(mhx_run* r, const float* x)
     mhx_ctx* ctx = r->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t n = (size_t)r->n, d = (size_t)r->dim;
-    HIP_TRY(hipMemcpy(r->d_x, x, d * n * sizeof(float), hipMemcpyHostToDevice));
+    COPY_SYNC(r->ctx->stream, r->d_x, x, d * n * sizeof(float), hipMemcpyHostToDevice);
     if (r->kind == RUN_EMCEE) { int rc = emcee_sync_state(r, 0); if (rc) return rc; }
     if (r->kind == RUN_MALA) return mala_eval_state(r, 0);   // src/MALA.jl:27-35: lp and gradient are recomputed
     // lp is a cache of logdensity(model, x) (src/AdvancedMH.jl:75): recompute it
@@ -1034,8 +1044,12 @@ extern "C" int mhx_run_set_state(mhx_run* r, const float* x)
 // ---- checkpoint / resume: the complete state of a run as one host blob ------------------------------------------
 struct ckpt_header {
     uint32_t magic, version;
-    int32_t kind, dim, n, pad;
+    int32_t kind, dim, n, flags;
     uint64_t tau, seed, first_id;
+    // what fixes the arithmetic of the continuation: the log-density, the proposal family, the kernel variant and
+    // the lanes per chain (summation order of lp); and the exact payload size
+    int32_t target_kind, prop_kind, variant, coop_L;
+    uint64_t payload_bytes;
 };
 static const uint32_t k_ckpt_magic = 0x5848484du;          // "MHXX"
 struct ckpt_part { void* dev; size_t bytes; };
@@ -1075,12 +1089,13 @@ extern "C" int mhx_run_save_state(mhx_run* r, void* blob, size_t bytes)
     HIP_TRY(hipSetDevice(r->ctx->device));
     if (r->kind == RUN_EMCEE) { int rc = emcee_sync_state(r, 1); if (rc) return rc; }      // walker-major -> ABI layout
     HIP_TRY(hipStreamSynchronize(r->ctx->stream));
-    ckpt_header h = {k_ckpt_magic, 1u, (int32_t)r->kind, r->dim, r->n, 0, r->tau, r->seed, r->first_id};
+    ckpt_header h = {k_ckpt_magic, 2u, (int32_t)r->kind, r->dim, r->n, r->flags & MHX_FLAG_STATIC_PROPOSAL, r->tau, r->seed, r->first_id,
+                     r->target->kind, r->prop_kind, r->variant, r->coop_L, (uint64_t)(need - sizeof(ckpt_header))};
     char* out = (char*)blob;
     memcpy(out, &h, sizeof h);
     out += sizeof h;
     for (const auto& p : ckpt_parts(r)) {
-        HIP_TRY(hipMemcpy(out, p.dev, p.bytes, hipMemcpyDeviceToHost));
+        COPY_SYNC(r->ctx->stream, out, p.dev, p.bytes, hipMemcpyDeviceToHost);
         out += p.bytes;
     }
     return MHX_OK;
@@ -1093,14 +1108,20 @@ extern "C" int mhx_run_load_state(mhx_run* r, const void* blob, size_t bytes)
     ckpt_header h;
     if (bytes < sizeof h) return fail(MHX_EINVAL, "mhx_run_load_state: the blob is too short");
     memcpy(&h, blob, sizeof h);
-    if (h.magic != k_ckpt_magic || h.version != 1u) return fail(MHX_EINVAL, "mhx_run_load_state: not a state blob of this library");
-    if (h.kind != (int32_t)r->kind || h.dim != r->dim || h.n != r->n || bytes < need)
+    if (h.magic != k_ckpt_magic || h.version != 2u) return fail(MHX_EINVAL, "mhx_run_load_state: not a state blob of this library version");
+    if (h.kind != (int32_t)r->kind || h.dim != r->dim || h.n != r->n || bytes != need || h.payload_bytes != need - sizeof h)
         return fail(MHX_EINVAL, "mhx_run_load_state: the blob is a state of sampler kind %d, dim %d, %d chains (%zu bytes); "
                                 "this run is kind %d, dim %d, %d chains (%zu bytes)", h.kind, h.dim, h.n, bytes, (int)r->kind, r->dim, r->n, need);
+    if (h.flags != (r->flags & MHX_FLAG_STATIC_PROPOSAL) || h.target_kind != r->target->kind || h.prop_kind != r->prop_kind ||
+        h.variant != r->variant || h.coop_L != r->coop_L)
+        return fail(MHX_EINVAL, "mhx_run_load_state: the blob was saved by a different configuration (target kind %d, proposal kind %d, "
+                                "static %d, kernel variant %d, %d lane(s) per chain; this run: %d, %d, %d, %d, %d) -- the continuation "
+                                "would not be the saved chain", h.target_kind, h.prop_kind, h.flags, h.variant, h.coop_L,
+                    r->target->kind, r->prop_kind, r->flags & MHX_FLAG_STATIC_PROPOSAL, r->variant, r->coop_L);
     HIP_TRY(hipSetDevice(r->ctx->device));
     const char* in = (const char*)blob + sizeof h;
     for (const auto& p : ckpt_parts(r)) {
-        HIP_TRY(hipMemcpy(p.dev, in, p.bytes, hipMemcpyHostToDevice));
+        COPY_SYNC(r->ctx->stream, p.dev, in, p.bytes, hipMemcpyHostToDevice);
         in += p.bytes;
     }
     // the counter-based streams continue where the saved run stopped: same seed, same global ids, same step counter

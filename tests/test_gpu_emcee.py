@@ -46,6 +46,27 @@ def test_emcee_corr_gauss_bit_exact(mhx, oracle, d, W, N, flags_name, lanes):
         assert chain.stats["kernel_variant"] == (4 if Lx > 1 else 2)
 
 
+@pytest.mark.parametrize("lanes", [1, 0])
+def test_emcee_continued_call_records_the_live_state(mhx, oracle, lanes):
+    """mhx_run_sample continues the chains: sample(5, 0) then sample(5, 0) on the register / cooperative kernels, whose
+    live state is the walker-major copy -- slot 0 of the second call is the ensemble as the first call left it."""
+    d, W = 20, 48
+    Sig = cases.sigma_ar1(d, 0.8)
+    init = cases.emcee_init(d, W, 9)
+    model = mhx.DensityModel(mhx.CorrGaussian(Sig))
+    run = mhx.Run(model, mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I))), seed=5, first_chain=1, reduce_lanes=lanes)
+    run.init(init)
+    run.sample(5, 0)
+    first, _ = run.samples()
+    run.sample(5, 0)
+    second, acc2 = run.samples()
+    ref = oracle.emcee(oracle.corr_gauss_from_cov(Sig, reduce_lanes=run.stats()["reduce_lanes"]), 2.0, 1, oracle.schedule(9), 5, 1, W, init)
+    _same(first, ref["samples"][:5], "first call")
+    _same(second, ref["samples"][4:], "second call (slot 0 = the state the first call ended in)")
+    _same(acc2[1:], ref["accepted"][5:], "accept flags")
+    run.close()
+
+
 def test_emcee_golden_trace(mhx):
     tr = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "traces.npz"))
     d, W = 3, 10

@@ -187,3 +187,27 @@ def test_ram_user_log_density(mhx, oracle, d):
     _same(chain.value, ref["samples"], "samples")
     _same(S, ref["S"], "S")
     _same(cnt, ref["accept_counts"], "accept counts")
+
+
+def test_ram_refused_factor_leaves_the_run_untouched(mhx, oracle):
+    """mhx_ram_set_factor validates before it touches the run: after MHX_ENOTPD the chains continue exactly as the
+    oracle's uninterrupted run (chains whose current factor sits in buffer 1 keep it)."""
+    import ctypes as C
+    d, Cn = 6, 40
+    Sig = cases.sigma_ar1(d, 0.7)
+    model = mhx.DensityModel(mhx.CorrGaussian(Sig))
+    run = mhx.Run(model, mhx.RobustAdaptiveMetropolis(), nchains=Cn, seed=17)
+    init = np.zeros((d, Cn), dtype=np.float32)
+    run.init(init)
+    run.sample(1, 15, 1, 15)                                 # 15 adapting transitions: selectors now differ per chain
+    bad = np.tile(np.eye(d, dtype=np.float32)[np.tril_indices(d)], (Cn, 1))
+    bad[7, 0] = -1.0
+    from mhx import _lib as L
+    rc = L.lib().mhx_ram_set_factor(run.h, L.fptr(L.f32(bad)))
+    assert rc == L.MHX_ENOTPD
+    run.sample(1, 10, 1, 10)
+    ref = oracle.ram(oracle.corr_gauss_from_cov(Sig), oracle.schedule(1, 25, 1, 25), 17, 0, Cn, init=init)
+    got, _ = run.samples()
+    assert np.array_equal(got.view(np.uint32), ref["samples"].view(np.uint32))
+    assert np.array_equal(run.factor()[0].view(np.uint32), ref["S"].view(np.uint32))
+    run.close()

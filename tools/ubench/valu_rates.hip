@@ -49,6 +49,22 @@ KERNEL(k_cndmask, UDECL, REP8(CND), USINK)
 #define ACCW(i) asm volatile("v_accvgpr_write_b32 a" #i ", %0\n v_accvgpr_read_b32 %0, a" #i : "+v"(a##i) : : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7");
 KERNEL(k_acc_wr_rd, UDECL, REP8(ACCW), USINK)
 
+// fp64 (the reference computes in Float64): the f64 engine's VALU ceiling comes from these
+#define DDECL double a0 = seed, a1 = seed + 1, a2 = seed + 2, a3 = seed + 3, a4 = seed + 4, a5 = seed + 5, a6 = seed + 6, a7 = seed + 7; double b = 1.0001 + threadIdx.x, c = 0.5;
+#define DSINK if (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 == 12345.0) out[1000000] = 1;
+#define FMA64(i) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(a##i) : "v"(b), "v"(c));
+KERNEL(k_fma64, DDECL, REP8(FMA64), DSINK)
+#define MUL64(i) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(a##i) : "v"(b));
+KERNEL(k_mul64, DDECL, REP8(MUL64), DSINK)
+#define ADD64(i) asm volatile("v_add_f64 %0, %0, %1" : "+v"(a##i) : "v"(b));
+KERNEL(k_add64, DDECL, REP8(ADD64), DSINK)
+#define RCP64(i) asm volatile("v_rcp_f64 %0, %0" : "+v"(a##i));
+KERNEL(k_rcp64, DDECL, REP8(RCP64), DSINK)
+#define SQRT64(i) asm volatile("v_sqrt_f64 %0, %0" : "+v"(a##i));
+KERNEL(k_sqrt64, DDECL, REP8(SQRT64), DSINK)
+#define RSQ64(i) asm volatile("v_rsq_f64 %0, %0" : "+v"(a##i));
+KERNEL(k_rsq64, DDECL, REP8(RSQ64), DSINK)
+
 // 64-bit products need register pairs: use plain C++ with an opaque barrier instead
 __global__ void __launch_bounds__(64) k_mad_u64(unsigned long long* out, unsigned seed)
 {
@@ -114,7 +130,7 @@ template <class K> static void run(const char* name, K k, int nblocks, unsigned 
 int main()
 {
     unsigned long long* d_out; hipMalloc(&d_out, 8 * 1000001);
-    for (int nb : {1024, 2048, 4096}) {
+    for (int nb : {1024, 2048, 4096, 8192}) {
         printf("--- %d waves (%d per SIMD)\n", nb, nb / 1024);
         run("v_fma_f32", k_fma, nb, d_out);
         run("v_fmaak_f32", k_fmaak, nb, d_out);
@@ -126,6 +142,12 @@ int main()
         run("v_mul_hi_u32", k_mul_hi, nb, d_out);
         run("v_mul_u32_u24", k_mul_u24, nb, d_out);
         run("mad_u64+xor", k_mad_u64, nb, d_out);
+        run("v_fma_f64", k_fma64, nb, d_out);
+        run("v_mul_f64", k_mul64, nb, d_out);
+        run("v_add_f64", k_add64, nb, d_out);
+        run("v_rcp_f64", k_rcp64, nb, d_out);
+        run("v_sqrt_f64", k_sqrt64, nb, d_out);
+        run("v_rsq_f64", k_rsq64, nb, d_out);
         run("v_sqrt_f32", k_sqrt, nb, d_out);
         run("v_cvt_f32_u32", k_cvt, nb, d_out);
         run("v_cndmask", k_cndmask, nb, d_out);
