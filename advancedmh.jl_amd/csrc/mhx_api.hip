@@ -26,27 +26,13 @@
 #include "mhx_rwmh_dense_kernels.h"
 #include "mhx_diag_kernels.h"
 #include "mhx_jit_embed.inc"   // generated: the device headers as string literals for hiprtc
-
-// ---------------------------------------------------------------------------------------------
-// errors
-static thread_local std::string g_err;
-
-static int fail(int code, const char* fmt, ...)
-{
-    char buf[2048];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    g_err = buf;
-    return code;
-}
+#include "mhx_impl.h"           // the prototypes of this instantiation (api_*), shared with the dispatcher mhx_abi.cpp
 
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                            \
         hipError_t e_ = (expr);                                                                     \
         if (e_ != hipSuccess)                                                                       \
-            return fail(MHX_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,  \
+            return mhx_fail(MHX_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,  \
                         __LINE__);                                                                  \
     } while (0)
 
@@ -58,50 +44,48 @@ static int fail(int code, const char* fmt, ...)
         HIP_TRY(hipStreamSynchronize(stream));                                                      \
     } while (0)
 
-extern "C" int mhx_version(void) { return MHX_VERSION; }
-extern "C" const char* mhx_last_error(void) { return g_err.c_str(); }
+namespace MHX_NS {
 
 // ---------------------------------------------------------------------------------------------
 // pre-built kernels (hipcc, gfx950)
 template <int D, int TK, int PK>
 __global__ void __launch_bounds__(64)
-k_rwmh_reg(const mhx_rwmh_args a, const float* __restrict__ tparams, const float* __restrict__ pvec)
+k_rwmh_reg(const mhx_rwmh_args a, const mhx_real* __restrict__ tparams, const mhx_real* __restrict__ pvec)
 {
     mhx_rwmh_reg_body<D, TK, PK>(a, tparams, pvec);
 }
 __global__ void __launch_bounds__(256)
-k_rwmh_generic(const mhx_rwmh_args a, const float* __restrict__ tparams, const float* __restrict__ pvec)
+k_rwmh_generic(const mhx_rwmh_args a, const mhx_real* __restrict__ tparams, const mhx_real* __restrict__ pvec)
 {
     mhx_rwmh_generic_body<MHX_TARGET_DYNAMIC>(a, tparams, pvec);
 }
 __global__ void __launch_bounds__(256)
-k_rwmh_init(const mhx_rwmh_args a, const float* __restrict__ tparams, const float* __restrict__ pvec, const int draw)
+k_rwmh_init(const mhx_rwmh_args a, const mhx_real* __restrict__ tparams, const mhx_real* __restrict__ pvec, const int draw)
 {
     mhx_rwmh_init_body<MHX_TARGET_DYNAMIC>(a, tparams, pvec, draw);
 }
 __global__ void __launch_bounds__(256)
-k_target_eval(const float* __restrict__ x, float* __restrict__ lp, const int n, const int d, const int kind,
-              const float* __restrict__ tparams, const int ntparams, const float tconst, const int lanes)
+k_target_eval(const mhx_real* __restrict__ x, mhx_real* __restrict__ lp, const int n, const int d, const int kind,
+              const mhx_real* __restrict__ tparams, const int ntparams, const mhx_real tconst, const int lanes)
 {
     mhx_target_eval_body<MHX_TARGET_DYNAMIC>(x, lp, n, d, kind, tparams, ntparams, tconst, lanes);
 }
 __global__ void __launch_bounds__(256)
-k_record_state(const float* __restrict__ x, const float* __restrict__ lp, const unsigned char* __restrict__ last_acc,
-               float* samples, unsigned char* accepted, const int n, const long ld, const int d, const long slot)
+k_record_state(const mhx_real* __restrict__ x, const mhx_real* __restrict__ lp, const unsigned char* __restrict__ last_acc,
+               mhx_real* samples, unsigned char* accepted, const int n, const long ld, const int d, const long slot)
 {
     mhx_record_state_body(x, lp, last_acc, samples, accepted, n, ld, d, slot);
 }
 
-// occupancy target of the cooperative kernel: its point is >= 2 waves per SIMD
-#define MHX_COOP_WAVES(NBL) ((NBL) <= 5 ? 4 : ((NBL) <= 13 ? 2 : 1))
+// (MHX_COOP_WAVES, the occupancy target of the cooperative kernel, comes from mhx_rwmh_kernels.h)
 template <int L, int NBL, int TK, int PK, bool MOM>
 __global__ void __launch_bounds__(256, MHX_COOP_WAVES(NBL))
-k_rwmh_coop(const mhx_rwmh_args a, const float* __restrict__ tparams, const float* __restrict__ pvec)
+k_rwmh_coop(const mhx_rwmh_args a, const mhx_real* __restrict__ tparams, const mhx_real* __restrict__ pvec)
 {
     mhx_rwmh_coop_body<L, NBL, TK, PK, MOM>(a, tparams, pvec);
 }
 __global__ void __launch_bounds__(256)
-k_moments_first(const float* __restrict__ x, const float* __restrict__ lp, float* mean, float* m2, const int n,
+k_moments_first(const mhx_real* __restrict__ x, const mhx_real* __restrict__ lp, mhx_real* mean, mhx_real* m2, const int n,
                 const long ld, const int d)
 {
     mhx_moments_first_body(x, lp, mean, m2, n, ld, d);
@@ -110,15 +94,28 @@ k_moments_first(const float* __restrict__ x, const float* __restrict__ lp, float
 // `fn` records samples, `fn_mom` keeps running moments instead (null: specialised by hiprtc on demand)
 struct prebuilt_coop {
     int L, NBL, TK, PK;
-    void (*fn)(const mhx_rwmh_args, const float*, const float*);
-    void (*fn_mom)(const mhx_rwmh_args, const float*, const float*);
+    void (*fn)(const mhx_rwmh_args, const mhx_real*, const mhx_real*);
+    void (*fn_mom)(const mhx_rwmh_args, const mhx_real*, const mhx_real*);
 };
+// the BASELINE shapes: C2 (65 536 chains x d = 100) and C5 (32 768 chains per GPU x d = 1000); a double takes two VGPRs,
+// so the fp64 engine spreads a chain over more lanes
+#if MHX_REAL64
+#define MHX_C2_L 8
+#define MHX_C2_NBL 4
+#define MHX_C5_L 64
+#define MHX_C5_NBL 4
+#else
+#define MHX_C2_L 2
+#define MHX_C2_NBL 13
+#define MHX_C5_L 32
+#define MHX_C5_NBL 8
+#endif
 static const prebuilt_coop k_prebuilt_coop[] = {
-    {2, 13, MHX_TARGET_ISO_GAUSS, MHX_PROP_ISO, k_rwmh_coop<2, 13, MHX_TARGET_ISO_GAUSS, MHX_PROP_ISO, false>, nullptr},
-    {32, 8, MHX_TARGET_FUNNEL, MHX_PROP_ISO, k_rwmh_coop<32, 8, MHX_TARGET_FUNNEL, MHX_PROP_ISO, false>,
-     k_rwmh_coop<32, 8, MHX_TARGET_FUNNEL, MHX_PROP_ISO, true>},
-    {32, 8, MHX_TARGET_BANANA, MHX_PROP_ISO, k_rwmh_coop<32, 8, MHX_TARGET_BANANA, MHX_PROP_ISO, false>,
-     k_rwmh_coop<32, 8, MHX_TARGET_BANANA, MHX_PROP_ISO, true>},
+    {MHX_C2_L, MHX_C2_NBL, MHX_TARGET_ISO_GAUSS, MHX_PROP_ISO, k_rwmh_coop<MHX_C2_L, MHX_C2_NBL, MHX_TARGET_ISO_GAUSS, MHX_PROP_ISO, false>, nullptr},
+    {MHX_C5_L, MHX_C5_NBL, MHX_TARGET_FUNNEL, MHX_PROP_ISO, k_rwmh_coop<MHX_C5_L, MHX_C5_NBL, MHX_TARGET_FUNNEL, MHX_PROP_ISO, false>,
+     k_rwmh_coop<MHX_C5_L, MHX_C5_NBL, MHX_TARGET_FUNNEL, MHX_PROP_ISO, true>},
+    {MHX_C5_L, MHX_C5_NBL, MHX_TARGET_BANANA, MHX_PROP_ISO, k_rwmh_coop<MHX_C5_L, MHX_C5_NBL, MHX_TARGET_BANANA, MHX_PROP_ISO, false>,
+     k_rwmh_coop<MHX_C5_L, MHX_C5_NBL, MHX_TARGET_BANANA, MHX_PROP_ISO, true>},
 };
 
 // sum of a u32 array into a u64 (one atomic per block)
@@ -134,10 +131,12 @@ k_sum_u32(const unsigned* __restrict__ v, const long n, unsigned long long* out)
     if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
 }
 
-struct prebuilt_reg { int D, TK, PK; void (*fn)(const mhx_rwmh_args, const float*, const float*); };
+struct prebuilt_reg { int D, TK, PK; void (*fn)(const mhx_rwmh_args, const mhx_real*, const mhx_real*); };
 static const prebuilt_reg k_prebuilt_reg[] = {
+#if !MHX_REAL64
     {100, MHX_TARGET_ISO_GAUSS, MHX_PROP_ISO, k_rwmh_reg<100, MHX_TARGET_ISO_GAUSS, MHX_PROP_ISO>},
-    {2, MHX_TARGET_IID_NORMAL, MHX_PROP_ISO, k_rwmh_reg<2, MHX_TARGET_IID_NORMAL, MHX_PROP_ISO>},
+#endif
+    {2, MHX_TARGET_IID_NORMAL, MHX_PROP_ISO, k_rwmh_reg<2, MHX_TARGET_IID_NORMAL, MHX_PROP_ISO>},     // C1, README.md:29-31
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -147,7 +146,7 @@ struct jit_module {
     std::map<std::string, hipFunction_t> fns;
 };
 
-struct mhx_ctx {
+struct mhx_ctx : mhx_handle_hdr {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -162,15 +161,16 @@ struct mhx_ctx {
     }
 };
 
-extern "C" int mhx_ctx_create(int device, mhx_ctx** out)
+int api_ctx_create(int device, mhx_ctx** out)
 {
-    if (!out) return fail(MHX_EINVAL, "mhx_ctx_create: out is NULL");
+    if (!out) return mhx_fail(MHX_EINVAL, "mhx_ctx_create: out is NULL");
     int n = 0;
     HIP_TRY(hipGetDeviceCount(&n));
-    if (device < 0 || device >= n) return fail(MHX_EINVAL, "mhx_ctx_create: device %d of %d", device, n);
+    if (device < 0 || device >= n) return mhx_fail(MHX_EINVAL, "mhx_ctx_create: device %d of %d", device, n);
     HIP_TRY(hipSetDevice(device));
     std::unique_ptr<mhx_ctx> c(new mhx_ctx);
     c->device = device;
+    c->dtype = MHX_REAL64 ? MHX_F64 : MHX_F32;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&c->ev0));
     HIP_TRY(hipEventCreate(&c->ev1));
@@ -178,7 +178,9 @@ extern "C" int mhx_ctx_create(int device, mhx_ctx** out)
     return MHX_OK;
 }
 
-extern "C" int mhx_ctx_destroy(mhx_ctx* ctx)
+int api_ctx_device(const mhx_ctx* ctx) { return ctx->device; }
+
+int api_ctx_destroy(mhx_ctx* ctx)
 {
     if (!ctx) return MHX_OK;
     (void)hipSetDevice(ctx->device);
@@ -200,8 +202,9 @@ static int jit_compile(mhx_ctx* ctx, const std::string& key, const std::string& 
                               "mhx_emcee_kernels.h", "mhx_ram_kernels.h", "mhx_mala_kernels.h",
                               "mhx_rwmh_dense_kernels.h"};
     hiprtcResult r = hiprtcCreateProgram(&prog, source.c_str(), "mhx_jit.hip", 7, hdr_src, hdr_name);
-    if (r != HIPRTC_SUCCESS) return fail(MHX_EJIT, "hiprtcCreateProgram: %s", hiprtcGetErrorString(r));
-    std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize"};
+    if (r != HIPRTC_SUCCESS) return mhx_fail(MHX_EJIT, "hiprtcCreateProgram: %s", hiprtcGetErrorString(r));
+    std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
+                                     MHX_REAL64 ? "-DMHX_REAL64=1" : "-DMHX_REAL64=0"};
     for (auto& d : defines) opts.push_back("-D" + d);
     std::vector<const char*> copts;
     for (auto& o : opts) copts.push_back(o.c_str());
@@ -213,7 +216,7 @@ static int jit_compile(mhx_ctx* ctx, const std::string& key, const std::string& 
         if (ls) hiprtcGetProgramLog(prog, &log[0]);
         hiprtcDestroyProgram(&prog);
         if (log.size() > 1800) log.resize(1800);
-        return fail(MHX_EJIT, "hiprtc compile failed (%s): %s", hiprtcGetErrorString(r), log.c_str());
+        return mhx_fail(MHX_EJIT, "hiprtc compile failed (%s): %s", hiprtcGetErrorString(r), log.c_str());
     }
     size_t cs = 0;
     hiprtcGetCodeSize(prog, &cs);
@@ -222,7 +225,7 @@ static int jit_compile(mhx_ctx* ctx, const std::string& key, const std::string& 
     hiprtcDestroyProgram(&prog);
     std::unique_ptr<jit_module> m(new jit_module);
     hipError_t e = hipModuleLoadData(&m->mod, code.data());
-    if (e != hipSuccess) return fail(MHX_EJIT, "hipModuleLoadData: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return mhx_fail(MHX_EJIT, "hipModuleLoadData: %s", hipGetErrorString(e));
     *out = m.get();
     ctx->jit[key] = std::move(m);
     return MHX_OK;
@@ -233,24 +236,24 @@ static int jit_function(jit_module* m, const char* name, hipFunction_t* fn)
     auto it = m->fns.find(name);
     if (it != m->fns.end()) { *fn = it->second; return MHX_OK; }
     hipError_t e = hipModuleGetFunction(fn, m->mod, name);
-    if (e != hipSuccess) return fail(MHX_EJIT, "hipModuleGetFunction(%s): %s", name, hipGetErrorString(e));
+    if (e != hipSuccess) return mhx_fail(MHX_EJIT, "hipModuleGetFunction(%s): %s", name, hipGetErrorString(e));
     m->fns[name] = *fn;
     return MHX_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
 // targets
-struct mhx_target {
+struct mhx_target : mhx_handle_hdr {
     mhx_ctx* ctx = nullptr;
     int kind = 0, dim = 0, nparams = 0;
-    float cst = 0.0f;
-    float* dparams = nullptr;
+    mhx_real cst = MHX_R(0.0);
+    mhx_real* dparams = nullptr;
     std::string user_src;        // MHX_TARGET_USER
     std::string user_key;        // hash of the source, for the JIT cache
     ~mhx_target() { if (dparams) (void)hipFree(dparams); }
 };
 
-static float target_const(int kind, int dim, const float* p)
+static mhx_real target_const(int kind, int dim, const mhx_real* p)
 {
     const double LOG_2PI = 1.8378770664093454835606594728112;
     double c = -0.5 * (double)dim * LOG_2PI;
@@ -266,52 +269,53 @@ static float target_const(int kind, int dim, const float* p)
     case MHX_TARGET_USER: c = 0.0; break;
     default: break;
     }
-    return (float)c;
+    return (mhx_real)c;
 }
 
-static int target_upload(mhx_target* t, const float* params, size_t nparams)
+static int target_upload(mhx_target* t, const mhx_real* params, size_t nparams)
 {
     t->nparams = (int)nparams;
     // one dummy element keeps the pointer valid for kinds without parameters
     const size_t n = nparams ? nparams : 1;
-    HIP_TRY(hipMalloc(&t->dparams, n * sizeof(float)));
-    if (nparams) COPY_SYNC(t->ctx->stream, t->dparams, params, nparams * sizeof(float), hipMemcpyHostToDevice);
-    else HIP_TRY(hipMemsetAsync(t->dparams, 0, sizeof(float), t->ctx->stream));
+    HIP_TRY(hipMalloc(&t->dparams, n * sizeof(mhx_real)));
+    if (nparams) COPY_SYNC(t->ctx->stream, t->dparams, params, nparams * sizeof(mhx_real), hipMemcpyHostToDevice);
+    else HIP_TRY(hipMemsetAsync(t->dparams, 0, sizeof(mhx_real), t->ctx->stream));
     return MHX_OK;
 }
 
-extern "C" int mhx_target_builtin(mhx_ctx* ctx, int kind, int dim, const float* params, size_t nparams,
+int api_target_builtin(mhx_ctx* ctx, int kind, int dim, const mhx_real* params, size_t nparams,
                                   mhx_target** out)
 {
-    if (!ctx || !out) return fail(MHX_EINVAL, "mhx_target_builtin: NULL argument");
-    if (dim <= 0) return fail(MHX_EINVAL, "mhx_target_builtin: dim must be positive, got %d", dim);
-    if (nparams && !params) return fail(MHX_EINVAL, "mhx_target_builtin: params is NULL");
+    if (!ctx || !out) return mhx_fail(MHX_EINVAL, "mhx_target_builtin: NULL argument");
+    if (dim <= 0) return mhx_fail(MHX_EINVAL, "mhx_target_builtin: dim must be positive, got %d", dim);
+    if (nparams && !params) return mhx_fail(MHX_EINVAL, "mhx_target_builtin: params is NULL");
     const size_t tri = (size_t)dim * ((size_t)dim + 1) / 2;
     switch (kind) {
     case MHX_TARGET_ISO_GAUSS:
-        if (nparams) return fail(MHX_EINVAL, "ISO_GAUSS takes no parameters");
+        if (nparams) return mhx_fail(MHX_EINVAL, "ISO_GAUSS takes no parameters");
         break;
     case MHX_TARGET_CORR_GAUSS:
-        if (nparams != tri) return fail(MHX_EINVAL, "CORR_GAUSS needs %zu packed-lower parameters, got %zu", tri, nparams);
+        if (nparams != tri) return mhx_fail(MHX_EINVAL, "CORR_GAUSS needs %zu packed-lower parameters, got %zu", tri, nparams);
         for (int i = 0; i < dim; ++i)
-            if (!(params[(size_t)i * (i + 1) / 2 + i] > 0.0f))
-                return fail(MHX_ENOTPD, "CORR_GAUSS: diagonal %d of inv(chol(Sigma)) is not positive", i);
+            if (!(params[(size_t)i * (i + 1) / 2 + i] > MHX_R(0.0)))
+                return mhx_fail(MHX_ENOTPD, "CORR_GAUSS: diagonal %d of inv(chol(Sigma)) is not positive", i);
         break;
     case MHX_TARGET_IID_NORMAL:
-        if (dim != 2) return fail(MHX_EINVAL, "IID_NORMAL is a 2-parameter (mu, sigma) model, dim=%d", dim);
-        if (nparams < 1) return fail(MHX_EINVAL, "IID_NORMAL needs at least one data point");
+        if (dim != 2) return mhx_fail(MHX_EINVAL, "IID_NORMAL is a 2-parameter (mu, sigma) model, dim=%d", dim);
+        if (nparams < 1) return mhx_fail(MHX_EINVAL, "IID_NORMAL needs at least one data point");
         break;
     case MHX_TARGET_BANANA:
-        if (dim < 2 || nparams != 1) return fail(MHX_EINVAL, "BANANA needs dim >= 2 and params = {b}");
+        if (dim < 2 || nparams != 1) return mhx_fail(MHX_EINVAL, "BANANA needs dim >= 2 and params = {b}");
         break;
     case MHX_TARGET_FUNNEL:
-        if (dim < 2 || nparams != 0) return fail(MHX_EINVAL, "FUNNEL needs dim >= 2 and no parameters");
+        if (dim < 2 || nparams != 0) return mhx_fail(MHX_EINVAL, "FUNNEL needs dim >= 2 and no parameters");
         break;
     default:
-        return fail(MHX_EINVAL, "mhx_target_builtin: unknown kind %d", kind);
+        return mhx_fail(MHX_EINVAL, "mhx_target_builtin: unknown kind %d", kind);
     }
     HIP_TRY(hipSetDevice(ctx->device));
     std::unique_ptr<mhx_target> t(new mhx_target);
+    t->dtype = ctx->dtype;
     t->ctx = ctx;
     t->kind = kind;
     t->dim = dim;
@@ -352,18 +356,19 @@ static int jit_generic_rwmh(const mhx_target* t, jit_module** m)
                        {"MHX_JIT_RWMH_GENERIC=1", "MHX_JIT_TK=" + std::to_string(t->kind)}, m);
 }
 
-extern "C" int mhx_target_from_hip_source(mhx_ctx* ctx, const char* src, int dim, const float* data,
+int api_target_from_hip_source(mhx_ctx* ctx, const char* src, int dim, const mhx_real* data,
                                           size_t ndata, mhx_target** out)
 {
-    if (!ctx || !src || !out) return fail(MHX_EINVAL, "mhx_target_from_hip_source: NULL argument");
-    if (dim <= 0) return fail(MHX_EINVAL, "mhx_target_from_hip_source: dim must be positive");
-    if (ndata && !data) return fail(MHX_EINVAL, "mhx_target_from_hip_source: data is NULL");
+    if (!ctx || !src || !out) return mhx_fail(MHX_EINVAL, "mhx_target_from_hip_source: NULL argument");
+    if (dim <= 0) return mhx_fail(MHX_EINVAL, "mhx_target_from_hip_source: dim must be positive");
+    if (ndata && !data) return mhx_fail(MHX_EINVAL, "mhx_target_from_hip_source: data is NULL");
     HIP_TRY(hipSetDevice(ctx->device));
     std::unique_ptr<mhx_target> t(new mhx_target);
+    t->dtype = ctx->dtype;
     t->ctx = ctx;
     t->kind = MHX_TARGET_USER;
     t->dim = dim;
-    t->cst = 0.0f;
+    t->cst = MHX_R(0.0);
     t->user_src = src;
     t->user_key = fnv_hex(t->user_src);
     int rc = target_upload(t.get(), data, ndata);
@@ -376,7 +381,7 @@ extern "C" int mhx_target_from_hip_source(mhx_ctx* ctx, const char* src, int dim
     return MHX_OK;
 }
 
-extern "C" int mhx_target_destroy(mhx_target* t)
+int api_target_destroy(mhx_target* t)
 {
     if (!t) return MHX_OK;
     (void)hipSetDevice(t->ctx->device);
@@ -390,21 +395,21 @@ static int launch_module(hipFunction_t fn, unsigned grid, unsigned block, hipStr
     return MHX_OK;
 }
 
-extern "C" int mhx_target_eval(mhx_ctx* ctx, const mhx_target* t, const float* x, int n, float* lp)
+int api_target_eval(mhx_ctx* ctx, const mhx_target* t, const mhx_real* x, int n, mhx_real* lp)
 {
-    if (!ctx || !t || !x || !lp || n <= 0) return fail(MHX_EINVAL, "mhx_target_eval: bad argument");
+    if (!ctx || !t || !x || !lp || n <= 0) return mhx_fail(MHX_EINVAL, "mhx_target_eval: bad argument");
     HIP_TRY(hipSetDevice(ctx->device));
-    float *dx = nullptr, *dlp = nullptr;
+    mhx_real *dx = nullptr, *dlp = nullptr;
     const size_t nx = (size_t)t->dim * (size_t)n;
-    HIP_TRY(hipMalloc(&dx, nx * sizeof(float)));
-    HIP_TRY(hipMalloc(&dlp, (size_t)n * sizeof(float)));
+    HIP_TRY(hipMalloc(&dx, nx * sizeof(mhx_real)));
+    HIP_TRY(hipMalloc(&dlp, (size_t)n * sizeof(mhx_real)));
     int rc = MHX_OK;
     do {
-        if (hipMemcpyAsync(dx, x, nx * sizeof(float), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { rc = fail(MHX_EHIP, "H2D copy failed"); break; }
+        if (hipMemcpyAsync(dx, x, nx * sizeof(mhx_real), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { rc = mhx_fail(MHX_EHIP, "H2D copy failed"); break; }
         const unsigned grid = (unsigned)((n + 255) / 256);
         int d = t->dim, kind = t->kind, np = t->nparams, lanes = 1;
-        float cst = t->cst;
-        const float* tp = t->dparams;
+        mhx_real cst = t->cst;
+        const mhx_real* tp = t->dparams;
         if (t->kind == MHX_TARGET_USER) {
             jit_module* m = nullptr;
             hipFunction_t fn;
@@ -415,8 +420,8 @@ extern "C" int mhx_target_eval(mhx_ctx* ctx, const mhx_target* t, const float* x
         } else {
             hipLaunchKernelGGL(k_target_eval, dim3(grid), dim3(256), 0, ctx->stream, dx, dlp, n, d, kind, tp, np, cst, lanes);
         }
-        if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) { rc = fail(MHX_EHIP, "target_eval kernel failed"); break; }
-        if (hipMemcpyAsync(lp, dlp, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = fail(MHX_EHIP, "D2H copy failed"); break; }
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) { rc = mhx_fail(MHX_EHIP, "target_eval kernel failed"); break; }
+        if (hipMemcpyAsync(lp, dlp, (size_t)n * sizeof(mhx_real), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = mhx_fail(MHX_EHIP, "D2H copy failed"); break; }
     } while (0);
     (void)hipFree(dx);
     (void)hipFree(dlp);
@@ -427,7 +432,7 @@ extern "C" int mhx_target_eval(mhx_ctx* ctx, const mhx_target* t, const float* x
 // runs
 enum run_kind { RUN_RWMH = 0, RUN_EMCEE = 1, RUN_RAM = 2, RUN_MALA = 3 };
 
-struct mhx_run {
+struct mhx_run : mhx_handle_hdr {
     mhx_ctx* ctx = nullptr;
     const mhx_target* target = nullptr;
     int kind = RUN_RWMH;
@@ -438,55 +443,57 @@ struct mhx_run {
     uint64_t tau = 0;                    // transitions done so far (RNG step counter)
     // rwmh
     int prop_kind = 0;
-    float prop_scale = 1.0f;
-    float* d_pvec = nullptr;
+    mhx_real prop_scale = MHX_R(1.0);
+    mhx_real* d_pvec = nullptr;
     // emcee
-    float stretch = 2.0f;
+    mhx_real stretch = MHX_R(2.0);
     size_t dense_lds = 0;                // dynamic LDS bytes of the dense cooperative RWMH kernel
-    float* d_xw = nullptr;               // walker-major copy [W][round4(dim)]: the state while the cooperative kernel runs
-    float* d_pmean = nullptr;            // drifting walk: mu[dim] then 2 L^-1 mu [dim]
-    float* d_qx = nullptr;               // static proposal: logpdf of the proposal at each chain's state (up to its constant)
+    mhx_real* d_xw = nullptr;               // walker-major copy [W][round4(dim)]: the state while the cooperative kernel runs
+    mhx_real* d_pmean = nullptr;            // drifting walk: mu[dim] then 2 L^-1 mu [dim]
+    mhx_real* d_qx = nullptr;               // static proposal: logpdf of the proposal at each chain's state (up to its constant)
     // mala
-    float mala_sigma = 1.0f;
-    float *d_gx = nullptr, *d_gy = nullptr, *d_z = nullptr;
+    mhx_real mala_sigma = MHX_R(1.0);
+    mhx_real *d_gx = nullptr, *d_gy = nullptr, *d_z = nullptr;
     // ram
     mhx_ram_cfg ramcfg{};
-    float* d_S = nullptr;                        // packed factors [n][2][tri_pad]: both buffers of a chain side by side
+    mhx_real* d_S = nullptr;                        // packed factors [n][2][tri_pad]: both buffers of a chain side by side
     unsigned char* d_Ssel = nullptr;             // which buffer holds chain c's current factor
     unsigned char* d_status = nullptr;
-    float *d_dmin = nullptr, *d_dmax = nullptr;  // [dim][n]
-    float* d_eta = nullptr;                      // adaptation step sizes of the current launch
+    mhx_real *d_dmin = nullptr, *d_dmax = nullptr;  // [dim][n]
+    mhx_real* d_eta = nullptr;                      // adaptation step sizes of the current launch
+    mhx_real* d_loga = nullptr;                     // [n] log acceptance ratio of each chain's latest transition
+    double last_eta = 0.0;                          // step size of the latest adapting transition (state.η; 0 before any)
     size_t eta_cap = 0;
     // state
-    float *d_x = nullptr, *d_lp = nullptr, *d_ybuf = nullptr;
+    mhx_real *d_x = nullptr, *d_lp = nullptr, *d_ybuf = nullptr;
     uint32_t* d_acc = nullptr;
     unsigned char* d_last = nullptr;
     unsigned long long* d_acc_total = nullptr;
     // sample buffer of the last mhx_run_sample
-    float* d_samples = nullptr;
+    mhx_real* d_samples = nullptr;
     unsigned char* d_accepted = nullptr;
     size_t samples_cap = 0, accepted_cap = 0;
     int64_t n_saved = 0;
     // running moments of the last mhx_run_sample(save = 2)
-    float *d_mom_mean = nullptr, *d_mom_m2 = nullptr;
+    mhx_real *d_mom_mean = nullptr, *d_mom_m2 = nullptr;
     size_t mom_cap = 0, mom_cap2 = 0;
     uint64_t mom_n = 0;                  // states folded in so far
     bool moments_mode = false;
-    void (*reg_fn_mom)(const mhx_rwmh_args, const float*, const float*) = nullptr;
+    void (*reg_fn_mom)(const mhx_rwmh_args, const mhx_real*, const mhx_real*) = nullptr;
     hipFunction_t jit_step_mom = nullptr;
     std::string coop_key;                // JIT key / defines of the cooperative kernel (for its moments twin)
     std::vector<std::string> coop_defs;
     // kernel choice
     int coop_L = 1;                      // lanes per chain (reduction shape of the separable targets)
     int variant = 0;
-    void (*reg_fn)(const mhx_rwmh_args, const float*, const float*) = nullptr;
+    void (*reg_fn)(const mhx_rwmh_args, const mhx_real*, const mhx_real*) = nullptr;
     hipFunction_t jit_step = nullptr, jit_init = nullptr;
     mhx_stats stats{};
 
     ~mhx_run()
     {
         void* ptrs[] = {d_pvec, d_S, d_Ssel, d_status, d_dmin, d_dmax, d_eta, d_x, d_lp, d_ybuf,
-                        d_acc, d_last, d_acc_total, d_samples, d_accepted, d_mom_mean, d_mom_m2, d_gx, d_gy, d_z, d_pmean, d_qx, d_xw};
+                        d_acc, d_last, d_acc_total, d_samples, d_accepted, d_mom_mean, d_mom_m2, d_gx, d_gy, d_z, d_pmean, d_qx, d_xw, d_loga};
         for (void* p : ptrs) if (p) (void)hipFree(p);
     }
 };
@@ -494,8 +501,8 @@ struct mhx_run {
 static int run_alloc_state(mhx_run* r)
 {
     const size_t n = (size_t)r->n, d = (size_t)r->dim;
-    HIP_TRY(hipMalloc(&r->d_x, d * n * sizeof(float)));
-    HIP_TRY(hipMalloc(&r->d_lp, n * sizeof(float)));
+    HIP_TRY(hipMalloc(&r->d_x, d * n * sizeof(mhx_real)));
+    HIP_TRY(hipMalloc(&r->d_lp, n * sizeof(mhx_real)));
     HIP_TRY(hipMalloc(&r->d_acc, n * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&r->d_last, n));
     HIP_TRY(hipMalloc(&r->d_acc_total, sizeof(unsigned long long)));
@@ -524,7 +531,7 @@ static mhx_rwmh_args rwmh_args(const mhx_run* r)
 }
 
 __global__ void __launch_bounds__(256)
-k_rwmh_whiten(const mhx_rwmh_args a, const float* __restrict__ pvec)
+k_rwmh_whiten(const mhx_rwmh_args a, const mhx_real* __restrict__ pvec)
 {
     mhx_rwmh_whiten_body(a, pvec);
 }
@@ -539,19 +546,20 @@ static int rwmh_whiten(mhx_run* r)
     return MHX_OK;
 }
 
-#define MHX_REG_MAX_DIM 160
-#define MHX_REG_MAX_DIM_DENSE 96
+// register budgets: a double takes two VGPRs
+#define MHX_REG_MAX_DIM (MHX_REAL64 ? 80 : 160)
+#define MHX_REG_MAX_DIM_DENSE (MHX_REAL64 ? 48 : 96)
 #define MHX_DENSE_COOP_MAX_DIM 256
 #define MHX_LDS_PER_BLOCK 163840             // gfx950: 160 KB of LDS, all of it available to one block
 // lanes per chain of the dense cooperative kernel: at most 12.5 rows of a factor per lane
-static int dense_coop_lanes(int d) { int L = 2; while (2 * d > 25 * L) L *= 2; return L; }
+static int dense_coop_lanes(int d) { int L = 2; while ((MHX_REAL64 ? 4 : 2) * d > 25 * L && L < 64) L *= 2; return L; }
 // dynamic LDS of the dense cooperative kernel: the candidate rows of a 4-wave block + `nimages` factor images
 static size_t dense_coop_lds_bytes(int d, int L, int nimages)
 {
     long total4 = 0;
     for (int m = 0; m * L < d; ++m) total4 += (long)((std::min(L * (m + 1), d) + 3) / 4) * L;
     const long rows4 = (long)MHX_EMCEE_COOP_WAVES * (64 / L) * ((((d + 3) & ~3) + 4) / 4);
-    return (size_t)(rows4 + nimages * total4) * 16;
+    return (size_t)(rows4 + nimages * total4) * 4 * sizeof(mhx_real);
 }
 static bool dense_coop_fits(int d, int L, int nimages)
 {
@@ -559,68 +567,71 @@ static bool dense_coop_fits(int d, int L, int nimages)
     return dense_coop_lds_bytes(d, L, nimages) <= MHX_LDS_PER_BLOCK;
 }
 
-extern "C" int mhx_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, mhx_run** out)
+int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, mhx_run** out)
 {
-    if (!ctx || !t || !cfg || !out) return fail(MHX_EINVAL, "mhx_rwmh_create: NULL argument");
+    if (!ctx || !t || !cfg || !out) return mhx_fail(MHX_EINVAL, "mhx_rwmh_create: NULL argument");
     if (cfg->dim != t->dim)
-        return fail(MHX_EINVAL, "mhx_rwmh_create: proposal dim %d != model dim %d", cfg->dim, t->dim);
-    if (cfg->nchains <= 0) return fail(MHX_EINVAL, "mhx_rwmh_create: nchains must be positive");
+        return mhx_fail(MHX_EINVAL, "mhx_rwmh_create: proposal dim %d != model dim %d", cfg->dim, t->dim);
+    if (cfg->nchains <= 0) return mhx_fail(MHX_EINVAL, "mhx_rwmh_create: nchains must be positive");
     const int d = cfg->dim;
+    const mhx_real* cfg_vec = (const mhx_real*)cfg->proposal_vec;       // reals of this instantiation (include/mhx.h)
+    const mhx_real* cfg_mean = (const mhx_real*)cfg->proposal_mean;
     size_t nvec = 0;
     switch (cfg->proposal_kind) {
     case MHX_PROP_ISO:
-        if (!(cfg->proposal_scale > 0.0f)) return fail(MHX_EINVAL, "ISO proposal needs a positive scale");
+        if (!(cfg->proposal_scale > 0.0)) return mhx_fail(MHX_EINVAL, "ISO proposal needs a positive scale");
         break;
     case MHX_PROP_DIAG: nvec = (size_t)d; break;
     case MHX_PROP_DENSE: nvec = (size_t)d * ((size_t)d + 1) / 2; break;
-    default: return fail(MHX_EINVAL, "mhx_rwmh_create: unknown proposal kind %d", cfg->proposal_kind);
+    default: return mhx_fail(MHX_EINVAL, "mhx_rwmh_create: unknown proposal kind %d", cfg->proposal_kind);
     }
-    if (nvec && !cfg->proposal_vec) return fail(MHX_EINVAL, "mhx_rwmh_create: proposal_vec is NULL");
+    if (nvec && !cfg_vec) return mhx_fail(MHX_EINVAL, "mhx_rwmh_create: proposal_vec is NULL");
     HIP_TRY(hipSetDevice(ctx->device));
     std::unique_ptr<mhx_run> r(new mhx_run);
+    r->dtype = ctx->dtype;
     r->ctx = ctx; r->target = t; r->kind = RUN_RWMH;
     r->dim = d; r->n = cfg->nchains; r->seed = cfg->seed; r->first_id = cfg->first_chain;
     r->flags = cfg->flags;
-    r->prop_kind = cfg->proposal_kind; r->prop_scale = cfg->proposal_scale;
-    HIP_TRY(hipMalloc(&r->d_pvec, (nvec ? nvec : 1) * sizeof(float)));
-    if (nvec) COPY_SYNC(ctx->stream, r->d_pvec, cfg->proposal_vec, nvec * sizeof(float), hipMemcpyHostToDevice);
+    r->prop_kind = cfg->proposal_kind; r->prop_scale = (mhx_real)cfg->proposal_scale;
+    HIP_TRY(hipMalloc(&r->d_pvec, (nvec ? nvec : 1) * sizeof(mhx_real)));
+    if (nvec) COPY_SYNC(ctx->stream, r->d_pvec, cfg_vec, nvec * sizeof(mhx_real), hipMemcpyHostToDevice);
     int rc = run_alloc_state(r.get());
     if (rc) return rc;
     // drifting random walk: keep mu and 2 L^-1 mu (double arithmetic on the host, rounded once) and use the
     // generic kernel, the only one that evaluates the Hastings ratio
     bool drift = false;
-    if (cfg->proposal_mean)
-        for (int k = 0; k < d; ++k) drift = drift || cfg->proposal_mean[k] != 0.0f;
+    if (cfg_mean)
+        for (int k = 0; k < d; ++k) drift = drift || cfg_mean[k] != MHX_R(0.0);
     if (drift) {
-        std::vector<float> pm(2 * (size_t)d);
+        std::vector<mhx_real> pm(2 * (size_t)d);
         std::vector<double> m((size_t)d);
         size_t off = 0;
         for (int i = 0; i < d; ++i) {
-            double acc = (double)cfg->proposal_mean[i];
+            double acc = (double)cfg_mean[i];
             if (cfg->proposal_kind == MHX_PROP_ISO) m[i] = acc / (double)cfg->proposal_scale;
-            else if (cfg->proposal_kind == MHX_PROP_DIAG) m[i] = acc / (double)cfg->proposal_vec[i];
+            else if (cfg->proposal_kind == MHX_PROP_DIAG) m[i] = acc / (double)cfg_vec[i];
             else {
-                for (int j = 0; j < i; ++j) acc -= (double)cfg->proposal_vec[off + j] * m[j];
-                m[i] = acc / (double)cfg->proposal_vec[off + i];
+                for (int j = 0; j < i; ++j) acc -= (double)cfg_vec[off + j] * m[j];
+                m[i] = acc / (double)cfg_vec[off + i];
                 off += (size_t)i + 1;
             }
-            pm[i] = cfg->proposal_mean[i];
-            pm[(size_t)d + i] = (float)(2.0 * m[i]);
+            pm[i] = cfg_mean[i];
+            pm[(size_t)d + i] = (mhx_real)(2.0 * m[i]);
         }
-        HIP_TRY(hipMalloc(&r->d_pmean, pm.size() * sizeof(float)));
-        COPY_SYNC(ctx->stream, r->d_pmean, pm.data(), pm.size() * sizeof(float), hipMemcpyHostToDevice);
-        if (cfg->reduce_lanes > 1) return fail(MHX_EINVAL, "a drifting random walk runs on the generic kernel: reduce_lanes must be 0 or 1");
+        HIP_TRY(hipMalloc(&r->d_pmean, pm.size() * sizeof(mhx_real)));
+        COPY_SYNC(ctx->stream, r->d_pmean, pm.data(), pm.size() * sizeof(mhx_real), hipMemcpyHostToDevice);
+        if (cfg->reduce_lanes > 1) return mhx_fail(MHX_EINVAL, "a drifting random walk runs on the generic kernel: reduce_lanes must be 0 or 1");
         r->flags |= MHX_FLAG_GENERIC;
     }
-    // static (independence) proposal, src/proposal.jl:9-11,66-83: generic kernel, one more float of state per chain
+    // static (independence) proposal, src/proposal.jl:9-11,66-83: generic kernel, one more mhx_real of state per chain
     if (cfg->flags & MHX_FLAG_STATIC_PROPOSAL) {
-        if (cfg->reduce_lanes > 1) return fail(MHX_EINVAL, "a static proposal runs on the generic kernel: reduce_lanes must be 0 or 1");
-        HIP_TRY(hipMalloc(&r->d_qx, (size_t)r->n * sizeof(float)));
+        if (cfg->reduce_lanes > 1) return mhx_fail(MHX_EINVAL, "a static proposal runs on the generic kernel: reduce_lanes must be 0 or 1");
+        HIP_TRY(hipMalloc(&r->d_qx, (size_t)r->n * sizeof(mhx_real)));
         r->flags |= MHX_FLAG_GENERIC;
     }
 
     // the register / cooperative kernels address a [dim+1][nchains] slab with 32-bit byte offsets
-    if (((uint64_t)d + 1) * (uint64_t)r->n * 4ull >= (1ull << 32)) r->flags |= MHX_FLAG_GENERIC;
+    if (((uint64_t)d + 1) * (uint64_t)r->n * (uint64_t)sizeof(mhx_real) >= (1ull << 32)) r->flags |= MHX_FLAG_GENERIC;
     // ---- kernel choice
     r->variant = 0;
     const int tk = t->kind, pk = r->prop_kind;
@@ -633,10 +644,11 @@ extern "C" int mhx_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh
     if (separable && pk != MHX_PROP_DENSE && !(r->flags & MHX_FLAG_GENERIC)) {
         if (cfg->reduce_lanes > 0) {
             L = cfg->reduce_lanes;
-            if (L > 64 || (L & (L - 1))) return fail(MHX_EINVAL, "reduce_lanes must be a power of two <= 64, got %d", L);
+            if (L > 64 || (L & (L - 1))) return mhx_fail(MHX_EINVAL, "reduce_lanes must be a power of two <= 64, got %d", L);
         } else {
-            while (L < 64 && (nblk + L - 1) / L > 13) L *= 2;
+            while (L < 64 && (nblk + L - 1) / L > MHX_COOP_NBL_AUTO) L *= 2;
             while (L < 64 && 2 * L <= nblk && (long)r->n * L / 64 < 2048) L *= 2;
+            if ((nblk + L - 1) / L > MHX_COOP_NBL_MAX) L = 1;      // not even a whole wave holds the chain: state in HBM
         }
     } else if (((tk == MHX_TARGET_CORR_GAUSS) || (tk == MHX_TARGET_ISO_GAUSS && pk == MHX_PROP_DENSE)) &&
                !(r->flags & (MHX_FLAG_GENERIC | MHX_FLAG_NO_JIT)) && d >= 2 && d <= MHX_DENSE_COOP_MAX_DIM &&
@@ -649,7 +661,7 @@ extern "C" int mhx_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh
         // 8.5e9 / 6.8e9 / 2.9e9 / 2.0e9 steps/s; the lane-per-chain register kernel 1.4e10 / 7.2e9 / 4.9e9 / - / -;
         // more rows per lane than ~16 spill)
         L = cfg->reduce_lanes > 1 ? cfg->reduce_lanes : dense_coop_lanes(d);
-        if (L > 64 || (L & (L - 1)) || L > d) return fail(MHX_EINVAL, "reduce_lanes must be a power of two <= min(64, dim), got %d", L);
+        if (L > 64 || (L & (L - 1)) || L > d) return mhx_fail(MHX_EINVAL, "reduce_lanes must be a power of two <= min(64, dim), got %d", L);
         jit_module* m = nullptr;
         const std::string key = "rwmh_dense/d=" + std::to_string(d) + "/l=" + std::to_string(L) + "/pk=" + std::to_string(pk) +
                                 "/tk=" + std::to_string(tk);
@@ -660,18 +672,18 @@ extern "C" int mhx_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh
         if (rc == MHX_OK) {
             r->dense_lds = dense_coop_lds_bytes(d, L, (tk == MHX_TARGET_CORR_GAUSS ? 1 : 0) + (pk == MHX_PROP_DENSE ? 1 : 0));
             if (hipFuncSetAttribute((const void*)r->jit_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->dense_lds) != hipSuccess)
-                rc = fail(MHX_EHIP, "dense cooperative kernel: %zu bytes of LDS refused", r->dense_lds);
+                rc = mhx_fail(MHX_EHIP, "dense cooperative kernel: %zu bytes of LDS refused", r->dense_lds);
         }
         if (rc == MHX_OK) { r->variant = 5; r->coop_L = L; }
         else if (cfg->reduce_lanes > 1) return rc;
         L = 1;                                                        // not the separable cooperative path below
     } else if (cfg->reduce_lanes > 1) {
-        return fail(MHX_EINVAL, "reduce_lanes > 1 needs a separable catalogue target or the dense Gaussian target "
+        return mhx_fail(MHX_EINVAL, "reduce_lanes > 1 needs a separable catalogue target or the dense Gaussian target "
                                 "(dim <= 128, JIT), and an ISO/DIAG proposal");
     }
     if (L > 1) {
         const int NBL = (nblk + L - 1) / L;
-        if (NBL > 16) return fail(MHX_EINVAL, "reduce_lanes=%d leaves %d blocks per lane (max 16)", L, NBL);
+        if (NBL > MHX_COOP_NBL_MAX) return mhx_fail(MHX_EINVAL, "reduce_lanes=%d leaves %d blocks per lane (max %d)", L, NBL, MHX_COOP_NBL_MAX);
         for (const auto& pb : k_prebuilt_coop)
             if (pb.L == L && pb.NBL == NBL && pb.TK == tk && pb.PK == pk) { r->reg_fn = pb.fn; r->reg_fn_mom = pb.fn_mom; r->variant = 3; }
         if (!r->variant && !(r->flags & MHX_FLAG_NO_JIT)) {
@@ -691,14 +703,14 @@ extern "C" int mhx_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh
                           "/pk=" + std::to_string(pk);
             r->coop_defs = {"MHX_JIT_RWMH_COOP=1", "MHX_JIT_L=" + std::to_string(L), "MHX_JIT_NBL=" + std::to_string(NBL),
                             "MHX_JIT_TK=" + std::to_string(tk), "MHX_JIT_PK=" + std::to_string(pk), "MHX_JIT_MOM=1"};
-        } else if (cfg->reduce_lanes > 1) return fail(MHX_EINVAL, "reduce_lanes=%d: no pre-built kernel and JIT disabled", L);
+        } else if (cfg->reduce_lanes > 1) return mhx_fail(MHX_EINVAL, "reduce_lanes=%d: no pre-built kernel and JIT disabled", L);
     }
     if (!r->variant && !(r->flags & MHX_FLAG_GENERIC)) {
         if (tk != MHX_TARGET_USER)
             for (const auto& pb : k_prebuilt_reg)
                 if (pb.D == d && pb.TK == tk && pb.PK == pk) { r->reg_fn = pb.fn; r->variant = 1; }
         if (!r->variant && !(r->flags & MHX_FLAG_NO_JIT) && d <= regmax &&
-            !(tk == MHX_TARGET_CORR_GAUSS && d > 64) && !(tk == MHX_TARGET_IID_NORMAL && t->nparams > 4096)) {
+            !(tk == MHX_TARGET_CORR_GAUSS && d > (MHX_REAL64 ? 32 : 64)) && !(tk == MHX_TARGET_IID_NORMAL && t->nparams > 4096)) {
             jit_module* m = nullptr;
             const std::string key = "rwmh_reg/d=" + std::to_string(d) + "/tk=" + std::to_string(tk) + "/pk=" +
                                     std::to_string(pk) + "/" + t->user_key;
@@ -717,29 +729,29 @@ extern "C" int mhx_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh
         if ((rc = jit_function(m, "mhx_jit_rwmh_init", &r->jit_init))) return rc;
         if (r->variant == 0 && (rc = jit_function(m, "mhx_jit_rwmh_generic", &r->jit_step))) return rc;
     }
-    if (r->variant == 0) HIP_TRY(hipMalloc(&r->d_ybuf, (size_t)d * (size_t)r->n * sizeof(float)));
+    if (r->variant == 0) HIP_TRY(hipMalloc(&r->d_ybuf, (size_t)d * (size_t)r->n * sizeof(mhx_real)));
     *out = r.release();
     return MHX_OK;
 }
 
 // ---- emcee / ram creation, init and stepping live in their own sections below
-static int emcee_init(mhx_run* r, const float* init);
+static int emcee_init(mhx_run* r, const mhx_real* init);
 static int emcee_sync_state(mhx_run* r, int to_abi);
 static int emcee_advance(mhx_run* r, uint64_t nsteps, uint32_t save_next, int save_slot, int thinning);
-static int ram_init(mhx_run* r, const float* init);
+static int ram_init(mhx_run* r, const mhx_real* init);
 static int ram_advance(mhx_run* r, uint64_t nsteps, uint64_t n_adapt, uint32_t save_next, int save_slot, int thinning);
-static int mala_init(mhx_run* r, const float* init);
+static int mala_init(mhx_run* r, const mhx_real* init);
 static int mala_eval_state(mhx_run* r, int reset_counts);
 static int mala_advance(mhx_run* r, uint64_t nsteps, uint32_t save_next, int save_slot, int thinning);
 
-static int rwmh_init(mhx_run* r, const float* init)
+static int rwmh_init(mhx_run* r, const mhx_real* init)
 {
     mhx_ctx* ctx = r->ctx;
     const size_t nx = (size_t)r->dim * (size_t)r->n;
-    if (init) HIP_TRY(hipMemcpyAsync(r->d_x, init, nx * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    if (init) HIP_TRY(hipMemcpyAsync(r->d_x, init, nx * sizeof(mhx_real), hipMemcpyHostToDevice, ctx->stream));
     mhx_rwmh_args a = rwmh_args(r);
-    const float* tp = r->target->dparams;
-    const float* pv = r->d_pvec;
+    const mhx_real* tp = r->target->dparams;
+    const mhx_real* pv = r->d_pvec;
     int draw = init ? 0 : 1;
     const unsigned grid = (unsigned)((r->n + 255) / 256);
     if (r->target->kind == MHX_TARGET_USER) {
@@ -759,8 +771,8 @@ static int rwmh_init(mhx_run* r, const float* init)
 static int rwmh_advance(mhx_run* r, uint64_t nsteps, uint32_t save_next, int save_slot, int thinning)
 {
     mhx_ctx* ctx = r->ctx;
-    const float* tp = r->target->dparams;
-    const float* pv = r->d_pvec;
+    const mhx_real* tp = r->target->dparams;
+    const mhx_real* pv = r->d_pvec;
     uint64_t done = 0;
     while (done < nsteps) {
         const uint64_t chunk = std::min<uint64_t>(nsteps - done, MHX_MAX_STEPS_PER_LAUNCH);
@@ -827,9 +839,9 @@ static int rwmh_advance(mhx_run* r, uint64_t nsteps, uint32_t save_next, int sav
     return MHX_OK;
 }
 
-extern "C" int mhx_run_init(mhx_run* r, const float* initial_params)
+int api_run_init(mhx_run* r, const mhx_real* initial_params)
 {
-    if (!r) return fail(MHX_EINVAL, "mhx_run_init: run is NULL");
+    if (!r) return mhx_fail(MHX_EINVAL, "mhx_run_init: run is NULL");
     HIP_TRY(hipSetDevice(r->ctx->device));
     int rc;
     switch (r->kind) {
@@ -861,27 +873,28 @@ static int ensure_buffer(void** p, size_t* cap, size_t need)
     if (*cap >= need && *p) return MHX_OK;
     if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
     hipError_t e = hipMalloc(p, need);
-    if (e != hipSuccess) return fail(MHX_ENOMEM, "sample buffer of %zu bytes: %s", need, hipGetErrorString(e));
+    if (e != hipSuccess) return mhx_fail(MHX_ENOMEM, "sample buffer of %zu bytes: %s", need, hipGetErrorString(e));
     *cap = need;
     return MHX_OK;
 }
 
-extern "C" int mhx_run_sample(mhx_run* r, const mhx_schedule* s, int save_samples)
+int api_run_sample(mhx_run* r, const mhx_schedule* s, int save_samples)
 {
-    if (!r || !s) return fail(MHX_EINVAL, "mhx_run_sample: NULL argument");
-    if (!r->initialised) return fail(MHX_ESTATE, "mhx_run_sample: call mhx_run_init first");
+    if (!r || !s) return mhx_fail(MHX_EINVAL, "mhx_run_sample: NULL argument");
+    if (!r->initialised) return mhx_fail(MHX_ESTATE, "mhx_run_sample: call mhx_run_init first");
     if (s->n_samples < 1 || s->thinning < 1 || s->discard_initial < 0 || s->num_warmup < 0)
-        return fail(MHX_EINVAL, "mhx_run_sample: bad schedule (N=%d discard=%d thinning=%d warmup=%d)",
+        return mhx_fail(MHX_EINVAL, "mhx_run_sample: bad schedule (N=%d discard=%d thinning=%d warmup=%d)",
                     s->n_samples, s->discard_initial, s->thinning, s->num_warmup);
     mhx_ctx* ctx = r->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
     uint64_t nT = 0, nA = 0;
     schedule_counts(s, &nT, &nA);
-    if (r->tau + nT >= 0xffffffffull) return fail(MHX_EINVAL, "step counter would exceed 2^32-1; start a new seed");
+    if (r->tau + nT >= 0xffffffffull) return mhx_fail(MHX_EINVAL, "step counter would exceed 2^32-1; start a new seed");
     const auto t0 = std::chrono::steady_clock::now();
     r->stats = mhx_stats{};
     r->stats.kernel_variant = r->variant;
     r->stats.reduce_lanes = r->coop_L;
+    r->stats.dtype = r->dtype;
     auto total_accepts = [&](unsigned long long* out) -> int {
         if (r->kind == RUN_EMCEE) {            // per-walker counts summed on demand (no atomics in the half-step kernels)
             HIP_TRY(hipMemsetAsync(r->d_acc_total, 0, sizeof(unsigned long long), ctx->stream));
@@ -902,7 +915,7 @@ extern "C" int mhx_run_sample(mhx_run* r, const mhx_schedule* s, int save_sample
     if (save_samples == MHX_SAVE_MOMENTS) {
         // running moments instead of a sample tensor
         if (r->kind != RUN_RWMH || (r->variant != 0 && r->variant != 3 && r->variant != 4))
-            return fail(MHX_EINVAL, "running moments need an RWMH run on the cooperative or the generic kernel "
+            return mhx_fail(MHX_EINVAL, "running moments need an RWMH run on the cooperative or the generic kernel "
                                     "(separable target, or MHX_FLAG_GENERIC); this run uses kernel variant %d", r->variant);
         if (((r->variant == 3 && !r->reg_fn_mom) || r->variant == 4) && !r->jit_step_mom) {
             jit_module* m = nullptr;
@@ -910,7 +923,7 @@ extern "C" int mhx_run_sample(mhx_run* r, const mhx_schedule* s, int save_sample
             if (rcj == MHX_OK) rcj = jit_function(m, "mhx_jit_rwmh_coop", &r->jit_step_mom);
             if (rcj) return rcj;
         }
-        const size_t bytes = ((size_t)r->dim + 1) * (size_t)r->n * sizeof(float);
+        const size_t bytes = ((size_t)r->dim + 1) * (size_t)r->n * sizeof(mhx_real);
         int rc = ensure_buffer((void**)&r->d_mom_mean, &r->mom_cap, bytes);
         if (rc) return rc;
         rc = ensure_buffer((void**)&r->d_mom_m2, &r->mom_cap2, bytes);
@@ -930,7 +943,7 @@ extern "C" int mhx_run_sample(mhx_run* r, const mhx_schedule* s, int save_sample
         }
     } else if (save_samples) {
         const size_t N = (size_t)s->n_samples, n = (size_t)r->n, d1 = (size_t)r->dim + 1;
-        int rc = ensure_buffer((void**)&r->d_samples, &r->samples_cap, N * d1 * n * sizeof(float));
+        int rc = ensure_buffer((void**)&r->d_samples, &r->samples_cap, N * d1 * n * sizeof(mhx_real));
         if (rc) return rc;
         rc = ensure_buffer((void**)&r->d_accepted, &r->accepted_cap, N * n);
         if (rc) return rc;
@@ -974,57 +987,57 @@ extern "C" int mhx_run_sample(mhx_run* r, const mhx_schedule* s, int save_sample
     return MHX_OK;
 }
 
-extern "C" int mhx_run_get_samples(mhx_run* r, float* samples, uint8_t* accepted)
+int api_run_get_samples(mhx_run* r, mhx_real* samples, uint8_t* accepted)
 {
-    if (!r) return fail(MHX_EINVAL, "mhx_run_get_samples: run is NULL");
+    if (!r) return mhx_fail(MHX_EINVAL, "mhx_run_get_samples: run is NULL");
     if (r->n_saved <= 0 || r->moments_mode)
-        return fail(MHX_ESTATE, "mhx_run_get_samples: the last mhx_run_sample kept no sample tensor");
+        return mhx_fail(MHX_ESTATE, "mhx_run_get_samples: the last mhx_run_sample kept no sample tensor");
     HIP_TRY(hipSetDevice(r->ctx->device));
     const size_t N = (size_t)r->n_saved, n = (size_t)r->n, d1 = (size_t)r->dim + 1;
-    if (samples) COPY_SYNC(r->ctx->stream, samples, r->d_samples, N * d1 * n * sizeof(float), hipMemcpyDeviceToHost);
+    if (samples) COPY_SYNC(r->ctx->stream, samples, r->d_samples, N * d1 * n * sizeof(mhx_real), hipMemcpyDeviceToHost);
     if (accepted) COPY_SYNC(r->ctx->stream, accepted, r->d_accepted, N * n, hipMemcpyDeviceToHost);
     return MHX_OK;
 }
 
-extern "C" int mhx_run_device_samples(mhx_run* r, void** samples, void** accepted, int64_t* n_samples)
+int api_run_device_samples(mhx_run* r, void** samples, void** accepted, int64_t* n_samples)
 {
-    if (!r) return fail(MHX_EINVAL, "mhx_run_device_samples: run is NULL");
+    if (!r) return mhx_fail(MHX_EINVAL, "mhx_run_device_samples: run is NULL");
     if (samples) *samples = r->d_samples;
     if (accepted) *accepted = r->d_accepted;
     if (n_samples) *n_samples = r->n_saved;
     return MHX_OK;
 }
 
-extern "C" int mhx_run_get_state(mhx_run* r, float* x, float* lp, uint32_t* accept_counts)
+int api_run_get_state(mhx_run* r, mhx_real* x, mhx_real* lp, uint32_t* accept_counts)
 {
-    if (!r) return fail(MHX_EINVAL, "mhx_run_get_state: run is NULL");
-    if (!r->initialised) return fail(MHX_ESTATE, "mhx_run_get_state: run is not initialised");
+    if (!r) return mhx_fail(MHX_EINVAL, "mhx_run_get_state: run is NULL");
+    if (!r->initialised) return mhx_fail(MHX_ESTATE, "mhx_run_get_state: run is not initialised");
     HIP_TRY(hipSetDevice(r->ctx->device));
     const size_t n = (size_t)r->n, d = (size_t)r->dim;
     if (x && r->kind == RUN_EMCEE) { int rc = emcee_sync_state(r, 1); if (rc) return rc; }
-    if (x) COPY_SYNC(r->ctx->stream, x, r->d_x, d * n * sizeof(float), hipMemcpyDeviceToHost);
-    if (lp) COPY_SYNC(r->ctx->stream, lp, r->d_lp, n * sizeof(float), hipMemcpyDeviceToHost);
+    if (x) COPY_SYNC(r->ctx->stream, x, r->d_x, d * n * sizeof(mhx_real), hipMemcpyDeviceToHost);
+    if (lp) COPY_SYNC(r->ctx->stream, lp, r->d_lp, n * sizeof(mhx_real), hipMemcpyDeviceToHost);
     if (accept_counts) COPY_SYNC(r->ctx->stream, accept_counts, r->d_acc, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
     return MHX_OK;
 }
 
-extern "C" int mhx_run_set_state(mhx_run* r, const float* x)
+int api_run_set_state(mhx_run* r, const mhx_real* x)
 {
-    if (!r || !x) return fail(MHX_EINVAL, "mhx_run_set_state: NULL argument");
-    if (!r->initialised) return fail(MHX_ESTATE, "mhx_run_set_state: run is not initialised");
+    if (!r || !x) return mhx_fail(MHX_EINVAL, "mhx_run_set_state: NULL argument");
+    if (!r->initialised) return mhx_fail(MHX_ESTATE, "mhx_run_set_state: run is not initialised");
     mhx_ctx* ctx = r->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t n = (size_t)r->n, d = (size_t)r->dim;
-    COPY_SYNC(r->ctx->stream, r->d_x, x, d * n * sizeof(float), hipMemcpyHostToDevice);
+    COPY_SYNC(r->ctx->stream, r->d_x, x, d * n * sizeof(mhx_real), hipMemcpyHostToDevice);
     if (r->kind == RUN_EMCEE) { int rc = emcee_sync_state(r, 0); if (rc) return rc; }
     if (r->kind == RUN_MALA) return mala_eval_state(r, 0);   // src/MALA.jl:27-35: lp and gradient are recomputed
     // lp is a cache of logdensity(model, x) (src/AdvancedMH.jl:75): recompute it
     const unsigned grid = (unsigned)((r->n + 255) / 256);
     int nn = r->n, dd = r->dim, kind = r->target->kind, np = r->target->nparams, lanes = r->coop_L;
-    float cst = r->target->cst;
-    const float* tp = r->target->dparams;
-    const float* dx = r->d_x;
-    float* dlp = r->d_lp;
+    mhx_real cst = r->target->cst;
+    const mhx_real* tp = r->target->dparams;
+    const mhx_real* dx = r->d_x;
+    mhx_real* dlp = r->d_lp;
     if (kind == MHX_TARGET_USER) {
         jit_module* m = nullptr;
         hipFunction_t fn;
@@ -1050,6 +1063,7 @@ struct ckpt_header {
     // the lanes per chain (summation order of lp); and the exact payload size
     int32_t target_kind, prop_kind, variant, coop_L;
     uint64_t payload_bytes;
+    double last_eta;           // RAM: step size of the latest adapting transition
 };
 static const uint32_t k_ckpt_magic = 0x5848484du;          // "MHXX"
 struct ckpt_part { void* dev; size_t bytes; };
@@ -1057,40 +1071,41 @@ struct ckpt_part { void* dev; size_t bytes; };
 static std::vector<ckpt_part> ckpt_parts(mhx_run* r)
 {
     const size_t n = (size_t)r->n, d = (size_t)r->dim;
-    std::vector<ckpt_part> p = {{r->d_x, d * n * sizeof(float)}, {r->d_lp, n * sizeof(float)},
+    std::vector<ckpt_part> p = {{r->d_x, d * n * sizeof(mhx_real)}, {r->d_lp, n * sizeof(mhx_real)},
                                 {r->d_acc, n * sizeof(uint32_t)}, {r->d_last, n}};
     if (r->kind == RUN_RAM) {
         const size_t trip = (size_t)mhx_ram_tri_pad(r->dim);
-        p.push_back({r->d_S, 2 * trip * n * sizeof(float)});
+        p.push_back({r->d_S, 2 * trip * n * sizeof(mhx_real)});
         p.push_back({r->d_Ssel, n});
         p.push_back({r->d_status, n});
-        p.push_back({r->d_dmin, d * n * sizeof(float)});
-        p.push_back({r->d_dmax, d * n * sizeof(float)});
+        p.push_back({r->d_dmin, d * n * sizeof(mhx_real)});
+        p.push_back({r->d_dmax, d * n * sizeof(mhx_real)});
+        p.push_back({r->d_loga, n * sizeof(mhx_real)});
     }
-    if (r->kind == RUN_MALA) p.push_back({r->d_gx, d * n * sizeof(float)});
-    if (r->d_qx) p.push_back({r->d_qx, n * sizeof(float)});
+    if (r->kind == RUN_MALA) p.push_back({r->d_gx, d * n * sizeof(mhx_real)});
+    if (r->d_qx) p.push_back({r->d_qx, n * sizeof(mhx_real)});
     return p;
 }
-extern "C" int mhx_run_state_size(mhx_run* r, size_t* bytes)
+int api_run_state_size(mhx_run* r, size_t* bytes)
 {
-    if (!r || !bytes) return fail(MHX_EINVAL, "mhx_run_state_size: NULL argument");
+    if (!r || !bytes) return mhx_fail(MHX_EINVAL, "mhx_run_state_size: NULL argument");
     size_t total = sizeof(ckpt_header);
     for (const auto& p : ckpt_parts(r)) total += p.bytes;
     *bytes = total;
     return MHX_OK;
 }
-extern "C" int mhx_run_save_state(mhx_run* r, void* blob, size_t bytes)
+int api_run_save_state(mhx_run* r, void* blob, size_t bytes)
 {
-    if (!r || !blob) return fail(MHX_EINVAL, "mhx_run_save_state: NULL argument");
-    if (!r->initialised) return fail(MHX_ESTATE, "mhx_run_save_state: run is not initialised");
+    if (!r || !blob) return mhx_fail(MHX_EINVAL, "mhx_run_save_state: NULL argument");
+    if (!r->initialised) return mhx_fail(MHX_ESTATE, "mhx_run_save_state: run is not initialised");
     size_t need = 0;
-    mhx_run_state_size(r, &need);
-    if (bytes < need) return fail(MHX_EINVAL, "mhx_run_save_state: the blob holds %zu bytes, the state needs %zu", bytes, need);
+    api_run_state_size(r, &need);
+    if (bytes < need) return mhx_fail(MHX_EINVAL, "mhx_run_save_state: the blob holds %zu bytes, the state needs %zu", bytes, need);
     HIP_TRY(hipSetDevice(r->ctx->device));
     if (r->kind == RUN_EMCEE) { int rc = emcee_sync_state(r, 1); if (rc) return rc; }      // walker-major -> ABI layout
     HIP_TRY(hipStreamSynchronize(r->ctx->stream));
     ckpt_header h = {k_ckpt_magic, 2u, (int32_t)r->kind, r->dim, r->n, r->flags & MHX_FLAG_STATIC_PROPOSAL, r->tau, r->seed, r->first_id,
-                     r->target->kind, r->prop_kind, r->variant, r->coop_L, (uint64_t)(need - sizeof(ckpt_header))};
+                     r->target->kind, r->prop_kind, r->variant, r->coop_L, (uint64_t)(need - sizeof(ckpt_header)), r->last_eta};
     char* out = (char*)blob;
     memcpy(out, &h, sizeof h);
     out += sizeof h;
@@ -1100,21 +1115,21 @@ extern "C" int mhx_run_save_state(mhx_run* r, void* blob, size_t bytes)
     }
     return MHX_OK;
 }
-extern "C" int mhx_run_load_state(mhx_run* r, const void* blob, size_t bytes)
+int api_run_load_state(mhx_run* r, const void* blob, size_t bytes)
 {
-    if (!r || !blob) return fail(MHX_EINVAL, "mhx_run_load_state: NULL argument");
+    if (!r || !blob) return mhx_fail(MHX_EINVAL, "mhx_run_load_state: NULL argument");
     size_t need = 0;
-    mhx_run_state_size(r, &need);
+    api_run_state_size(r, &need);
     ckpt_header h;
-    if (bytes < sizeof h) return fail(MHX_EINVAL, "mhx_run_load_state: the blob is too short");
+    if (bytes < sizeof h) return mhx_fail(MHX_EINVAL, "mhx_run_load_state: the blob is too short");
     memcpy(&h, blob, sizeof h);
-    if (h.magic != k_ckpt_magic || h.version != 2u) return fail(MHX_EINVAL, "mhx_run_load_state: not a state blob of this library version");
+    if (h.magic != k_ckpt_magic || h.version != 2u) return mhx_fail(MHX_EINVAL, "mhx_run_load_state: not a state blob of this library version");
     if (h.kind != (int32_t)r->kind || h.dim != r->dim || h.n != r->n || bytes != need || h.payload_bytes != need - sizeof h)
-        return fail(MHX_EINVAL, "mhx_run_load_state: the blob is a state of sampler kind %d, dim %d, %d chains (%zu bytes); "
+        return mhx_fail(MHX_EINVAL, "mhx_run_load_state: the blob is a state of sampler kind %d, dim %d, %d chains (%zu bytes); "
                                 "this run is kind %d, dim %d, %d chains (%zu bytes)", h.kind, h.dim, h.n, bytes, (int)r->kind, r->dim, r->n, need);
     if (h.flags != (r->flags & MHX_FLAG_STATIC_PROPOSAL) || h.target_kind != r->target->kind || h.prop_kind != r->prop_kind ||
         h.variant != r->variant || h.coop_L != r->coop_L)
-        return fail(MHX_EINVAL, "mhx_run_load_state: the blob was saved by a different configuration (target kind %d, proposal kind %d, "
+        return mhx_fail(MHX_EINVAL, "mhx_run_load_state: the blob was saved by a different configuration (target kind %d, proposal kind %d, "
                                 "static %d, kernel variant %d, %d lane(s) per chain; this run: %d, %d, %d, %d, %d) -- the continuation "
                                 "would not be the saved chain", h.target_kind, h.prop_kind, h.flags, h.variant, h.coop_L,
                     r->target->kind, r->prop_kind, r->flags & MHX_FLAG_STATIC_PROPOSAL, r->variant, r->coop_L);
@@ -1125,7 +1140,7 @@ extern "C" int mhx_run_load_state(mhx_run* r, const void* blob, size_t bytes)
         in += p.bytes;
     }
     // the counter-based streams continue where the saved run stopped: same seed, same global ids, same step counter
-    r->seed = h.seed; r->first_id = h.first_id; r->tau = h.tau;
+    r->seed = h.seed; r->first_id = h.first_id; r->tau = h.tau; r->last_eta = h.last_eta;
     r->initialised = true;
     r->n_saved = 0;
     HIP_TRY(hipMemsetAsync(r->d_acc_total, 0, sizeof(unsigned long long), r->ctx->stream));
@@ -1134,14 +1149,14 @@ extern "C" int mhx_run_load_state(mhx_run* r, const void* blob, size_t bytes)
     return MHX_OK;
 }
 
-extern "C" int mhx_run_stats(mhx_run* r, mhx_stats* out)
+int api_run_stats(mhx_run* r, mhx_stats* out)
 {
-    if (!r || !out) return fail(MHX_EINVAL, "mhx_run_stats: NULL argument");
+    if (!r || !out) return mhx_fail(MHX_EINVAL, "mhx_run_stats: NULL argument");
     *out = r->stats;
     return MHX_OK;
 }
 
-extern "C" int mhx_run_destroy(mhx_run* r)
+int api_run_destroy(mhx_run* r)
 {
     if (!r) return MHX_OK;
     (void)hipSetDevice(r->ctx->device);
@@ -1153,3 +1168,5 @@ extern "C" int mhx_run_destroy(mhx_run* r)
 #include "mhx_api_ram.inc"
 #include "mhx_api_mala.inc"
 #include "mhx_api_diag.inc"
+
+}  // namespace MHX_NS

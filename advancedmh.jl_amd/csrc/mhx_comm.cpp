@@ -1,0 +1,187 @@
+// mhx_comm.cpp -- the collectives of a run sharded over the GPUs of a node, behind the C ABI (include/mhx.h).
+//
+// One process per GPU; chains shard by global id with no data-path collective.  What needs
+// exchanging: the acceptance totals and the R-hat / ESS sums (ONE all-reduce of 3(dim+1)+3 doubles per reporting
+// interval) and, for ONE ensemble sharded over the GPUs, the moved slice of the walkers after every half-step (ONE
+// all-gather of a packed staging buffer).  RCCL over xGMI; librccl is resolved at run time (dlopen) so that libmhx.so
+// loads on a box without it and so that a process that already carries an RCCL (torch ships its own) uses that one.
+#include "mhx_impl.h"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <memory>
+#include <mutex>
+
+namespace {
+
+struct rccl_api {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+
+rccl_api g_rccl;
+std::once_flag g_rccl_once;
+
+void load_rccl()
+{
+    const char* override_path = getenv("MHX_RCCL_LIB");
+    const char* names[] = {override_path, "librccl.so.1", "librccl.so"};
+    // an RCCL that is already part of the process first (RTLD_NOLOAD), then a fresh load
+    for (int pass = 0; pass < 2 && !g_rccl.lib; ++pass)
+        for (const char* n : names)
+            if (n && !g_rccl.lib) g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
+    if (!g_rccl.lib) return;
+    auto sym = [&](const char* s) { return dlsym(g_rccl.lib, s); };
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))sym("ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))sym("ncclCommInitRank");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))sym("ncclCommDestroy");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))sym("ncclAllReduce");
+    g_rccl.AllGather = (decltype(g_rccl.AllGather))sym("ncclAllGather");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
+    g_rccl.ok = g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.CommDestroy && g_rccl.AllReduce && g_rccl.AllGather &&
+                g_rccl.GetErrorString;
+}
+
+int need_rccl(const char* who)
+{
+    std::call_once(g_rccl_once, load_rccl);
+    if (!g_rccl.ok) return mhx_fail(MHX_EHIP, "%s: librccl could not be loaded (set MHX_RCCL_LIB to its path)", who);
+    return MHX_OK;
+}
+
+}  // namespace
+
+struct mhx_comm {
+    int rank = 0, world = 1, device = 0;
+    ncclComm_t comm = nullptr;
+    hipStream_t stream = nullptr;
+    double* d_buf = nullptr;       // staging of the stats all-reduce
+    size_t cap = 0;
+    void* d_stage = nullptr;       // staging of the walker all-gather: [world][stride] bytes
+    size_t stage_cap = 0;
+};
+
+#define RCCL_TRY(expr)                                                                                            \
+    do {                                                                                                           \
+        ncclResult_t r_ = (expr);                                                                                  \
+        if (r_ != ncclSuccess) return mhx_fail(MHX_EHIP, "%s failed: %s", #expr, g_rccl.GetErrorString(r_));      \
+    } while (0)
+#define HIP_TRY(expr)                                                                                             \
+    do {                                                                                                           \
+        hipError_t e_ = (expr);                                                                                    \
+        if (e_ != hipSuccess) return mhx_fail(MHX_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_));           \
+    } while (0)
+
+extern "C" int mhx_comm_unique_id(void* id128)
+{
+    if (!id128) return mhx_fail(MHX_EINVAL, "mhx_comm_unique_id: id is NULL");
+    int rc = need_rccl("mhx_comm_unique_id");
+    if (rc) return rc;
+    ncclUniqueId id;
+    RCCL_TRY(g_rccl.GetUniqueId(&id));
+    static_assert(sizeof id == MHX_COMM_ID_BYTES, "unique id size");
+    memcpy(id128, &id, sizeof id);
+    return MHX_OK;
+}
+
+extern "C" int mhx_comm_init(mhx_ctx* ctx, int rank, int world, const void* id128, mhx_comm** out)
+{
+    if (!ctx || !out || !id128) return mhx_fail(MHX_EINVAL, "mhx_comm_init: NULL argument");
+    if (world < 1 || rank < 0 || rank >= world) return mhx_fail(MHX_EINVAL, "mhx_comm_init: rank %d of %d", rank, world);
+    int rc = need_rccl("mhx_comm_init");
+    if (rc) return rc;
+    int device = 0;
+    if ((rc = mhx_ctx_device(ctx, &device))) return rc;
+    HIP_TRY(hipSetDevice(device));
+    std::unique_ptr<mhx_comm> c(new mhx_comm);
+    c->rank = rank; c->world = world; c->device = device;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    RCCL_TRY(g_rccl.CommInitRank(&c->comm, world, id, rank));
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    *out = c.release();
+    return MHX_OK;
+}
+
+extern "C" int mhx_comm_destroy(mhx_comm* c)
+{
+    if (!c) return MHX_OK;
+    (void)hipSetDevice(c->device);
+    if (c->comm && g_rccl.ok) (void)g_rccl.CommDestroy(c->comm);
+    if (c->d_buf) (void)hipFree(c->d_buf);
+    if (c->d_stage) (void)hipFree(c->d_stage);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return MHX_OK;
+}
+
+extern "C" int mhx_comm_rank(const mhx_comm* c, int* rank, int* world)
+{
+    if (!c) return mhx_fail(MHX_EINVAL, "mhx_comm_rank: comm is NULL");
+    if (rank) *rank = c->rank;
+    if (world) *world = c->world;
+    return MHX_OK;
+}
+
+// sum over the ranks of n doubles given and returned in host memory: the acceptance totals and the R-hat / ESS sums of
+// mhx_run_diagnostics (latency-bound: 24 KB at dim = 1000)
+extern "C" int mhx_comm_allreduce_sum(mhx_comm* c, double* inout, size_t n)
+{
+    if (!c || (!inout && n)) return mhx_fail(MHX_EINVAL, "mhx_comm_allreduce_sum: NULL argument");
+    if (!n) return MHX_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->cap < n) {
+        if (c->d_buf) (void)hipFree(c->d_buf);
+        c->d_buf = nullptr; c->cap = 0;
+        HIP_TRY(hipMalloc(&c->d_buf, n * sizeof(double)));
+        c->cap = n;
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_buf, inout, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    RCCL_TRY(g_rccl.AllReduce(c->d_buf, c->d_buf, n, ncclDouble, ncclSum, c->comm, c->stream));
+    HIP_TRY(hipMemcpyAsync(inout, c->d_buf, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MHX_OK;
+}
+
+// ONE ensemble sharded over the ranks: after mhx_emcee_half_step moved this rank's slice of half `half`, exchange the
+// slices.  The slice of rank r is walkers [cnt r / world, cnt (r+1) / world) of the moving half (cnt = its size):
+// mhx_comm_slice below.  The rows, log-densities and accept bookkeeping of the slice are packed into one staging buffer
+// (fixed stride per rank), all-gathered with ONE collective on the run's stream and unpacked -- no host synchronisation.
+extern "C" int mhx_comm_slice(const mhx_comm* c, int cnt, int* begin, int* count)
+{
+    if (!c) return mhx_fail(MHX_EINVAL, "mhx_comm_slice: comm is NULL");
+    const long b = (long)cnt * c->rank / c->world, e = (long)cnt * (c->rank + 1) / c->world;
+    if (begin) *begin = (int)b;
+    if (count) *count = (int)(e - b);
+    return MHX_OK;
+}
+
+extern "C" int mhx_comm_allgather_walkers(mhx_comm* c, mhx_run* run, int half)
+{
+    if (!c || !run) return mhx_fail(MHX_EINVAL, "mhx_comm_allgather_walkers: NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    size_t stride = 0;
+    void* stream = nullptr;
+    int rc = mhx_emcee_exchange_plan(run, half, c->world, &stride, &stream);
+    if (rc) return rc;
+    const size_t need = stride * (size_t)c->world;
+    if (c->stage_cap < need) {
+        if (c->d_stage) (void)hipFree(c->d_stage);
+        c->d_stage = nullptr; c->stage_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_stage, need));
+        c->stage_cap = need;
+    }
+    if ((rc = mhx_emcee_exchange_pack(run, half, c->rank, c->world, (char*)c->d_stage + stride * (size_t)c->rank))) return rc;
+    if (c->world > 1)
+        RCCL_TRY(g_rccl.AllGather((char*)c->d_stage + stride * (size_t)c->rank, c->d_stage, stride, ncclChar, c->comm, (hipStream_t)stream));
+    return mhx_emcee_exchange_unpack(run, half, c->rank, c->world, c->d_stage, stride);
+}

@@ -18,34 +18,59 @@
 #define MHX_DEV __device__ __forceinline__
 #define MHX_HD __host__ __device__ __forceinline__
 
+// The engine is compiled twice from these headers: mhx_real = float (MHX_REAL64 = 0) and mhx_real = double (MHX_REAL64 = 1:
+// the reference computes in Float64 end to end -- Distributions' rand / logpdf, src/RobustAdaptiveMetropolis.jl:187-196).
+// The two pre-built instantiations live in their own namespaces inside libmhx.so; hiprtc gets -DMHX_REAL64=... and no
+// namespace (one module per specialisation).
+#ifndef MHX_REAL64
+#define MHX_REAL64 0
+#endif
+#if MHX_REAL64
+typedef double mhx_real;
+#define MHX_R(x) x
+#define MHX_NS mhx_f64
+#else
+typedef float mhx_real;
+#define MHX_R(x) x##f
+#define MHX_NS mhx_f32
+#endif
+#define MHX_RB ((unsigned)sizeof(mhx_real))              // bytes per real
+#ifdef __HIPCC_RTC__
+#define MHX_NS_BEGIN
+#define MHX_NS_END
+#else
+#define MHX_NS_BEGIN namespace MHX_NS {
+#define MHX_NS_END }
+#endif
+
 // ordering of ONE wave's LDS traffic (data that only the lanes of a wave exchange: no s_barrier needed)
 #define MHX_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
 typedef unsigned int mhx_u32;
 typedef unsigned long long mhx_u64;
-__device__ __forceinline__ mhx_u32 mhx_f2u_fwd(float f) { return __builtin_bit_cast(mhx_u32, f); }
+MHX_NS_BEGIN
 
 // signature of a user log-density in HIP source form (see include/mhx.h, mhx_target_from_hip_source)
 #define MHX_LOGDENSITY(x, d, data, ndata)                                                          \
     template <class MHX_X>                                                                          \
-    MHX_DEV float mhx_user_logdensity(const MHX_X& x, const int d, const float* __restrict__ data, \
-                                      const int ndata)
+    MHX_DEV mhx_real mhx_user_logdensity(const MHX_X& x, const int d, const mhx_real* __restrict__ data, \
+                                         const int ndata)
 
 // a user gradient in HIP source form: writes g.set(k, dlp/dx_k) and returns lp
 #define MHX_LOGDENSITY_AND_GRADIENT(x, g, d, data, ndata)                                                       \
     template <class MHX_X, class MHX_G>                                                                         \
-    MHX_DEV float mhx_user_logdensity_and_gradient(const MHX_X& x, const MHX_G& g, const int d,                 \
-                                                   const float* __restrict__ data, const int ndata)
+    MHX_DEV mhx_real mhx_user_logdensity_and_gradient(const MHX_X& x, const MHX_G& g, const int d,              \
+                                                      const mhx_real* __restrict__ data, const int ndata)
 
 // wave-uniform base pointer + 32-bit per-lane BYTE offset: lowers to the scalar-base addressing mode
 // (global_load/store v_off, ..., s[base:base+1]) instead of a 64-bit vector address per access
-MHX_DEV float mhx_ld_off(const float* base, mhx_u32 byte_off)
+MHX_DEV mhx_real mhx_ld_off(const mhx_real* base, mhx_u32 byte_off)
 {
-    return *(const float*)((const char*)base + byte_off);
+    return *(const mhx_real*)((const char*)base + byte_off);
 }
-MHX_DEV void mhx_st_off(float* base, mhx_u32 byte_off, float v) { *(float*)((char*)base + byte_off) = v; }
+MHX_DEV void mhx_st_off(mhx_real* base, mhx_u32 byte_off, mhx_real v) { *(mhx_real*)((char*)base + byte_off) = v; }
 
-// A [rows][ld] fp32 slab addressed through a buffer descriptor: wave-uniform base in the SRD, the row
+// A [rows][ld] slab of reals addressed through a buffer descriptor: wave-uniform base in the SRD, the row
 // offset in an SGPR (soffset), the lane's column offset in one VGPR (voffset) -- no per-access 64-bit
 // vector address arithmetic.  `bytes` bounds the slab (hardware range check).
 typedef __amdgpu_buffer_rsrc_t mhx_srd;
@@ -53,10 +78,18 @@ MHX_DEV mhx_srd mhx_make_srd(const void* base, mhx_u32 bytes)
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)bytes, 0x00020000);
 }
+#if MHX_REAL64
+typedef mhx_u32 mhx_u32v2 __attribute__((ext_vector_type(2)));
+MHX_DEV void mhx_srd_store(mhx_srd srd, mhx_u32 lane_byte_off, mhx_u32 row_byte_off, double v)
+{
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(mhx_u32v2, v), srd, (int)lane_byte_off, (int)row_byte_off, 0);
+}
+#else
 MHX_DEV void mhx_srd_store(mhx_srd srd, mhx_u32 lane_byte_off, mhx_u32 row_byte_off, float v)
 {
-    __builtin_amdgcn_raw_buffer_store_b32(mhx_f2u_fwd(v), srd, (int)lane_byte_off, (int)row_byte_off, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(mhx_u32, v), srd, (int)lane_byte_off, (int)row_byte_off, 0);
 }
+#endif
 
 // RNG stream tags: counter word 3 = tag << 28 | block
 #define MHX_STREAM_PROPOSAL 0u
@@ -97,6 +130,196 @@ MHX_DEV mhx_u32x4 mhx_philox(const mhx_philox_key& ks, mhx_u32 c0, mhx_u32 c1, m
     return o;
 }
 
+#if MHX_REAL64
+// ---------------------------------------------------------------------------------------------
+// fp64 arithmetic spec (coefficients: tools/fit_coeffs64.py; the CPU checker restates the same literals)
+MHX_DEV mhx_u64 mhx_d2u(double f) { return __builtin_bit_cast(mhx_u64, f); }
+MHX_DEV double  mhx_u2d(mhx_u64 u) { return __builtin_bit_cast(double, u); }
+MHX_DEV double  mhx_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+#define MHX_LN2_HI 0x1.62e42feep-1
+#define MHX_LN2_LO 0x1.a39ef35793c76p-33
+#define MHX_LOG2E  0x1.71547652b82fep+0
+#define MHX_INF    __builtin_inf()
+#define MHX_NAN    __builtin_nan("")
+
+// m in [sqrt(1/2), sqrt(2)), f = m - 1, s = f / (2 + f), z = s^2:
+//   log(1 + f) = 2 s + s z P(z) = f - hfsq + s (hfsq + z P(z)),  hfsq = f^2 / 2       (one correctly rounded division)
+MHX_DEV double mhx_log_core(mhx_u64 ix, const int eadj)
+{
+    const mhx_u64 t = ix - 0x3fe6a09e667f3bcdull;
+    const long long e = (long long)t >> 52;
+    const double m = mhx_u2d(ix - ((mhx_u64)e << 52));
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    double p = 0x1.2b59b70eb76c6p-3;
+    p = mhx_fma(p, z, 0x1.39fe42e9d4a8ap-3);
+    p = mhx_fma(p, z, 0x1.7462b58e4403ap-3);
+    p = mhx_fma(p, z, 0x1.c71c62e26212ep-3);
+    p = mhx_fma(p, z, 0x1.2492492df3ba9p-2);
+    p = mhx_fma(p, z, 0x1.99999999952ccp-2);
+    p = mhx_fma(p, z, 0x1.5555555555558p-1);
+    const double hfsq = (0.5 * f) * f;
+    const double ef = (double)((int)e + eadj);
+    const double t1 = s * mhx_fma(z, p, hfsq);
+    const double t2 = mhx_fma(ef, MHX_LN2_LO, t1);
+    const double t3 = hfsq - t2;
+    const double t4 = f - t3;
+    return mhx_fma(ef, MHX_LN2_HI, t4);
+}
+// log for a positive, normal, finite argument (every uniform we draw): no special cases
+MHX_DEV double mhx_log_pos(double x) { return mhx_log_core(mhx_d2u(x), 0); }
+// full-range log (user log-densities, emcee's log z)
+MHX_DEV double mhx_log(double x)
+{
+    mhx_u64 ix = mhx_d2u(x);
+    if ((ix << 1) == 0ull) return -MHX_INF;
+    if (ix >> 63) return MHX_NAN;
+    if (ix >= 0x7ff0000000000000ull) return x;
+    int eadj = 0;
+    if (ix < 0x0010000000000000ull) { x = x * 0x1p54; ix = mhx_d2u(x); eadj = -54; }
+    return mhx_log_core(ix, eadj);
+}
+
+MHX_DEV double mhx_exp(double x)
+{
+    if (x != x) return x;
+    if (x > 0x1.62e42fefa39efp+9) return MHX_INF;
+    if (x < -0x1.74910d52d3052p+9) return 0.0;
+    const double n = __builtin_rint(x * MHX_LOG2E);
+    double r = mhx_fma(n, -MHX_LN2_HI, x);
+    r = mhx_fma(n, -MHX_LN2_LO, r);
+    double p = 0x1.61bfaa228dde5p-33;
+    p = mhx_fma(p, r, 0x1.1f7f2776cfaf2p-29);
+    p = mhx_fma(p, r, 0x1.ae642c82e33d5p-26);
+    p = mhx_fma(p, r, 0x1.27e4d41966f2fp-22);
+    p = mhx_fma(p, r, 0x1.71de3a5aa7bb7p-19);
+    p = mhx_fma(p, r, 0x1.a01a01a9e991bp-16);
+    p = mhx_fma(p, r, 0x1.a01a01a0196acp-13);
+    p = mhx_fma(p, r, 0x1.6c16c16c15a68p-10);
+    p = mhx_fma(p, r, 0x1.1111111111111p-7);
+    p = mhx_fma(p, r, 0x1.5555555555557p-5);
+    p = mhx_fma(p, r, 0x1.5555555555555p-3);
+    p = mhx_fma(p, r, 0.5);
+    const double r2 = r * r;
+    double y = mhx_fma(r2, p, r) + 1.0;
+    const int ni = (int)n;
+    const int n1 = ni / 2;
+    const int n2 = ni - n1;
+    y = y * mhx_u2d((mhx_u64)(n1 + 1023) << 52);
+    y = y * mhx_u2d((mhx_u64)(n2 + 1023) << 52);
+    return y;
+}
+
+MHX_DEV double mhx_sqrt(double x) { return __builtin_sqrt(x); }   // correctly rounded (default HIP lowering)
+MHX_DEV double mhx_abs(double x) { return __builtin_fabs(x); }
+MHX_DEV double mhx_sqrt_normal(double x) { return __builtin_sqrt(x); }
+
+// sin/cos of 2 pi a / 2^64, a = hi:lo: integer quadrant reduction; the residual keeps 52 bits so that it is exact in
+// a double (r = (ri >> 10) 2^-54 turns, [-1/8, 1/8)); split leading constants, compensated cos: < 0.7 ulp each
+MHX_DEV void mhx_sincos2pi_u64(mhx_u32 hi, mhx_u32 lo, double& s, double& c)
+{
+    const mhx_u64 a = ((mhx_u64)hi << 32) | lo;
+    const mhx_u64 kk = a + 0x2000000000000000ull;
+    const mhx_u32 q = (mhx_u32)(kk >> 62);
+    const long long ri = (long long)(kk & 0x3fffffffffffffffull) - 0x2000000000000000ll;
+    const long long ti = ri >> 10;                                        // [-2^51, 2^51)
+    // exact integer -> double: 2^52 + 2^51 + ti is representable, subtract the bias again
+    const double r = (mhx_u2d(0x4338000000000000ull + (mhx_u64)ti) - 0x1.8p+52) * 0x1p-54;
+    const double u = r * r;
+    double s1 = -0x1.6cc577dadd922p-1;
+    s1 = mhx_fma(s1, u, 0x1.e8f036bcd3237p+1);
+    s1 = mhx_fma(s1, u, -0x1.e3074d2614b2dp+3);
+    s1 = mhx_fma(s1, u, 0x1.50783486facaap+5);
+    s1 = mhx_fma(s1, u, -0x1.32d2cce62b872p+6);
+    s1 = mhx_fma(s1, u, 0x1.466bc6775aae1p+6);
+    s1 = mhx_fma(s1, u, -0x1.4abbce625be53p+5);
+    const double ts = (r * u) * s1;
+    const double sp = mhx_fma(r, 0x1.921fb54442d18p+2, mhx_fma(r, 0x1.1a62633145c07p-52, ts));
+    double c2 = 0x1.1ebe62242e9d8p-2;
+    c2 = mhx_fma(c2, u, -0x1.b6df855cc99ffp+0);
+    c2 = mhx_fma(c2, u, 0x1.f9d38850e5eedp+2);
+    c2 = mhx_fma(c2, u, -0x1.a6d1f2a15a701p+4);
+    c2 = mhx_fma(c2, u, 0x1.e1f506891b72fp+5);
+    c2 = mhx_fma(c2, u, -0x1.55d3c7e3cbffap+6);
+    c2 = mhx_fma(c2, u, 0x1.03c1f081b5ac4p+6);
+    const double wc = (u * u) * c2;
+    const double vc = mhx_fma(u, -0x1.692b71366cc04p-50, wc);
+    const double ac = mhx_fma(u, -0x1.3bd3cc9be45dep+4, 1.0);
+    const double ec = mhx_fma(u, -0x1.3bd3cc9be45dep+4, 1.0 - ac);
+    const double cp = ac + (vc + ec);
+    const bool odd = (q & 1u) != 0u;
+    const double ss = odd ? cp : sp;
+    const double cc = odd ? sp : cp;
+    const mhx_u64 sneg = (mhx_u64)(q & 2u) << 62;
+    const mhx_u64 cneg = (mhx_u64)((q + 1u) & 2u) << 62;
+    s = mhx_u2d(mhx_d2u(ss) ^ sneg);
+    c = mhx_u2d(mhx_d2u(cc) ^ cneg);
+}
+
+// 52-bit uniforms from two Philox words, k = hi:lo >> 12: (k + 1/2) 2^-52 in (0,1) and k 2^-52 in [0,1), both exact
+MHX_DEV double mhx_u01_open(mhx_u32 hi, mhx_u32 lo)
+{
+    const mhx_u64 k = ((mhx_u64)hi << 20) | (lo >> 12);
+    return mhx_u2d(0x3ff0000000000000ull | k) - 0x1.fffffffffffffp-1;       // (1 + k 2^-52) - (1 - 2^-53)
+}
+MHX_DEV double mhx_u01_half(mhx_u32 hi, mhx_u32 lo)
+{
+    const mhx_u64 k = ((mhx_u64)hi << 20) | (lo >> 12);
+    return mhx_u2d(0x3ff0000000000000ull | k) - 1.0;
+}
+
+// Box-Muller from one Philox block: radius from (x, y), angle from (z, w)
+MHX_DEV void mhx_normal_pair(const mhx_u32x4& w, double& n0, double& n1)
+{
+    const double l = mhx_log_pos(mhx_u01_open(w.x, w.y));
+    const double rad = mhx_sqrt(-2.0 * l);
+    double s, c;
+    mhx_sincos2pi_u64(w.z, w.w, s, c);
+    n0 = rad * c;
+    n1 = rad * s;
+}
+
+// the 4 standard normals 4b..4b+3 of (id, step, stream): Philox blocks 2b and 2b+1
+MHX_DEV void mhx_normal4(const mhx_philox_key& ks, mhx_u32 id_lo, mhx_u32 id_hi, mhx_u32 step,
+                         mhx_u32 stream, mhx_u32 block, double n[4])
+{
+    const mhx_u32x4 w0 = mhx_philox(ks, id_lo, id_hi, step, (stream << 28) | (2u * block));
+    mhx_normal_pair(w0, n[0], n[1]);
+    const mhx_u32x4 w1 = mhx_philox(ks, id_lo, id_hi, step, (stream << 28) | (2u * block + 1u));
+    mhx_normal_pair(w1, n[2], n[3]);
+}
+
+// log of the accept uniform of `step`: one Philox block serves 2 consecutive steps.
+struct mhx_accept_cache { mhx_u32x4 w; mhx_u32 group; };
+#define MHX_ACCEPT_GROUP_SHIFT 1
+
+MHX_DEV double mhx_accept_logu(const mhx_philox_key& ks, mhx_u32 id_lo, mhx_u32 id_hi, mhx_u32 step,
+                               mhx_accept_cache& cache)
+{
+    const mhx_u32 g = step >> 1;
+    if (g != cache.group) {                           // wave-uniform
+        cache.w = mhx_philox(ks, id_lo, id_hi, g, MHX_STREAM_ACCEPT << 28);
+        cache.group = g;
+    }
+    const bool odd = (step & 1u) != 0u;               // wave-uniform select
+    return mhx_log_pos(mhx_u01_open(odd ? cache.w.z : cache.w.x, odd ? cache.w.w : cache.w.y));
+}
+
+// the draws of one stretch move (src/emcee.jl:48,52 partner, :81 stretch uniform, :93 accept)
+struct mhx_emcee_draws { mhx_u32 partner; double u, logu; };
+MHX_DEV mhx_emcee_draws mhx_emcee_draw(const mhx_philox_key& ks, mhx_u32 walker, mhx_u32 ens, mhx_u32 sweep)
+{
+    const mhx_u32x4 w = mhx_philox(ks, walker, ens, sweep, MHX_STREAM_EMCEE << 28);
+    const mhx_u32x4 v = mhx_philox(ks, walker, ens, sweep, (MHX_STREAM_EMCEE << 28) | 1u);
+    mhx_emcee_draws o;
+    o.partner = w.x;
+    o.u = mhx_u01_half(w.y, w.z);
+    o.logu = mhx_log_pos(mhx_u01_open(v.x, v.y));
+    return o;
+}
+#else
 // ---------------------------------------------------------------------------------------------
 MHX_DEV mhx_u32 mhx_f2u(float f) { return __builtin_bit_cast(mhx_u32, f); }
 MHX_DEV float   mhx_u2f(mhx_u32 u) { return __builtin_bit_cast(float, u); }
@@ -190,6 +413,7 @@ MHX_DEV float mhx_exp(float x)
 }
 
 MHX_DEV float mhx_sqrt(float x) { return __builtin_sqrtf(x); }   // correctly rounded (default HIP lowering)
+MHX_DEV float mhx_abs(float x) { return __builtin_fabsf(x); }
 
 // Correctly rounded sqrt for x that is +-0 or a NORMAL positive number: the hardware estimate (1 ulp) and
 // the same two-residual fix-up hipcc emits, without its denormal pre-scaling and class test (7 of 17
@@ -272,3 +496,19 @@ MHX_DEV float mhx_accept_logu(const mhx_philox_key& ks, mhx_u32 id_lo, mhx_u32 i
     const mhx_u32 k = j == 0u ? cache.w.x : (j == 1u ? cache.w.y : (j == 2u ? cache.w.z : cache.w.w));
     return mhx_log_pos(mhx_u01_open(k));
 }
+
+#define MHX_ACCEPT_GROUP_SHIFT 2
+
+// the draws of one stretch move (src/emcee.jl:48,52 partner, :81 stretch uniform, :93 accept): one Philox block
+struct mhx_emcee_draws { mhx_u32 partner; float u, logu; };
+MHX_DEV mhx_emcee_draws mhx_emcee_draw(const mhx_philox_key& ks, mhx_u32 walker, mhx_u32 ens, mhx_u32 sweep)
+{
+    const mhx_u32x4 w = mhx_philox(ks, walker, ens, sweep, MHX_STREAM_EMCEE << 28);
+    mhx_emcee_draws o;
+    o.partner = w.x;
+    o.u = mhx_u01_half(w.y);
+    o.logu = mhx_log_pos(mhx_u01_open(w.z));
+    return o;
+}
+#endif
+MHX_NS_END

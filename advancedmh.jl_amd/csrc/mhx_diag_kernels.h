@@ -8,15 +8,17 @@
 #pragma once
 #include "mhx_device_math.h"
 
+MHX_NS_BEGIN
+
 // grid (ceil(C/256), dim+1): one thread per (chain, parameter)
-MHX_DEV void mhx_diag_moments_body(const float* __restrict__ samples, const long N, const int d1, const long C,
+MHX_DEV void mhx_diag_moments_body(const mhx_real* __restrict__ samples, const long N, const int d1, const long C,
                                    double* __restrict__ mean, double* __restrict__ sums /* [3][d1] */, double* red)
 {
     const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int p = blockIdx.y;
     double m = 0.0, v = 0.0;
     if (c < C) {
-        const float* s = samples + (long)p * C + c;
+        const mhx_real* s = samples + (long)p * C + c;
         const long stride = (long)d1 * C;
         double sum = 0.0;
         for (long t = 0; t < N; ++t) sum += (double)s[t * stride];
@@ -42,7 +44,7 @@ MHX_DEV void mhx_diag_moments_body(const float* __restrict__ samples, const long
 }
 
 // grid (ceil(nc/64), dim+1, max_lag+1), block 64: acov[k][p] += sum_{c<nc} sum_t (x_t-m_c)(x_{t+k}-m_c)
-MHX_DEV void mhx_diag_autocov_body(const float* __restrict__ samples, const long N, const int d1, const long C,
+MHX_DEV void mhx_diag_autocov_body(const mhx_real* __restrict__ samples, const long N, const int d1, const long C,
                                    const long nc, const double* __restrict__ mean, double* __restrict__ acov)
 {
     const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -50,15 +52,15 @@ MHX_DEV void mhx_diag_autocov_body(const float* __restrict__ samples, const long
     const long k = blockIdx.z;
     double acc = 0.0;
     if (c < nc && k < N) {
-        const float* s = samples + (long)p * C + c;
+        const mhx_real* s = samples + (long)p * C + c;
         const long stride = (long)d1 * C;
-        const float m = (float)mean[(long)p * C + c];
-        float a0 = 0.0f, a1 = 0.0f;
+        const mhx_real m = (mhx_real)mean[(long)p * C + c];
+        mhx_real a0 = MHX_R(0.0), a1 = MHX_R(0.0);
         long t = 0;
         for (; t + 1 < N - k; t += 2) {
             a0 = mhx_fma(s[t * stride] - m, s[(t + k) * stride] - m, a0);
             a1 = mhx_fma(s[(t + 1) * stride] - m, s[(t + 1 + k) * stride] - m, a1);
-            if ((t & 1023) == 1022) { acc += (double)a0 + (double)a1; a0 = a1 = 0.0f; }
+            if ((t & 1023) == 1022) { acc += (double)a0 + (double)a1; a0 = a1 = MHX_R(0.0); }
         }
         for (; t < N - k; ++t) a0 = mhx_fma(s[t * stride] - m, s[(t + k) * stride] - m, a0);
         acc += (double)a0 + (double)a1;
@@ -68,7 +70,7 @@ MHX_DEV void mhx_diag_autocov_body(const float* __restrict__ samples, const long
 }
 
 // the same three sums from running moments (runs that kept no sample tensor): m_c = mean, s2_c = M2/(n-1)
-MHX_DEV void mhx_diag_from_moments_body(const float* __restrict__ mom_mean, const float* __restrict__ mom_m2,
+MHX_DEV void mhx_diag_from_moments_body(const mhx_real* __restrict__ mom_mean, const mhx_real* __restrict__ mom_m2,
                                         const long nsamp, const int d1, const long C, double* __restrict__ sums,
                                         double* red)
 {
@@ -92,3 +94,4 @@ MHX_DEV void mhx_diag_from_moments_body(const float* __restrict__ mom_mean, cons
         atomicAdd(&sums[(long)threadIdx.x * d1 + p], x);
     }
 }
+MHX_NS_END

@@ -20,24 +20,26 @@
 #pragma once
 #include "mhx_targets.h"
 
+MHX_NS_BEGIN
+
 struct mhx_emcee_args {
-    float* x;                 // [dim][W]   (ABI layout; the lane-per-walker kernels work on it)
-    float* xw;                // [W][round4(dim)] walker-major copy, zero padded: the state of the cooperative kernel
-    float* lp;                // [W]
+    mhx_real* x;                 // [dim][W]   (ABI layout; the lane-per-walker kernels work on it)
+    mhx_real* xw;                // [W][round4(dim)] walker-major copy, zero padded: the state of the cooperative kernel
+    mhx_real* lp;                // [W]
     mhx_u32* acc_count;       // [W]
     mhx_u64* acc_total;
-    float* samples;           // [slots][dim+1][W] or null
+    mhx_real* samples;           // [slots][dim+1][W] or null
     unsigned char* accepted;  // [slots][W] or null
     unsigned char* last_acc;  // [W]
-    float* ybuf;              // [dim][W] candidate scratch (run-time-dimension kernel)
+    mhx_real* ybuf;              // [dim][W] candidate scratch (run-time-dimension kernel)
     mhx_u64 seed;
     mhx_u64 ensemble_id;
     int nwalkers;
     int dim;
     int target_kind;
     int ntparams;
-    float tconst;
-    float stretch;            // a
+    mhx_real tconst;
+    mhx_real stretch;            // a
     mhx_u32 sweep;            // RNG step counter of this sweep
     int half;                 // 0: walkers [0, W/2) move; 1: walkers [W/2, W) move
     long save_slot;           // slot to record this sweep into, or -1
@@ -46,14 +48,14 @@ struct mhx_emcee_args {
                               // one slice per rank and exchanges the slices; a single GPU moves [0, size of the half))
 };
 
-typedef float mhx_e4 __attribute__((ext_vector_type(4)));
+typedef mhx_real mhx_e4 __attribute__((ext_vector_type(4)));
 
 // D > 0: compile-time dimension, candidate in registers; the walkers are read from the walker-major copy
 // [W][round4(D)] (a.xw): a walker and its partner are one contiguous row each, float4 loads, 4 cache lines
 // at d = 50 where the [dim][W] layout touches 50 per partner.  D == 0: run-time dimension, [dim][W] state,
 // candidate staged in ybuf.
 template <int D, int TK>
-MHX_DEV void mhx_emcee_half_body(const mhx_emcee_args& a, const float* __restrict__ tparams)
+MHX_DEV void mhx_emcee_half_body(const mhx_emcee_args& a, const mhx_real* __restrict__ tparams)
 {
     const int W = a.nwalkers;
     const int halfW = W / 2;
@@ -68,19 +70,19 @@ MHX_DEV void mhx_emcee_half_body(const mhx_emcee_args& a, const float* __restric
     const long ld = W;
 
     const mhx_philox_key ks = mhx_philox_schedule(a.seed);
-    const mhx_u32x4 w = mhx_philox(ks, (mhx_u32)i, (mhx_u32)a.ensemble_id, a.sweep, MHX_STREAM_EMCEE << 28);
+    const mhx_emcee_draws dr = mhx_emcee_draw(ks, (mhx_u32)i, (mhx_u32)a.ensemble_id, a.sweep);
     // partner from the complementary half (src/emcee.jl:48,52 draws from all other walkers)
-    const int j = ostart + (int)(((mhx_u64)w.x * (mhx_u64)(mhx_u32)osize) >> 32);
+    const int j = ostart + (int)(((mhx_u64)dr.partner * (mhx_u64)(mhx_u32)osize) >> 32);
     // src/emcee.jl:81  z = ((a - 1) * rand(rng) + 1)^2 / a
-    const float u = mhx_u01_half(w.y);
-    const float tt = mhx_fma(a.stretch - 1.0f, u, 1.0f);
-    const float z = (tt * tt) / a.stretch;
-    const float alphamult = (float)(d - 1) * mhx_log(z);                // :82
+    const mhx_real u = dr.u;
+    const mhx_real tt = mhx_fma(a.stretch - MHX_R(1.0), u, MHX_R(1.0));
+    const mhx_real z = (tt * tt) / a.stretch;
+    const mhx_real alphamult = (mhx_real)(d - 1) * mhx_log(z);                // :82
 
-    float lpy;
+    mhx_real lpy;
     constexpr int XP = D > 0 ? ((D + 3) & ~3) : 4;
-    float yreg[XP];
-    float* ys = a.ybuf + i;
+    mhx_real yreg[XP];
+    mhx_real* ys = a.ybuf + i;
     mhx_e4* xrow_i = D > 0 ? (mhx_e4*)(a.xw + (long)i * XP) : nullptr;
     if (D > 0) {
         const mhx_e4* xrow_j = (const mhx_e4*)(a.xw + (long)j * XP);
@@ -95,8 +97,8 @@ MHX_DEV void mhx_emcee_half_body(const mhx_emcee_args& a, const float* __restric
         lpy = mhx_target_eval<TK>(TK, yreg, D, tparams, a.ntparams, a.tconst);
     } else {
         for (int k = 0; k < d; ++k) {
-            const float xi = a.x[(long)k * ld + i];
-            const float xj = a.x[(long)k * ld + j];
+            const mhx_real xi = a.x[(long)k * ld + i];
+            const mhx_real xj = a.x[(long)k * ld + j];
             ys[(long)k * ld] = mhx_fma(z, xi - xj, xj);
         }
         mhx_strided_x yv;
@@ -104,9 +106,9 @@ MHX_DEV void mhx_emcee_half_body(const mhx_emcee_args& a, const float* __restric
         yv.ld = ld;
         lpy = mhx_target_eval<TK>(a.target_kind, yv, d, tparams, a.ntparams, a.tconst);
     }
-    const float lpi = a.lp[i];
-    const float alpha = (alphamult + lpy) - lpi;                        // :91
-    const float logu = mhx_log_pos(mhx_u01_open(w.z));
+    const mhx_real lpi = a.lp[i];
+    const mhx_real alpha = (alphamult + lpy) - lpi;                        // :91
+    const mhx_real logu = dr.logu;
     const bool acc = logu <= alpha;                                     // :93  -randexp <= alpha (non-strict)
     if (acc) {
         if (D > 0) {
@@ -124,7 +126,7 @@ MHX_DEV void mhx_emcee_half_body(const mhx_emcee_args& a, const float* __restric
     }
     a.last_acc[i] = acc ? 1 : 0;
     if (a.save_slot >= 0) {
-        float* row = a.samples + a.save_slot * (long)(d + 1) * ld + i;
+        mhx_real* row = a.samples + a.save_slot * (long)(d + 1) * ld + i;
         if (D > 0) {
 #pragma unroll
             for (int k = 0; k < D; ++k) row[(long)k * ld] = acc ? yreg[k] : a.xw[(long)i * XP + k];
@@ -140,7 +142,7 @@ MHX_DEV void mhx_emcee_half_body(const mhx_emcee_args& a, const float* __restric
 
 // initial walkers (src/emcee.jl:6-8): W log-density evaluations, accepted = false
 template <int TK>
-MHX_DEV void mhx_emcee_init_body(const mhx_emcee_args& a, const float* __restrict__ tparams)
+MHX_DEV void mhx_emcee_init_body(const mhx_emcee_args& a, const mhx_real* __restrict__ tparams)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.nwalkers) return;
@@ -185,7 +187,7 @@ struct mhx_emcee_geom {
 // this thread's float4 of the factor image, straight from the packed factor: unconditional, index-clamped
 // loads (zero selected afterwards), so that hipcc puts ALL of them in flight at once
 template <int D, int L>
-MHX_DEV void mhx_dense_image_load(const float* __restrict__ A, mhx_e4 (&areg)[mhx_emcee_geom<D, L>::NK][mhx_emcee_geom<D, L>::maxit()])
+MHX_DEV void mhx_dense_image_load(const mhx_real* __restrict__ A, mhx_e4 (&areg)[mhx_emcee_geom<D, L>::NK][mhx_emcee_geom<D, L>::maxit()])
 {
     typedef mhx_emcee_geom<D, L> GEO;
 #pragma unroll
@@ -197,12 +199,12 @@ MHX_DEV void mhx_dense_image_load(const float* __restrict__ A, mhx_e4 (&areg)[mh
             const int gg = ok ? g : 0;
             const int jj4 = gg / L, r = gg % L + L * m;
             const int base = r < D ? r * (r + 1) / 2 : 0;
-            float e[4];
+            mhx_real e[4];
 #pragma unroll
             for (int cidx = 0; cidx < 4; ++cidx) {
                 const bool in = ok && r < D && 4 * jj4 + cidx <= r;
-                const float a0 = A[in ? base + 4 * jj4 + cidx : 0];
-                e[cidx] = in ? a0 : 0.0f;
+                const mhx_real a0 = A[in ? base + 4 * jj4 + cidx : 0];
+                e[cidx] = in ? a0 : MHX_R(0.0);
             }
             areg[m][it].x = e[0]; areg[m][it].y = e[1]; areg[m][it].z = e[2]; areg[m][it].w = e[3];
         }
@@ -224,7 +226,7 @@ MHX_DEV void mhx_dense_image_store(const mhx_e4 (&areg)[mhx_emcee_geom<D, L>::NK
 // the whole image, in batches of row sets that keep at most 16 float4 of staging registers per thread (one
 // batch up to d = 128; a persistent kernel pays the extra round trips of a larger image once per launch)
 template <int D, int L>
-MHX_DEV void mhx_dense_image_fill(const float* __restrict__ A, mhx_e4* img4)
+MHX_DEV void mhx_dense_image_fill(const mhx_real* __restrict__ A, mhx_e4* img4)
 {
     typedef mhx_emcee_geom<D, L> GEO;
     constexpr int GB = GEO::maxit() >= 16 ? 1 : 16 / GEO::maxit();          // row sets per batch
@@ -242,12 +244,12 @@ MHX_DEV void mhx_dense_image_fill(const float* __restrict__ A, mhx_e4* img4)
                     const int gg = ok ? g : 0;
                     const int jj4 = gg / L, r = gg % L + L * m;
                     const int base = r < D ? r * (r + 1) / 2 : 0;
-                    float e[4];
+                    mhx_real e[4];
 #pragma unroll
                     for (int cidx = 0; cidx < 4; ++cidx) {
                         const bool in = ok && r < D && 4 * jj4 + cidx <= r;
-                        const float a0 = A[in ? base + 4 * jj4 + cidx : 0];
-                        e[cidx] = in ? a0 : 0.0f;
+                        const mhx_real a0 = A[in ? base + 4 * jj4 + cidx : 0];
+                        e[cidx] = in ? a0 : MHX_R(0.0);
                     }
                     regs[i][it].x = e[0]; regs[i][it].y = e[1]; regs[i][it].z = e[2]; regs[i][it].w = e[3];
                 }
@@ -269,12 +271,12 @@ MHX_DEV void mhx_dense_image_fill(const float* __restrict__ A, mhx_e4* img4)
 
 // rows l, l+L, ... of (lower-triangular image) x (row vector in LDS): ascending columns, one fmaf chain per row
 template <int D, int L>
-MHX_DEV void mhx_dense_rows(const mhx_e4* img4, const mhx_e4* row4, const int l, float (&w)[mhx_emcee_geom<D, L>::NK])
+MHX_DEV void mhx_dense_rows(const mhx_e4* img4, const mhx_e4* row4, const int l, mhx_real (&w)[mhx_emcee_geom<D, L>::NK])
 {
     typedef mhx_emcee_geom<D, L> GEO;
 #pragma unroll
     for (int m = 0; m < GEO::NK; ++m) {
-        float acc = 0.0f;
+        mhx_real acc = MHX_R(0.0);
 #pragma unroll
         for (int jj4 = 0; jj4 < GEO::len4(m); ++jj4) {
             const mhx_e4 av = img4[GEO::off4(m) + jj4 * L + l];
@@ -290,19 +292,19 @@ MHX_DEV void mhx_dense_rows(const mhx_e4* img4, const mhx_e4* row4, const int l,
 // lane l's share of |A y|^2: its rows of A y squared and summed in ascending row order; the L shares meet in the
 // caller's butterfly
 template <int D, int L>
-MHX_DEV float mhx_dense_rows_sq(const mhx_e4* Ash4, const mhx_e4* yrow4, const int l)
+MHX_DEV mhx_real mhx_dense_rows_sq(const mhx_e4* Ash4, const mhx_e4* yrow4, const int l)
 {
     typedef mhx_emcee_geom<D, L> GEO;
-    float w[GEO::NK];
+    mhx_real w[GEO::NK];
     mhx_dense_rows<D, L>(Ash4, yrow4, l, w);
-    float q = 0.0f;
+    mhx_real q = MHX_R(0.0);
 #pragma unroll
     for (int m = 0; m < GEO::NK; ++m) q = (l + L * m) < D ? mhx_fma(w[m], w[m], q) : q;
     return q;
 }
 
 template <int D, int L>
-MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const float* __restrict__ A, float* ysh_all, mhx_e4* Ash4)
+MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const mhx_real* __restrict__ A, mhx_real* ysh_all, mhx_e4* Ash4)
 {
     typedef mhx_emcee_geom<D, L> GEO;
     constexpr int CPW = 64 / L;                  // walkers per wave
@@ -315,7 +317,7 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const float* __restric
     mhx_e4 areg[ONE_BATCH ? NK : 1][GEO::maxit()];
     if constexpr (ONE_BATCH) mhx_dense_image_load<D, L>(A, areg);
     const int wave = threadIdx.x >> 6;
-    float* ysh = ysh_all + wave * (CPW * DP4);
+    mhx_real* ysh = ysh_all + wave * (CPW * DP4);
     const int W = a.nwalkers;
     const int halfW = W / 2;
     const int lo = a.half ? halfW : 0;
@@ -331,24 +333,24 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const float* __restric
     const long ld = W;
 
     const mhx_philox_key ks = mhx_philox_schedule(a.seed);
-    const mhx_u32x4 w4 = mhx_philox(ks, (mhx_u32)i, (mhx_u32)a.ensemble_id, a.sweep, MHX_STREAM_EMCEE << 28);
-    const int j = ostart + (int)(((mhx_u64)w4.x * (mhx_u64)(mhx_u32)osize) >> 32);
-    const float u = mhx_u01_half(w4.y);
-    const float tt = mhx_fma(a.stretch - 1.0f, u, 1.0f);
-    const float z = (tt * tt) / a.stretch;                               // src/emcee.jl:81
-    const float alphamult = (float)(D - 1) * mhx_log(z);                 // :82
+    const mhx_emcee_draws dr = mhx_emcee_draw(ks, (mhx_u32)i, (mhx_u32)a.ensemble_id, a.sweep);
+    const int j = ostart + (int)(((mhx_u64)dr.partner * (mhx_u64)(mhx_u32)osize) >> 32);
+    const mhx_real u = dr.u;
+    const mhx_real tt = mhx_fma(a.stretch - MHX_R(1.0), u, MHX_R(1.0));
+    const mhx_real z = (tt * tt) / a.stretch;                               // src/emcee.jl:81
+    const mhx_real alphamult = (mhx_real)(D - 1) * mhx_log(z);                 // :82
 
     // the move, element-wise on float4 slices of the two rows (lane l: float4 l, l+L, ...); the zero pad of
     // the rows gives the zero pad of y that multiplies the zeros of the factor image
     constexpr int NQ = GEO::NQ, NQL = GEO::NQL;
     mhx_e4 xs[NQL], ysl[NQL];
-    float* yrow = ysh + cw * DP4;
+    mhx_real* yrow = ysh + cw * DP4;
     mhx_e4* xrow_i = (mhx_e4*)(a.xw + (long)i * GEO::XP);
     const mhx_e4* xrow_j = (const mhx_e4*)(a.xw + (long)j * GEO::XP);
 #pragma unroll
     for (int m = 0; m < NQL; ++m) {
         const int q4 = l + L * m;
-        const mhx_e4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+        const mhx_e4 zero4 = {MHX_R(0.0), MHX_R(0.0), MHX_R(0.0), MHX_R(0.0)};
         xs[m] = zero4;
         ysl[m] = zero4;
         if (q4 < NQ) {
@@ -365,13 +367,13 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const float* __restric
     if constexpr (ONE_BATCH) mhx_dense_image_store<D, L>(areg, Ash4);
     else mhx_dense_image_fill<D, L>(A, Ash4);
     __syncthreads();
-    float q = mhx_dense_rows_sq<D, L>(Ash4, (const mhx_e4*)yrow, l);
+    mhx_real q = mhx_dense_rows_sq<D, L>(Ash4, (const mhx_e4*)yrow, l);
 #pragma unroll
     for (int off = 1; off < L; off <<= 1) q = q + __shfl_xor(q, off * CPW, 64);
-    const float lpy = mhx_fma(-0.5f, q, a.tconst);
-    const float lpi = a.lp[i];
-    const float alpha = (alphamult + lpy) - lpi;                         // :91
-    const float logu = mhx_log_pos(mhx_u01_open(w4.z));
+    const mhx_real lpy = mhx_fma(-MHX_R(0.5), q, a.tconst);
+    const mhx_real lpi = a.lp[i];
+    const mhx_real alpha = (alphamult + lpy) - lpi;                         // :91
+    const mhx_real logu = dr.logu;
     const bool acc = logu <= alpha;                                      // :93
     if (valid) {
         if (acc) {
@@ -383,7 +385,7 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const float* __restric
         if (a.save_slot >= 0) {
             // the record is [dim+1][W] (walker fastest): 16-byte runs per dimension from this wave's walkers
             // (staging it through LDS for 64-byte runs measured no faster)
-            float* row = a.samples + a.save_slot * (long)(D + 1) * ld + i;
+            mhx_real* row = a.samples + a.save_slot * (long)(D + 1) * ld + i;
 #pragma unroll
             for (int m = 0; m < NQL; ++m) {
                 const int k = 4 * (l + L * m);
@@ -409,20 +411,21 @@ extern "C" __global__ void __launch_bounds__(64 * MHX_EMCEE_COOP_WAVES)
 #else
 extern "C" __global__ void __launch_bounds__(64)
 #endif
-mhx_jit_emcee_half(const mhx_emcee_args a, const float* __restrict__ tparams)
+mhx_jit_emcee_half(const mhx_emcee_args a, const mhx_real* __restrict__ tparams)
 {
 #if MHX_JIT_L > 1
     // dynamic LDS (up to 160 KB per block on gfx950): [candidate rows][factor image]
     extern __shared__ mhx_e4 mhx_emcee_lds[];
     constexpr int YS4 = MHX_EMCEE_COOP_WAVES * (64 / MHX_JIT_L) * mhx_emcee_geom<MHX_JIT_DIM, MHX_JIT_L>::DP4 / 4;
-    mhx_emcee_coop_body<MHX_JIT_DIM, MHX_JIT_L>(a, tparams, (float*)mhx_emcee_lds, mhx_emcee_lds + YS4);
+    mhx_emcee_coop_body<MHX_JIT_DIM, MHX_JIT_L>(a, tparams, (mhx_real*)mhx_emcee_lds, mhx_emcee_lds + YS4);
 #else
     mhx_emcee_half_body<MHX_JIT_DIM, MHX_JIT_TK>(a, tparams);
 #endif
 }
 extern "C" __global__ void __launch_bounds__(256)
-mhx_jit_emcee_init(const mhx_emcee_args a, const float* __restrict__ tparams)
+mhx_jit_emcee_init(const mhx_emcee_args a, const mhx_real* __restrict__ tparams)
 {
     mhx_emcee_init_body<MHX_JIT_TK>(a, tparams);
 }
 #endif
+MHX_NS_END

@@ -13,79 +13,81 @@
 #pragma once
 #include "mhx_targets.h"
 
+MHX_NS_BEGIN
+
 // read/write view of one chain's column inside a [dim][ld] slab
 struct mhx_strided_rw {
-    float* base;
+    mhx_real* base;
     long ld;
-    MHX_DEV float operator[](int k) const { return base[(long)k * ld]; }
-    MHX_DEV void set(int k, float v) const { base[(long)k * ld] = v; }
+    MHX_DEV mhx_real operator[](int k) const { return base[(long)k * ld]; }
+    MHX_DEV void set(int k, mhx_real v) const { base[(long)k * ld] = v; }
 };
 
 // value and gradient of the catalogue targets; same accumulation order as mhx_target_eval
 template <int KIND, class X, class GO>
-MHX_DEV float mhx_target_grad(int kind, const X& x, const GO& g, const int d, const float* __restrict__ p,
-                              const int np, const float cst)
+MHX_DEV mhx_real mhx_target_grad(int kind, const X& x, const GO& g, const int d, const mhx_real* __restrict__ p,
+                              const int np, const mhx_real cst)
 {
     const int k_ = (KIND == MHX_TARGET_DYNAMIC) ? kind : KIND;
     switch (k_) {
     case MHX_TARGET_ISO_GAUSS: {
-        float q = 0.0f;
-        for (int k = 0; k < d; ++k) { const float v = x[k]; q = mhx_fma(v, v, q); g.set(k, -v); }
-        return mhx_fma(-0.5f, q, cst);
+        mhx_real q = MHX_R(0.0);
+        for (int k = 0; k < d; ++k) { const mhx_real v = x[k]; q = mhx_fma(v, v, q); g.set(k, -v); }
+        return mhx_fma(-MHX_R(0.5), q, cst);
     }
     case MHX_TARGET_CORR_GAUSS: {                      // grad = -A^T (A x)
-        float q = 0.0f;
+        mhx_real q = MHX_R(0.0);
         int off = 0;
         for (int i = 0; i < d; ++i) {                  // w = A x, parked in g
-            float w = 0.0f;
+            mhx_real w = MHX_R(0.0);
             for (int j = 0; j <= i; ++j) w = mhx_fma(p[off + j], x[j], w);
             g.set(i, w);
             q = mhx_fma(w, w, q);
             off += i + 1;
         }
         for (int j = 0; j < d; ++j) {                  // g_j = -sum_{i>=j} A_ij w_i (ascending i), in place
-            float acc = 0.0f;
+            mhx_real acc = MHX_R(0.0);
             for (int i = j; i < d; ++i) acc = mhx_fma(p[(long)i * (i + 1) / 2 + j], g[i], acc);
             g.set(j, -acc);
         }
-        return mhx_fma(-0.5f, q, cst);
+        return mhx_fma(-MHX_R(0.5), q, cst);
     }
     case MHX_TARGET_IID_NORMAL: {
-        const float mu = x[0], sigma = x[1];
-        if (!(sigma > 0.0f)) { g.set(0, 0.0f); g.set(1, 0.0f); return -MHX_INF; }
-        const float inv = 1.0f / sigma;
-        float acc = 0.0f, s1 = 0.0f;
+        const mhx_real mu = x[0], sigma = x[1];
+        if (!(sigma > MHX_R(0.0))) { g.set(0, MHX_R(0.0)); g.set(1, MHX_R(0.0)); return -MHX_INF; }
+        const mhx_real inv = MHX_R(1.0) / sigma;
+        mhx_real acc = MHX_R(0.0), s1 = MHX_R(0.0);
         for (int i = 0; i < np; ++i) {
-            const float z = (p[i] - mu) / sigma;
+            const mhx_real z = (p[i] - mu) / sigma;
             acc = mhx_fma(z, z, acc);
             s1 = s1 + z;
         }
-        const float nf = (float)np;
+        const mhx_real nf = (mhx_real)np;
         g.set(0, s1 * inv);
         g.set(1, (acc - nf) * inv);
-        const float tt = mhx_log(sigma) + MHX_HALF_LOG_2PI;
-        return mhx_fma(-0.5f, acc, -(nf * tt));
+        const mhx_real tt = mhx_log(sigma) + MHX_HALF_LOG_2PI;
+        return mhx_fma(-MHX_R(0.5), acc, -(nf * tt));
     }
     case MHX_TARGET_BANANA: {
-        const float b = p[0];
-        const float x0 = x[0];
-        float q = (x0 * x0) * 0.01f;
-        const float u = mhx_fma(b, mhx_fma(x0, x0, -100.0f), x[1]);
+        const mhx_real b = p[0];
+        const mhx_real x0 = x[0];
+        mhx_real q = (x0 * x0) * MHX_R(0.01);
+        const mhx_real u = mhx_fma(b, mhx_fma(x0, x0, -MHX_R(100.0)), x[1]);
         q = mhx_fma(u, u, q);
-        g.set(0, -(mhx_fma(x0, 0.01f, (2.0f * b) * (u * x0))));
+        g.set(0, -(mhx_fma(x0, MHX_R(0.01), (MHX_R(2.0) * b) * (u * x0))));
         g.set(1, -u);
-        for (int k = 2; k < d; ++k) { const float v = x[k]; q = mhx_fma(v, v, q); g.set(k, -v); }
-        return mhx_fma(-0.5f, q, cst);
+        for (int k = 2; k < d; ++k) { const mhx_real v = x[k]; q = mhx_fma(v, v, q); g.set(k, -v); }
+        return mhx_fma(-MHX_R(0.5), q, cst);
     }
     case MHX_TARGET_FUNNEL: {
-        const float v = x[0];
-        float q = 0.0f;
-        for (int k = 1; k < d; ++k) { const float xk = x[k]; q = mhx_fma(xk, xk, q); }
-        const float ev = mhx_exp(-v);
-        float r = (v * v) * 0x1.c71c72p-5f;
-        r = mhx_fma(0.5f * (float)(d - 1), v, r);
-        r = mhx_fma(0.5f * ev, q, r);
-        g.set(0, mhx_fma(0.5f * ev, q, -(mhx_fma(v, 0x1.c71c72p-4f, 0.5f * (float)(d - 1)))));
+        const mhx_real v = x[0];
+        mhx_real q = MHX_R(0.0);
+        for (int k = 1; k < d; ++k) { const mhx_real xk = x[k]; q = mhx_fma(xk, xk, q); }
+        const mhx_real ev = mhx_exp(-v);
+        mhx_real r = (v * v) * MHX_ONE_18;
+        r = mhx_fma(MHX_R(0.5) * (mhx_real)(d - 1), v, r);
+        r = mhx_fma(MHX_R(0.5) * ev, q, r);
+        g.set(0, mhx_fma(MHX_R(0.5) * ev, q, -(mhx_fma(v, MHX_ONE_9, MHX_R(0.5) * (mhx_real)(d - 1)))));
         for (int k = 1; k < d; ++k) g.set(k, -(ev * x[k]));
         return cst - r;
     }
@@ -99,17 +101,17 @@ MHX_DEV float mhx_target_grad(int kind, const X& x, const GO& g, const int d, co
 }
 
 struct mhx_mala_args {
-    float* x;                 // [dim][ld]
-    float* gx;                // [dim][ld] gradient at x (GradientTransition.gradient, src/MALA.jl:14-19)
-    float* lp;
+    mhx_real* x;                 // [dim][ld]
+    mhx_real* gx;                // [dim][ld] gradient at x (GradientTransition.gradient, src/MALA.jl:14-19)
+    mhx_real* lp;
     mhx_u32* acc_count;
     mhx_u64* acc_total;
-    float* samples;
+    mhx_real* samples;
     unsigned char* accepted;
     unsigned char* last_acc;
-    float* ybuf;              // [dim][ld] candidate
-    float* gybuf;             // [dim][ld] gradient at the candidate
-    float* zbuf;              // [dim][ld] proposal noise
+    mhx_real* ybuf;              // [dim][ld] candidate
+    mhx_real* gybuf;             // [dim][ld] gradient at the candidate
+    mhx_real* zbuf;              // [dim][ld] proposal noise
     mhx_u64 seed;
     mhx_u64 first_chain;
     int nchains;
@@ -117,10 +119,10 @@ struct mhx_mala_args {
     int dim;
     int target_kind;
     int ntparams;
-    float tconst;
-    float sigma;              // sqrt(sigma2)
-    float h;                  // sigma2 / 2
-    float hs;                 // sigma / 2
+    mhx_real tconst;
+    mhx_real sigma;              // sqrt(sigma2)
+    mhx_real h;                  // sigma2 / 2
+    mhx_real hs;                 // sigma / 2
     mhx_u32 step0;
     int nsteps;
     mhx_u32 save_next;
@@ -129,7 +131,7 @@ struct mhx_mala_args {
 };
 
 template <int TK>
-MHX_DEV void mhx_mala_body(const mhx_mala_args& a, const float* __restrict__ tparams)
+MHX_DEV void mhx_mala_body(const mhx_mala_args& a, const mhx_real* __restrict__ tparams)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= a.nchains) return;
@@ -138,10 +140,10 @@ MHX_DEV void mhx_mala_body(const mhx_mala_args& a, const float* __restrict__ tpa
     const mhx_philox_key ks = mhx_philox_schedule(a.seed);
     const long ld = a.ld;
     const int d = a.dim;
-    float* xs = a.x + c;
-    float* gs = a.gx + c;
-    float* ys = a.ybuf + c;
-    float* zs = a.zbuf + c;
+    mhx_real* xs = a.x + c;
+    mhx_real* gs = a.gx + c;
+    mhx_real* ys = a.ybuf + c;
+    mhx_real* zs = a.zbuf + c;
     mhx_strided_rw gy;
     gy.base = a.gybuf + c;
     gy.ld = ld;
@@ -149,7 +151,7 @@ MHX_DEV void mhx_mala_body(const mhx_mala_args& a, const float* __restrict__ tpa
     yv.base = ys;
     yv.ld = ld;
 
-    float lp = a.lp[c];
+    mhx_real lp = a.lp[c];
     mhx_u32 nacc = a.acc_count[c];
     mhx_u32 wave_acc = 0;
     bool last = a.last_acc[c] != 0;
@@ -163,14 +165,14 @@ MHX_DEV void mhx_mala_body(const mhx_mala_args& a, const float* __restrict__ tpa
     for (int it = 0; it < a.nsteps; ++it) {
         const mhx_u32 step = a.step0 + (mhx_u32)it;
         // ---- propose (src/MALA.jl:70): y = x + (sigma2/2) grad(x) + sigma z
-        float fwd = 0.0f;
+        mhx_real fwd = MHX_R(0.0);
         for (int b = 0; b < nblk; ++b) {
-            float n[4];
+            mhx_real n[4];
             mhx_normal4(ks, id_lo, id_hi, step, MHX_STREAM_PROPOSAL, (mhx_u32)b, n);
             for (int j = 0; j < 4; ++j) {
                 const int k = 4 * b + j;
                 if (k < d) {
-                    const float z = n[j];
+                    const mhx_real z = n[j];
                     ys[(long)k * ld] = mhx_fma(a.sigma, z, mhx_fma(a.h, gs[(long)k * ld], xs[(long)k * ld]));
                     zs[(long)k * ld] = z;
                     fwd = mhx_fma(z, z, fwd);
@@ -178,15 +180,15 @@ MHX_DEV void mhx_mala_body(const mhx_mala_args& a, const float* __restrict__ tpa
             }
         }
         // ---- value and gradient at the candidate (:73-75)
-        const float lpy = mhx_target_grad<TK>(a.target_kind, yv, gy, d, tparams, a.ntparams, a.tconst);
+        const mhx_real lpy = mhx_target_grad<TK>(a.target_kind, yv, gy, d, tparams, a.ntparams, a.tconst);
         // ---- log ratio of the proposal densities (:78-80)
-        float bwd = 0.0f;
+        mhx_real bwd = MHX_R(0.0);
         for (int k = 0; k < d; ++k) {
-            const float tk = mhx_fma(a.hs, gs[(long)k * ld] + gy[k], zs[(long)k * ld]);
+            const mhx_real tk = mhx_fma(a.hs, gs[(long)k * ld] + gy[k], zs[(long)k * ld]);
             bwd = mhx_fma(tk, tk, bwd);
         }
-        const float loga = (lpy - lp) + 0.5f * (fwd - bwd);              // :83
-        const float logu = mhx_accept_logu(ks, id_lo, id_hi, step, ac);
+        const mhx_real loga = (lpy - lp) + MHX_R(0.5) * (fwd - bwd);              // :83
+        const mhx_real logu = mhx_accept_logu(ks, id_lo, id_hi, step, ac);
         const bool acc = logu < loga;                                    // :86 (strict)
         if (acc) {
             for (int k = 0; k < d; ++k) { xs[(long)k * ld] = ys[(long)k * ld]; gs[(long)k * ld] = gy[k]; }
@@ -196,7 +198,7 @@ MHX_DEV void mhx_mala_body(const mhx_mala_args& a, const float* __restrict__ tpa
         last = acc;
         wave_acc += (mhx_u32)__popcll(__ballot(acc));
         if (step == save_next) {
-            float* row = a.samples + slot * (long)(d + 1) * ld + c;
+            mhx_real* row = a.samples + slot * (long)(d + 1) * ld + c;
             for (int k = 0; k < d; ++k) row[(long)k * ld] = xs[(long)k * ld];
             row[(long)d * ld] = lp;
             a.accepted[slot * ld + c] = acc ? 1 : 0;
@@ -217,13 +219,13 @@ MHX_DEV void mhx_mala_body(const mhx_mala_args& a, const float* __restrict__ tpa
 // recorded samples.  Same arithmetic as mhx_mala_body, statement for statement.
 template <int D>
 struct mhx_reg_rw {
-    float* v;                                        // a lane-private array that full unrolling turns into registers
-    MHX_DEV float operator[](int k) const { return v[k]; }
-    MHX_DEV void set(int k, float x) const { v[k] = x; }
+    mhx_real* v;                                        // a lane-private array that full unrolling turns into registers
+    MHX_DEV mhx_real operator[](int k) const { return v[k]; }
+    MHX_DEV void set(int k, mhx_real x) const { v[k] = x; }
 };
 
 template <int D, int TK>
-MHX_DEV void mhx_mala_reg_body(const mhx_mala_args& a, const float* __restrict__ tparams)
+MHX_DEV void mhx_mala_reg_body(const mhx_mala_args& a, const mhx_real* __restrict__ tparams)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= a.nchains) return;
@@ -231,12 +233,12 @@ MHX_DEV void mhx_mala_reg_body(const mhx_mala_args& a, const float* __restrict__
     const mhx_u32 id_lo = (mhx_u32)id, id_hi = (mhx_u32)(id >> 32);
     const mhx_philox_key ks = mhx_philox_schedule(a.seed);
     const long ld = a.ld;
-    float x[D], g[D], y[D], gyv[D], z[D];
+    mhx_real x[D], g[D], y[D], gyv[D], z[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) { x[k] = a.x[(long)k * ld + c]; g[k] = a.gx[(long)k * ld + c]; }
     mhx_reg_rw<D> gy;
     gy.v = gyv;
-    float lp = a.lp[c];
+    mhx_real lp = a.lp[c];
     mhx_u32 nacc = a.acc_count[c];
     mhx_u32 wave_acc = 0;
     bool last = a.last_acc[c] != 0;
@@ -249,10 +251,10 @@ MHX_DEV void mhx_mala_reg_body(const mhx_mala_args& a, const float* __restrict__
 
     for (int it = 0; it < a.nsteps; ++it) {
         const mhx_u32 step = a.step0 + (mhx_u32)it;
-        float fwd = 0.0f;
+        mhx_real fwd = MHX_R(0.0);
 #pragma unroll
         for (int b = 0; b < nblk; ++b) {
-            float n[4];
+            mhx_real n[4];
             mhx_normal4(ks, id_lo, id_hi, step, MHX_STREAM_PROPOSAL, (mhx_u32)b, n);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -264,15 +266,15 @@ MHX_DEV void mhx_mala_reg_body(const mhx_mala_args& a, const float* __restrict__
                 }
             }
         }
-        const float lpy = mhx_target_grad<TK>(TK, y, gy, D, tparams, a.ntparams, a.tconst);   // :73-75
-        float bwd = 0.0f;
+        const mhx_real lpy = mhx_target_grad<TK>(TK, y, gy, D, tparams, a.ntparams, a.tconst);   // :73-75
+        mhx_real bwd = MHX_R(0.0);
 #pragma unroll
         for (int k = 0; k < D; ++k) {
-            const float tk = mhx_fma(a.hs, g[k] + gyv[k], z[k]);
+            const mhx_real tk = mhx_fma(a.hs, g[k] + gyv[k], z[k]);
             bwd = mhx_fma(tk, tk, bwd);
         }
-        const float loga = (lpy - lp) + 0.5f * (fwd - bwd);              // :78-83
-        const float logu = mhx_accept_logu(ks, id_lo, id_hi, step, ac);
+        const mhx_real loga = (lpy - lp) + MHX_R(0.5) * (fwd - bwd);              // :78-83
+        const mhx_real logu = mhx_accept_logu(ks, id_lo, id_hi, step, ac);
         const bool acc = logu < loga;                                    // :86 (strict)
 #pragma unroll
         for (int k = 0; k < D; ++k) { x[k] = acc ? y[k] : x[k]; g[k] = acc ? gyv[k] : g[k]; }
@@ -281,7 +283,7 @@ MHX_DEV void mhx_mala_reg_body(const mhx_mala_args& a, const float* __restrict__
         last = acc;
         wave_acc += (mhx_u32)__popcll(__ballot(acc));
         if (step == save_next) {
-            float* row = a.samples + slot * (long)(D + 1) * ld + c;
+            mhx_real* row = a.samples + slot * (long)(D + 1) * ld + c;
 #pragma unroll
             for (int k = 0; k < D; ++k) row[(long)k * ld] = x[k];
             row[(long)D * ld] = lp;
@@ -301,7 +303,7 @@ MHX_DEV void mhx_mala_reg_body(const mhx_mala_args& a, const float* __restrict__
 
 // initial GradientTransition (src/MALA.jl:38-40): lp and gradient at the given initial_params
 template <int TK>
-MHX_DEV void mhx_mala_init_body(const mhx_mala_args& a, const float* __restrict__ tparams, const int reset_counts)
+MHX_DEV void mhx_mala_init_body(const mhx_mala_args& a, const mhx_real* __restrict__ tparams, const int reset_counts)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= a.nchains) return;
@@ -317,7 +319,7 @@ MHX_DEV void mhx_mala_init_body(const mhx_mala_args& a, const float* __restrict_
 
 #ifdef MHX_JIT_MALA
 extern "C" __global__ void __launch_bounds__(256)
-mhx_jit_mala(const mhx_mala_args a, const float* __restrict__ tparams)
+mhx_jit_mala(const mhx_mala_args a, const mhx_real* __restrict__ tparams)
 {
 #if MHX_JIT_DIM > 0
     mhx_mala_reg_body<MHX_JIT_DIM, MHX_JIT_TK>(a, tparams);
@@ -326,8 +328,9 @@ mhx_jit_mala(const mhx_mala_args a, const float* __restrict__ tparams)
 #endif
 }
 extern "C" __global__ void __launch_bounds__(256)
-mhx_jit_mala_init(const mhx_mala_args a, const float* __restrict__ tparams, const int reset_counts)
+mhx_jit_mala_init(const mhx_mala_args a, const mhx_real* __restrict__ tparams, const int reset_counts)
 {
     mhx_mala_init_body<MHX_JIT_TK>(a, tparams, reset_counts);
 }
 #endif
+MHX_NS_END

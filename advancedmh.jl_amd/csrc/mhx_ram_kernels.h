@@ -21,21 +21,25 @@
 #pragma once
 #include "mhx_targets.h"
 
+MHX_NS_BEGIN
+
 struct mhx_ram_args {
-    float* x;                 // [dim][ld]  (ABI layout; touched once per launch)
-    float* lp;                // [ld]
+    mhx_real* x;                 // [dim][ld]  (ABI layout; touched once per launch)
+    mhx_real* lp;                // [ld]
     mhx_u32* acc_count;
     mhx_u64* acc_total;
-    float* samples;           // [slots][dim+1][ld] or null
+    mhx_real* samples;           // [slots][dim+1][ld] or null
     unsigned char* accepted;
     unsigned char* last_acc;
-    float* S;                 // [nchains][2][tri_pad]: both buffers of a chain side by side, packed column-major lower
+    mhx_real* S;                 // [nchains][2][tri_pad]: both buffers of a chain side by side, packed column-major lower
     unsigned char* sel;       // [nchains] which buffer is current
     unsigned char* status;    // [nchains] bit0: a downdate left the PD cone, bit1: NaN log-ratio
-    float* dmin;              // [nchains][dim] running min of diag(S)
-    float* dmax;
-    const float* eta;         // [nsteps] adaptation step sizes iteration^-gamma of this launch
-    const float* acol;        // CORR_GAUSS target: inv(chol(Sigma)) packed column-major lower
+    mhx_real* dmin;              // [nchains][dim] running min of diag(S)
+    mhx_real* dmax;
+    mhx_real* loga;              // [nchains] log acceptance ratio min(lp' - lp, 0) of each chain's latest transition
+                              // (RobustAdaptiveMetropolisState.logα, RAM.jl:99-114, :141-147)
+    const mhx_real* eta;         // [nsteps] adaptation step sizes iteration^-gamma of this launch
+    const mhx_real* acol;        // CORR_GAUSS target: inv(chol(Sigma)) packed column-major lower
     mhx_u64 seed;
     mhx_u64 first_chain;
     int nchains;
@@ -43,9 +47,9 @@ struct mhx_ram_args {
     int dim;
     int target_kind;
     int ntparams;
-    float tconst;
-    float alpha;
-    float eig_lo, eig_hi;
+    mhx_real tconst;
+    mhx_real alpha;
+    mhx_real eig_lo, eig_hi;
     int default_bounds;
     mhx_u32 step0;
     int nsteps;
@@ -57,9 +61,9 @@ struct mhx_ram_args {
 
 // x accessor over LDS (broadcast reads: every lane of a group evaluates the target redundantly)
 struct mhx_lds_x {
-    const float* lds;      // wave-uniform base
-    int off;               // per lane: float offset of its chain's vector
-    MHX_DEV float operator[](int k) const { return lds[off + k]; }
+    const mhx_real* lds;      // wave-uniform base
+    int off;               // per lane: mhx_real offset of its chain's vector
+    MHX_DEV mhx_real operator[](int k) const { return lds[off + k]; }
 };
 
 MHX_DEV long mhx_ram_col_off(int i, int d) { return (long)i * d - ((long)i * (i - 1)) / 2; }
@@ -70,7 +74,7 @@ MHX_DEV long mhx_ram_col_off(int i, int d) { return (long)i * d - ((long)i * (i 
 #define MHX_RAM_SLACK 256
 MHX_HD long mhx_ram_tri_pad(int d) { return ((((long)d * (d + 1)) / 2 + 3) & ~3L) + MHX_RAM_SLACK; }
 
-typedef float mhx_f4 __attribute__((ext_vector_type(4)));
+typedef mhx_real mhx_f4 __attribute__((ext_vector_type(4)));
 
 // LDS plan of one wave (= one block), in floats:
 //   [ chain 0: ring | mirror ][ chain 1: ring | mirror ] ... [ chain 0: noise, next noise, candidate ][ chain 1 ... ]
@@ -106,11 +110,22 @@ struct mhx_ram_stream {
     mhx_f4 regs[NV];
 
     // reads past the triangle hit the slack / the next buffer (harmless) or the descriptor's range check (zeros)
+    // a piece = 4 reals per lane: one 16-byte load in fp32, two in fp64
     MHX_DEV void load(const int k)
     {
 #pragma unroll
-        for (int v = 0; v < NV; ++v)
+        for (int v = 0; v < NV; ++v) {
+#if MHX_REAL64
+            typedef double mhx_d2 __attribute__((ext_vector_type(2)));
+            const mhx_d2 p0 = __builtin_bit_cast(mhx_d2, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)vsrc, (k * NV + v) * (GS * 32), 0));
+            const mhx_d2 p1 = __builtin_bit_cast(mhx_d2, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)vsrc, (k * NV + v) * (GS * 32) + 16, 0));
+            mhx_f4 t;
+            t.x = p0.x; t.y = p0.y; t.z = p1.x; t.w = p1.y;
+            regs[v] = t;
+#else
             regs[v] = __builtin_bit_cast(mhx_f4, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)vsrc, (k * NV + v) * (GS * 16), 0));
+#endif
+        }
     }
     MHX_DEV void commit()
     {
@@ -128,11 +143,11 @@ struct mhx_ram_stream {
     }
     bool mlane[NV];
     MHX_DEV bool mirror_lane(const int v) const { return mlane[v]; }
-    // ring_f: float offset of the ring in LDS; tg: this lane's index among the GS lanes of the stream
-    MHX_DEV void begin(const mhx_srd srd_, const mhx_u32 chain_byte_off, const int d, const int tg, float* lds, const int ring_f)
+    // ring_f: mhx_real offset of the ring in LDS; tg: this lane's index among the GS lanes of the stream
+    MHX_DEV void begin(const mhx_srd srd_, const mhx_u32 chain_byte_off, const int d, const int tg, mhx_real* lds, const int ring_f)
     {
         srd = srd_;
-        vsrc = chain_byte_off + 16u * (mhx_u32)tg;
+        vsrc = chain_byte_off + (4u * MHX_RB) * (mhx_u32)tg;
         lds4 = (mhx_f4*)lds;
         r4 = (ring_f >> 2) + tg;
 #pragma unroll
@@ -184,18 +199,18 @@ struct mhx_ram_cols<G, R, R> {
 // slot accumulate whatever follows the column in the ring; nothing ever reads them.
 template <int G, int R>
 struct mhx_ram_matvec_f {
-    const float* lds;      // wave-uniform
-    int ring;              // per lane: float offset of the ring the column is read from, plus tg
-    int ush;               // per lane: float offset of the vector of its chain
+    const mhx_real* lds;      // wave-uniform
+    int ring;              // per lane: mhx_real offset of the ring the column is read from, plus tg
+    int ush;               // per lane: mhx_real offset of the vector of its chain
     int tg;
-    float v[R];
+    mhx_real v[R];
     template <int IR>
     MHX_DEV void col(const int il, const int i, const int roff, const int)
     {
-        const float* cp = lds + (ring + (roff - il));                   // row tg + G IR of this column
-        const float ui = lds[ush + i];
-        const float c0 = cp[0];
-        v[IR] = mhx_fma(tg >= il ? c0 : 0.0f, ui, v[IR]);               // rows above the diagonal: fma(0, u, v) == v
+        const mhx_real* cp = lds + (ring + (roff - il));                   // row tg + G IR of this column
+        const mhx_real ui = lds[ush + i];
+        const mhx_real c0 = cp[0];
+        v[IR] = mhx_fma(tg >= il ? c0 : MHX_R(0.0), ui, v[IR]);               // rows above the diagonal: fma(0, u, v) == v
 #pragma unroll
         for (int r = IR + 1; r < R; ++r) v[r] = mhx_fma(cp[G * (r - IR)], ui, v[r]);
     }
@@ -203,7 +218,7 @@ struct mhx_ram_matvec_f {
 // SHARED = the factor is the same for all chains of the wave (streamed once by all 64 lanes)
 template <int G, int R, bool SHARED>
 MHX_DEV void mhx_ram_matvec(const mhx_srd srd, const mhx_u32 chain_byte_off, const int ush, const int d, const int lane,
-                            float* lds, float (&v)[R])
+                            mhx_real* lds, mhx_real (&v)[R])
 {
     constexpr int GS = SHARED ? 64 : G;
     const int g = lane / G, tg = lane % G;
@@ -211,7 +226,7 @@ MHX_DEV void mhx_ram_matvec(const mhx_srd srd, const mhx_u32 chain_byte_off, con
     mhx_ram_matvec_f<G, R> f;
     f.lds = lds; f.ring = ring + tg; f.ush = ush; f.tg = tg;
 #pragma unroll
-    for (int r = 0; r < R; ++r) f.v[r] = 0.0f;
+    for (int r = 0; r < R; ++r) f.v[r] = MHX_R(0.0);
     mhx_ram_stream<GS, MHX_RAM_NV(R), MHX_RAM_MIRF(G, R)> st;
     st.begin(srd, chain_byte_off, d, SHARED ? lane : tg, lds, ring);
     mhx_ram_cols<G, R, 0>::run(st, d, 0, f);
@@ -222,32 +237,45 @@ MHX_DEV void mhx_ram_matvec(const mhx_srd srd, const mhx_u32 chain_byte_off, con
 // draw U = randn(d) of `step` into the chain's LDS slot (lane tg draws Philox blocks tg, tg+G, ...) and
 // return |U|^2 (ascending order, every lane of the group)
 template <int G>
-MHX_DEV float mhx_ram_draw(const mhx_philox_key& ks, mhx_u32 id_lo, mhx_u32 id_hi, mhx_u32 step, const int d,
-                           const int tg, float* lds, const int uoff)
+MHX_DEV mhx_real mhx_ram_draw(const mhx_philox_key& ks, mhx_u32 id_lo, mhx_u32 id_hi, mhx_u32 step, const int d,
+                           const int tg, mhx_real* lds, const int uoff)
 {
-    float* ush = lds + uoff;
+    mhx_real* ush = lds + uoff;
     const int nblk = (d + 3) >> 2;
     for (int b0 = 0; b0 < nblk; b0 += G) {                 // wave-uniform trip count
         const int b = b0 + tg;
-        float n[4];
+        mhx_real n[4];
         mhx_normal4(ks, id_lo, id_hi, step, MHX_STREAM_PROPOSAL, (mhx_u32)b, n);
 #pragma unroll
         for (int j = 0; j < 4; ++j) if (4 * b + j < d) ush[4 * b + j] = n[j];
     }
     MHX_WAVE_SYNC();
-    float nn = 0.0f;
-    for (int j = 0; j < d; ++j) { const float u = ush[j]; nn = mhx_fma(u, u, nn); }
+    mhx_real nn = MHX_R(0.0);
+    for (int j = 0; j < d; ++j) { const mhx_real u = ush[j]; nn = mhx_fma(u, u, nn); }
     return nn;
+}
+
+// v_readlane of a real (two dwords in fp64)
+MHX_DEV mhx_real mhx_readlane(const mhx_real x, const int lane)
+{
+#if MHX_REAL64
+    const mhx_u64 b = __builtin_bit_cast(mhx_u64, x);
+    const mhx_u32 lo = (mhx_u32)__builtin_amdgcn_readlane((int)(mhx_u32)b, lane);
+    const mhx_u32 hi = (mhx_u32)__builtin_amdgcn_readlane((int)(mhx_u32)(b >> 32), lane);
+    return __builtin_bit_cast(double, ((mhx_u64)hi << 32) | lo);
+#else
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane));
+#endif
 }
 
 // value of x in lane il of the caller's own group
 template <int G>
-MHX_DEV float mhx_ram_group_bcast(const float x, const int il, const int g)
+MHX_DEV mhx_real mhx_ram_group_bcast(const mhx_real x, const int il, const int g)
 {
-    float out = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), il));
+    mhx_real out = mhx_readlane(x, il);
 #pragma unroll
     for (int k = 1; k < 64 / G; ++k) {
-        const float o = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), k * G + il));
+        const mhx_real o = mhx_readlane(x, k * G + il);
         out = g == k ? o : out;
     }
     return out;
@@ -262,58 +290,58 @@ MHX_DEV float mhx_ram_group_bcast(const float x, const int il, const int g)
 // identity and the sweep copies its columns (the selector does not flip, so nobody reads the copy).
 template <int G, int R>
 struct mhx_ram_sweep_f {
-    const float* lds;      // wave-uniform
-    int ring;              // per lane: float offset of the ring of its chain
-    int unext;             // per lane: float offset of next step's noise of its chain
+    const mhx_real* lds;      // wave-uniform
+    int ring;              // per lane: mhx_real offset of the ring of its chain
+    int unext;             // per lane: mhx_real offset of next step's noise of its chain
     mhx_srd srd;           // both buffers of every chain of the wave
     mhx_u32 vbase;         // per lane: byte offset of row tg of the chain's new buffer (out of range: idle group)
     int tg, g;
-    float sg;              // per chain
+    mhx_real sg;              // per chain
     bool ok;               // per chain: the downdate is still positive definite
-    float w[R];            // the rank-1 vector, rotated column by column
-    float nd[R];           // new diagonal entries of the rows this lane owns
-    float vo[R];           // next step's S_old U'   (fused mat-vec)
-    float vn[R];           // next step's S_new U'
+    mhx_real w[R];            // the rank-1 vector, rotated column by column
+    mhx_real nd[R];           // new diagonal entries of the rows this lane owns
+    mhx_real vo[R];           // next step's S_old U'   (fused mat-vec)
+    mhx_real vn[R];           // next step's S_new U'
     template <int IR>
     MHX_DEV void col(const int il, const int i, const int roff, const int off)
     {
-        const float* cp = lds + (ring + tg + (roff - il));
+        const mhx_real* cp = lds + (ring + tg + (roff - il));
         const bool lo = tg >= il;                                      // row >= i inside slot IR
         const bool ondiag = tg == il;
-        const float c0 = lo ? cp[0] : 0.0f;
-        const float aii = lds[ring + roff];                            // the diagonal entry (broadcast read)
-        const float bi = mhx_ram_group_bcast<G>(w[IR], il, g);
-        float sn = bi / aii;
-        const bool bad = sg < 0.0f && sn * sn > 1.0f;                  // PosDefException upstream
+        const mhx_real c0 = lo ? cp[0] : MHX_R(0.0);
+        const mhx_real aii = lds[ring + roff];                            // the diagonal entry (broadcast read)
+        const mhx_real bi = mhx_ram_group_bcast<G>(w[IR], il, g);
+        mhx_real sn = bi / aii;
+        const bool bad = sg < MHX_R(0.0) && sn * sn > MHX_R(1.0);                  // PosDefException upstream
         if (__ballot(bad) != 0ull) {                                   // rare: that chain coasts from here on
             ok = ok && !bad;
-            sn = bad ? 0.0f : sn;
+            sn = bad ? MHX_R(0.0) : sn;
 #pragma unroll
-            for (int r = 0; r < R; ++r) w[r] = bad ? 0.0f : w[r];
+            for (int r = 0; r < R; ++r) w[r] = bad ? MHX_R(0.0) : w[r];
         }
-        const float ss = sg * sn;
-        const float cs = mhx_sqrt(mhx_fma(ss, sn, 1.0f));
-        const float rcs = 1.0f / cs;                                   // one reciprocal per column
-        const float diag = cs * aii;
-        const float un = lds[unext + i];
-        const mhx_u32 voff = vbase + 4u * (mhx_u32)(off - i);          // row tg of column i
+        const mhx_real ss = sg * sn;
+        const mhx_real cs = mhx_sqrt(mhx_fma(ss, sn, MHX_R(1.0)));
+        const mhx_real rcs = MHX_R(1.0) / cs;                                   // one reciprocal per column
+        const mhx_real diag = cs * aii;
+        const mhx_real un = lds[unext + i];
+        const mhx_u32 voff = vbase + MHX_RB * (mhx_u32)(off - i);          // row tg of column i
         {
-            const float vj = w[IR];
-            const float oe = mhx_fma(ss, vj, c0) * rcs;
-            const float wn = mhx_fma(cs, vj, -(sn * oe));
-            const float out = ondiag ? diag : oe;
-            w[IR] = ondiag ? 0.0f : wn;
+            const mhx_real vj = w[IR];
+            const mhx_real oe = mhx_fma(ss, vj, c0) * rcs;
+            const mhx_real wn = mhx_fma(cs, vj, -(sn * oe));
+            const mhx_real out = ondiag ? diag : oe;
+            w[IR] = ondiag ? MHX_R(0.0) : wn;
             nd[IR] = ondiag ? diag : nd[IR];
-            if (lo) mhx_srd_store(srd, voff + 4u * G * IR, 0u, out);
+            if (lo) mhx_srd_store(srd, voff + MHX_RB * G * IR, 0u, out);
             vo[IR] = mhx_fma(c0, un, vo[IR]);
             vn[IR] = mhx_fma(out, un, vn[IR]);
         }
 #pragma unroll
         for (int r = IR + 1; r < R; ++r) {
-            const float Aji = cp[G * (r - IR)], vj = w[r];
-            const float oe = mhx_fma(ss, vj, Aji) * rcs;
+            const mhx_real Aji = cp[G * (r - IR)], vj = w[r];
+            const mhx_real oe = mhx_fma(ss, vj, Aji) * rcs;
             w[r] = mhx_fma(cs, vj, -(sn * oe));
-            mhx_srd_store(srd, voff + 4u * G * r, 0u, oe);
+            mhx_srd_store(srd, voff + MHX_RB * G * r, 0u, oe);
             vo[r] = mhx_fma(Aji, un, vo[r]);
             vn[r] = mhx_fma(oe, un, vn[r]);
         }
@@ -322,7 +350,7 @@ struct mhx_ram_sweep_f {
 
 // G = lanes per chain, R = rows per lane (dim <= G R)
 template <int G, int R, int TK>
-MHX_DEV void mhx_ram_body(const mhx_ram_args& a, const float* __restrict__ tparams, float* lds)
+MHX_DEV void mhx_ram_body(const mhx_ram_args& a, const mhx_real* __restrict__ tparams, mhx_real* lds)
 {
     constexpr int CPW = 64 / G;                  // chains per wave (= per block)
     constexpr int RINGS = MHX_RAM_RING(G, R) + MHX_RAM_MIRF(G, R);
@@ -341,25 +369,25 @@ MHX_DEV void mhx_ram_body(const mhx_ram_args& a, const float* __restrict__ tpara
     const mhx_u64 id = a.first_chain + (mhx_u64)c;
     const mhx_u32 id_lo = (mhx_u32)id, id_hi = (mhx_u32)(id >> 32);
     const mhx_philox_key ks = mhx_philox_schedule(a.seed);
-    // per-lane LDS float offsets (the LDS base stays wave-uniform)
+    // per-lane LDS mhx_real offsets (the LDS base stays wave-uniform)
     const int ring = g * RINGS;                                         // 16-byte aligned
     int ucur = CPW * RINGS + g * 3 * d;   // [d] noise of the current step (dead after its mat-vec: target scratch)
     int unxt = ucur + d;                  // [d] noise of the next step (fused mat-vec)
     const int ysh = ucur + 2 * d;         // [d] candidate
     // both buffers of every chain of this wave through one descriptor; idle groups read chain c0
-    const mhx_srd srd = mhx_make_srd(a.S + c0 * 2 * tri_pad, (mhx_u32)(CPW * 2 * tri_pad * 4));
-    const mhx_srd srd_a = mhx_make_srd(a.acol, (mhx_u32)(tri_pad * 4));
+    const mhx_srd srd = mhx_make_srd(a.S + c0 * 2 * tri_pad, (mhx_u32)(CPW * 2 * tri_pad * MHX_RB));
+    const mhx_srd srd_a = mhx_make_srd(a.acol, (mhx_u32)(tri_pad * MHX_RB));
     const int gv = valid ? g : 0;
 
-    float x[R], dmn[R], dmx[R];
+    mhx_real x[R], dmn[R], dmx[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int row = tg + G * r;
-        x[r] = row < d ? a.x[(long)row * ld + c] : 0.0f;
-        dmn[r] = row < d ? a.dmin[(long)c * d + row] : 0.0f;
-        dmx[r] = row < d ? a.dmax[(long)c * d + row] : 0.0f;
+        x[r] = row < d ? a.x[(long)row * ld + c] : MHX_R(0.0);
+        dmn[r] = row < d ? a.dmin[(long)c * d + row] : MHX_R(0.0);
+        dmx[r] = row < d ? a.dmax[(long)c * d + row] : MHX_R(0.0);
     }
-    float lp = a.lp[c];
+    mhx_real lp = a.lp[c];
     mhx_u32 nacc = a.acc_count[c];
     mhx_u32 wave_acc = 0;
     bool last = a.last_acc[c] != 0;
@@ -370,14 +398,15 @@ MHX_DEV void mhx_ram_body(const mhx_ram_args& a, const float* __restrict__ tpara
     ac.w.x = ac.w.y = ac.w.z = ac.w.w = 0u;
     mhx_u32 save_next = a.save_next;
     long slot = a.save_slot;
+    mhx_real loga_last = a.loga[c];
     bool have_v = false;         // wave-uniform: v = S U of this step (and nn) came out of the previous sweep
-    float v[R], nn = 0.0f;
+    mhx_real v[R], nn = MHX_R(0.0);
 #pragma unroll
-    for (int r = 0; r < R; ++r) v[r] = 0.0f;
+    for (int r = 0; r < R; ++r) v[r] = MHX_R(0.0);
 
     for (int it = 0; it < a.nsteps; ++it) {
         const mhx_u32 step = a.step0 + (mhx_u32)it;
-        const mhx_u32 scur = (mhx_u32)((2 * gv + sel) * tri_pad * 4);      // byte offset of the current factor
+        const mhx_u32 scur = (mhx_u32)((2 * gv + sel) * tri_pad * MHX_RB);      // byte offset of the current factor
 
         // ---- U = randn(d), v = S U, x' = v + x   (RAM.jl:135-136)
         if (!have_v) {
@@ -385,7 +414,7 @@ MHX_DEV void mhx_ram_body(const mhx_ram_args& a, const float* __restrict__ tpara
             nn = mhx_ram_draw<G>(ks, id_lo, id_hi, step, d, tg, lds, ucur);
             mhx_ram_matvec<G, R, false>(srd, scur, ucur, d, lane, lds, v);
         }
-        float y[R];
+        mhx_real y[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int row = tg + G * r;
@@ -395,19 +424,19 @@ MHX_DEV void mhx_ram_body(const mhx_ram_args& a, const float* __restrict__ tpara
         MHX_WAVE_SYNC();
 
         // ---- lp' = logdensity(x')  (RAM.jl:140)
-        float lpy;
+        mhx_real lpy;
         const int kind = (TK == MHX_TARGET_DYNAMIC) ? a.target_kind : TK;
         if (kind == MHX_TARGET_CORR_GAUSS) {
             // cooperative column sweep over A = inv(chol(Sigma)): w_j += A_ji y_i, i ascending
-            float wv[R];
+            mhx_real wv[R];
             mhx_ram_matvec<G, R, true>(srd_a, 0u, ysh, d, lane, lds, wv);
             MHX_WAVE_SYNC();
 #pragma unroll
             for (int r = 0; r < R; ++r) if (tg + G * r < d) lds[ucur + tg + G * r] = wv[r];
             MHX_WAVE_SYNC();
-            float q = 0.0f;
-            for (int j = 0; j < d; ++j) { const float w = lds[ucur + j]; q = mhx_fma(w, w, q); }
-            lpy = mhx_fma(-0.5f, q, a.tconst);
+            mhx_real q = MHX_R(0.0);
+            for (int j = 0; j < d; ++j) { const mhx_real w = lds[ucur + j]; q = mhx_fma(w, w, q); }
+            lpy = mhx_fma(-MHX_R(0.5), q, a.tconst);
         } else {
             mhx_lds_x yv;
             yv.lds = lds; yv.off = ysh;
@@ -415,28 +444,29 @@ MHX_DEV void mhx_ram_body(const mhx_ram_args& a, const float* __restrict__ tpara
         }
 
         // ---- accept (RAM.jl:147-148): loga = min(lp' - lp, 0); accept iff randexp > -loga
-        const float diff = lpy - lp;
-        const float loga = (diff != diff) ? diff : (diff < 0.0f ? diff : 0.0f);
-        const float logu = mhx_accept_logu(ks, id_lo, id_hi, step, ac);
+        const mhx_real diff = lpy - lp;
+        const mhx_real loga = (diff != diff) ? diff : (diff < MHX_R(0.0) ? diff : MHX_R(0.0));
+        const mhx_real logu = mhx_accept_logu(ks, id_lo, id_hi, step, ac);
         const bool acc = logu < loga;
+        loga_last = loga;
 
         // ---- adapt (RAM.jl:153-173, :259-264) during warm-up; the step index is wave-uniform
         have_v = false;
         if (it < a.n_adapt) {
-            const float da = mhx_exp(loga) - a.alpha;                    // :159
+            const mhx_real da = mhx_exp(loga) - a.alpha;                    // :159
             const bool adapt = da == da;                                 // a NaN log-ratio skips the adaptation
             if (!adapt) st |= 2u;
-            const float eta = a.eta[it];                                 // :162 iteration^-gamma
-            const float coef = mhx_sqrt(eta * __builtin_fabsf(da)) / mhx_sqrt(nn);   // :163
+            const mhx_real eta = a.eta[it];                                 // :162 iteration^-gamma
+            const mhx_real coef = mhx_sqrt(eta * mhx_abs(da)) / mhx_sqrt(nn);   // :163
             const bool fuse = it + 1 < a.nsteps;                         // a next step exists in this launch
             mhx_ram_sweep_f<G, R> sw;
             sw.lds = lds; sw.ring = ring; sw.unext = unxt; sw.srd = srd; sw.tg = tg; sw.g = g;
-            sw.vbase = valid ? (mhx_u32)(((2 * g + (sel ^ 1)) * tri_pad + tg) * 4) : 0x80000000u;
-            sw.sg = da > 0.0f ? 1.0f : -1.0f;                            // :165 sign(da) == 1 ? update : downdate
+            sw.vbase = valid ? (mhx_u32)(((2 * g + (sel ^ 1)) * tri_pad + tg) * MHX_RB) : 0x80000000u;
+            sw.sg = da > MHX_R(0.0) ? MHX_R(1.0) : -MHX_R(1.0);                            // :165 sign(da) == 1 ? update : downdate
             sw.ok = true;
 #pragma unroll
-            for (int r = 0; r < R; ++r) { sw.w[r] = adapt ? v[r] * coef : 0.0f; sw.nd[r] = 0.0f; sw.vo[r] = 0.0f; sw.vn[r] = 0.0f; }
-            float nn_next = 0.0f;
+            for (int r = 0; r < R; ++r) { sw.w[r] = adapt ? v[r] * coef : MHX_R(0.0); sw.nd[r] = MHX_R(0.0); sw.vo[r] = MHX_R(0.0); sw.vn[r] = MHX_R(0.0); }
+            mhx_real nn_next = MHX_R(0.0);
             MHX_WAVE_SYNC();                                             // every lane is done with ucur / ysh
             if (fuse) nn_next = mhx_ram_draw<G>(ks, id_lo, id_hi, step + 1u, d, tg, lds, unxt);
             mhx_ram_stream<G, MHX_RAM_NV(R), MHX_RAM_MIRF(G, R)> stream;
@@ -482,7 +512,7 @@ MHX_DEV void mhx_ram_body(const mhx_ram_args& a, const float* __restrict__ tpara
         wave_acc += (mhx_u32)__popcll(__ballot(acc && valid && tg == 0));
         if (step == save_next) {
             if (valid) {
-                float* rowp = a.samples + slot * (long)(d + 1) * ld + c;
+                mhx_real* rowp = a.samples + slot * (long)(d + 1) * ld + c;
 #pragma unroll
                 for (int r = 0; r < R; ++r) if (tg + G * r < d) rowp[(long)(tg + G * r) * ld] = x[r];
                 if (tg == 0) {
@@ -511,6 +541,7 @@ MHX_DEV void mhx_ram_body(const mhx_ram_args& a, const float* __restrict__ tpara
             a.last_acc[c] = last ? 1 : 0;
             a.sel[c] = (unsigned char)sel;
             a.status[c] = (unsigned char)st;
+            a.loga[c] = loga_last;
         }
     }
     if (lane == 0) atomicAdd(a.acc_total, (mhx_u64)wave_acc);
@@ -518,19 +549,19 @@ MHX_DEV void mhx_ram_body(const mhx_ram_args& a, const float* __restrict__ tpara
 
 // initial state (RAM.jl:175-214): x0 = initial_params or randn(d); lp0; accepted = true (:213)
 template <int TK>
-MHX_DEV void mhx_ram_init_body(const mhx_ram_args& a, const float* __restrict__ tparams, const int draw)
+MHX_DEV void mhx_ram_init_body(const mhx_ram_args& a, const mhx_real* __restrict__ tparams, const int draw)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= a.nchains) return;
     const long ld = a.ld;
     const int d = a.dim;
-    float* xs = a.x + c;
+    mhx_real* xs = a.x + c;
     if (draw) {
         const mhx_u64 id = a.first_chain + (mhx_u64)c;
         const mhx_philox_key ks = mhx_philox_schedule(a.seed);
         const int nblk = (d + 3) >> 2;
         for (int b = 0; b < nblk; ++b) {
-            float n[4];
+            mhx_real n[4];
             mhx_normal4(ks, (mhx_u32)id, (mhx_u32)(id >> 32), 0u, MHX_STREAM_INIT, (mhx_u32)b, n);
             for (int j = 0; j < 4; ++j) if (4 * b + j < d) xs[(long)(4 * b + j) * ld] = n[j];
         }
@@ -542,18 +573,20 @@ MHX_DEV void mhx_ram_init_body(const mhx_ram_args& a, const float* __restrict__ 
     a.acc_count[c] = 0u;
     a.last_acc[c] = 1;
     a.status[c] = 0;
+    a.loga[c] = MHX_R(0.0);         // RAM.jl:211: RobustAdaptiveMetropolisState(x, lp, S, zero(T), 0, 1, true)
 }
 
 #ifdef MHX_JIT_RAM
 extern "C" __global__ void __launch_bounds__(64)
-mhx_jit_ram(const mhx_ram_args a, const float* __restrict__ tparams)
+mhx_jit_ram(const mhx_ram_args a, const mhx_real* __restrict__ tparams)
 {
-    extern __shared__ float mhx_ram_lds[];
+    extern __shared__ mhx_real mhx_ram_lds[];
     mhx_ram_body<MHX_JIT_G, MHX_JIT_R, MHX_JIT_TK>(a, tparams, mhx_ram_lds);
 }
 extern "C" __global__ void __launch_bounds__(256)
-mhx_jit_ram_init(const mhx_ram_args a, const float* __restrict__ tparams, const int draw)
+mhx_jit_ram_init(const mhx_ram_args a, const mhx_real* __restrict__ tparams, const int draw)
 {
     mhx_ram_init_body<MHX_JIT_TK>(a, tparams, draw);
 }
 #endif
+MHX_NS_END

@@ -14,11 +14,13 @@
 #include "mhx_rwmh_kernels.h"
 #include "mhx_emcee_kernels.h"
 
+MHX_NS_BEGIN
+
 // TK: MHX_TARGET_CORR_GAUSS (factor image A) or MHX_TARGET_ISO_GAUSS; PK: ISO / DIAG scales, or DENSE -- the
 // proposal's Cholesky factor as a second image: xi = L z is a row product like A y, and y = x + xi.
 template <int D, int L, int PK, int TK>
-MHX_DEV void mhx_rwmh_dense_coop_body(const mhx_rwmh_args& a, const float* __restrict__ A,
-                                      const float* __restrict__ pvec, float* ysh_all, mhx_e4* Ash4, mhx_e4* Lsh4)
+MHX_DEV void mhx_rwmh_dense_coop_body(const mhx_rwmh_args& a, const mhx_real* __restrict__ A,
+                                      const mhx_real* __restrict__ pvec, mhx_real* ysh_all, mhx_e4* Ash4, mhx_e4* Lsh4)
 {
     typedef mhx_emcee_geom<D, L> GEO;
     constexpr bool CORR = TK == MHX_TARGET_CORR_GAUSS;
@@ -41,26 +43,26 @@ MHX_DEV void mhx_rwmh_dense_coop_body(const mhx_rwmh_args& a, const float* __res
     const mhx_u64 id = a.first_chain + (mhx_u64)c;
     const mhx_u32 id_lo = (mhx_u32)id, id_hi = (mhx_u32)(id >> 32);
     const mhx_philox_key ks = mhx_philox_schedule(a.seed);
-    float* yrow = ysh_all + (wave * CPW + cw) * DP4;
+    mhx_real* yrow = ysh_all + (wave * CPW + cw) * DP4;
     mhx_e4* yrow4 = (mhx_e4*)yrow;
 
     // ---- state: float4 slices l, l+L, ... of x (ABI layout [dim][ld], touched once per launch)
     mhx_e4 xs[NQL];
-    float sc[NQL][4];                            // ISO / DIAG: scales of the owned dimensions; DENSE: 1 (0 in the pad)
+    mhx_real sc[NQL][4];                            // ISO / DIAG: scales of the owned dimensions; DENSE: 1 (0 in the pad)
 #pragma unroll
     for (int m = 0; m < NQL; ++m) {
         const int q4 = l + L * m;
-        float e[4];
+        mhx_real e[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int k = 4 * q4 + j;
             const bool in = q4 < NQ && k < D;
-            e[j] = in ? a.x[(long)k * ld + c] : 0.0f;
-            sc[m][j] = in ? (PK == MHX_PROP_ISO ? a.pscale : (DENSEP ? 1.0f : pvec[k])) : 0.0f;
+            e[j] = in ? a.x[(long)k * ld + c] : MHX_R(0.0);
+            sc[m][j] = in ? (PK == MHX_PROP_ISO ? a.pscale : (DENSEP ? MHX_R(1.0) : pvec[k])) : MHX_R(0.0);
         }
         xs[m].x = e[0]; xs[m].y = e[1]; xs[m].z = e[2]; xs[m].w = e[3];
     }
-    float lp = a.lp[c];
+    mhx_real lp = a.lp[c];
     mhx_u32 nacc = a.acc_count[c];
     mhx_u32 wave_acc = 0;
     bool last = a.last_acc[c] != 0;
@@ -79,10 +81,10 @@ MHX_DEV void mhx_rwmh_dense_coop_body(const mhx_rwmh_args& a, const float* __res
 #pragma unroll
         for (int m = 0; m < NQL; ++m) {
             const int q4 = l + L * m;
-            const mhx_e4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+            const mhx_e4 zero4 = {MHX_R(0.0), MHX_R(0.0), MHX_R(0.0), MHX_R(0.0)};
             ys[m] = zero4;
             if (q4 < NQ) {
-                float n[4];
+                mhx_real n[4];
                 mhx_normal4(ks, id_lo, id_hi, step, MHX_STREAM_PROPOSAL, (mhx_u32)q4, n);
                 if (DENSEP) {
                     ys[m].x = sc[m][0] * n[0]; ys[m].y = sc[m][1] * n[1]; ys[m].z = sc[m][2] * n[2]; ys[m].w = sc[m][3] * n[3];
@@ -97,7 +99,7 @@ MHX_DEV void mhx_rwmh_dense_coop_body(const mhx_rwmh_args& a, const float* __res
         }
         MHX_WAVE_SYNC();
         if (DENSEP) {
-            float xi[NK];
+            mhx_real xi[NK];
             mhx_dense_rows<D, L>(Lsh4, yrow4, l, xi);                    // xi_r = sum_{j<=r} L_rj z_j, ascending j
             MHX_WAVE_SYNC();                                             // every lane has read z
 #pragma unroll
@@ -118,7 +120,7 @@ MHX_DEV void mhx_rwmh_dense_coop_body(const mhx_rwmh_args& a, const float* __res
         }
         // ---- lp': dense Gaussian -1/2 |A y|^2 + const (rows l, l+L, ... by this lane); isotropic -1/2 |y|^2 + const
         // (the lane's slices in ascending order); butterfly over the chain's lanes
-        float q = 0.0f;
+        mhx_real q = MHX_R(0.0);
         if (CORR) {
             q = mhx_dense_rows_sq<D, L>(Ash4, yrow4, l);
         } else {
@@ -133,10 +135,10 @@ MHX_DEV void mhx_rwmh_dense_coop_body(const mhx_rwmh_args& a, const float* __res
         }
 #pragma unroll
         for (int off = 1; off < L; off <<= 1) q = q + __shfl_xor(q, off * CPW, 64);
-        const float lpy = mhx_fma(-0.5f, q, a.tconst);
+        const mhx_real lpy = mhx_fma(-MHX_R(0.5), q, a.tconst);
         MHX_WAVE_SYNC();                                                 // the row is free for the next candidate
         // ---- accept (src/mh-core.jl:104-114); a zero-mean random walk has no Hastings term
-        const float logu = mhx_accept_logu(ks, id_lo, id_hi, step, ac);
+        const mhx_real logu = mhx_accept_logu(ks, id_lo, id_hi, step, ac);
         const bool acc = logu < (lpy - lp);
 #pragma unroll
         for (int m = 0; m < NQL; ++m) xs[m] = acc ? ys[m] : xs[m];
@@ -146,7 +148,7 @@ MHX_DEV void mhx_rwmh_dense_coop_body(const mhx_rwmh_args& a, const float* __res
         wave_acc += (mhx_u32)__popcll(__ballot(acc && valid && l == 0));
         if (step == save_next) {                                         // wave-uniform
             if (valid) {
-                float* row = a.samples + slot * (long)(D + 1) * ld + c;
+                mhx_real* row = a.samples + slot * (long)(D + 1) * ld + c;
 #pragma unroll
                 for (int m = 0; m < NQL; ++m) {
                     const int k = 4 * (l + L * m);
@@ -185,13 +187,14 @@ MHX_DEV void mhx_rwmh_dense_coop_body(const mhx_rwmh_args& a, const float* __res
 #ifdef MHX_JIT_RWMH_DENSE
 // dynamic LDS (up to 160 KB per block on gfx950): [candidate rows][target image][proposal image]
 extern "C" __global__ void __launch_bounds__(64 * MHX_EMCEE_COOP_WAVES)
-mhx_jit_rwmh_dense(const mhx_rwmh_args a, const float* __restrict__ tparams, const float* __restrict__ pvec)
+mhx_jit_rwmh_dense(const mhx_rwmh_args a, const mhx_real* __restrict__ tparams, const mhx_real* __restrict__ pvec)
 {
     typedef mhx_emcee_geom<MHX_JIT_DIM, MHX_JIT_L> GEO;
     extern __shared__ mhx_e4 mhx_dense_lds[];
     constexpr int YS4 = MHX_EMCEE_COOP_WAVES * (64 / MHX_JIT_L) * GEO::DP4 / 4;
     mhx_e4* Ash4 = mhx_dense_lds + YS4;
     mhx_e4* Lsh4 = Ash4 + (MHX_JIT_TK == MHX_TARGET_CORR_GAUSS ? GEO::TOTAL4 : 0);
-    mhx_rwmh_dense_coop_body<MHX_JIT_DIM, MHX_JIT_L, MHX_JIT_PK, MHX_JIT_TK>(a, tparams, pvec, (float*)mhx_dense_lds, Ash4, Lsh4);
+    mhx_rwmh_dense_coop_body<MHX_JIT_DIM, MHX_JIT_L, MHX_JIT_PK, MHX_JIT_TK>(a, tparams, pvec, (mhx_real*)mhx_dense_lds, Ash4, Lsh4);
 }
 #endif
+MHX_NS_END

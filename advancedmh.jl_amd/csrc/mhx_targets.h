@@ -1,6 +1,6 @@
 // mhx_targets.h -- log-density catalogue evaluated per lane (one lane = one chain / walker).
 //
-// A target is a function of an indexable `x` (x[k] -> float): a register array in the
+// A target is a function of an indexable `x` (x[k] -> mhx_real): a register array in the
 // compile-time-dimension kernels, a strided view of the [dim][nchains] HBM state in the generic
 // ones.  Parameters (`p`) are wave-uniform and read through the scalar cache.  The summation
 // order of every target is part of the arithmetic spec: sequential fmaf
@@ -17,13 +17,23 @@
 #define MHX_TARGET_FUNNEL     4
 #define MHX_TARGET_USER       100
 
+#if MHX_REAL64
+#define MHX_HALF_LOG_2PI 0x1.d67f1c864beb5p-1
+#define MHX_ONE_18 0x1.c71c71c71c71cp-5
+#define MHX_ONE_9  0x1.c71c71c71c71cp-4
+#else
 #define MHX_HALF_LOG_2PI 0x1.d67f1cp-1f
+#define MHX_ONE_18 0x1.c71c72p-5f
+#define MHX_ONE_9  0x1.c71c72p-4f
+#endif
+
+MHX_NS_BEGIN
 
 // strided view of one chain's parameters inside a [dim][ld] array
 struct mhx_strided_x {
-    const float* base;   // &array[0][chain]
+    const mhx_real* base;   // &array[0][chain]
     long ld;
-    MHX_DEV float operator[](int k) const { return base[(long)k * ld]; }
+    MHX_DEV mhx_real operator[](int k) const { return base[(long)k * ld]; }
 };
 
 // A user log-density supplied as HIP source (mhx_target_from_hip_source) is placed by the JIT
@@ -35,60 +45,60 @@ struct mhx_strided_x {
 #define MHX_TARGET_DYNAMIC (-1)
 
 template <int KIND, class X>
-MHX_DEV float mhx_target_eval(int kind, const X& x, const int d, const float* __restrict__ p,
-                              const int np, const float cst)
+MHX_DEV mhx_real mhx_target_eval(int kind, const X& x, const int d, const mhx_real* __restrict__ p,
+                              const int np, const mhx_real cst)
 {
     const int k_ = (KIND == MHX_TARGET_DYNAMIC) ? kind : KIND;
     switch (k_) {
     case MHX_TARGET_ISO_GAUSS: {
-        float q = 0.0f;
+        mhx_real q = MHX_R(0.0);
 #pragma unroll
-        for (int k = 0; k < d; ++k) { const float v = x[k]; q = mhx_fma(v, v, q); }
-        return mhx_fma(-0.5f, q, cst);
+        for (int k = 0; k < d; ++k) { const mhx_real v = x[k]; q = mhx_fma(v, v, q); }
+        return mhx_fma(-MHX_R(0.5), q, cst);
     }
     case MHX_TARGET_CORR_GAUSS: {
-        float q = 0.0f;
+        mhx_real q = MHX_R(0.0);
         int off = 0;
 #pragma unroll
         for (int i = 0; i < d; ++i) {
-            float w = 0.0f;
+            mhx_real w = MHX_R(0.0);
 #pragma unroll
             for (int j = 0; j <= i; ++j) w = mhx_fma(p[off + j], x[j], w);
             q = mhx_fma(w, w, q);
             off += i + 1;
         }
-        return mhx_fma(-0.5f, q, cst);
+        return mhx_fma(-MHX_R(0.5), q, cst);
     }
     case MHX_TARGET_IID_NORMAL: {
-        const float mu = x[0], sigma = x[1];
-        if (!(sigma > 0.0f)) return -MHX_INF;         // theta[2] >= 0 support, and logpdf = -Inf at sigma == 0
-        float acc = 0.0f;
+        const mhx_real mu = x[0], sigma = x[1];
+        if (!(sigma > MHX_R(0.0))) return -MHX_INF;         // theta[2] >= 0 support, and logpdf = -Inf at sigma == 0
+        mhx_real acc = MHX_R(0.0);
         for (int i = 0; i < np; ++i) {
-            const float z = (p[i] - mu) / sigma;
+            const mhx_real z = (p[i] - mu) / sigma;
             acc = mhx_fma(z, z, acc);
         }
-        const float tt = mhx_log(sigma) + MHX_HALF_LOG_2PI;
-        return mhx_fma(-0.5f, acc, -((float)np * tt));
+        const mhx_real tt = mhx_log(sigma) + MHX_HALF_LOG_2PI;
+        return mhx_fma(-MHX_R(0.5), acc, -((mhx_real)np * tt));
     }
     case MHX_TARGET_BANANA: {
-        const float b = p[0];
-        const float x0 = x[0];
-        float q = (x0 * x0) * 0.01f;
-        const float u = mhx_fma(b, mhx_fma(x0, x0, -100.0f), x[1]);
+        const mhx_real b = p[0];
+        const mhx_real x0 = x[0];
+        mhx_real q = (x0 * x0) * MHX_R(0.01);
+        const mhx_real u = mhx_fma(b, mhx_fma(x0, x0, -MHX_R(100.0)), x[1]);
         q = mhx_fma(u, u, q);
 #pragma unroll
-        for (int k = 2; k < d; ++k) { const float v = x[k]; q = mhx_fma(v, v, q); }
-        return mhx_fma(-0.5f, q, cst);
+        for (int k = 2; k < d; ++k) { const mhx_real v = x[k]; q = mhx_fma(v, v, q); }
+        return mhx_fma(-MHX_R(0.5), q, cst);
     }
     case MHX_TARGET_FUNNEL: {
-        const float v = x[0];
-        float q = 0.0f;
+        const mhx_real v = x[0];
+        mhx_real q = MHX_R(0.0);
 #pragma unroll
-        for (int k = 1; k < d; ++k) { const float xk = x[k]; q = mhx_fma(xk, xk, q); }
-        const float ev = mhx_exp(-v);
-        float r = (v * v) * 0x1.c71c72p-5f;
-        r = mhx_fma(0.5f * (float)(d - 1), v, r);
-        r = mhx_fma(0.5f * ev, q, r);
+        for (int k = 1; k < d; ++k) { const mhx_real xk = x[k]; q = mhx_fma(xk, xk, q); }
+        const mhx_real ev = mhx_exp(-v);
+        mhx_real r = (v * v) * MHX_ONE_18;
+        r = mhx_fma(MHX_R(0.5) * (mhx_real)(d - 1), v, r);
+        r = mhx_fma(MHX_R(0.5) * ev, q, r);
         return cst - r;
     }
 #ifdef MHX_HAVE_USER_TARGET
@@ -105,44 +115,44 @@ MHX_DEV float mhx_target_eval(int kind, const X& x, const int d, const float* __
 // partial sums meet in an xor-butterfly with offsets 1, 2, 4, ...  Same arithmetic as
 // mhx_rwmh_coop_body, serialised.
 template <int KIND, class X>
-MHX_DEV float mhx_target_eval_lanes(int kind, const X& x, const int d, const float* __restrict__ p,
-                                    const int np, const float cst, const int L)
+MHX_DEV mhx_real mhx_target_eval_lanes(int kind, const X& x, const int d, const mhx_real* __restrict__ p,
+                                    const int np, const mhx_real cst, const int L)
 {
     const int k_ = (KIND == MHX_TARGET_DYNAMIC) ? kind : KIND;
     const bool separable = k_ == MHX_TARGET_ISO_GAUSS || k_ == MHX_TARGET_BANANA || k_ == MHX_TARGET_FUNNEL;
     if (L <= 1 || !(separable || k_ == MHX_TARGET_CORR_GAUSS)) return mhx_target_eval<KIND>(kind, x, d, p, np, cst);
-    float part[64];
+    mhx_real part[64];
     if (k_ == MHX_TARGET_CORR_GAUSS) {
         // shape of the cooperative ensemble kernel: lane l owns rows i = l, l+L, ... of A x
         for (int l = 0; l < L; ++l) {
-            float q = 0.0f;
+            mhx_real q = MHX_R(0.0);
             for (int i = l; i < d; i += L) {
-                const float* Ar = p + (long)i * (i + 1) / 2;
-                float w = 0.0f;
+                const mhx_real* Ar = p + (long)i * (i + 1) / 2;
+                mhx_real w = MHX_R(0.0);
                 for (int j = 0; j <= i; ++j) w = mhx_fma(Ar[j], x[j], w);
                 q = mhx_fma(w, w, q);
             }
             part[l] = q;
         }
         for (int off = 1; off < L; off <<= 1) {
-            float nxt[64];
+            mhx_real nxt[64];
             for (int l = 0; l < L; ++l) nxt[l] = part[l] + part[l ^ off];
             for (int l = 0; l < L; ++l) part[l] = nxt[l];
         }
-        return mhx_fma(-0.5f, part[0], cst);
+        return mhx_fma(-MHX_R(0.5), part[0], cst);
     }
     const int nblk = (d + 3) >> 2;
     for (int l = 0; l < L; ++l) {
-        float q = 0.0f;
+        mhx_real q = MHX_R(0.0);
         for (int b = l; b < nblk; b += L)
             for (int j = 0; j < 4; ++j) {
                 const int k = 4 * b + j;
                 if (k >= d) break;
-                const float v = x[k];
-                if (k_ == MHX_TARGET_BANANA && k == 0) q = (v * v) * 0.01f;
+                const mhx_real v = x[k];
+                if (k_ == MHX_TARGET_BANANA && k == 0) q = (v * v) * MHX_R(0.01);
                 else if (k_ == MHX_TARGET_BANANA && k == 1) {
-                    const float x0 = x[0];
-                    const float u = mhx_fma(p[0], mhx_fma(x0, x0, -100.0f), v);
+                    const mhx_real x0 = x[0];
+                    const mhx_real u = mhx_fma(p[0], mhx_fma(x0, x0, -MHX_R(100.0)), v);
                     q = mhx_fma(u, u, q);
                 } else if (k_ == MHX_TARGET_FUNNEL && k == 0) {
                 } else q = mhx_fma(v, v, q);
@@ -150,16 +160,17 @@ MHX_DEV float mhx_target_eval_lanes(int kind, const X& x, const int d, const flo
         part[l] = q;
     }
     for (int off = 1; off < L; off <<= 1) {
-        float nxt[64];
+        mhx_real nxt[64];
         for (int l = 0; l < L; ++l) nxt[l] = part[l] + part[l ^ off];
         for (int l = 0; l < L; ++l) part[l] = nxt[l];
     }
-    const float q = part[0];
-    if (k_ != MHX_TARGET_FUNNEL) return mhx_fma(-0.5f, q, cst);
-    const float v = x[0];
-    const float ev = mhx_exp(-v);
-    float r = (v * v) * 0x1.c71c72p-5f;
-    r = mhx_fma(0.5f * (float)(d - 1), v, r);
-    r = mhx_fma(0.5f * ev, q, r);
+    const mhx_real q = part[0];
+    if (k_ != MHX_TARGET_FUNNEL) return mhx_fma(-MHX_R(0.5), q, cst);
+    const mhx_real v = x[0];
+    const mhx_real ev = mhx_exp(-v);
+    mhx_real r = (v * v) * MHX_ONE_18;
+    r = mhx_fma(MHX_R(0.5) * (mhx_real)(d - 1), v, r);
+    r = mhx_fma(MHX_R(0.5) * ev, q, r);
     return cst - r;
 }
+MHX_NS_END

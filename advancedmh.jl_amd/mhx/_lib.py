@@ -36,33 +36,34 @@ class Schedule(C.Structure):
                 ("num_warmup", C.c_int32)]
 
 
+# scalars travel as double and are rounded once to the context's dtype; real buffers are void* (include/mhx.h)
 class RwmhCfg(C.Structure):
     _fields_ = [("dim", C.c_int32), ("nchains", C.c_int32), ("seed", C.c_uint64), ("first_chain", C.c_uint64),
-                ("proposal_kind", C.c_int32), ("proposal_scale", C.c_float),
-                ("proposal_vec", C.POINTER(C.c_float)), ("flags", C.c_int32),
-                ("proposal_mean", C.POINTER(C.c_float)), ("reduce_lanes", C.c_int32)]
+                ("proposal_kind", C.c_int32), ("proposal_scale", C.c_double),
+                ("proposal_vec", C.c_void_p), ("flags", C.c_int32),
+                ("proposal_mean", C.c_void_p), ("reduce_lanes", C.c_int32)]
 
 
 class EmceeCfg(C.Structure):
     _fields_ = [("dim", C.c_int32), ("nwalkers", C.c_int32), ("seed", C.c_uint64), ("ensemble_id", C.c_uint64),
-                ("stretch", C.c_float), ("flags", C.c_int32), ("reduce_lanes", C.c_int32)]
+                ("stretch", C.c_double), ("flags", C.c_int32), ("reduce_lanes", C.c_int32)]
 
 
 class RamCfg(C.Structure):
     _fields_ = [("dim", C.c_int32), ("nchains", C.c_int32), ("seed", C.c_uint64), ("first_chain", C.c_uint64),
-                ("alpha", C.c_float), ("gamma", C.c_float), ("eig_lo", C.c_float), ("eig_hi", C.c_float),
+                ("alpha", C.c_double), ("gamma", C.c_double), ("eig_lo", C.c_double), ("eig_hi", C.c_double),
                 ("flags", C.c_int32)]
 
 
 class MalaCfg(C.Structure):
     _fields_ = [("dim", C.c_int32), ("nchains", C.c_int32), ("seed", C.c_uint64), ("first_chain", C.c_uint64),
-                ("sigma2", C.c_float), ("flags", C.c_int32)]
+                ("sigma2", C.c_double), ("flags", C.c_int32)]
 
 
 class Stats(C.Structure):
     _fields_ = [("transitions", C.c_uint64), ("accepted", C.c_uint64), ("kernel_ms", C.c_double),
                 ("wall_ms", C.c_double), ("kernel_variant", C.c_int32), ("launches", C.c_int32),
-                ("reduce_lanes", C.c_int32)]
+                ("reduce_lanes", C.c_int32), ("dtype", C.c_int32)]
 
 
 class DiagCfg(C.Structure):
@@ -77,7 +78,28 @@ EXPORTS = [
     "mhx_run_get_state", "mhx_run_set_state", "mhx_run_stats", "mhx_run_device_samples",
     "mhx_run_destroy", "mhx_run_diagnostics", "mhx_run_ess_bulk_tail", "mhx_emcee_half_step", "mhx_emcee_end_sweep",
     "mhx_emcee_device_state", "mhx_run_state_size", "mhx_run_save_state", "mhx_run_load_state",
+    "mhx_ctx_dtype", "mhx_ctx_device", "mhx_ram_get_adapt_state", "mhx_emcee_exchange_plan", "mhx_emcee_exchange_pack",
+    "mhx_emcee_exchange_unpack", "mhx_comm_unique_id", "mhx_comm_init", "mhx_comm_destroy", "mhx_comm_rank",
+    "mhx_comm_allreduce_sum", "mhx_comm_slice", "mhx_comm_allgather_walkers",
 ]
+
+MHX_F32, MHX_F64 = 0, 1
+DTYPES = {"f32": MHX_F32, "f64": MHX_F64}
+NP_DTYPES = {"f32": np.float32, "f64": np.float64}
+# the reference computes in Float64 (Distributions, src/RobustAdaptiveMetropolis.jl:187-196): that is the default
+_default_dtype = os.environ.get("MHX_DTYPE", "f64")
+
+
+def set_default_dtype(dt):
+    """"f64" (the reference's arithmetic, default) or "f32" (same engine, half the bytes, ~3x the rate)."""
+    global _default_dtype
+    if dt not in DTYPES:
+        raise ValueError("dtype must be 'f32' or 'f64'")
+    _default_dtype = dt
+
+
+def get_default_dtype():
+    return _default_dtype
 
 _lib = None
 
@@ -91,26 +113,30 @@ def lib():
                               "there is no CPU fallback" % LIB_PATH)
         L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
         L.mhx_last_error.restype = C.c_char_p
-        vp, fp, u8p, u32p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_uint32)
+        vp, u8p, u32p = C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint32)
+        rp = C.c_void_p                                   # a buffer of reals of the context's dtype
         dp = C.POINTER(C.c_double)
-        L.mhx_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+        L.mhx_ctx_create.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]
         L.mhx_ctx_destroy.argtypes = [vp]
-        L.mhx_target_builtin.argtypes = [vp, C.c_int, C.c_int, fp, C.c_size_t, C.POINTER(vp)]
-        L.mhx_target_from_hip_source.argtypes = [vp, C.c_char_p, C.c_int, fp, C.c_size_t, C.POINTER(vp)]
+        L.mhx_ctx_dtype.argtypes = [vp]
+        L.mhx_ctx_device.argtypes = [vp, C.POINTER(C.c_int)]
+        L.mhx_target_builtin.argtypes = [vp, C.c_int, C.c_int, rp, C.c_size_t, C.POINTER(vp)]
+        L.mhx_target_from_hip_source.argtypes = [vp, C.c_char_p, C.c_int, rp, C.c_size_t, C.POINTER(vp)]
         L.mhx_target_destroy.argtypes = [vp]
-        L.mhx_target_eval.argtypes = [vp, vp, fp, C.c_int, fp]
+        L.mhx_target_eval.argtypes = [vp, vp, rp, C.c_int, rp]
         L.mhx_rwmh_create.argtypes = [vp, vp, C.POINTER(RwmhCfg), C.POINTER(vp)]
         L.mhx_emcee_create.argtypes = [vp, vp, C.POINTER(EmceeCfg), C.POINTER(vp)]
         L.mhx_ram_create.argtypes = [vp, vp, C.POINTER(RamCfg), C.POINTER(vp)]
         L.mhx_mala_create.argtypes = [vp, vp, C.POINTER(MalaCfg), C.POINTER(vp)]
-        L.mhx_ram_set_factor.argtypes = [vp, fp]
-        L.mhx_ram_get_factor.argtypes = [vp, fp, u8p]
-        L.mhx_ram_get_diag_range.argtypes = [vp, fp, fp]
-        L.mhx_run_init.argtypes = [vp, fp]
+        L.mhx_ram_set_factor.argtypes = [vp, rp]
+        L.mhx_ram_get_factor.argtypes = [vp, rp, u8p]
+        L.mhx_ram_get_diag_range.argtypes = [vp, rp, rp]
+        L.mhx_ram_get_adapt_state.argtypes = [vp, rp, dp, u8p, C.POINTER(C.c_uint64)]
+        L.mhx_run_init.argtypes = [vp, rp]
         L.mhx_run_sample.argtypes = [vp, C.POINTER(Schedule), C.c_int]
-        L.mhx_run_get_samples.argtypes = [vp, fp, u8p]
-        L.mhx_run_get_state.argtypes = [vp, fp, fp, u32p]
-        L.mhx_run_set_state.argtypes = [vp, fp]
+        L.mhx_run_get_samples.argtypes = [vp, rp, u8p]
+        L.mhx_run_get_state.argtypes = [vp, rp, rp, u32p]
+        L.mhx_run_set_state.argtypes = [vp, rp]
         L.mhx_run_stats.argtypes = [vp, C.POINTER(Stats)]
         L.mhx_run_device_samples.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int64)]
         L.mhx_run_destroy.argtypes = [vp]
@@ -120,8 +146,18 @@ def lib():
         L.mhx_run_load_state.argtypes = [vp, C.c_void_p, C.c_size_t]
         L.mhx_emcee_half_step.argtypes = [vp, C.c_int, C.c_int, C.c_int]
         L.mhx_emcee_end_sweep.argtypes = [vp]
-        L.mhx_emcee_device_state.argtypes = [vp, C.POINTER(fp), C.POINTER(C.c_int32), C.POINTER(fp), C.POINTER(u32p), C.POINTER(u8p)]
+        L.mhx_emcee_device_state.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int32), C.POINTER(vp), C.POINTER(u32p), C.POINTER(u8p)]
+        L.mhx_emcee_exchange_plan.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(vp)]
+        L.mhx_emcee_exchange_pack.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
+        L.mhx_emcee_exchange_unpack.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_size_t]
         L.mhx_run_ess_bulk_tail.argtypes = [vp, C.POINTER(DiagCfg), C.POINTER(C.c_int32), C.c_int32, dp, dp]
+        L.mhx_comm_unique_id.argtypes = [vp]
+        L.mhx_comm_init.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
+        L.mhx_comm_destroy.argtypes = [vp]
+        L.mhx_comm_rank.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.mhx_comm_allreduce_sum.argtypes = [vp, dp, C.c_size_t]
+        L.mhx_comm_slice.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.mhx_comm_allgather_walkers.argtypes = [vp, vp, C.c_int]
         _lib = L
     return _lib
 
@@ -137,8 +173,12 @@ def check(rc):
     raise MhxError(rc, msg)
 
 
-def fptr(a):
-    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_float))
+def rptr(a):
+    """pointer to a contiguous array of reals (float32 or float64, the caller made it the context's dtype)"""
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+fptr = rptr
 
 
 def u8ptr(a):
@@ -149,28 +189,34 @@ def u32ptr(a):
     return None if a is None else a.ctypes.data_as(C.POINTER(C.c_uint32))
 
 
-def f32(a):
-    return np.ascontiguousarray(a, dtype=np.float32)
-
-
 class Context:
-    """mhx_ctx: one per GPU."""
+    """mhx_ctx: one per GPU and dtype."""
 
     _default = {}
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, dtype=None):
+        dtype = dtype or _default_dtype
+        if dtype not in DTYPES:
+            raise ValueError("dtype must be 'f32' or 'f64'")
         self.h = C.c_void_p()
-        check(lib().mhx_ctx_create(device, C.byref(self.h)))
+        check(lib().mhx_ctx_create(device, DTYPES[dtype], C.byref(self.h)))
         self.device = device
+        self.dtype = dtype
+        self.real = NP_DTYPES[dtype]
+
+    def arr(self, a):
+        """contiguous array in this context's real type"""
+        return np.ascontiguousarray(a, dtype=self.real)
 
     @classmethod
-    def default(cls, device=None):
+    def default(cls, device=None, dtype=None):
         if device is None:
             device = int(os.environ.get("LOCAL_RANK", "0")) if os.environ.get("MHX_DEVICE") is None else int(
                 os.environ["MHX_DEVICE"])
-        if device not in cls._default:
-            cls._default[device] = cls(device)
-        return cls._default[device]
+        dtype = dtype or _default_dtype
+        if (device, dtype) not in cls._default:
+            cls._default[(device, dtype)] = cls(device, dtype)
+        return cls._default[(device, dtype)]
 
     def close(self):
         if self.h:

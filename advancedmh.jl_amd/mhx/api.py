@@ -90,7 +90,7 @@ class MvNormal:
 
 def pack_lower(M):
     M = np.asarray(M)
-    return np.concatenate([M[i, :i + 1] for i in range(M.shape[0])]).astype(np.float32)
+    return np.concatenate([M[i, :i + 1] for i in range(M.shape[0])]).astype(np.float64)
 
 
 def unpack_lower(p, d):
@@ -128,8 +128,8 @@ class _TargetSpec:
 
     def build(self, ctx):
         h = C.c_void_p()
-        p = None if self.params is None else L.f32(self.params)
-        L.check(L.lib().mhx_target_builtin(ctx.h, self.kind, self.dim, L.fptr(p), 0 if p is None else p.size,
+        p = None if self.params is None else ctx.arr(self.params)      # rounded once to the context's dtype
+        L.check(L.lib().mhx_target_builtin(ctx.h, self.kind, self.dim, L.rptr(p), 0 if p is None else p.size,
                                            C.byref(h)))
         return h
 
@@ -162,7 +162,7 @@ class IIDNormal(_TargetSpec):
     dim = 2
 
     def __init__(self, data):
-        self.params = L.f32(data).ravel()
+        self.params = np.asarray(data, dtype=np.float64).ravel()
 
 
 class Banana(_TargetSpec):
@@ -170,7 +170,7 @@ class Banana(_TargetSpec):
 
     def __init__(self, d, b=0.03):
         self.dim = int(d)
-        self.params = np.array([b], dtype=np.float32)
+        self.params = np.array([b], dtype=np.float64)
 
 
 class Funnel(_TargetSpec):
@@ -181,17 +181,18 @@ class Funnel(_TargetSpec):
 
 
 class HipLogDensity(_TargetSpec):
-    """A user log-density as HIP source:  MHX_LOGDENSITY(x, d, data, ndata) { ...; return lp; }"""
+    """A user log-density as HIP source:  MHX_LOGDENSITY(x, d, data, ndata) { ...; return lp; }  written against
+    `mhx_real` / `MHX_R(literal)` so that it compiles for either dtype."""
     kind = L.TARGET_USER
 
     def __init__(self, source, dim, data=None):
         self.source, self.dim = source, int(dim)
-        self.params = None if data is None else L.f32(data).ravel()
+        self.params = None if data is None else np.asarray(data, dtype=np.float64).ravel()
 
     def build(self, ctx):
         h = C.c_void_p()
-        p = self.params
-        L.check(L.lib().mhx_target_from_hip_source(ctx.h, self.source.encode(), self.dim, L.fptr(p),
+        p = None if self.params is None else ctx.arr(self.params)
+        L.check(L.lib().mhx_target_from_hip_source(ctx.h, self.source.encode(), self.dim, L.rptr(p),
                                                    0 if p is None else p.size, C.byref(h)))
         return h
 
@@ -218,19 +219,19 @@ class DensityModel:
         return self._handles[ctx]
 
 
-def logdensity(model, x, ctx=None):
+def logdensity(model, x, ctx=None, dtype=None):
     """logdensity(model, params) for one point (d,) or a batch (d, n) -- src/AdvancedMH.jl:74."""
     if isinstance(x, Transition):
         return x.lp                                              # cached, src/AdvancedMH.jl:75
-    ctx = ctx or L.Context.default()
-    x = L.f32(x)
+    ctx = ctx or L.Context.default(dtype=dtype)
+    x = ctx.arr(x)
     single = x.ndim == 1
     xb = x.reshape(model.dim, -1)
     if xb.shape[0] != model.dim:
         raise L.ArgumentError(L.MHX_EINVAL, "logdensity: x has the wrong dimension")
     xb = np.ascontiguousarray(xb)
-    lp = np.empty(xb.shape[1], dtype=np.float32)
-    L.check(L.lib().mhx_target_eval(ctx.h, model.handle(ctx), L.fptr(xb), xb.shape[1], L.fptr(lp)))
+    lp = np.empty(xb.shape[1], dtype=ctx.real)
+    L.check(L.lib().mhx_target_eval(ctx.h, model.handle(ctx), L.rptr(xb), xb.shape[1], L.rptr(lp)))
     return float(lp[0]) if single else lp
 
 
@@ -394,8 +395,9 @@ class Chains:
                     rhat=dg["rhat"][idx] if "rhat" in dg else np.full(len(idx), np.nan))
 
     def __repr__(self):
-        head = "Chains MCMC chain (%dx%dx%d Array{Float32, 3}), iterations %d:%d:%d" % (
-            self.value.shape[0], self.value.shape[1], self.value.shape[2], self.start, self.thin, self.range()[-1])
+        head = "Chains MCMC chain (%dx%dx%d Array{%s, 3}), iterations %d:%d:%d" % (
+            self.value.shape[0], self.value.shape[1], self.value.shape[2],
+            "Float64" if self.value.dtype == np.float64 else "Float32", self.start, self.thin, self.range()[-1])
         try:
             st = self.summarystats()
         except Exception:
@@ -414,8 +416,10 @@ class Chains:
 
 
 class Run:
-    def __init__(self, model, sampler, nchains=1, seed=0, first_chain=0, ctx=None, flags=0, reduce_lanes=0):
-        self.ctx = ctx or L.Context.default()
+    def __init__(self, model, sampler, nchains=1, seed=0, first_chain=0, ctx=None, flags=0, reduce_lanes=0, dtype=None):
+        self.ctx = ctx or L.Context.default(dtype=dtype)
+        self.real = self.ctx.real
+        f32 = self.ctx.arr                                  # (the name of round 1: now "an array of the context's reals")
         self.model, self.sampler = model, sampler
         self.h = C.c_void_p()
         lib = L.lib()
@@ -425,8 +429,8 @@ class Run:
             mv = sampler.proposal.proposal
             if mv.dim != d:
                 raise L.ArgumentError(L.MHX_EINVAL, "proposal dimension %d != model dimension %d" % (mv.dim, d))
-            vec = None if mv.vec is None else L.f32(mv.vec)
-            mean = L.f32(mv.mean) if np.any(mv.mean != 0) else None
+            vec = None if mv.vec is None else f32(mv.vec)
+            mean = f32(mv.mean) if np.any(mv.mean != 0) else None
             self._keep += [vec, mean]
             if isinstance(sampler.proposal, StaticProposal):
                 flags |= L.MHX_FLAG_STATIC_PROPOSAL
@@ -458,7 +462,7 @@ class Run:
                     S = np.stack([pack_lower(np.tril(sampler.S[c])) for c in range(nchains)])
                 else:
                     S = np.tile(pack_lower(np.tril(sampler.S)), (nchains, 1))
-                L.check(lib.mhx_ram_set_factor(self.h, L.fptr(L.f32(S))))
+                L.check(lib.mhx_ram_set_factor(self.h, L.rptr(f32(S))))
         else:
             raise L.ArgumentError(L.MHX_EINVAL, "unsupported sampler %r" % (sampler,))
         self.dim = d
@@ -468,7 +472,7 @@ class Run:
     def init(self, initial_params=None):
         ip = None
         if initial_params is not None:
-            ip = np.asarray(initial_params, dtype=np.float32)
+            ip = np.asarray(initial_params, dtype=self.real)
             if self.kind == "emcee" and ip.ndim == 2 and ip.shape == (self.n, self.dim) and self.n != self.dim:
                 ip = ip.T                                       # vector-of-walkers form
             if ip.ndim == 1:
@@ -477,12 +481,12 @@ class Run:
                 ip = np.repeat(ip.reshape(self.dim, 1), self.n, axis=1)
             if ip.shape != (self.dim, self.n):
                 raise L.ArgumentError(L.MHX_EINVAL, "initial_params must be (dim,) or (dim, nchains)")
-            ip = L.f32(ip)
+            ip = self.ctx.arr(ip)
         elif self.kind == "emcee":
             # src/emcee.jl:29-34: W draws from the wrapped prior; a one-off host draw (numpy Generator
             # seeded from the run seed), the device takes over from the first sweep.
             rng = np.random.default_rng([self.seed, 0xE3CEE])
-            ip = L.f32(np.stack([self.sampler.proposal.rand_initial(rng) for _ in range(self.n)], axis=1))
+            ip = self.ctx.arr(np.stack([self.sampler.proposal.rand_initial(rng) for _ in range(self.n)], axis=1))
         L.check(L.lib().mhx_run_init(self.h, L.fptr(ip)))
 
     def sample(self, n_samples, discard_initial=0, thinning=1, num_warmup=0, save=True):
@@ -495,43 +499,54 @@ class Run:
         n_saved = C.c_int64()
         L.check(L.lib().mhx_run_device_samples(self.h, None, None, C.byref(n_saved)))
         N = int(n_saved.value)
-        out = np.empty((N, self.dim + 1, self.n), dtype=np.float32)
+        out = np.empty((N, self.dim + 1, self.n), dtype=self.real)
         acc = np.empty((N, self.n), dtype=np.uint8) if want_accepted else None
         L.check(L.lib().mhx_run_get_samples(self.h, L.fptr(out), L.u8ptr(acc)))
         return out, acc
 
     def state(self):
-        x = np.empty((self.dim, self.n), dtype=np.float32)
-        lp = np.empty(self.n, dtype=np.float32)
+        x = np.empty((self.dim, self.n), dtype=self.real)
+        lp = np.empty(self.n, dtype=self.real)
         cnt = np.empty(self.n, dtype=np.uint32)
         L.check(L.lib().mhx_run_get_state(self.h, L.fptr(x), L.fptr(lp), L.u32ptr(cnt)))
         return x, lp, cnt
 
     def set_params(self, x):
         """AbstractMCMC.setparams!! (src/AdvancedMH.jl:150-157): replaces params, lp is re-evaluated."""
-        x = L.f32(x)
+        x = self.ctx.arr(x)
         if x.shape != (self.dim, self.n):
             raise L.ArgumentError(L.MHX_EINVAL, "set_params: x must be (dim, nchains)")
         L.check(L.lib().mhx_run_set_state(self.h, L.fptr(x)))
 
     def factor(self):
         nS = self.dim * (self.dim + 1) // 2
-        S = np.empty((self.n, nS), dtype=np.float32)
+        S = np.empty((self.n, nS), dtype=self.real)
         st = np.empty(self.n, dtype=np.uint8)
         L.check(L.lib().mhx_ram_get_factor(self.h, L.fptr(S), L.u8ptr(st)))
         return S, st
 
     def diag_range(self):
-        lo = np.empty((self.dim, self.n), dtype=np.float32)
-        hi = np.empty((self.dim, self.n), dtype=np.float32)
+        lo = np.empty((self.dim, self.n), dtype=self.real)
+        hi = np.empty((self.dim, self.n), dtype=self.real)
         L.check(L.lib().mhx_ram_get_diag_range(self.h, L.fptr(lo), L.fptr(hi)))
         return lo, hi
+
+    def adapt_state(self):
+        """The rest of RobustAdaptiveMetropolisState (src/RobustAdaptiveMetropolis.jl:99-114): logα of every chain's latest
+        transition (min(lp' - lp, 0): average exp(logα) for the acceptance probability), the step size η of the latest
+        warm-up transition, the iteration counter and isaccept."""
+        la = np.empty(self.n, dtype=self.real)
+        acc = np.empty(self.n, dtype=np.uint8)
+        eta, it = C.c_double(), C.c_uint64()
+        L.check(L.lib().mhx_ram_get_adapt_state(self.h, L.rptr(la), C.byref(eta), L.u8ptr(acc), C.byref(it)))
+        return dict(logα=la, η=eta.value, iteration=int(it.value), isaccept=acc.astype(bool))
 
     def stats(self):
         st = L.Stats()
         L.check(L.lib().mhx_run_stats(self.h, C.byref(st)))
         return dict(transitions=st.transitions, accepted=st.accepted, kernel_ms=st.kernel_ms, wall_ms=st.wall_ms,
-                    kernel_variant=st.kernel_variant, launches=st.launches, reduce_lanes=st.reduce_lanes)
+                    kernel_variant=st.kernel_variant, launches=st.launches, reduce_lanes=st.reduce_lanes,
+                    dtype="f64" if st.dtype == L.MHX_F64 else "f32")
 
     def diagnostics(self, max_lag=0, ess_chains=256, split=False):
         """Sums for R-hat / between-chain ESS (all chains) and, if max_lag > 0, the Geyer ESS from the multi-chain
@@ -637,11 +652,12 @@ class MCMCHIP(_ParallelTag):
 
 def sample(model, sampler, N, nchains=1, *more, initial_params=None, discard_initial=None, thinning=1, num_warmup=0,
            param_names=None, chain_type=Chains, seed=0, first_chain=0, callback=None, ctx=None, flags=0,
-           reduce_lanes=0, progress=False):
+           reduce_lanes=0, progress=False, dtype=None):
     """sample(model, sampler, N[, nchains]; kwargs...) -- AbstractMCMC.sample as re-exported by the
     reference (src/AdvancedMH.jl:30).  All chains advance together on the GPU (what
     `sample(model, spl, MCMCThreads(), N, nchains)` does with one task per chain, README.md:141-147).
 
+    dtype: "f64" (default: the reference's Float64) or "f32"; see mhx.set_default_dtype.
     discard_initial defaults to num_warmup [upstream]; `callback(run, i)` is called after each saved
     sample (the reference signature callback(rng, model, sampler, sample, state, i) carries objects
     that live on the device here -- the Run gives access to them)."""
@@ -654,7 +670,7 @@ def sample(model, sampler, N, nchains=1, *more, initial_params=None, discard_ini
     if discard_initial is None:
         discard_initial = num_warmup
     run = Run(model, sampler, nchains=nchains, seed=seed, first_chain=first_chain, ctx=ctx, flags=flags,
-              reduce_lanes=reduce_lanes)
+              reduce_lanes=reduce_lanes, dtype=dtype)
     run.init(initial_params)
     if callback is None:
         run.sample(N, discard_initial, thinning, num_warmup)

@@ -17,6 +17,11 @@
  *       samples  [n_samples][dim + 1][nchains]   (row `dim` is lp; cf. ext/AdvancedMHMCMCChainsExt.jl:96-105)
  *       accepted [n_samples][nchains]            (Transition.accepted, src/AdvancedMH.jl:61-65)
  *       S        [nchains][dim*(dim+1)/2]        packed lower triangle, row-major (RAM factor)
+ *   - `real` below is the context's arithmetic type: double for MHX_F64 -- what the reference computes in (Distributions'
+ *     Float64 rand / logpdf; src/RobustAdaptiveMetropolis.jl:187-196: T = eltype(sampler.gamma) = Float64) -- or float
+ *     for MHX_F32 (the same engine at half the bytes and ~3x the rate).  Every `void *` / `const void *` real buffer of
+ *     a call is an array of the dtype of the context the handle belongs to; scalar parameters travel as double and are
+ *     rounded once to the context's type.
  *   - a handle is not thread-safe; distinct contexts (one per GPU) may be driven concurrently.
  *   - chains carry GLOBAL ids first_chain .. first_chain+nchains-1 in their RNG counters, so a run
  *     sharded over several GPUs/processes is bit-identical to the unsharded run.
@@ -31,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MHX_VERSION 100 /* 0.1.0 */
+#define MHX_VERSION 200 /* 0.2.0: fp64 engine, dtype on the context, RCCL collectives */
 
 typedef enum {
     MHX_OK = 0,
@@ -50,7 +55,11 @@ typedef struct mhx_run mhx_run;       /* device-resident chains of one sampler +
 int mhx_version(void);
 const char *mhx_last_error(void);
 
-int mhx_ctx_create(int device, mhx_ctx **out);
+typedef enum { MHX_F32 = 0, MHX_F64 = 1 } mhx_dtype;
+
+int mhx_ctx_create(int device, int dtype /* mhx_dtype */, mhx_ctx **out);
+int mhx_ctx_dtype(const mhx_ctx *ctx);
+int mhx_ctx_device(const mhx_ctx *ctx, int *device);
 int mhx_ctx_destroy(mhx_ctx *ctx);
 
 /* ---------------------------------------------------------------------------------------------
@@ -64,16 +73,17 @@ typedef enum {
     MHX_TARGET_USER = 100      /* hiprtc-compiled user source                                              */
 } mhx_target_kind;
 
-int mhx_target_builtin(mhx_ctx *ctx, int kind, int dim, const float *params, size_t nparams,
+int mhx_target_builtin(mhx_ctx *ctx, int kind, int dim, const void *params, size_t nparams,
                        mhx_target **out);
 /* `src` must define   MHX_LOGDENSITY(x, d, data, ndata) { ... return lp; }   using x[k] and the
- * mhx_fma / mhx_log / mhx_exp / mhx_sqrt device functions; it is compiled by hiprtc and inlined
+ * mhx_fma / mhx_log / mhx_exp / mhx_sqrt device functions, written against `mhx_real` and `MHX_R(literal)` so that one
+ * text serves both dtypes (a source that says `float` is fp32-only); it is compiled by hiprtc and inlined
  * into the sampler kernels (the "JIT-lowered user log-density" of the design). */
-int mhx_target_from_hip_source(mhx_ctx *ctx, const char *src, int dim, const float *data, size_t ndata,
+int mhx_target_from_hip_source(mhx_ctx *ctx, const char *src, int dim, const void *data, size_t ndata,
                                mhx_target **out);
 int mhx_target_destroy(mhx_target *t);
 /* logdensity(model, x) for a batch: x [dim][n] (host) -> lp [n] (host).  src/AdvancedMH.jl:74 */
-int mhx_target_eval(mhx_ctx *ctx, const mhx_target *t, const float *x, int n, float *lp);
+int mhx_target_eval(mhx_ctx *ctx, const mhx_target *t, const void *x, int n, void *lp);
 
 /* ---------------------------------------------------------------------------------------------
  * Schedule.  Replaces the kwargs of AbstractMCMC.sample/mcmcsample [upstream]: N, discard_initial,
@@ -97,10 +107,10 @@ typedef struct {
     uint64_t seed;
     uint64_t first_chain;   /* global id of chain 0 of this shard */
     int32_t proposal_kind;  /* one of mhx_proposal_kind; src/proposal.jl:49-64 */
-    float proposal_scale;   /* ISO: sigma of N(0, sigma^2 I) */
-    const float *proposal_vec; /* DIAG: sigma_k [dim]; DENSE: chol(Sigma) packed lower [dim(dim+1)/2] */
+    double proposal_scale;   /* ISO: sigma of N(0, sigma^2 I) */
+    const void *proposal_vec; /* DIAG: sigma_k [dim]; DENSE: chol(Sigma) packed lower [dim(dim+1)/2] */
     int32_t flags;          /* MHX_FLAG_* */
-    const float *proposal_mean; /* NULL = zero mean.  mu[dim]: a drifting random walk x + mu + L z; its Hastings ratio
+    const void *proposal_mean; /* NULL = zero mean.  mu[dim]: a drifting random walk x + mu + L z; its Hastings ratio
                                q(x | y) - q(y | x) (src/proposal.jl:58-64,190-192) is then non-zero and is computed.
                                Runs on the generic kernel. */
     int32_t reduce_lanes;   /* lanes that share one chain (power of two <= 64) for the separable catalogue
@@ -126,7 +136,7 @@ typedef struct {
     int32_t nwalkers;
     uint64_t seed;
     uint64_t ensemble_id;
-    float stretch;          /* a = 2.0 */
+    double stretch;          /* a = 2.0 */
     int32_t flags;
     int32_t reduce_lanes;   /* lanes per walker (dense-Gaussian target): 0 = engine's choice, 1 = one lane per walker */
 } mhx_emcee_cfg;
@@ -141,18 +151,23 @@ typedef struct {
     int32_t nchains;
     uint64_t seed;
     uint64_t first_chain;
-    float alpha;            /* 0.234 */
-    float gamma;            /* 0.6 */
-    float eig_lo, eig_hi;   /* eigenvalue (diagonal) bounds, 0 and +inf */
+    double alpha;            /* 0.234 */
+    double gamma;            /* 0.6 */
+    double eig_lo, eig_hi;   /* eigenvalue (diagonal) bounds, 0 and +inf */
     int32_t flags;
 } mhx_ram_cfg;
 
 int mhx_ram_create(mhx_ctx *ctx, const mhx_target *t, const mhx_ram_cfg *cfg, mhx_run **out);
 /* in/out Cholesky factors, [nchains][dim(dim+1)/2]; S == NULL on set means identity */
-int mhx_ram_set_factor(mhx_run *run, const float *S);
-int mhx_ram_get_factor(mhx_run *run, float *S, uint8_t *status /* [nchains] or NULL */);
+int mhx_ram_set_factor(mhx_run *run, const void *S);
+int mhx_ram_get_factor(mhx_run *run, void *S, uint8_t *status /* [nchains] or NULL */);
 /* running min / max of diag(S) over every adapted state so far, [dim][nchains] each */
-int mhx_ram_get_diag_range(mhx_run *run, float *diag_min, float *diag_max);
+int mhx_ram_get_diag_range(mhx_run *run, void *diag_min, void *diag_max);
+/* the rest of RobustAdaptiveMetropolisState (src/RobustAdaptiveMetropolis.jl:99-114): log_alpha [nchains] reals = the log
+ * acceptance ratio min(lp' - lp, 0) of each chain's latest transition (kept bounded at 0 so that users can average
+ * exp(log_alpha), :141-147); *eta = the adaptation step size iteration^-gamma of the latest warm-up transition (0 before
+ * any, :211); isaccept [nchains]; *iteration = 1 + transitions so far.  Any pointer may be NULL. */
+int mhx_ram_get_adapt_state(mhx_run *run, void *log_alpha, double *eta, uint8_t *isaccept, uint64_t *iteration);
 
 /* ---------------------------------------------------------------------------------------------
  * Metropolis-adjusted Langevin.  Replaces MALA (src/MALA.jl:1-11), GradientTransition (:14-19) and its step
@@ -166,7 +181,7 @@ typedef struct {
     int32_t nchains;
     uint64_t seed;
     uint64_t first_chain;
-    float sigma2;
+    double sigma2;
     int32_t flags;
 } mhx_mala_cfg;
 
@@ -178,7 +193,7 @@ int mhx_mala_create(mhx_ctx *ctx, const mhx_target *t, const mhx_mala_cfg *cfg, 
  * a draw (RWMH: from the proposal; RAM: randn(d); Ensemble: initial walkers are required).
  * mhx_run_sample == the mcmcsample loop + bundle_samples into the device sample buffer.  It may be
  * called repeatedly; each call continues the chains (counter-based RNG => resumable). */
-int mhx_run_init(mhx_run *run, const float *initial_params /* host [dim][nchains] or NULL */);
+int mhx_run_init(mhx_run *run, const void *initial_params /* host [dim][nchains] or NULL */);
 /* save_samples: 0 = keep nothing, 1 = sample tensor, 2 = running moments only (per chain and parameter the
  * mean / M2 of the states the schedule selects; for runs whose sample tensor would not fit, e.g.
  * 262 144 chains x 1000 dims -- mhx_run_diagnostics then works from the moments; RWMH on the cooperative or
@@ -189,10 +204,10 @@ int mhx_run_init(mhx_run *run, const float *initial_params /* host [dim][nchains
 int mhx_run_sample(mhx_run *run, const mhx_schedule *sched, int save_samples);
 
 /* copy the sample buffer of the last mhx_run_sample to the host (either pointer may be NULL) */
-int mhx_run_get_samples(mhx_run *run, float *samples, uint8_t *accepted);
+int mhx_run_get_samples(mhx_run *run, void *samples, uint8_t *accepted);
 /* getparams / setparams!! (src/AdvancedMH.jl:146-157, src/RobustAdaptiveMetropolis.jl:116-121) */
-int mhx_run_get_state(mhx_run *run, float *x, float *lp, uint32_t *accept_counts);
-int mhx_run_set_state(mhx_run *run, const float *x /* lp is recomputed */);
+int mhx_run_get_state(mhx_run *run, void *x, void *lp, uint32_t *accept_counts);
+int mhx_run_set_state(mhx_run *run, const void *x /* lp is recomputed */);
 
 /* Checkpoint / resume -- the `state` half of AbstractMCMC's (sample, state) = step(...) and of upstream's
  * `initial_state` keyword (src/mh-core.jl:92-117, src/emcee.jl:14-24, src/RobustAdaptiveMetropolis.jl:99-114): the
@@ -214,6 +229,7 @@ typedef struct {
                                   5 hiprtc-specialised cooperative kernel for the dense Gaussian target (RWMH) */
     int32_t launches;
     int32_t reduce_lanes;      /* lanes per chain in effect (1 unless a cooperative kernel runs) */
+    int32_t dtype;             /* mhx_dtype of the run's context */
 } mhx_stats;
 int mhx_run_stats(mhx_run *run, mhx_stats *out);
 
@@ -247,6 +263,7 @@ int mhx_run_diagnostics(mhx_run *run, const mhx_diag_cfg *cfg, double *sum_m, do
                         double *sum_v, double *ess /* each [dim+1], any may be NULL */);
 
 /* ---- building blocks of ONE ensemble sharded over several GPUs (src/emcee.jl:14-24, parallel half-split form).
+ * (mhx_emcee_half_step is stream-ordered, not blocking: the exchange and the next half-step queue behind it.)
  * Every rank holds the whole ensemble; for each half h of a sweep every rank moves its own slice
  * [begin, begin + count) of the moving half with mhx_emcee_half_step and the ranks then exchange the slices (an
  * all-gather of the walker-major rows and the lp / accept arrays that mhx_emcee_device_state exposes -- device
@@ -255,7 +272,36 @@ int mhx_run_diagnostics(mhx_run *run, const mhx_diag_cfg *cfg, double *sum_m, do
  * exactly the walkers a single GPU would (advancedmh.jl_amd/mhx/dist.py: ShardedEnsemble). */
 int mhx_emcee_half_step(mhx_run *run, int half, int begin, int count);
 int mhx_emcee_end_sweep(mhx_run *run);
-int mhx_emcee_device_state(mhx_run *run, float **xw, int32_t *pitch, float **lp, uint32_t **acc_count, uint8_t **last_acc);
+int mhx_emcee_device_state(mhx_run *run, void **xw, int32_t *pitch /* reals per walker row */, void **lp, uint32_t **acc_count,
+                           uint8_t **last_acc);
+
+/* The exchange step of the sharded ensemble as stream-ordered pieces (what mhx_comm_allgather_walkers does with RCCL; a
+ * host that brings its own transport -- MPI, Distributed.jl -- uses them directly): every rank's slice of half `half` is
+ * walkers [cnt q / world, cnt (q+1) / world) of that half; *stride = bytes of one rank's part of the staging buffer
+ * ([world][stride], device memory), *stream = the hipStream_t the run's kernels are queued on.  pack writes this rank's
+ * slice (rows, lp, accept counts, last accept flags) to `part`, unpack scatters the parts of all OTHER ranks into the run. */
+int mhx_emcee_exchange_plan(mhx_run *run, int half, int world, size_t *stride, void **stream);
+int mhx_emcee_exchange_pack(mhx_run *run, int half, int rank, int world, void *part);
+int mhx_emcee_exchange_unpack(mhx_run *run, int half, int rank, int world, const void *stage, size_t stride);
+
+/* ---------------------------------------------------------------------------------------------
+ * Collectives (RCCL over xGMI; one process per GPU).  Chains shard by global id with no data-path collective; these
+ * carry the acceptance totals and the R-hat / ESS sums of a sharded run (ONE all-reduce of 3(dim+1)+3 doubles per
+ * reporting interval) and the half-step exchange of ONE ensemble sharded over the GPUs (ONE all-gather).  librccl is
+ * resolved at run time.  mhx_comm_unique_id is called on one rank; the 128 bytes travel to the others by whatever the
+ * host has (Distributed.jl, MPI, a file) and every rank calls mhx_comm_init with them. */
+typedef struct mhx_comm mhx_comm;
+#define MHX_COMM_ID_BYTES 128
+int mhx_comm_unique_id(void *id128);
+int mhx_comm_init(mhx_ctx *ctx, int rank, int world, const void *id128, mhx_comm **out);
+int mhx_comm_destroy(mhx_comm *comm);
+int mhx_comm_rank(const mhx_comm *comm, int *rank, int *world);
+/* in-place sum over the ranks of n doubles in HOST memory (blocking) */
+int mhx_comm_allreduce_sum(mhx_comm *comm, double *inout, size_t n);
+/* this rank's slice [*begin, *begin + *count) of a half with cnt walkers */
+int mhx_comm_slice(const mhx_comm *comm, int cnt, int *begin, int *count);
+/* after mhx_emcee_half_step(run, half, begin, count) with the slice above: exchange the moved slices (stream-ordered) */
+int mhx_comm_allgather_walkers(mhx_comm *comm, mhx_run *run, int half);
 
 /* Rank-normalised bulk ESS and tail ESS (Vehtari et al. 2021, sections 4.1-4.3; what MCMCChains / ArviZ print as
  * ess_bulk, ess_tail) of the parameters params[0..nparams) (indices into the dim+1 rows, lp = dim) of the sample

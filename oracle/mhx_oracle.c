@@ -1,9 +1,11 @@
 /*
  * mhx_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).  See mhx_oracle.h.
  *
- * Scalar, one chain at a time, fp32, written against the arithmetic spec of DESIGN.md section 3
- * so that it is bit-comparable with the HIP kernels.  Build: oracle/Makefile (gcc, -ffp-contract=off:
- * every fused multiply-add below is an explicit fmaf, every other operation rounds separately).
+ * Scalar, one chain at a time, written against the arithmetic spec of DESIGN.md section 3 so that it is
+ * bit-comparable with the HIP kernels.  One source, two builds (oracle/Makefile): ORC_F64=0 -> libmhx_oracle.so
+ * (`real` = float, the fp32 engine) and ORC_F64=1 -> libmhx_oracle64.so (`real` = double: the reference computes in
+ * Float64 end to end -- Distributions' rand / logpdf, src/RobustAdaptiveMetropolis.jl:187-196 `T = eltype(sampler.gamma)`).
+ * gcc, -ffp-contract=off: every fused multiply-add below is an explicit FMA, every other operation rounds separately.
  */
 #include "mhx_oracle.h"
 
@@ -11,10 +13,26 @@
 #include <stdlib.h>
 #include <string.h>
 
+#if ORC_F64
+#define R(x) x
+#define FMA(a, b, c) fma((a), (b), (c))
+#define SQRT(x) sqrt(x)
+#define FABS(x) fabs(x)
+#define RINT(x) rint(x)
+#else
+#define R(x) x##f
+#define FMA(a, b, c) fmaf((a), (b), (c))
+#define SQRT(x) sqrtf(x)
+#define FABS(x) fabsf(x)
+#define RINT(x) rintf(x)
+#endif
+
 /* ------------------------------------------------------------------------------------------ */
 /* bit casts                                                                                  */
 static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float    u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint64_t d2u(double f) { uint64_t u; memcpy(&u, &f, 8); return u; }
+static inline double   u2d(uint64_t u) { double f; memcpy(&f, &u, 8); return f; }
 
 /* ------------------------------------------------------------------------------------------ */
 /* Philox4x32-10 (Salmon et al. 2011; constants as in rocrand_philox4x32_10.h:62-65)          */
@@ -44,13 +62,17 @@ static void philox_at(uint64_t seed, uint64_t id, uint32_t step, uint32_t stream
     orc_philox4x32_10(ctr, key, out);
 }
 
+#if !ORC_F64
 /* ------------------------------------------------------------------------------------------ */
-/* transcendental spec (coefficients: tools/fit_coeffs.py)                                    */
+/* fp32 transcendental spec (coefficients: tools/fit_coeffs.py)                               */
 #define LN2_HI 0x1.62e4p-1f           /* 16 significant bits: e*LN2_HI is exact for |e| < 256 */
 #define LN2_LO 0x1.7f7d1cp-20f        /* ln2 - LN2_HI */
 #define LOG2E  0x1.715476p+0f
+#define HALF_LOG_2PI 0x1.d67f1cp-1f
+#define ONE_18 0x1.c71c72p-5f
+#define ONE_9  0x1.c71c72p-4f
 
-float orc_logf(float x)
+float orc_log(float x)
 {
     uint32_t ix = f2u(x);
     int eadj = 0;
@@ -81,7 +103,7 @@ float orc_logf(float x)
     return r;
 }
 
-float orc_expf(float x)
+float orc_exp(float x)
 {
     if (x != x) return x;
     if (x > 0x1.62e42ep+6f) return INFINITY;           /* > 88.72283 overflows */
@@ -137,7 +159,7 @@ float orc_u01_half(uint32_t k) { return (float)(k >> 8) * 0x1p-24f; }
 /* Box-Muller: radius from k0, angle from k1 */
 void orc_normal_pair(uint32_t k0, uint32_t k1, float *n0, float *n1)
 {
-    float l = orc_logf(orc_u01_open(k0));              /* <= 0 */
+    float l = orc_log(orc_u01_open(k0));               /* <= 0 */
     float rad = sqrtf(-2.0f * l);
     float s, c;
     orc_sincos2pi_u32(k1, &s, &c);
@@ -145,6 +167,7 @@ void orc_normal_pair(uint32_t k0, uint32_t k1, float *n0, float *n1)
     *n1 = rad * s;
 }
 
+/* normals 4b .. 4b+3 of (seed, chain, step, stream): one Philox block */
 void orc_normals(uint64_t seed, uint64_t chain, uint32_t step, uint32_t stream, int d, float *out)
 {
     for (int b = 0; 4 * b < d; ++b) {
@@ -161,15 +184,194 @@ float orc_accept_logu(uint64_t seed, uint64_t chain, uint32_t step)
 {
     uint32_t w[4];
     philox_at(seed, chain, step >> 2, ORC_STREAM_ACCEPT, 0, w);
-    return orc_logf(orc_u01_open(w[step & 3]));
+    return orc_log(orc_u01_open(w[step & 3]));
 }
+
+/* the draws of one stretch move (src/emcee.jl:48,52 partner, :81 stretch uniform, :93 accept): one Philox block */
+static void emcee_draws(uint64_t seed, uint64_t ens, int i, uint32_t sweep, uint32_t *partner_word, float *u, float *logu)
+{
+    uint32_t w[4];
+    philox_at(seed, ((uint64_t)ens << 32) | (uint32_t)i, sweep, ORC_STREAM_EMCEE, 0, w);
+    *partner_word = w[0];
+    *u = orc_u01_half(w[1]);
+    *logu = orc_log(orc_u01_open(w[2]));
+}
+
+#else /* ORC_F64 */
+/* ------------------------------------------------------------------------------------------ */
+/* fp64 transcendental spec (coefficients: tools/fit_coeffs64.py)                             */
+#define LN2_HI 0x1.62e42feep-1                  /* 32 significant bits: e*LN2_HI is exact for |e| < 2^20 */
+#define LN2_LO 0x1.a39ef35793c76p-33            /* ln2 - LN2_HI */
+#define LOG2E  0x1.71547652b82fep+0
+#define HALF_LOG_2PI 0x1.d67f1c864beb5p-1
+#define ONE_18 0x1.c71c71c71c71cp-5
+#define ONE_9  0x1.c71c71c71c71cp-4
+
+/* m in [sqrt(1/2), sqrt(2)), f = m - 1, s = f / (2 + f), z = s^2:
+ *   log(1 + f) = log((1+s)/(1-s)) = 2 s + s z P(z) = f - hfsq + s (hfsq + z P(z)),  hfsq = f^2 / 2
+ * (the classical argument reduction; one correctly rounded division) */
+double orc_log(double x)
+{
+    uint64_t ix = d2u(x);
+    int eadj = 0;
+    if ((ix << 1) == 0) return -INFINITY;
+    if (ix >> 63) return NAN;
+    if (ix >= 0x7ff0000000000000ull) return x;
+    if (ix < 0x0010000000000000ull) { x = x * 0x1p54; ix = d2u(x); eadj = -54; }
+    uint64_t t = ix - 0x3fe6a09e667f3bcdull;           /* bits(sqrt(1/2)) */
+    int64_t e = (int64_t)t >> 52;
+    double m = u2d(ix - ((uint64_t)e << 52));
+    double f = m - 1.0;
+    double s = f / (2.0 + f);
+    double z = s * s;
+    double p = 0x1.2b59b70eb76c6p-3;
+    p = fma(p, z, 0x1.39fe42e9d4a8ap-3);
+    p = fma(p, z, 0x1.7462b58e4403ap-3);
+    p = fma(p, z, 0x1.c71c62e26212ep-3);
+    p = fma(p, z, 0x1.2492492df3ba9p-2);
+    p = fma(p, z, 0x1.99999999952ccp-2);
+    p = fma(p, z, 0x1.5555555555558p-1);
+    double hfsq = (0.5 * f) * f;
+    double ef = (double)(e + eadj);
+    double t1 = s * fma(z, p, hfsq);
+    double t2 = fma(ef, LN2_LO, t1);
+    double t3 = hfsq - t2;
+    double t4 = f - t3;
+    return fma(ef, LN2_HI, t4);
+}
+
+double orc_exp(double x)
+{
+    if (x != x) return x;
+    if (x > 0x1.62e42fefa39efp+9) return INFINITY;      /* > 709.78 overflows */
+    if (x < -0x1.74910d52d3052p+9) return 0.0;          /* < -745.13 rounds to 0 */
+    double n = rint(x * LOG2E);
+    double r = fma(n, -LN2_HI, x);
+    r = fma(n, -LN2_LO, r);
+    double p = 0x1.61bfaa228dde5p-33;
+    p = fma(p, r, 0x1.1f7f2776cfaf2p-29);
+    p = fma(p, r, 0x1.ae642c82e33d5p-26);
+    p = fma(p, r, 0x1.27e4d41966f2fp-22);
+    p = fma(p, r, 0x1.71de3a5aa7bb7p-19);
+    p = fma(p, r, 0x1.a01a01a9e991bp-16);
+    p = fma(p, r, 0x1.a01a01a0196acp-13);
+    p = fma(p, r, 0x1.6c16c16c15a68p-10);
+    p = fma(p, r, 0x1.1111111111111p-7);
+    p = fma(p, r, 0x1.5555555555557p-5);
+    p = fma(p, r, 0x1.5555555555555p-3);
+    p = fma(p, r, 0.5);
+    double r2 = r * r;
+    double y = fma(r2, p, r) + 1.0;
+    int ni = (int)n;
+    int n1 = ni / 2;
+    int n2 = ni - n1;
+    y = y * u2d((uint64_t)(n1 + 1023) << 52);
+    y = y * u2d((uint64_t)(n2 + 1023) << 52);
+    return y;
+}
+
+/* angle = 2 pi a / 2^64, a = hi:lo.  Integer quadrant reduction; the residual keeps 52 bits so that it is exact in
+ * a double: r = ((ri >> 10) as double) * 2^-54 turns, [-1/8, 1/8) */
+void orc_sincos2pi_u64(uint32_t hi, uint32_t lo, double *s, double *c)
+{
+    uint64_t a = ((uint64_t)hi << 32) | lo;
+    uint64_t kk = a + 0x2000000000000000ull;           /* wraps mod 2^64 */
+    unsigned q = (unsigned)(kk >> 62);
+    int64_t ri = (int64_t)(kk & 0x3fffffffffffffffull) - 0x2000000000000000ll;   /* [-2^61, 2^61) */
+    int64_t ti = ri >> 10;                             /* arithmetic shift: [-2^51, 2^51) */
+    double r = (double)ti * 0x1p-54;
+    double u = r * r;
+    /* sin(2 pi r) = 2 pi r + r u S1(u), 2 pi = HI + LO;  cos(2 pi r) = 1 - 2 pi^2 u + u^2 C2(u), -2 pi^2 = HI + LO */
+    double s1 = -0x1.6cc577dadd922p-1;
+    s1 = fma(s1, u, 0x1.e8f036bcd3237p+1);
+    s1 = fma(s1, u, -0x1.e3074d2614b2dp+3);
+    s1 = fma(s1, u, 0x1.50783486facaap+5);
+    s1 = fma(s1, u, -0x1.32d2cce62b872p+6);
+    s1 = fma(s1, u, 0x1.466bc6775aae1p+6);
+    s1 = fma(s1, u, -0x1.4abbce625be53p+5);
+    double ts = (r * u) * s1;
+    double sp = fma(r, 0x1.921fb54442d18p+2, fma(r, 0x1.1a62633145c07p-52, ts));
+    double c2 = 0x1.1ebe62242e9d8p-2;
+    c2 = fma(c2, u, -0x1.b6df855cc99ffp+0);
+    c2 = fma(c2, u, 0x1.f9d38850e5eedp+2);
+    c2 = fma(c2, u, -0x1.a6d1f2a15a701p+4);
+    c2 = fma(c2, u, 0x1.e1f506891b72fp+5);
+    c2 = fma(c2, u, -0x1.55d3c7e3cbffap+6);
+    c2 = fma(c2, u, 0x1.03c1f081b5ac4p+6);
+    double wc = (u * u) * c2;
+    double vc = fma(u, -0x1.692b71366cc04p-50, wc);
+    double ac = fma(u, -0x1.3bd3cc9be45dep+4, 1.0);             /* in [0.69, 1]: 1 - ac is exact */
+    double ec = fma(u, -0x1.3bd3cc9be45dep+4, 1.0 - ac);        /* what the rounding of ac dropped */
+    double cp = ac + (vc + ec);
+    double ss = (q & 1) ? cp : sp;
+    double cc = (q & 1) ? sp : cp;
+    if (q == 2 || q == 3) ss = -ss;
+    if (q == 1 || q == 2) cc = -cc;
+    *s = ss; *c = cc;
+}
+
+/* 52-bit uniforms from two Philox words: k = hi:lo >> 12 */
+double orc_u01_open(uint32_t hi, uint32_t lo)          /* (0,1): (k + 1/2) 2^-52, exact */
+{
+    uint64_t k = ((uint64_t)hi << 20) | (lo >> 12);
+    return fma((double)k, 0x1p-52, 0x1p-53);
+}
+double orc_u01_half(uint32_t hi, uint32_t lo)          /* [0,1): k 2^-52 */
+{
+    uint64_t k = ((uint64_t)hi << 20) | (lo >> 12);
+    return (double)k * 0x1p-52;
+}
+
+/* Box-Muller from one Philox block: radius from (w0, w1), angle from (w2, w3) */
+void orc_normal_pair(const uint32_t w[4], double *n0, double *n1)
+{
+    double l = orc_log(orc_u01_open(w[0], w[1]));      /* < 0 */
+    double rad = sqrt(-2.0 * l);
+    double s, c;
+    orc_sincos2pi_u64(w[2], w[3], &s, &c);
+    *n0 = rad * c;
+    *n1 = rad * s;
+}
+
+/* normals 4b .. 4b+3 of (seed, chain, step, stream): Philox blocks 2b (normals 4b, 4b+1) and 2b+1 (4b+2, 4b+3) */
+void orc_normals(uint64_t seed, uint64_t chain, uint32_t step, uint32_t stream, int d, double *out)
+{
+    for (int b = 0; 4 * b < d; ++b) {
+        uint32_t w[4]; double n[4];
+        philox_at(seed, chain, step, stream, (uint32_t)(2 * b), w);
+        orc_normal_pair(w, &n[0], &n[1]);
+        philox_at(seed, chain, step, stream, (uint32_t)(2 * b + 1), w);
+        orc_normal_pair(w, &n[2], &n[3]);
+        for (int j = 0; j < 4 && 4 * b + j < d; ++j) out[4 * b + j] = n[j];
+    }
+}
+
+/* log of the accept uniform: the block is shared by 2 consecutive steps */
+double orc_accept_logu(uint64_t seed, uint64_t chain, uint32_t step)
+{
+    uint32_t w[4];
+    philox_at(seed, chain, step >> 1, ORC_STREAM_ACCEPT, 0, w);
+    return (step & 1) ? orc_log(orc_u01_open(w[2], w[3])) : orc_log(orc_u01_open(w[0], w[1]));
+}
+
+/* the draws of one stretch move: block 0 = partner word, stretch uniform (w1, w2); block 1 = accept uniform (w0, w1) */
+static void emcee_draws(uint64_t seed, uint64_t ens, int i, uint32_t sweep, uint32_t *partner_word, double *u, double *logu)
+{
+    uint32_t w[4];
+    philox_at(seed, ((uint64_t)ens << 32) | (uint32_t)i, sweep, ORC_STREAM_EMCEE, 0, w);
+    *partner_word = w[0];
+    *u = orc_u01_half(w[1], w[2]);
+    philox_at(seed, ((uint64_t)ens << 32) | (uint32_t)i, sweep, ORC_STREAM_EMCEE, 1, w);
+    *logu = orc_log(orc_u01_open(w[0], w[1]));
+}
+#endif
+
+#define LOG_2PI_D 1.8378770664093454835606594728112
 
 /* ------------------------------------------------------------------------------------------ */
 /* targets.  reference: logdensity(model, x) = model.logdensity(x), src/AdvancedMH.jl:74      */
-#define LOG_2PI_D 1.8378770664093454835606594728112
-#define HALF_LOG_2PI_F 0x1.d67f1cp-1f
 
-static float target_const(const orc_target *t)
+static real target_const(const orc_target *t)
 {
     const int d = t->dim;
     double c = -0.5 * (double)d * LOG_2PI_D;
@@ -183,123 +385,123 @@ static float target_const(const orc_target *t)
     case ORC_TARGET_FUNNEL: c -= log(3.0); break;
     default: break;
     }
-    return (float)c;
+    return (real)c;
 }
 
 /* sum of squares of a separable target with the L-lane reduction shape:
  * `first` elements are handled by the caller-supplied head (lane 0, block 0). */
-static float butterfly(float *p, int L)
+static real butterfly(real *p, int L)
 {
-    float tmp[64];
+    real tmp[64];
     for (int off = 1; off < L; off <<= 1) {
         for (int l = 0; l < L; ++l) tmp[l] = p[l] + p[l ^ off];
-        memcpy(p, tmp, sizeof(float) * (size_t)L);
+        memcpy(p, tmp, sizeof(real) * (size_t)L);
     }
     return p[0];
 }
 
-static float split_sum_squares(const orc_target *t, const float *x)
+static real split_sum_squares(const orc_target *t, const real *x)
 {
     const int d = t->dim, L = t->reduce_lanes, nblk = (d + 3) / 4;
-    float p[64];
+    real p[64];
     for (int l = 0; l < L; ++l) {
-        float q = 0.0f;
+        real q = R(0.0);
         for (int b = l; b < nblk; b += L)
             for (int j = 0; j < 4; ++j) {
                 const int k = 4 * b + j;
                 if (k >= d) break;
-                if (t->kind == ORC_TARGET_BANANA && k == 0) { q = (x[0] * x[0]) * 0.01f; continue; }
+                if (t->kind == ORC_TARGET_BANANA && k == 0) { q = (x[0] * x[0]) * R(0.01); continue; }
                 if (t->kind == ORC_TARGET_BANANA && k == 1) {
-                    float u = fmaf(t->params[0], fmaf(x[0], x[0], -100.0f), x[1]);
-                    q = fmaf(u, u, q);
+                    real u = FMA(t->params[0], FMA(x[0], x[0], -R(100.0)), x[1]);
+                    q = FMA(u, u, q);
                     continue;
                 }
                 if (t->kind == ORC_TARGET_FUNNEL && k == 0) continue;
-                q = fmaf(x[k], x[k], q);
+                q = FMA(x[k], x[k], q);
             }
         p[l] = q;
     }
     return butterfly(p, L);
 }
 
-float orc_target_eval(const orc_target *t, const float *x)
+real orc_target_eval(const orc_target *t, const real *x)
 {
     const int d = t->dim;
     if (t->reduce_lanes > 1 && t->kind == ORC_TARGET_CORR_GAUSS) {
         /* rows i = l, l+L, ... on lane l (each row-dot sequential), partial sums of squares in a butterfly */
-        const float *A = t->params;
+        const real *A = t->params;
         const int L = t->reduce_lanes;
-        float p[64];
+        real p[64];
         for (int l = 0; l < L; ++l) {
-            float q = 0.0f;
+            real q = R(0.0);
             for (int i = l; i < d; i += L) {
                 const size_t off = (size_t)i * ((size_t)i + 1) / 2;
-                float w = 0.0f;
-                for (int j = 0; j <= i; ++j) w = fmaf(A[off + j], x[j], w);
-                q = fmaf(w, w, q);
+                real w = R(0.0);
+                for (int j = 0; j <= i; ++j) w = FMA(A[off + j], x[j], w);
+                q = FMA(w, w, q);
             }
             p[l] = q;
         }
-        return fmaf(-0.5f, butterfly(p, L), target_const(t));
+        return FMA(-R(0.5), butterfly(p, L), target_const(t));
     }
     if (t->reduce_lanes > 1 && (t->kind == ORC_TARGET_ISO_GAUSS || t->kind == ORC_TARGET_BANANA ||
                                 t->kind == ORC_TARGET_FUNNEL)) {
-        const float q = split_sum_squares(t, x);
-        if (t->kind != ORC_TARGET_FUNNEL) return fmaf(-0.5f, q, target_const(t));
-        const float v = x[0];
-        float ev = orc_expf(-v);
-        float r = (v * v) * 0x1.c71c72p-5f;
-        r = fmaf(0.5f * (float)(d - 1), v, r);
-        r = fmaf(0.5f * ev, q, r);
+        const real q = split_sum_squares(t, x);
+        if (t->kind != ORC_TARGET_FUNNEL) return FMA(-R(0.5), q, target_const(t));
+        const real v = x[0];
+        real ev = orc_exp(-v);
+        real r = (v * v) * ONE_18;
+        r = FMA(R(0.5) * (real)(d - 1), v, r);
+        r = FMA(R(0.5) * ev, q, r);
         return target_const(t) - r;
     }
     switch (t->kind) {
     case ORC_TARGET_ISO_GAUSS: {                       /* logpdf(MvNormal(zeros(d), I), x) */
-        float q = 0.0f;
-        for (int k = 0; k < d; ++k) q = fmaf(x[k], x[k], q);
-        return fmaf(-0.5f, q, target_const(t));
+        real q = R(0.0);
+        for (int k = 0; k < d; ++k) q = FMA(x[k], x[k], q);
+        return FMA(-R(0.5), q, target_const(t));
     }
     case ORC_TARGET_CORR_GAUSS: {                      /* -1/2 |A x|^2 + const, A = inv(chol(Sigma)) */
-        const float *A = t->params;
-        float q = 0.0f;
+        const real *A = t->params;
+        real q = R(0.0);
         size_t off = 0;
         for (int i = 0; i < d; ++i) {
-            float w = 0.0f;
-            for (int j = 0; j <= i; ++j) w = fmaf(A[off + j], x[j], w);
-            q = fmaf(w, w, q);
+            real w = R(0.0);
+            for (int j = 0; j <= i; ++j) w = FMA(A[off + j], x[j], w);
+            q = FMA(w, w, q);
             off += (size_t)i + 1;
         }
-        return fmaf(-0.5f, q, target_const(t));
+        return FMA(-R(0.5), q, target_const(t));
     }
     case ORC_TARGET_IID_NORMAL: {                      /* README.md:29-31 / test/runtests.jl:26-28 */
-        const float mu = x[0], sigma = x[1];
-        if (!(sigma >= 0.0f)) return -INFINITY;        /* insupport(theta) = theta[2] >= 0 */
-        if (sigma == 0.0f) return -INFINITY;
-        float acc = 0.0f;
+        const real mu = x[0], sigma = x[1];
+        if (!(sigma >= R(0.0))) return -INFINITY;        /* insupport(theta) = theta[2] >= 0 */
+        if (sigma == R(0.0)) return -INFINITY;
+        real acc = R(0.0);
         for (int i = 0; i < t->nparams; ++i) {
-            float z = (t->params[i] - mu) / sigma;
-            acc = fmaf(z, z, acc);
+            real z = (t->params[i] - mu) / sigma;
+            acc = FMA(z, z, acc);
         }
-        float nf = (float)t->nparams;
-        float tt = orc_logf(sigma) + HALF_LOG_2PI_F;
-        return fmaf(-0.5f, acc, -(nf * tt));
+        real nf = (real)t->nparams;
+        real tt = orc_log(sigma) + HALF_LOG_2PI;
+        return FMA(-R(0.5), acc, -(nf * tt));
     }
     case ORC_TARGET_BANANA: {
-        const float b = t->params[0];
-        float q = (x[0] * x[0]) * 0.01f;
-        float u = fmaf(b, fmaf(x[0], x[0], -100.0f), x[1]);
-        q = fmaf(u, u, q);
-        for (int k = 2; k < d; ++k) q = fmaf(x[k], x[k], q);
-        return fmaf(-0.5f, q, target_const(t));
+        const real b = t->params[0];
+        real q = (x[0] * x[0]) * R(0.01);
+        real u = FMA(b, FMA(x[0], x[0], -R(100.0)), x[1]);
+        q = FMA(u, u, q);
+        for (int k = 2; k < d; ++k) q = FMA(x[k], x[k], q);
+        return FMA(-R(0.5), q, target_const(t));
     }
     case ORC_TARGET_FUNNEL: {
-        const float v = x[0];
-        float q = 0.0f;
-        for (int k = 1; k < d; ++k) q = fmaf(x[k], x[k], q);
-        float ev = orc_expf(-v);
-        float r = (v * v) * 0x1.c71c72p-5f;             /* 1/18 */
-        r = fmaf(0.5f * (float)(d - 1), v, r);
-        r = fmaf(0.5f * ev, q, r);
+        const real v = x[0];
+        real q = R(0.0);
+        for (int k = 1; k < d; ++k) q = FMA(x[k], x[k], q);
+        real ev = orc_exp(-v);
+        real r = (v * v) * ONE_18;             /* 1/18 */
+        r = FMA(R(0.5) * (real)(d - 1), v, r);
+        r = FMA(R(0.5) * ev, q, r);
         return target_const(t) - r;
     }
     case ORC_TARGET_CALLBACK:
@@ -312,21 +514,21 @@ float orc_target_eval(const orc_target *t, const float *x)
 /* ------------------------------------------------------------------------------------------ */
 /* proposal draw: xi ~ MvNormal(0, Sigma) = L z   [upstream Distributions rand(MvNormal), restated]
  * reference call sites: src/proposal.jl:24-25 (rand), :41-47 (initial), :49-56 (t + rand).   */
-static void propose_from(const orc_proposal *p, int d, const float *z, const float *x, float *y)
+static void propose_from(const orc_proposal *p, int d, const real *z, const real *x, real *y)
 {
-    const float *mu = p->mean;
+    const real *mu = p->mean;
     switch (p->kind) {
     case ORC_PROP_ISO:
-        for (int k = 0; k < d; ++k) y[k] = mu ? x[k] + fmaf(p->scale, z[k], mu[k]) : fmaf(p->scale, z[k], x[k]);
+        for (int k = 0; k < d; ++k) y[k] = mu ? x[k] + FMA(p->scale, z[k], mu[k]) : FMA(p->scale, z[k], x[k]);
         break;
     case ORC_PROP_DIAG:
-        for (int k = 0; k < d; ++k) y[k] = mu ? x[k] + fmaf(p->vec[k], z[k], mu[k]) : fmaf(p->vec[k], z[k], x[k]);
+        for (int k = 0; k < d; ++k) y[k] = mu ? x[k] + FMA(p->vec[k], z[k], mu[k]) : FMA(p->vec[k], z[k], x[k]);
         break;
     default: {
         size_t off = 0;
         for (int i = 0; i < d; ++i) {
-            float w = 0.0f;
-            for (int j = 0; j <= i; ++j) w = fmaf(p->vec[off + j], z[j], w);
+            real w = R(0.0);
+            for (int j = 0; j <= i; ++j) w = FMA(p->vec[off + j], z[j], w);
             y[i] = mu ? x[i] + (mu[i] + w) : x[i] + w;
             off += (size_t)i + 1;
         }
@@ -336,29 +538,29 @@ static void propose_from(const orc_proposal *p, int d, const float *z, const flo
 
 /* q(x) = -1/2 |L^-1 (x - mu)|^2: logpdf of the proposal at x up to its constant (src/proposal.jl:31-35);
  * forward substitution, every sum in ascending order */
-static float static_logq(const orc_proposal *p, int d, const float *x, float *t)
+static real static_logq(const orc_proposal *p, int d, const real *x, real *t)
 {
-    const float *mu = p->mean;
+    const real *mu = p->mean;
     size_t off = 0;
-    float q = 0.0f;
+    real q = R(0.0);
     for (int i = 0; i < d; ++i) {
-        const float r = mu ? x[i] - mu[i] : x[i];
+        const real r = mu ? x[i] - mu[i] : x[i];
         if (p->kind == ORC_PROP_ISO) t[i] = r / p->scale;
         else if (p->kind == ORC_PROP_DIAG) t[i] = r / p->vec[i];
         else {
-            float acc = 0.0f;
-            for (int j = 0; j < i; ++j) acc = fmaf(p->vec[off + j], t[j], acc);
+            real acc = R(0.0);
+            for (int j = 0; j < i; ++j) acc = FMA(p->vec[off + j], t[j], acc);
             t[i] = (r - acc) / p->vec[off + i];
             off += (size_t)i + 1;
         }
-        q = fmaf(t[i], t[i], q);
+        q = FMA(t[i], t[i], q);
     }
-    return -0.5f * q;
+    return -R(0.5) * q;
 }
 
 /* twice the whitened mean 2 L^-1 mu (host arithmetic in double, rounded once): with it the Hastings ratio of a
  * drifting random walk is  logq(x|y) - logq(y|x) = 1/2 |z|^2 - 1/2 |z + 2 L^-1 mu|^2   (src/proposal.jl:58-64,190-192) */
-static void whitened_mean2(const orc_proposal *p, int d, float *tm)
+static void whitened_mean2(const orc_proposal *p, int d, real *tm)
 {
     double *m = malloc(sizeof(double) * (size_t)d);
     size_t off = 0;
@@ -371,7 +573,7 @@ static void whitened_mean2(const orc_proposal *p, int d, float *tm)
             m[i] = acc / (double)p->vec[off + i];
             off += (size_t)i + 1;
         }
-        tm[i] = (float)(2.0 * m[i]);
+        tm[i] = (real)(2.0 * m[i]);
     }
     free(m);
 }
@@ -399,11 +601,11 @@ static int64_t save_slot(const orc_schedule *s, int64_t tau)
     return r / s->thinning;                            /* tau = discard_initial -> slot 0 */
 }
 
-static void record(float *samples, uint8_t *accepted, int64_t slot, int d, int C, int c,
-                   const float *x, float lp, int acc)
+static void record(real *samples, uint8_t *accepted, int64_t slot, int d, int C, int c,
+                   const real *x, real lp, int acc)
 {
     if (samples) {
-        float *row = samples + (size_t)slot * (size_t)(d + 1) * (size_t)C;
+        real *row = samples + (size_t)slot * (size_t)(d + 1) * (size_t)C;
         for (int k = 0; k < d; ++k) row[(size_t)k * C + c] = x[k];
         row[(size_t)d * C + c] = lp;
     }
@@ -414,16 +616,16 @@ static void record(float *samples, uint8_t *accepted, int64_t slot, int d, int C
 /* RWMH: src/mh-core.jl:76-86 (initial step) and :92-117 (step)                               */
 int orc_rwmh(const orc_target *t, const orc_proposal *p, const orc_schedule *s,
              uint64_t seed, uint64_t first_chain, int nchains,
-             const float *init, float *samples, uint8_t *accepted,
-             float *final_x, float *final_lp, uint32_t *accept_counts)
+             const real *init, real *samples, uint8_t *accepted,
+             real *final_x, real *final_lp, uint32_t *accept_counts)
 {
     const int d = t->dim, C = nchains;
     int64_t nT, nA;
     orc_schedule_counts(s, &nT, &nA);
-    float *x = malloc(sizeof(float) * (size_t)d * 5);
-    float *y = x + d, *z = y + d, *tm = z + d, *zero = tm + d;
+    real *x = malloc(sizeof(real) * (size_t)d * 5);
+    real *y = x + d, *z = y + d, *tm = z + d, *zero = tm + d;
     if (p->mean && !p->is_static) whitened_mean2(p, d, tm);
-    for (int k = 0; k < d; ++k) zero[k] = 0.0f;
+    for (int k = 0; k < d; ++k) zero[k] = R(0.0);
     for (int c = 0; c < C; ++c) {
         const uint64_t id = first_chain + (uint64_t)c;
         /* mh-core.jl:83  params = initial_params === nothing ? propose(rng, sampler, model) : initial_params
@@ -432,11 +634,11 @@ int orc_rwmh(const orc_target *t, const orc_proposal *p, const orc_schedule *s,
             for (int k = 0; k < d; ++k) x[k] = init[(size_t)k * C + c];
         } else {
             orc_normals(seed, id, 0, ORC_STREAM_INIT, d, z);
-            for (int k = 0; k < d; ++k) y[k] = 0.0f;
+            for (int k = 0; k < d; ++k) y[k] = R(0.0);
             propose_from(p, d, z, y, x);
         }
-        float lp = orc_target_eval(t, x);               /* mh-core.jl:84 transition(..., false) */
-        float qx = p->is_static ? static_logq(p, d, x, y) : 0.0f;
+        real lp = orc_target_eval(t, x);               /* mh-core.jl:84 transition(..., false) */
+        real qx = p->is_static ? static_logq(p, d, x, y) : R(0.0);
         uint32_t nacc = 0;
         int64_t slot = save_slot(s, 0);
         if (slot >= 0) record(samples, accepted, slot, d, C, c, x, lp, 0);
@@ -444,26 +646,26 @@ int orc_rwmh(const orc_target *t, const orc_proposal *p, const orc_schedule *s,
             const uint32_t step = (uint32_t)tau;
             orc_normals(seed, id, step, ORC_STREAM_PROPOSAL, d, z);
             propose_from(p, d, z, p->is_static ? zero : x, y);   /* mh-core.jl:100; static: proposal.jl:66-72 */
-            float lpy = orc_target_eval(t, y);          /* :103 */
-            float loga = lpy - lp;                      /* :104-105, Hastings ratio of a zero-mean RW == 0 */
-            float qy = 0.0f;
+            real lpy = orc_target_eval(t, y);          /* :103 */
+            real loga = lpy - lp;                      /* :104-105, Hastings ratio of a zero-mean RW == 0 */
+            real qy = R(0.0);
             if (p->is_static) {                         /* proposal.jl:74-83: q = logpdf(proposal, t) */
-                float fwd = 0.0f;
-                for (int k = 0; k < d; ++k) fwd = fmaf(z[k], z[k], fwd);
-                qy = -0.5f * fwd;
+                real fwd = R(0.0);
+                for (int k = 0; k < d; ++k) fwd = FMA(z[k], z[k], fwd);
+                qy = -R(0.5) * fwd;
                 loga = (lpy - lp) + (qx - qy);
             } else if (p->mean) {                       /* :105,119-123 -> proposal.jl:190-192 */
-                float fwd = 0.0f, bwd = 0.0f;
+                real fwd = R(0.0), bwd = R(0.0);
                 for (int k = 0; k < d; ++k) {
-                    fwd = fmaf(z[k], z[k], fwd);
-                    const float tk = z[k] + tm[k];
-                    bwd = fmaf(tk, tk, bwd);
+                    fwd = FMA(z[k], z[k], fwd);
+                    const real tk = z[k] + tm[k];
+                    bwd = FMA(tk, tk, bwd);
                 }
-                loga = (lpy - lp) + 0.5f * (fwd - bwd);
+                loga = (lpy - lp) + R(0.5) * (fwd - bwd);
             }
-            float logu = orc_accept_logu(seed, id, step);
+            real logu = orc_accept_logu(seed, id, step);
             int acc = logu < loga;                      /* :108  -randexp(rng) < loga (strict; NaN -> reject) */
-            if (acc) { memcpy(x, y, sizeof(float) * (size_t)d); lp = lpy; qx = qy; ++nacc; }
+            if (acc) { memcpy(x, y, sizeof(real) * (size_t)d); lp = lpy; qx = qy; ++nacc; }
             slot = save_slot(s, tau);
             if (slot >= 0) record(samples, accepted, slot, d, C, c, x, lp, acc);
         }
@@ -477,59 +679,56 @@ int orc_rwmh(const orc_target *t, const orc_proposal *p, const orc_schedule *s,
 
 /* ------------------------------------------------------------------------------------------ */
 /* emcee: src/emcee.jl:14-24 (step), :39-58 (sweep), :70-102 (stretch move)                   */
-static int stretch_move(const orc_target *t, float a, uint64_t seed, uint64_t ens, int i,
+static int stretch_move(const orc_target *t, real a, uint64_t seed, uint64_t ens, int i,
                         uint32_t sweep, int other_start, int other_size, int wrap_W,
-                        const float *cur, const float *oth_new, const float *oth_old, int use_seq,
-                        int W, float *xi, float *lpi, float *y, float *xj)
+                        const real *cur, const real *oth_new, const real *oth_old, int use_seq,
+                        int W, real *xi, real *lpi, real *y, real *xj)
 {
     const int d = t->dim;
-    uint32_t w[4];
-    uint32_t ctr[4] = { (uint32_t)i, (uint32_t)ens, sweep, (uint32_t)ORC_STREAM_EMCEE << 28 };
-    uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
-    orc_philox4x32_10(ctr, key, w);
+    uint32_t w0;
+    real u, logu;
+    emcee_draws(seed, ens, i, sweep, &w0, &u, &logu);
     int j;
     if (use_seq) {
         /* emcee.jl:48,52  idx = mod1(i + rand(1:W-1), W)  (never i) */
-        uint32_t r = 1u + (uint32_t)(((uint64_t)w[0] * (uint64_t)(W - 1)) >> 32);
+        uint32_t r = 1u + (uint32_t)(((uint64_t)w0 * (uint64_t)(W - 1)) >> 32);
         j = (int)(((uint64_t)i + r) % (uint64_t)wrap_W);
         /* emcee.jl:53  other = idx < i ? new_walkers[idx] : walkers[idx] */
-        const float *src = (j < i) ? oth_new : oth_old;
+        const real *src = (j < i) ? oth_new : oth_old;
         for (int k = 0; k < d; ++k) xj[k] = src[(size_t)k * W + j];
     } else {
-        j = other_start + (int)(((uint64_t)w[0] * (uint64_t)other_size) >> 32);
+        j = other_start + (int)(((uint64_t)w0 * (uint64_t)other_size) >> 32);
         for (int k = 0; k < d; ++k) xj[k] = cur[(size_t)k * W + j];
     }
     /* emcee.jl:81  z = ((a - 1) * rand(rng) + 1)^2 / a */
-    float u = orc_u01_half(w[1]);
-    float tt = fmaf(a - 1.0f, u, 1.0f);
-    float z = (tt * tt) / a;
-    float alphamult = (float)(d - 1) * orc_logf(z);     /* :82 */
-    for (int k = 0; k < d; ++k) y[k] = fmaf(z, xi[k] - xj[k], xj[k]);   /* :85 */
-    float lpy = orc_target_eval(t, y);                  /* :88 */
-    float alpha = (alphamult + lpy) - *lpi;             /* :91 */
-    float logu = orc_logf(orc_u01_open(w[2]));
+    real tt = FMA(a - R(1.0), u, R(1.0));
+    real z = (tt * tt) / a;
+    real alphamult = (real)(d - 1) * orc_log(z);     /* :82 */
+    for (int k = 0; k < d; ++k) y[k] = FMA(z, xi[k] - xj[k], xj[k]);   /* :85 */
+    real lpy = orc_target_eval(t, y);                  /* :88 */
+    real alpha = (alphamult + lpy) - *lpi;             /* :91 */
     int acc = logu <= alpha;                            /* :93  -randexp <= alpha (non-strict) */
-    if (acc) { memcpy(xi, y, sizeof(float) * (size_t)d); *lpi = lpy; }
+    if (acc) { memcpy(xi, y, sizeof(real) * (size_t)d); *lpi = lpy; }
     return acc;
 }
 
-int orc_emcee(const orc_target *t, float a, int mode, const orc_schedule *s,
+int orc_emcee(const orc_target *t, real a, int mode, const orc_schedule *s,
               uint64_t seed, uint64_t ensemble_id, int nwalkers,
-              const float *init, float *samples, uint8_t *accepted,
-              float *final_x, float *final_lp, uint32_t *accept_counts)
+              const real *init, real *samples, uint8_t *accepted,
+              real *final_x, real *final_lp, uint32_t *accept_counts)
 {
     const int d = t->dim, W = nwalkers;
     if (!init || W < 2) return -1;
     int64_t nT, nA;
     orc_schedule_counts(s, &nT, &nA);
-    float *cur = malloc(sizeof(float) * (size_t)d * W);
-    float *nxt = malloc(sizeof(float) * (size_t)d * W);
-    float *lp = malloc(sizeof(float) * (size_t)W);
-    float *lpn = malloc(sizeof(float) * (size_t)W);
+    real *cur = malloc(sizeof(real) * (size_t)d * W);
+    real *nxt = malloc(sizeof(real) * (size_t)d * W);
+    real *lp = malloc(sizeof(real) * (size_t)W);
+    real *lpn = malloc(sizeof(real) * (size_t)W);
     uint8_t *acc = malloc((size_t)W);
-    float *tmp = malloc(sizeof(float) * (size_t)d * 3);
-    float *xi = tmp, *y = tmp + d, *xj = tmp + 2 * d;
-    memcpy(cur, init, sizeof(float) * (size_t)d * W);
+    real *tmp = malloc(sizeof(real) * (size_t)d * 3);
+    real *xi = tmp, *y = tmp + d, *xj = tmp + 2 * d;
+    memcpy(cur, init, sizeof(real) * (size_t)d * W);
     for (int i = 0; i < W; ++i) {                       /* emcee.jl:6-8: W log-density evaluations */
         for (int k = 0; k < d; ++k) xi[k] = cur[(size_t)k * W + i];
         lp[i] = orc_target_eval(t, xi);
@@ -548,13 +747,13 @@ int orc_emcee(const orc_target *t, float a, int mode, const orc_schedule *s,
             /* reference-faithful Gauss-Seidel sweep, emcee.jl:50-55 */
             for (int i = 0; i < W; ++i) {
                 for (int k = 0; k < d; ++k) xi[k] = cur[(size_t)k * W + i];
-                float l = lp[i];
+                real l = lp[i];
                 acc[i] = (uint8_t)stretch_move(t, a, seed, ensemble_id, i, sweep, 0, 0, W, cur, nxt, cur,
                                                1, W, xi, &l, y, xj);
                 for (int k = 0; k < d; ++k) nxt[(size_t)k * W + i] = xi[k];
                 lpn[i] = l;
             }
-            float *sw = cur; cur = nxt; nxt = sw;
+            real *sw = cur; cur = nxt; nxt = sw;
             sw = lp; lp = lpn; lpn = sw;
         } else {
             /* parallel split: half 0 = [0, W/2) moves against half 1, then half 1 against updated half 0 */
@@ -563,7 +762,7 @@ int orc_emcee(const orc_target *t, float a, int mode, const orc_schedule *s,
                 const int ostart = h ? 0 : half, osize = h ? half : W - half;
                 for (int i = lo; i < hi; ++i) {
                     for (int k = 0; k < d; ++k) xi[k] = cur[(size_t)k * W + i];
-                    float l = lp[i];
+                    real l = lp[i];
                     acc[i] = (uint8_t)stretch_move(t, a, seed, ensemble_id, i, sweep, ostart, osize, W, cur,
                                                    NULL, NULL, 0, W, xi, &l, y, xj);
                     /* partners come from the other half only, so in-place update is race-free */
@@ -580,8 +779,8 @@ int orc_emcee(const orc_target *t, float a, int mode, const orc_schedule *s,
                 record(samples, accepted, slot, d, W, i, xi, lp[i], acc[i]);
             }
     }
-    if (final_x) memcpy(final_x, cur, sizeof(float) * (size_t)d * W);
-    if (final_lp) memcpy(final_lp, lp, sizeof(float) * (size_t)W);
+    if (final_x) memcpy(final_x, cur, sizeof(real) * (size_t)d * W);
+    if (final_lp) memcpy(final_lp, lp, sizeof(real) * (size_t)W);
     free(cur); free(nxt); free(lp); free(lpn); free(acc); free(tmp);
     return 0;
 }
@@ -592,26 +791,26 @@ int orc_emcee(const orc_target *t, float a, int mode, const orc_schedule *s,
  * src/RobustAdaptiveMetropolis.jl:165-171.  Column sweep: for each column i a Givens-type
  * rotation (c, s) from (S_ii, w_i) is applied to the sub-diagonal column and to w[i+1:].     */
 #define SIDX(i, j) ((size_t)(i) * ((size_t)(i) + 1) / 2 + (size_t)(j))
-int orc_chol_rank1(float *S, float *w, int d, int sign)
+int orc_chol_rank1(real *S, real *w, int d, int sign)
 {
     /* One sweep for both signs (the textbook rank-one modification; for sigma = -1 it is the upstream
      * lowrankdowndate! loop, for sigma = +1 it equals the upstream Givens form algebraically):
      *   s = w_i / S_ii,  c = sqrt(1 + sigma s^2),  S_ii <- c S_ii,
      *   S_ji <- (S_ji + sigma s w_j) / c,  w_j <- c w_j - s S_ji(new)            (spec 3.9) */
-    const float sg = sign > 0 ? 1.0f : -1.0f;
+    const real sg = sign > 0 ? R(1.0) : -R(1.0);
     for (int i = 0; i < d; ++i) {
-        const float a = S[SIDX(i, i)], b = w[i];
-        const float sn = b / a;
-        if (sign < 0 && sn * sn > 1.0f) return i + 1;   /* PosDefException(i) upstream */
-        const float ss = sg * sn;
-        const float c = sqrtf(fmaf(ss, sn, 1.0f));
-        const float rc = 1.0f / c;                        /* one reciprocal per column */
+        const real a = S[SIDX(i, i)], b = w[i];
+        const real sn = b / a;
+        if (sign < 0 && sn * sn > R(1.0)) return i + 1;   /* PosDefException(i) upstream */
+        const real ss = sg * sn;
+        const real c = SQRT(FMA(ss, sn, R(1.0)));
+        const real rc = R(1.0) / c;                        /* one reciprocal per column */
         S[SIDX(i, i)] = c * a;
         for (int j = i + 1; j < d; ++j) {
-            const float vj = w[j];
-            const float Aji = fmaf(ss, vj, S[SIDX(j, i)]) * rc;
+            const real vj = w[j];
+            const real Aji = FMA(ss, vj, S[SIDX(j, i)]) * rc;
             S[SIDX(j, i)] = Aji;
-            w[j] = fmaf(c, vj, -(sn * Aji));
+            w[j] = FMA(c, vj, -(sn * Aji));
         }
     }
     return 0;
@@ -622,26 +821,26 @@ int orc_chol_rank1(float *S, float *w, int d, int sign)
  * :153-173 (ram_adapt), :216-237 (step), :239-245 (valid_eigenvalues), :247-278 (step_warmup) */
 int orc_ram(const orc_target *t, const orc_ram_cfg *cfg, const orc_schedule *s,
             uint64_t seed, uint64_t first_chain, int nchains,
-            const float *init, const float *S_in, float *S_out,
-            float *samples, uint8_t *accepted, float *final_x, float *final_lp,
-            uint32_t *accept_counts, uint8_t *status, float *diag_min, float *diag_max)
+            const real *init, const real *S_in, real *S_out,
+            real *samples, uint8_t *accepted, real *final_x, real *final_lp,
+            uint32_t *accept_counts, uint8_t *status, real *diag_min, real *diag_max)
 {
     const int d = t->dim, C = nchains;
     const size_t nS = (size_t)d * ((size_t)d + 1) / 2;
     int64_t nT, nA;
     orc_schedule_counts(s, &nT, &nA);
-    float *x = malloc(sizeof(float) * (size_t)d * 5);
-    float *y = x + d, *U = y + d, *v = U + d, *w = v + d;
-    float *S = malloc(sizeof(float) * nS), *Sn = malloc(sizeof(float) * nS);
-    const int default_bounds = (cfg->eig_lo == 0.0f && isinf(cfg->eig_hi) && cfg->eig_hi > 0);
+    real *x = malloc(sizeof(real) * (size_t)d * 5);
+    real *y = x + d, *U = y + d, *v = U + d, *w = v + d;
+    real *S = malloc(sizeof(real) * nS), *Sn = malloc(sizeof(real) * nS);
+    const int default_bounds = (cfg->eig_lo == R(0.0) && isinf(cfg->eig_hi) && cfg->eig_hi > 0);
     for (int c = 0; c < C; ++c) {
         const uint64_t id = first_chain + (uint64_t)c;
         uint8_t st = 0;
         if (init) for (int k = 0; k < d; ++k) x[k] = init[(size_t)k * C + c];
         else orc_normals(seed, id, 0, ORC_STREAM_INIT, d, x);      /* :193 randn(rng, T, d) */
-        if (S_in) memcpy(S, S_in + (size_t)c * nS, sizeof(float) * nS);
-        else { memset(S, 0, sizeof(float) * nS); for (int i = 0; i < d; ++i) S[SIDX(i, i)] = 1.0f; }
-        float lp = orc_target_eval(t, x);                          /* :210 */
+        if (S_in) memcpy(S, S_in + (size_t)c * nS, sizeof(real) * nS);
+        else { memset(S, 0, sizeof(real) * nS); for (int i = 0; i < d; ++i) S[SIDX(i, i)] = R(1.0); }
+        real lp = orc_target_eval(t, x);                          /* :210 */
         uint32_t nacc = 0;
         if (diag_min) for (int k = 0; k < d; ++k) {
             diag_min[(size_t)k * C + c] = S[SIDX(k, k)];
@@ -653,44 +852,44 @@ int orc_ram(const orc_target *t, const orc_ram_cfg *cfg, const orc_schedule *s,
             const uint32_t step = (uint32_t)tau;                   /* == state.iteration */
             orc_normals(seed, id, step, ORC_STREAM_PROPOSAL, d, U);            /* :135 */
             for (int i = 0; i < d; ++i) {                                       /* :136 muladd(S, U, x) */
-                float acc = 0.0f;
-                for (int j = 0; j <= i; ++j) acc = fmaf(S[SIDX(i, j)], U[j], acc);
+                real acc = R(0.0);
+                for (int j = 0; j <= i; ++j) acc = FMA(S[SIDX(i, j)], U[j], acc);
                 v[i] = acc;
                 y[i] = acc + x[i];
             }
-            float lpy = orc_target_eval(t, y);                     /* :140 */
-            float diff = lpy - lp;
-            float loga = (diff != diff) ? diff : (diff < 0.0f ? diff : 0.0f);   /* :147 min(lp_new - lp, 0) */
-            float logu = orc_accept_logu(seed, id, step);
+            real lpy = orc_target_eval(t, y);                     /* :140 */
+            real diff = lpy - lp;
+            real loga = (diff != diff) ? diff : (diff < R(0.0) ? diff : R(0.0));   /* :147 min(lp_new - lp, 0) */
+            real logu = orc_accept_logu(seed, id, step);
             int acc = logu < loga;                                  /* :148 randexp(rng) > -loga */
             if (tau <= nA) {                                        /* step_warmup: adapt, :153-173 */
-                float da = orc_expf(loga) - cfg->alpha;             /* :159 */
+                real da = orc_exp(loga) - cfg->alpha;             /* :159 */
                 if (da == da) {
-                    float eta = (float)pow((double)step, -(double)cfg->gamma);   /* :162 */
-                    float nn = 0.0f;
-                    for (int j = 0; j < d; ++j) nn = fmaf(U[j], U[j], nn);
-                    float coef = sqrtf(eta * fabsf(da)) / sqrtf(nn);             /* :163 */
+                    real eta = (real)pow((double)step, -(double)cfg->gamma);   /* :162 */
+                    real nn = R(0.0);
+                    for (int j = 0; j < d; ++j) nn = FMA(U[j], U[j], nn);
+                    real coef = SQRT(eta * FABS(da)) / SQRT(nn);             /* :163 */
                     for (int j = 0; j < d; ++j) w[j] = v[j] * coef;
-                    memcpy(Sn, S, sizeof(float) * nS);
-                    int fail = orc_chol_rank1(Sn, w, d, da > 0.0f ? +1 : -1);   /* :165-171 */
+                    memcpy(Sn, S, sizeof(real) * nS);
+                    int fail = orc_chol_rank1(Sn, w, d, da > R(0.0) ? +1 : -1);   /* :165-171 */
                     int ok = !fail;
                     if (fail) st |= 1;
                     if (ok && !default_bounds)                                  /* :239-245, :259-264 */
                         for (int k = 0; k < d; ++k) {
-                            float e = Sn[SIDX(k, k)];
+                            real e = Sn[SIDX(k, k)];
                             if (!(cfg->eig_lo <= e && e <= cfg->eig_hi)) { ok = 0; break; }
                         }
-                    if (ok) { float *sw = S; S = Sn; Sn = sw; }
+                    if (ok) { real *sw = S; S = Sn; Sn = sw; }
                 } else {
                     st |= 2;                                        /* NaN log-ratio: adaptation skipped */
                 }
                 if (diag_min) for (int k = 0; k < d; ++k) {
-                    float e = S[SIDX(k, k)];
+                    real e = S[SIDX(k, k)];
                     if (e < diag_min[(size_t)k * C + c]) diag_min[(size_t)k * C + c] = e;
                     if (e > diag_max[(size_t)k * C + c]) diag_max[(size_t)k * C + c] = e;
                 }
             }
-            if (acc) { memcpy(x, y, sizeof(float) * (size_t)d); lp = lpy; ++nacc; }   /* :267-277 */
+            if (acc) { memcpy(x, y, sizeof(real) * (size_t)d); lp = lpy; ++nacc; }   /* :267-277 */
             slot = save_slot(s, tau);
             if (slot >= 0) record(samples, accepted, slot, d, C, c, x, lp, acc);
         }
@@ -698,7 +897,7 @@ int orc_ram(const orc_target *t, const orc_ram_cfg *cfg, const orc_schedule *s,
         if (final_lp) final_lp[c] = lp;
         if (accept_counts) accept_counts[c] = nacc;
         if (status) status[c] = st;
-        if (S_out) memcpy(S_out + (size_t)c * nS, S, sizeof(float) * nS);
+        if (S_out) memcpy(S_out + (size_t)c * nS, S, sizeof(real) * nS);
     }
     free(x); free(S); free(Sn);
     return 0;
@@ -707,7 +906,7 @@ int orc_ram(const orc_target *t, const orc_ram_cfg *cfg, const orc_schedule *s,
 /* ------------------------------------------------------------------------------------------ */
 /* gradients of the catalogue targets (what ForwardDiff / LogDensityProblems.logdensity_and_gradient
  * supply to the reference's MALA, src/MALA.jl:73-75, ext/AdvancedMHForwardDiffExt.jl:13-17)     */
-float orc_target_grad(const orc_target *t, const float *x, float *g, orc_logdensity_grad_fn user)
+real orc_target_grad(const orc_target *t, const real *x, real *g, orc_logdensity_grad_fn user)
 {
     const int d = t->dim;
     switch (t->kind) {
@@ -715,59 +914,59 @@ float orc_target_grad(const orc_target *t, const float *x, float *g, orc_logdens
         for (int k = 0; k < d; ++k) g[k] = -x[k];
         return orc_target_eval(t, x);
     case ORC_TARGET_CORR_GAUSS: {                      /* grad = -A^T (A x) */
-        const float *A = t->params;
-        float q = 0.0f;
+        const real *A = t->params;
+        real q = R(0.0);
         size_t off = 0;
         for (int i = 0; i < d; ++i) {                  /* w = A x, kept in g */
-            float w = 0.0f;
-            for (int j = 0; j <= i; ++j) w = fmaf(A[off + j], x[j], w);
+            real w = R(0.0);
+            for (int j = 0; j <= i; ++j) w = FMA(A[off + j], x[j], w);
             g[i] = w;
-            q = fmaf(w, w, q);
+            q = FMA(w, w, q);
             off += (size_t)i + 1;
         }
         for (int j = 0; j < d; ++j) {                  /* g_j = -sum_{i>=j} A_ij w_i, ascending i, in place */
-            float acc = 0.0f;
-            for (int i = j; i < d; ++i) acc = fmaf(A[SIDX(i, j)], g[i], acc);
+            real acc = R(0.0);
+            for (int i = j; i < d; ++i) acc = FMA(A[SIDX(i, j)], g[i], acc);
             g[j] = -acc;
         }
-        return fmaf(-0.5f, q, target_const(t));
+        return FMA(-R(0.5), q, target_const(t));
     }
     case ORC_TARGET_IID_NORMAL: {
-        const float mu = x[0], sigma = x[1];
-        if (!(sigma > 0.0f)) { g[0] = 0.0f; g[1] = 0.0f; return -INFINITY; }
-        const float inv = 1.0f / sigma;
-        float acc = 0.0f, s1 = 0.0f;
+        const real mu = x[0], sigma = x[1];
+        if (!(sigma > R(0.0))) { g[0] = R(0.0); g[1] = R(0.0); return -INFINITY; }
+        const real inv = R(1.0) / sigma;
+        real acc = R(0.0), s1 = R(0.0);
         for (int i = 0; i < t->nparams; ++i) {
-            const float z = (t->params[i] - mu) / sigma;
-            acc = fmaf(z, z, acc);
+            const real z = (t->params[i] - mu) / sigma;
+            acc = FMA(z, z, acc);
             s1 = s1 + z;
         }
-        const float nf = (float)t->nparams;
+        const real nf = (real)t->nparams;
         g[0] = s1 * inv;                               /* sum (y-mu)/sigma^2 */
         g[1] = (acc - nf) * inv;                       /* -n/sigma + sum (y-mu)^2/sigma^3 */
-        const float tt = orc_logf(sigma) + HALF_LOG_2PI_F;
-        return fmaf(-0.5f, acc, -(nf * tt));
+        const real tt = orc_log(sigma) + HALF_LOG_2PI;
+        return FMA(-R(0.5), acc, -(nf * tt));
     }
     case ORC_TARGET_BANANA: {
-        const float b = t->params[0];
-        const float x0 = x[0];
-        float q = (x0 * x0) * 0.01f;
-        const float u = fmaf(b, fmaf(x0, x0, -100.0f), x[1]);
-        q = fmaf(u, u, q);
-        g[0] = -(fmaf(x0, 0.01f, (2.0f * b) * (u * x0)));
+        const real b = t->params[0];
+        const real x0 = x[0];
+        real q = (x0 * x0) * R(0.01);
+        const real u = FMA(b, FMA(x0, x0, -R(100.0)), x[1]);
+        q = FMA(u, u, q);
+        g[0] = -(FMA(x0, R(0.01), (R(2.0) * b) * (u * x0)));
         g[1] = -u;
-        for (int k = 2; k < d; ++k) { q = fmaf(x[k], x[k], q); g[k] = -x[k]; }
-        return fmaf(-0.5f, q, target_const(t));
+        for (int k = 2; k < d; ++k) { q = FMA(x[k], x[k], q); g[k] = -x[k]; }
+        return FMA(-R(0.5), q, target_const(t));
     }
     case ORC_TARGET_FUNNEL: {
-        const float v = x[0];
-        float q = 0.0f;
-        for (int k = 1; k < d; ++k) q = fmaf(x[k], x[k], q);
-        const float ev = orc_expf(-v);
-        float r = (v * v) * 0x1.c71c72p-5f;
-        r = fmaf(0.5f * (float)(d - 1), v, r);
-        r = fmaf(0.5f * ev, q, r);
-        g[0] = fmaf(0.5f * ev, q, -(fmaf(v, 0x1.c71c72p-4f, 0.5f * (float)(d - 1))));   /* -v/9 - (d-1)/2 + e^-v q/2 */
+        const real v = x[0];
+        real q = R(0.0);
+        for (int k = 1; k < d; ++k) q = FMA(x[k], x[k], q);
+        const real ev = orc_exp(-v);
+        real r = (v * v) * ONE_18;
+        r = FMA(R(0.5) * (real)(d - 1), v, r);
+        r = FMA(R(0.5) * ev, q, r);
+        g[0] = FMA(R(0.5) * ev, q, -(FMA(v, ONE_9, R(0.5) * (real)(d - 1))));   /* -v/9 - (d-1)/2 + e^-v q/2 */
         for (int k = 1; k < d; ++k) g[k] = -(ev * x[k]);
         return target_const(t) - r;
     }
@@ -784,44 +983,44 @@ float orc_target_grad(const orc_target *t, const float *x, float *g, orc_logdens
  *   logratio = q(prop(grad y), x, y) - q(prop(grad x), y, x)                 (:78-80)
  *            = 1/2 |z|^2 - 1/2 |z + (sigma/2)(grad x + grad y)|^2
  *   accept iff -randexp < lp(y) - lp(x) + logratio                           (:83-86)            */
-int orc_mala(const orc_target *t, orc_logdensity_grad_fn user, float sigma2, const orc_schedule *s,
-             uint64_t seed, uint64_t first_chain, int nchains, const float *init,
-             float *samples, uint8_t *accepted, float *final_x, float *final_lp, uint32_t *accept_counts)
+int orc_mala(const orc_target *t, orc_logdensity_grad_fn user, real sigma2, const orc_schedule *s,
+             uint64_t seed, uint64_t first_chain, int nchains, const real *init,
+             real *samples, uint8_t *accepted, real *final_x, real *final_lp, uint32_t *accept_counts)
 {
     const int d = t->dim, C = nchains;
     if (!init) return -1;                                /* :37 "please specify initial parameters" */
     int64_t nT, nA;
     orc_schedule_counts(s, &nT, &nA);
-    const float sigma = sqrtf(sigma2);
-    const float h = (sigma * sigma) * 0.5f;              /* drift step sigma2/2 */
-    const float hs = 0.5f * sigma;
-    float *x = malloc(sizeof(float) * (size_t)d * 5);
-    float *gx = x + d, *y = gx + d, *gy = y + d, *z = gy + d;
+    const real sigma = SQRT(sigma2);
+    const real h = (sigma * sigma) * R(0.5);              /* drift step sigma2/2 */
+    const real hs = R(0.5) * sigma;
+    real *x = malloc(sizeof(real) * (size_t)d * 5);
+    real *gx = x + d, *y = gx + d, *gy = y + d, *z = gy + d;
     for (int c = 0; c < C; ++c) {
         const uint64_t id = first_chain + (uint64_t)c;
         for (int k = 0; k < d; ++k) x[k] = init[(size_t)k * C + c];
-        float lp = orc_target_grad(t, x, gx, user);      /* :38-40 GradientTransition(params, lp, grad, false) */
+        real lp = orc_target_grad(t, x, gx, user);      /* :38-40 GradientTransition(params, lp, grad, false) */
         uint32_t nacc = 0;
         int64_t slot = save_slot(s, 0);
         if (slot >= 0) record(samples, accepted, slot, d, C, c, x, lp, 0);
         for (int64_t tau = 1; tau <= nT; ++tau) {
             const uint32_t step = (uint32_t)tau;
             orc_normals(seed, id, step, ORC_STREAM_PROPOSAL, d, z);
-            float fwd = 0.0f;
+            real fwd = R(0.0);
             for (int k = 0; k < d; ++k) {
-                y[k] = fmaf(sigma, z[k], fmaf(h, gx[k], x[k]));
-                fwd = fmaf(z[k], z[k], fwd);
+                y[k] = FMA(sigma, z[k], FMA(h, gx[k], x[k]));
+                fwd = FMA(z[k], z[k], fwd);
             }
-            const float lpy = orc_target_grad(t, y, gy, user);
-            float bwd = 0.0f;
+            const real lpy = orc_target_grad(t, y, gy, user);
+            real bwd = R(0.0);
             for (int k = 0; k < d; ++k) {
-                const float tk = fmaf(hs, gx[k] + gy[k], z[k]);
-                bwd = fmaf(tk, tk, bwd);
+                const real tk = FMA(hs, gx[k] + gy[k], z[k]);
+                bwd = FMA(tk, tk, bwd);
             }
-            const float loga = (lpy - lp) + 0.5f * (fwd - bwd);
-            const float logu = orc_accept_logu(seed, id, step);
+            const real loga = (lpy - lp) + R(0.5) * (fwd - bwd);
+            const real logu = orc_accept_logu(seed, id, step);
             const int acc = logu < loga;
-            if (acc) { memcpy(x, y, sizeof(float) * (size_t)d); memcpy(gx, gy, sizeof(float) * (size_t)d); lp = lpy; ++nacc; }
+            if (acc) { memcpy(x, y, sizeof(real) * (size_t)d); memcpy(gx, gy, sizeof(real) * (size_t)d); lp = lpy; ++nacc; }
             slot = save_slot(s, tau);
             if (slot >= 0) record(samples, accepted, slot, d, C, c, x, lp, acc);
         }

@@ -32,17 +32,34 @@
 extern "C" {
 #endif
 
+/* `real` is float in libmhx_oracle.so (ORC_F64=0) and double in libmhx_oracle64.so (ORC_F64=1, the reference's Float64) */
+#ifndef ORC_F64
+#define ORC_F64 0
+#endif
+#if ORC_F64
+typedef double real;
+#else
+typedef float real;
+#endif
+
 /* ---- arithmetic spec primitives (exported so tests can pin them) ---- */
-void  orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
-float orc_logf(float x);
-float orc_expf(float x);
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+real orc_log(real x);
+real orc_exp(real x);
+#if ORC_F64
+void   orc_sincos2pi_u64(uint32_t hi, uint32_t lo, double *s, double *c);   /* angle 2 pi (hi:lo) / 2^64 */
+double orc_u01_open(uint32_t hi, uint32_t lo);   /* (0,1): (k + 1/2) 2^-52, k = hi:lo >> 12 */
+double orc_u01_half(uint32_t hi, uint32_t lo);   /* [0,1): k 2^-52                          */
+void   orc_normal_pair(const uint32_t w[4], double *n0, double *n1);
+#else
 void  orc_sincos2pi_u32(uint32_t k, float *s, float *c);
 float orc_u01_open(uint32_t k);      /* (0,1]  : fmaf((float)k, 2^-32, 2^-33) */
 float orc_u01_half(uint32_t k);      /* [0,1)  : (k>>8) * 2^-24               */
 void  orc_normal_pair(uint32_t k0, uint32_t k1, float *n0, float *n1);
+#endif
 /* d standard normals of (seed, chain, step, stream) -- the proposal noise of one chain-step */
-void  orc_normals(uint64_t seed, uint64_t chain, uint32_t step, uint32_t stream, int d, float *out);
-float orc_accept_logu(uint64_t seed, uint64_t chain, uint32_t step);
+void orc_normals(uint64_t seed, uint64_t chain, uint32_t step, uint32_t stream, int d, real *out);
+real orc_accept_logu(uint64_t seed, uint64_t chain, uint32_t step);
 
 /* RNG stream tags (c3 = tag<<28 | block) */
 enum { ORC_STREAM_PROPOSAL = 0, ORC_STREAM_ACCEPT = 1, ORC_STREAM_INIT = 2, ORC_STREAM_EMCEE = 3 };
@@ -56,12 +73,12 @@ enum {
     ORC_TARGET_FUNNEL      = 4,  /* params: none                                                  */
     ORC_TARGET_CALLBACK    = 100 /* user function pointer (DensityModel(f))                       */
 };
-typedef float (*orc_logdensity_fn)(const float *x, int d, const void *data);
+typedef real (*orc_logdensity_fn)(const real *x, int d, const void *data);
 
 typedef struct {
     int kind;
     int dim;
-    const float *params;     /* kind-specific, see above */
+    const real *params;     /* kind-specific, see above */
     int nparams;
     orc_logdensity_fn fn;    /* ORC_TARGET_CALLBACK */
     const void *fn_data;
@@ -72,15 +89,15 @@ typedef struct {
     int reduce_lanes;
 } orc_target;
 
-float orc_target_eval(const orc_target *t, const float *x);
+real orc_target_eval(const orc_target *t, const real *x);
 
 /* ---- proposals (RandomWalkProposal{_, <:MvNormal}, zero mean) ---- */
 enum { ORC_PROP_ISO = 0, ORC_PROP_DIAG = 1, ORC_PROP_DENSE = 2 };
 typedef struct {
     int kind;
-    float scale;          /* ISO: sigma                                  */
-    const float *vec;     /* DIAG: sigma_k[d]; DENSE: packed lower L     */
-    const float *mean;    /* NULL = zero mean; else mu[d]: the random walk drifts and the Hastings ratio
+    real scale;          /* ISO: sigma                                  */
+    const real *vec;     /* DIAG: sigma_k[d]; DENSE: packed lower L     */
+    const real *mean;    /* NULL = zero mean; else mu[d]: the random walk drifts and the Hastings ratio
                              q(x | y) - q(y | x) of src/proposal.jl:58-64,190-192 is no longer zero */
     int is_static;        /* StaticProposal (src/proposal.jl:9-11,66-83): the candidate is a draw mu + L z that
                              ignores the current state; ratio = logpdf(p, x) - logpdf(p, y)            */
@@ -100,42 +117,42 @@ void orc_schedule_counts(const orc_schedule *s, int64_t *n_transitions, int64_t 
  *      accepted[N][C].  chains are global ids first_chain .. first_chain+C-1. ---- */
 int orc_rwmh(const orc_target *t, const orc_proposal *p, const orc_schedule *s,
              uint64_t seed, uint64_t first_chain, int nchains,
-             const float *init /* [d][C] or NULL */, float *samples, uint8_t *accepted,
-             float *final_x /* [d][C] */, float *final_lp, uint32_t *accept_counts);
+             const real *init /* [d][C] or NULL */, real *samples, uint8_t *accepted,
+             real *final_x /* [d][C] */, real *final_lp, uint32_t *accept_counts);
 
 /* Ensemble(W, StretchProposal(prior, a)). mode 0 = reference-faithful sequential sweep
  * (src/emcee.jl:39-58), mode 1 = parallel half-split (what the HIP kernel runs). */
-int orc_emcee(const orc_target *t, float a, int mode, const orc_schedule *s,
+int orc_emcee(const orc_target *t, real a, int mode, const orc_schedule *s,
               uint64_t seed, uint64_t ensemble_id, int nwalkers,
-              const float *init /* [d][W], required */, float *samples, uint8_t *accepted,
-              float *final_x, float *final_lp, uint32_t *accept_counts);
+              const real *init /* [d][W], required */, real *samples, uint8_t *accepted,
+              real *final_x, real *final_lp, uint32_t *accept_counts);
 
 typedef struct {
-    float alpha;          /* target acceptance, 0.234 */
-    float gamma;          /* 0.6 */
-    float eig_lo, eig_hi; /* 0, +inf */
+    real alpha;          /* target acceptance, 0.234 */
+    real gamma;          /* 0.6 */
+    real eig_lo, eig_hi; /* 0, +inf */
 } orc_ram_cfg;
 /* S: packed lower row-major [C][d(d+1)/2], in = initial factor (NULL -> identity), out = final.
  * logalpha_trace (optional) [n_transitions][C]. status[C]: bit0 = a downdate hit s^2>1. */
 int orc_ram(const orc_target *t, const orc_ram_cfg *cfg, const orc_schedule *s,
             uint64_t seed, uint64_t first_chain, int nchains,
-            const float *init /* [d][C] or NULL -> randn */, const float *S_in, float *S_out,
-            float *samples, uint8_t *accepted, float *final_x, float *final_lp,
-            uint32_t *accept_counts, uint8_t *status, float *diag_min, float *diag_max);
+            const real *init /* [d][C] or NULL -> randn */, const real *S_in, real *S_out,
+            real *samples, uint8_t *accepted, real *final_x, real *final_lp,
+            uint32_t *accept_counts, uint8_t *status, real *diag_min, real *diag_max);
 
 /* value and gradient of a catalogue target (MALA); g[d] out.  CALLBACK targets: fn_grad in `t->fn_data`
  * is not supported -- user gradients are exercised through gcc-built sources in tests/user_targets.py. */
-typedef float (*orc_logdensity_grad_fn)(const float *x, float *g, int d, const void *data);
-float orc_target_grad(const orc_target *t, const float *x, float *g, orc_logdensity_grad_fn user);
+typedef real (*orc_logdensity_grad_fn)(const real *x, real *g, int d, const void *data);
+real orc_target_grad(const orc_target *t, const real *x, real *g, orc_logdensity_grad_fn user);
 
 /* MALA(g -> MvNormal((sigma2/2) g, sigma2 I)): src/MALA.jl:54-93.  init [d][C] is required (:37). */
-int orc_mala(const orc_target *t, orc_logdensity_grad_fn user, float sigma2, const orc_schedule *s,
-             uint64_t seed, uint64_t first_chain, int nchains, const float *init,
-             float *samples, uint8_t *accepted, float *final_x, float *final_lp, uint32_t *accept_counts);
+int orc_mala(const orc_target *t, orc_logdensity_grad_fn user, real sigma2, const orc_schedule *s,
+             uint64_t seed, uint64_t first_chain, int nchains, const real *init,
+             real *samples, uint8_t *accepted, real *final_x, real *final_lp, uint32_t *accept_counts);
 
 /* rank-1 Cholesky update (sign=+1) / downdate (sign=-1) of a packed lower factor, in place.
  * returns 0, or i+1 if the downdate failed at column i (S is then partially modified). */
-int orc_chol_rank1(float *S, float *w, int d, int sign);
+int orc_chol_rank1(real *S, real *w, int d, int sign);
 
 #ifdef __cplusplus
 }

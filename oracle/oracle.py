@@ -1,6 +1,9 @@
 """ctypes binding of the CPU oracle (TEST INFRASTRUCTURE -- never imported by the product path).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+
+Two builds of one source (oracle/Makefile): libmhx_oracle.so computes in float (the fp32 engine), libmhx_oracle64.so in
+double (the reference's Float64).  `set_dtype("f32" | "f64")` selects which one the module-level functions bind.
 """
 import ctypes as C
 import os
@@ -9,24 +12,59 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libmhx_oracle.so")
+_LIB_PATHS = {"f32": os.path.join(_HERE, "libmhx_oracle.so"), "f64": os.path.join(_HERE, "libmhx_oracle64.so")}
 
 STREAM_PROPOSAL, STREAM_ACCEPT, STREAM_INIT, STREAM_EMCEE = 0, 1, 2, 3
 TARGET_ISO_GAUSS, TARGET_CORR_GAUSS, TARGET_IID_NORMAL, TARGET_BANANA, TARGET_FUNNEL = 0, 1, 2, 3, 4
 TARGET_CALLBACK = 100
 PROP_ISO, PROP_DIAG, PROP_DENSE = 0, 1, 2
 
-LOGDENSITY_FN = C.CFUNCTYPE(C.c_float, C.POINTER(C.c_float), C.c_int, C.c_void_p)
+_DT = "f32"
 
 
-class _Target(C.Structure):
-    _fields_ = [("kind", C.c_int), ("dim", C.c_int), ("params", C.POINTER(C.c_float)),
-                ("nparams", C.c_int), ("fn", LOGDENSITY_FN), ("fn_data", C.c_void_p), ("reduce_lanes", C.c_int)]
+def set_dtype(dt):
+    """Select the arithmetic of every call below: "f32" or "f64"."""
+    global _DT
+    if dt not in _LIB_PATHS:
+        raise ValueError("dtype must be 'f32' or 'f64'")
+    _DT = dt
 
 
-class _Proposal(C.Structure):
-    _fields_ = [("kind", C.c_int), ("scale", C.c_float), ("vec", C.POINTER(C.c_float)), ("mean", C.POINTER(C.c_float)),
-                ("is_static", C.c_int)]
+def get_dtype():
+    return _DT
+
+
+def real():
+    """numpy dtype of the current build"""
+    return np.float64 if _DT == "f64" else np.float32
+
+
+def _creal():
+    return C.c_double if _DT == "f64" else C.c_float
+
+
+def _mk_types(cr):
+    fn = C.CFUNCTYPE(cr, C.c_void_p, C.c_int, C.c_void_p)
+    gfn = C.CFUNCTYPE(cr, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
+
+    class Target_(C.Structure):
+        _fields_ = [("kind", C.c_int), ("dim", C.c_int), ("params", C.c_void_p),
+                    ("nparams", C.c_int), ("fn", fn), ("fn_data", C.c_void_p), ("reduce_lanes", C.c_int)]
+
+    class Proposal_(C.Structure):
+        _fields_ = [("kind", C.c_int), ("scale", cr), ("vec", C.c_void_p), ("mean", C.c_void_p), ("is_static", C.c_int)]
+
+    class RamCfg_(C.Structure):
+        _fields_ = [("alpha", cr), ("gamma", cr), ("eig_lo", cr), ("eig_hi", cr)]
+
+    return dict(fn=fn, gfn=gfn, Target=Target_, Proposal=Proposal_, RamCfg=RamCfg_)
+
+
+_TYPES = {"f32": _mk_types(C.c_float), "f64": _mk_types(C.c_double)}
+
+
+def _T(name):
+    return _TYPES[_DT][name]
 
 
 class _Schedule(C.Structure):
@@ -34,46 +72,54 @@ class _Schedule(C.Structure):
                 ("num_warmup", C.c_int)]
 
 
-class _RamCfg(C.Structure):
-    _fields_ = [("alpha", C.c_float), ("gamma", C.c_float), ("eig_lo", C.c_float), ("eig_hi", C.c_float)]
-
-
 def build(force=False):
-    if force or not os.path.exists(_LIB_PATH) or (
-            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "mhx_oracle.c"))):
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
-    return _LIB_PATH
+    src = os.path.join(_HERE, "mhx_oracle.c")
+    if force or any(not os.path.exists(p) or os.path.getmtime(p) < os.path.getmtime(src) for p in _LIB_PATHS.values()):
+        if os.path.exists(src):
+            subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATHS[_DT]
 
 
-_lib = None
+_libs = {}
 
 
 def lib():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(_LIB_PATH):
+    if _DT not in _libs:
+        if not os.path.exists(_LIB_PATHS[_DT]):
             build()
-        L = C.CDLL(_LIB_PATH)
-        L.orc_logf.restype = C.c_float
-        L.orc_logf.argtypes = [C.c_float]
-        L.orc_expf.restype = C.c_float
-        L.orc_expf.argtypes = [C.c_float]
-        L.orc_u01_open.restype = C.c_float
-        L.orc_u01_open.argtypes = [C.c_uint32]
-        L.orc_u01_half.restype = C.c_float
-        L.orc_u01_half.argtypes = [C.c_uint32]
-        L.orc_accept_logu.restype = C.c_float
+        L = C.CDLL(_LIB_PATHS[_DT])
+        cr = _creal()
+        L.orc_log.restype = cr
+        L.orc_log.argtypes = [cr]
+        L.orc_exp.restype = cr
+        L.orc_exp.argtypes = [cr]
+        L.orc_u01_open.restype = cr
+        L.orc_u01_half.restype = cr
+        if _DT == "f64":
+            L.orc_u01_open.argtypes = [C.c_uint32, C.c_uint32]
+            L.orc_u01_half.argtypes = [C.c_uint32, C.c_uint32]
+        else:
+            L.orc_u01_open.argtypes = [C.c_uint32]
+            L.orc_u01_half.argtypes = [C.c_uint32]
+        L.orc_accept_logu.restype = cr
         L.orc_accept_logu.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32]
-        L.orc_target_eval.restype = C.c_float
-        L.orc_target_eval.argtypes = [C.POINTER(_Target), C.POINTER(C.c_float)]
-        L.orc_normals.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_float)]
+        L.orc_target_eval.restype = cr
+        L.orc_target_eval.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_target_grad.restype = cr
+        L.orc_normals.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
         L.orc_chol_rank1.restype = C.c_int
-        _lib = L
-    return _lib
+        L.orc_chol_rank1.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        _libs[_DT] = L
+    return _libs[_DT]
+
+
+def rarr(a):
+    """contiguous array in the current real type"""
+    return np.ascontiguousarray(a, dtype=real())
 
 
 def _fp(a):
-    return a.ctypes.data_as(C.POINTER(C.c_float)) if a is not None else None
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
 def _u8p(a):
@@ -92,24 +138,43 @@ def philox(ctr, key):
     return [int(v) for v in o]
 
 
-def logf(x):
+def log(x):
     L = lib()
-    return np.array([L.orc_logf(float(v)) for v in np.atleast_1d(x)], dtype=np.float32)
+    return np.array([L.orc_log(float(v)) for v in np.atleast_1d(x)], dtype=real())
 
 
-def expf(x):
+def exp(x):
     L = lib()
-    return np.array([L.orc_expf(float(v)) for v in np.atleast_1d(x)], dtype=np.float32)
+    return np.array([L.orc_exp(float(v)) for v in np.atleast_1d(x)], dtype=real())
+
+
+logf, expf = log, exp          # the fp32 names of round 1
 
 
 def sincos2pi_u32(k):
+    """f32 build: sin / cos of 2 pi k / 2^32"""
     s, c = C.c_float(), C.c_float()
     lib().orc_sincos2pi_u32(C.c_uint32(int(k)), C.byref(s), C.byref(c))
     return s.value, c.value
 
 
+def sincos2pi_u64(k):
+    """f64 build: sin / cos of 2 pi k / 2^64"""
+    s, c = C.c_double(), C.c_double()
+    lib().orc_sincos2pi_u64(C.c_uint32(int(k) >> 32), C.c_uint32(int(k) & 0xffffffff), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def u01_open(*words):
+    return lib().orc_u01_open(*[C.c_uint32(int(w)) for w in words])
+
+
+def u01_half(*words):
+    return lib().orc_u01_half(*[C.c_uint32(int(w)) for w in words])
+
+
 def normals(seed, chain, step, stream, d):
-    out = np.empty(d, dtype=np.float32)
+    out = np.empty(d, dtype=real())
     lib().orc_normals(seed, chain, step, stream, d, _fp(out))
     return out
 
@@ -124,17 +189,19 @@ class Target:
     def __init__(self, kind, dim, params=None, fn=None, fn_data=None, reduce_lanes=0):
         self.kind, self.dim = kind, dim
         self._fn_data = fn_data             # keep-alive for a ctypes object passed as void*
-        self.params = None if params is None else np.ascontiguousarray(params, dtype=np.float32)
+        self.params = None if params is None else np.ascontiguousarray(params, dtype=real())
         self._cb = None
         self._fn_addr = None
         if fn is not None:
             if isinstance(fn, int):             # raw C function pointer (e.g. from a gcc-built user source)
                 self._fn_addr = fn
             else:
+                cr, npr = _creal(), real()
+
                 def _tramp(xp, d, _data, fn=fn):
-                    return float(fn(np.ctypeslib.as_array(xp, shape=(d,)).copy()))
-                self._cb = LOGDENSITY_FN(_tramp)
-        self.c = _Target()
+                    return float(fn(np.ctypeslib.as_array(C.cast(xp, C.POINTER(cr)), shape=(d,)).astype(npr)))
+                self._cb = _T("fn")(_tramp)
+        self.c = _T("Target")()
         self.c.kind = kind
         self.c.dim = dim
         self.c.params = _fp(self.params)
@@ -142,7 +209,7 @@ class Target:
         if self._cb is not None:
             self.c.fn = self._cb
         elif self._fn_addr is not None:
-            self.c.fn = C.cast(self._fn_addr, LOGDENSITY_FN)
+            self.c.fn = C.cast(self._fn_addr, _T("fn"))
         self.c.fn_data = None if fn_data is None else C.cast(C.pointer(fn_data), C.c_void_p)
         self.c.reduce_lanes = int(reduce_lanes)
 
@@ -152,7 +219,7 @@ class Target:
         return self
 
     def __call__(self, x):
-        x = np.ascontiguousarray(x, dtype=np.float32)
+        x = np.ascontiguousarray(x, dtype=real())
         return lib().orc_target_eval(C.byref(self.c), _fp(x))
 
 
@@ -170,11 +237,11 @@ def corr_gauss_from_cov(Sigma, reduce_lanes=0):
 def pack_lower(M):
     M = np.asarray(M)
     d = M.shape[0]
-    return np.concatenate([M[i, :i + 1] for i in range(d)]).astype(np.float32)
+    return np.concatenate([M[i, :i + 1] for i in range(d)]).astype(real())
 
 
 def unpack_lower(p, d):
-    M = np.zeros((d, d), dtype=np.float32)
+    M = np.zeros((d, d), dtype=real())
     o = 0
     for i in range(d):
         M[i, :i + 1] = p[o:o + i + 1]
@@ -184,9 +251,9 @@ def unpack_lower(p, d):
 
 class Proposal:
     def __init__(self, kind, scale=1.0, vec=None, mean=None, static=False):
-        self.vec = None if vec is None else np.ascontiguousarray(vec, dtype=np.float32)
-        self.mean = None if mean is None else np.ascontiguousarray(mean, dtype=np.float32)
-        self.c = _Proposal(kind, float(scale), _fp(self.vec), _fp(self.mean), 1 if static else 0)
+        self.vec = None if vec is None else np.ascontiguousarray(vec, dtype=real())
+        self.mean = None if mean is None else np.ascontiguousarray(mean, dtype=real())
+        self.c = _T("Proposal")(kind, float(scale), _fp(self.vec), _fp(self.mean), 1 if static else 0)
 
 
 def schedule(n_samples, discard_initial=0, thinning=1, num_warmup=0):
@@ -201,13 +268,13 @@ def schedule_counts(s):
 
 def rwmh(target, prop, sched, seed, first_chain, nchains, init=None, save=True):
     d, N, Cn = target.dim, sched.n_samples, nchains
-    samples = np.empty((N, d + 1, Cn), dtype=np.float32) if save else None
+    samples = np.empty((N, d + 1, Cn), dtype=real()) if save else None
     accepted = np.empty((N, Cn), dtype=np.uint8) if save else None
-    fx = np.empty((d, Cn), dtype=np.float32)
-    flp = np.empty(Cn, dtype=np.float32)
+    fx = np.empty((d, Cn), dtype=real())
+    flp = np.empty(Cn, dtype=real())
     cnt = np.empty(Cn, dtype=np.uint32)
     if init is not None:
-        init = np.ascontiguousarray(init, dtype=np.float32)
+        init = np.ascontiguousarray(init, dtype=real())
         assert init.shape == (d, Cn)
     rc = lib().orc_rwmh(C.byref(target.c), C.byref(prop.c), C.byref(sched), C.c_uint64(seed),
                         C.c_uint64(first_chain), Cn, _fp(init), _fp(samples), _u8p(accepted), _fp(fx),
@@ -218,14 +285,14 @@ def rwmh(target, prop, sched, seed, first_chain, nchains, init=None, save=True):
 
 def emcee(target, a, mode, sched, seed, ensemble_id, nwalkers, init, save=True):
     d, N, W = target.dim, sched.n_samples, nwalkers
-    samples = np.empty((N, d + 1, W), dtype=np.float32) if save else None
+    samples = np.empty((N, d + 1, W), dtype=real()) if save else None
     accepted = np.empty((N, W), dtype=np.uint8) if save else None
-    fx = np.empty((d, W), dtype=np.float32)
-    flp = np.empty(W, dtype=np.float32)
+    fx = np.empty((d, W), dtype=real())
+    flp = np.empty(W, dtype=real())
     cnt = np.empty(W, dtype=np.uint32)
-    init = np.ascontiguousarray(init, dtype=np.float32)
+    init = np.ascontiguousarray(init, dtype=real())
     assert init.shape == (d, W)
-    rc = lib().orc_emcee(C.byref(target.c), C.c_float(a), mode, C.byref(sched), C.c_uint64(seed),
+    rc = lib().orc_emcee(C.byref(target.c), _creal()(a), mode, C.byref(sched), C.c_uint64(seed),
                          C.c_uint64(ensemble_id), W, _fp(init), _fp(samples), _u8p(accepted), _fp(fx),
                          _fp(flp), _u32p(cnt))
     assert rc == 0
@@ -236,20 +303,20 @@ def ram(target, sched, seed, first_chain, nchains, init=None, S_in=None, alpha=0
         eig_lo=0.0, eig_hi=float("inf"), save=True):
     d, N, Cn = target.dim, sched.n_samples, nchains
     nS = d * (d + 1) // 2
-    cfg = _RamCfg(alpha, gamma, eig_lo, eig_hi)
-    samples = np.empty((N, d + 1, Cn), dtype=np.float32) if save else None
+    cfg = _T("RamCfg")(alpha, gamma, eig_lo, eig_hi)
+    samples = np.empty((N, d + 1, Cn), dtype=real()) if save else None
     accepted = np.empty((N, Cn), dtype=np.uint8) if save else None
-    fx = np.empty((d, Cn), dtype=np.float32)
-    flp = np.empty(Cn, dtype=np.float32)
+    fx = np.empty((d, Cn), dtype=real())
+    flp = np.empty(Cn, dtype=real())
     cnt = np.empty(Cn, dtype=np.uint32)
     status = np.empty(Cn, dtype=np.uint8)
-    S_out = np.empty((Cn, nS), dtype=np.float32)
-    dmin = np.empty((d, Cn), dtype=np.float32)
-    dmax = np.empty((d, Cn), dtype=np.float32)
+    S_out = np.empty((Cn, nS), dtype=real())
+    dmin = np.empty((d, Cn), dtype=real())
+    dmax = np.empty((d, Cn), dtype=real())
     if init is not None:
-        init = np.ascontiguousarray(init, dtype=np.float32)
+        init = np.ascontiguousarray(init, dtype=real())
     if S_in is not None:
-        S_in = np.ascontiguousarray(S_in, dtype=np.float32)
+        S_in = np.ascontiguousarray(S_in, dtype=real())
         assert S_in.shape == (Cn, nS)
     rc = lib().orc_ram(C.byref(target.c), C.byref(cfg), C.byref(sched), C.c_uint64(seed),
                        C.c_uint64(first_chain), Cn, _fp(init), _fp(S_in), _fp(S_out), _fp(samples),
@@ -259,38 +326,36 @@ def ram(target, sched, seed, first_chain, nchains, init=None, S_in=None, alpha=0
                 status=status, S=S_out, diag_min=dmin, diag_max=dmax)
 
 
-GRAD_FN = C.CFUNCTYPE(C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_void_p)
 
 
 def target_grad(target, x, user_grad_addr=None):
-    x = np.ascontiguousarray(x, dtype=np.float32)
+    x = np.ascontiguousarray(x, dtype=real())
     g = np.empty_like(x)
     L = lib()
-    L.orc_target_grad.restype = C.c_float
-    ug = C.cast(user_grad_addr, GRAD_FN) if user_grad_addr else C.cast(None, GRAD_FN)
+    ug = C.cast(user_grad_addr, _T("gfn")) if user_grad_addr else C.cast(None, _T("gfn"))
     lp = L.orc_target_grad(C.byref(target.c), _fp(x), _fp(g), ug)
     return lp, g
 
 
 def mala(target, sigma2, sched, seed, first_chain, nchains, init, user_grad_addr=None, save=True):
     d, N, Cn = target.dim, sched.n_samples, nchains
-    samples = np.empty((N, d + 1, Cn), dtype=np.float32) if save else None
+    samples = np.empty((N, d + 1, Cn), dtype=real()) if save else None
     accepted = np.empty((N, Cn), dtype=np.uint8) if save else None
-    fx = np.empty((d, Cn), dtype=np.float32)
-    flp = np.empty(Cn, dtype=np.float32)
+    fx = np.empty((d, Cn), dtype=real())
+    flp = np.empty(Cn, dtype=real())
     cnt = np.empty(Cn, dtype=np.uint32)
-    init = np.ascontiguousarray(init, dtype=np.float32)
+    init = np.ascontiguousarray(init, dtype=real())
     assert init.shape == (d, Cn)
-    ug = C.cast(user_grad_addr, GRAD_FN) if user_grad_addr else C.cast(None, GRAD_FN)
-    rc = lib().orc_mala(C.byref(target.c), ug, C.c_float(sigma2), C.byref(sched), C.c_uint64(seed),
+    ug = C.cast(user_grad_addr, _T("gfn")) if user_grad_addr else C.cast(None, _T("gfn"))
+    rc = lib().orc_mala(C.byref(target.c), ug, _creal()(sigma2), C.byref(sched), C.c_uint64(seed),
                         C.c_uint64(first_chain), Cn, _fp(init), _fp(samples), _u8p(accepted), _fp(fx), _fp(flp), _u32p(cnt))
     assert rc == 0
     return dict(samples=samples, accepted=accepted, final_x=fx, final_lp=flp, accept_counts=cnt)
 
 
 def chol_rank1(S_packed, w, sign):
-    S = np.ascontiguousarray(S_packed, dtype=np.float32).copy()
-    w = np.ascontiguousarray(w, dtype=np.float32).copy()
+    S = np.ascontiguousarray(S_packed, dtype=real()).copy()
+    w = np.ascontiguousarray(w, dtype=real()).copy()
     d = w.size
     rc = lib().orc_chol_rank1(_fp(S), _fp(w), d, sign)
     return rc, S

@@ -5,6 +5,26 @@ import numpy as np
 S238 = float(np.float32(0.238))
 
 
+def f64():
+    """is the engine under test running in fp64 (the `real` fixture switched the default)?"""
+    import mhx
+    return mhx.get_default_dtype() == "f64"
+
+
+def R():
+    """numpy dtype of the engine under test"""
+    return np.float64 if f64() else np.float32
+
+
+def bits(a):
+    """the bit pattern of an array (floats as unsigned integers of their width): bit-exact comparisons, NaN-safe"""
+    a = np.ascontiguousarray(a)
+    if a.dtype.kind == "f":
+        return a.view({4: np.uint32, 8: np.uint64}[a.dtype.itemsize])
+    return a
+
+
+
 def sigma_ar1(d, rho):
     i = np.arange(d)
     return rho ** np.abs(i[:, None] - i[None, :])

@@ -25,3 +25,39 @@ def mhx():
     import mhx as m
     m.lib()          # fails loudly if libmhx.so is missing
     return m
+
+
+def pytest_generate_tests(metafunc):
+    """Every `-m gpu` parity test runs in both widths: the reference computes in Float64 (f64), f32 is the same engine
+    at half the bytes.  The `real` fixture switches the engine's default dtype and the oracle's build together."""
+    if "real" in metafunc.fixturenames:
+        metafunc.parametrize("real", ["f32", "f64"], indirect=True)
+
+
+@pytest.fixture
+def real(request):
+    import mhx as m
+    from oracle import oracle as O
+    dt = request.param
+    old_m, old_o = m.get_default_dtype(), O.get_dtype()
+    m.set_default_dtype(dt)
+    O.set_dtype(dt)
+    yield dt
+    m.set_default_dtype(old_m)
+    O.set_dtype(old_o)
+
+
+@pytest.fixture(autouse=True)
+def _default_width(request):
+    """Tests that do not ask for `real` run in fp32 (the golden fixtures of round 1 and the CPU-side oracle tests)."""
+    if "real" in request.fixturenames:
+        yield
+        return
+    import mhx as m
+    from oracle import oracle as O
+    old_m, old_o = m.get_default_dtype(), O.get_dtype()
+    m.set_default_dtype("f32")
+    O.set_dtype("f32")
+    yield
+    m.set_default_dtype(old_m)
+    O.set_dtype(old_o)

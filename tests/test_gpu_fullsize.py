@@ -13,11 +13,12 @@ pytestmark = pytest.mark.gpu
 def _same(a, b, what):
     a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
     assert a.shape == b.shape, what
-    bad = np.argwhere(a.view(np.uint32) != b.view(np.uint32)) if a.dtype == np.float32 else np.argwhere(a != b)
+    assert a.dtype == b.dtype, "%s: dtypes %s / %s" % (what, a.dtype, b.dtype)
+    bad = np.argwhere(cases.bits(a) != cases.bits(b))
     assert len(bad) == 0, "%s: %d mismatches, first at %s" % (what, len(bad), bad[0])
 
 
-def test_c2_full_size_rwmh(mhx, oracle):
+def test_c2_full_size_rwmh(mhx, oracle, real):
     """configs[1]: isotropic 100-dim Gaussian, RWMH, 65 536 chains."""
     d, C, N = 100, 65536, 40
     s = float(np.float32(2.38 / d ** 0.5))
@@ -25,7 +26,7 @@ def test_c2_full_size_rwmh(mhx, oracle):
     spl = mhx.RWMH(mhx.MvNormal(mhx.zeros(d), s * s * mhx.I))
     chain = mhx.sample(model, spl, N, C, seed=0xC0FFEE)
     L = chain.stats["reduce_lanes"]
-    assert chain.stats["kernel_variant"] == 3 and L == 2          # the pre-built cooperative kernel
+    assert chain.stats["kernel_variant"] == 3 and L == (8 if real == "f64" else 2)   # the pre-built cooperative kernel
     for first in (0, 31337, C - 64):                               # three subsets of 64 chains
         ref = oracle.rwmh(oracle.iso_gauss(d, reduce_lanes=L), oracle.Proposal(oracle.PROP_ISO, s), oracle.schedule(N),
                           0xC0FFEE, first, 64)
@@ -44,7 +45,7 @@ def test_c2_full_size_rwmh(mhx, oracle):
     _same(half.value, chain.value[:8, :, C // 2:], "upper shard")
 
 
-def test_c3_full_size_emcee(mhx, oracle):
+def test_c3_full_size_emcee(mhx, oracle, real):
     """configs[2]: Ensemble(16 384, StretchProposal), 50-dim correlated Gaussian -- the whole ensemble against the oracle."""
     d, W, N = 50, 16384, 4
     Sig = cases.sigma_ar1(d, 0.9)
@@ -59,7 +60,7 @@ def test_c3_full_size_emcee(mhx, oracle):
     assert chain.stats["accepted"] == int(ref["accept_counts"].sum())
 
 
-def test_c4_full_size_ram(mhx, oracle):
+def test_c4_full_size_ram(mhx, oracle, real):
     """configs[3]: RobustAdaptiveMetropolis, 200-dim Gaussian with kappa = 1e3, 32 768 chains (5.3 GB of factors)."""
     d, C, N = 200, 32768, 6
     rng = np.random.default_rng(7)
@@ -83,7 +84,7 @@ def test_c4_full_size_ram(mhx, oracle):
     run.close()
 
 
-def test_c4_full_size_is_deterministic_under_load(mhx):
+def test_c4_full_size_is_deterministic_under_load(mhx, real):
     """The sweep stores whole row slots and relies on a wave's stores to one address landing in program order
     (DESIGN.md 6.3); the spot-checked chains above could miss a rare reordering under full load, so the whole
     2.6 GB of factors of two identical runs must agree bit for bit, and every factor must be finite."""
@@ -98,11 +99,11 @@ def test_c4_full_size_is_deterministic_under_load(mhx):
         out.append((S.copy(), st.copy()))
         run.close()
     assert np.isfinite(out[0][0]).all()
-    assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
+    assert np.array_equal(cases.bits(out[0][0]), cases.bits(out[1][0]))
     assert np.array_equal(out[0][1], out[1][1])
 
 
-def test_c5_shard_size_rwmh(mhx, oracle):
+def test_c5_shard_size_rwmh(mhx, oracle, real):
     """configs[4], one GPU's shard: 1000-dim funnel, 32 768 chains with global ids of shard 5 of 8."""
     d, C, N = 1000, 32768, 5
     s = float(np.float32(2.38 / d ** 0.5))
@@ -110,7 +111,7 @@ def test_c5_shard_size_rwmh(mhx, oracle):
     chain = mhx.sample(mhx.DensityModel(mhx.Funnel(d)), mhx.RWMH(mhx.MvNormal(mhx.zeros(d), s * s * mhx.I)), N, C, seed=5,
                        first_chain=first)
     L = chain.stats["reduce_lanes"]
-    assert chain.stats["kernel_variant"] == 3 and L == 32
+    assert chain.stats["kernel_variant"] == 3 and L == (64 if real == "f64" else 32)
     ot = oracle.Target(oracle.TARGET_FUNNEL, d).with_lanes(L)
     for off in (0, C - 32):
         ref = oracle.rwmh(ot, oracle.Proposal(oracle.PROP_ISO, s), oracle.schedule(N), 5, first + off, 32)

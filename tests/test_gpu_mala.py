@@ -15,13 +15,14 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 def _same(a, b, what):
     a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
     assert a.shape == b.shape, what
-    bad = np.argwhere(a.view(np.uint32) != b.view(np.uint32)) if a.dtype == np.float32 else np.argwhere(a != b)
+    assert a.dtype == b.dtype, "%s: dtypes %s / %s" % (what, a.dtype, b.dtype)
+    bad = np.argwhere(cases.bits(a) != cases.bits(b))
     assert len(bad) == 0, "%s: %d mismatches, first at %s: %r vs %r" % (
         what, len(bad), bad[0], a[tuple(bad[0])], b[tuple(bad[0])])
 
 
 @pytest.mark.parametrize("name", ["iso", "corr", "banana", "funnel", "iid"])
-def test_mala_bit_exact(mhx, oracle, name):
+def test_mala_bit_exact(mhx, oracle, name, real):
     rng = np.random.default_rng(4)
     d, C, N = 7, 70, 30
     if name == "iso":
@@ -38,9 +39,9 @@ def test_mala_bit_exact(mhx, oracle, name):
         data = np.load(os.path.join(GOLD, "c1_normal_data.npy"))[:40]
         spec, ot = mhx.IIDNormal(data), oracle.Target(oracle.TARGET_IID_NORMAL, 2, params=data)
     init = (rng.normal(size=(d, C)) * 0.3 + 1.0).astype(np.float32)
-    chain = mhx.sample(mhx.DensityModel(spec), mhx.MALA(0.05), N, C, seed=8, first_chain=5, initial_params=init,
+    chain = mhx.sample(mhx.DensityModel(spec), mhx.MALA(float(np.float32(0.05))), N, C, seed=8, first_chain=5, initial_params=init,
                        discard_initial=3, thinning=2)
-    ref = oracle.mala(ot, np.float32(0.05), oracle.schedule(N, 3, 2), 8, 5, C, init)
+    ref = oracle.mala(ot, float(np.float32(0.05)), oracle.schedule(N, 3, 2), 8, 5, C, init)
     _same(chain.value, ref["samples"], "samples")
     _same(chain.accepted, ref["accepted"], "accepted")
     x, lp, cnt = chain.state.state()
@@ -48,7 +49,7 @@ def test_mala_bit_exact(mhx, oracle, name):
     _same(cnt, ref["accept_counts"], "accept counts")
 
 
-def test_mala_reference_tests(mhx, oracle):
+def test_mala_reference_tests(mhx, oracle, real):
     """test/runtests.jl:288-332 (basic) and :334-365 (issue #95)."""
     data = np.load(os.path.join(GOLD, "c1_normal_data.npy"))
     model = mhx.DensityModel(mhx.IIDNormal(data))

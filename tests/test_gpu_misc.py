@@ -15,12 +15,13 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 def _same(a, b, what):
     a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
     assert a.shape == b.shape, what
-    bad = np.argwhere(a.view(np.uint32) != b.view(np.uint32)) if a.dtype == np.float32 else np.argwhere(a != b)
+    assert a.dtype == b.dtype, "%s: dtypes %s / %s" % (what, a.dtype, b.dtype)
+    bad = np.argwhere(cases.bits(a) != cases.bits(b))
     assert len(bad) == 0, "%s: %d mismatches, first at %s: %r vs %r" % (
         what, len(bad), bad[0], a[tuple(bad[0])], b[tuple(bad[0])])
 
 
-def test_logdensity_batch_matches_oracle(mhx, oracle):
+def test_logdensity_batch_matches_oracle(mhx, oracle, real):
     rng = np.random.default_rng(0)
     d, n = 9, 300
     x = rng.normal(size=(d, n)).astype(np.float32)
@@ -35,20 +36,20 @@ def test_logdensity_batch_matches_oracle(mhx, oracle):
     ]
     for spec, ot in specs:
         lp = mhx.logdensity(mhx.DensityModel(spec), x)
-        want = np.array([ot(x[:, i]) for i in range(n)], dtype=np.float32)
+        want = np.array([ot(x[:, i]) for i in range(n)], dtype=cases.R())
         _same(lp, want, type(spec).__name__)
     data = rng.normal(size=30).astype(np.float32)
     th = np.stack([rng.normal(size=n), rng.normal(size=n) + 1.0]).astype(np.float32)   # some sigma < 0
     lp = mhx.logdensity(mhx.DensityModel(mhx.IIDNormal(data)), th)
     ot = oracle.Target(oracle.TARGET_IID_NORMAL, 2, params=data)
-    _same(lp, np.array([ot(th[:, i]) for i in range(n)], dtype=np.float32), "IIDNormal")
+    _same(lp, np.array([ot(th[:, i]) for i in range(n)], dtype=cases.R()), "IIDNormal")
     assert np.isneginf(lp[th[1] < 0]).all()
 
 
 @pytest.mark.parametrize("flags_name", ["auto", "nojit", "generic"])   # golden traces use the sequential (1-lane) shape
 @pytest.mark.parametrize("name", ["rwmh_iso", "rwmh_dense_corr", "rwmh_funnel", "rwmh_banana"])
-def test_rwmh_golden_traces_all_kernel_variants(mhx, name, flags_name):
-    tr = np.load(os.path.join(GOLD, "traces.npz"))
+def test_rwmh_golden_traces_all_kernel_variants(mhx, name, flags_name, real):
+    tr = np.load(os.path.join(GOLD, "traces64.npz" if real == "f64" else "traces.npz"))
     flags = {"auto": 0, "nojit": mhx.FLAG_NO_JIT, "generic": mhx.FLAG_GENERIC}[flags_name]
     if name == "rwmh_iso":
         chain = mhx.sample(mhx.DensityModel(mhx.IsoGaussian(5)), mhx.RWMH(mhx.MvNormal(mhx.zeros(5), 0.25 * mhx.I)), 32, 8,
@@ -71,7 +72,7 @@ def test_rwmh_golden_traces_all_kernel_variants(mhx, name, flags_name):
     assert chain.stats["kernel_variant"] == want_variant
 
 
-def test_c1_readme_plumbing(mhx, oracle):
+def test_c1_readme_plumbing(mhx, oracle, real):
     """BASELINE config 1 / README.md:25-40: Normal(mu, sigma) DensityModel, RWMH(MvNormal(zeros(2), I)),
     100 000 steps, ONE chain -- GPU result identical to the CPU oracle and close to the data's moments."""
     data = np.load(os.path.join(GOLD, "c1_normal_data.npy"))[:30]
@@ -90,13 +91,13 @@ def test_c1_readme_plumbing(mhx, oracle):
     assert (ess > 1000).all() and (ess < 30000).all()           # README.md:59-63 shows ESS ~ 3.9e3 of 1e5 draws
 
 
-def test_large_dim_streaming_kernel(mhx, oracle):
+def test_large_dim_streaming_kernel(mhx, oracle, real):
     """BASELINE config 5 shape: 1000-dim funnel / banana, state streamed from HBM (generic kernel)."""
     d, C, N = 1000, 96, 6
     s = float(np.float32(2.38 / d ** 0.5))
     for spec, ot in ((mhx.Funnel(d), oracle.Target(oracle.TARGET_FUNNEL, d)),
                      (mhx.Banana(d, 0.03), oracle.Target(oracle.TARGET_BANANA, d, params=[0.03]))):
-        for lanes, flags in ((0, 0), (1, 0), (16, 0), (0, mhx.FLAG_GENERIC)):
+        for lanes, flags in ((0, 0), (1, 0), (32 if real == "f64" else 16, 0), (0, mhx.FLAG_GENERIC)):
             chain = mhx.sample(mhx.DensityModel(spec), mhx.RWMH(mhx.MvNormal(mhx.zeros(d), s * s * mhx.I)), N, C, seed=55,
                                first_chain=1 << 33, reduce_lanes=lanes, flags=flags)
             L = chain.stats["reduce_lanes"]
@@ -108,7 +109,7 @@ def test_large_dim_streaming_kernel(mhx, oracle):
                 assert L == 1 and chain.stats["kernel_variant"] == 0       # state streamed from HBM
 
 
-def test_shard_invariance_and_resume(mhx):
+def test_shard_invariance_and_resume(mhx, real):
     """chains carry global ids: two shards == one run; a run continued in pieces == one long run."""
     d, C, N = 6, 200, 30
     model = mhx.DensityModel(mhx.IsoGaussian(d))
@@ -131,7 +132,7 @@ def test_shard_invariance_and_resume(mhx):
     assert (x2 == 0).all() and np.allclose(lp2, -0.5 * d * np.log(2 * np.pi), atol=1e-5)
 
 
-def test_diagnostics_match_numpy(mhx):
+def test_diagnostics_match_numpy(mhx, real):
     d, C, N = 3, 300, 400
     model = mhx.DensityModel(mhx.IsoGaussian(d))
     chain = mhx.sample(model, mhx.RWMH(mhx.MvNormal(mhx.zeros(d), 1.0 * mhx.I)), N, C, seed=3, discard_initial=200)
@@ -177,7 +178,7 @@ def test_diagnostics_match_numpy(mhx):
 
 
 @pytest.mark.parametrize("flags_name,d,C,lanes", [("auto", 1000, 70, 0), ("auto", 12, 300, 2), ("generic", 9, 130, 0)])
-def test_running_moments_match_sample_statistics(mhx, flags_name, d, C, lanes):
+def test_running_moments_match_sample_statistics(mhx, flags_name, d, C, lanes, real):
     """save = "moments": per-chain Welford mean / M2 kept on the device instead of the sample tensor (C5-sized runs);
     the R-hat / ESS sums from them equal the ones from the stored samples of the same chains."""
     flags = mhx.FLAG_GENERIC if flags_name == "generic" else 0
@@ -206,7 +207,7 @@ def test_running_moments_match_sample_statistics(mhx, flags_name, d, C, lanes):
             run.sample(N, disc, thin, 0, save="moments")
 
 
-def test_error_behaviour(mhx):
+def test_error_behaviour(mhx, real):
     with pytest.raises(mhx.ArgumentError):                      # dim mismatch
         mhx.sample(mhx.DensityModel(mhx.IsoGaussian(3)), mhx.RWMH(4), 5)
     with pytest.raises(mhx.ArgumentError):                      # a drifting walk declared symmetric
@@ -226,7 +227,7 @@ def test_error_behaviour(mhx):
 
 
 @pytest.mark.parametrize("flags_name", ["auto", "generic"])
-def test_infinite_and_nan_log_ratios(mhx, oracle, flags_name):
+def test_infinite_and_nan_log_ratios(mhx, oracle, flags_name, real):
     """src/mh-core.jl:104-108 edge cases: lp = -Inf at the start with a finite candidate (+Inf ratio => accept), a
     candidate outside the support (-Inf => reject), -Inf vs -Inf (NaN => reject) -- identical decisions on the GPU."""
     flags = mhx.FLAG_GENERIC if flags_name == "generic" else 0
@@ -242,7 +243,7 @@ def test_infinite_and_nan_log_ratios(mhx, oracle, flags_name):
     assert np.isneginf(chain.value[0, 2, :]).all() and np.isfinite(chain.value[-1, 2, :]).all()
 
 
-def test_ram_nan_log_ratio_skips_adaptation(mhx, oracle):
+def test_ram_nan_log_ratio_skips_adaptation(mhx, oracle, real):
     """RAM from a point of zero density towards more zero density: lp' - lp = NaN, the step is rejected and the
     factor is left alone (status bit 1), exactly as the oracle does."""
     data = np.zeros(4, dtype=np.float32)
@@ -258,7 +259,7 @@ def test_ram_nan_log_ratio_skips_adaptation(mhx, oracle):
     assert (st & 2).all()
 
 
-def test_symmetric_random_walk_on_a_scalar_model(mhx):
+def test_symmetric_random_walk_on_a_scalar_model(mhx, real):
     """test/runtests.jl:215-259: target Normal(5, 0.7) as a user log-density, SymmetricRandomWalkProposal(Normal(0, 1)),
     100 000 draws: mean and std within 0.05 (the symmetric flag only skips a Hastings ratio that is 0 anyway)."""
     src = """
@@ -278,7 +279,7 @@ def test_symmetric_random_walk_on_a_scalar_model(mhx):
 
 
 @pytest.mark.parametrize("kind", ["iso", "diag", "dense"])
-def test_drifting_random_walk_hastings_ratio(mhx, oracle, kind):
+def test_drifting_random_walk_hastings_ratio(mhx, oracle, kind, real):
     """RandomWalkProposal(MvNormal(mu != 0, Sigma)): the walk drifts and logratio_proposal_density
     (src/proposal.jl:58-64,190-192) is no longer 0 -- evaluated on the device, bit-exact against the oracle, and the
     chain still targets the model (the ratio cancels the drift)."""
@@ -306,18 +307,19 @@ def test_drifting_random_walk_hastings_ratio(mhx, oracle, kind):
 
 # ---- StaticProposal / StaticMH: the independence sampler of src/proposal.jl:9-11,66-83 --------------------
 @pytest.mark.parametrize("kind", ["iso", "diag", "dense", "dense_mean", "iso_mean"])
-def test_static_proposal_bit_exact(mhx, oracle, kind):
+def test_static_proposal_bit_exact(mhx, oracle, kind, real):
     d, C, N = 5, 7, 40
     rng = np.random.default_rng(11)
     mean = None
     if kind.startswith("iso"):
-        prop, op = mhx.MvNormal(mhx.zeros(d), 1.3 ** 2 * mhx.I), dict(kind=oracle.PROP_ISO, scale=float(np.float32(1.3)))
+        s13 = float(np.float32(1.3))                          # representable in both widths: sqrt(s13 * s13) == s13
+        prop, op = mhx.MvNormal(mhx.zeros(d), s13 * s13 * mhx.I), dict(kind=oracle.PROP_ISO, scale=s13)
         if kind == "iso_mean":
             mean = rng.normal(size=d) * 0.3
-            prop = mhx.MvNormal(mean, 1.3 ** 2 * mhx.I)
+            prop = mhx.MvNormal(mean, s13 * s13 * mhx.I)
     elif kind == "diag":
-        s = 0.5 + rng.random(d)
-        prop, op = [mhx.Normal(0.0, float(v)) for v in s], dict(kind=oracle.PROP_DIAG, vec=s.astype(np.float32))
+        s = (0.5 + rng.random(d)).astype(np.float32).astype(np.float64)
+        prop, op = [mhx.Normal(0.0, float(v)) for v in s], dict(kind=oracle.PROP_DIAG, vec=s)
     else:
         A = rng.normal(size=(d, d)) * 0.3
         Sig = A @ A.T + np.eye(d)
@@ -332,12 +334,12 @@ def test_static_proposal_bit_exact(mhx, oracle, kind):
         chain = mhx.sample(model, spl, N, C, seed=5, first_chain=3, initial_params=init, discard_initial=2, thinning=3)
         ref = oracle.rwmh(oracle.corr_gauss_from_cov(Sig_t), oracle.Proposal(mean=mean, static=True, **op),
                           oracle.schedule(N, 2, 3), 5, 3, C, init=init)
-        assert np.array_equal(chain.value.view(np.uint32), ref["samples"].view(np.uint32))
+        assert np.array_equal(cases.bits(chain.value), cases.bits(ref["samples"]))
         assert np.array_equal(chain.accepted, ref["accepted"])
         assert 0.02 < chain.accepted[1:].mean() < 0.98
 
 
-def test_static_mh_posterior_of_the_readme_model(mhx):
+def test_static_mh_posterior_of_the_readme_model(mhx, real):
     """test/runtests.jl:56-74 (StaticMH testset): the Normal(mu, sigma) model of the README under static proposals
     [Normal(0,1), Normal(0,1)] and MvNormal(zeros(2), I); posterior mean of mu ~ mean(data), sigma ~ std(data)."""
     data = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c1_normal_data.npy"))
@@ -348,7 +350,7 @@ def test_static_mh_posterior_of_the_readme_model(mhx):
         assert abs(mu - data.mean()) < 0.1 and abs(sig - data.std()) < 0.1, (mu, sig)
 
 
-def test_static_proposal_survives_setparams(mhx, oracle):
+def test_static_proposal_survives_setparams(mhx, oracle, real):
     """setparams!! replaces the state: the proposal's logpdf at the new state is recomputed with it."""
     d, C = 3, 4
     model = mhx.DensityModel(mhx.IsoGaussian(d))
@@ -360,11 +362,11 @@ def test_static_proposal_survives_setparams(mhx, oracle):
     run.sample(6, 0, 1, 0, save=True)
     got = run.samples()[0]
     ref = oracle.rwmh(oracle.iso_gauss(d), oracle.Proposal(oracle.PROP_ISO, 2.0, static=True), oracle.schedule(6), 2, 0, C, init=x0)
-    assert np.array_equal(got.view(np.uint32), ref["samples"].view(np.uint32))
+    assert np.array_equal(cases.bits(got), cases.bits(ref["samples"]))
     run.close()
 
 
-def test_runs_release_their_device_memory(mhx):
+def test_runs_release_their_device_memory(mhx, real):
     """create / init / sample / diagnostics / destroy cycles over every sampler leave the free-memory count unchanged."""
     import ctypes as C
     hip = C.CDLL("libamdhip64.so")
@@ -394,7 +396,7 @@ def test_runs_release_their_device_memory(mhx):
     assert before - free_bytes() < (1 << 20), "device memory leaked: %d bytes" % (before - free_bytes())
 
 
-def test_bulk_and_tail_ess_match_numpy(mhx):
+def test_bulk_and_tail_ess_match_numpy(mhx, real):
     """Rank-normalised bulk ESS and tail ESS (Vehtari et al. 2021) against a numpy / scipy restatement."""
     from scipy.stats import norm
     d, C, N = 2, 64, 600
@@ -441,7 +443,7 @@ def test_bulk_and_tail_ess_match_numpy(mhx):
     assert (np.abs(got["ess_bulk"][:d] / plain[:d] - 1) < 0.15).all()
 
 
-def test_chains_summary_statistics(mhx):
+def test_chains_summary_statistics(mhx, real):
     """chain.summarystats(): the MCMCChains table (README.md:59-63) from the device diagnostics; README model."""
     data = np.load(os.path.join(GOLD, "c1_normal_data.npy"))
     model = mhx.DensityModel(mhx.IIDNormal(data))
@@ -467,7 +469,7 @@ def test_readme_example_runs():
 
 
 @pytest.mark.parametrize("kind", ["rwmh_coop", "rwmh_dense", "rwmh_static", "emcee_coop", "emcee_user", "ram", "mala"])
-def test_checkpoint_and_resume(mhx, kind):
+def test_checkpoint_and_resume(mhx, kind, real):
     """mhx_run_save_state / mhx_run_load_state: a NEW run (created with another seed) that loads the blob continues the
     saved run bit for bit -- samples, accept flags, final state, RAM factors."""
     d, C = (40, 70) if kind != "emcee_user" else (6, 30)

@@ -13,7 +13,8 @@ pytestmark = pytest.mark.gpu
 def _same(a, b, what):
     a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
     assert a.shape == b.shape, what
-    bad = np.argwhere(a.view(np.uint32) != b.view(np.uint32)) if a.dtype == np.float32 else np.argwhere(a != b)
+    assert a.dtype == b.dtype, "%s: dtypes %s / %s" % (what, a.dtype, b.dtype)
+    bad = np.argwhere(cases.bits(a) != cases.bits(b))
     assert len(bad) == 0, "%s: %d mismatches, first at %s: %r vs %r" % (
         what, len(bad), bad[0], a[tuple(bad[0])], b[tuple(bad[0])])
 
@@ -27,7 +28,7 @@ def _run(mhx, model, spl, N, C, seed, first, init, **kw):
 
 
 @pytest.mark.parametrize("d,C,N,warm", [(4, 6, 24, 16), (2, 9, 50, 50), (70, 5, 12, 8), (200, 3, 8, 6)])
-def test_ram_bit_exact(mhx, oracle, d, C, N, warm):
+def test_ram_bit_exact(mhx, oracle, d, C, N, warm, real):
     Sig = cases.sigma_ar1(d, 0.7)
     init = np.zeros((d, C), dtype=np.float32)
     model = mhx.DensityModel(mhx.CorrGaussian(Sig))
@@ -45,7 +46,7 @@ def test_ram_bit_exact(mhx, oracle, d, C, N, warm):
     _same(st, ref["status"], "status")
 
 
-def test_ram_long_run_spans_several_launches(mhx, oracle):
+def test_ram_long_run_spans_several_launches(mhx, oracle, real):
     """9 000 transitions = three launches; adaptation stops inside the second one."""
     d, C = 3, 5
     Sig = cases.sigma_ar1(d, 0.5)
@@ -58,7 +59,7 @@ def test_ram_long_run_spans_several_launches(mhx, oracle):
     _same(cnt, ref["accept_counts"], "accept counts")
 
 
-def test_ram_iso_target_random_init_and_custom_factor(mhx, oracle):
+def test_ram_iso_target_random_init_and_custom_factor(mhx, oracle, real):
     d, C, N = 5, 7, 30
     rng = np.random.default_rng(3)
     L = np.tril(rng.normal(size=(d, d)) * 0.2) + np.eye(d)
@@ -74,8 +75,8 @@ def test_ram_iso_target_random_init_and_custom_factor(mhx, oracle):
         mhx.sample(model, mhx.RobustAdaptiveMetropolis(S=np.eye(d + 1)), 3, 1, initial_params=np.zeros(d))
 
 
-def test_ram_golden_traces(mhx):
-    tr = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "traces.npz"))
+def test_ram_golden_traces(mhx, real):
+    tr = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "traces64.npz" if real == "f64" else "traces.npz"))
     d = 4
     model = mhx.DensityModel(mhx.CorrGaussian(cases.sigma_ar1(d, 0.7)))
     chain = mhx.sample(model, mhx.RobustAdaptiveMetropolis(), 24, 6, seed=31, first_chain=2,
@@ -93,7 +94,7 @@ def test_ram_golden_traces(mhx):
 
 
 @pytest.mark.parametrize("var", [10.0, 0.01])
-def test_ram_eigenvalue_bounds_property(mhx, var):
+def test_ram_eigenvalue_bounds_property(mhx, var, real):
     """test/RobustAdaptiveMetropolis.jl:30-72, with the per-iteration callback replaced by the running
     diag(S) range the device keeps, and cross-checked with a real callback on a few chains."""
     Sig = np.array([[var, var / 2], [var / 2, var]])
@@ -114,7 +115,7 @@ def test_ram_eigenvalue_bounds_property(mhx, var):
     assert (diags >= 0.9).all() and (diags <= 1.1).all()
 
 
-def test_ram_doctest_covariance(mhx):
+def test_ram_doctest_covariance(mhx, real):
     """RAM.jl:17-70: 10 000 warm-up + 10 000 draws on a 2-d Gaussian with correlation 0.5."""
     Sig = np.array([[1.0, 0.5], [0.5, 1.0]])
     model = mhx.DensityModel(mhx.CorrGaussian(Sig))
@@ -133,7 +134,7 @@ def test_ram_doctest_covariance(mhx):
 # one dimension per pre-built kernel shape (lanes per chain x rows per lane): 16x{1,2,4}, 32x{3..8},
 # 64x{5,6,7,8,12,16}; odd chain counts leave idle lane groups in the last wave
 @pytest.mark.parametrize("d", [16, 30, 50, 64, 90, 128, 150, 190, 224, 250, 300, 380, 448, 500, 700, 1000])
-def test_ram_every_kernel_shape(mhx, oracle, d):
+def test_ram_every_kernel_shape(mhx, oracle, d, real):
     C, N, warm = 5, 5, 4
     Sig = cases.sigma_ar1(d, 0.6)
     init = np.zeros((d, C), dtype=np.float32)
@@ -148,7 +149,7 @@ def test_ram_every_kernel_shape(mhx, oracle, d):
     _same(st, ref["status"], "status")
 
 
-def test_ram_chains_of_one_wave_fail_independently(mhx, oracle):
+def test_ram_chains_of_one_wave_fail_independently(mhx, oracle, real):
     """Chains that share a wave (16-lane groups at d = 6) take different paths: one starts at NaN (its
     adaptation is skipped every step, status bit 1 -- RAM.jl:159); with a GROWING step size (gamma = -1,
     eta = iteration) the downdates of the others leave the PD cone at different steps (status bit 0, the
@@ -171,7 +172,7 @@ def test_ram_chains_of_one_wave_fail_independently(mhx, oracle):
 
 
 @pytest.mark.parametrize("d", [3, 40, 100])
-def test_ram_user_log_density(mhx, oracle, d):
+def test_ram_user_log_density(mhx, oracle, d, real):
     """A user log-density given as HIP source (hiprtc) under RAM, in 16- and 32-lane groups: independent Gaussians
     with per-dimension mean / std passed as data; the oracle evaluates the same source compiled for the host."""
     import user_targets
@@ -189,7 +190,7 @@ def test_ram_user_log_density(mhx, oracle, d):
     _same(cnt, ref["accept_counts"], "accept counts")
 
 
-def test_ram_refused_factor_leaves_the_run_untouched(mhx, oracle):
+def test_ram_refused_factor_leaves_the_run_untouched(mhx, oracle, real):
     """mhx_ram_set_factor validates before it touches the run: after MHX_ENOTPD the chains continue exactly as the
     oracle's uninterrupted run (chains whose current factor sits in buffer 1 keep it)."""
     import ctypes as C
@@ -203,11 +204,11 @@ def test_ram_refused_factor_leaves_the_run_untouched(mhx, oracle):
     bad = np.tile(np.eye(d, dtype=np.float32)[np.tril_indices(d)], (Cn, 1))
     bad[7, 0] = -1.0
     from mhx import _lib as L
-    rc = L.lib().mhx_ram_set_factor(run.h, L.fptr(L.f32(bad)))
+    rc = L.lib().mhx_ram_set_factor(run.h, L.rptr(run.ctx.arr(bad)))
     assert rc == L.MHX_ENOTPD
     run.sample(1, 10, 1, 10)
     ref = oracle.ram(oracle.corr_gauss_from_cov(Sig), oracle.schedule(1, 25, 1, 25), 17, 0, Cn, init=init)
     got, _ = run.samples()
-    assert np.array_equal(got.view(np.uint32), ref["samples"].view(np.uint32))
-    assert np.array_equal(run.factor()[0].view(np.uint32), ref["S"].view(np.uint32))
+    assert np.array_equal(cases.bits(got), cases.bits(ref["samples"]))
+    assert np.array_equal(cases.bits(run.factor()[0]), cases.bits(ref["S"]))
     run.close()

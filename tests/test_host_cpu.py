@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol(mhx):
     for name in declared:
         assert hasattr(lib, name), "libmhx.so does not export %s" % name
     assert sorted(mhx.EXPORTS) == declared
-    assert lib.mhx_version() == 100
+    assert lib.mhx_version() == 200
 
 
 def test_no_gpu_fails_loudly_not_silently(mhx):
@@ -195,7 +195,7 @@ def test_product_path_never_touches_the_oracle_or_a_cpu_fallback():
 
 
 def test_sharded_ensemble_slices_partition_a_half():
-    """mhx.dist.ShardedEnsemble.slices: contiguous, equal-sized (last ones possibly shorter or empty), covering the half."""
+    """mhx.dist.ShardedEnsemble.slices (the rule of mhx_comm_slice): contiguous, covering the half, sizes within one of each other."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "advancedmh.jl_amd"))
     from mhx.dist import ShardedEnsemble
@@ -205,6 +205,6 @@ def test_sharded_ensemble_slices_partition_a_half():
             assert len(sl) == world and sum(c for _, c in sl) == cnt
             pos = 0
             for b, c in sl:
-                assert c >= 0 and (c == 0 or b == pos)
+                assert c >= 0 and b == pos
                 pos += c
-            assert max(c for _, c in sl) == (cnt + world - 1) // world
+            assert max(c for _, c in sl) - min(c for _, c in sl) <= 1

@@ -132,3 +132,83 @@ def test_schedule_counts(oracle):
     assert oracle.schedule_counts(oracle.schedule(1000, 0, 1, 1000)) == (999, 999)          # test/RobustAdaptiveMetropolis.jl:44-55
     assert oracle.schedule_counts(oracle.schedule(10000, 10000, 1, 10000)) == (19999, 10000)  # RAM doctest
     assert oracle.schedule_counts(oracle.schedule(10, 5, 3, 8)) == (5 + 27, 5 + 2 * 3)
+
+
+# ---- the fp64 build (the reference's Float64 arithmetic): its own polynomials, 52-bit uniforms, 2 Philox blocks per 4 normals
+@pytest.fixture
+def oracle64(oracle):
+    old = oracle.get_dtype()
+    oracle.set_dtype("f64")
+    yield oracle
+    oracle.set_dtype(old)
+
+
+def _ulp64(got, want):
+    import mpmath as mp
+    ex = max(mp.floor(mp.log(abs(want), 2)), -1022) if want != 0 else -1074
+    return float(abs(mp.mpf(float(got)) - want) / mp.mpf(2) ** (ex - 52))
+
+
+def test_f64_log_exp_accuracy(oracle64):
+    mp = pytest.importorskip("mpmath")
+    mp.mp.dps = 40
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.uniform(0, 1, 1500), np.exp(rng.uniform(-700, 700, 1000)), 1 + rng.uniform(-1e-3, 1e-3, 500),
+                        rng.uniform(0.5, 2, 1500), [5e-324, 2.2250738585072014e-308]])
+    assert max(_ulp64(g, mp.log(mp.mpf(float(v)))) for g, v in zip(oracle64.log(x), x)) < 1.0
+    assert oracle64.log([0.0])[0] == -np.inf and np.isnan(oracle64.log([-1.0])[0]) and oracle64.log([np.inf])[0] == np.inf
+    x = np.concatenate([rng.uniform(-745, 709.7, 2500), rng.uniform(-1, 1, 1000), rng.uniform(-30, 30, 1000)])
+    assert max(_ulp64(g, mp.exp(mp.mpf(float(v)))) for g, v in zip(oracle64.exp(x), x)) < 1.0
+    assert oracle64.exp([-800.0])[0] == 0.0 and oracle64.exp([800.0])[0] == np.inf and oracle64.exp([0.0])[0] == 1.0
+
+
+def test_f64_sincos_accuracy(oracle64):
+    mp = pytest.importorskip("mpmath")
+    mp.mp.dps = 40
+    worst = 0.0
+    ks = [int(k) for k in np.random.default_rng(2).integers(0, 2 ** 64, 3000, dtype=np.uint64)] + [0, 1, 2 ** 61, 2 ** 62, 2 ** 63, 2 ** 64 - 1]
+    for k in ks:
+        s, c = oracle64.sincos2pi_u64(k)
+        kk = (k + 2 ** 61) % 2 ** 64                     # the spec's angle: quadrant + 52-bit residual
+        q, t = kk >> 62, ((kk & (2 ** 62 - 1)) - 2 ** 61) >> 10
+        ang = 2 * mp.pi * (mp.mpf(q) / 4 + mp.mpf(t) * mp.mpf(2) ** -54)
+        ws, wc = mp.sin(ang), mp.cos(ang)
+        if abs(ws) > mp.mpf("1e-30"):
+            worst = max(worst, _ulp64(s, ws))
+        if abs(wc) > mp.mpf("1e-30"):
+            worst = max(worst, _ulp64(c, wc))
+        assert abs(s * s + c * c - 1.0) < 4e-16
+    assert worst < 0.75
+    assert oracle64.sincos2pi_u64(0) == (0.0, 1.0)
+
+
+def test_f64_uniforms_and_normals(oracle64):
+    # (k + 1/2) 2^-52 and k 2^-52 with k = hi:lo >> 12, exactly
+    for hi, lo in ((0, 0), (0xffffffff, 0xffffffff), (0x12345678, 0x9abcdef0), (1, 0xfff), (0, 0x1000)):
+        k = ((hi << 32) | lo) >> 12
+        assert oracle64.u01_open(hi, lo) == (2 * k + 1) / 2.0 ** 53 and oracle64.u01_half(hi, lo) == k / 2.0 ** 52
+    assert 0.0 < oracle64.u01_open(0, 0) and oracle64.u01_open(0xffffffff, 0xffffffff) < 1.0
+    z = np.concatenate([oracle64.normals(7, c, 1, 0, 1000) for c in range(100)])
+    assert z.dtype == np.float64 and abs(z.mean()) < 0.02 and abs(z.std() - 1) < 0.02
+    assert stats.kstest(z, "norm").pvalue > 1e-3
+    # normals 4b .. 4b+3 come from Philox blocks 2b and 2b+1 of the stream: a prefix of a longer draw is the shorter draw
+    assert np.array_equal(oracle64.normals(7, 3, 9, 0, 7), oracle64.normals(7, 3, 9, 0, 100)[:7])
+    lu = np.array([oracle64.accept_logu(3, c, s) for c in range(60) for s in range(1, 41)])
+    assert (lu < 0).all() and stats.kstest(-lu, "expon").pvalue > 1e-3
+    # the accept block is shared by 2 consecutive steps (words 0:1 and 2:3 of one Philox block)
+    w = oracle64.philox([5, 0, 7 >> 1, 1 << 28], [3, 0])
+    assert oracle64.accept_logu(3, 5, 7) == oracle64.log([oracle64.u01_open(w[2], w[3])])[0]
+    assert oracle64.accept_logu(3, 5, 6) == oracle64.log([oracle64.u01_open(w[0], w[1])])[0]
+
+
+def test_c1_readme_model_runs_in_fp64(oracle64):
+    """BASELINE configs[0] / SURVEY 8(d) C1: the README's 2-parameter Normal(mu, sigma) model, RWMH(MvNormal(zeros(2), I)),
+    100 000 steps, one chain, fp64, seed 1234, on the CPU oracle (plumbing; the GPU twin is tests/test_gpu_misc.py)."""
+    import os
+    data = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c1_normal_data.npy"))[:30]
+    t = oracle64.Target(oracle64.TARGET_IID_NORMAL, 2, params=data)
+    r = oracle64.rwmh(t, oracle64.Proposal(oracle64.PROP_ISO, 1.0), oracle64.schedule(100000), 1234, 0, 1,
+                      init=np.array([[0.0], [1.0]]))
+    assert r["samples"].dtype == np.float64
+    mu, sig = r["samples"][:, 0, 0], r["samples"][:, 1, 0]
+    assert abs(mu.mean() - data.mean()) < 0.1 and abs(sig.mean() - data.std()) < 0.15 and (sig >= 0).all()

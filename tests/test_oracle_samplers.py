@@ -11,13 +11,9 @@ import user_targets
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-@pytest.fixture(scope="module")
-def traces():
-    return np.load(os.path.join(GOLD, "traces.npz"))
-
-
 @pytest.mark.parametrize("name", sorted(cases.TRACE_CASES))
-def test_oracle_reproduces_golden_traces(oracle, traces, name):
+def test_oracle_reproduces_golden_traces(oracle, real, name):
+    traces = np.load(os.path.join(GOLD, "traces64.npz" if real == "f64" else "traces.npz"))
     res = cases.TRACE_CASES[name](oracle)
     for k, v in res.items():
         want = traces["%s/%s" % (name, k)]
@@ -25,7 +21,7 @@ def test_oracle_reproduces_golden_traces(oracle, traces, name):
         assert np.array_equal(v.view(np.uint8), want.view(np.uint8)), "%s/%s drifted" % (name, k)
 
 
-def test_rwmh_normal_model_known_answer(oracle):
+def test_rwmh_normal_model_known_answer(oracle, real):
     """test/runtests.jl:76-94: RWMH(MvNormal(zeros(2), I)) on the Normal(mu, sigma) likelihood of 300
     N(0,1) points; posterior mean mu ~ 0, sigma ~ 1 (atol 0.1).  100 000 draws, one chain, as README.md:40."""
     data = np.load(os.path.join(GOLD, "c1_normal_data.npy"))
@@ -40,7 +36,7 @@ def test_rwmh_normal_model_known_answer(oracle):
     assert 0.001 < acc < 0.2                                   # unit-scale proposal on a sharp posterior (sd ~ 0.06)
 
 
-def test_rwmh_first_sample_and_schedule(oracle):
+def test_rwmh_first_sample_and_schedule(oracle, real):
     init = np.random.default_rng(0).normal(size=(3, 4)).astype(np.float32)
     r = oracle.rwmh(oracle.iso_gauss(3), oracle.Proposal(oracle.PROP_ISO, 0.7), oracle.schedule(6), 9, 0, 4, init=init)
     assert np.array_equal(r["samples"][0, :3, :], init) and not r["accepted"][0].any()   # test/runtests.jl:203-213
@@ -53,7 +49,7 @@ def test_rwmh_first_sample_and_schedule(oracle):
     assert np.array_equal(part["samples"], full["samples"][:, :, 2:])
 
 
-def test_rwmh_edge_cases(oracle):
+def test_rwmh_edge_cases(oracle, real):
     # lp = -inf at the start and a finite candidate: +inf log-ratio => accept
     t = oracle.Target(oracle.TARGET_IID_NORMAL, 2, params=np.zeros(5, dtype=np.float32))
     r = oracle.rwmh(t, oracle.Proposal(oracle.PROP_ISO, 0.5), oracle.schedule(200), 3, 0, 8,
@@ -70,7 +66,7 @@ def test_rwmh_edge_cases(oracle):
 
 
 @pytest.mark.parametrize("mode", [0, 1])
-def test_emcee_nig_known_answer_untransformed(oracle, mode):
+def test_emcee_nig_known_answer_untransformed(oracle, mode, real):
     """test/emcee.jl:3-42: E[s] = 49/24, E[m] = 7/6 (atol 0.1); Ensemble(1000, StretchProposal(...)), 1000 iterations.
     mode 0 = the reference's sequential sweep, mode 1 = the parallel half-split the GPU runs."""
     t = user_targets.host_target(oracle, user_targets.NIG_UNTRANSFORMED, 2)
@@ -86,7 +82,7 @@ def test_emcee_nig_known_answer_untransformed(oracle, mode):
     assert np.array_equal(r2["samples"], r["samples"][25:25 + 4 * 200:4])     # test/emcee.jl:39 index arithmetic
 
 
-def test_emcee_nig_known_answer_transformed(oracle):
+def test_emcee_nig_known_answer_transformed(oracle, real):
     """test/emcee.jl:44-83 (log-transformed space, initial walkers ~ MvNormal(zeros(2), I))."""
     t = user_targets.host_target(oracle, user_targets.NIG_TRANSFORMED, 2)
     W = 1000
@@ -97,7 +93,7 @@ def test_emcee_nig_known_answer_transformed(oracle):
     assert abs(m.mean() - 7 / 6) < 0.1
 
 
-def test_emcee_partner_is_never_self_and_initial_sample(oracle):
+def test_emcee_partner_is_never_self_and_initial_sample(oracle, real):
     d, W = 2, 6
     init = cases.emcee_init(d, W, 1)
     for mode in (0, 1):
@@ -109,7 +105,7 @@ def test_emcee_partner_is_never_self_and_initial_sample(oracle):
 
 
 @pytest.mark.parametrize("var", [10.0, 0.01])
-def test_ram_eigenvalue_bounds(oracle, var):
+def test_ram_eigenvalue_bounds(oracle, var, real):
     """test/RobustAdaptiveMetropolis.jl:30-72: diag(S) stays within [0.9, 1.1] and saturates the relevant bound."""
     Sig = np.array([[var, var / 2], [var / 2, var]])
     C = 8
@@ -123,7 +119,7 @@ def test_ram_eigenvalue_bounds(oracle, var):
     assert r["accepted"][0].all()                             # initial Transition(x, lp, true), RAM.jl:213
 
 
-def test_ram_doctest_covariance(oracle):
+def test_ram_doctest_covariance(oracle, real):
     """src/RobustAdaptiveMetropolis.jl:17-70: 2-d Gaussian, correlation 0.5; 10 000 warm-up + 10 000 draws from
     zeros(2): cov(chain) ~ Sigma (rtol 0.2); with bounds [0.1, 2.0]: |cov - Sigma| < 0.2."""
     Sig = np.array([[1.0, 0.5], [0.5, 1.0]])
@@ -140,7 +136,7 @@ def test_ram_doctest_covariance(oracle):
         assert (r["status"] & 1).sum() == 0
 
 
-def test_mala_known_answers(oracle):
+def test_mala_known_answers(oracle, real):
     """test/runtests.jl:288-366.  basic: the Normal(mu, sigma) model with sigma2 = 1e-3 from ones(2): means ~ (0, 1);
     issue #95: 2-d Gaussian Sigma = [1.5 .35; .35 1], sigma2 = 0.5: mean ~ 0 (atol .1), cov ~ Sigma (atol .2)."""
     data = np.load(os.path.join(GOLD, "c1_normal_data.npy"))
@@ -162,7 +158,7 @@ def test_mala_known_answers(oracle):
     assert np.abs(np.cov(v2.transpose(1, 0, 2).reshape(2, -1)) - Sig).max() < 0.2
 
 
-def test_catalogue_gradients_against_finite_differences(oracle):
+def test_catalogue_gradients_against_finite_differences(oracle, real):
     rng = np.random.default_rng(0)
     d = 6
     x = rng.normal(size=d).astype(np.float32)
@@ -177,7 +173,7 @@ def test_catalogue_gradients_against_finite_differences(oracle):
             assert abs(g[k] - (t(x + e) - t(x - e)) / 2e-3) < 2e-3 * max(1.0, abs(g[k]))
 
 
-def test_drifting_walk_is_corrected_by_the_hastings_ratio(oracle):
+def test_drifting_walk_is_corrected_by_the_hastings_ratio(oracle, real):
     """src/proposal.jl:58-64,190-192: with a non-zero proposal mean the ratio q(x|y) - q(y|x) is what keeps the target invariant."""
     d = 3
     mean = np.array([0.3, -0.2, 0.1], dtype=np.float32)
@@ -186,7 +182,7 @@ def test_drifting_walk_is_corrected_by_the_hastings_ratio(oracle):
     assert np.abs(v.mean(axis=(0, 2))).max() < 0.03 and np.abs(v.var(axis=(0, 2)) - 1).max() < 0.03
 
 
-def test_static_proposal_is_an_independence_sampler(oracle):
+def test_static_proposal_is_an_independence_sampler(oracle, real):
     """StaticProposal (src/proposal.jl:9-11,66-83): candidates ignore the state, the ratio carries the proposal's
     logpdf.  2-D Gaussian with correlation 0.5 under N(0, 2 I): mean 0, covariance recovered; the first sample of a
     run without initial_params is a draw from the proposal (src/mh-core.jl:83)."""

@@ -45,20 +45,29 @@ h = mp.log(2) / 2 * mp.mpf("1.0001")
 show("EXP E(r), deg 11: exp(r) = 1 + r + r^2 E(r)", mp.chebyfit(E, [-h, h], 12))
 
 
-# ---- sin(2 pi r) = r S(r^2), cos(2 pi r) = C(r^2), |r| <= 1/8
-def S(u):
-    if u < mp.mpf("1e-40"):
-        return 2 * mp.pi
+# ---- sin(2 pi r) = 2 pi r + r u S1(u),  cos(2 pi r) = 1 - 2 pi^2 u + u^2 C2(u),  u = r^2, |r| <= 1/8.
+#      The leading constants are split (hi + lo) so that their rounding does not reach the result.
+c1 = -2 * mp.pi ** 2
+
+
+def S1(u):
+    if u < mp.mpf("1e-30"):
+        return -(2 * mp.pi) ** 3 / 6
     r = mp.sqrt(u)
-    return mp.sin(2 * mp.pi * r) / r
+    return (mp.sin(2 * mp.pi * r) / r - 2 * mp.pi) / u
 
 
-def Cc(u):
-    return mp.cos(2 * mp.pi * mp.sqrt(u))
+def C2(u):
+    if u < mp.mpf("1e-20"):
+        return (2 * mp.pi) ** 4 / 24
+    return (mp.cos(2 * mp.pi * mp.sqrt(u)) - 1 - c1 * u) / (u * u)
 
 
-show("SIN S(u), deg 7: sin(2 pi r) = r S(r^2)", mp.chebyfit(S, [0, mp.mpf(1) / 64], 8))
-show("COS C(u), deg 8: cos(2 pi r) = C(r^2)", mp.chebyfit(Cc, [0, mp.mpf(1) / 64], 9))
+show("SIN S1(u), deg 6", mp.chebyfit(S1, [0, mp.mpf(1) / 64], 7))
+show("COS C2(u), deg 6", mp.chebyfit(C2, [0, mp.mpf(1) / 64], 7))
+for name, v in (("2PI", 2 * mp.pi), ("-2PI^2", c1)):
+    hi_ = float(v)
+    print("  %s_HI = %s   %s_LO = %s" % (name, hi_.hex(), name, float(v - mp.mpf(hi_)).hex()))
 
 print("// ln2 split: hi = 32 significant bits (n * hi exact for |n| < 2^20), lo = ln2 - hi")
 ln2 = mp.log(2)
