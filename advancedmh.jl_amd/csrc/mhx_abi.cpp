@@ -108,6 +108,11 @@ extern "C" int mhx_ram_set_factor(mhx_run* r, const void* S)
     NEED(r, "mhx_ram_set_factor");
     return is64(r) ? mhx_f64::api_ram_set_factor(R64(r), CD(S)) : mhx_f32::api_ram_set_factor(R32(r), CF(S));
 }
+extern "C" int mhx_ram_set_factor_all(mhx_run* r, const void* S)
+{
+    NEED(r, "mhx_ram_set_factor_all");
+    return is64(r) ? mhx_f64::api_ram_set_factor_all(R64(r), CD(S)) : mhx_f32::api_ram_set_factor_all(R32(r), CF(S));
+}
 extern "C" int mhx_ram_get_factor(mhx_run* r, void* S, uint8_t* status)
 {
     NEED(r, "mhx_ram_get_factor");

@@ -100,8 +100,8 @@ struct prebuilt_coop {
 // the BASELINE shapes: C2 (65 536 chains x d = 100) and C5 (32 768 chains per GPU x d = 1000); a double takes two VGPRs,
 // so the fp64 engine spreads a chain over more lanes
 #if MHX_REAL64
-#define MHX_C2_L 8
-#define MHX_C2_NBL 4
+#define MHX_C2_L 4
+#define MHX_C2_NBL 7
 #define MHX_C5_L 64
 #define MHX_C5_NBL 4
 #else
@@ -684,15 +684,22 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
     if (L > 1) {
         const int NBL = (nblk + L - 1) / L;
         if (NBL > MHX_COOP_NBL_MAX) return mhx_fail(MHX_EINVAL, "reduce_lanes=%d leaves %d blocks per lane (max %d)", L, NBL, MHX_COOP_NBL_MAX);
-        for (const auto& pb : k_prebuilt_coop)
-            if (pb.L == L && pb.NBL == NBL && pb.TK == tk && pb.PK == pk) { r->reg_fn = pb.fn; r->reg_fn_mom = pb.fn_mom; r->variant = 3; }
+        // tuning knobs: MHX_NO_PREBUILT=1 specialises with hiprtc even where a pre-built kernel exists; MHX_COOP_WAVES=w
+        // overrides the waves-per-SIMD launch bound of the hiprtc kernel (register budget 512 / w)
+        const char* no_prebuilt = getenv("MHX_NO_PREBUILT");
+        const char* waves_env = getenv("MHX_COOP_WAVES");
+        const int waves_override = waves_env ? atoi(waves_env) : 0;
+        if (!(no_prebuilt && atoi(no_prebuilt)) && !waves_override)
+            for (const auto& pb : k_prebuilt_coop)
+                if (pb.L == L && pb.NBL == NBL && pb.TK == tk && pb.PK == pk) { r->reg_fn = pb.fn; r->reg_fn_mom = pb.fn_mom; r->variant = 3; }
         if (!r->variant && !(r->flags & MHX_FLAG_NO_JIT)) {
             jit_module* m = nullptr;
             const std::string key = "rwmh_coop/l=" + std::to_string(L) + "/nbl=" + std::to_string(NBL) + "/tk=" +
-                                    std::to_string(tk) + "/pk=" + std::to_string(pk);
-            rc = jit_compile(ctx, key + "/mom=0", jit_source(t, "mhx_rwmh_kernels.h"),
-                             {"MHX_JIT_RWMH_COOP=1", "MHX_JIT_L=" + std::to_string(L), "MHX_JIT_NBL=" + std::to_string(NBL),
-                              "MHX_JIT_TK=" + std::to_string(tk), "MHX_JIT_PK=" + std::to_string(pk), "MHX_JIT_MOM=0"}, &m);
+                                    std::to_string(tk) + "/pk=" + std::to_string(pk) + "/w=" + std::to_string(waves_override);
+            std::vector<std::string> defs = {"MHX_JIT_RWMH_COOP=1", "MHX_JIT_L=" + std::to_string(L), "MHX_JIT_NBL=" + std::to_string(NBL),
+                                             "MHX_JIT_TK=" + std::to_string(tk), "MHX_JIT_PK=" + std::to_string(pk), "MHX_JIT_MOM=0"};
+            if (waves_override > 0) defs.push_back("MHX_JIT_WAVES=" + std::to_string(waves_override));
+            rc = jit_compile(ctx, key + "/mom=0", jit_source(t, "mhx_rwmh_kernels.h"), defs, &m);
             if (rc == MHX_OK) rc = jit_function(m, "mhx_jit_rwmh_coop", &r->jit_step);
             if (rc == MHX_OK) r->variant = 4;
             else if (cfg->reduce_lanes > 1) return rc;      // the caller asked for this shape explicitly

@@ -91,6 +91,19 @@ MHX_DEV void mhx_srd_store(mhx_srd srd, mhx_u32 lane_byte_off, mhx_u32 row_byte_
 }
 #endif
 
+// v_readlane of a real (two dwords in fp64)
+MHX_DEV mhx_real mhx_readlane(const mhx_real x, const int lane)
+{
+#if MHX_REAL64
+    const mhx_u64 b = __builtin_bit_cast(mhx_u64, x);
+    const mhx_u32 lo = (mhx_u32)__builtin_amdgcn_readlane((int)(mhx_u32)b, lane);
+    const mhx_u32 hi = (mhx_u32)__builtin_amdgcn_readlane((int)(mhx_u32)(b >> 32), lane);
+    return __builtin_bit_cast(double, ((mhx_u64)hi << 32) | lo);
+#else
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane));
+#endif
+}
+
 // RNG stream tags: counter word 3 = tag << 28 | block
 #define MHX_STREAM_PROPOSAL 0u
 #define MHX_STREAM_ACCEPT   1u
@@ -143,6 +156,21 @@ MHX_DEV double  mhx_fma(double a, double b, double c) { return __builtin_fma(a, 
 #define MHX_INF    __builtin_inf()
 #define MHX_NAN    __builtin_nan("")
 
+// a / b for finite normal operands whose quotient is normal (or a == 0): the correctly rounded sequence hipcc emits for an
+// fp64 division -- reciprocal estimate, two Newton steps, quotient, residual, final fma -- without its range scaling
+// (v_div_scale x 2) and special-case fix-up (v_div_fixup), which are the identity in that range: 8 instead of 11 instructions
+MHX_DEV double mhx_div_normal(const double a, const double b)
+{
+    double y = __builtin_amdgcn_rcp(b);
+    double e = mhx_fma(-b, y, 1.0);
+    y = mhx_fma(y, e, y);
+    e = mhx_fma(-b, y, 1.0);
+    y = mhx_fma(y, e, y);
+    const double q = a * y;
+    const double r = mhx_fma(-b, q, a);
+    return mhx_fma(r, y, q);
+}
+
 // m in [sqrt(1/2), sqrt(2)), f = m - 1, s = f / (2 + f), z = s^2:
 //   log(1 + f) = 2 s + s z P(z) = f - hfsq + s (hfsq + z P(z)),  hfsq = f^2 / 2       (one correctly rounded division)
 MHX_DEV double mhx_log_core(mhx_u64 ix, const int eadj)
@@ -151,7 +179,7 @@ MHX_DEV double mhx_log_core(mhx_u64 ix, const int eadj)
     const long long e = (long long)t >> 52;
     const double m = mhx_u2d(ix - ((mhx_u64)e << 52));
     const double f = m - 1.0;
-    const double s = f / (2.0 + f);
+    const double s = mhx_div_normal(f, 2.0 + f);       // 2 + f in [1.7, 2.42]; f == 0 or |f| >= 2^-53
     const double z = s * s;
     double p = 0x1.2b59b70eb76c6p-3;
     p = mhx_fma(p, z, 0x1.39fe42e9d4a8ap-3);
@@ -214,7 +242,22 @@ MHX_DEV double mhx_exp(double x)
 
 MHX_DEV double mhx_sqrt(double x) { return __builtin_sqrt(x); }   // correctly rounded (default HIP lowering)
 MHX_DEV double mhx_abs(double x) { return __builtin_fabs(x); }
-MHX_DEV double mhx_sqrt_normal(double x) { return __builtin_sqrt(x); }
+// Correctly rounded sqrt for a NORMAL positive x away from the ends of the exponent range (the Box-Muller radius argument
+// -2 ln u lies in [2.2e-16, 74]): the sequence hipcc emits -- v_rsq_f64, one coupled Goldschmidt step, two residual
+// corrections -- without its pre/post scaling for x < 2^-767 and its class test for 0 / inf: 10 instead of 17 instructions
+MHX_DEV double mhx_sqrt_normal(const double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = y * 0.5;
+    const double r = mhx_fma(-h, g, 0.5);
+    g = mhx_fma(g, r, g);
+    h = mhx_fma(h, r, h);
+    double d = mhx_fma(-g, g, x);
+    g = mhx_fma(d, h, g);
+    d = mhx_fma(-g, g, x);
+    return mhx_fma(d, h, g);
+}
 
 // sin/cos of 2 pi a / 2^64, a = hi:lo: integer quadrant reduction; the residual keeps 52 bits so that it is exact in
 // a double (r = (ri >> 10) 2^-54 turns, [-1/8, 1/8)); split leading constants, compensated cos: < 0.7 ulp each
@@ -274,7 +317,7 @@ MHX_DEV double mhx_u01_half(mhx_u32 hi, mhx_u32 lo)
 MHX_DEV void mhx_normal_pair(const mhx_u32x4& w, double& n0, double& n1)
 {
     const double l = mhx_log_pos(mhx_u01_open(w.x, w.y));
-    const double rad = mhx_sqrt(-2.0 * l);
+    const double rad = mhx_sqrt_normal(-2.0 * l);
     double s, c;
     mhx_sincos2pi_u64(w.z, w.w, s, c);
     n0 = rad * c;

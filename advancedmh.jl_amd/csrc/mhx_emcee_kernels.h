@@ -46,7 +46,22 @@ struct mhx_emcee_args {
     int reduce_lanes;         // lanes per walker (cooperative kernel), >= 1
     int t_begin, t_count;     // the slice of the moving half this launch moves (an ensemble sharded over GPUs moves
                               // one slice per rank and exchanges the slices; a single GPU moves [0, size of the half))
+    // initial walkers drawn on the device (src/emcee.jl:29-34: W draws from the wrapped prior, here (Mv)Normal): x_i = mu + L z
+    int init_kind;            // MHX_PROP_ISO / DIAG / DENSE
+    mhx_real init_scale;
+    const mhx_real* init_vec;    // DIAG: sigma[dim]; DENSE: chol(Sigma) packed lower
+    const mhx_real* init_mean;   // mu[dim] or null
+    // the reference's sequential sweep (one launch = the whole schedule, one wave): see mhx_emcee_seq_body
+    int nsweeps;              // sweeps of this launch
+    mhx_u32 save_next;        // first sweep whose state is recorded (0xffffffff: none), then every `thinning`-th
+    int thinning;
 };
+
+#ifndef MHX_PROP_ISO
+#define MHX_PROP_ISO   0
+#define MHX_PROP_DIAG  1
+#define MHX_PROP_DENSE 2
+#endif
 
 typedef mhx_real mhx_e4 __attribute__((ext_vector_type(4)));
 
@@ -140,12 +155,42 @@ MHX_DEV void mhx_emcee_half_body(const mhx_emcee_args& a, const mhx_real* __rest
     // cooperative kernel below for why there is no per-wave atomic in these short launches)
 }
 
-// initial walkers (src/emcee.jl:6-8): W log-density evaluations, accepted = false
+// initial walkers (src/emcee.jl:29-34, :6-8): with `draw`, walker i is a draw mu + L z from the wrapped (Mv)Normal prior,
+// z from Philox stream INIT of (ensemble, i); then W log-density evaluations, accepted = false
 template <int TK>
-MHX_DEV void mhx_emcee_init_body(const mhx_emcee_args& a, const mhx_real* __restrict__ tparams)
+MHX_DEV void mhx_emcee_init_body(const mhx_emcee_args& a, const mhx_real* __restrict__ tparams, const int draw)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.nwalkers) return;
+    if (draw) {
+        const mhx_philox_key ks = mhx_philox_schedule(a.seed);
+        const long ld = a.nwalkers;
+        const int d = a.dim;
+        mhx_real* xs = a.x + i;
+        const int nblk = (d + 3) >> 2;
+        for (int b = 0; b < nblk; ++b) {
+            mhx_real n[4];
+            mhx_normal4(ks, (mhx_u32)i, (mhx_u32)a.ensemble_id, 0u, MHX_STREAM_INIT, (mhx_u32)b, n);
+            for (int j = 0; j < 4; ++j) {
+                const int k = 4 * b + j;
+                if (k < d) {
+                    if (a.init_kind == MHX_PROP_DENSE) xs[(long)k * ld] = n[j];
+                    else {
+                        const mhx_real sc = a.init_kind == MHX_PROP_ISO ? a.init_scale : a.init_vec[k];
+                        xs[(long)k * ld] = a.init_mean ? mhx_fma(sc, n[j], a.init_mean[k]) : mhx_fma(sc, n[j], MHX_R(0.0));
+                    }
+                }
+            }
+        }
+        if (a.init_kind == MHX_PROP_DENSE) {
+            for (int r = d - 1; r >= 0; --r) {                  // rows in descending order: z is overwritten in place
+                const mhx_real* Lr = a.init_vec + (long)r * (r + 1) / 2;
+                mhx_real w = MHX_R(0.0);
+                for (int j = 0; j <= r; ++j) w = mhx_fma(Lr[j], xs[(long)j * ld], w);
+                xs[(long)r * ld] = a.init_mean ? a.init_mean[r] + w : w;
+            }
+        }
+    }
     mhx_strided_x xv;
     xv.base = a.x + i;
     xv.ld = a.nwalkers;
@@ -405,6 +450,71 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const mhx_real* __rest
     // address (~12 ns each) would cost more than the move; the host sums acc_count after the run.
 }
 
+// ---------------------------------------------------------------------------------------------
+// The reference's OWN sweep (src/emcee.jl:39-58): walkers move one after another, walker i pairs with idx = mod1(i + r, W),
+// r uniform on 1..W-1, and uses the ALREADY UPDATED position when idx < i (:53) -- Gauss-Seidel, serial in W by
+// construction.  One wave runs the whole schedule of a launch: lanes share the copy of a move's rows, lane 0 evaluates
+// the log-density in the sequential order of the spec (every target, user sources included), all lanes take its
+// decision.  It exists for fidelity, not speed (what Julia runs; MHX_FLAG_EMCEE_SEQUENTIAL): test/emcee.jl's 1000-walker
+// ensemble is one block.  In-place update == the reference's new_walkers / walkers pair: entries below i are new.
+template <int TK>
+MHX_DEV void mhx_emcee_seq_body(const mhx_emcee_args& a, const mhx_real* __restrict__ tparams)
+{
+    const int lane = threadIdx.x & 63;
+    const int W = a.nwalkers, d = a.dim;
+    const long ld = W;
+    const mhx_philox_key ks = mhx_philox_schedule(a.seed);
+    mhx_u32 save_next = a.save_next;
+    long slot = a.save_slot;
+    for (int s = 0; s < a.nsweeps; ++s) {
+        const mhx_u32 sweep = a.sweep + (mhx_u32)s;
+        const bool rec = sweep == save_next;
+        for (int i = 0; i < W; ++i) {
+            const mhx_emcee_draws dr = mhx_emcee_draw(ks, (mhx_u32)i, (mhx_u32)a.ensemble_id, sweep);
+            // src/emcee.jl:48,52  idx = mod1(i + rand(1:W-1), W): never i itself
+            const mhx_u32 r = 1u + (mhx_u32)(((mhx_u64)dr.partner * (mhx_u64)(mhx_u32)(W - 1)) >> 32);
+            const int j = (int)(((mhx_u64)(mhx_u32)i + r) % (mhx_u64)(mhx_u32)W);
+            const mhx_real tt = mhx_fma(a.stretch - MHX_R(1.0), dr.u, MHX_R(1.0));
+            const mhx_real z = (tt * tt) / a.stretch;                              // :81
+            const mhx_real alphamult = (mhx_real)(d - 1) * mhx_log(z);             // :82
+            mhx_real* ys = a.ybuf;                                                  // [dim] candidate of the current move
+            for (int k = lane; k < d; k += 64) {
+                const mhx_real xi = a.x[(long)k * ld + i], xj = a.x[(long)k * ld + j];
+                ys[k] = mhx_fma(z, xi - xj, xj);                                    // :85
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            mhx_real lpy = MHX_R(0.0);
+            if (lane == 0) {
+                mhx_strided_x yv;
+                yv.base = ys;
+                yv.ld = 1;
+                lpy = mhx_target_eval<TK>(a.target_kind, yv, d, tparams, a.ntparams, a.tconst);
+            }
+            lpy = mhx_readlane(lpy, 0);
+            const mhx_real lpi = a.lp[i];
+            const mhx_real alpha = (alphamult + lpy) - lpi;                         // :91
+            const bool acc = dr.logu <= alpha;                                      // :93 (non-strict)
+            if (acc) {
+                for (int k = lane; k < d; k += 64) a.x[(long)k * ld + i] = ys[k];
+                if (lane == 0) { a.lp[i] = lpy; a.acc_count[i] += 1u; }
+            }
+            if (lane == 0) a.last_acc[i] = acc ? 1 : 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (rec) {
+            mhx_real* row = a.samples + slot * (long)(d + 1) * ld;
+            for (long e = lane; e < (long)d * W; e += 64) row[e] = a.x[e];
+            for (int i = lane; i < W; i += 64) { row[(long)d * ld + i] = a.lp[i]; a.accepted[slot * ld + i] = a.last_acc[i]; }
+            save_next += (mhx_u32)a.thinning;
+            ++slot;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 #ifdef MHX_JIT_EMCEE
 #if MHX_JIT_L > 1
 extern "C" __global__ void __launch_bounds__(64 * MHX_EMCEE_COOP_WAVES)
@@ -423,9 +533,14 @@ mhx_jit_emcee_half(const mhx_emcee_args a, const mhx_real* __restrict__ tparams)
 #endif
 }
 extern "C" __global__ void __launch_bounds__(256)
-mhx_jit_emcee_init(const mhx_emcee_args a, const mhx_real* __restrict__ tparams)
+mhx_jit_emcee_init(const mhx_emcee_args a, const mhx_real* __restrict__ tparams, const int draw)
 {
-    mhx_emcee_init_body<MHX_JIT_TK>(a, tparams);
+    mhx_emcee_init_body<MHX_JIT_TK>(a, tparams, draw);
+}
+extern "C" __global__ void __launch_bounds__(64)
+mhx_jit_emcee_seq(const mhx_emcee_args a, const mhx_real* __restrict__ tparams)
+{
+    mhx_emcee_seq_body<MHX_JIT_TK>(a, tparams);
 }
 #endif
 MHX_NS_END

@@ -34,6 +34,7 @@ struct mhx_handle_hdr { int32_t dtype; };
     int api_ram_create(mhx_ctx* ctx, const mhx_target* t, const mhx_ram_cfg* cfg, mhx_run** out);                      \
     int api_mala_create(mhx_ctx* ctx, const mhx_target* t, const mhx_mala_cfg* cfg, mhx_run** out);                    \
     int api_ram_set_factor(mhx_run* r, const REAL* S);                                                                 \
+    int api_ram_set_factor_all(mhx_run* r, const REAL* S);                                                             \
     int api_ram_get_factor(mhx_run* r, REAL* S, uint8_t* status);                                                      \
     int api_ram_get_diag_range(mhx_run* r, REAL* diag_min, REAL* diag_max);                                            \
     int api_ram_get_adapt_state(mhx_run* r, REAL* log_alpha, double* eta, uint8_t* isaccept, uint64_t* iteration);     \

@@ -255,19 +255,6 @@ MHX_DEV mhx_real mhx_ram_draw(const mhx_philox_key& ks, mhx_u32 id_lo, mhx_u32 i
     return nn;
 }
 
-// v_readlane of a real (two dwords in fp64)
-MHX_DEV mhx_real mhx_readlane(const mhx_real x, const int lane)
-{
-#if MHX_REAL64
-    const mhx_u64 b = __builtin_bit_cast(mhx_u64, x);
-    const mhx_u32 lo = (mhx_u32)__builtin_amdgcn_readlane((int)(mhx_u32)b, lane);
-    const mhx_u32 hi = (mhx_u32)__builtin_amdgcn_readlane((int)(mhx_u32)(b >> 32), lane);
-    return __builtin_bit_cast(double, ((mhx_u64)hi << 32) | lo);
-#else
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane));
-#endif
-}
-
 // value of x in lane il of the caller's own group
 template <int G>
 MHX_DEV mhx_real mhx_ram_group_bcast(const mhx_real x, const int il, const int g)

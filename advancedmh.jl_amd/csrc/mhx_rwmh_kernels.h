@@ -29,9 +29,9 @@ MHX_NS_BEGIN
 // Cooperative kernel: blocks (4 dimensions each) a lane may own -- x and y are 8 reals per block, a double takes two
 // VGPRs -- and the waves per SIMD its launch bound asks for (its point is >= 2 waves per SIMD)
 #if MHX_REAL64
-#define MHX_COOP_NBL_AUTO 6
-#define MHX_COOP_NBL_MAX 8
-#define MHX_COOP_WAVES(NBL) ((NBL) <= 2 ? 4 : ((NBL) <= 6 ? 2 : 1))
+#define MHX_COOP_NBL_AUTO 7
+#define MHX_COOP_NBL_MAX 13
+#define MHX_COOP_WAVES(NBL) ((NBL) <= 2 ? 4 : ((NBL) <= 7 ? 2 : 1))
 #else
 #define MHX_COOP_NBL_AUTO 13
 #define MHX_COOP_NBL_MAX 16
@@ -625,7 +625,10 @@ mhx_jit_rwmh_reg(const mhx_rwmh_args a, const mhx_real* __restrict__ tparams, co
 }
 #endif
 #ifdef MHX_JIT_RWMH_COOP
-extern "C" __global__ void __launch_bounds__(256, MHX_COOP_WAVES(MHX_JIT_NBL))
+#ifndef MHX_JIT_WAVES
+#define MHX_JIT_WAVES MHX_COOP_WAVES(MHX_JIT_NBL)
+#endif
+extern "C" __global__ void __launch_bounds__(256, MHX_JIT_WAVES)
 mhx_jit_rwmh_coop(const mhx_rwmh_args a, const mhx_real* __restrict__ tparams, const mhx_real* __restrict__ pvec)
 {
     mhx_rwmh_coop_body<MHX_JIT_L, MHX_JIT_NBL, MHX_JIT_TK, MHX_JIT_PK, (MHX_JIT_MOM != 0)>(a, tparams, pvec);

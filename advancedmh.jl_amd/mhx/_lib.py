@@ -15,6 +15,7 @@ TARGET_USER = 100
 PROP_ISO, PROP_DIAG, PROP_DENSE = 0, 1, 2
 FLAG_NO_JIT, FLAG_GENERIC = 1, 2
 MHX_FLAG_STATIC_PROPOSAL = 4
+FLAG_EMCEE_SEQUENTIAL = 8
 
 
 class MhxError(RuntimeError):
@@ -46,7 +47,8 @@ class RwmhCfg(C.Structure):
 
 class EmceeCfg(C.Structure):
     _fields_ = [("dim", C.c_int32), ("nwalkers", C.c_int32), ("seed", C.c_uint64), ("ensemble_id", C.c_uint64),
-                ("stretch", C.c_double), ("flags", C.c_int32), ("reduce_lanes", C.c_int32)]
+                ("stretch", C.c_double), ("flags", C.c_int32), ("reduce_lanes", C.c_int32),
+                ("init_kind", C.c_int32), ("init_scale", C.c_double), ("init_vec", C.c_void_p), ("init_mean", C.c_void_p)]
 
 
 class RamCfg(C.Structure):
@@ -78,7 +80,7 @@ EXPORTS = [
     "mhx_run_get_state", "mhx_run_set_state", "mhx_run_stats", "mhx_run_device_samples",
     "mhx_run_destroy", "mhx_run_diagnostics", "mhx_run_ess_bulk_tail", "mhx_emcee_half_step", "mhx_emcee_end_sweep",
     "mhx_emcee_device_state", "mhx_run_state_size", "mhx_run_save_state", "mhx_run_load_state",
-    "mhx_ctx_dtype", "mhx_ctx_device", "mhx_ram_get_adapt_state", "mhx_emcee_exchange_plan", "mhx_emcee_exchange_pack",
+    "mhx_ctx_dtype", "mhx_ctx_device", "mhx_ram_set_factor_all", "mhx_ram_get_adapt_state", "mhx_emcee_exchange_plan", "mhx_emcee_exchange_pack",
     "mhx_emcee_exchange_unpack", "mhx_comm_unique_id", "mhx_comm_init", "mhx_comm_destroy", "mhx_comm_rank",
     "mhx_comm_allreduce_sum", "mhx_comm_slice", "mhx_comm_allgather_walkers",
 ]
@@ -129,6 +131,7 @@ def lib():
         L.mhx_ram_create.argtypes = [vp, vp, C.POINTER(RamCfg), C.POINTER(vp)]
         L.mhx_mala_create.argtypes = [vp, vp, C.POINTER(MalaCfg), C.POINTER(vp)]
         L.mhx_ram_set_factor.argtypes = [vp, rp]
+        L.mhx_ram_set_factor_all.argtypes = [vp, rp]
         L.mhx_ram_get_factor.argtypes = [vp, rp, u8p]
         L.mhx_ram_get_diag_range.argtypes = [vp, rp, rp]
         L.mhx_ram_get_adapt_state.argtypes = [vp, rp, dp, u8p, C.POINTER(C.c_uint64)]

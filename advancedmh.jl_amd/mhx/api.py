@@ -439,7 +439,24 @@ class Run:
             self.n = nchains
             self.kind = "rwmh"
         elif isinstance(sampler, Ensemble):
-            cfg = L.EmceeCfg(d, sampler.n_walkers, seed, first_chain, sampler.proposal.stretch_length, flags, reduce_lanes)
+            # the distribution StretchProposal wraps is the prior of the initial walkers (src/emcee.jl:29-34): a (Mv)Normal
+            # or a vector of Normals is drawn on the device, anything else by the host in init()
+            self._prior = None
+            try:
+                self._prior = _as_mvnormal(sampler.proposal.proposal)
+            except L.ArgumentError:
+                pass
+            ik, isc, ivec, imean = -1, 1.0, None, None
+            if self._prior is not None and self._prior.dim == d:
+                mvp = self._prior
+                ik, isc = mvp.kind, mvp.scale
+                ivec = None if mvp.vec is None else f32(mvp.vec)
+                imean = f32(mvp.mean) if np.any(mvp.mean != 0) else None
+                self._keep += [ivec, imean]
+            else:
+                self._prior = None
+            cfg = L.EmceeCfg(d, sampler.n_walkers, seed, first_chain, sampler.proposal.stretch_length, flags, reduce_lanes,
+                             ik, isc, L.rptr(ivec), L.rptr(imean))
             L.check(lib.mhx_emcee_create(self.ctx.h, model.handle(self.ctx), C.byref(cfg), C.byref(self.h)))
             self.n = sampler.n_walkers
             self.kind = "emcee"
@@ -458,11 +475,11 @@ class Run:
             self.n = nchains
             self.kind = "ram"
             if sampler.S is not None:
-                if sampler.S.ndim == 3:                      # one factor per chain (the C ABI's native form)
+                if sampler.S.ndim == 3:                      # one factor per chain
                     S = np.stack([pack_lower(np.tril(sampler.S[c])) for c in range(nchains)])
-                else:
-                    S = np.tile(pack_lower(np.tril(sampler.S)), (nchains, 1))
-                L.check(lib.mhx_ram_set_factor(self.h, L.rptr(f32(S))))
+                    L.check(lib.mhx_ram_set_factor(self.h, L.rptr(f32(S))))
+                else:                                        # the reference's form: one S for the sampler (RAM.jl:198-206)
+                    L.check(lib.mhx_ram_set_factor_all(self.h, L.rptr(f32(pack_lower(np.tril(sampler.S))))))
         else:
             raise L.ArgumentError(L.MHX_EINVAL, "unsupported sampler %r" % (sampler,))
         self.dim = d
@@ -482,9 +499,10 @@ class Run:
             if ip.shape != (self.dim, self.n):
                 raise L.ArgumentError(L.MHX_EINVAL, "initial_params must be (dim,) or (dim, nchains)")
             ip = self.ctx.arr(ip)
-        elif self.kind == "emcee":
-            # src/emcee.jl:29-34: W draws from the wrapped prior; a one-off host draw (numpy Generator
-            # seeded from the run seed), the device takes over from the first sweep.
+        elif self.kind == "emcee" and self._prior is None:
+            # src/emcee.jl:29-34: W draws from the wrapped prior.  A (Mv)Normal prior is drawn on the device
+            # (mhx_run_init(run, NULL)); any other Distribution: a one-off host draw (numpy Generator seeded from the run
+            # seed), the device takes over from the first sweep.
             rng = np.random.default_rng([self.seed, 0xE3CEE])
             ip = self.ctx.arr(np.stack([self.sampler.proposal.rand_initial(rng) for _ in range(self.n)], axis=1))
         L.check(L.lib().mhx_run_init(self.h, L.fptr(ip)))

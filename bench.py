@@ -1,18 +1,21 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark: MH steps/sec (all chains) + ESS/sec on the isotropic 100-dim
-Gaussian, RWMH, 65 536 chains per GPU (BASELINE.json configs[1]).
+"""bench.py -- headline benchmark: MH steps/sec (all chains) + ESS/sec.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config c2|c3|c4|c5] [--dtype f64|f32]
 
-One "step" = one pass of the hot path over one batch: ONE mhx_run_sample launch that advances all
-65 536 chains of this rank by `--inner` (default 250) Metropolis-Hastings transitions and records
-every state (the save-all semantics of the reference's `sample`) into the HBM-resident sample
-tensor [inner][d+1][chains].  Inputs (chain state) and outputs (samples) stay in HBM; nothing
-crosses PCIe inside the timed region.  Chains are sharded over ranks by global chain id
-(first_chain = rank * chains), no data-path collective; scaling is weak.
+Default: BASELINE.json configs[1] (C2) -- RWMH on the isotropic 100-dim Gaussian, 65 536 chains per GPU -- in fp64, the
+arithmetic the reference computes in (Distributions' Float64 rand / logpdf).  The same run also reports the fp32 engine
+as a second figure (`f32`), never as `value`.
 
-Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel against HBM with the
-algorithmic bytes of DESIGN.md section 7; `cpu_baseline` is the CPU oracle (a port of the
+One "step" = one pass of the hot path over one batch = ONE mhx_run_sample call that advances all chains of this rank by
+`--inner` transitions (C2: every state recorded into the HBM-resident sample tensor [inner][d+1][chains], the save-all
+semantics of the reference's `sample`).  Inputs (chain state) and outputs (samples) stay in HBM; nothing crosses PCIe
+inside the timed region.  Chains are sharded over ranks by global chain id (first_chain = rank * chains), no data-path
+collective; scaling is weak.  The only collective -- acceptance totals + R-hat sums, and the max-over-ranks time -- is
+ONE small all-reduce through the C ABI (mhx_comm_*: RCCL over xGMI).
+
+Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel against HBM with the algorithmic bytes of
+DESIGN.md section 7 and the HIP-event launch time measured here; `cpu_baseline` is the CPU oracle (a port of the
 reference algorithm, oracle/) timed on this host on a bounded sample -- rank 0, N=1 only.
 """
 import argparse
@@ -25,52 +28,322 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "advancedmh.jl_amd"))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s achievable)
-VALU_PEAK = 256 * 4 * 2.4e9 / 4.0   # wave64 VALU instructions per second: 16-lane SIMDs, 4 cycles per instruction
-D = 100
-CHAINS = 65536
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s achievable)
+# MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32 units, a wave64 VALU instruction issues over 2 cycles at 2.4 GHz (measured:
+# profiles/r02a_valu_rates.log -- v_fma_f32 1.10 ns per instruction per SIMD at 8 waves; v_fma_f64 is 4 cycles, v_mad_u64_u32
+# ~5, v_rcp_f64 / v_sqrt_f64 ~16).  The issue peak below is the 2-cycle one for every instruction class.
+VALU_PEAK = 256 * 4 * 2.4e9 / 2.0
 VARIANTS = {0: "generic", 1: "prebuilt-register", 2: "hiprtc-register", 3: "prebuilt-cooperative",
-            4: "hiprtc-cooperative", 5: "hiprtc-dense-cooperative"}
+            4: "hiprtc-cooperative", 5: "hiprtc-dense-cooperative", 6: "persistent-ensemble"}
+RB = {"f32": 4, "f64": 8}
 
 
-def algorithmic_bytes_per_launch(d, chains, inner):
-    """sample record 4(d+1)+1 B per chain-step (save-all) + one state
-    round trip per launch (read x, lp, accept count, last flag; write them back)."""
-    record = 4 * (d + 1) + 1
-    state = 2 * (4 * d + 4 + 4 + 1)
-    return chains * (inner * record + state)
-
-
-def cpu_baseline(d, inner, seed, target_seconds=10.0):
-    """The oracle (same algorithm, same Philox streams, scalar loop per chain) on all host cores:
-    chains statically partitioned over threads (the MCMCThreads analogue).  Bounded sample."""
-    import concurrent.futures as cf
+def sigma_ar1(d, rho):
     import numpy as np
-    from oracle import oracle as O
-    O.build()
-    s = float(np.float32(2.38 / d ** 0.5))
-    cores = os.cpu_count() or 1
-    tgt = O.iso_gauss(d)
+    i = np.arange(d)
+    return rho ** np.abs(i[:, None] - i[None, :])
 
-    def work(first, n, steps):
-        O.rwmh(tgt, O.Proposal(O.PROP_ISO, s), O.schedule(steps + 1), seed, first, n, save=True)
 
-    def pool(per_thread, steps):
+def sigma_illcond(d, kappa=1e3, seed=7):
+    """Sigma = Q diag(lambda) Q^T, lambda_i = kappa^((i-1)/(d-1)), Q = QR of a seeded Gaussian matrix"""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    Q, _ = np.linalg.qr(rng.normal(size=(d, d)))
+    lam = kappa ** (np.arange(d) / (d - 1.0))
+    return (Q * lam) @ Q.T
+
+
+def threads_rate(work, cores, target_seconds):
+    """work(thread_index, nchains) on `cores` threads, chains per thread sized to ~target_seconds of wall time;
+    returns (chains in total, seconds)"""
+    import concurrent.futures as cf
+
+    def pool(n):
         t0 = time.perf_counter()
         with cf.ThreadPoolExecutor(cores) as ex:
-            list(ex.map(lambda i: work(i * per_thread, per_thread, steps), range(cores)))
+            list(ex.map(lambda i: work(i, n), range(cores)))
         return time.perf_counter() - t0
 
+    pool(1)                                                  # thread start-up, page faults
+    t1 = pool(2)                                             # calibration: 2 chains per thread
+    n = max(2, int(2 * target_seconds / t1))
+    return cores * n, pool(n)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# workloads: each builds a Run for this rank and says what one step is, what it moves and how the CPU oracle does it
+
+
+class C2:
+    """BASELINE configs[1]: isotropic 100-dim standard MvNormal, RWMH, 65 536 chains per GPU, every state recorded"""
+    name = "c2"
+
+    def __init__(self, args, dtype):
+        self.d, self.C, self.inner, self.dtype = args.dim or 100, args.chains or 65536, args.inner or 250, dtype
+        self.lanes = args.lanes
+
+    def build(self, mhx, ctx, rank):
+        import numpy as np
+        d = self.d
+        self.s = float(np.float32(2.38 / d ** 0.5))
+        model = mhx.DensityModel(mhx.IsoGaussian(d))
+        spl = mhx.RWMH(mhx.MvNormal(mhx.zeros(d), self.s * self.s * mhx.I))
+        self.run = mhx.Run(model, spl, nchains=self.C, seed=0xC0FFEE, first_chain=rank * self.C, ctx=ctx, reduce_lanes=self.lanes)
+        self.run.init(None)                                # x0 ~ proposal draw (src/mh-core.jl:83), on the device
+        return self.run
+
+    def step(self):
+        # N = inner saved samples, the first one being the state after 1 transition: inner transitions
+        self.run.sample(self.inner, 1, 1, 0, save=True)
+        return self.run.stats()
+
+    def units_per_step(self):
+        return self.C * self.inner
+
+    def bytes_per_launch(self):
+        """sample record B(d+1)+1 per chain-step (save-all) + one state round trip per launch"""
+        B = RB[self.dtype]
+        return self.C * (self.inner * (B * (self.d + 1) + 1) + 2 * (B * self.d + B + 4 + 1))
+
+    def bytes_model(self):
+        return "record %d(d+1)+1 B per chain-step + state round trip per launch" % RB[self.dtype]
+
+    def describe(self):
+        return ("RWMH, isotropic %d-dim standard MvNormal target, %d chains per GPU, proposal N(0,(2.38/sqrt(d))^2 I), "
+                "%d transitions per launch, every state recorded" % (self.d, self.C, self.inner))
+
+    def cpu_baseline(self, O, target_seconds):
+        tgt = O.iso_gauss(self.d)
+        prop = O.Proposal(O.PROP_ISO, self.s)
+        inner = self.inner
+
+        def work(i, nchains):
+            O.rwmh(tgt, prop, O.schedule(inner + 1), 0xC0FFEE, i * nchains, nchains, save=True)
+        t0 = time.perf_counter()
+        O.rwmh(tgt, prop, O.schedule(101), 0xC0FFEE, 0, 8, save=True)
+        rate1 = 800 / (time.perf_counter() - t0)
+        cores = os.cpu_count() or 1
+        n, dt = threads_rate(work, cores, target_seconds)
+        return n * inner, dt, cores, "%d chains x %d transitions of the same d=%d workload; single thread %.3g steps/s" % (n, inner, self.d, rate1)
+
+
+class C5(C2):
+    """BASELINE configs[4], one GPU's shard: 1000-dim Neal's funnel, RWMH, 32 768 chains per GPU (262 144 over 8), no sample
+    tensor -- running moments of every 10th state for the R-hat reduction"""
+    name = "c5"
+
+    def __init__(self, args, dtype):
+        self.d, self.C, self.inner, self.dtype = args.dim or 1000, args.chains or 32768, args.inner or 200, dtype
+        self.lanes = args.lanes
+
+    def build(self, mhx, ctx, rank):
+        import numpy as np
+        d = self.d
+        self.s = float(np.float32(2.38 / d ** 0.5))
+        spl = mhx.RWMH(mhx.MvNormal(mhx.zeros(d), self.s * self.s * mhx.I))
+        self.run = mhx.Run(mhx.DensityModel(mhx.Funnel(d)), spl, nchains=self.C, seed=5, first_chain=rank * self.C, ctx=ctx,
+                           reduce_lanes=self.lanes)
+        self.run.init(None)
+        return self.run
+
+    def step(self):
+        self.run.sample(self.inner // 10, 10, 10, 0, save="moments")     # every 10th state folded into the moments
+        return self.run.stats()
+
+    def bytes_per_launch(self):
+        """the state lives in registers for a launch: HBM sees one state round trip and one moments round trip per launch"""
+        B = RB[self.dtype]
+        return self.C * (2 * (B * self.d + B + 4 + 1) + 4 * B * (self.d + 1))
+
+    def bytes_model(self):
+        return "state + running-moments round trip per launch (the chain state never leaves the registers inside a launch)"
+
+    def describe(self):
+        return ("RWMH, 1000-dim Neal's funnel, %d chains per GPU (global ids: shard of 8 x 32 768), proposal N(0,(2.38/sqrt(d))^2 I), "
+                "%d transitions per launch, running moments of every 10th state, R-hat by one all-reduce" % (self.C, self.inner))
+
+    def cpu_baseline(self, O, target_seconds):
+        tgt = O.Target(O.TARGET_FUNNEL, self.d)
+        prop = O.Proposal(O.PROP_ISO, self.s)
+        inner = self.inner
+
+        def work(i, nchains):
+            O.rwmh(tgt, prop, O.schedule(1, inner), 5, i * nchains, nchains, save=False)
+        cores = os.cpu_count() or 1
+        n, dt = threads_rate(work, cores, target_seconds)
+        return n * inner, dt, cores, "%d chains x %d transitions of the same d=%d funnel" % (n, inner, self.d)
+
+
+class C3:
+    """BASELINE configs[2]: emcee Ensemble(StretchProposal), 50-dim correlated Gaussian (rho = 0.9), 16 384 walkers"""
+    name = "c3"
+
+    def __init__(self, args, dtype):
+        self.d, self.W, self.inner, self.dtype = args.dim or 50, args.chains or 16384, args.inner or 500, dtype
+        self.lanes = args.lanes
+
+    def build(self, mhx, ctx, rank):
+        d = self.d
+        self.Sig = sigma_ar1(d, 0.9)
+        model = mhx.DensityModel(mhx.CorrGaussian(self.Sig))
+        spl = mhx.Ensemble(self.W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I)))
+        self.run = mhx.Run(model, spl, seed=3, first_chain=rank, ctx=ctx, reduce_lanes=self.lanes)   # one ensemble per GPU (replicas)
+        self.run.init(None)
+        return self.run
+
+    def step(self):
+        self.run.sample(self.inner, 1, 1, 0, save=True)
+        return self.run.stats()
+
+    def units_per_step(self):
+        return self.W * self.inner
+
+    def bytes_per_launch(self):
+        """per move read x_i, x_j, write x_i, lp r/w (3Bd + 2B) + record B(d+1)+1"""
+        B = RB[self.dtype]
+        return self.W * self.inner * (3 * B * self.d + 2 * B + B * (self.d + 1) + 1)
+
+    def bytes_model(self):
+        B = RB[self.dtype]
+        return "per move %d d + %d (x_i, x_j, x_i', lp) + record %d(d+1)+1" % (3 * B, 2 * B, B)
+
+    def describe(self):
+        return ("emcee Ensemble(StretchProposal a=2), %d-dim Gaussian Sigma_ij = 0.9^|i-j|, %d walkers (one ensemble per GPU), "
+                "%d sweeps per launch, every sweep recorded; parallel half-split sweep" % (self.d, self.W, self.inner))
+
+    def cpu_baseline(self, O, target_seconds):
+        import numpy as np
+        tgt = O.corr_gauss_from_cov(self.Sig)
+        W = self.W
+        init = np.random.default_rng(1).normal(size=(self.d, W))
+        t0 = time.perf_counter()
+        O.emcee(tgt, 2.0, 0, O.schedule(3), 3, 0, W, init, save=True)          # mode 0: the reference's sequential sweep
+        rate = 2 * W / (time.perf_counter() - t0)
+        sweeps = max(2, int(rate * target_seconds / W))
+        t0 = time.perf_counter()
+        O.emcee(tgt, 2.0, 0, O.schedule(sweeps + 1), 3, 0, W, init, save=True)
+        dt = time.perf_counter() - t0
+        return W * sweeps, dt, 1, "%d sequential sweeps (src/emcee.jl:39-58: inherently serial in W) of the same %d-walker ensemble, one thread" % (sweeps, W)
+
+
+class C4:
+    """BASELINE configs[3]: RobustAdaptiveMetropolis, 200-dim ill-conditioned Gaussian (kappa = 1e3), 32 768 chains, adapting"""
+    name = "c4"
+
+    def __init__(self, args, dtype):
+        self.d, self.C, self.inner, self.dtype = args.dim or 200, args.chains or 32768, args.inner or 100, dtype
+        self.moving = args.c4_moving
+
+    def build(self, mhx, ctx, rank):
+        import numpy as np
+        d = self.d
+        self.Sig = sigma_illcond(d)
+        model = mhx.DensityModel(mhx.CorrGaussian(self.Sig))
+        S0 = None
+        if self.moving:           # a variant that moves: random start on the target's scale, S0 = 2.38/sqrt(d) I (about 0.17 I)
+            S0 = (2.38 / d ** 0.5) * np.eye(d)
+        self.run = mhx.Run(model, mhx.RobustAdaptiveMetropolis(S=S0), nchains=self.C, seed=4, first_chain=rank * self.C, ctx=ctx)
+        if self.moving:
+            L = np.linalg.cholesky(self.Sig)
+            self.run.init(L @ np.random.default_rng(11).normal(size=(d, self.C)))
+        else:
+            self.run.init(np.zeros(d))                      # SURVEY 8(d): x0 = 0, S0 = I
+        return self.run
+
+    def step(self):
+        self.run.sample(1, self.inner, 1, self.inner, save=False)      # `inner` adapting transitions (step_warmup)
+        return self.run.stats()
+
+    def units_per_step(self):
+        return self.C * self.inner
+
+    def bytes_per_launch(self):
+        """one read + one write of the packed factor per adapting step, B d(d+1) + 2Bd + 2B"""
+        B = RB[self.dtype]
+        return self.C * self.inner * (B * self.d * (self.d + 1) + 2 * B * self.d + 2 * B)
+
+    def bytes_model(self):
+        B = RB[self.dtype]
+        return "per adapting step 1 read + 1 write of the packed factor: %d d(d+1)/2 x 2 + %d d + %d" % (B, 2 * B, 2 * B)
+
+    def describe(self):
+        return ("RobustAdaptiveMetropolis (alpha 0.234, gamma 0.6), %d-dim Gaussian, kappa = 1e3 (Q diag Q^T), %d chains per GPU each "
+                "with its own factor, %d adapting transitions per launch, %s" % (
+                    self.d, self.C, self.inner, "random start, S0 = 2.38/sqrt(d) I (the variant that moves)" if self.moving else "x0 = 0, S0 = I"))
+
+    def cpu_baseline(self, O, target_seconds):
+        import numpy as np
+        tgt = O.corr_gauss_from_cov(self.Sig)
+        inner, d = self.inner, self.d
+        init1 = np.zeros((d, 1))
+
+        def work(i, nchains):
+            O.ram(tgt, O.schedule(1, inner, 1, inner), 4, i * nchains, nchains, init=np.zeros((d, nchains)), save=False)
+        t0 = time.perf_counter()
+        O.ram(tgt, O.schedule(1, 20, 1, 20), 4, 0, 1, init=init1, save=False)
+        rate1 = 20 / (time.perf_counter() - t0)
+        cores = os.cpu_count() or 1
+        n, dt = threads_rate(work, cores, target_seconds)
+        return n * inner, dt, cores, "%d chains x %d adapting transitions of the same d=%d workload; single thread %.3g steps/s" % (n, inner, d, rate1)
+
+
+WORKLOADS = {"c2": C2, "c3": C3, "c4": C4, "c5": C5}
+
+
+def cpu_baseline(wl, dtype, target_seconds=10.0):
+    """The oracle (same algorithm, same Philox streams, scalar loop per chain; gcc -O3) on the host cores: chains
+    statically partitioned over threads (the MCMCThreads analogue).  Bounded sample."""
+    from oracle import oracle as O
+    O.build()
+    O.set_dtype(dtype)
+    units, dt, cores, sample = wl.cpu_baseline(O, target_seconds)
+    return {"value": units / dt, "unit": "MH steps/s", "cores": cores, "kind": "port",
+            "sample": "%s (oracle/mhx_oracle.c in %s, %d thread(s), %.1f s)" % (sample, dtype, cores, dt)}
+
+
+def timed(wl, steps, warmup, barrier):
+    for _ in range(max(0, 30 - warmup)):      # device spin-up (setup): the first ~20 launches after idle run below the steady clock
+        wl.step()
+    for _ in range(warmup):
+        wl.step()
+    barrier()
     t0 = time.perf_counter()
-    work(0, 8, 100)                                   # single-thread rate (the `sample(model, spl, N)` analogue)
-    rate1 = 800 / (time.perf_counter() - t0)
-    rate_all = cores * 8 * 100 / pool(8, 100)         # calibration on all cores
-    per_thread = max(1, int(rate_all * target_seconds / (inner * cores)))
-    dt = pool(per_thread, inner)
-    total = cores * per_thread * inner
-    return {"value": total / dt, "unit": "MH steps/s", "cores": cores, "kind": "port",
-            "sample": "%d chains x %d transitions of the same d=%d workload (oracle/mhx_oracle.c, %d threads, %.1f s); "
-                      "single-thread %.3g steps/s" % (cores * per_thread, inner, d, cores, dt, rate1)}
+    kernel_ms, accepted, transitions, st = 0.0, 0, 0, None
+    for _ in range(steps):
+        st = wl.step()                        # blocking: the stream is synchronised on return
+        kernel_ms += st["kernel_ms"]
+        accepted += st["accepted"]
+        transitions += st["transitions"]
+    barrier()
+    return time.perf_counter() - t0, kernel_ms, accepted, transitions, st
+
+
+def ess_window(mhx, wl, world):
+    """ESS/sec of SURVEY 8(d): rank-normalised bulk ESS (split chains, Geyer truncation) of a THINNED window long enough
+    for the autocorrelations to die out -- 256 draws `thin` transitions apart, thin chosen so that the window spans ~40
+    autocorrelation times (RWMH at the optimal scale: tau ~ d / 0.3; each split half ~20) -- over the wall time of
+    producing that window.  `reached_max_lag`: the multi-chain autocorrelation rho_t = 1 - (W - A_t) / var+ keeps the
+    floor (var+ - W) / var+ of finite chains, so with thousands of chains averaged its pair sums stay positive up to the
+    last lag; the estimate then carries every lag of the window."""
+    import numpy as np
+    d, run = wl.d, wl.run
+    thin = max(1, int(round(40 * (d / 0.3) / 256)))        # each split half spans ~20 autocorrelation times
+    n_draws = 256
+    t0 = time.perf_counter()
+    run.sample(n_draws, thin, thin, 0, save=True)
+    wall = time.perf_counter() - t0
+    st = run.stats()
+    params = sorted(set([0, d // 2, d - 1]))
+    b = run.ess_bulk_tail(params=params, max_lag=n_draws // 2 - 2, ess_chains=512, split=True)
+    dg = run.diagnostics(max_lag=0, split=True)
+    med = float(np.median(b["ess_bulk"]))
+    return {"estimator": "rank-normalised bulk ESS, split chains, Geyer initial monotone sequence (mhx_run_ess_bulk_tail)",
+            "window": "%d draws x %d chains, %d transitions apart (%d transitions per chain)" % (n_draws, run.n, thin, n_draws * thin),
+            "params": [int(p) for p in params], "ess_bulk": [float(v) for v in b["ess_bulk"]],
+            "reached_max_lag": [bool(v) for v in b["bulk_truncated"]],
+            "median": med, "per_transition_per_chain": med / (run.n * n_draws * thin),
+            "wall_s": wall, "kernel_ms": st["kernel_ms"], "rhat_max_split": float(np.nanmax(dg["rhat"][:d])),
+            "ess_per_sec": med / wall}
 
 
 def main():
@@ -78,138 +351,128 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5, help="untimed launches right before the timed ones")
-    ap.add_argument("--inner", type=int, default=250, help="MH transitions per chain per step (launch)")
-    ap.add_argument("--chains", type=int, default=CHAINS, help="chains per GPU")
-    ap.add_argument("--dim", type=int, default=D)
+    ap.add_argument("--config", choices=sorted(WORKLOADS), default="c2", help="BASELINE.json workload (c2 = the headline)")
+    ap.add_argument("--dtype", choices=["f64", "f32"], default="f64", help="arithmetic of the engine (the reference is Float64)")
+    ap.add_argument("--inner", type=int, default=0, help="transitions (sweeps) per chain per step (launch); 0 = the config's default")
+    ap.add_argument("--chains", type=int, default=0, help="chains (walkers) per GPU; 0 = the config's default")
+    ap.add_argument("--dim", type=int, default=0)
     ap.add_argument("--lanes", type=int, default=0, help="lanes per chain (0 = engine's choice)")
+    ap.add_argument("--c4-moving", action="store_true", help="c4: random start and S0 = 2.38/sqrt(d) I instead of x0 = 0, S0 = I")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-second-dtype", action="store_true", help="skip the fp32 figure")
+    ap.add_argument("--no-ess", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1 or os.environ.get("MHX_BENCH_FORCE_DIST"):      # the env knob exercises the RCCL path on 1 GPU
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import numpy as np
+    import torch
     import mhx
+    from mhx.dist import Comm, allreduce_stats
 
-    d, C, inner = args.dim, args.chains, args.inner
-    s = float(np.float32(2.38 / d ** 0.5))
-    ctx = mhx.Context(local_rank)
-    model = mhx.DensityModel(mhx.IsoGaussian(d))
-    spl = mhx.RWMH(mhx.MvNormal(mhx.zeros(d), s * s * mhx.I))
-    run = mhx.Run(model, spl, nchains=C, seed=0xC0FFEE, first_chain=rank * C, ctx=ctx, reduce_lanes=args.lanes)
-    run.init(None)                                    # x0 ~ proposal draw (src/mh-core.jl:83), on the device
+    torch.cuda.set_device(local_rank)
+    ctx = mhx.Context(local_rank, args.dtype)
+    comm = None
+    if world > 1 or os.environ.get("MHX_BENCH_FORCE_DIST"):      # the env knob exercises the RCCL path on 1 GPU
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        comm = Comm.from_env(ctx)
 
-    def step():
-        # N=inner saved samples, the first one being the state after 1 transition: inner transitions
-        run.sample(inner, 1, 1, 0, save=True)
-        return run.stats()
-
-    def sync():
-        if dist is not None:
-            import torch
+    def barrier():
+        torch.cuda.synchronize()
+        if comm is not None:
+            comm.allreduce_sum(np.zeros(1))                      # every rank has arrived
             torch.cuda.synchronize()
-            dist.barrier()
 
-    # device spin-up (setup, like init): the first ~20 launches after an idle period run below the steady clock
-    # (8.0e9 vs 9.2e9 steps/s); bring the GPU there whatever --warmup the caller picked
-    for _ in range(max(0, 30 - args.warmup)):
-        step()
-    for _ in range(args.warmup):
-        step()
-    sync()
-    t0 = time.perf_counter()
-    kernel_ms, accepted, transitions = 0.0, 0, 0
-    for _ in range(args.steps):
-        st = step()                                   # blocking: the stream is synchronised on return
-        kernel_ms += st["kernel_ms"]
-        accepted += st["accepted"]
-        transitions += st["transitions"]
-    sync()
-    dt = time.perf_counter() - t0
+    wl = WORKLOADS[args.config](args, args.dtype)
+    wl.build(mhx, ctx, rank)
+    dt, kernel_ms, accepted, transitions, st = timed(wl, args.steps, args.warmup, barrier)
     variant = st["kernel_variant"]
 
-    # Diagnostics of the LAST launch's sample tensor (outside the timed region): per-shard sums for R-hat
-    # and the between-chain ESS; across GPUs they combine with the one small all-reduce the design has.
-    diag = run.diagnostics(max_lag=0)
-    bulk = None
-    if world == 1:
-        try:                                          # rank-normalised bulk ESS of three parameters (device sort), for reference
-            b = run.ess_bulk_tail(params=[0, d // 2, d - 1], split=True)
-            bulk = {"params": [int(v) for v in b["params"]], "ess_bulk": [float(v) for v in b["ess_bulk"]],
-                    "upper_bound_only": [bool(v) for v in b["bulk_truncated"]],
-                    "note": "split chains, Geyer truncation; 250 draws per chain are shorter than the autocorrelation time, "
-                            "so the sequence is still positive at the last lag and the value is an upper bound -- "
-                            "ess_per_sec uses the between-chain estimator"}
-        except Exception as e:                        # never let a diagnostic break the bench line
-            bulk = {"error": str(e)}
-    if dist is not None:
-        import torch
-        from mhx.dist import allreduce_stats
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        diag = allreduce_stats(diag, accepted, transitions, device=torch.device("cuda", local_rank))   # RCCL over xGMI
-        acc_rate = diag["acceptance_rate"]
+    # outside the timed region: diagnostics, the ESS window, the fp32 figure, the CPU baseline
+    ess, diag = None, None
+    if args.config in ("c2", "c5"):
+        diag = wl.run.diagnostics(max_lag=0)
+    if comm is not None:
+        t = np.zeros(world)
+        t[rank] = dt
+        dt = float(comm.allreduce_sum(t).max())                  # MAX over ranks of the timed region
+        if diag is not None:
+            diag = allreduce_stats(diag, accepted, transitions, comm=comm)       # ONE all-reduce: RCCL over xGMI through the C ABI
+            acc_rate = diag["acceptance_rate"]
+        else:
+            v = comm.allreduce_sum(np.array([float(accepted), float(transitions)]))
+            acc_rate = v[0] / v[1]
     else:
         acc_rate = accepted / float(transitions)
+    if args.config == "c2" and not args.no_ess and rank == 0:
+        try:
+            ess = ess_window(mhx, wl, world)
+        except Exception as e:                                   # never let a diagnostic break the bench line
+            ess = {"error": str(e)}
 
     if rank == 0:
-        total_steps = float(C) * inner * args.steps * world
-        value = total_steps / dt
+        units = float(wl.units_per_step()) * args.steps * world
+        value = units / dt
+        launches = max(1, st["launches"])
         launch_s = kernel_ms * 1e-3 / args.steps
-        bytes_launch = algorithmic_bytes_per_launch(d, C, inner)
+        bytes_launch = wl.bytes_per_launch()
         achieved = bytes_launch / launch_s / 1e9
         traffic, valu = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        key = "%s_%s" % (args.config, args.dtype)
         if os.path.exists(tpath):
             try:
-                tj = json.load(open(tpath)).get("rwmh_d%d_c%d_inner%d" % (d, C, inner), {})
-                traffic = tj.get("hbm_bytes_per_launch")
-                if tj.get("valu_insts_per_launch"):
-                    # what actually bounds the kernel: wave-instructions (PMC SQ_INSTS_VALU) per second against
-                    # 256 CUs x 4 SIMDs x one wave64 VALU instruction per 4 cycles at 2.4 GHz
-                    rate = tj["valu_insts_per_launch"] / launch_s
-                    valu = {"wave_insts_per_launch": tj["valu_insts_per_launch"], "achieved_per_s": rate,
-                            "peak_per_s": VALU_PEAK, "frac": rate / VALU_PEAK}
+                tj = json.load(open(tpath)).get(key, {})
+                if tj.get("units_per_launch") == wl.units_per_step():
+                    traffic = tj.get("hbm_bytes_per_launch")
+                    if tj.get("valu_insts_per_launch"):
+                        rate = tj["valu_insts_per_launch"] / launch_s
+                        valu = {"wave_insts_per_launch": tj["valu_insts_per_launch"], "achieved_per_s": rate, "peak_per_s": VALU_PEAK,
+                                "frac": rate / VALU_PEAK, "source": tj.get("source"),
+                                "note": "wave64 VALU instructions (PMC SQ_INSTS_VALU) per second against 1024 SIMDs x one instruction "
+                                        "per 2 cycles at 2.4 GHz; the fp64 / 64-bit-multiply / transcendental instructions of the mix "
+                                        "take 4-16 cycles each, so 1.0 is not reachable by this instruction mix"}
             except Exception:
                 traffic, valu = None, None
-        essb = np.asarray(diag["ess_between"][:d], dtype=np.float64)
         out = {
             "metric": "MH steps/sec (all chains) + ESS/sec", "value": value, "unit": "MH steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "RWMH, isotropic %d-dim standard MvNormal target, %d chains per GPU, proposal "
-                                   "N(0,(2.38/sqrt(d))^2 I), %d transitions per launch, every state recorded" % (d, C, inner),
-                       "chains_per_gpu": C, "dim": d, "transitions_per_step": inner,
-                       "kernel_variant": VARIANTS[variant], "lanes_per_chain": st["reduce_lanes"],
-                       "sharding": "chains by global id, no data-path collective"},
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": wl.describe(), "name": args.config, "units_per_step_per_gpu": wl.units_per_step(),
+                       "kernel_variant": VARIANTS.get(variant, str(variant)), "lanes_per_unit": st["reduce_lanes"],
+                       "launches_per_step": launches,
+                       "sharding": "chains by global id, no data-path collective" if args.config != "c3" else "one ensemble per GPU (replicas)"},
             "acceptance_rate": acc_rate,
-            # ESS/sec: total effective sample size of ONE step's draws (median over the d parameters; between-chain
-            # estimator C * var+ / Var_c(chain means), include/mhx.h) divided by the wall time of one step
-            "ess_per_sec": float(np.median(essb)) / (dt / args.steps),
-            "ess": {"estimator": "between-chain, last step's %d draws x %d chains" % (inner, C * world),
-                    "median": float(np.median(essb)), "min": float(essb.min()),
-                    "rhat_max": float(np.max(diag["rhat"][:d])), "bulk": bulk},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_rwmh_coop<2,13,iso,iso>" if variant == 3 else "rwmh variant %d" % variant,
-                         "avg_launch_ms": launch_s * 1e3, "algorithmic_bytes_per_launch": bytes_launch,
-                         "valu": valu,
-                         "note": "VALU-issue-bound kernel (Philox4x32-10 + Box-Muller polynomials, 64 wave-instructions "
-                                 "per chain-step, PMC SQ_INSTS_VALU); HBM sees only the sample records"},
+                         "avg_launch_ms": launch_s * 1e3 / launches, "kernel_ms_per_step": launch_s * 1e3,
+                         "algorithmic_bytes_per_step": bytes_launch, "bytes_model": wl.bytes_model(), "valu": valu},
         }
+        if ess is not None:
+            out["ess_per_sec"] = ess.get("ess_per_sec")
+            out["ess"] = ess
+        if diag is not None:
+            out["rhat_max"] = float(np.nanmax(diag["rhat"][:wl.d]))
+        if world == 1 and not args.no_second_dtype and args.dtype == "f64":
+            try:                                                  # the same workload on the fp32 engine: a second figure, never `value`
+                ctx32 = mhx.Context(local_rank, "f32")
+                wl32 = WORKLOADS[args.config](args, "f32")
+                wl32.build(mhx, ctx32, rank)
+                n32 = max(5, args.steps // 2)
+                dt32, k32, a32, t32, st32 = timed(wl32, n32, 2, barrier)
+                out["f32"] = {"value": wl32.units_per_step() * n32 / dt32, "unit": "MH steps/s", "ms_per_step": dt32 * 1e3 / n32,
+                              "acceptance_rate": a32 / float(t32), "lanes_per_unit": st32["reduce_lanes"],
+                              "roofline_frac_hbm": wl32.bytes_per_launch() / (k32 * 1e-3 / n32) / 1e9 / HBM_PEAK_GBS,
+                              "note": "same engine compiled with mhx_real = float: half the bytes; not the reference's arithmetic"}
+                wl32.run.close()
+            except Exception as e:
+                out["f32"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(d, inner, 0xC0FFEE)
+            out["cpu_baseline"] = cpu_baseline(wl, args.dtype)
         # RCCL writes its version banner to the C stdout buffer: push it out first so the JSON line is the last one
         sys.stdout.flush()
         try:
@@ -218,8 +481,9 @@ def main():
         except Exception:
             pass
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    if comm is not None:
+        barrier()
+        comm.close()
 
 
 if __name__ == "__main__":

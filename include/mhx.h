@@ -121,6 +121,9 @@ typedef struct {
 
 #define MHX_FLAG_NO_JIT 1 /* never specialise with hiprtc; use the pre-built kernels only */
 #define MHX_FLAG_GENERIC 2 /* force the generic (state-in-HBM) kernel even when a register kernel exists */
+#define MHX_FLAG_EMCEE_SEQUENTIAL 8 /* Ensemble runs only: the reference's sweep (src/emcee.jl:39-58) -- walkers move one after
+                                      another and pair with already-updated walkers (Gauss-Seidel), one wavefront, for
+                                      fidelity checks at the reference's test sizes; the default is the parallel half-split */
 #define MHX_FLAG_STATIC_PROPOSAL 4 /* RWMH runs only: the proposal is a StaticProposal (src/proposal.jl:9-11,66-83) --
                                       the candidate is a draw mean + L z that ignores the current state (independence
                                       sampler) and the ratio is logpdf(p, x) - logpdf(p, y) */
@@ -137,8 +140,15 @@ typedef struct {
     uint64_t seed;
     uint64_t ensemble_id;
     double stretch;          /* a = 2.0 */
-    int32_t flags;
+    int32_t flags;          /* MHX_FLAG_*; MHX_FLAG_EMCEE_SEQUENTIAL selects the reference's own sweep */
     int32_t reduce_lanes;   /* lanes per walker (dense-Gaussian target): 0 = engine's choice, 1 = one lane per walker */
+    /* the distribution StretchProposal wraps (src/emcee.jl:63-68), used ONLY for the initial walkers (:29-34: W draws
+     * from it): a (Mv)Normal  mu + L z  drawn on the device by mhx_run_init(run, NULL).  init_kind < 0: none given --
+     * mhx_run_init then requires the walkers (any other prior is drawn by the host). */
+    int32_t init_kind;      /* mhx_proposal_kind, or -1 */
+    double init_scale;      /* ISO: sigma */
+    const void *init_vec;   /* DIAG: sigma_k [dim]; DENSE: chol(Sigma) packed lower [dim(dim+1)/2] */
+    const void *init_mean;  /* mu [dim] or NULL */
 } mhx_emcee_cfg;
 
 int mhx_emcee_create(mhx_ctx *ctx, const mhx_target *t, const mhx_emcee_cfg *cfg, mhx_run **out);
@@ -160,6 +170,8 @@ typedef struct {
 int mhx_ram_create(mhx_ctx *ctx, const mhx_target *t, const mhx_ram_cfg *cfg, mhx_run **out);
 /* in/out Cholesky factors, [nchains][dim(dim+1)/2]; S == NULL on set means identity */
 int mhx_ram_set_factor(mhx_run *run, const void *S);
+/* the same factor for every chain (RobustAdaptiveMetropolis(S = ...), :198-206): S [dim(dim+1)/2] */
+int mhx_ram_set_factor_all(mhx_run *run, const void *S);
 int mhx_ram_get_factor(mhx_run *run, void *S, uint8_t *status /* [nchains] or NULL */);
 /* running min / max of diag(S) over every adapted state so far, [dim][nchains] each */
 int mhx_ram_get_diag_range(mhx_run *run, void *diag_min, void *diag_max);
@@ -190,7 +202,7 @@ int mhx_mala_create(mhx_ctx *ctx, const mhx_target *t, const mhx_mala_cfg *cfg, 
 /* ---------------------------------------------------------------------------------------------
  * Running chains.  mhx_run_init == the initial AbstractMCMC.step (src/mh-core.jl:76-86,
  * src/emcee.jl:29-34, src/RobustAdaptiveMetropolis.jl:175-214): x0 = initial_params if given, else
- * a draw (RWMH: from the proposal; RAM: randn(d); Ensemble: initial walkers are required).
+ * a draw (RWMH: from the proposal; RAM: randn(d); Ensemble: W draws from the (Mv)Normal of cfg.init_*, else required).
  * mhx_run_sample == the mcmcsample loop + bundle_samples into the device sample buffer.  It may be
  * called repeatedly; each call continues the chains (counter-based RNG => resumable). */
 int mhx_run_init(mhx_run *run, const void *initial_params /* host [dim][nchains] or NULL */);
@@ -226,7 +238,8 @@ typedef struct {
     double wall_ms;            /* host wall time of the call                                            */
     int32_t kernel_variant;    /* 0 generic (HBM state), 1 pre-built register kernel, 2 hiprtc-specialised register
                                   kernel, 3 pre-built cooperative kernel, 4 hiprtc-specialised cooperative kernel,
-                                  5 hiprtc-specialised cooperative kernel for the dense Gaussian target (RWMH) */
+                                  5 hiprtc-specialised cooperative kernel for the dense Gaussian target (RWMH),
+                                  7 the reference's sequential ensemble sweep (MHX_FLAG_EMCEE_SEQUENTIAL) */
     int32_t launches;
     int32_t reduce_lanes;      /* lanes per chain in effect (1 unless a cooperative kernel runs) */
     int32_t dtype;             /* mhx_dtype of the run's context */

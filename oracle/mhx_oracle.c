@@ -714,11 +714,11 @@ static int stretch_move(const orc_target *t, real a, uint64_t seed, uint64_t ens
 
 int orc_emcee(const orc_target *t, real a, int mode, const orc_schedule *s,
               uint64_t seed, uint64_t ensemble_id, int nwalkers,
-              const real *init, real *samples, uint8_t *accepted,
+              const real *init, const orc_proposal *prior, real *samples, uint8_t *accepted,
               real *final_x, real *final_lp, uint32_t *accept_counts)
 {
     const int d = t->dim, W = nwalkers;
-    if (!init || W < 2) return -1;
+    if ((!init && !prior) || W < 2) return -1;
     int64_t nT, nA;
     orc_schedule_counts(s, &nT, &nA);
     real *cur = malloc(sizeof(real) * (size_t)d * W);
@@ -728,7 +728,28 @@ int orc_emcee(const orc_target *t, real a, int mode, const orc_schedule *s,
     uint8_t *acc = malloc((size_t)W);
     real *tmp = malloc(sizeof(real) * (size_t)d * 3);
     real *xi = tmp, *y = tmp + d, *xj = tmp + 2 * d;
-    memcpy(cur, init, sizeof(real) * (size_t)d * W);
+    if (init) memcpy(cur, init, sizeof(real) * (size_t)d * W);
+    else {
+        /* emcee.jl:29-34: the initial walkers are W draws from the wrapped prior -- here a (Mv)Normal mu + L z
+         * [upstream Distributions rand(MvNormal), restated], z from stream INIT of (ensemble, walker) */
+        const real *mu = prior->mean;
+        for (int i = 0; i < W; ++i) {
+            orc_normals(seed, (ensemble_id << 32) | (uint32_t)i, 0, ORC_STREAM_INIT, d, y);
+            size_t off = 0;
+            for (int k = 0; k < d; ++k) {
+                if (prior->kind == ORC_PROP_DENSE) {
+                    real w = R(0.0);
+                    for (int j = 0; j <= k; ++j) w = FMA(prior->vec[off + j], y[j], w);
+                    off += (size_t)k + 1;
+                    xi[k] = mu ? mu[k] + w : w;
+                } else {
+                    const real sc = prior->kind == ORC_PROP_ISO ? prior->scale : prior->vec[k];
+                    xi[k] = mu ? FMA(sc, y[k], mu[k]) : FMA(sc, y[k], R(0.0));
+                }
+            }
+            for (int k = 0; k < d; ++k) cur[(size_t)k * W + i] = xi[k];
+        }
+    }
     for (int i = 0; i < W; ++i) {                       /* emcee.jl:6-8: W log-density evaluations */
         for (int k = 0; k < d; ++k) xi[k] = cur[(size_t)k * W + i];
         lp[i] = orc_target_eval(t, xi);

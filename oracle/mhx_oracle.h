@@ -124,7 +124,8 @@ int orc_rwmh(const orc_target *t, const orc_proposal *p, const orc_schedule *s,
  * (src/emcee.jl:39-58), mode 1 = parallel half-split (what the HIP kernel runs). */
 int orc_emcee(const orc_target *t, real a, int mode, const orc_schedule *s,
               uint64_t seed, uint64_t ensemble_id, int nwalkers,
-              const real *init /* [d][W], required */, real *samples, uint8_t *accepted,
+              const real *init /* [d][W], or NULL: W draws from `prior` (src/emcee.jl:29-34) */,
+              const orc_proposal *prior /* the (Mv)Normal StretchProposal wraps, or NULL */, real *samples, uint8_t *accepted,
               real *final_x, real *final_lp, uint32_t *accept_counts);
 
 typedef struct {

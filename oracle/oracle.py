@@ -283,18 +283,20 @@ def rwmh(target, prop, sched, seed, first_chain, nchains, init=None, save=True):
     return dict(samples=samples, accepted=accepted, final_x=fx, final_lp=flp, accept_counts=cnt)
 
 
-def emcee(target, a, mode, sched, seed, ensemble_id, nwalkers, init, save=True):
+def emcee(target, a, mode, sched, seed, ensemble_id, nwalkers, init, save=True, prior=None):
+    """init [d][W], or None with `prior` (a Proposal: the (Mv)Normal the StretchProposal wraps): W draws from it"""
     d, N, W = target.dim, sched.n_samples, nwalkers
     samples = np.empty((N, d + 1, W), dtype=real()) if save else None
     accepted = np.empty((N, W), dtype=np.uint8) if save else None
     fx = np.empty((d, W), dtype=real())
     flp = np.empty(W, dtype=real())
     cnt = np.empty(W, dtype=np.uint32)
-    init = np.ascontiguousarray(init, dtype=real())
-    assert init.shape == (d, W)
+    if init is not None:
+        init = np.ascontiguousarray(init, dtype=real())
+        assert init.shape == (d, W)
     rc = lib().orc_emcee(C.byref(target.c), _creal()(a), mode, C.byref(sched), C.c_uint64(seed),
-                         C.c_uint64(ensemble_id), W, _fp(init), _fp(samples), _u8p(accepted), _fp(fx),
-                         _fp(flp), _u32p(cnt))
+                         C.c_uint64(ensemble_id), W, _fp(init), C.byref(prior.c) if prior is not None else None, _fp(samples),
+                         _u8p(accepted), _fp(fx), _fp(flp), _u32p(cnt))
     assert rc == 0
     return dict(samples=samples, accepted=accepted, final_x=fx, final_lp=flp, accept_counts=cnt)
 

@@ -69,6 +69,79 @@ def test_emcee_continued_call_records_the_live_state(mhx, oracle, lanes, real):
     run.close()
 
 
+@pytest.mark.parametrize("prior", ["iso", "diag_mean", "dense", "normals"])
+@pytest.mark.parametrize("mode", ["split", "sequential"])
+def test_emcee_initial_walkers_are_drawn_on_the_device(mhx, oracle, prior, mode, real):
+    """src/emcee.jl:29-34: without initial_params the walkers are W draws from the distribution StretchProposal wraps.  A
+    (Mv)Normal / vector-of-Normals prior is drawn by mhx_run_init(run, NULL) from Philox stream INIT -- the oracle draws the
+    same walkers -- and both sweeps continue from them bit for bit."""
+    d, W, N = 6, 50, 7
+    rng = np.random.default_rng(3)
+    Sig = cases.sigma_ar1(d, 0.8)
+    if prior == "iso":
+        s = float(np.float32(1.5))
+        dist, op = mhx.MvNormal(mhx.zeros(d), s * s * mhx.I), oracle.Proposal(oracle.PROP_ISO, s)
+    elif prior == "diag_mean":
+        sv = (0.5 + rng.random(d)).astype(np.float32).astype(np.float64)
+        mu = rng.normal(size=d).astype(np.float32).astype(np.float64)
+        dist, op = mhx.MvNormal(mu, sv ** 2), oracle.Proposal(oracle.PROP_DIAG, vec=sv, mean=mu)
+    elif prior == "dense":
+        Sp = 0.7 * cases.sigma_ar1(d, 0.3)
+        dist, op = mhx.MvNormal(mhx.zeros(d), Sp), oracle.Proposal(oracle.PROP_DENSE, vec=oracle.pack_lower(np.linalg.cholesky(Sp)))
+    else:
+        sv = np.array([2.0, 0.5, 1.0, 1.5, 0.25, 3.0])
+        dist, op = [mhx.Normal(0.0, float(v)) for v in sv], oracle.Proposal(oracle.PROP_DIAG, vec=sv)
+    model = mhx.DensityModel(mhx.CorrGaussian(Sig))
+    spl = mhx.Ensemble(W, mhx.StretchProposal(dist))
+    seq = mode == "sequential"
+    chain = mhx.sample(model, spl, N, seed=9, first_chain=4, reduce_lanes=1, flags=mhx.FLAG_EMCEE_SEQUENTIAL if seq else 0)
+    ref = oracle.emcee(oracle.corr_gauss_from_cov(Sig), 2.0, 0 if seq else 1, oracle.schedule(N), 9, 4, W, None, prior=op)
+    _same(chain.value, ref["samples"], "samples (slot 0 = the drawn walkers)")
+    _same(chain.accepted, ref["accepted"], "accepted")
+    assert np.abs(chain.value[0, :d, :]).max() > 0.1
+
+
+@pytest.mark.parametrize("d,W,N,user", [(3, 10, 16, False), (2, 37, 9, True), (50, 24, 5, False), (7, 130, 6, True)])
+def test_emcee_reference_sequential_sweep_bit_exact(mhx, oracle, d, W, N, user, real):
+    """MHX_FLAG_EMCEE_SEQUENTIAL: the reference's own sweep (src/emcee.jl:39-58 -- walkers one after another, partner
+    mod1(i + r, W), the already-updated position when idx < i) on the device, bit for bit against the oracle's mode 0,
+    catalogue and user log-densities, recorded with discard and thinning, continued calls."""
+    Sig = cases.sigma_ar1(d, 0.9)
+    init = cases.emcee_init(d, W, 5)
+    if user:
+        rng = np.random.default_rng(d)
+        data = np.concatenate([rng.normal(size=d), 0.5 + rng.random(d)]).astype(np.float32)
+        model = mhx.DensityModel(mhx.HipLogDensity(user_targets.SHIFTED_GAUSS, d, data=data))
+        ot = user_targets.host_target(oracle, user_targets.SHIFTED_GAUSS, d, data=data)
+    else:
+        model, ot = mhx.DensityModel(mhx.CorrGaussian(Sig)), oracle.corr_gauss_from_cov(Sig)
+    spl = mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I)))
+    chain = mhx.sample(model, spl, N, seed=21, first_chain=3, initial_params=init, discard_initial=2, thinning=3,
+                       flags=mhx.FLAG_EMCEE_SEQUENTIAL)
+    assert chain.stats["kernel_variant"] == 7 and chain.stats["launches"] == 1
+    ref = oracle.emcee(ot, 2.0, 0, oracle.schedule(N, 2, 3), 21, 3, W, init)
+    _same(chain.value, ref["samples"], "samples")
+    _same(chain.accepted, ref["accepted"], "accepted")
+    x, lp, cnt = chain.state.state()
+    _same(x, ref["final_x"], "final x")
+    _same(lp, ref["final_lp"], "final lp")
+    _same(cnt, ref["accept_counts"], "accept counts")
+    # a different Markov kernel from the parallel half-split: the traces differ
+    split = mhx.sample(model, spl, N, seed=21, first_chain=3, initial_params=init, discard_initial=2, thinning=3)
+    assert not np.array_equal(split.value, chain.value)
+
+
+def test_emcee_reference_sweep_known_answer(mhx, real):
+    """test/emcee.jl:16-42 at the reference's own sizes (1000 walkers, 1000 sweeps) with the reference's own sweep on the
+    device: E[s] = 49/24, E[m] = 7/6 (atol 0.1), and `range == 26:4:...` for discard_initial = 25, thinning = 4."""
+    model = mhx.DensityModel(mhx.HipLogDensity(user_targets.NIG_UNTRANSFORMED, 2))
+    spl = mhx.Ensemble(1000, mhx.StretchProposal([mhx.InverseGamma(2, 3), mhx.Normal(0, 1)]))
+    chain = mhx.sample(model, spl, 1000, seed=100, param_names=["s", "m"], flags=mhx.FLAG_EMCEE_SEQUENTIAL)
+    assert abs(chain.mean("s") - 49 / 24) < 0.1 and abs(chain.mean("m") - 7 / 6) < 0.1
+    chain = mhx.sample(model, spl, 50, seed=100, param_names=["s", "m"], discard_initial=25, thinning=4, flags=mhx.FLAG_EMCEE_SEQUENTIAL)
+    assert chain.range() == range(26, 26 + 4 * 50, 4)
+
+
 def test_emcee_golden_trace(mhx, real):
     tr = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "traces64.npz" if real == "f64" else "traces.npz"))
     d, W = 3, 10

@@ -30,7 +30,7 @@ def test_iso_gauss_rwmh_bit_exact(mhx, oracle, d, C, N, flags_name, lanes, real)
     flags = mhx.FLAG_GENERIC if flags_name == "generic" else 0
     if lanes > 1 and lanes > (d + 3) // 4:
         pytest.skip("more lanes than Philox blocks")
-    if lanes > 1 and -(-((d + 3) // 4) // lanes) > (8 if real == "f64" else 16):
+    if lanes > 1 and -(-((d + 3) // 4) // lanes) > (13 if real == "f64" else 16):
         pytest.skip("more blocks per lane than the cooperative kernel holds in registers")
     seed = 0xC0FFEE + d
     model = mhx.DensityModel(mhx.IsoGaussian(d))
