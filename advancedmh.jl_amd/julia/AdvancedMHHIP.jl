@@ -1,4 +1,4 @@
-# AdvancedMHHIP.jl -- thin `ccall` layer over libmhx.so (include/mhx.h) that plugs the MI355X engine
+# AdvancedMHHIP.jl -- thin `ccall` layer over libmhx.so (include/mhx.h, ABI 0.2) that plugs the MI355X engine
 # into AdvancedMH.jl through AbstractMCMC's ensemble dispatch:
 #
 #     chain = sample(model, RWMH(MvNormal(zeros(100), 0.0566I)), MCMCHIP(), 1_000, 65_536;
@@ -6,6 +6,7 @@
 #
 # One `ccall` sequence runs all chains x all steps on the GPU and returns the
 # (iterations, params..., lp, chains) tensor that ext/AdvancedMHMCMCChainsExt.jl:96-118 wraps.
+# The engine computes in Float64 by default -- the reference's arithmetic -- or in Float32 (`MCMCHIP(T = Float32)`).
 #
 # STATUS: written against include/mhx.h and reviewed by hand; neither this container nor the GPU
 # box has a `julia` binary, so this file has never been executed (DESIGN.md section 2).  The
@@ -27,21 +28,29 @@ function check(rc::Cint)
     error("libmhx error $rc: $msg")
 end
 
-# --- plain C structs of include/mhx.h ------------------------------------------------------------
+# --- plain C structs of include/mhx.h (scalars travel as double; real buffers are void* of the context's dtype) ---
 struct Schedule
     n_samples::Int32; discard_initial::Int32; thinning::Int32; num_warmup::Int32
 end
 struct RwmhCfg
     dim::Int32; nchains::Int32; seed::UInt64; first_chain::UInt64
-    proposal_kind::Int32; proposal_scale::Cfloat; proposal_vec::Ptr{Cfloat}; flags::Int32
-    proposal_mean::Ptr{Cfloat}; reduce_lanes::Int32
+    proposal_kind::Int32; proposal_scale::Cdouble; proposal_vec::Ptr{Cvoid}; flags::Int32
+    proposal_mean::Ptr{Cvoid}; reduce_lanes::Int32
 end
 struct EmceeCfg
-    dim::Int32; nwalkers::Int32; seed::UInt64; ensemble_id::UInt64; stretch::Cfloat; flags::Int32; reduce_lanes::Int32
+    dim::Int32; nwalkers::Int32; seed::UInt64; ensemble_id::UInt64; stretch::Cdouble; flags::Int32; reduce_lanes::Int32
+    init_kind::Int32; init_scale::Cdouble; init_vec::Ptr{Cvoid}; init_mean::Ptr{Cvoid}
 end
 struct MalaCfg
-    dim::Int32; nchains::Int32; seed::UInt64; first_chain::UInt64; sigma2::Cfloat; flags::Int32
+    dim::Int32; nchains::Int32; seed::UInt64; first_chain::UInt64; sigma2::Cdouble; flags::Int32
 end
+struct RamCfg
+    dim::Int32; nchains::Int32; seed::UInt64; first_chain::UInt64
+    alpha::Cdouble; gamma::Cdouble; eig_lo::Cdouble; eig_hi::Cdouble; flags::Int32
+end
+const MHX_FLAG_STATIC_PROPOSAL = Int32(4)
+const MHX_FLAG_EMCEE_SEQUENTIAL = Int32(8)
+
 """
     LangevinProposal(σ²)
 
@@ -50,63 +59,72 @@ dispatches to the device; a general closure keeps running on the CPU path.
 """
 struct LangevinProposal; sigma2::Float64; end
 (p::LangevinProposal)(g) = MvNormal((p.sigma2 / 2) .* g, p.sigma2 * I)
-struct RamCfg
-    dim::Int32; nchains::Int32; seed::UInt64; first_chain::UInt64
-    alpha::Cfloat; gamma::Cfloat; eig_lo::Cfloat; eig_hi::Cfloat; flags::Int32
-end
 
 # --- the ensemble tag AbstractMCMC dispatches on -------------------------------------------------
 """
-    MCMCHIP(; device = 0, first_chain = 0)
+    MCMCHIP(; device = 0, first_chain = 0, T = Float64, sequential_ensemble = false)
 
-Run all chains of `sample(model, sampler, MCMCHIP(), N, nchains)` on one MI355X.  With several
-processes (one per GPU) give each its shard via `first_chain`: chains carry global ids in their
-RNG counters, so the union of the shards is the unsharded run.
+Run all chains of `sample(model, sampler, MCMCHIP(), N, nchains)` on one MI355X.  `T` is the arithmetic of the engine:
+`Float64` (what AdvancedMH.jl computes in) or `Float32`.  With several processes (one per GPU) give each its shard via
+`first_chain`: chains carry global ids in their RNG counters, so the union of the shards is the unsharded run.
+`sequential_ensemble = true` runs `Ensemble` with the reference's own Gauss-Seidel sweep (src/emcee.jl:39-58) instead
+of the parallel half-split.
 """
 Base.@kwdef struct MCMCHIP <: AbstractMCMC.AbstractMCMCEnsemble
     device::Int = 0
     first_chain::Int = 0
+    T::DataType = Float64
+    sequential_ensemble::Bool = false
 end
+dtype_code(::Type{Float32}) = Cint(0)
+dtype_code(::Type{Float64}) = Cint(1)
 
 # --- device log-densities (DensityModel(f) cannot be lowered from a Julia closure) --------------
 abstract type DeviceLogDensity end
 struct IsoGaussian <: DeviceLogDensity; dim::Int; end
 struct CorrGaussian <: DeviceLogDensity; Σ::Matrix{Float64}; end
-struct IIDNormal <: DeviceLogDensity; data::Vector{Float32}; end          # README.md:29-31
-struct Banana <: DeviceLogDensity; dim::Int; b::Float32; end
+struct IIDNormal <: DeviceLogDensity; data::Vector{Float64}; end          # README.md:29-31
+struct Banana <: DeviceLogDensity; dim::Int; b::Float64; end
 struct Funnel <: DeviceLogDensity; dim::Int; end
-struct HipSource <: DeviceLogDensity; src::String; dim::Int; data::Vector{Float32}; end
+struct HipSource <: DeviceLogDensity; src::String; dim::Int; data::Vector{Float64}; end   # written against mhx_real / MHX_R()
 
-packlower(M) = Float32[M[i, j] for i in axes(M, 1) for j in 1:i]            # row-major packed lower
+packlower(::Type{T}, M) where {T} = T[M[i, j] for i in axes(M, 1) for j in 1:i]            # row-major packed lower
 
-function target(ctx::Ptr{Cvoid}, t::DeviceLogDensity)
+function target(::Type{T}, ctx::Ptr{Cvoid}, t::DeviceLogDensity) where {T}
     h = Ref{Ptr{Cvoid}}(C_NULL)
     if t isa HipSource
-        GC.@preserve t check(ccall((:mhx_target_from_hip_source, libmhx), Cint,
-            (Ptr{Cvoid}, Cstring, Cint, Ptr{Cfloat}, Csize_t, Ref{Ptr{Cvoid}}),
-            ctx, t.src, t.dim, t.data, length(t.data), h))
+        data = T.(t.data)
+        GC.@preserve data check(ccall((:mhx_target_from_hip_source, libmhx), Cint,
+            (Ptr{Cvoid}, Cstring, Cint, Ptr{Cvoid}, Csize_t, Ref{Ptr{Cvoid}}),
+            ctx, t.src, t.dim, data, length(data), h))
         return h[], t.dim
     end
-    kind, dim, p = t isa IsoGaussian ? (0, t.dim, Float32[]) :
-                   t isa CorrGaussian ? (1, size(t.Σ, 1), packlower(inv(cholesky(Symmetric(t.Σ)).L))) :
-                   t isa IIDNormal ? (2, 2, t.data) :
-                   t isa Banana ? (3, t.dim, Float32[t.b]) : (4, t.dim, Float32[])
+    kind, dim, p = t isa IsoGaussian ? (0, t.dim, T[]) :
+                   t isa CorrGaussian ? (1, size(t.Σ, 1), packlower(T, inv(cholesky(Symmetric(t.Σ)).L))) :
+                   t isa IIDNormal ? (2, 2, T.(t.data)) :
+                   t isa Banana ? (3, t.dim, T[t.b]) : (4, t.dim, T[])
     GC.@preserve p check(ccall((:mhx_target_builtin, libmhx), Cint,
-        (Ptr{Cvoid}, Cint, Cint, Ptr{Cfloat}, Csize_t, Ref{Ptr{Cvoid}}), ctx, kind, dim, p, length(p), h))
+        (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Csize_t, Ref{Ptr{Cvoid}}), ctx, kind, dim, p, length(p), h))
     return h[], dim
 end
 
-# MvNormal -> (kind, scale, vec); a non-zero mean is passed separately (drifting walk, Hastings ratio on the device)
-function proposal_spec(d::MvNormal)
+# (Mv)Normal -> (kind, scale, vec); a non-zero mean is passed separately (drifting walk, Hastings ratio on the device)
+function proposal_spec(::Type{T}, d::MvNormal) where {T}
     Σ = cov(d)
     if Σ ≈ Σ[1, 1] * I
-        return Int32(0), Float32(sqrt(Σ[1, 1])), Float32[]
+        return Int32(0), sqrt(Σ[1, 1]), T[]
     elseif isdiag(Σ)
-        return Int32(1), 1.0f0, Float32.(sqrt.(diag(Σ)))
+        return Int32(1), 1.0, T.(sqrt.(diag(Σ)))
     else
-        return Int32(2), 1.0f0, packlower(cholesky(Symmetric(Matrix(Σ))).L)
+        return Int32(2), 1.0, packlower(T, cholesky(Symmetric(Matrix(Σ))).L)
     end
 end
+proposal_spec(::Type{T}, d::Normal) where {T} = (Int32(1), 1.0, T[std(d)])
+proposal_spec(::Type{T}, ds::AbstractVector{<:Normal}) where {T} = (Int32(1), 1.0, T[std(d) for d in ds])
+proposal_mean(d::MvNormal) = mean(d)
+proposal_mean(d::Normal) = [mean(d)]
+proposal_mean(ds::AbstractVector{<:Normal}) = [mean(d) for d in ds]
+ptr_or_null(v::Vector) = isempty(v) ? Ptr{Cvoid}(C_NULL) : Ptr{Cvoid}(pointer(v))
 
 # --- the one entry point -------------------------------------------------------------------------
 function AbstractMCMC.sample(
@@ -115,85 +133,124 @@ function AbstractMCMC.sample(
     initial_params = nothing, discard_initial = nothing, thinning = 1, num_warmup = 0,
     param_names = missing, chain_type = MCMCChains.Chains, kwargs...,
 )
+    T = ens.T
     discard_initial === nothing && (discard_initial = num_warmup)           # upstream default
     seed = rand(rng, UInt64)                                                # per-run seed from the parent rng
     ctx = Ref{Ptr{Cvoid}}(C_NULL)
-    check(ccall((:mhx_ctx_create, libmhx), Cint, (Cint, Ref{Ptr{Cvoid}}), ens.device, ctx))
-    tgt, d = target(ctx[], model.logdensity)
+    tgt = Ptr{Cvoid}(C_NULL)
     run = Ref{Ptr{Cvoid}}(C_NULL)
-    n = nchains
-    if sampler isa AdvancedMH.MetropolisHastings
-        prop = sampler.proposal
-        prop isa Union{AdvancedMH.RandomWalkProposal, AdvancedMH.StaticProposal} ||
-            throw(ArgumentError("the GPU path implements RandomWalkProposal and StaticProposal over (Mv)Normal only"))
-        kind, scale, vec = proposal_spec(prop.proposal)
-        μ = Float32.(mean(prop.proposal))
-        flags = prop isa AdvancedMH.StaticProposal ? Int32(4) : Int32(0)    # MHX_FLAG_STATIC_PROPOSAL
-        GC.@preserve vec μ begin
-            cfg = RwmhCfg(d, n, seed, ens.first_chain, kind, scale, pointer(vec), flags,
-                          all(iszero, μ) ? Ptr{Cfloat}(C_NULL) : pointer(μ), 0)
-            check(ccall((:mhx_rwmh_create, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{RwmhCfg}, Ref{Ptr{Cvoid}}),
+    check(ccall((:mhx_ctx_create, libmhx), Cint, (Cint, Cint, Ref{Ptr{Cvoid}}), ens.device, dtype_code(T), ctx))
+    try                                     # every handle is released on every path (a thrown status must not leak device memory)
+        tgt, d = target(T, ctx[], model.logdensity)
+        n = nchains
+        if sampler isa AdvancedMH.MetropolisHastings
+            prop = sampler.proposal
+            prop isa Union{AdvancedMH.RandomWalkProposal, AdvancedMH.StaticProposal} ||
+                throw(ArgumentError("the GPU path implements RandomWalkProposal and StaticProposal over (Mv)Normal only"))
+            kind, scale, vec = proposal_spec(T, prop.proposal)
+            μ = T.(proposal_mean(prop.proposal))
+            flags = prop isa AdvancedMH.StaticProposal ? MHX_FLAG_STATIC_PROPOSAL : Int32(0)
+            GC.@preserve vec μ begin
+                cfg = RwmhCfg(d, n, seed, ens.first_chain, kind, scale, ptr_or_null(vec), flags,
+                              all(iszero, μ) ? Ptr{Cvoid}(C_NULL) : Ptr{Cvoid}(pointer(μ)), 0)
+                check(ccall((:mhx_rwmh_create, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{RwmhCfg}, Ref{Ptr{Cvoid}}),
+                            ctx[], tgt, cfg, run))
+            end
+        elseif sampler isa AdvancedMH.Ensemble
+            n = sampler.n_walkers
+            prior = sampler.proposal.proposal                               # what StretchProposal wraps: the prior of the initial walkers
+            flags = ens.sequential_ensemble ? MHX_FLAG_EMCEE_SEQUENTIAL : Int32(0)
+            if prior isa Union{MvNormal, Normal, AbstractVector{<:Normal}}  # drawn on the device (src/emcee.jl:29-34)
+                kind, scale, vec = proposal_spec(T, prior)
+                μ = T.(proposal_mean(prior))
+                GC.@preserve vec μ begin
+                    cfg = EmceeCfg(d, n, seed, ens.first_chain, sampler.proposal.stretch_length, flags, 0,
+                                   kind, scale, ptr_or_null(vec), all(iszero, μ) ? Ptr{Cvoid}(C_NULL) : Ptr{Cvoid}(pointer(μ)))
+                    check(ccall((:mhx_emcee_create, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{EmceeCfg}, Ref{Ptr{Cvoid}}),
+                                ctx[], tgt, cfg, run))
+                end
+            else                                                            # any other Distribution: W host draws, handed over
+                cfg = EmceeCfg(d, n, seed, ens.first_chain, sampler.proposal.stretch_length, flags, 0,
+                               Int32(-1), 1.0, Ptr{Cvoid}(C_NULL), Ptr{Cvoid}(C_NULL))
+                check(ccall((:mhx_emcee_create, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{EmceeCfg}, Ref{Ptr{Cvoid}}),
+                            ctx[], tgt, cfg, run))
+                if initial_params === nothing
+                    initial_params = reduce(hcat, [prior isa AbstractVector ? map(p -> rand(rng, p), prior) : rand(rng, prior) for _ in 1:n])
+                end
+            end
+        elseif sampler isa AdvancedMH.MALA
+            prop = sampler.proposal.proposal
+            prop isa LangevinProposal || throw(ArgumentError("the GPU path implements MALA(LangevinProposal(σ²)) only"))
+            initial_params === nothing && error("please specify initial parameters")   # src/MALA.jl:37
+            cfg = MalaCfg(d, n, seed, ens.first_chain, prop.sigma2, 0)
+            check(ccall((:mhx_mala_create, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{MalaCfg}, Ref{Ptr{Cvoid}}),
                         ctx[], tgt, cfg, run))
+        elseif sampler isa AdvancedMH.RobustAdaptiveMetropolis
+            cfg = RamCfg(d, n, seed, ens.first_chain, sampler.α, sampler.γ,
+                         sampler.eigenvalue_lower_bound, sampler.eigenvalue_upper_bound, 0)
+            check(ccall((:mhx_ram_create, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{RamCfg}, Ref{Ptr{Cvoid}}),
+                        ctx[], tgt, cfg, run))
+            if sampler.S !== nothing
+                size(sampler.S) == (d, d) || throw(ArgumentError("The provided `S` has the wrong dimensionality."))
+                S = packlower(T, LowerTriangular(sampler.S))                 # one factor for every chain (…RAM.jl:198-206)
+                GC.@preserve S check(ccall((:mhx_ram_set_factor_all, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), run[], S))
+            end
+        else
+            throw(ArgumentError("unsupported sampler $(typeof(sampler))"))
         end
-    elseif sampler isa AdvancedMH.Ensemble
-        n = sampler.n_walkers
-        cfg = EmceeCfg(d, n, seed, ens.first_chain, Float32(sampler.proposal.stretch_length), 0, 0)
-        check(ccall((:mhx_emcee_create, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{EmceeCfg}, Ref{Ptr{Cvoid}}),
-                    ctx[], tgt, cfg, run))
-        if initial_params === nothing                                       # src/emcee.jl:29-34
-            initial_params = reduce(hcat, [rand(rng, sampler.proposal.proposal) for _ in 1:n])
+
+        # initial AbstractMCMC.step: host layout x[dim][nchains], chain fastest == Julia Matrix{T}(n, d)
+        if initial_params === nothing
+            check(ccall((:mhx_run_init, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), run[], C_NULL))
+        else
+            x0 = initial_params isa AbstractVector{<:Real} ? repeat(T.(initial_params)', n, 1) :     # one point for every chain
+                                                             Matrix{T}(permutedims(initial_params))   # (dim, nchains) -> (nchains, dim)
+            GC.@preserve x0 check(ccall((:mhx_run_init, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), run[], x0))
         end
-    elseif sampler isa AdvancedMH.MALA
-        prop = sampler.proposal.proposal
-        prop isa LangevinProposal || throw(ArgumentError("the GPU path implements MALA(LangevinProposal(σ²)) only"))
-        initial_params === nothing && error("please specify initial parameters")   # src/MALA.jl:37
-        cfg = MalaCfg(d, n, seed, ens.first_chain, prop.sigma2, 0)
-        check(ccall((:mhx_mala_create, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{MalaCfg}, Ref{Ptr{Cvoid}}),
-                    ctx[], tgt, cfg, run))
-    elseif sampler isa AdvancedMH.RobustAdaptiveMetropolis
-        cfg = RamCfg(d, n, seed, ens.first_chain, sampler.α, sampler.γ,
-                     sampler.eigenvalue_lower_bound, sampler.eigenvalue_upper_bound, 0)
-        check(ccall((:mhx_ram_create, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{RamCfg}, Ref{Ptr{Cvoid}}),
-                    ctx[], tgt, cfg, run))
-        if sampler.S !== nothing
-            size(sampler.S) == (d, d) || throw(ArgumentError("The provided `S` has the wrong dimensionality."))
-            S = repeat(packlower(LowerTriangular(sampler.S)), 1, n)          # [tri, n] column-major == [n][tri] in C
-            GC.@preserve S check(ccall((:mhx_ram_set_factor, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cfloat}), run[], S))
-        end
-    else
-        throw(ArgumentError("unsupported sampler $(typeof(sampler))"))
+        sched = Schedule(N, discard_initial, thinning, num_warmup)
+        check(ccall((:mhx_run_sample, libmhx), Cint, (Ptr{Cvoid}, Ref{Schedule}, Cint), run[], sched, 1))
+
+        # C order [N][d+1][n] with the chain fastest == Julia Array{T,3}(n, d+1, N)
+        raw = Array{T,3}(undef, n, d + 1, N)
+        GC.@preserve raw check(ccall((:mhx_run_get_samples, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{UInt8}),
+                                     run[], raw, C_NULL))
+        vals = Float64.(permutedims(raw, (3, 2, 1)))                         # (iterations, params..lp, chains)
+        names = ismissing(param_names) ? [Symbol(:param_, i) for i in 1:d] : Symbol.(param_names)
+        chain_type === MCMCChains.Chains || return vals
+        # same call as ext/AdvancedMHMCMCChainsExt.jl:116-120
+        return MCMCChains.Chains(vals, vcat(names, [:lp]), (parameters = names, internals = [:lp]);
+                                 start = discard_initial + 1, thin = thinning)
+    finally
+        run[] != C_NULL && ccall((:mhx_run_destroy, libmhx), Cint, (Ptr{Cvoid},), run[])
+        tgt != C_NULL && ccall((:mhx_target_destroy, libmhx), Cint, (Ptr{Cvoid},), tgt)
+        ccall((:mhx_ctx_destroy, libmhx), Cint, (Ptr{Cvoid},), ctx[])
     end
-
-    # initial AbstractMCMC.step: host layout x[dim][nchains], chain fastest == Julia Matrix{Float32}(n, d)
-    init = initial_params === nothing ? Ptr{Cfloat}(C_NULL) :
-           (x0 = initial_params isa AbstractVector ? repeat(Float32.(initial_params)', n, 1) :
-                                                      Matrix{Float32}(permutedims(initial_params));
-            x0)
-    GC.@preserve init check(ccall((:mhx_run_init, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cfloat}), run[],
-                                  init isa Ptr ? init : pointer(init)))
-    sched = Schedule(N, discard_initial, thinning, num_warmup)
-    check(ccall((:mhx_run_sample, libmhx), Cint, (Ptr{Cvoid}, Ref{Schedule}, Cint), run[], sched, 1))
-
-    # C order [N][d+1][n] with the chain fastest == Julia Array{Float32,3}(n, d+1, N)
-    raw = Array{Float32,3}(undef, n, d + 1, N)
-    GC.@preserve raw check(ccall((:mhx_run_get_samples, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cfloat}, Ptr{UInt8}),
-                                 run[], raw, C_NULL))
-    vals = Float64.(permutedims(raw, (3, 2, 1)))                             # (iterations, params..lp, chains)
-    ccall((:mhx_run_destroy, libmhx), Cint, (Ptr{Cvoid},), run[])
-    ccall((:mhx_target_destroy, libmhx), Cint, (Ptr{Cvoid},), tgt)
-    ccall((:mhx_ctx_destroy, libmhx), Cint, (Ptr{Cvoid},), ctx[])
-
-    names = ismissing(param_names) ? [Symbol(:param_, i) for i in 1:d] : Symbol.(param_names)
-    chain_type === MCMCChains.Chains || return vals
-    # same call as ext/AdvancedMHMCMCChainsExt.jl:116-120
-    return MCMCChains.Chains(vals, vcat(names, [:lp]), (parameters = names, internals = [:lp]);
-                             start = discard_initial + 1, thin = thinning)
 end
 
 # convenience: default rng, and the ensemble samplers' nchains-free form
 AbstractMCMC.sample(model::AdvancedMH.DensityModel{<:DeviceLogDensity}, sampler::AdvancedMH.MHSampler,
                     ens::MCMCHIP, N::Integer, nchains::Integer = 1; kwargs...) =
     AbstractMCMC.sample(Random.default_rng(), model, sampler, ens, N, nchains; kwargs...)
+
+# --- collectives of a sharded run (RCCL over xGMI behind the C ABI; one Julia process per GPU, e.g. Distributed.jl) -----
+"""
+    unique_id() -> Vector{UInt8}     # 128 bytes, made on ONE process and sent to the others (Distributed.jl, MPI, a file)
+    comm = comm_init(ctx, rank, world, id)
+    allreduce_sum!(comm, v::Vector{Float64})     # acceptance totals + the R-hat / ESS sums of mhx_run_diagnostics
+"""
+function unique_id()
+    id = Vector{UInt8}(undef, 128)
+    GC.@preserve id check(ccall((:mhx_comm_unique_id, libmhx), Cint, (Ptr{Cvoid},), id))
+    return id
+end
+function comm_init(ctx::Ptr{Cvoid}, rank::Integer, world::Integer, id::Vector{UInt8})
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve id check(ccall((:mhx_comm_init, libmhx), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), ctx, rank, world, id, h))
+    return h[]
+end
+allreduce_sum!(comm::Ptr{Cvoid}, v::Vector{Float64}) =
+    (GC.@preserve v check(ccall((:mhx_comm_allreduce_sum, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Csize_t), comm, v, length(v))); v)
+comm_destroy(comm::Ptr{Cvoid}) = ccall((:mhx_comm_destroy, libmhx), Cint, (Ptr{Cvoid},), comm)
 
 export MCMCHIP, LangevinProposal, IsoGaussian, CorrGaussian, IIDNormal, Banana, Funnel, HipSource
 end # module

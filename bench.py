@@ -143,7 +143,13 @@ class C5(C2):
         spl = mhx.RWMH(mhx.MvNormal(mhx.zeros(d), self.s * self.s * mhx.I))
         self.run = mhx.Run(mhx.DensityModel(mhx.Funnel(d)), spl, nchains=self.C, seed=5, first_chain=rank * self.C, ctx=ctx,
                            reduce_lanes=self.lanes)
-        self.run.init(None)
+        # a stationary start (a draw from the funnel itself: v ~ N(0, 9), x_k ~ N(0, e^v)) instead of a burn-in: from the
+        # proposal-scale start of init(None) the chains spend thousands of transitions inflating |x|^2
+        rng = np.random.default_rng(1000 + rank)
+        x0 = rng.normal(size=(d, self.C))
+        x0[0] *= 3.0
+        x0[1:] *= np.exp(0.5 * x0[0])
+        self.run.init(x0)
         return self.run
 
     def step(self):
