@@ -307,6 +307,54 @@ def cpu_baseline(wl, dtype, target_seconds=10.0):
             "sample": "%s (oracle/mhx_oracle.c in %s, %d thread(s), %.1f s)" % (sample, dtype, cores, dt)}
 
 
+class GlooSum:
+    """Fallback transport of the bench's three tiny host-side all-reduces (torch.distributed, gloo): same interface as
+    mhx.dist.Comm.allreduce_sum.  Only used when the RCCL communicator behind the C ABI cannot be created."""
+
+    def __init__(self, dist):
+        self.dist = dist
+
+    def allreduce_sum(self, v):
+        import numpy as np
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float64).copy())
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t.numpy()
+
+    def close(self):
+        pass
+
+
+def make_collective(ctx, rank, world):
+    """One process per GPU under torchrun.  The rendezvous is torch.distributed's own (gloo on CPU: it only carries the
+    128-byte RCCL id from rank 0 to the others); the bench's collectives -- barrier, max-over-ranks time, acceptance totals
+    and R-hat sums -- then go through the C ABI (mhx_comm_*: RCCL over xGMI).  If the RCCL communicator cannot be created on
+    EVERY rank, all ranks fall back to gloo for those three small host-side all-reduces (reported in config.collective)."""
+    import numpy as np
+    import torch.distributed as dist
+    from mhx.dist import Comm
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    box = [Comm.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    comm, err = None, ""
+    try:
+        comm = Comm(ctx, rank, world, box[0])
+        comm.allreduce_sum(np.zeros(1))
+    except Exception as e:                                       # e.g. no librccl, or two ranks on one device
+        comm, err = None, str(e)[:200]
+    import torch
+    ok = torch.tensor([1.0 if comm is not None else 0.0], dtype=torch.float64)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)                    # all ranks or none
+    if ok.item() >= 1.0:
+        return comm, "mhx_comm_* (RCCL over xGMI, through the C ABI); rendezvous: torch.distributed gloo"
+    if comm is not None:
+        comm.close()
+    return GlooSum(dist), "torch.distributed gloo (fallback: the RCCL communicator could not be created: %s)" % err
+
+
 def timed(wl, steps, warmup, barrier):
     for _ in range(max(0, 30 - warmup)):      # device spin-up (setup): the first ~20 launches after idle run below the steady clock
         wl.step()
@@ -378,13 +426,12 @@ def main():
     import mhx
     from mhx.dist import Comm, allreduce_stats
 
+    local_rank %= max(1, torch.cuda.device_count())             # (several ranks on one device only when a box has fewer GPUs than ranks)
     torch.cuda.set_device(local_rank)
     ctx = mhx.Context(local_rank, args.dtype)
-    comm = None
-    if world > 1 or os.environ.get("MHX_BENCH_FORCE_DIST"):      # the env knob exercises the RCCL path on 1 GPU
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        comm = Comm.from_env(ctx)
+    comm, collective = None, None
+    if world > 1 or os.environ.get("MHX_BENCH_FORCE_DIST"):      # the env knob exercises the collective path on 1 GPU
+        comm, collective = make_collective(ctx, rank, world)
 
     def barrier():
         torch.cuda.synchronize()
@@ -451,7 +498,8 @@ def main():
             "config": {"workload": wl.describe(), "name": args.config, "units_per_step_per_gpu": wl.units_per_step(),
                        "kernel_variant": VARIANTS.get(variant, str(variant)), "lanes_per_unit": st["reduce_lanes"],
                        "launches_per_step": launches,
-                       "sharding": "chains by global id, no data-path collective" if args.config != "c3" else "one ensemble per GPU (replicas)"},
+                       "sharding": "chains by global id, no data-path collective" if args.config != "c3" else "one ensemble per GPU (replicas)",
+                       "collective": collective},
             "acceptance_rate": acc_rate,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -490,6 +538,9 @@ def main():
     if comm is not None:
         barrier()
         comm.close()
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":
