@@ -100,8 +100,8 @@ struct prebuilt_coop {
 // the BASELINE shapes: C2 (65 536 chains x d = 100) and C5 (32 768 chains per GPU x d = 1000); a double takes two VGPRs,
 // so the fp64 engine spreads a chain over more lanes
 #if MHX_REAL64
-#define MHX_C2_L 4
-#define MHX_C2_NBL 7
+#define MHX_C2_L 2
+#define MHX_C2_NBL 13
 #define MHX_C5_L 64
 #define MHX_C5_NBL 4
 #else
@@ -620,15 +620,12 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
         }
         HIP_TRY(hipMalloc(&r->d_pmean, pm.size() * sizeof(mhx_real)));
         COPY_SYNC(ctx->stream, r->d_pmean, pm.data(), pm.size() * sizeof(mhx_real), hipMemcpyHostToDevice);
-        if (cfg->reduce_lanes > 1) return mhx_fail(MHX_EINVAL, "a drifting random walk runs on the generic kernel: reduce_lanes must be 0 or 1");
-        r->flags |= MHX_FLAG_GENERIC;
     }
-    // static (independence) proposal, src/proposal.jl:9-11,66-83: generic kernel, one more mhx_real of state per chain
-    if (cfg->flags & MHX_FLAG_STATIC_PROPOSAL) {
-        if (cfg->reduce_lanes > 1) return mhx_fail(MHX_EINVAL, "a static proposal runs on the generic kernel: reduce_lanes must be 0 or 1");
-        HIP_TRY(hipMalloc(&r->d_qx, (size_t)r->n * sizeof(mhx_real)));
-        r->flags |= MHX_FLAG_GENERIC;
-    }
+    // static (independence) proposal, src/proposal.jl:9-11,66-83: one more mhx_real of state per chain
+    if (cfg->flags & MHX_FLAG_STATIC_PROPOSAL) HIP_TRY(hipMalloc(&r->d_qx, (size_t)r->n * sizeof(mhx_real)));
+    // walks with a Hastings ratio run on the cooperative kernel (separable target, ISO / DIAG proposal) or on the
+    // state-in-HBM kernel; the register kernels know the plain random walk only
+    const int walk = (cfg->flags & MHX_FLAG_STATIC_PROPOSAL) ? MHX_WALK_STATIC : (drift ? MHX_WALK_DRIFT : MHX_WALK_PLAIN);
 
     // the register / cooperative kernels address a [dim+1][nchains] slab with 32-bit byte offsets
     if (((uint64_t)d + 1) * (uint64_t)r->n * (uint64_t)sizeof(mhx_real) >= (1ull << 32)) r->flags |= MHX_FLAG_GENERIC;
@@ -641,17 +638,24 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
     // lanes per chain: cfg->reduce_lanes, or (auto) the smallest power of two that (a) keeps a lane's
     // blocks in registers (<= 13 blocks = 104 VGPRs of state) and (b) gives the chip >= 2 waves per SIMD
     int L = 1;
-    if (separable && pk != MHX_PROP_DENSE && !(r->flags & MHX_FLAG_GENERIC)) {
-        if (cfg->reduce_lanes > 0) {
+    bool coop_one_lane = false;                       // a walk with a Hastings ratio on ONE lane per chain: still the cooperative body
+    if (separable && pk != MHX_PROP_DENSE && !(r->flags & MHX_FLAG_GENERIC) && !(walk && (r->flags & MHX_FLAG_NO_JIT))) {
+        if (cfg->reduce_lanes > 1 || (cfg->reduce_lanes == 1 && walk)) {
             L = cfg->reduce_lanes;
             if (L > 64 || (L & (L - 1))) return mhx_fail(MHX_EINVAL, "reduce_lanes must be a power of two <= 64, got %d", L);
-        } else {
+        } else if (cfg->reduce_lanes == 0) {
             while (L < 64 && (nblk + L - 1) / L > MHX_COOP_NBL_AUTO) L *= 2;
+            // the kernels are bound by VALU throughput, and every block slot of a lane costs a full Philox + Box-Muller
+            // round whether it holds dimensions or padding: halve the lanes while that removes > 5 % of the slots and the
+            // blocks still fit a lane (C2 in fp64: 4 lanes x 7 = 28 slots for 25 blocks -> 2 lanes x 13 = 26: +4 %)
+            while (L > 1 && (nblk + L / 2 - 1) / (L / 2) <= MHX_COOP_NBL_MAX &&
+                   (long)(L / 2) * ((nblk + L / 2 - 1) / (L / 2)) * 105 < (long)L * ((nblk + L - 1) / L) * 100) L /= 2;
             while (L < 64 && 2 * L <= nblk && (long)r->n * L / 64 < 2048) L *= 2;
             if ((nblk + L - 1) / L > MHX_COOP_NBL_MAX) L = 1;      // not even a whole wave holds the chain: state in HBM
         }
+        coop_one_lane = walk && L == 1 && nblk <= MHX_COOP_NBL_MAX;
     } else if (((tk == MHX_TARGET_CORR_GAUSS) || (tk == MHX_TARGET_ISO_GAUSS && pk == MHX_PROP_DENSE)) &&
-               !(r->flags & (MHX_FLAG_GENERIC | MHX_FLAG_NO_JIT)) && d >= 2 && d <= MHX_DENSE_COOP_MAX_DIM &&
+               !walk && !(r->flags & (MHX_FLAG_GENERIC | MHX_FLAG_NO_JIT)) && d >= 2 && d <= MHX_DENSE_COOP_MAX_DIM &&
                (cfg->reduce_lanes > 1 || (cfg->reduce_lanes == 0 && d >= 16)) &&
                dense_coop_fits(d, cfg->reduce_lanes > 1 ? cfg->reduce_lanes : dense_coop_lanes(d),
                                (tk == MHX_TARGET_CORR_GAUSS ? 1 : 0) + (pk == MHX_PROP_DENSE ? 1 : 0))) {
@@ -681,7 +685,7 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
         return mhx_fail(MHX_EINVAL, "reduce_lanes > 1 needs a separable catalogue target or the dense Gaussian target "
                                 "(dim <= 128, JIT), and an ISO/DIAG proposal");
     }
-    if (L > 1) {
+    if (L > 1 || coop_one_lane) {
         const int NBL = (nblk + L - 1) / L;
         if (NBL > MHX_COOP_NBL_MAX) return mhx_fail(MHX_EINVAL, "reduce_lanes=%d leaves %d blocks per lane (max %d)", L, NBL, MHX_COOP_NBL_MAX);
         // tuning knobs: MHX_NO_PREBUILT=1 specialises with hiprtc even where a pre-built kernel exists; MHX_COOP_WAVES=w
@@ -689,15 +693,17 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
         const char* no_prebuilt = getenv("MHX_NO_PREBUILT");
         const char* waves_env = getenv("MHX_COOP_WAVES");
         const int waves_override = waves_env ? atoi(waves_env) : 0;
-        if (!(no_prebuilt && atoi(no_prebuilt)) && !waves_override)
+        if (!(no_prebuilt && atoi(no_prebuilt)) && !waves_override && !walk)
             for (const auto& pb : k_prebuilt_coop)
                 if (pb.L == L && pb.NBL == NBL && pb.TK == tk && pb.PK == pk) { r->reg_fn = pb.fn; r->reg_fn_mom = pb.fn_mom; r->variant = 3; }
         if (!r->variant && !(r->flags & MHX_FLAG_NO_JIT)) {
             jit_module* m = nullptr;
             const std::string key = "rwmh_coop/l=" + std::to_string(L) + "/nbl=" + std::to_string(NBL) + "/tk=" +
-                                    std::to_string(tk) + "/pk=" + std::to_string(pk) + "/w=" + std::to_string(waves_override);
+                                    std::to_string(tk) + "/pk=" + std::to_string(pk) + "/w=" + std::to_string(waves_override) +
+                                    "/walk=" + std::to_string(walk);
             std::vector<std::string> defs = {"MHX_JIT_RWMH_COOP=1", "MHX_JIT_L=" + std::to_string(L), "MHX_JIT_NBL=" + std::to_string(NBL),
-                                             "MHX_JIT_TK=" + std::to_string(tk), "MHX_JIT_PK=" + std::to_string(pk), "MHX_JIT_MOM=0"};
+                                             "MHX_JIT_TK=" + std::to_string(tk), "MHX_JIT_PK=" + std::to_string(pk), "MHX_JIT_MOM=0",
+                                             "MHX_JIT_WALK=" + std::to_string(walk)};
             if (waves_override > 0) defs.push_back("MHX_JIT_WAVES=" + std::to_string(waves_override));
             rc = jit_compile(ctx, key + "/mom=0", jit_source(t, "mhx_rwmh_kernels.h"), defs, &m);
             if (rc == MHX_OK) rc = jit_function(m, "mhx_jit_rwmh_coop", &r->jit_step);
@@ -707,10 +713,16 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
         if (r->variant) {
             r->coop_L = L;
             r->coop_key = "rwmh_coop/l=" + std::to_string(L) + "/nbl=" + std::to_string(NBL) + "/tk=" + std::to_string(tk) +
-                          "/pk=" + std::to_string(pk);
+                          "/pk=" + std::to_string(pk) + "/walk=" + std::to_string(walk);
             r->coop_defs = {"MHX_JIT_RWMH_COOP=1", "MHX_JIT_L=" + std::to_string(L), "MHX_JIT_NBL=" + std::to_string(NBL),
-                            "MHX_JIT_TK=" + std::to_string(tk), "MHX_JIT_PK=" + std::to_string(pk), "MHX_JIT_MOM=1"};
+                            "MHX_JIT_TK=" + std::to_string(tk), "MHX_JIT_PK=" + std::to_string(pk), "MHX_JIT_MOM=1",
+                            "MHX_JIT_WALK=" + std::to_string(walk)};
         } else if (cfg->reduce_lanes > 1) return mhx_fail(MHX_EINVAL, "reduce_lanes=%d: no pre-built kernel and JIT disabled", L);
+    }
+    if (!r->variant && walk) {
+        // no cooperative kernel for this target / proposal family: the state-in-HBM kernel evaluates the ratio
+        if (cfg->reduce_lanes > 1) return mhx_fail(MHX_EINVAL, "reduce_lanes > 1 with a drifting / static proposal needs a separable catalogue target and an ISO / DIAG proposal");
+        r->flags |= MHX_FLAG_GENERIC;
     }
     if (!r->variant && !(r->flags & MHX_FLAG_GENERIC)) {
         if (tk != MHX_TARGET_USER)
@@ -736,7 +748,8 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
         if ((rc = jit_function(m, "mhx_jit_rwmh_init", &r->jit_init))) return rc;
         if (r->variant == 0 && (rc = jit_function(m, "mhx_jit_rwmh_generic", &r->jit_step))) return rc;
     }
-    if (r->variant == 0) HIP_TRY(hipMalloc(&r->d_ybuf, (size_t)d * (size_t)r->n * sizeof(mhx_real)));
+    // candidate scratch of the state-in-HBM kernel; a static proposal whitens the state into it whatever kernel steps the chain
+    if (r->variant == 0 || r->d_qx) HIP_TRY(hipMalloc(&r->d_ybuf, (size_t)d * (size_t)r->n * sizeof(mhx_real)));
     *out = r.release();
     return MHX_OK;
 }

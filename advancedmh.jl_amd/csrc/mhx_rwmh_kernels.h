@@ -350,7 +350,15 @@ MHX_DEV void mhx_rwmh_whiten_body(const mhx_rwmh_args& a, const mhx_real* __rest
 //   - large d (1000): L = 64 is wave-per-chain, the whole state (4 VGPRs per 256 dimensions) stays
 //     in registers across a launch and nothing is streamed from HBM but the recorded samples.
 // The reduction shape L is part of the arithmetic spec (the oracle takes the same L).
-template <int L, int NBL, int TK, int PK, bool MOM>
+// WALK: 0 = zero-mean random walk (Hastings ratio exactly 0); 1 = drifting walk (proposal mean mu != 0:
+// y = x + (mu + s n), logratio = 1/2 sum n^2 - 1/2 sum (n + t)^2, t = 2 L^-1 mu; src/proposal.jl:58-64,190-192);
+// 2 = static proposal (independence sampler, src/proposal.jl:9-11,66-83: y = mu + s n whatever x is,
+// logratio = q(x) - q(y), q(y) = -1/2 sum n^2, q(x) one more real of chain state).  The two sums of a drifting / static
+// step are separable like the target's: per-lane partial sums in block order, the same butterfly (reduction shape L).
+#define MHX_WALK_PLAIN  0
+#define MHX_WALK_DRIFT  1
+#define MHX_WALK_STATIC 2
+template <int L, int NBL, int TK, int PK, bool MOM, int WALK = MHX_WALK_PLAIN>
 MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restrict__ tparams,
                                 const mhx_real* __restrict__ pvec)
 {
@@ -393,6 +401,22 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
     ac.w.x = ac.w.y = ac.w.z = ac.w.w = 0u;
     mhx_u32 save_next = a.save_next;
     long slot = a.save_slot;
+    // drifting / static walks: the lane's share of mu and of t = 2 L^-1 mu (a.pmean = mu[dim] then t[dim]); q(x) of the chain
+    constexpr int NW = WALK != MHX_WALK_PLAIN ? NBL : 1;
+    mhx_real pmu[NW][4], ptt[NW][4];
+    mhx_real qxc = MHX_R(0.0);
+    if (WALK != MHX_WALK_PLAIN) {
+#pragma unroll
+        for (int i = 0; i < NBL; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 4 * (l + L * i) + j;
+                const bool in = (i < NBL - 1 || k < d) && a.pmean != nullptr;
+                pmu[i][j] = in ? a.pmean[k] : MHX_R(0.0);
+                ptt[i][j] = (in && WALK == MHX_WALK_DRIFT) ? a.pmean[d + k] : MHX_R(0.0);
+            }
+        if (WALK == MHX_WALK_STATIC) qxc = a.qx[c];
+    }
     // running moments (MOM): continue the Welford recursion of the previous launches
     mhx_real mm[MOM ? NBL : 1][4], m2[MOM ? NBL : 1][4], lpm = MHX_R(0.0), lpm2 = MHX_R(0.0);
     mhx_u32 mom_n = a.mom_n0;
@@ -414,7 +438,7 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
         // Branch-free over the lane's blocks: a last block past the end of the vector (and the padding
         // dimensions of the final block) computes on zeros -- y = 0 there, and fma(0, 0, q) == q bit for
         // bit, so the partial sums need no predication.
-        mhx_real q = MHX_R(0.0);
+        mhx_real q = MHX_R(0.0), fwd = MHX_R(0.0), bwd = MHX_R(0.0);
 #pragma unroll
         for (int i = 0; i < NBL; ++i) {
             const int b = l + L * i;
@@ -427,7 +451,19 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
                     const int k = 4 * b + j;
                     sc = pvec[(i < NBL - 1 || k < d) ? k : 0];
                 }
-                mhx_real yk = mhx_fma(sc, n[j], x[i][j]);
+                mhx_real yk;
+                if (WALK == MHX_WALK_PLAIN) {
+                    yk = mhx_fma(sc, n[j], x[i][j]);
+                } else {
+                    // the same expressions as the state-in-HBM kernel: x + fma(s, n, mu) with a mean, fma(s, n, x) without;
+                    // a static proposal takes x = 0.  Padding dimensions contribute fma(0, 0, sum) == sum.
+                    const bool in = i < NBL - 1 || k_last + j < d;
+                    const mhx_real nk = in ? n[j] : MHX_R(0.0);
+                    const mhx_real xk = WALK == MHX_WALK_STATIC ? MHX_R(0.0) : x[i][j];
+                    yk = a.pmean ? xk + mhx_fma(sc, nk, pmu[i][j]) : mhx_fma(sc, nk, xk);
+                    fwd = mhx_fma(nk, nk, fwd);
+                    if (WALK == MHX_WALK_DRIFT) { const mhx_real tk = nk + ptt[i][j]; bwd = mhx_fma(tk, tk, bwd); }
+                }
                 if (i == NBL - 1) yk = (k_last + j < d) ? yk : MHX_R(0.0);
                 y[i][j] = yk;
                 const mhx_real sq = mhx_fma(yk, yk, q);
@@ -449,6 +485,14 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
         }
 #pragma unroll
         for (int off = 1; off < L; off <<= 1) q = q + __shfl_xor(q, off * CPW, 64);
+        if (WALK != MHX_WALK_PLAIN) {
+#pragma unroll
+            for (int off = 1; off < L; off <<= 1) fwd = fwd + __shfl_xor(fwd, off * CPW, 64);
+            if (WALK == MHX_WALK_DRIFT) {
+#pragma unroll
+                for (int off = 1; off < L; off <<= 1) bwd = bwd + __shfl_xor(bwd, off * CPW, 64);
+            }
+        }
         mhx_real lpy;
         if (TK == MHX_TARGET_FUNNEL) {
             const mhx_real v = __shfl(y[0][0], cw, 64);           // x1 lives in lane l == 0 of the chain
@@ -461,12 +505,17 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
             lpy = mhx_fma(-MHX_R(0.5), q, a.tconst);
         }
         const mhx_real logu = mhx_accept_logu(ks, id_lo, id_hi, step, ac);
-        const bool acc = logu < (lpy - lp);
+        // src/mh-core.jl:104-105 with logratio_proposal_density (src/proposal.jl:190-192 / :74-83) for the walks that have one
+        const mhx_real qy = -MHX_R(0.5) * fwd;
+        const mhx_real loga = WALK == MHX_WALK_STATIC ? (lpy - lp) + (qxc - qy)
+                            : (WALK == MHX_WALK_DRIFT ? (lpy - lp) + MHX_R(0.5) * (fwd - bwd) : (lpy - lp));
+        const bool acc = logu < loga;
 #pragma unroll
         for (int i = 0; i < NBL; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) x[i][j] = acc ? y[i][j] : x[i][j];
         lp = acc ? lpy : lp;
+        if (WALK == MHX_WALK_STATIC) qxc = acc ? qy : qxc;
         nacc += acc ? 1u : 0u;
         last = acc;
         wave_acc += (mhx_u32)__popcll(__ballot(acc && valid && l == 0));
@@ -514,6 +563,7 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
             a.lp[c] = lp;
             a.acc_count[c] = nacc;
             a.last_acc[c] = last ? 1 : 0;
+            if (WALK == MHX_WALK_STATIC) a.qx[c] = qxc;
         }
         if (MOM) {
 #pragma unroll
@@ -631,7 +681,10 @@ mhx_jit_rwmh_reg(const mhx_rwmh_args a, const mhx_real* __restrict__ tparams, co
 extern "C" __global__ void __launch_bounds__(256, MHX_JIT_WAVES)
 mhx_jit_rwmh_coop(const mhx_rwmh_args a, const mhx_real* __restrict__ tparams, const mhx_real* __restrict__ pvec)
 {
-    mhx_rwmh_coop_body<MHX_JIT_L, MHX_JIT_NBL, MHX_JIT_TK, MHX_JIT_PK, (MHX_JIT_MOM != 0)>(a, tparams, pvec);
+#ifndef MHX_JIT_WALK
+#define MHX_JIT_WALK 0
+#endif
+    mhx_rwmh_coop_body<MHX_JIT_L, MHX_JIT_NBL, MHX_JIT_TK, MHX_JIT_PK, (MHX_JIT_MOM != 0), MHX_JIT_WALK>(a, tparams, pvec);
 }
 #endif
 #ifdef MHX_JIT_RWMH_GENERIC

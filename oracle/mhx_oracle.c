@@ -558,6 +558,30 @@ static real static_logq(const orc_proposal *p, int d, const real *x, real *t)
     return -R(0.5) * q;
 }
 
+/* sum_k (z_k + add_k)^2 (add == NULL: sum z_k^2) with the reduction shape of the cooperative kernel: lane l accumulates the
+ * blocks b = l, l+L, ... of 4 dimensions in order, the L partial sums meet in the butterfly; L <= 1: plain ascending order */
+static real lanes_sumsq(const real *z, const real *add, int d, int L)
+{
+    if (L <= 1) {
+        real q = R(0.0);
+        for (int k = 0; k < d; ++k) { const real tk = add ? z[k] + add[k] : z[k]; q = FMA(tk, tk, q); }
+        return q;
+    }
+    const int nblk = (d + 3) / 4;
+    real p[64];
+    for (int l = 0; l < L; ++l) {
+        real q = R(0.0);
+        for (int b = l; b < nblk; b += L)
+            for (int j = 0; j < 4 && 4 * b + j < d; ++j) {
+                const int k = 4 * b + j;
+                const real tk = add ? z[k] + add[k] : z[k];
+                q = FMA(tk, tk, q);
+            }
+        p[l] = q;
+    }
+    return butterfly(p, L);
+}
+
 /* twice the whitened mean 2 L^-1 mu (host arithmetic in double, rounded once): with it the Hastings ratio of a
  * drifting random walk is  logq(x|y) - logq(y|x) = 1/2 |z|^2 - 1/2 |z + 2 L^-1 mu|^2   (src/proposal.jl:58-64,190-192) */
 static void whitened_mean2(const orc_proposal *p, int d, real *tm)
@@ -649,18 +673,14 @@ int orc_rwmh(const orc_target *t, const orc_proposal *p, const orc_schedule *s,
             real lpy = orc_target_eval(t, y);          /* :103 */
             real loga = lpy - lp;                      /* :104-105, Hastings ratio of a zero-mean RW == 0 */
             real qy = R(0.0);
+            /* the sums of the ratio take the target's reduction shape when the cooperative kernel runs the walk */
+            const int Lw = (p->kind != ORC_PROP_DENSE) ? t->reduce_lanes : 1;
             if (p->is_static) {                         /* proposal.jl:74-83: q = logpdf(proposal, t) */
-                real fwd = R(0.0);
-                for (int k = 0; k < d; ++k) fwd = FMA(z[k], z[k], fwd);
+                const real fwd = lanes_sumsq(z, NULL, d, Lw);
                 qy = -R(0.5) * fwd;
                 loga = (lpy - lp) + (qx - qy);
             } else if (p->mean) {                       /* :105,119-123 -> proposal.jl:190-192 */
-                real fwd = R(0.0), bwd = R(0.0);
-                for (int k = 0; k < d; ++k) {
-                    fwd = FMA(z[k], z[k], fwd);
-                    const real tk = z[k] + tm[k];
-                    bwd = FMA(tk, tk, bwd);
-                }
+                const real fwd = lanes_sumsq(z, NULL, d, Lw), bwd = lanes_sumsq(z, tm, d, Lw);
                 loga = (lpy - lp) + R(0.5) * (fwd - bwd);
             }
             real logu = orc_accept_logu(seed, id, step);

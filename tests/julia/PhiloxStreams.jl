@@ -7,7 +7,7 @@
 #     chain = sample(PhiloxStream(seed, chain_id; dim = d), model, RWMH(...), N; chain_type = Vector{...})
 #
 # makes `src/mh-core.jl:92-117`, `src/emcee.jl:39-102` and `src/RobustAdaptiveMetropolis.jl:123-278` consume the draws the
-# oracle and the device consume, so their traces are comparable number by number (julia/make_reference_traces.jl writes
+# oracle and the device consume, so their traces are comparable number by number (tests/julia/make_reference_traces.jl writes
 # them, tests/test_julia_reference_traces.py checks them).  What stays different is rounding only: the engine's spec fuses
 # `x + sigma z` and the sums of the log-densities with fma, Julia rounds products and sums separately -- relative
 # differences of a few ulp per step, which is why the comparison is toleranced (1e-9) and accept decisions are compared

@@ -1,11 +1,11 @@
 # make_reference_traces.jl -- run the UNMODIFIED AdvancedMH.jl on the engine's random streams and write the traces the
 # parity test reads.  One command turns "parity unpinned" into a red / green test:
 #
-#     julia --project=/path/to/AdvancedMH.jl advancedmh.jl_amd/julia/make_reference_traces.jl tests/golden/julia
+#     julia --project=/path/to/AdvancedMH.jl tests/julia/make_reference_traces.jl tests/golden/julia
 #     python -m pytest tests/test_julia_reference_traces.py
 #
 # Every case below mirrors a case of tests/julia_cases.py (same seed, global chain ids, schedule, model, sampler).  The
-# package's own `sample` runs each chain with a `PhiloxStream` (julia/PhiloxStreams.jl) as its rng, so
+# package's own `sample` runs each chain with a `PhiloxStream` (tests/julia/PhiloxStreams.jl) as its rng, so
 # src/mh-core.jl:92-117, src/emcee.jl:39-102 and src/RobustAdaptiveMetropolis.jl:123-278 consume the very draws the oracle
 # consumes; the test compares number by number (states to 1e-9, accept decisions wherever their margin exceeds it --
 # Julia rounds `x + sigma z` and the log-density sums in separate operations where the engine's spec fuses them).
@@ -15,7 +15,7 @@ using AdvancedMH, AbstractMCMC, Distributions, LinearAlgebra, Random
 include(joinpath(@__DIR__, "PhiloxStreams.jl"))
 using .PhiloxStreams
 
-outdir = length(ARGS) >= 1 ? ARGS[1] : joinpath(@__DIR__, "..", "..", "tests", "golden", "julia")
+outdir = length(ARGS) >= 1 ? ARGS[1] : joinpath(@__DIR__, "..", "golden", "julia")
 mkpath(outdir)
 
 # ---- a minimal .npy writer (format 1.0; Julia arrays are column-major: fortran_order = True) -----------------------

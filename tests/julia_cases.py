@@ -1,4 +1,4 @@
-"""The cases advancedmh.jl_amd/julia/make_reference_traces.jl runs through the UNMODIFIED AdvancedMH.jl (same seeds, global
+"""The cases tests/julia/make_reference_traces.jl runs through the UNMODIFIED AdvancedMH.jl (same seeds, global
 chain ids, schedules, models, samplers), here through the fp64 oracle.  tests/test_julia_reference_traces.py compares the
 two when the Julia traces are present (tests/golden/julia/)."""
 import numpy as np

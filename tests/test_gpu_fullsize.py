@@ -26,7 +26,7 @@ def test_c2_full_size_rwmh(mhx, oracle, real):
     spl = mhx.RWMH(mhx.MvNormal(mhx.zeros(d), s * s * mhx.I))
     chain = mhx.sample(model, spl, N, C, seed=0xC0FFEE)
     L = chain.stats["reduce_lanes"]
-    assert chain.stats["kernel_variant"] == 3 and L == (4 if real == "f64" else 2)   # the pre-built cooperative kernel
+    assert chain.stats["kernel_variant"] == 3 and L == 2   # the pre-built cooperative kernel
     for first in (0, 31337, C - 64):                               # three subsets of 64 chains
         ref = oracle.rwmh(oracle.iso_gauss(d, reduce_lanes=L), oracle.Proposal(oracle.PROP_ISO, s), oracle.schedule(N),
                           0xC0FFEE, first, 64)

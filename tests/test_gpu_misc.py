@@ -296,13 +296,57 @@ def test_drifting_random_walk_hastings_ratio(mhx, oracle, kind, real):
     model = mhx.DensityModel(mhx.IsoGaussian(d))
     spl = mhx.RWMH(mhx.MvNormal(mean, cov))
     chain = mhx.sample(model, spl, N, C, seed=5, first_chain=2)
-    assert chain.stats["kernel_variant"] == 0
+    # separable target + ISO / DIAG proposal: the cooperative kernel evaluates the ratio (one lane per chain at d = 3); a dense
+    # proposal: the state-in-HBM kernel
+    assert chain.stats["kernel_variant"] == (0 if kind == "dense" else 4) and chain.stats["reduce_lanes"] == 1
     ref = oracle.rwmh(oracle.iso_gauss(d), oprop, oracle.schedule(N), 5, 2, C)
     _same(chain.value, ref["samples"], "samples")
     _same(chain.accepted, ref["accepted"], "accepted")
     long = mhx.sample(model, spl, 4000, 256, seed=6, discard_initial=500)
     v = long.value[:, :d, :].astype(np.float64)
     assert np.abs(v.mean(axis=(0, 2))).max() < 0.05 and np.abs(v.var(axis=(0, 2)) - 1).max() < 0.05
+
+
+@pytest.mark.parametrize("target", ["iso", "banana", "funnel"])
+@pytest.mark.parametrize("walk", ["drift_iso", "drift_diag", "static_iso", "static_diag_mean"])
+@pytest.mark.parametrize("lanes", [0, 1, 4])
+def test_walks_with_a_hastings_ratio_on_the_cooperative_kernel(mhx, oracle, target, walk, lanes, real):
+    """Drifting random walks (src/proposal.jl:58-64,190-192) and static proposals (:9-11,66-83) on the separable catalogue
+    targets run on the cooperative kernel: L lanes per chain, the two sums of the ratio reduced like the log-density (lane
+    partial sums in block order + butterfly; the oracle takes the same shape).  Bit-exact, with discard / thinning, a
+    continued call and setparams (q(x) of a static proposal is chain state)."""
+    d, C, N = 37, 70, 14
+    rng = np.random.default_rng(7)
+    mean = (rng.normal(size=d) * (0.02 if walk.startswith("drift") else 0.05)).astype(np.float32).astype(np.float64)
+    s0 = float(np.float32(0.3 if walk.startswith("drift") else 1.0))
+    sv = (s0 * (0.9 + 0.2 * rng.random(d))).astype(np.float32).astype(np.float64)
+    diag = "diag" in walk
+    has_mean = walk != "static_iso"
+    dist = mhx.MvNormal(mean if has_mean else mhx.zeros(d), sv ** 2 if diag else s0 * s0 * mhx.I)
+    op = dict(kind=oracle.PROP_DIAG, vec=sv) if diag else dict(kind=oracle.PROP_ISO, scale=s0)
+    static = walk.startswith("static")
+    spl = mhx.StaticMH(dist) if static else mhx.RWMH(dist)
+    spec, ot = {"iso": (mhx.IsoGaussian(d), oracle.iso_gauss(d)),
+                "banana": (mhx.Banana(d, 0.03), oracle.Target(oracle.TARGET_BANANA, d, params=[0.03])),
+                "funnel": (mhx.Funnel(d), oracle.Target(oracle.TARGET_FUNNEL, d))}[target]
+    init = (rng.normal(size=(d, C)) * 0.5).astype(np.float32)
+    run = mhx.Run(mhx.DensityModel(spec), spl, nchains=C, seed=12, first_chain=5, reduce_lanes=lanes)
+    run.init(init)
+    run.sample(N, 2, 3, 0)
+    st = run.stats()
+    L = st["reduce_lanes"]
+    assert st["kernel_variant"] == 4 and (lanes == 0 or L == lanes)
+    oprop = oracle.Proposal(mean=mean if has_mean else None, static=static, **op)
+    ref = oracle.rwmh(ot.with_lanes(L), oprop, oracle.schedule(N, 2, 3), 12, 5, C, init=init)
+    got, acc = run.samples()
+    _same(got, ref["samples"], "samples (%d lanes)" % L)
+    _same(acc, ref["accepted"], "accepted")
+    # (a static N(0, I) proposal on the N(0, I) target is the exact independence sampler: every draw is accepted)
+    assert (target != "iso" or acc[1:].mean() > 0.01) and (walk == "static_iso" or acc[1:].mean() < 1.0)
+    run.sample(5, 1, 1, 0)                                   # a continued call: the same chain, 5 more states
+    ref2 = oracle.rwmh(ot.with_lanes(L), oprop, oracle.schedule(5, 2 + 3 * (N - 1) + 1, 1), 12, 5, C, init=init)
+    _same(run.samples()[0], ref2["samples"], "continued call")
+    run.close()
 
 
 # ---- StaticProposal / StaticMH: the independence sampler of src/proposal.jl:9-11,66-83 --------------------

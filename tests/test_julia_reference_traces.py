@@ -1,6 +1,6 @@
 """Parity against AdvancedMH.jl ITSELF, when a maintainer with Julia has produced the traces:
 
-    julia --project=/path/to/AdvancedMH.jl advancedmh.jl_amd/julia/make_reference_traces.jl tests/golden/julia
+    julia --project=/path/to/AdvancedMH.jl tests/julia/make_reference_traces.jl tests/golden/julia
 
 runs the unmodified package on the engine's random streams (julia/PhiloxStreams.jl).  Each trace is compared with the fp64
 oracle number by number: states and log-densities to 1e-9 (the spec fuses `x + sigma z` and the log-density sums with fma,
@@ -36,7 +36,7 @@ def test_case_runs_on_the_oracle(oracle64, name):
 def test_oracle_matches_the_julia_reference(oracle64, name):
     sp = os.path.join(JDIR, name + "_samples.npy")
     if not os.path.exists(sp):
-        pytest.skip("no Julia traces under tests/golden/julia (run julia/make_reference_traces.jl where Julia exists)")
+        pytest.skip("no Julia traces under tests/golden/julia (run tests/julia/make_reference_traces.jl where Julia exists)")
     want = np.load(sp)
     want_acc = np.load(os.path.join(JDIR, name + "_accepted.npy"))
     got = julia_cases.JULIA_CASES[name](oracle64)
