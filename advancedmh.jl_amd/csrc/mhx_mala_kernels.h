@@ -100,6 +100,38 @@ MHX_DEV mhx_real mhx_target_grad(int kind, const X& x, const GO& g, const int d,
     }
 }
 
+// value and gradient with the L-lane reduction shape of the cooperative kernel, by ONE lane (initial state, setparams):
+// the separable targets take their sum of squares from mhx_separable_q_lanes; everything else is mhx_target_grad
+template <int KIND, class X, class GO>
+MHX_DEV mhx_real mhx_target_grad_lanes(int kind, const X& x, const GO& g, const int d, const mhx_real* __restrict__ p,
+                                       const int np, const mhx_real cst, const int L)
+{
+    const int k_ = (KIND == MHX_TARGET_DYNAMIC) ? kind : KIND;
+    const bool separable = k_ == MHX_TARGET_ISO_GAUSS || k_ == MHX_TARGET_BANANA || k_ == MHX_TARGET_FUNNEL;
+    if (L <= 1 || !separable) return mhx_target_grad<KIND>(kind, x, g, d, p, np, cst);
+    const mhx_real q = mhx_separable_q_lanes(k_, x, d, p, L);
+    if (k_ == MHX_TARGET_ISO_GAUSS) {
+        for (int k = 0; k < d; ++k) g.set(k, -x[k]);
+        return mhx_fma(-MHX_R(0.5), q, cst);
+    }
+    if (k_ == MHX_TARGET_BANANA) {
+        const mhx_real b = p[0], x0 = x[0];
+        const mhx_real u = mhx_fma(b, mhx_fma(x0, x0, -MHX_R(100.0)), x[1]);
+        g.set(0, -(mhx_fma(x0, MHX_R(0.01), (MHX_R(2.0) * b) * (u * x0))));
+        g.set(1, -u);
+        for (int k = 2; k < d; ++k) g.set(k, -x[k]);
+        return mhx_fma(-MHX_R(0.5), q, cst);
+    }
+    const mhx_real v = x[0];
+    const mhx_real ev = mhx_exp(-v);
+    mhx_real r = (v * v) * MHX_ONE_18;
+    r = mhx_fma(MHX_R(0.5) * (mhx_real)(d - 1), v, r);
+    r = mhx_fma(MHX_R(0.5) * ev, q, r);
+    g.set(0, mhx_fma(MHX_R(0.5) * ev, q, -(mhx_fma(v, MHX_ONE_9, MHX_R(0.5) * (mhx_real)(d - 1)))));
+    for (int k = 1; k < d; ++k) g.set(k, -(ev * x[k]));
+    return cst - r;
+}
+
 struct mhx_mala_args {
     mhx_real* x;                 // [dim][ld]
     mhx_real* gx;                // [dim][ld] gradient at x (GradientTransition.gradient, src/MALA.jl:14-19)
@@ -128,7 +160,178 @@ struct mhx_mala_args {
     mhx_u32 save_next;
     int save_slot;
     int thinning;
+    int reduce_lanes;         // lanes per chain of the cooperative kernel (reduction shape of the sums), >= 1
 };
+
+// ---------------------------------------------------------------------------------------------
+// Cooperative MALA for the separable catalogue targets (iso-Gaussian, banana, funnel): L lanes share one chain exactly as
+// in mhx_rwmh_coop_body -- lane l owns the Philox blocks b = l, l+L, ... -- with state x, grad(x) and per step candidate,
+// its gradient and the noise in VGPRs (5 NBL float4 per lane).  The three sums of a step (the target's sum of squares,
+// |z|^2, |z + (sigma/2)(grad x + grad y)|^2) are lane partial sums in block order + the xor-butterfly: reduction shape L,
+// which the oracle takes too.  The gradients of these targets are element-wise once the few shared scalars are known
+// (banana: x1, u in lane 0's first block; funnel: v = x1 and the total sum of squares).
+template <int L, int NBL, int TK>
+MHX_DEV void mhx_mala_coop_body(const mhx_mala_args& a, const mhx_real* __restrict__ tparams)
+{
+    constexpr int CPW = 64 / L;
+    const int lane = threadIdx.x & 63;
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int cw = lane & (CPW - 1);
+    const int l = lane / CPW;
+    const long c_raw = wave * CPW + cw;
+    const bool valid = c_raw < a.nchains;
+    const long c = valid ? c_raw : (long)a.nchains - 1;
+    const mhx_u64 id = a.first_chain + (mhx_u64)c;
+    const mhx_u32 id_lo = (mhx_u32)id, id_hi = (mhx_u32)(id >> 32);
+    const mhx_philox_key ks = mhx_philox_schedule(a.seed);
+    const long ld = a.ld;
+    const int d = a.dim;
+    const int k_last = 4 * (l + L * (NBL - 1));
+
+    mhx_real x[NBL][4], gx[NBL][4];
+#pragma unroll
+    for (int i = 0; i < NBL; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = 4 * (l + L * i) + j;
+            const bool in = i < NBL - 1 || k < d;
+            x[i][j] = in ? a.x[(long)k * ld + c] : MHX_R(0.0);
+            gx[i][j] = in ? a.gx[(long)k * ld + c] : MHX_R(0.0);
+        }
+    mhx_real lp = a.lp[c];
+    mhx_u32 nacc = a.acc_count[c];
+    mhx_u32 wave_acc = 0;
+    bool last = a.last_acc[c] != 0;
+    mhx_accept_cache ac;
+    ac.group = 0xffffffffu;
+    ac.w.x = ac.w.y = ac.w.z = ac.w.w = 0u;
+    mhx_u32 save_next = a.save_next;
+    long slot = a.save_slot;
+
+    for (int it = 0; it < a.nsteps; ++it) {
+        const mhx_u32 step = a.step0 + (mhx_u32)it;
+        mhx_real y[NBL][4], gy[NBL][4], z[NBL][4];
+        mhx_real q = MHX_R(0.0), fwd = MHX_R(0.0);
+        // ---- propose (src/MALA.jl:70): y = x + (sigma2/2) grad(x) + sigma z; the target's sum of squares on the way
+#pragma unroll
+        for (int i = 0; i < NBL; ++i) {
+            mhx_real n[4];
+            mhx_normal4(ks, id_lo, id_hi, step, MHX_STREAM_PROPOSAL, (mhx_u32)(l + L * i), n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool in = i < NBL - 1 || k_last + j < d;
+                const mhx_real zk = in ? n[j] : MHX_R(0.0);
+                const mhx_real yk = in ? mhx_fma(a.sigma, zk, mhx_fma(a.h, gx[i][j], x[i][j])) : MHX_R(0.0);
+                z[i][j] = zk;
+                y[i][j] = yk;
+                fwd = mhx_fma(zk, zk, fwd);
+                const mhx_real sq = mhx_fma(yk, yk, q);
+                if (TK == MHX_TARGET_BANANA && i == 0 && j == 0) {
+                    q = l == 0 ? (yk * yk) * MHX_R(0.01) : sq;
+                } else if (TK == MHX_TARGET_BANANA && i == 0 && j == 1) {
+                    const mhx_real y0 = y[0][0];
+                    const mhx_real u = mhx_fma(tparams[0], mhx_fma(y0, y0, -MHX_R(100.0)), yk);
+                    q = l == 0 ? mhx_fma(u, u, q) : sq;
+                } else if (TK == MHX_TARGET_FUNNEL && i == 0 && j == 0) {
+                    q = l == 0 ? q : sq;
+                } else {
+                    q = sq;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int off = 1; off < L; off <<= 1) q = q + __shfl_xor(q, off * CPW, 64);
+#pragma unroll
+        for (int off = 1; off < L; off <<= 1) fwd = fwd + __shfl_xor(fwd, off * CPW, 64);
+        // ---- value and gradient at the candidate (:73-75): same expressions as mhx_target_grad
+        mhx_real lpy;
+        if (TK == MHX_TARGET_FUNNEL) {
+            const mhx_real v = __shfl(y[0][0], cw, 64);               // x1 lives in lane l == 0 of the chain
+            const mhx_real ev = mhx_exp(-v);
+            mhx_real r = (v * v) * MHX_ONE_18;
+            r = mhx_fma(MHX_R(0.5) * (mhx_real)(d - 1), v, r);
+            r = mhx_fma(MHX_R(0.5) * ev, q, r);
+            lpy = a.tconst - r;
+#pragma unroll
+            for (int i = 0; i < NBL; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gy[i][j] = -(ev * y[i][j]);
+            if (l == 0) gy[0][0] = mhx_fma(MHX_R(0.5) * ev, q, -(mhx_fma(v, MHX_ONE_9, MHX_R(0.5) * (mhx_real)(d - 1))));
+        } else {
+            lpy = mhx_fma(-MHX_R(0.5), q, a.tconst);
+#pragma unroll
+            for (int i = 0; i < NBL; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gy[i][j] = -y[i][j];
+            if (TK == MHX_TARGET_BANANA && l == 0) {
+                const mhx_real b = tparams[0], y0 = y[0][0];
+                const mhx_real u = mhx_fma(b, mhx_fma(y0, y0, -MHX_R(100.0)), y[0][1]);
+                gy[0][0] = -(mhx_fma(y0, MHX_R(0.01), (MHX_R(2.0) * b) * (u * y0)));
+                gy[0][1] = -u;
+            }
+        }
+        // ---- log ratio of the proposal densities (:78-80)
+        mhx_real bwd = MHX_R(0.0);
+#pragma unroll
+        for (int i = 0; i < NBL; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool in = i < NBL - 1 || k_last + j < d;
+                const mhx_real tk = in ? mhx_fma(a.hs, gx[i][j] + gy[i][j], z[i][j]) : MHX_R(0.0);
+                bwd = mhx_fma(tk, tk, bwd);
+            }
+#pragma unroll
+        for (int off = 1; off < L; off <<= 1) bwd = bwd + __shfl_xor(bwd, off * CPW, 64);
+        const mhx_real loga = (lpy - lp) + MHX_R(0.5) * (fwd - bwd);                 // :83
+        const mhx_real logu = mhx_accept_logu(ks, id_lo, id_hi, step, ac);
+        const bool acc = logu < loga;                                               // :86 (strict)
+#pragma unroll
+        for (int i = 0; i < NBL; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                x[i][j] = acc ? y[i][j] : x[i][j];
+                gx[i][j] = acc ? gy[i][j] : gx[i][j];
+            }
+        lp = acc ? lpy : lp;
+        nacc += acc ? 1u : 0u;
+        last = acc;
+        wave_acc += (mhx_u32)__popcll(__ballot(acc && valid && l == 0));
+        if (step == save_next) {
+            if (valid) {
+                mhx_real* row = a.samples + slot * (long)(d + 1) * ld + c;
+#pragma unroll
+                for (int i = 0; i < NBL; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int k = 4 * (l + L * i) + j;
+                        if (i < NBL - 1 || k < d) row[(long)k * ld] = x[i][j];
+                    }
+                if (l == 0) {
+                    row[(long)d * ld] = lp;
+                    a.accepted[slot * ld + c] = acc ? 1 : 0;
+                }
+            }
+            save_next += (mhx_u32)a.thinning;
+            ++slot;
+        }
+    }
+    if (valid) {
+#pragma unroll
+        for (int i = 0; i < NBL; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 4 * (l + L * i) + j;
+                if (i < NBL - 1 || k < d) { a.x[(long)k * ld + c] = x[i][j]; a.gx[(long)k * ld + c] = gx[i][j]; }
+            }
+        if (l == 0) {
+            a.lp[c] = lp;
+            a.acc_count[c] = nacc;
+            a.last_acc[c] = last ? 1 : 0;
+        }
+    }
+    if (lane == 0) atomicAdd(a.acc_total, (mhx_u64)wave_acc);
+}
 
 template <int TK>
 MHX_DEV void mhx_mala_body(const mhx_mala_args& a, const mhx_real* __restrict__ tparams)
@@ -313,10 +516,17 @@ MHX_DEV void mhx_mala_init_body(const mhx_mala_args& a, const mhx_real* __restri
     mhx_strided_rw g;
     g.base = a.gx + c;
     g.ld = a.ld;
-    a.lp[c] = mhx_target_grad<TK>(a.target_kind, xv, g, a.dim, tparams, a.ntparams, a.tconst);
+    a.lp[c] = mhx_target_grad_lanes<TK>(a.target_kind, xv, g, a.dim, tparams, a.ntparams, a.tconst, a.reduce_lanes);
     if (reset_counts) { a.acc_count[c] = 0u; a.last_acc[c] = 0; }
 }
 
+#ifdef MHX_JIT_MALA_COOP
+extern "C" __global__ void __launch_bounds__(256, MHX_JIT_WAVES)
+mhx_jit_mala_coop(const mhx_mala_args a, const mhx_real* __restrict__ tparams)
+{
+    mhx_mala_coop_body<MHX_JIT_L, MHX_JIT_NBL, MHX_JIT_TK>(a, tparams);
+}
+#endif
 #ifdef MHX_JIT_MALA
 extern "C" __global__ void __launch_bounds__(256)
 mhx_jit_mala(const mhx_mala_args a, const mhx_real* __restrict__ tparams)

@@ -110,6 +110,39 @@ MHX_DEV mhx_real mhx_target_eval(int kind, const X& x, const int d, const mhx_re
     }
 }
 
+// sum of squares of a separable target (ISO_GAUSS, BANANA, FUNNEL) in the L-lane reduction shape, evaluated by ONE lane:
+// lane l of the shape owns the Philox blocks b = l, l+L, ... (4 dimensions each); the L partial sums meet in an
+// xor-butterfly with offsets 1, 2, 4, ...
+template <class X>
+MHX_DEV mhx_real mhx_separable_q_lanes(const int k_, const X& x, const int d, const mhx_real* __restrict__ p, const int L)
+{
+    mhx_real part[64];
+    const int nblk = (d + 3) >> 2;
+    for (int l = 0; l < L; ++l) {
+        mhx_real q = MHX_R(0.0);
+        for (int b = l; b < nblk; b += L)
+            for (int j = 0; j < 4; ++j) {
+                const int k = 4 * b + j;
+                if (k >= d) break;
+                const mhx_real v = x[k];
+                if (k_ == MHX_TARGET_BANANA && k == 0) q = (v * v) * MHX_R(0.01);
+                else if (k_ == MHX_TARGET_BANANA && k == 1) {
+                    const mhx_real x0 = x[0];
+                    const mhx_real u = mhx_fma(p[0], mhx_fma(x0, x0, -MHX_R(100.0)), v);
+                    q = mhx_fma(u, u, q);
+                } else if (k_ == MHX_TARGET_FUNNEL && k == 0) {
+                } else q = mhx_fma(v, v, q);
+            }
+        part[l] = q;
+    }
+    for (int off = 1; off < L; off <<= 1) {
+        mhx_real nxt[64];
+        for (int l = 0; l < L; ++l) nxt[l] = part[l] + part[l ^ off];
+        for (int l = 0; l < L; ++l) part[l] = nxt[l];
+    }
+    return part[0];
+}
+
 // The separable targets evaluated with the L-lane reduction shape of the cooperative kernels, by ONE
 // lane (initial state, setparams): lane l of the shape owns the Philox blocks b = l, l+L, ...; the L
 // partial sums meet in an xor-butterfly with offsets 1, 2, 4, ...  Same arithmetic as
@@ -141,29 +174,7 @@ MHX_DEV mhx_real mhx_target_eval_lanes(int kind, const X& x, const int d, const 
         }
         return mhx_fma(-MHX_R(0.5), part[0], cst);
     }
-    const int nblk = (d + 3) >> 2;
-    for (int l = 0; l < L; ++l) {
-        mhx_real q = MHX_R(0.0);
-        for (int b = l; b < nblk; b += L)
-            for (int j = 0; j < 4; ++j) {
-                const int k = 4 * b + j;
-                if (k >= d) break;
-                const mhx_real v = x[k];
-                if (k_ == MHX_TARGET_BANANA && k == 0) q = (v * v) * MHX_R(0.01);
-                else if (k_ == MHX_TARGET_BANANA && k == 1) {
-                    const mhx_real x0 = x[0];
-                    const mhx_real u = mhx_fma(p[0], mhx_fma(x0, x0, -MHX_R(100.0)), v);
-                    q = mhx_fma(u, u, q);
-                } else if (k_ == MHX_TARGET_FUNNEL && k == 0) {
-                } else q = mhx_fma(v, v, q);
-            }
-        part[l] = q;
-    }
-    for (int off = 1; off < L; off <<= 1) {
-        mhx_real nxt[64];
-        for (int l = 0; l < L; ++l) nxt[l] = part[l] + part[l ^ off];
-        for (int l = 0; l < L; ++l) part[l] = nxt[l];
-    }
+    part[0] = mhx_separable_q_lanes(k_, x, d, p, L);
     const mhx_real q = part[0];
     if (k_ != MHX_TARGET_FUNNEL) return mhx_fma(-MHX_R(0.5), q, cst);
     const mhx_real v = x[0];

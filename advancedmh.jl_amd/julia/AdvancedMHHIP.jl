@@ -42,7 +42,7 @@ struct EmceeCfg
     init_kind::Int32; init_scale::Cdouble; init_vec::Ptr{Cvoid}; init_mean::Ptr{Cvoid}
 end
 struct MalaCfg
-    dim::Int32; nchains::Int32; seed::UInt64; first_chain::UInt64; sigma2::Cdouble; flags::Int32
+    dim::Int32; nchains::Int32; seed::UInt64; first_chain::UInt64; sigma2::Cdouble; flags::Int32; reduce_lanes::Int32
 end
 struct RamCfg
     dim::Int32; nchains::Int32; seed::UInt64; first_chain::UInt64
@@ -182,7 +182,7 @@ function AbstractMCMC.sample(
             prop = sampler.proposal.proposal
             prop isa LangevinProposal || throw(ArgumentError("the GPU path implements MALA(LangevinProposal(σ²)) only"))
             initial_params === nothing && error("please specify initial parameters")   # src/MALA.jl:37
-            cfg = MalaCfg(d, n, seed, ens.first_chain, prop.sigma2, 0)
+            cfg = MalaCfg(d, n, seed, ens.first_chain, prop.sigma2, 0, 0)
             check(ccall((:mhx_mala_create, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{MalaCfg}, Ref{Ptr{Cvoid}}),
                         ctx[], tgt, cfg, run))
         elseif sampler isa AdvancedMH.RobustAdaptiveMetropolis

@@ -59,7 +59,7 @@ class RamCfg(C.Structure):
 
 class MalaCfg(C.Structure):
     _fields_ = [("dim", C.c_int32), ("nchains", C.c_int32), ("seed", C.c_uint64), ("first_chain", C.c_uint64),
-                ("sigma2", C.c_double), ("flags", C.c_int32)]
+                ("sigma2", C.c_double), ("flags", C.c_int32), ("reduce_lanes", C.c_int32)]
 
 
 class Stats(C.Structure):

@@ -461,7 +461,7 @@ class Run:
             self.n = sampler.n_walkers
             self.kind = "emcee"
         elif isinstance(sampler, MALA):
-            cfg = L.MalaCfg(d, nchains, seed, first_chain, sampler.sigma2, flags)
+            cfg = L.MalaCfg(d, nchains, seed, first_chain, sampler.sigma2, flags, reduce_lanes)
             L.check(lib.mhx_mala_create(self.ctx.h, model.handle(self.ctx), C.byref(cfg), C.byref(self.h)))
             self.n = nchains
             self.kind = "mala"

@@ -195,6 +195,8 @@ typedef struct {
     uint64_t first_chain;
     double sigma2;
     int32_t flags;
+    int32_t reduce_lanes;   /* lanes per chain (separable catalogue targets): 0 = engine's choice, 1 = one lane per chain; the
+                               value in effect (mhx_stats.reduce_lanes) fixes the summation order of the three sums of a step */
 } mhx_mala_cfg;
 
 int mhx_mala_create(mhx_ctx *ctx, const mhx_target *t, const mhx_mala_cfg *cfg, mhx_run **out);

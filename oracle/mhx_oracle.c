@@ -950,6 +950,31 @@ int orc_ram(const orc_target *t, const orc_ram_cfg *cfg, const orc_schedule *s,
 real orc_target_grad(const orc_target *t, const real *x, real *g, orc_logdensity_grad_fn user)
 {
     const int d = t->dim;
+    if (t->reduce_lanes > 1 && (t->kind == ORC_TARGET_ISO_GAUSS || t->kind == ORC_TARGET_BANANA || t->kind == ORC_TARGET_FUNNEL)) {
+        /* the cooperative kernel's reduction shape: the sum of squares comes from the lane partial sums + butterfly, the
+         * gradient is element-wise from it */
+        const real q = split_sum_squares(t, x);
+        if (t->kind == ORC_TARGET_ISO_GAUSS) {
+            for (int k = 0; k < d; ++k) g[k] = -x[k];
+            return FMA(-R(0.5), q, target_const(t));
+        }
+        if (t->kind == ORC_TARGET_BANANA) {
+            const real b = t->params[0], x0 = x[0];
+            const real u = FMA(b, FMA(x0, x0, -R(100.0)), x[1]);
+            g[0] = -(FMA(x0, R(0.01), (R(2.0) * b) * (u * x0)));
+            g[1] = -u;
+            for (int k = 2; k < d; ++k) g[k] = -x[k];
+            return FMA(-R(0.5), q, target_const(t));
+        }
+        const real v = x[0];
+        const real ev = orc_exp(-v);
+        real r = (v * v) * ONE_18;
+        r = FMA(R(0.5) * (real)(d - 1), v, r);
+        r = FMA(R(0.5) * ev, q, r);
+        g[0] = FMA(R(0.5) * ev, q, -(FMA(v, ONE_9, R(0.5) * (real)(d - 1))));
+        for (int k = 1; k < d; ++k) g[k] = -(ev * x[k]);
+        return target_const(t) - r;
+    }
     switch (t->kind) {
     case ORC_TARGET_ISO_GAUSS:
         for (int k = 0; k < d; ++k) g[k] = -x[k];
@@ -1035,8 +1060,9 @@ int orc_mala(const orc_target *t, orc_logdensity_grad_fn user, real sigma2, cons
     const real sigma = SQRT(sigma2);
     const real h = (sigma * sigma) * R(0.5);              /* drift step sigma2/2 */
     const real hs = R(0.5) * sigma;
-    real *x = malloc(sizeof(real) * (size_t)d * 5);
-    real *gx = x + d, *y = gx + d, *gy = y + d, *z = gy + d;
+    real *x = malloc(sizeof(real) * (size_t)d * 6);
+    real *gx = x + d, *y = gx + d, *gy = y + d, *z = gy + d, *tk = z + d;
+    const int Lw = t->reduce_lanes;                      /* reduction shape of the three sums of a step */
     for (int c = 0; c < C; ++c) {
         const uint64_t id = first_chain + (uint64_t)c;
         for (int k = 0; k < d; ++k) x[k] = init[(size_t)k * C + c];
@@ -1047,17 +1073,11 @@ int orc_mala(const orc_target *t, orc_logdensity_grad_fn user, real sigma2, cons
         for (int64_t tau = 1; tau <= nT; ++tau) {
             const uint32_t step = (uint32_t)tau;
             orc_normals(seed, id, step, ORC_STREAM_PROPOSAL, d, z);
-            real fwd = R(0.0);
-            for (int k = 0; k < d; ++k) {
-                y[k] = FMA(sigma, z[k], FMA(h, gx[k], x[k]));
-                fwd = FMA(z[k], z[k], fwd);
-            }
+            for (int k = 0; k < d; ++k) y[k] = FMA(sigma, z[k], FMA(h, gx[k], x[k]));
+            const real fwd = lanes_sumsq(z, NULL, d, Lw);
             const real lpy = orc_target_grad(t, y, gy, user);
-            real bwd = R(0.0);
-            for (int k = 0; k < d; ++k) {
-                const real tk = FMA(hs, gx[k] + gy[k], z[k]);
-                bwd = FMA(tk, tk, bwd);
-            }
+            for (int k = 0; k < d; ++k) tk[k] = FMA(hs, gx[k] + gy[k], z[k]);
+            const real bwd = lanes_sumsq(tk, NULL, d, Lw);
             const real loga = (lpy - lp) + R(0.5) * (fwd - bwd);
             const real logu = orc_accept_logu(seed, id, step);
             const int acc = logu < loga;

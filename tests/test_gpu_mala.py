@@ -49,6 +49,56 @@ def test_mala_bit_exact(mhx, oracle, name, real):
     _same(cnt, ref["accept_counts"], "accept counts")
 
 
+@pytest.mark.parametrize("name", ["iso", "banana", "funnel"])
+@pytest.mark.parametrize("d,lanes", [(7, 2), (100, 0), (100, 4), (61, 8), (300, 0), (1000, 64)])
+def test_mala_cooperative_kernel_bit_exact(mhx, oracle, name, d, lanes, real):
+    """MALA on the cooperative kernel (L lanes per chain, state / gradient / candidate / noise in registers) for the separable
+    catalogue targets: above the register kernel's dimension budget by default, or where reduce_lanes asks for it.  The
+    target's sum of squares and the two sums of the proposal ratio take the reduction shape L; bit-exact against the oracle
+    with the same shape, recorded with discard / thinning, continued, and after setparams (lp and gradient re-evaluated)."""
+    nblk = (d + 3) // 4
+    if lanes and -(-nblk // lanes) > (4 if real == "f64" else 8):
+        pytest.skip("more blocks per lane than the cooperative MALA kernel holds in registers")
+    rng = np.random.default_rng(d)
+    C, N = 70, 9
+    spec, ot = {"iso": (mhx.IsoGaussian(d), oracle.iso_gauss(d)),
+                "banana": (mhx.Banana(d, 0.03), oracle.Target(oracle.TARGET_BANANA, d, params=[0.03])),
+                "funnel": (mhx.Funnel(d), oracle.Target(oracle.TARGET_FUNNEL, d))}[name]
+    s2 = float(np.float32(0.3 / d ** (1 / 3)))
+    init = (rng.normal(size=(d, C)) * 0.3).astype(np.float32)
+    run = mhx.Run(mhx.DensityModel(spec), mhx.MALA(s2), nchains=C, seed=8, first_chain=5, reduce_lanes=lanes)
+    run.init(init)
+    run.sample(N, 2, 2, 0)
+    st = run.stats()
+    L = st["reduce_lanes"]
+    if lanes > 1 or (lanes == 0 and d > (24 if real == "f64" else 48)):
+        assert st["kernel_variant"] == 4 and (lanes == 0 or L == lanes) and L > 1
+    ref = oracle.mala(ot.with_lanes(L), s2, oracle.schedule(N, 2, 2), 8, 5, C, init)
+    got, acc = run.samples()
+    _same(got, ref["samples"], "samples (%d lanes)" % L)
+    _same(acc, ref["accepted"], "accepted")
+    assert name != "iso" or acc[1:].mean() > 0.05
+    x, lp, cnt = run.state()
+    _same(x, ref["final_x"], "final x")
+    _same(lp, ref["final_lp"], "final lp")
+    _same(cnt, ref["accept_counts"], "accept counts")
+    x2 = (rng.normal(size=(d, C)) * 0.2).astype(np.float32)
+    run.set_params(x2)                                        # src/MALA.jl:27-35: lp and gradient are recomputed
+    run.sample(4, 1, 1, 0)
+    # the continuation of a chain restarted at x2 with the step counter where the run stands: compare through a second run
+    run2 = mhx.Run(mhx.DensityModel(spec), mhx.MALA(s2), nchains=C, seed=8, first_chain=5, reduce_lanes=1, flags=mhx.FLAG_GENERIC)
+    run2.init(init)
+    run2.sample(N, 2, 2, 0)
+    run2.set_params(x2)
+    run2.sample(4, 1, 1, 0)
+    if L == 1:
+        _same(run.samples()[0], run2.samples()[0], "after setparams")
+    else:                                                     # different reduction shapes: same chain up to rounding
+        assert np.allclose(run.samples()[0], run2.samples()[0], rtol=1e-3 if real == "f32" else 1e-9, atol=1e-3 if real == "f32" else 1e-9)
+    run.close()
+    run2.close()
+
+
 def test_mala_reference_tests(mhx, oracle, real):
     """test/runtests.jl:288-332 (basic) and :334-365 (issue #95)."""
     data = np.load(os.path.join(GOLD, "c1_normal_data.npy"))
