@@ -705,6 +705,7 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
                                              "MHX_JIT_TK=" + std::to_string(tk), "MHX_JIT_PK=" + std::to_string(pk), "MHX_JIT_MOM=0",
                                              "MHX_JIT_WALK=" + std::to_string(walk)};
             if (waves_override > 0) defs.push_back("MHX_JIT_WAVES=" + std::to_string(waves_override));
+            if (const char* il = getenv("MHX_COOP_INTERLEAVE")) defs.push_back(std::string("MHX_COOP_INTERLEAVE=") + il);   // tuning knob
             rc = jit_compile(ctx, key + "/mom=0", jit_source(t, "mhx_rwmh_kernels.h"), defs, &m);
             if (rc == MHX_OK) rc = jit_function(m, "mhx_jit_rwmh_coop", &r->jit_step);
             if (rc == MHX_OK) r->variant = 4;

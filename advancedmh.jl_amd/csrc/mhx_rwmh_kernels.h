@@ -481,7 +481,11 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
             }
             // keep the blocks in program order: with >= 2 waves per SIMD the other wave provides the
             // latency hiding, and interleaving blocks only inflates the live register set
+#ifndef MHX_COOP_INTERLEAVE
             __builtin_amdgcn_sched_barrier(0);
+#else
+            if ((i % MHX_COOP_INTERLEAVE) == MHX_COOP_INTERLEAVE - 1) __builtin_amdgcn_sched_barrier(0);
+#endif
         }
 #pragma unroll
         for (int off = 1; off < L; off <<= 1) q = q + __shfl_xor(q, off * CPW, 64);
