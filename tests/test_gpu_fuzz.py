@@ -145,8 +145,8 @@ def test_mala_random_configurations(mhx, oracle, case, real):
     seed, first = int(rng.integers(1, 1 << 40)), int(rng.integers(0, 1 << 20))
     chain = mhx.sample(mhx.DensityModel(tgt), mhx.MALA(s2), N, C, seed=seed, first_chain=first, initial_params=init,
                        discard_initial=di, thinning=th)
-    ref = oracle.mala(ot, s2, oracle.schedule(N, di, th), seed, first, C, init)
-    what = "case %d: d=%d C=%d %s" % (case, d, C, tname)
+    ref = oracle.mala(ot.with_lanes(chain.stats["reduce_lanes"]), s2, oracle.schedule(N, di, th), seed, first, C, init)
+    what = "case %d: d=%d C=%d %s, %d lane(s)" % (case, d, C, tname, chain.stats["reduce_lanes"])
     _same(chain.value, ref["samples"], what)
     _same(chain.accepted, ref["accepted"], what)
 
@@ -184,4 +184,4 @@ def test_dimensions_beyond_the_specialised_kernels(mhx, oracle, real):
     d, C = 500, 100
     init = (np.random.default_rng(1).normal(size=(d, C)) * 0.1).astype(np.float32)
     ch = mhx.sample(mhx.DensityModel(mhx.IsoGaussian(d)), mhx.MALA(0.01), 4, C, seed=6, initial_params=init)
-    same(ch.value, oracle.mala(oracle.iso_gauss(d), 0.01, oracle.schedule(4), 6, 0, C, init)["samples"], "mala d=500")
+    same(ch.value, oracle.mala(oracle.iso_gauss(d, reduce_lanes=ch.stats["reduce_lanes"]), 0.01, oracle.schedule(4), 6, 0, C, init)["samples"], "mala d=500")
