@@ -24,6 +24,7 @@
 #include "mhx_ram_kernels.h"
 #include "mhx_mala_kernels.h"
 #include "mhx_rwmh_dense_kernels.h"
+#include "mhx_rwmh_mfma_kernels.h"
 #include "mhx_diag_kernels.h"
 #include "mhx_jit_embed.inc"   // generated: the device headers as string literals for hiprtc
 #include "mhx_impl.h"           // the prototypes of this instantiation (api_*), shared with the dispatcher mhx_abi.cpp
@@ -197,11 +198,11 @@ static int jit_compile(mhx_ctx* ctx, const std::string& key, const std::string& 
     hiprtcProgram prog = nullptr;
     const char* hdr_src[] = {k_src_mhx_device_math_h, k_src_mhx_targets_h, k_src_mhx_rwmh_kernels_h,
                              k_src_mhx_emcee_kernels_h, k_src_mhx_ram_kernels_h, k_src_mhx_mala_kernels_h,
-                             k_src_mhx_rwmh_dense_kernels_h};
+                             k_src_mhx_rwmh_dense_kernels_h, k_src_mhx_rwmh_mfma_kernels_h};
     const char* hdr_name[] = {"mhx_device_math.h", "mhx_targets.h", "mhx_rwmh_kernels.h",
                               "mhx_emcee_kernels.h", "mhx_ram_kernels.h", "mhx_mala_kernels.h",
-                              "mhx_rwmh_dense_kernels.h"};
-    hiprtcResult r = hiprtcCreateProgram(&prog, source.c_str(), "mhx_jit.hip", 7, hdr_src, hdr_name);
+                              "mhx_rwmh_dense_kernels.h", "mhx_rwmh_mfma_kernels.h"};
+    hiprtcResult r = hiprtcCreateProgram(&prog, source.c_str(), "mhx_jit.hip", 8, hdr_src, hdr_name);
     if (r != HIPRTC_SUCCESS) return mhx_fail(MHX_EJIT, "hiprtcCreateProgram: %s", hiprtcGetErrorString(r));
     std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
                                      MHX_REAL64 ? "-DMHX_REAL64=1" : "-DMHX_REAL64=0"};
@@ -567,6 +568,28 @@ static bool dense_coop_fits(int d, int L, int nimages)
     return dense_coop_lds_bytes(d, L, nimages) <= MHX_LDS_PER_BLOCK;
 }
 
+// the matrix-core kernel (mhx_rwmh_mfma_kernels.h): 4 lanes per chain, NS = ceil(d/4) reals of state and of candidate per
+// lane, `nimages` operand images in LDS
+#define MHX_MFMA_MAX_NS (MHX_REAL64 ? 44 : 64)
+static size_t mfma_image_reals(int d)
+{
+    const int NS = (d + 3) / 4, NT = (d + 15) / 16;
+    const int last = std::min(4 * NT, NS);
+    return (size_t)(2 * (NT - 1) * NT + 4 * ((last + 3) / 4)) * 64;
+}
+static bool mfma_fits(int d, int reduce_lanes, int nimages)
+{
+    const char* no_mfma = getenv("MHX_NO_MFMA");                      // tuning knob: the vector kernel instead
+    return (reduce_lanes == 0 || reduce_lanes == 4) && d >= 16 && (d + 3) / 4 <= MHX_MFMA_MAX_NS && !(no_mfma && atoi(no_mfma)) &&
+           nimages * mfma_image_reals(d) * sizeof(mhx_real) <= MHX_LDS_PER_BLOCK;
+}
+static int mfma_waves(int d)
+{
+    const int NS = (d + 3) / 4;
+    if (const char* w = getenv("MHX_MFMA_WAVES")) return std::max(1, atoi(w));        // tuning knob
+    return MHX_REAL64 ? (NS <= 25 ? 2 : 1) : (NS <= 25 ? 3 : (NS <= 40 ? 2 : 1));
+}
+
 int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, mhx_run** out)
 {
     if (!ctx || !t || !cfg || !out) return mhx_fail(MHX_EINVAL, "mhx_rwmh_create: NULL argument");
@@ -657,14 +680,37 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
     } else if (((tk == MHX_TARGET_CORR_GAUSS) || (tk == MHX_TARGET_ISO_GAUSS && pk == MHX_PROP_DENSE)) &&
                !walk && !(r->flags & (MHX_FLAG_GENERIC | MHX_FLAG_NO_JIT)) && d >= 2 && d <= MHX_DENSE_COOP_MAX_DIM &&
                (cfg->reduce_lanes > 1 || (cfg->reduce_lanes == 0 && d >= 16)) &&
-               dense_coop_fits(d, cfg->reduce_lanes > 1 ? cfg->reduce_lanes : dense_coop_lanes(d),
-                               (tk == MHX_TARGET_CORR_GAUSS ? 1 : 0) + (pk == MHX_PROP_DENSE ? 1 : 0))) {
+               (mfma_fits(d, cfg->reduce_lanes, (tk == MHX_TARGET_CORR_GAUSS ? 1 : 0) + (pk == MHX_PROP_DENSE ? 1 : 0)) ||
+                dense_coop_fits(d, cfg->reduce_lanes > 1 ? cfg->reduce_lanes : dense_coop_lanes(d),
+                                (tk == MHX_TARGET_CORR_GAUSS ? 1 : 0) + (pk == MHX_PROP_DENSE ? 1 : 0)))) {
         // a dense factor in play (dense Gaussian target, dense proposal, or both): the cooperative kernel of
         // mhx_rwmh_dense_kernels.h (L lanes per chain, factor images in LDS).  Lanes per chain by default: at most
         // 12.5 rows per lane (measured at 65 536 chains, dense target: d = 32 / 50 / 64 / 100 / 128 run 1.8e10 /
         // 8.5e9 / 6.8e9 / 2.9e9 / 2.0e9 steps/s; the lane-per-chain register kernel 1.4e10 / 7.2e9 / 4.9e9 / - / -;
         // more rows per lane than ~16 spill)
+        // ONE factor for all chains makes the row products a GEMM over the chains of a wave: the matrix-core kernel
+        // (reduction shape L = 4, bit-identical to the vector kernel in that shape) wherever its images and state fit
+        const int nimg = (tk == MHX_TARGET_CORR_GAUSS ? 1 : 0) + (pk == MHX_PROP_DENSE ? 1 : 0);
+        if (mfma_fits(d, cfg->reduce_lanes, nimg)) {
+            jit_module* m = nullptr;
+            const int waves = mfma_waves(d);
+            const std::string key = "rwmh_mfma/d=" + std::to_string(d) + "/pk=" + std::to_string(pk) + "/tk=" + std::to_string(tk) +
+                                    "/w=" + std::to_string(waves);
+            rc = jit_compile(ctx, key, jit_source(t, "mhx_rwmh_mfma_kernels.h"),
+                             {"MHX_JIT_RWMH_MFMA=1", "MHX_JIT_DIM=" + std::to_string(d), "MHX_JIT_PK=" + std::to_string(pk),
+                              "MHX_JIT_TK=" + std::to_string(tk), "MHX_JIT_WAVES=" + std::to_string(waves)}, &m);
+            if (rc == MHX_OK) rc = jit_function(m, "mhx_jit_rwmh_mfma", &r->jit_step);
+            if (rc == MHX_OK) {
+                r->dense_lds = nimg * mfma_image_reals(d) * sizeof(mhx_real);
+                if (hipFuncSetAttribute((const void*)r->jit_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->dense_lds) != hipSuccess)
+                    rc = mhx_fail(MHX_EHIP, "matrix-core kernel: %zu bytes of LDS refused", r->dense_lds);
+            }
+            if (rc == MHX_OK) { r->variant = 8; r->coop_L = 4; }
+        }
         L = cfg->reduce_lanes > 1 ? cfg->reduce_lanes : dense_coop_lanes(d);
+        if (r->variant == 8 || !dense_coop_fits(d, L, nimg)) {
+            L = 1;
+        } else {
         if (L > 64 || (L & (L - 1)) || L > d) return mhx_fail(MHX_EINVAL, "reduce_lanes must be a power of two <= min(64, dim), got %d", L);
         jit_module* m = nullptr;
         const std::string key = "rwmh_dense/d=" + std::to_string(d) + "/l=" + std::to_string(L) + "/pk=" + std::to_string(pk) +
@@ -681,6 +727,7 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
         if (rc == MHX_OK) { r->variant = 5; r->coop_L = L; }
         else if (cfg->reduce_lanes > 1) return rc;
         L = 1;                                                        // not the separable cooperative path below
+        }
     } else if (cfg->reduce_lanes > 1) {
         return mhx_fail(MHX_EINVAL, "reduce_lanes > 1 needs a separable catalogue target or the dense Gaussian target "
                                 "(dim <= 128, JIT), and an ISO/DIAG proposal");
@@ -819,6 +866,11 @@ static int rwmh_advance(mhx_run* r, uint64_t nsteps, uint32_t save_next, int sav
                 int rc = launch_module(r->jit_step, grid, 256, ctx->stream, params);
                 if (rc) return rc;
             }
+        } else if (r->variant == 8) {
+            const unsigned grid = (unsigned)(((long)r->n + 16 * MHX_MFMA_WAVES - 1) / (16 * MHX_MFMA_WAVES));
+            void* params[] = {&a, &tp, &pv};
+            HIP_TRY(hipModuleLaunchKernel(r->jit_step, grid, 1, 1, 64 * MHX_MFMA_WAVES, 1, 1, (unsigned)r->dense_lds,
+                                          ctx->stream, params, nullptr));
         } else if (r->variant == 5) {
             const long per_block = (64 / r->coop_L) * MHX_EMCEE_COOP_WAVES;          // chains per block
             const unsigned grid = (unsigned)(((long)r->n + per_block - 1) / per_block);

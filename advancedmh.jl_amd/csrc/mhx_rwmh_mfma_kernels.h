@@ -1,0 +1,314 @@
+// mhx_rwmh_mfma_kernels.h -- random-walk Metropolis with a dense factor shared by all chains, on the matrix cores.
+//
+// With ONE factor for every chain -- the dense Gaussian target's A = inv(chol(Sigma)), a dense proposal's Cholesky
+// factor, or both -- the row products A y of the chains of a wave are a real GEMM: [16 rows] x [16 chains] tiles of
+// v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64.  The f32-input (and the f64) MFMA is an exact fma chain in k order --
+// D = fma(a_k3, b_k3, fma(a_k2, b_k2, fma(a_k1, b_k1, fma(a_k0, b_k0, C)))), one rounding per product -- so the
+// accumulator of row i after the k-steps 0 .. i/4 IS the arithmetic spec's w_i = sum_{j<=i} A_ij y_j (ascending j, fma from
+// 0; the zeros of the upper triangle add nothing): bit for bit the chain of mhx_rwmh_dense_kernels.h and of the oracle.
+// What the matrix pipe buys is not flops (its f32 / f64 rate equals the vector rate) but operands: one 4-byte A operand
+// per lane feeds 4 x 16 x 16 multiply-adds where the vector kernel reads one LDS value per lane per fma, and the MFMAs
+// run beside the VALU's Philox / Box-Muller work instead of competing with it for issue slots.
+//
+// Geometry.  A wave holds 16 chains; chain j = lane & 15 is spread over the four lanes g = lane >> 4:
+//   * lane g owns the dimensions k = 4s + g (s = 0 .. NS-1): exactly the B operand of k-step s (B[k = lane>>4][j]),
+//     so the candidate feeds the MFMAs from registers -- no LDS round trip for y;
+//   * the C/D fragment gives lane g the rows {4g + r} (f32) or {g + 4r} (f64) of a 16-row tile; the A image permutes
+//     the f32 rows so that both widths hold rows i = 16t + 4r + g in accumulator r -- the oracle's reduction shape
+//     L = 4 (lane g owns rows g, g+4, ...; partial sums meet in the xor butterfly 1, 2 = lanes ^16, ^32);
+//   * the same fragment is the dense proposal's xi = L z: row 16t + 4r + g lands on the lane that owns dimension
+//     4(4t+r) + g.
+// Proposal noise: a Philox "normal4" block is 4 consecutive dimensions = one per lane of a chain; lane g draws the
+// blocks b = g, g+4, ... and a 4x4 transpose over the chain's lanes (v_permlane32_swap + v_permlane16_swap) hands every
+// normal to its owner -- each block is drawn once.
+//
+// Same step as mhx_rwmh_reg_body (src/mh-core.jl:92-117; proposal src/proposal.jl:49-56).
+#pragma once
+#include "mhx_rwmh_kernels.h"
+
+MHX_NS_BEGIN
+
+#define MHX_MFMA_WAVES 4                          // waves per block (64 chains)
+
+#if MHX_REAL64
+typedef double mhx_acc4 __attribute__((ext_vector_type(4)));
+#define MHX_MFMA16(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+#else
+typedef float mhx_acc4 __attribute__((ext_vector_type(4)));
+#define MHX_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#endif
+
+// The operand image of a packed lower-triangular factor: for tile t (rows 16t .. 16t+15) the k-steps s = 0 .. S(t)-1
+// with S(t) = min(4(t+1), NS), padded to whole groups of 4 steps; a group holds, per lane, the 4 A operands of its
+// steps contiguously (one 16-byte LDS read in fp32, two in fp64).  Tile t starts at step 2t(t+1).
+template <int D>
+struct mhx_mfma_geom {
+    static constexpr int NS = (D + 3) / 4;                        // k-steps = reals of state per lane
+    static constexpr int NT = (D + 15) / 16;                      // row tiles
+    static constexpr int steps(int t) { return 4 * (t + 1) < NS ? 4 * (t + 1) : NS; }
+    static constexpr int groups(int t) { return (steps(t) + 3) / 4; }
+    static constexpr int first(int t) { return 2 * t * (t + 1); }
+    static constexpr int TOTAL = first(NT - 1) + 4 * groups(NT - 1);    // steps in the image
+    static constexpr long REALS = (long)TOTAL * 64;
+};
+
+// matrix row behind MFMA row m of tile t: the permutation that puts row 16t + 4r + g into accumulator r of lane group g
+MHX_DEV int mhx_mfma_row(int t, int m)
+{
+#if MHX_REAL64
+    return 16 * t + m;                              // C/D row = g + 4r
+#else
+    return 16 * t + 4 * (m & 3) + (m >> 2);        // C/D row = 4g + r
+#endif
+}
+
+template <int D>
+MHX_DEV void mhx_mfma_image_fill(const mhx_real* __restrict__ A, mhx_real* img)
+{
+    typedef mhx_mfma_geom<D> GEO;
+    for (int e = threadIdx.x; e < GEO::TOTAL * 64; e += blockDim.x) {
+        const int sg = e >> 6, ln = e & 63;
+        int t = 0;
+        while (t + 1 < GEO::NT && GEO::first(t + 1) <= sg) ++t;
+        const int s = sg - GEO::first(t);
+        const int i = mhx_mfma_row(t, ln & 15);
+        const int k = 4 * s + (ln >> 4);
+        const bool in = i < D && k <= i;
+        const mhx_real v = A[in ? (long)i * (i + 1) / 2 + k : 0];
+        img[(GEO::first(t) + (s & ~3)) * 64 + ln * 4 + (s & 3)] = in ? v : MHX_R(0.0);
+    }
+}
+
+// rows of `factor image` x `b`, two tiles at a time (two independent accumulator chains keep the matrix pipe issuing:
+// a dependent 16x16x4 MFMA waits 40 cycles, the issue interval is 32).  Component r of tile t's fragment is row
+// 16t + 4r + g.  SQ: fold the rows into q = fma(w, w, q) in ascending row order; else: store them in out[4t + r].
+template <int D, bool SQ>
+MHX_DEV void mhx_mfma_rows(const mhx_real* img, const int lane, const mhx_real (&b)[mhx_mfma_geom<D>::NS],
+                           mhx_real& q, mhx_real (&out)[mhx_mfma_geom<D>::NS])
+{
+    typedef mhx_mfma_geom<D> GEO;
+#pragma unroll
+    for (int t0 = 0; t0 < GEO::NT; t0 += 2) {
+        constexpr mhx_acc4 zero = {MHX_R(0.0), MHX_R(0.0), MHX_R(0.0), MHX_R(0.0)};
+        mhx_acc4 c[2] = {zero, zero};
+        const int t1 = t0 + 1 < GEO::NT ? t0 + 1 : t0;
+#pragma unroll
+        for (int grp = 0; grp < GEO::groups(t1); ++grp) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int t = t0 + h;
+                if (t < GEO::NT && grp < GEO::groups(t)) {
+                    const mhx_acc4 a4 = ((const mhx_acc4*)img)[(GEO::first(t) / 4 + grp) * 64 + lane];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (4 * grp + u < GEO::steps(t)) c[h] = MHX_MFMA16(a4[u], b[4 * grp + u], c[h]);
+                }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int t = t0 + h;
+            if (t < GEO::NT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (SQ) q = mhx_fma(c[h][r], c[h][r], q);
+                    else if (4 * t + r < GEO::NS) out[4 * t + r] = c[h][r];
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);            // keep the operand loads of later tiles out of this pair's registers
+    }
+}
+
+// 4x4 transpose over the four lanes of a chain (lanes j, j+16, j+32, j+48): lane g gives n[e] to lane e and receives
+// that lane's n[g].  v_permlane32_swap exchanges lanes 32-63 of its first operand with lanes 0-31 of the second,
+// v_permlane16_swap the odd 16-lane rows of the first with the even rows of the second.
+MHX_DEV void mhx_swap32(mhx_u32& a, mhx_u32& b)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0]; b = r[1];
+}
+MHX_DEV void mhx_swap16(mhx_u32& a, mhx_u32& b)
+{
+    const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    a = r[0]; b = r[1];
+}
+MHX_DEV void mhx_lanes4_transpose(mhx_real (&n)[4])
+{
+#if MHX_REAL64
+    mhx_u32 lo[4], hi[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const mhx_u64 w = (mhx_u64)__double_as_longlong(n[e]); lo[e] = (mhx_u32)w; hi[e] = (mhx_u32)(w >> 32); }
+    mhx_swap32(lo[0], lo[2]); mhx_swap32(hi[0], hi[2]);
+    mhx_swap32(lo[1], lo[3]); mhx_swap32(hi[1], hi[3]);
+    mhx_swap16(lo[0], lo[1]); mhx_swap16(hi[0], hi[1]);
+    mhx_swap16(lo[2], lo[3]); mhx_swap16(hi[2], hi[3]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) n[e] = __longlong_as_double((long long)(((mhx_u64)hi[e] << 32) | lo[e]));
+#else
+    mhx_u32 w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = __float_as_uint(n[e]);
+    mhx_swap32(w[0], w[2]);
+    mhx_swap32(w[1], w[3]);
+    mhx_swap16(w[0], w[1]);
+    mhx_swap16(w[2], w[3]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) n[e] = __uint_as_float(w[e]);
+#endif
+}
+
+// TK: MHX_TARGET_CORR_GAUSS (factor image A) or MHX_TARGET_ISO_GAUSS (with a dense proposal); PK: ISO / DIAG scales, or
+// DENSE -- the proposal's Cholesky factor as a second image.
+template <int D, int PK, int TK>
+MHX_DEV void mhx_rwmh_mfma_body(const mhx_rwmh_args& a, const mhx_real* __restrict__ A, const mhx_real* __restrict__ pvec,
+                                mhx_real* Aimg, mhx_real* Limg)
+{
+    typedef mhx_mfma_geom<D> GEO;
+    constexpr bool CORR = TK == MHX_TARGET_CORR_GAUSS;
+    constexpr bool DENSEP = PK == MHX_PROP_DENSE;
+    constexpr int NS = GEO::NS;
+    constexpr int NQD = (NS + 3) / 4;                 // quads of normal4 blocks (block b = dimensions 4b .. 4b+3)
+    if (CORR) mhx_mfma_image_fill<D>(A, Aimg);
+    if (DENSEP) mhx_mfma_image_fill<D>(pvec, Limg);
+    __syncthreads();
+
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15;
+    const int g = lane >> 4;
+    const long c_raw = ((long)blockIdx.x * MHX_MFMA_WAVES + wave) * 16 + j;
+    const bool valid = c_raw < a.nchains;
+    const long c = valid ? c_raw : (long)a.nchains - 1;      // idle groups shadow the last chain (loads only)
+    const long ld = a.ld;
+    const mhx_u64 id = a.first_chain + (mhx_u64)c;
+    const mhx_u32 id_lo = (mhx_u32)id, id_hi = (mhx_u32)(id >> 32);
+    const mhx_philox_key ks = mhx_philox_schedule(a.seed);
+
+    // rows 4s of a [dim][ld] slab are wave-uniform (SGPR offsets); the lane adds (g ld + c) reals -- the register /
+    // cooperative kernels only run on slabs below 4 GB
+    const mhx_u32 lane_off = ((mhx_u32)g * (mhx_u32)ld + (mhx_u32)c) * MHX_RB;
+    const mhx_u32 ldb = (mhx_u32)ld * MHX_RB;
+    // ---- state: dimensions 4s + g (ABI layout [dim][ld], touched once per launch); the pad stays zero
+    mhx_real xs[NS], sc[PK == MHX_PROP_DIAG ? NS : 1];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int k = 4 * s + g;
+        const bool in = 4 * s + 3 < D || k < D;              // only the last slot can fall into the pad
+        xs[s] = in ? mhx_ld_off(a.x + (long)(4 * s) * ld, lane_off) : MHX_R(0.0);
+        if (PK == MHX_PROP_DIAG) sc[s] = in ? pvec[k] : MHX_R(0.0);
+    }
+    mhx_real lp = a.lp[c];
+    mhx_u32 nacc = a.acc_count[c];
+    mhx_u32 wave_acc = 0;
+    bool last = a.last_acc[c] != 0;
+    mhx_accept_cache ac;
+    ac.group = 0xffffffffu;
+    ac.w.x = ac.w.y = ac.w.z = ac.w.w = 0u;
+    mhx_u32 save_next = a.save_next;
+    long slot = a.save_slot;
+
+    for (int it = 0; it < a.nsteps; ++it) {
+        const mhx_u32 step = a.step0 + (mhx_u32)it;
+        asm volatile("" ::: "memory");        // the factor images are re-read from LDS every step, not kept in registers
+        // ---- proposal noise: lane g draws the blocks 4qd + g, the transpose leaves z of dimension 4(4qd + e) + g in n[e]
+        mhx_real ys[NS];
+#pragma unroll
+        for (int qd = 0; qd < NQD; ++qd) {
+            mhx_real n[4];
+            mhx_normal4(ks, id_lo, id_hi, step, MHX_STREAM_PROPOSAL, (mhx_u32)(4 * qd + g), n);
+            mhx_lanes4_transpose(n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int s = 4 * qd + e;
+                if (s < NS) {                                                              // src/proposal.jl:49-56
+                    const bool in = 4 * s + 3 < D || 4 * s + g < D;
+                    if (DENSEP) ys[s] = in ? n[e] : MHX_R(0.0);
+                    else if (PK == MHX_PROP_DIAG) ys[s] = mhx_fma(sc[s], n[e], xs[s]);
+                    else ys[s] = in ? mhx_fma(a.pscale, n[e], xs[s]) : MHX_R(0.0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);        // one block of normals in flight at a time (register pressure)
+        }
+        if (DENSEP) {
+            // xi = L z by rows (ascending j, fma from 0); row 16t + 4r + g = dimension 4(4t + r) + g: this lane's
+            mhx_real xi[NS], unused = MHX_R(0.0);
+            mhx_mfma_rows<D, false>(Limg, lane, ys, unused, xi);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) ys[s] = (4 * s + 3 < D || 4 * s + g < D) ? xs[s] + xi[s] : MHX_R(0.0);
+        }
+        // ---- lp': dense Gaussian -1/2 |A y|^2 + const, rows g, g+4, ... by this lane; butterfly over the chain's lanes
+        mhx_real q = MHX_R(0.0);
+        if (CORR) {
+            mhx_real unused[NS];
+            mhx_mfma_rows<D, true>(Aimg, lane, ys, q, unused);
+        } else {
+            // isotropic target in the reduction shape L = 4 of the cooperative kernels: lane g owns the BLOCKS g, g+4, ...
+            // -- transpose the candidate back to blocks
+#pragma unroll
+            for (int qd = 0; qd < NQD; ++qd) {
+                mhx_real n[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) n[e] = 4 * qd + e < NS ? ys[4 * qd + e] : MHX_R(0.0);
+                mhx_lanes4_transpose(n);                       // n[e] = y of dimension 4(4qd + g) + e
+#pragma unroll
+                for (int e = 0; e < 4; ++e) q = mhx_fma(n[e], n[e], q);      // the pad is zero
+            }
+        }
+        q = q + __shfl_xor(q, 16, 64);
+        q = q + __shfl_xor(q, 32, 64);
+        const mhx_real lpy = mhx_fma(-MHX_R(0.5), q, a.tconst);
+        // ---- accept (src/mh-core.jl:104-114); a zero-mean random walk has no Hastings term
+        const mhx_real logu = mhx_accept_logu(ks, id_lo, id_hi, step, ac);
+        const bool acc = logu < (lpy - lp);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) xs[s] = acc ? ys[s] : xs[s];
+        lp = acc ? lpy : lp;
+        nacc += acc ? 1u : 0u;
+        last = acc;
+        wave_acc += (mhx_u32)__popcll(__ballot(acc && valid && g == 0));
+        if (step == save_next) {                                         // wave-uniform
+            if (valid) {
+                mhx_real* slotp = a.samples + slot * (long)(D + 1) * ld;
+                const mhx_srd srd = mhx_make_srd(slotp, (mhx_u32)(D + 1) * (mhx_u32)ld * MHX_RB);
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+                    if (4 * s + 3 < D || 4 * s + g < D) mhx_srd_store(srd, lane_off, (mhx_u32)(4 * s) * ldb, xs[s]);
+                if (g == 0) {
+                    slotp[(long)D * ld + c] = lp;
+                    a.accepted[slot * ld + c] = acc ? 1 : 0;
+                }
+            }
+            save_next += (mhx_u32)a.thinning;
+            ++slot;
+        }
+    }
+    if (valid) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            if (4 * s + 3 < D || 4 * s + g < D) mhx_st_off(a.x + (long)(4 * s) * ld, lane_off, xs[s]);
+        if (g == 0) {
+            a.lp[c] = lp;
+            a.acc_count[c] = nacc;
+            a.last_acc[c] = last ? 1 : 0;
+        }
+    }
+    if (lane == 0) atomicAdd(a.acc_total, (mhx_u64)wave_acc);
+}
+
+#ifdef MHX_JIT_RWMH_MFMA
+// dynamic LDS: [target image][proposal image]
+#ifndef MHX_JIT_WAVES
+#define MHX_JIT_WAVES 1
+#endif
+extern "C" __global__ void __launch_bounds__(64 * MHX_MFMA_WAVES, MHX_JIT_WAVES)
+mhx_jit_rwmh_mfma(const mhx_rwmh_args a, const mhx_real* __restrict__ tparams, const mhx_real* __restrict__ pvec)
+{
+    typedef mhx_mfma_geom<MHX_JIT_DIM> GEO;
+    extern __shared__ mhx_acc4 mhx_mfma_lds[];
+    mhx_real* Aimg = (mhx_real*)mhx_mfma_lds;
+    mhx_real* Limg = Aimg + (MHX_JIT_TK == MHX_TARGET_CORR_GAUSS ? GEO::REALS : 0);
+    mhx_rwmh_mfma_body<MHX_JIT_DIM, MHX_JIT_PK, MHX_JIT_TK>(a, tparams, pvec, Aimg, Limg);
+}
+#endif
+MHX_NS_END

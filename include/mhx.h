@@ -241,7 +241,9 @@ typedef struct {
     int32_t kernel_variant;    /* 0 generic (HBM state), 1 pre-built register kernel, 2 hiprtc-specialised register
                                   kernel, 3 pre-built cooperative kernel, 4 hiprtc-specialised cooperative kernel,
                                   5 hiprtc-specialised cooperative kernel for the dense Gaussian target (RWMH),
-                                  7 the reference's sequential ensemble sweep (MHX_FLAG_EMCEE_SEQUENTIAL) */
+                                  7 the reference's sequential ensemble sweep (MHX_FLAG_EMCEE_SEQUENTIAL),
+                                  8 matrix-core kernel: RWMH with one dense factor for all chains (dense Gaussian
+                                  target and / or dense proposal) on v_mfma_*_16x16x4, reduction shape 4 */
     int32_t launches;
     int32_t reduce_lanes;      /* lanes per chain in effect (1 unless a cooperative kernel runs) */
     int32_t dtype;             /* mhx_dtype of the run's context */

@@ -88,3 +88,12 @@ TRACE_CASES = {
     "ram": case_ram,
     "ram_bounds": case_ram_bounds,
 }
+
+
+def mfma_fits(d, lanes, nimages, real):
+    """Host rule of the matrix-core RWMH kernel (csrc/mhx_api.hip mfma_fits): default or 4 lanes, 16 <= d, the state of a
+    lane (ceil(d/4) reals) within the register budget, the operand images within the 160 KB of LDS of a block."""
+    ns, nt = (d + 3) // 4, (d + 15) // 16
+    reals = (2 * (nt - 1) * nt + 4 * ((min(4 * nt, ns) + 3) // 4)) * 64
+    return (lanes in (0, 4) and d >= 16 and ns <= (44 if real == "f64" else 64) and nimages >= 1 and
+            nimages * reals * (8 if real == "f64" else 4) <= 163840)

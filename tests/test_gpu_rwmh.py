@@ -93,7 +93,9 @@ def test_parallel_sampling_call_forms(mhx, real):
 @pytest.mark.parametrize("d,C,lanes,prop", [(100, 70, 0, "iso"), (128, 33, 16, "diag"), (70, 9, 8, "iso"), (5, 37, 2, "diag"),
                                             (50, 40, 4, "iso"), (99, 17, 32, "diag"), (100, 21, 0, "dense"), (37, 66, 4, "dense"),
                                             (96, 5, 8, "dense"), (100, 13, 0, "dense_iso_target"), (18, 130, 0, "dense_iso_target"),
-                                            (200, 9, 0, "iso"), (256, 5, 0, "diag"), (130, 7, 0, "dense"), (160, 6, 0, "dense_iso_target")])
+                                            (200, 9, 0, "iso"), (256, 5, 0, "diag"), (130, 7, 0, "dense"), (160, 6, 0, "dense_iso_target"),
+                                            (16, 100, 0, "iso"), (17, 35, 4, "dense"), (31, 64, 0, "diag"), (64, 16, 4, "dense"),
+                                            (100, 65, 4, "diag"), (176, 20, 0, "iso"), (100, 300, 8, "iso"), (50, 33, 2, "dense")])
 def test_dense_gaussian_target_cooperative_kernel(mhx, oracle, d, C, lanes, prop, real):
     """RWMH on the dense Gaussian target with L lanes per chain (mhx_rwmh_dense_kernels.h): the default above 64
     dimensions, on request below; ISO and DIAG proposals, random initial states, a schedule with discard and
@@ -120,7 +122,11 @@ def test_dense_gaussian_target_cooperative_kernel(mhx, oracle, d, C, lanes, prop
     st = run.stats()
     L = st["reduce_lanes"]
     want_L = lanes if lanes else next(v for v in (2, 4, 8, 16, 32, 64) if (4 if real == "f64" else 2) * d <= 25 * v or v == 64)   # <= 12.5 (fp64: 6.25) rows per lane
-    if real == "f64" and st["kernel_variant"] == 0:
+    nimg = (0 if iso_target else 1) + (1 if prop.startswith("dense") else 0)
+    if cases.mfma_fits(d, lanes, nimg, real):
+        # one factor for all chains: the matrix-core kernel (mhx_rwmh_mfma_kernels.h), reduction shape 4
+        assert st["kernel_variant"] == 8 and L == 4
+    elif real == "f64" and st["kernel_variant"] == 0:
         # fp64 factor images are twice the size: past ~128 dimensions they no longer fit the 160 KB of LDS of a block and
         # the run falls back to the state-in-HBM kernel (same chain, sequential reduction shape)
         assert d >= 128 and L == 1 and lanes == 0
