@@ -81,11 +81,12 @@ class C2:
     def __init__(self, args, dtype):
         self.d, self.C, self.inner, self.dtype = args.dim or 100, args.chains or 65536, args.inner or 250, dtype
         self.lanes = args.lanes
+        self.literal = getattr(args, "c2_literal", False)
 
     def build(self, mhx, ctx, rank):
         import numpy as np
         d = self.d
-        self.s = float(np.float32(2.38 / d ** 0.5))
+        self.s = 1.0 if self.literal else float(np.float32(2.38 / d ** 0.5))
         model = mhx.DensityModel(mhx.IsoGaussian(d))
         spl = mhx.RWMH(mhx.MvNormal(mhx.zeros(d), self.s * self.s * mhx.I))
         self.run = mhx.Run(model, spl, nchains=self.C, seed=0xC0FFEE, first_chain=rank * self.C, ctx=ctx, reduce_lanes=self.lanes)
@@ -109,8 +110,10 @@ class C2:
         return "record %d(d+1)+1 B per chain-step + state round trip per launch" % RB[self.dtype]
 
     def describe(self):
-        return ("RWMH, isotropic %d-dim standard MvNormal target, %d chains per GPU, proposal N(0,(2.38/sqrt(d))^2 I), "
-                "%d transitions per launch, every state recorded" % (self.d, self.C, self.inner))
+        return ("RWMH, isotropic %d-dim standard MvNormal target, %d chains per GPU, proposal %s, "
+                "%d transitions per launch, every state recorded" % (
+                    self.d, self.C, "N(0, I) (the literal RWMH(MvNormal(zeros(d), I)) of the config text)" if self.literal
+                    else "N(0,(2.38/sqrt(d))^2 I)", self.inner))
 
     def cpu_baseline(self, O, target_seconds):
         tgt = O.iso_gauss(self.d)
@@ -411,6 +414,8 @@ def main():
     ap.add_argument("--chains", type=int, default=0, help="chains (walkers) per GPU; 0 = the config's default")
     ap.add_argument("--dim", type=int, default=0)
     ap.add_argument("--lanes", type=int, default=0, help="lanes per chain (0 = engine's choice)")
+    ap.add_argument("--c2-literal", action="store_true", help="c2: proposal N(0, I) as the config text reads (acceptance ~ 0 at d = 100) "
+                    "instead of the tuned 2.38/sqrt(d)")
     ap.add_argument("--c4-moving", action="store_true", help="c4: random start and S0 = 2.38/sqrt(d) I instead of x0 = 0, S0 = I")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-second-dtype", action="store_true", help="skip the fp32 figure")
@@ -460,7 +465,7 @@ def main():
             acc_rate = v[0] / v[1]
     else:
         acc_rate = accepted / float(transitions)
-    if args.config == "c2" and not args.no_ess and rank == 0:
+    if args.config == "c2" and not args.no_ess and not args.c2_literal and rank == 0:
         try:
             ess = ess_window(mhx, wl, world)
         except Exception as e:                                   # never let a diagnostic break the bench line
