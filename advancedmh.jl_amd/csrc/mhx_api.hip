@@ -25,6 +25,7 @@
 #include "mhx_mala_kernels.h"
 #include "mhx_rwmh_dense_kernels.h"
 #include "mhx_rwmh_mfma_kernels.h"
+#include "mhx_mala_mfma_kernels.h"
 #include "mhx_diag_kernels.h"
 #include "mhx_jit_embed.inc"   // generated: the device headers as string literals for hiprtc
 #include "mhx_impl.h"           // the prototypes of this instantiation (api_*), shared with the dispatcher mhx_abi.cpp
@@ -198,11 +199,12 @@ static int jit_compile(mhx_ctx* ctx, const std::string& key, const std::string& 
     hiprtcProgram prog = nullptr;
     const char* hdr_src[] = {k_src_mhx_device_math_h, k_src_mhx_targets_h, k_src_mhx_rwmh_kernels_h,
                              k_src_mhx_emcee_kernels_h, k_src_mhx_ram_kernels_h, k_src_mhx_mala_kernels_h,
-                             k_src_mhx_rwmh_dense_kernels_h, k_src_mhx_rwmh_mfma_kernels_h};
+                             k_src_mhx_rwmh_dense_kernels_h, k_src_mhx_rwmh_mfma_kernels_h,
+                             k_src_mhx_mala_mfma_kernels_h};
     const char* hdr_name[] = {"mhx_device_math.h", "mhx_targets.h", "mhx_rwmh_kernels.h",
                               "mhx_emcee_kernels.h", "mhx_ram_kernels.h", "mhx_mala_kernels.h",
-                              "mhx_rwmh_dense_kernels.h", "mhx_rwmh_mfma_kernels.h"};
-    hiprtcResult r = hiprtcCreateProgram(&prog, source.c_str(), "mhx_jit.hip", 8, hdr_src, hdr_name);
+                              "mhx_rwmh_dense_kernels.h", "mhx_rwmh_mfma_kernels.h", "mhx_mala_mfma_kernels.h"};
+    hiprtcResult r = hiprtcCreateProgram(&prog, source.c_str(), "mhx_jit.hip", 9, hdr_src, hdr_name);
     if (r != HIPRTC_SUCCESS) return mhx_fail(MHX_EJIT, "hiprtcCreateProgram: %s", hiprtcGetErrorString(r));
     std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
                                      MHX_REAL64 ? "-DMHX_REAL64=1" : "-DMHX_REAL64=0"};
@@ -577,6 +579,7 @@ static size_t mfma_image_reals(int d)
     const int last = std::min(4 * NT, NS);
     return (size_t)(2 * (NT - 1) * NT + 4 * ((last + 3) / 4)) * 64;
 }
+static size_t mfma_image_reals_T(int d) { const int NT = (d + 15) / 16; return (size_t)(NT * (NT + 1) / 2) * 256; }   // the image of A^T
 static bool mfma_fits(int d, int reduce_lanes, int nimages)
 {
     const char* no_mfma = getenv("MHX_NO_MFMA");                      // tuning knob: the vector kernel instead

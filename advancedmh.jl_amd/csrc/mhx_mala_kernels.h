@@ -108,6 +108,30 @@ MHX_DEV mhx_real mhx_target_grad_lanes(int kind, const X& x, const GO& g, const 
 {
     const int k_ = (KIND == MHX_TARGET_DYNAMIC) ? kind : KIND;
     const bool separable = k_ == MHX_TARGET_ISO_GAUSS || k_ == MHX_TARGET_BANANA || k_ == MHX_TARGET_FUNNEL;
+    if (L > 1 && k_ == MHX_TARGET_CORR_GAUSS) {
+        // the matrix-core kernel's shape: w = A x by rows (parked in g), the squares of rows l, l+L, ... on lane l,
+        // butterfly; the gradient -A^T w as in mhx_target_grad
+        mhx_real part[64];
+        for (int l = 0; l < L; ++l) part[l] = MHX_R(0.0);
+        for (int i = 0; i < d; ++i) {
+            const mhx_real* Ar = p + (long)i * (i + 1) / 2;
+            mhx_real w = MHX_R(0.0);
+            for (int j = 0; j <= i; ++j) w = mhx_fma(Ar[j], x[j], w);
+            g.set(i, w);
+            part[i % L] = mhx_fma(w, w, part[i % L]);
+        }
+        for (int off = 1; off < L; off <<= 1) {
+            mhx_real nxt[64];
+            for (int l = 0; l < L; ++l) nxt[l] = part[l] + part[l ^ off];
+            for (int l = 0; l < L; ++l) part[l] = nxt[l];
+        }
+        for (int j = 0; j < d; ++j) {
+            mhx_real acc = MHX_R(0.0);
+            for (int i = j; i < d; ++i) acc = mhx_fma(p[(long)i * (i + 1) / 2 + j], g[i], acc);
+            g.set(j, -acc);
+        }
+        return mhx_fma(-MHX_R(0.5), part[0], cst);
+    }
     if (L <= 1 || !separable) return mhx_target_grad<KIND>(kind, x, g, d, p, np, cst);
     const mhx_real q = mhx_separable_q_lanes(k_, x, d, p, L);
     if (k_ == MHX_TARGET_ISO_GAUSS) {

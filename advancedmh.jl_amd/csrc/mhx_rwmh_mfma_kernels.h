@@ -50,6 +50,10 @@ struct mhx_mfma_geom {
     static constexpr int first(int t) { return 2 * t * (t + 1); }
     static constexpr int TOTAL = first(NT - 1) + 4 * groups(NT - 1);    // steps in the image
     static constexpr long REALS = (long)TOTAL * 64;
+    // the transposed factor (A^T w, upper triangular): tile t needs the k-groups t .. NT-1 (k = row of A >= 16t)
+    static constexpr int firstT(int t) { return t * NT - t * (t - 1) / 2; }      // in groups of 4 steps
+    static constexpr int GROUPS_T = NT * (NT + 1) / 2;
+    static constexpr long REALS_T = (long)GROUPS_T * 256;
 };
 
 // matrix row behind MFMA row m of tile t: the permutation that puts row 16t + 4r + g into accumulator r of lane group g
@@ -79,10 +83,28 @@ MHX_DEV void mhx_mfma_image_fill(const mhx_real* __restrict__ A, mhx_real* img)
     }
 }
 
+// image of A^T: operand (MFMA row m of tile t, k) = A[k][row(t, m)] for k >= row, groups of 4 k-steps from 4t on
+template <int D>
+MHX_DEV void mhx_mfma_image_fill_T(const mhx_real* __restrict__ A, mhx_real* img)
+{
+    typedef mhx_mfma_geom<D> GEO;
+    for (int e = threadIdx.x; e < GEO::GROUPS_T * 256; e += blockDim.x) {
+        const int gi = e >> 8, ln = (e >> 2) & 63, u = e & 3;
+        int t = 0;
+        while (t + 1 < GEO::NT && GEO::firstT(t + 1) <= gi) ++t;
+        const int grp = t + (gi - GEO::firstT(t));
+        const int i = 4 * (4 * grp + u) + (ln >> 4);             // k: the row of A
+        const int j = mhx_mfma_row(t, ln & 15);                  // the output row: the column of A
+        const bool in = i < D && j < D && i >= j;
+        const mhx_real v = A[in ? (long)i * (i + 1) / 2 + j : 0];
+        img[e] = in ? v : MHX_R(0.0);
+    }
+}
+
 // rows of `factor image` x `b`, two tiles at a time (two independent accumulator chains keep the matrix pipe issuing:
 // a dependent 16x16x4 MFMA waits 40 cycles, the issue interval is 32).  Component r of tile t's fragment is row
-// 16t + 4r + g.  SQ: fold the rows into q = fma(w, w, q) in ascending row order; else: store them in out[4t + r].
-template <int D, bool SQ>
+// 16t + 4r + g.  MODE & 1: fold the rows into q = fma(w, w, q) in ascending row order; MODE & 2: store them in out[4t + r].
+template <int D, int MODE>
 MHX_DEV void mhx_mfma_rows(const mhx_real* img, const int lane, const mhx_real (&b)[mhx_mfma_geom<D>::NS],
                            mhx_real& q, mhx_real (&out)[mhx_mfma_geom<D>::NS])
 {
@@ -111,12 +133,48 @@ MHX_DEV void mhx_mfma_rows(const mhx_real* img, const int lane, const mhx_real (
             if (t < GEO::NT) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (SQ) q = mhx_fma(c[h][r], c[h][r], q);
-                    else if (4 * t + r < GEO::NS) out[4 * t + r] = c[h][r];
+                    if (MODE & 1) q = mhx_fma(c[h][r], c[h][r], q);
+                    if ((MODE & 2) && 4 * t + r < GEO::NS) out[4 * t + r] = c[h][r];
                 }
             }
         }
         __builtin_amdgcn_sched_barrier(0);            // keep the operand loads of later tiles out of this pair's registers
+    }
+}
+
+// rows of (image of A^T) x `b`: out[4t + r] = sum_{k >= row} A[k][row] b_k, ascending k from 0 (the zeros below `row` add nothing)
+template <int D>
+MHX_DEV void mhx_mfma_rows_T(const mhx_real* imgT, const int lane, const mhx_real (&b)[mhx_mfma_geom<D>::NS],
+                             mhx_real (&out)[mhx_mfma_geom<D>::NS])
+{
+    typedef mhx_mfma_geom<D> GEO;
+#pragma unroll
+    for (int t0 = 0; t0 < GEO::NT; t0 += 2) {
+        constexpr mhx_acc4 zero = {MHX_R(0.0), MHX_R(0.0), MHX_R(0.0), MHX_R(0.0)};
+        mhx_acc4 c[2] = {zero, zero};
+#pragma unroll
+        for (int grp = t0; grp < GEO::NT; ++grp) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int t = t0 + h;
+                if (t < GEO::NT && grp >= t) {
+                    const mhx_acc4 a4 = ((const mhx_acc4*)imgT)[(GEO::firstT(t) + grp - t) * 64 + lane];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (4 * grp + u < GEO::NS) c[h] = MHX_MFMA16(a4[u], b[4 * grp + u], c[h]);
+                }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int t = t0 + h;
+            if (t < GEO::NT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * t + r < GEO::NS) out[4 * t + r] = c[h][r];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -233,7 +291,7 @@ MHX_DEV void mhx_rwmh_mfma_body(const mhx_rwmh_args& a, const mhx_real* __restri
         if (DENSEP) {
             // xi = L z by rows (ascending j, fma from 0); row 16t + 4r + g = dimension 4(4t + r) + g: this lane's
             mhx_real xi[NS], unused = MHX_R(0.0);
-            mhx_mfma_rows<D, false>(Limg, lane, ys, unused, xi);
+            mhx_mfma_rows<D, 2>(Limg, lane, ys, unused, xi);
 #pragma unroll
             for (int s = 0; s < NS; ++s) ys[s] = (4 * s + 3 < D || 4 * s + g < D) ? xs[s] + xi[s] : MHX_R(0.0);
         }
@@ -241,7 +299,7 @@ MHX_DEV void mhx_rwmh_mfma_body(const mhx_rwmh_args& a, const mhx_real* __restri
         mhx_real q = MHX_R(0.0);
         if (CORR) {
             mhx_real unused[NS];
-            mhx_mfma_rows<D, true>(Aimg, lane, ys, q, unused);
+            mhx_mfma_rows<D, 1>(Aimg, lane, ys, q, unused);
         } else {
             // isotropic target in the reduction shape L = 4 of the cooperative kernels: lane g owns the BLOCKS g, g+4, ...
             // -- transpose the candidate back to blocks

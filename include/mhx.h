@@ -195,7 +195,7 @@ typedef struct {
     uint64_t first_chain;
     double sigma2;
     int32_t flags;
-    int32_t reduce_lanes;   /* lanes per chain (separable catalogue targets): 0 = engine's choice, 1 = one lane per chain; the
+    int32_t reduce_lanes;   /* lanes per chain (separable catalogue targets; 4 = the matrix-core kernel of the dense Gaussian target): 0 = engine's choice, 1 = one lane per chain; the
                                value in effect (mhx_stats.reduce_lanes) fixes the summation order of the three sums of a step */
 } mhx_mala_cfg;
 
@@ -242,7 +242,7 @@ typedef struct {
                                   kernel, 3 pre-built cooperative kernel, 4 hiprtc-specialised cooperative kernel,
                                   5 hiprtc-specialised cooperative kernel for the dense Gaussian target (RWMH),
                                   7 the reference's sequential ensemble sweep (MHX_FLAG_EMCEE_SEQUENTIAL),
-                                  8 matrix-core kernel: RWMH with one dense factor for all chains (dense Gaussian
+                                  8 matrix-core kernel: RWMH / MALA with one dense factor for all chains (dense Gaussian
                                   target and / or dense proposal) on v_mfma_*_16x16x4, reduction shape 4 */
     int32_t launches;
     int32_t reduce_lanes;      /* lanes per chain in effect (1 unless a cooperative kernel runs) */

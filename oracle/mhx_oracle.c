@@ -990,6 +990,15 @@ real orc_target_grad(const orc_target *t, const real *x, real *g, orc_logdensity
             q = FMA(w, w, q);
             off += (size_t)i + 1;
         }
+        if (t->reduce_lanes > 1) {                     /* the matrix-core kernel's shape: the squares of rows l, l+L, ... on lane l */
+            real p[64];
+            for (int l = 0; l < t->reduce_lanes; ++l) {
+                real ql = R(0.0);
+                for (int i = l; i < d; i += t->reduce_lanes) ql = FMA(g[i], g[i], ql);
+                p[l] = ql;
+            }
+            q = butterfly(p, t->reduce_lanes);
+        }
         for (int j = 0; j < d; ++j) {                  /* g_j = -sum_{i>=j} A_ij w_i, ascending i, in place */
             real acc = R(0.0);
             for (int i = j; i < d; ++i) acc = FMA(A[SIDX(i, j)], g[i], acc);

@@ -99,6 +99,48 @@ def test_mala_cooperative_kernel_bit_exact(mhx, oracle, name, d, lanes, real):
     run2.close()
 
 
+@pytest.mark.parametrize("d,C,lanes", [(16, 70, 4), (40, 33, 0), (100, 70, 0), (100, 17, 4), (61, 16, 0), (128, 40, 0), (21, 130, 4), (150, 20, 0)])
+def test_mala_dense_target_matrix_core_kernel(mhx, oracle, d, C, lanes, real):
+    """MALA on the dense Gaussian target (mhx_mala_mfma_kernels.h): w = A y and grad = -A^T w as two triangular GEMMs over the
+    16 chains of a wave (v_mfma_*_16x16x4), 4 lanes per chain; the three sums of a step in the reduction shape 4.  Default above
+    the register kernel's budget, or reduce_lanes = 4.  Bit-exact against the oracle in that shape: discard / thinning, a
+    continued call, setparams (lp and gradient re-evaluated in the same shape)."""
+    rng = np.random.default_rng(d)
+    N = 9
+    Sig = cases.sigma_ar1(d, 0.6)
+    spec, ot = mhx.CorrGaussian(Sig), oracle.corr_gauss_from_cov(Sig)
+    s2 = float(np.float32(0.3 / d ** (1 / 3)))
+    init = (rng.normal(size=(d, C)) * 0.3).astype(np.float32)
+    run = mhx.Run(mhx.DensityModel(spec), mhx.MALA(s2), nchains=C, seed=8, first_chain=5, reduce_lanes=lanes)
+    run.init(init)
+    run.sample(N, 2, 2, 0)
+    st = run.stats()
+    if d == 150 and real == "f64":
+        assert st["kernel_variant"] == 0 and st["reduce_lanes"] == 1       # two fp64 images of d = 150: 196 KB, more than a block's LDS
+        run.close()
+        return
+    assert st["kernel_variant"] == 8 and st["reduce_lanes"] == 4           # both images of every case fit the 160 KB of LDS
+    L = st["reduce_lanes"]
+    ref = oracle.mala(ot.with_lanes(L), s2, oracle.schedule(N + 4, 2, 2), 8, 5, C, init)
+    got, acc = run.samples()
+    _same(got, ref["samples"][:N], "samples")
+    _same(acc, ref["accepted"][:N], "accepted")
+    assert acc[1:].mean() > 0.05
+    run.sample(4, 2, 2, 0)                                                 # continues the chain at the same cadence
+    _same(run.samples()[0], ref["samples"][N:], "continued call")
+    x, lp, cnt = run.state()
+    _same(x, ref["final_x"], "final x")
+    _same(lp, ref["final_lp"], "final lp")
+    _same(cnt, ref["accept_counts"], "accept counts")
+    # setparams: lp and gradient of the new state in the run's shape = a fresh run initialised there
+    x2 = (rng.normal(size=(d, C)) * 0.2).astype(np.float32)
+    run.set_params(x2)
+    _, lp2, _ = run.state()
+    fresh = oracle.mala(ot.with_lanes(L), s2, oracle.schedule(1), 8, 5, C, x2)
+    _same(lp2, fresh["final_lp"], "lp after setparams")
+    run.close()
+
+
 def test_mala_reference_tests(mhx, oracle, real):
     """test/runtests.jl:288-332 (basic) and :334-365 (issue #95)."""
     data = np.load(os.path.join(GOLD, "c1_normal_data.npy"))

@@ -31,3 +31,15 @@ for d in [int(v) for v in os.environ.get("DIMS", "32 50 64 100 128 200").split()
                               lanes=st["reduce_lanes"], steps_per_s=rate, tflops=rate * d * (d + 1) * (2 if prop == "dense" else 1) / 1e12,
                               acc=st["accepted"] / st["transitions"])), flush=True)
         run.close()
+    if os.environ.get("MALA", "1") != "0":
+        run = mhx.Run(mhx.DensityModel(mhx.CorrGaussian(Sig)), mhx.MALA(float(np.float32(0.5 / d ** (1 / 3)))), nchains=C, seed=1,
+                      reduce_lanes=int(os.environ.get("LANES", 0)))
+        run.init(np.zeros(d))
+        run.sample(1, 10, 1, 0, save=False)
+        run.sample(1, 50, 1, 0, save=False)
+        st = run.stats()
+        rate = st["transitions"] / (st["kernel_ms"] * 1e-3)
+        print(json.dumps(dict(config="MALA dense target d=%d C=%d %s" % (d, C, st["dtype"]), variant=st["kernel_variant"],
+                              lanes=st["reduce_lanes"], steps_per_s=rate, tflops=rate * 2 * d * (d + 1) / 1e12,
+                              acc=st["accepted"] / st["transitions"])), flush=True)
+        run.close()
