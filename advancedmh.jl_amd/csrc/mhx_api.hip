@@ -488,6 +488,7 @@ struct mhx_run : mhx_handle_hdr {
     std::vector<std::string> coop_defs;
     // kernel choice
     int coop_L = 1;                      // lanes per chain (reduction shape of the separable targets)
+    int coop_waves = MHX_EMCEE_COOP_WAVES;  // waves per block of the cooperative stretch move (tuning knob MHX_EMCEE_WAVES)
     int variant = 0;
     void (*reg_fn)(const mhx_rwmh_args, const mhx_real*, const mhx_real*) = nullptr;
     hipFunction_t jit_step = nullptr, jit_init = nullptr;
@@ -557,11 +558,11 @@ static int rwmh_whiten(mhx_run* r)
 // lanes per chain of the dense cooperative kernel: at most 12.5 rows of a factor per lane
 static int dense_coop_lanes(int d) { int L = 2; while ((MHX_REAL64 ? 4 : 2) * d > 25 * L && L < 64) L *= 2; return L; }
 // dynamic LDS of the dense cooperative kernel: the candidate rows of a 4-wave block + `nimages` factor images
-static size_t dense_coop_lds_bytes(int d, int L, int nimages)
+static size_t dense_coop_lds_bytes(int d, int L, int nimages, int waves = MHX_EMCEE_COOP_WAVES)
 {
     long total4 = 0;
     for (int m = 0; m * L < d; ++m) total4 += (long)((std::min(L * (m + 1), d) + 3) / 4) * L;
-    const long rows4 = (long)MHX_EMCEE_COOP_WAVES * (64 / L) * ((((d + 3) & ~3) + 4) / 4);
+    const long rows4 = (long)waves * (64 / L) * ((((d + 3) & ~3) + 4) / 4);
     return (size_t)(rows4 + nimages * total4) * 4 * sizeof(mhx_real);
 }
 static bool dense_coop_fits(int d, int L, int nimages)

@@ -208,7 +208,9 @@ MHX_DEV void mhx_emcee_init_body(const mhx_emcee_args& a, const mhx_real* __rest
 // xor-butterfly -- the reduction shape is part of the arithmetic spec (oracle: reduce_lanes = L).
 // The same image / row-product machinery serves random-walk Metropolis on dense factors
 // (mhx_rwmh_dense_kernels.h).
+#ifndef MHX_EMCEE_COOP_WAVES
 #define MHX_EMCEE_COOP_WAVES 4                   // waves per block: they share the LDS copy of the factor
+#endif
 
 // LDS image of the packed factor for L lanes per walker.  Lane l owns rows l, l+L, ...; row set m
 // (rows L m .. L m + L - 1) is stored as LEN4(m) groups of L float4 -- group jj4 holds columns
@@ -348,6 +350,12 @@ MHX_DEV mhx_real mhx_dense_rows_sq(const mhx_e4* Ash4, const mhx_e4* yrow4, cons
     return q;
 }
 
+// timing probe: MHX_EMCEE_PROBE = n (hiprtc define, tools only) ends the half-step after phase n
+#ifndef MHX_EMCEE_PROBE
+#define MHX_EMCEE_PROBE 0
+#endif
+#define MHX_PROBE(n, val) do { if (MHX_EMCEE_PROBE == (n)) { if ((val) == MHX_R(12345.678)) a.lp[0] = (val); return; } } while (0)
+
 template <int D, int L>
 MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const mhx_real* __restrict__ A, mhx_real* ysh_all, mhx_e4* Ash4)
 {
@@ -377,6 +385,9 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const mhx_real* __rest
     const int osize = a.half ? halfW : W - halfW;
     const long ld = W;
 
+    MHX_PROBE(1, (mhx_real)i);                                               // launch + arguments
+    const mhx_real lpi = a.lp[i];                                            // in flight with the rows
+    const mhx_u32 acc_i = a.acc_count[i];
     const mhx_philox_key ks = mhx_philox_schedule(a.seed);
     const mhx_emcee_draws dr = mhx_emcee_draw(ks, (mhx_u32)i, (mhx_u32)a.ensemble_id, a.sweep);
     const int j = ostart + (int)(((mhx_u64)dr.partner * (mhx_u64)(mhx_u32)osize) >> 32);
@@ -384,6 +395,7 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const mhx_real* __rest
     const mhx_real tt = mhx_fma(a.stretch - MHX_R(1.0), u, MHX_R(1.0));
     const mhx_real z = (tt * tt) / a.stretch;                               // src/emcee.jl:81
     const mhx_real alphamult = (mhx_real)(D - 1) * mhx_log(z);                 // :82
+    MHX_PROBE(2, alphamult + (mhx_real)j);                                   // + the draws
 
     // the move, element-wise on float4 slices of the two rows (lane l: float4 l, l+L, ...); the zero pad of
     // the rows gives the zero pad of y that multiplies the zeros of the factor image
@@ -409,14 +421,16 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const mhx_real* __rest
         }
         if (q4 < DP4 / 4) ((mhx_e4*)yrow)[q4] = ysl[m];
     }
+    MHX_PROBE(3, ysl[0].x);                                                  // + the two rows, the move
     if constexpr (ONE_BATCH) mhx_dense_image_store<D, L>(areg, Ash4);
     else mhx_dense_image_fill<D, L>(A, Ash4);
     __syncthreads();
+    MHX_PROBE(4, ysl[0].x + ((const mhx_real*)Ash4)[threadIdx.x]);           // + the factor image in LDS
     mhx_real q = mhx_dense_rows_sq<D, L>(Ash4, (const mhx_e4*)yrow, l);
 #pragma unroll
     for (int off = 1; off < L; off <<= 1) q = q + __shfl_xor(q, off * CPW, 64);
     const mhx_real lpy = mhx_fma(-MHX_R(0.5), q, a.tconst);
-    const mhx_real lpi = a.lp[i];
+    MHX_PROBE(5, lpy + ysl[0].x);                                            // + A y, the butterfly
     const mhx_real alpha = (alphamult + lpy) - lpi;                         // :91
     const mhx_real logu = dr.logu;
     const bool acc = logu <= alpha;                                      // :93
@@ -424,9 +438,10 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const mhx_real* __rest
         if (acc) {
 #pragma unroll
             for (int m = 0; m < NQL; ++m) { const int q4 = l + L * m; if (q4 < NQ) xrow_i[q4] = ysl[m]; }
-            if (l == 0) { a.lp[i] = lpy; a.acc_count[i] += 1u; }
+            if (l == 0) { a.lp[i] = lpy; a.acc_count[i] = acc_i + 1u; }
         }
         if (l == 0) a.last_acc[i] = acc ? 1 : 0;
+        if (MHX_EMCEE_PROBE == 6) return;                                    // + accept and the state update, no record
         if (a.save_slot >= 0) {
             // the record is [dim+1][W] (walker fastest): 16-byte runs per dimension from this wave's walkers
             // (staging it through LDS for 64-byte runs measured no faster)
