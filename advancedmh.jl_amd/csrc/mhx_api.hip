@@ -453,6 +453,8 @@ struct mhx_run : mhx_handle_hdr {
     size_t dense_lds = 0;                // dynamic LDS bytes of the dense cooperative RWMH kernel
     mhx_real* d_xw = nullptr;               // walker-major copy [W][round4(dim)]: the state while the cooperative kernel runs
     mhx_real* d_pmean = nullptr;            // drifting walk: mu[dim] then 2 L^-1 mu [dim]
+    mhx_real* d_mfma_img = nullptr;         // streamed matrix-core kernel: the operand images [target][proposal] in global memory
+    bool mfma_stream = false;
     mhx_real* d_qx = nullptr;               // static proposal: logpdf of the proposal at each chain's state (up to its constant)
     // mala
     mhx_real mala_sigma = MHX_R(1.0);
@@ -497,7 +499,7 @@ struct mhx_run : mhx_handle_hdr {
     ~mhx_run()
     {
         void* ptrs[] = {d_pvec, d_S, d_Ssel, d_status, d_dmin, d_dmax, d_eta, d_x, d_lp, d_ybuf,
-                        d_acc, d_last, d_acc_total, d_samples, d_accepted, d_mom_mean, d_mom_m2, d_gx, d_gy, d_z, d_pmean, d_qx, d_xw, d_loga};
+                        d_acc, d_last, d_acc_total, d_samples, d_accepted, d_mom_mean, d_mom_m2, d_gx, d_gy, d_z, d_pmean, d_qx, d_xw, d_loga, d_mfma_img};
         for (void* p : ptrs) if (p) (void)hipFree(p);
     }
 };
@@ -586,6 +588,24 @@ static bool mfma_fits(int d, int reduce_lanes, int nimages)
     const char* no_mfma = getenv("MHX_NO_MFMA");                      // tuning knob: the vector kernel instead
     return (reduce_lanes == 0 || reduce_lanes == 4) && d >= 16 && (d + 3) / 4 <= MHX_MFMA_MAX_NS && !(no_mfma && atoi(no_mfma)) &&
            nimages * mfma_image_reals(d) * sizeof(mhx_real) <= MHX_LDS_PER_BLOCK;
+}
+// streamed images (larger than a block's LDS): two ring buffers of whole 256-thread rounds of 16-byte pieces of the largest tile pair
+#define MHX_MFMA_STREAM_MAX_NS (MHX_REAL64 ? 64 : 100)
+static size_t mfma_ring_bytes(int d)
+{
+    const int NS = (d + 3) / 4, NT = (d + 15) / 16;
+    auto groups = [&](int t) { return (std::min(4 * (t + 1), NS) + 3) / 4; };
+    int maxg = 0;
+    for (int p = 0; 2 * p < NT; ++p) maxg = std::max(maxg, groups(2 * p) + (2 * p + 1 < NT ? groups(2 * p + 1) : 0));
+    const int p16 = (int)(4 * sizeof(mhx_real)) / 16;
+    const int pf = (maxg * 64 * p16 + 64 * MHX_MFMA_WAVES - 1) / (64 * MHX_MFMA_WAVES);
+    return (size_t)2 * pf * 64 * MHX_MFMA_WAVES * 16;
+}
+static bool mfma_stream_fits(int d, int reduce_lanes)
+{
+    const char* no_mfma = getenv("MHX_NO_MFMA");
+    return (reduce_lanes == 0 || reduce_lanes == 4) && d >= 16 && (d + 3) / 4 <= MHX_MFMA_STREAM_MAX_NS && !(no_mfma && atoi(no_mfma)) &&
+           mfma_ring_bytes(d) <= MHX_LDS_PER_BLOCK;
 }
 static int mfma_waves(int d)
 {
@@ -682,9 +702,10 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
         }
         coop_one_lane = walk && L == 1 && nblk <= MHX_COOP_NBL_MAX;
     } else if (((tk == MHX_TARGET_CORR_GAUSS) || (tk == MHX_TARGET_ISO_GAUSS && pk == MHX_PROP_DENSE)) &&
-               !walk && !(r->flags & (MHX_FLAG_GENERIC | MHX_FLAG_NO_JIT)) && d >= 2 && d <= MHX_DENSE_COOP_MAX_DIM &&
+               !walk && !(r->flags & (MHX_FLAG_GENERIC | MHX_FLAG_NO_JIT)) && d >= 2 && d <= 4 * MHX_MFMA_STREAM_MAX_NS &&
                (cfg->reduce_lanes > 1 || (cfg->reduce_lanes == 0 && d >= 16)) &&
                (mfma_fits(d, cfg->reduce_lanes, (tk == MHX_TARGET_CORR_GAUSS ? 1 : 0) + (pk == MHX_PROP_DENSE ? 1 : 0)) ||
+                mfma_stream_fits(d, cfg->reduce_lanes) ||
                 dense_coop_fits(d, cfg->reduce_lanes > 1 ? cfg->reduce_lanes : dense_coop_lanes(d),
                                 (tk == MHX_TARGET_CORR_GAUSS ? 1 : 0) + (pk == MHX_PROP_DENSE ? 1 : 0)))) {
         // a dense factor in play (dense Gaussian target, dense proposal, or both): the cooperative kernel of
@@ -710,6 +731,38 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
                     rc = mhx_fail(MHX_EHIP, "matrix-core kernel: %zu bytes of LDS refused", r->dense_lds);
             }
             if (rc == MHX_OK) { r->variant = 8; r->coop_L = 4; }
+        }
+        if (!r->variant && mfma_stream_fits(d, cfg->reduce_lanes)) {
+            // the images do not fit a block's LDS: they stay in global memory (built once, here) and every block walks them
+            // through an LDS ring, one tile pair at a time
+            jit_module* m = nullptr;
+            const std::string key = "rwmh_mfma_stream/d=" + std::to_string(d) + "/pk=" + std::to_string(pk) + "/tk=" + std::to_string(tk);
+            rc = jit_compile(ctx, key, jit_source(t, "mhx_rwmh_mfma_kernels.h"),
+                             {"MHX_JIT_RWMH_MFMA_STREAM=1", "MHX_JIT_DIM=" + std::to_string(d), "MHX_JIT_PK=" + std::to_string(pk),
+                              "MHX_JIT_TK=" + std::to_string(tk), "MHX_JIT_WAVES=1"}, &m);
+            hipFunction_t fimg = nullptr;
+            if (rc == MHX_OK) rc = jit_function(m, "mhx_jit_rwmh_mfma_stream", &r->jit_step);
+            if (rc == MHX_OK) rc = jit_function(m, "mhx_jit_mfma_image", &fimg);
+            if (rc == MHX_OK) {
+                r->dense_lds = mfma_ring_bytes(d);
+                if (hipFuncSetAttribute((const void*)r->jit_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->dense_lds) != hipSuccess)
+                    rc = mhx_fail(MHX_EHIP, "streamed matrix-core kernel: %zu bytes of LDS refused", r->dense_lds);
+            }
+            if (rc == MHX_OK) {
+                const size_t reals = mfma_image_reals(d);
+                HIP_TRY(hipMalloc(&r->d_mfma_img, 2 * reals * sizeof(mhx_real)));
+                HIP_TRY(hipMemsetAsync(r->d_mfma_img, 0, 2 * reals * sizeof(mhx_real), ctx->stream));
+                const mhx_real* srcs[2] = {tk == MHX_TARGET_CORR_GAUSS ? t->dparams : nullptr, pk == MHX_PROP_DENSE ? r->d_pvec : nullptr};
+                for (int im = 0; im < 2 && rc == MHX_OK; ++im) {
+                    if (!srcs[im]) continue;
+                    mhx_real* dst = r->d_mfma_img + im * reals;
+                    void* params[] = {(void*)&srcs[im], &dst};
+                    rc = launch_module(fimg, 1, 256, ctx->stream, params);
+                }
+                if (rc == MHX_OK) HIP_TRY(hipStreamSynchronize(ctx->stream));
+            }
+            if (rc == MHX_OK) { r->variant = 8; r->coop_L = 4; r->mfma_stream = true; }
+            else { r->jit_step = nullptr; }
         }
         L = cfg->reduce_lanes > 1 ? cfg->reduce_lanes : dense_coop_lanes(d);
         if (r->variant == 8 || !dense_coop_fits(d, L, nimg)) {
@@ -870,6 +923,13 @@ static int rwmh_advance(mhx_run* r, uint64_t nsteps, uint32_t save_next, int sav
                 int rc = launch_module(r->jit_step, grid, 256, ctx->stream, params);
                 if (rc) return rc;
             }
+        } else if (r->variant == 8 && r->mfma_stream) {
+            const unsigned grid = (unsigned)(((long)r->n + 16 * MHX_MFMA_WAVES - 1) / (16 * MHX_MFMA_WAVES));
+            mhx_real* gA = r->d_mfma_img;
+            mhx_real* gL = r->d_mfma_img + mfma_image_reals(r->dim);
+            void* params[] = {&a, &tp, &pv, &gA, &gL};
+            HIP_TRY(hipModuleLaunchKernel(r->jit_step, grid, 1, 1, 64 * MHX_MFMA_WAVES, 1, 1, (unsigned)r->dense_lds,
+                                          ctx->stream, params, nullptr));
         } else if (r->variant == 8) {
             const unsigned grid = (unsigned)(((long)r->n + 16 * MHX_MFMA_WAVES - 1) / (16 * MHX_MFMA_WAVES));
             void* params[] = {&a, &tp, &pv};

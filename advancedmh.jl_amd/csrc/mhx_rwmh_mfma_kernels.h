@@ -178,6 +178,93 @@ MHX_DEV void mhx_mfma_rows_T(const mhx_real* imgT, const int lane, const mhx_rea
     }
 }
 
+// ---- images larger than a block's LDS: streamed.  The image lives in HBM / L2 (built once per run); a block walks it in
+// chunks of one tile PAIR (adjacent in the image) through a two-buffer LDS ring: every thread holds its share of the NEXT
+// chunk in registers while the MFMAs of the current one run, drops it into the other buffer, one block barrier per chunk.
+template <int D>
+struct mhx_mfma_stream_geom {
+    typedef mhx_mfma_geom<D> GEO;
+    static constexpr int THREADS = 64 * MHX_MFMA_WAVES;
+    static constexpr int NP = (GEO::NT + 1) / 2;                                  // tile pairs = chunks per image
+    static constexpr int first(int p) { return GEO::first(2 * p) / 4; }           // in groups
+    static constexpr int groups(int p) { return GEO::groups(2 * p) + (2 * p + 1 < GEO::NT ? GEO::groups(2 * p + 1) : 0); }
+    static constexpr int maxg() { int m = 0; for (int p = 0; p < NP; ++p) m = groups(p) > m ? groups(p) : m; return m; }
+    static constexpr int MAXG = maxg();
+    static constexpr int P16 = (int)sizeof(mhx_acc4) / 16;                        // 16-byte pieces per lane and group
+    static constexpr int PF = (MAXG * 64 * P16 + THREADS - 1) / THREADS;          // 16-byte pieces per thread and chunk
+    static constexpr int pieces(int p) { return (groups(p) * 64 * P16 + THREADS - 1) / THREADS; }   // per thread, whole rounds
+    static constexpr long BUF_BYTES = (long)PF * THREADS * 16;                    // one ring buffer
+    static constexpr long RING_BYTES = 2 * BUF_BYTES;
+};
+
+// this thread's pieces of chunk p of the image behind the descriptor `img`: wave-uniform chunk offset (SGPR), one 32-bit lane
+// offset -- no 64-bit vector address per piece
+typedef mhx_u32 mhx_piece16 __attribute__((ext_vector_type(4)));
+template <int D>
+MHX_DEV void mhx_mfma_chunk_load(const mhx_srd img, const int p, mhx_piece16 (&pf)[mhx_mfma_stream_geom<D>::PF])
+{
+    typedef mhx_mfma_stream_geom<D> SG;
+    // whole rounds of the block, no per-thread predicate: the last round may run into the next chunk (ignored) or past the
+    // image (the descriptor's range check returns zeros)
+    const mhx_u32 voff = (mhx_u32)threadIdx.x * 16u;
+#pragma unroll
+    for (int i = 0; i < SG::PF; ++i) {
+        const mhx_u32 soff = (mhx_u32)(SG::first(p) * 64 * (int)sizeof(mhx_acc4) + i * SG::THREADS * 16);
+        if (i < SG::pieces(p)) pf[i] = __builtin_amdgcn_raw_buffer_load_b128(img, (int)voff, (int)soff, 0);
+    }
+}
+
+// mhx_mfma_rows over a streamed image.  `pf` holds chunk 0 of this image on entry and, on return, chunk 0 of `gnext` (the image
+// the step walks next -- itself if it is the only one); `parity` is the ring buffer the next chunk goes to.
+template <int D, int MODE>
+MHX_DEV void mhx_mfma_rows_stream(const mhx_srd gimg, const mhx_srd gnext, mhx_real* ring, const int lane,
+                                  const mhx_real (&b)[mhx_mfma_geom<D>::NS], mhx_real& q, mhx_real (&out)[mhx_mfma_geom<D>::NS],
+                                  mhx_piece16 (&pf)[mhx_mfma_stream_geom<D>::PF], int& parity)
+{
+    typedef mhx_mfma_geom<D> GEO;
+    typedef mhx_mfma_stream_geom<D> SG;
+#pragma unroll
+    for (int p = 0; p < SG::NP; ++p) {
+        mhx_acc4* buf = (mhx_acc4*)((char*)ring + (parity ? SG::BUF_BYTES : 0));
+#pragma unroll
+        for (int i = 0; i < SG::PF; ++i)
+            if (i < SG::pieces(p)) ((mhx_piece16*)buf)[(int)threadIdx.x + i * SG::THREADS] = pf[i];
+        __syncthreads();                                  // the chunk is complete; the other buffer is free (see above)
+        if (p + 1 < SG::NP) mhx_mfma_chunk_load<D>(gimg, p + 1, pf);
+        else mhx_mfma_chunk_load<D>(gnext, 0, pf);
+        constexpr mhx_acc4 zero = {MHX_R(0.0), MHX_R(0.0), MHX_R(0.0), MHX_R(0.0)};
+        mhx_acc4 c[2] = {zero, zero};
+        const int t0 = 2 * p;
+        const int t1 = t0 + 1 < GEO::NT ? t0 + 1 : t0;
+#pragma unroll
+        for (int grp = 0; grp < GEO::groups(t1); ++grp) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int t = t0 + h;
+                if (t < GEO::NT && grp < GEO::groups(t)) {
+                    const mhx_acc4 a4 = buf[(GEO::first(t) / 4 + grp - SG::first(p)) * 64 + lane];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (4 * grp + u < GEO::steps(t)) c[h] = MHX_MFMA16(a4[u], b[4 * grp + u], c[h]);
+                }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int t = t0 + h;
+            if (t < GEO::NT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (MODE & 1) q = mhx_fma(c[h][r], c[h][r], q);
+                    if ((MODE & 2) && 4 * t + r < GEO::NS) out[4 * t + r] = c[h][r];
+                }
+            }
+        }
+        parity ^= 1;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // 4x4 transpose over the four lanes of a chain (lanes j, j+16, j+32, j+48): lane g gives n[e] to lane e and receives
 // that lane's n[g].  v_permlane32_swap exchanges lanes 32-63 of its first operand with lanes 0-31 of the second,
 // v_permlane16_swap the odd 16-lane rows of the first with the even rows of the second.
@@ -218,18 +305,28 @@ MHX_DEV void mhx_lanes4_transpose(mhx_real (&n)[4])
 
 // TK: MHX_TARGET_CORR_GAUSS (factor image A) or MHX_TARGET_ISO_GAUSS (with a dense proposal); PK: ISO / DIAG scales, or
 // DENSE -- the proposal's Cholesky factor as a second image.
-template <int D, int PK, int TK>
+// STREAM: Aimg / Limg are the pre-built images in global memory and `ring` the LDS ring they are walked through; otherwise
+// they are LDS and filled here.
+template <int D, int PK, int TK, bool STREAM = false>
 MHX_DEV void mhx_rwmh_mfma_body(const mhx_rwmh_args& a, const mhx_real* __restrict__ A, const mhx_real* __restrict__ pvec,
-                                mhx_real* Aimg, mhx_real* Limg)
+                                mhx_real* Aimg, mhx_real* Limg, mhx_real* ring = nullptr)
 {
     typedef mhx_mfma_geom<D> GEO;
     constexpr bool CORR = TK == MHX_TARGET_CORR_GAUSS;
     constexpr bool DENSEP = PK == MHX_PROP_DENSE;
     constexpr int NS = GEO::NS;
     constexpr int NQD = (NS + 3) / 4;                 // quads of normal4 blocks (block b = dimensions 4b .. 4b+3)
-    if (CORR) mhx_mfma_image_fill<D>(A, Aimg);
-    if (DENSEP) mhx_mfma_image_fill<D>(pvec, Limg);
-    __syncthreads();
+    if (!STREAM) {
+        if (CORR) mhx_mfma_image_fill<D>(A, Aimg);
+        if (DENSEP) mhx_mfma_image_fill<D>(pvec, Limg);
+        __syncthreads();
+    }
+    // streamed images: the first chunk of the step's first image is in flight before the loop
+    mhx_piece16 pf[STREAM ? mhx_mfma_stream_geom<D>::PF : 1];
+    int parity = 0;
+    const mhx_u32 img_bytes = (mhx_u32)(GEO::REALS * (long)sizeof(mhx_real));
+    const mhx_srd sA = mhx_make_srd(STREAM ? (CORR ? Aimg : Limg) : nullptr, img_bytes), sL = mhx_make_srd(STREAM ? (DENSEP ? Limg : Aimg) : nullptr, img_bytes);
+    if constexpr (STREAM) mhx_mfma_chunk_load<D>(DENSEP ? sL : sA, 0, pf);
 
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
@@ -291,7 +388,8 @@ MHX_DEV void mhx_rwmh_mfma_body(const mhx_rwmh_args& a, const mhx_real* __restri
         if (DENSEP) {
             // xi = L z by rows (ascending j, fma from 0); row 16t + 4r + g = dimension 4(4t + r) + g: this lane's
             mhx_real xi[NS], unused = MHX_R(0.0);
-            mhx_mfma_rows<D, 2>(Limg, lane, ys, unused, xi);
+            if constexpr (STREAM) mhx_mfma_rows_stream<D, 2>(sL, CORR ? sA : sL, ring, lane, ys, unused, xi, pf, parity);
+            else mhx_mfma_rows<D, 2>(Limg, lane, ys, unused, xi);
 #pragma unroll
             for (int s = 0; s < NS; ++s) ys[s] = (4 * s + 3 < D || 4 * s + g < D) ? xs[s] + xi[s] : MHX_R(0.0);
         }
@@ -299,7 +397,8 @@ MHX_DEV void mhx_rwmh_mfma_body(const mhx_rwmh_args& a, const mhx_real* __restri
         mhx_real q = MHX_R(0.0);
         if (CORR) {
             mhx_real unused[NS];
-            mhx_mfma_rows<D, 1>(Aimg, lane, ys, q, unused);
+            if constexpr (STREAM) mhx_mfma_rows_stream<D, 1>(sA, DENSEP ? sL : sA, ring, lane, ys, q, unused, pf, parity);
+            else mhx_mfma_rows<D, 1>(Aimg, lane, ys, q, unused);
         } else {
             // isotropic target in the reduction shape L = 4 of the cooperative kernels: lane g owns the BLOCKS g, g+4, ...
             // -- transpose the candidate back to blocks
@@ -367,6 +466,24 @@ mhx_jit_rwmh_mfma(const mhx_rwmh_args a, const mhx_real* __restrict__ tparams, c
     mhx_real* Aimg = (mhx_real*)mhx_mfma_lds;
     mhx_real* Limg = Aimg + (MHX_JIT_TK == MHX_TARGET_CORR_GAUSS ? GEO::REALS : 0);
     mhx_rwmh_mfma_body<MHX_JIT_DIM, MHX_JIT_PK, MHX_JIT_TK>(a, tparams, pvec, Aimg, Limg);
+}
+#endif
+#ifdef MHX_JIT_RWMH_MFMA_STREAM
+#ifndef MHX_JIT_WAVES
+#define MHX_JIT_WAVES 1
+#endif
+// the image builder (one block, once per run) and the streamed kernel: dynamic LDS = the two-buffer ring
+extern "C" __global__ void __launch_bounds__(256)
+mhx_jit_mfma_image(const mhx_real* __restrict__ packed, mhx_real* img)
+{
+    mhx_mfma_image_fill<MHX_JIT_DIM>(packed, img);
+}
+extern "C" __global__ void __launch_bounds__(64 * MHX_MFMA_WAVES, MHX_JIT_WAVES)
+mhx_jit_rwmh_mfma_stream(const mhx_rwmh_args a, const mhx_real* __restrict__ tparams, const mhx_real* __restrict__ pvec,
+                         mhx_real* gAimg, mhx_real* gLimg)
+{
+    extern __shared__ mhx_acc4 mhx_mfma_ring[];
+    mhx_rwmh_mfma_body<MHX_JIT_DIM, MHX_JIT_PK, MHX_JIT_TK, true>(a, tparams, pvec, gAimg, gLimg, (mhx_real*)mhx_mfma_ring);
 }
 #endif
 MHX_NS_END

@@ -91,9 +91,17 @@ TRACE_CASES = {
 
 
 def mfma_fits(d, lanes, nimages, real):
-    """Host rule of the matrix-core RWMH kernel (csrc/mhx_api.hip mfma_fits): default or 4 lanes, 16 <= d, the state of a
-    lane (ceil(d/4) reals) within the register budget, the operand images within the 160 KB of LDS of a block."""
+    """Host rule of the matrix-core RWMH kernel (csrc/mhx_api.hip mfma_fits / mfma_stream_fits): default or 4 lanes, 16 <= d, and
+    either the operand images fit the 160 KB of LDS of a block with the lane's state (ceil(d/4) reals) in its register budget, or
+    they are streamed through an LDS ring (state up to 100 / 64 reals per lane in fp32 / fp64)."""
     ns, nt = (d + 3) // 4, (d + 15) // 16
+    rb = 8 if real == "f64" else 4
+    if not (lanes in (0, 4) and d >= 16 and nimages >= 1):
+        return False
     reals = (2 * (nt - 1) * nt + 4 * ((min(4 * nt, ns) + 3) // 4)) * 64
-    return (lanes in (0, 4) and d >= 16 and ns <= (44 if real == "f64" else 64) and nimages >= 1 and
-            nimages * reals * (8 if real == "f64" else 4) <= 163840)
+    if ns <= (44 if real == "f64" else 64) and nimages * reals * rb <= 163840:
+        return True
+    groups = lambda t: (min(4 * (t + 1), ns) + 3) // 4
+    maxg = max(groups(2 * p) + (groups(2 * p + 1) if 2 * p + 1 < nt else 0) for p in range((nt + 1) // 2))
+    pf = -(-(maxg * 64 * (4 * rb // 16)) // 256)
+    return ns <= (64 if real == "f64" else 100) and 2 * pf * 256 * 16 <= 163840
