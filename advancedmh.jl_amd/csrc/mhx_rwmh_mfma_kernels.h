@@ -6,9 +6,9 @@
 // D = fma(a_k3, b_k3, fma(a_k2, b_k2, fma(a_k1, b_k1, fma(a_k0, b_k0, C)))), one rounding per product -- so the
 // accumulator of row i after the k-steps 0 .. i/4 IS the arithmetic spec's w_i = sum_{j<=i} A_ij y_j (ascending j, fma from
 // 0; the zeros of the upper triangle add nothing): bit for bit the chain of mhx_rwmh_dense_kernels.h and of the oracle.
-// What the matrix pipe buys is not flops (its f32 / f64 rate equals the vector rate) but operands: one 4-byte A operand
-// per lane feeds 4 x 16 x 16 multiply-adds where the vector kernel reads one LDS value per lane per fma, and the MFMAs
-// run beside the VALU's Philox / Box-Muller work instead of competing with it for issue slots.
+// What the matrix instruction buys is not flops -- its f32 / f64 rate equals the vector rate, and on gfx950 it does not even
+// run beside the VALU (tools/ubench/mfma_overlap.hip: MFMAs + v_fma take the SUM of their times) -- but operands: one A
+// operand per lane feeds 4 x 16 x 16 multiply-adds where the vector kernel reads one LDS value per lane per fma.
 //
 // Geometry.  A wave holds 16 chains; chain j = lane & 15 is spread over the four lanes g = lane >> 4:
 //   * lane g owns the dimensions k = 4s + g (s = 0 .. NS-1): exactly the B operand of k-step s (B[k = lane>>4][j]),
