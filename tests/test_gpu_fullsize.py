@@ -116,3 +116,49 @@ def test_c5_shard_size_rwmh(mhx, oracle, real):
     for off in (0, C - 32):
         ref = oracle.rwmh(ot, oracle.Proposal(oracle.PROP_ISO, s), oracle.schedule(N), 5, first + off, 32)
         _same(chain.value[:, :, off:off + 32], ref["samples"], "samples of chains %d.." % (first + off))
+
+
+@pytest.mark.parametrize("target", ["funnel", "banana"])
+def test_c5_as_specified_eight_shards_on_one_device(mhx, oracle, target, real):
+    """configs[4] as written -- 1000 dimensions, 262 144 chains over 8 GPUs, R-hat by one reduction -- with the eight
+    32 768-chain shards run one after the other on this device (global chain ids, running moments of the thinned states):
+    the per-shard sums the ranks would all-reduce (mhx.dist.pack_stats) add up to the sums of ONE unsharded 262 144-chain
+    run, chains of the first, a middle and the last shard are the oracle's bit for bit, and the combined R-hat is finite."""
+    from mhx import api, dist
+    d, Cs, G, N, thin = 1000, 32768, 8, 3, 2
+    s = float(np.float32(2.38 / d ** 0.5))
+    tgt = mhx.Funnel(d) if target == "funnel" else mhx.Banana(d, 0.03)
+    ot = oracle.Target(oracle.TARGET_FUNNEL, d) if target == "funnel" else oracle.Target(oracle.TARGET_BANANA, d, params=[0.03])
+    model, spl = mhx.DensityModel(tgt), mhx.RWMH(mhx.MvNormal(mhx.zeros(d), s * s * mhx.I))
+    packed, lanes = [], None
+    for g in range(G):
+        run = mhx.Run(model, spl, nchains=Cs, seed=5, first_chain=g * Cs)
+        run.init(None)
+        run.sample(N, 1, thin, 0, save="moments")
+        st = run.stats()
+        lanes = st["reduce_lanes"]
+        dg = run.diagnostics()
+        packed.append(dist.pack_stats(dg, st["accepted"], st["transitions"]))
+        if g in (0, 3, 7):                                              # parity of a few chains of this shard
+            x, lp, cnt = run.state()
+            nt = 1 + thin * (N - 1)
+            ref = oracle.rwmh(ot.with_lanes(lanes), oracle.Proposal(oracle.PROP_ISO, s), oracle.schedule(nt + 1), 5, g * Cs + Cs - 16, 16)
+            _same(x[:, Cs - 16:], ref["final_x"], "final states, shard %d" % g)
+            _same(cnt[Cs - 16:], ref["accept_counts"], "accept counts, shard %d" % g)
+        run.close()
+    v = np.sum(packed, axis=0)                                           # what the all-reduce leaves on every rank
+    d1 = (v.size - 3) // 3
+    assert int(round(v[3 * d1 + 2])) == G * Cs
+    comb = api.combine_diagnostics(v[:d1], v[d1:2 * d1], v[2 * d1:3 * d1], G * Cs, N)
+    assert np.isfinite(comb["rhat"]).all() and (comb["rhat"] > 0.9).all()
+    # the same run unsharded: 262 144 chains at once
+    run = mhx.Run(model, spl, nchains=G * Cs, seed=5, first_chain=0)
+    run.init(None)
+    run.sample(N, 1, thin, 0, save="moments")
+    dg = run.diagnostics()
+    st = run.stats()
+    whole = dist.pack_stats(dg, st["accepted"], st["transitions"])
+    run.close()
+    assert st["reduce_lanes"] == lanes
+    assert v[3 * d1] == whole[3 * d1] and v[3 * d1 + 1] == whole[3 * d1 + 1]          # accepted, transitions: integers
+    assert np.allclose(v[:3 * d1], whole[:3 * d1], rtol=1e-9 if real == "f64" else 2e-4, atol=1e-6 if real == "f64" else 1e-1)
