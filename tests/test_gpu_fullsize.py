@@ -162,3 +162,26 @@ def test_c5_as_specified_eight_shards_on_one_device(mhx, oracle, target, real):
     assert st["reduce_lanes"] == lanes
     assert v[3 * d1] == whole[3 * d1] and v[3 * d1 + 1] == whole[3 * d1 + 1]          # accepted, transitions: integers
     assert np.allclose(v[:3 * d1], whole[:3 * d1], rtol=1e-9 if real == "f64" else 2e-4, atol=1e-6 if real == "f64" else 1e-1)
+
+
+def test_state_slab_beyond_four_gigabytes(mhx, oracle, real):
+    """Maximum sizes: the register / cooperative kernels address the [dim+1][nchains] slab with 32-bit byte offsets, so a run
+    whose slab reaches 4 GB must take the 64-bit state-in-HBM kernel on its own -- and still be the oracle's chains, first
+    and last (the last chains sit behind the 4 GB mark)."""
+    d = 100
+    rb = 8 if real == "f64" else 4
+    C = ((1 << 32) // ((d + 1) * rb) + 4096) // 64 * 64          # just past 2^32 bytes
+    s = float(np.float32(2.38 / d ** 0.5))
+    run = mhx.Run(mhx.DensityModel(mhx.IsoGaussian(d)), mhx.RWMH(mhx.MvNormal(mhx.zeros(d), s * s * mhx.I)), nchains=C, seed=11)
+    run.init(None)
+    run.sample(1, 3, 1, 0, save=False)
+    st = run.stats()
+    assert st["kernel_variant"] == 0 and st["reduce_lanes"] == 1 and st["transitions"] == 3 * C
+    x, lp, cnt = run.state()
+    run.close()
+    assert (d + 1) * rb * C >= 1 << 32
+    for first in (0, C - 8):
+        ref = oracle.rwmh(oracle.iso_gauss(d), oracle.Proposal(oracle.PROP_ISO, s), oracle.schedule(4), 11, first, 8)
+        _same(x[:, first:first + 8], ref["final_x"], "final states of chains %d.." % first)
+        _same(lp[first:first + 8], ref["final_lp"], "final lp")
+        _same(cnt[first:first + 8], ref["accept_counts"], "accept counts")
