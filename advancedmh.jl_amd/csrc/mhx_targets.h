@@ -57,15 +57,44 @@ MHX_DEV mhx_real mhx_target_eval(int kind, const X& x, const int d, const mhx_re
         return mhx_fma(-MHX_R(0.5), q, cst);
     }
     case MHX_TARGET_CORR_GAUSS: {
+        // w_i = sum_{j<=i} A_ij x_j (ascending j, fma from 0), q = sum_i w_i^2 (ascending i): rows are walked EIGHT at a time
+        // so that one read of x_j (a strided HBM / L2 access in the run-time-dimension kernels) feeds eight row chains --
+        // every chain and the order of the squares are those of the row-by-row loop, bit for bit
         mhx_real q = MHX_R(0.0);
-        int off = 0;
+        constexpr int RB8 = 8;
 #pragma unroll
-        for (int i = 0; i < d; ++i) {
-            mhx_real w = MHX_R(0.0);
+        for (int i0 = 0; i0 < d; i0 += RB8) {
+            mhx_real w[RB8];
+            int off[RB8];
 #pragma unroll
-            for (int j = 0; j <= i; ++j) w = mhx_fma(p[off + j], x[j], w);
-            q = mhx_fma(w, w, q);
-            off += i + 1;
+            for (int r = 0; r < RB8; ++r) { w[r] = MHX_R(0.0); off[r] = (i0 + r) * (i0 + r + 1) / 2; }
+            if (i0 + RB8 <= d) {
+                // a whole block of rows: columns 0 .. i0 feed all eight chains, the triangle behind them row by row
+#pragma unroll
+                for (int j = 0; j <= i0; ++j) {
+                    const mhx_real xj = x[j];
+#pragma unroll
+                    for (int r = 0; r < RB8; ++r) w[r] = mhx_fma(p[off[r] + j], xj, w[r]);
+                }
+#pragma unroll
+                for (int jj = 1; jj < RB8; ++jj) {
+                    const mhx_real xj = x[i0 + jj];
+#pragma unroll
+                    for (int r = jj; r < RB8; ++r) w[r] = mhx_fma(p[off[r] + i0 + jj], xj, w[r]);
+                }
+            } else {
+                const int jmax = d - 1;
+#pragma unroll
+                for (int j = 0; j <= jmax; ++j) {
+                    const mhx_real xj = x[j];
+#pragma unroll
+                    for (int r = 0; r < RB8; ++r)
+                        if (j <= i0 + r && i0 + r < d) w[r] = mhx_fma(p[off[r] + j], xj, w[r]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < RB8; ++r)
+                if (i0 + r < d) q = mhx_fma(w[r], w[r], q);
         }
         return mhx_fma(-MHX_R(0.5), q, cst);
     }
