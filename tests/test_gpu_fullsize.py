@@ -185,3 +185,22 @@ def test_state_slab_beyond_four_gigabytes(mhx, oracle, real):
         _same(x[:, first:first + 8], ref["final_x"], "final states of chains %d.." % first)
         _same(lp[first:first + 8], ref["final_lp"], "final lp")
         _same(cnt[first:first + 8], ref["accept_counts"], "accept counts")
+
+
+def test_c2_posterior_moments_at_scale(mhx, real):
+    """Known answer at the headline size: 65 536 chains x 40 000 transitions on the 100-dim standard normal, running moments of
+    every 40th state after 8 000 discarded -- pooled mean 0, within-chain variance 1, R-hat ~ 1 (north_star: posterior mean / std
+    within tolerance).  6.5e7 kept draws per parameter: the pooled mean's Monte Carlo error is ~ 1e-3 at tau ~ 300."""
+    d, C = 100, 65536
+    s = float(np.float32(2.38 / d ** 0.5))
+    run = mhx.Run(mhx.DensityModel(mhx.IsoGaussian(d)), mhx.RWMH(mhx.MvNormal(mhx.zeros(d), s * s * mhx.I)), nchains=C, seed=2024)
+    run.init(None)
+    run.sample(800, 8000, 40, 0, save="moments")
+    dg = run.diagnostics()
+    st = run.stats()
+    run.close()
+    assert 0.22 < st["accepted"] / st["transitions"] < 0.26                      # the 0.234 regime
+    assert np.abs(dg["mean"][:d]).max() < 6e-3, np.abs(dg["mean"][:d]).max()
+    assert np.abs(dg["W"][:d] - 1.0).max() < 0.02, np.abs(dg["W"][:d] - 1.0).max()
+    assert (dg["rhat"][:d] < 1.02).all() and (dg["rhat"][:d] > 0.99).all()
+    assert abs(dg["mean"][d] + 0.5 * d * (1.0 + np.log(2 * np.pi))) < 0.05         # E[lp] = -d/2 (1 + log 2 pi)
