@@ -204,3 +204,31 @@ def test_c2_posterior_moments_at_scale(mhx, real):
     assert np.abs(dg["W"][:d] - 1.0).max() < 0.02, np.abs(dg["W"][:d] - 1.0).max()
     assert (dg["rhat"][:d] < 1.02).all() and (dg["rhat"][:d] > 0.99).all()
     assert abs(dg["mean"][d] + 0.5 * d * (1.0 + np.log(2 * np.pi))) < 0.05         # E[lp] = -d/2 (1 + log 2 pi)
+
+
+def test_ram_adaptation_reaches_its_target_over_many_chains(mhx, real):
+    """RobustAdaptiveMetropolis drives the acceptance towards alpha = 0.234 (src/RobustAdaptiveMetropolis.jl:153-173): 32 768
+    chains on an 8-dim Gaussian with kappa = 100 from a random start, S0 = I.  The acceptance of transitions 6 000 - 7 000 (all chains) has moved from its early
+    value towards the target, no factor left the positive-definite cone, eta = n^-0.6 with the
+    iteration before its increment.  (At d = 200 the same pull takes O(1e5) transitions: a rank-1 step moves one direction.)"""
+    d, C = 8, 32768
+    rng = np.random.default_rng(7)
+    Q, _ = np.linalg.qr(rng.normal(size=(d, d)))
+    Sig = (Q * 100.0 ** (np.arange(d) / (d - 1.0))) @ Q.T
+    x0 = (np.linalg.cholesky(Sig) @ rng.normal(size=(d, C))).astype(np.float32)
+    run = mhx.Run(mhx.DensityModel(mhx.CorrGaussian(Sig)), mhx.RobustAdaptiveMetropolis(), nchains=C, seed=6)
+    run.init(x0)
+    marks = []
+    for nsteps in (500, 500, 5000, 1000):
+        run.sample(1, nsteps, 1, nsteps + 1, save=False)
+        marks.append(run.stats())
+    S, status = run.factor()
+    ad = run.adapt_state()
+    run.close()
+    rate = lambda m: m["accepted"] / float(m["transitions"])              # mhx_stats counts the last call
+    early, late = rate(marks[1]), rate(marks[3])
+    # from S0 = I (too small for variances up to 100) the acceptance starts high and is pulled down towards 0.234; with
+    # gamma = 0.6 the pull is slow -- 0.35 after 7 000 transitions (the oracle, bit for bit the same chains, says the same)
+    assert 0.234 - 0.02 < late < early - 0.05 and late < 0.40, (early, late)
+    assert (status == 0).all() and np.isfinite(S).all()
+    assert ad["iteration"] == 7001 and abs(ad["η"] - 7000.0 ** -0.6) < 1e-6 * ad["η"]
