@@ -232,3 +232,20 @@ def test_ram_adaptation_reaches_its_target_over_many_chains(mhx, real):
     assert 0.234 - 0.02 < late < early - 0.05 and late < 0.40, (early, late)
     assert (status == 0).all() and np.isfinite(S).all()
     assert ad["iteration"] == 7001 and abs(ad["η"] - 7000.0 ** -0.6) < 1e-6 * ad["η"]
+
+
+def test_c3_ensemble_known_answer_at_scale(mhx, real):
+    """configs[2] as a known answer: 16 384 walkers, 50-dim Gaussian with Sigma_ij = 0.9^|i-j|, initial walkers drawn on the
+    device from N(0, I); after 20 000 sweeps of burn-in (the stretch move mixes slowly in 50 dimensions) the walkers of 20 sweeps 200 apart reproduce mean 0, unit variances and
+    the neighbour correlation 0.9 (the stretch move leaves the target invariant, src/emcee.jl:70-102)."""
+    d, W = 50, 16384
+    Sig = cases.sigma_ar1(d, 0.9)
+    spl = mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I)))
+    chain = mhx.sample(mhx.DensityModel(mhx.CorrGaussian(Sig)), spl, 20, seed=12, discard_initial=20000, thinning=200)
+    v = chain.value[:, :d, :].astype(np.float64)                        # [20][d][W]
+    pooled = v.transpose(1, 0, 2).reshape(d, -1)
+    assert np.abs(pooled.mean(axis=1)).max() < 0.03
+    assert np.abs(pooled.var(axis=1) - 1.0).max() < 0.05
+    nb = [np.corrcoef(pooled[k], pooled[k + 1])[0, 1] for k in range(d - 1)]
+    assert abs(np.mean(nb) - 0.9) < 0.01 and np.abs(np.array(nb) - 0.9).max() < 0.03
+    assert 0.1 < chain.accepted[1:].mean() < 0.5
