@@ -249,3 +249,26 @@ def test_c3_ensemble_known_answer_at_scale(mhx, real):
     nb = [np.corrcoef(pooled[k], pooled[k + 1])[0, 1] for k in range(d - 1)]
     assert abs(np.mean(nb) - 0.9) < 0.01 and np.abs(np.array(nb) - 0.9).max() < 0.03
     assert 0.1 < chain.accepted[1:].mean() < 0.5
+
+
+@pytest.mark.parametrize("sampler", ["rwmh", "mala"])
+def test_matrix_core_kernels_known_answer(mhx, sampler, real):
+    """The dense Gaussian target on the matrix cores as a known answer: 16 384 chains on the 100-dim AR(1) Gaussian with
+    Sigma_ij = 0.6^|i-j| from x0 = 0; the states of 12 draws far apart reproduce mean 0, unit variances and the neighbour
+    correlation 0.6 -- RWMH (mhx_rwmh_mfma_kernels.h) and MALA (mhx_mala_mfma_kernels.h, src/MALA.jl:54-93)."""
+    d, C = 100, 16384
+    Sig = cases.sigma_ar1(d, 0.6)
+    model = mhx.DensityModel(mhx.CorrGaussian(Sig))
+    if sampler == "rwmh":
+        s = 2.38 / d ** 0.5
+        spl, disc, thin = mhx.RWMH(mhx.MvNormal(mhx.zeros(d), s * s * mhx.I)), 30000, 3000
+    else:
+        spl, disc, thin = mhx.MALA(0.3 / d ** (1 / 3)), 3000, 300
+    chain = mhx.sample(model, spl, 12, C, seed=21, discard_initial=disc, thinning=thin, initial_params=np.zeros(d))
+    assert chain.stats["kernel_variant"] == 8 and chain.stats["reduce_lanes"] == 4
+    v = chain.value[:, :d, :].astype(np.float64)
+    pooled = v.transpose(1, 0, 2).reshape(d, -1)
+    assert np.abs(pooled.mean(axis=1)).max() < 0.03
+    assert np.abs(pooled.var(axis=1) - 1.0).max() < 0.04
+    nb = np.array([np.corrcoef(pooled[k], pooled[k + 1])[0, 1] for k in range(d - 1)])
+    assert abs(nb.mean() - 0.6) < 0.01 and np.abs(nb - 0.6).max() < 0.03
