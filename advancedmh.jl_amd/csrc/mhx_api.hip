@@ -192,7 +192,7 @@ int api_ctx_destroy(mhx_ctx* ctx)
 
 // compile `source` (which #includes the embedded device headers) with hiprtc for gfx950
 static int jit_compile(mhx_ctx* ctx, const std::string& key, const std::string& source,
-                       const std::vector<std::string>& defines, jit_module** out)
+                       const std::vector<std::string>& defines, jit_module** out, const std::vector<std::string>& extra_opts = {})
 {
     auto it = ctx->jit.find(key);
     if (it != ctx->jit.end()) { *out = it->second.get(); return MHX_OK; }
@@ -209,6 +209,7 @@ static int jit_compile(mhx_ctx* ctx, const std::string& key, const std::string& 
     std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
                                      MHX_REAL64 ? "-DMHX_REAL64=1" : "-DMHX_REAL64=0"};
     for (auto& d : defines) opts.push_back("-D" + d);
+    for (auto& o : extra_opts) opts.push_back(o);
     std::vector<const char*> copts;
     for (auto& o : opts) copts.push_back(o.c_str());
     r = hiprtcCompileProgram(prog, (int)copts.size(), copts.data());
@@ -589,24 +590,32 @@ static bool mfma_fits(int d, int reduce_lanes, int nimages)
     return (reduce_lanes == 0 || reduce_lanes == 4) && d >= 16 && (d + 3) / 4 <= MHX_MFMA_MAX_NS && !(no_mfma && atoi(no_mfma)) &&
            nimages * mfma_image_reals(d) * sizeof(mhx_real) <= MHX_LDS_PER_BLOCK;
 }
-// streamed images (larger than a block's LDS): two ring buffers of whole 256-thread rounds of 16-byte pieces of the largest tile pair
+// streamed images (larger than a block's LDS): two ring buffers of whole 256-thread rounds of 16-byte pieces of the largest chunk
+// -- a tile pair, or (the largest dimensions) a single tile with the chain state re-read from its slab instead of held in registers
 #define MHX_MFMA_STREAM_MAX_NS (MHX_REAL64 ? 64 : 100)
-static size_t mfma_ring_bytes(int d)
+#define MHX_MFMA_XMEM_MAX_NS (MHX_REAL64 ? 128 : 250)   // fp64 d <= 512, fp32 d <= 1000: the candidate alone fills the registers of a wave (1 per SIMD)
+static size_t mfma_ring_bytes(int d, bool pair = true)
 {
     const int NS = (d + 3) / 4, NT = (d + 15) / 16;
     auto groups = [&](int t) { return (std::min(4 * (t + 1), NS) + 3) / 4; };
     int maxg = 0;
-    for (int p = 0; 2 * p < NT; ++p) maxg = std::max(maxg, groups(2 * p) + (2 * p + 1 < NT ? groups(2 * p + 1) : 0));
+    if (pair) for (int p = 0; 2 * p < NT; ++p) maxg = std::max(maxg, groups(2 * p) + (2 * p + 1 < NT ? groups(2 * p + 1) : 0));
+    else for (int t = 0; t < NT; ++t) maxg = std::max(maxg, groups(t));
     const int p16 = (int)(4 * sizeof(mhx_real)) / 16;
     const int pf = (maxg * 64 * p16 + 64 * MHX_MFMA_WAVES - 1) / (64 * MHX_MFMA_WAVES);
     return (size_t)2 * pf * 64 * MHX_MFMA_WAVES * 16;
 }
-static bool mfma_stream_fits(int d, int reduce_lanes)
+// 0 = no, 1 = tile pairs + state in registers, 2 = single tiles + state in HBM
+static int mfma_stream_mode(int d, int reduce_lanes)
 {
     const char* no_mfma = getenv("MHX_NO_MFMA");
-    return (reduce_lanes == 0 || reduce_lanes == 4) && d >= 16 && (d + 3) / 4 <= MHX_MFMA_STREAM_MAX_NS && !(no_mfma && atoi(no_mfma)) &&
-           mfma_ring_bytes(d) <= MHX_LDS_PER_BLOCK;
+    if (!((reduce_lanes == 0 || reduce_lanes == 4) && d >= 16) || (no_mfma && atoi(no_mfma))) return 0;
+    const int NS = (d + 3) / 4;
+    if (NS <= MHX_MFMA_STREAM_MAX_NS && mfma_ring_bytes(d, true) <= MHX_LDS_PER_BLOCK) return 1;
+    if (NS <= MHX_MFMA_XMEM_MAX_NS && mfma_ring_bytes(d, false) <= MHX_LDS_PER_BLOCK) return 2;
+    return 0;
 }
+static bool mfma_stream_fits(int d, int reduce_lanes) { return mfma_stream_mode(d, reduce_lanes) != 0; }
 static int mfma_waves(int d)
 {
     const int NS = (d + 3) / 4;
@@ -702,7 +711,7 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
         }
         coop_one_lane = walk && L == 1 && nblk <= MHX_COOP_NBL_MAX;
     } else if (((tk == MHX_TARGET_CORR_GAUSS) || (tk == MHX_TARGET_ISO_GAUSS && pk == MHX_PROP_DENSE)) &&
-               !walk && !(r->flags & (MHX_FLAG_GENERIC | MHX_FLAG_NO_JIT)) && d >= 2 && d <= 4 * MHX_MFMA_STREAM_MAX_NS &&
+               !walk && !(r->flags & (MHX_FLAG_GENERIC | MHX_FLAG_NO_JIT)) && d >= 2 && d <= 4 * std::max(MHX_MFMA_STREAM_MAX_NS, MHX_MFMA_XMEM_MAX_NS) &&
                (cfg->reduce_lanes > 1 || (cfg->reduce_lanes == 0 && d >= 16)) &&
                (mfma_fits(d, cfg->reduce_lanes, (tk == MHX_TARGET_CORR_GAUSS ? 1 : 0) + (pk == MHX_PROP_DENSE ? 1 : 0)) ||
                 mfma_stream_fits(d, cfg->reduce_lanes) ||
@@ -736,15 +745,21 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
             // the images do not fit a block's LDS: they stay in global memory (built once, here) and every block walks them
             // through an LDS ring, one tile pair at a time
             jit_module* m = nullptr;
-            const std::string key = "rwmh_mfma_stream/d=" + std::to_string(d) + "/pk=" + std::to_string(pk) + "/tk=" + std::to_string(tk);
+            const int smode = mfma_stream_mode(d, cfg->reduce_lanes);
+            const std::string key = "rwmh_mfma_stream/d=" + std::to_string(d) + "/pk=" + std::to_string(pk) + "/tk=" + std::to_string(tk) +
+                                    "/mode=" + std::to_string(smode);
+            // the kernel is fully unrolled over its tiles: lift hipcc's size limit for `#pragma unroll` (past it the candidate
+            // would be indexed dynamically, i.e. live in scratch)
             rc = jit_compile(ctx, key, jit_source(t, "mhx_rwmh_mfma_kernels.h"),
                              {"MHX_JIT_RWMH_MFMA_STREAM=1", "MHX_JIT_DIM=" + std::to_string(d), "MHX_JIT_PK=" + std::to_string(pk),
-                              "MHX_JIT_TK=" + std::to_string(tk), "MHX_JIT_WAVES=1"}, &m);
+                              "MHX_JIT_TK=" + std::to_string(tk), "MHX_JIT_WAVES=1", std::string("MHX_JIT_PAIR=") + (smode == 1 ? "1" : "0"),
+                              std::string("MHX_JIT_XMEM=") + (smode == 2 ? "1" : "0")}, &m,
+                             {"-mllvm", "-pragma-unroll-threshold=4000000"});
             hipFunction_t fimg = nullptr;
             if (rc == MHX_OK) rc = jit_function(m, "mhx_jit_rwmh_mfma_stream", &r->jit_step);
             if (rc == MHX_OK) rc = jit_function(m, "mhx_jit_mfma_image", &fimg);
             if (rc == MHX_OK) {
-                r->dense_lds = mfma_ring_bytes(d);
+                r->dense_lds = mfma_ring_bytes(d, smode == 1);
                 if (hipFuncSetAttribute((const void*)r->jit_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->dense_lds) != hipSuccess)
                     rc = mhx_fail(MHX_EHIP, "streamed matrix-core kernel: %zu bytes of LDS refused", r->dense_lds);
             }

@@ -91,6 +91,18 @@ MHX_DEV void mhx_srd_store(mhx_srd srd, mhx_u32 lane_byte_off, mhx_u32 row_byte_
 }
 #endif
 
+#if MHX_REAL64
+MHX_DEV double mhx_srd_load(mhx_srd srd, mhx_u32 lane_byte_off, mhx_u32 row_byte_off)
+{
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(srd, (int)lane_byte_off, (int)row_byte_off, 0));
+}
+#else
+MHX_DEV float mhx_srd_load(mhx_srd srd, mhx_u32 lane_byte_off, mhx_u32 row_byte_off)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, (int)lane_byte_off, (int)row_byte_off, 0));
+}
+#endif
+
 // v_readlane of a real (two dwords in fp64)
 MHX_DEV mhx_real mhx_readlane(const mhx_real x, const int lane)
 {

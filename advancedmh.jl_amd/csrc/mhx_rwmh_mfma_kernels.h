@@ -181,13 +181,15 @@ MHX_DEV void mhx_mfma_rows_T(const mhx_real* imgT, const int lane, const mhx_rea
 // ---- images larger than a block's LDS: streamed.  The image lives in HBM / L2 (built once per run); a block walks it in
 // chunks of one tile PAIR (adjacent in the image) through a two-buffer LDS ring: every thread holds its share of the NEXT
 // chunk in registers while the MFMAs of the current one run, drops it into the other buffer, one block barrier per chunk.
-template <int D>
+// PAIR: a chunk is a tile pair (two independent accumulator chains); otherwise one tile (half the ring: the largest images).
+template <int D, bool PAIR = true>
 struct mhx_mfma_stream_geom {
     typedef mhx_mfma_geom<D> GEO;
     static constexpr int THREADS = 64 * MHX_MFMA_WAVES;
-    static constexpr int NP = (GEO::NT + 1) / 2;                                  // tile pairs = chunks per image
-    static constexpr int first(int p) { return GEO::first(2 * p) / 4; }           // in groups
-    static constexpr int groups(int p) { return GEO::groups(2 * p) + (2 * p + 1 < GEO::NT ? GEO::groups(2 * p + 1) : 0); }
+    static constexpr int TPC = PAIR ? 2 : 1;                                      // tiles per chunk
+    static constexpr int NP = (GEO::NT + TPC - 1) / TPC;                          // chunks per image
+    static constexpr int first(int p) { return GEO::first(TPC * p) / 4; }         // in groups
+    static constexpr int groups(int p) { return GEO::groups(TPC * p) + (PAIR && 2 * p + 1 < GEO::NT ? GEO::groups(2 * p + 1) : 0); }
     static constexpr int maxg() { int m = 0; for (int p = 0; p < NP; ++p) m = groups(p) > m ? groups(p) : m; return m; }
     static constexpr int MAXG = maxg();
     static constexpr int P16 = (int)sizeof(mhx_acc4) / 16;                        // 16-byte pieces per lane and group
@@ -200,10 +202,10 @@ struct mhx_mfma_stream_geom {
 // this thread's pieces of chunk p of the image behind the descriptor `img`: wave-uniform chunk offset (SGPR), one 32-bit lane
 // offset -- no 64-bit vector address per piece
 typedef mhx_u32 mhx_piece16 __attribute__((ext_vector_type(4)));
-template <int D>
-MHX_DEV void mhx_mfma_chunk_load(const mhx_srd img, const int p, mhx_piece16 (&pf)[mhx_mfma_stream_geom<D>::PF])
+template <int D, bool PAIR>
+MHX_DEV void mhx_mfma_chunk_load(const mhx_srd img, const int p, mhx_piece16 (&pf)[mhx_mfma_stream_geom<D, PAIR>::PF])
 {
-    typedef mhx_mfma_stream_geom<D> SG;
+    typedef mhx_mfma_stream_geom<D, PAIR> SG;
     // whole rounds of the block, no per-thread predicate: the last round may run into the next chunk (ignored) or past the
     // image (the descriptor's range check returns zeros)
     const mhx_u32 voff = (mhx_u32)threadIdx.x * 16u;
@@ -216,13 +218,13 @@ MHX_DEV void mhx_mfma_chunk_load(const mhx_srd img, const int p, mhx_piece16 (&p
 
 // mhx_mfma_rows over a streamed image.  `pf` holds chunk 0 of this image on entry and, on return, chunk 0 of `gnext` (the image
 // the step walks next -- itself if it is the only one); `parity` is the ring buffer the next chunk goes to.
-template <int D, int MODE>
+template <int D, int MODE, bool PAIR>
 MHX_DEV void mhx_mfma_rows_stream(const mhx_srd gimg, const mhx_srd gnext, mhx_real* ring, const int lane,
                                   const mhx_real (&b)[mhx_mfma_geom<D>::NS], mhx_real& q, mhx_real (&out)[mhx_mfma_geom<D>::NS],
-                                  mhx_piece16 (&pf)[mhx_mfma_stream_geom<D>::PF], int& parity)
+                                  mhx_piece16 (&pf)[mhx_mfma_stream_geom<D, PAIR>::PF], int& parity)
 {
     typedef mhx_mfma_geom<D> GEO;
-    typedef mhx_mfma_stream_geom<D> SG;
+    typedef mhx_mfma_stream_geom<D, PAIR> SG;
 #pragma unroll
     for (int p = 0; p < SG::NP; ++p) {
         mhx_acc4* buf = (mhx_acc4*)((char*)ring + (parity ? SG::BUF_BYTES : 0));
@@ -230,16 +232,16 @@ MHX_DEV void mhx_mfma_rows_stream(const mhx_srd gimg, const mhx_srd gnext, mhx_r
         for (int i = 0; i < SG::PF; ++i)
             if (i < SG::pieces(p)) ((mhx_piece16*)buf)[(int)threadIdx.x + i * SG::THREADS] = pf[i];
         __syncthreads();                                  // the chunk is complete; the other buffer is free (see above)
-        if (p + 1 < SG::NP) mhx_mfma_chunk_load<D>(gimg, p + 1, pf);
-        else mhx_mfma_chunk_load<D>(gnext, 0, pf);
+        if (p + 1 < SG::NP) mhx_mfma_chunk_load<D, PAIR>(gimg, p + 1, pf);
+        else mhx_mfma_chunk_load<D, PAIR>(gnext, 0, pf);
         constexpr mhx_acc4 zero = {MHX_R(0.0), MHX_R(0.0), MHX_R(0.0), MHX_R(0.0)};
         mhx_acc4 c[2] = {zero, zero};
-        const int t0 = 2 * p;
-        const int t1 = t0 + 1 < GEO::NT ? t0 + 1 : t0;
+        const int t0 = SG::TPC * p;
+        const int t1 = PAIR && t0 + 1 < GEO::NT ? t0 + 1 : t0;
 #pragma unroll
         for (int grp = 0; grp < GEO::groups(t1); ++grp) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < SG::TPC; ++h) {
                 const int t = t0 + h;
                 if (t < GEO::NT && grp < GEO::groups(t)) {
                     const mhx_acc4 a4 = buf[(GEO::first(t) / 4 + grp - SG::first(p)) * 64 + lane];
@@ -250,7 +252,7 @@ MHX_DEV void mhx_mfma_rows_stream(const mhx_srd gimg, const mhx_srd gnext, mhx_r
             }
         }
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < SG::TPC; ++h) {
             const int t = t0 + h;
             if (t < GEO::NT) {
 #pragma unroll
@@ -307,7 +309,9 @@ MHX_DEV void mhx_lanes4_transpose(mhx_real (&n)[4])
 // DENSE -- the proposal's Cholesky factor as a second image.
 // STREAM: Aimg / Limg are the pre-built images in global memory and `ring` the LDS ring they are walked through; otherwise
 // they are LDS and filled here.
-template <int D, int PK, int TK, bool STREAM = false>
+// PAIR: see mhx_mfma_stream_geom.  XMEM: the chain state x is NOT held in registers -- the candidate alone is (the B operands) --
+// but re-read from its [dim][ld] slab when the candidate is formed and written back on accept: the largest dimensions.
+template <int D, int PK, int TK, bool STREAM = false, bool PAIR = true, bool XMEM = false>
 MHX_DEV void mhx_rwmh_mfma_body(const mhx_rwmh_args& a, const mhx_real* __restrict__ A, const mhx_real* __restrict__ pvec,
                                 mhx_real* Aimg, mhx_real* Limg, mhx_real* ring = nullptr)
 {
@@ -322,11 +326,11 @@ MHX_DEV void mhx_rwmh_mfma_body(const mhx_rwmh_args& a, const mhx_real* __restri
         __syncthreads();
     }
     // streamed images: the first chunk of the step's first image is in flight before the loop
-    mhx_piece16 pf[STREAM ? mhx_mfma_stream_geom<D>::PF : 1];
+    mhx_piece16 pf[STREAM ? mhx_mfma_stream_geom<D, PAIR>::PF : 1];
     int parity = 0;
     const mhx_u32 img_bytes = (mhx_u32)(GEO::REALS * (long)sizeof(mhx_real));
     const mhx_srd sA = mhx_make_srd(STREAM ? (CORR ? Aimg : Limg) : nullptr, img_bytes), sL = mhx_make_srd(STREAM ? (DENSEP ? Limg : Aimg) : nullptr, img_bytes);
-    if constexpr (STREAM) mhx_mfma_chunk_load<D>(DENSEP ? sL : sA, 0, pf);
+    if constexpr (STREAM) mhx_mfma_chunk_load<D, PAIR>(DENSEP ? sL : sA, 0, pf);
 
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
@@ -345,14 +349,28 @@ MHX_DEV void mhx_rwmh_mfma_body(const mhx_rwmh_args& a, const mhx_real* __restri
     const mhx_u32 lane_off = ((mhx_u32)g * (mhx_u32)ld + (mhx_u32)c) * MHX_RB;
     const mhx_u32 ldb = (mhx_u32)ld * MHX_RB;
     // ---- state: dimensions 4s + g (ABI layout [dim][ld], touched once per launch); the pad stays zero
-    mhx_real xs[NS], sc[PK == MHX_PROP_DIAG ? NS : 1];
+    mhx_real xs[XMEM ? 1 : NS], sc[PK == MHX_PROP_DIAG && !XMEM ? NS : 1];
+    if constexpr (!XMEM) {
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const int k = 4 * s + g;
-        const bool in = 4 * s + 3 < D || k < D;              // only the last slot can fall into the pad
-        xs[s] = in ? mhx_ld_off(a.x + (long)(4 * s) * ld, lane_off) : MHX_R(0.0);
-        if (PK == MHX_PROP_DIAG) sc[s] = in ? pvec[k] : MHX_R(0.0);
+        for (int s = 0; s < NS; ++s) {
+            const int k = 4 * s + g;
+            const bool in = 4 * s + 3 < D || k < D;              // only the last slot can fall into the pad
+            xs[s] = in ? mhx_ld_off(a.x + (long)(4 * s) * ld, lane_off) : MHX_R(0.0);
+            if (PK == MHX_PROP_DIAG) sc[s] = in ? pvec[k] : MHX_R(0.0);
+        }
     }
+    // slot s of the state / of the diagonal scales: a register, or (XMEM) a read of the slab / the scale vector
+    // (through a buffer descriptor: SGPR row offset + the lane offset -- 64-bit vector addresses per slot would be hoisted out of
+    // the step loop and cost two registers each)
+    const mhx_srd xsrd = mhx_make_srd(a.x, (mhx_u32)D * ldb);
+    auto xat = [&](const int s) -> mhx_real {
+        if constexpr (XMEM) return (4 * s + 3 < D || 4 * s + g < D) ? mhx_srd_load(xsrd, lane_off, (mhx_u32)(4 * s) * ldb) : MHX_R(0.0);
+        else return xs[s];
+    };
+    auto scat = [&](const int s) -> mhx_real {
+        if constexpr (XMEM) return (4 * s + 3 < D || 4 * s + g < D) ? pvec[4 * s + g] : MHX_R(0.0);
+        else return sc[s];
+    };
     mhx_real lp = a.lp[c];
     mhx_u32 nacc = a.acc_count[c];
     mhx_u32 wave_acc = 0;
@@ -379,8 +397,8 @@ MHX_DEV void mhx_rwmh_mfma_body(const mhx_rwmh_args& a, const mhx_real* __restri
                 if (s < NS) {                                                              // src/proposal.jl:49-56
                     const bool in = 4 * s + 3 < D || 4 * s + g < D;
                     if (DENSEP) ys[s] = in ? n[e] : MHX_R(0.0);
-                    else if (PK == MHX_PROP_DIAG) ys[s] = mhx_fma(sc[s], n[e], xs[s]);
-                    else ys[s] = in ? mhx_fma(a.pscale, n[e], xs[s]) : MHX_R(0.0);
+                    else if (PK == MHX_PROP_DIAG) ys[s] = mhx_fma(scat(s), n[e], xat(s));
+                    else ys[s] = in ? mhx_fma(a.pscale, n[e], xat(s)) : MHX_R(0.0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);        // one block of normals in flight at a time (register pressure)
@@ -388,16 +406,16 @@ MHX_DEV void mhx_rwmh_mfma_body(const mhx_rwmh_args& a, const mhx_real* __restri
         if (DENSEP) {
             // xi = L z by rows (ascending j, fma from 0); row 16t + 4r + g = dimension 4(4t + r) + g: this lane's
             mhx_real xi[NS], unused = MHX_R(0.0);
-            if constexpr (STREAM) mhx_mfma_rows_stream<D, 2>(sL, CORR ? sA : sL, ring, lane, ys, unused, xi, pf, parity);
+            if constexpr (STREAM) mhx_mfma_rows_stream<D, 2, PAIR>(sL, CORR ? sA : sL, ring, lane, ys, unused, xi, pf, parity);
             else mhx_mfma_rows<D, 2>(Limg, lane, ys, unused, xi);
 #pragma unroll
-            for (int s = 0; s < NS; ++s) ys[s] = (4 * s + 3 < D || 4 * s + g < D) ? xs[s] + xi[s] : MHX_R(0.0);
+            for (int s = 0; s < NS; ++s) ys[s] = (4 * s + 3 < D || 4 * s + g < D) ? xat(s) + xi[s] : MHX_R(0.0);
         }
         // ---- lp': dense Gaussian -1/2 |A y|^2 + const, rows g, g+4, ... by this lane; butterfly over the chain's lanes
         mhx_real q = MHX_R(0.0);
         if (CORR) {
             mhx_real unused[NS];
-            if constexpr (STREAM) mhx_mfma_rows_stream<D, 1>(sA, DENSEP ? sL : sA, ring, lane, ys, q, unused, pf, parity);
+            if constexpr (STREAM) mhx_mfma_rows_stream<D, 1, PAIR>(sA, DENSEP ? sL : sA, ring, lane, ys, q, unused, pf, parity);
             else mhx_mfma_rows<D, 1>(Aimg, lane, ys, q, unused);
         } else {
             // isotropic target in the reduction shape L = 4 of the cooperative kernels: lane g owns the BLOCKS g, g+4, ...
@@ -418,8 +436,17 @@ MHX_DEV void mhx_rwmh_mfma_body(const mhx_rwmh_args& a, const mhx_real* __restri
         // ---- accept (src/mh-core.jl:104-114); a zero-mean random walk has no Hastings term
         const mhx_real logu = mhx_accept_logu(ks, id_lo, id_hi, step, ac);
         const bool acc = logu < (lpy - lp);
+        if constexpr (XMEM) {
+            if (acc && valid) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s) xs[s] = acc ? ys[s] : xs[s];
+                for (int s = 0; s < NS; ++s)
+                    if (4 * s + 3 < D || 4 * s + g < D) mhx_srd_store(xsrd, lane_off, (mhx_u32)(4 * s) * ldb, ys[s]);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the slab is current before anything reads it again
+        } else {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) xs[s] = acc ? ys[s] : xs[s];
+        }
         lp = acc ? lpy : lp;
         nacc += acc ? 1u : 0u;
         last = acc;
@@ -429,8 +456,10 @@ MHX_DEV void mhx_rwmh_mfma_body(const mhx_rwmh_args& a, const mhx_real* __restri
                 mhx_real* slotp = a.samples + slot * (long)(D + 1) * ld;
                 const mhx_srd srd = mhx_make_srd(slotp, (mhx_u32)(D + 1) * (mhx_u32)ld * MHX_RB);
 #pragma unroll
-                for (int s = 0; s < NS; ++s)
-                    if (4 * s + 3 < D || 4 * s + g < D) mhx_srd_store(srd, lane_off, (mhx_u32)(4 * s) * ldb, xs[s]);
+                for (int s = 0; s < NS; ++s) {
+                    if (4 * s + 3 < D || 4 * s + g < D) mhx_srd_store(srd, lane_off, (mhx_u32)(4 * s) * ldb, xat(s));
+                    if (XMEM && (s & 7) == 7) __builtin_amdgcn_sched_barrier(0);      // a few re-reads of the slab in flight, not all
+                }
                 if (g == 0) {
                     slotp[(long)D * ld + c] = lp;
                     a.accepted[slot * ld + c] = acc ? 1 : 0;
@@ -441,9 +470,11 @@ MHX_DEV void mhx_rwmh_mfma_body(const mhx_rwmh_args& a, const mhx_real* __restri
         }
     }
     if (valid) {
+        if constexpr (!XMEM) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s)
-            if (4 * s + 3 < D || 4 * s + g < D) mhx_st_off(a.x + (long)(4 * s) * ld, lane_off, xs[s]);
+            for (int s = 0; s < NS; ++s)
+                if (4 * s + 3 < D || 4 * s + g < D) mhx_st_off(a.x + (long)(4 * s) * ld, lane_off, xs[s]);
+        }
         if (g == 0) {
             a.lp[c] = lp;
             a.acc_count[c] = nacc;
@@ -483,7 +514,14 @@ mhx_jit_rwmh_mfma_stream(const mhx_rwmh_args a, const mhx_real* __restrict__ tpa
                          mhx_real* gAimg, mhx_real* gLimg)
 {
     extern __shared__ mhx_acc4 mhx_mfma_ring[];
-    mhx_rwmh_mfma_body<MHX_JIT_DIM, MHX_JIT_PK, MHX_JIT_TK, true>(a, tparams, pvec, gAimg, gLimg, (mhx_real*)mhx_mfma_ring);
+#ifndef MHX_JIT_PAIR
+#define MHX_JIT_PAIR 1
+#endif
+#ifndef MHX_JIT_XMEM
+#define MHX_JIT_XMEM 0
+#endif
+    mhx_rwmh_mfma_body<MHX_JIT_DIM, MHX_JIT_PK, MHX_JIT_TK, true, MHX_JIT_PAIR != 0, MHX_JIT_XMEM != 0>(
+        a, tparams, pvec, gAimg, gLimg, (mhx_real*)mhx_mfma_ring);
 }
 #endif
 MHX_NS_END

@@ -104,4 +104,8 @@ def mfma_fits(d, lanes, nimages, real):
     groups = lambda t: (min(4 * (t + 1), ns) + 3) // 4
     maxg = max(groups(2 * p) + (groups(2 * p + 1) if 2 * p + 1 < nt else 0) for p in range((nt + 1) // 2))
     pf = -(-(maxg * 64 * (4 * rb // 16)) // 256)
-    return ns <= (64 if real == "f64" else 100) and 2 * pf * 256 * 16 <= 163840
+    if ns <= (64 if real == "f64" else 100) and 2 * pf * 256 * 16 <= 163840:
+        return True
+    # single-tile chunks, the chain state re-read from its slab: up to 128 (fp64) / 250 (fp32) reals of candidate per lane
+    pf1 = -(-(max(groups(t) for t in range(nt)) * 64 * (4 * rb // 16)) // 256)
+    return ns <= (128 if real == "f64" else 250) and 2 * pf1 * 256 * 16 <= 163840

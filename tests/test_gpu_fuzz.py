@@ -173,16 +173,17 @@ def test_dimensions_beyond_the_specialised_kernels(mhx, oracle, real):
     assert ch.stats["kernel_variant"] == 0
     same(ch.value, oracle.emcee(oracle.corr_gauss_from_cov(Sig), 2.0, 1, oracle.schedule(3), 2, 0, W, init)["samples"], "emcee dense d=300")
     ch = mhx.sample(mhx.DensityModel(mhx.CorrGaussian(Sig)), mhx.RWMH(mhx.MvNormal(mhx.zeros(d), 0.01 * mhx.I)), 4, 40, seed=7)
-    # fp32: the matrix-core kernel with the factor image streamed through LDS (reduction shape 4); fp64: 75 reals of state per
-    # lane are past its budget, state in HBM
-    assert (ch.stats["kernel_variant"], ch.stats["reduce_lanes"]) == ((0, 1) if real == "f64" else (8, 4))
+    # the matrix-core kernel with the factor image streamed through LDS (reduction shape 4); in fp64 with the chain state
+    # re-read from its slab (75 reals per lane are past the register-resident budget)
+    assert (ch.stats["kernel_variant"], ch.stats["reduce_lanes"]) == (8, 4)
     same(ch.value, oracle.rwmh(oracle.corr_gauss_from_cov(Sig, reduce_lanes=ch.stats["reduce_lanes"]), oracle.Proposal(oracle.PROP_ISO, 0.01 ** 0.5),
                                oracle.schedule(4), 7, 0, 40)["samples"], "rwmh dense d=300")
-    Sig5 = cases.sigma_ar1(500, 0.5)
-    ch = mhx.sample(mhx.DensityModel(mhx.CorrGaussian(Sig5)), mhx.RWMH(mhx.MvNormal(mhx.zeros(500), 0.01 * mhx.I)), 3, 20, seed=7)
+    Sig6 = cases.sigma_ar1(600, 0.5)                          # fp64: past every matrix-core variant (150 reals per lane), state in HBM
+    ch = mhx.sample(mhx.DensityModel(mhx.CorrGaussian(Sig6)), mhx.RWMH(mhx.MvNormal(mhx.zeros(600), 0.01 * mhx.I)), 3, 20, seed=7,
+                    flags=0 if real == "f64" else mhx.FLAG_GENERIC)
     assert ch.stats["kernel_variant"] == 0
-    same(ch.value, oracle.rwmh(oracle.corr_gauss_from_cov(Sig5), oracle.Proposal(oracle.PROP_ISO, 0.01 ** 0.5),
-                               oracle.schedule(3), 7, 0, 20)["samples"], "rwmh dense d=500")
+    same(ch.value, oracle.rwmh(oracle.corr_gauss_from_cov(Sig6), oracle.Proposal(oracle.PROP_ISO, 0.01 ** 0.5),
+                               oracle.schedule(3), 7, 0, 20)["samples"], "rwmh dense d=600")
     d, C = 1024, 6
     ch = mhx.sample(mhx.DensityModel(mhx.IsoGaussian(d)), mhx.RobustAdaptiveMetropolis(), 4, C, seed=5, num_warmup=4, initial_params=np.zeros(d))
     ref = oracle.ram(oracle.iso_gauss(d), oracle.schedule(4, 4, 1, 4), 5, 0, C, init=np.zeros((d, C), dtype=np.float32))
