@@ -97,7 +97,7 @@ def test_parallel_sampling_call_forms(mhx, real):
                                             (16, 100, 0, "iso"), (17, 35, 4, "dense"), (31, 64, 0, "diag"), (64, 16, 4, "dense"),
                                             (100, 65, 4, "diag"), (176, 20, 0, "iso"), (100, 300, 8, "iso"), (50, 33, 2, "dense"),
                                             (300, 20, 0, "iso"), (200, 70, 4, "dense"), (250, 17, 0, "diag"), (384, 9, 0, "dense_iso_target"),
-                                            (448, 9, 0, "diag")])
+                                            (448, 9, 0, "diag"), (300, 9, 0, "dense"), (272, 12, 4, "dense_iso_target")])
 def test_dense_gaussian_target_cooperative_kernel(mhx, oracle, d, C, lanes, prop, real):
     """RWMH on the dense Gaussian target with L lanes per chain (mhx_rwmh_dense_kernels.h): the default above 64
     dimensions, on request below; ISO and DIAG proposals, random initial states, a schedule with discard and
