@@ -16,15 +16,30 @@
 
 MHX_NS_BEGIN
 
-template <int D>
-MHX_DEV void mhx_mala_mfma_body(const mhx_mala_args& a, const mhx_real* __restrict__ A, mhx_real* Aimg, mhx_real* ATimg)
+// STREAM: both images are pre-built in global memory and walked through the LDS ring `ring` (mhx_rwmh_mfma_kernels.h), and x and
+// grad(x) are not held in registers but re-read from their slabs when the candidate / the backward sum is formed and written back
+// on accept: candidate, noise, w and the candidate's gradient are what a lane keeps.
+template <int D, bool STREAM = false>
+MHX_DEV void mhx_mala_mfma_body(const mhx_mala_args& a, const mhx_real* __restrict__ A, mhx_real* Aimg, mhx_real* ATimg,
+                                mhx_real* ring = nullptr)
 {
     typedef mhx_mfma_geom<D> GEO;
     constexpr int NS = GEO::NS;
     constexpr int NQD = (NS + 3) / 4;
-    mhx_mfma_image_fill<D>(A, Aimg);
-    mhx_mfma_image_fill_T<D>(A, ATimg);
-    __syncthreads();
+    if constexpr (!STREAM) {
+        mhx_mfma_image_fill<D>(A, Aimg);
+        mhx_mfma_image_fill_T<D>(A, ATimg);
+        __syncthreads();
+    }
+    typedef mhx_mfma_stream_geom<D, true, false> SGA;
+    typedef mhx_mfma_stream_geom<D, true, true> SGT;
+    constexpr int PFM = SGA::PF > SGT::PF ? SGA::PF : SGT::PF;             // the two images share prefetch registers and ring
+    constexpr long BUFM = SGA::BUF_BYTES > SGT::BUF_BYTES ? SGA::BUF_BYTES : SGT::BUF_BYTES;
+    mhx_piece16 pf[STREAM ? PFM : 1];
+    int parity = 0;
+    const mhx_srd sA = mhx_make_srd(STREAM ? Aimg : nullptr, (mhx_u32)(GEO::REALS * (long)sizeof(mhx_real)));
+    const mhx_srd sAT = mhx_make_srd(STREAM ? ATimg : nullptr, (mhx_u32)(GEO::REALS_T * (long)sizeof(mhx_real)));
+    if constexpr (STREAM) mhx_mfma_chunk_load<D, true, false>(sA, 0, pf);
 
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
@@ -40,13 +55,24 @@ MHX_DEV void mhx_mala_mfma_body(const mhx_mala_args& a, const mhx_real* __restri
     const mhx_u32 lane_off = ((mhx_u32)g * (mhx_u32)ld + (mhx_u32)c) * MHX_RB;
     const mhx_u32 ldb = (mhx_u32)ld * MHX_RB;
 
-    mhx_real xs[NS], gx[NS];
+    mhx_real xs[STREAM ? 1 : NS], gx[STREAM ? 1 : NS];
+    if constexpr (!STREAM) {
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const bool in = 4 * s + 3 < D || 4 * s + g < D;
-        xs[s] = in ? mhx_ld_off(a.x + (long)(4 * s) * ld, lane_off) : MHX_R(0.0);
-        gx[s] = in ? mhx_ld_off(a.gx + (long)(4 * s) * ld, lane_off) : MHX_R(0.0);
+        for (int s = 0; s < NS; ++s) {
+            const bool in = 4 * s + 3 < D || 4 * s + g < D;
+            xs[s] = in ? mhx_ld_off(a.x + (long)(4 * s) * ld, lane_off) : MHX_R(0.0);
+            gx[s] = in ? mhx_ld_off(a.gx + (long)(4 * s) * ld, lane_off) : MHX_R(0.0);
+        }
     }
+    const mhx_srd xsrd = mhx_make_srd(a.x, (mhx_u32)D * ldb), gsrd = mhx_make_srd(a.gx, (mhx_u32)D * ldb);
+    auto xat = [&](const int s) -> mhx_real {
+        if constexpr (STREAM) return (4 * s + 3 < D || 4 * s + g < D) ? mhx_srd_load(xsrd, lane_off, (mhx_u32)(4 * s) * ldb) : MHX_R(0.0);
+        else return xs[s];
+    };
+    auto gat = [&](const int s) -> mhx_real {
+        if constexpr (STREAM) return (4 * s + 3 < D || 4 * s + g < D) ? mhx_srd_load(gsrd, lane_off, (mhx_u32)(4 * s) * ldb) : MHX_R(0.0);
+        else return gx[s];
+    };
     mhx_real lp = a.lp[c];
     mhx_u32 nacc = a.acc_count[c];
     mhx_u32 wave_acc = 0;
@@ -80,7 +106,7 @@ MHX_DEV void mhx_mala_mfma_body(const mhx_mala_args& a, const mhx_real* __restri
                 const int s = 4 * qd + e;
                 if (s < NS) {
                     zs[s] = n[e];
-                    ys[s] = mhx_fma(a.sigma, n[e], mhx_fma(a.h, gx[s], xs[s]));
+                    ys[s] = mhx_fma(a.sigma, n[e], mhx_fma(a.h, gat(s), xat(s)));
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -90,11 +116,13 @@ MHX_DEV void mhx_mala_mfma_body(const mhx_mala_args& a, const mhx_real* __restri
         // ---- value and gradient at the candidate (:73-75): w = A y, lp' = -1/2 |w|^2 + const, grad = -A^T w
         mhx_real w[NS], gy[NS];
         mhx_real q = MHX_R(0.0);
-        mhx_mfma_rows<D, 3>(Aimg, lane, ys, q, w);
+        if constexpr (STREAM) mhx_mfma_rows_stream<D, 3, true, true, BUFM>(sA, sAT, ring, lane, ys, q, w, pf, parity);
+        else mhx_mfma_rows<D, 3>(Aimg, lane, ys, q, w);
         q = q + __shfl_xor(q, 16, 64);
         q = q + __shfl_xor(q, 32, 64);
         const mhx_real lpy = mhx_fma(-MHX_R(0.5), q, a.tconst);
-        mhx_mfma_rows_T<D>(ATimg, lane, w, gy);
+        if constexpr (STREAM) mhx_mfma_rows_T_stream<D, BUFM>(sAT, sA, ring, lane, w, gy, pf, parity);
+        else mhx_mfma_rows_T<D>(ATimg, lane, w, gy);
 #pragma unroll
         for (int s = 0; s < NS; ++s) gy[s] = -gy[s];
         // ---- log ratio of the proposal densities (:78-80): |z + (sigma/2)(grad x + grad y)|^2 in the block shape
@@ -105,7 +133,7 @@ MHX_DEV void mhx_mala_mfma_body(const mhx_mala_args& a, const mhx_real* __restri
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int s = 4 * qd + e;
-                n[e] = s < NS ? mhx_fma(a.hs, gx[s] + gy[s], zs[s]) : MHX_R(0.0);      // the pad is zero throughout
+                n[e] = s < NS ? mhx_fma(a.hs, gat(s) + gy[s], zs[s]) : MHX_R(0.0);      // the pad is zero throughout
             }
             mhx_lanes4_transpose(n);                                                  // block 4qd + g, element e
 #pragma unroll
@@ -116,8 +144,20 @@ MHX_DEV void mhx_mala_mfma_body(const mhx_mala_args& a, const mhx_real* __restri
         const mhx_real loga = (lpy - lp) + MHX_R(0.5) * (fq - bq);                    // :83
         const mhx_real logu = mhx_accept_logu(ks, id_lo, id_hi, step, ac);
         const bool acc = logu < loga;                                                 // :86 (strict)
+        if constexpr (STREAM) {
+            if (acc && valid) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s) { xs[s] = acc ? ys[s] : xs[s]; gx[s] = acc ? gy[s] : gx[s]; }
+                for (int s = 0; s < NS; ++s)
+                    if (4 * s + 3 < D || 4 * s + g < D) {
+                        mhx_srd_store(xsrd, lane_off, (mhx_u32)(4 * s) * ldb, ys[s]);
+                        mhx_srd_store(gsrd, lane_off, (mhx_u32)(4 * s) * ldb, gy[s]);
+                    }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the slabs are current before anything reads them again
+        } else {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) { xs[s] = acc ? ys[s] : xs[s]; gx[s] = acc ? gy[s] : gx[s]; }
+        }
         lp = acc ? lpy : lp;
         nacc += acc ? 1u : 0u;
         last = acc;
@@ -127,8 +167,10 @@ MHX_DEV void mhx_mala_mfma_body(const mhx_mala_args& a, const mhx_real* __restri
                 mhx_real* slotp = a.samples + slot * (long)(D + 1) * ld;
                 const mhx_srd srd = mhx_make_srd(slotp, (mhx_u32)(D + 1) * (mhx_u32)ld * MHX_RB);
 #pragma unroll
-                for (int s = 0; s < NS; ++s)
-                    if (4 * s + 3 < D || 4 * s + g < D) mhx_srd_store(srd, lane_off, (mhx_u32)(4 * s) * ldb, xs[s]);
+                for (int s = 0; s < NS; ++s) {
+                    if (4 * s + 3 < D || 4 * s + g < D) mhx_srd_store(srd, lane_off, (mhx_u32)(4 * s) * ldb, xat(s));
+                    if (STREAM && (s & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                }
                 if (g == 0) {
                     slotp[(long)D * ld + c] = lp;
                     a.accepted[slot * ld + c] = acc ? 1 : 0;
@@ -139,12 +181,14 @@ MHX_DEV void mhx_mala_mfma_body(const mhx_mala_args& a, const mhx_real* __restri
         }
     }
     if (valid) {
+        if constexpr (!STREAM) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s)
-            if (4 * s + 3 < D || 4 * s + g < D) {
-                mhx_st_off(a.x + (long)(4 * s) * ld, lane_off, xs[s]);
-                mhx_st_off(a.gx + (long)(4 * s) * ld, lane_off, gx[s]);
-            }
+            for (int s = 0; s < NS; ++s)
+                if (4 * s + 3 < D || 4 * s + g < D) {
+                    mhx_st_off(a.x + (long)(4 * s) * ld, lane_off, xs[s]);
+                    mhx_st_off(a.gx + (long)(4 * s) * ld, lane_off, gx[s]);
+                }
+        }
         if (g == 0) {
             a.lp[c] = lp;
             a.acc_count[c] = nacc;
@@ -166,6 +210,19 @@ mhx_jit_mala_mfma(const mhx_mala_args a, const mhx_real* __restrict__ tparams)
     extern __shared__ mhx_acc4 mhx_mala_mfma_lds[];
     mhx_real* Aimg = (mhx_real*)mhx_mala_mfma_lds;
     mhx_mala_mfma_body<MHX_JIT_DIM>(a, tparams, Aimg, Aimg + GEO::REALS);
+}
+#endif
+#ifdef MHX_JIT_MALA_MFMA_STREAM
+// the image builders (one block each, once per run) and the streamed kernel: dynamic LDS = the two-buffer ring
+extern "C" __global__ void __launch_bounds__(256)
+mhx_jit_mfma_image(const mhx_real* __restrict__ packed, mhx_real* img) { mhx_mfma_image_fill<MHX_JIT_DIM>(packed, img); }
+extern "C" __global__ void __launch_bounds__(256)
+mhx_jit_mfma_image_T(const mhx_real* __restrict__ packed, mhx_real* img) { mhx_mfma_image_fill_T<MHX_JIT_DIM>(packed, img); }
+extern "C" __global__ void __launch_bounds__(64 * MHX_MFMA_WAVES, 1)
+mhx_jit_mala_mfma_stream(const mhx_mala_args a, const mhx_real* __restrict__ tparams, mhx_real* gAimg, mhx_real* gATimg)
+{
+    extern __shared__ mhx_acc4 mhx_mala_mfma_ring[];
+    mhx_mala_mfma_body<MHX_JIT_DIM, true>(a, tparams, gAimg, gATimg, (mhx_real*)mhx_mala_mfma_ring);
 }
 #endif
 MHX_NS_END

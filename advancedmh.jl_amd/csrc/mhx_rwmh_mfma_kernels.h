@@ -182,14 +182,17 @@ MHX_DEV void mhx_mfma_rows_T(const mhx_real* imgT, const int lane, const mhx_rea
 // chunks of one tile PAIR (adjacent in the image) through a two-buffer LDS ring: every thread holds its share of the NEXT
 // chunk in registers while the MFMAs of the current one run, drops it into the other buffer, one block barrier per chunk.
 // PAIR: a chunk is a tile pair (two independent accumulator chains); otherwise one tile (half the ring: the largest images).
-template <int D, bool PAIR = true>
+// TRANS: the image of A^T (tile t holds the k-groups t .. NT-1).
+template <int D, bool PAIR = true, bool TRANS = false>
 struct mhx_mfma_stream_geom {
     typedef mhx_mfma_geom<D> GEO;
     static constexpr int THREADS = 64 * MHX_MFMA_WAVES;
     static constexpr int TPC = PAIR ? 2 : 1;                                      // tiles per chunk
     static constexpr int NP = (GEO::NT + TPC - 1) / TPC;                          // chunks per image
-    static constexpr int first(int p) { return GEO::first(TPC * p) / 4; }         // in groups
-    static constexpr int groups(int p) { return GEO::groups(TPC * p) + (PAIR && 2 * p + 1 < GEO::NT ? GEO::groups(2 * p + 1) : 0); }
+    static constexpr int tgroups(int t) { return TRANS ? GEO::NT - t : GEO::groups(t); }
+    static constexpr int tfirst(int t) { return TRANS ? GEO::firstT(t) : GEO::first(t) / 4; }         // in groups
+    static constexpr int first(int p) { return tfirst(TPC * p); }
+    static constexpr int groups(int p) { return tgroups(TPC * p) + (PAIR && 2 * p + 1 < GEO::NT ? tgroups(2 * p + 1) : 0); }
     static constexpr int maxg() { int m = 0; for (int p = 0; p < NP; ++p) m = groups(p) > m ? groups(p) : m; return m; }
     static constexpr int MAXG = maxg();
     static constexpr int P16 = (int)sizeof(mhx_acc4) / 16;                        // 16-byte pieces per lane and group
@@ -202,10 +205,11 @@ struct mhx_mfma_stream_geom {
 // this thread's pieces of chunk p of the image behind the descriptor `img`: wave-uniform chunk offset (SGPR), one 32-bit lane
 // offset -- no 64-bit vector address per piece
 typedef mhx_u32 mhx_piece16 __attribute__((ext_vector_type(4)));
-template <int D, bool PAIR>
-MHX_DEV void mhx_mfma_chunk_load(const mhx_srd img, const int p, mhx_piece16 (&pf)[mhx_mfma_stream_geom<D, PAIR>::PF])
+template <int D, bool PAIR, bool TRANS = false, int NPF>
+MHX_DEV void mhx_mfma_chunk_load(const mhx_srd img, const int p, mhx_piece16 (&pf)[NPF])
 {
-    typedef mhx_mfma_stream_geom<D, PAIR> SG;
+    typedef mhx_mfma_stream_geom<D, PAIR, TRANS> SG;
+    static_assert(NPF >= SG::PF, "prefetch registers for the largest chunk");
     // whole rounds of the block, no per-thread predicate: the last round may run into the next chunk (ignored) or past the
     // image (the descriptor's range check returns zeros)
     const mhx_u32 voff = (mhx_u32)threadIdx.x * 16u;
@@ -218,22 +222,23 @@ MHX_DEV void mhx_mfma_chunk_load(const mhx_srd img, const int p, mhx_piece16 (&p
 
 // mhx_mfma_rows over a streamed image.  `pf` holds chunk 0 of this image on entry and, on return, chunk 0 of `gnext` (the image
 // the step walks next -- itself if it is the only one); `parity` is the ring buffer the next chunk goes to.
-template <int D, int MODE, bool PAIR>
+// BUFB: bytes of one ring buffer (the caller's, when images of different chunk sizes share the ring)
+template <int D, int MODE, bool PAIR, bool NEXT_TRANS = false, long BUFB = mhx_mfma_stream_geom<D, PAIR>::BUF_BYTES, int NPF>
 MHX_DEV void mhx_mfma_rows_stream(const mhx_srd gimg, const mhx_srd gnext, mhx_real* ring, const int lane,
                                   const mhx_real (&b)[mhx_mfma_geom<D>::NS], mhx_real& q, mhx_real (&out)[mhx_mfma_geom<D>::NS],
-                                  mhx_piece16 (&pf)[mhx_mfma_stream_geom<D, PAIR>::PF], int& parity)
+                                  mhx_piece16 (&pf)[NPF], int& parity)
 {
     typedef mhx_mfma_geom<D> GEO;
     typedef mhx_mfma_stream_geom<D, PAIR> SG;
 #pragma unroll
     for (int p = 0; p < SG::NP; ++p) {
-        mhx_acc4* buf = (mhx_acc4*)((char*)ring + (parity ? SG::BUF_BYTES : 0));
+        mhx_acc4* buf = (mhx_acc4*)((char*)ring + (parity ? BUFB : 0));
 #pragma unroll
         for (int i = 0; i < SG::PF; ++i)
             if (i < SG::pieces(p)) ((mhx_piece16*)buf)[(int)threadIdx.x + i * SG::THREADS] = pf[i];
         __syncthreads();                                  // the chunk is complete; the other buffer is free (see above)
         if (p + 1 < SG::NP) mhx_mfma_chunk_load<D, PAIR>(gimg, p + 1, pf);
-        else mhx_mfma_chunk_load<D, PAIR>(gnext, 0, pf);
+        else mhx_mfma_chunk_load<D, PAIR, NEXT_TRANS>(gnext, 0, pf);
         constexpr mhx_acc4 zero = {MHX_R(0.0), MHX_R(0.0), MHX_R(0.0), MHX_R(0.0)};
         mhx_acc4 c[2] = {zero, zero};
         const int t0 = SG::TPC * p;
@@ -260,6 +265,54 @@ MHX_DEV void mhx_mfma_rows_stream(const mhx_srd gimg, const mhx_srd gnext, mhx_r
                     if (MODE & 1) q = mhx_fma(c[h][r], c[h][r], q);
                     if ((MODE & 2) && 4 * t + r < GEO::NS) out[4 * t + r] = c[h][r];
                 }
+            }
+        }
+        parity ^= 1;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// mhx_mfma_rows_T over a streamed image of A^T (tile pairs).  `pf` holds chunk 0 of this image on entry and chunk 0 of the
+// LOWER image `gnext` on return (the next step's A y); NEXT_TRANS = false says so to the loader.
+template <int D, long BUFB, int NPF>
+MHX_DEV void mhx_mfma_rows_T_stream(const mhx_srd gimgT, const mhx_srd gnext, mhx_real* ring, const int lane,
+                                    const mhx_real (&b)[mhx_mfma_geom<D>::NS], mhx_real (&out)[mhx_mfma_geom<D>::NS],
+                                    mhx_piece16 (&pf)[NPF], int& parity)
+{
+    typedef mhx_mfma_geom<D> GEO;
+    typedef mhx_mfma_stream_geom<D, true, true> SG;
+#pragma unroll
+    for (int p = 0; p < SG::NP; ++p) {
+        mhx_acc4* buf = (mhx_acc4*)((char*)ring + (parity ? BUFB : 0));
+#pragma unroll
+        for (int i = 0; i < SG::PF; ++i)
+            if (i < SG::pieces(p)) ((mhx_piece16*)buf)[(int)threadIdx.x + i * SG::THREADS] = pf[i];
+        __syncthreads();
+        if (p + 1 < SG::NP) mhx_mfma_chunk_load<D, true, true>(gimgT, p + 1, pf);
+        else mhx_mfma_chunk_load<D, true, false>(gnext, 0, pf);
+        constexpr mhx_acc4 zero = {MHX_R(0.0), MHX_R(0.0), MHX_R(0.0), MHX_R(0.0)};
+        mhx_acc4 c[2] = {zero, zero};
+        const int t0 = 2 * p;
+#pragma unroll
+        for (int grp = t0; grp < GEO::NT; ++grp) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int t = t0 + h;
+                if (t < GEO::NT && grp >= t) {
+                    const mhx_acc4 a4 = buf[(GEO::firstT(t) + grp - t - SG::first(p)) * 64 + lane];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (4 * grp + u < GEO::NS) c[h] = MHX_MFMA16(a4[u], b[4 * grp + u], c[h]);
+                }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int t = t0 + h;
+            if (t < GEO::NT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * t + r < GEO::NS) out[4 * t + r] = c[h][r];
             }
         }
         parity ^= 1;
