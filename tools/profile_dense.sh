@@ -11,7 +11,7 @@ for DT in f32 f64; do
   for NM in 0 1; do
     OUT=$REPO/gpurun_out/${TAG}_dense_${DT}_nomfma${NM}
     mkdir -p $OUT
-    export MHX_DTYPE=$DT MHX_NO_MFMA=$NM DIMS="100 128 200"
+    export MHX_DTYPE=$DT MHX_NO_MFMA=$NM DIMS="100 128 200 512"
     python $REPO/tools/bench_dense.py > $OUT/bench.jsonl 2>&1
     rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktrace -o bench -- python $REPO/tools/bench_dense.py > $OUT/ktrace.log 2>&1
     rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $OUT/pmc_sq -o bench -- python $REPO/tools/bench_dense.py > $OUT/pmc_sq.log 2>&1
