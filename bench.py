@@ -397,6 +397,7 @@ def ess_window(mhx, wl, world):
     return {"estimator": "rank-normalised bulk ESS, split chains, Geyer initial monotone sequence (mhx_run_ess_bulk_tail)",
             "window": "%d draws x %d chains, %d transitions apart (%d transitions per chain)" % (n_draws, run.n, thin, n_draws * thin),
             "params": [int(p) for p in params], "ess_bulk": [float(v) for v in b["ess_bulk"]],
+            "ess_tail": [float(v) for v in b["ess_tail"]], "tail_ess_per_sec": float(np.median(b["ess_tail"])) / wall,
             "reached_max_lag": [bool(v) for v in b["bulk_truncated"]],
             "median": med, "per_transition_per_chain": med / (run.n * n_draws * thin),
             "wall_s": wall, "kernel_ms": st["kernel_ms"], "rhat_max_split": float(np.nanmax(dg["rhat"][:d])),
