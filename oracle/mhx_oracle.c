@@ -636,6 +636,26 @@ static void record(real *samples, uint8_t *accepted, int64_t slot, int d, int C,
     if (accepted) accepted[(size_t)slot * C + c] = (uint8_t)acc;
 }
 
+/* Trace sink (tests only): per saved slot and chain [n_samples][C]
+ *   margin   -- the smallest |logu - logalpha| over the transitions since the previous saved slot: how far the closest
+ *               accept decision was from flipping (tests/test_julia_reference_traces.py compares decisions only where
+ *               the margin exceeds the rounding differences between this spec's fused sums and Julia's unfused ones);
+ *   logalpha, eta -- RAM: state.logalpha and state.eta after the saved transition (...RAM.jl:99-114).
+ * Thread-local: a sink set by one host thread is seen by the calls of that thread only. */
+static _Thread_local real *g_margin, *g_logalpha, *g_eta;
+void orc_set_trace(real *margin, real *logalpha, real *eta) { g_margin = margin; g_logalpha = logalpha; g_eta = eta; }
+
+static inline void margin_note(real *cur, real logu, real loga)
+{
+    real m = FABS(logu - loga);
+    if (m != m) m = (real)INFINITY;                    /* NaN ratio: rejected on both sides whatever the rounding */
+    if (m < *cur) *cur = m;
+}
+static inline void margin_flush(real *cur, int64_t slot, int C, int c)
+{
+    if (g_margin && slot >= 0) { g_margin[(size_t)slot * C + c] = *cur; *cur = (real)INFINITY; }
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* RWMH: src/mh-core.jl:76-86 (initial step) and :92-117 (step)                               */
 int orc_rwmh(const orc_target *t, const orc_proposal *p, const orc_schedule *s,
@@ -664,8 +684,10 @@ int orc_rwmh(const orc_target *t, const orc_proposal *p, const orc_schedule *s,
         real lp = orc_target_eval(t, x);               /* mh-core.jl:84 transition(..., false) */
         real qx = p->is_static ? static_logq(p, d, x, y) : R(0.0);
         uint32_t nacc = 0;
+        real mg = (real)INFINITY;
         int64_t slot = save_slot(s, 0);
         if (slot >= 0) record(samples, accepted, slot, d, C, c, x, lp, 0);
+        margin_flush(&mg, slot, C, c);
         for (int64_t tau = 1; tau <= nT; ++tau) {
             const uint32_t step = (uint32_t)tau;
             orc_normals(seed, id, step, ORC_STREAM_PROPOSAL, d, z);
@@ -685,9 +707,11 @@ int orc_rwmh(const orc_target *t, const orc_proposal *p, const orc_schedule *s,
             }
             real logu = orc_accept_logu(seed, id, step);
             int acc = logu < loga;                      /* :108  -randexp(rng) < loga (strict; NaN -> reject) */
+            margin_note(&mg, logu, loga);
             if (acc) { memcpy(x, y, sizeof(real) * (size_t)d); lp = lpy; qx = qy; ++nacc; }
             slot = save_slot(s, tau);
             if (slot >= 0) record(samples, accepted, slot, d, C, c, x, lp, acc);
+            margin_flush(&mg, slot, C, c);
         }
         if (final_x) for (int k = 0; k < d; ++k) final_x[(size_t)k * C + c] = x[k];
         if (final_lp) final_lp[c] = lp;
@@ -702,7 +726,7 @@ int orc_rwmh(const orc_target *t, const orc_proposal *p, const orc_schedule *s,
 static int stretch_move(const orc_target *t, real a, uint64_t seed, uint64_t ens, int i,
                         uint32_t sweep, int other_start, int other_size, int wrap_W,
                         const real *cur, const real *oth_new, const real *oth_old, int use_seq,
-                        int W, real *xi, real *lpi, real *y, real *xj)
+                        int W, real *xi, real *lpi, real *y, real *xj, real *mg)
 {
     const int d = t->dim;
     uint32_t w0;
@@ -728,6 +752,7 @@ static int stretch_move(const orc_target *t, real a, uint64_t seed, uint64_t ens
     real lpy = orc_target_eval(t, y);                  /* :88 */
     real alpha = (alphamult + lpy) - *lpi;             /* :91 */
     int acc = logu <= alpha;                            /* :93  -randexp <= alpha (non-strict) */
+    margin_note(mg, logu, alpha);
     if (acc) { memcpy(xi, y, sizeof(real) * (size_t)d); *lpi = lpy; }
     return acc;
 }
@@ -746,6 +771,8 @@ int orc_emcee(const orc_target *t, real a, int mode, const orc_schedule *s,
     real *lp = malloc(sizeof(real) * (size_t)W);
     real *lpn = malloc(sizeof(real) * (size_t)W);
     uint8_t *acc = malloc((size_t)W);
+    real *mgw = malloc(sizeof(real) * (size_t)W);
+    for (int i = 0; i < W; ++i) mgw[i] = (real)INFINITY;
     real *tmp = malloc(sizeof(real) * (size_t)d * 3);
     real *xi = tmp, *y = tmp + d, *xj = tmp + 2 * d;
     if (init) memcpy(cur, init, sizeof(real) * (size_t)d * W);
@@ -780,6 +807,7 @@ int orc_emcee(const orc_target *t, real a, int mode, const orc_schedule *s,
         for (int i = 0; i < W; ++i) {
             for (int k = 0; k < d; ++k) xi[k] = cur[(size_t)k * W + i];
             record(samples, accepted, slot, d, W, i, xi, lp[i], 0);
+            margin_flush(&mgw[i], slot, W, i);
         }
     const int half = W / 2;
     for (int64_t tau = 1; tau <= nT; ++tau) {
@@ -790,7 +818,7 @@ int orc_emcee(const orc_target *t, real a, int mode, const orc_schedule *s,
                 for (int k = 0; k < d; ++k) xi[k] = cur[(size_t)k * W + i];
                 real l = lp[i];
                 acc[i] = (uint8_t)stretch_move(t, a, seed, ensemble_id, i, sweep, 0, 0, W, cur, nxt, cur,
-                                               1, W, xi, &l, y, xj);
+                                               1, W, xi, &l, y, xj, &mgw[i]);
                 for (int k = 0; k < d; ++k) nxt[(size_t)k * W + i] = xi[k];
                 lpn[i] = l;
             }
@@ -805,7 +833,7 @@ int orc_emcee(const orc_target *t, real a, int mode, const orc_schedule *s,
                     for (int k = 0; k < d; ++k) xi[k] = cur[(size_t)k * W + i];
                     real l = lp[i];
                     acc[i] = (uint8_t)stretch_move(t, a, seed, ensemble_id, i, sweep, ostart, osize, W, cur,
-                                                   NULL, NULL, 0, W, xi, &l, y, xj);
+                                                   NULL, NULL, 0, W, xi, &l, y, xj, &mgw[i]);
                     /* partners come from the other half only, so in-place update is race-free */
                     for (int k = 0; k < d; ++k) cur[(size_t)k * W + i] = xi[k];
                     lp[i] = l;
@@ -818,11 +846,12 @@ int orc_emcee(const orc_target *t, real a, int mode, const orc_schedule *s,
             for (int i = 0; i < W; ++i) {
                 for (int k = 0; k < d; ++k) xi[k] = cur[(size_t)k * W + i];
                 record(samples, accepted, slot, d, W, i, xi, lp[i], acc[i]);
+                margin_flush(&mgw[i], slot, W, i);
             }
     }
     if (final_x) memcpy(final_x, cur, sizeof(real) * (size_t)d * W);
     if (final_lp) memcpy(final_lp, lp, sizeof(real) * (size_t)W);
-    free(cur); free(nxt); free(lp); free(lpn); free(acc); free(tmp);
+    free(cur); free(nxt); free(lp); free(lpn); free(acc); free(tmp); free(mgw);
     return 0;
 }
 
@@ -887,8 +916,13 @@ int orc_ram(const orc_target *t, const orc_ram_cfg *cfg, const orc_schedule *s,
             diag_min[(size_t)k * C + c] = S[SIDX(k, k)];
             diag_max[(size_t)k * C + c] = S[SIDX(k, k)];
         }
+        real mg = (real)INFINITY;
+        real st_loga = R(0.0), st_eta = R(0.0);                   /* :211 State(x, lp, S, zero(T), 0, 1, true) */
         int64_t slot = save_slot(s, 0);
         if (slot >= 0) record(samples, accepted, slot, d, C, c, x, lp, 1);   /* :213 Transition(x, lp, true) */
+        margin_flush(&mg, slot, C, c);
+        if (slot >= 0 && g_logalpha) g_logalpha[(size_t)slot * C + c] = st_loga;
+        if (slot >= 0 && g_eta) g_eta[(size_t)slot * C + c] = st_eta;
         for (int64_t tau = 1; tau <= nT; ++tau) {
             const uint32_t step = (uint32_t)tau;                   /* == state.iteration */
             orc_normals(seed, id, step, ORC_STREAM_PROPOSAL, d, U);            /* :135 */
@@ -903,10 +937,13 @@ int orc_ram(const orc_target *t, const orc_ram_cfg *cfg, const orc_schedule *s,
             real loga = (diff != diff) ? diff : (diff < R(0.0) ? diff : R(0.0));   /* :147 min(lp_new - lp, 0) */
             real logu = orc_accept_logu(seed, id, step);
             int acc = logu < loga;                                  /* :148 randexp(rng) > -loga */
+            margin_note(&mg, logu, loga);
+            st_loga = loga;                                         /* :231,:272 the new state's logalpha */
             if (tau <= nA) {                                        /* step_warmup: adapt, :153-173 */
                 real da = orc_exp(loga) - cfg->alpha;             /* :159 */
+                const real eta = (real)pow((double)step, -(double)cfg->gamma);   /* :162 */
+                st_eta = eta;                                       /* :273 (a fixed-S step keeps state.eta, :232) */
                 if (da == da) {
-                    real eta = (real)pow((double)step, -(double)cfg->gamma);   /* :162 */
                     real nn = R(0.0);
                     for (int j = 0; j < d; ++j) nn = FMA(U[j], U[j], nn);
                     real coef = SQRT(eta * FABS(da)) / SQRT(nn);             /* :163 */
@@ -933,6 +970,9 @@ int orc_ram(const orc_target *t, const orc_ram_cfg *cfg, const orc_schedule *s,
             if (acc) { memcpy(x, y, sizeof(real) * (size_t)d); lp = lpy; ++nacc; }   /* :267-277 */
             slot = save_slot(s, tau);
             if (slot >= 0) record(samples, accepted, slot, d, C, c, x, lp, acc);
+            margin_flush(&mg, slot, C, c);
+            if (slot >= 0 && g_logalpha) g_logalpha[(size_t)slot * C + c] = st_loga;
+            if (slot >= 0 && g_eta) g_eta[(size_t)slot * C + c] = st_eta;
         }
         if (final_x) for (int k = 0; k < d; ++k) final_x[(size_t)k * C + c] = x[k];
         if (final_lp) final_lp[c] = lp;
@@ -1077,8 +1117,10 @@ int orc_mala(const orc_target *t, orc_logdensity_grad_fn user, real sigma2, cons
         for (int k = 0; k < d; ++k) x[k] = init[(size_t)k * C + c];
         real lp = orc_target_grad(t, x, gx, user);      /* :38-40 GradientTransition(params, lp, grad, false) */
         uint32_t nacc = 0;
+        real mg = (real)INFINITY;
         int64_t slot = save_slot(s, 0);
         if (slot >= 0) record(samples, accepted, slot, d, C, c, x, lp, 0);
+        margin_flush(&mg, slot, C, c);
         for (int64_t tau = 1; tau <= nT; ++tau) {
             const uint32_t step = (uint32_t)tau;
             orc_normals(seed, id, step, ORC_STREAM_PROPOSAL, d, z);
@@ -1090,9 +1132,11 @@ int orc_mala(const orc_target *t, orc_logdensity_grad_fn user, real sigma2, cons
             const real loga = (lpy - lp) + R(0.5) * (fwd - bwd);
             const real logu = orc_accept_logu(seed, id, step);
             const int acc = logu < loga;
+            margin_note(&mg, logu, loga);
             if (acc) { memcpy(x, y, sizeof(real) * (size_t)d); memcpy(gx, gy, sizeof(real) * (size_t)d); lp = lpy; ++nacc; }
             slot = save_slot(s, tau);
             if (slot >= 0) record(samples, accepted, slot, d, C, c, x, lp, acc);
+            margin_flush(&mg, slot, C, c);
         }
         if (final_x) for (int k = 0; k < d; ++k) final_x[(size_t)k * C + c] = x[k];
         if (final_lp) final_lp[c] = lp;

@@ -151,6 +151,11 @@ int orc_mala(const orc_target *t, orc_logdensity_grad_fn user, real sigma2, cons
              uint64_t seed, uint64_t first_chain, int nchains, const real *init,
              real *samples, uint8_t *accepted, real *final_x, real *final_lp, uint32_t *accept_counts);
 
+/* Trace sink for tests (thread-local; all three optional, [n_samples][nchains], NULL switches off):
+ * margin = smallest |logu - logalpha| over the transitions that led to a saved slot; logalpha / eta = RAM's state.logalpha
+ * and state.eta after the saved transition (src/RobustAdaptiveMetropolis.jl:99-114, 141-147). */
+void orc_set_trace(real *margin, real *logalpha, real *eta);
+
 /* rank-1 Cholesky update (sign=+1) / downdate (sign=-1) of a packed lower factor, in place.
  * returns 0, or i+1 if the downdate failed at column i (S is then partially modified). */
 int orc_chol_rank1(real *S, real *w, int d, int sign);

@@ -107,6 +107,8 @@ def lib():
         L.orc_target_eval.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_target_grad.restype = cr
         L.orc_normals.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+        L.orc_set_trace.restype = None
+        L.orc_set_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_chol_rank1.restype = C.c_int
         L.orc_chol_rank1.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         _libs[_DT] = L
@@ -264,6 +266,24 @@ def schedule_counts(s):
     a, b = C.c_int64(), C.c_int64()
     lib().orc_schedule_counts(C.byref(s), C.byref(a), C.byref(b))
     return a.value, b.value
+
+
+def traced(fn, *args, **kw):
+    """Run a sampler of this module (rwmh / emcee / ram / mala) with the trace sink on.  The result gains `margin`
+    [n_samples][C] (the smallest |logu - logalpha| over the transitions that led to each saved slot: how far the closest
+    accept decision was from flipping) and, for RAM, `logalpha` / `eta` (state.logalpha, state.eta after the saved transition)."""
+    sched = next(a for a in args if isinstance(a, _Schedule))
+    ncol = [a for a in args if isinstance(a, (int, np.integer))][-1]          # nchains / nwalkers: the last integer argument
+    bufs = [np.full((sched.n_samples, ncol), np.nan, dtype=real()) for _ in range(3)]
+    lib().orc_set_trace(_fp(bufs[0]), _fp(bufs[1]), _fp(bufs[2]))
+    try:
+        r = fn(*args, **kw)
+    finally:
+        lib().orc_set_trace(None, None, None)
+    r["margin"] = bufs[0]
+    if fn is ram:
+        r["logalpha"], r["eta"] = bufs[1], bufs[2]
+    return r
 
 
 def rwmh(target, prop, sched, seed, first_chain, nchains, init=None, save=True):

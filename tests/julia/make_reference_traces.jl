@@ -10,8 +10,19 @@
 # consumes; the test compares number by number (states to 1e-9, accept decisions wherever their margin exceeds it --
 # Julia rounds `x + sigma z` and the log-density sums in separate operations where the engine's spec fuses them).
 #
+# Dispatch notes (the reference's own tests are the model):
+#   * RWMH / Ensemble accept a `DensityModel(f)` (src/mh-core.jl:76-117, src/emcee.jl:14-24 dispatch on
+#     `DensityModelOrLogDensityModel`);
+#   * RobustAdaptiveMetropolis' `step` methods accept ONLY `AbstractMCMC.LogDensityModel`
+#     (src/RobustAdaptiveMetropolis.jl:175-181, 216-222, 247-253), so its model is a LogDensityProblems object handed
+#     straight to `sample`, which wraps it -- exactly test/RobustAdaptiveMetropolis.jl:1-9,45-55;
+#   * MALA needs `logdensity_and_gradient` (src/MALA.jl:36-52,101-104): a LogDensityProblems object of order 1 with an
+#     analytic gradient, the form of test/runtests.jl:334-365 (no ForwardDiff needed).
+#
 # STATUS: never executed (no `julia` binary in the build container); written against AdvancedMH.jl v0.8.8's public API.
-using AdvancedMH, AbstractMCMC, Distributions, LinearAlgebra, Random
+# tests/test_julia_kit.py checks what can be checked without Julia: literals against the oracle, case lists in step
+# with tests/julia_cases.py, and that no RobustAdaptiveMetropolis / MALA case is given a DensityModel.
+using AdvancedMH, AbstractMCMC, Distributions, LinearAlgebra, LogDensityProblems, Random
 include(joinpath(@__DIR__, "PhiloxStreams.jl"))
 using .PhiloxStreams
 
@@ -42,6 +53,17 @@ end
 function banana(d, b)                       # N(0, diag(100, 1, ...)) with x2 <- x2 + b (x1^2 - 100)
     return x -> logpdf(Normal(0, 10), x[1]) + logpdf(Normal(0, 1), x[2] + b * (x[1]^2 - 100)) + sum(logpdf.(Normal(0, 1), x[3:end]))
 end
+
+# ---- the same Gaussians as LogDensityProblems objects (what RobustAdaptiveMetropolis and MALA dispatch on) -----------------
+struct GaussianLDP{A,B}
+    Σ::A            # covariance: the log-density is logpdf(MvNormal(0, Σ), x), as test/RobustAdaptiveMetropolis.jl:6-9
+    P::B            # inv(Σ), for the gradient -P x
+end
+GaussianLDP(Σ::AbstractMatrix) = GaussianLDP(Matrix(Σ), inv(Symmetric(Matrix(Σ))))
+LogDensityProblems.dimension(m::GaussianLDP) = size(m.Σ, 1)
+LogDensityProblems.capabilities(::Type{<:GaussianLDP}) = LogDensityProblems.LogDensityOrder{1}()
+LogDensityProblems.logdensity(m::GaussianLDP, x) = logpdf(MvNormal(zeros(size(m.Σ, 1)), Symmetric(m.Σ)), x)
+LogDensityProblems.logdensity_and_gradient(m::GaussianLDP, x) = (LogDensityProblems.logdensity(m, x), -(m.P * x))
 
 # one chain of sampler `spl`, global id `id`: (N, d+1) samples and N accept flags
 function run_chain(model, spl, N, seed, id, d; initial_params = nothing, kw...)
@@ -81,15 +103,24 @@ run_chains("rwmh_given_start", DensityModel(iso_gauss(3)), RWMH(MvNormal(zeros(3
            initial_params = [0.5, -1.0, 0.25])
 
 # ---- RobustAdaptiveMetropolis (src/RobustAdaptiveMetropolis.jl:123-278) ------------------------------------------------
+# the model is a LogDensityProblems object, NOT a DensityModel (see the dispatch notes above)
 let d = 4
-    run_chains("ram", DensityModel(corr_gauss(ar1(d, 0.7))), RobustAdaptiveMetropolis(), 24, 31, 2, 6, d;
+    run_chains("ram", GaussianLDP(ar1(d, 0.7)), RobustAdaptiveMetropolis(), 24, 31, 2, 6, d;
                initial_params = zeros(d), num_warmup = 16, discard_initial = 0)
-    run_chains("ram_random_start", DensityModel(corr_gauss(ar1(d, 0.7))), RobustAdaptiveMetropolis(), 30, 33, 0, 5, d;
+    run_chains("ram_random_start", GaussianLDP(ar1(d, 0.7)), RobustAdaptiveMetropolis(), 30, 33, 0, 5, d;
                num_warmup = 30, discard_initial = 0)
 end
 let Σ = [10.0 5.0; 5.0 10.0]
     spl = RobustAdaptiveMetropolis(; γ = 0.51, eigenvalue_lower_bound = 0.9, eigenvalue_upper_bound = 1.1)
-    run_chains("ram_bounds", DensityModel(corr_gauss(Σ)), spl, 40, 32, 0, 5, 2; initial_params = zeros(2), num_warmup = 40, discard_initial = 0)
+    run_chains("ram_bounds", GaussianLDP(Σ), spl, 40, 32, 0, 5, 2; initial_params = zeros(2), num_warmup = 40, discard_initial = 0)
+end
+
+# ---- MALA with the standard Langevin proposal (src/MALA.jl:54-93; the form of test/runtests.jl:352) ----------------------
+let σ² = 0.3
+    mala = MALA(g -> MvNormal((σ² / 2) .* g, σ² * I))
+    run_chains("mala_iso", GaussianLDP(Matrix(1.0I, 5, 5)), mala, 32, 41, 1, 6, 5; initial_params = fill(0.25, 5))
+    run_chains("mala_corr", GaussianLDP(ar1(4, 0.6)), mala, 32, 42, 0, 6, 4; initial_params = [1.0, -0.5, 0.25, 0.0],
+               discard_initial = 2, thinning = 3)
 end
 
 # ---- Ensemble / StretchProposal, the reference's own sequential sweep (src/emcee.jl:14-102) ----------------------------

@@ -4,7 +4,11 @@
 
 runs the unmodified package on the engine's random streams (julia/PhiloxStreams.jl).  Each trace is compared with the fp64
 oracle number by number: states and log-densities to 1e-9 (the spec fuses `x + sigma z` and the log-density sums with fma,
-Julia rounds them separately: a few ulp per step), accept decisions equal.  Without the traces (no `julia` binary exists in
+Julia rounds them separately: a few ulp per step).  Accept decisions are compared with MARGIN LOGIC (`compare_with_margin`):
+the oracle's trace sink reports for every saved sample the smallest |logu - logalpha| among the transitions behind it; a
+decision closer to the threshold than MARGIN may legitimately fall the other way under Julia's rounding, after which the two
+chains are different realisations -- so a chain (for an ensemble: every walker, they interact) is compared up to, not
+including, its first within-margin sample, and a difference BEFORE that point is a failure.  Without the traces (no `julia` binary exists in
 the build container or on the GPU box) the tests are skipped and parity stays "unpinned" (DESIGN.md section 2); the CPU-only
 part below still checks that every case runs through the oracle and that the trace files, if any, have the right shapes."""
 import os
@@ -32,6 +36,45 @@ def test_case_runs_on_the_oracle(oracle64, name):
     assert 0 < r["accepted"][1:].mean() < 1
 
 
+MARGIN = 1e-9          # |logu - logalpha| below this: the decision may flip under unfused rounding
+STATE_TOL = 1e-9       # states / log-densities: a few ulp per step over tens of steps
+LP_ATOL = 1e-8
+
+
+def compare_with_margin(got, want, want_acc, ensemble=False, margin=MARGIN):
+    """Compare oracle output `got` (samples [N][d+1][C], accepted [N][C], margin [N][C]) with reference traces.
+    Returns the number of (sample, chain) cells compared; raises AssertionError on a difference that rounding cannot explain."""
+    N, d1, C = want.shape
+    assert got["samples"].shape == want.shape, (got["samples"].shape, want.shape)
+    assert want_acc.shape == (N, C)
+    # NaN (never written) counts as close: be conservative.  Sample 1 of an un-discarded run is the initial state: no
+    # decision behind it, margin = +inf; with discard_initial > 0 it carries the smallest margin of the discarded transitions.
+    close = ~(got["margin"] > margin)
+    horizon = np.full(C, N)
+    for c in range(C):
+        hit = np.flatnonzero(close[:, c])
+        if hit.size:
+            horizon[c] = hit[0]
+    if ensemble:
+        horizon[:] = horizon.min()                      # walkers interact: one doubtful move taints the sweeps after it
+    compared = 0
+    for c in range(C):
+        h = horizon[c]
+        if h == 0:
+            continue
+        a_got, a_want = got["accepted"][:h, c], want_acc[:h, c].astype(np.uint8)
+        bad = np.flatnonzero(a_got != a_want)
+        assert bad.size == 0, "chain %d: accept decisions differ at samples %s with margins %s (> %g: not a rounding flip)" % (
+            c, bad[:5], got["margin"][bad[:5], c], margin)
+        np.testing.assert_allclose(got["samples"][:h, :d1 - 1, c], want[:h, :d1 - 1, c], rtol=STATE_TOL, atol=STATE_TOL,
+                                   err_msg="chain %d states" % c)
+        # lp: the catalogue targets carry the same normalising constants as logpdf(MvNormal(...)) / the Normal products
+        np.testing.assert_allclose(got["samples"][:h, d1 - 1, c], want[:h, d1 - 1, c], rtol=STATE_TOL, atol=LP_ATOL,
+                                   err_msg="chain %d log-density" % c)
+        compared += int(h)
+    return compared
+
+
 @pytest.mark.parametrize("name", sorted(julia_cases.JULIA_CASES))
 def test_oracle_matches_the_julia_reference(oracle64, name):
     sp = os.path.join(JDIR, name + "_samples.npy")
@@ -40,11 +83,55 @@ def test_oracle_matches_the_julia_reference(oracle64, name):
     want = np.load(sp)
     want_acc = np.load(os.path.join(JDIR, name + "_accepted.npy"))
     got = julia_cases.JULIA_CASES[name](oracle64)
-    assert want.shape == got["samples"].shape, (want.shape, got["samples"].shape)
-    # the initial Transition of RAM carries accepted = true (…RAM.jl:213), of RWMH / Ensemble false (src/mh-core.jl:84)
-    assert np.array_equal(want_acc.astype(np.uint8), got["accepted"]), "accept decisions differ at %s" % (
-        np.argwhere(want_acc != got["accepted"])[:5],)
-    d = want.shape[1] - 1
-    np.testing.assert_allclose(got["samples"][:, :d, :], want[:, :d, :], rtol=1e-9, atol=1e-9)
-    # lp: the catalogue targets carry the same normalising constants as logpdf(MvNormal(...)) / the Normal products
-    np.testing.assert_allclose(got["samples"][:, d, :], want[:, d, :], rtol=1e-9, atol=1e-8)
+    # the initial Transition of RAM carries accepted = true (…RAM.jl:213), of RWMH / MALA / Ensemble false (src/mh-core.jl:84)
+    compared = compare_with_margin(got, want, want_acc, ensemble=name.startswith("emcee"))
+    # the comparison must not be vacuous: at least 90 % of the cells lie before any doubtful decision in these cases
+    assert compared >= 0.9 * want.shape[0] * want.shape[2], "only %d of %d cells were comparable" % (compared, want.shape[0] * want.shape[2])
+
+
+# ---- the margin logic itself, exercised without Julia: perturbed copies of the oracle's own traces stand in for the reference ----
+def _as_reference(r):
+    return r["samples"].copy(), r["accepted"].copy()
+
+
+def test_margin_logic_accepts_rounding_level_differences(oracle64):
+    got = julia_cases.JULIA_CASES["rwmh_iso"](oracle64)
+    want, acc = _as_reference(got)
+    rng = np.random.default_rng(0)
+    want *= 1.0 + 1e-13 * rng.standard_normal(want.shape)          # a few hundred ulp: what unfused sums do
+    n = compare_with_margin(got, want, acc)
+    assert n == want.shape[0] * want.shape[2]
+
+
+def test_margin_logic_rejects_a_real_decision_difference(oracle64):
+    got = julia_cases.JULIA_CASES["rwmh_iso"](oracle64)
+    want, acc = _as_reference(got)
+    acc[7, 2] ^= 1                                                  # margin there is far above 1e-9
+    assert got["margin"][7, 2] > 1e-6
+    with pytest.raises(AssertionError, match="not a rounding flip"):
+        compare_with_margin(got, want, acc)
+
+
+def test_margin_logic_stops_at_a_within_margin_flip(oracle64):
+    got = julia_cases.JULIA_CASES["rwmh_iso"](oracle64)
+    want, acc = _as_reference(got)
+    got = dict(got, margin=got["margin"].copy())
+    got["margin"][5, 3] = 1e-12                                     # pretend sample 5 of chain 3 hung on a near-tie ...
+    acc[5:, 3] ^= 1                                                 # ... that fell the other way in the reference,
+    want[5:, :, 3] += 0.5                                           # so that everything after it differs
+    n = compare_with_margin(got, want, acc)
+    assert n == want.shape[0] * want.shape[2] - (want.shape[0] - 5)   # chain 3 compared up to sample 4 only
+    # the same flip one sample EARLIER than the near-tie is still an error
+    acc[4, 3] ^= 1
+    with pytest.raises(AssertionError):
+        compare_with_margin(got, want, acc)
+
+
+def test_margin_logic_taints_the_whole_ensemble(oracle64):
+    got = julia_cases.JULIA_CASES["emcee_seq"](oracle64)
+    want, acc = _as_reference(got)
+    got = dict(got, margin=got["margin"].copy())
+    got["margin"][9, 4] = 1e-12
+    want[9:] += 1.0                                                 # every walker may differ from sweep 9 on
+    n = compare_with_margin(got, want, acc, ensemble=True)
+    assert n == 9 * want.shape[2]
