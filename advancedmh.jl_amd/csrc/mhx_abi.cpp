@@ -3,6 +3,8 @@
 // of every handle is its mhx_dtype.  No device code here.
 #include "mhx_impl.h"
 
+#include <hip/hip_runtime_api.h>   // hipHostMalloc / hipHostFree only (mhx_host_alloc): no device code here
+
 #include <cstdarg>
 #include <cstdio>
 #include <string>
@@ -59,6 +61,34 @@ extern "C" int mhx_ctx_device(const mhx_ctx* ctx, int* device)
     if (!ctx || !device) return mhx_fail(MHX_EINVAL, "mhx_ctx_device: NULL argument");
     *device = is64(ctx) ? mhx_f64::api_ctx_device(reinterpret_cast<const mhx_f64::mhx_ctx*>(ctx)) : mhx_f32::api_ctx_device(reinterpret_cast<const mhx_f32::mhx_ctx*>(ctx));
     return MHX_OK;
+}
+extern "C" int mhx_ctx_jit_counts(const mhx_ctx* ctx, int64_t* compiles, int64_t* cache_hits)
+{
+    if (!ctx) return mhx_fail(MHX_EINVAL, "mhx_ctx_jit_counts: ctx is NULL");
+    long a = 0, b = 0;
+    if (is64(ctx)) mhx_f64::api_ctx_jit_counts(reinterpret_cast<const mhx_f64::mhx_ctx*>(ctx), &a, &b);
+    else mhx_f32::api_ctx_jit_counts(reinterpret_cast<const mhx_f32::mhx_ctx*>(ctx), &a, &b);
+    if (compiles) *compiles = a;
+    if (cache_hits) *cache_hits = b;
+    return MHX_OK;
+}
+extern "C" int mhx_host_alloc(size_t bytes, void** out)
+{
+    if (!out) return mhx_fail(MHX_EINVAL, "mhx_host_alloc: out is NULL");
+    *out = nullptr;
+    if (!bytes) return MHX_OK;
+    hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        *out = nullptr;
+        return mhx_fail(MHX_ENOMEM, "mhx_host_alloc: %zu page-locked bytes: %s", bytes, hipGetErrorString(e));
+    }
+    return MHX_OK;
+}
+extern "C" int mhx_host_free(void* p)
+{
+    if (!p) return MHX_OK;
+    hipError_t e = hipHostFree(p);
+    return e == hipSuccess ? MHX_OK : mhx_fail(MHX_EHIP, "mhx_host_free: %s", hipGetErrorString(e));
 }
 extern "C" int mhx_ctx_destroy(mhx_ctx* ctx)
 {
@@ -144,6 +174,12 @@ extern "C" int mhx_run_get_samples(mhx_run* r, void* samples, uint8_t* accepted)
 {
     NEED(r, "mhx_run_get_samples");
     return is64(r) ? mhx_f64::api_run_get_samples(R64(r), D(samples), accepted) : mhx_f32::api_run_get_samples(R32(r), F(samples), accepted);
+}
+extern "C" int mhx_run_sample_to_host(mhx_run* r, const mhx_schedule* s, void* samples, uint8_t* accepted, int32_t slab_samples)
+{
+    NEED(r, "mhx_run_sample_to_host");
+    return is64(r) ? mhx_f64::api_run_sample_to_host(R64(r), s, D(samples), accepted, slab_samples)
+                   : mhx_f32::api_run_sample_to_host(R32(r), s, F(samples), accepted, slab_samples);
 }
 extern "C" int mhx_run_device_samples(mhx_run* r, void** samples, void** accepted, int64_t* n_samples)
 {

@@ -17,6 +17,10 @@
 #include <string>
 #include <vector>
 
+#include <errno.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <rocprim/rocprim.hpp>   // device radix sort for the rank-normalised ESS (after <cstring>: it calls memset)
 
 #include "mhx_rwmh_kernels.h"
@@ -153,8 +157,17 @@ struct mhx_ctx : mhx_handle_hdr {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::map<std::string, std::unique_ptr<jit_module>> jit;
+    long jit_compiles = 0, jit_cache_hits = 0;      // hiprtc compilations / code objects taken from the on-disk cache
+    // the return path of mhx_run_sample_to_host: a second stream for the D2H copies + the slab hand-over events
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t slab_done[2] = {nullptr, nullptr}, slab_free[2] = {nullptr, nullptr};
     ~mhx_ctx()
     {
+        for (int i = 0; i < 2; ++i) {
+            if (slab_done[i]) (void)hipEventDestroy(slab_done[i]);
+            if (slab_free[i]) (void)hipEventDestroy(slab_free[i]);
+        }
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
         for (auto& kv : jit)
             if (kv.second && kv.second->mod) (void)hipModuleUnload(kv.second->mod);
         if (ev0) (void)hipEventDestroy(ev0);
@@ -181,6 +194,12 @@ int api_ctx_create(int device, mhx_ctx** out)
 }
 
 int api_ctx_device(const mhx_ctx* ctx) { return ctx->device; }
+int api_ctx_jit_counts(const mhx_ctx* ctx, long* compiles, long* cache_hits)
+{
+    if (compiles) *compiles = ctx->jit_compiles;
+    if (cache_hits) *cache_hits = ctx->jit_cache_hits;
+    return MHX_OK;
+}
 
 int api_ctx_destroy(mhx_ctx* ctx)
 {
@@ -190,13 +209,78 @@ int api_ctx_destroy(mhx_ctx* ctx)
     return MHX_OK;
 }
 
+// ---- persistent code-object cache -------------------------------------------------------------------------------------
+// hiprtc takes 0.3 s for a small specialisation and up to a minute for the unrolled matrix-core kernels (d = 1000); the code
+// object depends only on (source, embedded headers, options, compiler), so it is kept on disk: $MHX_CACHE_DIR, else
+// $XDG_CACHE_HOME/mhx, else $HOME/.cache/mhx; MHX_CACHE_DIR="" (or MHX_NO_JIT_CACHE=1) switches it off.  Files are written to
+// a temporary name and renamed, so concurrent processes (one per GPU) never see a partial object.
+static unsigned long long fnv64(const void* data, size_t n, unsigned long long h)
+{
+    const unsigned char* p = (const unsigned char*)data;
+    for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; }
+    return h;
+}
+static std::string jit_cache_dir()
+{
+    if (const char* off = getenv("MHX_NO_JIT_CACHE")) if (*off && *off != '0') return "";
+    std::string dir;
+    if (const char* e = getenv("MHX_CACHE_DIR")) { if (!*e) return ""; dir = e; }
+    else if (const char* x = getenv("XDG_CACHE_HOME")) { if (*x) dir = std::string(x) + "/mhx"; }
+    if (dir.empty()) { const char* h = getenv("HOME"); if (!h || !*h) return ""; dir = std::string(h) + "/.cache/mhx"; }
+    // mkdir -p (two levels are enough for the defaults; an explicit MHX_CACHE_DIR must have an existing parent)
+    const size_t cut = dir.find_last_of('/');
+    if (cut != std::string::npos && cut > 0) (void)mkdir(dir.substr(0, cut).c_str(), 0755);
+    if (mkdir(dir.c_str(), 0755) != 0 && errno != EEXIST) return "";
+    return dir;
+}
+static std::string jit_cache_name(const std::string& source, const std::vector<std::string>& opts, const char* const* hdr_src, int nhdr)
+{
+    unsigned long long h1 = 1469598103934665603ull, h2 = 0x9e3779b97f4a7c15ull;
+    auto mix = [&](const void* d, size_t n) { h1 = fnv64(d, n, h1); h2 = fnv64(d, n, h2 ^ (unsigned long long)n); };
+    mix(source.data(), source.size());
+    for (auto& o : opts) { mix(o.data(), o.size()); mix("\0", 1); }
+    for (int i = 0; i < nhdr; ++i) mix(hdr_src[i], strlen(hdr_src[i]));
+    int vmaj = 0, vmin = 0, rt = 0;
+    (void)hiprtcVersion(&vmaj, &vmin);
+    (void)hipRuntimeGetVersion(&rt);
+    const int ver[4] = {vmaj, vmin, rt, MHX_VERSION};
+    mix(ver, sizeof ver);
+    char b[64];
+    snprintf(b, sizeof b, "%016llx%016llx.hsaco", h1, h2);
+    return b;
+}
+static bool jit_cache_read(const std::string& path, std::vector<char>* code)
+{
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    bool ok = false;
+    if (fseek(f, 0, SEEK_END) == 0) {
+        const long n = ftell(f);
+        if (n > 16 && fseek(f, 0, SEEK_SET) == 0) {
+            code->resize((size_t)n);
+            ok = fread(code->data(), 1, (size_t)n, f) == (size_t)n && memcmp(code->data(), "\x7f" "ELF", 4) == 0;
+        }
+    }
+    fclose(f);
+    return ok;
+}
+static void jit_cache_write(const std::string& dir, const std::string& name, const std::vector<char>& code)
+{
+    char tmp[64];
+    snprintf(tmp, sizeof tmp, "/.tmp.%ld.%llx", (long)getpid(), (unsigned long long)(size_t)code.data());
+    const std::string t = dir + tmp;
+    FILE* f = fopen(t.c_str(), "wb");
+    if (!f) return;
+    const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
+    if (fclose(f) != 0 || !ok || rename(t.c_str(), (dir + "/" + name).c_str()) != 0) (void)remove(t.c_str());
+}
+
 // compile `source` (which #includes the embedded device headers) with hiprtc for gfx950
 static int jit_compile(mhx_ctx* ctx, const std::string& key, const std::string& source,
                        const std::vector<std::string>& defines, jit_module** out, const std::vector<std::string>& extra_opts = {})
 {
     auto it = ctx->jit.find(key);
     if (it != ctx->jit.end()) { *out = it->second.get(); return MHX_OK; }
-    hiprtcProgram prog = nullptr;
     const char* hdr_src[] = {k_src_mhx_device_math_h, k_src_mhx_targets_h, k_src_mhx_rwmh_kernels_h,
                              k_src_mhx_emcee_kernels_h, k_src_mhx_ram_kernels_h, k_src_mhx_mala_kernels_h,
                              k_src_mhx_rwmh_dense_kernels_h, k_src_mhx_rwmh_mfma_kernels_h,
@@ -204,12 +288,28 @@ static int jit_compile(mhx_ctx* ctx, const std::string& key, const std::string& 
     const char* hdr_name[] = {"mhx_device_math.h", "mhx_targets.h", "mhx_rwmh_kernels.h",
                               "mhx_emcee_kernels.h", "mhx_ram_kernels.h", "mhx_mala_kernels.h",
                               "mhx_rwmh_dense_kernels.h", "mhx_rwmh_mfma_kernels.h", "mhx_mala_mfma_kernels.h"};
-    hiprtcResult r = hiprtcCreateProgram(&prog, source.c_str(), "mhx_jit.hip", 9, hdr_src, hdr_name);
-    if (r != HIPRTC_SUCCESS) return mhx_fail(MHX_EJIT, "hiprtcCreateProgram: %s", hiprtcGetErrorString(r));
     std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
                                      MHX_REAL64 ? "-DMHX_REAL64=1" : "-DMHX_REAL64=0"};
     for (auto& d : defines) opts.push_back("-D" + d);
     for (auto& o : extra_opts) opts.push_back(o);
+    const std::string cdir = jit_cache_dir();
+    const std::string cname = cdir.empty() ? std::string() : jit_cache_name(source, opts, hdr_src, 9);
+    std::vector<char> code;
+    bool from_cache = !cdir.empty() && jit_cache_read(cdir + "/" + cname, &code);
+    if (from_cache) {
+        std::unique_ptr<jit_module> m(new jit_module);
+        if (hipModuleLoadData(&m->mod, code.data()) == hipSuccess) {
+            ctx->jit_cache_hits++;
+            *out = m.get();
+            ctx->jit[key] = std::move(m);
+            return MHX_OK;
+        }
+        (void)hipGetLastError();            // a stale / foreign object: fall through and compile
+        from_cache = false;
+    }
+    hiprtcProgram prog = nullptr;
+    hiprtcResult r = hiprtcCreateProgram(&prog, source.c_str(), "mhx_jit.hip", 9, hdr_src, hdr_name);
+    if (r != HIPRTC_SUCCESS) return mhx_fail(MHX_EJIT, "hiprtcCreateProgram: %s", hiprtcGetErrorString(r));
     std::vector<const char*> copts;
     for (auto& o : opts) copts.push_back(o.c_str());
     r = hiprtcCompileProgram(prog, (int)copts.size(), copts.data());
@@ -224,12 +324,14 @@ static int jit_compile(mhx_ctx* ctx, const std::string& key, const std::string& 
     }
     size_t cs = 0;
     hiprtcGetCodeSize(prog, &cs);
-    std::vector<char> code(cs);
+    code.resize(cs);
     hiprtcGetCode(prog, code.data());
     hiprtcDestroyProgram(&prog);
+    ctx->jit_compiles++;
     std::unique_ptr<jit_module> m(new jit_module);
     hipError_t e = hipModuleLoadData(&m->mod, code.data());
     if (e != hipSuccess) return mhx_fail(MHX_EJIT, "hipModuleLoadData: %s", hipGetErrorString(e));
+    if (!cdir.empty()) jit_cache_write(cdir, cname, code);
     *out = m.get();
     ctx->jit[key] = std::move(m);
     return MHX_OK;
@@ -779,6 +881,9 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
             if (rc == MHX_OK) { r->variant = 8; r->coop_L = 4; r->mfma_stream = true; }
             else { r->jit_step = nullptr; }
         }
+        // reduce_lanes = 4 asked for explicitly and a matrix-core kernel was tried but did not come up: the error is the
+        // caller's, like every other explicit reduce_lanes (no silent change of the summation shape)
+        if (!r->variant && rc != MHX_OK && cfg->reduce_lanes == 4) return rc;
         L = cfg->reduce_lanes > 1 ? cfg->reduce_lanes : dense_coop_lanes(d);
         if (r->variant == 8 || !dense_coop_fits(d, L, nimg)) {
             L = 1;
@@ -1030,6 +1135,20 @@ static int ensure_buffer(void** p, size_t* cap, size_t need)
     return MHX_OK;
 }
 
+// accepted proposals of all chains so far
+static int run_total_accepts(mhx_run* r, unsigned long long* out)
+{
+    mhx_ctx* ctx = r->ctx;
+    if (r->kind == RUN_EMCEE) {            // per-walker counts summed on demand (no atomics in the half-step kernels)
+        HIP_TRY(hipMemsetAsync(r->d_acc_total, 0, sizeof(unsigned long long), ctx->stream));
+        hipLaunchKernelGGL(k_sum_u32, dim3(64), dim3(256), 0, ctx->stream, (const unsigned*)r->d_acc, (long)r->n, r->d_acc_total);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    COPY_SYNC(r->ctx->stream, out, r->d_acc_total, sizeof *out, hipMemcpyDeviceToHost);
+    return MHX_OK;
+}
+
 int api_run_sample(mhx_run* r, const mhx_schedule* s, int save_samples)
 {
     if (!r || !s) return mhx_fail(MHX_EINVAL, "mhx_run_sample: NULL argument");
@@ -1047,16 +1166,7 @@ int api_run_sample(mhx_run* r, const mhx_schedule* s, int save_samples)
     r->stats.kernel_variant = r->variant;
     r->stats.reduce_lanes = r->coop_L;
     r->stats.dtype = r->dtype;
-    auto total_accepts = [&](unsigned long long* out) -> int {
-        if (r->kind == RUN_EMCEE) {            // per-walker counts summed on demand (no atomics in the half-step kernels)
-            HIP_TRY(hipMemsetAsync(r->d_acc_total, 0, sizeof(unsigned long long), ctx->stream));
-            hipLaunchKernelGGL(k_sum_u32, dim3(64), dim3(256), 0, ctx->stream, (const unsigned*)r->d_acc, (long)r->n, r->d_acc_total);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipStreamSynchronize(ctx->stream));
-        }
-        COPY_SYNC(r->ctx->stream, out, r->d_acc_total, sizeof *out, hipMemcpyDeviceToHost);
-        return MHX_OK;
-    };
+    auto total_accepts = [&](unsigned long long* out) -> int { return run_total_accepts(r, out); };
     unsigned long long acc_before = 0;
     { int rc0 = total_accepts(&acc_before); if (rc0) return rc0; }
 
@@ -1150,6 +1260,8 @@ int api_run_get_samples(mhx_run* r, mhx_real* samples, uint8_t* accepted)
     if (accepted) COPY_SYNC(r->ctx->stream, accepted, r->d_accepted, N * n, hipMemcpyDeviceToHost);
     return MHX_OK;
 }
+
+#include "mhx_api_host.inc"
 
 int api_run_device_samples(mhx_run* r, void** samples, void** accepted, int64_t* n_samples)
 {

@@ -107,7 +107,11 @@ extern "C" int mhx_comm_init(mhx_ctx* ctx, int rank, int world, const void* id12
     ncclUniqueId id;
     memcpy(&id, id128, sizeof id);
     RCCL_TRY(g_rccl.CommInitRank(&c->comm, world, id, rank));
-    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    const hipError_t es = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (es != hipSuccess) {                             // the unique_ptr frees the struct only: release the communicator too
+        (void)g_rccl.CommDestroy(c->comm);
+        return mhx_fail(MHX_EHIP, "mhx_comm_init: hipStreamCreateWithFlags: %s", hipGetErrorString(es));
+    }
     *out = c.release();
     return MHX_OK;
 }

@@ -24,6 +24,7 @@ struct mhx_handle_hdr { int32_t dtype; };
     int api_ctx_create(int device, mhx_ctx** out);                                                                     \
     int api_ctx_destroy(mhx_ctx* ctx);                                                                                 \
     int api_ctx_device(const mhx_ctx* ctx);                                                                            \
+    int api_ctx_jit_counts(const mhx_ctx* ctx, long* compiles, long* cache_hits);                                      \
     int api_target_builtin(mhx_ctx* ctx, int kind, int dim, const REAL* params, size_t nparams, mhx_target** out);     \
     int api_target_from_hip_source(mhx_ctx* ctx, const char* src, int dim, const REAL* data, size_t ndata,             \
                                    mhx_target** out);                                                                  \
@@ -41,6 +42,7 @@ struct mhx_handle_hdr { int32_t dtype; };
     int api_run_init(mhx_run* r, const REAL* initial_params);                                                          \
     int api_run_sample(mhx_run* r, const mhx_schedule* s, int save_samples);                                           \
     int api_run_get_samples(mhx_run* r, REAL* samples, uint8_t* accepted);                                             \
+    int api_run_sample_to_host(mhx_run* r, const mhx_schedule* s, REAL* samples, uint8_t* accepted, int slab_samples);  \
     int api_run_device_samples(mhx_run* r, void** samples, void** accepted, int64_t* n_samples);                       \
     int api_run_get_state(mhx_run* r, REAL* x, REAL* lp, uint32_t* accept_counts);                                     \
     int api_run_set_state(mhx_run* r, const REAL* x);                                                                  \

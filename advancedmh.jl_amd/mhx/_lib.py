@@ -83,6 +83,7 @@ EXPORTS = [
     "mhx_ctx_dtype", "mhx_ctx_device", "mhx_ram_set_factor_all", "mhx_ram_get_adapt_state", "mhx_emcee_exchange_plan", "mhx_emcee_exchange_pack",
     "mhx_emcee_exchange_unpack", "mhx_comm_unique_id", "mhx_comm_init", "mhx_comm_destroy", "mhx_comm_rank",
     "mhx_comm_allreduce_sum", "mhx_comm_slice", "mhx_comm_allgather_walkers",
+    "mhx_run_sample_to_host", "mhx_host_alloc", "mhx_host_free", "mhx_ctx_jit_counts",
 ]
 
 MHX_F32, MHX_F64 = 0, 1
@@ -138,6 +139,10 @@ def lib():
         L.mhx_run_init.argtypes = [vp, rp]
         L.mhx_run_sample.argtypes = [vp, C.POINTER(Schedule), C.c_int]
         L.mhx_run_get_samples.argtypes = [vp, rp, u8p]
+        L.mhx_run_sample_to_host.argtypes = [vp, C.POINTER(Schedule), rp, u8p, C.c_int32]
+        L.mhx_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+        L.mhx_host_free.argtypes = [vp]
+        L.mhx_ctx_jit_counts.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.mhx_run_get_state.argtypes = [vp, rp, rp, u32p]
         L.mhx_run_set_state.argtypes = [vp, rp]
         L.mhx_run_stats.argtypes = [vp, C.POINTER(Stats)]
@@ -192,6 +197,36 @@ def u32ptr(a):
     return None if a is None else a.ctypes.data_as(C.POINTER(C.c_uint32))
 
 
+class _Pinned:
+    """owner of one mhx_host_alloc block; freed when the last array viewing it is gone"""
+
+    def __init__(self, nbytes):
+        self.p = C.c_void_p()
+        check(lib().mhx_host_alloc(nbytes, C.byref(self.p)))
+
+    def __del__(self):
+        try:
+            if self.p:
+                lib().mhx_host_free(self.p)
+                self.p = C.c_void_p()
+        except Exception:
+            pass
+
+
+def host_array(shape, dtype):
+    """numpy array in page-locked host memory (mhx_host_alloc): device-to-host copies into it run at the link rate.
+    The block is released when the array (and every view of it) has been garbage-collected."""
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape, dtype=np.int64))
+    nbytes = n * dtype.itemsize
+    if nbytes == 0:
+        return np.empty(shape, dtype=dtype)
+    owner = _Pinned(nbytes)
+    buf = (C.c_ubyte * nbytes).from_address(owner.p.value)
+    buf._mhx_owner = owner                                 # the ctypes array is the numpy array's base: it keeps the block alive
+    return np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
+
+
 class Context:
     """mhx_ctx: one per GPU and dtype."""
 
@@ -210,6 +245,12 @@ class Context:
     def arr(self, a):
         """contiguous array in this context's real type"""
         return np.ascontiguousarray(a, dtype=self.real)
+
+    def jit_counts(self):
+        """(hiprtc compilations, code objects taken from the on-disk cache) of this context so far"""
+        a, b = C.c_int64(), C.c_int64()
+        check(lib().mhx_ctx_jit_counts(self.h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     @classmethod
     def default(cls, device=None, dtype=None):

@@ -513,6 +513,26 @@ class Run:
         mode = 2 if (isinstance(save, str) and save == "moments") or (save is not True and save == 2) else (1 if save else 0)
         L.check(L.lib().mhx_run_sample(self.h, C.byref(s), mode))
 
+    def sample_to_host(self, n_samples, discard_initial=0, thinning=1, num_warmup=0, want_accepted=True, out=None,
+                       out_accepted=None, slab_samples=0, pinned=True):
+        """mhx_run_sample_to_host: the whole schedule with the samples streamed to the host while the chains keep running
+        (two device slabs; what `sample` returns is a host tensor, ext/AdvancedMHMCMCChainsExt.jl:12-39).  Returns
+        (samples [N][dim+1][n], accepted [N][n] or None).  `pinned`: allocate the results page-locked (mhx_host_alloc);
+        `out` / `out_accepted`: caller-provided arrays (any host memory: registered for the call when not page-locked)."""
+        s = L.Schedule(n_samples, discard_initial, thinning, num_warmup)
+        shape = (n_samples, self.dim + 1, self.n)
+        if out is None:
+            out = L.host_array(shape, self.real) if pinned else np.empty(shape, dtype=self.real)
+        elif out.shape != shape or out.dtype != self.real or not out.flags.c_contiguous:
+            raise L.ArgumentError(L.MHX_EINVAL, "sample_to_host: out must be a C-contiguous %s array of shape %s" % (np.dtype(self.real), shape))
+        acc = out_accepted
+        if acc is None and want_accepted:
+            acc = L.host_array((n_samples, self.n), np.uint8) if pinned else np.empty((n_samples, self.n), dtype=np.uint8)
+        elif acc is not None and (acc.shape != (n_samples, self.n) or acc.dtype != np.uint8 or not acc.flags.c_contiguous):
+            raise L.ArgumentError(L.MHX_EINVAL, "sample_to_host: out_accepted must be a C-contiguous uint8 array of shape (N, nchains)")
+        L.check(L.lib().mhx_run_sample_to_host(self.h, C.byref(s), L.fptr(out), L.u8ptr(acc), slab_samples))
+        return out, acc
+
     def samples(self, want_accepted=True):
         n_saved = C.c_int64()
         L.check(L.lib().mhx_run_device_samples(self.h, None, None, C.byref(n_saved)))
@@ -691,8 +711,8 @@ def sample(model, sampler, N, nchains=1, *more, initial_params=None, discard_ini
               reduce_lanes=reduce_lanes, dtype=dtype)
     run.init(initial_params)
     if callback is None:
-        run.sample(N, discard_initial, thinning, num_warmup)
-        value, acc = run.samples()
+        # one call: the samples stream to the host while the chains advance (mhx_run_sample_to_host)
+        value, acc = run.sample_to_host(N, discard_initial, thinning, num_warmup)
     else:
         # one saved sample per call, so that the callback can look at every state
         chunks, accs = [], []

@@ -116,7 +116,8 @@ class ShardedEnsemble:
 
     exchange="rccl" (needs `comm`), or None: the same slicing with no collective (all slices on this device, one after
     the other) -- the single-GPU emulation the parity test uses.  exchange="torch" drives `_all_gather` below with
-    torch.distributed on tensors the caller supplies (the gloo CPU test of the slicing / padding logic)."""
+    torch.distributed on the tensors handed to `.tensors(...)` (the gloo CPU test of the slicing / padding logic; sweep()
+    refuses to run in this mode without them)."""
 
     def __init__(self, run, rank=0, world=1, group=None, exchange="rccl", comm=None):
         self.run, self.group = run, group
@@ -124,10 +125,18 @@ class ShardedEnsemble:
         if comm is not None:
             rank, world = comm.rank, comm.world
         self.rank, self.world = int(rank), int(world)
+        if exchange not in (None, "rccl", "torch"):
+            raise ValueError("exchange must be None (emulation on one device), 'rccl' or 'torch'")
         if exchange == "rccl" and comm is None:
             raise ValueError("exchange='rccl' needs a Comm")
         self.W = run.n
         self._t = None
+
+    def tensors(self, xw, lp, acc, last):
+        """exchange='torch': the whole-ensemble tensors (walker-major rows, lp, accept counts, last accept flags) that
+        `_all_gather` exchanges in place -- views of the run's device state, or CPU stand-ins in the gloo test."""
+        self._t = dict(xw=xw, lp=lp, acc=acc, last=last)
+        return self
 
     @staticmethod
     def slices(count, world):
@@ -149,7 +158,13 @@ class ShardedEnsemble:
                     continue
                 b, c = sl[self.rank]
                 L.check(lib.mhx_emcee_half_step(self.run.h, h, b, c))
-                self.comm.allgather_walkers(self.run, h)
+                if self.exchange == "rccl":
+                    self.comm.allgather_walkers(self.run, h)
+                else:                                        # "torch": torch.distributed collectives on the caller's tensors
+                    if self._t is None:
+                        raise RuntimeError("ShardedEnsemble(exchange='torch'): set .tensors(xw, lp, acc, last) first -- torch views "
+                                           "of the arrays mhx_emcee_device_state exposes (the half-step must have completed on them)")
+                    self._all_gather(lo, cnt, sl)
             L.check(lib.mhx_emcee_end_sweep(self.run.h))
 
     def _all_gather(self, lo, cnt, sl):

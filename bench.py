@@ -16,7 +16,11 @@ ONE small all-reduce through the C ABI (mhx_comm_*: RCCL over xGMI).
 
 Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel against HBM with the algorithmic bytes of
 DESIGN.md section 7 and the HIP-event launch time measured here; `cpu_baseline` is the CPU oracle (a port of the
-reference algorithm, oracle/) timed on this host on a bounded sample -- rank 0, N=1 only.
+reference algorithm, oracle/, rebuilt -O3 -march=native on the host that times it) on a bounded sample -- rank 0, N=1 only.
+At N=1 the default (c2) run also carries, all measured after the timed region:
+  `e2e_host`  the rate THROUGH the boundary -- samples back on the host (mhx_run_sample_to_host), save-all and thinned;
+  `configs`   the other BASELINE.json GPU configs (c3, c4, c4_moving, c5): value, roofline and cpu_baseline each;
+  `ess`       the ESS/sec window;  `f32` the fp32 engine on the same workload.
 """
 import argparse
 import json
@@ -34,7 +38,8 @@ HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.
 # ~5, v_rcp_f64 / v_sqrt_f64 ~16).  The issue peak below is the 2-cycle one for every instruction class.
 VALU_PEAK = 256 * 4 * 2.4e9 / 2.0
 VARIANTS = {0: "generic", 1: "prebuilt-register", 2: "hiprtc-register", 3: "prebuilt-cooperative",
-            4: "hiprtc-cooperative", 5: "hiprtc-dense-cooperative", 6: "persistent-ensemble"}
+            4: "hiprtc-cooperative", 5: "hiprtc-dense-cooperative", 6: "persistent-ensemble",
+            7: "sequential-ensemble-sweep (the reference's Gauss-Seidel order)", 8: "matrix-core (v_mfma_*_16x16x4, shared dense factor)"}
 RB = {"f32": 4, "f64": 8}
 
 
@@ -299,15 +304,22 @@ class C4:
 WORKLOADS = {"c2": C2, "c3": C3, "c4": C4, "c5": C5}
 
 
+_ORACLE_FLAGS = None
+
+
 def cpu_baseline(wl, dtype, target_seconds=10.0):
-    """The oracle (same algorithm, same Philox streams, scalar loop per chain; gcc -O3) on the host cores: chains
-    statically partitioned over threads (the MCMCThreads analogue).  Bounded sample."""
+    """The oracle (same algorithm, same Philox streams, scalar loop per chain) on the host cores: chains statically
+    partitioned over threads (the MCMCThreads analogue).  Bounded sample.  Built on this host with -O3 -march=native as
+    BASELINE.md's CPU-baseline plan says (oracle/Makefile `native`; bit-identical to the portable build the tests use)."""
+    global _ORACLE_FLAGS
     from oracle import oracle as O
     O.build()
+    if _ORACLE_FLAGS is None:
+        _ORACLE_FLAGS = O.use_native()
     O.set_dtype(dtype)
     units, dt, cores, sample = wl.cpu_baseline(O, target_seconds)
     return {"value": units / dt, "unit": "MH steps/s", "cores": cores, "kind": "port",
-            "sample": "%s (oracle/mhx_oracle.c in %s, %d thread(s), %.1f s)" % (sample, dtype, cores, dt)}
+            "sample": "%s (oracle/mhx_oracle.c in %s, %s, %d thread(s), %.1f s)" % (sample, dtype, _ORACLE_FLAGS, cores, dt)}
 
 
 class GlooSum:
@@ -328,7 +340,7 @@ class GlooSum:
         pass
 
 
-def make_collective(ctx, rank, world):
+def make_collective(ctx, rank, world, allow_gloo=False):
     """One process per GPU under torchrun.  The rendezvous is torch.distributed's own (gloo on CPU: it only carries the
     128-byte RCCL id from rank 0 to the others); the bench's collectives -- barrier, max-over-ranks time, acceptance totals
     and R-hat sums -- then go through the C ABI (mhx_comm_*: RCCL over xGMI).  If the RCCL communicator cannot be created on
@@ -355,11 +367,16 @@ def make_collective(ctx, rank, world):
         return comm, "mhx_comm_* (RCCL over xGMI, through the C ABI); rendezvous: torch.distributed gloo"
     if comm is not None:
         comm.close()
-    return GlooSum(dist), "torch.distributed gloo (fallback: the RCCL communicator could not be created: %s)" % err
+    if not allow_gloo:
+        # a multi-GPU line must not silently skip RCCL: without --allow-gloo the missing communicator is an error
+        raise RuntimeError("bench.py --gpus %d: the RCCL communicator behind the C ABI (mhx_comm_init) could not be created on every "
+                           "rank (%s); pass --allow-gloo to run the three small host-side all-reduces over torch.distributed gloo instead"
+                           % (world, err or "another rank failed"))
+    return GlooSum(dist), "torch.distributed gloo (--allow-gloo fallback: the RCCL communicator could not be created: %s)" % err
 
 
-def timed(wl, steps, warmup, barrier):
-    for _ in range(max(0, 30 - warmup)):      # device spin-up (setup): the first ~20 launches after idle run below the steady clock
+def timed(wl, steps, warmup, barrier, spin=30):
+    for _ in range(max(0, spin - warmup)):    # device spin-up (setup): the first ~20 launches after idle run below the steady clock
         wl.step()
     for _ in range(warmup):
         wl.step()
@@ -386,6 +403,8 @@ def ess_window(mhx, wl, world):
     d, run = wl.d, wl.run
     thin = max(1, int(round(40 * (d / 0.3) / 256)))        # each split half spans ~20 autocorrelation times
     n_draws = 256
+    # the timed launches used a buffer of `inner` draws: size it for this window first (an allocation of GBs is not sampling)
+    run.sample(n_draws, 1, 1, 0, save=True)
     t0 = time.perf_counter()
     run.sample(n_draws, thin, thin, 0, save=True)
     wall = time.perf_counter() - t0
@@ -404,6 +423,118 @@ def ess_window(mhx, wl, world):
             "ess_per_sec": med / wall}
 
 
+def config_block(wl, name, st, collective):
+    return {"workload": wl.describe(), "name": name, "units_per_step_per_gpu": wl.units_per_step(),
+            "kernel_variant": VARIANTS.get(st["kernel_variant"], str(st["kernel_variant"])), "lanes_per_unit": st["reduce_lanes"],
+            "launches_per_step": max(1, st["launches"]),
+            "sharding": "chains by global id, no data-path collective" if name != "c3" else "one ensemble per GPU (replicas)",
+            "collective": collective}
+
+
+def roofline_block(wl, name, dtype, kernel_ms, steps, st):
+    """The dominant kernel against HBM: algorithmic bytes per step over the HIP-event time of the step's
+    launches measured here; `traffic` / `valu` from the PMC passes of tools/profile_round.sh (profiles/traffic.json) when they
+    were taken on this workload."""
+    launches = max(1, st["launches"])
+    launch_s = kernel_ms * 1e-3 / steps
+    bytes_launch = wl.bytes_per_launch()
+    achieved = bytes_launch / launch_s / 1e9
+    traffic, valu = None, None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    key = "%s_%s" % (name, dtype)
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath)).get(key, {})
+            if tj.get("units_per_launch") == wl.units_per_step():
+                traffic = tj.get("hbm_bytes_per_launch")
+                if tj.get("valu_insts_per_launch"):
+                    rate = tj["valu_insts_per_launch"] / launch_s
+                    valu = {"wave_insts_per_launch": tj["valu_insts_per_launch"], "achieved_per_s": rate, "peak_per_s": VALU_PEAK,
+                            "frac": rate / VALU_PEAK, "source": tj.get("source"),
+                            "note": "wave64 VALU instructions (PMC SQ_INSTS_VALU) per second against 1024 SIMDs x one instruction "
+                                    "per 2 cycles at 2.4 GHz; the fp64 / 64-bit-multiply / transcendental instructions of the mix "
+                                    "take 4-16 cycles each, so 1.0 is not reachable by this instruction mix"}
+        except Exception:
+            traffic, valu = None, None
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "avg_launch_ms": launch_s * 1e3 / launches, "kernel_ms_per_step": launch_s * 1e3,
+            "algorithmic_bytes_per_step": bytes_launch, "bytes_model": wl.bytes_model(), "valu": valu}
+
+
+def other_configs(mhx, ctx, args, barrier):
+    """The other BASELINE.json GPU configs in the same driver run (N = 1, rank 0, after the headline's timed region): value,
+    roofline of the dominant kernel and a CPU baseline (2 s samples) for C3, C4 as specified, C4 from a start that moves, and
+    C5's per-GPU shard.  Fewer steps than the headline (C4 runs 0.26 s per step): every figure says how many."""
+    import copy
+    plan = [("c3", "c3", {}, 10, 10), ("c4", "c4", {}, 3, 2), ("c4_moving", "c4", {"c4_moving": True}, 3, 2), ("c5", "c5", {}, 10, 10)]
+    res = {}
+    for key, name, over, steps, spin in plan:
+        try:
+            a = copy.copy(args)
+            a.inner = a.chains = a.dim = a.lanes = 0
+            a.c4_moving = False
+            for k, v in over.items():
+                setattr(a, k, v)
+            w = WORKLOADS[name](a, args.dtype)
+            w.build(mhx, ctx, 0)
+            dt, kms, acc, tr, st = timed(w, steps, 2, barrier, spin=spin)
+            blk = {"value": w.units_per_step() * steps / dt, "unit": "MH steps/s", "steps": steps, "ms_per_step": dt * 1e3 / steps,
+                   "dtype": args.dtype, "acceptance_rate": acc / float(tr), "config": config_block(w, name, st, None),
+                   "roofline": roofline_block(w, name, args.dtype, kms, steps, st)}
+            w.run.close()
+            if not args.no_cpu_baseline:
+                blk["cpu_baseline"] = cpu_baseline(w, args.dtype, 2.0)
+            res[key] = blk
+        except Exception as e:                                   # one config must not take the line down
+            res[key] = {"error": str(e)[:300]}
+    return res
+
+
+def e2e_host(mhx, wl):
+    """"kernel time AND end-to-end including D2H of whatever is kept, both reported".  The reference's `sample`
+    returns a host container; mhx_run_sample_to_host streams the samples into page-locked host memory while the chains run.
+    Three figures on the headline workload: (a) save-all, every state of `inner` transitions to the host (the PCIe link is the
+    bound: B(d+1)+1 bytes per chain-step); (b) a thinned run (the ESS window's schedule), which returns at the kernel rate;
+    (c) the round-2 path for comparison -- mhx_run_sample, then one synchronous mhx_run_get_samples into pageable memory."""
+    import numpy as np
+    run, d, C, inner = wl.run, wl.d, wl.C, wl.inner
+    out = {}
+    t0 = time.perf_counter()
+    buf = mhx.host_array((inner, d + 1, C), run.real)
+    accb = mhx.host_array((inner, C), np.uint8)
+    out["pinned_alloc_s"] = time.perf_counter() - t0
+    run.sample_to_host(inner, 1, 1, 0, out=buf, out_accepted=accb)          # untimed: first touch of the slabs and streams
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run.sample_to_host(inner, 1, 1, 0, out=buf, out_accepted=accb)
+    w = (time.perf_counter() - t0) / reps
+    nbytes = buf.nbytes + accb.nbytes
+    out["save_all"] = {"value": C * inner / w, "unit": "MH steps/s with every state on the host", "wall_s": w, "host_GB": nbytes / 1e9,
+                       "link_GBps": nbytes / w / 1e9, "kernel_ms": run.stats()["kernel_ms"],
+                       "note": "mhx_run_sample_to_host into page-locked memory; bound by the PCIe Gen5 x16 link (63 GB/s spec), not by the kernel"}
+    thin = max(1, int(round(40 * (d / 0.3) / 256)))
+    n_draws = 256
+    tb = mhx.host_array((n_draws, d + 1, C), run.real)
+    ta = mhx.host_array((n_draws, C), np.uint8)
+    run.sample_to_host(n_draws, thin, thin, 0, out=tb, out_accepted=ta)
+    t0 = time.perf_counter()
+    run.sample_to_host(n_draws, thin, thin, 0, out=tb, out_accepted=ta)
+    w = time.perf_counter() - t0
+    out["thinned"] = {"value": C * n_draws * thin / w, "unit": "MH steps/s with the kept draws on the host", "wall_s": w,
+                      "schedule": "%d draws %d transitions apart" % (n_draws, thin), "host_GB": (tb.nbytes + ta.nbytes) / 1e9,
+                      "kernel_ms": run.stats()["kernel_ms"]}
+    del tb, ta
+    t0 = time.perf_counter()
+    run.sample(inner, 1, 1, 0, save=True)
+    old, _ = run.samples()
+    w = time.perf_counter() - t0
+    out["round2_path"] = {"value": C * inner / w, "wall_s": w, "note": "mhx_run_sample, then one synchronous mhx_run_get_samples into a fresh pageable array"}
+    del old
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -419,6 +550,11 @@ def main():
                     "instead of the tuned 2.38/sqrt(d)")
     ap.add_argument("--c4-moving", action="store_true", help="c4: random start and S0 = 2.38/sqrt(d) I instead of x0 = 0, S0 = I")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--allow-gloo", action="store_true", help="--gpus > 1: fall back to torch.distributed gloo for the host-side "
+                    "all-reduces when the RCCL communicator cannot be created (default: that is an error)")
+    ap.add_argument("--no-other-configs", action="store_true", help="c2 at N=1: skip the C3 / C4 / C4-moving / C5 lines under `configs`")
+    ap.add_argument("--no-e2e", action="store_true", help="c2 at N=1: skip the rate through the boundary (samples back on the host)")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="size of the CPU-baseline sample of the headline config")
     ap.add_argument("--no-second-dtype", action="store_true", help="skip the fp32 figure")
     ap.add_argument("--no-ess", action="store_true")
     args = ap.parse_args()
@@ -437,7 +573,7 @@ def main():
     ctx = mhx.Context(local_rank, args.dtype)
     comm, collective = None, None
     if world > 1 or os.environ.get("MHX_BENCH_FORCE_DIST"):      # the env knob exercises the collective path on 1 GPU
-        comm, collective = make_collective(ctx, rank, world)
+        comm, collective = make_collective(ctx, rank, world, args.allow_gloo)
 
     def barrier():
         torch.cuda.synchronize()
@@ -475,42 +611,14 @@ def main():
     if rank == 0:
         units = float(wl.units_per_step()) * args.steps * world
         value = units / dt
-        launches = max(1, st["launches"])
-        launch_s = kernel_ms * 1e-3 / args.steps
-        bytes_launch = wl.bytes_per_launch()
-        achieved = bytes_launch / launch_s / 1e9
-        traffic, valu = None, None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        key = "%s_%s" % (args.config, args.dtype)
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath)).get(key, {})
-                if tj.get("units_per_launch") == wl.units_per_step():
-                    traffic = tj.get("hbm_bytes_per_launch")
-                    if tj.get("valu_insts_per_launch"):
-                        rate = tj["valu_insts_per_launch"] / launch_s
-                        valu = {"wave_insts_per_launch": tj["valu_insts_per_launch"], "achieved_per_s": rate, "peak_per_s": VALU_PEAK,
-                                "frac": rate / VALU_PEAK, "source": tj.get("source"),
-                                "note": "wave64 VALU instructions (PMC SQ_INSTS_VALU) per second against 1024 SIMDs x one instruction "
-                                        "per 2 cycles at 2.4 GHz; the fp64 / 64-bit-multiply / transcendental instructions of the mix "
-                                        "take 4-16 cycles each, so 1.0 is not reachable by this instruction mix"}
-            except Exception:
-                traffic, valu = None, None
         out = {
             "metric": "MH steps/sec (all chains) + ESS/sec", "value": value, "unit": "MH steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": wl.describe(), "name": args.config, "units_per_step_per_gpu": wl.units_per_step(),
-                       "kernel_variant": VARIANTS.get(variant, str(variant)), "lanes_per_unit": st["reduce_lanes"],
-                       "launches_per_step": launches,
-                       "sharding": "chains by global id, no data-path collective" if args.config != "c3" else "one ensemble per GPU (replicas)",
-                       "collective": collective},
+            "config": config_block(wl, args.config, st, collective),
             "acceptance_rate": acc_rate,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "avg_launch_ms": launch_s * 1e3 / launches, "kernel_ms_per_step": launch_s * 1e3,
-                         "algorithmic_bytes_per_step": bytes_launch, "bytes_model": wl.bytes_model(), "valu": valu},
+            "roofline": roofline_block(wl, args.config, args.dtype, kernel_ms, args.steps, st),
         }
         if ess is not None:
             out["ess_per_sec"] = ess.get("ess_per_sec")
@@ -521,6 +629,11 @@ def main():
             # thinned window's split R-hat is ess.rhat_max_split
             out["rhat_last_launch"] = {"value": float(np.nanmax(diag["rhat"][:wl.d])),
                                        "note": "one launch of consecutive transitions across all ranks (the R-hat all-reduce); see ess.rhat_max_split"}
+        if world == 1 and args.config == "c2" and not args.no_e2e and not args.c2_literal:
+            try:
+                out["e2e_host"] = e2e_host(mhx, wl)
+            except Exception as e:
+                out["e2e_host"] = {"error": str(e)[:300]}
         if world == 1 and not args.no_second_dtype and args.dtype == "f64":
             try:                                                  # the same workload on the fp32 engine: a second figure, never `value`
                 ctx32 = mhx.Context(local_rank, "f32")
@@ -536,7 +649,10 @@ def main():
             except Exception as e:
                 out["f32"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(wl, args.dtype)
+            out["cpu_baseline"] = cpu_baseline(wl, args.dtype, args.cpu_seconds)
+        if world == 1 and args.config == "c2" and not args.no_other_configs and not args.c2_literal:
+            wl.run.close()                                        # 13.4 GB of samples: C4 needs the room
+            out["configs"] = other_configs(mhx, ctx, args, barrier)
         # RCCL writes its version banner to the C stdout buffer: push it out first so the JSON line is the last one
         sys.stdout.flush()
         try:

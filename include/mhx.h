@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MHX_VERSION 200 /* 0.2.0: fp64 engine, dtype on the context, RCCL collectives */
+#define MHX_VERSION 300 /* 0.3.0: overlapped host return path, page-locked host buffers, persistent JIT cache */
 
 typedef enum {
     MHX_OK = 0,
@@ -61,6 +61,16 @@ int mhx_ctx_create(int device, int dtype /* mhx_dtype */, mhx_ctx **out);
 int mhx_ctx_dtype(const mhx_ctx *ctx);
 int mhx_ctx_device(const mhx_ctx *ctx, int *device);
 int mhx_ctx_destroy(mhx_ctx *ctx);
+/* hiprtc specialisations of this context so far: compiled by hiprtc / loaded from the on-disk code-object cache
+ * ($MHX_CACHE_DIR, default ~/.cache/mhx; key = hash(source, device headers, options, hiprtc + runtime version);
+ * MHX_CACHE_DIR="" or MHX_NO_JIT_CACHE=1 switches the cache off).  Either pointer may be NULL. */
+int mhx_ctx_jit_counts(const mhx_ctx *ctx, int64_t *compiles, int64_t *cache_hits);
+
+/* Page-locked host memory for result tensors (the `Chains` array of ext/AdvancedMHMCMCChainsExt.jl:12-39 lives on the
+ * host): device-to-host copies into it run at the link rate and asynchronously.  Any other host buffer works too --
+ * mhx_run_sample_to_host registers it for the duration of the call. */
+int mhx_host_alloc(size_t bytes, void **out);
+int mhx_host_free(void *p);
 
 /* ---------------------------------------------------------------------------------------------
  * Targets.  Replaces DensityModel(f) / logdensity(model, x) (src/AdvancedMH.jl:52-54, :74-77). */
@@ -138,7 +148,7 @@ typedef struct {
     int32_t dim;
     int32_t nwalkers;
     uint64_t seed;
-    uint64_t ensemble_id;
+    uint64_t ensemble_id;    /* < 2^32: one word of the RNG counter (walker index is the other) */
     double stretch;          /* a = 2.0 */
     int32_t flags;          /* MHX_FLAG_*; MHX_FLAG_EMCEE_SEQUENTIAL selects the reference's own sweep */
     int32_t reduce_lanes;   /* lanes per walker (dense-Gaussian target): 0 = engine's choice, 1 = one lane per walker */
@@ -219,6 +229,16 @@ int mhx_run_sample(mhx_run *run, const mhx_schedule *sched, int save_samples);
 
 /* copy the sample buffer of the last mhx_run_sample to the host (either pointer may be NULL) */
 int mhx_run_get_samples(mhx_run *run, void *samples, uint8_t *accepted);
+/* mhx_run_sample + mhx_run_get_samples in ONE call with the copy overlapped: what `sample(model, sampler, N)` returns is
+ * a host container (bundle_samples, src/AdvancedMH.jl:80-104, ext/AdvancedMHMCMCChainsExt.jl:12-39).  The schedule is cut
+ * into slabs of |slab_samples| saved samples (0 = about 256 MiB); the kernels fill one device slab while the previous one
+ * drains to `samples` [n_samples][dim+1][nchains] / `accepted` [n_samples][nchains] (NULL = not wanted) on a second
+ * stream.  A tensor that fits into HBM stays there as well (mhx_run_device_samples and the diagnostics work as after
+ * mhx_run_sample); one that does not -- or slab_samples < 0 -- goes through TWO alternating slabs and the device keeps
+ * nothing (mhx_run_device_samples then reports 0 samples): n_samples is bounded by host memory, not by HBM.  Blocking; the
+ * buffers are complete on return.  Bit-identical to mhx_run_sample + mhx_run_get_samples.
+ * mhx_stats.kernel_ms then spans the kernels including their waits for a free slab, wall_ms the whole call. */
+int mhx_run_sample_to_host(mhx_run *run, const mhx_schedule *sched, void *samples, uint8_t *accepted, int32_t slab_samples);
 /* getparams / setparams!! (src/AdvancedMH.jl:146-157, src/RobustAdaptiveMetropolis.jl:116-121) */
 int mhx_run_get_state(mhx_run *run, void *x, void *lp, uint32_t *accept_counts);
 int mhx_run_set_state(mhx_run *run, const void *x /* lp is recomputed */);

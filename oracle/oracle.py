@@ -83,6 +83,22 @@ def build(force=False):
 _libs = {}
 
 
+def use_native():
+    """bench.py's cpu_baseline leg: rebuild the oracle with -O3 -march=native ON THIS HOST (oracle/Makefile `native`, into
+    oracle/_native/) and bind the module to it.  Returns the flags string in effect; on any failure the portable build
+    (-O3 -mavx2 -mfma) stays bound.  Bit-identical results either way (-ffp-contract=off in both)."""
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        nat = {"f32": os.path.join(_HERE, "_native", "libmhx_oracle.so"), "f64": os.path.join(_HERE, "_native", "libmhx_oracle64.so")}
+        for p in nat.values():
+            C.CDLL(p)                                   # loads on this host?
+        _LIB_PATHS.update(nat)
+        _libs.clear()
+        return "gcc -O3 -march=native -ffp-contract=off"
+    except Exception:
+        return "gcc -O3 -mavx2 -mfma -ffp-contract=off (portable build; the -march=native rebuild failed on this host)"
+
+
 def lib():
     if _DT not in _libs:
         if not os.path.exists(_LIB_PATHS[_DT]):

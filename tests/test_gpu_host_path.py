@@ -1,0 +1,171 @@
+"""GPU: the boundary's return path -- mhx_run_sample_to_host (samples streamed to the host while the chains run) must hand
+back exactly the tensor mhx_run_sample + mhx_run_get_samples produce, for every sampler, schedule and slab layout; page-locked
+result buffers; the on-disk hiprtc cache.  Reference contract: `sample` returns a HOST container
+(ext/AdvancedMHMCMCChainsExt.jl:12-39, src/AdvancedMH.jl:80-104)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b, what):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    assert a.shape == b.shape and a.dtype == b.dtype, what
+    bad = np.argwhere(cases.bits(a) != cases.bits(b))
+    assert len(bad) == 0, "%s: %d mismatches, first at %s" % (what, len(bad), bad[0])
+
+
+def _runs(mhx, kind, d, C, seed):
+    if kind == "rwmh":
+        model = mhx.DensityModel(mhx.IsoGaussian(d))
+        spl = mhx.RWMH(mhx.MvNormal(mhx.zeros(d), 0.09 * mhx.I))
+        mk = lambda: mhx.Run(model, spl, nchains=C, seed=seed, first_chain=5)
+        init = None
+    elif kind == "mala":
+        model = mhx.DensityModel(mhx.CorrGaussian(cases.sigma_ar1(d, 0.5)))
+        mk = lambda: mhx.Run(model, mhx.MALA(0.2), nchains=C, seed=seed)
+        init = np.full(d, 0.25)
+    elif kind == "ram":
+        model = mhx.DensityModel(mhx.CorrGaussian(cases.sigma_ar1(d, 0.7)))
+        mk = lambda: mhx.Run(model, mhx.RobustAdaptiveMetropolis(), nchains=C, seed=seed, first_chain=2)
+        init = np.zeros(d)
+    else:
+        model = mhx.DensityModel(mhx.CorrGaussian(cases.sigma_ar1(d, 0.9)))
+        mk = lambda: mhx.Run(model, mhx.Ensemble(C, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I))), seed=seed)
+        init = None
+    return mk, init
+
+
+@pytest.mark.parametrize("slab", [0, 1, 3, -1, -3, -4])
+@pytest.mark.parametrize("sched", [(11, 0, 1, 0), (10, 7, 3, 0), (1, 0, 1, 0), (9, 5, 2, 12), (2, 0, 4, 3)])
+@pytest.mark.parametrize("kind", ["rwmh", "emcee", "ram", "mala"])
+def test_streamed_samples_equal_the_device_tensor(mhx, real, kind, sched, slab):
+    d, C = (6, 70) if kind != "emcee" else (5, 64)
+    mk, init = _runs(mhx, kind, d, C, 77)
+    a, b = mk(), mk()
+    a.init(init), b.init(init)
+    N, di, th, nw = sched
+    a.sample(N, di, th, nw)
+    want, want_acc = a.samples()
+    got, got_acc = b.sample_to_host(N, di, th, nw, slab_samples=slab, pinned=(slab % 2 == 0))
+    _same(got, want, "%s samples, slab %d" % (kind, slab))
+    _same(got_acc, want_acc, "accepted")
+    sa, sb = a.stats(), b.stats()
+    assert sa["transitions"] == sb["transitions"] and sa["accepted"] == sb["accepted"]
+    for u, v in zip(a.state(), b.state()):
+        _same(u, v, "final state")
+    if kind == "ram":
+        _same(a.factor()[0], b.factor()[0], "factors")
+    # the device keeps the tensor unless the ring was asked for; then it keeps nothing
+    n_saved = C.c_int64()
+    mhx.check(mhx.lib().mhx_run_device_samples(b.h, None, None, C.byref(n_saved)))
+    ring = slab < 0 and N > -slab
+    assert n_saved.value == (0 if ring else N)
+    if not ring:
+        _same(b.samples()[0], want, "device tensor after the streamed call")
+    # both runs continue identically (the RNG counter advanced by the same number of transitions)
+    a.sample(3, 1, 1, 0)
+    g2, _ = b.sample_to_host(3, 1, 1, 0, slab_samples=-1)
+    _same(g2, a.samples()[0], "continuation")
+
+
+def test_sample_returns_pinned_host_tensor_and_summary_still_works(mhx, oracle, real):
+    d, C, N = 8, 96, 60
+    model = mhx.DensityModel(mhx.IsoGaussian(d))
+    spl = mhx.RWMH(mhx.MvNormal(mhx.zeros(d), 0.25 * mhx.I))
+    chain = mhx.sample(model, spl, N, C, seed=9)
+    ref = oracle.rwmh(oracle.iso_gauss(d, reduce_lanes=chain.stats["reduce_lanes"]), oracle.Proposal(oracle.PROP_ISO, 0.5),
+                      oracle.schedule(N), 9, 0, C)
+    _same(chain.value, ref["samples"], "samples")
+    st = chain.summarystats()                      # diagnostics on the tensor the device kept
+    assert np.isfinite(st["ess_bulk"]).all() and np.isfinite(st["rhat"]).all()
+    v = chain.value
+    del chain
+    assert np.isfinite(v).all()                    # the page-locked block outlives the Chains object while a view exists
+
+
+def test_caller_buffers_and_argument_errors(mhx, real):
+    d, C, N = 4, 64, 12
+    mk, _ = _runs(mhx, "rwmh", d, C, 3)
+    r = mk()
+    r.init(None)
+    out = np.empty((N, d + 1, C), dtype=r.real)
+    acc = np.empty((N, C), dtype=np.uint8)
+    got, got_acc = r.sample_to_host(N, 0, 1, 0, out=out, out_accepted=acc, slab_samples=-5)
+    assert got is out and got_acc is acc
+    r2 = mk()
+    r2.init(None)
+    r2.sample(N)
+    _same(out, r2.samples()[0], "caller buffer (pageable, registered for the call)")
+    with pytest.raises(mhx.ArgumentError):
+        r.sample_to_host(N, out=np.empty((N, d, C), dtype=r.real))
+    s = mhx.Schedule(4, 0, 1, 0)
+    assert mhx.lib().mhx_run_sample_to_host(r.h, C_byref(s), None, None, 0) == mhx.MHX_EINVAL
+    fresh = mk()
+    buf = np.empty((4, d + 1, C), dtype=r.real)
+    assert mhx.lib().mhx_run_sample_to_host(fresh.h, C_byref(s), buf.ctypes.data_as(C.c_void_p), None, 0) == mhx.MHX_ESTATE
+
+
+def C_byref(x):
+    return C.byref(x)
+
+
+def test_host_alloc_round_trip(mhx):
+    p = C.c_void_p()
+    mhx.check(mhx.lib().mhx_host_alloc(1 << 20, C.byref(p)))
+    assert p.value
+    C.memset(p, 0x5a, 1 << 20)
+    mhx.check(mhx.lib().mhx_host_free(p))
+    mhx.check(mhx.lib().mhx_host_alloc(0, C.byref(p)))
+    assert not p.value
+    a = mhx.host_array((3, 5), np.float64)
+    a[:] = 2.0
+    assert a.sum() == 30.0
+
+
+USER_SRC = """
+MHX_LOGDENSITY(x, d, data, ndata) {
+    mhx_real s = MHX_R(0.0);
+    for (int k = 0; k < d; ++k) s = mhx_fma(x[k] - MHX_R(%s), x[k] - MHX_R(%s), s);
+    return MHX_R(-0.5) * s;
+}
+"""
+
+
+def test_jit_objects_persist_across_contexts(mhx, real, tmp_path, monkeypatch):
+    monkeypatch.setenv("MHX_CACHE_DIR", str(tmp_path / "jit"))
+    shift = "0.%d" % (os.getpid() % 9973)                # a source nobody has compiled before
+    d, C = 5, 64
+
+    def run_once():
+        ctx = mhx.Context(0, real)
+        model = mhx.DensityModel(mhx.HipLogDensity(USER_SRC % (shift, shift), d))
+        r = mhx.Run(model, mhx.RWMH(mhx.MvNormal(mhx.zeros(d), 0.25 * mhx.I)), nchains=C, seed=1, ctx=ctx)
+        r.init(None)
+        r.sample(8)
+        v = r.samples()[0]
+        counts = ctx.jit_counts()
+        r.close()
+        return v, counts
+
+    v1, (comp1, hit1) = run_once()
+    assert comp1 >= 1 and hit1 == 0
+    files = sorted(os.listdir(tmp_path / "jit"))
+    assert files and all(f.endswith(".hsaco") for f in files)
+    v2, (comp2, hit2) = run_once()
+    assert comp2 == 0 and hit2 == comp1, "second context: every specialisation must come from the on-disk cache"
+    _same(v1, v2, "cached kernels give the same chains")
+    # a damaged object is ignored and rebuilt
+    with open(tmp_path / "jit" / files[0], "r+b") as f:
+        f.write(b"garbage!")
+    v3, (comp3, hit3) = run_once()
+    assert comp3 >= 1
+    _same(v1, v3, "after a rebuilt object")
+    monkeypatch.setenv("MHX_NO_JIT_CACHE", "1")
+    _, (comp4, hit4) = run_once()
+    assert hit4 == 0 and comp4 == comp1
