@@ -84,11 +84,11 @@ k_record_state(const mhx_real* __restrict__ x, const mhx_real* __restrict__ lp, 
 }
 
 // (MHX_COOP_WAVES, the occupancy target of the cooperative kernel, comes from mhx_rwmh_kernels.h)
-template <int L, int NBL, int TK, int PK, bool MOM>
+template <int L, int NBL, int TK, int PK, bool MOM, int GEN = MHX_GEN_BOX_MULLER>
 __global__ void __launch_bounds__(256, MHX_COOP_WAVES(NBL))
 k_rwmh_coop(const mhx_rwmh_args a, const mhx_real* __restrict__ tparams, const mhx_real* __restrict__ pvec)
 {
-    mhx_rwmh_coop_body<L, NBL, TK, PK, MOM>(a, tparams, pvec);
+    mhx_rwmh_coop_body<L, NBL, TK, PK, MOM, MHX_WALK_PLAIN, GEN>(a, tparams, pvec);
 }
 __global__ void __launch_bounds__(256)
 k_moments_first(const mhx_real* __restrict__ x, const mhx_real* __restrict__ lp, mhx_real* mean, mhx_real* m2, const int n,
@@ -102,6 +102,7 @@ struct prebuilt_coop {
     int L, NBL, TK, PK;
     void (*fn)(const mhx_rwmh_args, const mhx_real*, const mhx_real*);
     void (*fn_mom)(const mhx_rwmh_args, const mhx_real*, const mhx_real*);
+    int gen;                             // MHX_GEN_*: the normal generator the kernel was built with
 };
 // the BASELINE shapes: C2 (65 536 chains x d = 100) and C5 (32 768 chains per GPU x d = 1000); a double takes two VGPRs,
 // so the fp64 engine spreads a chain over more lanes
@@ -122,6 +123,14 @@ static const prebuilt_coop k_prebuilt_coop[] = {
      k_rwmh_coop<MHX_C5_L, MHX_C5_NBL, MHX_TARGET_FUNNEL, MHX_PROP_ISO, true>},
     {MHX_C5_L, MHX_C5_NBL, MHX_TARGET_BANANA, MHX_PROP_ISO, k_rwmh_coop<MHX_C5_L, MHX_C5_NBL, MHX_TARGET_BANANA, MHX_PROP_ISO, false>,
      k_rwmh_coop<MHX_C5_L, MHX_C5_NBL, MHX_TARGET_BANANA, MHX_PROP_ISO, true>},
+#if MHX_REAL64
+    // the same shapes with the ziggurat generator (MHX_FLAG_ZIGGURAT)
+    {MHX_C2_L, MHX_C2_NBL, MHX_TARGET_ISO_GAUSS, MHX_PROP_ISO,
+     k_rwmh_coop<MHX_C2_L, MHX_C2_NBL, MHX_TARGET_ISO_GAUSS, MHX_PROP_ISO, false, MHX_GEN_ZIGGURAT>, nullptr, MHX_GEN_ZIGGURAT},
+    {MHX_C5_L, MHX_C5_NBL, MHX_TARGET_FUNNEL, MHX_PROP_ISO,
+     k_rwmh_coop<MHX_C5_L, MHX_C5_NBL, MHX_TARGET_FUNNEL, MHX_PROP_ISO, false, MHX_GEN_ZIGGURAT>,
+     k_rwmh_coop<MHX_C5_L, MHX_C5_NBL, MHX_TARGET_FUNNEL, MHX_PROP_ISO, true, MHX_GEN_ZIGGURAT>, MHX_GEN_ZIGGURAT},
+#endif
 };
 
 // sum of a u32 array into a u64 (one atomic per block)
@@ -281,11 +290,11 @@ static int jit_compile(mhx_ctx* ctx, const std::string& key, const std::string& 
 {
     auto it = ctx->jit.find(key);
     if (it != ctx->jit.end()) { *out = it->second.get(); return MHX_OK; }
-    const char* hdr_src[] = {k_src_mhx_device_math_h, k_src_mhx_targets_h, k_src_mhx_rwmh_kernels_h,
+    const char* hdr_src[] = {k_src_mhx_zig_table_h, k_src_mhx_device_math_h, k_src_mhx_targets_h, k_src_mhx_rwmh_kernels_h,
                              k_src_mhx_emcee_kernels_h, k_src_mhx_ram_kernels_h, k_src_mhx_mala_kernels_h,
                              k_src_mhx_rwmh_dense_kernels_h, k_src_mhx_rwmh_mfma_kernels_h,
                              k_src_mhx_mala_mfma_kernels_h};
-    const char* hdr_name[] = {"mhx_device_math.h", "mhx_targets.h", "mhx_rwmh_kernels.h",
+    const char* hdr_name[] = {"mhx_zig_table.h", "mhx_device_math.h", "mhx_targets.h", "mhx_rwmh_kernels.h",
                               "mhx_emcee_kernels.h", "mhx_ram_kernels.h", "mhx_mala_kernels.h",
                               "mhx_rwmh_dense_kernels.h", "mhx_rwmh_mfma_kernels.h", "mhx_mala_mfma_kernels.h"};
     std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
@@ -293,7 +302,7 @@ static int jit_compile(mhx_ctx* ctx, const std::string& key, const std::string& 
     for (auto& d : defines) opts.push_back("-D" + d);
     for (auto& o : extra_opts) opts.push_back(o);
     const std::string cdir = jit_cache_dir();
-    const std::string cname = cdir.empty() ? std::string() : jit_cache_name(source, opts, hdr_src, 9);
+    const std::string cname = cdir.empty() ? std::string() : jit_cache_name(source, opts, hdr_src, 10);
     std::vector<char> code;
     bool from_cache = !cdir.empty() && jit_cache_read(cdir + "/" + cname, &code);
     if (from_cache) {
@@ -308,7 +317,7 @@ static int jit_compile(mhx_ctx* ctx, const std::string& key, const std::string& 
         from_cache = false;
     }
     hiprtcProgram prog = nullptr;
-    hiprtcResult r = hiprtcCreateProgram(&prog, source.c_str(), "mhx_jit.hip", 9, hdr_src, hdr_name);
+    hiprtcResult r = hiprtcCreateProgram(&prog, source.c_str(), "mhx_jit.hip", 10, hdr_src, hdr_name);
     if (r != HIPRTC_SUCCESS) return mhx_fail(MHX_EJIT, "hiprtcCreateProgram: %s", hiprtcGetErrorString(r));
     std::vector<const char*> copts;
     for (auto& o : opts) copts.push_back(o.c_str());
@@ -592,6 +601,8 @@ struct mhx_run : mhx_handle_hdr {
     std::string coop_key;                // JIT key / defines of the cooperative kernel (for its moments twin)
     std::vector<std::string> coop_defs;
     // kernel choice
+    int normal_gen = MHX_GEN_BOX_MULLER; // how stream bits become standard normals (MHX_FLAG_ZIGGURAT: the table ziggurat, fp64)
+    size_t coop_lds = 0;                 // dynamic LDS of the cooperative kernel (ziggurat: layer table + the step's normals)
     int coop_L = 1;                      // lanes per chain (reduction shape of the separable targets)
     int coop_waves = MHX_EMCEE_COOP_WAVES;  // waves per block of the cooperative stretch move (tuning knob MHX_EMCEE_WAVES)
     int variant = 0;
@@ -636,6 +647,7 @@ static mhx_rwmh_args rwmh_args(const mhx_run* r)
     if (r->moments_mode) { a.mom_mean = r->d_mom_mean; a.mom_m2 = r->d_mom_m2; a.mom_n0 = (mhx_u32)r->mom_n; }
     a.pmean = r->d_pmean;
     a.qx = r->d_qx;
+    a.normal_gen = r->normal_gen;
     return a;
 }
 
@@ -790,6 +802,8 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
     // ---- kernel choice
     r->variant = 0;
     const int tk = t->kind, pk = r->prop_kind;
+    if ((cfg->flags & MHX_FLAG_ZIGGURAT) && !MHX_REAL64)
+        return mhx_fail(MHX_EINVAL, "MHX_FLAG_ZIGGURAT: the ziggurat normal generator exists in fp64 contexts only");
     const int regmax = pk == MHX_PROP_DENSE ? MHX_REG_MAX_DIM_DENSE : MHX_REG_MAX_DIM;
     const int nblk = (d + 3) / 4;
     const bool separable = tk == MHX_TARGET_ISO_GAUSS || tk == MHX_TARGET_BANANA || tk == MHX_TARGET_FUNNEL;
@@ -811,7 +825,8 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
             while (L < 64 && 2 * L <= nblk && (long)r->n * L / 64 < 2048) L *= 2;
             if ((nblk + L - 1) / L > MHX_COOP_NBL_MAX) L = 1;      // not even a whole wave holds the chain: state in HBM
         }
-        coop_one_lane = walk && L == 1 && nblk <= MHX_COOP_NBL_MAX;
+        // (the ziggurat generator lives in the cooperative body: a chain on ONE lane still runs it there)
+        coop_one_lane = (walk || (cfg->flags & MHX_FLAG_ZIGGURAT)) && L == 1 && nblk <= MHX_COOP_NBL_MAX;
     } else if (((tk == MHX_TARGET_CORR_GAUSS) || (tk == MHX_TARGET_ISO_GAUSS && pk == MHX_PROP_DENSE)) &&
                !walk && !(r->flags & (MHX_FLAG_GENERIC | MHX_FLAG_NO_JIT)) && d >= 2 && d <= 4 * std::max(MHX_MFMA_STREAM_MAX_NS, MHX_MFMA_XMEM_MAX_NS) &&
                (cfg->reduce_lanes > 1 || (cfg->reduce_lanes == 0 && d >= 16)) &&
@@ -917,31 +932,54 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
         const char* no_prebuilt = getenv("MHX_NO_PREBUILT");
         const char* waves_env = getenv("MHX_COOP_WAVES");
         const int waves_override = waves_env ? atoi(waves_env) : 0;
+        const bool zig = (cfg->flags & MHX_FLAG_ZIGGURAT) != 0;
+#if MHX_REAL64
+        if (zig && MHX_ZIG_LDS_BYTES(NBL) > MHX_LDS_PER_BLOCK)
+            return mhx_fail(MHX_EINVAL, "MHX_FLAG_ZIGGURAT: %d blocks per lane need %d bytes of LDS per block (limit %d); use more lanes per chain",
+                            NBL, (int)MHX_ZIG_LDS_BYTES(NBL), (int)MHX_LDS_PER_BLOCK);
+#endif
         if (!(no_prebuilt && atoi(no_prebuilt)) && !waves_override && !walk)
             for (const auto& pb : k_prebuilt_coop)
-                if (pb.L == L && pb.NBL == NBL && pb.TK == tk && pb.PK == pk) { r->reg_fn = pb.fn; r->reg_fn_mom = pb.fn_mom; r->variant = 3; }
+                if (pb.L == L && pb.NBL == NBL && pb.TK == tk && pb.PK == pk && pb.gen == (zig ? MHX_GEN_ZIGGURAT : MHX_GEN_BOX_MULLER)) {
+                    r->reg_fn = pb.fn; r->reg_fn_mom = pb.fn_mom; r->variant = 3; r->normal_gen = pb.gen;
+#if MHX_REAL64
+                    if (zig) {
+                        r->coop_lds = MHX_ZIG_LDS_BYTES(NBL);
+                        for (auto f : {pb.fn, pb.fn_mom})
+                            if (f && hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->coop_lds) != hipSuccess)
+                                return mhx_fail(MHX_EHIP, "cooperative kernel (ziggurat): %zu bytes of LDS refused", r->coop_lds);
+                    }
+#endif
+                }
         if (!r->variant && !(r->flags & MHX_FLAG_NO_JIT)) {
             jit_module* m = nullptr;
             const std::string key = "rwmh_coop/l=" + std::to_string(L) + "/nbl=" + std::to_string(NBL) + "/tk=" +
                                     std::to_string(tk) + "/pk=" + std::to_string(pk) + "/w=" + std::to_string(waves_override) +
-                                    "/walk=" + std::to_string(walk);
+                                    "/walk=" + std::to_string(walk) + "/gen=" + std::to_string(zig ? 1 : 0);
             std::vector<std::string> defs = {"MHX_JIT_RWMH_COOP=1", "MHX_JIT_L=" + std::to_string(L), "MHX_JIT_NBL=" + std::to_string(NBL),
                                              "MHX_JIT_TK=" + std::to_string(tk), "MHX_JIT_PK=" + std::to_string(pk), "MHX_JIT_MOM=0",
-                                             "MHX_JIT_WALK=" + std::to_string(walk)};
+                                             "MHX_JIT_WALK=" + std::to_string(walk), std::string("MHX_JIT_GEN=") + (zig ? "1" : "0")};
             if (waves_override > 0) defs.push_back("MHX_JIT_WAVES=" + std::to_string(waves_override));
             if (const char* il = getenv("MHX_COOP_INTERLEAVE")) defs.push_back(std::string("MHX_COOP_INTERLEAVE=") + il);   // tuning knob
             rc = jit_compile(ctx, key + "/mom=0", jit_source(t, "mhx_rwmh_kernels.h"), defs, &m);
             if (rc == MHX_OK) rc = jit_function(m, "mhx_jit_rwmh_coop", &r->jit_step);
-            if (rc == MHX_OK) r->variant = 4;
-            else if (cfg->reduce_lanes > 1) return rc;      // the caller asked for this shape explicitly
+#if MHX_REAL64
+            if (rc == MHX_OK && zig) {
+                r->coop_lds = MHX_ZIG_LDS_BYTES(NBL);
+                if (hipFuncSetAttribute((const void*)r->jit_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->coop_lds) != hipSuccess)
+                    rc = mhx_fail(MHX_EHIP, "cooperative kernel (ziggurat): %zu bytes of LDS refused", r->coop_lds);
+            }
+#endif
+            if (rc == MHX_OK) { r->variant = 4; r->normal_gen = zig ? MHX_GEN_ZIGGURAT : MHX_GEN_BOX_MULLER; }
+            else if (cfg->reduce_lanes > 1 || zig) return rc;      // the caller asked for this shape explicitly
         }
         if (r->variant) {
             r->coop_L = L;
             r->coop_key = "rwmh_coop/l=" + std::to_string(L) + "/nbl=" + std::to_string(NBL) + "/tk=" + std::to_string(tk) +
-                          "/pk=" + std::to_string(pk) + "/walk=" + std::to_string(walk);
+                          "/pk=" + std::to_string(pk) + "/walk=" + std::to_string(walk) + "/gen=" + std::to_string(zig ? 1 : 0);
             r->coop_defs = {"MHX_JIT_RWMH_COOP=1", "MHX_JIT_L=" + std::to_string(L), "MHX_JIT_NBL=" + std::to_string(NBL),
                             "MHX_JIT_TK=" + std::to_string(tk), "MHX_JIT_PK=" + std::to_string(pk), "MHX_JIT_MOM=1",
-                            "MHX_JIT_WALK=" + std::to_string(walk)};
+                            "MHX_JIT_WALK=" + std::to_string(walk), std::string("MHX_JIT_GEN=") + (zig ? "1" : "0")};
         } else if (cfg->reduce_lanes > 1) return mhx_fail(MHX_EINVAL, "reduce_lanes=%d: no pre-built kernel and JIT disabled", L);
     }
     if (!r->variant && walk) {
@@ -973,6 +1011,9 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
         if ((rc = jit_function(m, "mhx_jit_rwmh_init", &r->jit_init))) return rc;
         if (r->variant == 0 && (rc = jit_function(m, "mhx_jit_rwmh_generic", &r->jit_step))) return rc;
     }
+    if ((cfg->flags & MHX_FLAG_ZIGGURAT) && r->normal_gen != MHX_GEN_ZIGGURAT)
+        return mhx_fail(MHX_EINVAL, "MHX_FLAG_ZIGGURAT: this run's kernel (variant %d) has no ziggurat form -- it exists on the cooperative "
+                                    "kernel of fp64 contexts (separable catalogue target, ISO / DIAG proposal, JIT allowed)", r->variant);
     // candidate scratch of the state-in-HBM kernel; a static proposal whitens the state into it whatever kernel steps the chain
     if (r->variant == 0 || r->d_qx) HIP_TRY(hipMalloc(&r->d_ybuf, (size_t)d * (size_t)r->n * sizeof(mhx_real)));
     *out = r.release();
@@ -1031,17 +1072,15 @@ static int rwmh_advance(mhx_run* r, uint64_t nsteps, uint32_t save_next, int sav
             const long threads = (((long)r->n + (64 / r->coop_L) - 1) / (64 / r->coop_L)) * 64;   // whole waves
             const unsigned grid = (unsigned)((threads + 255) / 256);
             if (r->moments_mode && r->reg_fn_mom) {
-                hipLaunchKernelGGL(r->reg_fn_mom, dim3(grid), dim3(256), 0, ctx->stream, a, tp, pv);
+                hipLaunchKernelGGL(r->reg_fn_mom, dim3(grid), dim3(256), r->coop_lds, ctx->stream, a, tp, pv);
             } else if (r->moments_mode) {
                 void* params[] = {&a, &tp, &pv};
-                int rc = launch_module(r->jit_step_mom, grid, 256, ctx->stream, params);
-                if (rc) return rc;
+                HIP_TRY(hipModuleLaunchKernel(r->jit_step_mom, grid, 1, 1, 256, 1, 1, (unsigned)r->coop_lds, ctx->stream, params, nullptr));
             } else if (r->variant == 3) {
-                hipLaunchKernelGGL(r->reg_fn, dim3(grid), dim3(256), 0, ctx->stream, a, tp, pv);
+                hipLaunchKernelGGL(r->reg_fn, dim3(grid), dim3(256), r->coop_lds, ctx->stream, a, tp, pv);
             } else {
                 void* params[] = {&a, &tp, &pv};
-                int rc = launch_module(r->jit_step, grid, 256, ctx->stream, params);
-                if (rc) return rc;
+                HIP_TRY(hipModuleLaunchKernel(r->jit_step, grid, 1, 1, 256, 1, 1, (unsigned)r->coop_lds, ctx->stream, params, nullptr));
             }
         } else if (r->variant == 8 && r->mfma_stream) {
             const unsigned grid = (unsigned)(((long)r->n + 16 * MHX_MFMA_WAVES - 1) / (16 * MHX_MFMA_WAVES));
@@ -1166,6 +1205,7 @@ int api_run_sample(mhx_run* r, const mhx_schedule* s, int save_samples)
     r->stats.kernel_variant = r->variant;
     r->stats.reduce_lanes = r->coop_L;
     r->stats.dtype = r->dtype;
+    r->stats.normal_gen = r->normal_gen;
     auto total_accepts = [&](unsigned long long* out) -> int { return run_total_accepts(r, out); };
     unsigned long long acc_before = 0;
     { int rc0 = total_accepts(&acc_before); if (rc0) return rc0; }
@@ -1183,6 +1223,9 @@ int api_run_sample(mhx_run* r, const mhx_schedule* s, int save_samples)
             jit_module* m = nullptr;
             int rcj = jit_compile(ctx, r->coop_key + "/mom=1", jit_source(r->target, "mhx_rwmh_kernels.h"), r->coop_defs, &m);
             if (rcj == MHX_OK) rcj = jit_function(m, "mhx_jit_rwmh_coop", &r->jit_step_mom);
+            if (rcj == MHX_OK && r->coop_lds &&
+                hipFuncSetAttribute((const void*)r->jit_step_mom, hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->coop_lds) != hipSuccess)
+                rcj = mhx_fail(MHX_EHIP, "cooperative kernel (ziggurat, moments): %zu bytes of LDS refused", r->coop_lds);
             if (rcj) return rcj;
         }
         const size_t bytes = ((size_t)r->dim + 1) * (size_t)r->n * sizeof(mhx_real);

@@ -48,6 +48,9 @@ typedef float mhx_real;
 
 typedef unsigned int mhx_u32;
 typedef unsigned long long mhx_u64;
+#if MHX_REAL64
+#include "mhx_zig_table.h"     // generated (tools/gen_zig_table.py): the layer table of the ziggurat normal generator
+#endif
 MHX_NS_BEGIN
 
 // signature of a user log-density in HIP source form (see include/mhx.h, mhx_target_from_hip_source)
@@ -362,6 +365,71 @@ MHX_DEV double mhx_accept_logu(const mhx_philox_key& ks, mhx_u32 id_lo, mhx_u32 
     return mhx_log_pos(mhx_u01_open(odd ? cache.w.z : cache.w.x, odd ? cache.w.w : cache.w.y));
 }
 
+// ---------------------------------------------------------------------------------------------
+// The ZIGGURAT normal generator of the fp64 spec (Marsaglia & Tsang 2000 in Doornik's ZIGNOR
+// form): MHX_ZIG_N equal-area layers under exp(-x^2/2), table x[0..N] (mhx_zig_table.h: x[0] = v/f(r), x[1] = r, x[N] = 0).
+// A normal takes 64 bits like a Box-Muller normal does -- Philox block p of (id, step, stream) serves normals 2p (words
+// x, y) and 2p + 1 (words z, w):
+//   r = hi:lo;  layer = lo mod N;  sign = bit 11 of lo;  u = (r >> 12) 2^-52 in [0, 1);  |x| = u x[layer]
+//   accept at once when |x| < x[layer + 1]  (99.6 % of the draws: a table look-up, a multiply and a compare);
+// otherwise rejection attempts t = 1, 2, ... from Philox block (n << 8 | t) of stream | 4, n = index of the normal in
+// its step:  layer 0: the tail beyond r (Marsaglia) -- xx = -log(U1)/r, yy = -log(U2), accept r + xx iff 2 yy >= xx^2;
+// else the wedge -- accept x iff f1 + U (f0 - f1) < 1 with f0 = exp(-(x_l^2 - x^2)/2), f1 = exp(-(x_{l+1}^2 - x^2)/2),
+// U from words (z, w); on rejection words (x, y) of the same block are the next candidate.
+#define MHX_STREAM_RETRY 4u
+#define MHX_GEN_BOX_MULLER 0
+#define MHX_GEN_ZIGGURAT 1
+__device__ const double mhx_zig_x[MHX_ZIG_N + 1] = MHX_ZIG_TABLE;
+
+MHX_DEV bool mhx_zig_try(const double* __restrict__ zt, const mhx_u32 hi, const mhx_u32 lo, double& x, mhx_u32& layer)
+{
+    layer = lo & (mhx_u32)(MHX_ZIG_N - 1);
+    const double u = mhx_u01_half(hi, lo);
+    const double ax = u * zt[layer];
+    x = mhx_u2d(mhx_d2u(ax) ^ ((mhx_u64)((lo << 20) & 0x80000000u) << 32));     // bit 11 of lo is the sign
+    return ax < zt[layer + 1];
+}
+
+// the normal behind a candidate (x, layer) that left its rectangle
+MHX_DEV double mhx_zig_slow(const mhx_philox_key& ks, const double* __restrict__ zt, const mhx_u32 id_lo, const mhx_u32 id_hi,
+                            const mhx_u32 step, const mhx_u32 stream, const mhx_u32 n, double x, mhx_u32 layer)
+{
+    for (mhx_u32 t = 1;; ++t) {
+        const mhx_u32x4 v = mhx_philox(ks, id_lo, id_hi, step, ((stream | MHX_STREAM_RETRY) << 28) | ((n << 8) | (t & 255u)));
+        if (layer == 0u) {
+            const double xx = mhx_log_pos(mhx_u01_open(v.x, v.y)) * MHX_ZIG_NEG_RINV;
+            const double yy = -mhx_log_pos(mhx_u01_open(v.z, v.w));
+            if (yy + yy >= xx * xx) return mhx_u2d(mhx_d2u(MHX_ZIG_R + xx) | (mhx_d2u(x) & 0x8000000000000000ull));
+        } else {
+            const double xl = zt[layer], xl1 = zt[layer + 1], xsq = x * x;
+            const double f0 = mhx_exp(-0.5 * (xl * xl - xsq)), f1 = mhx_exp(-0.5 * (xl1 * xl1 - xsq));
+            if (mhx_fma(mhx_u01_half(v.z, v.w), f0 - f1, f1) < 1.0) return x;
+            if (mhx_zig_try(zt, v.x, v.y, x, layer)) return x;
+        }
+    }
+}
+
+// normal number n (0-based) of (id, step, stream), straight from the table in global memory: the kernels off the hot path
+MHX_DEV double mhx_zig_normal(const mhx_philox_key& ks, const mhx_u32 id_lo, const mhx_u32 id_hi, const mhx_u32 step,
+                              const mhx_u32 stream, const mhx_u32 n)
+{
+    const mhx_u32x4 w = mhx_philox(ks, id_lo, id_hi, step, (stream << 28) | (n >> 1));
+    double x; mhx_u32 layer;
+    if (mhx_zig_try(mhx_zig_x, (n & 1u) ? w.z : w.x, (n & 1u) ? w.w : w.y, x, layer)) return x;
+    return mhx_zig_slow(ks, mhx_zig_x, id_lo, id_hi, step, stream, n, x, layer);
+}
+// the 4 normals 4b..4b+3 by either generator (lane-per-chain kernels: initial draws, generic paths)
+MHX_DEV void mhx_normal4_gen(const int gen, const mhx_philox_key& ks, mhx_u32 id_lo, mhx_u32 id_hi, mhx_u32 step,
+                             mhx_u32 stream, mhx_u32 block, double n[4])
+{
+    if (gen == MHX_GEN_ZIGGURAT) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) n[j] = mhx_zig_normal(ks, id_lo, id_hi, step, stream, 4u * block + (mhx_u32)j);
+    } else {
+        mhx_normal4(ks, id_lo, id_hi, step, stream, block, n);
+    }
+}
+
 // the draws of one stretch move (src/emcee.jl:48,52 partner, :81 stretch uniform, :93 accept)
 struct mhx_emcee_draws { mhx_u32 partner; double u, logu; };
 MHX_DEV mhx_emcee_draws mhx_emcee_draw(const mhx_philox_key& ks, mhx_u32 walker, mhx_u32 ens, mhx_u32 sweep)
@@ -533,6 +601,14 @@ MHX_DEV void mhx_normal4(const mhx_philox_key& ks, mhx_u32 id_lo, mhx_u32 id_hi,
     const mhx_u32x4 w = mhx_philox(ks, id_lo, id_hi, step, (stream << 28) | block);
     mhx_normal_pair(w.x, w.y, n[0], n[1]);
     mhx_normal_pair(w.z, w.w, n[2], n[3]);
+}
+#define MHX_GEN_BOX_MULLER 0
+#define MHX_GEN_ZIGGURAT 1
+// (the ziggurat generator exists in the fp64 engine only)
+MHX_DEV void mhx_normal4_gen(const int, const mhx_philox_key& ks, mhx_u32 id_lo, mhx_u32 id_hi, mhx_u32 step,
+                             mhx_u32 stream, mhx_u32 block, float n[4])
+{
+    mhx_normal4(ks, id_lo, id_hi, step, stream, block, n);
 }
 
 // log of the accept uniform of `step`: one Philox block serves 4 consecutive steps.

@@ -72,6 +72,7 @@ struct mhx_rwmh_args {
     const mhx_real* pmean;       // null = zero mean (the Hastings ratio is then exactly 0 and is not computed)
     // static (independence) proposal, generic kernel only: q(x) = -1/2 |L^-1 (x - mu)|^2 of each chain's state
     mhx_real* qx;                // [ld] or null = random walk
+    int normal_gen;              // MHX_GEN_*: how stream bits become standard normals (a property of the run: initial draw and proposals)
 };
 
 // one Welford step with the wave-uniform 1/n
@@ -358,11 +359,80 @@ MHX_DEV void mhx_rwmh_whiten_body(const mhx_rwmh_args& a, const mhx_real* __rest
 #define MHX_WALK_PLAIN  0
 #define MHX_WALK_DRIFT  1
 #define MHX_WALK_STATIC 2
-template <int L, int NBL, int TK, int PK, bool MOM, int WALK = MHX_WALK_PLAIN>
+#if MHX_REAL64
+// Dynamic LDS of the cooperative kernel with the ziggurat generator (GEN = MHX_GEN_ZIGGURAT), 256-thread blocks:
+//   [0, 8208)                       the layer table x[0..N]
+//   then per wave  NBL*4*64 doubles the step's normals, [pair of slots][lane][2] (a lane writes / reads 16 bytes, conflict-free)
+//                  64 u16           the queue of the candidates that left their rectangles: owner lane | slot << 6
+#define MHX_ZIG_TABLE_BYTES (((MHX_ZIG_N + 1) * 8 + 15) / 16 * 16)
+#define MHX_ZIG_WAVE_BYTES(NBL) ((NBL) * 4 * 64 * 8 + 128)
+#define MHX_ZIG_LDS_BYTES(NBL) (MHX_ZIG_TABLE_BYTES + 4 * MHX_ZIG_WAVE_BYTES(NBL))
+
+// The candidates of this wave-step that left their rectangles (0.4 % of the draws: a dozen per wave-step at d = 100), gathered
+// from all lanes into one queue and finished by as many lanes side by side -- ONE pass of the slow path per wave-step instead of
+// one per failing block.  fm: the lane's failed slots (bit s = slot 4 i + j).  A fixer lane re-derives the failed candidate from
+// its Philox block (nothing but the slot number was kept), runs the rejection loop of mhx_zig_slow and drops the normal into the
+// owner's place in `zn`.
+template <int L>
+MHX_DEV void mhx_zig_fixup(const mhx_philox_key& ks, const double* __restrict__ zt, double* __restrict__ zn,
+                           unsigned short* __restrict__ zq, const mhx_u64 fm, const int lane, const long wave,
+                           const mhx_u64 first_chain, const int nchains, const mhx_u32 step, const mhx_u32 stream)
+{
+    constexpr int CPW = 64 / L;
+    const int cnt = __popcll(fm);
+    int incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); incl += lane >= off ? t : 0; }
+    const int base = incl - cnt;                                   // this lane's first entry
+    const int total = __shfl(incl, 63, 64);
+    for (int win = 0; win < total; win += 64) {                    // (one window unless > 64 candidates failed at once)
+        mhx_u64 f = fm;
+        int e = base - win;
+        while (__ballot(f != 0ull)) {                              // wave-uniform: the largest number of failures of one lane
+            if (f != 0ull) {
+                const int sl = __ffsll((long long)f) - 1;
+                f &= f - 1ull;
+                if (e >= 0 && e < 64) zq[e] = (unsigned short)(lane | (sl << 6));
+                ++e;
+            }
+        }
+        MHX_WAVE_SYNC();
+        const int nent = total - win < 64 ? total - win : 64;
+        if (lane < nent) {
+            const int ent = zq[lane];
+            const int ol = ent & 63, sl = ent >> 6;
+            const long oc_raw = wave * CPW + (ol & (CPW - 1));
+            const mhx_u64 oid = first_chain + (mhx_u64)(oc_raw < nchains ? oc_raw : (long)nchains - 1);
+            const mhx_u32 b = (mhx_u32)(ol / CPW + L * (sl >> 2));
+            const mhx_u32 n = 4u * b + (mhx_u32)(sl & 3);
+            const mhx_u32x4 w = mhx_philox(ks, (mhx_u32)oid, (mhx_u32)(oid >> 32), step, (stream << 28) | (n >> 1));
+            double x; mhx_u32 layer;
+            (void)mhx_zig_try(zt, (n & 1u) ? w.z : w.x, (n & 1u) ? w.w : w.y, x, layer);     // fails by construction
+            x = mhx_zig_slow(ks, zt, (mhx_u32)oid, (mhx_u32)(oid >> 32), step, stream, n, x, layer);
+            zn[(((sl >> 1) * 64 + ol) << 1) + (sl & 1)] = x;
+        }
+        MHX_WAVE_SYNC();
+    }
+}
+#endif
+
+template <int L, int NBL, int TK, int PK, bool MOM, int WALK = MHX_WALK_PLAIN, int GEN = MHX_GEN_BOX_MULLER>
 MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restrict__ tparams,
                                 const mhx_real* __restrict__ pvec)
 {
     constexpr int CPW = 64 / L;                    // chains per wave
+    constexpr bool ZIG = GEN == MHX_GEN_ZIGGURAT;
+    static_assert(!ZIG || MHX_REAL64, "the ziggurat generator exists in the fp64 engine only");
+#if MHX_REAL64
+    extern __shared__ double mhx_coop_lds[];
+    const double* zt = mhx_coop_lds;
+    double* zn = mhx_coop_lds + MHX_ZIG_TABLE_BYTES / 8 + (threadIdx.x >> 6) * (MHX_ZIG_WAVE_BYTES(NBL) / 8);
+    unsigned short* zq = (unsigned short*)(zn + NBL * 4 * 64);
+    if (ZIG) {
+        for (int e = threadIdx.x; e <= MHX_ZIG_N; e += blockDim.x) mhx_coop_lds[e] = mhx_zig_x[e];
+        __syncthreads();
+    }
+#endif
     const int lane = threadIdx.x & 63;
     const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int cw = lane & (CPW - 1);
@@ -439,10 +509,48 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
         // dimensions of the final block) computes on zeros -- y = 0 there, and fma(0, 0, q) == q bit for
         // bit, so the partial sums need no predication.
         mhx_real q = MHX_R(0.0), fwd = MHX_R(0.0), bwd = MHX_R(0.0);
+#if MHX_REAL64
+        if (ZIG) {
+            // phase A: every slot's candidate by the fast path -- table look-up, multiply, compare -- into LDS; the slots that
+            // left their rectangles are noted in `fm` and finished by mhx_zig_fixup before the candidate state is formed
+            mhx_u64 fm = 0ull;
+#pragma unroll
+            for (int i = 0; i < NBL; ++i) {
+                const mhx_u32 b = (mhx_u32)(l + L * i);
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    const mhx_u32x4 w = mhx_philox(ks, id_lo, id_hi, step, (MHX_STREAM_PROPOSAL << 28) | (2u * b + (mhx_u32)pr));
+                    double n0, n1; mhx_u32 ly;
+                    bool f0 = !mhx_zig_try(zt, w.x, w.y, n0, ly);
+                    bool f1 = !mhx_zig_try(zt, w.z, w.w, n1, ly);
+                    if (i == NBL - 1) {                         // padding dimensions past the end of the vector need no normal
+                        f0 = f0 && (k_last + 2 * pr < d);
+                        f1 = f1 && (k_last + 2 * pr + 1 < d);
+                    }
+                    fm |= (f0 ? 1ull : 0ull) << (4 * i + 2 * pr);
+                    fm |= (f1 ? 1ull : 0ull) << (4 * i + 2 * pr + 1);
+                    typedef double mhx_d2 __attribute__((ext_vector_type(2)));
+                    mhx_d2 v2; v2.x = n0; v2.y = n1;
+                    *(mhx_d2*)(zn + (((i * 2 + pr) * 64 + lane) << 1)) = v2;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (__ballot(fm != 0ull))
+                mhx_zig_fixup<L>(ks, zt, zn, zq, fm, lane, wave, a.first_chain, a.nchains, step, MHX_STREAM_PROPOSAL);
+        }
+#endif
 #pragma unroll
         for (int i = 0; i < NBL; ++i) {
             const int b = l + L * i;
             mhx_real n[4];
+#if MHX_REAL64
+            if (ZIG) {
+                typedef double mhx_d2 __attribute__((ext_vector_type(2)));
+                const mhx_d2 v0 = *(const mhx_d2*)(zn + (((i * 2) * 64 + lane) << 1));
+                const mhx_d2 v1 = *(const mhx_d2*)(zn + (((i * 2 + 1) * 64 + lane) << 1));
+                n[0] = v0.x; n[1] = v0.y; n[2] = v1.x; n[3] = v1.y;
+            } else
+#endif
             mhx_normal4(ks, id_lo, id_hi, step, MHX_STREAM_PROPOSAL, (mhx_u32)b, n);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -603,7 +711,7 @@ MHX_DEV void mhx_rwmh_init_body(const mhx_rwmh_args& a, const mhx_real* __restri
         const int nblk = (d + 3) >> 2;
         for (int b = 0; b < nblk; ++b) {
             mhx_real n[4];
-            mhx_normal4(ks, id_lo, id_hi, 0u, MHX_STREAM_INIT, (mhx_u32)b, n);
+            mhx_normal4_gen(a.normal_gen, ks, id_lo, id_hi, 0u, MHX_STREAM_INIT, (mhx_u32)b, n);
             for (int j = 0; j < 4; ++j) {
                 const int k = 4 * b + j;
                 if (k < d) {
@@ -688,7 +796,10 @@ mhx_jit_rwmh_coop(const mhx_rwmh_args a, const mhx_real* __restrict__ tparams, c
 #ifndef MHX_JIT_WALK
 #define MHX_JIT_WALK 0
 #endif
-    mhx_rwmh_coop_body<MHX_JIT_L, MHX_JIT_NBL, MHX_JIT_TK, MHX_JIT_PK, (MHX_JIT_MOM != 0), MHX_JIT_WALK>(a, tparams, pvec);
+#ifndef MHX_JIT_GEN
+#define MHX_JIT_GEN MHX_GEN_BOX_MULLER
+#endif
+    mhx_rwmh_coop_body<MHX_JIT_L, MHX_JIT_NBL, MHX_JIT_TK, MHX_JIT_PK, (MHX_JIT_MOM != 0), MHX_JIT_WALK, MHX_JIT_GEN>(a, tparams, pvec);
 }
 #endif
 #ifdef MHX_JIT_RWMH_GENERIC

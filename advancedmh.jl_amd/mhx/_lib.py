@@ -16,6 +16,7 @@ PROP_ISO, PROP_DIAG, PROP_DENSE = 0, 1, 2
 FLAG_NO_JIT, FLAG_GENERIC = 1, 2
 MHX_FLAG_STATIC_PROPOSAL = 4
 FLAG_EMCEE_SEQUENTIAL = 8
+FLAG_ZIGGURAT = 16
 
 
 class MhxError(RuntimeError):
@@ -65,7 +66,7 @@ class MalaCfg(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("transitions", C.c_uint64), ("accepted", C.c_uint64), ("kernel_ms", C.c_double),
                 ("wall_ms", C.c_double), ("kernel_variant", C.c_int32), ("launches", C.c_int32),
-                ("reduce_lanes", C.c_int32), ("dtype", C.c_int32)]
+                ("reduce_lanes", C.c_int32), ("dtype", C.c_int32), ("normal_gen", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class DiagCfg(C.Structure):

@@ -416,7 +416,14 @@ class Chains:
 
 
 class Run:
-    def __init__(self, model, sampler, nchains=1, seed=0, first_chain=0, ctx=None, flags=0, reduce_lanes=0, dtype=None):
+    def __init__(self, model, sampler, nchains=1, seed=0, first_chain=0, ctx=None, flags=0, reduce_lanes=0, dtype=None,
+                 normal_gen=None):
+        """normal_gen: None / "box-muller" (default) or "ziggurat" (MHX_FLAG_ZIGGURAT: RWMH on the cooperative kernel of an fp64
+        context -- a different, cheaper stream of standard normals; reported in stats()["normal_gen"])."""
+        if normal_gen not in (None, "box-muller", "ziggurat"):
+            raise L.ArgumentError(L.MHX_EINVAL, "normal_gen must be None, 'box-muller' or 'ziggurat'")
+        if normal_gen == "ziggurat":
+            flags |= L.FLAG_ZIGGURAT
         self.ctx = ctx or L.Context.default(dtype=dtype)
         self.real = self.ctx.real
         f32 = self.ctx.arr                                  # (the name of round 1: now "an array of the context's reals")
@@ -584,7 +591,7 @@ class Run:
         L.check(L.lib().mhx_run_stats(self.h, C.byref(st)))
         return dict(transitions=st.transitions, accepted=st.accepted, kernel_ms=st.kernel_ms, wall_ms=st.wall_ms,
                     kernel_variant=st.kernel_variant, launches=st.launches, reduce_lanes=st.reduce_lanes,
-                    dtype="f64" if st.dtype == L.MHX_F64 else "f32")
+                    dtype="f64" if st.dtype == L.MHX_F64 else "f32", normal_gen=st.normal_gen)
 
     def diagnostics(self, max_lag=0, ess_chains=256, split=False):
         """Sums for R-hat / between-chain ESS (all chains) and, if max_lag > 0, the Geyer ESS from the multi-chain
@@ -690,7 +697,7 @@ class MCMCHIP(_ParallelTag):
 
 def sample(model, sampler, N, nchains=1, *more, initial_params=None, discard_initial=None, thinning=1, num_warmup=0,
            param_names=None, chain_type=Chains, seed=0, first_chain=0, callback=None, ctx=None, flags=0,
-           reduce_lanes=0, progress=False, dtype=None):
+           reduce_lanes=0, progress=False, dtype=None, normal_gen=None):
     """sample(model, sampler, N[, nchains]; kwargs...) -- AbstractMCMC.sample as re-exported by the
     reference (src/AdvancedMH.jl:30).  All chains advance together on the GPU (what
     `sample(model, spl, MCMCThreads(), N, nchains)` does with one task per chain, README.md:141-147).
@@ -708,7 +715,7 @@ def sample(model, sampler, N, nchains=1, *more, initial_params=None, discard_ini
     if discard_initial is None:
         discard_initial = num_warmup
     run = Run(model, sampler, nchains=nchains, seed=seed, first_chain=first_chain, ctx=ctx, flags=flags,
-              reduce_lanes=reduce_lanes, dtype=dtype)
+              reduce_lanes=reduce_lanes, dtype=dtype, normal_gen=normal_gen)
     run.init(initial_params)
     if callback is None:
         # one call: the samples stream to the host while the chains advance (mhx_run_sample_to_host)

@@ -43,6 +43,19 @@ VARIANTS = {0: "generic", 1: "prebuilt-register", 2: "hiprtc-register", 3: "preb
 RB = {"f32": 4, "f64": 8}
 
 
+GEN_TEXT = {None: "Box-Muller", "box-muller": "Box-Muller",
+            "ziggurat": "the table ziggurat of the fp64 spec (MHX_FLAG_ZIGGURAT: 1024 layers, 64 bits per normal, exact rejection sampling)"}
+
+
+def pick_gen(args, dtype):
+    """RWMH on the cooperative kernel: the ziggurat generator in fp64 (what Julia's own randn is), Box-Muller in fp32 (the fp64
+    engine alone has the ziggurat); --normal-gen overrides."""
+    g = getattr(args, "normal_gen", "auto")
+    if g == "auto":
+        return "ziggurat" if dtype == "f64" else None
+    return None if g == "box-muller" or dtype != "f64" else g
+
+
 def sigma_ar1(d, rho):
     import numpy as np
     i = np.arange(d)
@@ -87,6 +100,7 @@ class C2:
         self.d, self.C, self.inner, self.dtype = args.dim or 100, args.chains or 65536, args.inner or 250, dtype
         self.lanes = args.lanes
         self.literal = getattr(args, "c2_literal", False)
+        self.gen = pick_gen(args, dtype)
 
     def build(self, mhx, ctx, rank):
         import numpy as np
@@ -94,7 +108,8 @@ class C2:
         self.s = 1.0 if self.literal else float(np.float32(2.38 / d ** 0.5))
         model = mhx.DensityModel(mhx.IsoGaussian(d))
         spl = mhx.RWMH(mhx.MvNormal(mhx.zeros(d), self.s * self.s * mhx.I))
-        self.run = mhx.Run(model, spl, nchains=self.C, seed=0xC0FFEE, first_chain=rank * self.C, ctx=ctx, reduce_lanes=self.lanes)
+        self.run = mhx.Run(model, spl, nchains=self.C, seed=0xC0FFEE, first_chain=rank * self.C, ctx=ctx, reduce_lanes=self.lanes,
+                           normal_gen=self.gen)
         self.run.init(None)                                # x0 ~ proposal draw (src/mh-core.jl:83), on the device
         return self.run
 
@@ -116,13 +131,13 @@ class C2:
 
     def describe(self):
         return ("RWMH, isotropic %d-dim standard MvNormal target, %d chains per GPU, proposal %s, "
-                "%d transitions per launch, every state recorded" % (
+                "%d transitions per launch, every state recorded; standard normals by %s" % (
                     self.d, self.C, "N(0, I) (the literal RWMH(MvNormal(zeros(d), I)) of the config text)" if self.literal
-                    else "N(0,(2.38/sqrt(d))^2 I)", self.inner))
+                    else "N(0,(2.38/sqrt(d))^2 I)", self.inner, GEN_TEXT[self.gen]))
 
     def cpu_baseline(self, O, target_seconds):
         tgt = O.iso_gauss(self.d)
-        prop = O.Proposal(O.PROP_ISO, self.s)
+        prop = O.Proposal(O.PROP_ISO, self.s, normal_gen=1 if self.gen == "ziggurat" else 0)
         inner = self.inner
 
         def work(i, nchains):
@@ -143,6 +158,7 @@ class C5(C2):
     def __init__(self, args, dtype):
         self.d, self.C, self.inner, self.dtype = args.dim or 1000, args.chains or 32768, args.inner or 200, dtype
         self.lanes = args.lanes
+        self.gen = pick_gen(args, dtype)
 
     def build(self, mhx, ctx, rank):
         import numpy as np
@@ -150,7 +166,7 @@ class C5(C2):
         self.s = float(np.float32(2.38 / d ** 0.5))
         spl = mhx.RWMH(mhx.MvNormal(mhx.zeros(d), self.s * self.s * mhx.I))
         self.run = mhx.Run(mhx.DensityModel(mhx.Funnel(d)), spl, nchains=self.C, seed=5, first_chain=rank * self.C, ctx=ctx,
-                           reduce_lanes=self.lanes)
+                           reduce_lanes=self.lanes, normal_gen=self.gen)
         # a stationary start (a draw from the funnel itself: v ~ N(0, 9), x_k ~ N(0, e^v)) instead of a burn-in: from the
         # proposal-scale start of init(None) the chains spend thousands of transitions inflating |x|^2
         rng = np.random.default_rng(1000 + rank)
@@ -174,11 +190,12 @@ class C5(C2):
 
     def describe(self):
         return ("RWMH, 1000-dim Neal's funnel, %d chains per GPU (global ids: shard of 8 x 32 768), proposal N(0,(2.38/sqrt(d))^2 I), "
-                "%d transitions per launch, running moments of every 10th state, R-hat by one all-reduce" % (self.C, self.inner))
+                "%d transitions per launch, running moments of every 10th state, R-hat by one all-reduce; standard normals by %s" % (
+                    self.C, self.inner, GEN_TEXT[self.gen]))
 
     def cpu_baseline(self, O, target_seconds):
         tgt = O.Target(O.TARGET_FUNNEL, self.d)
-        prop = O.Proposal(O.PROP_ISO, self.s)
+        prop = O.Proposal(O.PROP_ISO, self.s, normal_gen=1 if self.gen == "ziggurat" else 0)
         inner = self.inner
 
         def work(i, nchains):
@@ -549,6 +566,8 @@ def main():
     ap.add_argument("--c2-literal", action="store_true", help="c2: proposal N(0, I) as the config text reads (acceptance ~ 0 at d = 100) "
                     "instead of the tuned 2.38/sqrt(d)")
     ap.add_argument("--c4-moving", action="store_true", help="c4: random start and S0 = 2.38/sqrt(d) I instead of x0 = 0, S0 = I")
+    ap.add_argument("--normal-gen", choices=["auto", "ziggurat", "box-muller"], default="auto",
+                    help="c2 / c5: how the RWMH kernel turns stream bits into standard normals (auto: ziggurat in fp64, Box-Muller in fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--allow-gloo", action="store_true", help="--gpus > 1: fall back to torch.distributed gloo for the host-side "
                     "all-reduces when the RCCL communicator cannot be created (default: that is an error)")

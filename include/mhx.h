@@ -134,6 +134,13 @@ typedef struct {
 #define MHX_FLAG_EMCEE_SEQUENTIAL 8 /* Ensemble runs only: the reference's sweep (src/emcee.jl:39-58) -- walkers move one after
                                       another and pair with already-updated walkers (Gauss-Seidel), one wavefront, for
                                       fidelity checks at the reference's test sizes; the default is the parallel half-split */
+#define MHX_FLAG_ZIGGURAT 16 /* RWMH runs, fp64 contexts: standard normals by the table ZIGGURAT of the arithmetic spec (DESIGN.md
+                                section 3.11: 1024 equal-area layers, 64 bits per normal, exact rejection sampling) instead of
+                                Box-Muller -- a third fewer instructions per transition on the cooperative kernel (separable
+                                catalogue targets, ISO / DIAG proposals).  It selects the STREAM of normals, so the chain differs
+                                from the Box-Muller chain of the same seed (both target the same law); the value in effect is
+                                reported in mhx_stats.normal_gen and fixes the chain bit for bit.  MHX_EINVAL where the run's
+                                kernel has no ziggurat form (fp32, dense factors, user targets, register / generic kernels). */
 #define MHX_FLAG_STATIC_PROPOSAL 4 /* RWMH runs only: the proposal is a StaticProposal (src/proposal.jl:9-11,66-83) --
                                       the candidate is a draw mean + L z that ignores the current state (independence
                                       sampler) and the ratio is logpdf(p, x) - logpdf(p, y) */
@@ -267,6 +274,8 @@ typedef struct {
     int32_t launches;
     int32_t reduce_lanes;      /* lanes per chain in effect (1 unless a cooperative kernel runs) */
     int32_t dtype;             /* mhx_dtype of the run's context */
+    int32_t normal_gen;        /* 0 Box-Muller, 1 ziggurat (MHX_FLAG_ZIGGURAT): how the run turns stream bits into normals */
+    int32_t reserved_;
 } mhx_stats;
 int mhx_run_stats(mhx_run *run, mhx_stats *out);
 

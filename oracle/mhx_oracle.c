@@ -366,6 +366,66 @@ static void emcee_draws(uint64_t seed, uint64_t ens, int i, uint32_t sweep, uint
 }
 #endif
 
+/* ------------------------------------------------------------------------------------------ */
+/* normal generators.  gen 0: Box-Muller (orc_normals).  gen 1 (fp64 only): the table ZIGGURAT of spec 3.11 --
+ * ORC_ZIG_N equal-area layers under exp(-x^2/2) (mhx_zig_table.h, generated by tools/gen_zig_table.py), 64 bits per normal:
+ * Philox block p of (chain, step, stream) serves normals 2p (words 0,1) and 2p+1 (words 2,3); r = hi:lo, layer = lo mod N,
+ * sign = bit 11 of lo, u = (r >> 12) 2^-52, |x| = u x[layer], accepted at once iff |x| < x[layer+1]; otherwise rejection
+ * attempts t = 1, 2, ... from block (n << 8 | t) of stream | 4 (n = index of the normal in its step): layer 0 = Marsaglia's
+ * tail beyond r, else the wedge test with the next candidate from the same block on rejection.
+ * (What Julia's randn does with its own 256-layer table and Xoshiro bits, Random/src/normal.jl -- restated, not copied.) */
+#if ORC_F64
+#include "mhx_zig_table.h"
+static const double zig_x[MHX_ZIG_N + 1] = MHX_ZIG_TABLE;
+
+static int zig_try(uint32_t hi, uint32_t lo, double *x, uint32_t *layer)
+{
+    *layer = lo & (uint32_t)(MHX_ZIG_N - 1);
+    const double u = orc_u01_half(hi, lo);
+    const double ax = u * zig_x[*layer];
+    *x = (lo & 2048u) ? -ax : ax;
+    return ax < zig_x[*layer + 1];
+}
+
+double orc_zig_normal(uint64_t seed, uint64_t chain, uint32_t step, uint32_t stream, uint32_t n)
+{
+    uint32_t w[4], layer;
+    double x;
+    philox_at(seed, chain, step, stream, n >> 1, w);
+    if (zig_try((n & 1u) ? w[2] : w[0], (n & 1u) ? w[3] : w[1], &x, &layer)) return x;
+    for (uint32_t t = 1;; ++t) {
+        philox_at(seed, chain, step, stream | 4u, (n << 8) | (t & 255u), w);
+        if (layer == 0u) {
+            const double xx = orc_log(orc_u01_open(w[0], w[1])) * MHX_ZIG_NEG_RINV;
+            const double yy = -orc_log(orc_u01_open(w[2], w[3]));
+            if (yy + yy >= xx * xx) return signbit(x) ? -(MHX_ZIG_R + xx) : (MHX_ZIG_R + xx);
+        } else {
+            const double xl = zig_x[layer], xl1 = zig_x[layer + 1], xsq = x * x;
+            const double f0 = orc_exp(-0.5 * (xl * xl - xsq)), f1 = orc_exp(-0.5 * (xl1 * xl1 - xsq));
+            if (fma(orc_u01_half(w[2], w[3]), f0 - f1, f1) < 1.0) return x;
+            if (zig_try(w[0], w[1], &x, &layer)) return x;
+        }
+    }
+}
+#endif
+
+void orc_normals_gen(int gen, uint64_t seed, uint64_t chain, uint32_t step, uint32_t stream, int d, real *out);
+static void normals_gen(int gen, uint64_t seed, uint64_t chain, uint32_t step, uint32_t stream, int d, real *out)
+{
+#if ORC_F64
+    if (gen == 1) {
+        for (int k = 0; k < d; ++k) out[k] = orc_zig_normal(seed, chain, step, stream, (uint32_t)k);
+        return;
+    }
+#endif
+    (void)gen;
+    orc_normals(seed, chain, step, stream, d, out);
+}
+void orc_normals_gen(int gen, uint64_t seed, uint64_t chain, uint32_t step, uint32_t stream, int d, real *out)
+{
+    normals_gen(gen, seed, chain, step, stream, d, out);
+}
+
 #define LOG_2PI_D 1.8378770664093454835606594728112
 
 /* ------------------------------------------------------------------------------------------ */
@@ -677,7 +737,7 @@ int orc_rwmh(const orc_target *t, const orc_proposal *p, const orc_schedule *s,
         if (init) {
             for (int k = 0; k < d; ++k) x[k] = init[(size_t)k * C + c];
         } else {
-            orc_normals(seed, id, 0, ORC_STREAM_INIT, d, z);
+            normals_gen(p->normal_gen, seed, id, 0, ORC_STREAM_INIT, d, z);
             for (int k = 0; k < d; ++k) y[k] = R(0.0);
             propose_from(p, d, z, y, x);
         }
@@ -690,7 +750,7 @@ int orc_rwmh(const orc_target *t, const orc_proposal *p, const orc_schedule *s,
         margin_flush(&mg, slot, C, c);
         for (int64_t tau = 1; tau <= nT; ++tau) {
             const uint32_t step = (uint32_t)tau;
-            orc_normals(seed, id, step, ORC_STREAM_PROPOSAL, d, z);
+            normals_gen(p->normal_gen, seed, id, step, ORC_STREAM_PROPOSAL, d, z);
             propose_from(p, d, z, p->is_static ? zero : x, y);   /* mh-core.jl:100; static: proposal.jl:66-72 */
             real lpy = orc_target_eval(t, y);          /* :103 */
             real loga = lpy - lp;                      /* :104-105, Hastings ratio of a zero-mean RW == 0 */

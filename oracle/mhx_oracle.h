@@ -101,6 +101,8 @@ typedef struct {
                              q(x | y) - q(y | x) of src/proposal.jl:58-64,190-192 is no longer zero */
     int is_static;        /* StaticProposal (src/proposal.jl:9-11,66-83): the candidate is a draw mu + L z that
                              ignores the current state; ratio = logpdf(p, x) - logpdf(p, y)            */
+    int normal_gen;       /* 0 Box-Muller; 1 (fp64 build only) the table ziggurat of spec 3.11 (MHX_FLAG_ZIGGURAT of the ABI):
+                             how the INIT and PROPOSAL stream bits of an RWMH run become standard normals */
 } orc_proposal;
 
 /* ---- schedule [upstream AbstractMCMC.mcmcsample, restated] ---- */
@@ -150,6 +152,13 @@ real orc_target_grad(const orc_target *t, const real *x, real *g, orc_logdensity
 int orc_mala(const orc_target *t, orc_logdensity_grad_fn user, real sigma2, const orc_schedule *s,
              uint64_t seed, uint64_t first_chain, int nchains, const real *init,
              real *samples, uint8_t *accepted, real *final_x, real *final_lp, uint32_t *accept_counts);
+
+/* the d standard normals of (seed, chain, step, stream) by generator `gen` (0 Box-Muller, 1 ziggurat: fp64 build only) */
+void orc_normals_gen(int gen, uint64_t seed, uint64_t chain, uint32_t step, uint32_t stream, int d, real *out);
+#if ORC_F64
+/* standard normal number n (0-based) of (seed, chain, step, stream) by the ziggurat generator (spec 3.11) */
+double orc_zig_normal(uint64_t seed, uint64_t chain, uint32_t step, uint32_t stream, uint32_t n);
+#endif
 
 /* Trace sink for tests (thread-local; all three optional, [n_samples][nchains], NULL switches off):
  * margin = smallest |logu - logalpha| over the transitions that led to a saved slot; logalpha / eta = RAM's state.logalpha

@@ -52,7 +52,7 @@ def _mk_types(cr):
                     ("nparams", C.c_int), ("fn", fn), ("fn_data", C.c_void_p), ("reduce_lanes", C.c_int)]
 
     class Proposal_(C.Structure):
-        _fields_ = [("kind", C.c_int), ("scale", cr), ("vec", C.c_void_p), ("mean", C.c_void_p), ("is_static", C.c_int)]
+        _fields_ = [("kind", C.c_int), ("scale", cr), ("vec", C.c_void_p), ("mean", C.c_void_p), ("is_static", C.c_int), ("normal_gen", C.c_int)]
 
     class RamCfg_(C.Structure):
         _fields_ = [("alpha", cr), ("gamma", cr), ("eig_lo", cr), ("eig_hi", cr)]
@@ -197,6 +197,13 @@ def normals(seed, chain, step, stream, d):
     return out
 
 
+def zig_normals(seed, chain, step, stream, d):
+    """d standard normals of (seed, chain, step, stream) by the ziggurat generator (fp64 build)"""
+    out = np.empty(d, dtype=np.float64)
+    lib().orc_normals_gen(1, C.c_uint64(seed), C.c_uint64(chain), C.c_uint32(step), C.c_uint32(stream), d, _fp(out))
+    return out
+
+
 def accept_logu(seed, chain, step):
     return lib().orc_accept_logu(seed, chain, step)
 
@@ -268,10 +275,13 @@ def unpack_lower(p, d):
 
 
 class Proposal:
-    def __init__(self, kind, scale=1.0, vec=None, mean=None, static=False):
+    def __init__(self, kind, scale=1.0, vec=None, mean=None, static=False, normal_gen=0):
+        """normal_gen: 0 Box-Muller, 1 the table ziggurat (fp64 build only; what MHX_FLAG_ZIGGURAT selects on the device)"""
+        if normal_gen and _DT != "f64":
+            raise ValueError("the ziggurat generator exists in the fp64 build only")
         self.vec = None if vec is None else np.ascontiguousarray(vec, dtype=real())
         self.mean = None if mean is None else np.ascontiguousarray(mean, dtype=real())
-        self.c = _T("Proposal")(kind, float(scale), _fp(self.vec), _fp(self.mean), 1 if static else 0)
+        self.c = _T("Proposal")(kind, float(scale), _fp(self.vec), _fp(self.mean), 1 if static else 0, int(normal_gen))
 
 
 def schedule(n_samples, discard_initial=0, thinning=1, num_warmup=0):

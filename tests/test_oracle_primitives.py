@@ -212,3 +212,77 @@ def test_c1_readme_model_runs_in_fp64(oracle64):
     assert r["samples"].dtype == np.float64
     mu, sig = r["samples"][:, 0, 0], r["samples"][:, 1, 0]
     assert abs(mu.mean() - data.mean()) < 0.1 and abs(sig.mean() - data.std()) < 0.15 and (sig >= 0).all()
+
+
+# ---- the ziggurat normal generator of the fp64 spec (3.11) -------------------------------------------------------------
+def _zig_table(path):
+    import re
+    txt = open(path).read()
+    n = int(re.search(r"#define MHX_ZIG_N (\d+)", txt).group(1))
+    body = txt[txt.index("#define MHX_ZIG_TABLE"):]
+    vals = [float.fromhex(t) for t in re.findall(r"-?0x[0-9a-f.]+p[+-]?\d+", body)]
+    r = float.fromhex(re.search(r"#define MHX_ZIG_R (\S+)", txt).group(1))
+    nri = float.fromhex(re.search(r"#define MHX_ZIG_NEG_RINV (\S+)", txt).group(1))
+    return n, np.array(vals), r, nri
+
+
+def test_ziggurat_table_is_equal_area_and_shared():
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dev = os.path.join(root, "advancedmh.jl_amd", "csrc", "mhx_zig_table.h")
+    orc = os.path.join(root, "oracle", "mhx_zig_table.h")
+    assert open(dev).read() == open(orc).read(), "device and oracle must read the same generated table (tools/gen_zig_table.py)"
+    n, x, r, nri = _zig_table(dev)
+    assert n == 1024 and x.size == n + 1 and x[1] == r and x[n] == 0.0 and abs(nri + 1.0 / r) < 1e-16
+    assert (np.diff(x) < 0).all()
+    mp = pytest.importorskip("mpmath")
+    mp.mp.dps = 40
+    f = lambda t: mp.exp(-mp.mpf(t) ** 2 / 2)
+    v = mp.mpf(r) * f(r) + mp.sqrt(mp.pi / 2) * mp.erfc(mp.mpf(r) / mp.sqrt(2))
+    assert abs(mp.mpf(x[0]) * f(r) / v - 1) < 1e-15                       # base strip: x[0] f(r) = v
+    for i in (1, 2, 17, 511, 1000, n - 1):                                  # layer i: x[i] (f(x[i+1]) - f(x[i])) = v
+        assert abs(mp.mpf(x[i]) * (f(x[i + 1]) - f(x[i])) / v - 1) < 1e-12, i
+
+
+def test_ziggurat_normals_are_standard(oracle64):
+    O = oracle64
+    x = np.concatenate([O.zig_normals(20260928, c, 5, O.STREAM_PROPOSAL, 500000) for c in range(8)])
+    n = x.size
+    assert abs(x.mean()) < 4.5 / np.sqrt(n) and abs(x.var() - 1) < 4.5 * np.sqrt(2.0 / n)
+    assert abs((x ** 3).mean()) < 4.5 * np.sqrt(15.0 / n) and abs((x ** 4).mean() - 3) < 4.5 * np.sqrt(96.0 / n)
+    assert stats.kstest(x[::3], "norm").pvalue > 1e-3
+    edges = stats.norm.ppf(np.linspace(0, 1, 257))
+    cnt, _ = np.histogram(x, edges)
+    chi2 = ((cnt - n / 256.0) ** 2 / (n / 256.0)).sum()
+    assert chi2 < stats.chi2.ppf(1 - 1e-4, 255), chi2
+    import os
+    _, _, r, _ = _zig_table(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "mhx_zig_table.h"))
+    for t in (1.0, 2.0, 3.0, r, 4.5):                                        # body, wedges and the tail beyond r
+        e = n * 2 * stats.norm.sf(t)
+        assert abs((np.abs(x) > t).sum() - e) < 4.5 * np.sqrt(e) + 1, (t, (np.abs(x) > t).sum(), e)
+    assert (x == 0).sum() <= 1 and np.isfinite(x).all()
+    # symmetric: flipping bit 11 of the low word flips the sign and nothing else -- the streams of +x and -x are the same
+    assert abs((x > 0).mean() - 0.5) < 4.5 * 0.5 / np.sqrt(n)
+
+
+def test_ziggurat_stream_layout(oracle64):
+    """Normal n of a step depends on Philox block n >> 1 of its stream (words 0,1 / 2,3) and, on rejection, on blocks
+    (n << 8 | t) of stream | 4 only: a prefix of a longer draw is the shorter draw, and rwmh with normal_gen = 1 uses exactly these."""
+    O = oracle64
+    a = O.zig_normals(3, 9, 2, O.STREAM_PROPOSAL, 40)
+    b = O.zig_normals(3, 9, 2, O.STREAM_PROPOSAL, 1000)
+    assert np.array_equal(a, b[:40])
+    d, s = 6, 0.5
+    r = O.rwmh(O.iso_gauss(d), O.Proposal(O.PROP_ISO, s, normal_gen=1), O.schedule(2), 3, 9, 1)
+    x0 = s * O.zig_normals(3, 9, 0, O.STREAM_INIT, d)                       # the initial draw fma(s, n, 0) == s * n (s = 1/2: exact)
+    assert np.array_equal(r["samples"][0, :d, 0], x0)
+    z = O.zig_normals(3, 9, 1, O.STREAM_PROPOSAL, d)
+    cand = x0 + s * z                                                       # s = 1/2: the product is exact, one rounding like the fma
+    got = r["samples"][1, :d, 0]
+    assert np.array_equal(got, cand if r["accepted"][1, 0] else x0)
+    with pytest.raises(ValueError):
+        O.set_dtype("f32")
+        try:
+            O.Proposal(O.PROP_ISO, s, normal_gen=1)
+        finally:
+            O.set_dtype("f64")
