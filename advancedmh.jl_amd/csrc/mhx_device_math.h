@@ -370,7 +370,8 @@ MHX_DEV double mhx_accept_logu(const mhx_philox_key& ks, mhx_u32 id_lo, mhx_u32 
 // form): MHX_ZIG_N equal-area layers under exp(-x^2/2), table x[0..N] (mhx_zig_table.h: x[0] = v/f(r), x[1] = r, x[N] = 0).
 // A normal takes 64 bits like a Box-Muller normal does -- Philox block p of (id, step, stream) serves normals 2p (words
 // x, y) and 2p + 1 (words z, w):
-//   r = hi:lo;  layer = lo mod N;  sign = bit 11 of lo;  u = (r >> 12) 2^-52 in [0, 1);  |x| = u x[layer]
+//   layer = lo mod N (bits 0..9);  sign = bit 31 of lo;  u = k 2^-52 in [0, 1) with the 52-bit k = (bits 11..30 of lo) : hi
+//   (laid out so that the double 1 + u is {0x3ff00000 | bits 11..30 of lo, hi}: no 64-bit shift);  |x| = u x[layer];
 //   accept at once when |x| < x[layer + 1]  (99.6 % of the draws: a table look-up, a multiply and a compare);
 // otherwise rejection attempts t = 1, 2, ... from Philox block (n << 8 | t) of stream | 4, n = index of the normal in
 // its step:  layer 0: the tail beyond r (Marsaglia) -- xx = -log(U1)/r, yy = -log(U2), accept r + xx iff 2 yy >= xx^2;
@@ -381,12 +382,23 @@ MHX_DEV double mhx_accept_logu(const mhx_philox_key& ks, mhx_u32 id_lo, mhx_u32 
 #define MHX_GEN_ZIGGURAT 1
 __device__ const double mhx_zig_x[MHX_ZIG_N + 1] = MHX_ZIG_TABLE;
 
+// the candidate's uniform: k 2^-52, k = (bits 11..30 of lo) : hi
+MHX_DEV double mhx_zig_u(const mhx_u32 hi, const mhx_u32 lo)
+{
+    const mhx_u32 top = 0x3ff00000u | ((lo >> 11) & 0xfffffu);
+    return mhx_u2d(((mhx_u64)top << 32) | hi) - 1.0;
+}
+// |x| with the candidate's sign (bit 31 of lo); ax >= 0
+MHX_DEV double mhx_zig_signed(const double ax, const mhx_u32 lo)
+{
+    const mhx_u64 b = mhx_d2u(ax);
+    return mhx_u2d(((mhx_u64)((mhx_u32)(b >> 32) | (lo & 0x80000000u)) << 32) | (mhx_u32)b);
+}
 MHX_DEV bool mhx_zig_try(const double* __restrict__ zt, const mhx_u32 hi, const mhx_u32 lo, double& x, mhx_u32& layer)
 {
     layer = lo & (mhx_u32)(MHX_ZIG_N - 1);
-    const double u = mhx_u01_half(hi, lo);
-    const double ax = u * zt[layer];
-    x = mhx_u2d(mhx_d2u(ax) ^ ((mhx_u64)((lo << 20) & 0x80000000u) << 32));     // bit 11 of lo is the sign
+    const double ax = mhx_zig_u(hi, lo) * zt[layer];
+    x = mhx_zig_signed(ax, lo);
     return ax < zt[layer + 1];
 }
 

@@ -379,22 +379,32 @@ MHX_DEV void mhx_zig_fixup(const mhx_philox_key& ks, const double* __restrict__ 
                            const mhx_u64 first_chain, const int nchains, const mhx_u32 step, const mhx_u32 stream)
 {
     constexpr int CPW = 64 / L;
-    const int cnt = __popcll(fm);
-    int incl = cnt;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); incl += lane >= off ? t : 0; }
-    const int base = incl - cnt;                                   // this lane's first entry
-    const int total = __shfl(incl, 63, 64);
+    // Queue positions without a prefix sum over the lanes: round k takes the k-th failure of every lane that has one; the
+    // lanes of a round are ranked by mbcnt over the round's ballot, the rounds follow each other in the queue.  (Nearly all
+    // lanes have 0 or 1 failure: one or two rounds.)  total = the number of candidates of this wave-step that failed.
+    int total = 0;
+    {
+        mhx_u64 f = fm;
+        for (;;) {
+            const mhx_u64 m = __ballot(f != 0ull);
+            if (m == 0ull) break;
+            total += __popcll(m);
+            f &= f - 1ull;
+        }
+    }
     for (int win = 0; win < total; win += 64) {                    // (one window unless > 64 candidates failed at once)
         mhx_u64 f = fm;
-        int e = base - win;
-        while (__ballot(f != 0ull)) {                              // wave-uniform: the largest number of failures of one lane
+        int base = -win;
+        for (;;) {
+            const mhx_u64 m = __ballot(f != 0ull);
+            if (m == 0ull) break;
             if (f != 0ull) {
+                const int e = base + (int)__builtin_amdgcn_mbcnt_hi((mhx_u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((mhx_u32)m, 0u));
                 const int sl = __ffsll((long long)f) - 1;
-                f &= f - 1ull;
                 if (e >= 0 && e < 64) zq[e] = (unsigned short)(lane | (sl << 6));
-                ++e;
             }
+            f &= f - 1ull;
+            base += __popcll(m);
         }
         MHX_WAVE_SYNC();
         const int nent = total - win < 64 ? total - win : 64;
@@ -514,29 +524,64 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
             // phase A: every slot's candidate by the fast path -- table look-up, multiply, compare -- into LDS; the slots that
             // left their rectangles are noted in `fm` and finished by mhx_zig_fixup before the candidate state is formed
             mhx_u64 fm = 0ull;
+            // Software pipeline over the lane's blocks: the table look-ups of block i are in flight while the Philox rounds of
+            // block i + 1 run (one wave per SIMD has no other wave to hide an LDS round trip behind): per block -- issue the 4
+            // look-ups (layers known since the previous stage), Philox of the next block, then consume.
+            typedef double mhx_d2 __attribute__((ext_vector_type(2)));
+            mhx_u32 khi[4], klo[4];                                 // the candidates' raw words (hi:lo) of the block in flight
+            {
+                const mhx_u32 b0 = (mhx_u32)l;
+                const mhx_u32x4 w0 = mhx_philox(ks, id_lo, id_hi, step, (MHX_STREAM_PROPOSAL << 28) | (2u * b0));
+                const mhx_u32x4 w1 = mhx_philox(ks, id_lo, id_hi, step, (MHX_STREAM_PROPOSAL << 28) | (2u * b0 + 1u));
+                khi[0] = w0.x; klo[0] = w0.y; khi[1] = w0.z; klo[1] = w0.w;
+                khi[2] = w1.x; klo[2] = w1.y; khi[3] = w1.z; klo[3] = w1.w;
+            }
 #pragma unroll
             for (int i = 0; i < NBL; ++i) {
-                const mhx_u32 b = (mhx_u32)(l + L * i);
+                mhx_d2 xe[4];                                       // x[layer], x[layer + 1] of the 4 candidates
 #pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
-                    const mhx_u32x4 w = mhx_philox(ks, id_lo, id_hi, step, (MHX_STREAM_PROPOSAL << 28) | (2u * b + (mhx_u32)pr));
-                    double n0, n1; mhx_u32 ly;
-                    bool f0 = !mhx_zig_try(zt, w.x, w.y, n0, ly);
-                    bool f1 = !mhx_zig_try(zt, w.z, w.w, n1, ly);
-                    if (i == NBL - 1) {                         // padding dimensions past the end of the vector need no normal
-                        f0 = f0 && (k_last + 2 * pr < d);
-                        f1 = f1 && (k_last + 2 * pr + 1 < d);
-                    }
-                    fm |= (f0 ? 1ull : 0ull) << (4 * i + 2 * pr);
-                    fm |= (f1 ? 1ull : 0ull) << (4 * i + 2 * pr + 1);
-                    typedef double mhx_d2 __attribute__((ext_vector_type(2)));
-                    mhx_d2 v2; v2.x = n0; v2.y = n1;
-                    *(mhx_d2*)(zn + (((i * 2 + pr) * 64 + lane) << 1)) = v2;
+                for (int j = 0; j < 4; ++j) {                       // (two 8-byte reads of one address: ds_read2_b64)
+                    const mhx_u32 ly = klo[j] & (mhx_u32)(MHX_ZIG_N - 1);
+                    xe[j].x = zt[ly]; xe[j].y = zt[ly + 1];
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                mhx_u32 nhi[4], nlo[4];
+                if (i + 1 < NBL) {
+                    const mhx_u32 b1 = (mhx_u32)(l + L * (i + 1));
+                    const mhx_u32x4 w0 = mhx_philox(ks, id_lo, id_hi, step, (MHX_STREAM_PROPOSAL << 28) | (2u * b1));
+                    const mhx_u32x4 w1 = mhx_philox(ks, id_lo, id_hi, step, (MHX_STREAM_PROPOSAL << 28) | (2u * b1 + 1u));
+                    nhi[0] = w0.x; nlo[0] = w0.y; nhi[1] = w0.z; nlo[1] = w0.w;
+                    nhi[2] = w1.x; nlo[2] = w1.y; nhi[3] = w1.z; nlo[3] = w1.w;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                double nn[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const double ax = mhx_zig_u(khi[j], klo[j]) * xe[j].x;
+                    nn[j] = mhx_zig_signed(ax, klo[j]);
+                    bool fail = !(ax < xe[j].y);
+                    if (i == NBL - 1) fail = fail && (k_last + j < d);   // padding dimensions past the end of the vector need no normal
+                    fm |= (fail ? 1ull : 0ull) << (4 * i + j);
+                }
+                mhx_d2 v2;
+                v2.x = nn[0]; v2.y = nn[1];
+                *(mhx_d2*)(zn + (((i * 2) * 64 + lane) << 1)) = v2;
+                v2.x = nn[2]; v2.y = nn[3];
+                *(mhx_d2*)(zn + (((i * 2 + 1) * 64 + lane) << 1)) = v2;
+                if (i + 1 < NBL) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { khi[j] = nhi[j]; klo[j] = nlo[j]; }
+                }
             }
             if (__ballot(fm != 0ull))
                 mhx_zig_fixup<L>(ks, zt, zn, zq, fm, lane, wave, a.first_chain, a.nchains, step, MHX_STREAM_PROPOSAL);
+            // the step's normals, final: all of them on their way to the registers the candidate will occupy (one wait)
+#pragma unroll
+            for (int i = 0; i < NBL; ++i) {
+                const mhx_d2 v0 = *(const mhx_d2*)(zn + (((i * 2) * 64 + lane) << 1));
+                const mhx_d2 v1 = *(const mhx_d2*)(zn + (((i * 2 + 1) * 64 + lane) << 1));
+                y[i][0] = v0.x; y[i][1] = v0.y; y[i][2] = v1.x; y[i][3] = v1.y;
+            }
         }
 #endif
 #pragma unroll
@@ -545,10 +590,7 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
             mhx_real n[4];
 #if MHX_REAL64
             if (ZIG) {
-                typedef double mhx_d2 __attribute__((ext_vector_type(2)));
-                const mhx_d2 v0 = *(const mhx_d2*)(zn + (((i * 2) * 64 + lane) << 1));
-                const mhx_d2 v1 = *(const mhx_d2*)(zn + (((i * 2 + 1) * 64 + lane) << 1));
-                n[0] = v0.x; n[1] = v0.y; n[2] = v1.x; n[3] = v1.y;
+                n[0] = y[i][0]; n[1] = y[i][1]; n[2] = y[i][2]; n[3] = y[i][3];
             } else
 #endif
             mhx_normal4(ks, id_lo, id_hi, step, MHX_STREAM_PROPOSAL, (mhx_u32)b, n);

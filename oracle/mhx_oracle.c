@@ -369,8 +369,8 @@ static void emcee_draws(uint64_t seed, uint64_t ens, int i, uint32_t sweep, uint
 /* ------------------------------------------------------------------------------------------ */
 /* normal generators.  gen 0: Box-Muller (orc_normals).  gen 1 (fp64 only): the table ZIGGURAT of spec 3.11 --
  * ORC_ZIG_N equal-area layers under exp(-x^2/2) (mhx_zig_table.h, generated by tools/gen_zig_table.py), 64 bits per normal:
- * Philox block p of (chain, step, stream) serves normals 2p (words 0,1) and 2p+1 (words 2,3); r = hi:lo, layer = lo mod N,
- * sign = bit 11 of lo, u = (r >> 12) 2^-52, |x| = u x[layer], accepted at once iff |x| < x[layer+1]; otherwise rejection
+ * Philox block p of (chain, step, stream) serves normals 2p (words hi = 0, lo = 1) and 2p+1 (words 2, 3); layer = lo mod N,
+ * sign = bit 31 of lo, u = k 2^-52 with k = (bits 11..30 of lo) : hi, |x| = u x[layer], accepted at once iff |x| < x[layer+1]; otherwise rejection
  * attempts t = 1, 2, ... from block (n << 8 | t) of stream | 4 (n = index of the normal in its step): layer 0 = Marsaglia's
  * tail beyond r, else the wedge test with the next candidate from the same block on rejection.
  * (What Julia's randn does with its own 256-layer table and Xoshiro bits, Random/src/normal.jl -- restated, not copied.) */
@@ -380,10 +380,11 @@ static const double zig_x[MHX_ZIG_N + 1] = MHX_ZIG_TABLE;
 
 static int zig_try(uint32_t hi, uint32_t lo, double *x, uint32_t *layer)
 {
-    *layer = lo & (uint32_t)(MHX_ZIG_N - 1);
-    const double u = orc_u01_half(hi, lo);
+    *layer = lo & (uint32_t)(MHX_ZIG_N - 1);                          /* bits 0..9 */
+    const uint64_t k = ((uint64_t)((lo >> 11) & 0xfffffu) << 32) | hi;   /* 52 bits: (bits 11..30 of lo) : hi */
+    const double u = (double)k * 0x1p-52;                              /* [0, 1), exact */
     const double ax = u * zig_x[*layer];
-    *x = (lo & 2048u) ? -ax : ax;
+    *x = (lo >> 31) ? -ax : ax;                                         /* bit 31 of lo is the sign */
     return ax < zig_x[*layer + 1];
 }
 
