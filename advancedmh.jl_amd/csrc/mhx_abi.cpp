@@ -153,6 +153,11 @@ extern "C" int mhx_ram_get_diag_range(mhx_run* r, void* diag_min, void* diag_max
     NEED(r, "mhx_ram_get_diag_range");
     return is64(r) ? mhx_f64::api_ram_get_diag_range(R64(r), D(diag_min), D(diag_max)) : mhx_f32::api_ram_get_diag_range(R32(r), F(diag_min), F(diag_max));
 }
+extern "C" int mhx_ram_get_step_stats(mhx_run* r, void* log_alpha, double* eta)
+{
+    NEED(r, "mhx_ram_get_step_stats");
+    return is64(r) ? mhx_f64::api_ram_get_step_stats(R64(r), D(log_alpha), eta) : mhx_f32::api_ram_get_step_stats(R32(r), F(log_alpha), eta);
+}
 extern "C" int mhx_ram_get_adapt_state(mhx_run* r, void* log_alpha, double* eta, uint8_t* isaccept, uint64_t* iteration)
 {
     NEED(r, "mhx_ram_get_adapt_state");

@@ -365,6 +365,8 @@ struct mhx_target : mhx_handle_hdr {
     mhx_real* dparams = nullptr;
     std::string user_src;        // MHX_TARGET_USER
     std::string user_key;        // hash of the source, for the JIT cache
+    int bandwidth = -1;          // CORR_GAUSS: largest r - c with A_rc != 0 (exact zeros only), -1 otherwise: a banded precision
+                                 // factor (Markov / autoregressive model) lets the row products skip the zeros
     ~mhx_target() { if (dparams) (void)hipFree(dparams); }
 };
 
@@ -435,6 +437,15 @@ int api_target_builtin(mhx_ctx* ctx, int kind, int dim, const mhx_real* params, 
     t->kind = kind;
     t->dim = dim;
     t->cst = target_const(kind, dim, params);
+    if (kind == MHX_TARGET_CORR_GAUSS) {
+        int bw = 0;
+        size_t off = 0;
+        for (int r = 0; r < dim; ++r) {
+            for (int c = 0; c < r - bw; ++c) if (params[off + c] != MHX_R(0.0)) { bw = r - c; break; }
+            off += (size_t)r + 1;
+        }
+        t->bandwidth = bw;
+    }
     int rc = target_upload(t.get(), params, nparams);
     if (rc) return rc;
     *out = t.release();
@@ -580,6 +591,11 @@ struct mhx_run : mhx_handle_hdr {
     mhx_real* d_eta = nullptr;                      // adaptation step sizes of the current launch
     mhx_real* d_loga = nullptr;                     // [n] log acceptance ratio of each chain's latest transition
     double last_eta = 0.0;                          // step size of the latest adapting transition (state.η; 0 before any)
+    mhx_real* d_rec_loga = nullptr;                 // [n_saved][n] logα of every recorded transition of the last sampling call
+    mhx_real* rec_loga_view = nullptr;              // where slot 0 of the current launches lands in it (slab-wise calls)
+    size_t rec_loga_cap = 0;
+    std::vector<double> rec_eta;                    // [n_saved] state.η after every recorded transition
+    int64_t rec_n = 0;                              // recorded transitions held by the two above
     size_t eta_cap = 0;
     // state
     mhx_real *d_x = nullptr, *d_lp = nullptr, *d_ybuf = nullptr;
@@ -604,6 +620,7 @@ struct mhx_run : mhx_handle_hdr {
     int normal_gen = MHX_GEN_BOX_MULLER; // how stream bits become standard normals (MHX_FLAG_ZIGGURAT: the table ziggurat, fp64)
     size_t coop_lds = 0;                 // dynamic LDS of the cooperative kernel (ziggurat: layer table + the step's normals)
     int coop_L = 1;                      // lanes per chain (reduction shape of the separable targets)
+    int emcee_band = -1;                 // bandwidth of the precision factor the cooperative stretch move exploits (-1: dense form)
     int coop_waves = MHX_EMCEE_COOP_WAVES;  // waves per block of the cooperative stretch move (tuning knob MHX_EMCEE_WAVES)
     int variant = 0;
     void (*reg_fn)(const mhx_rwmh_args, const mhx_real*, const mhx_real*) = nullptr;
@@ -613,7 +630,7 @@ struct mhx_run : mhx_handle_hdr {
     ~mhx_run()
     {
         void* ptrs[] = {d_pvec, d_S, d_Ssel, d_status, d_dmin, d_dmax, d_eta, d_x, d_lp, d_ybuf,
-                        d_acc, d_last, d_acc_total, d_samples, d_accepted, d_mom_mean, d_mom_m2, d_gx, d_gy, d_z, d_pmean, d_qx, d_xw, d_loga, d_mfma_img};
+                        d_acc, d_last, d_acc_total, d_samples, d_accepted, d_mom_mean, d_mom_m2, d_gx, d_gy, d_z, d_pmean, d_qx, d_xw, d_loga, d_mfma_img, d_rec_loga};
         for (void* p : ptrs) if (p) (void)hipFree(p);
     }
 };
@@ -671,6 +688,7 @@ static int rwmh_whiten(mhx_run* r)
 #define MHX_REG_MAX_DIM (MHX_REAL64 ? 80 : 160)
 #define MHX_REG_MAX_DIM_DENSE (MHX_REAL64 ? 48 : 96)
 #define MHX_DENSE_COOP_MAX_DIM 256
+#define MHX_EMCEE_MAX_BAND 8                 // widest band the band form of the cooperative stretch move is specialised for
 #define MHX_LDS_PER_BLOCK 163840             // gfx950: 160 KB of LDS, all of it available to one block
 // lanes per chain of the dense cooperative kernel: at most 12.5 rows of a factor per lane
 static int dense_coop_lanes(int d) { int L = 2; while ((MHX_REAL64 ? 4 : 2) * d > 25 * L && L < 64) L *= 2; return L; }
@@ -1026,6 +1044,7 @@ static int emcee_sync_state(mhx_run* r, int to_abi);
 static int emcee_advance(mhx_run* r, uint64_t nsteps, uint32_t save_next, int save_slot, int thinning);
 static int ram_init(mhx_run* r, const mhx_real* init);
 static int ram_advance(mhx_run* r, uint64_t nsteps, uint64_t n_adapt, uint32_t save_next, int save_slot, int thinning);
+static int ram_prepare_step_stats(mhx_run* r, const mhx_schedule* s, uint64_t n_adapt);
 static int mala_init(mhx_run* r, const mhx_real* init);
 static int mala_eval_state(mhx_run* r, int reset_counts);
 static int mala_advance(mhx_run* r, uint64_t nsteps, uint32_t save_next, int save_slot, int thinning);
@@ -1206,6 +1225,7 @@ int api_run_sample(mhx_run* r, const mhx_schedule* s, int save_samples)
     r->stats.reduce_lanes = r->coop_L;
     r->stats.dtype = r->dtype;
     r->stats.normal_gen = r->normal_gen;
+    r->stats.factor_band = r->kind == RUN_EMCEE ? r->emcee_band : -1;
     auto total_accepts = [&](unsigned long long* out) -> int { return run_total_accepts(r, out); };
     unsigned long long acc_before = 0;
     { int rc0 = total_accepts(&acc_before); if (rc0) return rc0; }
@@ -1214,6 +1234,8 @@ int api_run_sample(mhx_run* r, const mhx_schedule* s, int save_samples)
     int save_slot = 0;
     r->n_saved = 0;
     r->moments_mode = false;
+    r->rec_n = 0;
+    r->rec_loga_view = nullptr;
     if (save_samples == MHX_SAVE_MOMENTS) {
         // running moments instead of a sample tensor
         if (r->kind != RUN_RWMH || (r->variant != 0 && r->variant != 3 && r->variant != 4))
@@ -1253,6 +1275,7 @@ int api_run_sample(mhx_run* r, const mhx_schedule* s, int save_samples)
         rc = ensure_buffer((void**)&r->d_accepted, &r->accepted_cap, N * n);
         if (rc) return rc;
         r->n_saved = s->n_samples;
+        if (r->kind == RUN_RAM) { rc = ram_prepare_step_stats(r, s, nA); if (rc) return rc; }
         if (s->discard_initial == 0) {
             // sample 1 is the current state itself (test/runtests.jl:203-213: chain[1].params == initial_params)
             // an ensemble on the register / cooperative kernels lives in its walker-major copy: bring d_x up to date

@@ -350,25 +350,69 @@ MHX_DEV mhx_real mhx_dense_rows_sq(const mhx_e4* Ash4, const mhx_e4* yrow4, cons
     return q;
 }
 
+// A BANDED factor (A_rc == 0 for c < r - BW: the precision factor of a Markov / autoregressive Gaussian; BW = 1 for
+// Sigma_ij = rho^|i-j|): lane l's rows l, l+L, ... need BW + 1 products each instead of r + 1.  The band entries come straight
+// from the packed factor (index-clamped loads, issued at the top of the kernel), y from the wave's LDS row; the chain
+// w_r = fma(A_rc, y_c, w_r) over c = r-BW .. r starts from +0 like the dense one, whose skipped terms fma(0, y_c, w) leave w
+// unchanged bit for bit (y finite) -- same value, no factor image in LDS and no block barrier.
+template <int D, int L, int BW>
+MHX_DEV void mhx_band_load(const mhx_real* __restrict__ A, const int l, mhx_real (&ab)[mhx_emcee_geom<D, L>::NK][BW + 1])
+{
+#pragma unroll
+    for (int m = 0; m < mhx_emcee_geom<D, L>::NK; ++m) {
+        const int r = l + L * m;
+        const int base = r < D ? r * (r + 1) / 2 : 0;
+#pragma unroll
+        for (int t = 0; t <= BW; ++t) {
+            const int c = r - BW + t;
+            const bool in = r < D && c >= 0;
+            const mhx_real a0 = A[in ? base + c : 0];
+            ab[m][t] = in ? a0 : MHX_R(0.0);
+        }
+    }
+}
+template <int D, int L, int BW>
+MHX_DEV mhx_real mhx_band_rows_sq(const mhx_real (&ab)[mhx_emcee_geom<D, L>::NK][BW + 1], const mhx_real* yrow, const int l)
+{
+    mhx_real q = MHX_R(0.0);
+#pragma unroll
+    for (int m = 0; m < mhx_emcee_geom<D, L>::NK; ++m) {
+        const int r = l + L * m;
+        mhx_real w = MHX_R(0.0);
+#pragma unroll
+        for (int t = 0; t <= BW; ++t) {
+            const int c = r - BW + t;
+            const mhx_real yc = yrow[(r < D && c >= 0) ? c : 0];
+            w = mhx_fma(ab[m][t], yc, w);
+        }
+        q = r < D ? mhx_fma(w, w, q) : q;
+    }
+    return q;
+}
+
 // timing probe: MHX_EMCEE_PROBE = n (hiprtc define, tools only) ends the half-step after phase n
 #ifndef MHX_EMCEE_PROBE
 #define MHX_EMCEE_PROBE 0
 #endif
 #define MHX_PROBE(n, val) do { if (MHX_EMCEE_PROBE == (n)) { if ((val) == MHX_R(12345.678)) a.lp[0] = (val); return; } } while (0)
 
-template <int D, int L>
+// BW < 0: dense factor (image in LDS, one block barrier); BW >= 0: a factor of bandwidth BW (no image, no barrier)
+template <int D, int L, int BW = -1>
 MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const mhx_real* __restrict__ A, mhx_real* ysh_all, mhx_e4* Ash4)
 {
     typedef mhx_emcee_geom<D, L> GEO;
     constexpr int CPW = 64 / L;                  // walkers per wave
     constexpr int NK = GEO::NK;                  // dimensions (and rows) per lane
     constexpr int DP4 = GEO::DP4;
+    constexpr bool BAND = BW >= 0;
     // The factor goes to LDS once per block (a lane's row reads are scattered: from LDS, not L2); its loads fly
     // together with the walker rows below: the launch is a chain of memory latencies.
     // (images of more than 16 float4 per thread are filled in batches further down instead)
-    constexpr bool ONE_BATCH = NK * GEO::maxit() <= 16;
+    constexpr bool ONE_BATCH = !BAND && NK * GEO::maxit() <= 16;
     mhx_e4 areg[ONE_BATCH ? NK : 1][GEO::maxit()];
     if constexpr (ONE_BATCH) mhx_dense_image_load<D, L>(A, areg);
+    mhx_real ab[BAND ? NK : 1][BAND ? BW + 1 : 1];
+    if constexpr (BAND) mhx_band_load<D, L, BW>(A, (int)((threadIdx.x & 63) / CPW), ab);
     const int wave = threadIdx.x >> 6;
     mhx_real* ysh = ysh_all + wave * (CPW * DP4);
     const int W = a.nwalkers;
@@ -422,11 +466,17 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const mhx_real* __rest
         if (q4 < DP4 / 4) ((mhx_e4*)yrow)[q4] = ysl[m];
     }
     MHX_PROBE(3, ysl[0].x);                                                  // + the two rows, the move
-    if constexpr (ONE_BATCH) mhx_dense_image_store<D, L>(areg, Ash4);
-    else mhx_dense_image_fill<D, L>(A, Ash4);
-    __syncthreads();
-    MHX_PROBE(4, ysl[0].x + ((const mhx_real*)Ash4)[threadIdx.x]);           // + the factor image in LDS
-    mhx_real q = mhx_dense_rows_sq<D, L>(Ash4, (const mhx_e4*)yrow, l);
+    mhx_real q;
+    if constexpr (BAND) {
+        MHX_WAVE_SYNC();                                                     // the candidate rows of a wave are its own
+        q = mhx_band_rows_sq<D, L, BW>(ab, yrow, l);
+    } else {
+        if constexpr (ONE_BATCH) mhx_dense_image_store<D, L>(areg, Ash4);
+        else mhx_dense_image_fill<D, L>(A, Ash4);
+        __syncthreads();
+        MHX_PROBE(4, ysl[0].x + ((const mhx_real*)Ash4)[threadIdx.x]);       // + the factor image in LDS
+        q = mhx_dense_rows_sq<D, L>(Ash4, (const mhx_e4*)yrow, l);
+    }
 #pragma unroll
     for (int off = 1; off < L; off <<= 1) q = q + __shfl_xor(q, off * CPW, 64);
     const mhx_real lpy = mhx_fma(-MHX_R(0.5), q, a.tconst);
@@ -542,7 +592,10 @@ mhx_jit_emcee_half(const mhx_emcee_args a, const mhx_real* __restrict__ tparams)
     // dynamic LDS (up to 160 KB per block on gfx950): [candidate rows][factor image]
     extern __shared__ mhx_e4 mhx_emcee_lds[];
     constexpr int YS4 = MHX_EMCEE_COOP_WAVES * (64 / MHX_JIT_L) * mhx_emcee_geom<MHX_JIT_DIM, MHX_JIT_L>::DP4 / 4;
-    mhx_emcee_coop_body<MHX_JIT_DIM, MHX_JIT_L>(a, tparams, (mhx_real*)mhx_emcee_lds, mhx_emcee_lds + YS4);
+#ifndef MHX_JIT_BW
+#define MHX_JIT_BW -1
+#endif
+    mhx_emcee_coop_body<MHX_JIT_DIM, MHX_JIT_L, MHX_JIT_BW>(a, tparams, (mhx_real*)mhx_emcee_lds, mhx_emcee_lds + YS4);
 #else
     mhx_emcee_half_body<MHX_JIT_DIM, MHX_JIT_TK>(a, tparams);
 #endif

@@ -38,6 +38,8 @@ struct mhx_ram_args {
     mhx_real* dmax;
     mhx_real* loga;              // [nchains] log acceptance ratio min(lp' - lp, 0) of each chain's latest transition
                               // (RobustAdaptiveMetropolisState.logα, RAM.jl:99-114, :141-147)
+    mhx_real* rec_loga;          // [slots][ld] or null: the log acceptance ratio of every RECORDED transition (the state.logα a
+                              // callback would have seen after that step, test/RobustAdaptiveMetropolis.jl:11-28)
     const mhx_real* eta;         // [nsteps] adaptation step sizes iteration^-gamma of this launch
     const mhx_real* acol;        // CORR_GAUSS target: inv(chol(Sigma)) packed column-major lower
     mhx_u64 seed;
@@ -505,6 +507,7 @@ MHX_DEV void mhx_ram_body(const mhx_ram_args& a, const mhx_real* __restrict__ tp
                 if (tg == 0) {
                     rowp[(long)d * ld] = lp;
                     a.accepted[slot * ld + c] = acc ? 1 : 0;
+                    if (a.rec_loga) a.rec_loga[slot * ld + c] = loga;
                 }
             }
             save_next += (mhx_u32)a.thinning;

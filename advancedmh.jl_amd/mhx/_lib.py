@@ -17,6 +17,7 @@ FLAG_NO_JIT, FLAG_GENERIC = 1, 2
 MHX_FLAG_STATIC_PROPOSAL = 4
 FLAG_EMCEE_SEQUENTIAL = 8
 FLAG_ZIGGURAT = 16
+FLAG_DENSE_FACTOR = 32
 
 
 class MhxError(RuntimeError):
@@ -66,7 +67,7 @@ class MalaCfg(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("transitions", C.c_uint64), ("accepted", C.c_uint64), ("kernel_ms", C.c_double),
                 ("wall_ms", C.c_double), ("kernel_variant", C.c_int32), ("launches", C.c_int32),
-                ("reduce_lanes", C.c_int32), ("dtype", C.c_int32), ("normal_gen", C.c_int32), ("reserved_", C.c_int32)]
+                ("reduce_lanes", C.c_int32), ("dtype", C.c_int32), ("normal_gen", C.c_int32), ("factor_band", C.c_int32)]
 
 
 class DiagCfg(C.Structure):
@@ -84,7 +85,7 @@ EXPORTS = [
     "mhx_ctx_dtype", "mhx_ctx_device", "mhx_ram_set_factor_all", "mhx_ram_get_adapt_state", "mhx_emcee_exchange_plan", "mhx_emcee_exchange_pack",
     "mhx_emcee_exchange_unpack", "mhx_comm_unique_id", "mhx_comm_init", "mhx_comm_destroy", "mhx_comm_rank",
     "mhx_comm_allreduce_sum", "mhx_comm_slice", "mhx_comm_allgather_walkers",
-    "mhx_run_sample_to_host", "mhx_host_alloc", "mhx_host_free", "mhx_ctx_jit_counts",
+    "mhx_ram_get_step_stats", "mhx_run_sample_to_host", "mhx_host_alloc", "mhx_host_free", "mhx_ctx_jit_counts",
 ]
 
 MHX_F32, MHX_F64 = 0, 1
@@ -137,6 +138,7 @@ def lib():
         L.mhx_ram_get_factor.argtypes = [vp, rp, u8p]
         L.mhx_ram_get_diag_range.argtypes = [vp, rp, rp]
         L.mhx_ram_get_adapt_state.argtypes = [vp, rp, dp, u8p, C.POINTER(C.c_uint64)]
+        L.mhx_ram_get_step_stats.argtypes = [vp, rp, dp]
         L.mhx_run_init.argtypes = [vp, rp]
         L.mhx_run_sample.argtypes = [vp, C.POINTER(Schedule), C.c_int]
         L.mhx_run_get_samples.argtypes = [vp, rp, u8p]

@@ -142,15 +142,27 @@ class IsoGaussian(_TargetSpec):
         self.dim = int(d)
 
 
+def precision_factor(Sigma):
+    """A = inv(chol(Sigma)) in float64 (log-density -1/2 |A x|^2 + log det A), with the STRUCTURAL zeros of a sparse factor
+    restored: entries below 256 eps max|A| -- the round-off the inversion itself leaves where the exact factor is zero (a
+    Markov / autoregressive / banded-precision model: Sigma_ij = rho^|i-j| has a bidiagonal A, computed off-band entries
+    ~1e-15) -- are set to exactly 0.  The engine detects the bandwidth of an exactly banded factor and skips the zeros (same
+    bits: fma(0, y, w) == w), so this is what lets a banded model run at its own cost instead of the dense d(d+1)/2."""
+    A = np.linalg.inv(np.linalg.cholesky(np.asarray(Sigma, dtype=np.float64)))
+    A = np.tril(A)
+    A[np.abs(A) <= 256.0 * np.finfo(np.float64).eps * np.abs(A).max()] = 0.0
+    return A
+
+
 class CorrGaussian(_TargetSpec):
-    """logpdf(MvNormal(zeros(d), Sigma), x); stored as inv(chol(Sigma)) packed lower."""
+    """logpdf(MvNormal(zeros(d), Sigma), x); stored as inv(chol(Sigma)) packed lower (precision_factor)."""
     kind = L.TARGET_CORR_GAUSS
 
     def __init__(self, Sigma):
         Sigma = np.asarray(Sigma, dtype=np.float64)
         self.dim = Sigma.shape[0]
         try:
-            A = np.linalg.inv(np.linalg.cholesky(Sigma))
+            A = precision_factor(Sigma)
         except np.linalg.LinAlgError as e:
             raise L.PosDefException(L.MHX_ENOTPD, "CorrGaussian: Sigma is not positive definite") from e
         self.params = pack_lower(A)
@@ -519,6 +531,7 @@ class Run:
         s = L.Schedule(n_samples, discard_initial, thinning, num_warmup)
         mode = 2 if (isinstance(save, str) and save == "moments") or (save is not True and save == 2) else (1 if save else 0)
         L.check(L.lib().mhx_run_sample(self.h, C.byref(s), mode))
+        self._last_n = n_samples if mode == 1 else 0
 
     def sample_to_host(self, n_samples, discard_initial=0, thinning=1, num_warmup=0, want_accepted=True, out=None,
                        out_accepted=None, slab_samples=0, pinned=True):
@@ -538,6 +551,7 @@ class Run:
         elif acc is not None and (acc.shape != (n_samples, self.n) or acc.dtype != np.uint8 or not acc.flags.c_contiguous):
             raise L.ArgumentError(L.MHX_EINVAL, "sample_to_host: out_accepted must be a C-contiguous uint8 array of shape (N, nchains)")
         L.check(L.lib().mhx_run_sample_to_host(self.h, C.byref(s), L.fptr(out), L.u8ptr(acc), slab_samples))
+        self._last_n = n_samples
         return out, acc
 
     def samples(self, want_accepted=True):
@@ -586,12 +600,23 @@ class Run:
         L.check(L.lib().mhx_ram_get_adapt_state(self.h, L.rptr(la), C.byref(eta), L.u8ptr(acc), C.byref(it)))
         return dict(logα=la, η=eta.value, iteration=int(it.value), isaccept=acc.astype(bool))
 
+    def step_stats(self, n_samples=None):
+        """RobustAdaptiveMetropolis: the sampler state after EVERY recorded step of the last sampling call -- what the
+        reference's callback reads off `state` (test/RobustAdaptiveMetropolis.jl:11-28): dict(logα [N][nchains], η [N]);
+        mean(exp(logα)) is the acceptance rate the adaptation steers to α (RAM.jl:141-147).  isaccept = the accepted tensor."""
+        if n_samples is None:
+            n_samples = getattr(self, "_last_n", 0)
+        la = np.empty((n_samples, self.n), dtype=self.real)
+        eta = np.empty(n_samples, dtype=np.float64)
+        L.check(L.lib().mhx_ram_get_step_stats(self.h, L.rptr(la), eta.ctypes.data_as(C.POINTER(C.c_double))))
+        return {"logα": la, "η": eta, "logalpha": la, "eta": eta}
+
     def stats(self):
         st = L.Stats()
         L.check(L.lib().mhx_run_stats(self.h, C.byref(st)))
         return dict(transitions=st.transitions, accepted=st.accepted, kernel_ms=st.kernel_ms, wall_ms=st.wall_ms,
                     kernel_variant=st.kernel_variant, launches=st.launches, reduce_lanes=st.reduce_lanes,
-                    dtype="f64" if st.dtype == L.MHX_F64 else "f32", normal_gen=st.normal_gen)
+                    dtype="f64" if st.dtype == L.MHX_F64 else "f32", normal_gen=st.normal_gen, factor_band=st.factor_band)
 
     def diagnostics(self, max_lag=0, ess_chains=256, split=False):
         """Sums for R-hat / between-chain ESS (all chains) and, if max_lag > 0, the Geyer ESS from the multi-chain

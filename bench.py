@@ -212,10 +212,15 @@ class C3:
     def __init__(self, args, dtype):
         self.d, self.W, self.inner, self.dtype = args.dim or 50, args.chains or 16384, args.inner or 500, dtype
         self.lanes = args.lanes
+        self.rotated = getattr(args, "c3_rotated", False)
 
     def build(self, mhx, ctx, rank):
         d = self.d
+        import numpy as np
         self.Sig = sigma_ar1(d, 0.9)
+        if self.rotated:                                   # "also a dense-rotated variant" -- no structural zeros in the factor
+            Q, _ = np.linalg.qr(np.random.default_rng(50).normal(size=(d, d)))
+            self.Sig = Q @ self.Sig @ Q.T
         model = mhx.DensityModel(mhx.CorrGaussian(self.Sig))
         spl = mhx.Ensemble(self.W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I)))
         self.run = mhx.Run(model, spl, seed=3, first_chain=rank, ctx=ctx, reduce_lanes=self.lanes)   # one ensemble per GPU (replicas)
@@ -239,8 +244,13 @@ class C3:
         return "per move %d d + %d (x_i, x_j, x_i', lp) + record %d(d+1)+1" % (3 * B, 2 * B, B)
 
     def describe(self):
-        return ("emcee Ensemble(StretchProposal a=2), %d-dim Gaussian Sigma_ij = 0.9^|i-j|, %d walkers (one ensemble per GPU), "
-                "%d sweeps per launch, every sweep recorded; parallel half-split sweep" % (self.d, self.W, self.inner))
+        band = self.run.stats().get("factor_band", -1) if hasattr(self, "run") else -1
+        return ("emcee Ensemble(StretchProposal a=2), %d-dim Gaussian %s, %d walkers (one ensemble per GPU), "
+                "%d sweeps per launch, every sweep recorded; parallel half-split sweep; %s" % (
+                    self.d, "Sigma = Q (0.9^|i-j|) Q^T, Q a seeded rotation (dense precision factor)" if self.rotated else "Sigma_ij = 0.9^|i-j|",
+                    self.W, self.inner,
+                    "the precision factor inv(chol Sigma) is banded (bandwidth %d, detected): the row products skip its structural zeros" % band
+                    if band >= 0 else "dense precision factor: d(d+1)/2 products per move"))
 
     def cpu_baseline(self, O, target_seconds):
         import numpy as np
@@ -484,13 +494,15 @@ def other_configs(mhx, ctx, args, barrier):
     roofline of the dominant kernel and a CPU baseline (2 s samples) for C3, C4 as specified, C4 from a start that moves, and
     C5's per-GPU shard.  Fewer steps than the headline (C4 runs 0.26 s per step): every figure says how many."""
     import copy
-    plan = [("c3", "c3", {}, 10, 10), ("c4", "c4", {}, 3, 2), ("c4_moving", "c4", {"c4_moving": True}, 3, 2), ("c5", "c5", {}, 10, 10)]
+    plan = [("c3", "c3", {}, 10, 10), ("c3_rotated", "c3", {"c3_rotated": True}, 10, 10), ("c4", "c4", {}, 3, 2),
+            ("c4_moving", "c4", {"c4_moving": True}, 3, 2), ("c5", "c5", {}, 10, 10)]
     res = {}
     for key, name, over, steps, spin in plan:
         try:
             a = copy.copy(args)
             a.inner = a.chains = a.dim = a.lanes = 0
             a.c4_moving = False
+            a.c3_rotated = False
             for k, v in over.items():
                 setattr(a, k, v)
             w = WORKLOADS[name](a, args.dtype)
@@ -565,6 +577,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=0, help="lanes per chain (0 = engine's choice)")
     ap.add_argument("--c2-literal", action="store_true", help="c2: proposal N(0, I) as the config text reads (acceptance ~ 0 at d = 100) "
                     "instead of the tuned 2.38/sqrt(d)")
+    ap.add_argument("--c3-rotated", action="store_true", help="c3: the dense-rotated variant Sigma = Q (0.9^|i-j|) Q^T (no banded factor)")
     ap.add_argument("--c4-moving", action="store_true", help="c4: random start and S0 = 2.38/sqrt(d) I instead of x0 = 0, S0 = I")
     ap.add_argument("--normal-gen", choices=["auto", "ziggurat", "box-muller"], default="auto",
                     help="c2 / c5: how the RWMH kernel turns stream bits into standard normals (auto: ziggurat in fp64, Box-Muller in fp32)")

@@ -141,6 +141,8 @@ typedef struct {
                                 from the Box-Muller chain of the same seed (both target the same law); the value in effect is
                                 reported in mhx_stats.normal_gen and fixes the chain bit for bit.  MHX_EINVAL where the run's
                                 kernel has no ziggurat form (fp32, dense factors, user targets, register / generic kernels). */
+#define MHX_FLAG_DENSE_FACTOR 32 /* Ensemble runs: treat the precision factor of a dense-Gaussian target as dense even when it is
+                                   banded (exact zeros below a band of width <= 8 are otherwise detected and skipped -- same bits) */
 #define MHX_FLAG_STATIC_PROPOSAL 4 /* RWMH runs only: the proposal is a StaticProposal (src/proposal.jl:9-11,66-83) --
                                       the candidate is a draw mean + L z that ignores the current state (independence
                                       sampler) and the ratio is logpdf(p, x) - logpdf(p, y) */
@@ -197,6 +199,13 @@ int mhx_ram_get_diag_range(mhx_run *run, void *diag_min, void *diag_max);
  * exp(log_alpha), :141-147); *eta = the adaptation step size iteration^-gamma of the latest warm-up transition (0 before
  * any, :211); isaccept [nchains]; *iteration = 1 + transitions so far.  Any pointer may be NULL. */
 int mhx_ram_get_adapt_state(mhx_run *run, void *log_alpha, double *eta, uint8_t *isaccept, uint64_t *iteration);
+/* The same statistics for EVERY recorded step of the last mhx_run_sample / mhx_run_sample_to_host that kept samples -- what a
+ * `callback(rng, model, sampler, sample, state, i)` reads off `state` after each saved step in the reference
+ * (test/RobustAdaptiveMetropolis.jl:11-28,55): log_alpha [n_samples][nchains] reals = state.logα after the recorded transition
+ * (min(lp' - lp, 0): average exp(log_alpha) for the acceptance rate, RAM.jl:141-147; sample 1 of an un-discarded call carries
+ * the state's own value, 0 right after init, :211), eta [n_samples] doubles = state.η (iteration^-gamma of the latest adapting
+ * transition at or before that step; the same for every chain).  state.isaccept is the `accepted` tensor.  Either may be NULL. */
+int mhx_ram_get_step_stats(mhx_run *run, void *log_alpha, double *eta);
 
 /* ---------------------------------------------------------------------------------------------
  * Metropolis-adjusted Langevin.  Replaces MALA (src/MALA.jl:1-11), GradientTransition (:14-19) and its step
@@ -275,7 +284,8 @@ typedef struct {
     int32_t reduce_lanes;      /* lanes per chain in effect (1 unless a cooperative kernel runs) */
     int32_t dtype;             /* mhx_dtype of the run's context */
     int32_t normal_gen;        /* 0 Box-Muller, 1 ziggurat (MHX_FLAG_ZIGGURAT): how the run turns stream bits into normals */
-    int32_t reserved_;
+    int32_t factor_band;       /* Ensemble runs on a dense-Gaussian target: the bandwidth of the precision factor the kernel exploits
+                                  (0 = diagonal, 1 = bidiagonal: an AR(1) / Markov model, ...), -1 = none (dense form, other samplers) */
 } mhx_stats;
 int mhx_run_stats(mhx_run *run, mhx_stats *out);
 

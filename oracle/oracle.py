@@ -253,9 +253,12 @@ def iso_gauss(d, reduce_lanes=0):
 
 
 def corr_gauss_from_cov(Sigma, reduce_lanes=0):
-    """params = inv(chol(Sigma)) packed lower row-major, computed in float64 then rounded."""
+    """params = inv(chol(Sigma)) packed lower row-major, computed in float64 then rounded; entries at the round-off level of
+    the inversion (<= 256 eps max|A|: the structural zeros of a banded factor) are exact zeros -- the same preparation as the
+    host mirror's precision_factor (the checker must be handed the same numbers as the device)."""
     Sigma = np.asarray(Sigma, dtype=np.float64)
-    A = np.linalg.inv(np.linalg.cholesky(Sigma))
+    A = np.tril(np.linalg.inv(np.linalg.cholesky(Sigma)))
+    A[np.abs(A) <= 256.0 * np.finfo(np.float64).eps * np.abs(A).max()] = 0.0
     return Target(TARGET_CORR_GAUSS, Sigma.shape[0], pack_lower(A), reduce_lanes=reduce_lanes)
 
 

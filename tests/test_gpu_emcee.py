@@ -291,3 +291,43 @@ def test_sharded_ensemble_over_rccl_single_rank(mhx, oracle, real):
     _same(x, ref["final_x"], "final x")
     _same(lp, ref["final_lp"], "final lp")
     run.close()
+
+
+def _banded_sigma(d, bw, seed):
+    """Sigma = inv(A^T A) for a random lower factor A of bandwidth bw (a Gaussian Markov model of order bw)"""
+    rng = np.random.default_rng(seed)
+    A = np.zeros((d, d))
+    for r in range(d):
+        A[r, r] = 1.0 + rng.uniform(0.0, 1.0)
+        for c in range(max(0, r - bw), r):
+            A[r, c] = rng.normal() * 0.4
+    return np.linalg.inv(A.T @ A)
+
+
+@pytest.mark.parametrize("d,W,bw", [(50, 256, 1), (12, 130, 2), (33, 192, 5), (64, 128, 8), (20, 96, 0)])
+def test_banded_precision_factor_is_detected_and_bit_identical(mhx, oracle, real, d, W, bw):
+    """A Gaussian Markov target (banded inv(chol Sigma)): the cooperative stretch move skips the structural zeros -- the same
+    chain, bit for bit, as the dense form (MHX_FLAG_DENSE_FACTOR) and as the oracle's full row products."""
+    Sig = cases.sigma_ar1(d, 0.9) if bw == 1 else (_banded_sigma(d, bw, d) if bw else np.diag(np.linspace(0.5, 2.0, d)))
+    N = 7
+    init = cases.emcee_init(d, W, 5)
+    model = mhx.DensityModel(mhx.CorrGaussian(Sig))
+    spl = mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I)))
+    band = mhx.sample(model, spl, N, seed=9, initial_params=init)
+    dense = mhx.sample(model, spl, N, seed=9, initial_params=init, flags=mhx.FLAG_DENSE_FACTOR, reduce_lanes=band.stats["reduce_lanes"])
+    assert band.stats["factor_band"] == bw and dense.stats["factor_band"] == -1 and band.stats["kernel_variant"] == 4
+    _same(band.value, dense.value, "band form vs dense form")
+    _same(band.accepted, dense.accepted, "accepted")
+    ref = oracle.emcee(oracle.corr_gauss_from_cov(Sig, reduce_lanes=band.stats["reduce_lanes"]), 2.0, 1, oracle.schedule(N), 9, 0, W, init)
+    _same(band.value, ref["samples"], "band form vs oracle")
+    _same(band.accepted, ref["accepted"], "accepted vs oracle")
+
+
+def test_a_dense_factor_keeps_the_dense_form(mhx):
+    d, W = 24, 128
+    rng = np.random.default_rng(3)
+    Q, _ = np.linalg.qr(rng.normal(size=(d, d)))
+    Sig = Q @ cases.sigma_ar1(d, 0.9) @ Q.T                       # the rotated variant: no structural zeros
+    chain = mhx.sample(mhx.DensityModel(mhx.CorrGaussian(Sig)), mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I))),
+                       4, seed=1)
+    assert chain.stats["factor_band"] == -1

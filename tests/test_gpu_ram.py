@@ -212,3 +212,34 @@ def test_ram_refused_factor_leaves_the_run_untouched(mhx, oracle, real):
     assert np.array_equal(cases.bits(got), cases.bits(ref["samples"]))
     assert np.array_equal(cases.bits(run.factor()[0]), cases.bits(ref["S"]))
     run.close()
+
+
+@pytest.mark.parametrize("sched,slab", [((24, 0, 1, 16), 0), ((12, 5, 3, 20), 0), ((9, 5, 2, 12), -2), ((30, 0, 1, 30), 7)])
+def test_per_step_sampler_statistics(mhx, oracle, real, sched, slab):
+    """state.logα / state.η / state.isaccept after EVERY recorded step (what the reference's callback sees,
+    test/RobustAdaptiveMetropolis.jl:11-28,55), through mhx_run_sample and the slab-streamed mhx_run_sample_to_host."""
+    d, C = 6, 40
+    Sig = cases.sigma_ar1(d, 0.7)
+    N, di, th, nw = sched
+    run = mhx.Run(mhx.DensityModel(mhx.CorrGaussian(Sig)), mhx.RobustAdaptiveMetropolis(), nchains=C, seed=31, first_chain=2)
+    run.init(np.zeros(d))
+    if slab == 0:
+        run.sample(N, di, th, nw)
+        val, acc = run.samples()
+    else:
+        val, acc = run.sample_to_host(N, di, th, nw, slab_samples=slab)
+    st = run.step_stats()
+    ref = oracle.traced(oracle.ram, oracle.corr_gauss_from_cov(Sig), oracle.schedule(N, di, th, nw), 31, 2, C, init=np.zeros((d, C)))
+    _same(val, ref["samples"], "samples")
+    _same(st["logα"], ref["logalpha"], "log alpha of every recorded step")
+    assert np.array_equal(st["η"], ref["eta"][:, 0].astype(np.float64)) and (ref["eta"] == ref["eta"][:, :1]).all()
+    # the use the reference's comment names (RAM.jl:141-147): the mean acceptance probability
+    assert 0.0 < np.exp(st["logα"][1:]).mean() <= 1.0
+    # a second call continues: its first entry (discard_initial = 0) is the state's own logα, η carries over
+    run.sample(3, 0, 1, 0)
+    st2 = run.step_stats()
+    _same(st2["logα"][0], st["logα"][-1], "the state's logα opens the next call")
+    assert st2["η"][0] == st["η"][-1] and (st2["η"] == st["η"][-1]).all()
+    with pytest.raises(mhx.MhxError):
+        run.sample(4, 0, 1, 0, save=False)
+        run.step_stats()
