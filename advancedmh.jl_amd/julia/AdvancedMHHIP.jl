@@ -1,4 +1,4 @@
-# AdvancedMHHIP.jl -- thin `ccall` layer over libmhx.so (include/mhx.h, ABI 0.2) that plugs the MI355X engine
+# AdvancedMHHIP.jl -- thin `ccall` layer over libmhx.so (include/mhx.h, ABI 0.3) that plugs the MI355X engine
 # into AdvancedMH.jl through AbstractMCMC's ensemble dispatch:
 #
 #     chain = sample(model, RWMH(MvNormal(zeros(100), 0.0566I)), MCMCHIP(), 1_000, 65_536;
@@ -50,6 +50,7 @@ struct RamCfg
 end
 const MHX_FLAG_STATIC_PROPOSAL = Int32(4)
 const MHX_FLAG_EMCEE_SEQUENTIAL = Int32(8)
+const MHX_FLAG_ZIGGURAT = Int32(16)
 
 """
     LangevinProposal(σ²)
@@ -62,19 +63,21 @@ struct LangevinProposal; sigma2::Float64; end
 
 # --- the ensemble tag AbstractMCMC dispatches on -------------------------------------------------
 """
-    MCMCHIP(; device = 0, first_chain = 0, T = Float64, sequential_ensemble = false)
+    MCMCHIP(; device = 0, first_chain = 0, T = Float64, sequential_ensemble = false, ziggurat = false)
 
 Run all chains of `sample(model, sampler, MCMCHIP(), N, nchains)` on one MI355X.  `T` is the arithmetic of the engine:
 `Float64` (what AdvancedMH.jl computes in) or `Float32`.  With several processes (one per GPU) give each its shard via
 `first_chain`: chains carry global ids in their RNG counters, so the union of the shards is the unsharded run.
 `sequential_ensemble = true` runs `Ensemble` with the reference's own Gauss-Seidel sweep (src/emcee.jl:39-58) instead
-of the parallel half-split.
+of the parallel half-split.  `ziggurat = true` (Float64, RWMH on a separable catalogue target): standard normals by the
+engine's table ziggurat instead of Box-Muller (MHX_FLAG_ZIGGURAT -- what Julia's own `randn` is; a third faster).
 """
 Base.@kwdef struct MCMCHIP <: AbstractMCMC.AbstractMCMCEnsemble
     device::Int = 0
     first_chain::Int = 0
     T::DataType = Float64
     sequential_ensemble::Bool = false
+    ziggurat::Bool = false
 end
 dtype_code(::Type{Float32}) = Cint(0)
 dtype_code(::Type{Float64}) = Cint(1)
@@ -90,6 +93,20 @@ struct HipSource <: DeviceLogDensity; src::String; dim::Int; data::Vector{Float6
 
 packlower(::Type{T}, M) where {T} = T[M[i, j] for i in axes(M, 1) for j in 1:i]            # row-major packed lower
 
+"""
+    precision_factor(Σ) -> A = inv(chol(Σ)) with the structural zeros of a sparse factor restored
+
+Entries below 256 eps max|A| -- the round-off the inversion leaves where the exact factor is zero (Σ_ij = ρ^|i-j| has a
+bidiagonal A; computed off-band entries are ~1e-15) -- become exact zeros: the engine detects an exactly banded factor and
+skips the zeros (same bits).  The Python mirror (`mhx.precision_factor`) does the same.
+"""
+function precision_factor(Σ)
+    A = Matrix(inv(cholesky(Symmetric(Matrix{Float64}(Σ))).L))
+    tol = 256 * eps(Float64) * maximum(abs, A)
+    A[abs.(A) .<= tol] .= 0.0
+    return LowerTriangular(A)
+end
+
 function target(::Type{T}, ctx::Ptr{Cvoid}, t::DeviceLogDensity) where {T}
     h = Ref{Ptr{Cvoid}}(C_NULL)
     if t isa HipSource
@@ -100,7 +117,7 @@ function target(::Type{T}, ctx::Ptr{Cvoid}, t::DeviceLogDensity) where {T}
         return h[], t.dim
     end
     kind, dim, p = t isa IsoGaussian ? (0, t.dim, T[]) :
-                   t isa CorrGaussian ? (1, size(t.Σ, 1), packlower(T, inv(cholesky(Symmetric(t.Σ)).L))) :
+                   t isa CorrGaussian ? (1, size(t.Σ, 1), packlower(T, precision_factor(t.Σ))) :
                    t isa IIDNormal ? (2, 2, T.(t.data)) :
                    t isa Banana ? (3, t.dim, T[t.b]) : (4, t.dim, T[])
     GC.@preserve p check(ccall((:mhx_target_builtin, libmhx), Cint,
@@ -150,6 +167,7 @@ function AbstractMCMC.sample(
             kind, scale, vec = proposal_spec(T, prop.proposal)
             μ = T.(proposal_mean(prop.proposal))
             flags = prop isa AdvancedMH.StaticProposal ? MHX_FLAG_STATIC_PROPOSAL : Int32(0)
+            ens.ziggurat && (flags |= MHX_FLAG_ZIGGURAT)
             GC.@preserve vec μ begin
                 cfg = RwmhCfg(d, n, seed, ens.first_chain, kind, scale, ptr_or_null(vec), flags,
                               all(iszero, μ) ? Ptr{Cvoid}(C_NULL) : Ptr{Cvoid}(pointer(μ)), 0)
@@ -208,12 +226,18 @@ function AbstractMCMC.sample(
             GC.@preserve x0 check(ccall((:mhx_run_init, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), run[], x0))
         end
         sched = Schedule(N, discard_initial, thinning, num_warmup)
-        check(ccall((:mhx_run_sample, libmhx), Cint, (Ptr{Cvoid}, Ref{Schedule}, Cint), run[], sched, 1))
-
+        # ONE call: the schedule runs while finished slabs of samples stream into `raw` on a second HIP stream
+        # (mhx_run_sample_to_host registers the Julia array for the duration of the call; 0 = default slab size).
         # C order [N][d+1][n] with the chain fastest == Julia Array{T,3}(n, d+1, N)
         raw = Array{T,3}(undef, n, d + 1, N)
-        GC.@preserve raw check(ccall((:mhx_run_get_samples, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{UInt8}),
-                                     run[], raw, C_NULL))
+        GC.@preserve raw check(ccall((:mhx_run_sample_to_host, libmhx), Cint, (Ptr{Cvoid}, Ref{Schedule}, Ptr{Cvoid}, Ptr{UInt8}, Int32),
+                                     run[], sched, raw, C_NULL, 0))
+        if sampler isa AdvancedMH.RobustAdaptiveMetropolis && haskey(kwargs, :sampler_stats)
+            # what a callback reads off `state` after every saved step (test/RobustAdaptiveMetropolis.jl:11-28): logα (N x n), η (N)
+            logα = Matrix{T}(undef, n, N); η = Vector{Float64}(undef, N)
+            GC.@preserve logα η check(ccall((:mhx_ram_get_step_stats, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}), run[], logα, η))
+            kwargs[:sampler_stats][] = (logα = permutedims(logα), η = η)
+        end
         vals = Float64.(permutedims(raw, (3, 2, 1)))                         # (iterations, params..lp, chains)
         names = ismissing(param_names) ? [Symbol(:param_, i) for i in 1:d] : Symbol.(param_names)
         chain_type === MCMCChains.Chains || return vals

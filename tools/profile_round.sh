@@ -9,9 +9,9 @@ OUT=$REPO/gpurun_out/${TAG}_${CFG}_${DT}
 mkdir -p $OUT
 export TMPDIR=/tmp
 # bench.py spins the GPU up with 30 untimed launches before the warm-up, so the traced launches run at the steady clock
-BENCH="python $REPO/bench.py --config $CFG --dtype $DT --steps 10 --warmup 2 --no-cpu-baseline --no-second-dtype --no-ess $*"
+BENCH="python $REPO/bench.py --config $CFG --dtype $DT --steps 10 --warmup 2 --no-cpu-baseline --no-second-dtype --no-ess --no-other-configs --no-e2e $*"
 cd /tmp
-echo "== bench (unprofiled)"; python $REPO/bench.py --config $CFG --dtype $DT --no-cpu-baseline --no-second-dtype "$@" 2>/dev/null | tail -1 > $OUT/bench.json; cut -c1-400 $OUT/bench.json
+echo "== bench (unprofiled)"; python $REPO/bench.py --config $CFG --dtype $DT --no-cpu-baseline --no-second-dtype --no-other-configs --no-e2e "$@" 2>/dev/null | tail -1 > $OUT/bench.json; cut -c1-400 $OUT/bench.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktrace -o bench -- $BENCH > $OUT/ktrace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- $BENCH > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- $BENCH > $OUT/pmc_write.log 2>&1
