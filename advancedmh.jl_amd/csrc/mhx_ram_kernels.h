@@ -85,7 +85,11 @@ typedef mhx_real mhx_f4 __attribute__((ext_vector_type(4)));
 // it runs off the end of the ring: a column read is one per-column address plus compile-time offsets.
 // The factor of a dense Gaussian target is the same for every chain: the wave streams it ONCE through
 // the same LDS seen as a single ring (64 lanes x 16 B pieces) and all its chains read it from there.
-#define MHX_RAM_NV(R) ((R) <= 8 ? 2 : 4)
+#ifndef MHX_RAM_NV4_R
+#define MHX_RAM_NV4_R 99  // tuning knob (fp64): rows per lane from which a chunk is 4 pieces deep instead of 2. Measured at C4 (R = 4):
+                         // 8 KB in flight per wave but 22.8 KB of LDS (7 waves per CU instead of 8) -> 1.12e7 against 1.29e7 steps/s: off
+#endif
+#define MHX_RAM_NV(R) ((R) <= 8 ? ((MHX_REAL64 && (R) >= MHX_RAM_NV4_R) ? 4 : 2) : 4)
 #define MHX_RAM_CHF(G, R) (MHX_RAM_NV(R) * (G) * 4)
 #define MHX_RAM_RING(G, R) (2 * MHX_RAM_CHF(G, R))
 #define MHX_RAM_MIRF(G, R) ((G) * (R))

@@ -71,6 +71,14 @@ def sigma_illcond(d, kappa=1e3, seed=7):
     return (Q * lam) @ Q.T
 
 
+def host_cores():
+    """the cores this process may run on (a container's cpuset can be smaller than os.cpu_count())"""
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except Exception:
+        return os.cpu_count() or 1
+
+
 def threads_rate(work, cores, target_seconds):
     """work(thread_index, nchains) on `cores` threads, chains per thread sized to ~target_seconds of wall time;
     returns (chains in total, seconds)"""
@@ -145,7 +153,7 @@ class C2:
         t0 = time.perf_counter()
         O.rwmh(tgt, prop, O.schedule(101), 0xC0FFEE, 0, 8, save=True)
         rate1 = 800 / (time.perf_counter() - t0)
-        cores = os.cpu_count() or 1
+        cores = host_cores()
         n, dt = threads_rate(work, cores, target_seconds)
         return n * inner, dt, cores, "%d chains x %d transitions of the same d=%d workload; single thread %.3g steps/s" % (n, inner, self.d, rate1)
 
@@ -200,7 +208,7 @@ class C5(C2):
 
         def work(i, nchains):
             O.rwmh(tgt, prop, O.schedule(1, inner), 5, i * nchains, nchains, save=False)
-        cores = os.cpu_count() or 1
+        cores = host_cores()
         n, dt = threads_rate(work, cores, target_seconds)
         return n * inner, dt, cores, "%d chains x %d transitions of the same d=%d funnel" % (n, inner, self.d)
 
@@ -323,7 +331,7 @@ class C4:
         t0 = time.perf_counter()
         O.ram(tgt, O.schedule(1, 20, 1, 20), 4, 0, 1, init=init1, save=False)
         rate1 = 20 / (time.perf_counter() - t0)
-        cores = os.cpu_count() or 1
+        cores = host_cores()
         n, dt = threads_rate(work, cores, target_seconds)
         return n * inner, dt, cores, "%d chains x %d adapting transitions of the same d=%d workload; single thread %.3g steps/s" % (n, inner, d, rate1)
 
