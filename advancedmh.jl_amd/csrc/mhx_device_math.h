@@ -388,6 +388,13 @@ MHX_DEV double mhx_zig_u(const mhx_u32 hi, const mhx_u32 lo)
     const mhx_u32 top = 0x3ff00000u | ((lo >> 11) & 0xfffffu);
     return mhx_u2d(((mhx_u64)top << 32) | hi) - 1.0;
 }
+// u x_l in ONE operation: with m = 1 + u (exact) the product m x_l - x_l == u x_l exactly, and the fma rounds it once --
+// the same bits as the rounded product mhx_zig_u(hi, lo) * xl of the spec, without the subtraction
+MHX_DEV double mhx_zig_ax(const mhx_u32 hi, const mhx_u32 lo, const double xl)
+{
+    const mhx_u32 top = 0x3ff00000u | ((lo >> 11) & 0xfffffu);
+    return mhx_fma(mhx_u2d(((mhx_u64)top << 32) | hi), xl, -xl);
+}
 // |x| with the candidate's sign (bit 31 of lo); ax >= 0
 MHX_DEV double mhx_zig_signed(const double ax, const mhx_u32 lo)
 {
@@ -397,7 +404,7 @@ MHX_DEV double mhx_zig_signed(const double ax, const mhx_u32 lo)
 MHX_DEV bool mhx_zig_try(const double* __restrict__ zt, const mhx_u32 hi, const mhx_u32 lo, double& x, mhx_u32& layer)
 {
     layer = lo & (mhx_u32)(MHX_ZIG_N - 1);
-    const double ax = mhx_zig_u(hi, lo) * zt[layer];
+    const double ax = mhx_zig_ax(hi, lo, zt[layer]);
     x = mhx_zig_signed(ax, lo);
     return ax < zt[layer + 1];
 }

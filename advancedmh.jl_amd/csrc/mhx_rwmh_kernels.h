@@ -557,7 +557,7 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
                 double nn[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const double ax = mhx_zig_u(khi[j], klo[j]) * xe[j].x;
+                    const double ax = mhx_zig_ax(khi[j], klo[j], xe[j].x);
                     nn[j] = mhx_zig_signed(ax, klo[j]);
                     bool fail = !(ax < xe[j].y);
                     if (i == NBL - 1) fail = fail && (k_last + j < d);   // padding dimensions past the end of the vector need no normal

@@ -132,6 +132,67 @@ function normal_at(seed::UInt64, id::UInt64, step::UInt32, stream::UInt32, k::In
     return iseven(k) ? n0 : n1
 end
 
+# ---- the ZIGGURAT generator of the fp64 spec (DESIGN.md section 3.11; oracle/mhx_oracle.c: zig_try, orc_zig_normal) -------
+include(joinpath(@__DIR__, "zig_table.jl"))          # ZIG_N, ZIG_R, ZIG_NEG_RINV, ZIG_X (generated; same literals as mhx_zig_table.h)
+
+"exp of the spec: n = rint(x log2e), Cody-Waite with the 32-bit LN2_HI, degree-11 polynomial, two exact scalings"
+function spec_exp(x::Float64)
+    isnan(x) && return x
+    x > 0x1.62e42fefa39efp+9 && return Inf
+    x < -0x1.74910d52d3052p+9 && return 0.0
+    n = round(x * 0x1.71547652b82fep+0, RoundNearest)
+    r = fma(n, -LN2_HI, x)
+    r = fma(n, -LN2_LO, r)
+    p = 0x1.61bfaa228dde5p-33
+    p = fma(p, r, 0x1.1f7f2776cfaf2p-29)
+    p = fma(p, r, 0x1.ae642c82e33d5p-26)
+    p = fma(p, r, 0x1.27e4d41966f2fp-22)
+    p = fma(p, r, 0x1.71de3a5aa7bb7p-19)
+    p = fma(p, r, 0x1.a01a01a9e991bp-16)
+    p = fma(p, r, 0x1.a01a01a0196acp-13)
+    p = fma(p, r, 0x1.6c16c16c15a68p-10)
+    p = fma(p, r, 0x1.1111111111111p-7)
+    p = fma(p, r, 0x1.5555555555557p-5)
+    p = fma(p, r, 0x1.5555555555555p-3)
+    p = fma(p, r, 0.5)
+    y = fma(r * r, p, r) + 1.0
+    ni = Int(n); n1 = div(ni, 2); n2 = ni - n1            # div truncates toward zero like C's `/`
+    y = y * reinterpret(Float64, UInt64(n1 + 1023) << 52)
+    return y * reinterpret(Float64, UInt64(n2 + 1023) << 52)
+end
+
+"one candidate from the words (hi, lo): (accepted at once?, x, layer)"
+function zig_try(hi::UInt32, lo::UInt32)
+    layer = Int(lo & UInt32(ZIG_N - 1))                                          # bits 0..9
+    k = (UInt64((lo >> 11) & 0x000fffff) << 32) | UInt64(hi)                     # 52 bits: (bits 11..30 of lo) : hi
+    ax = (Float64(k) * 0x1p-52) * ZIG_X[layer + 1]
+    x = (lo >> 31) == 1 ? -ax : ax                                               # bit 31 of lo is the sign
+    return ax < ZIG_X[layer + 2], x, layer
+end
+
+"standard normal number n (0-based) of (seed, id, step, stream) by the ziggurat: attempt 0 from block n >> 1, rejections from stream | 4"
+function zig_normal_at(seed::UInt64, id::UInt64, step::UInt32, stream::UInt32, n::Int)
+    w = block(seed, id, step, stream, UInt32(n >> 1))
+    ok, x, layer = isodd(n) ? zig_try(w[3], w[4]) : zig_try(w[1], w[2])
+    ok && return x
+    t = UInt32(1)
+    while true
+        v = block(seed, id, step, stream | UInt32(4), (UInt32(n) << 8) | (t & 0x000000ff))
+        if layer == 0                                                            # Marsaglia's tail beyond r
+            xx = spec_log(u01_open(v[1], v[2])) * ZIG_NEG_RINV
+            yy = -spec_log(u01_open(v[3], v[4]))
+            yy + yy >= xx * xx && return signbit(x) ? -(ZIG_R + xx) : (ZIG_R + xx)
+        else                                                                     # the wedge of layer `layer`
+            xl, xl1, xsq = ZIG_X[layer + 1], ZIG_X[layer + 2], x * x
+            f0 = spec_exp(-0.5 * (xl * xl - xsq)); f1 = spec_exp(-0.5 * (xl1 * xl1 - xsq))
+            fma(u01_half(v[3], v[4]), f0 - f1, f1) < 1.0 && return x
+            ok, x, layer = zig_try(v[1], v[2])
+            ok && return x
+        end
+        t += UInt32(1)
+    end
+end
+
 "log of the accept uniform of `step` (one Philox block serves 2 consecutive steps)"
 function accept_logu(seed::UInt64, id::UInt64, step::UInt32)
     w = block(seed, id, step >> 1, STREAM_ACCEPT, UInt32(0))
@@ -140,13 +201,14 @@ end
 
 # ---- the scripted RNG ----------------------------------------------------------------------------------------------
 """
-    PhiloxStream(seed, id; dim, nwalkers = 0, initial_draw = true)
+    PhiloxStream(seed, id; dim, nwalkers = 0, initial_draw = true, ziggurat = false)
 
 One chain (`nwalkers == 0`: RWMH / MALA / RobustAdaptiveMetropolis -- per transition `dim` calls of `randn`, then one
 `randexp`) or one ensemble (`nwalkers > 0`: per move `rand(sampler of 1:W-1)`, `rand()`, `randexp()`, walkers in order,
 src/emcee.jl:39-58).  `id` is the global chain id (the ensemble id).  With `initial_draw` the first `dim` (ensemble:
 `nwalkers * dim`) normals come from stream INIT (the initial `propose`, src/mh-core.jl:83, src/emcee.jl:29-34,
-…RAM.jl:193); pass `initial_draw = false` when `initial_params` is given.
+…RAM.jl:193); pass `initial_draw = false` when `initial_params` is given.  `ziggurat = true`: a chain's normals by the
+engine's ziggurat generator (MHX_FLAG_ZIGGURAT; RWMH runs) instead of Box-Muller.
 """
 mutable struct PhiloxStream <: Random.AbstractRNG
     seed::UInt64
@@ -156,12 +218,13 @@ mutable struct PhiloxStream <: Random.AbstractRNG
     step::UInt32        # transition (sweep) being served; 0 = the initial draws
     k::Int              # chain: normals served in this step; ensemble, step 0: normals served so far
     walker::Int         # ensemble: 0-based walker whose move is being served
+    ziggurat::Bool      # chain: normals by the ziggurat generator
 end
-function PhiloxStream(seed::Integer, id::Integer; dim::Integer, nwalkers::Integer = 0, initial_draw::Bool = true)
-    return PhiloxStream(UInt64(seed), UInt64(id), Int(dim), Int(nwalkers), initial_draw ? UInt32(0) : UInt32(1), 0, 0)
+function PhiloxStream(seed::Integer, id::Integer; dim::Integer, nwalkers::Integer = 0, initial_draw::Bool = true, ziggurat::Bool = false)
+    return PhiloxStream(UInt64(seed), UInt64(id), Int(dim), Int(nwalkers), initial_draw ? UInt32(0) : UInt32(1), 0, 0, ziggurat)
 end
 
-Base.copy(r::PhiloxStream) = PhiloxStream(r.seed, r.id, r.dim, r.nwalkers, r.step, r.k, r.walker)
+Base.copy(r::PhiloxStream) = PhiloxStream(r.seed, r.id, r.dim, r.nwalkers, r.step, r.k, r.walker, r.ziggurat)
 Random.seed!(r::PhiloxStream, args...) = r                                   # the stream is fixed by (seed, id)
 
 function Random.randn(r::PhiloxStream, ::Type{Float64} = Float64)
@@ -173,7 +236,7 @@ function Random.randn(r::PhiloxStream, ::Type{Float64} = Float64)
         r.k == r.nwalkers * r.dim && (r.step = UInt32(1); r.k = 0)
         return z
     end
-    z = normal_at(r.seed, r.id, r.step, r.step == 0 ? STREAM_INIT : STREAM_PROPOSAL, r.k)
+    z = (r.ziggurat ? zig_normal_at : normal_at)(r.seed, r.id, r.step, r.step == 0 ? STREAM_INIT : STREAM_PROPOSAL, r.k)
     r.k += 1
     if r.step == 0 && r.k == r.dim                                           # the initial draw is complete
         r.step = UInt32(1); r.k = 0

@@ -66,8 +66,8 @@ LogDensityProblems.logdensity(m::GaussianLDP, x) = logpdf(MvNormal(zeros(size(m.
 LogDensityProblems.logdensity_and_gradient(m::GaussianLDP, x) = (LogDensityProblems.logdensity(m, x), -(m.P * x))
 
 # one chain of sampler `spl`, global id `id`: (N, d+1) samples and N accept flags
-function run_chain(model, spl, N, seed, id, d; initial_params = nothing, kw...)
-    rng = PhiloxStream(seed, id; dim = d, initial_draw = initial_params === nothing)
+function run_chain(model, spl, N, seed, id, d; initial_params = nothing, ziggurat = false, kw...)
+    rng = PhiloxStream(seed, id; dim = d, initial_draw = initial_params === nothing, ziggurat = ziggurat)
     ts = sample(rng, model, spl, N; chain_type = Any, progress = false, initial_params = initial_params, kw...)
     S = Matrix{Float64}(undef, N, d + 1)
     acc = Vector{UInt8}(undef, N)
@@ -101,6 +101,8 @@ run_chains("rwmh_banana", DensityModel(banana(5, 0.03)), RWMH([Normal(0, 2.0), N
            24, 14, 0, 7, 5)
 run_chains("rwmh_given_start", DensityModel(iso_gauss(3)), RWMH(MvNormal(zeros(3), 0.7^2 * I)), 40, 9, 0, 4, 3;
            initial_params = [0.5, -1.0, 0.25])
+# the engine's ziggurat normals (MHX_FLAG_ZIGGURAT): 64 chains x 48 transitions x 8 normals = 2.5e4 draws, ~100 through the slow paths
+run_chains("rwmh_iso_ziggurat", DensityModel(iso_gauss(8)), RWMH(MvNormal(zeros(8), 0.6^2 * I)), 48, 15, 7, 64, 8; ziggurat = true)
 
 # ---- RobustAdaptiveMetropolis (src/RobustAdaptiveMetropolis.jl:123-278) ------------------------------------------------
 # the model is a LogDensityProblems object, NOT a DensityModel (see the dispatch notes above)

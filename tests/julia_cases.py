@@ -30,6 +30,10 @@ def _rwmh_given_start(O):
     return O.traced(O.rwmh, O.iso_gauss(3), O.Proposal(O.PROP_ISO, 0.7), O.schedule(40), 9, 0, 4, init=init)
 
 
+def _rwmh_iso_ziggurat(O):
+    return O.traced(O.rwmh, O.iso_gauss(8), O.Proposal(O.PROP_ISO, 0.6, normal_gen=1), O.schedule(48), 15, 7, 64)
+
+
 def _ram(O):
     d = 4
     return O.traced(O.ram, O.corr_gauss_from_cov(cases.sigma_ar1(d, 0.7)), O.schedule(24, 0, 1, 16), 31, 2, 6, init=np.zeros((d, 6)))
@@ -60,6 +64,6 @@ def _emcee_seq(O):
 
 JULIA_CASES = {
     "rwmh_iso": _rwmh_iso, "rwmh_dense_corr": _rwmh_dense_corr, "rwmh_funnel": _rwmh_funnel, "rwmh_banana": _rwmh_banana,
-    "rwmh_given_start": _rwmh_given_start, "ram": _ram, "ram_random_start": _ram_random_start, "ram_bounds": _ram_bounds,
+    "rwmh_given_start": _rwmh_given_start, "rwmh_iso_ziggurat": _rwmh_iso_ziggurat, "ram": _ram, "ram_random_start": _ram_random_start, "ram_bounds": _ram_bounds,
     "mala_iso": _mala_iso, "mala_corr": _mala_corr, "emcee_seq": _emcee_seq,
 }

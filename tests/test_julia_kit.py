@@ -188,3 +188,43 @@ def test_case_numbers_agree_between_julia_and_python(oracle):
             assert sched[0] == N and sched[1] == want_di and sched[2] == int(kw.get("thinning", 1)) and sched[3] == int(kw.get("num_warmup", 0)), (name, sched, kw)
     finally:
         oracle.set_dtype(old)
+
+
+def test_exp_literals_and_ziggurat_table_match_the_oracle(sources):
+    """spec_exp (used by the ziggurat's wedge test) against orc_exp, and tests/julia/zig_table.jl against the generated header
+    the device and the oracle compile (one generator writes all three: tools/gen_zig_table.py)."""
+    jl, c64, _ = sources
+    jf = _floats(_jl_function(jl, "spec_exp"))
+    cf = _floats(_c_function(c64, "double orc_exp(double x)"))
+    log2e = float.fromhex(re.search(r"#define LOG2E\s+(\S+)", c64).group(1))     # a macro on the C side, a literal in the Julia function
+    assert jf.count(log2e) == 1
+    jf.remove(log2e)
+    assert len(jf) >= 13 and jf == cf, ([v.hex() for v in jf], [v.hex() for v in cf])
+    for needle in ("fma(n, -LN2_HI, x)", "fma(n, -LN2_LO, r)", "fma(r * r, p, r) + 1.0", "div(ni, 2)"):
+        assert needle in _jl_function(jl, "spec_exp"), needle
+    hdr = open(os.path.join(HERE, "..", "oracle", "mhx_zig_table.h")).read()
+    jt = open(os.path.join(HERE, "julia", "zig_table.jl")).read()
+    hx = [float.fromhex(t) for t in HEXF.findall(hdr[hdr.index("#define MHX_ZIG_TABLE"):])]
+    jx = [float.fromhex(t) for t in HEXF.findall(jt[jt.index("const ZIG_X"):])]
+    assert len(hx) == 1025 and hx == jx
+    for name_h, name_j in (("MHX_ZIG_R", "ZIG_R"), ("MHX_ZIG_NEG_RINV", "ZIG_NEG_RINV")):
+        a = float.fromhex(re.search(r"#define %s (\S+)" % name_h, hdr).group(1))
+        b = float.fromhex(re.search(r"const %s = (\S+)" % name_j, jt).group(1))
+        assert a == b, name_h
+    assert int(re.search(r"const ZIG_N = (\d+)", jt).group(1)) == int(re.search(r"#define MHX_ZIG_N (\d+)", hdr).group(1)) == 1024
+
+
+def test_julia_ziggurat_follows_the_oracle_bit_layout(sources):
+    jl, _, c = sources
+    body = _jl_function(jl, "zig_try")
+    # layer = bits 0..9, mantissa = (bits 11..30 of lo) : hi, sign = bit 31 of lo -- the same expressions as oracle zig_try
+    assert "lo & UInt32(ZIG_N - 1)" in body and "(lo >> 11) & 0x000fffff" in body and "(lo >> 31) == 1" in body
+    czt = c[c.index("static int zig_try("):c.index("double orc_zig_normal(")]
+    assert "(lo >> 11) & 0xfffffu" in czt and "(lo >> 31)" in czt and "lo & (uint32_t)(MHX_ZIG_N - 1)" in czt
+    jz = _jl_function(jl, "zig_normal_at")
+    cz = c[c.index("double orc_zig_normal("):c.index("static void normals_gen(")]
+    # retry stream and block numbering, tail and wedge tests
+    assert "stream | UInt32(4)" in jz and "stream | 4u" in cz
+    assert "(UInt32(n) << 8) | (t & 0x000000ff)" in jz and "(n << 8) | (t & 255u)" in cz
+    assert "yy + yy >= xx * xx" in jz and "yy + yy >= xx * xx" in cz
+    assert "fma(u01_half(v[3], v[4]), f0 - f1, f1) < 1.0" in jz and "fma(orc_u01_half(w[2], w[3]), f0 - f1, f1) < 1.0" in cz
