@@ -409,11 +409,11 @@ MHX_DEV bool mhx_zig_try(const double* __restrict__ zt, const mhx_u32 hi, const 
     return ax < zt[layer + 1];
 }
 
-// the normal behind a candidate (x, layer) that left its rectangle
+// the normal behind a candidate (x, layer) that left its rectangle: rejection attempts t0, t0 + 1, ...
 MHX_DEV double mhx_zig_slow(const mhx_philox_key& ks, const double* __restrict__ zt, const mhx_u32 id_lo, const mhx_u32 id_hi,
-                            const mhx_u32 step, const mhx_u32 stream, const mhx_u32 n, double x, mhx_u32 layer)
+                            const mhx_u32 step, const mhx_u32 stream, const mhx_u32 n, double x, mhx_u32 layer, const mhx_u32 t0 = 1u)
 {
-    for (mhx_u32 t = 1;; ++t) {
+    for (mhx_u32 t = t0;; ++t) {
         const mhx_u32x4 v = mhx_philox(ks, id_lo, id_hi, step, ((stream | MHX_STREAM_RETRY) << 28) | ((n << 8) | (t & 255u)));
         if (layer == 0u) {
             const double xx = mhx_log_pos(mhx_u01_open(v.x, v.y)) * MHX_ZIG_NEG_RINV;
@@ -426,6 +426,34 @@ MHX_DEV double mhx_zig_slow(const mhx_philox_key& ks, const double* __restrict__
             if (mhx_zig_try(zt, v.x, v.y, x, layer)) return x;
         }
     }
+}
+
+// The same normal, laid out for latency (the fix-up pass of the cooperative kernel runs a dozen lanes of a wave through this while
+// the other lanes wait): the Philox block of the failed candidate and the block of rejection attempt 1 are independent of each
+// other and of the table -- both are drawn up front, the table entries of the failed candidate AND of attempt 1's fresh candidate
+// are fetched together, and the common case (a wedge, settled by attempt 1) runs straight through; anything else (the tail beyond
+// r, a second rejection) continues in mhx_zig_slow from the attempt it has reached.  Same values as mhx_zig_try + mhx_zig_slow.
+MHX_DEV double mhx_zig_refine(const mhx_philox_key& ks, const double* __restrict__ zt, const mhx_u32 id_lo, const mhx_u32 id_hi,
+                              const mhx_u32 step, const mhx_u32 stream, const mhx_u32 n)
+{
+    const mhx_u32x4 w = mhx_philox(ks, id_lo, id_hi, step, (stream << 28) | (n >> 1));
+    const mhx_u32x4 v = mhx_philox(ks, id_lo, id_hi, step, ((stream | MHX_STREAM_RETRY) << 28) | ((n << 8) | 1u));
+    const mhx_u32 hi = (n & 1u) ? w.z : w.x, lo = (n & 1u) ? w.w : w.y;
+    mhx_u32 layer = lo & (mhx_u32)(MHX_ZIG_N - 1);
+    const mhx_u32 layer2 = v.y & (mhx_u32)(MHX_ZIG_N - 1);
+    const double xl = zt[layer], xl1 = zt[layer + 1];
+    const double xn = zt[layer2], xn1 = zt[layer2 + 1];
+    const double ax = mhx_zig_ax(hi, lo, xl);
+    double x = mhx_zig_signed(ax, lo);
+    if (ax < xl1) return x;                                        // (not a failed candidate after all: callers only send failures)
+    if (layer == 0u) return mhx_zig_slow(ks, zt, id_lo, id_hi, step, stream, n, x, layer, 1u);
+    const double xsq = x * x;
+    const double f0 = mhx_exp(-0.5 * (xl * xl - xsq)), f1 = mhx_exp(-0.5 * (xl1 * xl1 - xsq));
+    if (mhx_fma(mhx_u01_half(v.z, v.w), f0 - f1, f1) < 1.0) return x;
+    const double ax2 = mhx_zig_ax(v.x, v.y, xn);
+    x = mhx_zig_signed(ax2, v.y);
+    if (ax2 < xn1) return x;
+    return mhx_zig_slow(ks, zt, id_lo, id_hi, step, stream, n, x, layer2, 2u);
 }
 
 // normal number n (0-based) of (id, step, stream), straight from the table in global memory: the kernels off the hot path

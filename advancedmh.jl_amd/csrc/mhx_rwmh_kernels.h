@@ -381,18 +381,10 @@ MHX_DEV void mhx_zig_fixup(const mhx_philox_key& ks, const double* __restrict__ 
     constexpr int CPW = 64 / L;
     // Queue positions without a prefix sum over the lanes: round k takes the k-th failure of every lane that has one; the
     // lanes of a round are ranked by mbcnt over the round's ballot, the rounds follow each other in the queue.  (Nearly all
-    // lanes have 0 or 1 failure: one or two rounds.)  total = the number of candidates of this wave-step that failed.
+    // lanes have 0 or 1 failure: one or two rounds.)  One pass both numbers and stores the first 64 entries -- all of them
+    // unless more than 64 candidates of the wave-step failed, in which case further windows of 64 follow.
     int total = 0;
-    {
-        mhx_u64 f = fm;
-        for (;;) {
-            const mhx_u64 m = __ballot(f != 0ull);
-            if (m == 0ull) break;
-            total += __popcll(m);
-            f &= f - 1ull;
-        }
-    }
-    for (int win = 0; win < total; win += 64) {                    // (one window unless > 64 candidates failed at once)
+    for (int win = 0; win == 0 || win < total; win += 64) {
         mhx_u64 f = fm;
         int base = -win;
         for (;;) {
@@ -406,6 +398,7 @@ MHX_DEV void mhx_zig_fixup(const mhx_philox_key& ks, const double* __restrict__ 
             f &= f - 1ull;
             base += __popcll(m);
         }
+        total = base + win;
         MHX_WAVE_SYNC();
         const int nent = total - win < 64 ? total - win : 64;
         if (lane < nent) {
@@ -415,11 +408,8 @@ MHX_DEV void mhx_zig_fixup(const mhx_philox_key& ks, const double* __restrict__ 
             const mhx_u64 oid = first_chain + (mhx_u64)(oc_raw < nchains ? oc_raw : (long)nchains - 1);
             const mhx_u32 b = (mhx_u32)(ol / CPW + L * (sl >> 2));
             const mhx_u32 n = 4u * b + (mhx_u32)(sl & 3);
-            const mhx_u32x4 w = mhx_philox(ks, (mhx_u32)oid, (mhx_u32)(oid >> 32), step, (stream << 28) | (n >> 1));
-            double x; mhx_u32 layer;
-            (void)mhx_zig_try(zt, (n & 1u) ? w.z : w.x, (n & 1u) ? w.w : w.y, x, layer);     // fails by construction
-            x = mhx_zig_slow(ks, zt, (mhx_u32)oid, (mhx_u32)(oid >> 32), step, stream, n, x, layer);
-            zn[(((sl >> 1) * 64 + ol) << 1) + (sl & 1)] = x;
+            // nothing but the slot number was kept: the failed candidate is re-derived from its Philox block
+            zn[(((sl >> 1) * 64 + ol) << 1) + (sl & 1)] = mhx_zig_refine(ks, zt, (mhx_u32)oid, (mhx_u32)(oid >> 32), step, stream, n);
         }
         MHX_WAVE_SYNC();
     }
@@ -591,7 +581,10 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
                     for (int e = 0; e < 4 * GB; ++e) { khi[e] = nhi[e]; klo[e] = nlo[e]; }
                 }
             }
-            if (__ballot(fm != 0ull))
+#ifndef MHX_ZIG_PROBE
+#define MHX_ZIG_PROBE 0        // timing probe (tools only, hiprtc define via MHX_ZIG_PROBE in the environment): 1 = skip the fix-up (WRONG normals)
+#endif
+            if (MHX_ZIG_PROBE != 1 && __ballot(fm != 0ull))
                 mhx_zig_fixup<L>(ks, zt, zn, zq, fm, lane, wave, a.first_chain, a.nchains, step, MHX_STREAM_PROPOSAL);
             // the step's normals, final: all of them on their way to the registers the candidate will occupy (one wait)
 #pragma unroll
