@@ -43,6 +43,9 @@ struct mhx_emcee_args {
     mhx_u32 sweep;            // RNG step counter of this sweep
     int half;                 // 0: walkers [0, W/2) move; 1: walkers [W/2, W) move
     long save_slot;           // slot to record this sweep into, or -1
+    long rec_other_slot;      // cooperative kernel: slot into which THIS launch records the half that is NOT moving (at rest since the
+                              // previous half-step, hence final for its sweep), or -1.  The record of a half then leaves at the START of the
+                              // next launch, off its critical path, instead of at the end of the launch that moved it (host: emcee_advance)
     int reduce_lanes;         // lanes per walker (cooperative kernel), >= 1
     int t_begin, t_count;     // the slice of the moving half this launch moves (an ensemble sharded over GPUs moves
                               // one slice per rank and exchanges the slices; a single GPU moves [0, size of the half))
@@ -396,6 +399,14 @@ MHX_DEV mhx_real mhx_band_rows_sq(const mhx_real (&ab)[mhx_emcee_geom<D, L>::NK]
 #endif
 #define MHX_PROBE(n, val) do { if (MHX_EMCEE_PROBE == (n)) { if ((val) == MHX_R(12345.678)) a.lp[0] = (val); return; } } while (0)
 
+#ifndef MHX_EMCEE_REC_STORE
+#define MHX_EMCEE_REC_STORE 0       // tuning knob: how the record leaves -- 0 plain stores, 1 non-temporal
+#endif
+#if MHX_EMCEE_REC_STORE == 1
+#define MHX_REC_ST(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define MHX_REC_ST(p, v) (*(p) = (v))
+#endif
 // BW < 0: dense factor (image in LDS, one block barrier); BW >= 0: a factor of bandwidth BW (no image, no barrier)
 template <int D, int L, int BW = -1>
 MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const mhx_real* __restrict__ A, mhx_real* ysh_all, mhx_e4* Ash4)
@@ -432,6 +443,17 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const mhx_real* __rest
     MHX_PROBE(1, (mhx_real)i);                                               // launch + arguments
     const mhx_real lpi = a.lp[i];                                            // in flight with the rows
     const mhx_u32 acc_i = a.acc_count[i];
+    // deferred record (a.rec_other_slot): this group's walker of the half at rest -- loads issued here, stores after the move
+    const int io = (a.rec_other_slot >= 0 && valid && t_raw < osize) ? ostart + t_raw : -1;
+    mhx_e4 xo[mhx_emcee_geom<D, L>::NQL];
+    mhx_real lpo = MHX_R(0.0);
+    unsigned char lao = 0;
+    if (io >= 0) {
+        const mhx_e4* xrow_o = (const mhx_e4*)(a.xw + (long)io * GEO::XP);
+#pragma unroll
+        for (int m = 0; m < mhx_emcee_geom<D, L>::NQL; ++m) { const int q4 = l + L * m; if (q4 < mhx_emcee_geom<D, L>::NQ) xo[m] = xrow_o[q4]; }
+        if (l == 0) { lpo = a.lp[io]; lao = a.last_acc[io]; }
+    }
     const mhx_philox_key ks = mhx_philox_schedule(a.seed);
     const mhx_emcee_draws dr = mhx_emcee_draw(ks, (mhx_u32)i, (mhx_u32)a.ensemble_id, a.sweep);
     const int j = ostart + (int)(((mhx_u64)dr.partner * (mhx_u64)(mhx_u32)osize) >> 32);
@@ -466,6 +488,31 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const mhx_real* __rest
         if (q4 < DP4 / 4) ((mhx_e4*)yrow)[q4] = ysl[m];
     }
     MHX_PROBE(3, ysl[0].x);                                                  // + the two rows, the move
+    if (MHX_EMCEE_PROBE != 6 && a.rec_other_slot >= 0) {
+        // the partner row x_j was requested after these loads: they have arrived.  The stores have the rest of the launch to drain.
+        auto rec = [&](const int iw, const mhx_e4 (&xr)[mhx_emcee_geom<D, L>::NQL], const mhx_real lpr, const unsigned char lar) {
+            mhx_real* row = a.samples + a.rec_other_slot * (long)(D + 1) * ld + iw;
+#pragma unroll
+            for (int m = 0; m < NQL; ++m) {
+                const int k = 4 * (l + L * m);
+                if (k + 0 < D) MHX_REC_ST(&row[(long)(k + 0) * ld], xr[m].x);
+                if (k + 1 < D) MHX_REC_ST(&row[(long)(k + 1) * ld], xr[m].y);
+                if (k + 2 < D) MHX_REC_ST(&row[(long)(k + 2) * ld], xr[m].z);
+                if (k + 3 < D) MHX_REC_ST(&row[(long)(k + 3) * ld], xr[m].w);
+            }
+            if (l == 0) { MHX_REC_ST(&row[(long)D * ld], lpr); a.accepted[a.rec_other_slot * ld + iw] = lar; }
+        };
+        if (io >= 0) rec(io, xo, lpo, lao);
+        // the half at rest may be one walker larger than the moving one (odd W): the first group takes it too
+        if (valid && t_raw + cnt < osize) {
+            const int ie = ostart + t_raw + cnt;
+            mhx_e4 xe[mhx_emcee_geom<D, L>::NQL];
+            const mhx_e4* xrow_e = (const mhx_e4*)(a.xw + (long)ie * GEO::XP);
+#pragma unroll
+            for (int m = 0; m < NQL; ++m) { const int q4 = l + L * m; if (q4 < NQ) xe[m] = xrow_e[q4]; }
+            rec(ie, xe, l == 0 ? a.lp[ie] : MHX_R(0.0), l == 0 ? a.last_acc[ie] : (unsigned char)0);
+        }
+    }
     mhx_real q;
     if constexpr (BAND) {
         MHX_WAVE_SYNC();                                                     // the candidate rows of a wave are its own
@@ -500,13 +547,13 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const mhx_real* __rest
             for (int m = 0; m < NQL; ++m) {
                 const int k = 4 * (l + L * m);
                 const mhx_e4 v = acc ? ysl[m] : xs[m];
-                if (k + 0 < D) row[(long)(k + 0) * ld] = v.x;
-                if (k + 1 < D) row[(long)(k + 1) * ld] = v.y;
-                if (k + 2 < D) row[(long)(k + 2) * ld] = v.z;
-                if (k + 3 < D) row[(long)(k + 3) * ld] = v.w;
+                if (k + 0 < D) MHX_REC_ST(&row[(long)(k + 0) * ld], v.x);
+                if (k + 1 < D) MHX_REC_ST(&row[(long)(k + 1) * ld], v.y);
+                if (k + 2 < D) MHX_REC_ST(&row[(long)(k + 2) * ld], v.z);
+                if (k + 3 < D) MHX_REC_ST(&row[(long)(k + 3) * ld], v.w);
             }
             if (l == 0) {
-                row[(long)D * ld] = acc ? lpy : lpi;
+                MHX_REC_ST(&row[(long)D * ld], acc ? lpy : lpi);
                 a.accepted[a.save_slot * ld + i] = acc ? 1 : 0;
             }
         }
