@@ -822,6 +822,8 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
     const int tk = t->kind, pk = r->prop_kind;
     if ((cfg->flags & MHX_FLAG_ZIGGURAT) && !MHX_REAL64)
         return mhx_fail(MHX_EINVAL, "MHX_FLAG_ZIGGURAT: the ziggurat normal generator exists in fp64 contexts only");
+    if ((cfg->flags & MHX_FLAG_ZIGGURAT) && d >= (1 << 20))      // the retry blocks are numbered (normal index << 8 | attempt) in 28 bits
+        return mhx_fail(MHX_EINVAL, "MHX_FLAG_ZIGGURAT: dim must be below 2^20");
     const int regmax = pk == MHX_PROP_DENSE ? MHX_REG_MAX_DIM_DENSE : MHX_REG_MAX_DIM;
     const int nblk = (d + 3) / 4;
     const bool separable = tk == MHX_TARGET_ISO_GAUSS || tk == MHX_TARGET_BANANA || tk == MHX_TARGET_FUNNEL;
