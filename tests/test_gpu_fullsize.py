@@ -272,3 +272,51 @@ def test_matrix_core_kernels_known_answer(mhx, sampler, real):
     assert np.abs(pooled.var(axis=1) - 1.0).max() < 0.04
     nb = np.array([np.corrcoef(pooled[k], pooled[k + 1])[0, 1] for k in range(d - 1)])
     assert abs(nb.mean() - 0.6) < 0.01 and np.abs(nb - 0.6).max() < 0.03
+
+
+def test_c2_and_c5_full_size_with_ziggurat_normals(mhx, oracle):
+    """The two configurations bench.py runs with MHX_FLAG_ZIGGURAT, at their full sizes (fp64): C2 -- 65 536 chains, the pre-built
+    kernel, three 64-chain subsets against the oracle and two half-size shards against the whole; C5 -- one GPU's shard of the
+    1000-dim funnel with global ids, running moments of a continuation."""
+    old_m, old_o = mhx.get_default_dtype(), oracle.get_dtype()
+    mhx.set_default_dtype("f64")
+    oracle.set_dtype("f64")
+    try:
+        d, C, N = 100, 65536, 24
+        s = float(np.float32(2.38 / d ** 0.5))
+        model = mhx.DensityModel(mhx.IsoGaussian(d))
+        spl = mhx.RWMH(mhx.MvNormal(mhx.zeros(d), s * s * mhx.I))
+        chain = mhx.sample(model, spl, N, C, seed=0xC0FFEE, normal_gen="ziggurat")
+        assert chain.stats["kernel_variant"] == 3 and chain.stats["reduce_lanes"] == 2 and chain.stats["normal_gen"] == 1
+        for first in (0, 31337, C - 64):
+            ref = oracle.rwmh(oracle.iso_gauss(d, reduce_lanes=2), oracle.Proposal(oracle.PROP_ISO, s, normal_gen=1), oracle.schedule(N),
+                              0xC0FFEE, first, 64)
+            _same(chain.value[:, :, first:first + 64], ref["samples"], "C2 samples of chains %d.." % first)
+            _same(chain.accepted[:, first:first + 64], ref["accepted"], "accepted")
+        half = mhx.sample(model, spl, 6, C // 2, seed=0xC0FFEE, first_chain=C // 2, reduce_lanes=2, normal_gen="ziggurat")
+        _same(half.value, chain.value[:6, :, C // 2:], "upper shard")
+        assert chain.stats["accepted"] == int(chain.accepted[1:].sum())
+        del chain, half
+        d, Cs, N = 1000, 32768, 4
+        s = float(np.float32(2.38 / d ** 0.5))
+        first = 3 * Cs
+        run = mhx.Run(mhx.DensityModel(mhx.Funnel(d)), mhx.RWMH(mhx.MvNormal(mhx.zeros(d), s * s * mhx.I)), nchains=Cs, seed=5,
+                      first_chain=first, normal_gen="ziggurat")
+        run.init(None)
+        run.sample(N)
+        val, acc = run.samples()
+        st = run.stats()
+        assert st["kernel_variant"] == 3 and st["reduce_lanes"] == 64 and st["normal_gen"] == 1
+        ot = oracle.Target(oracle.TARGET_FUNNEL, d).with_lanes(64)
+        for off in (0, Cs - 16):
+            ref = oracle.rwmh(ot, oracle.Proposal(oracle.PROP_ISO, s, normal_gen=1), oracle.schedule(N + 10), 5, first + off, 16)
+            _same(val[:, :, off:off + 16], ref["samples"][:N], "C5 samples of chains %d.." % (first + off))
+            if off == 0:
+                keep = ref
+        run.sample(2, 5, 5, 0, save="moments")                      # the pre-built moments twin: states after 5 and 10 more transitions
+        x, lp, cnt = run.state()
+        _same(x[:, :16], keep["samples"][N + 9, :d, :], "state after the moments continuation")
+        assert np.isfinite(run.diagnostics()["mean"]).all()
+    finally:
+        mhx.set_default_dtype(old_m)
+        oracle.set_dtype(old_o)
