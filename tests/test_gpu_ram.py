@@ -243,3 +243,26 @@ def test_per_step_sampler_statistics(mhx, oracle, real, sched, slab):
     with pytest.raises(mhx.MhxError):
         run.sample(4, 0, 1, 0, save=False)
         run.step_stats()
+
+
+def test_adaptation_steers_the_mean_acceptance_probability_to_alpha(mhx, real):
+    """What the reference keeps `logα` bounded at 0 for (RAM.jl:141-147): "users can just take an average of (exp of) the logα
+    values" -- with the per-step statistics the analogue of the reference's callback test (test/RobustAdaptiveMetropolis.jl:11-28):
+    after a few thousand adapting steps the mean acceptance probability sits at α = 0.234, and η follows iteration^-γ."""
+    d, C, N = 8, 256, 4000
+    Sig = cases.sigma_ar1(d, 0.6) * np.linspace(0.5, 3.0, d)[:, None] * np.linspace(0.5, 3.0, d)[None, :]
+    run = mhx.Run(mhx.DensityModel(mhx.CorrGaussian(Sig)), mhx.RobustAdaptiveMetropolis(), nchains=C, seed=12)
+    run.init(np.zeros(d))
+    run.sample(N, 0, 1, N)                                    # every step adapts, every state recorded
+    st = run.step_stats()
+    val, acc = run.samples()
+    la, eta = st["logα"], st["η"]
+    assert la.shape == (N, C) and (la <= 0).all() and (la[0] == 0).all()
+    p = np.exp(la[N // 2:].astype(np.float64)).mean()
+    assert abs(p - 0.234) < 0.02, p
+    assert abs(acc[N // 2:].mean() - 0.234) < 0.02           # and the realised acceptance agrees with it
+    k = np.arange(1, N)                                       # sample i + 1 is behind transition i: η = i^-0.6
+    want = k.astype(np.float64) ** -0.6
+    assert eta[0] == 0.0 and np.allclose(eta[1:], want, rtol=1e-6 if real == "f32" else 1e-14)
+    S, status = run.factor()
+    assert (status == 0).all() and np.isfinite(S).all()
