@@ -409,7 +409,11 @@ MHX_DEV void mhx_zig_fixup(const mhx_philox_key& ks, const double* __restrict__ 
             const mhx_u32 b = (mhx_u32)(ol / CPW + L * (sl >> 2));
             const mhx_u32 n = 4u * b + (mhx_u32)(sl & 3);
             // nothing but the slot number was kept: the failed candidate is re-derived from its Philox block
+#if defined(MHX_ZIG_PROBE) && MHX_ZIG_PROBE == 2
+            zn[(((sl >> 1) * 64 + ol) << 1) + (sl & 1)] = (double)n * 1e-3 + (double)(mhx_u32)oid * 1e-9;      // timing probe: queue and syncs, no refinement
+#else
             zn[(((sl >> 1) * 64 + ol) << 1) + (sl & 1)] = mhx_zig_refine(ks, zt, (mhx_u32)oid, (mhx_u32)(oid >> 32), step, stream, n);
+#endif
         }
         MHX_WAVE_SYNC();
     }
