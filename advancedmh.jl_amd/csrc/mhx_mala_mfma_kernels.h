@@ -198,6 +198,258 @@ MHX_DEV void mhx_mala_mfma_body(const mhx_mala_args& a, const mhx_real* __restri
     if (lane == 0) atomicAdd(a.acc_total, (mhx_u64)wave_acc);
 }
 
+
+// ---- LEAN mode: ONE vector per lane.  The largest dimensions (fp64 d = 201 ... 512, fp32 d = 401 ... 1000) leave a lane room
+// for one vector of ceil(d/4) reals beside the streaming registers, so the step is arranged around a single array v:
+//   v = y                       the candidate (its noise goes to the z slab as it is drawn)
+//   v = A y    IN PLACE         row tiles in DESCENDING order: tile t reads y[0 .. 16t+15], so once it is done the y of its own
+//                               rows is dead and the fragment takes its place (an accumulator is the same ascending fma chain
+//                               whatever order the tiles are visited in)
+//   q = |v|^2                   afterwards, in ascending row order -- the spec's order
+//   v = A^T v  IN PLACE         tiles ascending: tile t reads w[16t ..]: dead below, replaced by the fragment
+//   grad y = -v, the backward sum with z re-read from its slab; on accept y is RE-FORMED from x, grad x and z (same expression,
+//   same operands: same bits) and x, grad x are rewritten.
+// Both images stream through the ring one tile (or tile pair) per chunk, A from its LAST chunk down, A^T from its first up.
+template <int D, bool PAIR, long BUFB, int NPF>
+MHX_DEV void mhx_mfma_rows_stream_desc(const mhx_srd gimg, const mhx_srd gnextT, mhx_real* ring, const int lane,
+                                       mhx_real (&v)[mhx_mfma_geom<D>::NS], mhx_piece16 (&pf)[NPF], int& parity)
+{
+    typedef mhx_mfma_geom<D> GEO;
+    typedef mhx_mfma_stream_geom<D, PAIR> SG;
+#pragma unroll
+    for (int p = SG::NP - 1; p >= 0; --p) {
+        mhx_acc4* buf = (mhx_acc4*)((char*)ring + (parity ? BUFB : 0));
+#pragma unroll
+        for (int i = 0; i < SG::PF; ++i)
+            if (i < SG::pieces(p)) ((mhx_piece16*)buf)[(int)threadIdx.x + i * SG::THREADS] = pf[i];
+        __syncthreads();
+        if (p > 0) mhx_mfma_chunk_load<D, PAIR>(gimg, p - 1, pf);
+        else mhx_mfma_chunk_load<D, PAIR, true>(gnextT, 0, pf);                   // next: A^T from its first chunk
+        constexpr mhx_acc4 zero = {MHX_R(0.0), MHX_R(0.0), MHX_R(0.0), MHX_R(0.0)};
+        mhx_acc4 c[2] = {zero, zero};
+        const int t0 = SG::TPC * p;
+        const int t1 = PAIR && t0 + 1 < GEO::NT ? t0 + 1 : t0;
+#pragma unroll
+        for (int grp = 0; grp < GEO::groups(t1); ++grp) {
+#pragma unroll
+            for (int h = 0; h < SG::TPC; ++h) {
+                const int t = t0 + h;
+                if (t < GEO::NT && grp < GEO::groups(t)) {
+                    const mhx_acc4 a4 = buf[(GEO::first(t) / 4 + grp - SG::first(p)) * 64 + lane];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (4 * grp + u < GEO::steps(t)) c[h] = MHX_MFMA16(a4[u], v[4 * grp + u], c[h]);
+                }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < SG::TPC; ++h) {
+            const int t = t0 + h;
+            if (t < GEO::NT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * t + r < GEO::NS) v[4 * t + r] = c[h][r];               // rows 16t.. of A y replace y[16t..]: no lower tile reads them
+            }
+        }
+        parity ^= 1;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// A^T w over the streamed image of A^T, in place (tiles ascending), one tile or a pair per chunk; on return `pf` holds the LAST
+// chunk of the lower image `gnext` (where the next step's descending A y starts)
+template <int D, bool PAIR, long BUFB, int NPF>
+MHX_DEV void mhx_mfma_rows_T_stream_inplace(const mhx_srd gimgT, const mhx_srd gnext, mhx_real* ring, const int lane,
+                                            mhx_real (&v)[mhx_mfma_geom<D>::NS], mhx_piece16 (&pf)[NPF], int& parity)
+{
+    typedef mhx_mfma_geom<D> GEO;
+    typedef mhx_mfma_stream_geom<D, PAIR, true> SG;
+    typedef mhx_mfma_stream_geom<D, PAIR, false> SGA;
+#pragma unroll
+    for (int p = 0; p < SG::NP; ++p) {
+        mhx_acc4* buf = (mhx_acc4*)((char*)ring + (parity ? BUFB : 0));
+#pragma unroll
+        for (int i = 0; i < SG::PF; ++i)
+            if (i < SG::pieces(p)) ((mhx_piece16*)buf)[(int)threadIdx.x + i * SG::THREADS] = pf[i];
+        __syncthreads();
+        if (p + 1 < SG::NP) mhx_mfma_chunk_load<D, PAIR, true>(gimgT, p + 1, pf);
+        else mhx_mfma_chunk_load<D, PAIR, false>(gnext, SGA::NP - 1, pf);
+        constexpr mhx_acc4 zero = {MHX_R(0.0), MHX_R(0.0), MHX_R(0.0), MHX_R(0.0)};
+        mhx_acc4 c[2] = {zero, zero};
+        const int t0 = SG::TPC * p;
+#pragma unroll
+        for (int grp = t0; grp < GEO::NT; ++grp) {
+#pragma unroll
+            for (int h = 0; h < SG::TPC; ++h) {
+                const int t = t0 + h;
+                if (t < GEO::NT && grp >= t) {
+                    const mhx_acc4 a4 = buf[(GEO::firstT(t) + grp - t - SG::first(p)) * 64 + lane];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (4 * grp + u < GEO::NS) c[h] = MHX_MFMA16(a4[u], v[4 * grp + u], c[h]);
+                }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < SG::TPC; ++h) {
+            const int t = t0 + h;
+            if (t < GEO::NT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * t + r < GEO::NS) v[4 * t + r] = c[h][r];               // no later tile reads w below its own rows
+            }
+        }
+        parity ^= 1;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int D, bool PAIR>
+MHX_DEV void mhx_mala_mfma_lean_body(const mhx_mala_args& a, mhx_real* Aimg, mhx_real* ATimg, mhx_real* ring)
+{
+    typedef mhx_mfma_geom<D> GEO;
+    constexpr int NS = GEO::NS;
+    constexpr int NQD = (NS + 3) / 4;
+    typedef mhx_mfma_stream_geom<D, PAIR, false> SGA;
+    typedef mhx_mfma_stream_geom<D, PAIR, true> SGT;
+    constexpr int PFM = SGA::PF > SGT::PF ? SGA::PF : SGT::PF;
+    constexpr long BUFM = SGA::BUF_BYTES > SGT::BUF_BYTES ? SGA::BUF_BYTES : SGT::BUF_BYTES;
+    mhx_piece16 pf[PFM];
+    int parity = 0;
+    const mhx_srd sA = mhx_make_srd(Aimg, (mhx_u32)(GEO::REALS * (long)sizeof(mhx_real)));
+    const mhx_srd sAT = mhx_make_srd(ATimg, (mhx_u32)(GEO::REALS_T * (long)sizeof(mhx_real)));
+    mhx_mfma_chunk_load<D, PAIR, false>(sA, SGA::NP - 1, pf);
+
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15;
+    const int g = lane >> 4;
+    const long c_raw = ((long)blockIdx.x * MHX_MFMA_WAVES + wave) * 16 + j;
+    const bool valid = c_raw < a.nchains;
+    const long c = valid ? c_raw : (long)a.nchains - 1;
+    const long ld = a.ld;
+    const mhx_u64 id = a.first_chain + (mhx_u64)c;
+    const mhx_u32 id_lo = (mhx_u32)id, id_hi = (mhx_u32)(id >> 32);
+    const mhx_philox_key ks = mhx_philox_schedule(a.seed);
+    const mhx_u32 lane_off = ((mhx_u32)g * (mhx_u32)ld + (mhx_u32)c) * MHX_RB;
+    const mhx_u32 ldb = (mhx_u32)ld * MHX_RB;
+    const mhx_srd xsrd = mhx_make_srd(a.x, (mhx_u32)D * ldb), gsrd = mhx_make_srd(a.gx, (mhx_u32)D * ldb);
+    const mhx_srd zsrd = mhx_make_srd(a.zbuf, (mhx_u32)D * ldb);
+    auto own = [&](const int s) -> bool { return 4 * s + 3 < D || 4 * s + g < D; };
+    auto xat = [&](const int s) -> mhx_real { return own(s) ? mhx_srd_load(xsrd, lane_off, (mhx_u32)(4 * s) * ldb) : MHX_R(0.0); };
+    auto gat = [&](const int s) -> mhx_real { return own(s) ? mhx_srd_load(gsrd, lane_off, (mhx_u32)(4 * s) * ldb) : MHX_R(0.0); };
+    auto zat = [&](const int s) -> mhx_real { return own(s) ? mhx_srd_load(zsrd, lane_off, (mhx_u32)(4 * s) * ldb) : MHX_R(0.0); };
+    mhx_real lp = a.lp[c];
+    mhx_u32 nacc = a.acc_count[c];
+    mhx_u32 wave_acc = 0;
+    bool last = a.last_acc[c] != 0;
+    mhx_accept_cache ac;
+    ac.group = 0xffffffffu;
+    ac.w.x = ac.w.y = ac.w.z = ac.w.w = 0u;
+    mhx_u32 save_next = a.save_next;
+    long slot = a.save_slot;
+
+    for (int it = 0; it < a.nsteps; ++it) {
+        const mhx_u32 step = a.step0 + (mhx_u32)it;
+        asm volatile("" ::: "memory");
+        mhx_real v[NS];
+        mhx_real fq = MHX_R(0.0);
+        // ---- noise and candidate (src/MALA.jl:70); the noise of dimension 4s + g goes to the z slab
+#pragma unroll
+        for (int qd = 0; qd < NQD; ++qd) {
+            mhx_real n[4];
+            mhx_normal4(ks, id_lo, id_hi, step, MHX_STREAM_PROPOSAL, (mhx_u32)(4 * qd + g), n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k0 = 4 * (4 * qd) + e;
+                if (k0 + 12 >= D) n[e] = (k0 + 4 * g < D) ? n[e] : MHX_R(0.0);
+                fq = mhx_fma(n[e], n[e], fq);
+            }
+            mhx_lanes4_transpose(n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int s = 4 * qd + e;
+                if (s < NS) {
+                    if (own(s) && valid) mhx_srd_store(zsrd, lane_off, (mhx_u32)(4 * s) * ldb, n[e]);
+                    v[s] = mhx_fma(a.sigma, n[e], mhx_fma(a.h, gat(s), xat(s)));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        fq = fq + __shfl_xor(fq, 16, 64);
+        fq = fq + __shfl_xor(fq, 32, 64);
+        // ---- w = A y (in place, tiles descending), lp' = -1/2 |w|^2 + const in ascending row order
+        mhx_mfma_rows_stream_desc<D, PAIR, BUFM>(sA, sAT, ring, lane, v, pf, parity);
+        mhx_real q = MHX_R(0.0);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) q = mhx_fma(v[s], v[s], q);
+        q = q + __shfl_xor(q, 16, 64);
+        q = q + __shfl_xor(q, 32, 64);
+        const mhx_real lpy = mhx_fma(-MHX_R(0.5), q, a.tconst);
+        // ---- grad = -A^T w (in place, tiles ascending)
+        mhx_mfma_rows_T_stream_inplace<D, PAIR, BUFM>(sAT, sA, ring, lane, v, pf, parity);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) v[s] = -v[s];
+        // ---- log ratio of the proposal densities (:78-80)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // (the z slab written above is read back here by the same lane)
+        mhx_real bq = MHX_R(0.0);
+#pragma unroll
+        for (int qd = 0; qd < NQD; ++qd) {
+            mhx_real n[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int s = 4 * qd + e;
+                n[e] = s < NS ? mhx_fma(a.hs, gat(s) + v[s], zat(s)) : MHX_R(0.0);
+            }
+            mhx_lanes4_transpose(n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bq = mhx_fma(n[e], n[e], bq);
+        }
+        bq = bq + __shfl_xor(bq, 16, 64);
+        bq = bq + __shfl_xor(bq, 32, 64);
+        const mhx_real loga = (lpy - lp) + MHX_R(0.5) * (fq - bq);
+        const mhx_real logu = mhx_accept_logu(ks, id_lo, id_hi, step, ac);
+        const bool acc = logu < loga;
+        if (acc && valid) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                if (own(s)) {
+                    const mhx_real ynew = mhx_fma(a.sigma, zat(s), mhx_fma(a.h, gat(s), xat(s)));   // the candidate again: same operands, same bits
+                    mhx_srd_store(xsrd, lane_off, (mhx_u32)(4 * s) * ldb, ynew);
+                    mhx_srd_store(gsrd, lane_off, (mhx_u32)(4 * s) * ldb, v[s]);
+                }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the slabs are current before anything reads them again
+        lp = acc ? lpy : lp;
+        nacc += acc ? 1u : 0u;
+        last = acc;
+        wave_acc += (mhx_u32)__popcll(__ballot(acc && valid && g == 0));
+        if (step == save_next) {
+            if (valid) {
+                mhx_real* slotp = a.samples + slot * (long)(D + 1) * ld;
+                const mhx_srd srd = mhx_make_srd(slotp, (mhx_u32)(D + 1) * (mhx_u32)ld * MHX_RB);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    if (own(s)) mhx_srd_store(srd, lane_off, (mhx_u32)(4 * s) * ldb, xat(s));
+                    if ((s & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                }
+                if (g == 0) {
+                    slotp[(long)D * ld + c] = lp;
+                    a.accepted[slot * ld + c] = acc ? 1 : 0;
+                }
+            }
+            save_next += (mhx_u32)a.thinning;
+            ++slot;
+        }
+    }
+    if (valid && g == 0) {
+        a.lp[c] = lp;
+        a.acc_count[c] = nacc;
+        a.last_acc[c] = last ? 1 : 0;
+    }
+    if (lane == 0) atomicAdd(a.acc_total, (mhx_u64)wave_acc);
+}
+
 #ifdef MHX_JIT_MALA_MFMA
 #ifndef MHX_JIT_WAVES
 #define MHX_JIT_WAVES 1
@@ -223,6 +475,21 @@ mhx_jit_mala_mfma_stream(const mhx_mala_args a, const mhx_real* __restrict__ tpa
 {
     extern __shared__ mhx_acc4 mhx_mala_mfma_ring[];
     mhx_mala_mfma_body<MHX_JIT_DIM, true>(a, tparams, gAimg, gATimg, (mhx_real*)mhx_mala_mfma_ring);
+}
+#endif
+#ifdef MHX_JIT_MALA_MFMA_LEAN
+#ifndef MHX_JIT_PAIR
+#define MHX_JIT_PAIR 0
+#endif
+extern "C" __global__ void __launch_bounds__(256)
+mhx_jit_mfma_image(const mhx_real* __restrict__ packed, mhx_real* img) { mhx_mfma_image_fill<MHX_JIT_DIM>(packed, img); }
+extern "C" __global__ void __launch_bounds__(256)
+mhx_jit_mfma_image_T(const mhx_real* __restrict__ packed, mhx_real* img) { mhx_mfma_image_fill_T<MHX_JIT_DIM>(packed, img); }
+extern "C" __global__ void __launch_bounds__(64 * MHX_MFMA_WAVES, 1)
+mhx_jit_mala_mfma_lean(const mhx_mala_args a, const mhx_real* __restrict__ tparams, mhx_real* gAimg, mhx_real* gATimg)
+{
+    extern __shared__ mhx_acc4 mhx_mala_mfma_ring[];
+    mhx_mala_mfma_lean_body<MHX_JIT_DIM, (MHX_JIT_PAIR != 0)>(a, gAimg, gATimg, (mhx_real*)mhx_mala_mfma_ring);
 }
 #endif
 MHX_NS_END

@@ -99,7 +99,7 @@ def test_mala_cooperative_kernel_bit_exact(mhx, oracle, name, d, lanes, real):
     run2.close()
 
 
-@pytest.mark.parametrize("d,C,lanes", [(16, 70, 4), (40, 33, 0), (100, 70, 0), (100, 17, 4), (61, 16, 0), (128, 40, 0), (21, 130, 4), (150, 20, 0), (200, 33, 0), (330, 9, 0)])
+@pytest.mark.parametrize("d,C,lanes", [(16, 70, 4), (40, 33, 0), (100, 70, 0), (100, 17, 4), (61, 16, 0), (128, 40, 0), (21, 130, 4), (150, 20, 0), (200, 33, 0), (330, 9, 0), (256, 20, 0), (512, 9, 4)])
 def test_mala_dense_target_matrix_core_kernel(mhx, oracle, d, C, lanes, real):
     """MALA on the dense Gaussian target (mhx_mala_mfma_kernels.h): w = A y and grad = -A^T w as two triangular GEMMs over the
     16 chains of a wave (v_mfma_*_16x16x4), 4 lanes per chain; the three sums of a step in the reduction shape 4.  Default above
@@ -115,11 +115,8 @@ def test_mala_dense_target_matrix_core_kernel(mhx, oracle, d, C, lanes, real):
     run.init(init)
     run.sample(N, 2, 2, 0)
     st = run.stats()
-    if d == 330 and real == "f64":
-        assert st["kernel_variant"] == 0 and st["reduce_lanes"] == 1       # 83 reals per lane x 4 vectors: past the streamed kernel's registers
-        run.close()
-        return
-    # both images in LDS, or (fp64 d >= 150, every width at d = 200 and 330) streamed from global memory with x and grad(x) in HBM
+    # both images in LDS; or (fp64 d >= 150, every width at d = 200 and 330) streamed from global memory with x and grad(x) in HBM;
+    # or (fp64 d = 256, 330, 512, fp32 d = 512) the LEAN form: one vector per lane, A y and A^T w in place, the noise through its slab
     assert st["kernel_variant"] == 8 and st["reduce_lanes"] == 4
     L = st["reduce_lanes"]
     ref = oracle.mala(ot.with_lanes(L), s2, oracle.schedule(N + 4, 2, 2), 8, 5, C, init)
