@@ -6,5 +6,6 @@ from .api import (I, Banana, Chains, CorrGaussian, DensityModel, Ensemble, Funne
                   RobustAdaptiveMetropolis, Run, RWMH, StaticMH, StaticProposal, combine_diagnostics, StretchProposal,
                   SymmetricRandomWalkProposal, Transition,
                   logdensity, pack_lower, sample, unpack_lower, zeros)
+from . import trace
 
 __all__ = [n for n in dir() if not n.startswith("_")]

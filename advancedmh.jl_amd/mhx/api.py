@@ -210,12 +210,22 @@ class HipLogDensity(_TargetSpec):
 
 
 class DensityModel:
-    """DensityModel(logdensity) -- src/AdvancedMH.jl:52-54."""
+    """DensityModel(logdensity) -- src/AdvancedMH.jl:52-54.  `logdensity` is a catalogue log-density, HipLogDensity(source, dim),
+    or a Python callable of the parameter vector together with `dim`: the callable is traced once (mhx/trace.py) and lowered
+    to the HIP source form, with its reverse-mode gradient (MALA) unless gradient=False."""
 
-    def __init__(self, logdensity):
+    def __init__(self, logdensity, dim=None, gradient=True):
+        self.traced = None
         if callable(logdensity) and not isinstance(logdensity, _TargetSpec):
-            raise L.ArgumentError(L.MHX_EINVAL, "a Python callable cannot be lowered to the GPU; pass a catalogue "
-                                  "log-density or HipLogDensity(source, dim)")
+            if dim is None:
+                raise L.ArgumentError(L.MHX_EINVAL, "DensityModel(f): pass dim=<number of parameters> so that the callable "
+                                      "can be traced (or a catalogue log-density / HipLogDensity(source, dim))")
+            from . import trace as _trace
+            try:
+                self.traced = _trace.trace(logdensity, dim, gradient=gradient)
+            except _trace.TraceError as e:
+                raise L.ArgumentError(L.MHX_EINVAL, "DensityModel(f): the callable cannot be traced: %s" % e) from e
+            logdensity = HipLogDensity(self.traced.source, dim)
         if not isinstance(logdensity, _TargetSpec):
             raise L.ArgumentError(L.MHX_EINVAL, "DensityModel: unsupported log-density %r" % (logdensity,))
         self.logdensity = logdensity

@@ -28,3 +28,21 @@ chain = mhx.sample(model, spl, 400, 256, param_names=["mu", "sigma"], chain_type
 print(chain)
 print("data: mean %.4f std %.4f;  acceptance rate %.3f;  kernel variant %d" % (
     data.mean(), data.std(), chain.accepted[1:].mean(), chain.stats["kernel_variant"]))
+
+# The same model written the way the README writes it -- a closure over `data` -- traced into kernel source (mhx/trace.py):
+import math  # noqa: E402
+
+import mhx.trace as T  # noqa: E402
+
+
+def density(theta):                                                   # README.md:25-31
+    mu, sigma = theta
+    lp = sum(-0.5 * ((y - mu) / sigma) ** 2 - T.log(sigma) - 0.5 * math.log(2 * math.pi) for y in data)
+    return T.where(sigma >= 0, lp, -math.inf)
+
+
+closure_model = mhx.DensityModel(density, dim=2)
+chain2 = mhx.sample(closure_model, spl, 400, 256, param_names=["mu", "sigma"], chain_type=mhx.Chains, discard_initial=200,
+                    initial_params=np.array([0.0, 1.0]), seed=1234)
+print("closure model (%d traced operations): mean mu %.4f sigma %.4f   [catalogue model: %.4f %.4f]" % (
+    closure_model.traced.n_operations, chain2.mean("mu"), chain2.mean("sigma"), chain.mean("mu"), chain.mean("sigma")))

@@ -93,11 +93,13 @@ typedef double mhx_real;
 #define MHX_R(x) x
 static inline double mhx_fma(double a, double b, double c) { return fma(a, b, c); }
 static inline double mhx_sqrt(double x) { return sqrt(x); }
+static inline double mhx_abs(double x) { return fabs(x); }
 #else
 typedef float mhx_real;
 #define MHX_R(x) x##f
 static inline float mhx_fma(float a, float b, float c) { return fmaf(a, b, c); }
 static inline float mhx_sqrt(float x) { return sqrtf(x); }
+static inline float mhx_abs(float x) { return fabsf(x); }
 #endif
 extern "C" { mhx_real orc_log(mhx_real); mhx_real orc_exp(mhx_real); }
 static inline mhx_real mhx_log(mhx_real x) { return orc_log(x); }
