@@ -79,10 +79,14 @@ MHX_HD long mhx_ram_tri_pad(int d) { return ((((long)d * (d + 1)) / 2 + 3) & ~3L
 typedef mhx_real mhx_f4 __attribute__((ext_vector_type(4)));
 
 // LDS plan of one wave (= one block), in floats:
-//   [ chain 0: ring | mirror ][ chain 1: ring | mirror ] ... [ chain 0: noise, next noise, candidate ][ chain 1 ... ]
+//   [ chain 0: ring | mirror ][ chain 1: ring | mirror ] ... [ chain 0: vector ][ chain 1: vector ] ...
 // ring = 2 chunks of CHF floats, a chunk = NV x (G lanes x 16 B) >= the longest column; the mirror
-// repeats the first G R floats of the ring behind it, so every column is CONTIGUOUS in LDS even when
-// it runs off the end of the ring: a column read is one per-column address plus compile-time offsets.
+// repeats the first d floats (rounded up to 4) of the ring behind it, so every column is CONTIGUOUS in LDS even when
+// it runs off the end of the ring: a column read is one per-column address plus compile-time offsets (row slots past
+// the column read whatever follows -- the vectors, still inside the allocation -- and nothing uses them).
+// ONE d-vector per chain serves, in turn, as the noise U of a step that has to form S U itself, the candidate the
+// target reads, the target's scratch and the NEXT step's noise during the sweep: each dies before the next is written
+// (LDS, not registers, bounds the resident waves: 11.4 KB per wave at d = 200 in fp64, 15 KB with three vectors).
 // The factor of a dense Gaussian target is the same for every chain: the wave streams it ONCE through
 // the same LDS seen as a single ring (64 lanes x 16 B pieces) and all its chains read it from there.
 #ifndef MHX_RAM_NV4_R
@@ -92,9 +96,10 @@ typedef mhx_real mhx_f4 __attribute__((ext_vector_type(4)));
 #define MHX_RAM_NV(R) ((R) <= 8 ? ((MHX_REAL64 && (R) >= MHX_RAM_NV4_R) ? 4 : 2) : 4)
 #define MHX_RAM_CHF(G, R) (MHX_RAM_NV(R) * (G) * 4)
 #define MHX_RAM_RING(G, R) (2 * MHX_RAM_CHF(G, R))
-#define MHX_RAM_MIRF(G, R) ((G) * (R))
-#define MHX_RAM_FIXED_FLOATS(G, R) ((64 / (G)) * (MHX_RAM_RING(G, R) + MHX_RAM_MIRF(G, R)))
-#define MHX_RAM_LDS_FLOATS(G, R, d) (MHX_RAM_FIXED_FLOATS(G, R) + (64 / (G)) * 3 * (d))
+#define MHX_RAM_MIRF(G, R) ((G) * (R))      // upper bound of the mirror (compile time); mhx_ram_mirror(d) reals are kept
+MHX_HD int mhx_ram_mirror(int d) { return (d + 3) & ~3; }
+MHX_HD int mhx_ram_rings(int ring_f, int d) { return ring_f + mhx_ram_mirror(d); }
+#define MHX_RAM_LDS_FLOATS(G, R, d) ((64 / (G)) * (mhx_ram_rings(MHX_RAM_RING(G, R), d) + mhx_ram_mirror(d)))
 
 
 // Streaming a packed factor: GS lanes pull one contiguous array in full-width pieces -- NV x (GS lanes
@@ -141,7 +146,7 @@ struct mhx_ram_stream {
         if (!(committed & 1)) {
 #pragma unroll
             for (int v = 0; v < NV; ++v)
-                if (4 * v * GS < MIRF && (4 * (v + 1) * GS <= MIRF || mirror_lane(v))) lds4[r4 + 2 * NV * GS + v * GS] = regs[v];
+                if (4 * v * GS < MIRF && mirror_lane(v)) lds4[r4 + 2 * NV * GS + v * GS] = regs[v];
         }
         ++committed;
         avail = committed * CHF < tri ? committed * CHF : tri;
@@ -157,7 +162,7 @@ struct mhx_ram_stream {
         lds4 = (mhx_f4*)lds;
         r4 = (ring_f >> 2) + tg;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) mlane[v] = 4 * (v * GS + tg) < MIRF;
+        for (int v = 0; v < NV; ++v) mlane[v] = 4 * (v * GS + tg) < mhx_ram_mirror(d);
         tri = d * (d + 1) / 2;
         nchunks = (tri + CHF - 1) / CHF;
         committed = 0;
@@ -228,7 +233,7 @@ MHX_DEV void mhx_ram_matvec(const mhx_srd srd, const mhx_u32 chain_byte_off, con
 {
     constexpr int GS = SHARED ? 64 : G;
     const int g = lane / G, tg = lane % G;
-    const int ring = SHARED ? 0 : g * (MHX_RAM_RING(G, R) + MHX_RAM_MIRF(G, R));
+    const int ring = SHARED ? 0 : g * mhx_ram_rings(MHX_RAM_RING(G, R), d);
     mhx_ram_matvec_f<G, R> f;
     f.lds = lds; f.ring = ring + tg; f.ush = ush; f.tg = tg;
 #pragma unroll
@@ -346,7 +351,7 @@ template <int G, int R, int TK>
 MHX_DEV void mhx_ram_body(const mhx_ram_args& a, const mhx_real* __restrict__ tparams, mhx_real* lds)
 {
     constexpr int CPW = 64 / G;                  // chains per wave (= per block)
-    constexpr int RINGS = MHX_RAM_RING(G, R) + MHX_RAM_MIRF(G, R);
+    const int RINGS = mhx_ram_rings(MHX_RAM_RING(G, R), a.dim);
     // XCD-aware mapping: blocks b, b+8, ... run on one XCD; give them consecutive chain groups
     const int nb = gridDim.x;
     const int per = (nb + 7) >> 3;
@@ -364,9 +369,9 @@ MHX_DEV void mhx_ram_body(const mhx_ram_args& a, const mhx_real* __restrict__ tp
     const mhx_philox_key ks = mhx_philox_schedule(a.seed);
     // per-lane LDS mhx_real offsets (the LDS base stays wave-uniform)
     const int ring = g * RINGS;                                         // 16-byte aligned
-    int ucur = CPW * RINGS + g * 3 * d;   // [d] noise of the current step (dead after its mat-vec: target scratch)
-    int unxt = ucur + d;                  // [d] noise of the next step (fused mat-vec)
-    const int ysh = ucur + 2 * d;         // [d] candidate
+    const int ucur = CPW * RINGS + g * mhx_ram_mirror(d);   // [d] noise of a step that forms S U itself (dead after that mat-vec), then target scratch
+    const int unxt = ucur;                // [d] noise of the next step (fused mat-vec): drawn after the target is done with ysh / ucur
+    const int ysh = ucur;                 // [d] candidate (written after S U has consumed the noise)
     // both buffers of every chain of this wave through one descriptor; idle groups read chain c0
     const mhx_srd srd = mhx_make_srd(a.S + c0 * 2 * tri_pad, (mhx_u32)(CPW * 2 * tri_pad * MHX_RB));
     const mhx_srd srd_a = mhx_make_srd(a.acol, (mhx_u32)(tri_pad * MHX_RB));
@@ -492,7 +497,6 @@ MHX_DEV void mhx_ram_body(const mhx_ram_args& a, const mhx_real* __restrict__ tp
                 for (int r = 0; r < R; ++r) v[r] = ok ? sw.vn[r] : sw.vo[r];
                 nn = nn_next;
                 have_v = true;
-                const int sp = ucur; ucur = unxt; unxt = sp;
             }
         }
 

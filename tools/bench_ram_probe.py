@@ -24,7 +24,7 @@ for name in sys.argv[1:] or ["iso", "corr"]:
     for phase, (n, nad) in (("adapting", (100, 100)), ("fixed", (100, 0))):
         run.sample(1, n, 1, nad, save=False)
         st = run.stats()
-        tri = d * (d + 1) // 2 * 4
+        tri = d * (d + 1) // 2 * (8 if mhx.get_default_dtype() == "f64" else 4)
         per = (2 * tri if nad else tri)
         print(json.dumps(dict(target=name, phase=phase, steps_per_s=st["transitions"] / (st["kernel_ms"] * 1e-3),
                               kernel_ms=st["kernel_ms"], acceptance=st["accepted"] / st["transitions"],
