@@ -146,6 +146,49 @@ static void run_flat(f4* in, f4* out, long n4, int grid)
     printf("flat float4 copy, grid %-7d     %.1f GB/s\n", grid, (double)n4 * 32.0 * reps / (ms * 1e-3) / 1e9);
 }
 
+
+// the RAM sweep's residency (8 - 12 waves per CU, set by dynamic LDS) and two layouts of the segments: private contiguous 80 KB
+// (PRIVATE) or chunk-interleaved (chunk k of segment s at (k nseg + s) chunks: waves in step read one contiguous region)
+template <int NV, bool ILV>
+__global__ void __launch_bounds__(64) k_stream_res(const f4* __restrict__ in, f4* __restrict__ out, int nvec, long stride4, int nseg)
+{
+    extern __shared__ float pad[];
+    const long seg = blockIdx.x;
+    const int t = threadIdx.x;
+    const int nch = nvec / (NV * 64);
+    auto at = [&](int k, int v) -> long { return ILV ? ((long)k * nseg + seg) * (NV * 64) + v * 64 + t : seg * stride4 + (long)(k * NV + v) * 64 + t; };
+    f4 regs[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) regs[v] = in[at(0, v)];
+    for (int k = 0; k < nch; ++k) {
+        f4 cur[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) cur[v] = regs[v];
+        if (k + 1 < nch) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) regs[v] = in[at(k + 1, v)];
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) out[at(k, v)] = cur[v] * 1.0001f;
+    }
+    if (nvec < 0) pad[t] = 0.0f;
+}
+template <int NV, bool ILV>
+static void run_res(f4* in, f4* out, int nseg, int nvec, long stride4, int lds_bytes)
+{
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((k_stream_res<NV, ILV>), dim3(nseg), dim3(64), lds_bytes, 0, in, out, nvec, stride4, nseg);
+    hipEventRecord(e0);
+    const int reps = 10;
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((k_stream_res<NV, ILV>), dim3(nseg), dim3(64), lds_bytes, 0, in, out, nvec, stride4, nseg);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double bytes = (double)nseg * (nvec / (NV * 64)) * (NV * 64) * 32.0 * reps;
+    printf("copy, %-11s NV=%d, %2d waves per CU  %.1f GB/s\n", ILV ? "interleaved" : "private", NV, 163840 / lds_bytes, bytes / (ms * 1e-3) / 1e9);
+}
+
 template <int NV, bool WRITE>
 static void run(const char* name, f4* in, f4* out, float* sink, int nseg, int nvec, long stride4)
 {
@@ -183,6 +226,12 @@ int main()
     run_dma<1>(in, out, nseg, nvec, stride4);
     run_dma<2>(in, out, nseg, nvec, stride4);
     run_dma<4>(in, out, nseg, nvec, stride4);
+    for (int lds : {20000, 13600, 10000, 5000}) {
+        run_res<4, false>(in, out, nseg, nvec, stride4, lds);
+        run_res<4, true>(in, out, nseg, nvec, stride4, lds);
+        run_res<8, false>(in, out, nseg, nvec, stride4, lds);
+        run_res<8, true>(in, out, nseg, nvec, stride4, lds);
+    }
     run_fill(out, (long)nseg * stride4);
     run_flat(in, out, (long)nseg * stride4, 2048);
     run_flat(in, out, (long)nseg * stride4, 8192);
