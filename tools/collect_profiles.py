@@ -17,6 +17,8 @@ def main(tags):
     traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
     for tag in tags:
         for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", tag + "_*"))):
+            if not os.path.isdir(d):
+                continue
             name = os.path.basename(d)                       # <tag>_<cfg>_<dtype>
             _, cfg, dt = name.rsplit("_", 2)
             sj = os.path.join(d, "summary.json")
