@@ -214,21 +214,25 @@ class DensityModel:
     or a Python callable of the parameter vector together with `dim`: the callable is traced once (mhx/trace.py) and lowered
     to the HIP source form, with its reverse-mode gradient (MALA) unless gradient=False."""
 
-    def __init__(self, logdensity, dim=None, gradient=True):
+    def __init__(self, logdensity, dim=None, gradient=True, names=None):
         self.traced = None
+        if names is not None:                   # the closure reads its parameters by name (x.a, x["a"]): test/runtests.jl:184
+            names = [str(n) for n in names]
+            dim = len(names) if dim is None else dim
         if callable(logdensity) and not isinstance(logdensity, _TargetSpec):
             if dim is None:
                 raise L.ArgumentError(L.MHX_EINVAL, "DensityModel(f): pass dim=<number of parameters> so that the callable "
                                       "can be traced (or a catalogue log-density / HipLogDensity(source, dim))")
             from . import trace as _trace
             try:
-                self.traced = _trace.trace(logdensity, dim, gradient=gradient)
+                self.traced = _trace.trace(logdensity, dim, gradient=gradient, names=names)
             except _trace.TraceError as e:
                 raise L.ArgumentError(L.MHX_EINVAL, "DensityModel(f): the callable cannot be traced: %s" % e) from e
             logdensity = HipLogDensity(self.traced.source, dim)
         if not isinstance(logdensity, _TargetSpec):
             raise L.ArgumentError(L.MHX_EINVAL, "DensityModel: unsupported log-density %r" % (logdensity,))
         self.logdensity = logdensity
+        self.param_names = names
         self._handles = {}
 
     @property
@@ -296,9 +300,29 @@ class StaticProposal:
 
 
 class MetropolisHastings:
-    """MetropolisHastings(proposal) -- src/mh-core.jl:44-46."""
+    """MetropolisHastings(proposal) -- src/mh-core.jl:44-46.  `proposal`: a RandomWalkProposal / StaticProposal, or -- the
+    reference's NamedTuple of proposals, test/runtests.jl:136-160, :187 -- a dict {name: proposal} of scalar Normal proposals
+    of ONE kind (all random-walk or all static); its keys name the parameters (src/AdvancedMH.jl:96-104)."""
 
     def __init__(self, proposal):
+        self.param_names = None
+        if isinstance(proposal, dict):
+            if not proposal:
+                raise L.ArgumentError(L.MHX_EINVAL, "MetropolisHastings: empty proposal")
+            kinds = {type(p) for p in proposal.values()}
+            if kinds not in ({RandomWalkProposal}, {StaticProposal}):
+                raise L.ArgumentError(L.MHX_EINVAL, "a NamedTuple of proposals is lowered when every entry is a RandomWalkProposal or "
+                                      "every entry is a StaticProposal (mixed / function proposals stay on the CPU reference)")
+            parts = list(proposal.values())
+            if any(q.proposal.dim != 1 for q in parts):
+                raise L.ArgumentError(L.MHX_EINVAL, "a NamedTuple of proposals takes one scalar Normal per name")
+            mv = MvNormal([float(q.proposal.mean[0]) for q in parts],
+                          np.array([float(q.proposal.vec[0]) ** 2 if q.proposal.kind == L.PROP_DIAG else q.proposal.scale ** 2 for q in parts]))
+            self.param_names = [str(k) for k in proposal]
+            if kinds == {StaticProposal}:
+                proposal = StaticProposal(mv)
+            else:
+                proposal = RandomWalkProposal(mv, all(q.issymmetric for q in parts))
         if not isinstance(proposal, (RandomWalkProposal, StaticProposal)):
             raise L.ArgumentError(L.MHX_EINVAL, "the GPU path implements RandomWalkProposal and StaticProposal "
                                   "over (Mv)Normal distributions only")
@@ -774,6 +798,8 @@ def sample(model, sampler, N, nchains=1, *more, initial_params=None, discard_ini
             callback(run, i)
         value, acc = np.concatenate(chunks, axis=0), np.concatenate(accs, axis=0)
     d = model.dim
+    if param_names is None:                                         # a NamedTuple of proposals / named parameters carry their names
+        param_names = getattr(sampler, "param_names", None) or getattr(model, "param_names", None)
     if param_names is None:
         names = ["param_%d" % (i + 1) for i in range(d)]           # src/AdvancedMH.jl:91
     else:
@@ -785,4 +811,47 @@ def sample(model, sampler, N, nchains=1, *more, initial_params=None, discard_ini
         return Chains(value, names, discard_initial + 1, thinning, accepted=acc, stats=run.stats(), state=run)
     if chain_type is np.ndarray:
         return value
-    raise L.ArgumentError(L.MHX_EINVAL, "chain_type must be Chains or numpy.ndarray")
+    if chain_type is StructArray:
+        return StructArray(value, names)
+    if chain_type in (Transition, dict):
+        # Vector{Transition} (the reference's default container, src/mh-core.jl:76-117) / Vector{NamedTuple}
+        # (ext/AdvancedMHStructArraysExt.jl, src/AdvancedMH.jl:96-125: the parameters by name, then lp): one list per chain,
+        # the bare list for a single chain
+        out = bundle_samples(value, acc, names, chain_type)
+        return out[0] if value.shape[2] == 1 else out
+    raise L.ArgumentError(L.MHX_EINVAL, "chain_type must be Chains, numpy.ndarray, StructArray, Transition or dict")
+
+
+class StructArray:
+    """chain_type=StructArray (ext/AdvancedMHStructArraysExt.jl; test/runtests.jl:63-73 reads `chain.μ`): one array per
+    parameter and `lp`, [iteration] for a single chain, [iteration, chain] otherwise -- views of the sample tensor."""
+
+    def __init__(self, value, names):
+        self._names = list(names)
+        for k, n in enumerate(self._names):
+            col = value[:, k, :]
+            self.__dict__[n] = col[:, 0] if value.shape[2] == 1 else col
+
+    def __getitem__(self, name):
+        return self.__dict__[name]
+
+    def keys(self):
+        return tuple(self._names)
+
+    def __len__(self):
+        return len(self.__dict__[self._names[0]])
+
+
+def bundle_samples(value, accepted, names, chain_type):
+    """Host reshaping of the sample tensor value[iteration, parameter (+ lp), chain] into per-chain lists of Transition
+    (params, lp, accepted) or of dicts {name: value, ..., "lp": lp} -- what the reference's bundle_samples methods build
+    (src/AdvancedMH.jl:96-125)."""
+    N, d1, C = value.shape
+    out = []
+    for c in range(C):
+        if chain_type is Transition:
+            out.append([Transition(value[i, :d1 - 1, c].copy(), value[i, d1 - 1, c], bool(accepted[i, c]) if accepted is not None else None)
+                        for i in range(N)])
+        else:
+            out.append([dict(zip(names, value[i, :, c].tolist())) for i in range(N)])
+    return out

@@ -28,7 +28,7 @@ import math
 
 import numpy as np
 
-__all__ = ["log", "exp", "sqrt", "abs", "fma", "where", "minimum", "maximum", "square", "trace", "Traced", "Sym", "Vec", "TraceError"]
+__all__ = ["log", "exp", "sqrt", "abs", "fma", "where", "minimum", "maximum", "square", "trace", "Traced", "Sym", "Vec", "NamedVec", "TraceError"]
 
 
 class TraceError(TypeError):
@@ -561,14 +561,37 @@ class Traced:
         return sum(1 for i in self._reachable([self.out]) if self.g.nodes[i][0] not in ("c", "x"))
 
 
-def trace(f, dim, gradient=True):
-    """Run `f` once on a vector of `dim` traced parameters and return the recorded program (a `Traced`)."""
+class NamedVec(Vec):
+    """Parameters that also answer to their names: x.a, x["a"] (the reference's NamedTuple parameters, test/runtests.jl:184)."""
+
+    def __init__(self, items, names):
+        Vec.__init__(self, items)
+        self.__dict__["_names"] = {n: k for k, n in enumerate(names)}
+
+    def __getattr__(self, name):
+        names = self.__dict__.get("_names", {})
+        if name in names:
+            return self.items[names[name]]
+        raise AttributeError(name)
+
+    def __getitem__(self, k):
+        if isinstance(k, str):
+            return self.items[self._names[k]]
+        return Vec.__getitem__(self, k)
+
+
+def trace(f, dim, gradient=True, names=None):
+    """Run `f` once on a vector of `dim` traced parameters and return the recorded program (a `Traced`).  With `names` the
+    parameters are also reachable as x.<name> / x["<name>"]."""
     dim = int(dim)
     if dim < 1:
         raise TraceError("dim must be >= 1")
+    if names is not None and len(names) != dim:
+        raise TraceError("names: %d given for %d parameters" % (len(names), dim))
     g = _Graph()
     g.node("c", _const_key(0.0))        # node 0: lets where() lift plain numbers without a Sym at hand
-    x = Vec([Sym(g, g.node("x", k)) for k in range(dim)])
+    x = [Sym(g, g.node("x", k)) for k in range(dim)]
+    x = NamedVec(x, names) if names is not None else Vec(x)
     out = f(x)
     if isinstance(out, Vec) and len(out) == 1:
         out = out[0]
