@@ -19,7 +19,8 @@ DESIGN.md section 7 and the HIP-event launch time measured here; `cpu_baseline` 
 reference algorithm, oracle/, rebuilt -O3 -march=native on the host that times it) on a bounded sample -- rank 0, N=1 only.
 At N=1 the default (c2) run also carries, all measured after the timed region:
   `e2e_host`  the rate THROUGH the boundary -- samples back on the host (mhx_run_sample_to_host), save-all and thinned;
-  `configs`   the other BASELINE.json GPU configs (c3, c4, c4_moving, c5): value, roofline and cpu_baseline each;
+  `configs`   the other BASELINE.json GPU configs and their SURVEY 8(d) variants (c2_literal, c3, c3_rotated, c4, c4_moving,
+              c4_fixed, c5, c5_banana): value, roofline and cpu_baseline each;
   `ess`       the ESS/sec window;  `f32` the fp32 engine on the same workload.
 """
 import argparse
@@ -167,14 +168,23 @@ class C5(C2):
         self.d, self.C, self.inner, self.dtype = args.dim or 1000, args.chains or 32768, args.inner or 200, dtype
         self.lanes = args.lanes
         self.gen = pick_gen(args, dtype)
+        self.banana = getattr(args, "c5_banana", False)    # x2 <- x2 + b (x1^2 - 100), b = 0.03
 
     def build(self, mhx, ctx, rank):
         import numpy as np
         d = self.d
         self.s = float(np.float32(2.38 / d ** 0.5))
         spl = mhx.RWMH(mhx.MvNormal(mhx.zeros(d), self.s * self.s * mhx.I))
-        self.run = mhx.Run(mhx.DensityModel(mhx.Funnel(d)), spl, nchains=self.C, seed=5, first_chain=rank * self.C, ctx=ctx,
+        model = mhx.DensityModel(mhx.Banana(d, 0.03) if self.banana else mhx.Funnel(d))
+        self.run = mhx.Run(model, spl, nchains=self.C, seed=5, first_chain=rank * self.C, ctx=ctx,
                            reduce_lanes=self.lanes, normal_gen=self.gen)
+        if self.banana:                 # a stationary start: x1 ~ N(0, 100), x2 = z - b (x1^2 - 100), the rest N(0, 1)
+            rng = np.random.default_rng(2000 + rank)
+            x0 = rng.normal(size=(d, self.C))
+            x0[0] *= 10.0
+            x0[1] -= 0.03 * (x0[0] ** 2 - 100.0)
+            self.run.init(x0)
+            return self.run
         # a stationary start (a draw from the funnel itself: v ~ N(0, 9), x_k ~ N(0, e^v)) instead of a burn-in: from the
         # proposal-scale start of init(None) the chains spend thousands of transitions inflating |x|^2
         rng = np.random.default_rng(1000 + rank)
@@ -197,12 +207,12 @@ class C5(C2):
         return "state + running-moments round trip per launch (the chain state never leaves the registers inside a launch)"
 
     def describe(self):
-        return ("RWMH, 1000-dim Neal's funnel, %d chains per GPU (global ids: shard of 8 x 32 768), proposal N(0,(2.38/sqrt(d))^2 I), "
+        return ("RWMH, 1000-dim %s, %d chains per GPU (global ids: shard of 8 x 32 768), proposal N(0,(2.38/sqrt(d))^2 I), "
                 "%d transitions per launch, running moments of every 10th state, R-hat by one all-reduce; standard normals by %s" % (
-                    self.C, self.inner, GEN_TEXT[self.gen]))
+                    "banana (b = 0.03 on N(0, diag(100, 1, ...)))" if self.banana else "Neal's funnel", self.C, self.inner, GEN_TEXT[self.gen]))
 
     def cpu_baseline(self, O, target_seconds):
-        tgt = O.Target(O.TARGET_FUNNEL, self.d)
+        tgt = O.Target(O.TARGET_BANANA, self.d, params=[0.03]) if self.banana else O.Target(O.TARGET_FUNNEL, self.d)
         prop = O.Proposal(O.PROP_ISO, self.s, normal_gen=1 if self.gen == "ziggurat" else 0)
         inner = self.inner
 
@@ -210,7 +220,7 @@ class C5(C2):
             O.rwmh(tgt, prop, O.schedule(1, inner), 5, i * nchains, nchains, save=False)
         cores = host_cores()
         n, dt = threads_rate(work, cores, target_seconds)
-        return n * inner, dt, cores, "%d chains x %d transitions of the same d=%d funnel" % (n, inner, self.d)
+        return n * inner, dt, cores, "%d chains x %d transitions of the same d=%d %s" % (n, inner, self.d, "banana" if self.banana else "funnel")
 
 
 class C3:
@@ -282,6 +292,7 @@ class C4:
     def __init__(self, args, dtype):
         self.d, self.C, self.inner, self.dtype = args.dim or 200, args.chains or 32768, args.inner or 100, dtype
         self.moving = args.c4_moving
+        self.fixed = getattr(args, "c4_fixed", False)      # "... + 500 fixed steps": S frozen after a warm-up
 
     def build(self, mhx, ctx, rank):
         import numpy as np
@@ -297,10 +308,13 @@ class C4:
             self.run.init(L @ np.random.default_rng(11).normal(size=(d, self.C)))
         else:
             self.run.init(np.zeros(d))                      # x0 = 0, S0 = I
+        if self.fixed:
+            self.run.sample(1, self.inner, 1, self.inner, save=False)   # a warm-up first: the timed steps run on adapted factors
         return self.run
 
     def step(self):
-        self.run.sample(1, self.inner, 1, self.inner, save=False)      # `inner` adapting transitions (step_warmup)
+        # `inner` adapting transitions (step_warmup), or `inner` transitions with the factor frozen (RAM.jl:216-237)
+        self.run.sample(1, self.inner, 1, 0 if self.fixed else self.inner, save=False)
         return self.run.stats()
 
     def units_per_step(self):
@@ -309,16 +323,21 @@ class C4:
     def bytes_per_launch(self):
         """one read + one write of the packed factor per adapting step, B d(d+1) + 2Bd + 2B"""
         B = RB[self.dtype]
+        if self.fixed:
+            return self.C * self.inner * (B * self.d * (self.d + 1) // 2 + 2 * B * self.d + 2 * B)
         return self.C * self.inner * (B * self.d * (self.d + 1) + 2 * B * self.d + 2 * B)
 
     def bytes_model(self):
         B = RB[self.dtype]
+        if self.fixed:
+            return "per fixed-factor step 1 read of the packed factor: %d d(d+1)/2 + %d d + %d" % (B, 2 * B, 2 * B)
         return "per adapting step 1 read + 1 write of the packed factor: %d d(d+1)/2 x 2 + %d d + %d" % (B, 2 * B, 2 * B)
 
     def describe(self):
         return ("RobustAdaptiveMetropolis (alpha 0.234, gamma 0.6), %d-dim Gaussian, kappa = 1e3 (Q diag Q^T), %d chains per GPU each "
-                "with its own factor, %d adapting transitions per launch, %s" % (
-                    self.d, self.C, self.inner, "random start, S0 = 2.38/sqrt(d) I (the variant that moves)" if self.moving else "x0 = 0, S0 = I"))
+                "with its own factor, %d %s transitions per launch, %s" % (
+                    self.d, self.C, self.inner, "fixed-factor (after %d adapting ones)" % self.inner if self.fixed else "adapting",
+                    "random start, S0 = 2.38/sqrt(d) I (the variant that moves)" if self.moving else "x0 = 0, S0 = I"))
 
     def cpu_baseline(self, O, target_seconds):
         import numpy as np
@@ -326,14 +345,17 @@ class C4:
         inner, d = self.inner, self.d
         init1 = np.zeros((d, 1))
 
+        warm = 0 if self.fixed else inner                  # fixed-factor steps: the oracle's steps on S0 cost what they cost on any S
+
         def work(i, nchains):
-            O.ram(tgt, O.schedule(1, inner, 1, inner), 4, i * nchains, nchains, init=np.zeros((d, nchains)), save=False)
+            O.ram(tgt, O.schedule(1, inner, 1, warm), 4, i * nchains, nchains, init=np.zeros((d, nchains)), save=False)
         t0 = time.perf_counter()
-        O.ram(tgt, O.schedule(1, 20, 1, 20), 4, 0, 1, init=init1, save=False)
+        O.ram(tgt, O.schedule(1, 20, 1, 20 if warm else 0), 4, 0, 1, init=init1, save=False)
         rate1 = 20 / (time.perf_counter() - t0)
         cores = host_cores()
         n, dt = threads_rate(work, cores, target_seconds)
-        return n * inner, dt, cores, "%d chains x %d adapting transitions of the same d=%d workload; single thread %.3g steps/s" % (n, inner, d, rate1)
+        return n * inner, dt, cores, "%d chains x %d %s transitions of the same d=%d workload; single thread %.3g steps/s" % (
+            n, inner, "fixed-factor" if self.fixed else "adapting", d, rate1)
 
 
 WORKLOADS = {"c2": C2, "c3": C3, "c4": C4, "c5": C5}
@@ -480,7 +502,9 @@ def roofline_block(wl, name, dtype, kernel_ms, steps, st):
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath)).get(key, {})
-            if tj.get("units_per_launch") == wl.units_per_step():
+            # (a variant whose kernel or byte count differs from the profiled one carries no PMC figures)
+            own_pmc = not (getattr(wl, "fixed", False) or getattr(wl, "banana", False) or getattr(wl, "rotated", False))
+            if own_pmc and tj.get("units_per_launch") == wl.units_per_step():
                 traffic = tj.get("hbm_bytes_per_launch")
                 if tj.get("valu_insts_per_launch"):
                     rate = tj["valu_insts_per_launch"] / launch_s
@@ -499,18 +523,20 @@ def roofline_block(wl, name, dtype, kernel_ms, steps, st):
 
 def other_configs(mhx, ctx, args, barrier):
     """The other BASELINE.json GPU configs in the same driver run (N = 1, rank 0, after the headline's timed region): value,
-    roofline of the dominant kernel and a CPU baseline (2 s samples) for C3, C4 as specified, C4 from a start that moves, and
-    C5's per-GPU shard.  Fewer steps than the headline (C4 runs 0.26 s per step): every figure says how many."""
+    roofline of the dominant kernel and a CPU baseline (2 s samples) for C2 with the literal N(0, I) proposal, C3 (and its
+    dense-rotated variant), C4 as specified, from a start that moves, and with the factor frozen, and C5's per-GPU shard on the
+    funnel and on the banana.  Fewer steps than the headline (C4 runs 0.26 s per step): every figure says how many."""
     import copy
-    plan = [("c3", "c3", {}, 10, 10), ("c3_rotated", "c3", {"c3_rotated": True}, 10, 10), ("c4", "c4", {}, 3, 2),
-            ("c4_moving", "c4", {"c4_moving": True}, 3, 2), ("c5", "c5", {}, 10, 10)]
+    plan = [("c2_literal", "c2", {"c2_literal": True}, 20, 10),
+            ("c3", "c3", {}, 10, 10), ("c3_rotated", "c3", {"c3_rotated": True}, 10, 10), ("c4", "c4", {}, 3, 2),
+            ("c4_moving", "c4", {"c4_moving": True}, 3, 2), ("c4_fixed", "c4", {"c4_fixed": True}, 3, 2),
+            ("c5", "c5", {}, 10, 10), ("c5_banana", "c5", {"c5_banana": True}, 10, 10)]
     res = {}
     for key, name, over, steps, spin in plan:
         try:
             a = copy.copy(args)
             a.inner = a.chains = a.dim = a.lanes = 0
-            a.c4_moving = False
-            a.c3_rotated = False
+            a.c4_moving = a.c4_fixed = a.c3_rotated = a.c5_banana = a.c2_literal = False
             for k, v in over.items():
                 setattr(a, k, v)
             w = WORKLOADS[name](a, args.dtype)
@@ -586,6 +612,8 @@ def main():
     ap.add_argument("--c2-literal", action="store_true", help="c2: proposal N(0, I) as the config text reads (acceptance ~ 0 at d = 100) "
                     "instead of the tuned 2.38/sqrt(d)")
     ap.add_argument("--c3-rotated", action="store_true", help="c3: the dense-rotated variant Sigma = Q (0.9^|i-j|) Q^T (no banded factor)")
+    ap.add_argument("--c4-fixed", action="store_true", help="c4: the fixed-factor steps that follow the warm-up (1 read of S per step)")
+    ap.add_argument("--c5-banana", action="store_true", help="c5: the banana target of SURVEY 8(d) (ii) instead of Neal's funnel")
     ap.add_argument("--c4-moving", action="store_true", help="c4: random start and S0 = 2.38/sqrt(d) I instead of x0 = 0, S0 = I")
     ap.add_argument("--normal-gen", choices=["auto", "ziggurat", "box-muller"], default="auto",
                     help="c2 / c5: how the RWMH kernel turns stream bits into standard normals (auto: ziggurat in fp64, Box-Muller in fp32)")
