@@ -976,12 +976,15 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
             const std::string key = "rwmh_coop/l=" + std::to_string(L) + "/nbl=" + std::to_string(NBL) + "/tk=" +
                                     std::to_string(tk) + "/pk=" + std::to_string(pk) + "/w=" + std::to_string(waves_override) +
                                     "/walk=" + std::to_string(walk) + "/gen=" + std::to_string(zig ? 1 : 0) +
-                                    (getenv("MHX_ZIG_PROBE") ? std::string("/zp=") + getenv("MHX_ZIG_PROBE") : std::string());
+                                    (getenv("MHX_ZIG_PROBE") ? std::string("/zp=") + getenv("MHX_ZIG_PROBE") : std::string()) +
+                                    (getenv("MHX_ZIG_FORCE_FAIL") ? std::string("/zff=") + getenv("MHX_ZIG_FORCE_FAIL") : std::string());
             std::vector<std::string> defs = {"MHX_JIT_RWMH_COOP=1", "MHX_JIT_L=" + std::to_string(L), "MHX_JIT_NBL=" + std::to_string(NBL),
                                              "MHX_JIT_TK=" + std::to_string(tk), "MHX_JIT_PK=" + std::to_string(pk), "MHX_JIT_MOM=0",
                                              "MHX_JIT_WALK=" + std::to_string(walk), std::string("MHX_JIT_GEN=") + (zig ? "1" : "0")};
             if (waves_override > 0) defs.push_back("MHX_JIT_WAVES=" + std::to_string(waves_override));
             if (const char* il = getenv("MHX_COOP_INTERLEAVE")) defs.push_back(std::string("MHX_COOP_INTERLEAVE=") + il);   // tuning knob
+            if (const char* zf = getenv("MHX_ZIG_FORCE_FAIL"))             // test knob: see mhx_rwmh_kernels.h (the chains stay valid)
+                if (atoi(zf) > 0) defs.push_back(std::string("MHX_ZIG_FORCE_FAIL=") + std::to_string(atoi(zf)));
             if (const char* zp = getenv("MHX_ZIG_PROBE")) {                // timing probe: the chains of such a run are NOT valid
                 defs.push_back(std::string("MHX_ZIG_PROBE=") + zp);
                 fprintf(stderr, "mhx: MHX_ZIG_PROBE=%s -- timing probe, this run's chains are NOT valid\n", zp);

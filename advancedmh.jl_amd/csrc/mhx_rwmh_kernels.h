@@ -570,6 +570,11 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
                             const double ax = mhx_zig_ax(khi[4 * bb + j], klo[4 * bb + j], xe[4 * bb + j].x);
                             nn[j] = mhx_zig_signed(ax, klo[4 * bb + j]);
                             bool fail = !(ax < xe[4 * bb + j].y);
+#ifdef MHX_ZIG_FORCE_FAIL       // test knob (hiprtc define from the environment): every n-th slot is sent through the fix-up although
+                                // its candidate is inside its rectangle -- the refinement re-derives the same normal, so the chains
+                                // are unchanged while the queue runs through several 64-entry windows per wave-step
+                            fail = fail || ((4 * i + j + lane) % (MHX_ZIG_FORCE_FAIL) == 0);
+#endif
                             if (i == NBL - 1) fail = fail && (k_last + j < d);   // padding dimensions past the end of the vector need no normal
                             fm |= (fail ? 1ull : 0ull) << (4 * i + j);
                         }

@@ -132,3 +132,21 @@ def test_device_normals_pass_distribution_checks(mhx, f64):
     for t in (2.0, 3.0, 4.0388498461095045):
         e = n * 2 * st.norm.sf(t)
         assert abs((np.abs(x) > t).sum() - e) < 5 * np.sqrt(e) + 1, t
+
+
+@pytest.mark.parametrize("every", [3, 7])
+def test_fixup_queue_windows(mhx, oracle, f64, monkeypatch, every):
+    """More than 64 candidates of one wave-step in the fix-up queue (never seen in practice: a dozen fail) -- forced by the
+    MHX_ZIG_FORCE_FAIL test knob, which sends every n-th slot through the queue although its candidate is inside its rectangle;
+    the refinement re-derives the same normal, so the chains must still equal the oracle's bit for bit."""
+    monkeypatch.setenv("MHX_ZIG_FORCE_FAIL", str(every))
+    monkeypatch.setenv("MHX_NO_PREBUILT", "1")
+    for d, C, N, lanes in [(100, 70, 12, 2), (100, 33, 9, 4), (1000, 5, 6, 64), (13, 200, 10, 1)]:
+        model = mhx.DensityModel(mhx.IsoGaussian(d))
+        spl = mhx.RWMH(mhx.MvNormal(mhx.zeros(d), S * S * mhx.I))
+        chain = mhx.sample(model, spl, N, C, seed=77 + d, first_chain=2, reduce_lanes=lanes, normal_gen="ziggurat")
+        assert chain.stats["kernel_variant"] == 4 and chain.stats["normal_gen"] == 1
+        L = chain.stats["reduce_lanes"]
+        ref = oracle.rwmh(oracle.iso_gauss(d, reduce_lanes=L), oracle.Proposal(oracle.PROP_ISO, S, normal_gen=1), oracle.schedule(N), 77 + d, 2, C)
+        _same(chain.value, ref["samples"], "samples d=%d lanes=%d" % (d, lanes))
+        _same(chain.accepted, ref["accepted"], "accepted")
