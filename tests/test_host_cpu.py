@@ -208,3 +208,23 @@ def test_sharded_ensemble_slices_partition_a_half():
                 assert c >= 0 and b == pos
                 pos += c
             assert max(c for _, c in sl) - min(c for _, c in sl) <= 1
+
+
+def test_bench_byte_models_match_the_survey():
+    """roofline.achieved = algorithmic bytes / kernel time: the per-unit figures of SURVEY.md 8(d) in both widths (fp64 doubles
+    every real; the accept flag stays one byte)."""
+    import argparse
+    import bench
+    ns = argparse.Namespace(dim=0, chains=0, inner=0, lanes=0, c2_literal=False, c3_rotated=False, c4_moving=False, c4_fixed=False,
+                            c5_banana=False, normal_gen="auto")
+    for dt, B in (("f32", 4), ("f64", 8)):
+        c2 = bench.WORKLOADS["c2"](ns, dt)
+        per_step = c2.bytes_per_launch() / (c2.C * c2.inner)
+        assert abs(per_step - (B * 101 + 1 + 2 * (B * 100 + B + 4 + 1) / c2.inner)) < 1e-6        # 405 B/step as K -> inf (fp32); + x, lp, counter, flag per launch
+        c3 = bench.WORKLOADS["c3"](ns, dt)
+        assert c3.bytes_per_launch() / c3.units_per_step() == 3 * B * 50 + 2 * B + B * 51 + 1      # 813 B/move (fp32)
+        c4 = bench.WORKLOADS["c4"](ns, dt)
+        assert c4.bytes_per_launch() / c4.units_per_step() == B * 200 * 201 + 2 * B * 200 + 2 * B  # 162.4 KB/step (fp32)
+    ns.c4_fixed = True
+    c4f = bench.WORKLOADS["c4"](ns, "f32")
+    assert c4f.bytes_per_launch() / c4f.units_per_step() == 4 * 200 * 201 // 2 + 8 * 200 + 8
