@@ -19,8 +19,8 @@ DESIGN.md section 7 and the HIP-event launch time measured here; `cpu_baseline` 
 reference algorithm, oracle/, rebuilt -O3 -march=native on the host that times it) on a bounded sample -- rank 0, N=1 only.
 At N=1 the default (c2) run also carries, all measured after the timed region:
   `e2e_host`  the rate THROUGH the boundary -- samples back on the host (mhx_run_sample_to_host), save-all and thinned;
-  `configs`   the other BASELINE.json GPU configs and their SURVEY 8(d) variants (c2_literal, c3, c3_rotated, c4, c4_moving,
-              c4_fixed, c5, c5_banana): value, roofline and cpu_baseline each;
+  `configs`   the other BASELINE.json GPU configs and their SURVEY 8(d) variants (c1, c2_literal, c3, c3_rotated, c4,
+              c4_moving, c4_fixed, c5, c5_banana): value, roofline and cpu_baseline each;
   `ess`       the ESS/sec window;  `f32` the fp32 engine on the same workload.
 """
 import argparse
@@ -358,7 +358,53 @@ class C4:
             n, inner, "fixed-factor" if self.fixed else "adapting", d, rate1)
 
 
-WORKLOADS = {"c2": C2, "c3": C3, "c4": C4, "c5": C5}
+class C1:
+    """BASELINE configs[0], the reference's own CPU-runnable case (README.md:18-63): d = 2, Normal(mu, sigma) likelihood of 30
+    data points, RWMH with N(0, I), ONE chain, 100 000 draws.  On a GPU this is plumbing -- a single chain occupies one lane
+    of one wave and runs at the latency of one transition -- reported so that the line says what a user who ports the README
+    example unchanged gets; `chains` > 1 is what the engine is for."""
+    name = "c1"
+
+    def __init__(self, args, dtype):
+        self.d, self.C, self.inner, self.dtype = 2, args.chains or 1, args.inner or 100000, dtype
+
+    def build(self, mhx, ctx, rank):
+        import numpy as np
+        self.data = np.random.default_rng(1234).normal(size=30)
+        model = mhx.DensityModel(mhx.IIDNormal(self.data))
+        self.run = mhx.Run(model, mhx.RWMH(mhx.MvNormal(mhx.zeros(2), mhx.I)), nchains=self.C, seed=1234, first_chain=rank * self.C, ctx=ctx)
+        self.run.init(np.array([0.0, 1.0]))
+        return self.run
+
+    def step(self):
+        self.run.sample(self.inner, 1, 1, 0, save=True)
+        return self.run.stats()
+
+    def units_per_step(self):
+        return self.C * self.inner
+
+    def bytes_per_launch(self):
+        B = RB[self.dtype]
+        return self.C * (self.inner * (B * 3 + 1) + 2 * (B * 2 + B + 5))
+
+    def bytes_model(self):
+        return "record %d(d+1)+1 B per chain-step (a latency-bound single chain: the HBM fraction is not the point)" % RB[self.dtype]
+
+    def describe(self):
+        return ("RWMH, d = 2 Normal(mu, sigma) likelihood of 30 data points (README.md:18-63), proposal N(0, I), %d chain(s) x %d draws, "
+                "every state recorded" % (self.C, self.inner))
+
+    def cpu_baseline(self, O, target_seconds):
+        tgt = O.Target(O.TARGET_IID_NORMAL, 2, params=self.data)
+        prop = O.Proposal(O.PROP_ISO, 1.0)
+        import numpy as np
+        t0 = time.perf_counter()
+        O.rwmh(tgt, prop, O.schedule(self.inner), 1234, 0, 1, init=np.array([[0.0], [1.0]]), save=True)
+        dt = time.perf_counter() - t0
+        return self.inner, dt, 1, "1 chain x %d draws of the same model, one thread (what `sample(model, spl, N)` is)" % self.inner
+
+
+WORKLOADS = {"c1": C1, "c2": C2, "c3": C3, "c4": C4, "c5": C5}
 
 
 _ORACLE_FLAGS = None
@@ -527,7 +573,7 @@ def other_configs(mhx, ctx, args, barrier):
     dense-rotated variant), C4 as specified, from a start that moves, and with the factor frozen, and C5's per-GPU shard on the
     funnel and on the banana.  Fewer steps than the headline (C4 runs 0.26 s per step): every figure says how many."""
     import copy
-    plan = [("c2_literal", "c2", {"c2_literal": True}, 20, 10),
+    plan = [("c1", "c1", {}, 3, 1), ("c2_literal", "c2", {"c2_literal": True}, 20, 10),
             ("c3", "c3", {}, 10, 10), ("c3_rotated", "c3", {"c3_rotated": True}, 10, 10), ("c4", "c4", {}, 3, 2),
             ("c4_moving", "c4", {"c4_moving": True}, 3, 2), ("c4_fixed", "c4", {"c4_fixed": True}, 3, 2),
             ("c5", "c5", {}, 10, 10), ("c5_banana", "c5", {"c5_banana": True}, 10, 10)]
