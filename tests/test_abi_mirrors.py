@@ -1,0 +1,78 @@
+"""The three descriptions of the C ABI's plain structs -- include/mhx.h, the ctypes mirror (mhx/_lib.py) and the Julia glue
+(julia/AdvancedMHHIP.jl) -- must agree field for field (name, order, type); and every entry point the Julia glue `ccall`s must be
+declared in the header.  A drift would corrupt a configuration silently on the other side of the boundary."""
+import ctypes as C
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HDR = open(os.path.join(ROOT, "include", "mhx.h")).read()
+JL = open(os.path.join(ROOT, "advancedmh.jl_amd", "julia", "AdvancedMHHIP.jl")).read()
+
+
+def header_structs():
+    src = re.sub(r"/\*.*?\*/", "", HDR, flags=re.S)
+    out = {}
+    for body, name in re.findall(r"typedef\s+struct\s*\{(.*?)\}\s*(\w+)\s*;", src, flags=re.S):
+        fields = []
+        for decl in body.split(";"):
+            decl = " ".join(decl.split())
+            if not decl:
+                continue
+            m = re.match(r"(const void \*|void \*|int32_t|uint32_t|int64_t|uint64_t|double|float|uint8_t)\s*(.*)$", decl)
+            assert m, "unparsed declaration %r in %s" % (decl, name)
+            for nm in m.group(2).split(","):
+                fields.append((nm.strip().lstrip("*").strip(), m.group(1).strip()))
+        out[name] = fields
+    return out
+
+
+CT = {"int32_t": C.c_int32, "uint32_t": C.c_uint32, "int64_t": C.c_int64, "uint64_t": C.c_uint64, "double": C.c_double,
+      "float": C.c_float, "uint8_t": C.c_uint8, "const void *": C.c_void_p, "void *": C.c_void_p}
+JT = {"int32_t": "Int32", "uint32_t": "UInt32", "int64_t": "Int64", "uint64_t": "UInt64", "double": "Cdouble", "float": "Cfloat",
+      "uint8_t": "UInt8", "const void *": "Ptr{Cvoid}", "void *": "Ptr{Cvoid}"}
+PAIRS = {"mhx_schedule": "Schedule", "mhx_rwmh_cfg": "RwmhCfg", "mhx_emcee_cfg": "EmceeCfg", "mhx_ram_cfg": "RamCfg",
+         "mhx_mala_cfg": "MalaCfg", "mhx_stats": "Stats", "mhx_diag_cfg": "DiagCfg"}
+
+
+def test_ctypes_mirror_matches_the_header():
+    import mhx._lib as L
+    hs = header_structs()
+    for cname, pyname in PAIRS.items():
+        assert cname in hs, "%s not found in include/mhx.h" % cname
+        want = [(n, CT[t]) for n, t in hs[cname]]
+        got = list(getattr(L, pyname)._fields_)
+        assert got == want, "%s vs %s:\n%r\n%r" % (pyname, cname, got, want)
+
+
+def julia_structs():
+    out = {}
+    for name, body in re.findall(r"^struct\s+(\w+)\s*\n(.*?)^end", JL, flags=re.S | re.M):
+        fields = []
+        for part in re.split(r"[;\n]", body):
+            part = part.split("#")[0].strip()
+            if part:
+                n, t = part.split("::")
+                fields.append((n.strip(), t.strip()))
+        out[name] = fields
+    return out
+
+
+def test_julia_structs_match_the_header():
+    hs, js = header_structs(), julia_structs()
+    for cname, jname in PAIRS.items():
+        if jname not in js:                     # the glue only declares the structs it passes
+            continue
+        want = [(n, JT[t]) for n, t in hs[cname]]
+        assert js[jname] == want, "%s vs %s:\n%r\n%r" % (jname, cname, js[jname], want)
+    assert {"Schedule", "RwmhCfg", "EmceeCfg", "RamCfg", "MalaCfg"} <= set(js)
+
+
+def test_every_ccall_of_the_julia_glue_is_declared():
+    declared = set(re.findall(r"\b(mhx_\w+)\s*\(", re.sub(r"/\*.*?\*/", "", HDR, flags=re.S)))
+    called = set(re.findall(r"ccall\(\(:(\w+),", JL))
+    assert called, "no ccall found"
+    assert called <= declared, "ccall of undeclared entry points: %r" % sorted(called - declared)
+    flags = dict(re.findall(r"#define\s+(MHX_FLAG_\w+)\s+(\d+)", HDR))
+    for name, val in re.findall(r"const\s+(MHX_FLAG_\w+)\s*=\s*Int32\((\d+)\)", JL):
+        assert flags.get(name) == val, "%s = %s in the glue, %s in the header" % (name, val, flags.get(name))
