@@ -426,6 +426,10 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
 {
     constexpr int CPW = 64 / L;                    // chains per wave
     constexpr bool ZIG = GEN == MHX_GEN_ZIGGURAT;
+#ifndef MHX_COOP_ZKEEP
+#define MHX_COOP_ZKEEP 1
+#endif
+    constexpr bool ZKEEP = MHX_COOP_ZKEEP && MHX_REAL64 && WALK == MHX_WALK_PLAIN && PK == MHX_PROP_ISO;   // (fp32: a select is one instruction already)
     static_assert(!ZIG || MHX_REAL64, "the ziggurat generator exists in the fp64 engine only");
 #if MHX_REAL64
     extern __shared__ double mhx_coop_lds[];
@@ -512,7 +516,7 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
         // Branch-free over the lane's blocks: a last block past the end of the vector (and the padding
         // dimensions of the final block) computes on zeros -- y = 0 there, and fma(0, 0, q) == q bit for
         // bit, so the partial sums need no predication.
-        mhx_real q = MHX_R(0.0), fwd = MHX_R(0.0), bwd = MHX_R(0.0);
+        mhx_real q = MHX_R(0.0), fwd = MHX_R(0.0), bwd = MHX_R(0.0), y00 = MHX_R(0.0);
 #if MHX_REAL64
         if (ZIG) {
             // phase A: every slot's candidate by the fast path -- table look-up, multiply, compare -- into LDS; the slots that
@@ -635,12 +639,17 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
                     if (WALK == MHX_WALK_DRIFT) { const mhx_real tk = nk + ptt[i][j]; bwd = mhx_fma(tk, tk, bwd); }
                 }
                 if (i == NBL - 1) yk = (k_last + j < d) ? yk : MHX_R(0.0);
-                y[i][j] = yk;
+                // ZKEEP (plain walk, one scale for all dimensions): the registers of the candidate keep the NORMAL instead -- the
+                // accepted state is re-formed as fma(s_acc, n, x) with s_acc = accepted ? s : 0, the same fma (or x itself, exactly)
+                // in one instruction per real where a select of a double takes two.  A padding dimension keeps n = 0: x stays 0.
+                if (ZKEEP) y[i][j] = (i == NBL - 1 && !(k_last + j < d)) ? MHX_R(0.0) : n[j];
+                else y[i][j] = yk;
+                if (i == 0 && j == 0) y00 = yk;
                 const mhx_real sq = mhx_fma(yk, yk, q);
                 if (TK == MHX_TARGET_BANANA && i == 0 && j == 0) {
                     q = l == 0 ? (yk * yk) * MHX_R(0.01) : sq;           // x1 ~ N(0, 100)
                 } else if (TK == MHX_TARGET_BANANA && i == 0 && j == 1) {
-                    const mhx_real y0 = y[0][0];
+                    const mhx_real y0 = y00;
                     const mhx_real u = mhx_fma(tparams[0], mhx_fma(y0, y0, -MHX_R(100.0)), yk);
                     q = l == 0 ? mhx_fma(u, u, q) : sq;
                 } else if (TK == MHX_TARGET_FUNNEL && i == 0 && j == 0) {
@@ -669,7 +678,7 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
         }
         mhx_real lpy;
         if (TK == MHX_TARGET_FUNNEL) {
-            const mhx_real v = __shfl(y[0][0], cw, 64);           // x1 lives in lane l == 0 of the chain
+            const mhx_real v = __shfl(y00, cw, 64);               // x1 lives in lane l == 0 of the chain
             const mhx_real ev = mhx_exp(-v);
             mhx_real r = (v * v) * MHX_ONE_18;
             r = mhx_fma(MHX_R(0.5) * (mhx_real)(d - 1), v, r);
@@ -684,10 +693,11 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
         const mhx_real loga = WALK == MHX_WALK_STATIC ? (lpy - lp) + (qxc - qy)
                             : (WALK == MHX_WALK_DRIFT ? (lpy - lp) + MHX_R(0.5) * (fwd - bwd) : (lpy - lp));
         const bool acc = logu < loga;
+        const mhx_real s_acc = acc ? a.pscale : MHX_R(0.0);
 #pragma unroll
         for (int i = 0; i < NBL; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) x[i][j] = acc ? y[i][j] : x[i][j];
+            for (int j = 0; j < 4; ++j) x[i][j] = ZKEEP ? mhx_fma(s_acc, y[i][j], x[i][j]) : (acc ? y[i][j] : x[i][j]);
         lp = acc ? lpy : lp;
         if (WALK == MHX_WALK_STATIC) qxc = acc ? qy : qxc;
         nacc += acc ? 1u : 0u;
