@@ -12,7 +12,8 @@ export TMPDIR=/tmp
 BENCH="python $REPO/bench.py --config $CFG --dtype $DT --steps 10 --warmup 2 --no-cpu-baseline --no-second-dtype --no-ess --no-other-configs --no-e2e $*"
 cd /tmp
 echo "== bench (unprofiled)"; python $REPO/bench.py --config $CFG --dtype $DT --no-cpu-baseline --no-second-dtype --no-other-configs --no-e2e "$@" 2>/dev/null | tail -1 > $OUT/bench.json; cut -c1-400 $OUT/bench.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktrace -o bench -- $BENCH > $OUT/ktrace.log 2>&1
+# the trace pass runs 100 timed launches so that its average is the steady-state one (the ~20 launches after idle run below the steady clock)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktrace -o bench -- ${BENCH/--steps 10/--steps 100} > $OUT/ktrace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- $BENCH > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- $BENCH > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU --output-format csv -d $OUT/pmc_sq -o bench -- $BENCH > $OUT/pmc_sq.log 2>&1
