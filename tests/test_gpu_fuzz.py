@@ -61,12 +61,16 @@ def test_rwmh_random_configurations(mhx, oracle, case, real):
     spl = mhx.StaticMH(dist) if static else mhx.RWMH(dist)
     init = None if rng.integers(0, 2) else (rng.normal(size=(d, C)) * 0.5).astype(np.float32)
     seed, first = int(rng.integers(1, 1 << 40)), int(rng.integers(0, 1 << 33))
+    # the ziggurat generator (fp64, separable targets, ISO / DIAG proposals: the cooperative kernel) on a third of the eligible cases
+    zig = real == "f64" and tname != "corr" and pname != "dense" and bool(rng.integers(0, 3) == 0)
     chain = mhx.sample(mhx.DensityModel(tgt), spl, N, C, seed=seed, first_chain=first, initial_params=init,
-                       discard_initial=di, thinning=th)
+                       discard_initial=di, thinning=th, normal_gen="ziggurat" if zig else None)
     L = chain.stats["reduce_lanes"]
-    ref = oracle.rwmh(ot(L), oracle.Proposal(mean=mean, static=static, **op), oracle.schedule(N, di, th), seed, first, C, init=init)
-    what = "case %d: d=%d C=%d %s/%s static=%s mean=%s variant=%d L=%d" % (case, d, C, tname, pname, static, mean is not None,
-                                                                        chain.stats["kernel_variant"], L)
+    assert chain.stats["normal_gen"] == (1 if zig else 0)
+    ref = oracle.rwmh(ot(L), oracle.Proposal(mean=mean, static=static, normal_gen=1 if zig else 0, **op), oracle.schedule(N, di, th),
+                      seed, first, C, init=init)
+    what = "case %d: d=%d C=%d %s/%s static=%s mean=%s zig=%s variant=%d L=%d" % (case, d, C, tname, pname, static, mean is not None, zig,
+                                                                               chain.stats["kernel_variant"], L)
     _same(chain.value, ref["samples"], what)
     _same(chain.accepted, ref["accepted"], what)
     x, lp, cnt = chain.state.state()
