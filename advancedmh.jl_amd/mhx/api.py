@@ -228,7 +228,7 @@ class DensityModel:
                 self.traced = _trace.trace(logdensity, dim, gradient=gradient, names=names)
             except _trace.TraceError as e:
                 raise L.ArgumentError(L.MHX_EINVAL, "DensityModel(f): the callable cannot be traced: %s" % e) from e
-            logdensity = HipLogDensity(self.traced.source, dim)
+            logdensity = HipLogDensity(self.traced.source, dim, data=self.traced.data)      # (the rows of its sum_over loops)
         if not isinstance(logdensity, _TargetSpec):
             raise L.ArgumentError(L.MHX_EINVAL, "DensityModel: unsupported log-density %r" % (logdensity,))
         self.logdensity = logdensity

@@ -11,8 +11,10 @@ engine's arithmetic (no re-association, no contraction: `a * b + c` is a product
 one), in the order the Python function performed them; sums run left to right.  Closed-over numbers and numpy arrays
 become literals (exact: hexadecimal floating point; fp32 engines round each literal once).  Control flow on parameter
 VALUES cannot be traced -- `if x[0] > 0:` raises; write `where(x[0] > 0, lp, -inf)` (both sides are evaluated).  Loops
-over Python ranges unroll, so the program grows with the number of operations: meant for the reference's kind of model
-(a few parameters, tens to thousands of data points), not for d = 10^4.
+over Python ranges unroll, so the program grows with the number of operations; a sum over the rows of a data set is
+recorded as ONE loop by `sum_over(data, fn)` -- the rows travel to the device as the log-density's data block, the body is
+traced once, what does not depend on the row is computed outside, and the gradient is one fused adjoint loop over the same
+rows -- so a likelihood over 10^5 points costs a dozen lines of kernel source.
 
     def nig(theta):                       # test/emcee.jl:5-14
         s, m = theta
@@ -28,7 +30,7 @@ import math
 
 import numpy as np
 
-__all__ = ["log", "exp", "sqrt", "abs", "fma", "where", "minimum", "maximum", "square", "trace", "Traced", "Sym", "Vec", "NamedVec", "TraceError"]
+__all__ = ["log", "exp", "sqrt", "abs", "fma", "where", "minimum", "maximum", "square", "sum_over", "trace", "Traced", "Sym", "Vec", "NamedVec", "TraceError"]
 
 
 class TraceError(TypeError):
@@ -41,6 +43,8 @@ class _Graph:
     def __init__(self):
         self.nodes = []                 # (op, args) ; args are node ids, floats (op 'c') or ints (op 'x')
         self.index = {}
+        self.loops, self.data, self.data_len, self.in_loop = [], [], 0, None      # sum_over: rows, offsets into the data block
+        self.loop_group = {}            # loop node -> group key (the loops of one group are emitted as one)
 
     def node(self, op, *args):
         key = (op,) + args
@@ -364,14 +368,118 @@ def _lit(key):
     return "MHX_R(%s)" % key
 
 
+_ACTIVE = []          # graphs being traced (innermost last): sum_over() records into the innermost one
+
+
+def sum_over(data, fn):
+    """sum(fn(row) for row in data), recorded as ONE loop over the rows instead of len(data) copies of fn's operations: `data`
+    (a 1-D array: fn gets a number; 2-D: fn gets the row as a vector) travels to the device as the log-density's data block and
+    the kernel source stays as small as fn.  Everything inside fn that does not depend on the row is computed once, outside the
+    loop.  The sum runs over the rows in order, `acc = acc + term`, from 0.  Outside a trace (plain floats) it is that sum."""
+    arr = np.asarray(data, dtype=np.float64)
+    if arr.ndim not in (1, 2) or arr.size == 0:
+        raise TraceError("sum_over: data must be a non-empty 1-D or 2-D array")
+    rows = arr.reshape(arr.shape[0], -1)
+    if not _ACTIVE:
+        acc = 0.0
+        for r in rows:
+            acc = acc + fn(float(r[0]) if arr.ndim == 1 else Vec([float(v) for v in r]))
+        return acc
+    g = _ACTIVE[-1]
+    if g.in_loop is not None:
+        raise TraceError("sum_over inside sum_over is not supported")
+    lid = len(g.loops)
+    g.loops.append({"off": g.data_len, "n": rows.shape[0], "m": rows.shape[1]})
+    g.data.append(rows.ravel())
+    g.data_len += rows.size
+    lv = [Sym(g, g.node("lv", lid, j)) for j in range(rows.shape[1])]
+    g.in_loop = lid
+    try:
+        r = fn(lv[0] if arr.ndim == 1 else Vec(lv))
+    finally:
+        g.in_loop = None
+    if isinstance(r, (int, float, np.integer, np.floating)):
+        r = Sym(g, g.node("c", _const_key(r)))
+    if not isinstance(r, Sym) or r.g is not g:
+        raise TraceError("sum_over: fn must return one number")
+    node = g.node("loop", lid, r.i)
+    g.loop_group.setdefault(node, ("f", node))
+    return Sym(g, node)
+
+
 class Traced:
     """The recorded program of one log-density: `.source` (HIP source form, with the reverse-mode gradient unless
-    gradient=False), `.dim`, `.evaluate(x)` / `.gradient(x)` (the same program in numpy float64, for checks)."""
+    gradient=False), `.dim`, `.data` (the rows of its sum_over loops, what the source's `data` argument must point to, or
+    None), `.evaluate(x)` / `.gradient(x)` (the same program in numpy float64, for checks)."""
 
     def __init__(self, g, out, dim, gradient=True):
         self.g, self.out, self.dim = g, out, int(dim)
+        self._ld = {}
         self.grad = self._reverse() if gradient else None
+        self.data = np.concatenate(g.data) if g.data else None
         self.source = self._emit()
+
+    # -- which loop (if any) a node is computed in: the loop whose row it depends on
+    def _loop_of(self, i):
+        memo, nodes = self._ld, self.g.nodes
+        stack = [i]
+        while stack:
+            j = stack[-1]
+            if j in memo:
+                stack.pop()
+                continue
+            key = nodes[j]
+            if key[0] == "lv":
+                memo[j] = key[1]
+                stack.pop()
+                continue
+            if key[0] in ("c", "x", "loop"):                  # (a loop node is the finished sum: an outer value)
+                memo[j] = None
+                stack.pop()
+                continue
+            deps = self._deps(j)
+            todo = [d for d in deps if d not in memo]
+            if todo:
+                stack.extend(todo)
+                continue
+            ls = {memo[d] for d in deps} - {None}
+            if len(ls) > 1:
+                raise TraceError("a value depends on the rows of two different sum_over loops")
+            memo[j] = ls.pop() if ls else None
+            stack.pop()
+        return memo[i]
+
+    # -- one operation's vector-Jacobian product: (input node, contribution) pairs for the adjoint z of node i
+    def _vjp(self, i, z):
+        g = self.g
+        S = lambda k: Sym(g, k)
+        key = g.nodes[i]
+        op, a = key[0], key[1:]
+        if op == "add":
+            return [(a[0], z), (a[1], z)]
+        if op == "sub":
+            return [(a[0], z), (a[1], -z)]
+        if op == "mul":
+            return [(a[0], z * S(a[1])), (a[1], z * S(a[0]))]
+        if op == "div":
+            q = z / S(a[1])
+            return [(a[0], q), (a[1], -(q * S(i)))]
+        if op == "neg":
+            return [(a[0], -z)]
+        if op == "log":
+            return [(a[0], z / S(a[0]))]
+        if op == "exp":
+            return [(a[0], z * S(i))]
+        if op == "sqrt":
+            return [(a[0], z * (0.5 / S(i)))]
+        if op == "abs":
+            return [(a[0], where(S(a[0]) >= 0.0, z, -z))]
+        if op == "fma":
+            return [(a[0], z * S(a[1])), (a[1], z * S(a[0])), (a[2], z)]
+        if op == "sel":
+            c = Cond(g, a[0])
+            return [(a[1], where(c, z, 0.0)), (a[2], where(c, 0.0, z))]
+        return []
 
     # -- reverse mode: adjoints are recorded into the same graph, so that they share subexpressions with the value
     def _reverse(self):
@@ -381,38 +489,40 @@ class Traced:
         bar = {self.out: S(g.node("c", _const_key(1.0)))}
         reach = self._reachable([self.out])
 
-        def acc(i, v):
-            bar[i] = v if i not in bar else bar[i] + v
+        def acc(d, i, v):
+            d[i] = v if i not in d else d[i] + v
 
         for i in sorted(reach, reverse=True):
-            if i not in bar or i >= n_fwd:
+            if i not in bar or i >= n_fwd or self._loop_of(i) is not None:
                 continue
             z, key = bar[i], g.nodes[i]
-            op, a = key[0], key[1:]
-            if op == "add":
-                acc(a[0], z); acc(a[1], z)
-            elif op == "sub":
-                acc(a[0], z); acc(a[1], -z)
-            elif op == "mul":
-                acc(a[0], z * S(a[1])); acc(a[1], z * S(a[0]))
-            elif op == "div":
-                q = z / S(a[1])
-                acc(a[0], q); acc(a[1], -(q * S(i)))
-            elif op == "neg":
-                acc(a[0], -z)
-            elif op == "log":
-                acc(a[0], z / S(a[0]))
-            elif op == "exp":
-                acc(a[0], z * S(i))
-            elif op == "sqrt":
-                acc(a[0], z * (0.5 / S(i)))
-            elif op == "abs":
-                acc(a[0], where(S(a[0]) >= 0.0, z, -z))
-            elif op == "fma":
-                acc(a[0], z * S(a[1])); acc(a[1], z * S(a[0])); acc(a[2], z)
-            elif op == "sel":
-                c = Cond(g, a[0])
-                acc(a[1], where(c, z, 0.0)); acc(a[2], where(c, 0.0, z))
+            if key[0] != "loop":
+                for k, v in self._vjp(i, z):
+                    acc(bar, k, v)
+                continue
+            # d/du sum_rows f(row; u) = sum_rows df/du: the adjoint sweep of the loop body with the (row-independent) seed z
+            # gives, per outer input u of the body, a row-dependent term; each is summed by a loop of its own over the same
+            # rows (the emitter fuses the loops of one group into one)
+            lid, root = key[1], key[2]
+            if self._loop_of(root) is None:                         # the term does not depend on the row: n * term
+                acc(bar, root, z * float(g.loops[lid]["n"]))
+                continue
+            inner = sorted((k for k in self._reachable([root]) if self._loop_of(k) == lid), reverse=True)
+            ibar, obar = {root: z}, {}
+            for k in inner:
+                if k not in ibar:
+                    continue
+                for u, v in self._vjp(k, ibar[k]):
+                    if g.nodes[u][0] in ("c", "lv"):
+                        continue
+                    acc(ibar if self._loop_of(u) == lid else obar, u, v)
+            members = []
+            for u in sorted(obar):
+                node = g.node("loop", lid, obar[u].i)
+                g.loop_group[node] = ("r", i)
+                members.append((u, node))
+            for u, node in members:                                 # (only now: nothing between the members may depend on one)
+                acc(bar, u, S(node))
         zero = g.node("c", _const_key(0.0))
         out = []
         for k in range(self.dim):
@@ -431,8 +541,10 @@ class Traced:
     def _deps(self, i):
         key = self.g.nodes[i]
         op = key[0]
-        if op in ("c", "x"):
+        if op in ("c", "x", "lv"):
             return []
+        if op == "loop":
+            return [key[2]]
         if op == "sel":
             d = list(key[2:])
             self._cond_nodes(key[1], d)
@@ -460,36 +572,66 @@ class Traced:
             return "(!%s)" % self._cond_src(key[1], name)
         return "true" if key[1] else "false"
 
+    def _rhs(self, i, name):
+        key = self.g.nodes[i]
+        op, a = key[0], key[1:]
+        if op == "x":
+            return "x[%d]" % a[0]
+        if op == "lv":
+            lp = self.g.loops[a[0]]
+            return "data[%d + k * %d + %d]" % (lp["off"], lp["m"], a[1]) if lp["m"] > 1 else "data[%d + k]" % lp["off"]
+        if op in _ARITH:
+            return "%s %s %s" % (name(a[0]), {"add": "+", "sub": "-", "mul": "*", "div": "/"}[op], name(a[1]))
+        if op == "neg":
+            return "-%s" % name(a[0])
+        if op in ("log", "exp", "sqrt", "abs"):
+            return "mhx_%s(%s)" % (op, name(a[0]))
+        if op == "fma":
+            return "mhx_fma(%s, %s, %s)" % tuple(name(v) for v in a)
+        if op == "sel":
+            return "%s ? %s : %s" % (self._cond_src(a[0], name), name(a[1]), name(a[2]))
+        raise AssertionError(op)
+
     def _body(self, roots):
-        nodes = self.g.nodes
+        nodes, g = self.g.nodes, self.g
         live = self._reachable(roots)
         name = lambda i: _lit(nodes[i][1]) if nodes[i][0] == "c" else "t%d" % i
-        lines = []
+        # loop nodes of one group are emitted as ONE loop, at the position of the group's last live member
+        groups = {}
+        for i in live:
+            if nodes[i][0] == "loop":
+                groups.setdefault(g.loop_group[i], []).append(i)
+        at = {max(m): sorted(m) for m in groups.values()}
+        lines, nops = [], 0
         for i in sorted(live):
-            key = nodes[i]
-            op, a = key[0], key[1:]
-            if op == "c":
+            op = nodes[i][0]
+            if op == "c" or (op != "loop" and self._loop_of(i) is not None):
                 continue
-            if op == "x":
-                rhs = "x[%d]" % a[0]
-            elif op in _ARITH:
-                rhs = "%s %s %s" % (name(a[0]), {"add": "+", "sub": "-", "mul": "*", "div": "/"}[op], name(a[1]))
-            elif op == "neg":
-                rhs = "-%s" % name(a[0])
-            elif op in ("log", "exp", "sqrt", "abs"):
-                rhs = "mhx_%s(%s)" % (op, name(a[0]))
-            elif op == "fma":
-                rhs = "mhx_fma(%s, %s, %s)" % tuple(name(v) for v in a)
-            elif op == "sel":
-                rhs = "%s ? %s : %s" % (self._cond_src(a[0], name), name(a[1]), name(a[2]))
-            else:
-                raise AssertionError(op)
-            lines.append("    const mhx_real t%d = %s;" % (i, rhs))
+            if op != "loop":
+                lines.append("    const mhx_real t%d = %s;" % (i, self._rhs(i, name)))
+                nops += op != "x"
+                continue
+            if i not in at:
+                continue
+            members = at[i]
+            lid = nodes[i][1]
+            body = sorted(k for k in self._reachable([nodes[m][2] for m in members]) if self._loop_of(k) == lid)
+            lines.append("    mhx_real %s;" % ", ".join("t%d = MHX_R(0x0.0p+0)" % m for m in members))
+            lines.append("    for (int k = 0; k < %d; ++k) {" % g.loops[lid]["n"])
+            for k in body:
+                lines.append("        const mhx_real t%d = %s;" % (k, self._rhs(k, name)))
+                nops += nodes[k][0] != "lv"
+            for m in members:
+                lines.append("        t%d = t%d + %s;" % (m, m, name(nodes[m][2])))
+                nops += 1
+            lines.append("    }")
+        self._nops = nops
         return lines, name
 
     def _emit(self):
         lines, name = self._body([self.out])
-        src = ["// traced by mhx.trace (advancedmh.jl_amd/mhx/trace.py): %d operations" % len(lines),
+        src = ["// traced by mhx.trace (advancedmh.jl_amd/mhx/trace.py): %d operations in the source%s" % (
+                   self._nops, "" if self.data is None else "; data block of %d reals" % self.data.size),
                "MHX_LOGDENSITY(x, d, data, ndata)", "{"] + lines + ["    return %s;" % name(self.out), "}"]
         if self.grad is not None:
             lines, name = self._body([self.out] + self.grad)
@@ -499,53 +641,72 @@ class Traced:
         return "\n".join(src) + "\n"
 
     # -- the same program on numpy float64 (checks; the engine's log / exp differ from libm's in the last bit)
+    def _eval_node(self, i, val, x, row):
+        key = self.g.nodes[i]
+        op, a = key[0], key[1:]
+
+        def cond(c):
+            if c[0] == "cmp":
+                p, q = val[c[2]], val[c[3]]
+                return {"lt": p < q, "le": p <= q, "gt": p > q, "ge": p >= q, "eq": p == q, "ne": p != q}[c[1]]
+            if c[0] == "and":
+                return cond(c[1]) and cond(c[2])
+            if c[0] == "or":
+                return cond(c[1]) or cond(c[2])
+            if c[0] == "not":
+                return not cond(c[1])
+            return c[1]
+
+        if op == "c":
+            return math.nan if a[0] == "nan" else float.fromhex(a[0])
+        if op == "x":
+            return x[a[0]]
+        if op == "lv":
+            return row[a[1]]
+        if op == "add":
+            return val[a[0]] + val[a[1]]
+        if op == "sub":
+            return val[a[0]] - val[a[1]]
+        if op == "mul":
+            return val[a[0]] * val[a[1]]
+        if op == "div":
+            return np.float64(val[a[0]]) / np.float64(val[a[1]])
+        if op == "neg":
+            return -val[a[0]]
+        if op == "log":
+            return _pylog(val[a[0]])
+        if op == "exp":
+            return _pyexp(val[a[0]])
+        if op == "sqrt":
+            return _pysqrt(val[a[0]])
+        if op == "abs":
+            return builtins_abs(val[a[0]])
+        if op == "fma":
+            return _fma_float(float(val[a[0]]), float(val[a[1]]), float(val[a[2]]))
+        if op == "sel":
+            return val[a[1]] if cond(a[0]) else val[a[2]]
+        raise AssertionError(op)
+
     def _run(self, x, roots):
-        nodes, val = self.g.nodes, {}
+        nodes, g, val = self.g.nodes, self.g, {}
         x = np.asarray(x, dtype=np.float64)
-
-        def cond(key):
-            if key[0] == "cmp":
-                a, b = val[key[2]], val[key[3]]
-                return {"lt": a < b, "le": a <= b, "gt": a > b, "ge": a >= b, "eq": a == b, "ne": a != b}[key[1]]
-            if key[0] == "and":
-                return cond(key[1]) and cond(key[2])
-            if key[0] == "or":
-                return cond(key[1]) or cond(key[2])
-            if key[0] == "not":
-                return not cond(key[1])
-            return key[1]
-
         with np.errstate(all="ignore"):
             for i in sorted(self._reachable(roots)):
-                key = nodes[i]
-                op, a = key[0], key[1:]
-                if op == "c":
-                    v = math.nan if a[0] == "nan" else float.fromhex(a[0])
-                elif op == "x":
-                    v = x[a[0]]
-                elif op == "add":
-                    v = val[a[0]] + val[a[1]]
-                elif op == "sub":
-                    v = val[a[0]] - val[a[1]]
-                elif op == "mul":
-                    v = val[a[0]] * val[a[1]]
-                elif op == "div":
-                    v = np.float64(val[a[0]]) / np.float64(val[a[1]])
-                elif op == "neg":
-                    v = -val[a[0]]
-                elif op == "log":
-                    v = _pylog(val[a[0]])
-                elif op == "exp":
-                    v = _pyexp(val[a[0]])
-                elif op == "sqrt":
-                    v = _pysqrt(val[a[0]])
-                elif op == "abs":
-                    v = builtins_abs(val[a[0]])
-                elif op == "fma":
-                    v = _fma_float(float(val[a[0]]), float(val[a[1]]), float(val[a[2]]))
-                elif op == "sel":
-                    v = val[a[1]] if cond(a[0]) else val[a[2]]
-                val[i] = np.float64(v)
+                if self._loop_of(i) is not None:
+                    continue
+                if nodes[i][0] != "loop":
+                    val[i] = np.float64(self._eval_node(i, val, x, None))
+                    continue
+                lid, root = nodes[i][1], nodes[i][2]
+                lp = g.loops[lid]
+                rows = g.data[lid].reshape(lp["n"], lp["m"])
+                body = sorted(k for k in self._reachable([root]) if self._loop_of(k) == lid)
+                acc = np.float64(0.0)
+                for r in rows:
+                    for k in body:
+                        val[k] = np.float64(self._eval_node(k, val, x, r))
+                    acc = acc + val[root]
+                val[i] = acc
         return [float(val[r]) for r in roots]
 
     def evaluate(self, x):
@@ -558,7 +719,9 @@ class Traced:
 
     @property
     def n_operations(self):
-        return sum(1 for i in self._reachable([self.out]) if self.g.nodes[i][0] not in ("c", "x"))
+        """operations of the value function's source (a loop body counts once)"""
+        self._body([self.out])
+        return self._nops
 
 
 class NamedVec(Vec):
@@ -592,7 +755,11 @@ def trace(f, dim, gradient=True, names=None):
     g.node("c", _const_key(0.0))        # node 0: lets where() lift plain numbers without a Sym at hand
     x = [Sym(g, g.node("x", k)) for k in range(dim)]
     x = NamedVec(x, names) if names is not None else Vec(x)
-    out = f(x)
+    _ACTIVE.append(g)
+    try:
+        out = f(x)
+    finally:
+        _ACTIVE.pop()
     if isinstance(out, Vec) and len(out) == 1:
         out = out[0]
     if isinstance(out, (int, float, np.integer, np.floating)):      # a constant density: still a program

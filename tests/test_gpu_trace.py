@@ -22,7 +22,7 @@ def _same(a, b, what):
 def test_traced_logdensity_bit_exact(mhx, oracle, name, real):
     f, d, x0 = M.MODELS[name]
     model = mhx.DensityModel(f, dim=d)
-    ut = user_targets.host_target(oracle, model.traced.source, d)
+    ut = user_targets.host_target(oracle, model.traced.source, d, data=model.traced.data)
     rng = np.random.default_rng(3)
     x = (np.array(x0)[:, None] + rng.normal(size=(d, 500))).astype(cases.R())      # some points outside the support
     lp = mhx.logdensity(model, x)
@@ -39,7 +39,7 @@ def test_readme_example_rwmh(mhx, oracle, real):
     chain = mhx.sample(model, spl, N, C, seed=9, initial_params=init, param_names=["μ", "σ"], discard_initial=500)
     assert abs(chain.mean("μ") - M.README_DATA.mean()) < 0.1 and abs(chain.mean("σ") - M.README_DATA.std()) < 0.15
     assert (chain["σ"] > 0).all()
-    ut = user_targets.host_target(oracle, model.traced.source, 2)
+    ut = user_targets.host_target(oracle, model.traced.source, 2, data=model.traced.data)
     ref = oracle.rwmh(ut, oracle.Proposal(oracle.PROP_ISO, 0.5), oracle.schedule(300, 500), 9, 0, C, init=init)
     _same(chain.value[:300], ref["samples"], "samples")
     _same(chain.accepted[:300], ref["accepted"], "accepted")
@@ -52,7 +52,7 @@ def test_nig_emcee_known_answer(mhx, oracle, real):
     spl = mhx.Ensemble(W, mhx.StretchProposal([mhx.InverseGamma(2, 3), mhx.Normal(0, 1)]))
     chain = mhx.sample(model, spl, 1000, seed=100, param_names=["s", "m"])
     assert abs(chain.mean("s") - 49 / 24) < 0.1 and abs(chain.mean("m") - 7 / 6) < 0.1
-    ut = user_targets.host_target(oracle, model.traced.source, 2)
+    ut = user_targets.host_target(oracle, model.traced.source, 2, data=model.traced.data)
     ref = oracle.emcee(ut, 2.0, 1, oracle.schedule(200), 100, 0, W, chain.value[0, :2, :])
     _same(chain.value[:200], ref["samples"], "samples")
 
@@ -67,7 +67,7 @@ def test_traced_gradient_drives_mala(mhx, oracle, real):
     v = chain.value[:, :2, :].astype(np.float64)
     assert np.abs(v.mean(axis=(0, 2))).max() < 0.1
     assert np.abs(np.cov(v.transpose(1, 0, 2).reshape(2, -1)) - Sig).max() < 0.2
-    ut = user_targets.host_target(oracle, model.traced.source, 2)
+    ut = user_targets.host_target(oracle, model.traced.source, 2, data=model.traced.data)
     ref = oracle.mala(ut, 0.5, oracle.schedule(200), 1, 0, C, init, user_grad_addr=ut.grad_addr)
     _same(chain.value[:200], ref["samples"], "samples")
     # without the gradient the capability check refuses MALA (src/MALA.jl:42-52)
@@ -81,6 +81,23 @@ def test_traced_model_under_ram(mhx, oracle, real):
     model = mhx.DensityModel(M.rosenbrock_like, dim=d)
     init = np.zeros((d, C), dtype=cases.R())
     chain = mhx.sample(model, mhx.RobustAdaptiveMetropolis(), N, C, seed=17, initial_params=init, num_warmup=warm, discard_initial=0)
-    ut = user_targets.host_target(oracle, model.traced.source, d)
+    ut = user_targets.host_target(oracle, model.traced.source, d, data=model.traced.data)
     ref = oracle.ram(ut, oracle.schedule(N, 0, 1, warm), 17, 0, C, init=init)
     _same(chain.value, ref["samples"], "samples")
+
+
+def test_regression_with_a_data_loop_under_mala(mhx, oracle, real):
+    """A closure over 150 rows of data as ONE loop in the kernel (T.sum_over), its gradient from the trace's fused adjoint loop:
+    MALA recovers the least-squares line; bit-exact vs the oracle on the emitted source and its data block."""
+    model = mhx.DensityModel(M.regression, dim=3)
+    assert model.traced.data.size == 300 and model.traced.n_operations < 40
+    C = 64
+    init = np.tile(np.array([[0.0], [0.0], [0.0]], dtype=cases.R()), (1, C))
+    chain = mhx.sample(model, mhx.MALA(2e-3), 6000, C, initial_params=init, seed=3, discard_initial=1500)
+    t, y = M.REG_DATA[:, 0], M.REG_DATA[:, 1]
+    b_ols, a_ols = np.polyfit(t, y, 1)
+    v = chain.value[:, :3, :].astype(np.float64).mean(axis=(0, 2))
+    assert abs(v[0] - a_ols) < 0.05 and abs(v[1] - b_ols) < 0.05 and abs(np.exp(v[2]) - 0.3) < 0.06
+    ut = user_targets.host_target(oracle, model.traced.source, 3, data=model.traced.data)
+    ref = oracle.mala(ut, 2e-3, oracle.schedule(100, 1500), 3, 0, C, init, user_grad_addr=ut.grad_addr)
+    _same(chain.value[:100], ref["samples"], "samples")

@@ -106,7 +106,7 @@ def test_emitted_source_compiles_for_the_host_and_agrees(name, dt):
     try:
         f, d, x0 = M.MODELS[name]
         tr = T.trace(f, d)
-        ut = user_targets.host_target(O, tr.source, d)
+        ut = user_targets.host_target(O, tr.source, d, data=tr.data)
         R = O.real()
         tol = 1e-12 if dt == "f64" else 2e-5
         rng = np.random.default_rng(8)
@@ -117,9 +117,36 @@ def test_emitted_source_compiles_for_the_host_and_agrees(name, dt):
             got = float(ut(x))
             assert abs(got - want) <= tol * max(1.0, abs(want)), (name, got, want)
             g = np.empty(d, dtype=R)
-            lp = gfn(x.ctypes.data, g.ctypes.data, d, None)
+            lp = gfn(x.ctypes.data, g.ctypes.data, d, C.addressof(ut._keep[2]) if ut._keep[2] is not None else None)
             assert np.float64(lp) == np.float64(got)
             gw = tr.gradient(x.astype(np.float64))
             assert np.allclose(g, gw, rtol=50 * tol, atol=50 * tol), (name, g, gw)
     finally:
         O.set_dtype(old)
+
+
+def test_sum_over_is_one_loop_with_the_row_independent_part_outside():
+    tr = T.trace(M.big_data_density, 2)
+    value_fn = tr.source.split("MHX_LOGDENSITY_AND_GRADIENT")[0]
+    assert value_fn.count("for (int k = 0; k < 2000; ++k)") == 1
+    assert value_fn.index("mhx_log(") < value_fn.index("for (int k")          # log(sigma) is not recomputed per row
+    assert tr.n_operations < 20 and tr.data.shape == (2000,)
+    grad_fn = tr.source.split("MHX_LOGDENSITY_AND_GRADIENT")[1]
+    assert grad_fn.count("for (int k = 0; k < 2000; ++k)") == 2               # the value's loop and ONE fused loop for both partials
+    # outside a trace sum_over is the plain sum, in the same order
+    x = [0.3, 1.9]
+    assert tr.evaluate(x) == M.big_data_density(x)
+    assert T.trace(M.regression, 3).data.shape == (300,)                      # two columns per row, row-major
+
+
+def test_sum_over_misuse_is_reported():
+    with pytest.raises(T.TraceError, match="inside sum_over"):
+        T.trace(lambda x: T.sum_over([1.0, 2.0], lambda y: T.sum_over([3.0], lambda z: x[0] * y * z)), 1)
+    with pytest.raises(T.TraceError, match="two different sum_over"):
+        keep = []
+        T.trace(lambda x: T.sum_over([1.0, 2.0], lambda y: keep.append(y) or x[0] * y) + T.sum_over([3.0, 4.0], lambda z: keep[0] * z), 1)
+    with pytest.raises(T.TraceError, match="non-empty"):
+        T.trace(lambda x: T.sum_over([], lambda y: x[0] * y), 1)
+    # a term that does not depend on the row, and one that does not depend on the parameters either
+    tr = T.trace(lambda x: T.sum_over([1.0, 2.0, 4.0], lambda y: x[0] * x[0]) + T.sum_over([1.0, 2.0, 4.0], lambda y: y), 1)
+    assert tr.evaluate([3.0]) == 27.0 + 7.0 and tr.gradient([3.0])[0] == 18.0

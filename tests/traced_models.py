@@ -47,5 +47,28 @@ def rosenbrock_like(x):
     return -(b * b) * 0.05 - 0.5 * (x[2] - a) ** 2 + T.log(c + 2.0) - T.maximum(x[0], -50.0) ** 2 * 0.125
 
 
-MODELS = {"readme": (readme_density, 2, [0.3, 1.2]), "nig": (nig, 2, [1.4, 0.6]), "quadratic": (quadratic, 2, [0.5, -0.8]),
+# the same likelihood over 2000 points as ONE loop in the kernel source (T.sum_over) instead of 2000 copies of the body
+BIG_DATA = np.random.default_rng(77).normal(loc=0.4, scale=1.7, size=2000)
+
+
+def big_data_density(theta):
+    mu, sigma = theta
+    ls = T.log(sigma)                                       # row-independent: computed once, outside the loop
+    lp = T.sum_over(BIG_DATA, lambda y: -0.5 * ((y - mu) / sigma) ** 2 - ls - 0.5 * LOG2PI)
+    return T.where(sigma > 0, lp, -math.inf)
+
+
+# a regression with two columns per row: y ~ Normal(a + b t, exp(ls))
+_T = np.linspace(-1.0, 2.0, 150)
+REG_DATA = np.stack([_T, 0.7 - 1.3 * _T + 0.3 * np.random.default_rng(5).normal(size=150)], axis=1)
+
+
+def regression(theta):
+    a, b, ls = theta
+    s = T.exp(ls)
+    return T.sum_over(REG_DATA, lambda row: -0.5 * ((row[1] - (a + b * row[0])) / s) ** 2 - ls) - 0.5 * (a * a + b * b) * 0.01
+
+
+MODELS = {"big_data": (big_data_density, 2, [0.4, 1.7]), "regression": (regression, 3, [0.5, -1.0, -1.0]),
+          "readme": (readme_density, 2, [0.3, 1.2]), "nig": (nig, 2, [1.4, 0.6]), "quadratic": (quadratic, 2, [0.5, -0.8]),
           "rosenbrock_like": (rosenbrock_like, 3, [0.7, -0.4, 1.1])}
