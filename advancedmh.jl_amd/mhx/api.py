@@ -375,15 +375,35 @@ class RobustAdaptiveMetropolis:
 
 
 class MALA:
-    """MALA(sigma2): the reference's `MALA(g -> MvNormal((sigma2 / 2) .* g, sigma2 * I))` (src/MALA.jl:1-11,
-    test/runtests.jl:291).  Only this standard Langevin proposal is lowered to the device; a general
-    gradient -> Distribution closure stays on the CPU reference."""
+    """MALA(sigma2), or the reference's own form `MALA(g -> MvNormal((sigma2 / 2) .* g, sigma2 * I))` (src/MALA.jl:1-11,
+    test/runtests.jl:291,352) as a Python callable of the gradient: the callable is probed once the dimension is known and
+    must be that Langevin proposal -- mean (sigma2 / 2) g, covariance sigma2 I; any other gradient -> Distribution closure
+    stays on the CPU reference."""
 
     def __init__(self, sigma2):
-        if callable(sigma2):
-            raise L.ArgumentError(L.MHX_EINVAL, "MALA on the GPU path takes sigma2, i.e. the proposal "
-                                  "g -> MvNormal((sigma2/2) g, sigma2 I); an arbitrary closure cannot be lowered")
-        self.sigma2 = float(sigma2)
+        self.closure = sigma2 if callable(sigma2) else None
+        self.sigma2 = None if callable(sigma2) else float(sigma2)
+
+    def resolve(self, d):
+        """sigma2 of the Langevin proposal the closure describes (probed at g = 0, g = 1 and a ramp)."""
+        if self.closure is None:
+            return self.sigma2
+        bad = L.ArgumentError(L.MHX_EINVAL, "MALA on the GPU path takes sigma2 or the Langevin closure g -> MvNormal((sigma2/2) g, sigma2 I); "
+                              "this closure is not of that form and cannot be lowered")
+        try:
+            p0, p1, p2 = (_as_mvnormal(self.closure(g)) for g in (np.zeros(d), np.ones(d), np.arange(1.0, d + 1.0)))
+        except L.ArgumentError:
+            raise bad from None
+        for q in (p0, p1, p2):
+            iso = q.kind == L.PROP_ISO or (q.kind == L.PROP_DIAG and np.all(q.vec == q.vec[0]))
+            if q.dim != d or not iso:
+                raise bad
+        s2 = (p0.scale if p0.kind == L.PROP_ISO else float(p0.vec[0])) ** 2
+        same = all(abs((q.scale if q.kind == L.PROP_ISO else float(q.vec[0])) ** 2 - s2) <= 1e-12 * s2 for q in (p1, p2))
+        if not (same and np.all(p0.mean == 0) and np.allclose(p1.mean, 0.5 * s2, rtol=1e-12, atol=0)
+                and np.allclose(p2.mean, 0.5 * s2 * np.arange(1.0, d + 1.0), rtol=1e-12, atol=0)):
+            raise bad
+        return float(s2)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -514,7 +534,7 @@ class Run:
             self.n = sampler.n_walkers
             self.kind = "emcee"
         elif isinstance(sampler, MALA):
-            cfg = L.MalaCfg(d, nchains, seed, first_chain, sampler.sigma2, flags, reduce_lanes)
+            cfg = L.MalaCfg(d, nchains, seed, first_chain, sampler.resolve(d), flags, reduce_lanes)
             L.check(lib.mhx_mala_create(self.ctx.h, model.handle(self.ctx), C.byref(cfg), C.byref(self.h)))
             self.n = nchains
             self.kind = "mala"

@@ -70,3 +70,13 @@ def test_scalar_parameter_closure(mhx, real):
     assert chain.range() == range(1, 10_001) and abs(chain.mean("μ") - DATA.mean()) < 0.1
     chain_b = mhx.sample(model, mhx.StaticMH(mhx.Normal(0, 1)), 10_000, 4, param_names=["μ"], seed=5, discard_initial=25, thinning=4)
     assert chain_b.range() == range(26, 26 + 4 * 10_000, 4) and abs(chain_b.mean("μ") - DATA.mean()) < 0.1
+
+
+def test_mala_closure_form_runs_the_same_chain(mhx, real):
+    """test/runtests.jl:291: MALA(x -> MvNormal((σ² / 2) .* x, σ² * I)) is MALA(σ²) of the engine."""
+    model = mhx.DensityModel(density, dim=2)
+    s2 = 1e-3
+    init = np.ones(2)
+    a = mhx.sample(model, mhx.MALA(lambda g: mhx.MvNormal(0.5 * s2 * g, s2 * mhx.I)), 50, 8, initial_params=init, seed=4)
+    b = mhx.sample(model, mhx.MALA(s2), 50, 8, initial_params=init, seed=4)
+    assert np.array_equal(a.value, b.value) and a.accepted[1:].mean() > 0.2

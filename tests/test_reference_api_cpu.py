@@ -52,3 +52,18 @@ def test_named_parameters_in_a_traced_closure():
     assert by_key.evaluate([2.0, 5.0]) == 12.0
     with pytest.raises(T.TraceError, match="names"):
         T.trace(lambda x: x[0], 3, names=("a", "b"))
+
+
+def test_mala_takes_the_reference_closure_form():
+    """MALA(x -> MvNormal((σ² / 2) .* x, σ² * I))  (test/runtests.jl:291,352)"""
+    s2 = 0.37
+    spl = mhx.MALA(lambda g: mhx.MvNormal(0.5 * s2 * g, s2 * mhx.I))
+    assert spl.resolve(5) == pytest.approx(s2, rel=1e-15) and mhx.MALA(s2).resolve(5) == s2
+    diag = mhx.MALA(lambda g: mhx.MvNormal(0.5 * s2 * g, np.full(g.size, s2)))           # the same covariance written as a vector
+    assert diag.resolve(3) == pytest.approx(s2, rel=1e-15)
+    for wrong in (lambda g: mhx.MvNormal(g, mhx.I),                          # test/runtests.jl:43: not a Langevin step (mean g, not g / 2)
+                  lambda g: mhx.MvNormal(0.5 * s2 * g + 1.0, s2 * mhx.I),   # shifted
+                  lambda g: mhx.MvNormal(0.5 * s2 * g, np.linspace(1, 2, g.size)),   # anisotropic
+                  lambda g: 3.0):
+        with pytest.raises(mhx.ArgumentError, match="Langevin"):
+            mhx.MALA(wrong).resolve(4)
