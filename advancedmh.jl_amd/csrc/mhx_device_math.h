@@ -83,9 +83,12 @@ MHX_DEV mhx_srd mhx_make_srd(const void* base, mhx_u32 bytes)
 }
 #if MHX_REAL64
 typedef mhx_u32 mhx_u32v2 __attribute__((ext_vector_type(2)));
+#ifndef MHX_SRD_STORE_AUX
+#define MHX_SRD_STORE_AUX 0     // cache-policy bits of the slab stores (tuning knob: 1 sc0, 2 nt, 16 sc1)
+#endif
 MHX_DEV void mhx_srd_store(mhx_srd srd, mhx_u32 lane_byte_off, mhx_u32 row_byte_off, double v)
 {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(mhx_u32v2, v), srd, (int)lane_byte_off, (int)row_byte_off, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(mhx_u32v2, v), srd, (int)lane_byte_off, (int)row_byte_off, MHX_SRD_STORE_AUX);
 }
 #else
 MHX_DEV void mhx_srd_store(mhx_srd srd, mhx_u32 lane_byte_off, mhx_u32 row_byte_off, float v)
