@@ -104,6 +104,14 @@ run_chains("rwmh_given_start", DensityModel(iso_gauss(3)), RWMH(MvNormal(zeros(3
 # the engine's ziggurat normals (MHX_FLAG_ZIGGURAT): 64 chains x 48 transitions x 8 normals = 2.5e4 draws, ~100 through the slow paths
 run_chains("rwmh_iso_ziggurat", DensityModel(iso_gauss(8)), RWMH(MvNormal(zeros(8), 0.6^2 * I)), 48, 15, 7, 64, 8; ziggurat = true)
 
+# a drifting random walk (non-zero proposal mean: the Hastings ratio of src/proposal.jl:58-64,190-192 is not zero) and an independence
+# sampler (StaticMH: src/proposal.jl:9-11,66-83); Distributions' logpdf rounds differently from the engine's ratio, the accept-margin
+# logic of tests/test_julia_reference_traces.py absorbs that
+let μ = [0.3, -0.2, 0.1, 0.25]
+    run_chains("rwmh_drift", DensityModel(iso_gauss(4)), RWMH(MvNormal(μ, 0.6^2 * I)), 40, 16, 0, 6, 4; initial_params = zeros(4))
+    run_chains("rwmh_static", DensityModel(corr_gauss(ar1(4, 0.5))), StaticMH(MvNormal(μ, 1.2^2 * I)), 40, 17, 0, 6, 4; initial_params = zeros(4))
+end
+
 # ---- RobustAdaptiveMetropolis (src/RobustAdaptiveMetropolis.jl:123-278) ------------------------------------------------
 # the model is a LogDensityProblems object, NOT a DensityModel (see the dispatch notes above)
 let d = 4

@@ -34,6 +34,20 @@ def _rwmh_iso_ziggurat(O):
     return O.traced(O.rwmh, O.iso_gauss(8), O.Proposal(O.PROP_ISO, 0.6, normal_gen=1), O.schedule(48), 15, 7, 64)
 
 
+_MU = np.array([0.3, -0.2, 0.1, 0.25])
+
+
+def _rwmh_drift(O):
+    """a random walk with a non-zero mean: the Hastings ratio q(x | y) - q(y | x) is not zero (src/proposal.jl:58-64,190-192)"""
+    return O.traced(O.rwmh, O.iso_gauss(4), O.Proposal(O.PROP_ISO, 0.6, mean=_MU), O.schedule(40), 16, 0, 6, init=np.zeros((4, 6)))
+
+
+def _rwmh_static(O):
+    """StaticMH: an independence sampler, ratio logpdf(p, x) - logpdf(p, y) (src/proposal.jl:9-11,66-83)"""
+    return O.traced(O.rwmh, O.corr_gauss_from_cov(cases.sigma_ar1(4, 0.5)), O.Proposal(O.PROP_ISO, 1.2, mean=_MU, static=True), O.schedule(40), 17, 0, 6,
+                    init=np.zeros((4, 6)))
+
+
 def _ram(O):
     d = 4
     return O.traced(O.ram, O.corr_gauss_from_cov(cases.sigma_ar1(d, 0.7)), O.schedule(24, 0, 1, 16), 31, 2, 6, init=np.zeros((d, 6)))
@@ -64,6 +78,6 @@ def _emcee_seq(O):
 
 JULIA_CASES = {
     "rwmh_iso": _rwmh_iso, "rwmh_dense_corr": _rwmh_dense_corr, "rwmh_funnel": _rwmh_funnel, "rwmh_banana": _rwmh_banana,
-    "rwmh_given_start": _rwmh_given_start, "rwmh_iso_ziggurat": _rwmh_iso_ziggurat, "ram": _ram, "ram_random_start": _ram_random_start, "ram_bounds": _ram_bounds,
+    "rwmh_given_start": _rwmh_given_start, "rwmh_iso_ziggurat": _rwmh_iso_ziggurat, "rwmh_drift": _rwmh_drift, "rwmh_static": _rwmh_static, "ram": _ram, "ram_random_start": _ram_random_start, "ram_bounds": _ram_bounds,
     "mala_iso": _mala_iso, "mala_corr": _mala_corr, "emcee_seq": _emcee_seq,
 }
