@@ -461,6 +461,39 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
     const int k_last = 4 * (l + L * (NBL - 1));               // first dimension of the last block
 
     mhx_real x[NBL][4], y[NBL][4];
+#if MHX_REAL64
+    // A wave per chain (L = 64) touches 8 bytes per row of a [dim][chains] array: a quarter of every 32-byte sector it reads or
+    // dirties (PMC: 3.3 x the algorithmic write bytes on C5).  With the ziggurat's slab at hand the four chains of a block meet in
+    // LDS -- T[k][wave] -- and every row moves as ONE 32-byte access: the state and both moment arrays, once per launch each way.
+    const bool tr_io = ZIG && CPW == 1 && blockDim.x == 256 && (ld & 3) == 0 && ((wave & ~3L) + 4 <= a.nchains);   // block-uniform
+    auto fetch4 = [&](const mhx_real* base, auto& v) {
+        typedef double mhx_d2 __attribute__((ext_vector_type(2)));
+        double* T = mhx_coop_lds + MHX_ZIG_TABLE_BYTES / 8;
+        const int w4 = (int)(threadIdx.x >> 6);
+        const long c0 = wave & ~3L;
+        __syncthreads();
+        for (int k = (int)threadIdx.x; k < d; k += 256) {
+            const mhx_d2* src = (const mhx_d2*)(base + (long)k * ld + c0);
+            *(mhx_d2*)(T + 4 * k) = src[0];
+            *(mhx_d2*)(T + 4 * k + 2) = src[1];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NBL; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 4 * (l + L * i) + j;
+                v[i][j] = (i < NBL - 1 || k < d) ? T[4 * k + w4] : MHX_R(0.0);
+            }
+    };
+#else
+    const bool tr_io = false;
+#endif
+    if (tr_io) {
+#if MHX_REAL64
+        fetch4(a.x, x);
+#endif
+    } else {
 #pragma unroll
     for (int i = 0; i < NBL; ++i)
 #pragma unroll
@@ -468,8 +501,12 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
             const mhx_real* col = a.x + (long)(4 * L * i + j) * ld;
             if (i < NBL - 1) x[i][j] = mhx_ld_off(col, lane_off);
             else x[i][j] = (k_last + j < d) ? mhx_ld_off(col, lane_off) : MHX_R(0.0);
-            y[i][j] = MHX_R(0.0);
         }
+    }
+#pragma unroll
+    for (int i = 0; i < NBL; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[i][j] = MHX_R(0.0);
     mhx_real lp = a.lp[c];
     mhx_u32 nacc = a.acc_count[c];
     mhx_u32 wave_acc = 0;
@@ -499,6 +536,11 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
     mhx_real mm[MOM ? NBL : 1][4], m2[MOM ? NBL : 1][4], lpm = MHX_R(0.0), lpm2 = MHX_R(0.0);
     mhx_u32 mom_n = a.mom_n0;
     if (MOM) {
+        if (tr_io && mom_n) {
+#if MHX_REAL64
+            if constexpr (MOM) { fetch4(a.mom_mean, mm); fetch4(a.mom_m2, m2); }
+#endif
+        } else {
 #pragma unroll
         for (int i = 0; i < NBL; ++i)
 #pragma unroll
@@ -508,6 +550,7 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
                 mm[i][j] = (in && mom_n) ? mhx_ld_off(a.mom_mean + e, lane_off) : MHX_R(0.0);
                 m2[i][j] = (in && mom_n) ? mhx_ld_off(a.mom_m2 + e, lane_off) : MHX_R(0.0);
             }
+        }
         if (mom_n) { lpm = a.mom_mean[(long)d * ld + c]; lpm2 = a.mom_m2[(long)d * ld + c]; }
     }
 
@@ -734,7 +777,39 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
             ++slot;
         }
     }
+#if MHX_REAL64
+    const bool tr_out = tr_io;
+    auto flush4 = [&](mhx_real* base, const auto& v) {
+        typedef double mhx_d2 __attribute__((ext_vector_type(2)));
+        double* T = mhx_coop_lds + MHX_ZIG_TABLE_BYTES / 8;
+        const int w4 = (int)(threadIdx.x >> 6);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NBL; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 4 * (l + L * i) + j;
+                if (i < NBL - 1 || k < d) T[4 * k + w4] = v[i][j];
+            }
+        __syncthreads();
+        const long c0 = wave & ~3L;
+        for (int k = (int)threadIdx.x; k < d; k += 256) {
+            const mhx_d2 p0 = *(const mhx_d2*)(T + 4 * k), p1 = *(const mhx_d2*)(T + 4 * k + 2);
+            mhx_d2* dst = (mhx_d2*)(base + (long)k * ld + c0);
+            dst[0] = p0; dst[1] = p1;
+        }
+    };
+#else
+    const bool tr_out = false;
+#endif
+    if (tr_out) {
+#if MHX_REAL64
+        flush4(a.x, x);
+        if constexpr (MOM) { flush4(a.mom_mean, mm); flush4(a.mom_m2, m2); }
+#endif
+    }
     if (valid) {
+        if (!tr_out) {
 #pragma unroll
         for (int i = 0; i < NBL; ++i)
 #pragma unroll
@@ -743,6 +818,7 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
                 if (i < NBL - 1) mhx_st_off(col, lane_off, x[i][j]);
                 else if (k_last + j < d) mhx_st_off(col, lane_off, x[i][j]);
             }
+        }
         if (l == 0) {
             a.lp[c] = lp;
             a.acc_count[c] = nacc;
@@ -750,6 +826,7 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
             if (WALK == MHX_WALK_STATIC) a.qx[c] = qxc;
         }
         if (MOM) {
+            if (!tr_out) {
 #pragma unroll
             for (int i = 0; i < NBL; ++i)
 #pragma unroll
@@ -758,6 +835,7 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
                     const long e = (long)(4 * L * i + j) * ld;
                     if (in) { mhx_st_off(a.mom_mean + e, lane_off, mm[i][j]); mhx_st_off(a.mom_m2 + e, lane_off, m2[i][j]); }
                 }
+            }
             if (l == 0) { a.mom_mean[(long)d * ld + c] = lpm; a.mom_m2[(long)d * ld + c] = lpm2; }
         }
     }
