@@ -619,6 +619,7 @@ struct mhx_run : mhx_handle_hdr {
     // kernel choice
     int normal_gen = MHX_GEN_BOX_MULLER; // how stream bits become standard normals (MHX_FLAG_ZIGGURAT: the table ziggurat, fp64)
     size_t coop_lds = 0;                 // dynamic LDS of the cooperative kernel (ziggurat: layer table + the step's normals)
+    int coop_tr = 0;                     // ... and whether it holds the row-transposition buffer of the one / two-chains-per-wave shapes
     int coop_L = 1;                      // lanes per chain (reduction shape of the separable targets)
     int emcee_band = -1;                 // bandwidth of the precision factor the cooperative stretch move exploits (-1: dense form)
     int coop_waves = MHX_EMCEE_COOP_WAVES;  // waves per block of the cooperative stretch move (tuning knob MHX_EMCEE_WAVES)
@@ -665,6 +666,7 @@ static mhx_rwmh_args rwmh_args(const mhx_run* r)
     a.pmean = r->d_pmean;
     a.qx = r->d_qx;
     a.normal_gen = r->normal_gen;
+    a.tr_lds = r->coop_tr;
     return a;
 }
 
@@ -1002,6 +1004,13 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
             else if (cfg->reduce_lanes > 1 || zig) return rc;      // the caller asked for this shape explicitly
         }
         if (r->variant) {
+            // one or two chains per wave: rows of the [dim][chains] arrays move through LDS, CB = 4 * (64 / L) chains at a time
+            // (mhx_rwmh_coop_body); the ziggurat's slab holds that buffer, the Box-Muller kernels get one of their own
+            if (L >= 32) {
+                const size_t need = (size_t)d * (size_t)(4 * (64 / L)) * sizeof(mhx_real);
+                if (zig) r->coop_tr = 1;
+                else if (need <= 65536) { r->coop_lds = (need + 15) & ~(size_t)15; r->coop_tr = 1; }
+            }
             r->coop_L = L;
             r->coop_key = "rwmh_coop/l=" + std::to_string(L) + "/nbl=" + std::to_string(NBL) + "/tk=" + std::to_string(tk) +
                           "/pk=" + std::to_string(pk) + "/walk=" + std::to_string(walk) + "/gen=" + std::to_string(zig ? 1 : 0);
@@ -1099,7 +1108,8 @@ static int rwmh_advance(mhx_run* r, uint64_t nsteps, uint32_t save_next, int sav
         a.thinning = thinning;
         if (r->variant == 3 || r->variant == 4) {
             const long threads = (((long)r->n + (64 / r->coop_L) - 1) / (64 / r->coop_L)) * 64;   // whole waves
-            const unsigned grid = (unsigned)((threads + 255) / 256);
+            unsigned grid = (unsigned)((threads + 255) / 256);
+            if (r->coop_L >= 32) grid = (grid + 7u) & ~7u;          // the kernel's XCD-aware block -> chain map wants whole rounds of 8
             if (r->moments_mode && r->reg_fn_mom) {
                 hipLaunchKernelGGL(r->reg_fn_mom, dim3(grid), dim3(256), r->coop_lds, ctx->stream, a, tp, pv);
             } else if (r->moments_mode) {

@@ -72,6 +72,8 @@ struct mhx_rwmh_args {
     const mhx_real* pmean;       // null = zero mean (the Hastings ratio is then exactly 0 and is not computed)
     // static (independence) proposal, generic kernel only: q(x) = -1/2 |L^-1 (x - mu)|^2 of each chain's state
     mhx_real* qx;                // [ld] or null = random walk
+    int tr_lds;                  // cooperative kernel, one or two chains per wave: the block has dim x (chains per block) reals of LDS to
+                                 // move rows of the [dim][chains] arrays through (see mhx_rwmh_coop_body)
     int normal_gen;              // MHX_GEN_*: how stream bits become standard normals (a property of the run: initial draw and proposals)
 };
 
@@ -359,6 +361,7 @@ MHX_DEV void mhx_rwmh_whiten_body(const mhx_rwmh_args& a, const mhx_real* __rest
 #define MHX_WALK_PLAIN  0
 #define MHX_WALK_DRIFT  1
 #define MHX_WALK_STATIC 2
+#define MHX_ZIG_TABLE_BYTES_ANY (((1024 + 1) * 8 + 15) / 16 * 16)      // == MHX_ZIG_TABLE_BYTES (fp64 builds; checked there)
 #if MHX_REAL64
 // Dynamic LDS of the cooperative kernel with the ziggurat generator (GEN = MHX_GEN_ZIGGURAT), 256-thread blocks:
 //   [0, 8208)                       the layer table x[0..N]
@@ -367,6 +370,7 @@ MHX_DEV void mhx_rwmh_whiten_body(const mhx_rwmh_args& a, const mhx_real* __rest
 #define MHX_ZIG_TABLE_BYTES (((MHX_ZIG_N + 1) * 8 + 15) / 16 * 16)
 #define MHX_ZIG_WAVE_BYTES(NBL) ((NBL) * 4 * 64 * 8 + 128)
 #define MHX_ZIG_LDS_BYTES(NBL) (MHX_ZIG_TABLE_BYTES + 4 * MHX_ZIG_WAVE_BYTES(NBL))
+static_assert(MHX_ZIG_TABLE_BYTES == MHX_ZIG_TABLE_BYTES_ANY, "ziggurat table size");
 
 // The candidates of this wave-step that left their rectangles (0.4 % of the draws: a dozen per wave-step at d = 100), gathered
 // from all lanes into one queue and finished by as many lanes side by side -- ONE pass of the slow path per wave-step instead of
@@ -431,8 +435,8 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
 #endif
     constexpr bool ZKEEP = MHX_COOP_ZKEEP && MHX_REAL64 && WALK == MHX_WALK_PLAIN && PK == MHX_PROP_ISO;   // (fp32: a select is one instruction already)
     static_assert(!ZIG || MHX_REAL64, "the ziggurat generator exists in the fp64 engine only");
-#if MHX_REAL64
     extern __shared__ double mhx_coop_lds[];
+#if MHX_REAL64
     const double* zt = mhx_coop_lds;
     double* zn = mhx_coop_lds + MHX_ZIG_TABLE_BYTES / 8 + (threadIdx.x >> 6) * (MHX_ZIG_WAVE_BYTES(NBL) / 8);
     unsigned short* zq = (unsigned short*)(zn + NBL * 4 * 64);
@@ -442,7 +446,11 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
     }
 #endif
     const int lane = threadIdx.x & 63;
-    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    // One or two chains per wave (L = 64, 32): a block covers 32 or 64 bytes of a row of the [dim][chains] arrays, less than a cache
+    // line -- blocks b, b + 8, b + 16, ... run on ONE XCD (round-robin dispatch), so they get CONSECUTIVE chain groups and the line
+    // they share is assembled in one L2 instead of leaving four XCDs in four partial write-backs (the host rounds the grid to 8)
+    const long blk = CPW <= 2 ? (long)(blockIdx.x & 7u) * (long)((gridDim.x + 7u) >> 3) + (long)(blockIdx.x >> 3) : (long)blockIdx.x;
+    const long wave = (blk * blockDim.x + threadIdx.x) >> 6;
     const int cw = lane & (CPW - 1);
     const int l = lane / CPW;
     const long c_raw = wave * CPW + cw;
@@ -461,21 +469,26 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
     const int k_last = 4 * (l + L * (NBL - 1));               // first dimension of the last block
 
     mhx_real x[NBL][4], y[NBL][4];
-#if MHX_REAL64
-    // A wave per chain (L = 64) touches 8 bytes per row of a [dim][chains] array: a quarter of every 32-byte sector it reads or
-    // dirties (PMC: 3.3 x the algorithmic write bytes on C5).  With the ziggurat's slab at hand the four chains of a block meet in
-    // LDS -- T[k][wave] -- and every row moves as ONE 32-byte access: the state and both moment arrays, once per launch each way.
-    const bool tr_io = ZIG && CPW == 1 && blockDim.x == 256 && (ld & 3) == 0 && ((wave & ~3L) + 4 <= a.nchains);   // block-uniform
+    // One or two chains per wave (L = 64, 32) touch 8 or 16 bytes per row of a [dim][chains] array: a fraction of every 32-byte
+    // sector they read or dirty (PMC on C5: 3.3 x the algorithmic write bytes), and a d = 1000 run that records every state
+    // ran at 0.6 TB/s.  The CB = 4 or 8 chains of a block therefore meet in LDS -- T[k][chain of the block], in the ziggurat's
+    // slab or in a buffer of its own (a.tr_lds) -- and every row moves as ONE CB-real access: the state, the moment arrays
+    // (once per launch each way) and the record of a saved step.
+    constexpr int CB = 4 * CPW;                                    // chains per 256-thread block
+    constexpr int NCH = CB * (int)sizeof(mhx_real) / 16;           // 16-byte pieces of a row segment
+    mhx_real* const Tb = (mhx_real*)((char*)mhx_coop_lds + (ZIG ? MHX_ZIG_TABLE_BYTES_ANY : 0));
+    const bool tr_io = CPW <= 2 && NCH >= 1 && a.tr_lds && blockDim.x == 256 && (((mhx_u64)ld * sizeof(mhx_real)) & 15ull) == 0 &&
+                       ((wave & ~3L) * CPW + CB <= a.nchains);     // block-uniform: every chain of the block exists
+    typedef mhx_u32 mhx_tr16 __attribute__((ext_vector_type(4)));
     auto fetch4 = [&](const mhx_real* base, auto& v) {
-        typedef double mhx_d2 __attribute__((ext_vector_type(2)));
-        double* T = mhx_coop_lds + MHX_ZIG_TABLE_BYTES / 8;
-        const int w4 = (int)(threadIdx.x >> 6);
-        const long c0 = wave & ~3L;
+        const int cb = (int)(threadIdx.x >> 6) * CPW + cw;
+        const long c0 = (wave & ~3L) * CPW;
         __syncthreads();
         for (int k = (int)threadIdx.x; k < d; k += 256) {
-            const mhx_d2* src = (const mhx_d2*)(base + (long)k * ld + c0);
-            *(mhx_d2*)(T + 4 * k) = src[0];
-            *(mhx_d2*)(T + 4 * k + 2) = src[1];
+            const mhx_tr16* src = (const mhx_tr16*)(base + (long)k * ld + c0);
+            mhx_tr16* dst = (mhx_tr16*)(Tb + (long)CB * k);
+#pragma unroll
+            for (int e = 0; e < (NCH > 0 ? NCH : 1); ++e) dst[e] = src[e];
         }
         __syncthreads();
 #pragma unroll
@@ -483,16 +496,32 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = 4 * (l + L * i) + j;
-                v[i][j] = (i < NBL - 1 || k < d) ? T[4 * k + w4] : MHX_R(0.0);
+                v[i][j] = (i < NBL - 1 || k < d) ? Tb[CB * k + cb] : MHX_R(0.0);
             }
+        __syncthreads();                         // (the memory is the waves' own again only when every wave has taken its values)
     };
-#else
-    const bool tr_io = false;
-#endif
+    auto flush4 = [&](mhx_real* base, const auto& v) {
+        const int cb = (int)(threadIdx.x >> 6) * CPW + cw;
+        const long c0 = (wave & ~3L) * CPW;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NBL; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 4 * (l + L * i) + j;
+                if (i < NBL - 1 || k < d) Tb[CB * k + cb] = v[i][j];
+            }
+        __syncthreads();
+        for (int k = (int)threadIdx.x; k < d; k += 256) {
+            const mhx_tr16* src = (const mhx_tr16*)(Tb + (long)CB * k);
+            mhx_tr16* dst = (mhx_tr16*)(base + (long)k * ld + c0);
+#pragma unroll
+            for (int e = 0; e < (NCH > 0 ? NCH : 1); ++e) dst[e] = src[e];
+        }
+        __syncthreads();                         // (a wave that runs ahead writes the next step's normals into this memory)
+    };
     if (tr_io) {
-#if MHX_REAL64
         fetch4(a.x, x);
-#endif
     } else {
 #pragma unroll
     for (int i = 0; i < NBL; ++i)
@@ -537,9 +566,7 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
     mhx_u32 mom_n = a.mom_n0;
     if (MOM) {
         if (tr_io && mom_n) {
-#if MHX_REAL64
             if constexpr (MOM) { fetch4(a.mom_mean, mm); fetch4(a.mom_m2, m2); }
-#endif
         } else {
 #pragma unroll
         for (int i = 0; i < NBL; ++i)
@@ -755,6 +782,16 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
                 for (int j = 0; j < 4; ++j) mhx_welford(x[i][j], rn, mm[i][j], m2[i][j]);
             mhx_welford(lp, rn, lpm, lpm2);
             save_next += (mhx_u32)a.thinning;
+        } else if (step == save_next && tr_io) {
+            // (one or two chains per wave: the record leaves through the block's LDS as whole row segments, see fetch4)
+            mhx_real* slotp = a.samples + slot * (long)(d + 1) * ld;
+            flush4(slotp, x);
+            if (l == 0) {
+                slotp[(long)d * ld + c] = lp;
+                a.accepted[slot * ld + c] = acc ? 1 : 0;
+            }
+            save_next += (mhx_u32)a.thinning;
+            ++slot;
         } else if (step == save_next) {
             if (valid) {
                 mhx_real* slotp = a.samples + slot * (long)(d + 1) * ld;
@@ -777,36 +814,10 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
             ++slot;
         }
     }
-#if MHX_REAL64
     const bool tr_out = tr_io;
-    auto flush4 = [&](mhx_real* base, const auto& v) {
-        typedef double mhx_d2 __attribute__((ext_vector_type(2)));
-        double* T = mhx_coop_lds + MHX_ZIG_TABLE_BYTES / 8;
-        const int w4 = (int)(threadIdx.x >> 6);
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < NBL; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = 4 * (l + L * i) + j;
-                if (i < NBL - 1 || k < d) T[4 * k + w4] = v[i][j];
-            }
-        __syncthreads();
-        const long c0 = wave & ~3L;
-        for (int k = (int)threadIdx.x; k < d; k += 256) {
-            const mhx_d2 p0 = *(const mhx_d2*)(T + 4 * k), p1 = *(const mhx_d2*)(T + 4 * k + 2);
-            mhx_d2* dst = (mhx_d2*)(base + (long)k * ld + c0);
-            dst[0] = p0; dst[1] = p1;
-        }
-    };
-#else
-    const bool tr_out = false;
-#endif
     if (tr_out) {
-#if MHX_REAL64
         flush4(a.x, x);
         if constexpr (MOM) { flush4(a.mom_mean, mm); flush4(a.mom_m2, m2); }
-#endif
     }
     if (valid) {
         if (!tr_out) {
