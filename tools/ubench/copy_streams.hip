@@ -189,6 +189,56 @@ static void run_res(f4* in, f4* out, int nseg, int nvec, long stride4, int lds_b
     printf("copy, %-11s NV=%d, %2d waves per CU  %.1f GB/s\n", ILV ? "interleaved" : "private", NV, 163840 / lds_bytes, bytes / (ms * 1e-3) / 1e9);
 }
 
+// the copy split over TWO waves of a block: wave 0 only loads (global -> registers -> LDS), wave 1 only stores (LDS -> global), one
+// block barrier per chunk, two LDS slots -- neither wave's in-order memory counter ever holds both kinds of access
+template <int NV>
+__global__ void __launch_bounds__(128) k_stream_split(const f4* __restrict__ in, f4* __restrict__ out, int nvec, long stride4)
+{
+    __shared__ f4 ring[2 * NV * 64];
+    const long seg = blockIdx.x;
+    const f4* src = in + seg * stride4;
+    f4* dst = out + seg * stride4;
+    const int t = threadIdx.x & 63;
+    const bool loader = threadIdx.x < 64;
+    const int nch = nvec / (NV * 64);
+    f4 regs[NV];
+    if (loader) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) regs[v] = src[v * 64 + t];
+    }
+    for (int k = 0; k < nch; ++k) {
+        const int sl = k & 1;
+        if (loader) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) ring[(sl * NV + v) * 64 + t] = regs[v];
+            if (k + 1 < nch) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) regs[v] = src[((k + 1) * NV + v) * 64 + t];
+            }
+        }
+        __syncthreads();
+        if (!loader) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) dst[(k * NV + v) * 64 + t] = ring[(sl * NV + v) * 64 + t] * 1.0001f;
+        }
+    }
+}
+template <int NV>
+static void run_split(f4* in, f4* out, int nseg, int nvec, long stride4)
+{
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((k_stream_split<NV>), dim3(nseg), dim3(128), 0, 0, in, out, nvec, stride4);
+    hipEventRecord(e0);
+    const int reps = 10;
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((k_stream_split<NV>), dim3(nseg), dim3(128), 0, 0, in, out, nvec, stride4);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double bytes = (double)nseg * (nvec / (NV * 64)) * (NV * 64) * 32.0 * reps;
+    printf("copy, loader wave + storer wave NV=%d  %.1f GB/s\n", NV, bytes / (ms * 1e-3) / 1e9);
+}
+
 template <int NV, bool WRITE>
 static void run(const char* name, f4* in, f4* out, float* sink, int nseg, int nvec, long stride4)
 {
@@ -232,6 +282,10 @@ int main()
         run_res<8, false>(in, out, nseg, nvec, stride4, lds);
         run_res<8, true>(in, out, nseg, nvec, stride4, lds);
     }
+    run_split<1>(in, out, nseg, nvec, stride4);
+    run_split<2>(in, out, nseg, nvec, stride4);
+    run_split<4>(in, out, nseg, nvec, stride4);
+    run_split<8>(in, out, nseg, nvec, stride4);
     run_fill(out, (long)nseg * stride4);
     run_flat(in, out, (long)nseg * stride4, 2048);
     run_flat(in, out, (long)nseg * stride4, 8192);
