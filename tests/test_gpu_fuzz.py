@@ -197,3 +197,46 @@ def test_dimensions_beyond_the_specialised_kernels(mhx, oracle, real):
     init = (np.random.default_rng(1).normal(size=(d, C)) * 0.1).astype(np.float32)
     ch = mhx.sample(mhx.DensityModel(mhx.IsoGaussian(d)), mhx.MALA(0.01), 4, C, seed=6, initial_params=init)
     same(ch.value, oracle.mala(oracle.iso_gauss(d, reduce_lanes=ch.stats["reduce_lanes"]), 0.01, oracle.schedule(4), 6, 0, C, init)["samples"], "mala d=500")
+
+
+@pytest.mark.parametrize("case", range(16))
+def test_large_dimension_shapes_random_configurations(mhx, oracle, case, real):
+    """One or two chains per wave (d = 130 ... 1000): state, moments and the per-step record move through LDS as whole row
+    segments when all chains of a block exist, element-wise otherwise -- odd chain counts exercise both in one run; both
+    generators, recorded and moments-only runs, a continued call."""
+    rng = np.random.default_rng(5000 + case + 100000 * SEED_OFFSET)
+    d = int(rng.choice([130, 200, 257, 515, 1000]))
+    C = int(rng.choice([1, 3, 4, 5, 8, 9, 37, 64]))
+    lanes = int(rng.choice([0, 32, 64]))
+    N, di, th = int(rng.integers(1, 6)), int(rng.integers(0, 3)), int(rng.integers(1, 3))
+    tname = str(rng.choice(["iso", "funnel", "banana"]))
+    zig = real == "f64" and bool(rng.integers(0, 2))
+    if lanes and -(-((d + 3) // 4) // lanes) > (13 if real == "f64" else 16):
+        pytest.skip("more blocks per lane than the cooperative kernel holds")
+    tgt = {"iso": mhx.IsoGaussian(d), "funnel": mhx.Funnel(d), "banana": mhx.Banana(d, 0.03)}[tname]
+    s = float(np.float32(0.1))
+    seed = 7 + case
+    run = mhx.Run(mhx.DensityModel(tgt), mhx.RWMH(mhx.MvNormal(mhx.zeros(d), s * s * mhx.I)), nchains=C, seed=seed, first_chain=case,
+                  reduce_lanes=lanes, normal_gen="ziggurat" if zig else None)
+    run.init(None)
+    moments = bool(rng.integers(0, 2))
+    if moments:
+        run.sample(N, di, th, 0, save="moments")
+        run.sample(N, th, th, 0, save="moments")
+    else:
+        run.sample(N, di, th, 0)
+    L = run.stats()["reduce_lanes"]
+    ot = {"iso": oracle.iso_gauss(d, reduce_lanes=L), "funnel": oracle.Target(oracle.TARGET_FUNNEL, d, reduce_lanes=L),
+          "banana": oracle.Target(oracle.TARGET_BANANA, d, params=[0.03], reduce_lanes=L)}[tname]
+    prop = oracle.Proposal(oracle.PROP_ISO, s, normal_gen=1 if zig else 0)
+    what = "case %d: d=%d C=%d lanes=%d L=%d %s zig=%s moments=%s" % (case, d, C, lanes, L, tname, zig, moments)
+    if moments:
+        total = di + 1 + (N - 1) * th + N * th                # transitions of both calls
+        ref = oracle.rwmh(ot, prop, oracle.schedule(1, total - 1), seed, case, C)
+        _same(run.state()[0], ref["final_x"], what)
+    else:
+        ref = oracle.rwmh(ot, prop, oracle.schedule(N, di, th), seed, case, C)
+        v, a = run.samples()
+        _same(v, ref["samples"], what)
+        _same(a, ref["accepted"], what)
+    run.close()
