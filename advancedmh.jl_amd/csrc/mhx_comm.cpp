@@ -25,6 +25,8 @@ struct rccl_api {
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;        // optional: what the communicator itself reports
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     bool ok = false;
 };
 
@@ -47,6 +49,8 @@ void load_rccl()
     g_rccl.AllReduce = (decltype(g_rccl.AllReduce))sym("ncclAllReduce");
     g_rccl.AllGather = (decltype(g_rccl.AllGather))sym("ncclAllGather");
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
+    g_rccl.CommCount = (decltype(g_rccl.CommCount))sym("ncclCommCount");
+    g_rccl.CommUserRank = (decltype(g_rccl.CommUserRank))sym("ncclCommUserRank");
     g_rccl.ok = g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.CommDestroy && g_rccl.AllReduce && g_rccl.AllGather &&
                 g_rccl.GetErrorString;
 }
@@ -131,8 +135,14 @@ extern "C" int mhx_comm_destroy(mhx_comm* c)
 extern "C" int mhx_comm_rank(const mhx_comm* c, int* rank, int* world)
 {
     if (!c) return mhx_fail(MHX_EINVAL, "mhx_comm_rank: comm is NULL");
-    if (rank) *rank = c->rank;
-    if (world) *world = c->world;
+    int r = c->rank, w = c->world;
+    // what RCCL itself says about this communicator (a launcher's claim is not evidence): ncclCommUserRank / ncclCommCount
+    if (c->comm && g_rccl.CommCount && g_rccl.CommUserRank) {
+        RCCL_TRY(g_rccl.CommCount(c->comm, &w));
+        RCCL_TRY(g_rccl.CommUserRank(c->comm, &r));
+    }
+    if (rank) *rank = r;
+    if (world) *world = w;
     return MHX_OK;
 }
 

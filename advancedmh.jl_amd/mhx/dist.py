@@ -66,6 +66,13 @@ class Comm:
         L.check(L.lib().mhx_comm_allreduce_sum(self.h, v.ctypes.data_as(C.POINTER(C.c_double)), v.size))
         return v
 
+    def rank_world(self):
+        """(rank, world) as the communicator itself reports them (mhx_comm_rank: ncclCommUserRank / ncclCommCount)"""
+        from . import _lib as L
+        r, w = C.c_int(), C.c_int()
+        L.check(L.lib().mhx_comm_rank(self.h, C.byref(r), C.byref(w)))
+        return r.value, w.value
+
     def slice(self, cnt):
         from . import _lib as L
         b, c = C.c_int(), C.c_int()

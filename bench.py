@@ -14,18 +14,31 @@ inside the timed region.  Chains are sharded over ranks by global chain id (firs
 collective; scaling is weak.  The only collective -- acceptance totals + R-hat sums, and the max-over-ranks time -- is
 ONE small all-reduce through the C ABI (mhx_comm_*: RCCL over xGMI).
 
-Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel against HBM with the algorithmic bytes of
-DESIGN.md section 7 and the HIP-event launch time measured here; `cpu_baseline` is the CPU oracle (a port of the
-reference algorithm, oracle/, rebuilt -O3 -march=native on the host that times it) on a bounded sample -- rank 0, N=1 only.
-At N=1 the default (c2) run also carries, all measured after the timed region:
+Launching.  `python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset) makes THIS process the launcher: it starts
+N ranks of itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / a free MASTER_PORT), one per GPU, and rank 0 prints
+the line.  Under torchrun (WORLD_SIZE set) the process is one rank.  A line never claims what did not run: --gpus must equal
+WORLD_SIZE, the box must have N devices (unless --allow-gloo, the one-GPU rehearsal), `n_gpus` is the number of DISTINCT devices
+the ranks opened, `n_ranks` the number of processes, and `config.collective` names the transport with the rank count RCCL itself
+reported (mhx_comm_rank).  `--dry-run` runs launcher, rendezvous and the host-side combining with no device and no engine
+(CPU rehearsal of the N-rank flow; `value` is null).
+
+Prints ONE JSON line on rank 0, < 8 KB (the driver keeps an 8 KB tail): numbers only -- what each field means, the byte
+models and the workload texts are DESIGN.md section 7.  `roofline` prices the dominant kernel (bound "hbm": algorithmic bytes
+of DESIGN.md section 7 over the HIP-event launch time measured here; bound "valu": PMC wave-instructions per launch over the
+same time against the issue peak); `cpu_baseline` is the CPU oracle (a port of the reference algorithm, oracle/, rebuilt -O3
+-march=native on the host that times it) on a bounded sample -- rank 0, N=1 only.  At N=1 the default (c2) run also carries,
+all measured after the timed region:
   `e2e_host`  the rate THROUGH the boundary -- samples back on the host (mhx_run_sample_to_host), save-all and thinned;
-  `configs`   the other BASELINE.json GPU configs and their SURVEY 8(d) variants (c1, c2_literal, c3, c3_rotated, c4,
-              c4_moving, c4_fixed, c5, c5_banana): value, roofline and cpu_baseline each;
+  `configs`   the other BASELINE.json configs and their SURVEY 8(d) variants (c1, c2_literal, c3, c3_rotated, c4,
+              c4_moving, c4_fixed, c5, c5_banana): {value, ms_per_step, acc, bound, frac, traffic_ratio, cpu, ...} each;
   `ess`       the ESS/sec window;  `f32` the fp32 engine on the same workload.
 """
 import argparse
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -38,14 +51,10 @@ HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.
 # profiles/r02a_valu_rates.log -- v_fma_f32 1.10 ns per instruction per SIMD at 8 waves; v_fma_f64 is 4 cycles, v_mad_u64_u32
 # ~5, v_rcp_f64 / v_sqrt_f64 ~16).  The issue peak below is the 2-cycle one for every instruction class.
 VALU_PEAK = 256 * 4 * 2.4e9 / 2.0
-VARIANTS = {0: "generic", 1: "prebuilt-register", 2: "hiprtc-register", 3: "prebuilt-cooperative",
-            4: "hiprtc-cooperative", 5: "hiprtc-dense-cooperative", 6: "persistent-ensemble",
-            7: "sequential-ensemble-sweep (the reference's Gauss-Seidel order)", 8: "matrix-core (v_mfma_*_16x16x4, shared dense factor)"}
 RB = {"f32": 4, "f64": 8}
 
 
-GEN_TEXT = {None: "Box-Muller", "box-muller": "Box-Muller",
-            "ziggurat": "the table ziggurat of the fp64 spec (MHX_FLAG_ZIGGURAT: 1024 layers, 64 bits per normal, exact rejection sampling)"}
+GEN_TEXT = {None: "Box-Muller", "box-muller": "Box-Muller", "ziggurat": "ziggurat"}
 
 
 def pick_gen(args, dtype):
@@ -72,29 +81,83 @@ def sigma_illcond(d, kappa=1e3, seed=7):
     return (Q * lam) @ Q.T
 
 
-def host_cores():
-    """the cores this process may run on (a container's cpuset can be smaller than os.cpu_count())"""
+def sig(x, n=5):
+    """a float rounded to n significant digits (the line is numbers, not prose: < 8 KB)"""
+    if x is None or isinstance(x, (bool, str)):
+        return x
+    x = float(x)
+    if x == 0.0 or not math.isfinite(x):
+        return x
+    return float("%.*g" % (n, x))
+
+
+def cgroup_cpu_quota():
+    """cores the container's CPU controller grants (cgroup v2 cpu.max, v1 cfs_quota / cfs_period), or None when unlimited"""
     try:
-        return max(1, len(os.sched_getaffinity(0)))
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return float(q) / float(p)
     except Exception:
-        return os.cpu_count() or 1
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and p > 0:
+            return q / p
+    except Exception:
+        pass
+    return None
 
 
-def threads_rate(work, cores, target_seconds):
-    """work(thread_index, nchains) on `cores` threads, chains per thread sized to ~target_seconds of wall time;
-    returns (chains in total, seconds)"""
-    import concurrent.futures as cf
+def host_cores():
+    """(threads to run, logical CPUs of the affinity mask, SMT siblings per core, cgroup quota or None): the affinity mask can be
+    wider than what the CPU controller grants -- a quota caps the thread count"""
+    try:
+        logical = max(1, len(os.sched_getaffinity(0)))
+    except Exception:
+        logical = os.cpu_count() or 1
+    smt = 1
+    try:
+        sib = open("/sys/devices/system/cpu/cpu0/topology/thread_siblings_list").read().strip()
+        smt = max(1, len([x for part in sib.split(",") for x in ([part] if "-" not in part else
+                                                                  range(int(part.split("-")[0]), int(part.split("-")[1]) + 1))]))
+    except Exception:
+        pass
+    quota = cgroup_cpu_quota()
+    threads = logical if quota is None else max(1, min(logical, int(math.ceil(quota))))
+    return threads, logical, smt, quota
 
-    def pool(n):
-        t0 = time.perf_counter()
-        with cf.ThreadPoolExecutor(cores) as ex:
-            list(ex.map(lambda i: work(i, n), range(cores)))
-        return time.perf_counter() - t0
 
-    pool(1)                                                  # thread start-up, page faults
-    t1 = pool(2)                                             # calibration: 2 chains per thread
-    n = max(2, int(2 * target_seconds / t1))
-    return cores * n, pool(n)
+def mt_baseline(run_mt, units_per_chain, target_seconds):
+    """The CPU baseline of a many-chain config: oracle/mhx_oracle_mt.c -- POSIX threads, a chain per task, each chain's record
+    contiguous (the MCMCThreads shape).  run_mt(nchains, nthreads) -> (wall seconds, per-thread CPU seconds).  Single-thread rate
+    first, then every hardware thread the host grants and (with SMT) one thread per physical core; the better one is `value`.
+    parallel_efficiency = value / (threads x single-thread rate); below 0.5 `why` says where it went: "cpu-not-granted" (the
+    threads got less CPU time than wall x threads: a quota or a busy host), else "smt-or-memory" (the time was granted and each
+    thread ran slower: hyperthread siblings share a core's pipes, or the records exceed the caches)."""
+    w, _ = run_mt(1, 1)                                       # warm: page faults, thread start
+    w, _ = run_mt(2, 1)
+    n1 = max(2, int(2 * min(1.0, 0.15 * target_seconds) / max(w, 1e-6)))
+    w1, _ = run_mt(n1, 1)
+    single = n1 * units_per_chain / w1
+    threads, logical, smt, quota = host_cores()
+    tries = [threads] + ([threads // smt] if smt > 1 and threads // smt >= 1 and quota is None else [])
+    best = None
+    for nt in tries:
+        per = 0.8 * target_seconds / len(tries)
+        n = max(2 * nt, int(nt * single * per / units_per_chain))
+        w, busy = run_mt(n, nt)
+        rate = n * units_per_chain / w
+        granted = float(busy.sum()) / w
+        if best is None or rate > best["value"]:
+            best = {"value": rate, "cores": nt, "chains": n, "wall_s": w, "granted": granted}
+    eff = best["value"] / (best["cores"] * single)
+    out = {"value": best["value"], "cores": best["cores"], "threads_used": best["cores"], "single_thread": single,
+           "parallel_efficiency": eff, "cpu_granted": best["granted"], "logical_cpus": logical, "smt": smt, "cgroup_quota": quota,
+           "chains": best["chains"], "wall_s": best["wall_s"]}
+    if eff < 0.5:
+        out["why"] = "cpu-not-granted" if best["granted"] < 0.5 * best["cores"] else "smt-or-memory"
+    return out
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -135,28 +198,17 @@ class C2:
         B = RB[self.dtype]
         return self.C * (self.inner * (B * (self.d + 1) + 1) + 2 * (B * self.d + B + 4 + 1))
 
-    def bytes_model(self):
-        return "record %d(d+1)+1 B per chain-step + state round trip per launch" % RB[self.dtype]
-
     def describe(self):
-        return ("RWMH, isotropic %d-dim standard MvNormal target, %d chains per GPU, proposal %s, "
-                "%d transitions per launch, every state recorded; standard normals by %s" % (
-                    self.d, self.C, "N(0, I) (the literal RWMH(MvNormal(zeros(d), I)) of the config text)" if self.literal
-                    else "N(0,(2.38/sqrt(d))^2 I)", self.inner, GEN_TEXT[self.gen]))
+        return "RWMH d=%d iso-Gaussian, %d chains/GPU, proposal %s, %d transitions/launch, save-all, %s normals" % (
+            self.d, self.C, "N(0,I) (literal)" if self.literal else "N(0,(2.38/sqrt d)^2 I)", self.inner, GEN_TEXT[self.gen])
 
     def cpu_baseline(self, O, target_seconds):
         tgt = O.iso_gauss(self.d)
         prop = O.Proposal(O.PROP_ISO, self.s, normal_gen=1 if self.gen == "ziggurat" else 0)
-        inner = self.inner
-
-        def work(i, nchains):
-            O.rwmh(tgt, prop, O.schedule(inner + 1), 0xC0FFEE, i * nchains, nchains, save=True)
-        t0 = time.perf_counter()
-        O.rwmh(tgt, prop, O.schedule(101), 0xC0FFEE, 0, 8, save=True)
-        rate1 = 800 / (time.perf_counter() - t0)
-        cores = host_cores()
-        n, dt = threads_rate(work, cores, target_seconds)
-        return n * inner, dt, cores, "%d chains x %d transitions of the same d=%d workload; single thread %.3g steps/s" % (n, inner, self.d, rate1)
+        sched = O.schedule(self.inner + 1)
+        r = mt_baseline(lambda n, nt: O.mt_rwmh(tgt, prop, sched, 0xC0FFEE, 0, n, nt, save=True), self.inner, target_seconds)
+        r["sample"] = "%d chains x %d transitions, d=%d, save-all" % (r["chains"], self.inner, self.d)
+        return r
 
 
 class C5(C2):
@@ -203,24 +255,17 @@ class C5(C2):
         B = RB[self.dtype]
         return self.C * (2 * (B * self.d + B + 4 + 1) + 4 * B * (self.d + 1))
 
-    def bytes_model(self):
-        return "state + running-moments round trip per launch (the chain state never leaves the registers inside a launch)"
-
     def describe(self):
-        return ("RWMH, 1000-dim %s, %d chains per GPU (global ids: shard of 8 x 32 768), proposal N(0,(2.38/sqrt(d))^2 I), "
-                "%d transitions per launch, running moments of every 10th state, R-hat by one all-reduce; standard normals by %s" % (
-                    "banana (b = 0.03 on N(0, diag(100, 1, ...)))" if self.banana else "Neal's funnel", self.C, self.inner, GEN_TEXT[self.gen]))
+        return "RWMH d=%d %s, %d chains/GPU (1 of 8 shards, global ids), proposal N(0,(2.38/sqrt d)^2 I), %d transitions/launch, moments of every 10th state, %s normals" % (
+            self.d, "banana b=0.03" if self.banana else "funnel", self.C, self.inner, GEN_TEXT[self.gen])
 
     def cpu_baseline(self, O, target_seconds):
         tgt = O.Target(O.TARGET_BANANA, self.d, params=[0.03]) if self.banana else O.Target(O.TARGET_FUNNEL, self.d)
         prop = O.Proposal(O.PROP_ISO, self.s, normal_gen=1 if self.gen == "ziggurat" else 0)
-        inner = self.inner
-
-        def work(i, nchains):
-            O.rwmh(tgt, prop, O.schedule(1, inner), 5, i * nchains, nchains, save=False)
-        cores = host_cores()
-        n, dt = threads_rate(work, cores, target_seconds)
-        return n * inner, dt, cores, "%d chains x %d transitions of the same d=%d %s" % (n, inner, self.d, "banana" if self.banana else "funnel")
+        sched = O.schedule(1, self.inner)
+        r = mt_baseline(lambda n, nt: O.mt_rwmh(tgt, prop, sched, 5, 0, n, nt, save=False), self.inner, target_seconds)
+        r["sample"] = "%d chains x %d transitions, d=%d %s" % (r["chains"], self.inner, self.d, "banana" if self.banana else "funnel")
+        return r
 
 
 class C3:
@@ -257,18 +302,10 @@ class C3:
         B = RB[self.dtype]
         return self.W * self.inner * (3 * B * self.d + 2 * B + B * (self.d + 1) + 1)
 
-    def bytes_model(self):
-        B = RB[self.dtype]
-        return "per move %d d + %d (x_i, x_j, x_i', lp) + record %d(d+1)+1" % (3 * B, 2 * B, B)
-
     def describe(self):
         band = self.run.stats().get("factor_band", -1) if hasattr(self, "run") else -1
-        return ("emcee Ensemble(StretchProposal a=2), %d-dim Gaussian %s, %d walkers (one ensemble per GPU), "
-                "%d sweeps per launch, every sweep recorded; parallel half-split sweep; %s" % (
-                    self.d, "Sigma = Q (0.9^|i-j|) Q^T, Q a seeded rotation (dense precision factor)" if self.rotated else "Sigma_ij = 0.9^|i-j|",
-                    self.W, self.inner,
-                    "the precision factor inv(chol Sigma) is banded (bandwidth %d, detected): the row products skip its structural zeros" % band
-                    if band >= 0 else "dense precision factor: d(d+1)/2 products per move"))
+        return "emcee stretch a=2, d=%d Gaussian %s, %d walkers (one ensemble/GPU), %d sweeps/step, save-all, half-split sweep, factor %s" % (
+            self.d, "Q(0.9^|i-j|)Q^T" if self.rotated else "0.9^|i-j|", self.W, self.inner, "band %d" % band if band >= 0 else "dense")
 
     def cpu_baseline(self, O, target_seconds):
         import numpy as np
@@ -282,7 +319,8 @@ class C3:
         t0 = time.perf_counter()
         O.emcee(tgt, 2.0, 0, O.schedule(sweeps + 1), 3, 0, W, init, save=True)
         dt = time.perf_counter() - t0
-        return W * sweeps, dt, 1, "%d sequential sweeps (src/emcee.jl:39-58: inherently serial in W) of the same %d-walker ensemble, one thread" % (sweeps, W)
+        return {"value": W * sweeps / dt, "cores": 1, "threads_used": 1, "single_thread": W * sweeps / dt, "parallel_efficiency": 1.0,
+                "wall_s": dt, "sample": "%d sequential sweeps (src/emcee.jl:39-58 is serial in W), %d walkers" % (sweeps, W)}
 
 
 class C4:
@@ -327,35 +365,21 @@ class C4:
             return self.C * self.inner * (B * self.d * (self.d + 1) // 2 + 2 * B * self.d + 2 * B)
         return self.C * self.inner * (B * self.d * (self.d + 1) + 2 * B * self.d + 2 * B)
 
-    def bytes_model(self):
-        B = RB[self.dtype]
-        if self.fixed:
-            return "per fixed-factor step 1 read of the packed factor: %d d(d+1)/2 + %d d + %d" % (B, 2 * B, 2 * B)
-        return "per adapting step 1 read + 1 write of the packed factor: %d d(d+1)/2 x 2 + %d d + %d" % (B, 2 * B, 2 * B)
-
     def describe(self):
-        return ("RobustAdaptiveMetropolis (alpha 0.234, gamma 0.6), %d-dim Gaussian, kappa = 1e3 (Q diag Q^T), %d chains per GPU each "
-                "with its own factor, %d %s transitions per launch, %s" % (
-                    self.d, self.C, self.inner, "fixed-factor (after %d adapting ones)" % self.inner if self.fixed else "adapting",
-                    "random start, S0 = 2.38/sqrt(d) I (the variant that moves)" if self.moving else "x0 = 0, S0 = I"))
+        return "RAM alpha=0.234 gamma=0.6, d=%d Gaussian kappa=1e3, %d chains/GPU (own factor each), %d %s transitions/launch, %s" % (
+            self.d, self.C, self.inner, "fixed-factor" if self.fixed else "adapting",
+            "random start, S0=2.38/sqrt(d) I" if self.moving else "x0=0, S0=I")
 
     def cpu_baseline(self, O, target_seconds):
         import numpy as np
         tgt = O.corr_gauss_from_cov(self.Sig)
         inner, d = self.inner, self.d
-        init1 = np.zeros((d, 1))
-
+        init1 = np.zeros(d)
         warm = 0 if self.fixed else inner                  # fixed-factor steps: the oracle's steps on S0 cost what they cost on any S
-
-        def work(i, nchains):
-            O.ram(tgt, O.schedule(1, inner, 1, warm), 4, i * nchains, nchains, init=np.zeros((d, nchains)), save=False)
-        t0 = time.perf_counter()
-        O.ram(tgt, O.schedule(1, 20, 1, 20 if warm else 0), 4, 0, 1, init=init1, save=False)
-        rate1 = 20 / (time.perf_counter() - t0)
-        cores = host_cores()
-        n, dt = threads_rate(work, cores, target_seconds)
-        return n * inner, dt, cores, "%d chains x %d %s transitions of the same d=%d workload; single thread %.3g steps/s" % (
-            n, inner, "fixed-factor" if self.fixed else "adapting", d, rate1)
+        sched = O.schedule(1, inner, 1, warm)
+        r = mt_baseline(lambda n, nt: O.mt_ram(tgt, sched, 4, 0, n, nt, save=False, init1=init1), inner, target_seconds)
+        r["sample"] = "%d chains x %d %s transitions, d=%d" % (r["chains"], inner, "fixed-factor" if self.fixed else "adapting", d)
+        return r
 
 
 class C1:
@@ -387,12 +411,8 @@ class C1:
         B = RB[self.dtype]
         return self.C * (self.inner * (B * 3 + 1) + 2 * (B * 2 + B + 5))
 
-    def bytes_model(self):
-        return "record %d(d+1)+1 B per chain-step (a latency-bound single chain: the HBM fraction is not the point)" % RB[self.dtype]
-
     def describe(self):
-        return ("RWMH, d = 2 Normal(mu, sigma) likelihood of 30 data points (README.md:18-63), proposal N(0, I), %d chain(s) x %d draws, "
-                "every state recorded" % (self.C, self.inner))
+        return "RWMH d=2 Normal(mu,sigma) likelihood of 30 points (README.md:18-63), proposal N(0,I), %d chain x %d draws, save-all" % (self.C, self.inner)
 
     def cpu_baseline(self, O, target_seconds):
         tgt = O.Target(O.TARGET_IID_NORMAL, 2, params=self.data)
@@ -401,7 +421,8 @@ class C1:
         t0 = time.perf_counter()
         O.rwmh(tgt, prop, O.schedule(self.inner), 1234, 0, 1, init=np.array([[0.0], [1.0]]), save=True)
         dt = time.perf_counter() - t0
-        return self.inner, dt, 1, "1 chain x %d draws of the same model, one thread (what `sample(model, spl, N)` is)" % self.inner
+        return {"value": self.inner / dt, "cores": 1, "threads_used": 1, "single_thread": self.inner / dt, "parallel_efficiency": 1.0,
+                "wall_s": dt, "sample": "1 chain x %d draws, one thread (`sample(model, spl, N)`)" % self.inner}
 
 
 WORKLOADS = {"c1": C1, "c2": C2, "c3": C3, "c4": C4, "c5": C5}
@@ -410,24 +431,37 @@ WORKLOADS = {"c1": C1, "c2": C2, "c3": C3, "c4": C4, "c5": C5}
 _ORACLE_FLAGS = None
 
 
-def cpu_baseline(wl, dtype, target_seconds=10.0):
-    """The oracle (same algorithm, same Philox streams, scalar loop per chain) on the host cores: chains statically
-    partitioned over threads (the MCMCThreads analogue).  Bounded sample.  Built on this host with -O3 -march=native as
-    BASELINE.md's CPU-baseline plan says (oracle/Makefile `native`; bit-identical to the portable build the tests use)."""
+def cpu_baseline(wl, dtype, target_seconds=10.0, compact=False):
+    """The oracle (same algorithm, same Philox streams, scalar loop per chain) on the host cores: a chain per task over POSIX
+    threads (oracle/mhx_oracle_mt.c -- the MCMCThreads analogue; each chain's record contiguous).  Bounded sample.  Built on
+    this host with -O3 -march=native as BASELINE.md's CPU-baseline plan says (oracle/Makefile `native`; bit-identical to the
+    portable build the tests use)."""
     global _ORACLE_FLAGS
     from oracle import oracle as O
     O.build()
     if _ORACLE_FLAGS is None:
         _ORACLE_FLAGS = O.use_native()
     O.set_dtype(dtype)
-    units, dt, cores, sample = wl.cpu_baseline(O, target_seconds)
-    return {"value": units / dt, "unit": "MH steps/s", "cores": cores, "kind": "port",
-            "sample": "%s (oracle/mhx_oracle.c in %s, %s, %d thread(s), %.1f s)" % (sample, dtype, _ORACLE_FLAGS, cores, dt)}
+    r = wl.cpu_baseline(O, target_seconds)
+    if compact:
+        out = {"value": sig(r["value"]), "cores": r["cores"], "single_thread": sig(r["single_thread"], 4),
+               "parallel_efficiency": sig(r["parallel_efficiency"], 3)}
+        if "why" in r:
+            out["why"] = r["why"]
+        return out
+    out = {"value": r["value"], "unit": "MH steps/s", "cores": r["cores"], "kind": "port",
+           "sample": "%s; oracle %s, %s, %.1f s" % (r["sample"], dtype, "native" if "native" in _ORACLE_FLAGS else "portable", r["wall_s"]),
+           "threads_used": r["threads_used"], "single_thread": sig(r["single_thread"]), "parallel_efficiency": sig(r["parallel_efficiency"], 3)}
+    for k in ("cpu_granted", "logical_cpus", "smt", "cgroup_quota", "why"):
+        if k in r:
+            out[k] = sig(r[k], 4)
+    return out
 
 
 class GlooSum:
     """Fallback transport of the bench's three tiny host-side all-reduces (torch.distributed, gloo): same interface as
-    mhx.dist.Comm.allreduce_sum.  Only used when the RCCL communicator behind the C ABI cannot be created."""
+    mhx.dist.Comm.allreduce_sum.  Only used when the RCCL communicator behind the C ABI cannot be created (--allow-gloo) and by
+    --dry-run."""
 
     def __init__(self, dist):
         self.dist = dist
@@ -443,18 +477,26 @@ class GlooSum:
         pass
 
 
-def make_collective(ctx, rank, world, allow_gloo=False):
-    """One process per GPU under torchrun.  The rendezvous is torch.distributed's own (gloo on CPU: it only carries the
-    128-byte RCCL id from rank 0 to the others); the bench's collectives -- barrier, max-over-ranks time, acceptance totals
-    and R-hat sums -- then go through the C ABI (mhx_comm_*: RCCL over xGMI).  If the RCCL communicator cannot be created on
-    EVERY rank, all ranks fall back to gloo for those three small host-side all-reduces (reported in config.collective)."""
-    import numpy as np
+def rendezvous(rank, world):
+    """torch.distributed's own rendezvous (gloo on CPU; MASTER_ADDR / MASTER_PORT from the launcher): it carries the 128-byte RCCL
+    id from rank 0 to the others and is the --allow-gloo / --dry-run transport"""
     import torch.distributed as dist
-    from mhx.dist import Comm
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
     if not dist.is_initialized():
         dist.init_process_group("gloo", rank=rank, world_size=world)
+    return dist
+
+
+def make_collective(ctx, rank, world, allow_gloo=False):
+    """One process per GPU.  The bench's collectives -- barrier, max-over-ranks time, acceptance totals and R-hat sums -- go
+    through the C ABI (mhx_comm_*: RCCL over xGMI).  Returns (transport, text, ranks): `ranks` is what the transport itself
+    reports (mhx_comm_rank -> ncclCommCount).  If the RCCL communicator cannot be created on EVERY rank, all ranks fall back to
+    gloo for those small host-side all-reduces -- only with --allow-gloo, and the line says so."""
+    import numpy as np
+    import torch
+    from mhx.dist import Comm
+    dist = rendezvous(rank, world)
     box = [Comm.unique_id() if rank == 0 else None]
     dist.broadcast_object_list(box, src=0)
     comm, err = None, ""
@@ -463,19 +505,21 @@ def make_collective(ctx, rank, world, allow_gloo=False):
         comm.allreduce_sum(np.zeros(1))
     except Exception as e:                                       # e.g. no librccl, or two ranks on one device
         comm, err = None, str(e)[:200]
-    import torch
     ok = torch.tensor([1.0 if comm is not None else 0.0], dtype=torch.float64)
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)                    # all ranks or none
     if ok.item() >= 1.0:
-        return comm, "mhx_comm_* (RCCL over xGMI, through the C ABI); rendezvous: torch.distributed gloo"
+        r, w = comm.rank_world()
+        if w != world or r != rank:
+            raise RuntimeError("bench.py: RCCL reports rank %d of %d, the launcher said %d of %d" % (r, w, rank, world))
+        return comm, "rccl(mhx_comm_*), %d ranks" % w, w
     if comm is not None:
         comm.close()
     if not allow_gloo:
         # a multi-GPU line must not silently skip RCCL: without --allow-gloo the missing communicator is an error
         raise RuntimeError("bench.py --gpus %d: the RCCL communicator behind the C ABI (mhx_comm_init) could not be created on every "
-                           "rank (%s); pass --allow-gloo to run the three small host-side all-reduces over torch.distributed gloo instead"
+                           "rank (%s); pass --allow-gloo to run the small host-side all-reduces over torch.distributed gloo instead"
                            % (world, err or "another rank failed"))
-    return GlooSum(dist), "torch.distributed gloo (--allow-gloo fallback: the RCCL communicator could not be created: %s)" % err
+    return GlooSum(dist), "gloo, %d ranks (--allow-gloo: no RCCL communicator: %s)" % (dist.get_world_size(), err[:80]), dist.get_world_size()
 
 
 def timed(wl, steps, warmup, barrier, spin=30):
@@ -496,12 +540,10 @@ def timed(wl, steps, warmup, barrier, spin=30):
 
 
 def ess_window(mhx, wl, world):
-    """ESS/sec of SURVEY 8(d): rank-normalised bulk ESS (split chains, Geyer truncation) of a THINNED window long enough
-    for the autocorrelations to die out -- 256 draws `thin` transitions apart, thin chosen so that the window spans ~40
-    autocorrelation times (RWMH at the optimal scale: tau ~ d / 0.3; each split half ~20) -- over the wall time of
-    producing that window.  `reached_max_lag`: the multi-chain autocorrelation rho_t = 1 - (W - A_t) / var+ keeps the
-    floor (var+ - W) / var+ of finite chains, so with thousands of chains averaged its pair sums stay positive up to the
-    last lag; the estimate then carries every lag of the window."""
+    """ESS/sec of SURVEY 8(d): rank-normalised bulk ESS (split chains, Geyer truncation; mhx_run_ess_bulk_tail) of a THINNED
+    window long enough for the autocorrelations to die out -- 256 draws `thin` transitions apart, thin chosen so that the window
+    spans ~40 autocorrelation times (RWMH at the optimal scale: tau ~ d / 0.3; each split half ~20) -- over the wall time of
+    producing that window."""
     import numpy as np
     d, run = wl.d, wl.run
     thin = max(1, int(round(40 * (d / 0.3) / 256)))        # each split half spans ~20 autocorrelation times
@@ -516,62 +558,62 @@ def ess_window(mhx, wl, world):
     b = run.ess_bulk_tail(params=params, max_lag=n_draws // 2 - 2, ess_chains=512, split=True)
     dg = run.diagnostics(max_lag=0, split=True)
     med = float(np.median(b["ess_bulk"]))
-    return {"estimator": "rank-normalised bulk ESS, split chains, Geyer initial monotone sequence (mhx_run_ess_bulk_tail)",
-            "window": "%d draws x %d chains, %d transitions apart (%d transitions per chain)" % (n_draws, run.n, thin, n_draws * thin),
-            "params": [int(p) for p in params], "ess_bulk": [float(v) for v in b["ess_bulk"]],
-            "ess_tail": [float(v) for v in b["ess_tail"]], "tail_ess_per_sec": float(np.median(b["ess_tail"])) / wall,
-            "reached_max_lag": [bool(v) for v in b["bulk_truncated"]],
-            "median": med, "per_transition_per_chain": med / (run.n * n_draws * thin),
-            "wall_s": wall, "kernel_ms": st["kernel_ms"], "rhat_max_split": float(np.nanmax(dg["rhat"][:d])),
-            "ess_per_sec": med / wall}
+    return {"draws": n_draws, "thin": thin, "chains": run.n, "params": [int(p) for p in params],
+            "ess_bulk": [sig(v) for v in b["ess_bulk"]], "ess_tail": [sig(v) for v in b["ess_tail"]],
+            "tail_ess_per_sec": sig(float(np.median(b["ess_tail"])) / wall), "median": sig(med),
+            "per_transition_per_chain": sig(med / (run.n * n_draws * thin)), "wall_s": sig(wall), "kernel_ms": sig(st["kernel_ms"]),
+            "rhat_max_split": sig(float(np.nanmax(dg["rhat"][:d]))), "ess_per_sec": med / wall}
+
+
+KERNELS = {0: "generic", 1: "prebuilt-register", 2: "hiprtc-register", 3: "prebuilt-cooperative", 4: "hiprtc-cooperative",
+           5: "hiprtc-dense-cooperative", 6: "persistent-ensemble", 7: "sequential-ensemble-sweep", 8: "matrix-core"}
 
 
 def config_block(wl, name, st, collective):
     return {"workload": wl.describe(), "name": name, "units_per_step_per_gpu": wl.units_per_step(),
-            "kernel_variant": VARIANTS.get(st["kernel_variant"], str(st["kernel_variant"])), "lanes_per_unit": st["reduce_lanes"],
+            "kernel_variant": KERNELS.get(st["kernel_variant"], str(st["kernel_variant"])), "lanes_per_unit": st["reduce_lanes"],
             "launches_per_step": max(1, st["launches"]),
             "sharding": "chains by global id, no data-path collective" if name != "c3" else "one ensemble per GPU (replicas)",
             "collective": collective}
 
 
-def roofline_block(wl, name, dtype, kernel_ms, steps, st):
-    """The dominant kernel against HBM: algorithmic bytes per step over the HIP-event time of the step's
-    launches measured here; `traffic` / `valu` from the PMC passes of tools/profile_round.sh (profiles/traffic.json) when they
-    were taken on this workload."""
+def pmc_of(wl, name, dtype):
+    """PMC figures of tools/profile_round.sh (profiles/traffic.json) when they were taken on exactly this workload"""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        tj = json.load(open(tpath)).get("%s_%s" % (name, dtype), {})
+    except Exception:
+        return {}
+    return tj if tj.get("units_per_launch") == wl.units_per_step() else {}
+
+
+def roofline_block(wl, key, dtype, kernel_ms, steps, st):
+    """The dominant kernel against its bound.  HBM-bound configs: algorithmic bytes per step over the
+    HIP-event time of the step's launches measured here.  C5 keeps its state in registers for a whole launch and is bound by VALU
+    issue: PMC wave-instructions per launch (profiles/traffic.json) over the same time against 1024 SIMDs x 1 instruction per 2
+    cycles at 2.4 GHz; its HBM figure rides along as `hbm_frac`.  `traffic` = PMC HBM bytes per step (FETCH_SIZE x 2 + WRITE_SIZE)."""
     launches = max(1, st["launches"])
     launch_s = kernel_ms * 1e-3 / steps
     bytes_launch = wl.bytes_per_launch()
     achieved = bytes_launch / launch_s / 1e9
-    traffic, valu = None, None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    key = "%s_%s" % (name, dtype)
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath)).get(key, {})
-            # (a variant whose kernel or byte count differs from the profiled one carries no PMC figures)
-            own_pmc = not (getattr(wl, "fixed", False) or getattr(wl, "banana", False) or getattr(wl, "rotated", False))
-            if own_pmc and tj.get("units_per_launch") == wl.units_per_step():
-                traffic = tj.get("hbm_bytes_per_launch")
-                if tj.get("valu_insts_per_launch"):
-                    rate = tj["valu_insts_per_launch"] / launch_s
-                    valu = {"wave_insts_per_launch": tj["valu_insts_per_launch"], "achieved_per_s": rate, "peak_per_s": VALU_PEAK,
-                            "frac": rate / VALU_PEAK, "source": tj.get("source"),
-                            "note": "wave64 VALU instructions (PMC SQ_INSTS_VALU) per second against 1024 SIMDs x one instruction "
-                                    "per 2 cycles at 2.4 GHz; the fp64 / 64-bit-multiply / transcendental instructions of the mix "
-                                    "take 4-16 cycles each, so 1.0 is not reachable by this instruction mix"}
-        except Exception:
-            traffic, valu = None, None
-    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "avg_launch_ms": launch_s * 1e3 / launches, "kernel_ms_per_step": launch_s * 1e3,
-            "algorithmic_bytes_per_step": bytes_launch, "bytes_model": wl.bytes_model(), "valu": valu}
+    tj = pmc_of(wl, key, dtype)
+    traffic = tj.get("hbm_bytes_per_launch")
+    valu_frac = tj["valu_insts_per_launch"] / launch_s / VALU_PEAK if tj.get("valu_insts_per_launch") else None
+    out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+           "traffic": traffic, "avg_launch_ms": launch_s * 1e3 / launches, "algorithmic_bytes_per_step": bytes_launch,
+           "valu_frac": sig(valu_frac, 4)}
+    if wl.name == "c5" and valu_frac is not None:
+        out = {"bound": "valu", "achieved": tj["valu_insts_per_launch"] / launch_s, "peak": VALU_PEAK, "unit": "wave-inst/s",
+               "frac": valu_frac, "traffic": traffic, "avg_launch_ms": launch_s * 1e3 / launches,
+               "valu_insts_per_step": tj["valu_insts_per_launch"], "algorithmic_bytes_per_step": bytes_launch,
+               "hbm_frac": sig(achieved / HBM_PEAK_GBS, 4)}
+    return out
 
 
 def other_configs(mhx, ctx, args, barrier):
-    """The other BASELINE.json GPU configs in the same driver run (N = 1, rank 0, after the headline's timed region): value,
-    roofline of the dominant kernel and a CPU baseline (2 s samples) for C2 with the literal N(0, I) proposal, C3 (and its
-    dense-rotated variant), C4 as specified, from a start that moves, and with the factor frozen, and C5's per-GPU shard on the
-    funnel and on the banana.  Fewer steps than the headline (C4 runs 0.26 s per step): every figure says how many."""
+    """The other BASELINE.json configs in the same driver run (N = 1, rank 0, after the headline's timed region), one compact
+    block each: value, ms_per_step, acceptance, bound / frac of the dominant kernel, PMC traffic over algorithmic bytes, launch
+    time, and the CPU baseline (2 s samples).  What each key is: DESIGN.md section 7."""
     import copy
     plan = [("c1", "c1", {}, 3, 1), ("c2_literal", "c2", {"c2_literal": True}, 20, 10),
             ("c3", "c3", {}, 10, 10), ("c3_rotated", "c3", {"c3_rotated": True}, 10, 10), ("c4", "c4", {}, 3, 2),
@@ -588,31 +630,37 @@ def other_configs(mhx, ctx, args, barrier):
             w = WORKLOADS[name](a, args.dtype)
             w.build(mhx, ctx, 0)
             dt, kms, acc, tr, st = timed(w, steps, 2, barrier, spin=spin)
-            blk = {"value": w.units_per_step() * steps / dt, "unit": "MH steps/s", "steps": steps, "ms_per_step": dt * 1e3 / steps,
-                   "dtype": args.dtype, "acceptance_rate": acc / float(tr), "config": config_block(w, name, st, None),
-                   "roofline": roofline_block(w, name, args.dtype, kms, steps, st)}
+            rf = roofline_block(w, key, args.dtype, kms, steps, st)
+            blk = {"value": sig(w.units_per_step() * steps / dt), "ms_per_step": sig(dt * 1e3 / steps), "acc": sig(acc / float(tr), 3),
+                   "bound": rf["bound"], "frac": sig(rf["frac"], 4),
+                   "traffic_ratio": sig(rf["traffic"] / rf["algorithmic_bytes_per_step"], 4) if rf.get("traffic") else None,
+                   "launch_us": sig(rf["avg_launch_ms"] * 1e3, 4), "kernel": KERNELS.get(st["kernel_variant"], "?"), "lanes": st["reduce_lanes"]}
+            if rf["bound"] == "valu":
+                blk["hbm_frac"] = rf["hbm_frac"]
+            if st.get("factor_band", -1) >= 0:
+                blk["band"] = st["factor_band"]
             w.run.close()
             if not args.no_cpu_baseline:
-                blk["cpu_baseline"] = cpu_baseline(w, args.dtype, 2.0)
+                blk["cpu"] = cpu_baseline(w, args.dtype, 2.0, compact=True)
             res[key] = blk
         except Exception as e:                                   # one config must not take the line down
-            res[key] = {"error": str(e)[:300]}
+            res[key] = {"error": str(e)[:160]}
     return res
 
 
 def e2e_host(mhx, wl):
     """"kernel time AND end-to-end including D2H of whatever is kept, both reported".  The reference's `sample`
     returns a host container; mhx_run_sample_to_host streams the samples into page-locked host memory while the chains run.
-    Three figures on the headline workload: (a) save-all, every state of `inner` transitions to the host (the PCIe link is the
-    bound: B(d+1)+1 bytes per chain-step); (b) a thinned run (the ESS window's schedule), which returns at the kernel rate;
-    (c) the round-2 path for comparison -- mhx_run_sample, then one synchronous mhx_run_get_samples into pageable memory."""
+    Three figures on the headline workload: save_all -- every state of `inner` transitions to the host (the PCIe link is the
+    bound: B(d+1)+1 bytes per chain-step); thinned -- the ESS window's schedule, which returns at the kernel rate; round2_path --
+    mhx_run_sample, then one synchronous mhx_run_get_samples into pageable memory."""
     import numpy as np
     run, d, C, inner = wl.run, wl.d, wl.C, wl.inner
     out = {}
     t0 = time.perf_counter()
     buf = mhx.host_array((inner, d + 1, C), run.real)
     accb = mhx.host_array((inner, C), np.uint8)
-    out["pinned_alloc_s"] = time.perf_counter() - t0
+    out["pinned_alloc_s"] = sig(time.perf_counter() - t0, 3)
     run.sample_to_host(inner, 1, 1, 0, out=buf, out_accepted=accb)          # untimed: first touch of the slabs and streams
     reps = 3
     t0 = time.perf_counter()
@@ -620,9 +668,8 @@ def e2e_host(mhx, wl):
         run.sample_to_host(inner, 1, 1, 0, out=buf, out_accepted=accb)
     w = (time.perf_counter() - t0) / reps
     nbytes = buf.nbytes + accb.nbytes
-    out["save_all"] = {"value": C * inner / w, "unit": "MH steps/s with every state on the host", "wall_s": w, "host_GB": nbytes / 1e9,
-                       "link_GBps": nbytes / w / 1e9, "kernel_ms": run.stats()["kernel_ms"],
-                       "note": "mhx_run_sample_to_host into page-locked memory; bound by the PCIe Gen5 x16 link (63 GB/s spec), not by the kernel"}
+    out["save_all"] = {"value": sig(C * inner / w), "wall_s": sig(w, 4), "host_GB": sig(nbytes / 1e9, 4), "link_GBps": sig(nbytes / w / 1e9, 4),
+                       "kernel_ms": sig(run.stats()["kernel_ms"], 4)}
     thin = max(1, int(round(40 * (d / 0.3) / 256)))
     n_draws = 256
     tb = mhx.host_array((n_draws, d + 1, C), run.real)
@@ -631,17 +678,107 @@ def e2e_host(mhx, wl):
     t0 = time.perf_counter()
     run.sample_to_host(n_draws, thin, thin, 0, out=tb, out_accepted=ta)
     w = time.perf_counter() - t0
-    out["thinned"] = {"value": C * n_draws * thin / w, "unit": "MH steps/s with the kept draws on the host", "wall_s": w,
-                      "schedule": "%d draws %d transitions apart" % (n_draws, thin), "host_GB": (tb.nbytes + ta.nbytes) / 1e9,
-                      "kernel_ms": run.stats()["kernel_ms"]}
+    out["thinned"] = {"value": sig(C * n_draws * thin / w), "wall_s": sig(w, 4), "draws": n_draws, "thin": thin,
+                      "host_GB": sig((tb.nbytes + ta.nbytes) / 1e9, 4), "kernel_ms": sig(run.stats()["kernel_ms"], 4)}
     del tb, ta
     t0 = time.perf_counter()
     run.sample(inner, 1, 1, 0, save=True)
     old, _ = run.samples()
     w = time.perf_counter() - t0
-    out["round2_path"] = {"value": C * inner / w, "wall_s": w, "note": "mhx_run_sample, then one synchronous mhx_run_get_samples into a fresh pageable array"}
+    out["round2_path"] = {"value": sig(C * inner / w), "wall_s": sig(w, 4)}
     del old
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# launching: --gpus N without a launcher starts N ranks of this script; a rank refuses a command line that disagrees with it
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def visible_devices():
+    import torch
+    return torch.cuda.device_count()
+
+
+def launch_ranks(args):
+    """This process is the launcher (WORLD_SIZE unset, --gpus N > 1): N children of the same command line, one per GPU, rank 0's
+    stdout is ours.  Exit code: the first non-zero child's.  A failing rank takes the others down (they would wait in a
+    collective for ever)."""
+    n = args.gpus
+    if not args.dry_run:
+        have = visible_devices()
+        if have < n and not args.allow_gloo:
+            sys.stderr.write("bench.py --gpus %d: this box has %d GPU(s); refusing to print a %d-GPU line (the one-GPU rehearsal of "
+                             "the %d-rank flow is --allow-gloo, the device-free one --dry-run)\n" % (n, have, n, n))
+            return 2
+    env = dict(os.environ)
+    env.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
+               MHX_BENCH_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC: what RCCL needs between processes on this driver
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc, alive = 0, list(procs)
+    while alive:
+        time.sleep(0.05)
+        for p in list(alive):
+            c = p.poll()
+            if c is None:
+                continue
+            alive.remove(p)
+            if c != 0 and rc == 0:
+                rc = c
+                for q in alive:                                   # our own children, by pid
+                    q.terminate()
+    return rc
+
+
+def dry_run(args, rank, world):
+    """--dry-run: the N-rank flow with no device and no engine -- rendezvous, barrier, max-over-ranks time and the summed
+    totals over gloo; each rank's "step" is a counter.  Proves on a CPU box that `--gpus N` really is N processes."""
+    import numpy as np
+    comm = GlooSum(rendezvous(rank, world)) if world > 1 else None
+
+    def barrier():
+        if comm is not None:
+            comm.allreduce_sum(np.zeros(1))
+    barrier()
+    t0 = time.perf_counter()
+    units = 0
+    for _ in range(args.steps):
+        units += 1000
+    barrier()
+    dt = time.perf_counter() - t0
+    ranks, total, pids = 1, float(units), [os.getpid()]
+    if comm is not None:
+        t = np.zeros(world)
+        t[rank] = dt
+        dt = float(comm.allreduce_sum(t).max())
+        v = comm.allreduce_sum(np.array([1.0, float(units)]))
+        ranks, total = int(round(v[0])), float(v[1])
+        p = np.zeros(world)
+        p[rank] = os.getpid()
+        pids = [int(x) for x in comm.allreduce_sum(p)]
+    if rank == 0:
+        print(json.dumps({"metric": "MH steps/sec (all chains) + ESS/sec", "value": None, "unit": "MH steps/s", "dry_run": True,
+                          "n_gpus": 0, "n_ranks": ranks, "distinct_processes": len(set(pids)), "steps": args.steps, "warmup": args.warmup,
+                          "units_all_ranks": total, "ms_per_step": dt * 1e3 / max(1, args.steps), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "none (dry run: no device, no engine)",
+                          "config": {"workload": "dry run of the %d-rank flow" % world, "name": args.config,
+                                     "collective": "gloo, %d ranks (dry run)" % ranks}}), flush=True)
+    if comm is not None:
+        barrier()
+        comm.dist.destroy_process_group()
+    return 0
 
 
 def main():
@@ -664,30 +801,52 @@ def main():
     ap.add_argument("--normal-gen", choices=["auto", "ziggurat", "box-muller"], default="auto",
                     help="c2 / c5: how the RWMH kernel turns stream bits into standard normals (auto: ziggurat in fp64, Box-Muller in fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--allow-gloo", action="store_true", help="--gpus > 1: fall back to torch.distributed gloo for the host-side "
-                    "all-reduces when the RCCL communicator cannot be created (default: that is an error)")
+    ap.add_argument("--allow-gloo", action="store_true", help="--gpus > 1: the one-GPU rehearsal -- fewer devices than ranks are "
+                    "accepted (ranks share devices; n_gpus says how many were really opened) and the host-side all-reduces fall back to "
+                    "torch.distributed gloo when the RCCL communicator cannot be created (default: both are errors)")
+    ap.add_argument("--dry-run", action="store_true", help="launcher + rendezvous + host-side combining only: no device, no engine")
     ap.add_argument("--no-other-configs", action="store_true", help="c2 at N=1: skip the C3 / C4 / C4-moving / C5 lines under `configs`")
     ap.add_argument("--no-e2e", action="store_true", help="c2 at N=1: skip the rate through the boundary (samples back on the host)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="size of the CPU-baseline sample of the headline config")
     ap.add_argument("--no-second-dtype", action="store_true", help="skip the fp32 figure")
     ap.add_argument("--no-ess", action="store_true")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(launch_ranks(args))                          # this process is the launcher
+        rank, local_rank, world = 0, 0, 1
+    else:
+        rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        world = int(os.environ["WORLD_SIZE"])
+        if world != args.gpus:                                   # never print an N-GPU line from a different number of ranks
+            sys.stderr.write("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; refusing to run\n" % (args.gpus, world))
+            sys.exit(2)
+    if args.dry_run:
+        sys.exit(dry_run(args, rank, world))
 
     import numpy as np
     import torch
     import mhx
-    from mhx.dist import Comm, allreduce_stats
+    from mhx.dist import allreduce_stats
 
-    local_rank %= max(1, torch.cuda.device_count())             # (several ranks on one device only when a box has fewer GPUs than ranks)
-    torch.cuda.set_device(local_rank)
-    ctx = mhx.Context(local_rank, args.dtype)
-    comm, collective = None, None
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        sys.stderr.write("bench.py: no GPU visible (the engine has no CPU path); --dry-run rehearses the launch without one\n")
+        sys.exit(2)
+    if ndev < world and not args.allow_gloo:
+        sys.stderr.write("bench.py --gpus %d: %d device(s) visible to rank %d; refusing (ranks would share a GPU). --allow-gloo accepts it "
+                         "as a rehearsal\n" % (args.gpus, ndev, rank))
+        sys.exit(2)
+    device = local_rank % ndev                                   # (several ranks on one device only in the --allow-gloo rehearsal)
+    torch.cuda.set_device(device)
+    ctx = mhx.Context(device, args.dtype)
+    comm, collective, ranks_reported = None, None, 1
     if world > 1 or os.environ.get("MHX_BENCH_FORCE_DIST"):      # the env knob exercises the collective path on 1 GPU
-        comm, collective = make_collective(ctx, rank, world, args.allow_gloo)
+        comm, collective, ranks_reported = make_collective(ctx, rank, world, args.allow_gloo)
 
     def barrier():
         torch.cuda.synchronize()
@@ -695,10 +854,19 @@ def main():
             comm.allreduce_sum(np.zeros(1))                      # every rank has arrived
             torch.cuda.synchronize()
 
+    # the devices the ranks REALLY opened: n_gpus of the line is their number, not the flag
+    n_gpus = 1
+    if comm is not None:
+        ids = np.zeros(world)
+        ids[rank] = 1 + device
+        n_gpus = len(set(int(round(v)) for v in comm.allreduce_sum(ids)))
+        if n_gpus != world and not args.allow_gloo:
+            sys.stderr.write("bench.py --gpus %d: the %d ranks opened %d distinct device(s)\n" % (args.gpus, world, n_gpus))
+            sys.exit(2)
+
     wl = WORKLOADS[args.config](args, args.dtype)
     wl.build(mhx, ctx, rank)
     dt, kernel_ms, accepted, transitions, st = timed(wl, args.steps, args.warmup, barrier)
-    variant = st["kernel_variant"]
 
     # outside the timed region: diagnostics, the ESS window, the fp32 figure, the CPU baseline
     ess, diag = None, None
@@ -716,57 +884,63 @@ def main():
             acc_rate = v[0] / v[1]
     else:
         acc_rate = accepted / float(transitions)
-    if args.config == "c2" and not args.no_ess and not args.c2_literal and rank == 0:
+    if args.config == "c2" and not args.no_ess and not args.c2_literal and rank == 0 and world == 1:
         try:
             ess = ess_window(mhx, wl, world)
         except Exception as e:                                   # never let a diagnostic break the bench line
-            ess = {"error": str(e)}
+            ess = {"error": str(e)[:160]}
 
     if rank == 0:
         units = float(wl.units_per_step()) * args.steps * world
         value = units / dt
         out = {
             "metric": "MH steps/sec (all chains) + ESS/sec", "value": value, "unit": "MH steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": n_gpus, "n_ranks": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": config_block(wl, args.config, st, collective),
-            "acceptance_rate": acc_rate,
+            "acceptance_rate": sig(acc_rate, 4),
             "roofline": roofline_block(wl, args.config, args.dtype, kernel_ms, args.steps, st),
         }
+        if comm is not None:
+            out["config"]["ranks_reported_by_transport"] = ranks_reported
+            if n_gpus != world:
+                out["oversubscribed"] = "%d ranks share %d device(s): a rehearsal of the flow, not a scaling point" % (world, n_gpus)
         if ess is not None:
             out["ess_per_sec"] = ess.get("ess_per_sec")
             out["ess"] = ess
         if diag is not None:
-            # the all-reduced between / within statistic of the LAST timed launch only (250 consecutive transitions, shorter
-            # than one autocorrelation time at d = 100): it exercises the collective, it is not a convergence claim -- the
-            # thinned window's split R-hat is ess.rhat_max_split
-            out["rhat_last_launch"] = {"value": float(np.nanmax(diag["rhat"][:wl.d])),
-                                       "note": "one launch of consecutive transitions across all ranks (the R-hat all-reduce); see ess.rhat_max_split"}
+            # the all-reduced between / within statistic of the LAST timed launch only (consecutive transitions, shorter than one
+            # autocorrelation time at d = 100): it exercises the collective, it is not a convergence claim -- see ess.rhat_max_split
+            out["rhat_last_launch"] = sig(float(np.nanmax(diag["rhat"][:wl.d])))
         if world == 1 and args.config == "c2" and not args.no_e2e and not args.c2_literal:
             try:
                 out["e2e_host"] = e2e_host(mhx, wl)
             except Exception as e:
-                out["e2e_host"] = {"error": str(e)[:300]}
+                out["e2e_host"] = {"error": str(e)[:160]}
         if world == 1 and not args.no_second_dtype and args.dtype == "f64":
             try:                                                  # the same workload on the fp32 engine: a second figure, never `value`
-                ctx32 = mhx.Context(local_rank, "f32")
+                ctx32 = mhx.Context(device, "f32")
                 wl32 = WORKLOADS[args.config](args, "f32")
                 wl32.build(mhx, ctx32, rank)
                 n32 = max(5, args.steps // 2)
                 dt32, k32, a32, t32, st32 = timed(wl32, n32, 2, barrier)
-                out["f32"] = {"value": wl32.units_per_step() * n32 / dt32, "unit": "MH steps/s", "ms_per_step": dt32 * 1e3 / n32,
-                              "acceptance_rate": a32 / float(t32), "lanes_per_unit": st32["reduce_lanes"],
-                              "roofline_frac_hbm": wl32.bytes_per_launch() / (k32 * 1e-3 / n32) / 1e9 / HBM_PEAK_GBS,
-                              "note": "same engine compiled with mhx_real = float: half the bytes; not the reference's arithmetic"}
+                out["f32"] = {"value": sig(wl32.units_per_step() * n32 / dt32), "ms_per_step": sig(dt32 * 1e3 / n32),
+                              "acc": sig(a32 / float(t32), 3), "lanes": st32["reduce_lanes"],
+                              "frac": sig(wl32.bytes_per_launch() / (k32 * 1e-3 / n32) / 1e9 / HBM_PEAK_GBS, 4)}
                 wl32.run.close()
             except Exception as e:
-                out["f32"] = {"error": str(e)}
+                out["f32"] = {"error": str(e)[:160]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, args.dtype, args.cpu_seconds)
         if world == 1 and args.config == "c2" and not args.no_other_configs and not args.c2_literal:
             wl.run.close()                                        # 13.4 GB of samples: C4 needs the room
             out["configs"] = other_configs(mhx, ctx, args, barrier)
+        line = json.dumps(out, separators=(",", ":"))
+        if len(line) >= 8000:                                     # the driver keeps an 8 KB tail: drop detail before the contract keys go
+            for k in ("ess", "e2e_host"):
+                out.pop(k, None)
+            line = json.dumps(out, separators=(",", ":"))
         # RCCL writes its version banner to the C stdout buffer: push it out first so the JSON line is the last one
         sys.stdout.flush()
         try:
@@ -774,7 +948,7 @@ def main():
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
-        print(json.dumps(out), flush=True)
+        print(line, flush=True)
     if comm is not None:
         barrier()
         comm.close()

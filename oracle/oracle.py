@@ -127,6 +127,9 @@ def lib():
         L.orc_set_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_chol_rank1.restype = C.c_int
         L.orc_chol_rank1.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        for f in (L.orc_mt_rwmh, L.orc_mt_ram):
+            f.restype = C.c_double
+            f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         _libs[_DT] = L
     return _libs[_DT]
 
@@ -377,6 +380,26 @@ def ram(target, sched, seed, first_chain, nchains, init=None, S_in=None, alpha=0
                 status=status, S=S_out, diag_min=dmin, diag_max=dmax)
 
 
+
+
+def mt_rwmh(target, prop, sched, seed, first_chain, nchains, nthreads, save=True, init1=None):
+    """bench.py's CPU baseline (oracle/mhx_oracle_mt.c): `nchains` independent chains on `nthreads` POSIX threads, each chain
+    one orc_rwmh call with its own contiguous [N][d+1] record.  Returns (wall seconds, per-thread CPU seconds)."""
+    busy = np.zeros(max(1, nthreads), dtype=np.float64)
+    init1 = None if init1 is None else np.ascontiguousarray(init1, dtype=real())
+    w = lib().orc_mt_rwmh(C.addressof(target.c), C.addressof(prop.c), C.addressof(sched), seed, first_chain, nchains, nthreads,
+                          1 if save else 0, _fp(init1), _fp(busy))
+    return w, busy
+
+
+def mt_ram(target, sched, seed, first_chain, nchains, nthreads, save=False, init1=None, alpha=0.234, gamma=0.6):
+    """the same for RobustAdaptiveMetropolis chains (identity start factor each)"""
+    busy = np.zeros(max(1, nthreads), dtype=np.float64)
+    cfg = _T("RamCfg")(alpha, gamma, 0.0, float("inf"))
+    init1 = None if init1 is None else np.ascontiguousarray(init1, dtype=real())
+    w = lib().orc_mt_ram(C.addressof(target.c), C.addressof(cfg), C.addressof(sched), seed, first_chain, nchains, nthreads,
+                         1 if save else 0, _fp(init1), _fp(busy))
+    return w, busy
 
 
 def target_grad(target, x, user_grad_addr=None):

@@ -2,6 +2,7 @@
 argument checking mirrors the reference's error behaviour, and the multi-GPU statistics path
 (chains sharded by global id + one all-reduce) is exercised with world_size 2 on gloo."""
 import ctypes
+import json
 import os
 import re
 import socket
@@ -228,3 +229,90 @@ def test_bench_byte_models_match_the_survey():
     ns.c4_fixed = True
     c4f = bench.WORKLOADS["c4"](ns, "f32")
     assert c4f.bytes_per_launch() / c4f.units_per_step() == 4 * 200 * 201 // 2 + 8 * 200 + 8
+
+
+def _run_bench(argv, env_extra=None, timeout=180):
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=timeout, text=True)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    return p.returncode, (json.loads(lines[-1]) if lines else None), p.stderr
+
+
+def test_bench_gpus_n_without_a_launcher_starts_n_ranks():
+    """`python bench.py --gpus 2` with no launcher around it IS two processes (the flag used to be parsed and ignored).
+    Device-free rehearsal (--dry-run: launcher, gloo rendezvous, barrier, max-over-ranks time, summed totals)."""
+    rc, line, err = _run_bench(["--gpus", "2", "--dry-run", "--steps", "4"])
+    assert rc == 0, err
+    assert line["n_ranks"] == 2 and line["distinct_processes"] == 2 and line["dry_run"] is True
+    assert line["units_all_ranks"] == 2 * 4 * 1000 and line["value"] is None and line["n_gpus"] == 0
+    assert "2 ranks" in line["config"]["collective"]
+
+
+def test_bench_under_a_launcher_is_one_rank_of_it():
+    """the driver's form: python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2"""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                       # rank 0 alone prints
+    line = json.loads(lines[0])
+    assert line["n_ranks"] == 2 and line["distinct_processes"] == 2
+
+
+def test_bench_refuses_to_claim_ranks_or_gpus_it_does_not_have():
+    import torch
+    # --gpus disagrees with the launcher's WORLD_SIZE: refused before anything runs
+    rc, line, err = _run_bench(["--gpus", "2", "--dry-run"], {"WORLD_SIZE": "3", "RANK": "0", "LOCAL_RANK": "0"})
+    assert rc != 0 and line is None and "WORLD_SIZE=3" in err
+    rc, line, err = _run_bench(["--gpus", "1", "--dry-run"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert rc != 0 and line is None
+    if not torch.cuda.is_available():
+        # fewer devices than ranks: no line (the engine has no CPU path and a 2-GPU line needs 2 GPUs)
+        rc, line, err = _run_bench(["--gpus", "2"])
+        assert rc != 0 and line is None and "refusing" in err
+        rc, line, err = _run_bench([])
+        assert rc != 0 and line is None
+
+
+def test_bench_line_fits_the_drivers_tail():
+    """The driver keeps an 8 KB tail of stdout: the whole line has to fit.  Checked on the last full line a GPU box printed
+    (profiles/r04*_bench_full.json, committed) and on the worst case the compact blocks can reach."""
+    import glob
+    import bench
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r04*_bench_full.json")))
+    for f in files:
+        text = open(f).read().strip().splitlines()[-1]
+        assert len(text) < 8000, (f, len(text))
+        line = json.loads(text)
+        for k in ("c1", "c2_literal", "c3", "c3_rotated", "c4", "c4_moving", "c4_fixed", "c5", "c5_banana"):
+            assert k in line["configs"], (f, k)
+            assert "error" not in line["configs"][k], (f, k, line["configs"][k])
+    # a compact block with every optional key and full-width numbers stays small: 9 of them + the top level < 8000
+    blk = {"value": 1.2345e9, "ms_per_step": 123.45, "acc": 0.234, "bound": "valu", "frac": 0.4321, "traffic_ratio": 1.2345,
+           "launch_us": 12345.0, "kernel": "sequential-ensemble-sweep", "lanes": 64, "hbm_frac": 0.0171, "band": 1,
+           "cpu": {"value": 1.2345e6, "cores": 256, "single_thread": 12340.0, "parallel_efficiency": 0.432, "why": "smt-or-memory"}}
+    assert len(json.dumps(blk, separators=(",", ":"))) < 400
+    assert bench.sig(1234567.891, 5) == 1234600.0 and bench.sig(None) is None and bench.sig(0.000123456, 3) == 0.000123
+
+
+def test_cpu_baseline_driver_matches_the_oracle_and_reports_threads(oracle):
+    """oracle/mhx_oracle_mt.c (bench.py's CPU baseline: POSIX threads, a chain per task) runs the oracle's own sampler: the
+    thread count changes the wall time, never a result; busy seconds come back per thread."""
+    oracle.set_dtype("f64")
+    t, p, s = oracle.iso_gauss(10), oracle.Proposal(oracle.PROP_ISO, 0.5), oracle.schedule(40)
+    w, busy = oracle.mt_rwmh(t, p, s, 7, 0, 24, 3, save=True)
+    assert w > 0 and busy.shape == (3,) and busy.sum() > 0
+    w1, busy1 = oracle.mt_rwmh(t, p, s, 7, 0, 24, 1, save=False)
+    assert busy1.shape == (1,)
+    tg = oracle.corr_gauss_from_cov(np.eye(6) + 0.3)
+    w, busy = oracle.mt_ram(tg, oracle.schedule(1, 30, 1, 30), 4, 0, 8, 2, init1=np.zeros(6))
+    assert w > 0 and busy.shape == (2,)
+    oracle.set_dtype("f32")
