@@ -72,6 +72,16 @@ extern "C" int mhx_ctx_jit_counts(const mhx_ctx* ctx, int64_t* compiles, int64_t
     if (cache_hits) *cache_hits = b;
     return MHX_OK;
 }
+extern "C" int mhx_ctx_host_pin_counts(const mhx_ctx* ctx, int64_t* registered, int64_t* released)
+{
+    if (!ctx) return mhx_fail(MHX_EINVAL, "mhx_ctx_host_pin_counts: ctx is NULL");
+    long a = 0, b = 0;
+    if (is64(ctx)) mhx_f64::api_ctx_host_pin_counts(reinterpret_cast<const mhx_f64::mhx_ctx*>(ctx), &a, &b);
+    else mhx_f32::api_ctx_host_pin_counts(reinterpret_cast<const mhx_f32::mhx_ctx*>(ctx), &a, &b);
+    if (registered) *registered = a;
+    if (released) *released = b;
+    return MHX_OK;
+}
 extern "C" int mhx_host_alloc(size_t bytes, void** out)
 {
     if (!out) return mhx_fail(MHX_EINVAL, "mhx_host_alloc: out is NULL");
@@ -153,10 +163,14 @@ extern "C" int mhx_ram_get_diag_range(mhx_run* r, void* diag_min, void* diag_max
     NEED(r, "mhx_ram_get_diag_range");
     return is64(r) ? mhx_f64::api_ram_get_diag_range(R64(r), D(diag_min), D(diag_max)) : mhx_f32::api_ram_get_diag_range(R32(r), F(diag_min), F(diag_max));
 }
-extern "C" int mhx_ram_get_step_stats(mhx_run* r, void* log_alpha, double* eta)
+extern "C" int mhx_ram_get_step_stats(mhx_run* r, void* log_alpha, double* eta, int64_t capacity, int64_t* n_recorded)
 {
     NEED(r, "mhx_ram_get_step_stats");
-    return is64(r) ? mhx_f64::api_ram_get_step_stats(R64(r), D(log_alpha), eta) : mhx_f32::api_ram_get_step_stats(R32(r), F(log_alpha), eta);
+    long nrec = 0;
+    const int rc = is64(r) ? mhx_f64::api_ram_get_step_stats(R64(r), D(log_alpha), eta, (long)capacity, &nrec)
+                           : mhx_f32::api_ram_get_step_stats(R32(r), F(log_alpha), eta, (long)capacity, &nrec);
+    if (n_recorded) *n_recorded = nrec;
+    return rc;
 }
 extern "C" int mhx_ram_get_adapt_state(mhx_run* r, void* log_alpha, double* eta, uint8_t* isaccept, uint64_t* iteration)
 {

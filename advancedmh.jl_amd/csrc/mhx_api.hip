@@ -170,6 +170,7 @@ struct mhx_ctx : mhx_handle_hdr {
     // the return path of mhx_run_sample_to_host: a second stream for the D2H copies + the slab hand-over events
     hipStream_t copy_stream = nullptr;
     hipEvent_t slab_done[2] = {nullptr, nullptr}, slab_free[2] = {nullptr, nullptr};
+    long pins_registered = 0, pins_released = 0;    // caller buffers page-locked for the duration of a call / released again
     ~mhx_ctx()
     {
         for (int i = 0; i < 2; ++i) {
@@ -203,6 +204,13 @@ int api_ctx_create(int device, mhx_ctx** out)
 }
 
 int api_ctx_device(const mhx_ctx* ctx) { return ctx->device; }
+int api_ctx_host_pin_counts(const mhx_ctx* ctx, long* registered, long* released)
+{
+    if (registered) *registered = ctx->pins_registered;
+    if (released) *released = ctx->pins_released;
+    return MHX_OK;
+}
+
 int api_ctx_jit_counts(const mhx_ctx* ctx, long* compiles, long* cache_hits)
 {
     if (compiles) *compiles = ctx->jit_compiles;
@@ -1068,11 +1076,34 @@ static int mala_init(mhx_run* r, const mhx_real* init);
 static int mala_eval_state(mhx_run* r, int reset_counts);
 static int mala_advance(mhx_run* r, uint64_t nsteps, uint32_t save_next, int save_slot, int thinning);
 
+// A caller-supplied state enters an RWMH chain with -0.0 coordinates as +0.0 (x + 0.0: every other value, NaN and the
+// infinities included, is unchanged; -0.0 == +0.0, so `chain[1].params == initial_params` of test/runtests.jl:203-213 holds).
+// The chain itself never produces a -0.0 (a rounded sum is -0 only if both terms are), and the fp64 plain-walk kernel relies on
+// that: it re-forms a REJECTED state as fma(0, n, x), which is x exactly for every x but -0.0.  The oracle does the same
+// (orc_rwmh, `init`).
+__global__ void k_plus_zero(mhx_real* x, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = x[i] + MHX_R(0.0);
+}
+
+static int rwmh_canonical_zero(mhx_run* r)
+{
+    const size_t nx = (size_t)r->dim * (size_t)r->n;
+    hipLaunchKernelGGL(k_plus_zero, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, r->ctx->stream, r->d_x, nx);
+    HIP_TRY(hipGetLastError());
+    return MHX_OK;
+}
+
 static int rwmh_init(mhx_run* r, const mhx_real* init)
 {
     mhx_ctx* ctx = r->ctx;
     const size_t nx = (size_t)r->dim * (size_t)r->n;
-    if (init) HIP_TRY(hipMemcpyAsync(r->d_x, init, nx * sizeof(mhx_real), hipMemcpyHostToDevice, ctx->stream));
+    if (init) {
+        HIP_TRY(hipMemcpyAsync(r->d_x, init, nx * sizeof(mhx_real), hipMemcpyHostToDevice, ctx->stream));
+        int rcz = rwmh_canonical_zero(r);
+        if (rcz) return rcz;
+    }
     mhx_rwmh_args a = rwmh_args(r);
     const mhx_real* tp = r->target->dparams;
     const mhx_real* pv = r->d_pvec;
@@ -1379,6 +1410,7 @@ int api_run_set_state(mhx_run* r, const mhx_real* x)
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t n = (size_t)r->n, d = (size_t)r->dim;
     COPY_SYNC(r->ctx->stream, r->d_x, x, d * n * sizeof(mhx_real), hipMemcpyHostToDevice);
+    if (r->kind == RUN_RWMH) { int rc = rwmh_canonical_zero(r); if (rc) return rc; }
     if (r->kind == RUN_EMCEE) { int rc = emcee_sync_state(r, 0); if (rc) return rc; }
     if (r->kind == RUN_MALA) return mala_eval_state(r, 0);   // src/MALA.jl:27-35: lp and gradient are recomputed
     // lp is a cache of logdensity(model, x) (src/AdvancedMH.jl:75): recompute it

@@ -25,6 +25,7 @@ struct mhx_handle_hdr { int32_t dtype; };
     int api_ctx_destroy(mhx_ctx* ctx);                                                                                 \
     int api_ctx_device(const mhx_ctx* ctx);                                                                            \
     int api_ctx_jit_counts(const mhx_ctx* ctx, long* compiles, long* cache_hits);                                      \
+    int api_ctx_host_pin_counts(const mhx_ctx* ctx, long* registered, long* released);                                  \
     int api_target_builtin(mhx_ctx* ctx, int kind, int dim, const REAL* params, size_t nparams, mhx_target** out);     \
     int api_target_from_hip_source(mhx_ctx* ctx, const char* src, int dim, const REAL* data, size_t ndata,             \
                                    mhx_target** out);                                                                  \
@@ -39,7 +40,7 @@ struct mhx_handle_hdr { int32_t dtype; };
     int api_ram_get_factor(mhx_run* r, REAL* S, uint8_t* status);                                                      \
     int api_ram_get_diag_range(mhx_run* r, REAL* diag_min, REAL* diag_max);                                            \
     int api_ram_get_adapt_state(mhx_run* r, REAL* log_alpha, double* eta, uint8_t* isaccept, uint64_t* iteration);     \
-    int api_ram_get_step_stats(mhx_run* r, REAL* log_alpha, double* eta);                                              \
+    int api_ram_get_step_stats(mhx_run* r, REAL* log_alpha, double* eta, long capacity, long* n_recorded);             \
     int api_run_init(mhx_run* r, const REAL* initial_params);                                                          \
     int api_run_sample(mhx_run* r, const mhx_schedule* s, int save_samples);                                           \
     int api_run_get_samples(mhx_run* r, REAL* samples, uint8_t* accepted);                                             \

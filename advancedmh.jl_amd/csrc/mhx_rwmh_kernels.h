@@ -712,6 +712,8 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
                 // ZKEEP (plain walk, one scale for all dimensions): the registers of the candidate keep the NORMAL instead -- the
                 // accepted state is re-formed as fma(s_acc, n, x) with s_acc = accepted ? s : 0, the same fma (or x itself, exactly)
                 // in one instruction per real where a select of a double takes two.  A padding dimension keeps n = 0: x stays 0.
+                // (fma(0, n, x) == x for every x but -0.0, which a chain never holds: mhx_run_init / set_state turn a caller's -0.0
+                // into +0.0 -- rwmh_canonical_zero in mhx_api.hip -- and a rounded sum is -0 only if both terms are.)
                 if (ZKEEP) y[i][j] = (i == NBL - 1 && !(k_last + j < d)) ? MHX_R(0.0) : n[j];
                 else y[i][j] = yk;
                 if (i == 0 && j == 0) y00 = yk;

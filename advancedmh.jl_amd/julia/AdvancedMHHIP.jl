@@ -94,17 +94,26 @@ struct HipSource <: DeviceLogDensity; src::String; dim::Int; data::Vector{Float6
 packlower(::Type{T}, M) where {T} = T[M[i, j] for i in axes(M, 1) for j in 1:i]            # row-major packed lower
 
 """
-    precision_factor(Σ) -> A = inv(chol(Σ)) with the structural zeros of a sparse factor restored
+    precision_factor(Σ) -> A = inv(chol(Σ)) with the structural zeros of a banded factor restored
 
-Entries below 256 eps max|A| -- the round-off the inversion leaves where the exact factor is zero (Σ_ij = ρ^|i-j| has a
-bidiagonal A; computed off-band entries are ~1e-15) -- become exact zeros: the engine detects an exactly banded factor and
-skips the zeros (same bits).  The Python mirror (`mhx.precision_factor`) does the same.
+Σ_ij = ρ^|i-j| has a bidiagonal A; the inversion leaves round-off ~1e-15 where the exact factor is zero.  An OFF-diagonal entry
+counts as round-off iff |A_ij| <= 256 eps |A_jj| (relative to its column's scale: x_j ~ 1/A_jj at stationarity; the diagonal is never
+touched), and the cleaned factor is used only if it is then banded (bandwidth <= 8: the engine detects an exactly banded factor
+and skips the zeros, same bits) -- otherwise the raw inverse is kept.  The Python mirror (`mhx.precision_factor`) does the same.
 """
 function precision_factor(Σ)
     A = Matrix(inv(cholesky(Symmetric(Matrix{Float64}(Σ))).L))
-    tol = 256 * eps(Float64) * maximum(abs, A)
-    A[abs.(A) .<= tol] .= 0.0
-    return LowerTriangular(A)
+    d = size(A, 1)
+    B = copy(A)
+    bw = 0
+    for j in 1:d, i in j:d
+        if i != j && abs(A[i, j]) <= 256 * eps(Float64) * abs(A[j, j])
+            B[i, j] = 0.0
+        elseif B[i, j] != 0.0
+            bw = max(bw, i - j)
+        end
+    end
+    return LowerTriangular(d > 1 && bw <= min(8, d - 2) ? B : A)
 end
 
 function target(::Type{T}, ctx::Ptr{Cvoid}, t::DeviceLogDensity) where {T}
@@ -235,7 +244,7 @@ function AbstractMCMC.sample(
         if sampler isa AdvancedMH.RobustAdaptiveMetropolis && haskey(kwargs, :sampler_stats)
             # what a callback reads off `state` after every saved step (test/RobustAdaptiveMetropolis.jl:11-28): logα (N x n), η (N)
             logα = Matrix{T}(undef, n, N); η = Vector{Float64}(undef, N)
-            GC.@preserve logα η check(ccall((:mhx_ram_get_step_stats, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}), run[], logα, η))
+            GC.@preserve logα η check(ccall((:mhx_ram_get_step_stats, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Int64, Ptr{Int64}), run[], logα, η, size(logα, 2), C_NULL))
             kwargs[:sampler_stats][] = (logα = permutedims(logα), η = η)
         end
         vals = Float64.(permutedims(raw, (3, 2, 1)))                         # (iterations, params..lp, chains)

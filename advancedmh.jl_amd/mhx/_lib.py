@@ -85,7 +85,7 @@ EXPORTS = [
     "mhx_ctx_dtype", "mhx_ctx_device", "mhx_ram_set_factor_all", "mhx_ram_get_adapt_state", "mhx_emcee_exchange_plan", "mhx_emcee_exchange_pack",
     "mhx_emcee_exchange_unpack", "mhx_comm_unique_id", "mhx_comm_init", "mhx_comm_destroy", "mhx_comm_rank",
     "mhx_comm_allreduce_sum", "mhx_comm_slice", "mhx_comm_allgather_walkers",
-    "mhx_ram_get_step_stats", "mhx_run_sample_to_host", "mhx_host_alloc", "mhx_host_free", "mhx_ctx_jit_counts",
+    "mhx_ram_get_step_stats", "mhx_run_sample_to_host", "mhx_host_alloc", "mhx_host_free", "mhx_ctx_jit_counts", "mhx_ctx_host_pin_counts",
 ]
 
 MHX_F32, MHX_F64 = 0, 1
@@ -138,7 +138,7 @@ def lib():
         L.mhx_ram_get_factor.argtypes = [vp, rp, u8p]
         L.mhx_ram_get_diag_range.argtypes = [vp, rp, rp]
         L.mhx_ram_get_adapt_state.argtypes = [vp, rp, dp, u8p, C.POINTER(C.c_uint64)]
-        L.mhx_ram_get_step_stats.argtypes = [vp, rp, dp]
+        L.mhx_ram_get_step_stats.argtypes = [vp, rp, dp, C.c_int64, C.POINTER(C.c_int64)]
         L.mhx_run_init.argtypes = [vp, rp]
         L.mhx_run_sample.argtypes = [vp, C.POINTER(Schedule), C.c_int]
         L.mhx_run_get_samples.argtypes = [vp, rp, u8p]
@@ -146,6 +146,7 @@ def lib():
         L.mhx_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
         L.mhx_host_free.argtypes = [vp]
         L.mhx_ctx_jit_counts.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.mhx_ctx_host_pin_counts.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.mhx_run_get_state.argtypes = [vp, rp, rp, u32p]
         L.mhx_run_set_state.argtypes = [vp, rp]
         L.mhx_run_stats.argtypes = [vp, C.POINTER(Stats)]
@@ -253,6 +254,12 @@ class Context:
         """(hiprtc compilations, code objects taken from the on-disk cache) of this context so far"""
         a, b = C.c_int64(), C.c_int64()
         check(lib().mhx_ctx_jit_counts(self.h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
+    def host_pin_counts(self):
+        """(caller buffers page-locked for a mhx_run_sample_to_host call, released again) so far: equal between calls"""
+        a, b = C.c_int64(), C.c_int64()
+        check(lib().mhx_ctx_host_pin_counts(self.h, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
 
     @classmethod

@@ -142,16 +142,27 @@ class IsoGaussian(_TargetSpec):
         self.dim = int(d)
 
 
+MAX_BAND = 8        # MHX_EMCEE_MAX_BAND: the widest band the engine's band form is specialised for
+
+
 def precision_factor(Sigma):
-    """A = inv(chol(Sigma)) in float64 (log-density -1/2 |A x|^2 + log det A), with the STRUCTURAL zeros of a sparse factor
-    restored: entries below 256 eps max|A| -- the round-off the inversion itself leaves where the exact factor is zero (a
-    Markov / autoregressive / banded-precision model: Sigma_ij = rho^|i-j| has a bidiagonal A, computed off-band entries
-    ~1e-15) -- are set to exactly 0.  The engine detects the bandwidth of an exactly banded factor and skips the zeros (same
-    bits: fma(0, y, w) == w), so this is what lets a banded model run at its own cost instead of the dense d(d+1)/2."""
-    A = np.linalg.inv(np.linalg.cholesky(np.asarray(Sigma, dtype=np.float64)))
-    A = np.tril(A)
-    A[np.abs(A) <= 256.0 * np.finfo(np.float64).eps * np.abs(A).max()] = 0.0
-    return A
+    """A = inv(chol(Sigma)) in float64 (log-density -1/2 |A x|^2 + log det A), with the STRUCTURAL zeros of a banded factor
+    restored.  A Markov / autoregressive / banded-precision model (Sigma_ij = rho^|i-j|: A is bidiagonal) comes out of the
+    inversion with round-off ~1e-15 where the exact factor is zero; the engine detects an EXACTLY banded factor and skips the
+    zeros (same bits: fma(0, y, w) == w), which lets such a model run at its own cost instead of the dense d(d+1)/2.
+    The rule is scale-aware and conservative: an OFF-diagonal entry is round-off iff |A_ij| <= 256 eps |A_jj| (relative
+    to its COLUMN's scale: at stationarity x_j ~ 1/A_jj, so dropping the entry moves row i of A x -- a unit-variance number -- by
+    less than 256 eps; a model whose standard deviations span many decades keeps every genuine entry);
+    the diagonal is never touched; and the cleaned factor is used only if it really is banded (bandwidth <= 8, the engine's band
+    form) -- otherwise the raw inverse is kept, the reference's MvNormal has no truncation at all."""
+    A = np.tril(np.linalg.inv(np.linalg.cholesky(np.asarray(Sigma, dtype=np.float64))))
+    d = A.shape[0]
+    dg = np.abs(np.diag(A))
+    noise = np.abs(A) <= 256.0 * np.finfo(np.float64).eps * dg[None, :]
+    noise[np.arange(d), np.arange(d)] = False
+    B = np.where(noise, 0.0, A)
+    i, j = np.nonzero(B)
+    return B if d > 1 and int((i - j).max()) <= min(MAX_BAND, d - 2) else A
 
 
 class CorrGaussian(_TargetSpec):
@@ -595,13 +606,23 @@ class Run:
         `out` / `out_accepted`: caller-provided arrays (any host memory: registered for the call when not page-locked)."""
         s = L.Schedule(n_samples, discard_initial, thinning, num_warmup)
         shape = (n_samples, self.dim + 1, self.n)
+
+        def result(shp, dt):
+            # page-locked when asked for and available; a host that cannot lock that much (ulimit -l, fragmented memory) gets
+            # pageable memory -- the C side registers what it can for the call and otherwise copies pageable
+            if pinned:
+                try:
+                    return L.host_array(shp, dt)
+                except L.MhxError:
+                    pass
+            return np.empty(shp, dtype=dt)
         if out is None:
-            out = L.host_array(shape, self.real) if pinned else np.empty(shape, dtype=self.real)
+            out = result(shape, self.real)
         elif out.shape != shape or out.dtype != self.real or not out.flags.c_contiguous:
             raise L.ArgumentError(L.MHX_EINVAL, "sample_to_host: out must be a C-contiguous %s array of shape %s" % (np.dtype(self.real), shape))
         acc = out_accepted
         if acc is None and want_accepted:
-            acc = L.host_array((n_samples, self.n), np.uint8) if pinned else np.empty((n_samples, self.n), dtype=np.uint8)
+            acc = result((n_samples, self.n), np.uint8)
         elif acc is not None and (acc.shape != (n_samples, self.n) or acc.dtype != np.uint8 or not acc.flags.c_contiguous):
             raise L.ArgumentError(L.MHX_EINVAL, "sample_to_host: out_accepted must be a C-contiguous uint8 array of shape (N, nchains)")
         L.check(L.lib().mhx_run_sample_to_host(self.h, C.byref(s), L.fptr(out), L.u8ptr(acc), slab_samples))
@@ -658,11 +679,14 @@ class Run:
         """RobustAdaptiveMetropolis: the sampler state after EVERY recorded step of the last sampling call -- what the
         reference's callback reads off `state` (test/RobustAdaptiveMetropolis.jl:11-28): dict(logα [N][nchains], η [N]);
         mean(exp(logα)) is the acceptance rate the adaptation steers to α (RAM.jl:141-147).  isaccept = the accepted tensor."""
-        if n_samples is None:
-            n_samples = getattr(self, "_last_n", 0)
+        nrec = C.c_int64()
+        L.check(L.lib().mhx_ram_get_step_stats(self.h, None, None, 0, C.byref(nrec)))      # the count the engine recorded
+        if n_samples is not None and int(n_samples) != nrec.value:
+            raise L.ArgumentError(L.MHX_EINVAL, "step_stats: n_samples = %d, the last sampling call recorded %d" % (n_samples, nrec.value))
+        n_samples = int(nrec.value)
         la = np.empty((n_samples, self.n), dtype=self.real)
         eta = np.empty(n_samples, dtype=np.float64)
-        L.check(L.lib().mhx_ram_get_step_stats(self.h, L.rptr(la), eta.ctypes.data_as(C.POINTER(C.c_double))))
+        L.check(L.lib().mhx_ram_get_step_stats(self.h, L.rptr(la), eta.ctypes.data_as(C.POINTER(C.c_double)), n_samples, None))
         return {"logα": la, "η": eta, "logalpha": la, "eta": eta}
 
     def stats(self):

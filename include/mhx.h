@@ -70,6 +70,9 @@ int mhx_ctx_jit_counts(const mhx_ctx *ctx, int64_t *compiles, int64_t *cache_hit
  * host): device-to-host copies into it run at the link rate and asynchronously.  Any other host buffer works too --
  * mhx_run_sample_to_host registers it for the duration of the call. */
 int mhx_host_alloc(size_t bytes, void **out);
+/* Caller buffers this context page-locked for the duration of a mhx_run_sample_to_host call (hipHostRegister) and released
+ * again: equal between calls, whatever path a call left by (every exit first drains both streams).  Either may be NULL. */
+int mhx_ctx_host_pin_counts(const mhx_ctx *ctx, int64_t *registered, int64_t *released);
 int mhx_host_free(void *p);
 
 /* ---------------------------------------------------------------------------------------------
@@ -204,8 +207,10 @@ int mhx_ram_get_adapt_state(mhx_run *run, void *log_alpha, double *eta, uint8_t 
  * (test/RobustAdaptiveMetropolis.jl:11-28,55): log_alpha [n_samples][nchains] reals = state.logα after the recorded transition
  * (min(lp' - lp, 0): average exp(log_alpha) for the acceptance rate, RAM.jl:141-147; sample 1 of an un-discarded call carries
  * the state's own value, 0 right after init, :211), eta [n_samples] doubles = state.η (iteration^-gamma of the latest adapting
- * transition at or before that step; the same for every chain).  state.isaccept is the `accepted` tensor.  Either may be NULL. */
-int mhx_ram_get_step_stats(mhx_run *run, void *log_alpha, double *eta);
+ * transition at or before that step; the same for every chain).  state.isaccept is the `accepted` tensor.  Either may be NULL.
+ * `capacity` = the number of samples the two buffers hold: fewer than the last call recorded is MHX_EINVAL (nothing is written);
+ * n_recorded (may be NULL) receives that count -- with both buffers NULL the call is just this query. */
+int mhx_ram_get_step_stats(mhx_run *run, void *log_alpha, double *eta, int64_t capacity, int64_t *n_recorded);
 
 /* ---------------------------------------------------------------------------------------------
  * Metropolis-adjusted Langevin.  Replaces MALA (src/MALA.jl:1-11), GradientTransition (:14-19) and its step
@@ -232,7 +237,8 @@ int mhx_mala_create(mhx_ctx *ctx, const mhx_target *t, const mhx_mala_cfg *cfg, 
  * src/emcee.jl:29-34, src/RobustAdaptiveMetropolis.jl:175-214): x0 = initial_params if given, else
  * a draw (RWMH: from the proposal; RAM: randn(d); Ensemble: W draws from the (Mv)Normal of cfg.init_*, else required).
  * mhx_run_sample == the mcmcsample loop + bundle_samples into the device sample buffer.  It may be
- * called repeatedly; each call continues the chains (counter-based RNG => resumable). */
+ * called repeatedly; each call continues the chains (counter-based RNG => resumable).  RWMH: a -0.0 coordinate of a caller's state
+ * (here and in mhx_run_set_state) enters the chain as +0.0 -- equal under ==, so `chain[1].params == initial_params` holds. */
 int mhx_run_init(mhx_run *run, const void *initial_params /* host [dim][nchains] or NULL */);
 /* save_samples: 0 = keep nothing, 1 = sample tensor, 2 = running moments only (per chain and parameter the
  * mean / M2 of the states the schedule selects; for runs whose sample tensor would not fit, e.g.

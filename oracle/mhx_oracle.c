@@ -736,7 +736,9 @@ int orc_rwmh(const orc_target *t, const orc_proposal *p, const orc_schedule *s,
         /* mh-core.jl:83  params = initial_params === nothing ? propose(rng, sampler, model) : initial_params
          * proposal.jl:41-47: the initial propose is a bare draw from the proposal (x = 0 + xi). */
         if (init) {
-            for (int k = 0; k < d; ++k) x[k] = init[(size_t)k * C + c];
+            /* a caller-supplied -0.0 enters the chain as +0.0 (x + 0.0; every other value unchanged; equal under ==): the
+             * engine does the same in mhx_run_init / mhx_run_set_state, see rwmh_canonical_zero in csrc/mhx_api.hip */
+            for (int k = 0; k < d; ++k) x[k] = init[(size_t)k * C + c] + R(0.0);
         } else {
             normals_gen(p->normal_gen, seed, id, 0, ORC_STREAM_INIT, d, z);
             for (int k = 0; k < d; ++k) y[k] = R(0.0);

@@ -256,12 +256,20 @@ def iso_gauss(d, reduce_lanes=0):
 
 
 def corr_gauss_from_cov(Sigma, reduce_lanes=0):
-    """params = inv(chol(Sigma)) packed lower row-major, computed in float64 then rounded; entries at the round-off level of
-    the inversion (<= 256 eps max|A|: the structural zeros of a banded factor) are exact zeros -- the same preparation as the
-    host mirror's precision_factor (the checker must be handed the same numbers as the device)."""
+    """params = inv(chol(Sigma)) packed lower row-major, computed in float64 then rounded.  The checker must be handed the same
+    numbers as the device, so this restates the host mirror's rule for a banded factor (mhx.precision_factor): off-diagonal
+    entries at the round-off level of the inversion, |A_ij| <= 256 eps |A_jj|, become exact zeros IF the cleaned factor
+    is then banded (bandwidth <= 8); otherwise the raw inverse is used."""
     Sigma = np.asarray(Sigma, dtype=np.float64)
     A = np.tril(np.linalg.inv(np.linalg.cholesky(Sigma)))
-    A[np.abs(A) <= 256.0 * np.finfo(np.float64).eps * np.abs(A).max()] = 0.0
+    d = A.shape[0]
+    dg = np.abs(np.diag(A))
+    noise = np.abs(A) <= 256.0 * np.finfo(np.float64).eps * dg[None, :]
+    noise[np.arange(d), np.arange(d)] = False
+    B = np.where(noise, 0.0, A)
+    i, j = np.nonzero(B)
+    if d > 1 and int((i - j).max()) <= min(8, d - 2):
+        A = B
     return Target(TARGET_CORR_GAUSS, Sigma.shape[0], pack_lower(A), reduce_lanes=reduce_lanes)
 
 

@@ -266,3 +266,24 @@ def test_adaptation_steers_the_mean_acceptance_probability_to_alpha(mhx, real):
     assert eta[0] == 0.0 and np.allclose(eta[1:], want, rtol=1e-6 if real == "f32" else 1e-14)
     S, status = run.factor()
     assert (status == 0).all() and np.isfinite(S).all()
+
+
+def test_step_stats_never_writes_past_the_callers_buffers(mhx, real):
+    """mhx_ram_get_step_stats takes the capacity of the caller's buffers -- fewer rows than the last call recorded is an
+    error, nothing is written; the count itself can be queried."""
+    import ctypes as C
+    d, nch, N = 4, 32, 10
+    run = mhx.Run(mhx.DensityModel(mhx.IsoGaussian(d)), mhx.RobustAdaptiveMetropolis(), nchains=nch, seed=3)
+    run.init(np.zeros(d))
+    run.sample(N, 0, 1, N)
+    nrec = C.c_int64()
+    mhx.check(mhx.lib().mhx_ram_get_step_stats(run.h, None, None, 0, C.byref(nrec)))
+    assert nrec.value == N
+    la = np.full((N - 1, nch), 7.0, dtype=run.real)
+    eta = np.full(N - 1, 7.0)
+    rc = mhx.lib().mhx_ram_get_step_stats(run.h, la.ctypes.data_as(C.c_void_p), eta.ctypes.data_as(C.POINTER(C.c_double)), N - 1, None)
+    assert rc == mhx.MHX_EINVAL and (la == 7.0).all() and (eta == 7.0).all()
+    with pytest.raises(mhx.ArgumentError):
+        run.step_stats(n_samples=N - 1)
+    assert run.step_stats(n_samples=N)["logα"].shape == (N, nch)
+    run.close()

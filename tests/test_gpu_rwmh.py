@@ -150,3 +150,29 @@ def test_dense_gaussian_target_cooperative_kernel(mhx, oracle, d, C, lanes, prop
     _same(cnt, ref["accept_counts"], "accept counts")
     assert (0.02 if d <= 128 else 0.0) <= ref["accepted"][1:].mean() < 0.9
     run.close()
+
+
+@pytest.mark.parametrize("lanes", [1, 2])
+def test_negative_zero_initial_coordinates(mhx, oracle, real, lanes):
+    """the fp64 plain-walk kernel re-forms a rejected state as fma(0, n, x), which is x for every x but -0.0.  A
+    caller-supplied -0.0 therefore enters the chain as +0.0 on both sides (mhx_run_init / mhx_run_set_state; orc_rwmh): equal
+    under ==, so sample 1 == initial_params (test/runtests.jl:203-213) still holds, and the chain is the oracle's bit for bit."""
+    d, C, N = 100, 64, 24
+    s = float(np.float32(2.38 / d ** 0.5))
+    init = np.random.default_rng(3).normal(size=(d, C))
+    init[::3] = -0.0
+    init[1::7] = 0.0
+    model = mhx.DensityModel(mhx.IsoGaussian(d))
+    spl = mhx.RWMH(mhx.MvNormal(mhx.zeros(d), s * s * mhx.I))
+    chain = mhx.sample(model, spl, N, C, seed=8, initial_params=init, reduce_lanes=lanes)
+    ref = oracle.rwmh(oracle.iso_gauss(d, reduce_lanes=chain.stats["reduce_lanes"]), oracle.Proposal(oracle.PROP_ISO, s), oracle.schedule(N),
+                      8, 0, C, init=init)
+    _same(chain.value, ref["samples"], "samples")
+    _same(chain.accepted, ref["accepted"], "accepted")
+    assert (chain.value[0, :d] == init.astype(cases.R())).all()             # == holds, -0.0 == 0.0
+    assert not np.signbit(chain.value[:, :d][chain.value[:, :d] == 0]).any()  # no -0.0 anywhere in the chain
+    # the same through setparams!!
+    run = mhx.Run(model, spl, nchains=C, seed=8, reduce_lanes=lanes)
+    run.init(np.ones((d, C)))
+    run.set_params(init)
+    assert not np.signbit(run.state()[0][init == 0]).any()
