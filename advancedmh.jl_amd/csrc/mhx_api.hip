@@ -631,6 +631,9 @@ struct mhx_run : mhx_handle_hdr {
     int coop_L = 1;                      // lanes per chain (reduction shape of the separable targets)
     int emcee_band = -1;                 // bandwidth of the precision factor the cooperative stretch move exploits (-1: dense form)
     int coop_waves = MHX_EMCEE_COOP_WAVES;  // waves per block of the cooperative stretch move (tuning knob MHX_EMCEE_WAVES)
+    size_t emcee_stamp_words = 0;        // MHX_EMCEE_STAMPS (tools): 64-bit words of the stamp buffer in d_ybuf
+    int emcee_wpb = 64;                  // walkers per block of the scalar-factor form
+    bool emcee_scal = false;             // the scalar-factor form of the cooperative stretch move (variant 9): coop_L waves per block, 64 walkers
     int variant = 0;
     void (*reg_fn)(const mhx_rwmh_args, const mhx_real*, const mhx_real*) = nullptr;
     hipFunction_t jit_step = nullptr, jit_init = nullptr;

@@ -399,6 +399,18 @@ MHX_DEV mhx_real mhx_band_rows_sq(const mhx_real (&ab)[mhx_emcee_geom<D, L>::NK]
 #endif
 #define MHX_PROBE(n, val) do { if (MHX_EMCEE_PROBE == (n)) { if ((val) == MHX_R(12345.678)) a.lp[0] = (val); return; } } while (0)
 
+// timing stamps (tools only, MHX_EMCEE_STAMPS=1 at run creation): lane 0 of every wave stores s_memtime / s_memrealtime at its phase
+// boundaries into a.ybuf ([waves of the launch][16] 64-bit words; the host writes the last launch's buffer to $MHX_EMCEE_STAMPS_FILE)
+#ifndef MHX_EMCEE_STAMPS
+#define MHX_EMCEE_STAMPS 0
+#endif
+#if MHX_EMCEE_STAMPS
+#define MHX_STAMP(k) do { if ((threadIdx.x & 63) == 0) { mhx_u64* sp_ = (mhx_u64*)a.ybuf + ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16; \
+        sp_[2 * (k)] = __builtin_amdgcn_s_memtime(); sp_[2 * (k) + 1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define MHX_STAMP(k) do { } while (0)
+#endif
+
 #ifndef MHX_EMCEE_REC_STORE
 #define MHX_EMCEE_REC_STORE 0       // tuning knob: how the record leaves -- 0 plain stores, 1 non-temporal
 #endif
@@ -563,6 +575,431 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const mhx_real* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
+// The SCALAR-FACTOR form of the cooperative stretch move (dense precision factor; round 4).
+//
+// The factor A = inv(chol Sigma) is the same for every walker.  In the lane-group form above a lane owns ROWS of A y, so the A
+// operand differs from lane to lane and has to come from an LDS image that every block rebuilds in every 5-us launch (index
+// arithmetic, zero selects, a block barrier), and every fma needs an LDS read of A.  Here a lane owns a WALKER during the
+// mat-vec: all 64 lanes of a wave then multiply by the SAME A_rc, which is a wave-uniform value -- it streams through the scalar
+// cache (s_load_dwordxN straight from the packed factor: a row is contiguous) into SGPR pairs and is the scalar operand of
+// v_fma: no image, no LDS traffic for A, one fma instruction per product.  The rows are split over the NW waves of a block by
+// r mod NW (wave g: rows g, g + NW, ...), which is the spec's reduction shape L = NW (oracle: reduce_lanes = NW): every row is one
+// ascending fma chain from +0, wave g sums the squares of its rows in ascending order, the NW partial sums meet in the butterfly's
+// tree ((q0 + q1) + (q2 + q3)) + ... -- bit for bit what the lane-group form with L = NW computes.
+//   phase 1 (NW lanes per walker, as above): draws, the two rows, the move y = x_j + z (x_i - x_j); y goes to the block's LDS
+//           as a [64 walkers][YS] array whose pitch is an odd number of 16-byte units (conflict-free b128 reads by walker);
+//   phase 2 (lane = walker, wave = row class): y of the lane's walker into registers, the row products against SGPR operands,
+//           the wave's partial sum of squares to LDS;
+//   phase 3 (phase 1's mapping, whose registers still hold x_i and y): the butterfly tree, the accept test, state and record.
+// Two block barriers; 64 walkers per block of NW waves.
+#ifndef MHX_EMCEE_SCAL_WPB
+#define MHX_EMCEE_SCAL_WPB 64                // walkers per block of the scalar-factor form (64: every lane of phase 2 owns one; 32: half)
+#endif
+template <int D, int NW>
+struct mhx_emcee_sgeom {
+    static constexpr int WPB = MHX_EMCEE_SCAL_WPB;             // walkers per block
+    static constexpr int LM = 64 * NW / WPB;                   // lanes per walker in the move mapping
+    static constexpr int XP = (D + 3) & ~3;                    // pitch of a walker's row in the walker-major state
+    static constexpr int NQ = XP / 4;                          // e4 per walker
+    static constexpr int NQL = (NQ + LM - 1) / LM;             // e4 slots per lane in the move mapping
+    static constexpr int U = 16 / (int)sizeof(mhx_real);       // reals per 16 bytes
+    static constexpr int YS = ((XP / U) | 1) * U;              // y pitch: >= XP, an odd number of 16-byte units
+    static constexpr int LDS_REALS = WPB * YS + NW * 64;       // y rows + the partial sums
+};
+
+typedef mhx_real mhx_e2 __attribute__((ext_vector_type(2)));
+
+// wave g's rows of A y, squared and summed: A_rc is wave-uniform (kernel argument + compile-time offset: a scalar load)
+template <int D, int NW, int G>
+MHX_DEV mhx_real mhx_scal_rows_sq(const mhx_real* __restrict__ A, const mhx_real (&y)[(D + 3) & ~3])
+{
+    mhx_real q = MHX_R(0.0);
+#pragma unroll
+    for (int r = G; r < D; r += NW) {
+        const mhx_real* Ar = A + (r * (r + 1)) / 2;
+        mhx_real w = MHX_R(0.0);
+#pragma unroll
+        for (int c = 0; c <= r; ++c) w = mhx_fma(Ar[c], y[c], w);
+        q = mhx_fma(w, w, q);
+    }
+    return q;
+}
+template <int D, int NW, int G = 0>
+MHX_DEV mhx_real mhx_scal_rows_dispatch(const int g, const mhx_real* __restrict__ A, const mhx_real (&y)[(D + 3) & ~3])
+{
+    if constexpr (G < NW) {
+        if (g == G) return mhx_scal_rows_sq<D, NW, G>(A, y);       // g is wave-uniform: a scalar branch
+        return mhx_scal_rows_dispatch<D, NW, G + 1>(g, A, y);
+    } else {
+        return MHX_R(0.0);
+    }
+}
+
+// The same rows with the factor in VGPRs and a DPP broadcast as the multiplier (MHX_EMCEE_SCAL_MODE 1, the default): scalar loads
+// return out of order, so a wave can only wait for ALL of them (lgkmcnt(0)) and the ~20 x16 pieces of a row class cannot be kept in
+// flight behind the products that consume them -- the SGPR file holds two or three pieces.  Vector loads count in order and the
+// VGPR file is large: each wave fetches ITS rows at the top of the kernel, 16 columns per load (lane k of every 16-lane row of the
+// wave holds A[r][16 b + k]: one 128-byte segment), they land while phase 1 runs, and the product is
+//     v_fmac_f64_dpp w, vA, y_c row_newbcast:k        (w += vA[lane k of the row] * y_c; f32 alike)
+// -- still one instruction per product, the multiplier wave-uniform by construction.  The columns run in the outer loop and a wave's
+// rows in the inner one, so consecutive instructions belong to different accumulator chains; every chain is ascending in c from +0.
+// One column of a row class as ONE asm statement: the products w_m += A[r_m][c] * y_c of the N rows that reach column c, back to back.
+// The compiler cannot put anything between them, so the two wait states a DPP source needs after a VALU write (a register copy or an
+// AGPR reload of a factor piece -- the compiler does not look inside asm) are paid once per column (s_nop 1), not once per product.
+#if MHX_REAL64
+#define MHX_DPP_FMAC "v_fmac_f64_dpp"
+#else
+#define MHX_DPP_FMAC "v_fmac_f32_dpp"
+#endif
+#define MHX_DPP_TAIL " row_mask:0xf bank_mask:0xf\n\t"
+template <int K> MHX_DEV void mhx_dpp_col1(mhx_real& w0, const mhx_real a0, const mhx_real yc)
+{
+    asm volatile("s_nop 1\n\t"
+                 MHX_DPP_FMAC " %0, %1, %2 row_newbcast:%3" MHX_DPP_TAIL
+                 : "+v"(w0) : "v"(a0), "v"(yc), "n"(K));
+}
+template <int K> MHX_DEV void mhx_dpp_col2(mhx_real& w0, mhx_real& w1, const mhx_real a0, const mhx_real a1, const mhx_real yc)
+{
+    asm volatile("s_nop 1\n\t"
+                 MHX_DPP_FMAC " %0, %2, %4 row_newbcast:%5" MHX_DPP_TAIL
+                 MHX_DPP_FMAC " %1, %3, %4 row_newbcast:%5" MHX_DPP_TAIL
+                 : "+v"(w0), "+v"(w1) : "v"(a0), "v"(a1), "v"(yc), "n"(K));
+}
+template <int K> MHX_DEV void mhx_dpp_col3(mhx_real& w0, mhx_real& w1, mhx_real& w2, const mhx_real a0, const mhx_real a1, const mhx_real a2, const mhx_real yc)
+{
+    asm volatile("s_nop 1\n\t"
+                 MHX_DPP_FMAC " %0, %3, %6 row_newbcast:%7" MHX_DPP_TAIL
+                 MHX_DPP_FMAC " %1, %4, %6 row_newbcast:%7" MHX_DPP_TAIL
+                 MHX_DPP_FMAC " %2, %5, %6 row_newbcast:%7" MHX_DPP_TAIL
+                 : "+v"(w0), "+v"(w1), "+v"(w2) : "v"(a0), "v"(a1), "v"(a2), "v"(yc), "n"(K));
+}
+template <int K> MHX_DEV void mhx_dpp_col4(mhx_real& w0, mhx_real& w1, mhx_real& w2, mhx_real& w3, const mhx_real a0, const mhx_real a1, const mhx_real a2, const mhx_real a3, const mhx_real yc)
+{
+    asm volatile("s_nop 1\n\t"
+                 MHX_DPP_FMAC " %0, %4, %8 row_newbcast:%9" MHX_DPP_TAIL
+                 MHX_DPP_FMAC " %1, %5, %8 row_newbcast:%9" MHX_DPP_TAIL
+                 MHX_DPP_FMAC " %2, %6, %8 row_newbcast:%9" MHX_DPP_TAIL
+                 MHX_DPP_FMAC " %3, %7, %8 row_newbcast:%9" MHX_DPP_TAIL
+                 : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(yc), "n"(K));
+}
+template <int K> MHX_DEV void mhx_dpp_col5(mhx_real& w0, mhx_real& w1, mhx_real& w2, mhx_real& w3, mhx_real& w4, const mhx_real a0, const mhx_real a1, const mhx_real a2, const mhx_real a3, const mhx_real a4, const mhx_real yc)
+{
+    asm volatile("s_nop 1\n\t"
+                 MHX_DPP_FMAC " %0, %5, %10 row_newbcast:%11" MHX_DPP_TAIL
+                 MHX_DPP_FMAC " %1, %6, %10 row_newbcast:%11" MHX_DPP_TAIL
+                 MHX_DPP_FMAC " %2, %7, %10 row_newbcast:%11" MHX_DPP_TAIL
+                 MHX_DPP_FMAC " %3, %8, %10 row_newbcast:%11" MHX_DPP_TAIL
+                 MHX_DPP_FMAC " %4, %9, %10 row_newbcast:%11" MHX_DPP_TAIL
+                 : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3), "+v"(w4) : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(yc), "n"(K));
+}
+template <int K> MHX_DEV void mhx_dpp_col6(mhx_real& w0, mhx_real& w1, mhx_real& w2, mhx_real& w3, mhx_real& w4, mhx_real& w5, const mhx_real a0, const mhx_real a1, const mhx_real a2, const mhx_real a3, const mhx_real a4, const mhx_real a5, const mhx_real yc)
+{
+    asm volatile("s_nop 1\n\t"
+                 MHX_DPP_FMAC " %0, %6, %12 row_newbcast:%13" MHX_DPP_TAIL
+                 MHX_DPP_FMAC " %1, %7, %12 row_newbcast:%13" MHX_DPP_TAIL
+                 MHX_DPP_FMAC " %2, %8, %12 row_newbcast:%13" MHX_DPP_TAIL
+                 MHX_DPP_FMAC " %3, %9, %12 row_newbcast:%13" MHX_DPP_TAIL
+                 MHX_DPP_FMAC " %4, %10, %12 row_newbcast:%13" MHX_DPP_TAIL
+                 MHX_DPP_FMAC " %5, %11, %12 row_newbcast:%13" MHX_DPP_TAIL
+                 : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3), "+v"(w4), "+v"(w5) : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(yc), "n"(K));
+}
+template <int K> MHX_DEV void mhx_dpp_col7(mhx_real& w0, mhx_real& w1, mhx_real& w2, mhx_real& w3, mhx_real& w4, mhx_real& w5, mhx_real& w6, const mhx_real a0, const mhx_real a1, const mhx_real a2, const mhx_real a3, const mhx_real a4, const mhx_real a5, const mhx_real a6, const mhx_real yc)
+{
+    asm volatile("s_nop 1\n\t"
+                 MHX_DPP_FMAC " %0, %7, %14 row_newbcast:%15" MHX_DPP_TAIL
+                 MHX_DPP_FMAC " %1, %8, %14 row_newbcast:%15" MHX_DPP_TAIL
+                 MHX_DPP_FMAC " %2, %9, %14 row_newbcast:%15" MHX_DPP_TAIL
+                 MHX_DPP_FMAC " %3, %10, %14 row_newbcast:%15" MHX_DPP_TAIL
+                 MHX_DPP_FMAC " %4, %11, %14 row_newbcast:%15" MHX_DPP_TAIL
+                 MHX_DPP_FMAC " %5, %12, %14 row_newbcast:%15" MHX_DPP_TAIL
+                 MHX_DPP_FMAC " %6, %13, %14 row_newbcast:%15" MHX_DPP_TAIL
+                 : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3), "+v"(w4), "+v"(w5), "+v"(w6) : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(yc), "n"(K));
+}
+template <int K> MHX_DEV void mhx_dpp_col8(mhx_real& w0, mhx_real& w1, mhx_real& w2, mhx_real& w3, mhx_real& w4, mhx_real& w5, mhx_real& w6, mhx_real& w7, const mhx_real a0, const mhx_real a1, const mhx_real a2, const mhx_real a3, const mhx_real a4, const mhx_real a5, const mhx_real a6, const mhx_real a7, const mhx_real yc)
+{
+    asm volatile("s_nop 1\n\t"
+                 MHX_DPP_FMAC " %0, %8, %16 row_newbcast:%17" MHX_DPP_TAIL
+                 MHX_DPP_FMAC " %1, %9, %16 row_newbcast:%17" MHX_DPP_TAIL
+                 MHX_DPP_FMAC " %2, %10, %16 row_newbcast:%17" MHX_DPP_TAIL
+                 MHX_DPP_FMAC " %3, %11, %16 row_newbcast:%17" MHX_DPP_TAIL
+                 MHX_DPP_FMAC " %4, %12, %16 row_newbcast:%17" MHX_DPP_TAIL
+                 MHX_DPP_FMAC " %5, %13, %16 row_newbcast:%17" MHX_DPP_TAIL
+                 MHX_DPP_FMAC " %6, %14, %16 row_newbcast:%17" MHX_DPP_TAIL
+                 MHX_DPP_FMAC " %7, %15, %16 row_newbcast:%17" MHX_DPP_TAIL
+                 : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3), "+v"(w4), "+v"(w5), "+v"(w6), "+v"(w7) : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7), "v"(yc), "n"(K));
+}
+template <int D, int NW>
+struct mhx_bcast_geom {
+    static constexpr int NRMAX = (D + NW - 1) / NW;            // rows of a class, at most
+    static constexpr int CHMAX = (D - 1) / 16 + 1;             // 16-column pieces of a row, at most
+    static constexpr int TOT = D * (D + 1) / 2;
+};
+// this wave's pieces: the same code for every row class g (wave-uniform row arithmetic on the scalar side); row set m of class g
+// is row g + NW m, and every class loads as many pieces of it as the longest row of the set needs -- a piece past the end of a
+// short row holds the next rows of the packed factor (never used), past the end of the factor the last element
+template <int D, int NW>
+MHX_DEV void mhx_bcast_load(const int g, const mhx_real* __restrict__ A, const int lane16,
+                            mhx_real (&av)[mhx_bcast_geom<D, NW>::NRMAX][mhx_bcast_geom<D, NW>::CHMAX])
+{
+    constexpr int TOT = mhx_bcast_geom<D, NW>::TOT;
+#pragma unroll
+    for (int m = 0; m < mhx_bcast_geom<D, NW>::NRMAX; ++m) {
+        const int r0 = g + NW * m;
+        const int r = r0 < D ? r0 : D - 1;
+        const int base = (r * (r + 1)) / 2 + lane16;
+        const int rmax = (NW * m + NW - 1) < D ? (NW * m + NW - 1) : D - 1;          // longest row of the set (folds after unrolling)
+#pragma unroll
+        for (int b = 0; 16 * b <= rmax; ++b) {
+            const int idx = base + 16 * b;
+            av[m][b] = A[idx < TOT ? idx : TOT - 1];
+        }
+    }
+}
+// rows M0 .. M0 + N - 1 of the class (N <= 8) at column C
+template <int K, int N, int M0, int B, int NR, int CH>
+MHX_DEV void mhx_bcast_group(mhx_real (&w)[NR], const mhx_real (&av)[NR][CH], const mhx_real yc)
+{
+    if constexpr (N == 1) mhx_dpp_col1<K>(w[M0], av[M0][B], yc);
+    else if constexpr (N == 2) mhx_dpp_col2<K>(w[M0], w[M0 + 1], av[M0][B], av[M0 + 1][B], yc);
+    else if constexpr (N == 3) mhx_dpp_col3<K>(w[M0], w[M0 + 1], w[M0 + 2], av[M0][B], av[M0 + 1][B], av[M0 + 2][B], yc);
+    else if constexpr (N == 4) mhx_dpp_col4<K>(w[M0], w[M0 + 1], w[M0 + 2], w[M0 + 3], av[M0][B], av[M0 + 1][B], av[M0 + 2][B], av[M0 + 3][B], yc);
+    else if constexpr (N == 5) mhx_dpp_col5<K>(w[M0], w[M0 + 1], w[M0 + 2], w[M0 + 3], w[M0 + 4], av[M0][B], av[M0 + 1][B], av[M0 + 2][B], av[M0 + 3][B],
+                                               av[M0 + 4][B], yc);
+    else if constexpr (N == 6) mhx_dpp_col6<K>(w[M0], w[M0 + 1], w[M0 + 2], w[M0 + 3], w[M0 + 4], w[M0 + 5], av[M0][B], av[M0 + 1][B], av[M0 + 2][B],
+                                               av[M0 + 3][B], av[M0 + 4][B], av[M0 + 5][B], yc);
+    else if constexpr (N == 7) mhx_dpp_col7<K>(w[M0], w[M0 + 1], w[M0 + 2], w[M0 + 3], w[M0 + 4], w[M0 + 5], w[M0 + 6], av[M0][B], av[M0 + 1][B],
+                                               av[M0 + 2][B], av[M0 + 3][B], av[M0 + 4][B], av[M0 + 5][B], av[M0 + 6][B], yc);
+    else mhx_dpp_col8<K>(w[M0], w[M0 + 1], w[M0 + 2], w[M0 + 3], w[M0 + 4], w[M0 + 5], w[M0 + 6], w[M0 + 7], av[M0][B], av[M0 + 1][B], av[M0 + 2][B],
+                         av[M0 + 3][B], av[M0 + 4][B], av[M0 + 5][B], av[M0 + 6][B], av[M0 + 7][B], yc);
+}
+// the rows of class G that reach column C are the row sets M0 .. NR - 1 (row G + NW m >= C); in groups of at most 8
+template <int D, int NW, int G, int C, int M0>
+MHX_DEV void mhx_bcast_groups(const mhx_real (&av)[mhx_bcast_geom<D, NW>::NRMAX][mhx_bcast_geom<D, NW>::CHMAX], const mhx_real yc,
+                              mhx_real (&w)[mhx_bcast_geom<D, NW>::NRMAX])
+{
+    constexpr int NR = (D - G + NW - 1) / NW;                 // rows of class G
+    if constexpr (M0 < NR) {
+        constexpr int N = NR - M0 < 8 ? NR - M0 : 8;
+        mhx_bcast_group<C % 16, N, M0, C / 16>(w, av, yc);
+        mhx_bcast_groups<D, NW, G, C, M0 + N>(av, yc, w);
+    }
+}
+template <int D, int NW, int G, int C>
+MHX_DEV void mhx_bcast_column(const mhx_real (&av)[mhx_bcast_geom<D, NW>::NRMAX][mhx_bcast_geom<D, NW>::CHMAX], const mhx_real (&y)[(D + 3) & ~3],
+                              mhx_real (&w)[mhx_bcast_geom<D, NW>::NRMAX])
+{
+    if constexpr (C < D) {
+        constexpr int M0 = C <= G ? 0 : (C - G + NW - 1) / NW;   // first row set whose row reaches column C
+        mhx_bcast_groups<D, NW, G, C, M0>(av, y[C], w);
+        mhx_bcast_column<D, NW, G, C + 1>(av, y, w);
+    }
+}
+template <int D, int NW, int G>
+MHX_DEV mhx_real mhx_bcast_rows_sq(const mhx_real (&av)[mhx_bcast_geom<D, NW>::NRMAX][mhx_bcast_geom<D, NW>::CHMAX], const mhx_real (&y)[(D + 3) & ~3])
+{
+    mhx_real w[mhx_bcast_geom<D, NW>::NRMAX];
+#pragma unroll
+    for (int m = 0; m < mhx_bcast_geom<D, NW>::NRMAX; ++m) w[m] = MHX_R(0.0);
+    mhx_bcast_column<D, NW, G, 0>(av, y, w);
+    mhx_real q = MHX_R(0.0);
+#pragma unroll
+    for (int m = 0; G + NW * m < D; ++m) q = mhx_fma(w[m], w[m], q);
+    return q;
+}
+template <int D, int NW, int G = 0>
+MHX_DEV mhx_real mhx_bcast_rows_dispatch(const int g, const mhx_real (&av)[mhx_bcast_geom<D, NW>::NRMAX][mhx_bcast_geom<D, NW>::CHMAX],
+                                         const mhx_real (&y)[(D + 3) & ~3])
+{
+    if constexpr (G < NW) {
+        if (g == G) return mhx_bcast_rows_sq<D, NW, G>(av, y);
+        return mhx_bcast_rows_dispatch<D, NW, G + 1>(g, av, y);
+    } else {
+        return MHX_R(0.0);
+    }
+}
+
+#ifndef MHX_EMCEE_SCAL_REC
+#define MHX_EMCEE_SCAL_REC 1                 // how the record leaves: 0 straight from the move mapping (4-walker runs), 1 through the block's LDS (whole row segments)
+#endif
+#ifndef MHX_EMCEE_SCAL_MODE
+#define MHX_EMCEE_SCAL_MODE 1                // how the wave-uniform factor reaches the products: 0 scalar loads -> SGPR operands, 1 vector loads -> DPP broadcast
+#endif
+template <int D, int NW>
+MHX_DEV void mhx_emcee_scal_body(const mhx_emcee_args& a, const mhx_real* __restrict__ A, mhx_real* lds)
+{
+    typedef mhx_emcee_sgeom<D, NW> GEO;
+    constexpr int XP = GEO::XP, NQ = GEO::NQ, NQL = GEO::NQL, YS = GEO::YS, WPB = GEO::WPB, LM = GEO::LM;
+    mhx_real* ysh = lds;                         // [WPB][YS]
+    mhx_real* qsh = lds + WPB * YS;              // [NW][64]
+    const int tid = threadIdx.x;
+    MHX_STAMP(0);
+    const int g = __builtin_amdgcn_readfirstlane(tid >> 6);                  // this wave's row class in phase 2
+    // ---- phase 1: LM lanes per walker.  A chain of latencies, so the loads go out in the order their addresses are known:
+    // the walker's own row and lp at once, the partner's row as soon as the draw names it, then this wave's pieces of the factor
+    // (needed only in phase 2: vector loads count in order, so they must follow the rows or the rows would wait for them too).
+    const int wm = tid / LM, l = tid % LM;
+    const int W = a.nwalkers;
+    const int halfW = W / 2;
+    const int lo = a.half ? halfW : 0;
+    const int cnt = a.half ? W - halfW : halfW;
+    const int t_raw = a.t_begin + blockIdx.x * WPB + wm;
+    const bool valid = t_raw < cnt && t_raw < a.t_begin + a.t_count;
+    const int i = lo + (valid ? t_raw : cnt - 1);
+    const int ostart = a.half ? 0 : halfW;
+    const int osize = a.half ? halfW : W - halfW;
+    const long ld = W;
+    MHX_PROBE(1, (mhx_real)i);
+    mhx_e4 xs[NQL], xjs[NQL], ysl[NQL];
+    mhx_e4* xrow_i = (mhx_e4*)(a.xw + (long)i * XP);
+    const mhx_e4 zero4 = {MHX_R(0.0), MHX_R(0.0), MHX_R(0.0), MHX_R(0.0)};
+#pragma unroll
+    for (int m = 0; m < NQL; ++m) { const int q4 = l + LM * m; xs[m] = q4 < NQ ? xrow_i[q4] : zero4; }
+    const mhx_real lpi = a.lp[i];
+    const mhx_u32 acc_i = a.acc_count[i];
+    const mhx_philox_key ks = mhx_philox_schedule(a.seed);
+    const mhx_emcee_draws dr = mhx_emcee_draw(ks, (mhx_u32)i, (mhx_u32)a.ensemble_id, a.sweep);
+    const int j = ostart + (int)(((mhx_u64)dr.partner * (mhx_u64)(mhx_u32)osize) >> 32);
+    const mhx_e4* xrow_j = (const mhx_e4*)(a.xw + (long)j * XP);
+#pragma unroll
+    for (int m = 0; m < NQL; ++m) { const int q4 = l + LM * m; xjs[m] = q4 < NQ ? xrow_j[q4] : zero4; }
+    __builtin_amdgcn_sched_barrier(0);
+    mhx_real av[mhx_bcast_geom<D, NW>::NRMAX][mhx_bcast_geom<D, NW>::CHMAX];
+    if constexpr (MHX_EMCEE_SCAL_MODE == 1) mhx_bcast_load<D, NW>(g, A, tid & 15, av);   // in flight until phase 2
+    __builtin_amdgcn_sched_barrier(0);
+    const mhx_real tt = mhx_fma(a.stretch - MHX_R(1.0), dr.u, MHX_R(1.0));
+    const mhx_real z = (tt * tt) / a.stretch;                                // src/emcee.jl:81
+    const mhx_real alphamult = (mhx_real)(D - 1) * mhx_log(z);               // :82
+    MHX_PROBE(2, alphamult + (mhx_real)j);
+    mhx_real* yrow = ysh + wm * YS;
+#pragma unroll
+    for (int m = 0; m < NQL; ++m) {
+        const int q4 = l + LM * m;
+        ysl[m] = zero4;
+        if (q4 < NQ) {
+            const mhx_e4 xi = xs[m];
+            const mhx_e4 xj = xjs[m];
+            ysl[m].x = mhx_fma(z, xi.x - xj.x, xj.x);                        // :85
+            ysl[m].y = mhx_fma(z, xi.y - xj.y, xj.y);
+            ysl[m].z = mhx_fma(z, xi.z - xj.z, xj.z);
+            ysl[m].w = mhx_fma(z, xi.w - xj.w, xj.w);
+            // (the row pitch is a multiple of 16 bytes, not of sizeof(e4) in fp64: two 16-byte halves there)
+            if constexpr (sizeof(mhx_real) == 8) {
+                mhx_e2 h0 = {ysl[m].x, ysl[m].y}, h1 = {ysl[m].z, ysl[m].w};
+                ((mhx_e2*)(yrow + 4 * q4))[0] = h0;
+                ((mhx_e2*)(yrow + 4 * q4))[1] = h1;
+            } else {
+                *(mhx_e4*)(yrow + 4 * q4) = ysl[m];
+            }
+        }
+    }
+    MHX_PROBE(3, ysl[0].x);
+    MHX_STAMP(1);
+    __syncthreads();
+    MHX_STAMP(2);
+    // ---- phase 2: lane = walker, wave = row class
+    {
+        const int wv = tid & 63;
+        mhx_real y[XP];
+        const mhx_real* yr = ysh + (wv < WPB ? wv : WPB - 1) * YS;     // (WPB < 64: the upper lanes idle along)
+        if constexpr (sizeof(mhx_real) == 8) {
+#pragma unroll
+            for (int k = 0; k < XP / 2; ++k) { const mhx_e2 v = ((const mhx_e2*)yr)[k]; y[2 * k] = v.x; y[2 * k + 1] = v.y; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < XP / 4; ++k) { const mhx_e4 v = ((const mhx_e4*)yr)[k]; y[4 * k] = v.x; y[4 * k + 1] = v.y; y[4 * k + 2] = v.z; y[4 * k + 3] = v.w; }
+        }
+        MHX_PROBE(4, y[0]);
+        MHX_STAMP(3);
+        if constexpr (MHX_EMCEE_SCAL_MODE == 1) qsh[g * 64 + wv] = mhx_bcast_rows_dispatch<D, NW>(g, av, y);
+        else qsh[g * 64 + wv] = mhx_scal_rows_dispatch<D, NW>(g, A, y);
+    }
+    MHX_STAMP(4);
+    __syncthreads();
+    MHX_STAMP(5);
+    // ---- phase 3: back in the move mapping
+    mhx_real qv[NW];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) qv[k] = qsh[k * 64 + wm];
+#pragma unroll
+    for (int off = 1; off < NW; off <<= 1)
+#pragma unroll
+        for (int k = 0; k < NW; k += 2 * off) qv[k] = qv[k] + qv[k + off];          // the butterfly's tree
+    const mhx_real lpy = mhx_fma(-MHX_R(0.5), qv[0], a.tconst);
+    MHX_PROBE(5, lpy + ysl[0].x);
+    const mhx_real alpha = (alphamult + lpy) - lpi;                          // :91
+    const bool acc = dr.logu <= alpha;                                       // :93
+#if MHX_EMCEE_SCAL_REC
+    // the record leaves as whole row segments: the final rows (candidate or walker) meet in the block's LDS -- the candidate rows
+    // are there already, a rejected move puts the walker back -- and every row k of the [dim+1][W] record is then written for the
+    // block's WPB consecutive walkers at once (WPB * sizeof(real) contiguous bytes) instead of 4 walkers at a time
+    if (valid && acc) {
+#pragma unroll
+        for (int m = 0; m < NQL; ++m) { const int q4 = l + LM * m; if (q4 < NQ) xrow_i[q4] = ysl[m]; }
+        if (l == 0) { a.lp[i] = lpy; a.acc_count[i] = acc_i + 1u; }
+    }
+    if (valid && l == 0) a.last_acc[i] = acc ? 1 : 0;
+    MHX_STAMP(6);
+    if (MHX_EMCEE_PROBE == 6) return;
+    if (a.save_slot >= 0) {                                                 // (uniform)
+        if (!acc) {
+#pragma unroll
+            for (int m = 0; m < NQL; ++m) {
+                const int q4 = l + LM * m;
+                if (q4 < NQ) {
+                    if constexpr (sizeof(mhx_real) == 8) {
+                        mhx_e2 h0 = {xs[m].x, xs[m].y}, h1 = {xs[m].z, xs[m].w};
+                        ((mhx_e2*)(yrow + 4 * q4))[0] = h0;
+                        ((mhx_e2*)(yrow + 4 * q4))[1] = h1;
+                    } else {
+                        *(mhx_e4*)(yrow + 4 * q4) = xs[m];
+                    }
+                }
+            }
+        }
+        if (l == 0) qsh[wm] = acc ? lpy : lpi;                              // (the partial sums have been read: phase 3 is past them)
+        if (l == 1 || LM == 1) qsh[64 + wm] = acc ? MHX_R(1.0) : MHX_R(0.0);
+        __syncthreads();
+        const int wr = tid % WPB, ks = tid / WPB;                            // walker of the block, first row of this thread
+        const int tw = a.t_begin + blockIdx.x * WPB + wr;
+        if (tw < cnt && tw < a.t_begin + a.t_count) {
+            mhx_real* col = a.samples + a.save_slot * (long)(D + 1) * ld + (lo + tw);
+#pragma unroll
+            for (int k = ks; k < D + 1; k += LM) MHX_REC_ST(&col[(long)k * ld], k < D ? ysh[wr * YS + k] : qsh[wr]);
+            if (ks == LM - 1) a.accepted[a.save_slot * ld + lo + tw] = qsh[64 + wr] != MHX_R(0.0) ? 1 : 0;
+        }
+    }
+#else
+    if (valid) {
+        if (acc) {
+#pragma unroll
+            for (int m = 0; m < NQL; ++m) { const int q4 = l + LM * m; if (q4 < NQ) xrow_i[q4] = ysl[m]; }
+            if (l == 0) { a.lp[i] = lpy; a.acc_count[i] = acc_i + 1u; }
+        }
+        if (l == 0) a.last_acc[i] = acc ? 1 : 0;
+        MHX_STAMP(6);
+        if (MHX_EMCEE_PROBE == 6) return;
+        if (a.save_slot >= 0) {
+            mhx_real* row = a.samples + a.save_slot * (long)(D + 1) * ld + i;
+#pragma unroll
+            for (int m = 0; m < NQL; ++m) {
+                const int k = 4 * (l + LM * m);
+                const mhx_e4 v = acc ? ysl[m] : xs[m];
+                if (k + 0 < D) MHX_REC_ST(&row[(long)(k + 0) * ld], v.x);
+                if (k + 1 < D) MHX_REC_ST(&row[(long)(k + 1) * ld], v.y);
+                if (k + 2 < D) MHX_REC_ST(&row[(long)(k + 2) * ld], v.z);
+                if (k + 3 < D) MHX_REC_ST(&row[(long)(k + 3) * ld], v.w);
+            }
+            if (l == 0) {
+                MHX_REC_ST(&row[(long)D * ld], acc ? lpy : lpi);
+                a.accepted[a.save_slot * ld + i] = acc ? 1 : 0;
+            }
+        }
+    }
+#endif
+    MHX_STAMP(7);
+}
+
+// ---------------------------------------------------------------------------------------------
 // The reference's OWN sweep (src/emcee.jl:39-58): walkers move one after another, walker i pairs with idx = mod1(i + r, W),
 // r uniform on 1..W-1, and uses the ALREADY UPDATED position when idx < i (:53) -- Gauss-Seidel, serial in W by
 // construction.  One wave runs the whole schedule of a launch: lanes share the copy of a move's rows, lane 0 evaluates
@@ -628,14 +1065,23 @@ MHX_DEV void mhx_emcee_seq_body(const mhx_emcee_args& a, const mhx_real* __restr
 }
 
 #ifdef MHX_JIT_EMCEE
-#if MHX_JIT_L > 1
+#ifndef MHX_JIT_SCAL
+#define MHX_JIT_SCAL 0
+#endif
+#if MHX_JIT_SCAL
+extern "C" __global__ void __launch_bounds__(64 * MHX_JIT_L)
+#elif MHX_JIT_L > 1
 extern "C" __global__ void __launch_bounds__(64 * MHX_EMCEE_COOP_WAVES)
 #else
 extern "C" __global__ void __launch_bounds__(64)
 #endif
 mhx_jit_emcee_half(const mhx_emcee_args a, const mhx_real* __restrict__ tparams)
 {
-#if MHX_JIT_L > 1
+#if MHX_JIT_SCAL
+    // the scalar-factor form: MHX_JIT_L waves per block = row classes = reduction shape; dynamic LDS = y rows + partial sums
+    extern __shared__ mhx_e4 mhx_emcee_lds[];
+    mhx_emcee_scal_body<MHX_JIT_DIM, MHX_JIT_L>(a, tparams, (mhx_real*)mhx_emcee_lds);
+#elif MHX_JIT_L > 1
     // dynamic LDS (up to 160 KB per block on gfx950): [candidate rows][factor image]
     extern __shared__ mhx_e4 mhx_emcee_lds[];
     constexpr int YS4 = MHX_EMCEE_COOP_WAVES * (64 / MHX_JIT_L) * mhx_emcee_geom<MHX_JIT_DIM, MHX_JIT_L>::DP4 / 4;

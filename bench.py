@@ -566,12 +566,19 @@ def ess_window(mhx, wl, world):
 
 
 KERNELS = {0: "generic", 1: "prebuilt-register", 2: "hiprtc-register", 3: "prebuilt-cooperative", 4: "hiprtc-cooperative",
-           5: "hiprtc-dense-cooperative", 6: "persistent-ensemble", 7: "sequential-ensemble-sweep", 8: "matrix-core"}
+           5: "hiprtc-dense-cooperative", 6: "persistent-ensemble", 7: "sequential-ensemble-sweep", 8: "matrix-core",
+           9: "scalar-factor-ensemble"}
+
+
+def kernel_name(wl, st):
+    if wl.name == "c4":
+        return "ram-streamed-factor"                               # k_ram<G,R,W>: lane groups, the factor streamed through an LDS ring
+    return KERNELS.get(st["kernel_variant"], str(st["kernel_variant"]))
 
 
 def config_block(wl, name, st, collective):
     return {"workload": wl.describe(), "name": name, "units_per_step_per_gpu": wl.units_per_step(),
-            "kernel_variant": KERNELS.get(st["kernel_variant"], str(st["kernel_variant"])), "lanes_per_unit": st["reduce_lanes"],
+            "kernel_variant": kernel_name(wl, st), "lanes_per_unit": st["reduce_lanes"],
             "launches_per_step": max(1, st["launches"]),
             "sharding": "chains by global id, no data-path collective" if name != "c3" else "one ensemble per GPU (replicas)",
             "collective": collective}
@@ -634,7 +641,7 @@ def other_configs(mhx, ctx, args, barrier):
             blk = {"value": sig(w.units_per_step() * steps / dt), "ms_per_step": sig(dt * 1e3 / steps), "acc": sig(acc / float(tr), 3),
                    "bound": rf["bound"], "frac": sig(rf["frac"], 4),
                    "traffic_ratio": sig(rf["traffic"] / rf["algorithmic_bytes_per_step"], 4) if rf.get("traffic") else None,
-                   "launch_us": sig(rf["avg_launch_ms"] * 1e3, 4), "kernel": KERNELS.get(st["kernel_variant"], "?"), "lanes": st["reduce_lanes"]}
+                   "launch_us": sig(rf["avg_launch_ms"] * 1e3, 4), "kernel": kernel_name(wl, st), "lanes": st["reduce_lanes"]}
             if rf["bound"] == "valu":
                 blk["hbm_frac"] = rf["hbm_frac"]
             if st.get("factor_band", -1) >= 0:

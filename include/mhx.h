@@ -285,7 +285,10 @@ typedef struct {
                                   5 hiprtc-specialised cooperative kernel for the dense Gaussian target (RWMH),
                                   7 the reference's sequential ensemble sweep (MHX_FLAG_EMCEE_SEQUENTIAL),
                                   8 matrix-core kernel: RWMH / MALA with one dense factor for all chains (dense Gaussian
-                                  target and / or dense proposal) on v_mfma_*_16x16x4, reduction shape 4 */
+                                  target and / or dense proposal) on v_mfma_*_16x16x4, reduction shape 4,
+                                  9 scalar-factor form of the cooperative stretch move (dense precision factor: a lane owns a
+                                  walker during A y, the wave-uniform factor entry is a DPP-broadcast / SGPR operand; reduction
+                                  shape = reduce_lanes = waves per block) */
     int32_t launches;
     int32_t reduce_lanes;      /* lanes per chain in effect (1 unless a cooperative kernel runs) */
     int32_t dtype;             /* mhx_dtype of the run's context */

@@ -358,3 +358,66 @@ def test_deferred_record_writes_the_same_tensor(mhx, real, W, monkeypatch):
         got = run_it(slab)
         _same(got[0], want[0], "samples, deferred record, slab %d" % slab)
         _same(got[1], want[1], "accepted")
+
+
+def _rotated(d, rho=0.9, seed=50):
+    Q, _ = np.linalg.qr(np.random.default_rng(seed).normal(size=(d, d)))
+    return Q @ cases.sigma_ar1(d, rho) @ Q.T
+
+
+@pytest.mark.parametrize("d,W", [(50, 200), (17, 70), (64, 129), (33, 64), (8, 66)])
+def test_scalar_factor_form_runs_a_dense_factor_bit_exact(mhx, oracle, real, d, W):
+    """Round 4: a DENSE precision factor (the rotated C3 target: no band to exploit) runs the scalar-factor form of the cooperative
+    stretch move -- variant 9: a lane owns a walker during A y, the wave-uniform factor entry is the DPP-broadcast operand of
+    v_fmac, rows split over the 8 waves of a block = the spec's reduction shape 8 -- and is the oracle's chain bit for bit, through a
+    discarded prefix, thinning, the initial draw on the device and a slab-streamed call (src/emcee.jl:70-102)."""
+    Sig = _rotated(d)
+    model = mhx.DensityModel(mhx.CorrGaussian(Sig))
+    spl = mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I)))
+    chain = mhx.sample(model, spl, 7, seed=13, discard_initial=2, thinning=2)
+    assert chain.stats["kernel_variant"] == 9 and chain.stats["reduce_lanes"] == 8 and chain.stats["factor_band"] == -1
+    ref = oracle.emcee(oracle.corr_gauss_from_cov(Sig, reduce_lanes=8), 2.0, 1, oracle.schedule(7, 2, 2), 13, 0, W, None,
+                       prior=oracle.Proposal(oracle.PROP_ISO, 1.0))
+    _same(chain.value, ref["samples"], "samples")
+    _same(chain.accepted, ref["accepted"], "accepted")
+    assert chain.stats["accepted"] == int(ref["accept_counts"].sum())
+    r = mhx.Run(model, spl, seed=13)
+    r.init(None)
+    got, got_acc = r.sample_to_host(7, 2, 2, 0, slab_samples=-3)
+    _same(got, ref["samples"], "slab-streamed")
+    _same(got_acc, ref["accepted"], "accepted, slab-streamed")
+
+
+@pytest.mark.parametrize("knobs", [{"MHX_EMCEE_SCALAR": "4"}, {"MHX_EMCEE_SCALAR": "16"}, {"MHX_EMCEE_SCAL_WPB": "64"}, {"MHX_EMCEE_SCAL_WPB": "16"},
+                                   {"MHX_EMCEE_SCAL_MODE": "0"}, {"MHX_EMCEE_SCAL_REC": "0"}, {"MHX_EMCEE_SCALAR": "0"}])
+def test_scalar_factor_form_every_shape_and_the_lane_group_form_agree_with_the_oracle(mhx, oracle, real, knobs, monkeypatch):
+    """The tuning knobs of the scalar-factor form (waves per block = reduction shape 4 / 16, walkers per block, SGPR operands instead
+    of the DPP broadcast, the record straight from the move mapping) and MHX_EMCEE_SCALAR=0 (the lane-group form with its LDS image):
+    every one of them is the oracle's chain for the reduction shape it reports."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    d, W = 50, 131
+    Sig = _rotated(d)
+    init = cases.emcee_init(d, W, 7)
+    chain = mhx.sample(mhx.DensityModel(mhx.CorrGaussian(Sig)), mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I))), 6,
+                       seed=5, initial_params=init)
+    L = chain.stats["reduce_lanes"]
+    assert chain.stats["kernel_variant"] == (4 if knobs.get("MHX_EMCEE_SCALAR") == "0" else 9)
+    if "MHX_EMCEE_SCALAR" in knobs and knobs["MHX_EMCEE_SCALAR"] != "0":
+        assert L == int(knobs["MHX_EMCEE_SCALAR"])
+    ref = oracle.emcee(oracle.corr_gauss_from_cov(Sig, reduce_lanes=L), 2.0, 1, oracle.schedule(6), 5, 0, W, init)
+    _same(chain.value, ref["samples"], "samples %r" % knobs)
+    _same(chain.accepted, ref["accepted"], "accepted")
+
+
+def test_a_large_dense_factor_falls_back_to_the_lane_group_form(mhx, oracle, real):
+    """past the register budget of the scalar-factor form (the candidate of a walker in the VGPRs of one lane) the lane-group form
+    with its LDS image takes over: same answer, reduction shape as reported"""
+    d, W = 120 if real == "f64" else 230, 64
+    Sig = _rotated(d, 0.5)
+    init = cases.emcee_init(d, W, 2)
+    chain = mhx.sample(mhx.DensityModel(mhx.CorrGaussian(Sig)), mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I))), 3,
+                       seed=2, initial_params=init)
+    assert chain.stats["kernel_variant"] == 4
+    ref = oracle.emcee(oracle.corr_gauss_from_cov(Sig, reduce_lanes=chain.stats["reduce_lanes"]), 2.0, 1, oracle.schedule(3), 2, 0, W, init)
+    _same(chain.value, ref["samples"], "samples")

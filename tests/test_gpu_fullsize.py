@@ -60,6 +60,22 @@ def test_c3_full_size_emcee(mhx, oracle, real):
     assert chain.stats["accepted"] == int(ref["accept_counts"].sum())
 
 
+def test_c3_rotated_full_size_emcee(mhx, oracle, real):
+    """SURVEY 8(d) C3 "also a dense-rotated variant": Sigma = Q (0.9^|i-j|) Q^T, no structural zeros in the factor -- the whole
+    16 384-walker ensemble on the scalar-factor form (variant 9, reduction shape 8) against the oracle."""
+    d, W, N = 50, 16384, 4
+    Q, _ = np.linalg.qr(np.random.default_rng(50).normal(size=(d, d)))
+    Sig = Q @ cases.sigma_ar1(d, 0.9) @ Q.T
+    init = cases.emcee_init(d, W, 11)
+    chain = mhx.sample(mhx.DensityModel(mhx.CorrGaussian(Sig)), mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I))),
+                       N, seed=3, initial_params=init)
+    assert chain.stats["kernel_variant"] == 9 and chain.stats["reduce_lanes"] == 8 and chain.stats["factor_band"] == -1
+    ref = oracle.emcee(oracle.corr_gauss_from_cov(Sig, reduce_lanes=8), 2.0, 1, oracle.schedule(N), 3, 0, W, init)
+    _same(chain.value, ref["samples"], "samples")
+    _same(chain.accepted, ref["accepted"], "accepted")
+    assert chain.stats["accepted"] == int(ref["accept_counts"].sum())
+
+
 def test_c4_full_size_ram(mhx, oracle, real):
     """configs[3]: RobustAdaptiveMetropolis, 200-dim Gaussian with kappa = 1e3, 32 768 chains (5.3 GB of factors)."""
     d, C, N = 200, 32768, 6
