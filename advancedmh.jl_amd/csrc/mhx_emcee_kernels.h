@@ -419,7 +419,10 @@ MHX_DEV mhx_real mhx_band_rows_sq(const mhx_real (&ab)[mhx_emcee_geom<D, L>::NK]
 #else
 #define MHX_REC_ST(p, v) (*(p) = (v))
 #endif
-// BW < 0: dense factor (image in LDS, one block barrier); BW >= 0: a factor of bandwidth BW (no image, no barrier)
+#ifndef MHX_EMCEE_COOP_REC
+#define MHX_EMCEE_COOP_REC 0                 // how the record leaves the lane-group form: 0 straight from the lanes (4-walker runs), 1 through the block's LDS (a block barrier: measured slower here, 5.96 against 5.27 us on C3 -- the waves of this form do not otherwise wait for each other; it pays in the scalar-factor form, which has its barriers anyway)
+#endif
+// BW < 0: dense factor (image in LDS, one block barrier); BW >= 0: a factor of bandwidth BW (no image, no barrier before the record)
 template <int D, int L, int BW = -1>
 MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const mhx_real* __restrict__ A, mhx_real* ysh_all, mhx_e4* Ash4)
 {
@@ -453,6 +456,15 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const mhx_real* __rest
     const long ld = W;
 
     MHX_PROBE(1, (mhx_real)i);                                               // launch + arguments
+    // the walker's own row does not wait for the draw (the partner's does): its loads go out first
+    constexpr int NQ = GEO::NQ, NQL = GEO::NQL;
+    mhx_e4 xs[NQL], ysl[NQL];
+    mhx_e4* xrow_i = (mhx_e4*)(a.xw + (long)i * GEO::XP);
+    {
+        const mhx_e4 zero4 = {MHX_R(0.0), MHX_R(0.0), MHX_R(0.0), MHX_R(0.0)};
+#pragma unroll
+        for (int m = 0; m < NQL; ++m) { const int q4 = l + L * m; xs[m] = q4 < NQ ? xrow_i[q4] : zero4; }
+    }
     const mhx_real lpi = a.lp[i];                                            // in flight with the rows
     const mhx_u32 acc_i = a.acc_count[i];
     // deferred record (a.rec_other_slot): this group's walker of the half at rest -- loads issued here, stores after the move
@@ -477,21 +489,16 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const mhx_real* __rest
 
     // the move, element-wise on float4 slices of the two rows (lane l: float4 l, l+L, ...); the zero pad of
     // the rows gives the zero pad of y that multiplies the zeros of the factor image
-    constexpr int NQ = GEO::NQ, NQL = GEO::NQL;
-    mhx_e4 xs[NQL], ysl[NQL];
     mhx_real* yrow = ysh + cw * DP4;
-    mhx_e4* xrow_i = (mhx_e4*)(a.xw + (long)i * GEO::XP);
     const mhx_e4* xrow_j = (const mhx_e4*)(a.xw + (long)j * GEO::XP);
 #pragma unroll
     for (int m = 0; m < NQL; ++m) {
         const int q4 = l + L * m;
         const mhx_e4 zero4 = {MHX_R(0.0), MHX_R(0.0), MHX_R(0.0), MHX_R(0.0)};
-        xs[m] = zero4;
         ysl[m] = zero4;
         if (q4 < NQ) {
-            const mhx_e4 xi = xrow_i[q4];
+            const mhx_e4 xi = xs[m];
             const mhx_e4 xj = xrow_j[q4];
-            xs[m] = xi;
             ysl[m].x = mhx_fma(z, xi.x - xj.x, xj.x);                    // :85
             ysl[m].y = mhx_fma(z, xi.y - xj.y, xj.y);
             ysl[m].z = mhx_fma(z, xi.z - xj.z, xj.z);
@@ -551,7 +558,7 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const mhx_real* __rest
         }
         if (l == 0) a.last_acc[i] = acc ? 1 : 0;
         if (MHX_EMCEE_PROBE == 6) return;                                    // + accept and the state update, no record
-        if (a.save_slot >= 0) {
+        if (!MHX_EMCEE_COOP_REC && a.save_slot >= 0) {
             // the record is [dim+1][W] (walker fastest): 16-byte runs per dimension from this wave's walkers
             // (staging it through LDS for 64-byte runs measured no faster)
             mhx_real* row = a.samples + a.save_slot * (long)(D + 1) * ld + i;
@@ -570,6 +577,30 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const mhx_real* __rest
             }
         }
     }
+#if MHX_EMCEE_COOP_REC
+    // The record leaves as whole row segments (round 4): the final rows of the block's walkers meet in its LDS -- the candidate
+    // rows are there, a rejected move puts the walker back, lp and the accept flag ride in the row's tail -- and every row k of the
+    // [dim+1][W] record is written for all the block's consecutive walkers at once (32 x sizeof(real) contiguous bytes at C3's shape
+    // instead of 4 walkers per store).  A tuning knob (MHX_EMCEE_COOP_REC=1), off by default: see the macro.
+    if (MHX_EMCEE_PROBE != 6 && a.save_slot >= 0) {                          // (uniform)
+        if (!acc) {
+#pragma unroll
+            for (int m = 0; m < NQL; ++m) { const int q4 = l + L * m; if (q4 < NQ) ((mhx_e4*)yrow)[q4] = xs[m]; }
+        }
+        if (l == 0) { yrow[GEO::XP] = acc ? lpy : lpi; yrow[GEO::XP + 1] = acc ? MHX_R(1.0) : MHX_R(0.0); }
+        __syncthreads();
+        constexpr int WPBC = MHX_EMCEE_COOP_WAVES * CPW;                     // walkers per block; threads / WPBC == L
+        const int wr = threadIdx.x % WPBC, ks = threadIdx.x / WPBC;
+        const int tw = a.t_begin + blockIdx.x * WPBC + wr;
+        if (tw < cnt && tw < a.t_begin + a.t_count) {
+            const mhx_real* fin = ysh_all + wr * DP4;
+            mhx_real* col = a.samples + a.save_slot * (long)(D + 1) * ld + (lo + tw);
+#pragma unroll
+            for (int k = ks; k < D + 1; k += L) MHX_REC_ST(&col[(long)k * ld], fin[k < D ? k : GEO::XP]);
+            if (ks == L - 1) a.accepted[a.save_slot * ld + lo + tw] = fin[GEO::XP + 1] != MHX_R(0.0) ? 1 : 0;
+        }
+    }
+#endif
     // no per-wave atomic here: a half-step is one short launch of ~1000 waves, and 1000 atomics on one
     // address (~12 ns each) would cost more than the move; the host sums acc_count after the run.
 }

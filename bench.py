@@ -641,7 +641,7 @@ def other_configs(mhx, ctx, args, barrier):
             blk = {"value": sig(w.units_per_step() * steps / dt), "ms_per_step": sig(dt * 1e3 / steps), "acc": sig(acc / float(tr), 3),
                    "bound": rf["bound"], "frac": sig(rf["frac"], 4),
                    "traffic_ratio": sig(rf["traffic"] / rf["algorithmic_bytes_per_step"], 4) if rf.get("traffic") else None,
-                   "launch_us": sig(rf["avg_launch_ms"] * 1e3, 4), "kernel": kernel_name(wl, st), "lanes": st["reduce_lanes"]}
+                   "launch_us": sig(rf["avg_launch_ms"] * 1e3, 4), "kernel": kernel_name(w, st), "lanes": st["reduce_lanes"]}
             if rf["bound"] == "valu":
                 blk["hbm_frac"] = rf["hbm_frac"]
             if st.get("factor_band", -1) >= 0:
