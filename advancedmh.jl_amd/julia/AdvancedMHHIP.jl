@@ -152,11 +152,72 @@ proposal_mean(d::Normal) = [mean(d)]
 proposal_mean(ds::AbstractVector{<:Normal}) = [mean(d) for d in ds]
 ptr_or_null(v::Vector) = isempty(v) ? Ptr{Cvoid}(C_NULL) : Ptr{Cvoid}(pointer(v))
 
+# --- the state of a run: what `(sample, state) = step(...)` hands on, for ALL chains at once --------------------------------------
+"""
+    HIPState
+
+The complete state of a finished `sample(...; return_state = true)` call -- every chain's position, cached log-density,
+accept bookkeeping, RAM factors and the RNG step counter, as ONE opaque blob (`mhx_run_save_state`) -- plus the positions in the
+clear.  Hand it back as `initial_state = st` (upstream's keyword) to continue the SAME chains bit for bit: the engine's streams are
+counter-based, so a resumed run is the uninterrupted one (src/mh-core.jl:92-117; src/RobustAdaptiveMetropolis.jl:99-114).
+`AbstractMCMC.getparams(st)` returns the positions (dim x nchains, the `initial_params` shape); `setparams!!(st, params)` returns a
+state whose chains restart from `params` with their log-density re-evaluated (`mhx_run_set_state`), everything else -- factors,
+counters, streams -- kept: src/AdvancedMH.jl:146-157, src/RobustAdaptiveMetropolis.jl:116-121.
+"""
+struct HIPState{T}
+    blob::Vector{UInt8}
+    params::Matrix{T}                       # (dim, nchains)
+    lp::Vector{T}
+    new_params::Union{Nothing,Matrix{T}}    # set by setparams!!: applied after the blob is loaded
+end
+AbstractMCMC.getparams(st::HIPState) = st.new_params === nothing ? st.params : st.new_params
+AbstractMCMC.getparams(::AbstractMCMC.AbstractModel, st::HIPState) = AbstractMCMC.getparams(st)
+AbstractMCMC.setparams!!(st::HIPState{T}, params) where {T} = HIPState{T}(st.blob, st.params, st.lp, Matrix{T}(params))
+AbstractMCMC.setparams!!(::AbstractMCMC.AbstractModel, st::HIPState, params) = AbstractMCMC.setparams!!(st, params)
+
+function save_state(::Type{T}, run::Ptr{Cvoid}, n::Integer, d::Integer) where {T}
+    nb = Ref{Csize_t}(0)
+    check(ccall((:mhx_run_state_size, libmhx), Cint, (Ptr{Cvoid}, Ref{Csize_t}), run, nb))
+    blob = Vector{UInt8}(undef, nb[])
+    GC.@preserve blob check(ccall((:mhx_run_save_state, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), run, blob, nb[]))
+    x = Matrix{T}(undef, n, d); lp = Vector{T}(undef, n)          # host layout x[dim][nchains], chain fastest == Matrix{T}(n, d)
+    GC.@preserve x lp check(ccall((:mhx_run_get_state, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{UInt32}), run, x, lp, C_NULL))
+    return HIPState{T}(blob, permutedims(x), lp, nothing)
+end
+function load_state(run::Ptr{Cvoid}, st::HIPState{T}) where {T}
+    blob = st.blob
+    GC.@preserve blob check(ccall((:mhx_run_load_state, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), run, blob, length(blob)))
+    if st.new_params !== nothing
+        x = Matrix{T}(permutedims(st.new_params))                 # (dim, nchains) -> (nchains, dim)
+        GC.@preserve x check(ccall((:mhx_run_set_state, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), run, x))
+    end
+    return nothing
+end
+
+"""
+    SampleTensor{T} <: AbstractArray{T,3}
+
+The (iterations, params..lp, chains) view of the C-order `[N][dim+1][nchains]` buffer the engine filled -- `PermutedDimsArray` over
+the page-locked block of `mhx_host_alloc`, no copy; released by a finalizer (`mhx_host_free`).
+"""
+mutable struct HostBlock{T}
+    ptr::Ptr{T}
+    raw::Array{T,3}                          # (nchains, dim+1, N) over `ptr`
+end
+function host_tensor(::Type{T}, n::Integer, d1::Integer, N::Integer) where {T}
+    p = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:mhx_host_alloc, libmhx), Cint, (Csize_t, Ref{Ptr{Cvoid}}), n * d1 * N * sizeof(T), p)
+    (rc != 0 || p[] == C_NULL) && return nothing                  # a host that cannot page-lock that much: the caller falls back to an Array
+    blk = HostBlock{T}(Ptr{T}(p[]), unsafe_wrap(Array, Ptr{T}(p[]), (n, d1, N); own = false))
+    finalizer(b -> ccall((:mhx_host_free, libmhx), Cint, (Ptr{Cvoid},), b.ptr), blk)
+    return blk
+end
+
 # --- the one entry point -------------------------------------------------------------------------
 function AbstractMCMC.sample(
     rng::Random.AbstractRNG, model::AdvancedMH.DensityModel{<:DeviceLogDensity}, sampler::AdvancedMH.MHSampler,
     ens::MCMCHIP, N::Integer, nchains::Integer;
-    initial_params = nothing, discard_initial = nothing, thinning = 1, num_warmup = 0,
+    initial_params = nothing, initial_state = nothing, return_state = false, discard_initial = nothing, thinning = 1, num_warmup = 0,
     param_names = missing, chain_type = MCMCChains.Chains, kwargs...,
 )
     T = ens.T
@@ -227,7 +288,10 @@ function AbstractMCMC.sample(
         end
 
         # initial AbstractMCMC.step: host layout x[dim][nchains], chain fastest == Julia Matrix{T}(n, d)
-        if initial_params === nothing
+        if initial_state !== nothing                                       # upstream's `initial_state`: continue the same chains
+            initial_state isa HIPState{T} || throw(ArgumentError("initial_state must be the HIPState{$T} a `return_state = true` call returned"))
+            load_state(run[], initial_state)
+        elseif initial_params === nothing
             check(ccall((:mhx_run_init, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), run[], C_NULL))
         else
             x0 = initial_params isa AbstractVector{<:Real} ? repeat(T.(initial_params)', n, 1) :     # one point for every chain
@@ -238,21 +302,28 @@ function AbstractMCMC.sample(
         # ONE call: the schedule runs while finished slabs of samples stream into `raw` on a second HIP stream
         # (mhx_run_sample_to_host registers the Julia array for the duration of the call; 0 = default slab size).
         # C order [N][d+1][n] with the chain fastest == Julia Array{T,3}(n, d+1, N)
-        raw = Array{T,3}(undef, n, d + 1, N)
-        GC.@preserve raw check(ccall((:mhx_run_sample_to_host, libmhx), Cint, (Ptr{Cvoid}, Ref{Schedule}, Ptr{Cvoid}, Ptr{UInt8}, Int32),
-                                     run[], sched, raw, C_NULL, 0))
+        blk = host_tensor(T, n, d + 1, N)                                  # page-locked: the copies run at the link rate
+        raw = blk === nothing ? Array{T,3}(undef, n, d + 1, N) : blk.raw
+        GC.@preserve raw blk check(ccall((:mhx_run_sample_to_host, libmhx), Cint, (Ptr{Cvoid}, Ref{Schedule}, Ptr{Cvoid}, Ptr{UInt8}, Int32),
+                                         run[], sched, raw, C_NULL, 0))
+        state = return_state ? save_state(T, run[], n, d) : nothing
         if sampler isa AdvancedMH.RobustAdaptiveMetropolis && haskey(kwargs, :sampler_stats)
             # what a callback reads off `state` after every saved step (test/RobustAdaptiveMetropolis.jl:11-28): logα (N x n), η (N)
             logα = Matrix{T}(undef, n, N); η = Vector{Float64}(undef, N)
             GC.@preserve logα η check(ccall((:mhx_ram_get_step_stats, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Int64, Ptr{Int64}), run[], logα, η, size(logα, 2), C_NULL))
             kwargs[:sampler_stats][] = (logα = permutedims(logα), η = η)
         end
-        vals = Float64.(permutedims(raw, (3, 2, 1)))                         # (iterations, params..lp, chains)
+        # (iterations, params..lp, chains): for T == Float64 a VIEW of the buffer the engine filled (no permuted copy, no conversion:
+        # C2's 13 GB tensor stays one allocation); the view keeps the block alive.  Float32 results are widened once.
+        view3 = PermutedDimsArray(raw, (3, 2, 1))
+        vals = T === Float64 ? view3 : Float64.(view3)
         names = ismissing(param_names) ? [Symbol(:param_, i) for i in 1:d] : Symbol.(param_names)
-        chain_type === MCMCChains.Chains || return vals
-        # same call as ext/AdvancedMHMCMCChainsExt.jl:116-120
-        return MCMCChains.Chains(vals, vcat(names, [:lp]), (parameters = names, internals = [:lp]);
-                                 start = discard_initial + 1, thin = thinning)
+        if chain_type === MCMCChains.Chains
+            # same call as ext/AdvancedMHMCMCChainsExt.jl:116-120 (Chains copies into its own AxisArray)
+            vals = MCMCChains.Chains(vals, vcat(names, [:lp]), (parameters = names, internals = [:lp]);
+                                     start = discard_initial + 1, thin = thinning)
+        end
+        return return_state ? (vals, state) : vals
     finally
         run[] != C_NULL && ccall((:mhx_run_destroy, libmhx), Cint, (Ptr{Cvoid},), run[])
         tgt != C_NULL && ccall((:mhx_target_destroy, libmhx), Cint, (Ptr{Cvoid},), tgt)
@@ -285,5 +356,5 @@ allreduce_sum!(comm::Ptr{Cvoid}, v::Vector{Float64}) =
     (GC.@preserve v check(ccall((:mhx_comm_allreduce_sum, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Csize_t), comm, v, length(v))); v)
 comm_destroy(comm::Ptr{Cvoid}) = ccall((:mhx_comm_destroy, libmhx), Cint, (Ptr{Cvoid},), comm)
 
-export MCMCHIP, LangevinProposal, IsoGaussian, CorrGaussian, IIDNormal, Banana, Funnel, HipSource
+export MCMCHIP, HIPState, LangevinProposal, IsoGaussian, CorrGaussian, IIDNormal, Banana, Funnel, HipSource
 end # module

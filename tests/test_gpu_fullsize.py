@@ -250,6 +250,55 @@ def test_ram_adaptation_reaches_its_target_over_many_chains(mhx, real):
     assert ad["iteration"] == 7001 and abs(ad["η"] - 7000.0 ** -0.6) < 1e-6 * ad["η"]
 
 
+def test_c4_known_answers_at_dimension_200(mhx, real):
+    """configs[3] at ITS dimension (the adaptation's known answer ran at d = 8 only).  Two answers at d = 200, kappa = 1e3,
+    from the start that moves (x0 ~ target, S0 = 2.38/sqrt(d) I):
+    (1) an exact invariant of ram_adapt (src/RobustAdaptiveMetropolis.jl:153-173): S S^T <- S (I + eta dalpha u u^T / |u|^2) S^T multiplies
+        det(S S^T) by (1 + eta dalpha), so for EVERY chain  log det S_N - log det S_0 = 1/2 sum_n log(1 + eta_n (exp(logalpha_n) - alpha))
+        over its adapting transitions -- checked per chain from the per-step statistics against the factors the device holds;
+    (2) the pull towards alpha = 0.234: from 0.65 the mean acceptance probability over 32 768 chains falls monotonically (at d = 200 and
+        gamma = 0.6 a rank-1 step moves one direction in two hundred: 0.647 -> 0.634 in 2 000 transitions, O(1e6) to arrive), every factor
+        stays in the positive-definite cone."""
+    import bench
+    d = 200
+    Sig = bench.sigma_illcond(d)
+    Lc = np.linalg.cholesky(Sig)
+    s0 = 2.38 / d ** 0.5
+    model = mhx.DensityModel(mhx.CorrGaussian(Sig))
+    # (1)
+    C, N = 1024, 160
+    run = mhx.Run(model, mhx.RobustAdaptiveMetropolis(S=s0 * np.eye(d)), nchains=C, seed=4)
+    run.init(Lc @ np.random.default_rng(11).normal(size=(d, C)))
+    run.sample(N, 0, 1, N)                                      # every transition adapts, every state recorded
+    st = run.step_stats()
+    S, status = run.factor()
+    run.close()
+    assert (status == 0).all()
+    la = st["logα"].astype(np.float64)[1:]                      # sample n + 1 is behind transition n
+    eta = st["η"][1:]
+    assert np.allclose(eta, np.arange(1, N, dtype=np.float64) ** -0.6, rtol=1e-6 if real == "f32" else 1e-14)
+    want = 0.5 * np.log1p(eta[:, None] * (np.exp(la) - 0.234)).sum(axis=0)          # [C]
+    diag_idx = np.cumsum(np.arange(1, d + 1)) - 1               # packed lower, row-major: the diagonal entries
+    got = np.log(S.astype(np.float64)[:, diag_idx]).sum(axis=1) - d * np.log(float(run.real(s0)))
+    assert np.abs(got - want).max() < (2e-3 if real == "f32" else 1e-9), np.abs(got - want).max()
+    assert (want > 0).all()                                     # acceptance above alpha: every factor grew
+    # (2)
+    C = 32768
+    run = mhx.Run(model, mhx.RobustAdaptiveMetropolis(S=s0 * np.eye(d)), nchains=C, seed=4)
+    run.init(Lc @ np.random.default_rng(11).normal(size=(d, C)))
+    marks = []
+    for n in (200, 800, 1000):
+        run.sample(1, n, 1, n, save=False)
+        marks.append(float(np.exp(run.adapt_state()["logα"].astype(np.float64)).mean()))
+    S, status = run.factor()
+    ad = run.adapt_state()
+    run.close()
+    assert (status == 0).all() and np.isfinite(S).all()
+    # standard error of a mean over 32 768 chains ~ 0.002: the steps are 0.008 and 0.005
+    assert 0.66 > marks[0] > marks[1] + 0.004 and marks[1] > marks[2] + 0.002 and marks[2] > 0.60, marks
+    assert ad["iteration"] == 2001
+
+
 def test_c3_ensemble_known_answer_at_scale(mhx, real):
     """configs[2] as a known answer: 16 384 walkers, 50-dim Gaussian with Sigma_ij = 0.9^|i-j|, initial walkers drawn on the
     device from N(0, I); after 20 000 sweeps of burn-in (the stretch move mixes slowly in 50 dimensions) the walkers of 20 sweeps 200 apart reproduce mean 0, unit variances and
