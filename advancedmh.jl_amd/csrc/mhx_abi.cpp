@@ -163,6 +163,21 @@ extern "C" int mhx_ram_get_diag_range(mhx_run* r, void* diag_min, void* diag_max
     NEED(r, "mhx_ram_get_diag_range");
     return is64(r) ? mhx_f64::api_ram_get_diag_range(R64(r), D(diag_min), D(diag_max)) : mhx_f32::api_ram_get_diag_range(R32(r), F(diag_min), F(diag_max));
 }
+extern "C" int mhx_ram_watch_factors(mhx_run* r, const int32_t* chains, int32_t n)
+{
+    NEED(r, "mhx_ram_watch_factors");
+    return is64(r) ? mhx_f64::api_ram_watch_factors(R64(r), chains, n) : mhx_f32::api_ram_watch_factors(R32(r), chains, n);
+}
+extern "C" int mhx_ram_get_watched_factors(mhx_run* r, void* S, int64_t capacity, int64_t* n_recorded, int32_t* n_watched)
+{
+    NEED(r, "mhx_ram_get_watched_factors");
+    long nrec = 0; int nw = 0;
+    const int rc = is64(r) ? mhx_f64::api_ram_get_watched_factors(R64(r), D(S), (long)capacity, &nrec, &nw)
+                           : mhx_f32::api_ram_get_watched_factors(R32(r), F(S), (long)capacity, &nrec, &nw);
+    if (n_recorded) *n_recorded = nrec;
+    if (n_watched) *n_watched = nw;
+    return rc;
+}
 extern "C" int mhx_ram_get_step_stats(mhx_run* r, void* log_alpha, double* eta, int64_t capacity, int64_t* n_recorded)
 {
     NEED(r, "mhx_ram_get_step_stats");

@@ -602,6 +602,12 @@ struct mhx_run : mhx_handle_hdr {
     mhx_real* d_rec_loga = nullptr;                 // [n_saved][n] logα of every recorded transition of the last sampling call
     mhx_real* rec_loga_view = nullptr;              // where slot 0 of the current launches lands in it (slab-wise calls)
     size_t rec_loga_cap = 0;
+    // RAM: the factors of a few watched chains after every recorded step (mhx_ram_watch_factors)
+    int32_t* d_watch_chains = nullptr;
+    mhx_real* d_watch = nullptr;                    // [n recorded][watch_n][dim (dim + 1) / 2], packed row-major
+    size_t watch_cap = 0;
+    int watch_n = 0;
+    long watch_count = 0;
     std::vector<double> rec_eta;                    // [n_saved] state.η after every recorded transition
     int64_t rec_n = 0;                              // recorded transitions held by the two above
     size_t eta_cap = 0;
@@ -642,7 +648,8 @@ struct mhx_run : mhx_handle_hdr {
     ~mhx_run()
     {
         void* ptrs[] = {d_pvec, d_S, d_Ssel, d_status, d_dmin, d_dmax, d_eta, d_x, d_lp, d_ybuf,
-                        d_acc, d_last, d_acc_total, d_samples, d_accepted, d_mom_mean, d_mom_m2, d_gx, d_gy, d_z, d_pmean, d_qx, d_xw, d_loga, d_mfma_img, d_rec_loga};
+                        d_acc, d_last, d_acc_total, d_samples, d_accepted, d_mom_mean, d_mom_m2, d_gx, d_gy, d_z, d_pmean, d_qx, d_xw, d_loga, d_mfma_img, d_rec_loga,
+                        d_watch_chains, d_watch};
         for (void* p : ptrs) if (p) (void)hipFree(p);
     }
 };

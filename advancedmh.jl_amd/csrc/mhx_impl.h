@@ -41,6 +41,8 @@ struct mhx_handle_hdr { int32_t dtype; };
     int api_ram_get_diag_range(mhx_run* r, REAL* diag_min, REAL* diag_max);                                            \
     int api_ram_get_adapt_state(mhx_run* r, REAL* log_alpha, double* eta, uint8_t* isaccept, uint64_t* iteration);     \
     int api_ram_get_step_stats(mhx_run* r, REAL* log_alpha, double* eta, long capacity, long* n_recorded);             \
+    int api_ram_watch_factors(mhx_run* r, const int32_t* chains, int n);                                               \
+    int api_ram_get_watched_factors(mhx_run* r, REAL* S, long capacity, long* n_recorded, int* n_watched);             \
     int api_run_init(mhx_run* r, const REAL* initial_params);                                                          \
     int api_run_sample(mhx_run* r, const mhx_schedule* s, int save_samples);                                           \
     int api_run_get_samples(mhx_run* r, REAL* samples, uint8_t* accepted);                                             \

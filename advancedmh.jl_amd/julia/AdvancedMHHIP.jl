@@ -1,4 +1,4 @@
-# AdvancedMHHIP.jl -- thin `ccall` layer over libmhx.so (include/mhx.h, ABI 0.3) that plugs the MI355X engine
+# AdvancedMHHIP.jl -- thin `ccall` layer over libmhx.so (include/mhx.h, ABI 0.4) that plugs the MI355X engine
 # into AdvancedMH.jl through AbstractMCMC's ensemble dispatch:
 #
 #     chain = sample(model, RWMH(MvNormal(zeros(100), 0.0566I)), MCMCHIP(), 1_000, 65_536;
@@ -298,6 +298,10 @@ function AbstractMCMC.sample(
                                                              Matrix{T}(permutedims(initial_params))   # (dim, nchains) -> (nchains, dim)
             GC.@preserve x0 check(ccall((:mhx_run_init, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), run[], x0))
         end
+        watch = sampler isa AdvancedMH.RobustAdaptiveMetropolis && haskey(kwargs, :watch_chains) ? Int32.(collect(kwargs[:watch_chains]) .- 1) : Int32[]
+        if !isempty(watch)                                                   # state.S of these chains after every saved step
+            GC.@preserve watch check(ccall((:mhx_ram_watch_factors, libmhx), Cint, (Ptr{Cvoid}, Ptr{Int32}, Int32), run[], watch, length(watch)))
+        end
         sched = Schedule(N, discard_initial, thinning, num_warmup)
         # ONE call: the schedule runs while finished slabs of samples stream into `raw` on a second HIP stream
         # (mhx_run_sample_to_host registers the Julia array for the duration of the call; 0 = default slab size).
@@ -311,7 +315,16 @@ function AbstractMCMC.sample(
             # what a callback reads off `state` after every saved step (test/RobustAdaptiveMetropolis.jl:11-28): logα (N x n), η (N)
             logα = Matrix{T}(undef, n, N); η = Vector{Float64}(undef, N)
             GC.@preserve logα η check(ccall((:mhx_ram_get_step_stats, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Int64, Ptr{Int64}), run[], logα, η, size(logα, 2), C_NULL))
-            kwargs[:sampler_stats][] = (logα = permutedims(logα), η = η)
+            Ss = nothing
+            if !isempty(watch)                                               # (tri, watched, N): packed lower factors, row-major
+                tri = d * (d + 1) ÷ 2
+                Sp = Array{T,3}(undef, tri, length(watch), N)
+                GC.@preserve Sp check(ccall((:mhx_ram_get_watched_factors, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int32}),
+                                            run[], Sp, N, C_NULL, C_NULL))
+                unpack(p) = LowerTriangular([i >= j ? p[i * (i - 1) ÷ 2 + j] : zero(T) for i in 1:d, j in 1:d])
+                Ss = [unpack(view(Sp, :, w, i)) for i in 1:N, w in 1:length(watch)]   # Ss[i, w] == state.S of chain watch[w] after saved step i
+            end
+            kwargs[:sampler_stats][] = (logα = permutedims(logα), η = η, S = Ss)
         end
         # (iterations, params..lp, chains): for T == Float64 a VIEW of the buffer the engine filled (no permuted copy, no conversion:
         # C2's 13 GB tensor stays one allocation); the view keeps the block alive.  Float32 results are widened once.

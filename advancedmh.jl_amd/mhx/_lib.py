@@ -85,7 +85,7 @@ EXPORTS = [
     "mhx_ctx_dtype", "mhx_ctx_device", "mhx_ram_set_factor_all", "mhx_ram_get_adapt_state", "mhx_emcee_exchange_plan", "mhx_emcee_exchange_pack",
     "mhx_emcee_exchange_unpack", "mhx_comm_unique_id", "mhx_comm_init", "mhx_comm_destroy", "mhx_comm_rank",
     "mhx_comm_allreduce_sum", "mhx_comm_slice", "mhx_comm_allgather_walkers",
-    "mhx_ram_get_step_stats", "mhx_run_sample_to_host", "mhx_host_alloc", "mhx_host_free", "mhx_ctx_jit_counts", "mhx_ctx_host_pin_counts",
+    "mhx_ram_get_step_stats", "mhx_ram_watch_factors", "mhx_ram_get_watched_factors", "mhx_run_sample_to_host", "mhx_host_alloc", "mhx_host_free", "mhx_ctx_jit_counts", "mhx_ctx_host_pin_counts",
 ]
 
 MHX_F32, MHX_F64 = 0, 1
@@ -139,6 +139,8 @@ def lib():
         L.mhx_ram_get_diag_range.argtypes = [vp, rp, rp]
         L.mhx_ram_get_adapt_state.argtypes = [vp, rp, dp, u8p, C.POINTER(C.c_uint64)]
         L.mhx_ram_get_step_stats.argtypes = [vp, rp, dp, C.c_int64, C.POINTER(C.c_int64)]
+        L.mhx_ram_watch_factors.argtypes = [vp, C.POINTER(C.c_int32), C.c_int32]
+        L.mhx_ram_get_watched_factors.argtypes = [vp, rp, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
         L.mhx_run_init.argtypes = [vp, rp]
         L.mhx_run_sample.argtypes = [vp, C.POINTER(Schedule), C.c_int]
         L.mhx_run_get_samples.argtypes = [vp, rp, u8p]

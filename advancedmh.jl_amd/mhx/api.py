@@ -675,6 +675,26 @@ class Run:
         L.check(L.lib().mhx_ram_get_adapt_state(self.h, L.rptr(la), C.byref(eta), L.u8ptr(acc), C.byref(it)))
         return dict(logα=la, η=eta.value, iteration=int(it.value), isaccept=acc.astype(bool))
 
+    def watch_factors(self, chains):
+        """RobustAdaptiveMetropolis: keep `state.S` of these chains after EVERY recorded step of the following sampling calls -- what a
+        reference callback that stores state.S records (test/RobustAdaptiveMetropolis.jl:11-28).  [] switches it off."""
+        ch = np.ascontiguousarray(chains, dtype=np.int32)
+        L.check(L.lib().mhx_ram_watch_factors(self.h, ch.ctypes.data_as(C.POINTER(C.c_int32)), ch.size))
+
+    def watched_factors(self, full=True):
+        """[n recorded][n watched] lower-triangular factors of the last sampling call (full=False: packed row-major)"""
+        nrec, nw = C.c_int64(), C.c_int32()
+        L.check(L.lib().mhx_ram_get_watched_factors(self.h, None, 0, C.byref(nrec), C.byref(nw)))
+        tri = self.dim * (self.dim + 1) // 2
+        S = np.empty((nrec.value, nw.value, tri), dtype=self.real)
+        L.check(L.lib().mhx_ram_get_watched_factors(self.h, L.rptr(S), nrec.value, None, None))
+        if not full:
+            return S
+        out = np.zeros((nrec.value, nw.value, self.dim, self.dim), dtype=self.real)
+        il = np.tril_indices(self.dim)
+        out[:, :, il[0], il[1]] = S
+        return out
+
     def step_stats(self, n_samples=None):
         """RobustAdaptiveMetropolis: the sampler state after EVERY recorded step of the last sampling call -- what the
         reference's callback reads off `state` (test/RobustAdaptiveMetropolis.jl:11-28): dict(logα [N][nchains], η [N]);

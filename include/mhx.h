@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MHX_VERSION 300 /* 0.3.0: overlapped host return path, page-locked host buffers, persistent JIT cache */
+#define MHX_VERSION 400 /* 0.4.0: mhx_ram_get_step_stats takes a capacity, watched factors, host pin accounting, kernel variant 9 (0.3.0: overlapped host return path, page-locked host buffers, persistent JIT cache) */
 
 typedef enum {
     MHX_OK = 0,
@@ -211,6 +211,15 @@ int mhx_ram_get_adapt_state(mhx_run *run, void *log_alpha, double *eta, uint8_t 
  * `capacity` = the number of samples the two buffers hold: fewer than the last call recorded is MHX_EINVAL (nothing is written);
  * n_recorded (may be NULL) receives that count -- with both buffers NULL the call is just this query. */
 int mhx_ram_get_step_stats(mhx_run *run, void *log_alpha, double *eta, int64_t capacity, int64_t *n_recorded);
+
+/* state.S of a few WATCHED chains after EVERY recorded step -- what a reference callback that stores `state.S` keeps
+ * (test/RobustAdaptiveMetropolis.jl:11-28; :57-69 checks the eigenvalue bounds on that record).  mhx_ram_watch_factors(run, chains, n)
+ * names the chains (indices into this run, n = 0 switches it off); every later mhx_run_sample / mhx_run_sample_to_host that keeps
+ * samples also keeps S [n_samples][n][dim (dim + 1) / 2] (packed lower, row-major, like mhx_ram_get_factor); a watched run ends a
+ * launch at every recorded transition, others are unaffected.  mhx_ram_get_watched_factors copies the record out: `capacity` = the
+ * number of samples S holds (fewer than recorded: MHX_EINVAL); n_recorded / n_watched may be NULL; S == NULL just queries them. */
+int mhx_ram_watch_factors(mhx_run *run, const int32_t *chains, int32_t n);
+int mhx_ram_get_watched_factors(mhx_run *run, void *S, int64_t capacity, int64_t *n_recorded, int32_t *n_watched);
 
 /* ---------------------------------------------------------------------------------------------
  * Metropolis-adjusted Langevin.  Replaces MALA (src/MALA.jl:1-11), GradientTransition (:14-19) and its step
