@@ -367,8 +367,19 @@ MHX_DEV void mhx_rwmh_whiten_body(const mhx_rwmh_args& a, const mhx_real* __rest
 //   [0, 8208)                       the layer table x[0..N]
 //   then per wave  NBL*4*64 doubles the step's normals, [pair of slots][lane][2] (a lane writes / reads 16 bytes, conflict-free)
 //                  64 u16           the queue of the candidates that left their rectangles: owner lane | slot << 6
+//                  KS x 64 u64      the lanes' masks of failed slots, one per step of the group
+// KS (round 4): the normals of KS consecutive steps are generated back to back and their failed candidates finished in ONE pass --
+// the fix-up pass costs a wave what it costs whether it repairs 4 candidates or 40 (the queue, two wave syncs, one walk through the
+// rejection code), and at d = 1000 (a wave per chain, 16 slots per lane: 4 failures per wave-step) it was a third of the kernel.
+// KS is the largest group (<= 4) whose slabs leave the LDS for as many blocks per CU as the launch bound asks for.
 #define MHX_ZIG_TABLE_BYTES (((MHX_ZIG_N + 1) * 8 + 15) / 16 * 16)
-#define MHX_ZIG_WAVE_BYTES(NBL) ((NBL) * 4 * 64 * 8 + 128)
+#define MHX_ZIG_SLAB_BYTES(NBL) ((NBL) * 4 * 64 * 8)
+#ifndef MHX_ZIG_KS_FORCE
+#define MHX_ZIG_KS_FORCE 0
+#endif
+#define MHX_ZIG_KS_FIT(NBL) ((163840 / MHX_COOP_WAVES(NBL) - MHX_ZIG_TABLE_BYTES - 512) / (4 * (MHX_ZIG_SLAB_BYTES(NBL) + 512 + 32)))
+#define MHX_ZIG_KS(NBL) (MHX_ZIG_KS_FORCE > 0 ? MHX_ZIG_KS_FORCE : (MHX_ZIG_KS_FIT(NBL) < 1 ? 1 : (MHX_ZIG_KS_FIT(NBL) > 4 ? 4 : MHX_ZIG_KS_FIT(NBL))))
+#define MHX_ZIG_WAVE_BYTES(NBL) (MHX_ZIG_KS(NBL) * (MHX_ZIG_SLAB_BYTES(NBL) + 512) + 128)
 #define MHX_ZIG_LDS_BYTES(NBL) (MHX_ZIG_TABLE_BYTES + 4 * MHX_ZIG_WAVE_BYTES(NBL))
 static_assert(MHX_ZIG_TABLE_BYTES == MHX_ZIG_TABLE_BYTES_ANY, "ziggurat table size");
 
@@ -377,10 +388,12 @@ static_assert(MHX_ZIG_TABLE_BYTES == MHX_ZIG_TABLE_BYTES_ANY, "ziggurat table si
 // one per failing block.  fm: the lane's failed slots (bit s = slot 4 i + j).  A fixer lane re-derives the failed candidate from
 // its Philox block (nothing but the slot number was kept), runs the rejection loop of mhx_zig_slow and drops the normal into the
 // owner's place in `zn`.
+// (a group of `ng` steps: zfm[s][lane] = the lane's failed slots of step step0 + s, whose normals live in zn + s * slabd)
 template <int L>
 MHX_DEV void mhx_zig_fixup(const mhx_philox_key& ks, const double* __restrict__ zt, double* __restrict__ zn,
-                           unsigned short* __restrict__ zq, const mhx_u64 fm, const int lane, const long wave,
-                           const mhx_u64 first_chain, const int nchains, const mhx_u32 step, const mhx_u32 stream)
+                           unsigned short* __restrict__ zq, const mhx_u64* __restrict__ zfm, const int ng, const int slabd,
+                           const int lane, const long wave,
+                           const mhx_u64 first_chain, const int nchains, const mhx_u32 step0, const mhx_u32 stream)
 {
     constexpr int CPW = 64 / L;
     // Queue positions without a prefix sum over the lanes: round k takes the k-th failure of every lane that has one; the
@@ -389,34 +402,38 @@ MHX_DEV void mhx_zig_fixup(const mhx_philox_key& ks, const double* __restrict__ 
     // unless more than 64 candidates of the wave-step failed, in which case further windows of 64 follow.
     int total = 0;
     for (int win = 0; win == 0 || win < total; win += 64) {
-        mhx_u64 f = fm;
         int base = -win;
-        for (;;) {
-            const mhx_u64 m = __ballot(f != 0ull);
-            if (m == 0ull) break;
-            if (f != 0ull) {
-                const int e = base + (int)__builtin_amdgcn_mbcnt_hi((mhx_u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((mhx_u32)m, 0u));
-                const int sl = __ffsll((long long)f) - 1;
-                if (e >= 0 && e < 64) zq[e] = (unsigned short)(lane | (sl << 6));
+        for (int s = 0; s < ng; ++s) {
+            mhx_u64 f = zfm[s * 64 + lane];
+            for (;;) {
+                const mhx_u64 m = __ballot(f != 0ull);
+                if (m == 0ull) break;
+                if (f != 0ull) {
+                    const int e = base + (int)__builtin_amdgcn_mbcnt_hi((mhx_u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((mhx_u32)m, 0u));
+                    const int sl = __ffsll((long long)f) - 1;
+                    if (e >= 0 && e < 64) zq[e] = (unsigned short)(lane | (sl << 6) | (s << 12));
+                }
+                f &= f - 1ull;
+                base += __popcll(m);
             }
-            f &= f - 1ull;
-            base += __popcll(m);
         }
         total = base + win;
         MHX_WAVE_SYNC();
         const int nent = total - win < 64 ? total - win : 64;
         if (lane < nent) {
             const int ent = zq[lane];
-            const int ol = ent & 63, sl = ent >> 6;
+            const int ol = ent & 63, sl = (ent >> 6) & 63, sg = ent >> 12;
+            const mhx_u32 step = step0 + (mhx_u32)sg;
+            double* const zns = zn + sg * slabd;
             const long oc_raw = wave * CPW + (ol & (CPW - 1));
             const mhx_u64 oid = first_chain + (mhx_u64)(oc_raw < nchains ? oc_raw : (long)nchains - 1);
             const mhx_u32 b = (mhx_u32)(ol / CPW + L * (sl >> 2));
             const mhx_u32 n = 4u * b + (mhx_u32)(sl & 3);
             // nothing but the slot number was kept: the failed candidate is re-derived from its Philox block
 #if defined(MHX_ZIG_PROBE) && MHX_ZIG_PROBE == 2
-            zn[(((sl >> 1) * 64 + ol) << 1) + (sl & 1)] = (double)n * 1e-3 + (double)(mhx_u32)oid * 1e-9;      // timing probe: queue and syncs, no refinement
+            zns[(((sl >> 1) * 64 + ol) << 1) + (sl & 1)] = (double)n * 1e-3 + (double)(mhx_u32)oid * 1e-9;      // timing probe: queue and syncs, no refinement
 #else
-            zn[(((sl >> 1) * 64 + ol) << 1) + (sl & 1)] = mhx_zig_refine(ks, zt, (mhx_u32)oid, (mhx_u32)(oid >> 32), step, stream, n);
+            zns[(((sl >> 1) * 64 + ol) << 1) + (sl & 1)] = mhx_zig_refine(ks, zt, (mhx_u32)oid, (mhx_u32)(oid >> 32), step, stream, n);
 #endif
         }
         MHX_WAVE_SYNC();
@@ -437,9 +454,17 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
     static_assert(!ZIG || MHX_REAL64, "the ziggurat generator exists in the fp64 engine only");
     extern __shared__ double mhx_coop_lds[];
 #if MHX_REAL64
+    typedef double mhx_d2 __attribute__((ext_vector_type(2)));
+    constexpr int KS = ZIG ? MHX_ZIG_KS(NBL) : 1;                   // steps per fix-up group
+#else
+    constexpr int KS = 1;
+#endif
+#if MHX_REAL64
     const double* zt = mhx_coop_lds;
-    double* zn = mhx_coop_lds + MHX_ZIG_TABLE_BYTES / 8 + (threadIdx.x >> 6) * (MHX_ZIG_WAVE_BYTES(NBL) / 8);
-    unsigned short* zq = (unsigned short*)(zn + NBL * 4 * 64);
+    constexpr int SLABD = NBL * 4 * 64;                            // doubles of one step's normals
+    double* zn0 = mhx_coop_lds + MHX_ZIG_TABLE_BYTES / 8 + (threadIdx.x >> 6) * (MHX_ZIG_WAVE_BYTES(NBL) / 8);
+    unsigned short* zq = (unsigned short*)(zn0 + KS * SLABD);
+    mhx_u64* zfm = (mhx_u64*)(zn0 + KS * SLABD + 16);
     if (ZIG) {
         for (int e = threadIdx.x; e <= MHX_ZIG_N; e += blockDim.x) mhx_coop_lds[e] = mhx_zig_x[e];
         __syncthreads();
@@ -581,21 +606,24 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
         if (mom_n) { lpm = a.mom_mean[(long)d * ld + c]; lpm2 = a.mom_m2[(long)d * ld + c]; }
     }
 
-    for (int it = 0; it < a.nsteps; ++it) {
-        const mhx_u32 step = a.step0 + (mhx_u32)it;
-        // Branch-free over the lane's blocks: a last block past the end of the vector (and the padding
-        // dimensions of the final block) computes on zeros -- y = 0 there, and fma(0, 0, q) == q bit for
-        // bit, so the partial sums need no predication.
-        mhx_real q = MHX_R(0.0), fwd = MHX_R(0.0), bwd = MHX_R(0.0), y00 = MHX_R(0.0);
+    // (a saved step of the one- / two-chains-per-wave shapes stages its record in the slab memory: no groups then)
+    const int ks_eff = (ZIG && !(tr_io && a.samples != nullptr && a.save_next != MHX_NO_SAVE)) ? KS : 1;
+    for (int it0 = 0; it0 < a.nsteps; it0 += ks_eff) {
+    const int ng = a.nsteps - it0 < ks_eff ? a.nsteps - it0 : ks_eff;
 #if MHX_REAL64
-        if (ZIG) {
+    if (ZIG) {
+        bool anyfail = false;
+#pragma unroll 1
+        for (int sg = 0; sg < ng; ++sg) {
+            const mhx_u32 step = a.step0 + (mhx_u32)(it0 + sg);
+            double* const zn = zn0 + sg * SLABD;
+            {
             // phase A: every slot's candidate by the fast path -- table look-up, multiply, compare -- into LDS; the slots that
             // left their rectangles are noted in `fm` and finished by mhx_zig_fixup before the candidate state is formed
             mhx_u64 fm = 0ull;
             // Software pipeline over the lane's blocks: the table look-ups of block i are in flight while the Philox rounds of
             // block i + 1 run (one wave per SIMD has no other wave to hide an LDS round trip behind): per block -- issue the 4
             // look-ups (layers known since the previous stage), Philox of the next block, then consume.
-            typedef double mhx_d2 __attribute__((ext_vector_type(2)));
             // MHX_ZIG_GB blocks per pipeline stage = 2 MHX_ZIG_GB independent Philox chains in flight.  Measured at C2: two blocks
             // per stage (four chains) 4.61e9 steps/s against 4.86e9 with one -- the rounds are not waiting on each other, the
             // extra live words cost more than the extra chains buy (C5: 4.88e8 against 5.36e8).
@@ -664,11 +692,28 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
                     for (int e = 0; e < 4 * GB; ++e) { khi[e] = nhi[e]; klo[e] = nlo[e]; }
                 }
             }
+            zfm[sg * 64 + lane] = fm;
+            anyfail = anyfail || fm != 0ull;
+            }
+        }
 #ifndef MHX_ZIG_PROBE
 #define MHX_ZIG_PROBE 0        // timing probe (tools only, hiprtc define via MHX_ZIG_PROBE in the environment): 1 = skip the fix-up (WRONG normals)
 #endif
-            if (MHX_ZIG_PROBE != 1 && __ballot(fm != 0ull))
-                mhx_zig_fixup<L>(ks, zt, zn, zq, fm, lane, wave, a.first_chain, a.nchains, step, MHX_STREAM_PROPOSAL);
+        if (MHX_ZIG_PROBE != 1 && __ballot(anyfail))
+            mhx_zig_fixup<L>(ks, zt, zn0, zq, zfm, ng, SLABD, lane, wave, a.first_chain, a.nchains, a.step0 + (mhx_u32)it0, MHX_STREAM_PROPOSAL);
+    }
+#endif
+#pragma unroll 1
+    for (int sg = 0; sg < ng; ++sg) {
+        const int it = it0 + sg;
+        const mhx_u32 step = a.step0 + (mhx_u32)it;
+        // Branch-free over the lane's blocks: a last block past the end of the vector (and the padding
+        // dimensions of the final block) computes on zeros -- y = 0 there, and fma(0, 0, q) == q bit for
+        // bit, so the partial sums need no predication.
+        mhx_real q = MHX_R(0.0), fwd = MHX_R(0.0), bwd = MHX_R(0.0), y00 = MHX_R(0.0);
+#if MHX_REAL64
+        if (ZIG) {
+            const double* const zn = zn0 + sg * SLABD;
             // the step's normals, final: all of them on their way to the registers the candidate will occupy (one wait)
 #pragma unroll
             for (int i = 0; i < NBL; ++i) {
@@ -815,6 +860,7 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
             save_next += (mhx_u32)a.thinning;
             ++slot;
         }
+    }
     }
     const bool tr_out = tr_io;
     if (tr_out) {
