@@ -53,7 +53,9 @@ def main(tags):
                               "known byte counts of the C2 and C4 kernels)",
                 "source": "profiles/%s_summary.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_*, separate passes)" % name,
             }
-            traffic["%s_%s" % (cfg, dt)] = entry
+            # variants of a config profiled under their own tag: r04rot_c3_f64 -> c3_rotated_f64, r04ban_c5_f64 -> c5_banana_f64, ...
+            variant = {"rot": "_rotated", "ban": "_banana", "mov": "_moving", "fix": "_fixed", "lit": "_literal"}.get(tag[-3:], "")
+            traffic["%s%s_%s" % (cfg, variant, dt)] = entry
             print(name, "-> traffic[%s_%s]: hbm %.4g B, valu %.4g per step; trace %.4g ns vs HIP events %.4g ns per dispatch" % (
                 cfg, dt, entry["hbm_bytes_per_launch"], entry["valu_insts_per_launch"], entry["trace_avg_ns_per_dispatch"] or 0,
                 entry["bench_hip_event_ms_per_dispatch"] * 1e6))
