@@ -9,7 +9,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DOMINANT = {"c2": "k_rwmh_coop", "c5": "k_rwmh_coop", "c3": "emcee_half", "c4": "k_ram<"}
+DOMINANT = {"c2": "rwmh_coop", "c5": "rwmh_coop", "c3": "emcee_half", "c4": "k_ram<"}
 
 
 def main(tags):
@@ -56,8 +56,8 @@ def main(tags):
             # variants of a config profiled under their own tag: r04rot_c3_f64 -> c3_rotated_f64, r04ban_c5_f64 -> c5_banana_f64, ...
             variant = {"rot": "_rotated", "ban": "_banana", "mov": "_moving", "fix": "_fixed", "lit": "_literal"}.get(tag[-3:], "")
             traffic["%s%s_%s" % (cfg, variant, dt)] = entry
-            print(name, "-> traffic[%s_%s]: hbm %.4g B, valu %.4g per step; trace %.4g ns vs HIP events %.4g ns per dispatch" % (
-                cfg, dt, entry["hbm_bytes_per_launch"], entry["valu_insts_per_launch"], entry["trace_avg_ns_per_dispatch"] or 0,
+            print(name, "-> traffic[%s%s_%s]: hbm %.4g B, valu %.4g per step; trace %.4g ns vs HIP events %.4g ns per dispatch" % (
+                cfg, variant, dt, entry["hbm_bytes_per_launch"], entry["valu_insts_per_launch"], entry["trace_avg_ns_per_dispatch"] or 0,
                 entry["bench_hip_event_ms_per_dispatch"] * 1e6))
     json.dump(traffic, open(tpath, "w"), indent=1)
 
