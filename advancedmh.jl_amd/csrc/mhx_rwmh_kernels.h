@@ -451,6 +451,10 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
 #define MHX_COOP_ZKEEP 1
 #endif
     constexpr bool ZKEEP = MHX_COOP_ZKEEP && MHX_REAL64 && WALK == MHX_WALK_PLAIN && PK == MHX_PROP_ISO;   // (fp32: a select is one instruction already)
+#ifndef MHX_COOP_ZRELOAD
+#define MHX_COOP_ZRELOAD 0     // tuning knob, OFF: measured C2 4.76e9 against 5.11e9 steps/s, C5 5.68e8 against 5.91e8 (profiles/r04i_zreload_ab.log)
+#endif
+    constexpr bool ZRELOAD = MHX_COOP_ZRELOAD && ZKEEP && GEN == MHX_GEN_ZIGGURAT;
     static_assert(!ZIG || MHX_REAL64, "the ziggurat generator exists in the fp64 engine only");
     extern __shared__ double mhx_coop_lds[];
 #if MHX_REAL64
@@ -712,13 +716,17 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
         // bit, so the partial sums need no predication.
         mhx_real q = MHX_R(0.0), fwd = MHX_R(0.0), bwd = MHX_R(0.0), y00 = MHX_R(0.0);
 #if MHX_REAL64
-        if (ZIG) {
-            const double* const zn = zn0 + sg * SLABD;
+        // ZRELOAD (ziggurat + ZKEEP; a measured dead end kept as a knob): the normals stay in the slab -- read once for the candidate /
+        // target and once more for the accepted state -- instead of occupying the candidate's 8 NBL registers between the two.  It
+        // sheds a fifth of the AGPR spill traffic and loses 7 % at C2, 4 % at C5: at one or two waves per SIMD the second LDS
+        // round trip of every step is exposed latency
+        const double* const zn_c = ZIG ? (const double*)(zn0 + sg * SLABD) : nullptr;
+        if (ZIG && !ZRELOAD) {
             // the step's normals, final: all of them on their way to the registers the candidate will occupy (one wait)
 #pragma unroll
             for (int i = 0; i < NBL; ++i) {
-                const mhx_d2 v0 = *(const mhx_d2*)(zn + (((i * 2) * 64 + lane) << 1));
-                const mhx_d2 v1 = *(const mhx_d2*)(zn + (((i * 2 + 1) * 64 + lane) << 1));
+                const mhx_d2 v0 = *(const mhx_d2*)(zn_c + (((i * 2) * 64 + lane) << 1));
+                const mhx_d2 v1 = *(const mhx_d2*)(zn_c + (((i * 2 + 1) * 64 + lane) << 1));
                 y[i][0] = v0.x; y[i][1] = v0.y; y[i][2] = v1.x; y[i][3] = v1.y;
             }
         }
@@ -728,7 +736,11 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
             const int b = l + L * i;
             mhx_real n[4];
 #if MHX_REAL64
-            if (ZIG) {
+            if (ZIG && ZRELOAD) {
+                const mhx_d2 v0 = *(const mhx_d2*)(zn_c + (((i * 2) * 64 + lane) << 1));
+                const mhx_d2 v1 = *(const mhx_d2*)(zn_c + (((i * 2 + 1) * 64 + lane) << 1));
+                n[0] = v0.x; n[1] = v0.y; n[2] = v1.x; n[3] = v1.y;
+            } else if (ZIG) {
                 n[0] = y[i][0]; n[1] = y[i][1]; n[2] = y[i][2]; n[3] = y[i][3];
             } else
 #endif
@@ -759,7 +771,8 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
                 // in one instruction per real where a select of a double takes two.  A padding dimension keeps n = 0: x stays 0.
                 // (fma(0, n, x) == x for every x but -0.0, which a chain never holds: mhx_run_init / set_state turn a caller's -0.0
                 // into +0.0 -- rwmh_canonical_zero in mhx_api.hip -- and a rounded sum is -0 only if both terms are.)
-                if (ZKEEP) y[i][j] = (i == NBL - 1 && !(k_last + j < d)) ? MHX_R(0.0) : n[j];
+                if (ZRELOAD) { }
+                else if (ZKEEP) y[i][j] = (i == NBL - 1 && !(k_last + j < d)) ? MHX_R(0.0) : n[j];
                 else y[i][j] = yk;
                 if (i == 0 && j == 0) y00 = yk;
                 const mhx_real sq = mhx_fma(yk, yk, q);
@@ -811,10 +824,27 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
                             : (WALK == MHX_WALK_DRIFT ? (lpy - lp) + MHX_R(0.5) * (fwd - bwd) : (lpy - lp));
         const bool acc = logu < loga;
         const mhx_real s_acc = acc ? a.pscale : MHX_R(0.0);
+#if MHX_REAL64
+        if (ZRELOAD) {
+#pragma unroll
+            for (int i = 0; i < NBL; ++i) {
+                const mhx_d2 v0 = *(const mhx_d2*)(zn_c + (((i * 2) * 64 + lane) << 1));
+                const mhx_d2 v1 = *(const mhx_d2*)(zn_c + (((i * 2 + 1) * 64 + lane) << 1));
+                const mhx_real nn[4] = {v0.x, v0.y, v1.x, v1.y};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const mhx_real nj = (i == NBL - 1 && !(k_last + j < d)) ? MHX_R(0.0) : nn[j];      // a padding dimension stays 0
+                    x[i][j] = mhx_fma(s_acc, nj, x[i][j]);
+                }
+            }
+        } else
+#endif
+        {
 #pragma unroll
         for (int i = 0; i < NBL; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) x[i][j] = ZKEEP ? mhx_fma(s_acc, y[i][j], x[i][j]) : (acc ? y[i][j] : x[i][j]);
+        }
         lp = acc ? lpy : lp;
         if (WALK == MHX_WALK_STATIC) qxc = acc ? qy : qxc;
         nacc += acc ? 1u : 0u;
