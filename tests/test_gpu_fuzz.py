@@ -240,3 +240,52 @@ def test_large_dimension_shapes_random_configurations(mhx, oracle, case, real):
         _same(v, ref["samples"], what)
         _same(a, ref["accepted"], what)
     run.close()
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_dense_factor_ensembles_random_configurations(mhx, oracle, case, real, monkeypatch):
+    """The scalar-factor form of the cooperative stretch move (round 4) over random dense factors: dimension 8 ... 68 (odd ones,
+    multiples of 4 and of 16), odd and tiny ensembles (a single block, ragged last blocks, halves of different size), random
+    waves per block / walkers per block / operand mode, thinning and a discarded prefix, a resumed call, both widths."""
+    rng = np.random.default_rng(7000 + case + 100000 * SEED_OFFSET)
+    d = int(rng.choice([8, 9, 12, 15, 16, 17, 23, 31, 32, 33, 47, 48, 49, 50, 63, 64, 65, 68]))
+    W = int(rng.choice([2 * d + 2, 67, 128, 129, 193, 320, 1025]))
+    W = max(W, 4)
+    N, di, th = _schedule(rng)
+    knobs = {}
+    if rng.integers(0, 2):
+        knobs["MHX_EMCEE_SCALAR"] = str(rng.choice([4, 8, 16]))
+    if rng.integers(0, 2):
+        knobs["MHX_EMCEE_SCAL_WPB"] = str(rng.choice([16, 32, 64]))
+    if rng.integers(0, 4) == 0:
+        knobs["MHX_EMCEE_SCAL_MODE"] = "0"
+    if rng.integers(0, 4) == 0:
+        knobs["MHX_EMCEE_SCAL_REC"] = "0"
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    A = rng.normal(size=(d, d))
+    Sig = A @ A.T / d + np.diag(0.2 + rng.random(d))               # a dense SPD matrix: no band
+    seed, ens = int(rng.integers(1, 1 << 40)), int(rng.integers(0, 1 << 20))
+    a = float(np.float32(1.5 + rng.random()))
+    init = None if rng.integers(0, 2) else (rng.normal(size=(d, W)) * 0.5).astype(np.float32)
+    prior = mhx.MvNormal(mhx.zeros(d), mhx.I)
+    run = mhx.Run(mhx.DensityModel(mhx.CorrGaussian(Sig)), mhx.Ensemble(W, mhx.StretchProposal(prior, a)), seed=seed, first_chain=ens)
+    run.init(init)
+    run.sample(N, di, th, 0)
+    st = run.stats()
+    L = st["reduce_lanes"]
+    if d * (2 if real == "f64" else 1) <= 136 and int(knobs.get("MHX_EMCEE_SCALAR", 8)) <= d:
+        assert st["kernel_variant"] == 9, (knobs, st)
+    val, acc = run.samples()
+    what = "case %d: d=%d W=%d N=%d di=%d th=%d a=%g knobs=%r variant=%d L=%d" % (case, d, W, N, di, th, a, knobs, st["kernel_variant"], L)
+    ot = oracle.corr_gauss_from_cov(Sig, reduce_lanes=L)
+    ref = oracle.emcee(ot, a, 1, oracle.schedule(N, di, th), seed, ens, W, init, prior=oracle.Proposal(oracle.PROP_ISO, 1.0))
+    _same(val, ref["samples"], what)
+    _same(acc, ref["accepted"], what)
+    # a second call continues the same ensemble (the oracle: one longer schedule)
+    run.sample(3, 1, 1, 0)
+    val2, _ = run.samples()
+    nT = di + (N - 1) * th
+    ref2 = oracle.emcee(ot, a, 1, oracle.schedule(3, nT + 1, 1), seed, ens, W, init, prior=oracle.Proposal(oracle.PROP_ISO, 1.0))
+    _same(val2, ref2["samples"], what + " (resumed)")
+    run.close()
