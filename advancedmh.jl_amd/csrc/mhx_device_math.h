@@ -692,4 +692,83 @@ MHX_DEV mhx_emcee_draws mhx_emcee_draw(const mhx_philox_key& ks, mhx_u32 walker,
     return o;
 }
 #endif
+
+// ---------------------------------------------------------------------------------------------
+// One step of the xor-butterfly of the reduction shapes (spec 3.7): q + (the q of lane ^ DIST), DIST a power of two below 64.
+// `__shfl_xor` of a double compiles to two ds_bpermute_b32 and a wait -- an LDS round trip (~120 cycles) per step, six of them in a
+// row for a wave-per-chain sum, on the critical path of every step.  Round 4: the same sum from the VALU's own cross-lane paths --
+// DPP moves inside a row of 16 lanes (quad_perm for 1 and 2, row_shl / row_shr under bank masks for 4, row_ror:8 for 8) and the
+// gfx950 row / half swaps for 16 and 32 (v_permlane16_swap, v_permlane32_swap: with both operands a copy of q they leave the even /
+// lower part in one register and the odd / upper part in the other, and their sum IS q + partner for every lane -- in the upper
+// lanes as partner + q, the same bits).  Bit-identical to the shuffle form.  All 64 lanes must be active.
+#ifndef MHX_BUTTERFLY_DPP
+#define MHX_BUTTERFLY_DPP 1
+#endif
+template <int CTRL, int BANKS>
+MHX_DEV mhx_u32 mhx_dpp_mov(const mhx_u32 old, const mhx_u32 v)
+{
+    return (mhx_u32)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, 0xf, BANKS, false);
+}
+template <int DIST>
+MHX_DEV mhx_u32 mhx_lane_xor_u32(const mhx_u32 v)
+{
+    static_assert(DIST == 1 || DIST == 2 || DIST == 4 || DIST == 8, "DPP distances");
+    if constexpr (DIST == 1) return mhx_dpp_mov<0xB1, 0xf>(v, v);            // quad_perm:[1,0,3,2]
+    else if constexpr (DIST == 2) return mhx_dpp_mov<0x4E, 0xf>(v, v);       // quad_perm:[2,3,0,1]
+    else if constexpr (DIST == 4) {
+        const mhx_u32 t = mhx_dpp_mov<0x104, 0x5>(v, v);                     // row_shl:4 -> banks 0, 2 read lane + 4
+        return mhx_dpp_mov<0x114, 0xa>(t, v);                                // row_shr:4 -> banks 1, 3 read lane - 4
+    } else return mhx_dpp_mov<0x128, 0xf>(v, v);                             // row_ror:8 == lane ^ 8 within a row of 16
+}
+template <int DIST>
+MHX_DEV mhx_real mhx_butterfly_add(const mhx_real q)
+{
+#if MHX_BUTTERFLY_DPP
+    if constexpr (DIST == 16 || DIST == 32) {
+#if MHX_REAL64
+        const mhx_u64 b = __builtin_bit_cast(mhx_u64, q);
+        const mhx_u32 lo = (mhx_u32)b, hi = (mhx_u32)(b >> 32);
+        mhx_u32 alo, blo, ahi, bhi;
+        if constexpr (DIST == 16) {
+            const auto r0 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false); alo = r0[0]; blo = r0[1];
+            const auto r1 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false); ahi = r1[0]; bhi = r1[1];
+        } else {
+            const auto r0 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false); alo = r0[0]; blo = r0[1];
+            const auto r1 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false); ahi = r1[0]; bhi = r1[1];
+        }
+        const double a = __builtin_bit_cast(double, (mhx_u64)alo | ((mhx_u64)ahi << 32));
+        const double c = __builtin_bit_cast(double, (mhx_u64)blo | ((mhx_u64)bhi << 32));
+        return a + c;
+#else
+        const mhx_u32 w = __builtin_bit_cast(mhx_u32, q);
+        mhx_u32 aw, bw;
+        if constexpr (DIST == 16) { const auto r = __builtin_amdgcn_permlane16_swap(w, w, false, false); aw = r[0]; bw = r[1]; }
+        else { const auto r = __builtin_amdgcn_permlane32_swap(w, w, false, false); aw = r[0]; bw = r[1]; }
+        return __builtin_bit_cast(float, aw) + __builtin_bit_cast(float, bw);
+#endif
+    } else {
+#if MHX_REAL64
+        const mhx_u64 b = __builtin_bit_cast(mhx_u64, q);
+        const mhx_u32 lo = mhx_lane_xor_u32<DIST>((mhx_u32)b), hi = mhx_lane_xor_u32<DIST>((mhx_u32)(b >> 32));
+        return q + __builtin_bit_cast(double, (mhx_u64)lo | ((mhx_u64)hi << 32));
+#else
+        return q + __builtin_bit_cast(float, mhx_lane_xor_u32<DIST>(__builtin_bit_cast(mhx_u32, q)));
+#endif
+    }
+#else
+    return q + __shfl_xor(q, DIST, 64);
+#endif
+}
+// the whole butterfly of reduction shape L for 64 / L chains per wave (lane = l * CPW + chain): offsets CPW, 2 CPW, ... below 64
+template <int L, int OFF = 1>
+MHX_DEV mhx_real mhx_butterfly(mhx_real q)
+{
+    if constexpr (OFF < L) {
+        q = mhx_butterfly_add<OFF * (64 / L)>(q);
+        return mhx_butterfly<L, 2 * OFF>(q);
+    } else {
+        return q;
+    }
+}
+
 MHX_NS_END

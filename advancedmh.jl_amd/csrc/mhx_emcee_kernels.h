@@ -543,8 +543,7 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const mhx_real* __rest
         MHX_PROBE(4, ysl[0].x + ((const mhx_real*)Ash4)[threadIdx.x]);       // + the factor image in LDS
         q = mhx_dense_rows_sq<D, L>(Ash4, (const mhx_e4*)yrow, l);
     }
-#pragma unroll
-    for (int off = 1; off < L; off <<= 1) q = q + __shfl_xor(q, off * CPW, 64);
+    q = mhx_butterfly<L>(q);
     const mhx_real lpy = mhx_fma(-MHX_R(0.5), q, a.tconst);
     MHX_PROBE(5, lpy + ysl[0].x);                                            // + A y, the butterfly
     const mhx_real alpha = (alphamult + lpy) - lpi;                         // :91

@@ -264,10 +264,8 @@ MHX_DEV void mhx_mala_coop_body(const mhx_mala_args& a, const mhx_real* __restri
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int off = 1; off < L; off <<= 1) q = q + __shfl_xor(q, off * CPW, 64);
-#pragma unroll
-        for (int off = 1; off < L; off <<= 1) fwd = fwd + __shfl_xor(fwd, off * CPW, 64);
+        q = mhx_butterfly<L>(q);
+        fwd = mhx_butterfly<L>(fwd);
         // ---- value and gradient at the candidate (:73-75): same expressions as mhx_target_grad
         mhx_real lpy;
         if (TK == MHX_TARGET_FUNNEL) {
@@ -305,8 +303,7 @@ MHX_DEV void mhx_mala_coop_body(const mhx_mala_args& a, const mhx_real* __restri
                 const mhx_real tk = in ? mhx_fma(a.hs, gx[i][j] + gy[i][j], z[i][j]) : MHX_R(0.0);
                 bwd = mhx_fma(tk, tk, bwd);
             }
-#pragma unroll
-        for (int off = 1; off < L; off <<= 1) bwd = bwd + __shfl_xor(bwd, off * CPW, 64);
+        bwd = mhx_butterfly<L>(bwd);
         const mhx_real loga = (lpy - lp) + MHX_R(0.5) * (fwd - bwd);                 // :83
         const mhx_real logu = mhx_accept_logu(ks, id_lo, id_hi, step, ac);
         const bool acc = logu < loga;                                               // :86 (strict)

@@ -111,15 +111,15 @@ MHX_DEV void mhx_mala_mfma_body(const mhx_mala_args& a, const mhx_real* __restri
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        fq = fq + __shfl_xor(fq, 16, 64);
-        fq = fq + __shfl_xor(fq, 32, 64);
+        fq = mhx_butterfly_add<16>(fq);
+        fq = mhx_butterfly_add<32>(fq);
         // ---- value and gradient at the candidate (:73-75): w = A y, lp' = -1/2 |w|^2 + const, grad = -A^T w
         mhx_real w[NS], gy[NS];
         mhx_real q = MHX_R(0.0);
         if constexpr (STREAM) mhx_mfma_rows_stream<D, 3, true, true, BUFM>(sA, sAT, ring, lane, ys, q, w, pf, parity);
         else mhx_mfma_rows<D, 3>(Aimg, lane, ys, q, w);
-        q = q + __shfl_xor(q, 16, 64);
-        q = q + __shfl_xor(q, 32, 64);
+        q = mhx_butterfly_add<16>(q);
+        q = mhx_butterfly_add<32>(q);
         const mhx_real lpy = mhx_fma(-MHX_R(0.5), q, a.tconst);
         if constexpr (STREAM) mhx_mfma_rows_T_stream<D, BUFM>(sAT, sA, ring, lane, w, gy, pf, parity);
         else mhx_mfma_rows_T<D>(ATimg, lane, w, gy);
@@ -139,8 +139,8 @@ MHX_DEV void mhx_mala_mfma_body(const mhx_mala_args& a, const mhx_real* __restri
 #pragma unroll
             for (int e = 0; e < 4; ++e) bq = mhx_fma(n[e], n[e], bq);
         }
-        bq = bq + __shfl_xor(bq, 16, 64);
-        bq = bq + __shfl_xor(bq, 32, 64);
+        bq = mhx_butterfly_add<16>(bq);
+        bq = mhx_butterfly_add<32>(bq);
         const mhx_real loga = (lpy - lp) + MHX_R(0.5) * (fq - bq);                    // :83
         const mhx_real logu = mhx_accept_logu(ks, id_lo, id_hi, step, ac);
         const bool acc = logu < loga;                                                 // :86 (strict)
@@ -376,15 +376,15 @@ MHX_DEV void mhx_mala_mfma_lean_body(const mhx_mala_args& a, mhx_real* Aimg, mhx
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        fq = fq + __shfl_xor(fq, 16, 64);
-        fq = fq + __shfl_xor(fq, 32, 64);
+        fq = mhx_butterfly_add<16>(fq);
+        fq = mhx_butterfly_add<32>(fq);
         // ---- w = A y (in place, tiles descending), lp' = -1/2 |w|^2 + const in ascending row order
         mhx_mfma_rows_stream_desc<D, PAIR, BUFM>(sA, sAT, ring, lane, v, pf, parity);
         mhx_real q = MHX_R(0.0);
 #pragma unroll
         for (int s = 0; s < NS; ++s) q = mhx_fma(v[s], v[s], q);
-        q = q + __shfl_xor(q, 16, 64);
-        q = q + __shfl_xor(q, 32, 64);
+        q = mhx_butterfly_add<16>(q);
+        q = mhx_butterfly_add<32>(q);
         const mhx_real lpy = mhx_fma(-MHX_R(0.5), q, a.tconst);
         // ---- grad = -A^T w (in place, tiles ascending)
         mhx_mfma_rows_T_stream_inplace<D, PAIR, BUFM>(sAT, sA, ring, lane, v, pf, parity);
@@ -405,8 +405,8 @@ MHX_DEV void mhx_mala_mfma_lean_body(const mhx_mala_args& a, mhx_real* Aimg, mhx
 #pragma unroll
             for (int e = 0; e < 4; ++e) bq = mhx_fma(n[e], n[e], bq);
         }
-        bq = bq + __shfl_xor(bq, 16, 64);
-        bq = bq + __shfl_xor(bq, 32, 64);
+        bq = mhx_butterfly_add<16>(bq);
+        bq = mhx_butterfly_add<32>(bq);
         const mhx_real loga = (lpy - lp) + MHX_R(0.5) * (fq - bq);
         const mhx_real logu = mhx_accept_logu(ks, id_lo, id_hi, step, ac);
         const bool acc = logu < loga;

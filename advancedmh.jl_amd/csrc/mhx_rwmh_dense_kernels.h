@@ -133,8 +133,7 @@ MHX_DEV void mhx_rwmh_dense_coop_body(const mhx_rwmh_args& a, const mhx_real* __
                 if (k + 3 < D) q = mhx_fma(ys[m].w, ys[m].w, q);
             }
         }
-#pragma unroll
-        for (int off = 1; off < L; off <<= 1) q = q + __shfl_xor(q, off * CPW, 64);
+        q = mhx_butterfly<L>(q);
         const mhx_real lpy = mhx_fma(-MHX_R(0.5), q, a.tconst);
         MHX_WAVE_SYNC();                                                 // the row is free for the next candidate
         // ---- accept (src/mh-core.jl:104-114); a zero-mean random walk has no Hastings term

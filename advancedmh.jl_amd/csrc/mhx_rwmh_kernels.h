@@ -796,15 +796,10 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
             if ((i % MHX_COOP_INTERLEAVE) == MHX_COOP_INTERLEAVE - 1) __builtin_amdgcn_sched_barrier(0);
 #endif
         }
-#pragma unroll
-        for (int off = 1; off < L; off <<= 1) q = q + __shfl_xor(q, off * CPW, 64);
+        q = mhx_butterfly<L>(q);
         if (WALK != MHX_WALK_PLAIN) {
-#pragma unroll
-            for (int off = 1; off < L; off <<= 1) fwd = fwd + __shfl_xor(fwd, off * CPW, 64);
-            if (WALK == MHX_WALK_DRIFT) {
-#pragma unroll
-                for (int off = 1; off < L; off <<= 1) bwd = bwd + __shfl_xor(bwd, off * CPW, 64);
-            }
+            fwd = mhx_butterfly<L>(fwd);
+            if (WALK == MHX_WALK_DRIFT) bwd = mhx_butterfly<L>(bwd);
         }
         mhx_real lpy;
         if (TK == MHX_TARGET_FUNNEL) {

@@ -483,8 +483,8 @@ MHX_DEV void mhx_rwmh_mfma_body(const mhx_rwmh_args& a, const mhx_real* __restri
                 for (int e = 0; e < 4; ++e) q = mhx_fma(n[e], n[e], q);      // the pad is zero
             }
         }
-        q = q + __shfl_xor(q, 16, 64);
-        q = q + __shfl_xor(q, 32, 64);
+        q = mhx_butterfly_add<16>(q);
+        q = mhx_butterfly_add<32>(q);
         const mhx_real lpy = mhx_fma(-MHX_R(0.5), q, a.tconst);
         // ---- accept (src/mh-core.jl:104-114); a zero-mean random walk has no Hastings term
         const mhx_real logu = mhx_accept_logu(ks, id_lo, id_hi, step, ac);
