@@ -574,3 +574,34 @@ def test_checkpoint_and_resume(mhx, kind, real):
             other.close()
     a.close()
     b.close()
+
+
+def test_bench_two_ranks_on_this_box_and_the_line_says_what_ran():
+    """`python bench.py --gpus 2` as the driver would issue it for N = 2, on a box with ONE GPU: refused (a 2-GPU line needs two
+    devices); with --allow-gloo the launcher starts two ranks that share the device and the line reports exactly that -- n_ranks 2,
+    n_gpus = the distinct devices opened, `oversubscribed` -- with both ranks' chains in `value` (the flag used to be
+    parsed and ignored, so an 8-GPU scaling run would have recorded eight 1-GPU lines)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    ndev = torch.cuda.device_count()
+    base = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--inner", "20", "--chains", "4096",
+            "--no-cpu-baseline"]
+    if ndev < 2:
+        p = subprocess.run(base + ["--gpus", "2"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        assert p.returncode != 0 and "refusing" in p.stderr and not [l for l in p.stdout.splitlines() if l.startswith("{")]
+    p = subprocess.run(base + ["--gpus", "2", "--allow-gloo"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_ranks"] == 2 and line["n_gpus"] == min(2, ndev) and line["config"]["ranks_reported_by_transport"] == 2
+    assert ("oversubscribed" in line) == (ndev < 2)
+    assert line["config"]["units_per_step_per_gpu"] == 4096 * 20 and line["value"] > 0
+    assert abs(line["value"] - 2 * 4096 * 20 * 2 / (line["ms_per_step"] * 1e-3 * 2)) < 1e-6 * line["value"]   # both ranks' chains over the max-over-ranks time
+    assert 0.1 < line["acceptance_rate"] < 0.4
+    assert len(lines[0]) < 8000
