@@ -610,6 +610,27 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
         if (mom_n) { lpm = a.mom_mean[(long)d * ld + c]; lpm2 = a.mom_m2[(long)d * ld + c]; }
     }
 
+    // DEFER_REC (round 4, OFF): without the record the same kernel runs 6.3e9 steps/s against 5.2e9, so this variant lets the record of
+    // a saved step leave not in one burst of 4 NBL stores behind the accept test but block by block inside the NEXT step's
+    // generation phase, between its Philox rounds (the state is unchanged until that step's own accept).  No branches: the stores are always issued, through a buffer descriptor whose range is empty when the previous
+    // step was not a saved one (the range check drops them), and idle lanes carry an offset past every range.
+#ifndef MHX_COOP_DEFER_REC
+#define MHX_COOP_DEFER_REC 0   // a measured dead end kept as a knob: bit-exact, C2 4.88-4.96e9 against 5.10e9 steps/s wherever in the generation
+                               // phase the stores sit (profiles/r04q_defer_rec_ab*.log) -- what the record costs is the issue of 4 NBL
+                               // 8-byte-per-lane stores itself, not their arriving in one burst
+#endif
+    constexpr bool DEFER_REC = MHX_COOP_DEFER_REC && ZIG && KS == 1 && !MOM;
+    const mhx_u32 ldb_rec = (mhx_u32)ld * MHX_RB;
+    const mhx_u32 lane_off_rec = valid ? lane_off : 0xfffffff0u;
+    mhx_srd rec_srd = mhx_make_srd(a.x, 0u);                   // empty range: nothing pending
+    auto rec_block = [&](const int i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const mhx_u32 rowb = (mhx_u32)(4 * L * i + j) * ldb_rec;     // wave-uniform -> soffset
+            if (i < NBL - 1) mhx_srd_store(rec_srd, lane_off_rec, rowb, x[i][j]);
+            else if (k_last + j < d) mhx_srd_store(rec_srd, lane_off_rec, rowb, x[i][j]);
+        }
+    };
     // (a saved step of the one- / two-chains-per-wave shapes stages its record in the slab memory: no groups then)
     const int ks_eff = (ZIG && !(tr_io && a.samples != nullptr && a.save_next != MHX_NO_SAVE)) ? KS : 1;
     for (int it0 = 0; it0 < a.nsteps; it0 += ks_eff) {
@@ -662,10 +683,22 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
                     const mhx_u32 ly = klo[e] & (mhx_u32)(MHX_ZIG_N - 1);
                     xe[e].x = zt[ly]; xe[e].y = zt[ly + 1];
                 }
+#ifndef MHX_DEFER_POS
+#define MHX_DEFER_POS 1
+#endif
+                if constexpr (DEFER_REC && MHX_DEFER_POS == 2) {
+#pragma unroll
+                    for (int bb = 0; bb < GB; ++bb) { if (grp * GB + bb < NBL) rec_block(grp * GB + bb); }
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 mhx_u32 nhi[4 * GB], nlo[4 * GB];
                 if (grp + 1 < NG) draw(grp + 1, nhi, nlo);
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (DEFER_REC && MHX_DEFER_POS <= 1) {
+#pragma unroll
+                    for (int bb = 0; bb < GB; ++bb) { if (grp * GB + bb < NBL) rec_block(grp * GB + bb); }
+                    if (MHX_DEFER_POS == 0) __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int bb = 0; bb < GB; ++bb) {
                     const int i = grp * GB + bb;
@@ -857,8 +890,19 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
         } else if (step == save_next && tr_io) {
             // (one or two chains per wave: the record leaves through the block's LDS as whole row segments, see fetch4)
             mhx_real* slotp = a.samples + slot * (long)(d + 1) * ld;
+            if constexpr (DEFER_REC) rec_srd = mhx_make_srd(a.x, 0u);
             flush4(slotp, x);
             if (l == 0) {
+                slotp[(long)d * ld + c] = lp;
+                a.accepted[slot * ld + c] = acc ? 1 : 0;
+            }
+            save_next += (mhx_u32)a.thinning;
+            ++slot;
+        } else if (DEFER_REC && step == save_next) {
+            // the state's rows follow during the next step's generation phase (or after the loop); lp and the flag go now
+            mhx_real* slotp = a.samples + slot * (long)(d + 1) * ld;
+            rec_srd = mhx_make_srd(slotp, (mhx_u32)(d + 1) * (mhx_u32)ld * MHX_RB);
+            if (valid && l == 0) {
                 slotp[(long)d * ld + c] = lp;
                 a.accepted[slot * ld + c] = acc ? 1 : 0;
             }
@@ -884,8 +928,14 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
             }
             save_next += (mhx_u32)a.thinning;
             ++slot;
+        } else if (DEFER_REC) {
+            rec_srd = mhx_make_srd(a.x, 0u);                      // not a saved step: the next generation phase stores nothing
         }
     }
+    }
+    if constexpr (DEFER_REC) {                                    // the record of the launch's last step, if it was a saved one
+#pragma unroll
+        for (int i = 0; i < NBL; ++i) rec_block(i);
     }
     const bool tr_out = tr_io;
     if (tr_out) {
