@@ -316,6 +316,28 @@ def test_c3_ensemble_known_answer_at_scale(mhx, real):
     assert 0.1 < chain.accepted[1:].mean() < 0.5
 
 
+def test_c3_rotated_ensemble_known_answer_at_scale(mhx, real):
+    """The dense-rotated C3 target as a known answer on the scalar-factor form (variant 9): Sigma = Q (0.9^|i-j|) Q^T has no structure the
+    kernel could exploit; rotated back by Q^T the walkers must show the AR(1) model again -- mean 0, unit variances, neighbour
+    correlation 0.9 -- after the same burn-in as the banded test (the stretch move is affine-invariant: identical mixing)."""
+    d, W = 50, 16384
+    Q, _ = np.linalg.qr(np.random.default_rng(50).normal(size=(d, d)))
+    Sig = Q @ cases.sigma_ar1(d, 0.9) @ Q.T
+    spl = mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I)))
+    chain = mhx.sample(mhx.DensityModel(mhx.CorrGaussian(Sig)), spl, 20, seed=12, discard_initial=20000, thinning=200)
+    assert chain.stats["kernel_variant"] == 9
+    v = chain.value[:, :d, :].astype(np.float64)                        # [20][d][W]
+    pooled = Q.T @ v.transpose(1, 0, 2).reshape(d, -1)                  # back in the AR(1) coordinates
+    assert np.abs(pooled.mean(axis=1)).max() < 0.03
+    assert np.abs(pooled.var(axis=1) - 1.0).max() < 0.05
+    nb = [np.corrcoef(pooled[k], pooled[k + 1])[0, 1] for k in range(d - 1)]
+    assert abs(np.mean(nb) - 0.9) < 0.01 and np.abs(np.array(nb) - 0.9).max() < 0.03
+    # log-density of the kept walkers: E[lp] = -d/2 - d/2 log(2 pi) - 1/2 log det Sigma, det Sigma = (1 - 0.81)^(d-1)
+    want = -0.5 * d * (1.0 + np.log(2 * np.pi)) - 0.5 * (d - 1) * np.log(1.0 - 0.81)
+    assert abs(chain.value[:, d, :].astype(np.float64).mean() - want) < 0.1
+    assert 0.1 < chain.accepted[1:].mean() < 0.5
+
+
 @pytest.mark.parametrize("sampler", ["rwmh", "mala"])
 def test_matrix_core_kernels_known_answer(mhx, sampler, real):
     """The dense Gaussian target on the matrix cores as a known answer: 16 384 chains on the 100-dim AR(1) Gaussian with
