@@ -639,6 +639,10 @@ struct mhx_run : mhx_handle_hdr {
     int coop_waves = MHX_EMCEE_COOP_WAVES;  // waves per block of the cooperative stretch move (tuning knob MHX_EMCEE_WAVES)
     size_t emcee_stamp_words = 0;        // MHX_EMCEE_STAMPS (tools): 64-bit words of the stamp buffer in d_ybuf
     int emcee_wpb = 64;                  // walkers per block of the scalar-factor form
+    hipFunction_t jit_sweep = nullptr;   // the stretch move as ONE launch per sweep (mhx_emcee_coop_sweep_body); state double-buffered:
+    mhx_real *d_xw2 = nullptr, *d_lp2 = nullptr;   // ... the buffers the next sweep writes (swapped with d_xw / d_lp after every launch)
+    size_t sweep_lds = 0;
+    bool emcee_preload = false;          // the half-step kernel takes its hot arguments as preloaded scalars (MHX_JIT_PRELOAD)
     bool emcee_scal = false;             // the scalar-factor form of the cooperative stretch move (variant 9): coop_L waves per block, 64 walkers
     int variant = 0;
     void (*reg_fn)(const mhx_rwmh_args, const mhx_real*, const mhx_real*) = nullptr;
@@ -649,7 +653,7 @@ struct mhx_run : mhx_handle_hdr {
     {
         void* ptrs[] = {d_pvec, d_S, d_Ssel, d_status, d_dmin, d_dmax, d_eta, d_x, d_lp, d_ybuf,
                         d_acc, d_last, d_acc_total, d_samples, d_accepted, d_mom_mean, d_mom_m2, d_gx, d_gy, d_z, d_pmean, d_qx, d_xw, d_loga, d_mfma_img, d_rec_loga,
-                        d_watch_chains, d_watch};
+                        d_watch_chains, d_watch, d_xw2, d_lp2};
         for (void* p : ptrs) if (p) (void)hipFree(p);
     }
 };

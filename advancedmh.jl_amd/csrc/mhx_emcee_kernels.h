@@ -26,6 +26,10 @@ struct mhx_emcee_args {
     mhx_real* x;                 // [dim][W]   (ABI layout; the lane-per-walker kernels work on it)
     mhx_real* xw;                // [W][round4(dim)] walker-major copy, zero padded: the state of the cooperative kernel
     mhx_real* lp;                // [W]
+    mhx_real* xw_out;            // the sweep kernels (one launch per sweep) read xw / lp and write the new state here
+    mhx_real* lp_out;
+    int all_rows;                // sweep kernels: 1 = every walker's row goes to xw_out (the first launch after the state was set from
+                                 // outside); 0 = only the rows xw_out does not hold already (see mhx_emcee_coop_sweep_body)
     mhx_u32* acc_count;       // [W]
     mhx_u64* acc_total;
     mhx_real* samples;           // [slots][dim+1][W] or null
@@ -605,6 +609,180 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const mhx_real* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
+// ONE LAUNCH PER SWEEP (round 4).  A half-step is a 5-us launch of which 2.7 us is the kernel boundary, and the two half-steps
+// of a sweep are dependent launches only because the second half moves against the NEW state of the first.  But the draws of a
+// walker are a function of (seed, ensemble, sweep, walker) alone: a walker b of the second half knows its partner a before any
+// memory has answered, and a's partner b' as well -- so the group that moves b RE-DOES a's move from the old state (rows a, b'
+// and lp_a as the launch found them), which is bit for bit what the group that owns a computes, and then moves b against the
+// result.  No group waits for another one; the price is a second (and, below, a third) row product for the second half's
+// groups and a state that is double-buffered (xw / lp are read, xw_out / lp_out take EVERY walker's new row: a's old row must
+// outlive the launch that replaces it; the host swaps the buffers -- and a walker that moved neither in this sweep nor in the one
+// before is not written at all: the buffer this launch writes is the one the launch before READ, it holds the state of two sweeps ago,
+// which for such a walker is its state now; last_acc carries "moved in the previous sweep", so a third of the rows are stored).  The chain of b is not even two moves deep: its candidate
+// is formed for both outcomes of a's accept test -- y_b0 against x_a, y_b1 against y_a -- and the three row products run side by
+// side; the test then selects.  Same chains, same records, same counters as two half-step launches (oracle: mode 1).
+// Blocks [0, nbB) move the second half (the longer program: dispatched first), the others the first half.
+template <int D, int L, int BW = -1>
+MHX_DEV void mhx_emcee_coop_sweep_body(const mhx_emcee_args& a, const mhx_real* __restrict__ A, mhx_real* ysh_all, mhx_e4* Ash4)
+{
+    typedef mhx_emcee_geom<D, L> GEO;
+    constexpr int CPW = 64 / L;
+    constexpr int NK = GEO::NK;
+    constexpr int DP4 = GEO::DP4;
+    constexpr int NQ = GEO::NQ, NQL = GEO::NQL;
+    constexpr bool BAND = BW >= 0;
+    constexpr bool ONE_BATCH = !BAND && NK * GEO::maxit() <= 16;
+    constexpr int WPBK = MHX_EMCEE_COOP_WAVES * CPW;                         // walkers per block
+    mhx_e4 areg[ONE_BATCH ? NK : 1][GEO::maxit()];
+    if constexpr (ONE_BATCH) mhx_dense_image_load<D, L>(A, areg);
+    mhx_real ab[BAND ? NK : 1][BAND ? BW + 1 : 1];
+    if constexpr (BAND) mhx_band_load<D, L, BW>(A, (int)((threadIdx.x & 63) / CPW), ab);
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int cw = lane & (CPW - 1);
+    const int l = lane / CPW;
+    mhx_real* yrow = ysh_all + (wave * 3 * CPW + cw) * DP4;                  // three candidate rows per walker: + CPW * DP4 each
+    const int W = a.nwalkers;
+    const int halfW = W / 2, cntB = W - halfW;
+    const int nbB = (cntB + WPBK - 1) / WPBK;
+    const bool second = (int)blockIdx.x < nbB;                               // (block-uniform)
+    const int blk = second ? (int)blockIdx.x : (int)blockIdx.x - nbB;
+    const int cnt = second ? cntB : halfW;
+    const int t_raw = (blk * MHX_EMCEE_COOP_WAVES + wave) * CPW + cw;
+    const bool valid = t_raw < cnt;
+    const int i = (second ? halfW : 0) + (valid ? t_raw : cnt - 1);
+    const long ld = W;
+    const mhx_e4 zero4 = {MHX_R(0.0), MHX_R(0.0), MHX_R(0.0), MHX_R(0.0)};
+
+    mhx_e4 xs[NQL], ysl[NQL];
+    const mhx_e4* xrow_i = (const mhx_e4*)(a.xw + (long)i * GEO::XP);
+#pragma unroll
+    for (int m = 0; m < NQL; ++m) { const int q4 = l + L * m; xs[m] = q4 < NQ ? xrow_i[q4] : zero4; }
+    const mhx_real lpi = a.lp[i];
+    const mhx_u32 acc_i = a.acc_count[i];
+    const bool moved_before = a.all_rows != 0 || a.last_acc[i] != 0;         // xw_out does not hold this walker's row
+    const mhx_philox_key ks = mhx_philox_schedule(a.seed);
+    const mhx_emcee_draws dr = mhx_emcee_draw(ks, (mhx_u32)i, (mhx_u32)a.ensemble_id, a.sweep);
+    // the partner: the second half draws from the first ([0, halfW)), the first from the second
+    const int j = (second ? 0 : halfW) + (int)(((mhx_u64)dr.partner * (mhx_u64)(mhx_u32)(second ? halfW : cntB)) >> 32);
+    const mhx_real tt = mhx_fma(a.stretch - MHX_R(1.0), dr.u, MHX_R(1.0));
+    const mhx_real z = (tt * tt) / a.stretch;                               // src/emcee.jl:81
+    const mhx_real alphamult = (mhx_real)(D - 1) * mhx_log(z);              // :82
+    const mhx_e4* xrow_j = (const mhx_e4*)(a.xw + (long)j * GEO::XP);
+    MHX_PROBE(2, alphamult + (mhx_real)j + xs[0].x + lpi);                  // launch, own row, the draws
+    auto stretch = [](const mhx_real zz, const mhx_e4 xi, const mhx_e4 xj) {   // :85, element-wise
+        mhx_e4 y;
+        y.x = mhx_fma(zz, xi.x - xj.x, xj.x);
+        y.y = mhx_fma(zz, xi.y - xj.y, xj.y);
+        y.z = mhx_fma(zz, xi.z - xj.z, xj.z);
+        y.w = mhx_fma(zz, xi.w - xj.w, xj.w);
+        return y;
+    };
+    auto row_products = [&](const mhx_real* yr) {
+        mhx_real q;
+        if constexpr (BAND) q = mhx_band_rows_sq<D, L, BW>(ab, yr, l);
+        else q = mhx_dense_rows_sq<D, L>(Ash4, (const mhx_e4*)yr, l);
+        return q;
+    };
+    auto image_ready = [&]() {
+        if constexpr (BAND) MHX_WAVE_SYNC();                                 // the candidate rows of a wave are its own
+        else {
+            if constexpr (ONE_BATCH) mhx_dense_image_store<D, L>(areg, Ash4);
+            else mhx_dense_image_fill<D, L>(A, Ash4);
+            __syncthreads();
+        }
+    };
+    mhx_real lpy;
+    if (!second) {
+#pragma unroll
+        for (int m = 0; m < NQL; ++m) {
+            const int q4 = l + L * m;
+            ysl[m] = q4 < NQ ? stretch(z, xs[m], xrow_j[q4]) : zero4;
+            if (q4 < DP4 / 4) ((mhx_e4*)yrow)[q4] = ysl[m];
+        }
+        image_ready();
+        MHX_PROBE(3, ysl[0].x);                                              // + the partner rows, the candidates in LDS
+        const mhx_real q = mhx_butterfly<L>(row_products(yrow));
+        lpy = mhx_fma(-MHX_R(0.5), q, a.tconst);
+    } else {
+        // j is a walker of the first half: its own move of this sweep, from the state this launch found
+        const mhx_emcee_draws da = mhx_emcee_draw(ks, (mhx_u32)j, (mhx_u32)a.ensemble_id, a.sweep);
+        const int jb = halfW + (int)(((mhx_u64)da.partner * (mhx_u64)(mhx_u32)cntB) >> 32);
+        const mhx_e4* xrow_b = (const mhx_e4*)(a.xw + (long)jb * GEO::XP);
+        const mhx_real lpa = a.lp[j];
+        const mhx_real ta = mhx_fma(a.stretch - MHX_R(1.0), da.u, MHX_R(1.0));
+        const mhx_real za = (ta * ta) / a.stretch;
+        const mhx_real alphamult_a = (mhx_real)(D - 1) * mhx_log(za);
+        mhx_e4 y1[NQL];
+#pragma unroll
+        for (int m = 0; m < NQL; ++m) {
+            const int q4 = l + L * m;
+            mhx_e4 ya = zero4;
+            ysl[m] = zero4; y1[m] = zero4;
+            if (q4 < NQ) {
+                const mhx_e4 xa = xrow_j[q4];
+                ya = stretch(za, xa, xrow_b[q4]);                           // a's candidate
+                ysl[m] = stretch(z, xs[m], xa);                              // this walker's candidate if a stays
+                y1[m] = stretch(z, xs[m], ya);                               //                          if a moves
+            }
+            if (q4 < DP4 / 4) {
+                ((mhx_e4*)yrow)[q4] = ya;
+                ((mhx_e4*)(yrow + CPW * DP4))[q4] = ysl[m];
+                ((mhx_e4*)(yrow + 2 * CPW * DP4))[q4] = y1[m];
+            }
+        }
+        image_ready();
+        MHX_PROBE(3, ysl[0].x + y1[0].x);
+        const mhx_real qa = mhx_butterfly<L>(row_products(yrow));
+        const mhx_real q0 = mhx_butterfly<L>(row_products(yrow + CPW * DP4));
+        const mhx_real q1 = mhx_butterfly<L>(row_products(yrow + 2 * CPW * DP4));
+        const mhx_real lpya = mhx_fma(-MHX_R(0.5), qa, a.tconst);
+        const bool acc_a = da.logu <= (alphamult_a + lpya) - lpa;           // a's accept test (:91-93), as its own group runs it
+        lpy = mhx_fma(-MHX_R(0.5), acc_a ? q1 : q0, a.tconst);
+#pragma unroll
+        for (int m = 0; m < NQL; ++m) {
+            ysl[m].x = acc_a ? y1[m].x : ysl[m].x; ysl[m].y = acc_a ? y1[m].y : ysl[m].y;
+            ysl[m].z = acc_a ? y1[m].z : ysl[m].z; ysl[m].w = acc_a ? y1[m].w : ysl[m].w;
+        }
+    }
+    MHX_PROBE(5, lpy + ysl[0].x);                                            // + the row products, the butterflies
+    const mhx_real alpha = (alphamult + lpy) - lpi;                         // :91
+    const bool acc = dr.logu <= alpha;                                      // :93
+    if (valid) {
+        mhx_e4* xrow_o = (mhx_e4*)(a.xw_out + (long)i * GEO::XP);
+#pragma unroll
+        for (int m = 0; m < NQL; ++m) {
+            const int q4 = l + L * m;
+            mhx_e4 v;
+            v.x = acc ? ysl[m].x : xs[m].x; v.y = acc ? ysl[m].y : xs[m].y; v.z = acc ? ysl[m].z : xs[m].z; v.w = acc ? ysl[m].w : xs[m].w;
+            ysl[m] = v;
+            if (q4 < NQ && (acc || (moved_before && MHX_EMCEE_PROBE < 7))) xrow_o[q4] = v;      // (probes 7, 8: timing only, accepted rows alone)
+        }
+        if (l == 0) {
+            a.lp_out[i] = acc ? lpy : lpi;
+            if (acc) a.acc_count[i] = acc_i + 1u;
+            a.last_acc[i] = acc ? 1 : 0;
+        }
+        if (MHX_EMCEE_PROBE == 6 || MHX_EMCEE_PROBE == 7) return;            // + accept and the new state, no record
+        if (a.save_slot >= 0) {
+            mhx_real* row = a.samples + a.save_slot * (long)(D + 1) * ld + i;
+#pragma unroll
+            for (int m = 0; m < NQL; ++m) {
+                const int k = 4 * (l + L * m);
+                if (k + 0 < D) MHX_REC_ST(&row[(long)(k + 0) * ld], ysl[m].x);
+                if (k + 1 < D) MHX_REC_ST(&row[(long)(k + 1) * ld], ysl[m].y);
+                if (k + 2 < D) MHX_REC_ST(&row[(long)(k + 2) * ld], ysl[m].z);
+                if (k + 3 < D) MHX_REC_ST(&row[(long)(k + 3) * ld], ysl[m].w);
+            }
+            if (l == 0) {
+                MHX_REC_ST(&row[(long)D * ld], acc ? lpy : lpi);
+                a.accepted[a.save_slot * ld + i] = acc ? 1 : 0;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // The SCALAR-FACTOR form of the cooperative stretch move (dense precision factor; round 4).
 //
 // The factor A = inv(chol Sigma) is the same for every walker.  In the lane-group form above a lane owns ROWS of A y, so the A
@@ -1098,6 +1276,9 @@ MHX_DEV void mhx_emcee_seq_body(const mhx_emcee_args& a, const mhx_real* __restr
 #ifndef MHX_JIT_SCAL
 #define MHX_JIT_SCAL 0
 #endif
+#ifndef MHX_JIT_PRELOAD
+#define MHX_JIT_PRELOAD 0
+#endif
 #if MHX_JIT_SCAL
 extern "C" __global__ void __launch_bounds__(64 * MHX_JIT_L)
 #elif MHX_JIT_L > 1
@@ -1105,8 +1286,22 @@ extern "C" __global__ void __launch_bounds__(64 * MHX_EMCEE_COOP_WAVES)
 #else
 extern "C" __global__ void __launch_bounds__(64)
 #endif
+#if MHX_JIT_PRELOAD
+// kernarg preload (gfx950: the first user SGPRs of a wave are filled from the head of the kernarg segment by the dispatcher): the
+// fields the half-step's first dependent chain starts from -- state rows, counters of the draw, the moving slice -- come FIRST and as
+// plain scalars (a by-value struct is `byref` and cannot be preloaded), so no wave waits for an s_load of them; the rest of the
+// argument block follows and is fetched as before.  The host passes the same values twice (emcee_launch_half).
+mhx_jit_emcee_half(mhx_real* const xw, mhx_real* const lp, const mhx_u64 seed, const mhx_u64 ensemble_id, const mhx_u32 sweep,
+                   const int half, const int nwalkers, const int t_begin, const int t_count,
+                   const mhx_emcee_args a0, const mhx_real* __restrict__ tparams)
+{
+    mhx_emcee_args a = a0;
+    a.xw = xw; a.lp = lp; a.seed = seed; a.ensemble_id = ensemble_id; a.sweep = sweep; a.half = half; a.nwalkers = nwalkers;
+    a.t_begin = t_begin; a.t_count = t_count;
+#else
 mhx_jit_emcee_half(const mhx_emcee_args a, const mhx_real* __restrict__ tparams)
 {
+#endif
 #if MHX_JIT_SCAL
     // the scalar-factor form: MHX_JIT_L waves per block = row classes = reduction shape; dynamic LDS = y rows + partial sums
     extern __shared__ mhx_e4 mhx_emcee_lds[];
@@ -1123,6 +1318,16 @@ mhx_jit_emcee_half(const mhx_emcee_args a, const mhx_real* __restrict__ tparams)
     mhx_emcee_half_body<MHX_JIT_DIM, MHX_JIT_TK>(a, tparams);
 #endif
 }
+#if !MHX_JIT_SCAL && MHX_JIT_L > 1
+// one launch per sweep (lane-group form): three candidate rows per walker in LDS, then the factor image
+extern "C" __global__ void __launch_bounds__(64 * MHX_EMCEE_COOP_WAVES)
+mhx_jit_emcee_sweep(const mhx_emcee_args a, const mhx_real* __restrict__ tparams)
+{
+    extern __shared__ mhx_e4 mhx_emcee_lds[];
+    constexpr int YS4 = 3 * MHX_EMCEE_COOP_WAVES * (64 / MHX_JIT_L) * mhx_emcee_geom<MHX_JIT_DIM, MHX_JIT_L>::DP4 / 4;
+    mhx_emcee_coop_sweep_body<MHX_JIT_DIM, MHX_JIT_L, MHX_JIT_BW>(a, tparams, (mhx_real*)mhx_emcee_lds, mhx_emcee_lds + YS4);
+}
+#endif
 extern "C" __global__ void __launch_bounds__(256)
 mhx_jit_emcee_init(const mhx_emcee_args a, const mhx_real* __restrict__ tparams, const int draw)
 {
