@@ -306,7 +306,7 @@ static int jit_compile(mhx_ctx* ctx, const std::string& key, const std::string& 
                               "mhx_emcee_kernels.h", "mhx_ram_kernels.h", "mhx_mala_kernels.h",
                               "mhx_rwmh_dense_kernels.h", "mhx_rwmh_mfma_kernels.h", "mhx_mala_mfma_kernels.h"};
     std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
-                                     MHX_REAL64 ? "-DMHX_REAL64=1" : "-DMHX_REAL64=0"};
+                                     MHX_REAL64 ? "-DMHX_REAL64=1" : "-DMHX_REAL64=0", "-DMHX_XW_LINE=" + std::to_string(MHX_XW_LINE)};
     for (auto& d : defines) opts.push_back("-D" + d);
     for (auto& o : extra_opts) opts.push_back(o);
     const std::string cdir = jit_cache_dir();

@@ -64,6 +64,19 @@ struct mhx_emcee_args {
     int thinning;
 };
 
+// Pitch (in reals) of a walker's row in the walker-major state: round4(dim) reals.  MHX_XW_LINE = 128 (a build-time knob) rounds rows
+// of at least a cache line up to whole 128-byte lines, so that a rewritten row is rewritten as FULL lines -- measured on C3's sweep
+// kernel: 8.33 us per sweep against 8.07 with the tight pitch (416-byte rows in fp64: the extra lines cost more than the partial
+// ones), so the tight pitch stays.
+#ifndef MHX_XW_LINE
+#define MHX_XW_LINE 0
+#endif
+MHX_HD constexpr int mhx_xw_pitch(const int d)
+{
+    const int xp = (d + 3) & ~3, rb = xp * (int)sizeof(mhx_real);
+    return (MHX_XW_LINE > 0 && rb >= MHX_XW_LINE) ? ((rb + MHX_XW_LINE - 1) / MHX_XW_LINE) * MHX_XW_LINE / (int)sizeof(mhx_real) : xp;
+}
+
 #ifndef MHX_PROP_ISO
 #define MHX_PROP_ISO   0
 #define MHX_PROP_DIAG  1
@@ -105,9 +118,9 @@ MHX_DEV void mhx_emcee_half_body(const mhx_emcee_args& a, const mhx_real* __rest
     constexpr int XP = D > 0 ? ((D + 3) & ~3) : 4;
     mhx_real yreg[XP];
     mhx_real* ys = a.ybuf + i;
-    mhx_e4* xrow_i = D > 0 ? (mhx_e4*)(a.xw + (long)i * XP) : nullptr;
+    mhx_e4* xrow_i = D > 0 ? (mhx_e4*)(a.xw + (long)i * mhx_xw_pitch(D)) : nullptr;
     if (D > 0) {
-        const mhx_e4* xrow_j = (const mhx_e4*)(a.xw + (long)j * XP);
+        const mhx_e4* xrow_j = (const mhx_e4*)(a.xw + (long)j * mhx_xw_pitch(D));
 #pragma unroll
         for (int q = 0; q < XP / 4; ++q) {
             const mhx_e4 xi = xrow_i[q], xj = xrow_j[q];                  // the zero pad of the rows stays zero
@@ -151,7 +164,7 @@ MHX_DEV void mhx_emcee_half_body(const mhx_emcee_args& a, const mhx_real* __rest
         mhx_real* row = a.samples + a.save_slot * (long)(d + 1) * ld + i;
         if (D > 0) {
 #pragma unroll
-            for (int k = 0; k < D; ++k) row[(long)k * ld] = acc ? yreg[k] : a.xw[(long)i * XP + k];
+            for (int k = 0; k < D; ++k) row[(long)k * ld] = acc ? yreg[k] : a.xw[(long)i * mhx_xw_pitch(D) + k];
         } else {
             for (int k = 0; k < d; ++k) row[(long)k * ld] = a.x[(long)k * ld + i];
         }
@@ -423,6 +436,14 @@ MHX_DEV mhx_real mhx_band_rows_sq(const mhx_real (&ab)[mhx_emcee_geom<D, L>::NK]
 #else
 #define MHX_REC_ST(p, v) (*(p) = (v))
 #endif
+#ifndef MHX_EMCEE_ROW_STORE
+#define MHX_EMCEE_ROW_STORE 1       // tuning knob (sweep kernels): how the new rows leave -- 0 plain stores, 1 non-temporal (8.34 -> 8.09 us per sweep on C3)
+#endif
+#if MHX_EMCEE_ROW_STORE == 1
+#define MHX_ROW_ST(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define MHX_ROW_ST(p, v) (*(p) = (v))
+#endif
 #ifndef MHX_EMCEE_COOP_REC
 #define MHX_EMCEE_COOP_REC 0                 // how the record leaves the lane-group form: 0 straight from the lanes (4-walker runs), 1 through the block's LDS (a block barrier: measured slower here, 5.96 against 5.27 us on C3 -- the waves of this form do not otherwise wait for each other; it pays in the scalar-factor form, which has its barriers anyway)
 #endif
@@ -463,7 +484,7 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const mhx_real* __rest
     // the walker's own row does not wait for the draw (the partner's does): its loads go out first
     constexpr int NQ = GEO::NQ, NQL = GEO::NQL;
     mhx_e4 xs[NQL], ysl[NQL];
-    mhx_e4* xrow_i = (mhx_e4*)(a.xw + (long)i * GEO::XP);
+    mhx_e4* xrow_i = (mhx_e4*)(a.xw + (long)i * mhx_xw_pitch(D));
     {
         const mhx_e4 zero4 = {MHX_R(0.0), MHX_R(0.0), MHX_R(0.0), MHX_R(0.0)};
 #pragma unroll
@@ -477,7 +498,7 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const mhx_real* __rest
     mhx_real lpo = MHX_R(0.0);
     unsigned char lao = 0;
     if (io >= 0) {
-        const mhx_e4* xrow_o = (const mhx_e4*)(a.xw + (long)io * GEO::XP);
+        const mhx_e4* xrow_o = (const mhx_e4*)(a.xw + (long)io * mhx_xw_pitch(D));
 #pragma unroll
         for (int m = 0; m < mhx_emcee_geom<D, L>::NQL; ++m) { const int q4 = l + L * m; if (q4 < mhx_emcee_geom<D, L>::NQ) xo[m] = xrow_o[q4]; }
         if (l == 0) { lpo = a.lp[io]; lao = a.last_acc[io]; }
@@ -494,7 +515,7 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const mhx_real* __rest
     // the move, element-wise on float4 slices of the two rows (lane l: float4 l, l+L, ...); the zero pad of
     // the rows gives the zero pad of y that multiplies the zeros of the factor image
     mhx_real* yrow = ysh + cw * DP4;
-    const mhx_e4* xrow_j = (const mhx_e4*)(a.xw + (long)j * GEO::XP);
+    const mhx_e4* xrow_j = (const mhx_e4*)(a.xw + (long)j * mhx_xw_pitch(D));
 #pragma unroll
     for (int m = 0; m < NQL; ++m) {
         const int q4 = l + L * m;
@@ -530,7 +551,7 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const mhx_real* __rest
         if (valid && t_raw + cnt < osize) {
             const int ie = ostart + t_raw + cnt;
             mhx_e4 xe[mhx_emcee_geom<D, L>::NQL];
-            const mhx_e4* xrow_e = (const mhx_e4*)(a.xw + (long)ie * GEO::XP);
+            const mhx_e4* xrow_e = (const mhx_e4*)(a.xw + (long)ie * mhx_xw_pitch(D));
 #pragma unroll
             for (int m = 0; m < NQL; ++m) { const int q4 = l + L * m; if (q4 < NQ) xe[m] = xrow_e[q4]; }
             rec(ie, xe, l == 0 ? a.lp[ie] : MHX_R(0.0), l == 0 ? a.last_acc[ie] : (unsigned char)0);
@@ -655,7 +676,7 @@ MHX_DEV void mhx_emcee_coop_sweep_body(const mhx_emcee_args& a, const mhx_real* 
     const mhx_e4 zero4 = {MHX_R(0.0), MHX_R(0.0), MHX_R(0.0), MHX_R(0.0)};
 
     mhx_e4 xs[NQL], ysl[NQL];
-    const mhx_e4* xrow_i = (const mhx_e4*)(a.xw + (long)i * GEO::XP);
+    const mhx_e4* xrow_i = (const mhx_e4*)(a.xw + (long)i * mhx_xw_pitch(D));
 #pragma unroll
     for (int m = 0; m < NQL; ++m) { const int q4 = l + L * m; xs[m] = q4 < NQ ? xrow_i[q4] : zero4; }
     const mhx_real lpi = a.lp[i];
@@ -668,7 +689,7 @@ MHX_DEV void mhx_emcee_coop_sweep_body(const mhx_emcee_args& a, const mhx_real* 
     const mhx_real tt = mhx_fma(a.stretch - MHX_R(1.0), dr.u, MHX_R(1.0));
     const mhx_real z = (tt * tt) / a.stretch;                               // src/emcee.jl:81
     const mhx_real alphamult = (mhx_real)(D - 1) * mhx_log(z);              // :82
-    const mhx_e4* xrow_j = (const mhx_e4*)(a.xw + (long)j * GEO::XP);
+    const mhx_e4* xrow_j = (const mhx_e4*)(a.xw + (long)j * mhx_xw_pitch(D));
     MHX_PROBE(2, alphamult + (mhx_real)j + xs[0].x + lpi);                  // launch, own row, the draws
     auto stretch = [](const mhx_real zz, const mhx_e4 xi, const mhx_e4 xj) {   // :85, element-wise
         mhx_e4 y;
@@ -708,7 +729,7 @@ MHX_DEV void mhx_emcee_coop_sweep_body(const mhx_emcee_args& a, const mhx_real* 
         // j is a walker of the first half: its own move of this sweep, from the state this launch found
         const mhx_emcee_draws da = mhx_emcee_draw(ks, (mhx_u32)j, (mhx_u32)a.ensemble_id, a.sweep);
         const int jb = halfW + (int)(((mhx_u64)da.partner * (mhx_u64)(mhx_u32)cntB) >> 32);
-        const mhx_e4* xrow_b = (const mhx_e4*)(a.xw + (long)jb * GEO::XP);
+        const mhx_e4* xrow_b = (const mhx_e4*)(a.xw + (long)jb * mhx_xw_pitch(D));
         const mhx_real lpa = a.lp[j];
         const mhx_real ta = mhx_fma(a.stretch - MHX_R(1.0), da.u, MHX_R(1.0));
         const mhx_real za = (ta * ta) / a.stretch;
@@ -749,14 +770,14 @@ MHX_DEV void mhx_emcee_coop_sweep_body(const mhx_emcee_args& a, const mhx_real* 
     const mhx_real alpha = (alphamult + lpy) - lpi;                         // :91
     const bool acc = dr.logu <= alpha;                                      // :93
     if (valid) {
-        mhx_e4* xrow_o = (mhx_e4*)(a.xw_out + (long)i * GEO::XP);
+        mhx_e4* xrow_o = (mhx_e4*)(a.xw_out + (long)i * mhx_xw_pitch(D));
 #pragma unroll
         for (int m = 0; m < NQL; ++m) {
             const int q4 = l + L * m;
             mhx_e4 v;
             v.x = acc ? ysl[m].x : xs[m].x; v.y = acc ? ysl[m].y : xs[m].y; v.z = acc ? ysl[m].z : xs[m].z; v.w = acc ? ysl[m].w : xs[m].w;
             ysl[m] = v;
-            if (q4 < NQ && (acc || (moved_before && MHX_EMCEE_PROBE < 7))) xrow_o[q4] = v;      // (probes 7, 8: timing only, accepted rows alone)
+            if (q4 < NQ && (acc || (moved_before && MHX_EMCEE_PROBE < 7))) MHX_ROW_ST(&xrow_o[q4], v);      // (probes 7, 8: timing only, accepted rows alone)
         }
         if (l == 0) {
             a.lp_out[i] = acc ? lpy : lpi;
@@ -1058,7 +1079,7 @@ MHX_DEV void mhx_emcee_scal_body(const mhx_emcee_args& a, const mhx_real* __rest
     const long ld = W;
     MHX_PROBE(1, (mhx_real)i);
     mhx_e4 xs[NQL], xjs[NQL], ysl[NQL];
-    mhx_e4* xrow_i = (mhx_e4*)(a.xw + (long)i * XP);
+    mhx_e4* xrow_i = (mhx_e4*)(a.xw + (long)i * mhx_xw_pitch(D));
     const mhx_e4 zero4 = {MHX_R(0.0), MHX_R(0.0), MHX_R(0.0), MHX_R(0.0)};
 #pragma unroll
     for (int m = 0; m < NQL; ++m) { const int q4 = l + LM * m; xs[m] = q4 < NQ ? xrow_i[q4] : zero4; }
@@ -1067,7 +1088,7 @@ MHX_DEV void mhx_emcee_scal_body(const mhx_emcee_args& a, const mhx_real* __rest
     const mhx_philox_key ks = mhx_philox_schedule(a.seed);
     const mhx_emcee_draws dr = mhx_emcee_draw(ks, (mhx_u32)i, (mhx_u32)a.ensemble_id, a.sweep);
     const int j = ostart + (int)(((mhx_u64)dr.partner * (mhx_u64)(mhx_u32)osize) >> 32);
-    const mhx_e4* xrow_j = (const mhx_e4*)(a.xw + (long)j * XP);
+    const mhx_e4* xrow_j = (const mhx_e4*)(a.xw + (long)j * mhx_xw_pitch(D));
 #pragma unroll
     for (int m = 0; m < NQL; ++m) { const int q4 = l + LM * m; xjs[m] = q4 < NQ ? xrow_j[q4] : zero4; }
     __builtin_amdgcn_sched_barrier(0);

@@ -323,6 +323,44 @@ def test_banded_precision_factor_is_detected_and_bit_identical(mhx, oracle, real
     _same(band.accepted, ref["accepted"], "accepted vs oracle")
 
 
+@pytest.mark.parametrize("d,W,bw,lanes", [(50, 256, 1, 0), (50, 131, 1, 16), (12, 130, 2, 4), (33, 193, 5, 8), (20, 96, 0, 0), (7, 3, 1, 2),
+                                          (64, 2, 8, 16)])
+def test_one_launch_per_sweep_is_the_same_chain_as_two_half_steps(mhx, oracle, real, d, W, bw, lanes, monkeypatch):
+    """The banded lane-group form moves BOTH halves in one launch (the second half's groups re-do their partner's move from the
+    old state; walker rows double-buffered, only rows the other buffer does not hold are stored): the same tensor, accept flags
+    and counters as two half-step launches (MHX_EMCEE_FUSED=0) and as the oracle's split sweep -- odd W, ensembles smaller than a
+    block, thinning + a discarded prefix, a continued call, a state handed in from outside in between."""
+    Sig = cases.sigma_ar1(d, 0.9) if bw == 1 else (_banded_sigma(d, bw, d) if bw else np.diag(np.linspace(0.5, 2.0, d)))
+    init = cases.emcee_init(d, W, 5)
+    model = mhx.DensityModel(mhx.CorrGaussian(Sig))
+    spl = mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I)))
+
+    def go(fused):
+        monkeypatch.setenv("MHX_EMCEE_FUSED", "1" if fused else "0")
+        r = mhx.Run(model, spl, seed=9, reduce_lanes=lanes)
+        r.init(init)
+        l0 = r.stats()["launches"]
+        r.sample(6, 3, 2, 0)                                   # 3 discarded, every 2nd of the rest
+        a = r.samples() + (r.stats()["launches"] - l0,)
+        r.sample(4, 0, 1, 0)                                   # continued: the first launch finds the other buffer stale
+        b = r.samples()
+        x, lp, cnt = r.state()
+        r.set_params(x[:, ::-1].copy())                        # walkers handed in from outside (reversed order)
+        r.sample(3, 0, 1, 0)
+        c = r.samples() + (r.state()[2], r.stats()["reduce_lanes"])
+        return a, b, c
+
+    f, u = go(True), go(False)
+    assert f[0][2] in (13, 14) and u[0][2] == 2 * f[0][2], (f[0][2], u[0][2])           # one launch per sweep against two
+    for k, (pf, pu) in enumerate(zip(f, u)):
+        _same(pf[0], pu[0], "samples, call %d" % k)
+        _same(pf[1], pu[1], "accepted, call %d" % k)
+    _same(f[2][2], u[2][2], "acceptance counters")
+    ref = oracle.emcee(oracle.corr_gauss_from_cov(Sig, reduce_lanes=f[2][3]), 2.0, 1, oracle.schedule(6, 3, 2), 9, 0, W, init)
+    _same(f[0][0], ref["samples"], "one launch per sweep vs oracle")
+    _same(f[0][1], ref["accepted"], "accepted vs oracle")
+
+
 def test_a_dense_factor_keeps_the_dense_form(mhx):
     d, W = 24, 128
     rng = np.random.default_rng(3)
