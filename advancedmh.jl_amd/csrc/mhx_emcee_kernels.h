@@ -1229,6 +1229,200 @@ MHX_DEV void mhx_emcee_scal_body(const mhx_emcee_args& a, const mhx_real* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
+// The scalar-factor form as ONE LAUNCH PER SWEEP (see mhx_emcee_coop_sweep_body for the idea: the groups of the second half re-do
+// their partners' moves from the old state; all three candidates of such a walker -- the partner's, and its own for both outcomes
+// of the partner's accept test -- go through phase 2 side by side).  The row products are what this form is bound by in fp64 (a
+// v_fmac_f64_dpp issues every 8 cycles, and phase 2 runs on 64 lanes whatever the number of candidate rows), so a block is MIXED:
+// WPB / 2 walkers of the second half (three candidate rows each) and WPB / 2 of the first (one row) -- with WPB = 32 exactly 64 rows,
+// every lane of phase 2 busy (the half-step kernel runs it half empty at this size), ONE pass.  Waves [0, NW / 2) hold the second
+// half's walkers in the move mapping.  Rows in LDS: [0, HB) the partners' candidates, [HB, 2 HB) own against x_a, [2 HB, 3 HB) own
+// against y_a, [3 HB, 4 HB) the first half's candidates.  State double-buffered as in the lane-group form (xw / lp read, xw_out /
+// lp_out written; rows the other buffer already holds are not stored).  DPP operand mode, WPB = 32 (the latency shape) only.
+template <int D, int NW>
+MHX_DEV void mhx_emcee_scal_sweep_body(const mhx_emcee_args& a, const mhx_real* __restrict__ A, mhx_real* lds)
+{
+    typedef mhx_emcee_sgeom<D, NW> GEO;
+    constexpr int XP = GEO::XP, NQ = GEO::NQ, NQL = GEO::NQL, YS = GEO::YS, WPB = GEO::WPB, LM = GEO::LM;
+    constexpr int HB = WPB / 2;                  // walkers of each half per block
+    static_assert(WPB == 32, "the mixed block fills the 64 lanes of phase 2 with 2 WPB candidate rows");
+    mhx_real* ysh = lds;                         // [2 WPB][YS]
+    mhx_real* qsh = lds + 2 * WPB * YS;          // [NW][64]
+    mhx_real* fin = qsh + NW * 64;               // [2][WPB]: lp and accept flag of the final rows (the record's tail)
+    const int tid = threadIdx.x;
+    const int g = __builtin_amdgcn_readfirstlane(tid >> 6);                  // this wave's row class in phase 2
+    const int wm = tid / LM, l = tid % LM;
+    const bool second = __builtin_amdgcn_readfirstlane(wm < HB ? 1 : 0) != 0;   // (wave-uniform: LM lanes per walker, 64 / LM walkers per wave)
+    const int ws = second ? wm : wm - HB;                                    // walker of its half within the block
+    const int W = a.nwalkers;
+    const int halfW = W / 2, cntB = W - halfW;
+    const int cnt = second ? cntB : halfW;
+    const int t_raw = (int)blockIdx.x * HB + ws;
+    const bool valid = t_raw < cnt;
+    const int lo = second ? halfW : 0;
+    const int i = lo + (valid ? t_raw : cnt - 1);
+    const int r0 = second ? ws : 3 * HB + ws;                                // this walker's first candidate row
+    const long ld = W;
+    const mhx_e4 zero4 = {MHX_R(0.0), MHX_R(0.0), MHX_R(0.0), MHX_R(0.0)};
+    // ---- phase 1 (LM lanes per walker): every address is a function of the counters -- own row, partner's row, and (second
+    // half) the partner's partner's row go out before anything has come back; then this wave's pieces of the factor
+    mhx_e4 xs[NQL], xjs[NQL], xbs[NQL], ysl[NQL], y1[NQL];
+    const mhx_e4* xrow_i = (const mhx_e4*)(a.xw + (long)i * mhx_xw_pitch(D));
+#pragma unroll
+    for (int m = 0; m < NQL; ++m) { const int q4 = l + LM * m; xs[m] = q4 < NQ ? xrow_i[q4] : zero4; }
+    const mhx_real lpi = a.lp[i];
+    const mhx_u32 acc_i = a.acc_count[i];
+    const bool moved_before = a.all_rows != 0 || a.last_acc[i] != 0;         // xw_out does not hold this walker's row
+    const mhx_philox_key ks = mhx_philox_schedule(a.seed);
+    const mhx_emcee_draws dr = mhx_emcee_draw(ks, (mhx_u32)i, (mhx_u32)a.ensemble_id, a.sweep);
+    const int j = (second ? 0 : halfW) + (int)(((mhx_u64)dr.partner * (mhx_u64)(mhx_u32)(second ? halfW : cntB)) >> 32);
+    const mhx_e4* xrow_j = (const mhx_e4*)(a.xw + (long)j * mhx_xw_pitch(D));
+#pragma unroll
+    for (int m = 0; m < NQL; ++m) { const int q4 = l + LM * m; xjs[m] = q4 < NQ ? xrow_j[q4] : zero4; }
+    mhx_emcee_draws da = dr;
+    mhx_real lpa = MHX_R(0.0);
+    if (second) {
+        da = mhx_emcee_draw(ks, (mhx_u32)j, (mhx_u32)a.ensemble_id, a.sweep);   // j's own draws of this sweep (j is of the first half)
+        const int jb = halfW + (int)(((mhx_u64)da.partner * (mhx_u64)(mhx_u32)cntB) >> 32);
+        const mhx_e4* xrow_b = (const mhx_e4*)(a.xw + (long)jb * mhx_xw_pitch(D));
+#pragma unroll
+        for (int m = 0; m < NQL; ++m) { const int q4 = l + LM * m; xbs[m] = q4 < NQ ? xrow_b[q4] : zero4; }
+        lpa = a.lp[j];
+    }
+    MHX_PROBE(2, (mhx_real)j + xs[0].x + lpi + lpa + da.u);                  // launch, own row, the draws' integer part
+    __builtin_amdgcn_sched_barrier(0);
+    mhx_real av[mhx_bcast_geom<D, NW>::NRMAX][mhx_bcast_geom<D, NW>::CHMAX];
+    mhx_bcast_load<D, NW>(g, A, tid & 15, av);                               // in flight until phase 2
+    __builtin_amdgcn_sched_barrier(0);
+    const mhx_real tt = mhx_fma(a.stretch - MHX_R(1.0), dr.u, MHX_R(1.0));
+    const mhx_real z = (tt * tt) / a.stretch;                                // src/emcee.jl:81
+    const mhx_real alphamult = (mhx_real)(D - 1) * mhx_log(z);               // :82
+    auto stretch = [](const mhx_real zz, const mhx_e4 xi, const mhx_e4 xj) {   // :85, element-wise
+        mhx_e4 y;
+        y.x = mhx_fma(zz, xi.x - xj.x, xj.x);
+        y.y = mhx_fma(zz, xi.y - xj.y, xj.y);
+        y.z = mhx_fma(zz, xi.z - xj.z, xj.z);
+        y.w = mhx_fma(zz, xi.w - xj.w, xj.w);
+        return y;
+    };
+    auto put = [](mhx_real* row, const int q4, const mhx_e4 v) {             // (the row pitch is a multiple of 16 bytes, not of sizeof(e4) in fp64)
+        if constexpr (sizeof(mhx_real) == 8) {
+            mhx_e2 h0 = {v.x, v.y}, h1 = {v.z, v.w};
+            ((mhx_e2*)(row + 4 * q4))[0] = h0;
+            ((mhx_e2*)(row + 4 * q4))[1] = h1;
+        } else {
+            *(mhx_e4*)(row + 4 * q4) = v;
+        }
+    };
+    mhx_real* yrow = ysh + r0 * YS;
+    mhx_real alphamult_a = MHX_R(0.0);
+    if (!second) {
+#pragma unroll
+        for (int m = 0; m < NQL; ++m) {
+            const int q4 = l + LM * m;
+            ysl[m] = zero4; y1[m] = zero4;
+            if (q4 < NQ) { ysl[m] = stretch(z, xs[m], xjs[m]); put(yrow, q4, ysl[m]); }
+        }
+    } else {
+        const mhx_real ta = mhx_fma(a.stretch - MHX_R(1.0), da.u, MHX_R(1.0));
+        const mhx_real za = (ta * ta) / a.stretch;
+        alphamult_a = (mhx_real)(D - 1) * mhx_log(za);
+#pragma unroll
+        for (int m = 0; m < NQL; ++m) {
+            const int q4 = l + LM * m;
+            ysl[m] = zero4; y1[m] = zero4;
+            if (q4 < NQ) {
+                const mhx_e4 ya = stretch(za, xjs[m], xbs[m]);               // the partner's candidate
+                ysl[m] = stretch(z, xs[m], xjs[m]);                          // this walker's, if the partner stays
+                y1[m] = stretch(z, xs[m], ya);                               //                if it moves
+                put(yrow, q4, ya);
+                put(yrow + HB * YS, q4, ysl[m]);
+                put(yrow + 2 * HB * YS, q4, y1[m]);
+            }
+        }
+    }
+    MHX_PROBE(3, ysl[0].x + y1[0].x + alphamult_a);                          // + the rows, the candidates in LDS
+    __syncthreads();
+    // ---- phase 2: lane = candidate row (all 64), wave = row class
+    {
+        const int wv = tid & 63;
+        mhx_real y[XP];
+        const mhx_real* yr = ysh + wv * YS;
+        if constexpr (sizeof(mhx_real) == 8) {
+#pragma unroll
+            for (int k = 0; k < XP / 2; ++k) { const mhx_e2 v = ((const mhx_e2*)yr)[k]; y[2 * k] = v.x; y[2 * k + 1] = v.y; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < XP / 4; ++k) { const mhx_e4 v = ((const mhx_e4*)yr)[k]; y[4 * k] = v.x; y[4 * k + 1] = v.y; y[4 * k + 2] = v.z; y[4 * k + 3] = v.w; }
+        }
+        MHX_PROBE(4, y[0] + y[XP - 1]);                                      // + barrier, y in registers
+        qsh[g * 64 + wv] = mhx_bcast_rows_dispatch<D, NW>(g, av, y);
+    }
+    __syncthreads();
+    // ---- phase 3: back in the move mapping
+    auto tree = [&](const int r) {                                           // the butterfly's tree over the NW partial sums of row r
+        mhx_real qv[NW];
+#pragma unroll
+        for (int k = 0; k < NW; ++k) qv[k] = qsh[k * 64 + r];
+#pragma unroll
+        for (int off = 1; off < NW; off <<= 1)
+#pragma unroll
+            for (int k = 0; k < NW; k += 2 * off) qv[k] = qv[k] + qv[k + off];
+        return qv[0];
+    };
+    mhx_real lpy = mhx_fma(-MHX_R(0.5), tree(r0), a.tconst);
+    if (second) {
+        const bool acc_a = da.logu <= (alphamult_a + lpy) - lpa;             // the partner's accept test, as its own group runs it
+        lpy = mhx_fma(-MHX_R(0.5), acc_a ? tree(2 * HB + ws) : tree(HB + ws), a.tconst);
+#pragma unroll
+        for (int m = 0; m < NQL; ++m) {
+            ysl[m].x = acc_a ? y1[m].x : ysl[m].x; ysl[m].y = acc_a ? y1[m].y : ysl[m].y;
+            ysl[m].z = acc_a ? y1[m].z : ysl[m].z; ysl[m].w = acc_a ? y1[m].w : ysl[m].w;
+        }
+    }
+    MHX_PROBE(5, lpy + ysl[0].x);                                            // + the row products, the trees
+    const mhx_real alpha = (alphamult + lpy) - lpi;                          // :91
+    const bool acc = dr.logu <= alpha;                                       // :93
+#pragma unroll
+    for (int m = 0; m < NQL; ++m) {
+        ysl[m].x = acc ? ysl[m].x : xs[m].x; ysl[m].y = acc ? ysl[m].y : xs[m].y;
+        ysl[m].z = acc ? ysl[m].z : xs[m].z; ysl[m].w = acc ? ysl[m].w : xs[m].w;
+    }
+    if (valid) {
+        mhx_e4* xrow_o = (mhx_e4*)(a.xw_out + (long)i * mhx_xw_pitch(D));
+        if (acc || moved_before) {
+#pragma unroll
+            for (int m = 0; m < NQL; ++m) { const int q4 = l + LM * m; if (q4 < NQ) MHX_ROW_ST(&xrow_o[q4], ysl[m]); }
+        }
+        if (l == 0) {
+            a.lp_out[i] = acc ? lpy : lpi;
+            if (acc) a.acc_count[i] = acc_i + 1u;
+            a.last_acc[i] = acc ? 1 : 0;
+        }
+    }
+    if (MHX_EMCEE_PROBE == 6) return;                                        // + accept and the new state, no record
+    if (a.save_slot >= 0) {                                                 // (uniform)
+        // the record leaves as whole row segments through the block's LDS: the final row replaces the walker's first candidate row
+        // (phase 2 is past it), then every row k of the [dim+1][W] record is written for the HB consecutive walkers of each half
+#pragma unroll
+        for (int m = 0; m < NQL; ++m) { const int q4 = l + LM * m; if (q4 < NQ) put(yrow, q4, ysl[m]); }
+        if (l == 0) fin[wm] = acc ? lpy : lpi;
+        if (l == 1 || LM == 1) fin[WPB + wm] = acc ? MHX_R(1.0) : MHX_R(0.0);
+        __syncthreads();
+        const int wr = tid % WPB, kk = tid / WPB;                            // walker slot of the block, first row of this thread
+        const bool sec = wr < HB;
+        const int tw = (int)blockIdx.x * HB + (sec ? wr : wr - HB);
+        if (tw < (sec ? cntB : halfW)) {
+            const mhx_real* frow = ysh + (sec ? wr : 3 * HB + (wr - HB)) * YS;
+            const long iw = (sec ? halfW : 0) + tw;
+            mhx_real* col = a.samples + a.save_slot * (long)(D + 1) * ld + iw;
+#pragma unroll
+            for (int k = kk; k < D + 1; k += LM) MHX_REC_ST(&col[(long)k * ld], k < D ? frow[k] : fin[wr]);
+            if (kk == LM - 1) a.accepted[a.save_slot * ld + iw] = fin[WPB + wr] != MHX_R(0.0) ? 1 : 0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // The reference's OWN sweep (src/emcee.jl:39-58): walkers move one after another, walker i pairs with idx = mod1(i + r, W),
 // r uniform on 1..W-1, and uses the ALREADY UPDATED position when idx < i (:53) -- Gauss-Seidel, serial in W by
 // construction.  One wave runs the whole schedule of a launch: lanes share the copy of a move's rows, lane 0 evaluates
@@ -1339,6 +1533,15 @@ mhx_jit_emcee_half(const mhx_emcee_args a, const mhx_real* __restrict__ tparams)
     mhx_emcee_half_body<MHX_JIT_DIM, MHX_JIT_TK>(a, tparams);
 #endif
 }
+#if MHX_JIT_SCAL && MHX_EMCEE_SCAL_MODE == 1 && MHX_EMCEE_SCAL_WPB == 32
+// one launch per sweep (scalar-factor form, mixed blocks): LDS = [64] candidate rows, [NW][64] partial sums, [2][WPB] lp and flag
+extern "C" __global__ void __launch_bounds__(64 * MHX_JIT_L)
+mhx_jit_emcee_sweep(const mhx_emcee_args a, const mhx_real* __restrict__ tparams)
+{
+    extern __shared__ mhx_e4 mhx_emcee_lds[];
+    mhx_emcee_scal_sweep_body<MHX_JIT_DIM, MHX_JIT_L>(a, tparams, (mhx_real*)mhx_emcee_lds);
+}
+#endif
 #if !MHX_JIT_SCAL && MHX_JIT_L > 1
 // one launch per sweep (lane-group form): three candidate rows per walker in LDS, then the factor image
 extern "C" __global__ void __launch_bounds__(64 * MHX_EMCEE_COOP_WAVES)

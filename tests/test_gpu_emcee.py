@@ -361,6 +361,40 @@ def test_one_launch_per_sweep_is_the_same_chain_as_two_half_steps(mhx, oracle, r
     _same(f[0][1], ref["accepted"], "accepted vs oracle")
 
 
+@pytest.mark.parametrize("d,W,knobs", [(50, 200, {}), (17, 71, {}), (64, 129, {}), (33, 64, {"MHX_EMCEE_SCALAR": "4"}),
+                                       (16, 66, {"MHX_EMCEE_SCALAR": "16"}), (24, 3, {}), (50, 2, {}), (12, 33, {})])
+def test_scalar_factor_form_one_launch_per_sweep(mhx, oracle, real, d, W, knobs, monkeypatch):
+    """The scalar-factor form (dense factor) with both halves in one launch: mixed blocks of 16 walkers of each half, the second
+    half's carry three candidate rows each through phase 2 (64 rows: every lane busy).  Same tensor as two half-step launches and
+    as the oracle; 4 / 8 / 16 row classes, odd W, ensembles smaller than a block, a continued call."""
+    Sig = _rotated(d)
+    init = cases.emcee_init(d, W, 5)
+    model = mhx.DensityModel(mhx.CorrGaussian(Sig))
+    spl = mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I)))
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+
+    def go(fused):
+        monkeypatch.setenv("MHX_EMCEE_FUSED", "1" if fused else "0")
+        r = mhx.Run(model, spl, seed=11)
+        r.init(init)
+        l0 = r.stats()["launches"]
+        r.sample(5, 2, 2, 0)
+        a = r.samples() + (r.stats()["launches"] - l0,)
+        r.sample(3, 0, 1, 0)
+        return a, r.samples() + (r.state()[2], r.stats())
+
+    f, u = go(True), go(False)
+    assert f[1][3]["kernel_variant"] == 9 and u[0][2] == 2 * f[0][2], (f[1][3], f[0][2], u[0][2])
+    for k in range(2):
+        _same(f[k][0], u[k][0], "samples, call %d" % k)
+        _same(f[k][1], u[k][1], "accepted, call %d" % k)
+    _same(f[1][2], u[1][2], "acceptance counters")
+    ref = oracle.emcee(oracle.corr_gauss_from_cov(Sig, reduce_lanes=f[1][3]["reduce_lanes"]), 2.0, 1, oracle.schedule(5, 2, 2), 11, 0, W, init)
+    _same(f[0][0], ref["samples"], "one launch per sweep vs oracle")
+    _same(f[0][1], ref["accepted"], "accepted vs oracle")
+
+
 def test_a_dense_factor_keeps_the_dense_form(mhx):
     d, W = 24, 128
     rng = np.random.default_rng(3)
