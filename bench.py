@@ -303,9 +303,11 @@ class C3:
         return self.W * self.inner * (3 * B * self.d + 2 * B + B * (self.d + 1) + 1)
 
     def describe(self):
-        band = self.run.stats().get("factor_band", -1) if hasattr(self, "run") else -1
-        return "emcee stretch a=2, d=%d Gaussian %s, %d walkers (one ensemble/GPU), %d sweeps/step, save-all, half-split sweep, factor %s" % (
-            self.d, "Q(0.9^|i-j|)Q^T" if self.rotated else "0.9^|i-j|", self.W, self.inner, "band %d" % band if band >= 0 else "dense")
+        st = self.run.stats() if hasattr(self, "run") else {}
+        band = st.get("factor_band", -1)
+        per_sweep = "one launch per sweep" if 0 < st.get("launches", 0) <= self.inner else "two launches per sweep"
+        return "emcee stretch a=2, d=%d Gaussian %s, %d walkers (one ensemble/GPU), %d sweeps/step, save-all, half-split sweep (%s), factor %s" % (
+            self.d, "Q(0.9^|i-j|)Q^T" if self.rotated else "0.9^|i-j|", self.W, self.inner, per_sweep, "band %d" % band if band >= 0 else "dense")
 
     def cpu_baseline(self, O, target_seconds):
         import numpy as np
