@@ -175,6 +175,107 @@ MHX_DEV void mhx_emcee_half_body(const mhx_emcee_args& a, const mhx_real* __rest
     // cooperative kernel below for why there is no per-wave atomic in these short launches)
 }
 
+// The same kernel as ONE LAUNCH PER SWEEP (round 4; the idea and the double-buffered state are described at
+// mhx_emcee_coop_sweep_body): blocks [0, nbB) move the second half, whose lanes first re-do their partner's move from the old
+// state -- a second evaluation of the log-density (any target, user source included) instead of a second launch -- and then move
+// against its result.  Two candidates live in registers at a time; rows that are needed again are re-read (they are in L1 / L2).
+template <int D, int TK>
+MHX_DEV void mhx_emcee_sweep_reg_body(const mhx_emcee_args& a, const mhx_real* __restrict__ tparams)
+{
+    static_assert(D > 0, "the sweep kernel works on the walker-major rows of the compile-time-dimension form");
+    const int W = a.nwalkers;
+    const int halfW = W / 2, cntB = W - halfW;
+    const int nbB = (cntB + (int)blockDim.x - 1) / (int)blockDim.x;
+    const bool second = (int)blockIdx.x < nbB;                               // (block-uniform)
+    const int blk = second ? (int)blockIdx.x : (int)blockIdx.x - nbB;
+    const int cnt = second ? cntB : halfW;
+    const int t = blk * (int)blockDim.x + (int)threadIdx.x;
+    if (t >= cnt) return;
+    const int i = (second ? halfW : 0) + t;
+    const long ld = W;
+    constexpr int XP = (D + 3) & ~3;
+    const mhx_philox_key ks = mhx_philox_schedule(a.seed);
+    const mhx_emcee_draws dr = mhx_emcee_draw(ks, (mhx_u32)i, (mhx_u32)a.ensemble_id, a.sweep);
+    const int j = (second ? 0 : halfW) + (int)(((mhx_u64)dr.partner * (mhx_u64)(mhx_u32)(second ? halfW : cntB)) >> 32);
+    const mhx_real tt = mhx_fma(a.stretch - MHX_R(1.0), dr.u, MHX_R(1.0));
+    const mhx_real z = (tt * tt) / a.stretch;                                // src/emcee.jl:81
+    const mhx_real alphamult = (mhx_real)(D - 1) * mhx_log(z);               // :82
+    const mhx_e4* xrow_i = (const mhx_e4*)(a.xw + (long)i * mhx_xw_pitch(D));
+    const mhx_e4* xrow_j = (const mhx_e4*)(a.xw + (long)j * mhx_xw_pitch(D));
+    const mhx_real lpi = a.lp[i];
+    const bool moved_before = a.all_rows != 0 || a.last_acc[i] != 0;         // xw_out does not hold this walker's row
+    mhx_real yreg[XP];
+    if (!second) {
+#pragma unroll
+        for (int q = 0; q < XP / 4; ++q) {
+            const mhx_e4 xi = xrow_i[q], xj = xrow_j[q];                     // the zero pad of the rows stays zero
+            yreg[4 * q + 0] = mhx_fma(z, xi.x - xj.x, xj.x);                 // :85
+            yreg[4 * q + 1] = mhx_fma(z, xi.y - xj.y, xj.y);
+            yreg[4 * q + 2] = mhx_fma(z, xi.z - xj.z, xj.z);
+            yreg[4 * q + 3] = mhx_fma(z, xi.w - xj.w, xj.w);
+        }
+    } else {
+        // j is a walker of the first half: its own move of this sweep, from the state this launch found
+        const mhx_emcee_draws da = mhx_emcee_draw(ks, (mhx_u32)j, (mhx_u32)a.ensemble_id, a.sweep);
+        const int jb = halfW + (int)(((mhx_u64)da.partner * (mhx_u64)(mhx_u32)cntB) >> 32);
+        const mhx_e4* xrow_b = (const mhx_e4*)(a.xw + (long)jb * mhx_xw_pitch(D));
+        const mhx_real lpa = a.lp[j];
+        const mhx_real ta = mhx_fma(a.stretch - MHX_R(1.0), da.u, MHX_R(1.0));
+        const mhx_real za = (ta * ta) / a.stretch;
+        const mhx_real alphamult_a = (mhx_real)(D - 1) * mhx_log(za);
+        mhx_real ya[XP];
+#pragma unroll
+        for (int q = 0; q < XP / 4; ++q) {
+            const mhx_e4 xa = xrow_j[q], xb = xrow_b[q];
+            ya[4 * q + 0] = mhx_fma(za, xa.x - xb.x, xb.x);
+            ya[4 * q + 1] = mhx_fma(za, xa.y - xb.y, xb.y);
+            ya[4 * q + 2] = mhx_fma(za, xa.z - xb.z, xb.z);
+            ya[4 * q + 3] = mhx_fma(za, xa.w - xb.w, xb.w);
+        }
+        const mhx_real lpya = mhx_target_eval<TK>(TK, ya, D, tparams, a.ntparams, a.tconst);
+        const bool acc_a = da.logu <= (alphamult_a + lpya) - lpa;            // the partner's accept test (:91-93), as its own lane runs it
+#pragma unroll
+        for (int q = 0; q < XP / 4; ++q) {
+            const mhx_e4 xi = xrow_i[q], xa = xrow_j[q];
+            const mhx_real p0 = acc_a ? ya[4 * q + 0] : xa.x, p1 = acc_a ? ya[4 * q + 1] : xa.y;
+            const mhx_real p2 = acc_a ? ya[4 * q + 2] : xa.z, p3 = acc_a ? ya[4 * q + 3] : xa.w;
+            yreg[4 * q + 0] = mhx_fma(z, xi.x - p0, p0);
+            yreg[4 * q + 1] = mhx_fma(z, xi.y - p1, p1);
+            yreg[4 * q + 2] = mhx_fma(z, xi.z - p2, p2);
+            yreg[4 * q + 3] = mhx_fma(z, xi.w - p3, p3);
+        }
+    }
+    const mhx_real lpy = mhx_target_eval<TK>(TK, yreg, D, tparams, a.ntparams, a.tconst);
+    const mhx_real alpha = (alphamult + lpy) - lpi;                          // :91
+    const bool acc = dr.logu <= alpha;                                       // :93
+    if (!acc) {
+#pragma unroll
+        for (int q = 0; q < XP / 4; ++q) {
+            const mhx_e4 xi = xrow_i[q];
+            yreg[4 * q + 0] = xi.x; yreg[4 * q + 1] = xi.y; yreg[4 * q + 2] = xi.z; yreg[4 * q + 3] = xi.w;
+        }
+    }
+    if (acc || moved_before) {
+        mhx_e4* xrow_o = (mhx_e4*)(a.xw_out + (long)i * mhx_xw_pitch(D));
+#pragma unroll
+        for (int q = 0; q < XP / 4; ++q) {
+            mhx_e4 v;
+            v.x = yreg[4 * q + 0]; v.y = yreg[4 * q + 1]; v.z = yreg[4 * q + 2]; v.w = yreg[4 * q + 3];
+            xrow_o[q] = v;
+        }
+    }
+    a.lp_out[i] = acc ? lpy : lpi;
+    if (acc) a.acc_count[i] += 1u;
+    a.last_acc[i] = acc ? 1 : 0;
+    if (a.save_slot >= 0) {
+        mhx_real* row = a.samples + a.save_slot * (long)(D + 1) * ld + i;
+#pragma unroll
+        for (int k = 0; k < D; ++k) row[(long)k * ld] = yreg[k];
+        row[(long)D * ld] = acc ? lpy : lpi;
+        a.accepted[a.save_slot * ld + i] = acc ? 1 : 0;
+    }
+}
+
 // initial walkers (src/emcee.jl:29-34, :6-8): with `draw`, walker i is a draw mu + L z from the wrapped (Mv)Normal prior,
 // z from Philox stream INIT of (ensemble, i); then W log-density evaluations, accepted = false
 template <int TK>
@@ -1540,6 +1641,14 @@ mhx_jit_emcee_sweep(const mhx_emcee_args a, const mhx_real* __restrict__ tparams
 {
     extern __shared__ mhx_e4 mhx_emcee_lds[];
     mhx_emcee_scal_sweep_body<MHX_JIT_DIM, MHX_JIT_L>(a, tparams, (mhx_real*)mhx_emcee_lds);
+}
+#endif
+#if !MHX_JIT_SCAL && MHX_JIT_L == 1 && MHX_JIT_DIM > 0
+// one launch per sweep (lane per walker, any target)
+extern "C" __global__ void __launch_bounds__(64)
+mhx_jit_emcee_sweep(const mhx_emcee_args a, const mhx_real* __restrict__ tparams)
+{
+    mhx_emcee_sweep_reg_body<MHX_JIT_DIM, MHX_JIT_TK>(a, tparams);
 }
 #endif
 #if !MHX_JIT_SCAL && MHX_JIT_L > 1

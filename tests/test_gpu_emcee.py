@@ -45,7 +45,7 @@ def test_emcee_corr_gauss_bit_exact(mhx, oracle, d, W, N, flags_name, lanes, rea
         assert chain.stats["kernel_variant"] == 0 and Lx == 1
     else:
         # the register kernel holds a walker and its candidate in VGPRs: up to 64 dimensions in fp32, 32 in fp64
-        assert chain.stats["kernel_variant"] == (4 if Lx > 1 else (2 if d <= (32 if real == "f64" else 64) else 0))
+        assert chain.stats["kernel_variant"] == (4 if Lx > 1 else (2 if d <= 64 else 0))
 
 
 @pytest.mark.parametrize("lanes", [1, 0])
@@ -216,7 +216,7 @@ def test_emcee_user_log_density_walker_major_rows(mhx, oracle, d, W, real):
     init = cases.emcee_init(d, W, 2)
     spl = mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I)))
     chain = mhx.sample(model, spl, 9, seed=6, first_chain=2, initial_params=init, discard_initial=1, thinning=2)
-    assert chain.stats["kernel_variant"] == (2 if d <= (32 if real == "f64" else 64) else 0)
+    assert chain.stats["kernel_variant"] == (2 if d <= 64 else 0)
     ref = oracle.emcee(ut, 2.0, 1, oracle.schedule(9, 1, 2), 6, 2, W, init)
     _same(chain.value, ref["samples"], "samples")
     _same(chain.accepted, ref["accepted"], "accepted")
@@ -224,6 +224,47 @@ def test_emcee_user_log_density_walker_major_rows(mhx, oracle, d, W, real):
     _same(x, ref["final_x"], "final x")
     _same(lp, ref["final_lp"], "final lp")
     _same(cnt, ref["accept_counts"], "accept counts")
+
+
+@pytest.mark.parametrize("d,W,kind", [(7, 37, "user"), (50, 200, "user"), (64, 10, "user"), (3, 2, "user"), (2, 131, "iid"), (30, 66, "banana")])
+def test_lane_per_walker_kernel_one_launch_per_sweep(mhx, oracle, d, W, kind, real, monkeypatch):
+    """The register kernel (any target) with both halves in one launch: the second half's lanes evaluate the log-density twice --
+    their partner's candidate, then their own.  Same tensor as two half-step launches and as the oracle (user source, catalogue
+    targets; odd W, W = 2, blocks that hold one half's tail, a continued call)."""
+    if kind == "user":
+        data = np.concatenate([np.linspace(-1.0, 1.0, d), np.linspace(0.5, 2.0, d)]).astype(np.float32)
+        model = mhx.DensityModel(mhx.HipLogDensity(user_targets.SHIFTED_GAUSS, d, data=data))
+        tgt = user_targets.host_target(oracle, user_targets.SHIFTED_GAUSS, d, data=data)
+    elif kind == "iid":
+        data = np.random.default_rng(5).normal(size=30)
+        model = mhx.DensityModel(mhx.IIDNormal(data))
+        tgt = oracle.Target(oracle.TARGET_IID_NORMAL, 2, params=data)
+    else:
+        model = mhx.DensityModel(mhx.Banana(d, 0.03))
+        tgt = oracle.Target(oracle.TARGET_BANANA, d, params=[0.03])
+    init = cases.emcee_init(d, W, 2)
+    if kind == "iid":
+        init[1] = np.abs(init[1]) + 0.5
+    spl = mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I)))
+
+    def go(fused):
+        monkeypatch.setenv("MHX_EMCEE_FUSED", "1" if fused else "0")
+        r = mhx.Run(model, spl, seed=21, reduce_lanes=1)
+        r.init(init)
+        r.sample(5, 2, 2, 0)
+        a = r.samples() + (r.stats()["launches"],)
+        r.sample(3, 0, 1, 0)
+        return a, r.samples() + (r.state()[2], r.stats()["kernel_variant"])
+
+    f, u = go(True), go(False)
+    assert f[1][3] == 2 and u[0][2] == 2 * f[0][2], (f[1][3], f[0][2], u[0][2])
+    for k in range(2):
+        _same(f[k][0], u[k][0], "samples, call %d" % k)
+        _same(f[k][1], u[k][1], "accepted, call %d" % k)
+    _same(f[1][2], u[1][2], "acceptance counters")
+    ref = oracle.emcee(tgt, 2.0, 1, oracle.schedule(5, 2, 2), 21, 0, W, init)
+    _same(f[0][0], ref["samples"], "one launch per sweep vs oracle")
+    _same(f[0][1], ref["accepted"], "accepted vs oracle")
 
 
 @pytest.mark.parametrize("world", [2, 3, 8])
