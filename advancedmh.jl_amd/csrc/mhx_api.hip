@@ -632,6 +632,7 @@ struct mhx_run : mhx_handle_hdr {
     std::vector<std::string> coop_defs;
     // kernel choice
     int normal_gen = MHX_GEN_BOX_MULLER; // how stream bits become standard normals (MHX_FLAG_ZIGGURAT: the table ziggurat, fp64)
+    size_t reg_lds = 0;                  // dynamic LDS of the register kernel: the tail of a state that does not fit beside the candidate
     size_t coop_lds = 0;                 // dynamic LDS of the cooperative kernel (ziggurat: layer table + the step's normals)
     int coop_tr = 0;                     // ... and whether it holds the row-transposition buffer of the one / two-chains-per-wave shapes
     int coop_L = 1;                      // lanes per chain (reduction shape of the separable targets)
@@ -711,6 +712,8 @@ static int rwmh_whiten(mhx_run* r)
 // register budgets: a double takes two VGPRs
 #define MHX_REG_MAX_DIM (MHX_REAL64 ? 80 : 160)
 #define MHX_REG_MAX_DIM_DENSE (MHX_REAL64 ? 48 : 96)
+#define MHX_REG_XR_ALL (MHX_REAL64 ? 64 : 128)          // up to here the whole state stays in registers beside the candidate
+#define MHX_REG_XR_CAP (MHX_REAL64 ? 60 : 120)          // above: this many coordinates of it, the rest in LDS
 #define MHX_DENSE_COOP_MAX_DIM 256
 #define MHX_EMCEE_MAX_BAND 8                 // widest band the band form of the cooperative stretch move is specialised for
 #define MHX_LDS_PER_BLOCK 163840             // gfx950: 160 KB of LDS, all of it available to one block
@@ -848,7 +851,8 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
         return mhx_fail(MHX_EINVAL, "MHX_FLAG_ZIGGURAT: the ziggurat normal generator exists in fp64 contexts only");
     if ((cfg->flags & MHX_FLAG_ZIGGURAT) && d >= (1 << 20))      // the retry blocks are numbered (normal index << 8 | attempt) in 28 bits
         return mhx_fail(MHX_EINVAL, "MHX_FLAG_ZIGGURAT: dim must be below 2^20");
-    const int regmax = pk == MHX_PROP_DENSE ? MHX_REG_MAX_DIM_DENSE : MHX_REG_MAX_DIM;
+    int regmax = pk == MHX_PROP_DENSE ? MHX_REG_MAX_DIM_DENSE : MHX_REG_MAX_DIM;
+    if (const char* rm = getenv("MHX_REG_MAX_DIM")) regmax = atoi(rm);      // tuning knob
     const int nblk = (d + 3) / 4;
     const bool separable = tk == MHX_TARGET_ISO_GAUSS || tk == MHX_TARGET_BANANA || tk == MHX_TARGET_FUNNEL;
     // lanes per chain: cfg->reduce_lanes, or (auto) the smallest power of two that (a) keeps a lane's
@@ -1050,15 +1054,34 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
         if (tk != MHX_TARGET_USER)
             for (const auto& pb : k_prebuilt_reg)
                 if (pb.D == d && pb.TK == tk && pb.PK == pk) { r->reg_fn = pb.fn; r->variant = 1; }
+        // The candidate must be whole in a lane's registers (an arbitrary log-density reads all of it); the state need not be: above
+        // MHX_REG_XR_ALL dimensions only its first MHX_REG_XR_CAP coordinates stay in registers, the tail lives in LDS
+        // (mhx_rwmh_reg_body<..., XR>).  That carries the kernel to twice its old dimension limit -- an fp64 user log-density at
+        // d = 100 ran the state-in-HBM kernel at 4.9e8 steps/s, now 2.4e9 -- and is faster below it too (fp64 d = 80: 2.8 -> 3.3e9,
+        // fp32 d = 160: 1.6 -> 2.8e9): tools/reg_xr_sweep.sh, profiles/r04v_reg_xr_sweep.log.  ISO / DIAG proposals.
+        // -amdgpu-unroll-threshold-private: hipcc unrolls a loop over a private array only up to a cost of 2 700; a user's
+        // `for (k < d)` loop above that (d = 100 with one division per term) stays a loop, its array lands in scratch memory and
+        // the kernel runs 3 x slower (the cliff between d = 96 and d = 100 of the first measurement).
+        const bool split = d > MHX_REG_XR_ALL && d <= 2 * MHX_REG_MAX_DIM && pk != MHX_PROP_DENSE;
+        if (!getenv("MHX_REG_MAX_DIM") && split) regmax = 2 * MHX_REG_MAX_DIM;
         if (!r->variant && !(r->flags & MHX_FLAG_NO_JIT) && d <= regmax &&
             !(tk == MHX_TARGET_CORR_GAUSS && d > (MHX_REAL64 ? 32 : 64)) && !(tk == MHX_TARGET_IID_NORMAL && t->nparams > 4096)) {
             jit_module* m = nullptr;
+            int xr = split ? MHX_REG_XR_CAP : d;
+            if (const char* xe = getenv("MHX_REG_XR")) xr = std::max(0, std::min(d, atoi(xe)));      // tuning knobs
+            const char* ut = getenv("MHX_REG_UNROLL");
+            std::vector<std::string> xo;
+            if (!ut || atoi(ut) > 0) xo = {"-mllvm", std::string("-amdgpu-unroll-threshold-private=") + (ut ? ut : "100000")};
             const std::string key = "rwmh_reg/d=" + std::to_string(d) + "/tk=" + std::to_string(tk) + "/pk=" +
-                                    std::to_string(pk) + "/" + t->user_key;
+                                    std::to_string(pk) + "/xr=" + std::to_string(xr) + (ut ? std::string("/ut=") + ut : std::string()) + "/" + t->user_key;
             rc = jit_compile(ctx, key, jit_source(t, "mhx_rwmh_kernels.h"),
                              {"MHX_JIT_RWMH_REG=1", "MHX_JIT_DIM=" + std::to_string(d),
-                              "MHX_JIT_TK=" + std::to_string(tk), "MHX_JIT_PK=" + std::to_string(pk)}, &m);
+                              "MHX_JIT_TK=" + std::to_string(tk), "MHX_JIT_PK=" + std::to_string(pk), "MHX_JIT_XR=" + std::to_string(xr)}, &m, xo);
             if (rc == MHX_OK) rc = jit_function(m, "mhx_jit_rwmh_reg", &r->jit_step);
+            r->reg_lds = (size_t)(d - xr) * 64 * sizeof(mhx_real);
+            if (rc == MHX_OK && r->reg_lds > 65536 &&
+                hipFuncSetAttribute((const void*)r->jit_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->reg_lds) != hipSuccess)
+                rc = mhx_fail(MHX_EHIP, "register kernel: %zu bytes of LDS refused", r->reg_lds);
             if (rc == MHX_OK) r->variant = 2;
             else if (tk == MHX_TARGET_USER) return rc;      // no pre-built kernel can run a user source
             // built-in target: the generic kernel below computes the same chain; keep the message
@@ -1190,8 +1213,7 @@ static int rwmh_advance(mhx_run* r, uint64_t nsteps, uint32_t save_next, int sav
         } else if (r->variant == 2) {
             const unsigned grid = (unsigned)((r->n + 63) / 64);
             void* params[] = {&a, &tp, &pv};
-            int rc = launch_module(r->jit_step, grid, 64, ctx->stream, params);
-            if (rc) return rc;
+            HIP_TRY(hipModuleLaunchKernel(r->jit_step, grid, 1, 1, 64, 1, 1, (unsigned)r->reg_lds, ctx->stream, params, nullptr));
         } else if (r->target->kind == MHX_TARGET_USER) {
             const unsigned grid = (unsigned)((r->n + 255) / 256);
             void* params[] = {&a, &tp, &pv};

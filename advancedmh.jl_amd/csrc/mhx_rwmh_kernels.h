@@ -86,21 +86,31 @@ MHX_DEV void mhx_welford(mhx_real x, mhx_real rn, mhx_real& mean, mhx_real& m2)
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int D, int TK, int PK>
+// XR < D (round 4): the candidate y must be whole in a lane's registers (an arbitrary log-density reads all of it), the STATE need
+// not be -- it is read once per step to form the candidate and written where a move is accepted.  Its first XR coordinates stay in
+// registers, the rest live in the block's LDS as [k][lane] (one wave per block: conflict-free columns), so that x, y and the
+// generator's temporaries fit 512 VGPRs without spilling: fp64 user targets of 80 < d <= 160 (fp32: 160 < d <= 320) run here
+// instead of on the state-in-HBM kernel (d = 100, 65 536 chains, fp64: 4.9e8 -> see DESIGN 6.1).  Same arithmetic, same chains.
+template <int D, int TK, int PK, int XR = D>
 MHX_DEV void mhx_rwmh_reg_body(const mhx_rwmh_args& a, const mhx_real* __restrict__ tparams,
-                               const mhx_real* __restrict__ pvec)
+                               const mhx_real* __restrict__ pvec, mhx_real* xl = nullptr)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if constexpr (XR < D) xl += threadIdx.x;                  // this lane's column of the [D - XR][64] state tail
     if (c >= a.nchains) return;
     const mhx_u64 id = a.first_chain + (mhx_u64)c;
     const mhx_u32 id_lo = (mhx_u32)id, id_hi = (mhx_u32)(id >> 32);
     const mhx_philox_key ks = mhx_philox_schedule(a.seed);
     const long ld = a.ld;
 
-    mhx_real x[D], y[D];
+    mhx_real x[XR > 0 ? XR : 1], y[D];
+    auto getx = [&](const int k) -> mhx_real { return k < XR ? x[k < XR ? k : 0] : xl[(k - XR) * 64]; };
     const mhx_u32 cu = (mhx_u32)c * MHX_RB;  // row pointers are wave-uniform (scalar), the lane adds its byte offset
 #pragma unroll
-    for (int k = 0; k < D; ++k) x[k] = mhx_ld_off(a.x + (long)k * ld, cu);
+    for (int k = 0; k < D; ++k) {
+        const mhx_real v = mhx_ld_off(a.x + (long)k * ld, cu);
+        if (k < XR) x[k < XR ? k : 0] = v; else xl[(k - XR) * 64] = v;
+    }
     mhx_real lp = a.lp[c];
     mhx_u32 nacc = a.acc_count[c];
     mhx_u32 wave_acc = 0;
@@ -129,7 +139,7 @@ MHX_DEV void mhx_rwmh_reg_body(const mhx_rwmh_args& a, const mhx_real* __restric
                 mhx_real w = MHX_R(0.0);
 #pragma unroll
                 for (int j = 0; j <= r; ++j) w = mhx_fma(pvec[off + j], z[j], w);
-                y[r] = x[r] + w;
+                y[r] = getx(r) + w;
                 off += r + 1;
             }
         } else {
@@ -140,7 +150,7 @@ MHX_DEV void mhx_rwmh_reg_body(const mhx_rwmh_args& a, const mhx_real* __restric
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int k = 4 * b + j;
-                    if (k < D) y[k] = mhx_fma(PK == MHX_PROP_ISO ? a.pscale : pvec[k], n[j], x[k]);
+                    if (k < D) y[k] = mhx_fma(PK == MHX_PROP_ISO ? a.pscale : pvec[k], n[j], getx(k));
                 }
             }
         }
@@ -149,7 +159,10 @@ MHX_DEV void mhx_rwmh_reg_body(const mhx_rwmh_args& a, const mhx_real* __restric
         const mhx_real logu = mhx_accept_logu(ks, id_lo, id_hi, step, ac);
         const bool acc = logu < (lpy - lp);          // strict; NaN compares false => reject
 #pragma unroll
-        for (int k = 0; k < D; ++k) x[k] = acc ? y[k] : x[k];
+        for (int k = 0; k < D; ++k) {
+            if (k < XR) x[k < XR ? k : 0] = acc ? y[k] : x[k < XR ? k : 0];
+            else if (acc) xl[(k - XR) * 64] = y[k];
+        }
         lp = acc ? lpy : lp;
         nacc += acc ? 1u : 0u;
         last = acc;
@@ -160,7 +173,7 @@ MHX_DEV void mhx_rwmh_reg_body(const mhx_rwmh_args& a, const mhx_real* __restric
             const mhx_srd srd = mhx_make_srd(slotp, (mhx_u32)(D + 1) * (mhx_u32)ld * MHX_RB);
             const mhx_u32 ldb = (mhx_u32)ld * MHX_RB;
 #pragma unroll
-            for (int k = 0; k < D; ++k) mhx_srd_store(srd, cu, (mhx_u32)k * ldb, x[k]);
+            for (int k = 0; k < D; ++k) mhx_srd_store(srd, cu, (mhx_u32)k * ldb, getx(k));
             mhx_srd_store(srd, cu, (mhx_u32)D * ldb, lp);
             a.accepted[slot * ld + c] = acc ? 1 : 0;
             save_next += (mhx_u32)a.thinning;
@@ -168,7 +181,7 @@ MHX_DEV void mhx_rwmh_reg_body(const mhx_rwmh_args& a, const mhx_real* __restric
         }
     }
 #pragma unroll
-    for (int k = 0; k < D; ++k) mhx_st_off(a.x + (long)k * ld, cu, x[k]);
+    for (int k = 0; k < D; ++k) mhx_st_off(a.x + (long)k * ld, cu, getx(k));
     a.lp[c] = lp;
     a.acc_count[c] = nacc;
     a.last_acc[c] = last ? 1 : 0;
@@ -1064,10 +1077,18 @@ MHX_DEV void mhx_moments_first_body(const mhx_real* __restrict__ x, const mhx_re
 
 // JIT entry points: hiprtc compiles this header with the specialisation macros defined
 #ifdef MHX_JIT_RWMH_REG
+#ifndef MHX_JIT_XR
+#define MHX_JIT_XR MHX_JIT_DIM
+#endif
 extern "C" __global__ void __launch_bounds__(64)
 mhx_jit_rwmh_reg(const mhx_rwmh_args a, const mhx_real* __restrict__ tparams, const mhx_real* __restrict__ pvec)
 {
+#if MHX_JIT_XR < MHX_JIT_DIM
+    extern __shared__ mhx_real mhx_reg_state_tail[];           // [MHX_JIT_DIM - MHX_JIT_XR][64]
+    mhx_rwmh_reg_body<MHX_JIT_DIM, MHX_JIT_TK, MHX_JIT_PK, MHX_JIT_XR>(a, tparams, pvec, mhx_reg_state_tail);
+#else
     mhx_rwmh_reg_body<MHX_JIT_DIM, MHX_JIT_TK, MHX_JIT_PK>(a, tparams, pvec);
+#endif
 }
 #endif
 #ifdef MHX_JIT_RWMH_COOP

@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 import cases
+import user_targets
 
 pytestmark = pytest.mark.gpu
 
@@ -50,8 +51,8 @@ def test_iso_gauss_rwmh_bit_exact(mhx, oracle, d, C, N, flags_name, lanes, real)
     if flags_name == "generic":
         assert chain.stats["kernel_variant"] == 0 and L == 1
     elif lanes == 1:
-        # the register kernel holds x and y in VGPRs: up to 160 dimensions in fp32, 80 in fp64 (two VGPRs per double)
-        assert chain.stats["kernel_variant"] in ((1, 2) if d <= (80 if real == "f64" else 160) else (0,))
+        # the register kernel holds the candidate in VGPRs and the state in VGPRs + LDS: up to 320 dimensions in fp32, 160 in fp64
+        assert chain.stats["kernel_variant"] in ((1, 2) if d <= (160 if real == "f64" else 320) else (0,))
     elif lanes > 1:
         assert chain.stats["kernel_variant"] in (3, 4) and L == lanes
     else:
@@ -176,3 +177,41 @@ def test_negative_zero_initial_coordinates(mhx, oracle, real, lanes):
     run.init(np.ones((d, C)))
     run.set_params(init)
     assert not np.signbit(run.state()[0][init == 0]).any()
+
+
+@pytest.mark.parametrize("d,C,prop", [(65, 130, "iso"), (100, 70, "diag"), (128, 64, "iso"), (160, 33, "diag"), (200, 65, "iso"), (320, 10, "diag"),
+                                      (64, 66, "iso"), (96, 5, "dense"), (40, 9, "dense")])
+def test_user_log_density_register_kernel_with_the_state_tail_in_lds(mhx, oracle, real, d, C, prop):
+    """A user log-density needs the whole candidate in one lane's registers; above 64 (fp32: 128) dimensions the state keeps only
+    its head there and its tail in LDS -- the register kernel then reaches d = 160 in fp64 (320 in fp32) instead of handing an
+    fp64 d = 100 model to the state-in-HBM kernel.  Same chain as the oracle: ISO / DIAG proposals, chains that do not fill a wave,
+    thinning with a discarded prefix, the state after the call; a dense proposal keeps its own limits."""
+    limit = 160 if real == "f64" else 320
+    rng = np.random.default_rng(d)
+    data = np.concatenate([rng.normal(size=d), 0.5 + rng.random(d)]).astype(np.float32)
+    model = mhx.DensityModel(mhx.HipLogDensity(user_targets.SHIFTED_GAUSS, d, data=data))
+    ut = user_targets.host_target(oracle, user_targets.SHIFTED_GAUSS, d, data=data)
+    if prop == "iso":
+        s = float(np.float32(2.38 / d ** 0.5))
+        spl, op = mhx.RWMH(mhx.MvNormal(mhx.zeros(d), s * s * mhx.I)), oracle.Proposal(oracle.PROP_ISO, s)
+    elif prop == "diag":
+        sv = (np.float32(2.38 / d ** 0.5) * (0.5 + rng.random(d))).astype(np.float32)
+        spl, op = mhx.RWMH([mhx.Normal(0.0, float(v)) for v in sv]), oracle.Proposal(oracle.PROP_DIAG, vec=sv)
+    else:
+        Sp = (2.38 ** 2 / d) * cases.sigma_ar1(d, 0.3)
+        spl, op = mhx.RWMH(mhx.MvNormal(mhx.zeros(d), Sp)), oracle.Proposal(oracle.PROP_DENSE, vec=oracle.pack_lower(np.linalg.cholesky(Sp)))
+    init = rng.normal(size=(d, C))
+    r = mhx.Run(model, spl, nchains=C, seed=77, first_chain=3)
+    r.init(init)
+    r.sample(6, 3, 2, 0)
+    got, got_acc = r.samples()
+    var = r.stats()["kernel_variant"]
+    in_registers = d <= ((48 if real == "f64" else 96) if prop == "dense" else limit)
+    assert var == (2 if in_registers else 0), var
+    ref = oracle.rwmh(ut, op, oracle.schedule(6, 3, 2), 77, 3, C, init=init)
+    _same(got, ref["samples"], "samples")
+    _same(got_acc, ref["accepted"], "accepted")
+    x, lp, cnt = r.state()
+    _same(x, ref["final_x"], "final x")
+    _same(lp, ref["final_lp"], "final lp")
+    _same(cnt, ref["accept_counts"], "accept counts")
