@@ -172,13 +172,23 @@ class C2:
         self.d, self.C, self.inner, self.dtype = args.dim or 100, args.chains or 65536, args.inner or 250, dtype
         self.lanes = args.lanes
         self.literal = getattr(args, "c2_literal", False)
-        self.gen = pick_gen(args, dtype)
+        self.user = getattr(args, "c2_user", False)       # the same target as a user log-density in HIP source: DensityModel(f), JIT-lowered
+        self.gen = "box-muller" if self.user else pick_gen(args, dtype)
+
+    USER_SOURCE = """
+MHX_LOGDENSITY(x, d, data, ndata)
+{
+    mhx_real q = MHX_R(0.0);
+    for (int k = 0; k < d; ++k) q = mhx_fma(x[k], x[k], q);
+    return -MHX_R(0.5) * q;
+}
+"""
 
     def build(self, mhx, ctx, rank):
         import numpy as np
         d = self.d
         self.s = 1.0 if self.literal else float(np.float32(2.38 / d ** 0.5))
-        model = mhx.DensityModel(mhx.IsoGaussian(d))
+        model = mhx.DensityModel(mhx.HipLogDensity(self.USER_SOURCE, d) if self.user else mhx.IsoGaussian(d))
         spl = mhx.RWMH(mhx.MvNormal(mhx.zeros(d), self.s * self.s * mhx.I))
         self.run = mhx.Run(model, spl, nchains=self.C, seed=0xC0FFEE, first_chain=rank * self.C, ctx=ctx, reduce_lanes=self.lanes,
                            normal_gen=self.gen)
@@ -199,8 +209,9 @@ class C2:
         return self.C * (self.inner * (B * (self.d + 1) + 1) + 2 * (B * self.d + B + 4 + 1))
 
     def describe(self):
-        return "RWMH d=%d iso-Gaussian, %d chains/GPU, proposal %s, %d transitions/launch, save-all, %s normals" % (
-            self.d, self.C, "N(0,I) (literal)" if self.literal else "N(0,(2.38/sqrt d)^2 I)", self.inner, GEN_TEXT[self.gen])
+        return "RWMH d=%d iso-Gaussian%s, %d chains/GPU, proposal %s, %d transitions/launch, save-all, %s normals" % (
+            self.d, " as a user log-density (HIP source, hiprtc)" if self.user else "", self.C,
+            "N(0,I) (literal)" if self.literal else "N(0,(2.38/sqrt d)^2 I)", self.inner, GEN_TEXT[self.gen])
 
     def cpu_baseline(self, O, target_seconds):
         tgt = O.iso_gauss(self.d)
@@ -624,7 +635,7 @@ def other_configs(mhx, ctx, args, barrier):
     block each: value, ms_per_step, acceptance, bound / frac of the dominant kernel, PMC traffic over algorithmic bytes, launch
     time, and the CPU baseline (2 s samples).  What each key is: DESIGN.md section 7."""
     import copy
-    plan = [("c1", "c1", {}, 3, 1), ("c2_literal", "c2", {"c2_literal": True}, 20, 10),
+    plan = [("c1", "c1", {}, 3, 1), ("c2_literal", "c2", {"c2_literal": True}, 20, 10), ("c2_user", "c2", {"c2_user": True}, 10, 5),
             ("c3", "c3", {}, 10, 10), ("c3_rotated", "c3", {"c3_rotated": True}, 10, 10), ("c4", "c4", {}, 3, 2),
             ("c4_moving", "c4", {"c4_moving": True}, 3, 2), ("c4_fixed", "c4", {"c4_fixed": True}, 3, 2),
             ("c5", "c5", {}, 10, 10), ("c5_banana", "c5", {"c5_banana": True}, 10, 10)]
@@ -633,7 +644,7 @@ def other_configs(mhx, ctx, args, barrier):
         try:
             a = copy.copy(args)
             a.inner = a.chains = a.dim = a.lanes = 0
-            a.c4_moving = a.c4_fixed = a.c3_rotated = a.c5_banana = a.c2_literal = False
+            a.c4_moving = a.c4_fixed = a.c3_rotated = a.c5_banana = a.c2_literal = a.c2_user = False
             for k, v in over.items():
                 setattr(a, k, v)
             w = WORKLOADS[name](a, args.dtype)
@@ -803,6 +814,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=0, help="lanes per chain (0 = engine's choice)")
     ap.add_argument("--c2-literal", action="store_true", help="c2: proposal N(0, I) as the config text reads (acceptance ~ 0 at d = 100) "
                     "instead of the tuned 2.38/sqrt(d)")
+    ap.add_argument("--c2-user", action="store_true", help="c2: the target as a user log-density in HIP source (DensityModel(f), JIT-lowered, one lane per chain)")
     ap.add_argument("--c3-rotated", action="store_true", help="c3: the dense-rotated variant Sigma = Q (0.9^|i-j|) Q^T (no banded factor)")
     ap.add_argument("--c4-fixed", action="store_true", help="c4: the fixed-factor steps that follow the warm-up (1 read of S per step)")
     ap.add_argument("--c5-banana", action="store_true", help="c5: the banana target of SURVEY 8(d) (ii) instead of Neal's funnel")
@@ -893,7 +905,7 @@ def main():
             acc_rate = v[0] / v[1]
     else:
         acc_rate = accepted / float(transitions)
-    if args.config == "c2" and not args.no_ess and not args.c2_literal and rank == 0 and world == 1:
+    if args.config == "c2" and not args.no_ess and not args.c2_literal and not args.c2_user and rank == 0 and world == 1:
         try:
             ess = ess_window(mhx, wl, world)
         except Exception as e:                                   # never let a diagnostic break the bench line
@@ -922,7 +934,7 @@ def main():
             # the all-reduced between / within statistic of the LAST timed launch only (consecutive transitions, shorter than one
             # autocorrelation time at d = 100): it exercises the collective, it is not a convergence claim -- see ess.rhat_max_split
             out["rhat_last_launch"] = sig(float(np.nanmax(diag["rhat"][:wl.d])))
-        if world == 1 and args.config == "c2" and not args.no_e2e and not args.c2_literal:
+        if world == 1 and args.config == "c2" and not args.no_e2e and not args.c2_literal and not args.c2_user:
             try:
                 out["e2e_host"] = e2e_host(mhx, wl)
             except Exception as e:
@@ -942,7 +954,7 @@ def main():
                 out["f32"] = {"error": str(e)[:160]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, args.dtype, args.cpu_seconds)
-        if world == 1 and args.config == "c2" and not args.no_other_configs and not args.c2_literal:
+        if world == 1 and args.config == "c2" and not args.no_other_configs and not args.c2_literal and not args.c2_user:
             wl.run.close()                                        # 13.4 GB of samples: C4 needs the room
             out["configs"] = other_configs(mhx, ctx, args, barrier)
         line = json.dumps(out, separators=(",", ":"))
