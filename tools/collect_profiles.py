@@ -9,7 +9,11 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DOMINANT = {"c2": "rwmh_coop", "c5": "rwmh_coop", "c3": "emcee_half", "c4": "k_ram<"}
+DOMINANT = {"c2": ("rwmh_coop", "mhx_jit_rwmh_reg"), "c5": ("rwmh_coop",), "c3": ("mhx_jit_emcee_sweep", "emcee_half"), "c4": ("k_ram<",)}
+
+
+def dominant(cfg, name):
+    return any(d in name for d in DOMINANT[cfg]) and "init" not in name
 
 
 def main(tags):
@@ -32,12 +36,12 @@ def main(tags):
             if ks:
                 shutil.copy(ks[0], os.path.join(ROOT, "profiles", name + "_kernel_stats.csv"))
             # the dominant kernel's counters, per mhx_run_sample call (= bench step): per-dispatch mean x dispatches per step
-            key = next((k for k in rep.get("counters", {}) if DOMINANT[cfg] in k and "init" not in k), None)
+            key = next((k for k in rep.get("counters", {}) if dominant(cfg, k)), None)
             if key is None or not bench:
                 continue
             c = rep["counters"][key]
             per_step = bench["config"].get("launches_per_step", 1)
-            stats = next((r for r in rep.get("kernel_stats", []) if r["Name"] == key or DOMINANT[cfg] in r["Name"] and "init" not in r["Name"]), None)
+            stats = next((r for r in rep.get("kernel_stats", []) if r["Name"] == key or dominant(cfg, r["Name"])), None)
             entry = {
                 "units_per_launch": bench["config"]["units_per_step_per_gpu"],
                 "dispatches_per_step": per_step,
@@ -54,7 +58,7 @@ def main(tags):
                 "source": "profiles/%s_summary.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_*, separate passes)" % name,
             }
             # variants of a config profiled under their own tag: r04rot_c3_f64 -> c3_rotated_f64, r04ban_c5_f64 -> c5_banana_f64, ...
-            variant = {"rot": "_rotated", "ban": "_banana", "mov": "_moving", "fix": "_fixed", "lit": "_literal"}.get(tag[-3:], "")
+            variant = {"rot": "_rotated", "ban": "_banana", "mov": "_moving", "fix": "_fixed", "lit": "_literal", "usr": "_user"}.get(tag[-3:], "")
             traffic["%s%s_%s" % (cfg, variant, dt)] = entry
             print(name, "-> traffic[%s%s_%s]: hbm %.4g B, valu %.4g per step; trace %.4g ns vs HIP events %.4g ns per dispatch" % (
                 cfg, variant, dt, entry["hbm_bytes_per_launch"], entry["valu_insts_per_launch"], entry["trace_avg_ns_per_dispatch"] or 0,
