@@ -45,7 +45,7 @@ def test_emcee_corr_gauss_bit_exact(mhx, oracle, d, W, N, flags_name, lanes, rea
         assert chain.stats["kernel_variant"] == 0 and Lx == 1
     else:
         # the register kernel holds a walker and its candidate in VGPRs: up to 64 dimensions in fp32, 32 in fp64
-        assert chain.stats["kernel_variant"] == (4 if Lx > 1 else (2 if d <= 64 else 0))
+        assert chain.stats["kernel_variant"] == (4 if Lx > 1 else (2 if d <= 160 else 0))
 
 
 @pytest.mark.parametrize("lanes", [1, 0])
@@ -205,7 +205,7 @@ def test_emcee_cooperative_kernel_large_dimensions(mhx, oracle, d, W, N, lanes, 
     _same(lp, ref["final_lp"], "final lp")
 
 
-@pytest.mark.parametrize("d,W", [(7, 37), (50, 64), (64, 10)])
+@pytest.mark.parametrize("d,W", [(7, 37), (50, 64), (64, 10), (100, 66), (160, 5), (161, 4)])
 def test_emcee_user_log_density_walker_major_rows(mhx, oracle, d, W, real):
     """The register kernel (user log-density in HIP source) on walker-major rows: dimensions with and without
     padding, recorded sweeps with thinning, state read back in the ABI layout."""
@@ -216,7 +216,7 @@ def test_emcee_user_log_density_walker_major_rows(mhx, oracle, d, W, real):
     init = cases.emcee_init(d, W, 2)
     spl = mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I)))
     chain = mhx.sample(model, spl, 9, seed=6, first_chain=2, initial_params=init, discard_initial=1, thinning=2)
-    assert chain.stats["kernel_variant"] == (2 if d <= 64 else 0)
+    assert chain.stats["kernel_variant"] == (2 if d <= 160 else 0)
     ref = oracle.emcee(ut, 2.0, 1, oracle.schedule(9, 1, 2), 6, 2, W, init)
     _same(chain.value, ref["samples"], "samples")
     _same(chain.accepted, ref["accepted"], "accepted")
