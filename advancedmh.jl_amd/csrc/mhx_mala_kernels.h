@@ -448,18 +448,33 @@ struct mhx_reg_rw {
     MHX_DEV void set(int k, mhx_real x) const { v[k] = x; }
 };
 
-template <int D, int TK>
-MHX_DEV void mhx_mala_reg_body(const mhx_mala_args& a, const mhx_real* __restrict__ tparams)
+// XR < D (round 4): only the candidate and its gradient have to be whole in a lane's registers while the user's function runs; the
+// state, its gradient and the step's noise are touched once per step each -- their first XR coordinates stay in registers, the tails
+// live in the block's LDS as [3][D - XR][lane] (one wave per block).  Carries the kernel from d = 24 / 48 (fp64 / fp32) to 64 / 128;
+// the run-time-dimension kernel it replaces there is 10-20 x slower (tools/bench_mala_user.py).  Same arithmetic, same chains.
+template <int D, int TK, int XR = D>
+MHX_DEV void mhx_mala_reg_body(const mhx_mala_args& a, const mhx_real* __restrict__ tparams, mhx_real* tails = nullptr)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr int NT = D - XR;                                       // coordinates per vector in LDS
+    mhx_real* xl = tails + threadIdx.x;                              // [NT][64], then g, then z
+    mhx_real* gl = xl + NT * 64;
+    mhx_real* zl = gl + NT * 64;
     if (c >= a.nchains) return;
     const mhx_u64 id = a.first_chain + (mhx_u64)c;
     const mhx_u32 id_lo = (mhx_u32)id, id_hi = (mhx_u32)(id >> 32);
     const mhx_philox_key ks = mhx_philox_schedule(a.seed);
     const long ld = a.ld;
-    mhx_real x[D], g[D], y[D], gyv[D], z[D];
+    constexpr int XA = XR > 0 ? XR : 1;
+    mhx_real x[XA], g[XA], y[D], gyv[D], z[XA];
+    auto getx = [&](const int k) -> mhx_real { return k < XR ? x[k < XR ? k : 0] : xl[(k - XR) * 64]; };
+    auto getg = [&](const int k) -> mhx_real { return k < XR ? g[k < XR ? k : 0] : gl[(k - XR) * 64]; };
+    auto getz = [&](const int k) -> mhx_real { return k < XR ? z[k < XR ? k : 0] : zl[(k - XR) * 64]; };
 #pragma unroll
-    for (int k = 0; k < D; ++k) { x[k] = a.x[(long)k * ld + c]; g[k] = a.gx[(long)k * ld + c]; }
+    for (int k = 0; k < D; ++k) {
+        const mhx_real xv = a.x[(long)k * ld + c], gv = a.gx[(long)k * ld + c];
+        if (k < XR) { x[k < XR ? k : 0] = xv; g[k < XR ? k : 0] = gv; } else { xl[(k - XR) * 64] = xv; gl[(k - XR) * 64] = gv; }
+    }
     mhx_reg_rw<D> gy;
     gy.v = gyv;
     mhx_real lp = a.lp[c];
@@ -484,8 +499,8 @@ MHX_DEV void mhx_mala_reg_body(const mhx_mala_args& a, const mhx_real* __restric
             for (int j = 0; j < 4; ++j) {
                 const int k = 4 * b + j;
                 if (k < D) {
-                    z[k] = n[j];
-                    y[k] = mhx_fma(a.sigma, n[j], mhx_fma(a.h, g[k], x[k]));      // src/MALA.jl:70
+                    if (k < XR) z[k < XR ? k : 0] = n[j]; else zl[(k - XR) * 64] = n[j];
+                    y[k] = mhx_fma(a.sigma, n[j], mhx_fma(a.h, getg(k), getx(k)));      // src/MALA.jl:70
                     fwd = mhx_fma(n[j], n[j], fwd);
                 }
             }
@@ -494,14 +509,17 @@ MHX_DEV void mhx_mala_reg_body(const mhx_mala_args& a, const mhx_real* __restric
         mhx_real bwd = MHX_R(0.0);
 #pragma unroll
         for (int k = 0; k < D; ++k) {
-            const mhx_real tk = mhx_fma(a.hs, g[k] + gyv[k], z[k]);
+            const mhx_real tk = mhx_fma(a.hs, getg(k) + gyv[k], getz(k));
             bwd = mhx_fma(tk, tk, bwd);
         }
         const mhx_real loga = (lpy - lp) + MHX_R(0.5) * (fwd - bwd);              // :78-83
         const mhx_real logu = mhx_accept_logu(ks, id_lo, id_hi, step, ac);
         const bool acc = logu < loga;                                    // :86 (strict)
 #pragma unroll
-        for (int k = 0; k < D; ++k) { x[k] = acc ? y[k] : x[k]; g[k] = acc ? gyv[k] : g[k]; }
+        for (int k = 0; k < D; ++k) {
+            if (k < XR) { x[k < XR ? k : 0] = acc ? y[k] : x[k < XR ? k : 0]; g[k < XR ? k : 0] = acc ? gyv[k] : g[k < XR ? k : 0]; }
+            else if (acc) { xl[(k - XR) * 64] = y[k]; gl[(k - XR) * 64] = gyv[k]; }
+        }
         lp = acc ? lpy : lp;
         nacc += acc ? 1u : 0u;
         last = acc;
@@ -509,7 +527,7 @@ MHX_DEV void mhx_mala_reg_body(const mhx_mala_args& a, const mhx_real* __restric
         if (step == save_next) {
             mhx_real* row = a.samples + slot * (long)(D + 1) * ld + c;
 #pragma unroll
-            for (int k = 0; k < D; ++k) row[(long)k * ld] = x[k];
+            for (int k = 0; k < D; ++k) row[(long)k * ld] = getx(k);
             row[(long)D * ld] = lp;
             a.accepted[slot * ld + c] = acc ? 1 : 0;
             save_next += (mhx_u32)a.thinning;
@@ -517,7 +535,7 @@ MHX_DEV void mhx_mala_reg_body(const mhx_mala_args& a, const mhx_real* __restric
         }
     }
 #pragma unroll
-    for (int k = 0; k < D; ++k) { a.x[(long)k * ld + c] = x[k]; a.gx[(long)k * ld + c] = g[k]; }
+    for (int k = 0; k < D; ++k) { a.x[(long)k * ld + c] = getx(k); a.gx[(long)k * ld + c] = getg(k); }
     a.lp[c] = lp;
     a.acc_count[c] = nacc;
     a.last_acc[c] = last ? 1 : 0;
@@ -549,10 +567,19 @@ mhx_jit_mala_coop(const mhx_mala_args a, const mhx_real* __restrict__ tparams)
 }
 #endif
 #ifdef MHX_JIT_MALA
+#if defined(MHX_JIT_XR) && MHX_JIT_DIM > 0 && MHX_JIT_XR < MHX_JIT_DIM
+// the register kernel with the tails of x, grad(x) and the noise in LDS: one wave per block
+extern "C" __global__ void __launch_bounds__(64)
+mhx_jit_mala_split(const mhx_mala_args a, const mhx_real* __restrict__ tparams)
+{
+    extern __shared__ mhx_real mhx_mala_tails[];               // [3][MHX_JIT_DIM - MHX_JIT_XR][64]
+    mhx_mala_reg_body<MHX_JIT_DIM, MHX_JIT_TK, MHX_JIT_XR>(a, tparams, mhx_mala_tails);
+}
+#endif
 extern "C" __global__ void __launch_bounds__(256)
 mhx_jit_mala(const mhx_mala_args a, const mhx_real* __restrict__ tparams)
 {
-#if MHX_JIT_DIM > 0
+#if MHX_JIT_DIM > 0 && !(defined(MHX_JIT_XR) && MHX_JIT_XR < MHX_JIT_DIM)
     mhx_mala_reg_body<MHX_JIT_DIM, MHX_JIT_TK>(a, tparams);
 #else
     mhx_mala_body<MHX_JIT_TK>(a, tparams);

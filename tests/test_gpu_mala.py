@@ -171,3 +171,24 @@ def test_mala_reference_tests(mhx, oracle, real):
     run.set_params(np.ones_like(x))
     x2, lp2, _ = run.state()
     assert (x2 == 1).all() and np.allclose(lp2, lp2[0])
+
+
+@pytest.mark.parametrize("d,C", [(7, 70), (24, 130), (25, 66), (40, 64), (64, 33), (100, 10), (128, 5), (129, 4)])
+def test_mala_user_gradient_register_kernel_with_tails_in_lds(mhx, oracle, d, C, real):
+    """A user log-density with its gradient (HIP source) on the register kernel: up to 24 (fp32: 48) dimensions all five vectors are
+    registers; above that, to 64 (128), only the candidate and its gradient are -- state, gradient and noise keep their tails in LDS --
+    instead of the run-time-dimension kernel (10-20 x slower).  Bit-exact against the oracle running the same source on the host."""
+    rng = np.random.default_rng(d)
+    data = np.concatenate([rng.normal(size=d), 1.0 / (0.5 + rng.random(d))]).astype(np.float32)
+    model = mhx.DensityModel(mhx.HipLogDensity(user_targets.SHIFTED_GAUSS_WITH_GRADIENT, d, data=data))
+    ut = user_targets.host_target(oracle, user_targets.SHIFTED_GAUSS_WITH_GRADIENT, d, data=data)
+    s2 = float(np.float32(0.3 / d ** (1.0 / 3.0)))
+    init = rng.normal(size=(d, C)).astype(np.float32)
+    chain = mhx.sample(model, mhx.MALA(s2), 12, C, seed=5, first_chain=2, initial_params=init, discard_initial=2, thinning=3)
+    assert chain.stats["kernel_variant"] == (2 if d <= (64 if real == "f64" else 128) else 0)
+    ref = oracle.mala(ut, s2, oracle.schedule(12, 2, 3), 5, 2, C, init, user_grad_addr=ut.grad_addr)
+    _same(chain.value, ref["samples"], "samples")
+    _same(chain.accepted, ref["accepted"], "accepted")
+    x, lp, cnt = chain.state.state()
+    _same(x, ref["final_x"], "final x")
+    _same(cnt, ref["accept_counts"], "accept counts")

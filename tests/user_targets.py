@@ -60,6 +60,26 @@ MHX_LOGDENSITY(x, d, data, ndata)
 }
 """
 
+# independent shifted Gaussians with their gradient (data = [shift[d], 1/scale[d]]): a cheap MALA model for any dimension
+SHIFTED_GAUSS_WITH_GRADIENT = r"""
+MHX_LOGDENSITY(x, d, data, ndata)
+{
+    mhx_real q = MHX_R(0.0);
+    for (int k = 0; k < d; ++k) { const mhx_real z = (x[k] - data[k]) * data[d + k]; q = mhx_fma(z, z, q); }
+    return -MHX_R(0.5) * q;
+}
+MHX_LOGDENSITY_AND_GRADIENT(x, g, d, data, ndata)
+{
+    mhx_real q = MHX_R(0.0);
+    for (int k = 0; k < d; ++k) {
+        const mhx_real z = (x[k] - data[k]) * data[d + k];
+        q = mhx_fma(z, z, q);
+        g.set(k, -z * data[d + k]);
+    }
+    return -MHX_R(0.5) * q;
+}
+"""
+
 # test/runtests.jl:334-365 (issue #95): TheNormalLogDensity(A): lp = -x'Ax/2, gradient = -Ax; data = A row-major
 QUADRATIC_WITH_GRADIENT = r"""
 MHX_LOGDENSITY(x, d, data, ndata)
