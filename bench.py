@@ -287,6 +287,22 @@ class C3:
         self.d, self.W, self.inner, self.dtype = args.dim or 50, args.chains or 16384, args.inner or 500, dtype
         self.lanes = args.lanes
         self.rotated = getattr(args, "c3_rotated", False)
+        self.user = getattr(args, "c3_user", False)       # the AR(1) target as a user log-density in HIP source (DensityModel(f)): lane per walker
+
+    # log N(0, Sigma), Sigma_ij = rho^|i-j|, through the bidiagonal precision factor: data = [diag[d], sub[d]]
+    USER_SOURCE = """
+MHX_LOGDENSITY(x, d, data, ndata)
+{
+    mhx_real q = MHX_R(0.0);
+    mhx_real prev = MHX_R(0.0);
+    for (int k = 0; k < d; ++k) {
+        const mhx_real w = mhx_fma(data[k], x[k], data[d + k] * prev);
+        q = mhx_fma(w, w, q);
+        prev = x[k];
+    }
+    return -MHX_R(0.5) * q;
+}
+"""
 
     def build(self, mhx, ctx, rank):
         d = self.d
@@ -295,7 +311,12 @@ class C3:
         if self.rotated:                                   # "also a dense-rotated variant" -- no structural zeros in the factor
             Q, _ = np.linalg.qr(np.random.default_rng(50).normal(size=(d, d)))
             self.Sig = Q @ self.Sig @ Q.T
-        model = mhx.DensityModel(mhx.CorrGaussian(self.Sig))
+        if self.user:
+            A = np.linalg.inv(np.linalg.cholesky(self.Sig))                      # lower bidiagonal for the AR(1) model
+            data = np.concatenate([np.diag(A), np.concatenate([[0.0], np.diag(A, -1)])])
+            model = mhx.DensityModel(mhx.HipLogDensity(self.USER_SOURCE, d, data=data))
+        else:
+            model = mhx.DensityModel(mhx.CorrGaussian(self.Sig))
         spl = mhx.Ensemble(self.W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I)))
         self.run = mhx.Run(model, spl, seed=3, first_chain=rank, ctx=ctx, reduce_lanes=self.lanes)   # one ensemble per GPU (replicas)
         self.run.init(None)
@@ -317,8 +338,9 @@ class C3:
         st = self.run.stats() if hasattr(self, "run") else {}
         band = st.get("factor_band", -1)
         per_sweep = "one launch per sweep" if 0 < st.get("launches", 0) <= self.inner else "two launches per sweep"
-        return "emcee stretch a=2, d=%d Gaussian %s, %d walkers (one ensemble/GPU), %d sweeps/step, save-all, half-split sweep (%s), factor %s" % (
-            self.d, "Q(0.9^|i-j|)Q^T" if self.rotated else "0.9^|i-j|", self.W, self.inner, per_sweep, "band %d" % band if band >= 0 else "dense")
+        return "emcee stretch a=2, d=%d Gaussian %s, %d walkers (one ensemble/GPU), %d sweeps/step, save-all, half-split sweep (%s), %s" % (
+            self.d, "Q(0.9^|i-j|)Q^T" if self.rotated else "0.9^|i-j|", self.W, self.inner, per_sweep,
+            "user log-density (HIP source, hiprtc)" if self.user else "factor " + ("band %d" % band if band >= 0 else "dense"))
 
     def cpu_baseline(self, O, target_seconds):
         import numpy as np
@@ -636,7 +658,7 @@ def other_configs(mhx, ctx, args, barrier):
     time, and the CPU baseline (2 s samples).  What each key is: DESIGN.md section 7."""
     import copy
     plan = [("c1", "c1", {}, 3, 1), ("c2_literal", "c2", {"c2_literal": True}, 20, 10), ("c2_user", "c2", {"c2_user": True}, 10, 5),
-            ("c3", "c3", {}, 10, 10), ("c3_rotated", "c3", {"c3_rotated": True}, 10, 10), ("c4", "c4", {}, 3, 2),
+            ("c3", "c3", {}, 10, 10), ("c3_rotated", "c3", {"c3_rotated": True}, 10, 10), ("c3_user", "c3", {"c3_user": True}, 10, 10), ("c4", "c4", {}, 3, 2),
             ("c4_moving", "c4", {"c4_moving": True}, 3, 2), ("c4_fixed", "c4", {"c4_fixed": True}, 3, 2),
             ("c5", "c5", {}, 10, 10), ("c5_banana", "c5", {"c5_banana": True}, 10, 10)]
     res = {}
@@ -644,7 +666,7 @@ def other_configs(mhx, ctx, args, barrier):
         try:
             a = copy.copy(args)
             a.inner = a.chains = a.dim = a.lanes = 0
-            a.c4_moving = a.c4_fixed = a.c3_rotated = a.c5_banana = a.c2_literal = a.c2_user = False
+            a.c4_moving = a.c4_fixed = a.c3_rotated = a.c5_banana = a.c2_literal = a.c2_user = a.c3_user = False
             for k, v in over.items():
                 setattr(a, k, v)
             w = WORKLOADS[name](a, args.dtype)
@@ -815,6 +837,7 @@ def main():
     ap.add_argument("--c2-literal", action="store_true", help="c2: proposal N(0, I) as the config text reads (acceptance ~ 0 at d = 100) "
                     "instead of the tuned 2.38/sqrt(d)")
     ap.add_argument("--c2-user", action="store_true", help="c2: the target as a user log-density in HIP source (DensityModel(f), JIT-lowered, one lane per chain)")
+    ap.add_argument("--c3-user", action="store_true", help="c3: the AR(1) target as a user log-density in HIP source (lane per walker, any-target kernel)")
     ap.add_argument("--c3-rotated", action="store_true", help="c3: the dense-rotated variant Sigma = Q (0.9^|i-j|) Q^T (no banded factor)")
     ap.add_argument("--c4-fixed", action="store_true", help="c4: the fixed-factor steps that follow the warm-up (1 read of S per step)")
     ap.add_argument("--c5-banana", action="store_true", help="c5: the banana target of SURVEY 8(d) (ii) instead of Neal's funnel")
