@@ -301,16 +301,16 @@ static int jit_compile(mhx_ctx* ctx, const std::string& key, const std::string& 
     const char* hdr_src[] = {k_src_mhx_zig_table_h, k_src_mhx_device_math_h, k_src_mhx_targets_h, k_src_mhx_rwmh_kernels_h,
                              k_src_mhx_emcee_kernels_h, k_src_mhx_ram_kernels_h, k_src_mhx_mala_kernels_h,
                              k_src_mhx_rwmh_dense_kernels_h, k_src_mhx_rwmh_mfma_kernels_h,
-                             k_src_mhx_mala_mfma_kernels_h};
+                             k_src_mhx_mala_mfma_kernels_h, k_src_mhx_emcee_mfma_kernels_h};
     const char* hdr_name[] = {"mhx_zig_table.h", "mhx_device_math.h", "mhx_targets.h", "mhx_rwmh_kernels.h",
                               "mhx_emcee_kernels.h", "mhx_ram_kernels.h", "mhx_mala_kernels.h",
-                              "mhx_rwmh_dense_kernels.h", "mhx_rwmh_mfma_kernels.h", "mhx_mala_mfma_kernels.h"};
+                              "mhx_rwmh_dense_kernels.h", "mhx_rwmh_mfma_kernels.h", "mhx_mala_mfma_kernels.h", "mhx_emcee_mfma_kernels.h"};
     std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
                                      MHX_REAL64 ? "-DMHX_REAL64=1" : "-DMHX_REAL64=0", "-DMHX_XW_LINE=" + std::to_string(MHX_XW_LINE)};
     for (auto& d : defines) opts.push_back("-D" + d);
     for (auto& o : extra_opts) opts.push_back(o);
     const std::string cdir = jit_cache_dir();
-    const std::string cname = cdir.empty() ? std::string() : jit_cache_name(source, opts, hdr_src, 10);
+    const std::string cname = cdir.empty() ? std::string() : jit_cache_name(source, opts, hdr_src, 11);
     std::vector<char> code;
     bool from_cache = !cdir.empty() && jit_cache_read(cdir + "/" + cname, &code);
     if (from_cache) {
@@ -325,7 +325,7 @@ static int jit_compile(mhx_ctx* ctx, const std::string& key, const std::string& 
         from_cache = false;
     }
     hiprtcProgram prog = nullptr;
-    hiprtcResult r = hiprtcCreateProgram(&prog, source.c_str(), "mhx_jit.hip", 10, hdr_src, hdr_name);
+    hiprtcResult r = hiprtcCreateProgram(&prog, source.c_str(), "mhx_jit.hip", 11, hdr_src, hdr_name);
     if (r != HIPRTC_SUCCESS) return mhx_fail(MHX_EJIT, "hiprtcCreateProgram: %s", hiprtcGetErrorString(r));
     std::vector<const char*> copts;
     for (auto& o : opts) copts.push_back(o.c_str());
@@ -644,6 +644,7 @@ struct mhx_run : mhx_handle_hdr {
     mhx_real *d_xw2 = nullptr, *d_lp2 = nullptr;   // ... the buffers the next sweep writes (swapped with d_xw / d_lp after every launch)
     size_t sweep_lds = 0;
     bool emcee_preload = false;          // the half-step kernel takes its hot arguments as preloaded scalars (MHX_JIT_PRELOAD)
+    bool emcee_mfma = false;             // the matrix-core form of the stretch move (variant 10): 4 lanes per walker, operand image in d_mfma_img
     bool emcee_scal = false;             // the scalar-factor form of the cooperative stretch move (variant 9): coop_L waves per block, 64 walkers
     int variant = 0;
     void (*reg_fn)(const mhx_rwmh_args, const mhx_real*, const mhx_real*) = nullptr;

@@ -297,7 +297,10 @@ typedef struct {
                                   target and / or dense proposal) on v_mfma_*_16x16x4, reduction shape 4,
                                   9 scalar-factor form of the cooperative stretch move (dense precision factor: a lane owns a
                                   walker during A y, the wave-uniform factor entry is a DPP-broadcast / SGPR operand; reduction
-                                  shape = reduce_lanes = waves per block) */
+                                  shape = reduce_lanes = waves per block),
+                                  10 matrix-core form of the stretch move (dense precision factor, dim <= 64 in fp64 / 128 in fp32:
+                                  4 lanes per walker, A y of the 16 walkers of a wave on v_mfma_*_16x16x4, the factor's operands
+                                  fetched into registers from an image built once per run; reduction shape 4) */
     int32_t launches;
     int32_t reduce_lanes;      /* lanes per chain in effect (1 unless a cooperative kernel runs) */
     int32_t dtype;             /* mhx_dtype of the run's context */

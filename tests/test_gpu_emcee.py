@@ -412,6 +412,7 @@ def test_scalar_factor_form_one_launch_per_sweep(mhx, oracle, real, d, W, knobs,
     init = cases.emcee_init(d, W, 5)
     model = mhx.DensityModel(mhx.CorrGaussian(Sig))
     spl = mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I)))
+    monkeypatch.setenv("MHX_EMCEE_MFMA", "0")                 # (the matrix-core form would take these shapes by default)
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
 
@@ -479,11 +480,13 @@ def _rotated(d, rho=0.9, seed=50):
 
 
 @pytest.mark.parametrize("d,W", [(50, 200), (17, 70), (64, 129), (33, 64), (8, 66)])
-def test_scalar_factor_form_runs_a_dense_factor_bit_exact(mhx, oracle, real, d, W):
+def test_scalar_factor_form_runs_a_dense_factor_bit_exact(mhx, oracle, real, d, W, monkeypatch):
     """Round 4: a DENSE precision factor (the rotated C3 target: no band to exploit) runs the scalar-factor form of the cooperative
     stretch move -- variant 9: a lane owns a walker during A y, the wave-uniform factor entry is the DPP-broadcast operand of
     v_fmac, rows split over the 8 waves of a block = the spec's reduction shape 8 -- and is the oracle's chain bit for bit, through a
-    discarded prefix, thinning, the initial draw on the device and a slab-streamed call (src/emcee.jl:70-102)."""
+    discarded prefix, thinning, the initial draw on the device and a slab-streamed call (src/emcee.jl:70-102).  (MHX_EMCEE_MFMA=0:
+    the matrix-core form is the default for these shapes since the end of round 4.)"""
+    monkeypatch.setenv("MHX_EMCEE_MFMA", "0")
     Sig = _rotated(d)
     model = mhx.DensityModel(mhx.CorrGaussian(Sig))
     spl = mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I)))
@@ -507,6 +510,7 @@ def test_scalar_factor_form_every_shape_and_the_lane_group_form_agree_with_the_o
     """The tuning knobs of the scalar-factor form (waves per block = reduction shape 4 / 16, walkers per block, SGPR operands instead
     of the DPP broadcast, the record straight from the move mapping) and MHX_EMCEE_SCALAR=0 (the lane-group form with its LDS image):
     every one of them is the oracle's chain for the reduction shape it reports."""
+    monkeypatch.setenv("MHX_EMCEE_MFMA", "0")
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
     d, W = 50, 131
@@ -534,3 +538,50 @@ def test_a_large_dense_factor_falls_back_to_the_lane_group_form(mhx, oracle, rea
     assert chain.stats["kernel_variant"] == 4
     ref = oracle.emcee(oracle.corr_gauss_from_cov(Sig, reduce_lanes=chain.stats["reduce_lanes"]), 2.0, 1, oracle.schedule(3), 2, 0, W, init)
     _same(chain.value, ref["samples"], "samples")
+
+
+@pytest.mark.parametrize("d,W", [(50, 200), (8, 66), (17, 71), (33, 64), (64, 129), (24, 3), (50, 2), (12, 33), (100, 40), (128, 19)])
+def test_matrix_core_form_of_the_stretch_move(mhx, oracle, real, d, W, monkeypatch):
+    """A dense precision factor on the matrix cores (variant 10): 4 lanes per walker, the candidate formed in the MFMA's B-operand
+    layout, the factor's operand image built once per run and fetched into registers per launch -- no LDS, no barrier; reduction
+    shape 4.  As one launch per sweep and as two half-step launches: the oracle's chain bit for bit (odd W, ensembles smaller than
+    a wave, thinning with a discarded prefix, a continued call, the initial draw on the device)."""
+    limit = 64 if real == "f64" else 128
+    monkeypatch.setenv("MHX_EMCEE_MFMA", "1")               # (by default only large fp64 ensembles take this form)
+    Sig = _rotated(d, 0.9 if d <= 64 else 0.5)
+    init = cases.emcee_init(d, W, 5)
+    model = mhx.DensityModel(mhx.CorrGaussian(Sig))
+    spl = mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I)))
+
+    def go(fused):
+        monkeypatch.setenv("MHX_EMCEE_FUSED", "1" if fused else "0")
+        r = mhx.Run(model, spl, seed=11)
+        r.init(init)
+        r.sample(5, 2, 2, 0)
+        a = r.samples() + (r.stats()["launches"],)
+        r.sample(3, 0, 1, 0)
+        return a, r.samples() + (r.state()[2], r.stats())
+
+    f, u = go(True), go(False)
+    st = f[1][3]
+    if d > limit:
+        assert st["kernel_variant"] != 10
+        return
+    assert st["kernel_variant"] == 10 and st["reduce_lanes"] == 4 and u[0][2] == 2 * f[0][2], (st, f[0][2], u[0][2])
+    for k in range(2):
+        _same(f[k][0], u[k][0], "samples, call %d" % k)
+        _same(f[k][1], u[k][1], "accepted, call %d" % k)
+    _same(f[1][2], u[1][2], "acceptance counters")
+    ref = oracle.emcee(oracle.corr_gauss_from_cov(Sig, reduce_lanes=4), 2.0, 1, oracle.schedule(5, 2, 2), 11, 0, W, init)
+    _same(f[0][0], ref["samples"], "matrix-core form vs oracle")
+    _same(f[0][1], ref["accepted"], "accepted vs oracle")
+    # the initial draw on the device, a slab-streamed call
+    chain = mhx.sample(model, spl, 7, seed=13, discard_initial=2, thinning=2)
+    ref = oracle.emcee(oracle.corr_gauss_from_cov(Sig, reduce_lanes=4), 2.0, 1, oracle.schedule(7, 2, 2), 13, 0, W, None,
+                       prior=oracle.Proposal(oracle.PROP_ISO, 1.0))
+    _same(chain.value, ref["samples"], "device-drawn walkers")
+    r = mhx.Run(model, spl, seed=13)
+    r.init(None)
+    got, got_acc = r.sample_to_host(7, 2, 2, 0, slab_samples=-3)
+    _same(got, ref["samples"], "slab-streamed")
+    _same(got_acc, ref["accepted"], "accepted, slab-streamed")

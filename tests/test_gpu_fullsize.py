@@ -60,17 +60,21 @@ def test_c3_full_size_emcee(mhx, oracle, real):
     assert chain.stats["accepted"] == int(ref["accept_counts"].sum())
 
 
-def test_c3_rotated_full_size_emcee(mhx, oracle, real):
+@pytest.mark.parametrize("form", ["matrix-core", "scalar-factor"])
+def test_c3_rotated_full_size_emcee(mhx, oracle, real, form, monkeypatch):
     """SURVEY 8(d) C3 "also a dense-rotated variant": Sigma = Q (0.9^|i-j|) Q^T, no structural zeros in the factor -- the whole
-    16 384-walker ensemble on the scalar-factor form (variant 9, reduction shape 8) against the oracle."""
+    16 384-walker ensemble against the oracle on the matrix-core form (variant 10, reduction shape 4: the default) and on the
+    scalar-factor form (variant 9, reduction shape 8: MHX_EMCEE_MFMA=0)."""
+    want_variant, want_L = (10, 4) if form == "matrix-core" else (9, 8)
+    monkeypatch.setenv("MHX_EMCEE_MFMA", "1" if form == "matrix-core" else "0")    # (default: matrix-core in fp64 at this size)
     d, W, N = 50, 16384, 4
     Q, _ = np.linalg.qr(np.random.default_rng(50).normal(size=(d, d)))
     Sig = Q @ cases.sigma_ar1(d, 0.9) @ Q.T
     init = cases.emcee_init(d, W, 11)
     chain = mhx.sample(mhx.DensityModel(mhx.CorrGaussian(Sig)), mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I))),
                        N, seed=3, initial_params=init)
-    assert chain.stats["kernel_variant"] == 9 and chain.stats["reduce_lanes"] == 8 and chain.stats["factor_band"] == -1
-    ref = oracle.emcee(oracle.corr_gauss_from_cov(Sig, reduce_lanes=8), 2.0, 1, oracle.schedule(N), 3, 0, W, init)
+    assert chain.stats["kernel_variant"] == want_variant and chain.stats["reduce_lanes"] == want_L and chain.stats["factor_band"] == -1
+    ref = oracle.emcee(oracle.corr_gauss_from_cov(Sig, reduce_lanes=want_L), 2.0, 1, oracle.schedule(N), 3, 0, W, init)
     _same(chain.value, ref["samples"], "samples")
     _same(chain.accepted, ref["accepted"], "accepted")
     assert chain.stats["accepted"] == int(ref["accept_counts"].sum())
@@ -317,7 +321,7 @@ def test_c3_ensemble_known_answer_at_scale(mhx, real):
 
 
 def test_c3_rotated_ensemble_known_answer_at_scale(mhx, real):
-    """The dense-rotated C3 target as a known answer on the scalar-factor form (variant 9): Sigma = Q (0.9^|i-j|) Q^T has no structure the
+    """The dense-rotated C3 target as a known answer on the dense-factor kernel (matrix-core form, variant 10): Sigma = Q (0.9^|i-j|) Q^T has no structure the
     kernel could exploit; rotated back by Q^T the walkers must show the AR(1) model again -- mean 0, unit variances, neighbour
     correlation 0.9 -- after the same burn-in as the banded test (the stretch move is affine-invariant: identical mixing)."""
     d, W = 50, 16384
@@ -325,7 +329,7 @@ def test_c3_rotated_ensemble_known_answer_at_scale(mhx, real):
     Sig = Q @ cases.sigma_ar1(d, 0.9) @ Q.T
     spl = mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I)))
     chain = mhx.sample(mhx.DensityModel(mhx.CorrGaussian(Sig)), spl, 20, seed=12, discard_initial=20000, thinning=200)
-    assert chain.stats["kernel_variant"] == 9
+    assert chain.stats["kernel_variant"] in (9, 10)
     v = chain.value[:, :d, :].astype(np.float64)                        # [20][d][W]
     pooled = Q.T @ v.transpose(1, 0, 2).reshape(d, -1)                  # back in the AR(1) coordinates
     assert np.abs(pooled.mean(axis=1)).max() < 0.03

@@ -261,6 +261,8 @@ def test_dense_factor_ensembles_random_configurations(mhx, oracle, case, real, m
         knobs["MHX_EMCEE_SCAL_MODE"] = "0"
     if rng.integers(0, 4) == 0:
         knobs["MHX_EMCEE_SCAL_REC"] = "0"
+    if "MHX_EMCEE_SCALAR" not in knobs and rng.integers(0, 2):
+        knobs["MHX_EMCEE_MFMA"] = "1"                            # the matrix-core form (by default only large fp64 ensembles): d <= 64 (fp32: 128)
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
     A = rng.normal(size=(d, d))
@@ -274,7 +276,10 @@ def test_dense_factor_ensembles_random_configurations(mhx, oracle, case, real, m
     run.sample(N, di, th, 0)
     st = run.stats()
     L = st["reduce_lanes"]
-    if d * (2 if real == "f64" else 1) <= 136 and int(knobs.get("MHX_EMCEE_SCALAR", 8)) <= d:
+    mfma = knobs.get("MHX_EMCEE_MFMA") == "1" and d >= 8 and d <= (64 if real == "f64" else 128)
+    if mfma:
+        assert st["kernel_variant"] == 10 and L == 4, (knobs, st)
+    elif d * (2 if real == "f64" else 1) <= 136 and int(knobs.get("MHX_EMCEE_SCALAR", 8)) <= d:
         assert st["kernel_variant"] == 9, (knobs, st)
     val, acc = run.samples()
     what = "case %d: d=%d W=%d N=%d di=%d th=%d a=%g knobs=%r variant=%d L=%d" % (case, d, W, N, di, th, a, knobs, st["kernel_variant"], L)
