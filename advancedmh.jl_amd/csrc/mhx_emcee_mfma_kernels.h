@@ -15,8 +15,8 @@
 // a 16x16x4 MFMA does 1024 products in 32.
 //
 // SWEEP = false: one half-step per launch (in place, slices for a sharded ensemble); SWEEP = true: the whole sweep in one launch
-// (mhx_emcee_coop_sweep_body has the idea: the second half's lanes re-do their partner's move from the old state, candidates for
-// both outcomes of its accept test; the three products share the lane's A operands), state double-buffered.
+// (mhx_emcee_coop_sweep_body has the idea: the second half's lanes re-do their partner's move from the old state, then move
+// against its result; both products use the lane's A operands), state double-buffered.
 #pragma once
 #include "mhx_emcee_kernels.h"
 #include "mhx_rwmh_mfma_kernels.h"
@@ -145,14 +145,15 @@ MHX_DEV void mhx_emcee_mfma_body(const mhx_emcee_args& a, const mhx_real* __rest
             y0[s] = mhx_fma(z, xs[s] - xj[s], xj[s]);                            // this walker's, if the partner stays
             y1[s] = mhx_fma(z, xs[s] - ya[s], ya[s]);                            //                if it moves
         }
+        // (no speculation here, unlike the lane-group form: one wave carries the whole product of its walkers, so a third product is
+        // a third of a microsecond-long MFMA chain -- the partner's test first, then the one candidate it selects)
         const mhx_real qa = mhx_butterfly_add<32>(mhx_butterfly_add<16>(mhx_mfma_rows_sq_areg<D>(areg, ya)));
-        const mhx_real q0 = mhx_butterfly_add<32>(mhx_butterfly_add<16>(mhx_mfma_rows_sq_areg<D>(areg, y0)));
-        const mhx_real q1 = mhx_butterfly_add<32>(mhx_butterfly_add<16>(mhx_mfma_rows_sq_areg<D>(areg, y1)));
         const mhx_real lpya = mhx_fma(-MHX_R(0.5), qa, a.tconst);
         const bool acc_a = da.logu <= (alphamult_a + lpya) - lpa;                // the partner's accept test, as its own lanes run it
-        lpy = mhx_fma(-MHX_R(0.5), acc_a ? q1 : q0, a.tconst);
 #pragma unroll
         for (int s = 0; s < NS; ++s) y0[s] = acc_a ? y1[s] : y0[s];
+        const mhx_real qb = mhx_butterfly_add<32>(mhx_butterfly_add<16>(mhx_mfma_rows_sq_areg<D>(areg, y0)));
+        lpy = mhx_fma(-MHX_R(0.5), qb, a.tconst);
     }
     const mhx_real alpha = (alphamult + lpy) - lpi;                              // :91
     const bool acc = dr.logu <= alpha;                                           // :93
