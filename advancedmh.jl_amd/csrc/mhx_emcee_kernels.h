@@ -782,7 +782,27 @@ MHX_DEV void mhx_emcee_coop_sweep_body(const mhx_emcee_args& a, const mhx_real* 
     for (int m = 0; m < NQL; ++m) { const int q4 = l + L * m; xs[m] = q4 < NQ ? xrow_i[q4] : zero4; }
     const mhx_real lpi = a.lp[i];
     const mhx_u32 acc_i = a.acc_count[i];
-    const bool moved_before = a.all_rows != 0 || a.last_acc[i] != 0;         // xw_out does not hold this walker's row
+    const unsigned char last_i = a.last_acc[i];
+    const bool moved_before = a.all_rows != 0 || last_i != 0;                // xw_out does not hold this walker's row
+    // the record of the PREVIOUS sweep (a.rec_other_slot >= 0): the row just loaded is that sweep's final state of this walker, lp and
+    // the flag ride along -- so its stores leave here, at the top of the launch, and have the whole kernel to drain, instead of at the
+    // end of the launch that moved the walker, where the kernel boundary waits for them (no extra load: unlike the half-step form's
+    // deferred record, every walker's row is read by its own group anyway)
+    if (a.rec_other_slot >= 0 && valid) {
+        mhx_real* row = a.samples + a.rec_other_slot * (long)(D + 1) * ld + i;
+#pragma unroll
+        for (int m = 0; m < NQL; ++m) {
+            const int k = 4 * (l + L * m);
+            if (k + 0 < D) MHX_REC_ST(&row[(long)(k + 0) * ld], xs[m].x);
+            if (k + 1 < D) MHX_REC_ST(&row[(long)(k + 1) * ld], xs[m].y);
+            if (k + 2 < D) MHX_REC_ST(&row[(long)(k + 2) * ld], xs[m].z);
+            if (k + 3 < D) MHX_REC_ST(&row[(long)(k + 3) * ld], xs[m].w);
+        }
+        if (l == 0) {
+            MHX_REC_ST(&row[(long)D * ld], lpi);
+            a.accepted[a.rec_other_slot * ld + i] = last_i;
+        }
+    }
     const mhx_philox_key ks = mhx_philox_schedule(a.seed);
     const mhx_emcee_draws dr = mhx_emcee_draw(ks, (mhx_u32)i, (mhx_u32)a.ensemble_id, a.sweep);
     // the partner: the second half draws from the first ([0, halfW)), the first from the second

@@ -448,6 +448,32 @@ def test_a_dense_factor_keeps_the_dense_form(mhx):
 
 
 @pytest.mark.parametrize("W", [128, 131])
+def test_sweep_kernel_deferred_record_writes_the_same_tensor(mhx, real, W, monkeypatch):
+    """MHX_EMCEE_SWEEP_DEFER=1 (tuning knob): the one-launch-per-sweep kernel records a sweep at the top of the NEXT launch, the
+    call's last one by a small kernel of its own.  Same tensor, through thinning, a discarded prefix and slab-wise calls."""
+    d = 10
+    Sig = cases.sigma_ar1(d, 0.8)
+    init = cases.emcee_init(d, W, 3)
+    model = mhx.DensityModel(mhx.CorrGaussian(Sig))
+    spl = mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I)))
+
+    def run_it(slab):
+        r = mhx.Run(model, spl, seed=4)
+        r.init(init)
+        if slab:
+            return r.sample_to_host(9, 2, 3, 0, slab_samples=slab)
+        r.sample(9, 2, 3, 0)
+        return r.samples()
+
+    want = run_it(0)
+    monkeypatch.setenv("MHX_EMCEE_SWEEP_DEFER", "1")
+    for slab in (0, 2, 4):
+        got = run_it(slab)
+        _same(got[0], want[0], "samples, slab %d" % slab)
+        _same(got[1], want[1], "accepted, slab %d" % slab)
+
+
+@pytest.mark.parametrize("W", [128, 131])
 def test_deferred_record_writes_the_same_tensor(mhx, real, W, monkeypatch):
     """MHX_EMCEE_DEFER=1 (tuning knob): the record of a half leaves at the start of the NEXT launch (the half is at rest and final
     for its sweep) instead of at the end of the launch that moved it; odd W: the half at rest is one walker larger.  Same tensor,
