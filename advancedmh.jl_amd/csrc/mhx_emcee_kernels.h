@@ -811,6 +811,12 @@ MHX_DEV void mhx_emcee_coop_sweep_body(const mhx_emcee_args& a, const mhx_real* 
     const mhx_real z = (tt * tt) / a.stretch;                               // src/emcee.jl:81
     const mhx_real alphamult = (mhx_real)(D - 1) * mhx_log(z);              // :82
     const mhx_e4* xrow_j = (const mhx_e4*)(a.xw + (long)j * mhx_xw_pitch(D));
+    // the partner's row goes out the moment the draw names it -- before the second half works out ITS partner's partner (left in the
+    // candidate loop, these loads were issued behind the second draw's Philox rounds and logarithm)
+    mhx_e4 xjs[NQL];
+#pragma unroll
+    for (int m = 0; m < NQL; ++m) { const int q4 = l + L * m; xjs[m] = q4 < NQ ? xrow_j[q4] : zero4; }
+    __builtin_amdgcn_sched_barrier(0);
     MHX_PROBE(2, alphamult + (mhx_real)j + xs[0].x + lpi);                  // launch, own row, the draws
     auto stretch = [](const mhx_real zz, const mhx_e4 xi, const mhx_e4 xj) {   // :85, element-wise
         mhx_e4 y;
@@ -839,7 +845,7 @@ MHX_DEV void mhx_emcee_coop_sweep_body(const mhx_emcee_args& a, const mhx_real* 
 #pragma unroll
         for (int m = 0; m < NQL; ++m) {
             const int q4 = l + L * m;
-            ysl[m] = q4 < NQ ? stretch(z, xs[m], xrow_j[q4]) : zero4;
+            ysl[m] = q4 < NQ ? stretch(z, xs[m], xjs[m]) : zero4;
             if (q4 < DP4 / 4) ((mhx_e4*)yrow)[q4] = ysl[m];
         }
         image_ready();
@@ -862,7 +868,7 @@ MHX_DEV void mhx_emcee_coop_sweep_body(const mhx_emcee_args& a, const mhx_real* 
             mhx_e4 ya = zero4;
             ysl[m] = zero4; y1[m] = zero4;
             if (q4 < NQ) {
-                const mhx_e4 xa = xrow_j[q4];
+                const mhx_e4 xa = xjs[m];
                 ya = stretch(za, xa, xrow_b[q4]);                           // a's candidate
                 ysl[m] = stretch(z, xs[m], xa);                              // this walker's candidate if a stays
                 y1[m] = stretch(z, xs[m], ya);                               //                          if a moves
