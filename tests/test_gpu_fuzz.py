@@ -294,3 +294,82 @@ def test_dense_factor_ensembles_random_configurations(mhx, oracle, case, real, m
     ref2 = oracle.emcee(ot, a, 1, oracle.schedule(3, nT + 1, 1), seed, ens, W, init, prior=oracle.Proposal(oracle.PROP_ISO, 1.0))
     _same(val2, ref2["samples"], what + " (resumed)")
     run.close()
+
+
+def _banded_sigma(d, bw, rng):
+    A = np.zeros((d, d))
+    for r in range(d):
+        A[r, r] = 1.0 + rng.uniform(0.0, 1.0)
+        for c in range(max(0, r - bw), r):
+            A[r, c] = rng.normal() * 0.4
+    return np.linalg.inv(A.T @ A)
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_ensemble_sweep_launches_random_configurations(mhx, oracle, case, real, monkeypatch):
+    """One launch per sweep (round 4) over random ensembles: banded factors on the lane-group form, dense ones on the scalar-factor or
+    the matrix-core form, user-style targets on the lane-per-walker kernel; dimensions with and without padding, odd and tiny
+    ensembles, random lanes per walker, thinning with a discarded prefix, a resumed call; and the same run as two half-step launches
+    per sweep (MHX_EMCEE_FUSED=0) must give the same tensor."""
+    rng = np.random.default_rng(9100 + case + 100000 * SEED_OFFSET)
+    kind = ["band", "dense", "mfma", "banana"][case % 4]
+    d = int(rng.choice([8, 9, 12, 16, 17, 23, 32, 33, 48, 50, 63, 64]))
+    W = int(rng.choice([2, 3, 2 * d + 2, 67, 128, 129, 193, 320, 1025]))
+    N, di, th = _schedule(rng)
+    lanes = 0
+    if kind == "band":
+        bw = int(rng.choice([0, 1, 2, 5, 8]))
+        bw = min(bw, d - 2)
+        Sig = _banded_sigma(d, bw, rng) if bw else np.diag(0.5 + rng.random(d))
+        lanes = int(rng.choice([0, 0, 2, 4, 8, 16]))
+        lanes = lanes if lanes <= d else 0
+        spec = mhx.CorrGaussian(Sig)
+    elif kind in ("dense", "mfma"):
+        A = rng.normal(size=(d, d))
+        Sig = A @ A.T / d + np.diag(0.2 + rng.random(d))
+        spec = mhx.CorrGaussian(Sig)
+        monkeypatch.setenv("MHX_EMCEE_MFMA", "1" if kind == "mfma" else "0")
+    else:
+        spec = mhx.Banana(d, 0.03)
+        lanes = 1
+    seed, ens = int(rng.integers(1, 1 << 40)), int(rng.integers(0, 1 << 20))
+    a = float(np.float32(1.5 + rng.random()))
+    init = None if rng.integers(0, 2) else (rng.normal(size=(d, W)) * 0.5).astype(np.float32)
+    prior = mhx.MvNormal(mhx.zeros(d), mhx.I)
+
+    def go(fused):
+        monkeypatch.setenv("MHX_EMCEE_FUSED", "1" if fused else "0")
+        run = mhx.Run(mhx.DensityModel(spec), mhx.Ensemble(W, mhx.StretchProposal(prior, a)), seed=seed, first_chain=ens, reduce_lanes=lanes)
+        run.init(init)
+        run.sample(N, di, th, 0)
+        st = run.stats()
+        first = run.samples()
+        run.sample(3, 1, 1, 0)
+        second = run.samples()
+        cnt = run.state()[2]
+        run.close()
+        return st, first, second, cnt
+
+    st, first, second, cnt = go(True)
+    st0, first0, second0, cnt0 = go(False)
+    L = st["reduce_lanes"]
+    nT = di + (N - 1) * th
+    what = "case %d: %s d=%d W=%d N=%d di=%d th=%d a=%g lanes=%d variant=%d L=%d launches %d / %d" % (
+        case, kind, d, W, N, di, th, a, lanes, st["kernel_variant"], L, st["launches"], st0["launches"])
+    # (a shape whose three candidate rows per walker do not fit the block's LDS keeps its half-steps: few lanes per walker)
+    assert st0["launches"] in (st["launches"], 2 * st["launches"]) and st["kernel_variant"] == st0["kernel_variant"], what
+    if kind != "band" or lanes in (0, 8, 16):
+        assert st0["launches"] == 2 * st["launches"], what
+    if kind == "mfma":
+        assert st["kernel_variant"] == 10 and L == 4, what
+    for u, v, w in ((first, first0, "first call"), (second, second0, "resumed call")):
+        _same(u[0], v[0], what + ": one launch vs two, " + w)
+        _same(u[1], v[1], what + ": accepted, " + w)
+    _same(cnt, cnt0, what + ": counters")
+    ot = oracle.Target(oracle.TARGET_BANANA, d, params=[0.03]) if kind == "banana" else oracle.corr_gauss_from_cov(Sig, reduce_lanes=L)
+    pr = oracle.Proposal(oracle.PROP_ISO, 1.0)
+    ref = oracle.emcee(ot, a, 1, oracle.schedule(N, di, th), seed, ens, W, init, prior=pr)
+    _same(first[0], ref["samples"], what)
+    _same(first[1], ref["accepted"], what)
+    ref2 = oracle.emcee(ot, a, 1, oracle.schedule(3, nT + 1, 1), seed, ens, W, init, prior=pr)
+    _same(second[0], ref2["samples"], what + " (resumed)")
