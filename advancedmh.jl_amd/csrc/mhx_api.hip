@@ -640,6 +640,8 @@ struct mhx_run : mhx_handle_hdr {
     int coop_waves = MHX_EMCEE_COOP_WAVES;  // waves per block of the cooperative stretch move (tuning knob MHX_EMCEE_WAVES)
     size_t emcee_stamp_words = 0;        // MHX_EMCEE_STAMPS (tools): 64-bit words of the stamp buffer in d_ybuf
     int emcee_wpb = 64;                  // walkers per block of the scalar-factor form
+    hipFunction_t jit_persist = nullptr; // a small ensemble as one persistent block (mhx_emcee_persist_body): a whole call per launch
+    size_t persist_lds = 0;
     hipFunction_t jit_sweep = nullptr;   // the stretch move as ONE launch per sweep (mhx_emcee_coop_sweep_body); state double-buffered:
     mhx_real *d_xw2 = nullptr, *d_lp2 = nullptr;   // ... the buffers the next sweep writes (swapped with d_xw / d_lp after every launch)
     size_t sweep_lds = 0;

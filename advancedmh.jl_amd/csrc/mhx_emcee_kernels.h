@@ -276,6 +276,89 @@ MHX_DEV void mhx_emcee_sweep_reg_body(const mhx_emcee_args& a, const mhx_real* _
     }
 }
 
+// A SMALL ensemble (W <= 1024: the sizes emcee is mostly run at -- a few walkers per dimension) as ONE persistent block: thread t owns
+// walker t for the whole call, its row in registers and, for its partners to read, in the block's LDS ([W][XP + 1] reals); the
+// half-steps of all the call's sweeps are separated by block barriers instead of kernel boundaries (2.7 us each, of the 3.4-4.9 us
+// a sweep launch of such an ensemble takes).  Same draws, same arithmetic (lane per walker, reduction shape 1), same record as the
+// sweep / half-step launches.  a.nsweeps sweeps from a.sweep on; a.save_next / a.thinning / a.save_slot as in the sequential form.
+template <int D, int TK>
+MHX_DEV void mhx_emcee_persist_body(const mhx_emcee_args& a, const mhx_real* __restrict__ tparams, mhx_real* xsh)
+{
+    static_assert(D > 0, "compile-time dimension");
+    constexpr int XP = (D + 3) & ~3;
+    constexpr int XS = XP + 1;                                   // LDS row pitch: odd, the walkers' columns spread over the banks
+    const int W = a.nwalkers;
+    const int halfW = W / 2, cntB = W - halfW;
+    const int t = (int)threadIdx.x;
+    const bool owner = t < W;
+    const int i = owner ? t : W - 1;
+    const long ld = W;
+    const mhx_philox_key ks = mhx_philox_schedule(a.seed);
+    mhx_real x[XP], y[XP];
+    const mhx_real* xrow_g = a.xw + (long)i * mhx_xw_pitch(D);
+#pragma unroll
+    for (int k = 0; k < XP; ++k) x[k] = xrow_g[k];
+    mhx_real* xrow_s = xsh + i * XS;
+    if (owner) {
+#pragma unroll
+        for (int k = 0; k < XP; ++k) xrow_s[k] = x[k];
+    }
+    mhx_real lp = a.lp[i];
+    mhx_u32 nacc = a.acc_count[i];
+    bool last = a.last_acc[i] != 0;
+    const bool second = t >= halfW;                              // which half this thread's walker is in
+    mhx_u32 save_next = a.save_next;
+    long slot = a.save_slot;
+    __syncthreads();
+    for (int s = 0; s < a.nsweeps; ++s) {
+        const mhx_u32 sweep = a.sweep + (mhx_u32)s;
+        // the draws of this walker's move of the sweep do not depend on anything: taken before the barriers, off the critical path
+        const mhx_emcee_draws dr = mhx_emcee_draw(ks, (mhx_u32)i, (mhx_u32)a.ensemble_id, sweep);
+        const int j = (second ? 0 : halfW) + (int)(((mhx_u64)dr.partner * (mhx_u64)(mhx_u32)(second ? halfW : cntB)) >> 32);
+        const mhx_real tt = mhx_fma(a.stretch - MHX_R(1.0), dr.u, MHX_R(1.0));
+        const mhx_real z = (tt * tt) / a.stretch;                            // src/emcee.jl:81
+        const mhx_real alphamult = (mhx_real)(D - 1) * mhx_log(z);           // :82
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (owner && (h == 1) == second) {                               // (whole waves except at the seam of the halves)
+                const mhx_real* xj = xsh + j * XS;
+#pragma unroll
+                for (int k = 0; k < XP; ++k) { const mhx_real p = xj[k]; y[k] = mhx_fma(z, x[k] - p, p); }      // :85 (the pad stays zero)
+                const mhx_real lpy = mhx_target_eval<TK>(TK, y, D, tparams, a.ntparams, a.tconst);
+                const mhx_real alpha = (alphamult + lpy) - lp;               // :91
+                const bool acc = dr.logu <= alpha;                           // :93
+                if (acc) {
+#pragma unroll
+                    for (int k = 0; k < XP; ++k) { x[k] = y[k]; xrow_s[k] = y[k]; }
+                    lp = lpy;
+                    nacc += 1u;
+                }
+                last = acc;
+            }
+            __syncthreads();
+        }
+        if (sweep == save_next) {
+            if (owner) {
+                mhx_real* row = a.samples + slot * (long)(D + 1) * ld + i;
+#pragma unroll
+                for (int k = 0; k < D; ++k) row[(long)k * ld] = x[k];
+                row[(long)D * ld] = lp;
+                a.accepted[slot * ld + i] = last ? 1 : 0;
+            }
+            save_next += (mhx_u32)a.thinning;
+            ++slot;
+        }
+    }
+    if (owner) {
+        mhx_real* xrow_o = a.xw + (long)i * mhx_xw_pitch(D);
+#pragma unroll
+        for (int k = 0; k < XP; ++k) xrow_o[k] = x[k];
+        a.lp[i] = lp;
+        a.acc_count[i] = nacc;
+        a.last_acc[i] = last ? 1 : 0;
+    }
+}
+
 // initial walkers (src/emcee.jl:29-34, :6-8): with `draw`, walker i is a draw mu + L z from the wrapped (Mv)Normal prior,
 // z from Philox stream INIT of (ensemble, i); then W log-density evaluations, accepted = false
 template <int TK>
@@ -1670,6 +1753,15 @@ mhx_jit_emcee_sweep(const mhx_emcee_args a, const mhx_real* __restrict__ tparams
 }
 #endif
 #if !MHX_JIT_SCAL && MHX_JIT_L == 1 && MHX_JIT_DIM > 0
+#ifdef MHX_JIT_PERSIST_THREADS
+// a small ensemble as one persistent block (lane per walker, any target): dynamic LDS = [W][round4(D) + 1] reals
+extern "C" __global__ void __launch_bounds__(MHX_JIT_PERSIST_THREADS)
+mhx_jit_emcee_persist(const mhx_emcee_args a, const mhx_real* __restrict__ tparams)
+{
+    extern __shared__ mhx_e4 mhx_emcee_lds[];
+    mhx_emcee_persist_body<MHX_JIT_DIM, MHX_JIT_TK>(a, tparams, (mhx_real*)mhx_emcee_lds);
+}
+#endif
 // one launch per sweep (lane per walker, any target)
 extern "C" __global__ void __launch_bounds__(64)
 mhx_jit_emcee_sweep(const mhx_emcee_args a, const mhx_real* __restrict__ tparams)

@@ -292,6 +292,8 @@ typedef struct {
     int32_t kernel_variant;    /* 0 generic (HBM state), 1 pre-built register kernel, 2 hiprtc-specialised register
                                   kernel, 3 pre-built cooperative kernel, 4 hiprtc-specialised cooperative kernel,
                                   5 hiprtc-specialised cooperative kernel for the dense Gaussian target (RWMH),
+                                  6 a small ensemble (<= 1024 walkers, lane per walker) as ONE persistent block: a whole sampling
+                                  call per launch, block barriers between the half-steps,
                                   7 the reference's sequential ensemble sweep (MHX_FLAG_EMCEE_SEQUENTIAL),
                                   8 matrix-core kernel: RWMH / MALA with one dense factor for all chains (dense Gaussian
                                   target and / or dense proposal) on v_mfma_*_16x16x4, reduction shape 4,

@@ -45,7 +45,7 @@ def test_emcee_corr_gauss_bit_exact(mhx, oracle, d, W, N, flags_name, lanes, rea
         assert chain.stats["kernel_variant"] == 0 and Lx == 1
     else:
         # the register kernel holds a walker and its candidate in VGPRs: up to 64 dimensions in fp32, 32 in fp64
-        assert chain.stats["kernel_variant"] == (4 if Lx > 1 else (2 if d <= 160 else 0))
+        assert chain.stats["kernel_variant"] in ((4,) if Lx > 1 else ((2, 6) if d <= 160 else (0,)))       # 6: a small ensemble as one persistent block
 
 
 @pytest.mark.parametrize("lanes", [1, 0])
@@ -216,7 +216,7 @@ def test_emcee_user_log_density_walker_major_rows(mhx, oracle, d, W, real):
     init = cases.emcee_init(d, W, 2)
     spl = mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I)))
     chain = mhx.sample(model, spl, 9, seed=6, first_chain=2, initial_params=init, discard_initial=1, thinning=2)
-    assert chain.stats["kernel_variant"] == (2 if d <= 160 else 0)
+    assert chain.stats["kernel_variant"] in ((2, 6) if d <= 160 else (0,))     # (6: a small ensemble as one persistent block)
     ref = oracle.emcee(ut, 2.0, 1, oracle.schedule(9, 1, 2), 6, 2, W, init)
     _same(chain.value, ref["samples"], "samples")
     _same(chain.accepted, ref["accepted"], "accepted")
@@ -246,6 +246,8 @@ def test_lane_per_walker_kernel_one_launch_per_sweep(mhx, oracle, d, W, kind, re
     if kind == "iid":
         init[1] = np.abs(init[1]) + 0.5
     spl = mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I)))
+
+    monkeypatch.setenv("MHX_EMCEE_PERSIST", "0")             # (these sizes would run as one persistent block)
 
     def go(fused):
         monkeypatch.setenv("MHX_EMCEE_FUSED", "1" if fused else "0")
@@ -611,3 +613,55 @@ def test_matrix_core_form_of_the_stretch_move(mhx, oracle, real, d, W, monkeypat
     got, got_acc = r.sample_to_host(7, 2, 2, 0, slab_samples=-3)
     _same(got, ref["samples"], "slab-streamed")
     _same(got_acc, ref["accepted"], "accepted, slab-streamed")
+
+
+@pytest.mark.parametrize("d,W,kind", [(2, 1000, "user"), (10, 64, "user"), (7, 37, "user"), (50, 200, "user"), (24, 1024, "user"), (3, 2, "user"),
+                                      (2, 131, "iid"), (30, 66, "banana"), (10, 1025, "user")])
+def test_small_ensemble_as_one_persistent_block(mhx, oracle, d, W, kind, real, monkeypatch):
+    """An ensemble of at most 1024 walkers on the lane-per-walker kernel runs a whole sampling call as ONE launch of one persistent
+    block (variant 6): thread = walker, rows in LDS for the partners, block barriers between the half-steps.  Same tensor, state and
+    counters as the sweep launches (MHX_EMCEE_PERSIST=0) and as the oracle -- thinning with a discarded prefix, a continued call, a
+    slab-streamed call, the reference's own ensemble size (1000 walkers, d = 2)."""
+    if kind == "user":
+        data = np.concatenate([np.linspace(-1.0, 1.0, d), np.linspace(0.5, 2.0, d)]).astype(np.float32)
+        model = mhx.DensityModel(mhx.HipLogDensity(user_targets.SHIFTED_GAUSS, d, data=data))
+        tgt = user_targets.host_target(oracle, user_targets.SHIFTED_GAUSS, d, data=data)
+    elif kind == "iid":
+        data = np.random.default_rng(5).normal(size=30)
+        model = mhx.DensityModel(mhx.IIDNormal(data))
+        tgt = oracle.Target(oracle.TARGET_IID_NORMAL, 2, params=data)
+    else:
+        model = mhx.DensityModel(mhx.Banana(d, 0.03))
+        tgt = oracle.Target(oracle.TARGET_BANANA, d, params=[0.03])
+    init = cases.emcee_init(d, W, 2)
+    if kind == "iid":
+        init[1] = np.abs(init[1]) + 0.5
+    spl = mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I)))
+
+    def go(persist):
+        monkeypatch.setenv("MHX_EMCEE_PERSIST", "1" if persist else "0")
+        r = mhx.Run(model, spl, seed=21, reduce_lanes=1)
+        r.init(init)
+        r.sample(5, 2, 2, 0)
+        a = r.samples() + (r.stats(),)
+        r.sample(3, 0, 1, 0)
+        b = r.samples() + r.state()
+        r2 = mhx.Run(model, spl, seed=21, reduce_lanes=1)
+        r2.init(init)
+        c = r2.sample_to_host(5, 2, 2, 0, slab_samples=2)
+        return a, b, c
+
+    p, u = go(True), go(False)
+    fits = W <= 1024 and (2 if real == "f64" else 1) * 2 * ((d + 3) & ~3) + 48 <= 512 // ((((W + 63) // 64) + 3) // 4)
+    assert p[0][2]["kernel_variant"] == (6 if fits else 2) and u[0][2]["kernel_variant"] == 2, (p[0][2], u[0][2])
+    if fits:
+        assert p[0][2]["launches"] == 1
+    for k in range(2):
+        _same(p[k][0], u[k][0], "samples, call %d" % k)
+        _same(p[k][1], u[k][1], "accepted, call %d" % k)
+    for k, what in ((2, "x"), (3, "lp"), (4, "counters")):
+        _same(p[1][k], u[1][k], what)
+    _same(p[2][0], u[2][0], "slab-streamed samples")
+    ref = oracle.emcee(tgt, 2.0, 1, oracle.schedule(5, 2, 2), 21, 0, W, init)
+    _same(p[0][0], ref["samples"], "persistent block vs oracle")
+    _same(p[0][1], ref["accepted"], "accepted vs oracle")
