@@ -332,6 +332,7 @@ def test_ensemble_sweep_launches_random_configurations(mhx, oracle, case, real, 
     else:
         spec = mhx.Banana(d, 0.03)
         lanes = 1
+        monkeypatch.setenv("MHX_EMCEE_PERSIST", "0")         # (small ensembles on this kernel would run as one persistent block)
     seed, ens = int(rng.integers(1, 1 << 40)), int(rng.integers(0, 1 << 20))
     a = float(np.float32(1.5 + rng.random()))
     init = None if rng.integers(0, 2) else (rng.normal(size=(d, W)) * 0.5).astype(np.float32)
