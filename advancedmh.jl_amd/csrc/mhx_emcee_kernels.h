@@ -194,25 +194,38 @@ MHX_DEV void mhx_emcee_sweep_reg_body(const mhx_emcee_args& a, const mhx_real* _
     const int i = (second ? halfW : 0) + t;
     const long ld = W;
     constexpr int XP = (D + 3) & ~3;
+    // the walker's own row, lp and flag do not wait for the draws: their loads go out first (left where they are used, they were issued
+    // behind the Philox rounds and, in the second half, behind the partner's whole evaluation)
+    // (while four rows of registers fit a lane comfortably: fp32 up to d = 64; a d = 50 row in fp64 is 104 VGPRs and holding it through
+    // both evaluations costs more than the early load buys -- 11.2 against 9.9 us per sweep -- so there the row is re-read where needed)
+    constexpr bool EARLY = XP * (int)(sizeof(mhx_real) / 4) * 4 <= 256;
+    mhx_real xi_reg[EARLY ? XP : 1];
+    const mhx_real* xi_mem = a.xw + (long)i * mhx_xw_pitch(D);
+    if constexpr (EARLY) {
+        const mhx_e4* xr = (const mhx_e4*)xi_mem;
+#pragma unroll
+        for (int q = 0; q < XP / 4; ++q) { const mhx_e4 v = xr[q]; xi_reg[4 * q] = v.x; xi_reg[4 * q + 1] = v.y; xi_reg[4 * q + 2] = v.z; xi_reg[4 * q + 3] = v.w; }
+    }
+    auto xi = [&](const int k) -> mhx_real { if constexpr (EARLY) return xi_reg[k]; else return xi_mem[k]; };
+    const mhx_real lpi = a.lp[i];
+    const bool moved_before = a.all_rows != 0 || a.last_acc[i] != 0;         // xw_out does not hold this walker's row
+    __builtin_amdgcn_sched_barrier(0);
     const mhx_philox_key ks = mhx_philox_schedule(a.seed);
     const mhx_emcee_draws dr = mhx_emcee_draw(ks, (mhx_u32)i, (mhx_u32)a.ensemble_id, a.sweep);
     const int j = (second ? 0 : halfW) + (int)(((mhx_u64)dr.partner * (mhx_u64)(mhx_u32)(second ? halfW : cntB)) >> 32);
     const mhx_real tt = mhx_fma(a.stretch - MHX_R(1.0), dr.u, MHX_R(1.0));
     const mhx_real z = (tt * tt) / a.stretch;                                // src/emcee.jl:81
     const mhx_real alphamult = (mhx_real)(D - 1) * mhx_log(z);               // :82
-    const mhx_e4* xrow_i = (const mhx_e4*)(a.xw + (long)i * mhx_xw_pitch(D));
     const mhx_e4* xrow_j = (const mhx_e4*)(a.xw + (long)j * mhx_xw_pitch(D));
-    const mhx_real lpi = a.lp[i];
-    const bool moved_before = a.all_rows != 0 || a.last_acc[i] != 0;         // xw_out does not hold this walker's row
     mhx_real yreg[XP];
     if (!second) {
 #pragma unroll
         for (int q = 0; q < XP / 4; ++q) {
-            const mhx_e4 xi = xrow_i[q], xj = xrow_j[q];                     // the zero pad of the rows stays zero
-            yreg[4 * q + 0] = mhx_fma(z, xi.x - xj.x, xj.x);                 // :85
-            yreg[4 * q + 1] = mhx_fma(z, xi.y - xj.y, xj.y);
-            yreg[4 * q + 2] = mhx_fma(z, xi.z - xj.z, xj.z);
-            yreg[4 * q + 3] = mhx_fma(z, xi.w - xj.w, xj.w);
+            const mhx_e4 xj = xrow_j[q];                                     // the zero pad of the rows stays zero
+            yreg[4 * q + 0] = mhx_fma(z, xi(4 * q + 0) - xj.x, xj.x);        // :85
+            yreg[4 * q + 1] = mhx_fma(z, xi(4 * q + 1) - xj.y, xj.y);
+            yreg[4 * q + 2] = mhx_fma(z, xi(4 * q + 2) - xj.z, xj.z);
+            yreg[4 * q + 3] = mhx_fma(z, xi(4 * q + 3) - xj.w, xj.w);
         }
     } else {
         // j is a walker of the first half: its own move of this sweep, from the state this launch found
@@ -236,13 +249,13 @@ MHX_DEV void mhx_emcee_sweep_reg_body(const mhx_emcee_args& a, const mhx_real* _
         const bool acc_a = da.logu <= (alphamult_a + lpya) - lpa;            // the partner's accept test (:91-93), as its own lane runs it
 #pragma unroll
         for (int q = 0; q < XP / 4; ++q) {
-            const mhx_e4 xi = xrow_i[q], xa = xrow_j[q];
+            const mhx_e4 xa = xrow_j[q];
             const mhx_real p0 = acc_a ? ya[4 * q + 0] : xa.x, p1 = acc_a ? ya[4 * q + 1] : xa.y;
             const mhx_real p2 = acc_a ? ya[4 * q + 2] : xa.z, p3 = acc_a ? ya[4 * q + 3] : xa.w;
-            yreg[4 * q + 0] = mhx_fma(z, xi.x - p0, p0);
-            yreg[4 * q + 1] = mhx_fma(z, xi.y - p1, p1);
-            yreg[4 * q + 2] = mhx_fma(z, xi.z - p2, p2);
-            yreg[4 * q + 3] = mhx_fma(z, xi.w - p3, p3);
+            yreg[4 * q + 0] = mhx_fma(z, xi(4 * q + 0) - p0, p0);
+            yreg[4 * q + 1] = mhx_fma(z, xi(4 * q + 1) - p1, p1);
+            yreg[4 * q + 2] = mhx_fma(z, xi(4 * q + 2) - p2, p2);
+            yreg[4 * q + 3] = mhx_fma(z, xi(4 * q + 3) - p3, p3);
         }
     }
     const mhx_real lpy = mhx_target_eval<TK>(TK, yreg, D, tparams, a.ntparams, a.tconst);
@@ -250,10 +263,7 @@ MHX_DEV void mhx_emcee_sweep_reg_body(const mhx_emcee_args& a, const mhx_real* _
     const bool acc = dr.logu <= alpha;                                       // :93
     if (!acc) {
 #pragma unroll
-        for (int q = 0; q < XP / 4; ++q) {
-            const mhx_e4 xi = xrow_i[q];
-            yreg[4 * q + 0] = xi.x; yreg[4 * q + 1] = xi.y; yreg[4 * q + 2] = xi.z; yreg[4 * q + 3] = xi.w;
-        }
+        for (int k = 0; k < XP; ++k) yreg[k] = xi(k);
     }
     if (acc || moved_before) {
         mhx_e4* xrow_o = (mhx_e4*)(a.xw_out + (long)i * mhx_xw_pitch(D));
