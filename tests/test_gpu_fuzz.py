@@ -261,8 +261,8 @@ def test_dense_factor_ensembles_random_configurations(mhx, oracle, case, real, m
         knobs["MHX_EMCEE_SCAL_MODE"] = "0"
     if rng.integers(0, 4) == 0:
         knobs["MHX_EMCEE_SCAL_REC"] = "0"
-    if "MHX_EMCEE_SCALAR" not in knobs and rng.integers(0, 2):
-        knobs["MHX_EMCEE_MFMA"] = "1"                            # the matrix-core form (by default only large fp64 ensembles): d <= 64 (fp32: 128)
+    if "MHX_EMCEE_SCALAR" not in knobs:
+        knobs["MHX_EMCEE_MFMA"] = str(int(rng.integers(0, 2)))   # the matrix-core form, d <= 64 (fp32: 128), or explicitly not
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
     A = rng.normal(size=(d, d))
