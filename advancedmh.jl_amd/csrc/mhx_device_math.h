@@ -86,15 +86,22 @@ typedef mhx_u32 mhx_u32v2 __attribute__((ext_vector_type(2)));
 #ifndef MHX_SRD_STORE_AUX
 #define MHX_SRD_STORE_AUX 0     // cache-policy bits of the slab stores (tuning knob: 1 sc0, 2 nt, 16 sc1)
 #endif
+template <int AUX = MHX_SRD_STORE_AUX>
 MHX_DEV void mhx_srd_store(mhx_srd srd, mhx_u32 lane_byte_off, mhx_u32 row_byte_off, double v)
 {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(mhx_u32v2, v), srd, (int)lane_byte_off, (int)row_byte_off, MHX_SRD_STORE_AUX);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(mhx_u32v2, v), srd, (int)lane_byte_off, (int)row_byte_off, AUX);
 }
 #else
+template <int AUX = 0>
 MHX_DEV void mhx_srd_store(mhx_srd srd, mhx_u32 lane_byte_off, mhx_u32 row_byte_off, float v)
 {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(mhx_u32, v), srd, (int)lane_byte_off, (int)row_byte_off, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(mhx_u32, v), srd, (int)lane_byte_off, (int)row_byte_off, AUX);
 }
+#endif
+// The sample record is written once and not read again by the kernel that writes it: non-temporal stores (aux bit 1) -- C2 3.00 ->
+// 2.95 ms per launch (profiles/r04x_record_ab.log).  (The RAM factor stores are the opposite case: MHX_SRD_STORE_AUX)
+#ifndef MHX_REC_STORE_AUX
+#define MHX_REC_STORE_AUX 2
 #endif
 
 #if MHX_REAL64
@@ -759,6 +766,70 @@ MHX_DEV mhx_real mhx_butterfly_add(const mhx_real q)
     return q + __shfl_xor(q, DIST, 64);
 #endif
 }
+// The value of lane ^ 1 (quad_perm:[1,0,3,2]); both lanes of a pair must be active.
+MHX_DEV mhx_real mhx_lane_swap1(const mhx_real v)
+{
+#if MHX_REAL64
+    const mhx_u64 b = __builtin_bit_cast(mhx_u64, v);
+    const mhx_u32 lo = mhx_lane_xor_u32<1>((mhx_u32)b), hi = mhx_lane_xor_u32<1>((mhx_u32)(b >> 32));
+    return __builtin_bit_cast(double, (mhx_u64)lo | ((mhx_u64)hi << 32));
+#else
+    return __builtin_bit_cast(float, mhx_lane_xor_u32<1>(__builtin_bit_cast(mhx_u32, v)));
+#endif
+}
+// Two rows x two neighbouring columns of a [rows][ld] slab as ONE store per lane (round 4, tools/ubench/store_width.hip: at one
+// wave per SIMD the record of a wave-step costs by the store INSTRUCTION, not by the byte -- 52 x 8 bytes per lane add 34 % to a
+// stand-in wave-step, 26 x 16 bytes of the same rows 13 %, the transposes included 14 %).  Lanes 2m and 2m + 1 hold columns
+// 2m and 2m + 1; both hold the values (a, b) of rows (r, r + 1).  After a 2 x 2 transpose between the two lanes the even lane
+// writes row r of both columns and the odd lane row r + 1: the same bytes at the same addresses, half the stores.  Returns the
+// pair this lane writes; its address is (row r + odd) of column 2m.
+MHX_DEV void mhx_pair_rows(const mhx_real a, const mhx_real b, mhx_real& v0, mhx_real& v1)
+{
+    // v0 = odd ? (b of lane ^ 1) : a;  v1 = odd ? b : (a of lane ^ 1) -- the select and the lane swap in ONE instruction per
+    // 32-bit word (v_cndmask_b32 takes its lane mask from vcc and a DPP control on src0; hipcc emits move + DPP move + select)
+    const mhx_u64 even = 0x5555555555555555ull;
+#if MHX_REAL64
+    const mhx_u64 ab = __builtin_bit_cast(mhx_u64, a), bb = __builtin_bit_cast(mhx_u64, b);
+    const mhx_u32 alo = (mhx_u32)ab, ahi = (mhx_u32)(ab >> 32), blo = (mhx_u32)bb, bhi = (mhx_u32)(bb >> 32);
+    mhx_u32 p0, p1, q0, q1;
+    // (s_nop: a DPP operand written by the VALU instruction just before needs two wait states, and nothing checks inside an asm)
+    asm("s_mov_b64 vcc, %8\n\ts_nop 0\n\t"
+        "v_cndmask_b32_dpp %0, %6, %4, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %1, %7, %5, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_not_b64 vcc, vcc\n\t"
+        "v_cndmask_b32_dpp %2, %4, %6, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %3, %5, %7, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+        : "=&v"(p0), "=&v"(p1), "=&v"(q0), "=&v"(q1) : "v"(alo), "v"(ahi), "v"(blo), "v"(bhi), "s"(even) : "vcc", "scc");
+    v0 = __builtin_bit_cast(double, (mhx_u64)p0 | ((mhx_u64)p1 << 32));
+    v1 = __builtin_bit_cast(double, (mhx_u64)q0 | ((mhx_u64)q1 << 32));
+#else
+    const mhx_u32 aw = __builtin_bit_cast(mhx_u32, a), bw = __builtin_bit_cast(mhx_u32, b);
+    mhx_u32 p, q;
+    asm("s_mov_b64 vcc, %4\n\ts_nop 0\n\t"
+        "v_cndmask_b32_dpp %0, %3, %2, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_not_b64 vcc, vcc\n\t"
+        "v_cndmask_b32_dpp %1, %2, %3, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+        : "=&v"(p), "=&v"(q) : "v"(aw), "v"(bw), "s"(even) : "vcc", "scc");
+    v0 = __builtin_bit_cast(float, p);
+    v1 = __builtin_bit_cast(float, q);
+#endif
+}
+MHX_DEV void mhx_srd_store2(mhx_srd srd, mhx_u32 lane_byte_off, mhx_u32 row_byte_off, const mhx_real v0, const mhx_real v1)
+{
+#if MHX_REAL64
+    typedef mhx_u32 mhx_u32v4 __attribute__((ext_vector_type(4)));
+    const mhx_u64 b0 = __builtin_bit_cast(mhx_u64, v0), b1 = __builtin_bit_cast(mhx_u64, v1);
+    mhx_u32v4 w;
+    w.x = (mhx_u32)b0; w.y = (mhx_u32)(b0 >> 32); w.z = (mhx_u32)b1; w.w = (mhx_u32)(b1 >> 32);
+    __builtin_amdgcn_raw_buffer_store_b128(w, srd, (int)lane_byte_off, (int)row_byte_off, MHX_REC_STORE_AUX);
+#else
+    typedef mhx_u32 mhx_u32w2 __attribute__((ext_vector_type(2)));
+    mhx_u32w2 w;
+    w.x = __builtin_bit_cast(mhx_u32, v0); w.y = __builtin_bit_cast(mhx_u32, v1);
+    __builtin_amdgcn_raw_buffer_store_b64(w, srd, (int)lane_byte_off, (int)row_byte_off, MHX_REC_STORE_AUX);
+#endif
+}
+
 // the whole butterfly of reduction shape L for 64 / L chains per wave (lane = l * CPW + chain): offsets CPW, 2 CPW, ... below 64
 template <int L, int OFF = 1>
 MHX_DEV mhx_real mhx_butterfly(mhx_real q)

@@ -172,9 +172,12 @@ MHX_DEV void mhx_rwmh_reg_body(const mhx_rwmh_args& a, const mhx_real* __restric
             mhx_real* slotp = a.samples + slot * (long)(D + 1) * ld;
             const mhx_srd srd = mhx_make_srd(slotp, (mhx_u32)(D + 1) * (mhx_u32)ld * MHX_RB);
             const mhx_u32 ldb = (mhx_u32)ld * MHX_RB;
+            // (the row offset as a running scalar sum behind an opaque asm: see MHX_COOP_REC_RUN in mhx_rwmh_coop_body)
+            mhx_u32 roff = 0u;
+            asm volatile("" : "+s"(roff));
 #pragma unroll
-            for (int k = 0; k < D; ++k) mhx_srd_store(srd, cu, (mhx_u32)k * ldb, getx(k));
-            mhx_srd_store(srd, cu, (mhx_u32)D * ldb, lp);
+            for (int k = 0; k < D; ++k) { mhx_srd_store<MHX_REC_STORE_AUX>(srd, cu, roff, getx(k)); roff += ldb; }
+            mhx_srd_store<MHX_REC_STORE_AUX>(srd, cu, roff, lp);
             a.accepted[slot * ld + c] = acc ? 1 : 0;
             save_next += (mhx_u32)a.thinning;
             ++slot;
@@ -487,6 +490,22 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
         __syncthreads();
     }
 #endif
+    // STAGGER (round 4 probe): every block of a launch runs the same instruction stream from the same start, so all CUs reach the
+    // record of a step together and the chip's 53 MB of it arrive as one burst per step.  A start-up delay by a phase of
+    // blockIdx (16 phases per step, all of them present in every XCD) spreads the bursts over the step.
+#ifndef MHX_COOP_STAGGER
+#define MHX_COOP_STAGGER 0
+#endif
+    if (MHX_COOP_STAGGER > 0) {
+        const int ph = (int)(((blockIdx.x >> 3) + 2u * (blockIdx.x & 7u)) & 15u);
+        for (int e = 0; e < ph; ++e) __builtin_amdgcn_s_sleep(MHX_COOP_STAGGER);
+    }
+#ifndef MHX_COOP_WSTAG
+#define MHX_COOP_WSTAG 0
+#endif
+    if (MHX_COOP_WSTAG > 0) {                        // the same between the waves of a block (they share the CU's path to memory)
+        for (int e = 0; e < (int)(threadIdx.x >> 6); ++e) __builtin_amdgcn_s_sleep(MHX_COOP_WSTAG);
+    }
     const int lane = threadIdx.x & 63;
     // One or two chains per wave (L = 64, 32): a block covers 32 or 64 bytes of a row of the [dim][chains] arrays, less than a cache
     // line -- blocks b, b + 8, b + 16, ... run on ONE XCD (round-robin dispatch), so they get CONSECUTIVE chain groups and the line
@@ -644,6 +663,19 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
             else if (k_last + j < d) mhx_srd_store(rec_srd, lane_off_rec, rowb, x[i][j]);
         }
     };
+    // WIDE_REC (round 4): neighbouring lanes hold neighbouring chains (CPW >= 2), so two rows of two chains leave as one 2-real
+    // store per lane after a 2 x 2 lane transpose -- half the store instructions for the same bytes.  Kernel-uniform condition: an
+    // even number of chains (a pair is valid or idle as a whole) and an even leading dimension (the pair's address is aligned).
+#ifndef MHX_COOP_WIDE_REC
+#define MHX_COOP_WIDE_REC 0    // built, bit-exact, no gain (C2 3.11 ms per launch either way): a store costs its issue -- address and data
+                               // registers read out of the wave -- so half the stores of twice the data plus four selects each save
+                               // nothing, while the running row offset below takes 4 % off the narrow form
+#endif
+#ifndef MHX_REC_PROBE
+#define MHX_REC_PROBE 0        // timing probes (the record of such a run is NOT valid): 1 = every record into slot 0 (the stores stay in
+                               // the caches), 2 = a buffer descriptor of range 0 (issued, range-checked away: no traffic at all)
+#endif
+    const bool wide_rec = MHX_COOP_WIDE_REC && CPW >= 2 && !DEFER_REC && !MOM && !tr_io && !(a.nchains & 1) && !(ld & 1L);
     // (a saved step of the one- / two-chains-per-wave shapes stages its record in the slab memory: no groups then)
     const int ks_eff = (ZIG && !(tr_io && a.samples != nullptr && a.save_next != MHX_NO_SAVE)) ? KS : 1;
     for (int it0 = 0; it0 < a.nsteps; it0 += ks_eff) {
@@ -921,18 +953,60 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
             }
             save_next += (mhx_u32)a.thinning;
             ++slot;
+        } else if (step == save_next && wide_rec) {
+            // the record as 2 NBL stores of two rows x two chains each (mhx_pair_rows) instead of 4 NBL one-row stores
+            if (valid) {                                   // (an even number of chains: the lanes of a pair are valid or idle together)
+                mhx_real* slotp = a.samples + (MHX_REC_PROBE == 1 ? 0L : slot) * (long)(d + 1) * ld;
+                const mhx_srd srd = mhx_make_srd(slotp, MHX_REC_PROBE == 2 ? 0u : (mhx_u32)(d + 1) * (mhx_u32)ld * MHX_RB);
+                const mhx_u32 ldb = (mhx_u32)ld * MHX_RB;
+                const int odd = lane & 1;
+                const mhx_u32 lane_off_w = ((mhx_u32)(4 * l) * (mhx_u32)ld + (mhx_u32)(c & ~1L)) * MHX_RB + (odd ? ldb : 0u);
+                // the row offsets as a running scalar sum that starts behind an opaque asm: as 2 NBL loop-invariant products hipcc
+                // hoists them out of the step loop, spills them to lanes of a VGPR and pays v_readlane + s_nop 4 per store
+#ifndef MHX_WIDE_REC_RUN
+#define MHX_WIDE_REC_RUN 1
+#endif
+                mhx_u32 roff = 0u;
+                if (MHX_WIDE_REC_RUN) asm volatile("" : "+s"(roff));
+#pragma unroll
+                for (int i = 0; i < NBL; ++i)
+#pragma unroll
+                    for (int jp = 0; jp < 2; ++jp) {
+                        mhx_real v0, v1;
+                        mhx_pair_rows(x[i][2 * jp], x[i][2 * jp + 1], v0, v1);
+                        const mhx_u32 rowb = MHX_WIDE_REC_RUN ? roff : (mhx_u32)(4 * L * i + 2 * jp) * ldb;    // wave-uniform -> soffset
+                        roff += (jp == 0 ? 2u : (mhx_u32)(4 * L - 2)) * ldb;
+                        if (i < NBL - 1) mhx_srd_store2(srd, lane_off_w, rowb, v0, v1);
+                        else if (k_last + 2 * jp + odd < d) mhx_srd_store2(srd, lane_off_w, rowb, v0, v1);
+                    }
+                if (l == 0) {
+                    slotp[(long)d * ld + c] = lp;
+                    a.accepted[slot * ld + c] = acc ? 1 : 0;
+                }
+            }
+            save_next += (mhx_u32)a.thinning;
+            ++slot;
         } else if (step == save_next) {
             if (valid) {
-                mhx_real* slotp = a.samples + slot * (long)(d + 1) * ld;
-                const mhx_srd srd = mhx_make_srd(slotp, (mhx_u32)(d + 1) * (mhx_u32)ld * MHX_RB);
+                mhx_real* slotp = a.samples + (MHX_REC_PROBE == 1 ? 0L : slot) * (long)(d + 1) * ld;
+                const mhx_srd srd = mhx_make_srd(slotp, MHX_REC_PROBE == 2 ? 0u : (mhx_u32)(d + 1) * (mhx_u32)ld * MHX_RB);
                 const mhx_u32 ldb = (mhx_u32)ld * MHX_RB;
+                // REC_RUN (round 4): the row offset as a running scalar sum behind an opaque asm.  As 4 NBL loop-invariant products
+                // hipcc hoists the offsets out of the step loop, spills them to lanes of a VGPR and pays v_readlane + s_nop 4 per
+                // store -- and at one wave per SIMD the record costs by the instruction, not by the byte (MHX_REC_PROBE)
+#ifndef MHX_COOP_REC_RUN
+#define MHX_COOP_REC_RUN 1
+#endif
+                mhx_u32 roff = 0u;
+                if (MHX_COOP_REC_RUN) asm volatile("" : "+s"(roff));
 #pragma unroll
                 for (int i = 0; i < NBL; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const mhx_u32 rowb = (mhx_u32)(4 * L * i + j) * ldb;     // wave-uniform -> soffset
-                        if (i < NBL - 1) mhx_srd_store(srd, lane_off, rowb, x[i][j]);
-                        else if (k_last + j < d) mhx_srd_store(srd, lane_off, rowb, x[i][j]);
+                        const mhx_u32 rowb = MHX_COOP_REC_RUN ? roff : (mhx_u32)(4 * L * i + j) * ldb;     // wave-uniform -> soffset
+                        roff += (j < 3 ? 1u : (mhx_u32)(4 * L - 3)) * ldb;
+                        if (i < NBL - 1) mhx_srd_store<MHX_REC_STORE_AUX>(srd, lane_off, rowb, x[i][j]);
+                        else if (k_last + j < d) mhx_srd_store<MHX_REC_STORE_AUX>(srd, lane_off, rowb, x[i][j]);
                     }
                 if (l == 0) {
                     slotp[(long)d * ld + c] = lp;
