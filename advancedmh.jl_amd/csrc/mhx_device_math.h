@@ -405,11 +405,13 @@ MHX_DEV double mhx_zig_ax(const mhx_u32 hi, const mhx_u32 lo, const double xl)
     const mhx_u32 top = 0x3ff00000u | ((lo >> 11) & 0xfffffu);
     return mhx_fma(mhx_u2d(((mhx_u64)top << 32) | hi), xl, -xl);
 }
-// |x| with the candidate's sign (bit 31 of lo); ax >= 0
-MHX_DEV double mhx_zig_signed(const double ax, const mhx_u32 lo)
+// |x| with the candidate's sign (bit 31 of lo); ax >= 0.  `sign` = 0x80000000: handed in by the hot loop from a scalar register
+// that hipcc cannot see through, because gfx950 has the three-operand (lo & sign) | hi -- v_and_or_b32 -- but no literal
+// constants in that encoding: with the constant in the source the pair stays v_and_b32 + v_or_b32
+MHX_DEV double mhx_zig_signed(const double ax, const mhx_u32 lo, const mhx_u32 sign = 0x80000000u)
 {
     const mhx_u64 b = mhx_d2u(ax);
-    return mhx_u2d(((mhx_u64)((mhx_u32)(b >> 32) | (lo & 0x80000000u)) << 32) | (mhx_u32)b);
+    return mhx_u2d(((mhx_u64)((mhx_u32)(b >> 32) | (lo & sign)) << 32) | (mhx_u32)b);
 }
 MHX_DEV bool mhx_zig_try(const double* __restrict__ zt, const mhx_u32 hi, const mhx_u32 lo, double& x, mhx_u32& layer)
 {

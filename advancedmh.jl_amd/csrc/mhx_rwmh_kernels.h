@@ -720,6 +720,8 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
                 }
             };
             draw(0, khi, klo);
+            mhx_u32 zsign = 0x80000000u;                            // (opaque: see mhx_zig_signed)
+            asm volatile("" : "+s"(zsign));
 #pragma unroll
             for (int grp = 0; grp < NG; ++grp) {
                 mhx_d2 xe[4 * GB];                                  // x[layer], x[layer + 1] of the stage's candidates
@@ -749,19 +751,39 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
                     const int i = grp * GB + bb;
                     if (i < NBL) {
                         double nn[4];
+                        mhx_u32 nib = 0u;                   // the block's four failure bits (1, 2, 4, 8: inline constants of the selects)
+                        // Three ways to shorten the fast path, measured one by one (profiles/r04y_fastpath_ab.log; C2 = 13 blocks per lane at
+                        // one wave per SIMD, C5 = 4 blocks at two): ANDOR -- the sign merge as one v_and_or_b32 (mhx_zig_signed) -- C2
+                        // 2.955 -> 2.888 ms per launch; FABS -- the compare on |signed x|, so that the merge happens in place (-70 v_mov)
+                        // -- and NIB -- the block's failure bits selected from inline constants, then one shift per block: fewer
+                        // instructions both, C2 unchanged / 3.4 % SLOWER with them (e64 compares into SGPR pairs feed the selects),
+                        // C5 1 % faster with all three.  Hence by shape.
+#ifndef MHX_ZIG_ANDOR
+#define MHX_ZIG_ANDOR 1
+#endif
+#ifndef MHX_ZIG_FABS
+#define MHX_ZIG_FABS (NBL <= 4)
+#endif
+#ifndef MHX_ZIG_NIB
+#define MHX_ZIG_NIB (NBL <= 4)
+#endif
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const double ax = mhx_zig_ax(khi[4 * bb + j], klo[4 * bb + j], xe[4 * bb + j].x);
-                            nn[j] = mhx_zig_signed(ax, klo[4 * bb + j]);
-                            bool fail = !(ax < xe[4 * bb + j].y);
+                            nn[j] = MHX_ZIG_ANDOR ? mhx_zig_signed(ax, klo[4 * bb + j], zsign) : mhx_zig_signed(ax, klo[4 * bb + j]);
+                            // (|x| of the signed value: a source modifier of the compare, and `ax` dies at the sign merge -- the merge
+                            // then happens in place instead of into a register that a v_mov brings back for the 16-byte LDS write)
+                            bool fail = MHX_ZIG_FABS ? !(__builtin_fabs(nn[j]) < xe[4 * bb + j].y) : !(ax < xe[4 * bb + j].y);
 #ifdef MHX_ZIG_FORCE_FAIL       // test knob (hiprtc define from the environment): every n-th slot is sent through the fix-up although
                                 // its candidate is inside its rectangle -- the refinement re-derives the same normal, so the chains
                                 // are unchanged while the queue runs through several 64-entry windows per wave-step
                             fail = fail || ((4 * i + j + lane) % (MHX_ZIG_FORCE_FAIL) == 0);
 #endif
                             if (i == NBL - 1) fail = fail && (k_last + j < d);   // padding dimensions past the end of the vector need no normal
-                            fm |= (fail ? 1ull : 0ull) << (4 * i + j);
+                            if (MHX_ZIG_NIB) nib |= fail ? (1u << j) : 0u;
+                            else fm |= (fail ? 1ull : 0ull) << (4 * i + j);
                         }
+                        if (MHX_ZIG_NIB) fm |= (mhx_u64)nib << (4 * i);
                         mhx_d2 v2;
                         v2.x = nn[0]; v2.y = nn[1];
                         *(mhx_d2*)(zn + (((i * 2) * 64 + lane) << 1)) = v2;
