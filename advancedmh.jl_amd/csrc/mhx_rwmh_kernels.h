@@ -401,15 +401,26 @@ static_assert(MHX_ZIG_TABLE_BYTES == MHX_ZIG_TABLE_BYTES_ANY, "ziggurat table si
 
 // The candidates of this wave-step that left their rectangles (0.4 % of the draws: a dozen per wave-step at d = 100), gathered
 // from all lanes into one queue and finished by as many lanes side by side -- ONE pass of the slow path per wave-step instead of
-// one per failing block.  fm: the lane's failed slots (bit s = slot 4 i + j).  A fixer lane re-derives the failed candidate from
+// one per failing block.  fm: the lane's failed slots (slot s = 4 i + j at bit s, or at bit 63 - s with MHX_ZIG_SIGNACC).  A fixer lane re-derives the failed candidate from
 // its Philox block (nothing but the slot number was kept), runs the rejection loop of mhx_zig_slow and drops the normal into the
 // owner's place in `zn`.
 // (a group of `ng` steps: zfm[s][lane] = the lane's failed slots of step step0 + s, whose normals live in zn + s * slabd)
+// SIGNACC (round 4): the failed slots of a lane not from compare + select + or (2.75 instructions per candidate) but from the SIGN of
+// |x| - x[layer + 1] -- set exactly when the candidate is inside its rectangle -- shifted into a word by ONE v_alignbit_b32 per
+// candidate ({w, hi(diff)} >> 31): subtract + alignbit = 2.  A word for slots 0..31, one for the rest; inverted, masked and put
+// together once per step with slot s at bit 63 - s.  Same failures: the difference of two doubles is -0 / +0 / of the exact sign.
+// Measured (profiles/r04y_fastpath_ab.log): 47 instructions fewer per wave-step than compare + select, and SLOWER -- C2 2.945 against
+// 2.912 ms per launch, C5 equal: fma -> merge -> subtract -> alignbit is one dependent chain per candidate, and at one wave per SIMD
+// a dependent instruction waits out its producer.  Off.
+#ifndef MHX_ZIG_SIGNACC
+#define MHX_ZIG_SIGNACC 0
+#endif
 template <int L>
 MHX_DEV void mhx_zig_fixup(const mhx_philox_key& ks, const double* __restrict__ zt, double* __restrict__ zn,
                            unsigned short* __restrict__ zq, const mhx_u64* __restrict__ zfm, const int ng, const int slabd,
                            const int lane, const long wave,
-                           const mhx_u64 first_chain, const int nchains, const mhx_u32 step0, const mhx_u32 stream)
+                           const mhx_u64 first_chain, const int nchains, const mhx_u32 step0, const mhx_u32 stream,
+                           const bool fm_in_reg = false, const mhx_u64 fm_reg = 0ull)
 {
     constexpr int CPW = 64 / L;
     // Queue positions without a prefix sum over the lanes: round k takes the k-th failure of every lane that has one; the
@@ -420,16 +431,17 @@ MHX_DEV void mhx_zig_fixup(const mhx_philox_key& ks, const double* __restrict__ 
     for (int win = 0; win == 0 || win < total; win += 64) {
         int base = -win;
         for (int s = 0; s < ng; ++s) {
-            mhx_u64 f = zfm[s * 64 + lane];
+            mhx_u64 f = fm_in_reg ? fm_reg : zfm[s * 64 + lane];      // (a group of one step: the mask never went to LDS)
             for (;;) {
                 const mhx_u64 m = __ballot(f != 0ull);
                 if (m == 0ull) break;
                 if (f != 0ull) {
                     const int e = base + (int)__builtin_amdgcn_mbcnt_hi((mhx_u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((mhx_u32)m, 0u));
-                    const int sl = __ffsll((long long)f) - 1;
+                    const int sl = MHX_ZIG_SIGNACC ? __clzll((long long)f) : __ffsll((long long)f) - 1;
                     if (e >= 0 && e < 64) zq[e] = (unsigned short)(lane | (sl << 6) | (s << 12));
                 }
-                f &= f - 1ull;
+                if (MHX_ZIG_SIGNACC) f &= ~(0x8000000000000000ull >> (f != 0ull ? __clzll((long long)f) : 0));
+                else f &= f - 1ull;
                 base += __popcll(m);
             }
         }
@@ -677,12 +689,17 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
 #endif
     const bool wide_rec = MHX_COOP_WIDE_REC && CPW >= 2 && !DEFER_REC && !MOM && !tr_io && !(a.nchains & 1) && !(ld & 1L);
     // (a saved step of the one- / two-chains-per-wave shapes stages its record in the slab memory: no groups then)
+    mhx_u64 zpad = ~0ull;                                       // SIGNACC: the slots of this lane that hold dimensions (bit 63 - slot)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (!(k_last + j < d)) zpad &= ~(0x8000000000000000ull >> (4 * (NBL - 1) + j));
     const int ks_eff = (ZIG && !(tr_io && a.samples != nullptr && a.save_next != MHX_NO_SAVE)) ? KS : 1;
     for (int it0 = 0; it0 < a.nsteps; it0 += ks_eff) {
     const int ng = a.nsteps - it0 < ks_eff ? a.nsteps - it0 : ks_eff;
 #if MHX_REAL64
     if (ZIG) {
         bool anyfail = false;
+        mhx_u64 fm1 = 0ull;                                         // KS == 1: the step's failure mask, kept in a register
 #pragma unroll 1
         for (int sg = 0; sg < ng; ++sg) {
             const mhx_u32 step = a.step0 + (mhx_u32)(it0 + sg);
@@ -691,6 +708,7 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
             // phase A: every slot's candidate by the fast path -- table look-up, multiply, compare -- into LDS; the slots that
             // left their rectangles are noted in `fm` and finished by mhx_zig_fixup before the candidate state is formed
             mhx_u64 fm = 0ull;
+            mhx_u32 aw0 = 0u, aw1 = 0u;                             // SIGNACC: "inside its rectangle" bits, newest at bit 0
             // Software pipeline over the lane's blocks: the table look-ups of block i are in flight while the Philox rounds of
             // block i + 1 run (one wave per SIMD has no other wave to hide an LDS round trip behind): per block -- issue the 4
             // look-ups (layers known since the previous stage), Philox of the next block, then consume.
@@ -773,6 +791,12 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
                             nn[j] = MHX_ZIG_ANDOR ? mhx_zig_signed(ax, klo[4 * bb + j], zsign) : mhx_zig_signed(ax, klo[4 * bb + j]);
                             // (|x| of the signed value: a source modifier of the compare, and `ax` dies at the sign merge -- the merge
                             // then happens in place instead of into a register that a v_mov brings back for the 16-byte LDS write)
+                            if (MHX_ZIG_SIGNACC) {
+                                const mhx_u32 dh = (mhx_u32)(mhx_d2u(__builtin_fabs(nn[j]) - xe[4 * bb + j].y) >> 32);    // (|signed x|: a source modifier; ax dies at the merge)
+                                if (4 * i + j < 32) aw0 = __builtin_amdgcn_alignbit(aw0, dh, 31u);
+                                else aw1 = __builtin_amdgcn_alignbit(aw1, dh, 31u);
+                                continue;
+                            }
                             bool fail = MHX_ZIG_FABS ? !(__builtin_fabs(nn[j]) < xe[4 * bb + j].y) : !(ax < xe[4 * bb + j].y);
 #ifdef MHX_ZIG_FORCE_FAIL       // test knob (hiprtc define from the environment): every n-th slot is sent through the fix-up although
                                 // its candidate is inside its rectangle -- the refinement re-derives the same normal, so the chains
@@ -796,7 +820,20 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
                     for (int e = 0; e < 4 * GB; ++e) { khi[e] = nhi[e]; klo[e] = nlo[e]; }
                 }
             }
-            zfm[sg * 64 + lane] = fm;
+            if (MHX_ZIG_SIGNACC) {
+                constexpr int N0 = 4 * NBL < 32 ? 4 * NBL : 32, N1 = 4 * NBL - N0;
+                const mhx_u32 f0 = ~aw0 & (N0 == 32 ? 0xffffffffu : ((1u << (N0 & 31)) - 1u));
+                const mhx_u32 f1 = N1 > 0 ? ~aw1 & ((1u << (N1 & 31)) - 1u) : 0u;
+                fm = ((mhx_u64)f0 << (64 - N0)) | (N1 > 0 ? (mhx_u64)f1 << ((32 - N1) & 31) : 0ull);
+                fm &= zpad;                                          // padding dimensions past the end of the vector need no normal
+#ifdef MHX_ZIG_FORCE_FAIL
+#pragma unroll
+                for (int sl = 0; sl < 4 * NBL; ++sl)
+                    if ((sl + lane) % (MHX_ZIG_FORCE_FAIL) == 0 && (sl < 4 * (NBL - 1) || k_last + (sl & 3) < d)) fm |= 0x8000000000000000ull >> sl;
+#endif
+            }
+            if (KS > 1) zfm[sg * 64 + lane] = fm;
+            fm1 = fm;
             anyfail = anyfail || fm != 0ull;
             }
         }
@@ -804,7 +841,8 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
 #define MHX_ZIG_PROBE 0        // timing probe (tools only, hiprtc define via MHX_ZIG_PROBE in the environment): 1 = skip the fix-up (WRONG normals)
 #endif
         if (MHX_ZIG_PROBE != 1 && __ballot(anyfail))
-            mhx_zig_fixup<L>(ks, zt, zn0, zq, zfm, ng, SLABD, lane, wave, a.first_chain, a.nchains, a.step0 + (mhx_u32)it0, MHX_STREAM_PROPOSAL);
+            mhx_zig_fixup<L>(ks, zt, zn0, zq, zfm, ng, SLABD, lane, wave, a.first_chain, a.nchains, a.step0 + (mhx_u32)it0, MHX_STREAM_PROPOSAL,
+                             KS == 1, fm1);
     }
 #endif
 #pragma unroll 1
