@@ -321,12 +321,19 @@ MHX_DEV void mhx_mala_coop_body(const mhx_mala_args& a, const mhx_real* __restri
         if (step == save_next) {
             if (valid) {
                 mhx_real* row = a.samples + slot * (long)(d + 1) * ld + c;
+                // (buffer descriptor + running scalar row offset behind an opaque asm: MHX_COOP_REC_RUN in mhx_rwmh_kernels.h)
+                const mhx_srd srd = mhx_make_srd(a.samples + slot * (long)(d + 1) * ld, (mhx_u32)(d + 1) * (mhx_u32)ld * MHX_RB);
+                const mhx_u32 ldb = (mhx_u32)ld * MHX_RB;
+                const mhx_u32 loff = ((mhx_u32)(4 * l) * (mhx_u32)ld + (mhx_u32)c) * MHX_RB;
+                mhx_u32 roff = 0u;
+                asm volatile("" : "+s"(roff));
 #pragma unroll
                 for (int i = 0; i < NBL; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int k = 4 * (l + L * i) + j;
-                        if (i < NBL - 1 || k < d) row[(long)k * ld] = x[i][j];
+                        if (i < NBL - 1 || k < d) mhx_srd_store<MHX_REC_STORE_AUX>(srd, loff, roff, x[i][j]);
+                        roff += (j < 3 ? 1u : (mhx_u32)(4 * L - 3)) * ldb;
                     }
                 if (l == 0) {
                     row[(long)d * ld] = lp;
@@ -526,8 +533,14 @@ MHX_DEV void mhx_mala_reg_body(const mhx_mala_args& a, const mhx_real* __restric
         wave_acc += (mhx_u32)__popcll(__ballot(acc));
         if (step == save_next) {
             mhx_real* row = a.samples + slot * (long)(D + 1) * ld + c;
+            {   // (buffer descriptor + running scalar row offset behind an opaque asm: MHX_COOP_REC_RUN in mhx_rwmh_kernels.h)
+                const mhx_srd srd = mhx_make_srd(a.samples + slot * (long)(D + 1) * ld, (mhx_u32)(D + 1) * (mhx_u32)ld * MHX_RB);
+                const mhx_u32 ldb = (mhx_u32)ld * MHX_RB, loff = (mhx_u32)c * MHX_RB;
+                mhx_u32 roff = 0u;
+                asm volatile("" : "+s"(roff));
 #pragma unroll
-            for (int k = 0; k < D; ++k) row[(long)k * ld] = getx(k);
+                for (int k = 0; k < D; ++k) { mhx_srd_store<MHX_REC_STORE_AUX>(srd, loff, roff, getx(k)); roff += ldb; }
+            }
             row[(long)D * ld] = lp;
             a.accepted[slot * ld + c] = acc ? 1 : 0;
             save_next += (mhx_u32)a.thinning;

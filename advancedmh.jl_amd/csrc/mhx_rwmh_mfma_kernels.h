@@ -508,9 +508,12 @@ MHX_DEV void mhx_rwmh_mfma_body(const mhx_rwmh_args& a, const mhx_real* __restri
             if (valid) {
                 mhx_real* slotp = a.samples + slot * (long)(D + 1) * ld;
                 const mhx_srd srd = mhx_make_srd(slotp, (mhx_u32)(D + 1) * (mhx_u32)ld * MHX_RB);
+                mhx_u32 roff = 0u;                               // (running row offset behind an opaque asm: MHX_COOP_REC_RUN, mhx_rwmh_kernels.h)
+                asm volatile("" : "+s"(roff));
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
-                    if (4 * s + 3 < D || 4 * s + g < D) mhx_srd_store(srd, lane_off, (mhx_u32)(4 * s) * ldb, xat(s));
+                    if (4 * s + 3 < D || 4 * s + g < D) mhx_srd_store<MHX_REC_STORE_AUX>(srd, lane_off, roff, xat(s));
+                    roff += 4u * ldb;
                     if (XMEM && (s & 7) == 7) __builtin_amdgcn_sched_barrier(0);      // a few re-reads of the slab in flight, not all
                 }
                 if (g == 0) {
