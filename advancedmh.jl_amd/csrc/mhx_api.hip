@@ -293,9 +293,13 @@ static void jit_cache_write(const std::string& dir, const std::string& name, con
 }
 
 // compile `source` (which #includes the embedded device headers) with hiprtc for gfx950
-static int jit_compile(mhx_ctx* ctx, const std::string& key, const std::string& source,
+static int jit_compile(mhx_ctx* ctx, const std::string& key_in, const std::string& source,
                        const std::vector<std::string>& defines, jit_module** out, const std::vector<std::string>& extra_opts = {})
 {
+    // MHX_JIT_DEFS="NAME=VALUE NAME=VALUE": extra defines for every hiprtc compile of this process -- how the tests and the A/B
+    // scripts reach the kernels' compile-time knobs (MHX_COOP_WIDE_REC, MHX_ZIG_SIGNACC, ...); part of both cache keys
+    const char* xdefs = getenv("MHX_JIT_DEFS");
+    const std::string key = (xdefs && *xdefs) ? key_in + "/xd=" + xdefs : key_in;
     auto it = ctx->jit.find(key);
     if (it != ctx->jit.end()) { *out = it->second.get(); return MHX_OK; }
     const char* hdr_src[] = {k_src_mhx_zig_table_h, k_src_mhx_device_math_h, k_src_mhx_targets_h, k_src_mhx_rwmh_kernels_h,
@@ -308,6 +312,14 @@ static int jit_compile(mhx_ctx* ctx, const std::string& key, const std::string& 
     std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
                                      MHX_REAL64 ? "-DMHX_REAL64=1" : "-DMHX_REAL64=0", "-DMHX_XW_LINE=" + std::to_string(MHX_XW_LINE)};
     for (auto& d : defines) opts.push_back("-D" + d);
+    if (xdefs)
+        for (const char* p = xdefs; *p;) {
+            while (*p == ' ') ++p;
+            const char* e = p;
+            while (*e && *e != ' ') ++e;
+            if (e > p) opts.push_back("-D" + std::string(p, e));
+            p = e;
+        }
     for (auto& o : extra_opts) opts.push_back(o);
     const std::string cdir = jit_cache_dir();
     const std::string cname = cdir.empty() ? std::string() : jit_cache_name(source, opts, hdr_src, 11);

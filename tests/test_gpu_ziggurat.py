@@ -150,3 +150,35 @@ def test_fixup_queue_windows(mhx, oracle, f64, monkeypatch, every):
         ref = oracle.rwmh(oracle.iso_gauss(d, reduce_lanes=L), oracle.Proposal(oracle.PROP_ISO, S, normal_gen=1), oracle.schedule(N), 77 + d, 2, C)
         _same(chain.value, ref["samples"], "samples d=%d lanes=%d" % (d, lanes))
         _same(chain.accepted, ref["accepted"], "accepted")
+
+
+@pytest.mark.parametrize("defs", ["MHX_COOP_WIDE_REC=1", "MHX_COOP_WIDE_REC=1 MHX_WIDE_REC_RUN=0", "MHX_COOP_REC_RUN=0", "MHX_ZIG_SIGNACC=1",
+                                  "MHX_ZIG_FABS=1 MHX_ZIG_NIB=1", "MHX_ZIG_ANDOR=0 MHX_ZIG_FABS=0 MHX_ZIG_NIB=0", "MHX_REC_STORE_AUX=0"])
+def test_measured_knobs_of_the_cooperative_kernel_change_no_bit(mhx, oracle, f64, monkeypatch, defs):
+    """The kernel forms that were measured and kept as knobs (the record as 16-byte stores of two rows x two chains after a
+    lane transpose, row offsets hoisted or running, failure bits from the sign of |x| - x[layer + 1], the fast-path variants, plain
+    instead of non-temporal record stores) are data movement and instruction selection only: every one of them, compiled by hiprtc
+    through MHX_JIT_DEFS, yields the oracle's chains bit for bit -- even / odd chain counts, a last block with padding, two shapes."""
+    monkeypatch.setenv("MHX_JIT_DEFS", defs)
+    monkeypatch.setenv("MHX_NO_PREBUILT", "1")
+    for d, C, N, lanes in [(100, 70, 9, 2), (100, 33, 7, 2), (98, 64, 6, 4), (1000, 6, 5, 64)]:
+        model = mhx.DensityModel(mhx.IsoGaussian(d))
+        spl = mhx.RWMH(mhx.MvNormal(mhx.zeros(d), S * S * mhx.I))
+        chain = mhx.sample(model, spl, N, C, seed=31 + d, first_chain=5, reduce_lanes=lanes, normal_gen="ziggurat")
+        assert chain.stats["kernel_variant"] == 4 and chain.stats["normal_gen"] == 1
+        L = chain.stats["reduce_lanes"]
+        ref = oracle.rwmh(oracle.iso_gauss(d, reduce_lanes=L), oracle.Proposal(oracle.PROP_ISO, S, normal_gen=1), oracle.schedule(N), 31 + d, 5, C)
+        _same(chain.value, ref["samples"], "samples d=%d lanes=%d defs=%s" % (d, lanes, defs))
+        _same(chain.accepted, ref["accepted"], "accepted")
+
+
+def test_jit_defs_reach_hiprtc(mhx, f64, monkeypatch, tmp_path):
+    """(what makes the test above a test: a define that cannot compile must fail the run's creation, in a fresh cache directory)"""
+    monkeypatch.setenv("MHX_CACHE_DIR", str(tmp_path / "jit"))
+    monkeypatch.setenv("MHX_JIT_DEFS", "MHX_COOP_REC_RUN=)")
+    monkeypatch.setenv("MHX_NO_PREBUILT", "1")
+    model = mhx.DensityModel(mhx.IsoGaussian(100))
+    spl = mhx.RWMH(mhx.MvNormal(mhx.zeros(100), S * S * mhx.I))
+    with pytest.raises(Exception) as ei:
+        mhx.sample(model, spl, 4, 64, seed=1, reduce_lanes=2, normal_gen="ziggurat")
+    assert "hiprtc" in str(ei.value)
