@@ -689,7 +689,7 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
 #endif
     const bool wide_rec = MHX_COOP_WIDE_REC && CPW >= 2 && !DEFER_REC && !MOM && !tr_io && !(a.nchains & 1) && !(ld & 1L);
     // (a saved step of the one- / two-chains-per-wave shapes stages its record in the slab memory: no groups then)
-    mhx_u64 zpad = ~0ull;                                       // SIGNACC: the slots of this lane that hold dimensions (bit 63 - slot)
+    [[maybe_unused]] mhx_u64 zpad = ~0ull;                      // SIGNACC: the slots of this lane that hold dimensions (bit 63 - slot)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
         if (!(k_last + j < d)) zpad &= ~(0x8000000000000000ull >> (4 * (NBL - 1) + j));
