@@ -679,6 +679,8 @@ def other_configs(mhx, ctx, args, barrier):
                    "launch_us": sig(rf["avg_launch_ms"] * 1e3, 4), "kernel": kernel_name(w, st), "lanes": st["reduce_lanes"]}
             if rf["bound"] == "valu":
                 blk["hbm_frac"] = rf["hbm_frac"]
+                # fp64, 32-bit multiplies and v_bitop3_b32 -- this kernel's instructions -- issue over 4 cycles, not 2 (r02a_valu_rates.log)
+                blk["frac_4cycle_class"] = sig(2.0 * rf["frac"], 4)
             if st.get("factor_band", -1) >= 0:
                 blk["band"] = st["factor_band"]
             w.run.close()
