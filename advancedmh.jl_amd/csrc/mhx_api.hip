@@ -1066,7 +1066,7 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
         r->flags |= MHX_FLAG_GENERIC;
     }
     if (!r->variant && !(r->flags & MHX_FLAG_GENERIC)) {
-        if (tk != MHX_TARGET_USER)
+        if (tk != MHX_TARGET_USER && !(cfg->flags & MHX_FLAG_ZIGGURAT))
             for (const auto& pb : k_prebuilt_reg)
                 if (pb.D == d && pb.TK == tk && pb.PK == pk) { r->reg_fn = pb.fn; r->variant = 1; }
         // The candidate must be whole in a lane's registers (an arbitrary log-density reads all of it); the state need not be: above
@@ -1087,17 +1087,25 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
             const char* ut = getenv("MHX_REG_UNROLL");
             std::vector<std::string> xo;
             if (!ut || atoi(ut) > 0) xo = {"-mllvm", std::string("-amdgpu-unroll-threshold-private=") + (ut ? ut : "100000")};
+            // MHX_FLAG_ZIGGURAT (fp64, ISO / DIAG proposal): the register kernel's ziggurat form (mhx_rwmh_reg_zig_body) -- any target,
+            // a user's HIP source included
+            const bool zig_reg = MHX_REAL64 && (cfg->flags & MHX_FLAG_ZIGGURAT) && pk != MHX_PROP_DENSE;
             const std::string key = "rwmh_reg/d=" + std::to_string(d) + "/tk=" + std::to_string(tk) + "/pk=" +
-                                    std::to_string(pk) + "/xr=" + std::to_string(xr) + (ut ? std::string("/ut=") + ut : std::string()) + "/" + t->user_key;
-            rc = jit_compile(ctx, key, jit_source(t, "mhx_rwmh_kernels.h"),
-                             {"MHX_JIT_RWMH_REG=1", "MHX_JIT_DIM=" + std::to_string(d),
-                              "MHX_JIT_TK=" + std::to_string(tk), "MHX_JIT_PK=" + std::to_string(pk), "MHX_JIT_XR=" + std::to_string(xr)}, &m, xo);
+                                    std::to_string(pk) + "/xr=" + std::to_string(xr) + (ut ? std::string("/ut=") + ut : std::string()) +
+                                    (zig_reg ? "/gen=1" : "") + "/" + t->user_key;
+            std::vector<std::string> rdefs = {"MHX_JIT_RWMH_REG=1", "MHX_JIT_DIM=" + std::to_string(d),
+                                              "MHX_JIT_TK=" + std::to_string(tk), "MHX_JIT_PK=" + std::to_string(pk), "MHX_JIT_XR=" + std::to_string(xr)};
+            if (zig_reg) rdefs.push_back("MHX_JIT_GEN=1");
+            rc = jit_compile(ctx, key, jit_source(t, "mhx_rwmh_kernels.h"), rdefs, &m, xo);
             if (rc == MHX_OK) rc = jit_function(m, "mhx_jit_rwmh_reg", &r->jit_step);
             r->reg_lds = (size_t)(d - xr) * 64 * sizeof(mhx_real);
+#if MHX_REAL64
+            if (zig_reg) r->reg_lds = MHX_REG_ZIG_LDS_BYTES(d, xr);
+#endif
             if (rc == MHX_OK && r->reg_lds > 65536 &&
                 hipFuncSetAttribute((const void*)r->jit_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->reg_lds) != hipSuccess)
                 rc = mhx_fail(MHX_EHIP, "register kernel: %zu bytes of LDS refused", r->reg_lds);
-            if (rc == MHX_OK) r->variant = 2;
+            if (rc == MHX_OK) { r->variant = 2; if (zig_reg) r->normal_gen = MHX_GEN_ZIGGURAT; }
             else if (tk == MHX_TARGET_USER) return rc;      // no pre-built kernel can run a user source
             // built-in target: the generic kernel below computes the same chain; keep the message
         }
@@ -1110,7 +1118,8 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
     }
     if ((cfg->flags & MHX_FLAG_ZIGGURAT) && r->normal_gen != MHX_GEN_ZIGGURAT)
         return mhx_fail(MHX_EINVAL, "MHX_FLAG_ZIGGURAT: this run's kernel (variant %d) has no ziggurat form -- it exists on the cooperative "
-                                    "kernel of fp64 contexts (separable catalogue target, ISO / DIAG proposal, JIT allowed)", r->variant);
+                                    "kernel (separable catalogue target) and on the register kernel (any target within its dimension limit) of "
+                                    "fp64 contexts, ISO / DIAG proposal, JIT allowed", r->variant);
     // candidate scratch of the state-in-HBM kernel; a static proposal whitens the state into it whatever kernel steps the chain
     if (r->variant == 0 || r->d_qx) HIP_TRY(hipMalloc(&r->d_ybuf, (size_t)d * (size_t)r->n * sizeof(mhx_real)));
     *out = r.release();

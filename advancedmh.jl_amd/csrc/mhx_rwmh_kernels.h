@@ -469,6 +469,209 @@ MHX_DEV void mhx_zig_fixup(const mhx_philox_key& ks, const double* __restrict__ 
 }
 #endif
 
+#if MHX_REAL64
+// ---------------------------------------------------------------------------------------------
+// The register kernel (lane per chain, any target incl. a user's HIP source) with the ZIGGURAT generator (round 4, second
+// session).  Box-Muller is 3/5 of that kernel's instructions (~73 per normal against ~25 for Philox + table fast path); what kept
+// the ziggurat off it is the patch: the normals ARE the candidate's registers, and a register array cannot be indexed by a
+// per-lane slot number.  Here: phase A writes every fast-path normal into y[k] and notes the failures in a per-lane bit mask; the
+// failures of the whole wave-step (0.43 % x 64 D: 27 at d = 100) are queued as in mhx_zig_fixup and refined side by side by as
+// many lanes, which leave the values in LDS by queue position; then every owner walks its failures once more, round by round like
+// the queue did, fetches the round's value and every register of the mask word takes it where the slot number says so -- three
+// straight-line instructions per register and round, ~600 per wave-step at d = 100 -- no slab of normals (which at a lane per
+// chain would be 51 KB per wave).  Every lane stays alive (idle lanes shadow the last chain) because the queue and the
+// patch are wave-wide.  LDS of the one-wave block: [layer table][queue][results][state tail (D - XR) x 64].  Same normals as
+// mhx_zig_normal, hence the oracle's chains at reduction shape 1.
+#define MHX_REG_ZIG_LDS_BYTES(D, XR) ((size_t)((D) - (XR)) * 64 * 8 + MHX_ZIG_TABLE_BYTES + 128 + 512)
+template <int D, int TK, int PK, int XR = D>
+MHX_DEV void mhx_rwmh_reg_zig_body(const mhx_rwmh_args& a, const mhx_real* __restrict__ tparams,
+                                   const mhx_real* __restrict__ pvec, double* __restrict__ lds)
+{
+    static_assert(PK != MHX_PROP_DENSE, "ISO / DIAG proposals");
+    constexpr int NW = (D + 63) / 64;                          // words of the failure mask
+    const int lane = (int)threadIdx.x;                         // one wave per block
+    const long c_raw = (long)blockIdx.x * 64 + lane;
+    const bool valid = c_raw < a.nchains;
+    const long c = valid ? c_raw : (long)a.nchains - 1;        // idle lanes shadow the last chain (loads only)
+    double* const zt = lds;                                    // (the table at offset 0: its look-up addresses need no base)
+    unsigned short* const zq = (unsigned short*)(zt + MHX_ZIG_TABLE_BYTES / 8);      // 64 entries
+    double* const zres = zt + MHX_ZIG_TABLE_BYTES / 8 + 16;                           // 64 refined normals
+    double* const xl = zres + 64 + lane;                       // this lane's column of the [D - XR][64] state tail
+    for (int e = lane; e <= MHX_ZIG_N; e += 64) zt[e] = mhx_zig_x[e];
+    __syncthreads();
+    const mhx_u64 id = a.first_chain + (mhx_u64)c;
+    const mhx_u32 id_lo = (mhx_u32)id, id_hi = (mhx_u32)(id >> 32);
+    const mhx_philox_key ks = mhx_philox_schedule(a.seed);
+    const long ld = a.ld;
+
+    double x[XR > 0 ? XR : 1], y[D];
+    auto getx = [&](const int k) -> double { return k < XR ? x[k < XR ? k : 0] : xl[(k - XR) * 64]; };
+    const mhx_u32 cu = (mhx_u32)c * MHX_RB;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const double v = mhx_ld_off(a.x + (long)k * ld, cu);
+        if (k < XR) x[k < XR ? k : 0] = v; else xl[(k - XR) * 64] = v;
+    }
+    double lp = a.lp[c];
+    mhx_u32 nacc = a.acc_count[c];
+    mhx_u32 wave_acc = 0;
+    bool last = a.last_acc[c] != 0;
+    mhx_accept_cache ac;
+    ac.group = 0xffffffffu;
+    ac.w.x = ac.w.y = ac.w.z = ac.w.w = 0u;
+    mhx_u32 save_next = a.save_next;
+    long slot = a.save_slot;
+    mhx_u32 zsign = 0x80000000u;                               // (opaque: see mhx_zig_signed)
+    asm volatile("" : "+s"(zsign));
+
+    for (int i = 0; i < a.nsteps; ++i) {
+        const mhx_u32 step = a.step0 + (mhx_u32)i;
+        // ---- phase A: normal n of the step from Philox block n >> 1 (words x, y / z, w), fast path; failures noted
+        // (the chain id behind an empty asm: otherwise hipcc hoists the id-only first round and a half of all D / 2 Philox calls out
+        // of the step loop -- 150 registers it does not have: they go to scratch memory and come back every step)
+        mhx_u32 idl = id_lo, idh = id_hi;
+        asm volatile("" : "+v"(idl), "+v"(idh));
+        mhx_u64 fmw[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) fmw[w] = 0ull;
+        // Software pipeline over the Philox blocks: the table look-ups of block p are in flight while the rounds of block p + 1 run
+        // (one wave per SIMD has nothing else to hide an LDS round trip behind; straight after each other the look-ups cost a
+        // quarter of the kernel: 100 x ~100 cycles per wave-step)
+        constexpr int NP = (D + 1) / 2;
+        mhx_u32x4 w4 = mhx_philox(ks, idl, idh, step, (MHX_STREAM_PROPOSAL << 28) | 0u);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            typedef double mhx_d2 __attribute__((ext_vector_type(2)));
+            mhx_d2 xe[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const mhx_u32 ly = (h ? w4.w : w4.y) & (mhx_u32)(MHX_ZIG_N - 1);
+                xe[h].x = zt[ly]; xe[h].y = zt[ly + 1];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mhx_u32x4 wn = w4;
+            if (p + 1 < NP) wn = mhx_philox(ks, idl, idh, step, (MHX_STREAM_PROPOSAL << 28) | (mhx_u32)(p + 1));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int n = 2 * p + h;
+                if (n < D) {
+                    const mhx_u32 hi = h ? w4.z : w4.x, lo = h ? w4.w : w4.y;
+                    const double ax = mhx_zig_ax(hi, lo, xe[h].x);
+                    y[n] = mhx_zig_signed(ax, lo, zsign);
+                    const bool fail = !(ax < xe[h].y);
+                    fmw[n >> 6] |= (fail ? 1ull : 0ull) << (n & 63);
+                }
+            }
+            w4 = wn;
+        }
+        // ---- the wave-step's failures: queue, refine side by side, hand back
+        bool anyfail = false;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) anyfail = anyfail || fmw[w] != 0ull;
+        if (__ballot(anyfail)) {
+            int total = 0;
+            for (int win = 0; win == 0 || win < total; win += 64) {
+                int base = -win;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    mhx_u64 f = fmw[w];
+                    for (;;) {
+                        const mhx_u64 m = __ballot(f != 0ull);
+                        if (m == 0ull) break;
+                        if (f != 0ull) {
+                            const int e = base + (int)__builtin_amdgcn_mbcnt_hi((mhx_u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((mhx_u32)m, 0u));
+                            const int sl = 64 * w + __ffsll((long long)f) - 1;
+                            if (e >= 0 && e < 64) zq[e] = (unsigned short)(lane | (sl << 6));
+                        }
+                        f &= f - 1ull;
+                        base += __popcll(m);
+                    }
+                }
+                total = base + win;
+                MHX_WAVE_SYNC();
+                const int nent = total - win < 64 ? total - win : 64;
+                mhx_u32 ent = 0u;
+                double val = 0.0;
+                if (lane < nent) {
+                    ent = zq[lane];
+                    const int ol = (int)(ent & 63u);
+                    const long oc_raw = (long)blockIdx.x * 64 + ol;
+                    const mhx_u64 oid = a.first_chain + (mhx_u64)(oc_raw < a.nchains ? oc_raw : (long)a.nchains - 1);
+                    val = mhx_zig_refine(ks, zt, (mhx_u32)oid, (mhx_u32)(oid >> 32), step, MHX_STREAM_PROPOSAL, ent >> 6);
+                }
+                if (lane < nent) zres[lane] = val;
+                MHX_WAVE_SYNC();
+                // back to the owners: the same walk as the queue's -- a lane's r-th failure of word w sits at the position it was
+                // given there -- and every register of the word takes the value where the slot number says so: straight-line
+                // compare + select per register and round (a wave-uniform branch per failure into one of D registers costs
+                // hipcc's allocator a copy of the whole candidate per iteration; a run-time index sends the array to scratch)
+                base = -win;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    mhx_u64 f = fmw[w];
+                    for (;;) {
+                        const mhx_u64 m = __ballot(f != 0ull);
+                        if (m == 0ull) break;
+                        const int e = base + (int)__builtin_amdgcn_mbcnt_hi((mhx_u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((mhx_u32)m, 0u));
+                        const bool has = f != 0ull && e >= 0 && e < 64;
+                        int sls = has ? __ffsll((long long)f) - 1 : -1;
+                        asm volatile("" : "+v"(sls));          // (else hipcc splits the test into `has` AND a compare: 5 instructions per register for 3)
+                        const double pv = zres[has ? e : 0];
+#pragma unroll
+                        for (int b = 0; b < 64; ++b)
+                            if (64 * w + b < D) y[64 * w + b] = sls == b ? pv : y[64 * w + b];
+                        f &= f - 1ull;
+                        base += __popcll(m);
+                    }
+                }
+                MHX_WAVE_SYNC();                               // (the next window writes the queue and the results again)
+            }
+        }
+        // ---- propose: y = x + s n   (src/proposal.jl:49-56)
+#pragma unroll
+        for (int k = 0; k < D; ++k) y[k] = mhx_fma(PK == MHX_PROP_ISO ? a.pscale : pvec[k], y[k], getx(k));
+        // ---- log-density of the candidate and the accept test (src/mh-core.jl:103-108)
+        const double lpy = mhx_target_eval<TK>(TK, y, D, tparams, a.ntparams, a.tconst);
+        const double logu = mhx_accept_logu(ks, id_lo, id_hi, step, ac);
+        const bool acc = logu < (lpy - lp);          // strict; NaN compares false => reject
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            if (k < XR) x[k < XR ? k : 0] = acc ? y[k] : x[k < XR ? k : 0];
+            else if (acc) xl[(k - XR) * 64] = y[k];
+        }
+        lp = acc ? lpy : lp;
+        nacc += acc ? 1u : 0u;
+        last = acc;
+        wave_acc += (mhx_u32)__popcll(__ballot(acc && valid));
+        // ---- record (ext/AdvancedMHMCMCChainsExt.jl:96-105 layout, chain fastest)
+        if (step == save_next) {
+            if (valid) {
+                mhx_real* slotp = a.samples + slot * (long)(D + 1) * ld;
+                const mhx_srd srd = mhx_make_srd(slotp, (mhx_u32)(D + 1) * (mhx_u32)ld * MHX_RB);
+                const mhx_u32 ldb = (mhx_u32)ld * MHX_RB;
+                mhx_u32 roff = 0u;                            // (running row offset: MHX_COOP_REC_RUN in mhx_rwmh_coop_body)
+                asm volatile("" : "+s"(roff));
+#pragma unroll
+                for (int k = 0; k < D; ++k) { mhx_srd_store<MHX_REC_STORE_AUX>(srd, cu, roff, getx(k)); roff += ldb; }
+                mhx_srd_store<MHX_REC_STORE_AUX>(srd, cu, roff, lp);
+                a.accepted[slot * ld + c] = acc ? 1 : 0;
+            }
+            save_next += (mhx_u32)a.thinning;
+            ++slot;
+        }
+    }
+    if (valid) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) mhx_st_off(a.x + (long)k * ld, cu, getx(k));
+        a.lp[c] = lp;
+        a.acc_count[c] = nacc;
+        a.last_acc[c] = last ? 1 : 0;
+    }
+    if (lane == 0) atomicAdd(a.acc_total, (mhx_u64)wave_acc);
+}
+#endif
+
 template <int L, int NBL, int TK, int PK, bool MOM, int WALK = MHX_WALK_PLAIN, int GEN = MHX_GEN_BOX_MULLER>
 MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restrict__ tparams,
                                 const mhx_real* __restrict__ pvec)
@@ -1217,7 +1420,10 @@ MHX_DEV void mhx_moments_first_body(const mhx_real* __restrict__ x, const mhx_re
 extern "C" __global__ void __launch_bounds__(64)
 mhx_jit_rwmh_reg(const mhx_rwmh_args a, const mhx_real* __restrict__ tparams, const mhx_real* __restrict__ pvec)
 {
-#if MHX_JIT_XR < MHX_JIT_DIM
+#if defined(MHX_JIT_GEN) && MHX_JIT_GEN == 1
+    extern __shared__ double mhx_reg_zig_lds[];                // MHX_REG_ZIG_LDS_BYTES(MHX_JIT_DIM, MHX_JIT_XR)
+    mhx_rwmh_reg_zig_body<MHX_JIT_DIM, MHX_JIT_TK, MHX_JIT_PK, MHX_JIT_XR>(a, tparams, pvec, mhx_reg_zig_lds);
+#elif MHX_JIT_XR < MHX_JIT_DIM
     extern __shared__ mhx_real mhx_reg_state_tail[];           // [MHX_JIT_DIM - MHX_JIT_XR][64]
     mhx_rwmh_reg_body<MHX_JIT_DIM, MHX_JIT_TK, MHX_JIT_PK, MHX_JIT_XR>(a, tparams, pvec, mhx_reg_state_tail);
 #else

@@ -173,7 +173,7 @@ class C2:
         self.lanes = args.lanes
         self.literal = getattr(args, "c2_literal", False)
         self.user = getattr(args, "c2_user", False)       # the same target as a user log-density in HIP source: DensityModel(f), JIT-lowered
-        self.gen = "box-muller" if self.user else pick_gen(args, dtype)
+        self.gen = pick_gen(args, dtype)                  # (the register kernel of a user log-density has its ziggurat form too)
 
     USER_SOURCE = """
 MHX_LOGDENSITY(x, d, data, ndata)

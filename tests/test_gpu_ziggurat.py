@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 import cases
+import user_targets
 
 pytestmark = pytest.mark.gpu
 
@@ -182,3 +183,49 @@ def test_jit_defs_reach_hiprtc(mhx, f64, monkeypatch, tmp_path):
     with pytest.raises(Exception) as ei:
         mhx.sample(model, spl, 4, 64, seed=1, reduce_lanes=2, normal_gen="ziggurat")
     assert "hiprtc" in str(ei.value)
+
+
+@pytest.mark.parametrize("d,C,prop", [(5, 70, "iso"), (64, 33, "diag"), (100, 130, "iso"), (100, 64, "diag"), (130, 40, "iso"), (160, 65, "iso")])
+def test_ziggurat_on_the_register_kernel_with_a_user_log_density(mhx, oracle, f64, d, C, prop):
+    """normal_gen="ziggurat" on the lane-per-chain register kernel (any target; here a user's HIP source): fast-path normals straight
+    into the candidate's registers, the wave-step's failures queued, refined side by side and handed back to their owners' registers.
+    Same chains as the oracle at reduction shape 1 -- chains that do not fill a wave (idle lanes shadow the last chain), the state's
+    tail in LDS above 64 dimensions, one / two / three words of failure mask, thinning with a discarded prefix, the state after."""
+    rng = np.random.default_rng(1000 + d)
+    data = np.concatenate([rng.normal(size=d), 0.5 + rng.random(d)]).astype(np.float32)
+    model = mhx.DensityModel(mhx.HipLogDensity(user_targets.SHIFTED_GAUSS, d, data=data))
+    ut = user_targets.host_target(oracle, user_targets.SHIFTED_GAUSS, d, data=data)
+    if prop == "iso":
+        s = float(np.float32(2.38 / d ** 0.5))
+        spl, op = mhx.RWMH(mhx.MvNormal(mhx.zeros(d), s * s * mhx.I)), oracle.Proposal(oracle.PROP_ISO, s, normal_gen=1)
+    else:
+        sv = (np.float32(2.38 / d ** 0.5) * (0.5 + rng.random(d))).astype(np.float32)
+        spl, op = mhx.RWMH([mhx.Normal(0.0, float(v)) for v in sv]), oracle.Proposal(oracle.PROP_DIAG, vec=sv, normal_gen=1)
+    init = rng.normal(size=(d, C))
+    r = mhx.Run(model, spl, nchains=C, seed=91, first_chain=7, normal_gen="ziggurat")
+    r.init(init)
+    r.sample(40, 4, 3, 0)
+    got, got_acc = r.samples()
+    st_ = r.stats()
+    assert st_["kernel_variant"] == 2 and st_["normal_gen"] == 1
+    ref = oracle.rwmh(ut, op, oracle.schedule(40, 4, 3), 91, 7, C, init=init)
+    _same(got, ref["samples"], "samples")
+    _same(got_acc, ref["accepted"], "accepted")
+    x, lp, cnt = r.state()
+    _same(x, ref["final_x"], "final x")
+    _same(lp, ref["final_lp"], "final lp")
+    _same(cnt, ref["accept_counts"], "accept counts")
+
+
+def test_ziggurat_register_kernel_draws_its_own_start(mhx, oracle, f64):
+    """(no initial_params: the start is a bare proposal draw by the same generator, src/proposal.jl:41-47)"""
+    d, C = 24, 100
+    data = np.concatenate([np.zeros(d), np.ones(d)]).astype(np.float32)
+    model = mhx.DensityModel(mhx.HipLogDensity(user_targets.SHIFTED_GAUSS, d, data=data))
+    ut = user_targets.host_target(oracle, user_targets.SHIFTED_GAUSS, d, data=data)
+    s = float(np.float32(0.5))
+    chain = mhx.sample(model, mhx.RWMH(mhx.MvNormal(mhx.zeros(d), s * s * mhx.I)), 30, C, seed=5, normal_gen="ziggurat")
+    assert chain.stats["kernel_variant"] == 2 and chain.stats["normal_gen"] == 1
+    ref = oracle.rwmh(ut, oracle.Proposal(oracle.PROP_ISO, s, normal_gen=1), oracle.schedule(30), 5, 0, C)
+    _same(chain.value, ref["samples"], "samples")
+    _same(chain.accepted, ref["accepted"], "accepted")
