@@ -618,9 +618,20 @@ MHX_DEV void mhx_rwmh_reg_zig_body(const mhx_rwmh_args& a, const mhx_real* __res
                         int sls = has ? __ffsll((long long)f) - 1 : -1;
                         asm volatile("" : "+v"(sls));          // (else hipcc splits the test into `has` AND a compare: 5 instructions per register for 3)
                         const double pv = zres[has ? e : 0];
+                        // (registers in blocks of 8, a block skipped when no lane's slot lies in it: the first round of a word has
+                        // a dozen failures all over it, the later rounds one or two)
+#ifndef MHX_REG_ZIG_SKIP
+#define MHX_REG_ZIG_SKIP 0     // measured: 3.35 against 3.25 ms per launch at c2_user -- the ballots and branches cost more than the skipped selects
+#endif
+                        const int sblk = sls >> 3;
 #pragma unroll
-                        for (int b = 0; b < 64; ++b)
-                            if (64 * w + b < D) y[64 * w + b] = sls == b ? pv : y[64 * w + b];
+                        for (int blk = 0; blk < 8; ++blk) {
+                            if (64 * w + 8 * blk < D && (!MHX_REG_ZIG_SKIP || __ballot(sblk == blk) != 0ull)) {
+#pragma unroll
+                                for (int b = 8 * blk; b < 8 * blk + 8; ++b)
+                                    if (64 * w + b < D) y[64 * w + b] = sls == b ? pv : y[64 * w + b];
+                            }
+                        }
                         f &= f - 1ull;
                         base += __popcll(m);
                     }

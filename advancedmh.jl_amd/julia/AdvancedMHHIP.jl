@@ -69,7 +69,7 @@ Run all chains of `sample(model, sampler, MCMCHIP(), N, nchains)` on one MI355X.
 `Float64` (what AdvancedMH.jl computes in) or `Float32`.  With several processes (one per GPU) give each its shard via
 `first_chain`: chains carry global ids in their RNG counters, so the union of the shards is the unsharded run.
 `sequential_ensemble = true` runs `Ensemble` with the reference's own Gauss-Seidel sweep (src/emcee.jl:39-58) instead
-of the parallel half-split.  `ziggurat = true` (Float64, RWMH on a separable catalogue target): standard normals by the
+of the parallel half-split.  `ziggurat = true` (Float64, RWMH with an isotropic / diagonal proposal: catalogue targets and `HipSource` log-densities): standard normals by the
 engine's table ziggurat instead of Box-Muller (MHX_FLAG_ZIGGURAT -- what Julia's own `randn` is; a third faster).
 """
 Base.@kwdef struct MCMCHIP <: AbstractMCMC.AbstractMCMCEnsemble

@@ -495,8 +495,9 @@ class Chains:
 class Run:
     def __init__(self, model, sampler, nchains=1, seed=0, first_chain=0, ctx=None, flags=0, reduce_lanes=0, dtype=None,
                  normal_gen=None):
-        """normal_gen: None / "box-muller" (default) or "ziggurat" (MHX_FLAG_ZIGGURAT: RWMH on the cooperative kernel of an fp64
-        context -- a different, cheaper stream of standard normals; reported in stats()["normal_gen"])."""
+        """normal_gen: None / "box-muller" (default) or "ziggurat" (MHX_FLAG_ZIGGURAT: RWMH on the cooperative or the register
+        kernel of an fp64 context, user log-densities included -- a different, cheaper stream of standard normals; reported in
+        stats()["normal_gen"])."""
         if normal_gen not in (None, "box-muller", "ziggurat"):
             raise L.ArgumentError(L.MHX_EINVAL, "normal_gen must be None, 'box-muller' or 'ziggurat'")
         if normal_gen == "ziggurat":

@@ -140,10 +140,11 @@ typedef struct {
 #define MHX_FLAG_ZIGGURAT 16 /* RWMH runs, fp64 contexts: standard normals by the table ZIGGURAT of the arithmetic spec (DESIGN.md
                                 section 3.11: 1024 equal-area layers, 64 bits per normal, exact rejection sampling) instead of
                                 Box-Muller -- a third fewer instructions per transition on the cooperative kernel (separable
-                                catalogue targets, ISO / DIAG proposals).  It selects the STREAM of normals, so the chain differs
+                                catalogue targets) and on the register kernel (any target within its dimension limit, a user's
+                                HIP source included), ISO / DIAG proposals.  It selects the STREAM of normals, so the chain differs
                                 from the Box-Muller chain of the same seed (both target the same law); the value in effect is
                                 reported in mhx_stats.normal_gen and fixes the chain bit for bit.  MHX_EINVAL where the run's
-                                kernel has no ziggurat form (fp32, dense factors, user targets, register / generic kernels). */
+                                kernel has no ziggurat form (fp32, dense factors, the matrix-core and state-in-HBM kernels). */
 #define MHX_FLAG_DENSE_FACTOR 32 /* Ensemble runs: treat the precision factor of a dense-Gaussian target as dense even when it is
                                    banded (exact zeros below a band of width <= 8 are otherwise detected and skipped -- same bits) */
 #define MHX_FLAG_STATIC_PROPOSAL 4 /* RWMH runs only: the proposal is a StaticProposal (src/proposal.jl:9-11,66-83) --
