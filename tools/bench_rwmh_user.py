@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """RWMH with a user log-density in HIP source (JIT-lowered, evaluated per lane): independent shifted Gaussians, 65 536 chains,
-save-all launches of 50 transitions.  DIMS="50 80 100 128", MHX_DTYPE=f32|f64.  Which kernel runs it and how fast."""
+save-all launches of 50 transitions.  DIMS="50 80 100 128", MHX_DTYPE=f32|f64, MHX_GEN=ziggurat (fp64: the register kernel's ziggurat form).  Which kernel runs it and how fast."""
 import json
 import os
 import sys
@@ -18,7 +18,7 @@ for d in [int(x) for x in os.environ.get("DIMS", "50 80 100 128").split()]:
     data = np.concatenate([np.zeros(d), np.ones(d)]).astype(np.float32)
     model = mhx.DensityModel(mhx.HipLogDensity(user_targets.SHIFTED_GAUSS, d, data=data))
     s = float(np.float32(2.38 / d ** 0.5))
-    run = mhx.Run(model, mhx.RWMH(mhx.MvNormal(mhx.zeros(d), s * s * mhx.I)), nchains=C, seed=1)
+    run = mhx.Run(model, mhx.RWMH(mhx.MvNormal(mhx.zeros(d), s * s * mhx.I)), nchains=C, seed=1, normal_gen=os.environ.get("MHX_GEN") or None)
     run.init(np.zeros(d))
     run.sample(50, 0, 1, 0, save=True)
     run.sample(50, 0, 1, 0, save=True)
