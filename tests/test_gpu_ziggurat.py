@@ -229,3 +229,23 @@ def test_ziggurat_register_kernel_draws_its_own_start(mhx, oracle, f64):
     ref = oracle.rwmh(ut, oracle.Proposal(oracle.PROP_ISO, s, normal_gen=1), oracle.schedule(30), 5, 0, C)
     _same(chain.value, ref["samples"], "samples")
     _same(chain.accepted, ref["accepted"], "accepted")
+
+
+def test_ziggurat_register_kernel_block_skip_knob_changes_no_bit(mhx, oracle, f64, monkeypatch):
+    """(MHX_REG_ZIG_SKIP = 1: the patch rounds skip blocks of 8 registers no lane's slot lies in -- measured slower, kept as a knob)"""
+    monkeypatch.setenv("MHX_JIT_DEFS", "MHX_REG_ZIG_SKIP=1")
+    d, C = 100, 70
+    rng = np.random.default_rng(4)
+    data = np.concatenate([rng.normal(size=d), 0.5 + rng.random(d)]).astype(np.float32)
+    model = mhx.DensityModel(mhx.HipLogDensity(user_targets.SHIFTED_GAUSS, d, data=data))
+    ut = user_targets.host_target(oracle, user_targets.SHIFTED_GAUSS, d, data=data)
+    s = float(np.float32(2.38 / d ** 0.5))
+    init = rng.normal(size=(d, C))
+    r = mhx.Run(model, mhx.RWMH(mhx.MvNormal(mhx.zeros(d), s * s * mhx.I)), nchains=C, seed=12, normal_gen="ziggurat")
+    r.init(init)
+    r.sample(25)
+    got, got_acc = r.samples()
+    assert r.stats()["kernel_variant"] == 2 and r.stats()["normal_gen"] == 1
+    ref = oracle.rwmh(ut, oracle.Proposal(oracle.PROP_ISO, s, normal_gen=1), oracle.schedule(25), 12, 0, C, init=init)
+    _same(got, ref["samples"], "samples")
+    _same(got_acc, ref["accepted"], "accepted")
