@@ -158,10 +158,23 @@ MHX_DEV void mhx_rwmh_reg_body(const mhx_rwmh_args& a, const mhx_real* __restric
         const mhx_real lpy = mhx_target_eval<TK>(TK, y, D, tparams, a.ntparams, a.tconst);
         const mhx_real logu = mhx_accept_logu(ks, id_lo, id_hi, step, ac);
         const bool acc = logu < (lpy - lp);          // strict; NaN compares false => reject
+#ifndef MHX_REG_ACC_BRANCH
+#define MHX_REG_ACC_BRANCH MHX_REAL64    // (fp64: see MHX_REG_ZIG_BRANCH in mhx_rwmh_reg_zig_body -- the accepted lanes move the candidate over the state)
+#endif
+        if (MHX_REG_ACC_BRANCH) {
+            if (acc) {
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    if (k < XR) x[k < XR ? k : 0] = y[k];
+                    else xl[(k - XR) * 64] = y[k];
+                }
+            }
+        } else {
 #pragma unroll
         for (int k = 0; k < D; ++k) {
             if (k < XR) x[k < XR ? k : 0] = acc ? y[k] : x[k < XR ? k : 0];
             else if (acc) xl[(k - XR) * 64] = y[k];
+        }
         }
         lp = acc ? lpy : lp;
         nacc += acc ? 1u : 0u;
@@ -646,10 +659,25 @@ MHX_DEV void mhx_rwmh_reg_zig_body(const mhx_rwmh_args& a, const mhx_real* __res
         const double lpy = mhx_target_eval<TK>(TK, y, D, tparams, a.ntparams, a.tconst);
         const double logu = mhx_accept_logu(ks, id_lo, id_hi, step, ac);
         const bool acc = logu < (lpy - lp);          // strict; NaN compares false => reject
+#ifndef MHX_REG_ZIG_BRANCH
+#define MHX_REG_ZIG_BRANCH 1
+#endif
+        if (MHX_REG_ZIG_BRANCH) {
+            // (the accepted lanes MOVE the candidate over the state under their execute mask: where the state's registers are AGPRs
+            // -- d = 100: all 60 of them -- a select costs read + 2 v_cndmask + write per real, the move one write per word)
+            if (acc) {
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    if (k < XR) x[k < XR ? k : 0] = y[k];
+                    else xl[(k - XR) * 64] = y[k];
+                }
+            }
+        } else {
 #pragma unroll
         for (int k = 0; k < D; ++k) {
             if (k < XR) x[k < XR ? k : 0] = acc ? y[k] : x[k < XR ? k : 0];
             else if (acc) xl[(k - XR) * 64] = y[k];
+        }
         }
         lp = acc ? lpy : lp;
         nacc += acc ? 1u : 0u;
