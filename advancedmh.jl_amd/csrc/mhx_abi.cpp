@@ -7,9 +7,13 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <mutex>
 #include <string>
 
 static thread_local std::string g_err;
+static std::mutex g_jit_mu;
+void mhx_jit_lock() { g_jit_mu.lock(); }
+void mhx_jit_unlock() { g_jit_mu.unlock(); }
 
 int mhx_fail(int code, const char* fmt, ...)
 {
@@ -61,6 +65,23 @@ extern "C" int mhx_ctx_device(const mhx_ctx* ctx, int* device)
     if (!ctx || !device) return mhx_fail(MHX_EINVAL, "mhx_ctx_device: NULL argument");
     *device = is64(ctx) ? mhx_f64::api_ctx_device(reinterpret_cast<const mhx_f64::mhx_ctx*>(ctx)) : mhx_f32::api_ctx_device(reinterpret_cast<const mhx_f32::mhx_ctx*>(ctx));
     return MHX_OK;
+}
+extern "C" int mhx_ctx_set_option(mhx_ctx* ctx, const char* name, const char* value)
+{
+    NEED(ctx, "mhx_ctx_set_option");
+    return is64(ctx) ? mhx_f64::api_ctx_set_option(C64(ctx), name, value) : mhx_f32::api_ctx_set_option(C32(ctx), name, value);
+}
+extern "C" int mhx_ctx_get_option(const mhx_ctx* ctx, const char* name, char* buf, size_t len)
+{
+    NEED(ctx, "mhx_ctx_get_option");
+    return is64(ctx) ? mhx_f64::api_ctx_get_option(reinterpret_cast<const mhx_f64::mhx_ctx*>(ctx), name, buf, len)
+                     : mhx_f32::api_ctx_get_option(reinterpret_cast<const mhx_f32::mhx_ctx*>(ctx), name, buf, len);
+}
+extern "C" int mhx_ctx_pci_bus_id(const mhx_ctx* ctx, char* buf, size_t len)
+{
+    NEED(ctx, "mhx_ctx_pci_bus_id");
+    return is64(ctx) ? mhx_f64::api_ctx_pci_bus_id(reinterpret_cast<const mhx_f64::mhx_ctx*>(ctx), buf, len)
+                     : mhx_f32::api_ctx_pci_bus_id(reinterpret_cast<const mhx_f32::mhx_ctx*>(ctx), buf, len);
 }
 extern "C" int mhx_ctx_jit_counts(const mhx_ctx* ctx, int64_t* compiles, int64_t* cache_hits)
 {
@@ -249,6 +270,12 @@ extern "C" int mhx_run_stats(mhx_run* r, mhx_stats* out)
 {
     NEED(r, "mhx_run_stats");
     return is64(r) ? mhx_f64::api_run_stats(R64(r), out) : mhx_f32::api_run_stats(R32(r), out);
+}
+extern "C" int mhx_run_shape(const mhx_run* r, int32_t* dim, int32_t* nchains)
+{
+    NEED(r, "mhx_run_shape");
+    return is64(r) ? mhx_f64::api_run_shape(reinterpret_cast<const mhx_f64::mhx_run*>(r), dim, nchains)
+                   : mhx_f32::api_run_shape(reinterpret_cast<const mhx_f32::mhx_run*>(r), dim, nchains);
 }
 extern "C" int mhx_run_destroy(mhx_run* r)
 {

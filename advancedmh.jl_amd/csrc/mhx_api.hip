@@ -31,7 +31,11 @@
 #include "mhx_rwmh_mfma_kernels.h"
 #include "mhx_mala_mfma_kernels.h"
 #include "mhx_diag_kernels.h"
-#include "mhx_jit_embed.inc"   // generated: the device headers as string literals for hiprtc
+#ifdef MHX_TOOLS_BUILD
+#include "mhx_jit_embed_tools.inc"   // generated: the device headers as string literals for hiprtc, probes included
+#else
+#include "mhx_jit_embed.inc"         // generated (embed_headers.py --release): the same text without its MHX_TOOLS_BUILD blocks
+#endif
 #include "mhx_impl.h"           // the prototypes of this instantiation (api_*), shared with the dispatcher mhx_abi.cpp
 
 #define HIP_TRY(expr)                                                                              \
@@ -171,6 +175,8 @@ struct mhx_ctx : mhx_handle_hdr {
     hipStream_t copy_stream = nullptr;
     hipEvent_t slab_done[2] = {nullptr, nullptr}, slab_free[2] = {nullptr, nullptr};
     long pins_registered = 0, pins_released = 0;    // caller buffers page-locked for the duration of a call / released again
+    std::map<std::string, std::string> options;     // mhx_ctx_set_option: explicit engine options (never the environment)
+    bool tainted = false;                           // a probe / fault-injection option of the tools build was set: results may be invalid
     ~mhx_ctx()
     {
         for (int i = 0; i < 2; ++i) {
@@ -204,6 +210,70 @@ int api_ctx_create(int device, mhx_ctx** out)
 }
 
 int api_ctx_device(const mhx_ctx* ctx) { return ctx->device; }
+
+// ---- engine options (include/mhx.h: mhx_ctx_set_option) -------------------------------------------------------------------
+// probe = 1: timing probes and fault injection -- they exist in the tools build only (libmhx_tools.so, -DMHX_TOOLS_BUILD) and
+// taint the context; the release library does not even carry their names.
+struct opt_name { const char* name; int probe; };
+static const opt_name k_opt_names[] = {
+    {"NO_PREBUILT", 0}, {"NO_MFMA", 0}, {"MFMA_WAVES", 0}, {"REG_MAX_DIM", 0}, {"REG_XR", 0}, {"REG_UNROLL", 0}, {"COOP_WAVES", 0},
+    {"MALA_XR", 0}, {"RAM_G", 0}, {"RAM_LDS_PAD", 0},
+    {"EMCEE_MFMA", 0}, {"EMCEE_MFMA_WAVES", 0}, {"EMCEE_SCALAR", 0}, {"EMCEE_SCAL_MODE", 0}, {"EMCEE_SCAL_WPB", 0}, {"EMCEE_SCAL_REC", 0},
+    {"EMCEE_FUSED", 0}, {"EMCEE_PERSIST", 0}, {"EMCEE_PRELOAD", 0}, {"EMCEE_DEFER", 0}, {"EMCEE_SWEEP_DEFER", 0}, {"EMCEE_WAVES", 0},
+    {"EMCEE_REC_STORE", 0}, {"EMCEE_ROW_STORE", 0}, {"EMCEE_COOP_REC", 0},
+#ifdef MHX_TOOLS_BUILD
+    {"ZIG_PROBE", 1}, {"ZIG_FORCE_FAIL", 1}, {"JIT_DEFS", 1}, {"EMCEE_PROBE", 1}, {"EMCEE_STAMPS", 1}, {"EMCEE_STAMPS_FILE", 1},
+    {"FAULT_SLAB", 1},
+#endif
+};
+static const opt_name* opt_find(const char* name)
+{
+    if (name)
+        for (const opt_name& o : k_opt_names)
+            if (!strcmp(o.name, name)) return &o;
+    return nullptr;
+}
+// probe options are compiled out of the release library, names included
+#ifdef MHX_TOOLS_BUILD
+#define MHX_PROBE_OPT(ctx, name) opt(ctx, name)
+#else
+#define MHX_PROBE_OPT(ctx, name) ((const char*)nullptr)
+#endif
+// the value of an option, or nullptr when unset (the shape of the getenv() calls this replaced)
+static const char* opt(const mhx_ctx* ctx, const char* name)
+{
+    if (!ctx || ctx->options.empty()) return nullptr;
+    auto it = ctx->options.find(name);
+    return it == ctx->options.end() ? nullptr : it->second.c_str();
+}
+int api_ctx_set_option(mhx_ctx* ctx, const char* name, const char* value)
+{
+    const opt_name* o = opt_find(name);
+    if (!o) return mhx_fail(MHX_EINVAL, "mhx_ctx_set_option: unknown option '%s'%s", name ? name : "(null)",
+#ifdef MHX_TOOLS_BUILD
+                            "");
+#else
+                            " (timing probes and fault injection exist in the tools build only: libmhx_tools.so)");
+#endif
+    if (!value) { ctx->options.erase(name); return MHX_OK; }
+    ctx->options[name] = value;
+    if (o->probe) ctx->tainted = true;              // sticky: a context that ever carried a probe stays marked
+    return MHX_OK;
+}
+int api_ctx_get_option(const mhx_ctx* ctx, const char* name, char* buf, size_t len)
+{
+    if (!opt_find(name)) return mhx_fail(MHX_EINVAL, "mhx_ctx_get_option: unknown option '%s'", name ? name : "(null)");
+    if (!buf || !len) return mhx_fail(MHX_EINVAL, "mhx_ctx_get_option: no buffer");
+    const char* v = opt(ctx, name);
+    snprintf(buf, len, "%s", v ? v : "");
+    return MHX_OK;
+}
+int api_ctx_pci_bus_id(const mhx_ctx* ctx, char* buf, size_t len)
+{
+    if (!buf || len < 16) return mhx_fail(MHX_EINVAL, "mhx_ctx_pci_bus_id: buffer of >= 16 bytes needed");
+    HIP_TRY(hipDeviceGetPCIBusId(buf, (int)len, ctx->device));
+    return MHX_OK;
+}
 int api_ctx_host_pin_counts(const mhx_ctx* ctx, long* registered, long* released)
 {
     if (registered) *registered = ctx->pins_registered;
@@ -296,9 +366,11 @@ static void jit_cache_write(const std::string& dir, const std::string& name, con
 static int jit_compile(mhx_ctx* ctx, const std::string& key_in, const std::string& source,
                        const std::vector<std::string>& defines, jit_module** out, const std::vector<std::string>& extra_opts = {})
 {
-    // MHX_JIT_DEFS="NAME=VALUE NAME=VALUE": extra defines for every hiprtc compile of this process -- how the tests and the A/B
-    // scripts reach the kernels' compile-time knobs (MHX_COOP_WIDE_REC, MHX_ZIG_SIGNACC, ...); part of both cache keys
-    const char* xdefs = getenv("MHX_JIT_DEFS");
+    // tools build, option JIT_DEFS = "NAME=VALUE NAME=VALUE": extra defines for every hiprtc compile of the context -- how the A/B
+    // scripts reach the kernels' compile-time knobs; part of both cache keys.  It taints the context (a define can change a
+    // kernel's LDS layout behind the host's back), and the release library has no such door.
+    const char* xdefs = MHX_PROBE_OPT(ctx, "JIT_DEFS");
+    struct jit_guard { jit_guard() { mhx_jit_lock(); } ~jit_guard() { mhx_jit_unlock(); } } one_at_a_time;
     const std::string key = (xdefs && *xdefs) ? key_in + "/xd=" + xdefs : key_in;
     auto it = ctx->jit.find(key);
     if (it != ctx->jit.end()) { *out = it->second.get(); return MHX_OK; }
@@ -311,6 +383,9 @@ static int jit_compile(mhx_ctx* ctx, const std::string& key_in, const std::strin
                               "mhx_rwmh_dense_kernels.h", "mhx_rwmh_mfma_kernels.h", "mhx_mala_mfma_kernels.h", "mhx_emcee_mfma_kernels.h"};
     std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
                                      MHX_REAL64 ? "-DMHX_REAL64=1" : "-DMHX_REAL64=0", "-DMHX_XW_LINE=" + std::to_string(MHX_XW_LINE)};
+#ifdef MHX_TOOLS_BUILD
+    opts.push_back("-DMHX_TOOLS_BUILD=1");              // the embedded headers of this build carry the probes
+#endif
     for (auto& d : defines) opts.push_back("-D" + d);
     if (xdefs)
         for (const char* p = xdefs; *p;) {
@@ -758,9 +833,9 @@ static size_t mfma_image_reals(int d)
     return (size_t)(2 * (NT - 1) * NT + 4 * ((last + 3) / 4)) * 64;
 }
 static size_t mfma_image_reals_T(int d) { const int NT = (d + 15) / 16; return (size_t)(NT * (NT + 1) / 2) * 256; }   // the image of A^T
-static bool mfma_fits(int d, int reduce_lanes, int nimages)
+static bool mfma_fits(const mhx_ctx* ctx, int d, int reduce_lanes, int nimages)
 {
-    const char* no_mfma = getenv("MHX_NO_MFMA");                      // tuning knob: the vector kernel instead
+    const char* no_mfma = opt(ctx, "NO_MFMA");                      // tuning knob: the vector kernel instead
     return (reduce_lanes == 0 || reduce_lanes == 4) && d >= 16 && (d + 3) / 4 <= MHX_MFMA_MAX_NS && !(no_mfma && atoi(no_mfma)) &&
            nimages * mfma_image_reals(d) * sizeof(mhx_real) <= MHX_LDS_PER_BLOCK;
 }
@@ -780,20 +855,20 @@ static size_t mfma_ring_bytes(int d, bool pair = true)
     return (size_t)2 * pf * 64 * MHX_MFMA_WAVES * 16;
 }
 // 0 = no, 1 = tile pairs + state in registers, 2 = single tiles + state in HBM
-static int mfma_stream_mode(int d, int reduce_lanes)
+static int mfma_stream_mode(const mhx_ctx* ctx, int d, int reduce_lanes)
 {
-    const char* no_mfma = getenv("MHX_NO_MFMA");
+    const char* no_mfma = opt(ctx, "NO_MFMA");
     if (!((reduce_lanes == 0 || reduce_lanes == 4) && d >= 16) || (no_mfma && atoi(no_mfma))) return 0;
     const int NS = (d + 3) / 4;
     if (NS <= MHX_MFMA_STREAM_MAX_NS && mfma_ring_bytes(d, true) <= MHX_LDS_PER_BLOCK) return 1;
     if (NS <= MHX_MFMA_XMEM_MAX_NS && mfma_ring_bytes(d, false) <= MHX_LDS_PER_BLOCK) return 2;
     return 0;
 }
-static bool mfma_stream_fits(int d, int reduce_lanes) { return mfma_stream_mode(d, reduce_lanes) != 0; }
-static int mfma_waves(int d)
+static bool mfma_stream_fits(const mhx_ctx* ctx, int d, int reduce_lanes) { return mfma_stream_mode(ctx, d, reduce_lanes) != 0; }
+static int mfma_waves(const mhx_ctx* ctx, int d)
 {
     const int NS = (d + 3) / 4;
-    if (const char* w = getenv("MHX_MFMA_WAVES")) return std::max(1, atoi(w));        // tuning knob
+    if (const char* w = opt(ctx, "MFMA_WAVES")) return std::max(1, atoi(w));        // tuning knob
     return MHX_REAL64 ? (NS <= 25 ? 2 : 1) : (NS <= 25 ? 3 : (NS <= 40 ? 2 : 1));
 }
 
@@ -867,7 +942,7 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
     if ((cfg->flags & MHX_FLAG_ZIGGURAT) && d >= (1 << 20))      // the retry blocks are numbered (normal index << 8 | attempt) in 28 bits
         return mhx_fail(MHX_EINVAL, "MHX_FLAG_ZIGGURAT: dim must be below 2^20");
     int regmax = pk == MHX_PROP_DENSE ? MHX_REG_MAX_DIM_DENSE : MHX_REG_MAX_DIM;
-    if (const char* rm = getenv("MHX_REG_MAX_DIM")) regmax = atoi(rm);      // tuning knob
+    if (const char* rm = opt(ctx, "REG_MAX_DIM")) regmax = atoi(rm);      // tuning knob
     const int nblk = (d + 3) / 4;
     const bool separable = tk == MHX_TARGET_ISO_GAUSS || tk == MHX_TARGET_BANANA || tk == MHX_TARGET_FUNNEL;
     // lanes per chain: cfg->reduce_lanes, or (auto) the smallest power of two that (a) keeps a lane's
@@ -893,8 +968,8 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
     } else if (((tk == MHX_TARGET_CORR_GAUSS) || (tk == MHX_TARGET_ISO_GAUSS && pk == MHX_PROP_DENSE)) &&
                !walk && !(r->flags & (MHX_FLAG_GENERIC | MHX_FLAG_NO_JIT)) && d >= 2 && d <= 4 * std::max(MHX_MFMA_STREAM_MAX_NS, MHX_MFMA_XMEM_MAX_NS) &&
                (cfg->reduce_lanes > 1 || (cfg->reduce_lanes == 0 && d >= 16)) &&
-               (mfma_fits(d, cfg->reduce_lanes, (tk == MHX_TARGET_CORR_GAUSS ? 1 : 0) + (pk == MHX_PROP_DENSE ? 1 : 0)) ||
-                mfma_stream_fits(d, cfg->reduce_lanes) ||
+               (mfma_fits(ctx, d, cfg->reduce_lanes, (tk == MHX_TARGET_CORR_GAUSS ? 1 : 0) + (pk == MHX_PROP_DENSE ? 1 : 0)) ||
+                mfma_stream_fits(ctx, d, cfg->reduce_lanes) ||
                 dense_coop_fits(d, cfg->reduce_lanes > 1 ? cfg->reduce_lanes : dense_coop_lanes(d),
                                 (tk == MHX_TARGET_CORR_GAUSS ? 1 : 0) + (pk == MHX_PROP_DENSE ? 1 : 0)))) {
         // a dense factor in play (dense Gaussian target, dense proposal, or both): the cooperative kernel of
@@ -905,9 +980,9 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
         // ONE factor for all chains makes the row products a GEMM over the chains of a wave: the matrix-core kernel
         // (reduction shape L = 4, bit-identical to the vector kernel in that shape) wherever its images and state fit
         const int nimg = (tk == MHX_TARGET_CORR_GAUSS ? 1 : 0) + (pk == MHX_PROP_DENSE ? 1 : 0);
-        if (mfma_fits(d, cfg->reduce_lanes, nimg)) {
+        if (mfma_fits(ctx, d, cfg->reduce_lanes, nimg)) {
             jit_module* m = nullptr;
-            const int waves = mfma_waves(d);
+            const int waves = mfma_waves(ctx, d);
             const std::string key = "rwmh_mfma/d=" + std::to_string(d) + "/pk=" + std::to_string(pk) + "/tk=" + std::to_string(tk) +
                                     "/w=" + std::to_string(waves);
             rc = jit_compile(ctx, key, jit_source(t, "mhx_rwmh_mfma_kernels.h"),
@@ -921,11 +996,11 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
             }
             if (rc == MHX_OK) { r->variant = 8; r->coop_L = 4; }
         }
-        if (!r->variant && mfma_stream_fits(d, cfg->reduce_lanes)) {
+        if (!r->variant && mfma_stream_fits(ctx, d, cfg->reduce_lanes)) {
             // the images do not fit a block's LDS: they stay in global memory (built once, here) and every block walks them
             // through an LDS ring, one tile pair at a time
             jit_module* m = nullptr;
-            const int smode = mfma_stream_mode(d, cfg->reduce_lanes);
+            const int smode = mfma_stream_mode(ctx, d, cfg->reduce_lanes);
             const std::string key = "rwmh_mfma_stream/d=" + std::to_string(d) + "/pk=" + std::to_string(pk) + "/tk=" + std::to_string(tk) +
                                     "/mode=" + std::to_string(smode);
             // the kernel is fully unrolled over its tiles: lift hipcc's size limit for `#pragma unroll` (past it the candidate
@@ -992,8 +1067,8 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
         if (NBL > MHX_COOP_NBL_MAX) return mhx_fail(MHX_EINVAL, "reduce_lanes=%d leaves %d blocks per lane (max %d)", L, NBL, MHX_COOP_NBL_MAX);
         // tuning knobs: MHX_NO_PREBUILT=1 specialises with hiprtc even where a pre-built kernel exists; MHX_COOP_WAVES=w
         // overrides the waves-per-SIMD launch bound of the hiprtc kernel (register budget 512 / w)
-        const char* no_prebuilt = getenv("MHX_NO_PREBUILT");
-        const char* waves_env = getenv("MHX_COOP_WAVES");
+        const char* no_prebuilt = opt(ctx, "NO_PREBUILT");
+        const char* waves_env = opt(ctx, "COOP_WAVES");
         const int waves_override = waves_env ? atoi(waves_env) : 0;
         const bool zig = (cfg->flags & MHX_FLAG_ZIGGURAT) != 0;
 #if MHX_REAL64
@@ -1018,20 +1093,24 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
             jit_module* m = nullptr;
             const std::string key = "rwmh_coop/l=" + std::to_string(L) + "/nbl=" + std::to_string(NBL) + "/tk=" +
                                     std::to_string(tk) + "/pk=" + std::to_string(pk) + "/w=" + std::to_string(waves_override) +
-                                    "/walk=" + std::to_string(walk) + "/gen=" + std::to_string(zig ? 1 : 0) +
-                                    (getenv("MHX_ZIG_PROBE") ? std::string("/zp=") + getenv("MHX_ZIG_PROBE") : std::string()) +
-                                    (getenv("MHX_ZIG_FORCE_FAIL") ? std::string("/zff=") + getenv("MHX_ZIG_FORCE_FAIL") : std::string());
+                                    "/walk=" + std::to_string(walk) + "/gen=" + std::to_string(zig ? 1 : 0)
+#ifdef MHX_TOOLS_BUILD
+                                    + (opt(ctx, "ZIG_PROBE") ? std::string("/zp=") + opt(ctx, "ZIG_PROBE") : std::string()) +
+                                    (opt(ctx, "ZIG_FORCE_FAIL") ? std::string("/zff=") + opt(ctx, "ZIG_FORCE_FAIL") : std::string())
+#endif
+                                    ;
             std::vector<std::string> defs = {"MHX_JIT_RWMH_COOP=1", "MHX_JIT_L=" + std::to_string(L), "MHX_JIT_NBL=" + std::to_string(NBL),
                                              "MHX_JIT_TK=" + std::to_string(tk), "MHX_JIT_PK=" + std::to_string(pk), "MHX_JIT_MOM=0",
                                              "MHX_JIT_WALK=" + std::to_string(walk), std::string("MHX_JIT_GEN=") + (zig ? "1" : "0")};
             if (waves_override > 0) defs.push_back("MHX_JIT_WAVES=" + std::to_string(waves_override));
-            if (const char* il = getenv("MHX_COOP_INTERLEAVE")) defs.push_back(std::string("MHX_COOP_INTERLEAVE=") + il);   // tuning knob
-            if (const char* zf = getenv("MHX_ZIG_FORCE_FAIL"))             // test knob: see mhx_rwmh_kernels.h (the chains stay valid)
+#ifdef MHX_TOOLS_BUILD
+            if (const char* zf = opt(ctx, "ZIG_FORCE_FAIL"))                       // test hook: see mhx_rwmh_kernels.h (the chains stay valid)
                 if (atoi(zf) > 0) defs.push_back(std::string("MHX_ZIG_FORCE_FAIL=") + std::to_string(atoi(zf)));
-            if (const char* zp = getenv("MHX_ZIG_PROBE")) {                // timing probe: the chains of such a run are NOT valid
+            if (const char* zp = opt(ctx, "ZIG_PROBE")) {                          // timing probe: the chains of such a run are NOT valid
                 defs.push_back(std::string("MHX_ZIG_PROBE=") + zp);
-                fprintf(stderr, "mhx: MHX_ZIG_PROBE=%s -- timing probe, this run's chains are NOT valid\n", zp);
+                fprintf(stderr, "mhx (tools build): ZIG_PROBE=%s -- timing probe, this run's chains are NOT valid (stats.tainted = 1)\n", zp);
             }
+#endif
             rc = jit_compile(ctx, key + "/mom=0", jit_source(t, "mhx_rwmh_kernels.h"), defs, &m);
             if (rc == MHX_OK) rc = jit_function(m, "mhx_jit_rwmh_coop", &r->jit_step);
 #if MHX_REAL64
@@ -1078,13 +1157,13 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
         // `for (k < d)` loop above that (d = 100 with one division per term) stays a loop, its array lands in scratch memory and
         // the kernel runs 3 x slower (the cliff between d = 96 and d = 100 of the first measurement).
         const bool split = d > MHX_REG_XR_ALL && d <= 2 * MHX_REG_MAX_DIM && pk != MHX_PROP_DENSE;
-        if (!getenv("MHX_REG_MAX_DIM") && split) regmax = 2 * MHX_REG_MAX_DIM;
+        if (!opt(ctx, "REG_MAX_DIM") && split) regmax = 2 * MHX_REG_MAX_DIM;
         if (!r->variant && !(r->flags & MHX_FLAG_NO_JIT) && d <= regmax &&
             !(tk == MHX_TARGET_CORR_GAUSS && d > (MHX_REAL64 ? 32 : 64)) && !(tk == MHX_TARGET_IID_NORMAL && t->nparams > 4096)) {
             jit_module* m = nullptr;
             int xr = split ? MHX_REG_XR_CAP : d;
-            if (const char* xe = getenv("MHX_REG_XR")) xr = std::max(0, std::min(d, atoi(xe)));      // tuning knobs
-            const char* ut = getenv("MHX_REG_UNROLL");
+            if (const char* xe = opt(ctx, "REG_XR")) xr = std::max(0, std::min(d, atoi(xe)));      // tuning knobs
+            const char* ut = opt(ctx, "REG_UNROLL");
             std::vector<std::string> xo;
             if (!ut || atoi(ut) > 0) xo = {"-mllvm", std::string("-amdgpu-unroll-threshold-private=") + (ut ? ut : "100000")};
             // MHX_FLAG_ZIGGURAT (fp64, ISO / DIAG proposal): the register kernel's ziggurat form (mhx_rwmh_reg_zig_body) -- any target,
@@ -1346,6 +1425,7 @@ int api_run_sample(mhx_run* r, const mhx_schedule* s, int save_samples)
     r->n_saved = 0;
     r->moments_mode = false;
     r->rec_n = 0;
+    r->watch_count = 0;              // (with rec_n: a call that keeps nothing must not leave the previous call's watched factors behind)
     r->rec_loga_view = nullptr;
     if (save_samples == MHX_SAVE_MOMENTS) {
         // running moments instead of a sample tensor
@@ -1595,6 +1675,15 @@ int api_run_stats(mhx_run* r, mhx_stats* out)
 {
     if (!r || !out) return mhx_fail(MHX_EINVAL, "mhx_run_stats: NULL argument");
     *out = r->stats;
+    out->tainted = r->ctx->tainted ? 1 : 0;
+    out->reserved_ = 0;
+    return MHX_OK;
+}
+
+int api_run_shape(const mhx_run* r, int32_t* dim, int32_t* nchains)
+{
+    if (dim) *dim = r->dim;
+    if (nchains) *nchains = r->n;
     return MHX_OK;
 }
 

@@ -11,9 +11,12 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <thread>
 
 namespace {
 
@@ -72,6 +75,7 @@ struct mhx_comm {
     size_t cap = 0;
     void* d_stage = nullptr;       // staging of the walker all-gather: [world][stride] bytes
     size_t stage_cap = 0;
+    double op_timeout_s = MHX_COMM_INIT_TIMEOUT_S;   // deadline of one blocking collective (mhx_comm_set_timeout)
 };
 
 #define RCCL_TRY(expr)                                                                                            \
@@ -97,10 +101,25 @@ extern "C" int mhx_comm_unique_id(void* id128)
     return MHX_OK;
 }
 
-extern "C" int mhx_comm_init(mhx_ctx* ctx, int rank, int world, const void* id128, mhx_comm** out)
+// ncclCommInitRank blocks until EVERY rank of `world` has called it: a rank that died, a wrong id or a broken fabric is a hang,
+// not an error.  The call therefore runs on a helper thread and the caller waits for it with a deadline; on expiry the helper
+// (and whatever RCCL holds) is abandoned -- the process can still report, fall back to another transport, and exit.
+namespace {
+struct init_job {
+    std::mutex mu;
+    std::condition_variable cv;
+    bool done = false;
+    ncclResult_t res = ncclSuccess;
+    hipError_t dev = hipSuccess;
+    ncclComm_t comm = nullptr;
+};
+}  // namespace
+
+extern "C" int mhx_comm_init_timed(mhx_ctx* ctx, int rank, int world, const void* id128, double timeout_s, mhx_comm** out)
 {
     if (!ctx || !out || !id128) return mhx_fail(MHX_EINVAL, "mhx_comm_init: NULL argument");
     if (world < 1 || rank < 0 || rank >= world) return mhx_fail(MHX_EINVAL, "mhx_comm_init: rank %d of %d", rank, world);
+    if (!(timeout_s > 0)) timeout_s = MHX_COMM_INIT_TIMEOUT_S;
     int rc = need_rccl("mhx_comm_init");
     if (rc) return rc;
     int device = 0;
@@ -110,7 +129,38 @@ extern "C" int mhx_comm_init(mhx_ctx* ctx, int rank, int world, const void* id12
     c->rank = rank; c->world = world; c->device = device;
     ncclUniqueId id;
     memcpy(&id, id128, sizeof id);
-    RCCL_TRY(g_rccl.CommInitRank(&c->comm, world, id, rank));
+#ifdef MHX_TOOLS_BUILD
+    // fault injection of the tools build (libmhx_tools.so; tests of the transport ladder): "fail" = an error, "hang" = never returns
+    const char* fault = getenv("MHX_FAULT_RCCL_INIT");
+    if (fault && !strcmp(fault, "fail")) return mhx_fail(MHX_EHIP, "mhx_comm_init: rank %d of %d: injected failure (MHX_FAULT_RCCL_INIT)", rank, world);
+#endif
+    auto job = std::make_shared<init_job>();
+    std::thread([job, id, world, rank, device
+#ifdef MHX_TOOLS_BUILD
+                 , fault
+#endif
+    ] {
+        ncclComm_t comm = nullptr;
+        ncclResult_t r = ncclSuccess;
+        const hipError_t e = hipSetDevice(device);
+#ifdef MHX_TOOLS_BUILD
+        if (fault && !strcmp(fault, "hang")) for (;;) std::this_thread::sleep_for(std::chrono::seconds(3600));
+#endif
+        if (e == hipSuccess) r = g_rccl.CommInitRank(&comm, world, id, rank);
+        std::lock_guard<std::mutex> lk(job->mu);
+        job->dev = e; job->res = r; job->comm = comm; job->done = true;
+        job->cv.notify_all();
+    }).detach();
+    {
+        std::unique_lock<std::mutex> lk(job->mu);
+        if (!job->cv.wait_for(lk, std::chrono::duration<double>(timeout_s), [&] { return job->done; }))
+            return mhx_fail(MHX_EHIP, "mhx_comm_init: rank %d of %d (device %d): ncclCommInitRank did not return within %.0f s "
+                            "(a rank that never arrived, a stale id, or a fabric that cannot connect the ranks)", rank, world, device, timeout_s);
+    }
+    if (job->dev != hipSuccess) return mhx_fail(MHX_EHIP, "mhx_comm_init: rank %d: hipSetDevice(%d): %s", rank, device, hipGetErrorString(job->dev));
+    if (job->res != ncclSuccess)
+        return mhx_fail(MHX_EHIP, "mhx_comm_init: rank %d of %d (device %d): ncclCommInitRank failed: %s", rank, world, device, g_rccl.GetErrorString(job->res));
+    c->comm = job->comm;
     const hipError_t es = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (es != hipSuccess) {                             // the unique_ptr frees the struct only: release the communicator too
         (void)g_rccl.CommDestroy(c->comm);
@@ -118,6 +168,11 @@ extern "C" int mhx_comm_init(mhx_ctx* ctx, int rank, int world, const void* id12
     }
     *out = c.release();
     return MHX_OK;
+}
+
+extern "C" int mhx_comm_init(mhx_ctx* ctx, int rank, int world, const void* id128, mhx_comm** out)
+{
+    return mhx_comm_init_timed(ctx, rank, world, id128, MHX_COMM_INIT_TIMEOUT_S, out);
 }
 
 extern "C" int mhx_comm_destroy(mhx_comm* c)
@@ -129,6 +184,13 @@ extern "C" int mhx_comm_destroy(mhx_comm* c)
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+    return MHX_OK;
+}
+
+extern "C" int mhx_comm_set_timeout(mhx_comm* c, double seconds)
+{
+    if (!c || !(seconds > 0)) return mhx_fail(MHX_EINVAL, "mhx_comm_set_timeout: comm is NULL or seconds <= 0");
+    c->op_timeout_s = seconds;
     return MHX_OK;
 }
 
@@ -162,7 +224,20 @@ extern "C" int mhx_comm_allreduce_sum(mhx_comm* c, double* inout, size_t n)
     HIP_TRY(hipMemcpyAsync(c->d_buf, inout, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     RCCL_TRY(g_rccl.AllReduce(c->d_buf, c->d_buf, n, ncclDouble, ncclSum, c->comm, c->stream));
     HIP_TRY(hipMemcpyAsync(inout, c->d_buf, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    // a collective a peer never joins does not fail, it waits: poll with a deadline instead of hipStreamSynchronize
+    const auto t0 = std::chrono::steady_clock::now();
+    for (long spins = 0;; ++spins) {
+        const hipError_t q = hipStreamQuery(c->stream);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) return mhx_fail(MHX_EHIP, "mhx_comm_allreduce_sum: %s", hipGetErrorString(q));
+        if (spins > 2000) {
+            const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (waited > c->op_timeout_s)
+                return mhx_fail(MHX_EHIP, "mhx_comm_allreduce_sum: rank %d of %d: the all-reduce of %zu doubles did not complete within %.0f s "
+                                "(a peer never joined it)", c->rank, c->world, n, c->op_timeout_s);
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+    }
     return MHX_OK;
 }
 

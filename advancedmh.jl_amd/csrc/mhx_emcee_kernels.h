@@ -604,14 +604,18 @@ MHX_DEV mhx_real mhx_band_rows_sq(const mhx_real (&ab)[mhx_emcee_geom<D, L>::NK]
     return q;
 }
 
-// timing probe: MHX_EMCEE_PROBE = n (hiprtc define, tools only) ends the half-step after phase n
+// Timing points: empty in the release library (the tools build defines them; its block is not part of the embedded source).
+#ifdef MHX_TOOLS_BUILD
+// libmhx_tools.so, options EMCEE_PROBE / EMCEE_STAMPS of mhx_ctx_set_option: end a half-step after its n-th phase (wrong chains,
+// right latencies) / stamp s_memtime at the phase boundaries
 #ifndef MHX_EMCEE_PROBE
 #define MHX_EMCEE_PROBE 0
 #endif
-#define MHX_PROBE(n, val) do { if (MHX_EMCEE_PROBE == (n)) { if ((val) == MHX_R(12345.678)) a.lp[0] = (val); return; } } while (0)
-
-// timing stamps (tools only, MHX_EMCEE_STAMPS=1 at run creation): lane 0 of every wave stores s_memtime / s_memrealtime at its phase
-// boundaries into a.ybuf ([waves of the launch][16] 64-bit words; the host writes the last launch's buffer to $MHX_EMCEE_STAMPS_FILE)
+#define MHX_TP(n, val) do { if (MHX_EMCEE_PROBE == (n)) { if ((val) == MHX_R(12345.678)) a.lp[0] = (val); return; } } while (0)
+#define MHX_TP_IS(n) (MHX_EMCEE_PROBE == (n))
+#define MHX_TP_LT(n) (MHX_EMCEE_PROBE < (n))
+// stamps: lane 0 of every wave stores s_memtime / s_memrealtime at its phase boundaries into a.ybuf ([waves of the launch][16]
+// 64-bit words; the host writes the last launch's buffer to the file named by option EMCEE_STAMPS_FILE)
 #ifndef MHX_EMCEE_STAMPS
 #define MHX_EMCEE_STAMPS 0
 #endif
@@ -619,6 +623,12 @@ MHX_DEV mhx_real mhx_band_rows_sq(const mhx_real (&ab)[mhx_emcee_geom<D, L>::NK]
 #define MHX_STAMP(k) do { if ((threadIdx.x & 63) == 0) { mhx_u64* sp_ = (mhx_u64*)a.ybuf + ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16; \
         sp_[2 * (k)] = __builtin_amdgcn_s_memtime(); sp_[2 * (k) + 1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
+#define MHX_STAMP(k) do { } while (0)
+#endif
+#else
+#define MHX_TP(n, val) do { } while (0)
+#define MHX_TP_IS(n) false
+#define MHX_TP_LT(n) true
 #define MHX_STAMP(k) do { } while (0)
 #endif
 
@@ -674,7 +684,7 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const mhx_real* __rest
     const int osize = a.half ? halfW : W - halfW;
     const long ld = W;
 
-    MHX_PROBE(1, (mhx_real)i);                                               // launch + arguments
+    MHX_TP(1, (mhx_real)i);                                               // launch + arguments
     // the walker's own row does not wait for the draw (the partner's does): its loads go out first
     constexpr int NQ = GEO::NQ, NQL = GEO::NQL;
     mhx_e4 xs[NQL], ysl[NQL];
@@ -704,7 +714,7 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const mhx_real* __rest
     const mhx_real tt = mhx_fma(a.stretch - MHX_R(1.0), u, MHX_R(1.0));
     const mhx_real z = (tt * tt) / a.stretch;                               // src/emcee.jl:81
     const mhx_real alphamult = (mhx_real)(D - 1) * mhx_log(z);                 // :82
-    MHX_PROBE(2, alphamult + (mhx_real)j);                                   // + the draws
+    MHX_TP(2, alphamult + (mhx_real)j);                                   // + the draws
 
     // the move, element-wise on float4 slices of the two rows (lane l: float4 l, l+L, ...); the zero pad of
     // the rows gives the zero pad of y that multiplies the zeros of the factor image
@@ -725,8 +735,8 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const mhx_real* __rest
         }
         if (q4 < DP4 / 4) ((mhx_e4*)yrow)[q4] = ysl[m];
     }
-    MHX_PROBE(3, ysl[0].x);                                                  // + the two rows, the move
-    if (MHX_EMCEE_PROBE != 6 && a.rec_other_slot >= 0) {
+    MHX_TP(3, ysl[0].x);                                                  // + the two rows, the move
+    if (!MHX_TP_IS(6) && a.rec_other_slot >= 0) {
         // the partner row x_j was requested after these loads: they have arrived.  The stores have the rest of the launch to drain.
         auto rec = [&](const int iw, const mhx_e4 (&xr)[mhx_emcee_geom<D, L>::NQL], const mhx_real lpr, const unsigned char lar) {
             mhx_real* row = a.samples + a.rec_other_slot * (long)(D + 1) * ld + iw;
@@ -759,12 +769,12 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const mhx_real* __rest
         if constexpr (ONE_BATCH) mhx_dense_image_store<D, L>(areg, Ash4);
         else mhx_dense_image_fill<D, L>(A, Ash4);
         __syncthreads();
-        MHX_PROBE(4, ysl[0].x + ((const mhx_real*)Ash4)[threadIdx.x]);       // + the factor image in LDS
+        MHX_TP(4, ysl[0].x + ((const mhx_real*)Ash4)[threadIdx.x]);       // + the factor image in LDS
         q = mhx_dense_rows_sq<D, L>(Ash4, (const mhx_e4*)yrow, l);
     }
     q = mhx_butterfly<L>(q);
     const mhx_real lpy = mhx_fma(-MHX_R(0.5), q, a.tconst);
-    MHX_PROBE(5, lpy + ysl[0].x);                                            // + A y, the butterfly
+    MHX_TP(5, lpy + ysl[0].x);                                            // + A y, the butterfly
     const mhx_real alpha = (alphamult + lpy) - lpi;                         // :91
     const mhx_real logu = dr.logu;
     const bool acc = logu <= alpha;                                      // :93
@@ -775,7 +785,7 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const mhx_real* __rest
             if (l == 0) { a.lp[i] = lpy; a.acc_count[i] = acc_i + 1u; }
         }
         if (l == 0) a.last_acc[i] = acc ? 1 : 0;
-        if (MHX_EMCEE_PROBE == 6) return;                                    // + accept and the state update, no record
+        if (MHX_TP_IS(6)) return;                                    // + accept and the state update, no record
         if (!MHX_EMCEE_COOP_REC && a.save_slot >= 0) {
             // the record is [dim+1][W] (walker fastest): 16-byte runs per dimension from this wave's walkers
             // (staging it through LDS for 64-byte runs measured no faster)
@@ -800,7 +810,7 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const mhx_real* __rest
     // rows are there, a rejected move puts the walker back, lp and the accept flag ride in the row's tail -- and every row k of the
     // [dim+1][W] record is written for all the block's consecutive walkers at once (32 x sizeof(real) contiguous bytes at C3's shape
     // instead of 4 walkers per store).  A tuning knob (MHX_EMCEE_COOP_REC=1), off by default: see the macro.
-    if (MHX_EMCEE_PROBE != 6 && a.save_slot >= 0) {                          // (uniform)
+    if (!MHX_TP_IS(6) && a.save_slot >= 0) {                          // (uniform)
         if (!acc) {
 #pragma unroll
             for (int m = 0; m < NQL; ++m) { const int q4 = l + L * m; if (q4 < NQ) ((mhx_e4*)yrow)[q4] = xs[m]; }
@@ -910,7 +920,7 @@ MHX_DEV void mhx_emcee_coop_sweep_body(const mhx_emcee_args& a, const mhx_real* 
 #pragma unroll
     for (int m = 0; m < NQL; ++m) { const int q4 = l + L * m; xjs[m] = q4 < NQ ? xrow_j[q4] : zero4; }
     __builtin_amdgcn_sched_barrier(0);
-    MHX_PROBE(2, alphamult + (mhx_real)j + xs[0].x + lpi);                  // launch, own row, the draws
+    MHX_TP(2, alphamult + (mhx_real)j + xs[0].x + lpi);                  // launch, own row, the draws
     auto stretch = [](const mhx_real zz, const mhx_e4 xi, const mhx_e4 xj) {   // :85, element-wise
         mhx_e4 y;
         y.x = mhx_fma(zz, xi.x - xj.x, xj.x);
@@ -942,7 +952,7 @@ MHX_DEV void mhx_emcee_coop_sweep_body(const mhx_emcee_args& a, const mhx_real* 
             if (q4 < DP4 / 4) ((mhx_e4*)yrow)[q4] = ysl[m];
         }
         image_ready();
-        MHX_PROBE(3, ysl[0].x);                                              // + the partner rows, the candidates in LDS
+        MHX_TP(3, ysl[0].x);                                              // + the partner rows, the candidates in LDS
         const mhx_real q = mhx_butterfly<L>(row_products(yrow));
         lpy = mhx_fma(-MHX_R(0.5), q, a.tconst);
     } else {
@@ -973,7 +983,7 @@ MHX_DEV void mhx_emcee_coop_sweep_body(const mhx_emcee_args& a, const mhx_real* 
             }
         }
         image_ready();
-        MHX_PROBE(3, ysl[0].x + y1[0].x);
+        MHX_TP(3, ysl[0].x + y1[0].x);
         const mhx_real qa = mhx_butterfly<L>(row_products(yrow));
         const mhx_real q0 = mhx_butterfly<L>(row_products(yrow + CPW * DP4));
         const mhx_real q1 = mhx_butterfly<L>(row_products(yrow + 2 * CPW * DP4));
@@ -986,7 +996,7 @@ MHX_DEV void mhx_emcee_coop_sweep_body(const mhx_emcee_args& a, const mhx_real* 
             ysl[m].z = acc_a ? y1[m].z : ysl[m].z; ysl[m].w = acc_a ? y1[m].w : ysl[m].w;
         }
     }
-    MHX_PROBE(5, lpy + ysl[0].x);                                            // + the row products, the butterflies
+    MHX_TP(5, lpy + ysl[0].x);                                            // + the row products, the butterflies
     const mhx_real alpha = (alphamult + lpy) - lpi;                         // :91
     const bool acc = dr.logu <= alpha;                                      // :93
     if (valid) {
@@ -997,14 +1007,14 @@ MHX_DEV void mhx_emcee_coop_sweep_body(const mhx_emcee_args& a, const mhx_real* 
             mhx_e4 v;
             v.x = acc ? ysl[m].x : xs[m].x; v.y = acc ? ysl[m].y : xs[m].y; v.z = acc ? ysl[m].z : xs[m].z; v.w = acc ? ysl[m].w : xs[m].w;
             ysl[m] = v;
-            if (q4 < NQ && (acc || (moved_before && MHX_EMCEE_PROBE < 7))) MHX_ROW_ST(&xrow_o[q4], v);      // (probes 7, 8: timing only, accepted rows alone)
+            if (q4 < NQ && (acc || (moved_before && MHX_TP_LT(7)))) MHX_ROW_ST(&xrow_o[q4], v);      // (probes 7, 8: timing only, accepted rows alone)
         }
         if (l == 0) {
             a.lp_out[i] = acc ? lpy : lpi;
             if (acc) a.acc_count[i] = acc_i + 1u;
             a.last_acc[i] = acc ? 1 : 0;
         }
-        if (MHX_EMCEE_PROBE == 6 || MHX_EMCEE_PROBE == 7) return;            // + accept and the new state, no record
+        if (MHX_TP_IS(6) || MHX_TP_IS(7)) return;            // + accept and the new state, no record
         if (a.save_slot >= 0) {
             mhx_real* row = a.samples + a.save_slot * (long)(D + 1) * ld + i;
 #pragma unroll
@@ -1297,7 +1307,7 @@ MHX_DEV void mhx_emcee_scal_body(const mhx_emcee_args& a, const mhx_real* __rest
     const int ostart = a.half ? 0 : halfW;
     const int osize = a.half ? halfW : W - halfW;
     const long ld = W;
-    MHX_PROBE(1, (mhx_real)i);
+    MHX_TP(1, (mhx_real)i);
     mhx_e4 xs[NQL], xjs[NQL], ysl[NQL];
     mhx_e4* xrow_i = (mhx_e4*)(a.xw + (long)i * mhx_xw_pitch(D));
     const mhx_e4 zero4 = {MHX_R(0.0), MHX_R(0.0), MHX_R(0.0), MHX_R(0.0)};
@@ -1318,7 +1328,7 @@ MHX_DEV void mhx_emcee_scal_body(const mhx_emcee_args& a, const mhx_real* __rest
     const mhx_real tt = mhx_fma(a.stretch - MHX_R(1.0), dr.u, MHX_R(1.0));
     const mhx_real z = (tt * tt) / a.stretch;                                // src/emcee.jl:81
     const mhx_real alphamult = (mhx_real)(D - 1) * mhx_log(z);               // :82
-    MHX_PROBE(2, alphamult + (mhx_real)j);
+    MHX_TP(2, alphamult + (mhx_real)j);
     mhx_real* yrow = ysh + wm * YS;
 #pragma unroll
     for (int m = 0; m < NQL; ++m) {
@@ -1341,7 +1351,7 @@ MHX_DEV void mhx_emcee_scal_body(const mhx_emcee_args& a, const mhx_real* __rest
             }
         }
     }
-    MHX_PROBE(3, ysl[0].x);
+    MHX_TP(3, ysl[0].x);
     MHX_STAMP(1);
     __syncthreads();
     MHX_STAMP(2);
@@ -1357,7 +1367,7 @@ MHX_DEV void mhx_emcee_scal_body(const mhx_emcee_args& a, const mhx_real* __rest
 #pragma unroll
             for (int k = 0; k < XP / 4; ++k) { const mhx_e4 v = ((const mhx_e4*)yr)[k]; y[4 * k] = v.x; y[4 * k + 1] = v.y; y[4 * k + 2] = v.z; y[4 * k + 3] = v.w; }
         }
-        MHX_PROBE(4, y[0]);
+        MHX_TP(4, y[0]);
         MHX_STAMP(3);
         if constexpr (MHX_EMCEE_SCAL_MODE == 1) qsh[g * 64 + wv] = mhx_bcast_rows_dispatch<D, NW>(g, av, y);
         else qsh[g * 64 + wv] = mhx_scal_rows_dispatch<D, NW>(g, A, y);
@@ -1374,7 +1384,7 @@ MHX_DEV void mhx_emcee_scal_body(const mhx_emcee_args& a, const mhx_real* __rest
 #pragma unroll
         for (int k = 0; k < NW; k += 2 * off) qv[k] = qv[k] + qv[k + off];          // the butterfly's tree
     const mhx_real lpy = mhx_fma(-MHX_R(0.5), qv[0], a.tconst);
-    MHX_PROBE(5, lpy + ysl[0].x);
+    MHX_TP(5, lpy + ysl[0].x);
     const mhx_real alpha = (alphamult + lpy) - lpi;                          // :91
     const bool acc = dr.logu <= alpha;                                       // :93
 #if MHX_EMCEE_SCAL_REC
@@ -1388,7 +1398,7 @@ MHX_DEV void mhx_emcee_scal_body(const mhx_emcee_args& a, const mhx_real* __rest
     }
     if (valid && l == 0) a.last_acc[i] = acc ? 1 : 0;
     MHX_STAMP(6);
-    if (MHX_EMCEE_PROBE == 6) return;
+    if (MHX_TP_IS(6)) return;
     if (a.save_slot >= 0) {                                                 // (uniform)
         if (!acc) {
 #pragma unroll
@@ -1426,7 +1436,7 @@ MHX_DEV void mhx_emcee_scal_body(const mhx_emcee_args& a, const mhx_real* __rest
         }
         if (l == 0) a.last_acc[i] = acc ? 1 : 0;
         MHX_STAMP(6);
-        if (MHX_EMCEE_PROBE == 6) return;
+        if (MHX_TP_IS(6)) return;
         if (a.save_slot >= 0) {
             mhx_real* row = a.samples + a.save_slot * (long)(D + 1) * ld + i;
 #pragma unroll
@@ -1508,7 +1518,7 @@ MHX_DEV void mhx_emcee_scal_sweep_body(const mhx_emcee_args& a, const mhx_real* 
         for (int m = 0; m < NQL; ++m) { const int q4 = l + LM * m; xbs[m] = q4 < NQ ? xrow_b[q4] : zero4; }
         lpa = a.lp[j];
     }
-    MHX_PROBE(2, (mhx_real)j + xs[0].x + lpi + lpa + da.u);                  // launch, own row, the draws' integer part
+    MHX_TP(2, (mhx_real)j + xs[0].x + lpi + lpa + da.u);                  // launch, own row, the draws' integer part
     __builtin_amdgcn_sched_barrier(0);
     mhx_real av[mhx_bcast_geom<D, NW>::NRMAX][mhx_bcast_geom<D, NW>::CHMAX];
     mhx_bcast_load<D, NW>(g, A, tid & 15, av);                               // in flight until phase 2
@@ -1560,7 +1570,7 @@ MHX_DEV void mhx_emcee_scal_sweep_body(const mhx_emcee_args& a, const mhx_real* 
             }
         }
     }
-    MHX_PROBE(3, ysl[0].x + y1[0].x + alphamult_a);                          // + the rows, the candidates in LDS
+    MHX_TP(3, ysl[0].x + y1[0].x + alphamult_a);                          // + the rows, the candidates in LDS
     __syncthreads();
     // ---- phase 2: lane = candidate row (all 64), wave = row class
     {
@@ -1574,7 +1584,7 @@ MHX_DEV void mhx_emcee_scal_sweep_body(const mhx_emcee_args& a, const mhx_real* 
 #pragma unroll
             for (int k = 0; k < XP / 4; ++k) { const mhx_e4 v = ((const mhx_e4*)yr)[k]; y[4 * k] = v.x; y[4 * k + 1] = v.y; y[4 * k + 2] = v.z; y[4 * k + 3] = v.w; }
         }
-        MHX_PROBE(4, y[0] + y[XP - 1]);                                      // + barrier, y in registers
+        MHX_TP(4, y[0] + y[XP - 1]);                                      // + barrier, y in registers
         qsh[g * 64 + wv] = mhx_bcast_rows_dispatch<D, NW>(g, av, y);
     }
     __syncthreads();
@@ -1599,7 +1609,7 @@ MHX_DEV void mhx_emcee_scal_sweep_body(const mhx_emcee_args& a, const mhx_real* 
             ysl[m].z = acc_a ? y1[m].z : ysl[m].z; ysl[m].w = acc_a ? y1[m].w : ysl[m].w;
         }
     }
-    MHX_PROBE(5, lpy + ysl[0].x);                                            // + the row products, the trees
+    MHX_TP(5, lpy + ysl[0].x);                                            // + the row products, the trees
     const mhx_real alpha = (alphamult + lpy) - lpi;                          // :91
     const bool acc = dr.logu <= alpha;                                       // :93
 #pragma unroll
@@ -1619,7 +1629,7 @@ MHX_DEV void mhx_emcee_scal_sweep_body(const mhx_emcee_args& a, const mhx_real* 
             a.last_acc[i] = acc ? 1 : 0;
         }
     }
-    if (MHX_EMCEE_PROBE == 6) return;                                        // + accept and the new state, no record
+    if (MHX_TP_IS(6)) return;                                        // + accept and the new state, no record
     if (a.save_slot >= 0) {                                                 // (uniform)
         // the record leaves as whole row segments through the block's LDS: the final row replaces the walker's first candidate row
         // (phase 2 is past it), then every row k of the [dim+1][W] record is written for the HB consecutive walkers of each half

@@ -16,6 +16,10 @@ int mhx_fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)
 
 struct mhx_handle_hdr { int32_t dtype; };
 
+// hiprtc is entered by one thread at a time (the member threads of a group may each need a specialisation): mhx_abi.cpp
+void mhx_jit_lock();
+void mhx_jit_unlock();
+
 #define MHX_IMPL_DECLARE(NS, REAL)                                                                                     \
     namespace NS {                                                                                                     \
     struct mhx_ctx;                                                                                                    \
@@ -24,6 +28,10 @@ struct mhx_handle_hdr { int32_t dtype; };
     int api_ctx_create(int device, mhx_ctx** out);                                                                     \
     int api_ctx_destroy(mhx_ctx* ctx);                                                                                 \
     int api_ctx_device(const mhx_ctx* ctx);                                                                            \
+    int api_ctx_set_option(mhx_ctx* ctx, const char* name, const char* value);                                         \
+    int api_ctx_get_option(const mhx_ctx* ctx, const char* name, char* buf, size_t len);                               \
+    int api_ctx_pci_bus_id(const mhx_ctx* ctx, char* buf, size_t len);                                                 \
+    int api_run_shape(const mhx_run* r, int32_t* dim, int32_t* nchains);                                               \
     int api_ctx_jit_counts(const mhx_ctx* ctx, long* compiles, long* cache_hits);                                      \
     int api_ctx_host_pin_counts(const mhx_ctx* ctx, long* registered, long* released);                                  \
     int api_target_builtin(mhx_ctx* ctx, int kind, int dim, const REAL* params, size_t nparams, mhx_target** out);     \

@@ -158,10 +158,9 @@ MHX_DEV void mhx_rwmh_reg_body(const mhx_rwmh_args& a, const mhx_real* __restric
         const mhx_real lpy = mhx_target_eval<TK>(TK, y, D, tparams, a.ntparams, a.tconst);
         const mhx_real logu = mhx_accept_logu(ks, id_lo, id_hi, step, ac);
         const bool acc = logu < (lpy - lp);          // strict; NaN compares false => reject
-#ifndef MHX_REG_ACC_BRANCH
-#define MHX_REG_ACC_BRANCH MHX_REAL64    // (fp64: see MHX_REG_ZIG_BRANCH in mhx_rwmh_reg_zig_body -- the accepted lanes move the candidate over the state)
-#endif
-        if (MHX_REG_ACC_BRANCH) {
+        // (fp64: the accepted lanes MOVE the candidate over the state under their execute mask -- where the state's registers are
+        // AGPRs a select costs read + 2 v_cndmask + write per real, the move one write per word; fp32: a select is one instruction)
+        if (MHX_REAL64) {
             if (acc) {
 #pragma unroll
                 for (int k = 0; k < D; ++k) {
@@ -185,7 +184,7 @@ MHX_DEV void mhx_rwmh_reg_body(const mhx_rwmh_args& a, const mhx_real* __restric
             mhx_real* slotp = a.samples + slot * (long)(D + 1) * ld;
             const mhx_srd srd = mhx_make_srd(slotp, (mhx_u32)(D + 1) * (mhx_u32)ld * MHX_RB);
             const mhx_u32 ldb = (mhx_u32)ld * MHX_RB;
-            // (the row offset as a running scalar sum behind an opaque asm: see MHX_COOP_REC_RUN in mhx_rwmh_coop_body)
+            // (the row offset as a running scalar sum behind an opaque asm: see the record of mhx_rwmh_coop_body)
             mhx_u32 roff = 0u;
             asm volatile("" : "+s"(roff));
 #pragma unroll
@@ -403,31 +402,20 @@ MHX_DEV void mhx_rwmh_whiten_body(const mhx_rwmh_args& a, const mhx_real* __rest
 // KS is the largest group (<= 4) whose slabs leave the LDS for as many blocks per CU as the launch bound asks for.
 #define MHX_ZIG_TABLE_BYTES (((MHX_ZIG_N + 1) * 8 + 15) / 16 * 16)
 #define MHX_ZIG_SLAB_BYTES(NBL) ((NBL) * 4 * 64 * 8)
-#ifndef MHX_ZIG_KS_FORCE
-#define MHX_ZIG_KS_FORCE 0
-#endif
 #define MHX_ZIG_KS_FIT(NBL) ((163840 / MHX_COOP_WAVES(NBL) - MHX_ZIG_TABLE_BYTES - 512) / (4 * (MHX_ZIG_SLAB_BYTES(NBL) + 512 + 32)))
-#define MHX_ZIG_KS(NBL) (MHX_ZIG_KS_FORCE > 0 ? MHX_ZIG_KS_FORCE : (MHX_ZIG_KS_FIT(NBL) < 1 ? 1 : (MHX_ZIG_KS_FIT(NBL) > 4 ? 4 : MHX_ZIG_KS_FIT(NBL))))
+#define MHX_ZIG_KS(NBL) (MHX_ZIG_KS_FIT(NBL) < 1 ? 1 : (MHX_ZIG_KS_FIT(NBL) > 4 ? 4 : MHX_ZIG_KS_FIT(NBL)))
 #define MHX_ZIG_WAVE_BYTES(NBL) (MHX_ZIG_KS(NBL) * (MHX_ZIG_SLAB_BYTES(NBL) + 512) + 128)
 #define MHX_ZIG_LDS_BYTES(NBL) (MHX_ZIG_TABLE_BYTES + 4 * MHX_ZIG_WAVE_BYTES(NBL))
 static_assert(MHX_ZIG_TABLE_BYTES == MHX_ZIG_TABLE_BYTES_ANY, "ziggurat table size");
 
 // The candidates of this wave-step that left their rectangles (0.4 % of the draws: a dozen per wave-step at d = 100), gathered
 // from all lanes into one queue and finished by as many lanes side by side -- ONE pass of the slow path per wave-step instead of
-// one per failing block.  fm: the lane's failed slots (slot s = 4 i + j at bit s, or at bit 63 - s with MHX_ZIG_SIGNACC).  A fixer lane re-derives the failed candidate from
+// one per failing block.  fm: the lane's failed slots (slot s = 4 i + j at bit s).  A fixer lane re-derives the failed candidate from
 // its Philox block (nothing but the slot number was kept), runs the rejection loop of mhx_zig_slow and drops the normal into the
 // owner's place in `zn`.
 // (a group of `ng` steps: zfm[s][lane] = the lane's failed slots of step step0 + s, whose normals live in zn + s * slabd)
-// SIGNACC (round 4): the failed slots of a lane not from compare + select + or (2.75 instructions per candidate) but from the SIGN of
-// |x| - x[layer + 1] -- set exactly when the candidate is inside its rectangle -- shifted into a word by ONE v_alignbit_b32 per
-// candidate ({w, hi(diff)} >> 31): subtract + alignbit = 2.  A word for slots 0..31, one for the rest; inverted, masked and put
-// together once per step with slot s at bit 63 - s.  Same failures: the difference of two doubles is -0 / +0 / of the exact sign.
-// Measured (profiles/r04y_fastpath_ab.log): 47 instructions fewer per wave-step than compare + select, and SLOWER -- C2 2.945 against
-// 2.912 ms per launch, C5 equal: fma -> merge -> subtract -> alignbit is one dependent chain per candidate, and at one wave per SIMD
-// a dependent instruction waits out its producer.  Off.
-#ifndef MHX_ZIG_SIGNACC
-#define MHX_ZIG_SIGNACC 0
-#endif
+// (Measured and removed in round 5, profiles/r04y_fastpath_ab.log: the failure bits from the SIGN of |x| - x[layer + 1] shifted in by
+// one v_alignbit_b32 per candidate -- 47 instructions fewer per wave-step and SLOWER, one dependent chain per candidate.)
 template <int L>
 MHX_DEV void mhx_zig_fixup(const mhx_philox_key& ks, const double* __restrict__ zt, double* __restrict__ zn,
                            unsigned short* __restrict__ zq, const mhx_u64* __restrict__ zfm, const int ng, const int slabd,
@@ -450,11 +438,10 @@ MHX_DEV void mhx_zig_fixup(const mhx_philox_key& ks, const double* __restrict__ 
                 if (m == 0ull) break;
                 if (f != 0ull) {
                     const int e = base + (int)__builtin_amdgcn_mbcnt_hi((mhx_u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((mhx_u32)m, 0u));
-                    const int sl = MHX_ZIG_SIGNACC ? __clzll((long long)f) : __ffsll((long long)f) - 1;
+                    const int sl = __ffsll((long long)f) - 1;
                     if (e >= 0 && e < 64) zq[e] = (unsigned short)(lane | (sl << 6) | (s << 12));
                 }
-                if (MHX_ZIG_SIGNACC) f &= ~(0x8000000000000000ull >> (f != 0ull ? __clzll((long long)f) : 0));
-                else f &= f - 1ull;
+                f &= f - 1ull;
                 base += __popcll(m);
             }
         }
@@ -471,11 +458,7 @@ MHX_DEV void mhx_zig_fixup(const mhx_philox_key& ks, const double* __restrict__ 
             const mhx_u32 b = (mhx_u32)(ol / CPW + L * (sl >> 2));
             const mhx_u32 n = 4u * b + (mhx_u32)(sl & 3);
             // nothing but the slot number was kept: the failed candidate is re-derived from its Philox block
-#if defined(MHX_ZIG_PROBE) && MHX_ZIG_PROBE == 2
-            zns[(((sl >> 1) * 64 + ol) << 1) + (sl & 1)] = (double)n * 1e-3 + (double)(mhx_u32)oid * 1e-9;      // timing probe: queue and syncs, no refinement
-#else
             zns[(((sl >> 1) * 64 + ol) << 1) + (sl & 1)] = mhx_zig_refine(ks, zt, (mhx_u32)oid, (mhx_u32)(oid >> 32), step, stream, n);
-#endif
         }
         MHX_WAVE_SYNC();
     }
@@ -631,15 +614,11 @@ MHX_DEV void mhx_rwmh_reg_zig_body(const mhx_rwmh_args& a, const mhx_real* __res
                         int sls = has ? __ffsll((long long)f) - 1 : -1;
                         asm volatile("" : "+v"(sls));          // (else hipcc splits the test into `has` AND a compare: 5 instructions per register for 3)
                         const double pv = zres[has ? e : 0];
-                        // (registers in blocks of 8, a block skipped when no lane's slot lies in it: the first round of a word has
-                        // a dozen failures all over it, the later rounds one or two)
-#ifndef MHX_REG_ZIG_SKIP
-#define MHX_REG_ZIG_SKIP 0     // measured: 3.35 against 3.25 ms per launch at c2_user -- the ballots and branches cost more than the skipped selects
-#endif
-                        const int sblk = sls >> 3;
+                        // (skipping a block of 8 registers when no lane's slot lies in it was measured: 3.35 against 3.25 ms per launch at
+                        // c2_user -- the ballots and branches cost more than the skipped selects)
 #pragma unroll
                         for (int blk = 0; blk < 8; ++blk) {
-                            if (64 * w + 8 * blk < D && (!MHX_REG_ZIG_SKIP || __ballot(sblk == blk) != 0ull)) {
+                            if (64 * w + 8 * blk < D) {
 #pragma unroll
                                 for (int b = 8 * blk; b < 8 * blk + 8; ++b)
                                     if (64 * w + b < D) y[64 * w + b] = sls == b ? pv : y[64 * w + b];
@@ -659,25 +638,14 @@ MHX_DEV void mhx_rwmh_reg_zig_body(const mhx_rwmh_args& a, const mhx_real* __res
         const double lpy = mhx_target_eval<TK>(TK, y, D, tparams, a.ntparams, a.tconst);
         const double logu = mhx_accept_logu(ks, id_lo, id_hi, step, ac);
         const bool acc = logu < (lpy - lp);          // strict; NaN compares false => reject
-#ifndef MHX_REG_ZIG_BRANCH
-#define MHX_REG_ZIG_BRANCH 1
-#endif
-        if (MHX_REG_ZIG_BRANCH) {
-            // (the accepted lanes MOVE the candidate over the state under their execute mask: where the state's registers are AGPRs
-            // -- d = 100: all 60 of them -- a select costs read + 2 v_cndmask + write per real, the move one write per word)
-            if (acc) {
+        // (the accepted lanes MOVE the candidate over the state under their execute mask: where the state's registers are AGPRs
+        // -- d = 100: all 60 of them -- a select costs read + 2 v_cndmask + write per real, the move one write per word)
+        if (acc) {
 #pragma unroll
-                for (int k = 0; k < D; ++k) {
-                    if (k < XR) x[k < XR ? k : 0] = y[k];
-                    else xl[(k - XR) * 64] = y[k];
-                }
+            for (int k = 0; k < D; ++k) {
+                if (k < XR) x[k < XR ? k : 0] = y[k];
+                else xl[(k - XR) * 64] = y[k];
             }
-        } else {
-#pragma unroll
-        for (int k = 0; k < D; ++k) {
-            if (k < XR) x[k < XR ? k : 0] = acc ? y[k] : x[k < XR ? k : 0];
-            else if (acc) xl[(k - XR) * 64] = y[k];
-        }
         }
         lp = acc ? lpy : lp;
         nacc += acc ? 1u : 0u;
@@ -689,7 +657,7 @@ MHX_DEV void mhx_rwmh_reg_zig_body(const mhx_rwmh_args& a, const mhx_real* __res
                 mhx_real* slotp = a.samples + slot * (long)(D + 1) * ld;
                 const mhx_srd srd = mhx_make_srd(slotp, (mhx_u32)(D + 1) * (mhx_u32)ld * MHX_RB);
                 const mhx_u32 ldb = (mhx_u32)ld * MHX_RB;
-                mhx_u32 roff = 0u;                            // (running row offset: MHX_COOP_REC_RUN in mhx_rwmh_coop_body)
+                mhx_u32 roff = 0u;                            // (running row offset: see the record of mhx_rwmh_coop_body)
                 asm volatile("" : "+s"(roff));
 #pragma unroll
                 for (int k = 0; k < D; ++k) { mhx_srd_store<MHX_REC_STORE_AUX>(srd, cu, roff, getx(k)); roff += ldb; }
@@ -717,14 +685,9 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
 {
     constexpr int CPW = 64 / L;                    // chains per wave
     constexpr bool ZIG = GEN == MHX_GEN_ZIGGURAT;
-#ifndef MHX_COOP_ZKEEP
-#define MHX_COOP_ZKEEP 1
-#endif
-    constexpr bool ZKEEP = MHX_COOP_ZKEEP && MHX_REAL64 && WALK == MHX_WALK_PLAIN && PK == MHX_PROP_ISO;   // (fp32: a select is one instruction already)
-#ifndef MHX_COOP_ZRELOAD
-#define MHX_COOP_ZRELOAD 0     // tuning knob, OFF: measured C2 4.76e9 against 5.11e9 steps/s, C5 5.68e8 against 5.91e8 (profiles/r04i_zreload_ab.log)
-#endif
-    constexpr bool ZRELOAD = MHX_COOP_ZRELOAD && ZKEEP && GEN == MHX_GEN_ZIGGURAT;
+    constexpr bool ZKEEP = MHX_REAL64 && WALK == MHX_WALK_PLAIN && PK == MHX_PROP_ISO;   // (fp32: a select is one instruction already)
+    // (re-reading the normals from LDS at the accept instead of keeping them in registers: C2 4.76e9 against 5.11e9 steps/s, removed --
+    // profiles/r04i_zreload_ab.log)
     static_assert(!ZIG || MHX_REAL64, "the ziggurat generator exists in the fp64 engine only");
     extern __shared__ double mhx_coop_lds[];
 #if MHX_REAL64
@@ -744,22 +707,8 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
         __syncthreads();
     }
 #endif
-    // STAGGER (round 4 probe): every block of a launch runs the same instruction stream from the same start, so all CUs reach the
-    // record of a step together and the chip's 53 MB of it arrive as one burst per step.  A start-up delay by a phase of
-    // blockIdx (16 phases per step, all of them present in every XCD) spreads the bursts over the step.
-#ifndef MHX_COOP_STAGGER
-#define MHX_COOP_STAGGER 0
-#endif
-    if (MHX_COOP_STAGGER > 0) {
-        const int ph = (int)(((blockIdx.x >> 3) + 2u * (blockIdx.x & 7u)) & 15u);
-        for (int e = 0; e < ph; ++e) __builtin_amdgcn_s_sleep(MHX_COOP_STAGGER);
-    }
-#ifndef MHX_COOP_WSTAG
-#define MHX_COOP_WSTAG 0
-#endif
-    if (MHX_COOP_WSTAG > 0) {                        // the same between the waves of a block (they share the CU's path to memory)
-        for (int e = 0; e < (int)(threadIdx.x >> 6); ++e) __builtin_amdgcn_s_sleep(MHX_COOP_WSTAG);
-    }
+    // (a start-up stagger between blocks / between the waves of a block, so that the chip's record of a step does not leave as one
+    // burst: built, no gain, removed -- profiles/r04x_record_ab.log)
     const int lane = threadIdx.x & 63;
     // One or two chains per wave (L = 64, 32): a block covers 32 or 64 bytes of a row of the [dim][chains] arrays, less than a cache
     // line -- blocks b, b + 8, b + 16, ... run on ONE XCD (round-robin dispatch), so they get CONSECUTIVE chain groups and the line
@@ -896,45 +845,11 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
         if (mom_n) { lpm = a.mom_mean[(long)d * ld + c]; lpm2 = a.mom_m2[(long)d * ld + c]; }
     }
 
-    // DEFER_REC (round 4, OFF): without the record the same kernel runs 6.3e9 steps/s against 5.2e9, so this variant lets the record of
-    // a saved step leave not in one burst of 4 NBL stores behind the accept test but block by block inside the NEXT step's
-    // generation phase, between its Philox rounds (the state is unchanged until that step's own accept).  No branches: the stores are always issued, through a buffer descriptor whose range is empty when the previous
-    // step was not a saved one (the range check drops them), and idle lanes carry an offset past every range.
-#ifndef MHX_COOP_DEFER_REC
-#define MHX_COOP_DEFER_REC 0   // a measured dead end kept as a knob: bit-exact, C2 4.88-4.96e9 against 5.10e9 steps/s wherever in the generation
-                               // phase the stores sit (profiles/r04q_defer_rec_ab*.log) -- what the record costs is the issue of 4 NBL
-                               // 8-byte-per-lane stores itself, not their arriving in one burst
-#endif
-    constexpr bool DEFER_REC = MHX_COOP_DEFER_REC && ZIG && KS == 1 && !MOM;
-    const mhx_u32 ldb_rec = (mhx_u32)ld * MHX_RB;
-    const mhx_u32 lane_off_rec = valid ? lane_off : 0xfffffff0u;
-    mhx_srd rec_srd = mhx_make_srd(a.x, 0u);                   // empty range: nothing pending
-    auto rec_block = [&](const int i) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const mhx_u32 rowb = (mhx_u32)(4 * L * i + j) * ldb_rec;     // wave-uniform -> soffset
-            if (i < NBL - 1) mhx_srd_store(rec_srd, lane_off_rec, rowb, x[i][j]);
-            else if (k_last + j < d) mhx_srd_store(rec_srd, lane_off_rec, rowb, x[i][j]);
-        }
-    };
-    // WIDE_REC (round 4): neighbouring lanes hold neighbouring chains (CPW >= 2), so two rows of two chains leave as one 2-real
-    // store per lane after a 2 x 2 lane transpose -- half the store instructions for the same bytes.  Kernel-uniform condition: an
-    // even number of chains (a pair is valid or idle as a whole) and an even leading dimension (the pair's address is aligned).
-#ifndef MHX_COOP_WIDE_REC
-#define MHX_COOP_WIDE_REC 0    // built, bit-exact, no gain (C2 3.11 ms per launch either way): a store costs its issue -- address and data
-                               // registers read out of the wave -- so half the stores of twice the data plus four selects each save
-                               // nothing, while the running row offset below takes 4 % off the narrow form
-#endif
-#ifndef MHX_REC_PROBE
-#define MHX_REC_PROBE 0        // timing probes (the record of such a run is NOT valid): 1 = every record into slot 0 (the stores stay in
-                               // the caches), 2 = a buffer descriptor of range 0 (issued, range-checked away: no traffic at all)
-#endif
-    const bool wide_rec = MHX_COOP_WIDE_REC && CPW >= 2 && !DEFER_REC && !MOM && !tr_io && !(a.nchains & 1) && !(ld & 1L);
+    // What the record of a saved step costs is the ISSUE of its 4 NBL stores (6.3e9 steps/s without it against 5.4e9), not their bytes
+    // or their arriving in one burst.  Measured, bit-exact, no gain, removed in round 5 (A/B logs under profiles/): the stores spread
+    // over the NEXT step's generation phase through an empty-range buffer descriptor (r04q_defer_rec_ab*.log), 16-byte stores of two
+    // rows x two chains after a 2 x 2 lane transpose (r04x_record_ab.log).
     // (a saved step of the one- / two-chains-per-wave shapes stages its record in the slab memory: no groups then)
-    [[maybe_unused]] mhx_u64 zpad = ~0ull;                      // SIGNACC: the slots of this lane that hold dimensions (bit 63 - slot)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        if (!(k_last + j < d)) zpad &= ~(0x8000000000000000ull >> (4 * (NBL - 1) + j));
     const int ks_eff = (ZIG && !(tr_io && a.samples != nullptr && a.save_next != MHX_NO_SAVE)) ? KS : 1;
     for (int it0 = 0; it0 < a.nsteps; it0 += ks_eff) {
     const int ng = a.nsteps - it0 < ks_eff ? a.nsteps - it0 : ks_eff;
@@ -950,17 +865,13 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
             // phase A: every slot's candidate by the fast path -- table look-up, multiply, compare -- into LDS; the slots that
             // left their rectangles are noted in `fm` and finished by mhx_zig_fixup before the candidate state is formed
             mhx_u64 fm = 0ull;
-            mhx_u32 aw0 = 0u, aw1 = 0u;                             // SIGNACC: "inside its rectangle" bits, newest at bit 0
             // Software pipeline over the lane's blocks: the table look-ups of block i are in flight while the Philox rounds of
             // block i + 1 run (one wave per SIMD has no other wave to hide an LDS round trip behind): per block -- issue the 4
             // look-ups (layers known since the previous stage), Philox of the next block, then consume.
-            // MHX_ZIG_GB blocks per pipeline stage = 2 MHX_ZIG_GB independent Philox chains in flight.  Measured at C2: two blocks
-            // per stage (four chains) 4.61e9 steps/s against 4.86e9 with one -- the rounds are not waiting on each other, the
-            // extra live words cost more than the extra chains buy (C5: 4.88e8 against 5.36e8).
-#ifndef MHX_ZIG_GB
-#define MHX_ZIG_GB 1
-#endif
-            constexpr int GB = MHX_ZIG_GB;
+            // GB blocks per pipeline stage = 2 GB independent Philox chains in flight.  Measured at C2: two blocks per stage (four
+            // chains) 4.61e9 steps/s against 4.86e9 with one -- the rounds are not waiting on each other, the extra live words
+            // cost more than the extra chains buy (C5: 4.88e8 against 5.36e8).
+            constexpr int GB = 1;
             constexpr int NG = (NBL + GB - 1) / GB;                 // stages
             mhx_u32 khi[4 * GB], klo[4 * GB];                       // the candidates' raw words (hi:lo) of the stage in flight
             auto draw = [&](const int grp, mhx_u32 (&hi)[4 * GB], mhx_u32 (&lo)[4 * GB]) {
@@ -990,22 +901,10 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
                     const mhx_u32 ly = klo[e] & (mhx_u32)(MHX_ZIG_N - 1);
                     xe[e].x = zt[ly]; xe[e].y = zt[ly + 1];
                 }
-#ifndef MHX_DEFER_POS
-#define MHX_DEFER_POS 1
-#endif
-                if constexpr (DEFER_REC && MHX_DEFER_POS == 2) {
-#pragma unroll
-                    for (int bb = 0; bb < GB; ++bb) { if (grp * GB + bb < NBL) rec_block(grp * GB + bb); }
-                }
                 __builtin_amdgcn_sched_barrier(0);
                 mhx_u32 nhi[4 * GB], nlo[4 * GB];
                 if (grp + 1 < NG) draw(grp + 1, nhi, nlo);
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (DEFER_REC && MHX_DEFER_POS <= 1) {
-#pragma unroll
-                    for (int bb = 0; bb < GB; ++bb) { if (grp * GB + bb < NBL) rec_block(grp * GB + bb); }
-                    if (MHX_DEFER_POS == 0) __builtin_amdgcn_sched_barrier(0);
-                }
 #pragma unroll
                 for (int bb = 0; bb < GB; ++bb) {
                     const int i = grp * GB + bb;
@@ -1018,38 +917,26 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
                         // -- and NIB -- the block's failure bits selected from inline constants, then one shift per block: fewer
                         // instructions both, C2 unchanged / 3.4 % SLOWER with them (e64 compares into SGPR pairs feed the selects),
                         // C5 1 % faster with all three.  Hence by shape.
-#ifndef MHX_ZIG_ANDOR
-#define MHX_ZIG_ANDOR 1
-#endif
-#ifndef MHX_ZIG_FABS
-#define MHX_ZIG_FABS (NBL <= 4)
-#endif
-#ifndef MHX_ZIG_NIB
-#define MHX_ZIG_NIB (NBL <= 4)
-#endif
+                        constexpr bool ZFABS = NBL <= 4, ZNIB = NBL <= 4;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const double ax = mhx_zig_ax(khi[4 * bb + j], klo[4 * bb + j], xe[4 * bb + j].x);
-                            nn[j] = MHX_ZIG_ANDOR ? mhx_zig_signed(ax, klo[4 * bb + j], zsign) : mhx_zig_signed(ax, klo[4 * bb + j]);
+                            nn[j] = mhx_zig_signed(ax, klo[4 * bb + j], zsign);
                             // (|x| of the signed value: a source modifier of the compare, and `ax` dies at the sign merge -- the merge
                             // then happens in place instead of into a register that a v_mov brings back for the 16-byte LDS write)
-                            if (MHX_ZIG_SIGNACC) {
-                                const mhx_u32 dh = (mhx_u32)(mhx_d2u(__builtin_fabs(nn[j]) - xe[4 * bb + j].y) >> 32);    // (|signed x|: a source modifier; ax dies at the merge)
-                                if (4 * i + j < 32) aw0 = __builtin_amdgcn_alignbit(aw0, dh, 31u);
-                                else aw1 = __builtin_amdgcn_alignbit(aw1, dh, 31u);
-                                continue;
-                            }
-                            bool fail = MHX_ZIG_FABS ? !(__builtin_fabs(nn[j]) < xe[4 * bb + j].y) : !(ax < xe[4 * bb + j].y);
-#ifdef MHX_ZIG_FORCE_FAIL       // test knob (hiprtc define from the environment): every n-th slot is sent through the fix-up although
+                            bool fail = ZFABS ? !(__builtin_fabs(nn[j]) < xe[4 * bb + j].y) : !(ax < xe[4 * bb + j].y);
+#ifdef MHX_TOOLS_BUILD
+#ifdef MHX_ZIG_FORCE_FAIL       // test hook of the tools build (option ZIG_FORCE_FAIL): every n-th slot is sent through the fix-up although
                                 // its candidate is inside its rectangle -- the refinement re-derives the same normal, so the chains
                                 // are unchanged while the queue runs through several 64-entry windows per wave-step
                             fail = fail || ((4 * i + j + lane) % (MHX_ZIG_FORCE_FAIL) == 0);
 #endif
+#endif
                             if (i == NBL - 1) fail = fail && (k_last + j < d);   // padding dimensions past the end of the vector need no normal
-                            if (MHX_ZIG_NIB) nib |= fail ? (1u << j) : 0u;
+                            if (ZNIB) nib |= fail ? (1u << j) : 0u;
                             else fm |= (fail ? 1ull : 0ull) << (4 * i + j);
                         }
-                        if (MHX_ZIG_NIB) fm |= (mhx_u64)nib << (4 * i);
+                        if (ZNIB) fm |= (mhx_u64)nib << (4 * i);
                         mhx_d2 v2;
                         v2.x = nn[0]; v2.y = nn[1];
                         *(mhx_d2*)(zn + (((i * 2) * 64 + lane) << 1)) = v2;
@@ -1062,27 +949,19 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
                     for (int e = 0; e < 4 * GB; ++e) { khi[e] = nhi[e]; klo[e] = nlo[e]; }
                 }
             }
-            if (MHX_ZIG_SIGNACC) {
-                constexpr int N0 = 4 * NBL < 32 ? 4 * NBL : 32, N1 = 4 * NBL - N0;
-                const mhx_u32 f0 = ~aw0 & (N0 == 32 ? 0xffffffffu : ((1u << (N0 & 31)) - 1u));
-                const mhx_u32 f1 = N1 > 0 ? ~aw1 & ((1u << (N1 & 31)) - 1u) : 0u;
-                fm = ((mhx_u64)f0 << (64 - N0)) | (N1 > 0 ? (mhx_u64)f1 << ((32 - N1) & 31) : 0ull);
-                fm &= zpad;                                          // padding dimensions past the end of the vector need no normal
-#ifdef MHX_ZIG_FORCE_FAIL
-#pragma unroll
-                for (int sl = 0; sl < 4 * NBL; ++sl)
-                    if ((sl + lane) % (MHX_ZIG_FORCE_FAIL) == 0 && (sl < 4 * (NBL - 1) || k_last + (sl & 3) < d)) fm |= 0x8000000000000000ull >> sl;
-#endif
-            }
             if (KS > 1) zfm[sg * 64 + lane] = fm;
             fm1 = fm;
             anyfail = anyfail || fm != 0ull;
             }
         }
+#ifdef MHX_TOOLS_BUILD
 #ifndef MHX_ZIG_PROBE
-#define MHX_ZIG_PROBE 0        // timing probe (tools only, hiprtc define via MHX_ZIG_PROBE in the environment): 1 = skip the fix-up (WRONG normals)
+#define MHX_ZIG_PROBE 0        // timing probe of the tools build (option ZIG_PROBE): 1 = skip the fix-up (WRONG normals)
 #endif
         if (MHX_ZIG_PROBE != 1 && __ballot(anyfail))
+#else
+        if (__ballot(anyfail))
+#endif
             mhx_zig_fixup<L>(ks, zt, zn0, zq, zfm, ng, SLABD, lane, wave, a.first_chain, a.nchains, a.step0 + (mhx_u32)it0, MHX_STREAM_PROPOSAL,
                              KS == 1, fm1);
     }
@@ -1096,12 +975,8 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
         // bit, so the partial sums need no predication.
         mhx_real q = MHX_R(0.0), fwd = MHX_R(0.0), bwd = MHX_R(0.0), y00 = MHX_R(0.0);
 #if MHX_REAL64
-        // ZRELOAD (ziggurat + ZKEEP; a measured dead end kept as a knob): the normals stay in the slab -- read once for the candidate /
-        // target and once more for the accepted state -- instead of occupying the candidate's 8 NBL registers between the two.  It
-        // sheds a fifth of the AGPR spill traffic and loses 7 % at C2, 4 % at C5: at one or two waves per SIMD the second LDS
-        // round trip of every step is exposed latency
         const double* const zn_c = ZIG ? (const double*)(zn0 + sg * SLABD) : nullptr;
-        if (ZIG && !ZRELOAD) {
+        if (ZIG) {
             // the step's normals, final: all of them on their way to the registers the candidate will occupy (one wait)
 #pragma unroll
             for (int i = 0; i < NBL; ++i) {
@@ -1116,11 +991,7 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
             const int b = l + L * i;
             mhx_real n[4];
 #if MHX_REAL64
-            if (ZIG && ZRELOAD) {
-                const mhx_d2 v0 = *(const mhx_d2*)(zn_c + (((i * 2) * 64 + lane) << 1));
-                const mhx_d2 v1 = *(const mhx_d2*)(zn_c + (((i * 2 + 1) * 64 + lane) << 1));
-                n[0] = v0.x; n[1] = v0.y; n[2] = v1.x; n[3] = v1.y;
-            } else if (ZIG) {
+            if (ZIG) {
                 n[0] = y[i][0]; n[1] = y[i][1]; n[2] = y[i][2]; n[3] = y[i][3];
             } else
 #endif
@@ -1151,8 +1022,7 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
                 // in one instruction per real where a select of a double takes two.  A padding dimension keeps n = 0: x stays 0.
                 // (fma(0, n, x) == x for every x but -0.0, which a chain never holds: mhx_run_init / set_state turn a caller's -0.0
                 // into +0.0 -- rwmh_canonical_zero in mhx_api.hip -- and a rounded sum is -0 only if both terms are.)
-                if (ZRELOAD) { }
-                else if (ZKEEP) y[i][j] = (i == NBL - 1 && !(k_last + j < d)) ? MHX_R(0.0) : n[j];
+                if (ZKEEP) y[i][j] = (i == NBL - 1 && !(k_last + j < d)) ? MHX_R(0.0) : n[j];
                 else y[i][j] = yk;
                 if (i == 0 && j == 0) y00 = yk;
                 const mhx_real sq = mhx_fma(yk, yk, q);
@@ -1170,11 +1040,7 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
             }
             // keep the blocks in program order: with >= 2 waves per SIMD the other wave provides the
             // latency hiding, and interleaving blocks only inflates the live register set
-#ifndef MHX_COOP_INTERLEAVE
             __builtin_amdgcn_sched_barrier(0);
-#else
-            if ((i % MHX_COOP_INTERLEAVE) == MHX_COOP_INTERLEAVE - 1) __builtin_amdgcn_sched_barrier(0);
-#endif
         }
         q = mhx_butterfly<L>(q);
         if (WALK != MHX_WALK_PLAIN) {
@@ -1199,27 +1065,10 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
                             : (WALK == MHX_WALK_DRIFT ? (lpy - lp) + MHX_R(0.5) * (fwd - bwd) : (lpy - lp));
         const bool acc = logu < loga;
         const mhx_real s_acc = acc ? a.pscale : MHX_R(0.0);
-#if MHX_REAL64
-        if (ZRELOAD) {
-#pragma unroll
-            for (int i = 0; i < NBL; ++i) {
-                const mhx_d2 v0 = *(const mhx_d2*)(zn_c + (((i * 2) * 64 + lane) << 1));
-                const mhx_d2 v1 = *(const mhx_d2*)(zn_c + (((i * 2 + 1) * 64 + lane) << 1));
-                const mhx_real nn[4] = {v0.x, v0.y, v1.x, v1.y};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const mhx_real nj = (i == NBL - 1 && !(k_last + j < d)) ? MHX_R(0.0) : nn[j];      // a padding dimension stays 0
-                    x[i][j] = mhx_fma(s_acc, nj, x[i][j]);
-                }
-            }
-        } else
-#endif
-        {
 #pragma unroll
         for (int i = 0; i < NBL; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) x[i][j] = ZKEEP ? mhx_fma(s_acc, y[i][j], x[i][j]) : (acc ? y[i][j] : x[i][j]);
-        }
         lp = acc ? lpy : lp;
         if (WALK == MHX_WALK_STATIC) qxc = acc ? qy : qxc;
         nacc += acc ? 1u : 0u;
@@ -1237,7 +1086,6 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
         } else if (step == save_next && tr_io) {
             // (one or two chains per wave: the record leaves through the block's LDS as whole row segments, see fetch4)
             mhx_real* slotp = a.samples + slot * (long)(d + 1) * ld;
-            if constexpr (DEFER_REC) rec_srd = mhx_make_srd(a.x, 0u);
             flush4(slotp, x);
             if (l == 0) {
                 slotp[(long)d * ld + c] = lp;
@@ -1245,67 +1093,21 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
             }
             save_next += (mhx_u32)a.thinning;
             ++slot;
-        } else if (DEFER_REC && step == save_next) {
-            // the state's rows follow during the next step's generation phase (or after the loop); lp and the flag go now
-            mhx_real* slotp = a.samples + slot * (long)(d + 1) * ld;
-            rec_srd = mhx_make_srd(slotp, (mhx_u32)(d + 1) * (mhx_u32)ld * MHX_RB);
-            if (valid && l == 0) {
-                slotp[(long)d * ld + c] = lp;
-                a.accepted[slot * ld + c] = acc ? 1 : 0;
-            }
-            save_next += (mhx_u32)a.thinning;
-            ++slot;
-        } else if (step == save_next && wide_rec) {
-            // the record as 2 NBL stores of two rows x two chains each (mhx_pair_rows) instead of 4 NBL one-row stores
-            if (valid) {                                   // (an even number of chains: the lanes of a pair are valid or idle together)
-                mhx_real* slotp = a.samples + (MHX_REC_PROBE == 1 ? 0L : slot) * (long)(d + 1) * ld;
-                const mhx_srd srd = mhx_make_srd(slotp, MHX_REC_PROBE == 2 ? 0u : (mhx_u32)(d + 1) * (mhx_u32)ld * MHX_RB);
-                const mhx_u32 ldb = (mhx_u32)ld * MHX_RB;
-                const int odd = lane & 1;
-                const mhx_u32 lane_off_w = ((mhx_u32)(4 * l) * (mhx_u32)ld + (mhx_u32)(c & ~1L)) * MHX_RB + (odd ? ldb : 0u);
-                // the row offsets as a running scalar sum that starts behind an opaque asm: as 2 NBL loop-invariant products hipcc
-                // hoists them out of the step loop, spills them to lanes of a VGPR and pays v_readlane + s_nop 4 per store
-#ifndef MHX_WIDE_REC_RUN
-#define MHX_WIDE_REC_RUN 1
-#endif
-                mhx_u32 roff = 0u;
-                if (MHX_WIDE_REC_RUN) asm volatile("" : "+s"(roff));
-#pragma unroll
-                for (int i = 0; i < NBL; ++i)
-#pragma unroll
-                    for (int jp = 0; jp < 2; ++jp) {
-                        mhx_real v0, v1;
-                        mhx_pair_rows(x[i][2 * jp], x[i][2 * jp + 1], v0, v1);
-                        const mhx_u32 rowb = MHX_WIDE_REC_RUN ? roff : (mhx_u32)(4 * L * i + 2 * jp) * ldb;    // wave-uniform -> soffset
-                        roff += (jp == 0 ? 2u : (mhx_u32)(4 * L - 2)) * ldb;
-                        if (i < NBL - 1) mhx_srd_store2(srd, lane_off_w, rowb, v0, v1);
-                        else if (k_last + 2 * jp + odd < d) mhx_srd_store2(srd, lane_off_w, rowb, v0, v1);
-                    }
-                if (l == 0) {
-                    slotp[(long)d * ld + c] = lp;
-                    a.accepted[slot * ld + c] = acc ? 1 : 0;
-                }
-            }
-            save_next += (mhx_u32)a.thinning;
-            ++slot;
         } else if (step == save_next) {
             if (valid) {
-                mhx_real* slotp = a.samples + (MHX_REC_PROBE == 1 ? 0L : slot) * (long)(d + 1) * ld;
-                const mhx_srd srd = mhx_make_srd(slotp, MHX_REC_PROBE == 2 ? 0u : (mhx_u32)(d + 1) * (mhx_u32)ld * MHX_RB);
+                mhx_real* slotp = a.samples + slot * (long)(d + 1) * ld;
+                const mhx_srd srd = mhx_make_srd(slotp, (mhx_u32)(d + 1) * (mhx_u32)ld * MHX_RB);
                 const mhx_u32 ldb = (mhx_u32)ld * MHX_RB;
-                // REC_RUN (round 4): the row offset as a running scalar sum behind an opaque asm.  As 4 NBL loop-invariant products
-                // hipcc hoists the offsets out of the step loop, spills them to lanes of a VGPR and pays v_readlane + s_nop 4 per
-                // store -- and at one wave per SIMD the record costs by the instruction, not by the byte (MHX_REC_PROBE)
-#ifndef MHX_COOP_REC_RUN
-#define MHX_COOP_REC_RUN 1
-#endif
+                // The row offset as a running scalar sum behind an opaque asm (round 4).  As 4 NBL loop-invariant products hipcc
+                // hoists the offsets out of the step loop, spills them to lanes of a VGPR and pays v_readlane + s_nop 4 per store --
+                // and at one wave per SIMD the record costs by the instruction, not by the byte (profiles/r04x_record_ab.log)
                 mhx_u32 roff = 0u;
-                if (MHX_COOP_REC_RUN) asm volatile("" : "+s"(roff));
+                asm volatile("" : "+s"(roff));
 #pragma unroll
                 for (int i = 0; i < NBL; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const mhx_u32 rowb = MHX_COOP_REC_RUN ? roff : (mhx_u32)(4 * L * i + j) * ldb;     // wave-uniform -> soffset
+                        const mhx_u32 rowb = roff;                                                 // wave-uniform -> soffset
                         roff += (j < 3 ? 1u : (mhx_u32)(4 * L - 3)) * ldb;
                         if (i < NBL - 1) mhx_srd_store<MHX_REC_STORE_AUX>(srd, lane_off, rowb, x[i][j]);
                         else if (k_last + j < d) mhx_srd_store<MHX_REC_STORE_AUX>(srd, lane_off, rowb, x[i][j]);
@@ -1317,14 +1119,8 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
             }
             save_next += (mhx_u32)a.thinning;
             ++slot;
-        } else if (DEFER_REC) {
-            rec_srd = mhx_make_srd(a.x, 0u);                      // not a saved step: the next generation phase stores nothing
         }
     }
-    }
-    if constexpr (DEFER_REC) {                                    // the record of the launch's last step, if it was a saved one
-#pragma unroll
-        for (int i = 0; i < NBL; ++i) rec_block(i);
     }
     const bool tr_out = tr_io;
     if (tr_out) {

@@ -7,6 +7,8 @@ import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MHX_LIB") or os.path.join(os.path.dirname(_PKG), "libmhx.so")
+# the tools build (`make -C csrc tools`): the same engine + timing probes and fault injection; never loaded unless asked for
+TOOLS_LIB_PATH = os.path.join(os.path.dirname(_PKG), "libmhx_tools.so")
 
 MHX_OK, MHX_EINVAL, MHX_ENOMEM, MHX_EHIP, MHX_EJIT, MHX_ENOTPD, MHX_ESTATE = 0, -1, -2, -3, -4, -5, -6
 
@@ -67,7 +69,8 @@ class MalaCfg(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("transitions", C.c_uint64), ("accepted", C.c_uint64), ("kernel_ms", C.c_double),
                 ("wall_ms", C.c_double), ("kernel_variant", C.c_int32), ("launches", C.c_int32),
-                ("reduce_lanes", C.c_int32), ("dtype", C.c_int32), ("normal_gen", C.c_int32), ("factor_band", C.c_int32)]
+                ("reduce_lanes", C.c_int32), ("dtype", C.c_int32), ("normal_gen", C.c_int32), ("factor_band", C.c_int32),
+                ("tainted", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class DiagCfg(C.Structure):
@@ -86,6 +89,9 @@ EXPORTS = [
     "mhx_emcee_exchange_unpack", "mhx_comm_unique_id", "mhx_comm_init", "mhx_comm_destroy", "mhx_comm_rank",
     "mhx_comm_allreduce_sum", "mhx_comm_slice", "mhx_comm_allgather_walkers",
     "mhx_ram_get_step_stats", "mhx_ram_watch_factors", "mhx_ram_get_watched_factors", "mhx_run_sample_to_host", "mhx_host_alloc", "mhx_host_free", "mhx_ctx_jit_counts", "mhx_ctx_host_pin_counts",
+    "mhx_ctx_set_option", "mhx_ctx_get_option", "mhx_ctx_pci_bus_id", "mhx_run_shape", "mhx_comm_init_timed", "mhx_comm_set_timeout",
+    "mhx_group_create", "mhx_group_destroy", "mhx_group_size", "mhx_group_ctx", "mhx_group_shard", "mhx_group_attach", "mhx_group_run",
+    "mhx_group_init", "mhx_group_sample", "mhx_group_sample_to_host", "mhx_group_stats", "mhx_group_diagnostics", "mhx_group_ess_bulk_tail",
 ]
 
 MHX_F32, MHX_F64 = 0, 1
@@ -107,16 +113,32 @@ def get_default_dtype():
     return _default_dtype
 
 _lib = None
+_lib_path = LIB_PATH
+_loaded = {}
+
+
+def use_library(path=None):
+    """Bind the host mirror to another build of the library -- `use_library(TOOLS_LIB_PATH)` for the tools build (timing probes,
+    fault injection: tests and A/B scripts), `use_library()` back to libmhx.so.  Contexts, models and runs of the previous
+    binding must not be used afterwards (the default contexts are forgotten here)."""
+    global _lib, _lib_path
+    _lib_path = path or LIB_PATH
+    _lib = None
+    Context._default = {}
+    Context._default_options = {}
+    return lib()
 
 
 def lib():
     """Load libmhx.so (built in-tree by __graft_entry__.build()).  Fails loudly when absent."""
     global _lib
+    if _lib is None and _lib_path in _loaded:
+        _lib = _loaded[_lib_path]
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise ImportError("libmhx.so not found at %s -- run `python __graft_entry__.py` (build()) first; "
-                              "there is no CPU fallback" % LIB_PATH)
-        L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        if not os.path.exists(_lib_path):
+            raise ImportError("%s not found -- run `python __graft_entry__.py` (build()) first; "
+                              "there is no CPU fallback" % _lib_path)
+        L = C.CDLL(_lib_path, mode=C.RTLD_GLOBAL)
         L.mhx_last_error.restype = C.c_char_p
         vp, u8p, u32p = C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint32)
         rp = C.c_void_p                                   # a buffer of reals of the context's dtype
@@ -172,7 +194,27 @@ def lib():
         L.mhx_comm_allreduce_sum.argtypes = [vp, dp, C.c_size_t]
         L.mhx_comm_slice.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.mhx_comm_allgather_walkers.argtypes = [vp, vp, C.c_int]
-        _lib = L
+        L.mhx_comm_init_timed.argtypes = [vp, C.c_int, C.c_int, vp, C.c_double, C.POINTER(vp)]
+        L.mhx_comm_set_timeout.argtypes = [vp, C.c_double]
+        L.mhx_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
+        L.mhx_ctx_get_option.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_size_t]
+        L.mhx_ctx_pci_bus_id.argtypes = [vp, C.c_char_p, C.c_size_t]
+        L.mhx_run_shape.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        pvp, i32p, i64p = C.POINTER(vp), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+        L.mhx_group_create.argtypes = [i32p, C.c_int32, C.c_int, pvp]
+        L.mhx_group_destroy.argtypes = [vp]
+        L.mhx_group_size.argtypes = [vp, i32p]
+        L.mhx_group_ctx.argtypes = [vp, C.c_int32, pvp]
+        L.mhx_group_shard.argtypes = [vp, C.c_int64, C.c_int32, C.POINTER(C.c_uint64), i32p]
+        L.mhx_group_attach.argtypes = [vp, pvp]
+        L.mhx_group_run.argtypes = [vp, C.c_int32, pvp]
+        L.mhx_group_init.argtypes = [vp, pvp]
+        L.mhx_group_sample.argtypes = [vp, C.POINTER(Schedule), C.c_int]
+        L.mhx_group_sample_to_host.argtypes = [vp, C.POINTER(Schedule), pvp, pvp, C.c_int32]
+        L.mhx_group_stats.argtypes = [vp, C.POINTER(Stats)]
+        L.mhx_group_diagnostics.argtypes = [vp, C.POINTER(DiagCfg), dp, dp, dp, dp, i64p]
+        L.mhx_group_ess_bulk_tail.argtypes = [vp, C.POINTER(DiagCfg), i32p, C.c_int32, dp, dp]
+        _lib = _loaded[_lib_path] = L
     return _lib
 
 
@@ -237,16 +279,53 @@ class Context:
     """mhx_ctx: one per GPU and dtype."""
 
     _default = {}
+    _default_options = {}      # set_default_option: applied to the default contexts, present and future
 
-    def __init__(self, device=0, dtype=None):
+    def __init__(self, device=0, dtype=None, handle=None):
+        """`handle`: wrap a context somebody else owns (a member of a Group) instead of creating one."""
         dtype = dtype or _default_dtype
         if dtype not in DTYPES:
             raise ValueError("dtype must be 'f32' or 'f64'")
         self.h = C.c_void_p()
-        check(lib().mhx_ctx_create(device, DTYPES[dtype], C.byref(self.h)))
+        self.borrowed = handle is not None
+        if handle is not None:
+            self.h = handle
+        else:
+            check(lib().mhx_ctx_create(device, DTYPES[dtype], C.byref(self.h)))
         self.device = device
         self.dtype = dtype
         self.real = NP_DTYPES[dtype]
+
+    def set_option(self, name, value):
+        """mhx_ctx_set_option: an explicit engine option (kernel form / tuning; include/mhx.h lists them) for the runs created on
+        this context from now on.  value None unsets.  The library reads no such thing from the environment."""
+        check(lib().mhx_ctx_set_option(self.h, str(name).encode(), None if value is None else str(value).encode()))
+
+    def get_option(self, name):
+        buf = C.create_string_buffer(256)
+        check(lib().mhx_ctx_get_option(self.h, str(name).encode(), buf, len(buf)))
+        return buf.value.decode()
+
+    def pci_bus_id(self):
+        """"dddd:bb:dd.f" of the device (independent of HIP_VISIBLE_DEVICES ordinals): distinct ids = distinct GPUs"""
+        buf = C.create_string_buffer(32)
+        check(lib().mhx_ctx_pci_bus_id(self.h, buf, len(buf)))
+        return buf.value.decode()
+
+    @classmethod
+    def set_default_option(cls, name, value):
+        """the option on every default context (Context.default) that exists or will be created; None unsets"""
+        if value is None:
+            cls._default_options.pop(name, None)
+        else:
+            cls._default_options[name] = str(value)
+        for c in cls._default.values():
+            c.set_option(name, value)
+
+    @classmethod
+    def clear_default_options(cls):
+        for name in list(cls._default_options):
+            cls.set_default_option(name, None)
 
     def arr(self, a):
         """contiguous array in this context's real type"""
@@ -271,10 +350,12 @@ class Context:
                 os.environ["MHX_DEVICE"])
         dtype = dtype or _default_dtype
         if (device, dtype) not in cls._default:
-            cls._default[(device, dtype)] = cls(device, dtype)
+            c = cls._default[(device, dtype)] = cls(device, dtype)
+            for name, value in cls._default_options.items():
+                c.set_option(name, value)
         return cls._default[(device, dtype)]
 
     def close(self):
-        if self.h:
+        if self.h and not self.borrowed:
             lib().mhx_ctx_destroy(self.h)
-            self.h = C.c_void_p()
+        self.h = C.c_void_p()

@@ -715,7 +715,8 @@ class Run:
         L.check(L.lib().mhx_run_stats(self.h, C.byref(st)))
         return dict(transitions=st.transitions, accepted=st.accepted, kernel_ms=st.kernel_ms, wall_ms=st.wall_ms,
                     kernel_variant=st.kernel_variant, launches=st.launches, reduce_lanes=st.reduce_lanes,
-                    dtype="f64" if st.dtype == L.MHX_F64 else "f32", normal_gen=st.normal_gen, factor_band=st.factor_band)
+                    dtype="f64" if st.dtype == L.MHX_F64 else "f32", normal_gen=st.normal_gen, factor_band=st.factor_band,
+                    tainted=st.tainted)
 
     def diagnostics(self, max_lag=0, ess_chains=256, split=False):
         """Sums for R-hat / between-chain ESS (all chains) and, if max_lag > 0, the Geyer ESS from the multi-chain
@@ -821,7 +822,7 @@ class MCMCHIP(_ParallelTag):
 
 def sample(model, sampler, N, nchains=1, *more, initial_params=None, discard_initial=None, thinning=1, num_warmup=0,
            param_names=None, chain_type=Chains, seed=0, first_chain=0, callback=None, ctx=None, flags=0,
-           reduce_lanes=0, progress=False, dtype=None, normal_gen=None):
+           reduce_lanes=0, progress=False, dtype=None, normal_gen=None, allow_tainted=False):
     """sample(model, sampler, N[, nchains]; kwargs...) -- AbstractMCMC.sample as re-exported by the
     reference (src/AdvancedMH.jl:30).  All chains advance together on the GPU (what
     `sample(model, spl, MCMCThreads(), N, nchains)` does with one task per chain, README.md:141-147).
@@ -829,7 +830,10 @@ def sample(model, sampler, N, nchains=1, *more, initial_params=None, discard_ini
     dtype: "f64" (default: the reference's Float64) or "f32"; see mhx.set_default_dtype.
     discard_initial defaults to num_warmup [upstream]; `callback(run, i)` is called after each saved
     sample (the reference signature callback(rng, model, sampler, sample, state, i) carries objects
-    that live on the device here -- the Run gives access to them)."""
+    that live on the device here -- the Run gives access to them).
+
+    allow_tainted: a run of a context that carries a timing probe / fault-injection option of the TOOLS build (mhx_stats.tainted)
+    may hold invalid chains; `sample` refuses to wrap it into a container unless this is set (tests of the hooks themselves)."""
     if isinstance(N, _ParallelTag):                 # sample(model, spl, MCMCThreads(), N, nchains)
         if not more:
             raise L.ArgumentError(L.MHX_EINVAL, "sample(model, sampler, parallel, N, nchains): nchains is missing")
@@ -862,6 +866,9 @@ def sample(model, sampler, N, nchains=1, *more, initial_params=None, discard_ini
             chunks.append(v), accs.append(a)
             callback(run, i)
         value, acc = np.concatenate(chunks, axis=0), np.concatenate(accs, axis=0)
+    if run.stats()["tainted"] and not allow_tainted:
+        raise L.MhxError(L.MHX_ESTATE, "sample: the run's context is tainted (a probe / fault-injection option of the tools build was "
+                         "set on it): its chains may be invalid; pass allow_tainted=True to look at them anyway")
     d = model.dim
     if param_names is None:                                         # a NamedTuple of proposals / named parameters carry their names
         param_names = getattr(sampler, "param_names", None) or getattr(model, "param_names", None)

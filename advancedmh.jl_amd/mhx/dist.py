@@ -24,6 +24,159 @@ def pack_stats(diag, accepted, transitions):
                            [float(accepted), float(transitions), float(diag["n_chains"])]]).astype(np.float64)
 
 
+class Group:
+    """mhx_group: many chains over many GPUs as ONE call from ONE process -- the `sample(model, spl, MCMCThreads(), N, nchains)` of
+    the reference (README.md:135-148) with one host thread per GPU behind the C ABI instead of one task per chain.
+
+        g = Group([0, 1, 2, 3])                       # member i on device devices[i]; entries may repeat ([0, 0]: two members on GPU 0)
+        g.create(model, sampler, nchains=65536, seed=1)    # member runs over contiguous blocks of global chain ids, attached
+        g.init(None); g.sample(250, 1, 1, 0)          # all members side by side
+        g.stats(); g.diagnostics()                    # totals / R-hat over ALL chains (host sum of what ranks all-reduce over RCCL)
+
+    The union of the members' chains is the unsharded run bit for bit (tests/test_gpu_group.py)."""
+
+    def __init__(self, devices, dtype=None):
+        from . import _lib as L
+        self.dtype = dtype or L.get_default_dtype()
+        self.devices = [int(d) for d in devices]
+        dv = (C.c_int32 * len(self.devices))(*self.devices)
+        self.h = C.c_void_p()
+        L.check(L.lib().mhx_group_create(dv, len(self.devices), L.DTYPES[self.dtype], C.byref(self.h)))
+        self.ctxs = []
+        for i, dev in enumerate(self.devices):
+            ch = C.c_void_p()
+            L.check(L.lib().mhx_group_ctx(self.h, i, C.byref(ch)))
+            self.ctxs.append(L.Context(dev, self.dtype, handle=ch))
+        self.runs = []
+
+    def __len__(self):
+        return len(self.devices)
+
+    def shard(self, nchains_total, i):
+        from . import _lib as L
+        first, cnt = C.c_uint64(), C.c_int32()
+        L.check(L.lib().mhx_group_shard(self.h, int(nchains_total), i, C.byref(first), C.byref(cnt)))
+        return int(first.value), int(cnt.value)
+
+    def set_option(self, name, value):
+        for c in self.ctxs:
+            c.set_option(name, value)
+
+    def pci_bus_ids(self):
+        return [c.pci_bus_id() for c in self.ctxs]
+
+    def create(self, model, sampler, nchains=1, seed=0, first_chain=0, **kw):
+        """One Run per member: chains [first_chain + shard) by global id (an Ensemble: one ensemble per member, ids first_chain + i)."""
+        from .api import Ensemble, Run
+        self.close_runs()
+        for i, ctx in enumerate(self.ctxs):
+            if isinstance(sampler, Ensemble):
+                self.runs.append(Run(model, sampler, seed=seed, first_chain=first_chain + i, ctx=ctx, **kw))
+            else:
+                f, n = self.shard(nchains, i)
+                self.runs.append(Run(model, sampler, nchains=n, seed=seed, first_chain=first_chain + f, ctx=ctx, **kw))
+        return self.attach(self.runs)
+
+    def attach(self, runs):
+        from . import _lib as L
+        self.runs = list(runs)
+        hs = (C.c_void_p * len(self.runs))(*[r.h for r in self.runs])
+        L.check(L.lib().mhx_group_attach(self.h, hs))
+        self.dim = self.runs[0].dim
+        self.n = sum(r.n for r in self.runs)
+        return self
+
+    def init(self, initial_params=None):
+        """None: every member draws its chains' initial states on the device.  (dim,) for all chains, or (dim, n_total): the columns are
+        dealt to the members in chain order."""
+        from . import _lib as L
+        if initial_params is None:
+            L.check(L.lib().mhx_group_init(self.h, None))
+            return
+        ip = np.asarray(initial_params)
+        parts, o = [], 0
+        for r in self.runs:
+            if ip.ndim == 1:
+                parts.append(r.ctx.arr(np.repeat(ip.reshape(-1, 1), r.n, axis=1)))
+            else:
+                parts.append(r.ctx.arr(ip[:, o:o + r.n]))
+                o += r.n
+        ptrs = (C.c_void_p * len(parts))(*[p.ctypes.data for p in parts])
+        L.check(L.lib().mhx_group_init(self.h, ptrs))
+
+    def sample(self, n_samples, discard_initial=0, thinning=1, num_warmup=0, save=True):
+        from . import _lib as L
+        s = L.Schedule(n_samples, discard_initial, thinning, num_warmup)
+        mode = 2 if (isinstance(save, str) and save == "moments") or (save is not True and save == 2) else (1 if save else 0)
+        L.check(L.lib().mhx_group_sample(self.h, C.byref(s), mode))
+
+    def sample_to_host(self, n_samples, discard_initial=0, thinning=1, num_warmup=0, want_accepted=True, slab_samples=0, out=None,
+                       out_accepted=None):
+        """mhx_group_sample_to_host: returns (list of per-member tensors [N][dim+1][n_i], list of accepted [N][n_i] or None);
+        `np.concatenate(values, axis=2)` is the tensor of the unsharded run."""
+        from . import _lib as L
+        s = L.Schedule(n_samples, discard_initial, thinning, num_warmup)
+        vals = out or [L.host_array((n_samples, self.dim + 1, r.n), r.real) for r in self.runs]
+        accs = out_accepted or ([L.host_array((n_samples, r.n), np.uint8) for r in self.runs] if want_accepted else None)
+        vp = (C.c_void_p * len(vals))(*[v.ctypes.data for v in vals])
+        ap = (C.c_void_p * len(vals))(*[a.ctypes.data for a in accs]) if accs is not None else None
+        L.check(L.lib().mhx_group_sample_to_host(self.h, C.byref(s), vp, ap, slab_samples))
+        return vals, accs
+
+    def stats(self):
+        from . import _lib as L
+        st = L.Stats()
+        L.check(L.lib().mhx_group_stats(self.h, C.byref(st)))
+        return dict(transitions=st.transitions, accepted=st.accepted, kernel_ms=st.kernel_ms, wall_ms=st.wall_ms,
+                    kernel_variant=st.kernel_variant, launches=st.launches, reduce_lanes=st.reduce_lanes,
+                    dtype="f64" if st.dtype == L.MHX_F64 else "f32", normal_gen=st.normal_gen, factor_band=st.factor_band,
+                    tainted=st.tainted)
+
+    def diagnostics(self, max_lag=0, ess_chains=256, split=False):
+        """R-hat / between-chain ESS over ALL chains of the group from the host-summed statistics (mhx_group_diagnostics)"""
+        from . import _lib as L
+        from .api import combine_diagnostics
+        d1 = self.dim + 1
+        arrs = [np.zeros(d1, dtype=np.float64) for _ in range(4)]
+        ptrs = [a.ctypes.data_as(C.POINTER(C.c_double)) for a in arrs]
+        if max_lag <= 0:
+            ptrs[3] = None
+        nch = C.c_int64()
+        cfg = L.DiagCfg(max_lag, ess_chains, 1 if split else 0)
+        L.check(L.lib().mhx_group_diagnostics(self.h, C.byref(cfg), *ptrs, C.byref(nch)))
+        n_saved = C.c_int64()
+        L.check(L.lib().mhx_run_device_samples(self.runs[0].h, None, None, C.byref(n_saved)))
+        ns = int(n_saved.value) // (2 if split else 1)
+        if ns == 0 and getattr(self.runs[0], "_moments_n", 0):
+            ns = self.runs[0]._moments_n
+        out = dict(sum_m=arrs[0], sum_m2=arrs[1], sum_v=arrs[2], n_chains=int(nch.value), n_samples=ns)
+        if max_lag > 0:
+            out["ess_geyer"] = np.abs(arrs[3])
+            out["ess_geyer_truncated"] = arrs[3] < 0
+        out.update(combine_diagnostics(out["sum_m"], out["sum_m2"], out["sum_v"], out["n_chains"], max(ns, 1)))
+        return out
+
+    def close_runs(self):
+        for r in self.runs:
+            r.close()
+        self.runs = []
+
+    def close(self):
+        from . import _lib as L
+        self.close_runs()
+        if self.h:
+            L.lib().mhx_group_destroy(self.h)
+            self.h = C.c_void_p()
+            for c in self.ctxs:
+                c.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Comm:
     """mhx_comm: an RCCL communicator behind the C ABI.  `Comm(ctx, rank, world, unique_id)`; `Comm.from_env(ctx)` takes
     rank / world / rendezvous from the torchrun environment (RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT) and hands the

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MHX_VERSION 400 /* 0.4.0: mhx_ram_get_step_stats takes a capacity, watched factors, host pin accounting, kernel variant 9 (0.3.0: overlapped host return path, page-locked host buffers, persistent JIT cache) */
+#define MHX_VERSION 500 /* 0.5.0: mhx_group_* (many GPUs from one process), mhx_ctx_set_option (explicit engine options: the library no longer reads tuning variables from the environment), mhx_stats.tainted, mhx_comm_init_timed / deadlines on the collectives, mhx_ctx_pci_bus_id, mhx_run_shape; 0.4.0: mhx_ram_get_step_stats takes a capacity, watched factors, host pin accounting, kernel variant 9 (0.3.0: overlapped host return path, page-locked host buffers, persistent JIT cache) */
 
 typedef enum {
     MHX_OK = 0,
@@ -61,6 +61,26 @@ int mhx_ctx_create(int device, int dtype /* mhx_dtype */, mhx_ctx **out);
 int mhx_ctx_dtype(const mhx_ctx *ctx);
 int mhx_ctx_device(const mhx_ctx *ctx, int *device);
 int mhx_ctx_destroy(mhx_ctx *ctx);
+/* "dddd:bb:dd.f" of the context's device (hipDeviceGetPCIBusId): ordinals depend on HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES, the
+ * bus id does not -- N ranks (or the members of a group) run on N GPUs iff their bus ids are distinct.  len >= 16. */
+int mhx_ctx_pci_bus_id(const mhx_ctx *ctx, char *buf, size_t len);
+
+/* Engine options: explicit, per context, set BEFORE the runs they steer are created.  The library reads nothing but
+ * MHX_CACHE_DIR / MHX_NO_JIT_CACHE / XDG_CACHE_HOME / HOME (where compiled kernels are kept) and MHX_RCCL_LIB from the environment;
+ * which kernel form runs is chosen from (dim, chains, dtype) unless an option says otherwise, and mhx_stats reports the form.
+ * Every option below yields the SAME chain law and, for a given reduction shape, the same bits (each form is held to the oracle
+ * in tests/): they exist so that every form can be reached at every size, and for A/B measurements.
+ *   kernel form     NO_PREBUILT NO_MFMA EMCEE_MFMA EMCEE_SCALAR EMCEE_FUSED EMCEE_PERSIST EMCEE_DEFER EMCEE_SWEEP_DEFER
+ *                   EMCEE_PRELOAD RAM_G
+ *   tuning          COOP_WAVES MFMA_WAVES REG_MAX_DIM REG_XR REG_UNROLL MALA_XR EMCEE_WAVES EMCEE_MFMA_WAVES
+ *                   EMCEE_SCAL_WPB EMCEE_SCAL_MODE EMCEE_SCAL_REC EMCEE_REC_STORE EMCEE_ROW_STORE EMCEE_COOP_REC RAM_LDS_PAD
+ * value == NULL unsets.  An unknown name is MHX_EINVAL.  The tools build (libmhx_tools.so, `make tools`) additionally knows
+ * timing probes and fault injection (ZIG_PROBE, EMCEE_PROBE, EMCEE_STAMPS, ZIG_FORCE_FAIL, FAULT_SLAB, JIT_DEFS): setting one
+ * marks the context TAINTED -- mhx_stats.tainted = 1 for every run of it, and the host mirrors refuse to build a Chains from
+ * such a run.  In libmhx.so those names do not exist. */
+int mhx_ctx_set_option(mhx_ctx *ctx, const char *name, const char *value);
+/* the value in effect ("" when unset) copied to buf; MHX_EINVAL for an unknown name */
+int mhx_ctx_get_option(const mhx_ctx *ctx, const char *name, char *buf, size_t len);
 /* hiprtc specialisations of this context so far: compiled by hiprtc / loaded from the on-disk code-object cache
  * ($MHX_CACHE_DIR, default ~/.cache/mhx; key = hash(source, device headers, options, hiprtc + runtime version);
  * MHX_CACHE_DIR="" or MHX_NO_JIT_CACHE=1 switches the cache off).  Either pointer may be NULL. */
@@ -310,8 +330,13 @@ typedef struct {
     int32_t normal_gen;        /* 0 Box-Muller, 1 ziggurat (MHX_FLAG_ZIGGURAT): how the run turns stream bits into normals */
     int32_t factor_band;       /* Ensemble runs on a dense-Gaussian target: the bandwidth of the precision factor the kernel exploits
                                   (0 = diagonal, 1 = bidiagonal: an AR(1) / Markov model, ...), -1 = none (dense form, other samplers) */
+    int32_t tainted;           /* 1: a probe / fault-injection option of the tools build was set on the run's context -- the chains of
+                                  such a run may be INVALID (timing probes skip work).  Always 0 from libmhx.so. */
+    int32_t reserved_;
 } mhx_stats;
 int mhx_run_stats(mhx_run *run, mhx_stats *out);
+/* dimension and number of chains (walkers) of a run; either pointer may be NULL */
+int mhx_run_shape(const mhx_run *run, int32_t *dim, int32_t *nchains);
 
 /* device pointers of the sample buffer of the last mhx_run_sample (for zero-copy consumers on the
  * same HIP runtime, e.g. diagnostics or a torch tensor view); valid until the next sample/destroy */
@@ -374,6 +399,14 @@ typedef struct mhx_comm mhx_comm;
 #define MHX_COMM_ID_BYTES 128
 int mhx_comm_unique_id(void *id128);
 int mhx_comm_init(mhx_ctx *ctx, int rank, int world, const void *id128, mhx_comm **out);
+/* ncclCommInitRank returns only when EVERY rank has called it: a missing rank, a stale id or a fabric that cannot connect the
+ * ranks is a hang, not an error.  mhx_comm_init waits MHX_COMM_INIT_TIMEOUT_S for it, mhx_comm_init_timed `timeout_s` (<= 0: the
+ * default); on expiry MHX_EHIP with a message that names the rank -- the caller can report it or fall back to another transport
+ * (bench.py: RCCL behind this ABI, then torch.distributed's own nccl backend, then gloo).  mhx_comm_set_timeout bounds every
+ * later blocking collective of the communicator the same way (default: the same 300 s). */
+#define MHX_COMM_INIT_TIMEOUT_S 300.0
+int mhx_comm_init_timed(mhx_ctx *ctx, int rank, int world, const void *id128, double timeout_s, mhx_comm **out);
+int mhx_comm_set_timeout(mhx_comm *comm, double seconds);
 int mhx_comm_destroy(mhx_comm *comm);
 int mhx_comm_rank(const mhx_comm *comm, int *rank, int *world);
 /* in-place sum over the ranks of n doubles in HOST memory (blocking) */
@@ -390,6 +423,41 @@ int mhx_comm_allgather_walkers(mhx_comm *comm, mhx_run *run, int half);
  * (cfg.max_lag, cfg.ess_chains, cfg.split) is taken of those series.  Negated values: as for ess[] above. */
 int mhx_run_ess_bulk_tail(mhx_run *run, const mhx_diag_cfg *cfg, const int32_t *params, int32_t nparams,
                           double *ess_bulk, double *ess_tail /* each [nparams], either may be NULL */);
+
+/* ---------------------------------------------------------------------------------------------
+ * Many chains over many GPUs as ONE call from ONE process.  Replaces `sample(model, sampler, MCMCThreads(), N, nchains)`
+ * (README.md:135-148: one task per chain) -- here one host thread per GPU behind the ABI.  A group is N member contexts (one
+ * per entry of `devices`; entries may repeat -- several members on one device are legal, which is how the form is verified on a
+ * one-GPU box), N persistent worker threads and the host-side sum of the statistics that ranks of a multi-process run all-reduce
+ * over RCCL (mhx_comm_allreduce_sum).  Chains shard by global id with no data-path collective, so member i's run is created by
+ * the caller on mhx_group_ctx(g, i) like any run, with cfg.first_chain / cfg.nchains from mhx_group_shard (ensembles: one per
+ * member, distinct ensemble_id), and attached; the group then drives all members CONCURRENTLY:
+ *     mhx_group_init / _sample / _sample_to_host   == mhx_run_init / _sample / _sample_to_host of every member, side by side
+ *     mhx_group_stats        transitions / accepted summed, kernel_ms = the slowest member, wall_ms = the whole call
+ *     mhx_group_diagnostics  the sums of mhx_run_diagnostics added in member order (+ the chain count): R-hat over ALL chains
+ * The union of the members' chains is bit for bit the unsharded run (tests/test_gpu_group.py).  A failing member's message is
+ * returned with its index and device.  Ownership: the group owns contexts and threads; the caller destroys runs and targets
+ * BEFORE mhx_group_destroy.  One group call at a time (a group is a handle: not thread-safe). */
+typedef struct mhx_group mhx_group;
+int mhx_group_create(const int32_t *devices, int32_t n, int dtype /* mhx_dtype */, mhx_group **out);
+int mhx_group_destroy(mhx_group *g);
+int mhx_group_size(const mhx_group *g, int32_t *n);
+int mhx_group_ctx(mhx_group *g, int32_t i, mhx_ctx **ctx);      /* borrowed: valid until mhx_group_destroy */
+/* member i's contiguous block of `nchains_total` global chain ids (sizes differ by at most one) */
+int mhx_group_shard(const mhx_group *g, int64_t nchains_total, int32_t i, uint64_t *first_chain, int32_t *nchains);
+int mhx_group_attach(mhx_group *g, mhx_run *const *runs /* [n]: runs[i] was created on mhx_group_ctx(g, i); equal dim */);
+int mhx_group_run(mhx_group *g, int32_t i, mhx_run **run);
+int mhx_group_init(mhx_group *g, const void *const *initial_params /* NULL, or [n] host pointers, each NULL or [dim][nchains_i] */);
+int mhx_group_sample(mhx_group *g, const mhx_schedule *sched, int save_samples);
+int mhx_group_sample_to_host(mhx_group *g, const mhx_schedule *sched, void *const *samples /* [n] host tensors [n_samples][dim+1][nchains_i] */,
+                             uint8_t *const *accepted /* NULL, or [n] (entries may be NULL) */, int32_t slab_samples);
+int mhx_group_stats(mhx_group *g, mhx_stats *out);
+/* ess (optional): the members' ESS added (each from the autocovariances of its own shard); negated when any member's was.
+ * *n_chains = the chains behind the sums (2x with cfg.split). */
+int mhx_group_diagnostics(mhx_group *g, const mhx_diag_cfg *cfg, double *sum_m, double *sum_m2, double *sum_v, double *ess /* each [dim+1] or NULL */,
+                          int64_t *n_chains);
+/* bulk / tail ESS of every member (ranks pooled within a member's shard) added over the members */
+int mhx_group_ess_bulk_tail(mhx_group *g, const mhx_diag_cfg *cfg, const int32_t *params, int32_t nparams, double *ess_bulk, double *ess_tail);
 
 #ifdef __cplusplus
 }

@@ -61,3 +61,40 @@ def _default_width(request):
     yield
     m.set_default_dtype(old_m)
     O.set_dtype(old_o)
+
+
+class _EngineOptions:
+    """mhx_ctx_set_option on the default contexts for the duration of one test.  The library reads no tuning variable from the
+    environment; `setenv("MHX_EMCEE_MFMA", "0")` keeps the call shape of the rounds that did (name with or without the MHX_ prefix)."""
+
+    def __init__(self, m):
+        self.m = m
+
+    def setenv(self, name, value):
+        self.m.set_option(name[4:] if name.startswith("MHX_") else name, value)
+
+    set = setenv
+
+    def delenv(self, name):
+        self.m.set_option(name[4:] if name.startswith("MHX_") else name, None)
+
+
+@pytest.fixture
+def engine():
+    """explicit engine options (kernel form / tuning) on the release library"""
+    import mhx as m
+    yield _EngineOptions(m)
+    m.clear_options()
+
+
+@pytest.fixture
+def tools_engine():
+    """the tools build (libmhx_tools.so: timing probes, fault injection) bound for one test; its probe options taint the
+    context -- chains of such runs are only built with allow_tainted=True"""
+    import mhx as m
+    m.use_library(m.TOOLS_LIB_PATH)
+    try:
+        yield _EngineOptions(m)
+    finally:
+        m.clear_options()
+        m.use_library()

@@ -227,7 +227,7 @@ def test_emcee_user_log_density_walker_major_rows(mhx, oracle, d, W, real):
 
 
 @pytest.mark.parametrize("d,W,kind", [(7, 37, "user"), (50, 200, "user"), (64, 10, "user"), (3, 2, "user"), (2, 131, "iid"), (30, 66, "banana")])
-def test_lane_per_walker_kernel_one_launch_per_sweep(mhx, oracle, d, W, kind, real, monkeypatch):
+def test_lane_per_walker_kernel_one_launch_per_sweep(mhx, oracle, d, W, kind, real, engine):
     """The register kernel (any target) with both halves in one launch: the second half's lanes evaluate the log-density twice --
     their partner's candidate, then their own.  Same tensor as two half-step launches and as the oracle (user source, catalogue
     targets; odd W, W = 2, blocks that hold one half's tail, a continued call)."""
@@ -247,10 +247,10 @@ def test_lane_per_walker_kernel_one_launch_per_sweep(mhx, oracle, d, W, kind, re
         init[1] = np.abs(init[1]) + 0.5
     spl = mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I)))
 
-    monkeypatch.setenv("MHX_EMCEE_PERSIST", "0")             # (these sizes would run as one persistent block)
+    engine.setenv("MHX_EMCEE_PERSIST", "0")             # (these sizes would run as one persistent block)
 
     def go(fused):
-        monkeypatch.setenv("MHX_EMCEE_FUSED", "1" if fused else "0")
+        engine.setenv("MHX_EMCEE_FUSED", "1" if fused else "0")
         r = mhx.Run(model, spl, seed=21, reduce_lanes=1)
         r.init(init)
         r.sample(5, 2, 2, 0)
@@ -368,7 +368,7 @@ def test_banded_precision_factor_is_detected_and_bit_identical(mhx, oracle, real
 
 @pytest.mark.parametrize("d,W,bw,lanes", [(50, 256, 1, 0), (50, 131, 1, 16), (12, 130, 2, 4), (33, 193, 5, 8), (20, 96, 0, 0), (7, 3, 1, 2),
                                           (64, 2, 8, 16)])
-def test_one_launch_per_sweep_is_the_same_chain_as_two_half_steps(mhx, oracle, real, d, W, bw, lanes, monkeypatch):
+def test_one_launch_per_sweep_is_the_same_chain_as_two_half_steps(mhx, oracle, real, d, W, bw, lanes, engine):
     """The banded lane-group form moves BOTH halves in one launch (the second half's groups re-do their partner's move from the
     old state; walker rows double-buffered, only rows the other buffer does not hold are stored): the same tensor, accept flags
     and counters as two half-step launches (MHX_EMCEE_FUSED=0) and as the oracle's split sweep -- odd W, ensembles smaller than a
@@ -379,7 +379,7 @@ def test_one_launch_per_sweep_is_the_same_chain_as_two_half_steps(mhx, oracle, r
     spl = mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I)))
 
     def go(fused):
-        monkeypatch.setenv("MHX_EMCEE_FUSED", "1" if fused else "0")
+        engine.setenv("MHX_EMCEE_FUSED", "1" if fused else "0")
         r = mhx.Run(model, spl, seed=9, reduce_lanes=lanes)
         r.init(init)
         l0 = r.stats()["launches"]
@@ -406,7 +406,7 @@ def test_one_launch_per_sweep_is_the_same_chain_as_two_half_steps(mhx, oracle, r
 
 @pytest.mark.parametrize("d,W,knobs", [(50, 200, {}), (17, 71, {}), (64, 129, {}), (33, 64, {"MHX_EMCEE_SCALAR": "4"}),
                                        (16, 66, {"MHX_EMCEE_SCALAR": "16"}), (24, 3, {}), (50, 2, {}), (12, 33, {})])
-def test_scalar_factor_form_one_launch_per_sweep(mhx, oracle, real, d, W, knobs, monkeypatch):
+def test_scalar_factor_form_one_launch_per_sweep(mhx, oracle, real, d, W, knobs, engine):
     """The scalar-factor form (dense factor) with both halves in one launch: mixed blocks of 16 walkers of each half, the second
     half's carry three candidate rows each through phase 2 (64 rows: every lane busy).  Same tensor as two half-step launches and
     as the oracle; 4 / 8 / 16 row classes, odd W, ensembles smaller than a block, a continued call."""
@@ -414,12 +414,12 @@ def test_scalar_factor_form_one_launch_per_sweep(mhx, oracle, real, d, W, knobs,
     init = cases.emcee_init(d, W, 5)
     model = mhx.DensityModel(mhx.CorrGaussian(Sig))
     spl = mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I)))
-    monkeypatch.setenv("MHX_EMCEE_MFMA", "0")                 # (the matrix-core form would take these shapes by default)
+    engine.setenv("MHX_EMCEE_MFMA", "0")                 # (the matrix-core form would take these shapes by default)
     for k, v in knobs.items():
-        monkeypatch.setenv(k, v)
+        engine.setenv(k, v)
 
     def go(fused):
-        monkeypatch.setenv("MHX_EMCEE_FUSED", "1" if fused else "0")
+        engine.setenv("MHX_EMCEE_FUSED", "1" if fused else "0")
         r = mhx.Run(model, spl, seed=11)
         r.init(init)
         l0 = r.stats()["launches"]
@@ -450,7 +450,7 @@ def test_a_dense_factor_keeps_the_dense_form(mhx):
 
 
 @pytest.mark.parametrize("W", [128, 131])
-def test_sweep_kernel_deferred_record_writes_the_same_tensor(mhx, real, W, monkeypatch):
+def test_sweep_kernel_deferred_record_writes_the_same_tensor(mhx, real, W, engine):
     """MHX_EMCEE_SWEEP_DEFER=1 (tuning knob): the one-launch-per-sweep kernel records a sweep at the top of the NEXT launch, the
     call's last one by a small kernel of its own.  Same tensor, through thinning, a discarded prefix and slab-wise calls."""
     d = 10
@@ -468,7 +468,7 @@ def test_sweep_kernel_deferred_record_writes_the_same_tensor(mhx, real, W, monke
         return r.samples()
 
     want = run_it(0)
-    monkeypatch.setenv("MHX_EMCEE_SWEEP_DEFER", "1")
+    engine.setenv("MHX_EMCEE_SWEEP_DEFER", "1")
     for slab in (0, 2, 4):
         got = run_it(slab)
         _same(got[0], want[0], "samples, slab %d" % slab)
@@ -476,7 +476,7 @@ def test_sweep_kernel_deferred_record_writes_the_same_tensor(mhx, real, W, monke
 
 
 @pytest.mark.parametrize("W", [128, 131])
-def test_deferred_record_writes_the_same_tensor(mhx, real, W, monkeypatch):
+def test_deferred_record_writes_the_same_tensor(mhx, real, W, engine):
     """MHX_EMCEE_DEFER=1 (tuning knob): the record of a half leaves at the start of the NEXT launch (the half is at rest and final
     for its sweep) instead of at the end of the launch that moved it; odd W: the half at rest is one walker larger.  Same tensor,
     through thinning, a discarded prefix and slab-wise calls."""
@@ -495,7 +495,7 @@ def test_deferred_record_writes_the_same_tensor(mhx, real, W, monkeypatch):
         return r.samples()
 
     want = run_it(0)
-    monkeypatch.setenv("MHX_EMCEE_DEFER", "1")
+    engine.setenv("MHX_EMCEE_DEFER", "1")
     for slab in (0, 4, -2):
         got = run_it(slab)
         _same(got[0], want[0], "samples, deferred record, slab %d" % slab)
@@ -508,13 +508,13 @@ def _rotated(d, rho=0.9, seed=50):
 
 
 @pytest.mark.parametrize("d,W", [(50, 200), (17, 70), (64, 129), (33, 64), (8, 66)])
-def test_scalar_factor_form_runs_a_dense_factor_bit_exact(mhx, oracle, real, d, W, monkeypatch):
+def test_scalar_factor_form_runs_a_dense_factor_bit_exact(mhx, oracle, real, d, W, engine):
     """Round 4: a DENSE precision factor (the rotated C3 target: no band to exploit) runs the scalar-factor form of the cooperative
     stretch move -- variant 9: a lane owns a walker during A y, the wave-uniform factor entry is the DPP-broadcast operand of
     v_fmac, rows split over the 8 waves of a block = the spec's reduction shape 8 -- and is the oracle's chain bit for bit, through a
     discarded prefix, thinning, the initial draw on the device and a slab-streamed call (src/emcee.jl:70-102).  (MHX_EMCEE_MFMA=0:
     the matrix-core form is the default for these shapes since the end of round 4.)"""
-    monkeypatch.setenv("MHX_EMCEE_MFMA", "0")
+    engine.setenv("MHX_EMCEE_MFMA", "0")
     Sig = _rotated(d)
     model = mhx.DensityModel(mhx.CorrGaussian(Sig))
     spl = mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I)))
@@ -534,13 +534,13 @@ def test_scalar_factor_form_runs_a_dense_factor_bit_exact(mhx, oracle, real, d, 
 
 @pytest.mark.parametrize("knobs", [{"MHX_EMCEE_SCALAR": "4"}, {"MHX_EMCEE_SCALAR": "16"}, {"MHX_EMCEE_SCAL_WPB": "64"}, {"MHX_EMCEE_SCAL_WPB": "16"},
                                    {"MHX_EMCEE_SCAL_MODE": "0"}, {"MHX_EMCEE_SCAL_REC": "0"}, {"MHX_EMCEE_SCALAR": "0"}])
-def test_scalar_factor_form_every_shape_and_the_lane_group_form_agree_with_the_oracle(mhx, oracle, real, knobs, monkeypatch):
+def test_scalar_factor_form_every_shape_and_the_lane_group_form_agree_with_the_oracle(mhx, oracle, real, knobs, engine):
     """The tuning knobs of the scalar-factor form (waves per block = reduction shape 4 / 16, walkers per block, SGPR operands instead
     of the DPP broadcast, the record straight from the move mapping) and MHX_EMCEE_SCALAR=0 (the lane-group form with its LDS image):
     every one of them is the oracle's chain for the reduction shape it reports."""
-    monkeypatch.setenv("MHX_EMCEE_MFMA", "0")
+    engine.setenv("MHX_EMCEE_MFMA", "0")
     for k, v in knobs.items():
-        monkeypatch.setenv(k, v)
+        engine.setenv(k, v)
     d, W = 50, 131
     Sig = _rotated(d)
     init = cases.emcee_init(d, W, 7)
@@ -569,20 +569,20 @@ def test_a_large_dense_factor_falls_back_to_the_lane_group_form(mhx, oracle, rea
 
 
 @pytest.mark.parametrize("d,W", [(50, 200), (8, 66), (17, 71), (33, 64), (64, 129), (24, 3), (50, 2), (12, 33), (100, 40), (128, 19)])
-def test_matrix_core_form_of_the_stretch_move(mhx, oracle, real, d, W, monkeypatch):
+def test_matrix_core_form_of_the_stretch_move(mhx, oracle, real, d, W, engine):
     """A dense precision factor on the matrix cores (variant 10): 4 lanes per walker, the candidate formed in the MFMA's B-operand
     layout, the factor's operand image built once per run and fetched into registers per launch -- no LDS, no barrier; reduction
     shape 4.  As one launch per sweep and as two half-step launches: the oracle's chain bit for bit (odd W, ensembles smaller than
     a wave, thinning with a discarded prefix, a continued call, the initial draw on the device)."""
     limit = 64 if real == "f64" else 128
-    monkeypatch.setenv("MHX_EMCEE_MFMA", "1")               # (by default only large fp64 ensembles take this form)
+    engine.setenv("MHX_EMCEE_MFMA", "1")               # (by default only large fp64 ensembles take this form)
     Sig = _rotated(d, 0.9 if d <= 64 else 0.5)
     init = cases.emcee_init(d, W, 5)
     model = mhx.DensityModel(mhx.CorrGaussian(Sig))
     spl = mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I)))
 
     def go(fused):
-        monkeypatch.setenv("MHX_EMCEE_FUSED", "1" if fused else "0")
+        engine.setenv("MHX_EMCEE_FUSED", "1" if fused else "0")
         r = mhx.Run(model, spl, seed=11)
         r.init(init)
         r.sample(5, 2, 2, 0)
@@ -617,7 +617,7 @@ def test_matrix_core_form_of_the_stretch_move(mhx, oracle, real, d, W, monkeypat
 
 @pytest.mark.parametrize("d,W,kind", [(2, 1000, "user"), (10, 64, "user"), (7, 37, "user"), (50, 200, "user"), (24, 1024, "user"), (3, 2, "user"),
                                       (2, 131, "iid"), (30, 66, "banana"), (10, 1025, "user")])
-def test_small_ensemble_as_one_persistent_block(mhx, oracle, d, W, kind, real, monkeypatch):
+def test_small_ensemble_as_one_persistent_block(mhx, oracle, d, W, kind, real, engine):
     """An ensemble of at most 1024 walkers on the lane-per-walker kernel runs a whole sampling call as ONE launch of one persistent
     block (variant 6): thread = walker, rows in LDS for the partners, block barriers between the half-steps.  Same tensor, state and
     counters as the sweep launches (MHX_EMCEE_PERSIST=0) and as the oracle -- thinning with a discarded prefix, a continued call, a
@@ -639,7 +639,7 @@ def test_small_ensemble_as_one_persistent_block(mhx, oracle, d, W, kind, real, m
     spl = mhx.Ensemble(W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I)))
 
     def go(persist):
-        monkeypatch.setenv("MHX_EMCEE_PERSIST", "1" if persist else "0")
+        engine.setenv("MHX_EMCEE_PERSIST", "1" if persist else "0")
         r = mhx.Run(model, spl, seed=21, reduce_lanes=1)
         r.init(init)
         r.sample(5, 2, 2, 0)

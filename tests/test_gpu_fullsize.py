@@ -61,12 +61,12 @@ def test_c3_full_size_emcee(mhx, oracle, real):
 
 
 @pytest.mark.parametrize("form", ["matrix-core", "scalar-factor"])
-def test_c3_rotated_full_size_emcee(mhx, oracle, real, form, monkeypatch):
+def test_c3_rotated_full_size_emcee(mhx, oracle, real, form, engine):
     """SURVEY 8(d) C3 "also a dense-rotated variant": Sigma = Q (0.9^|i-j|) Q^T, no structural zeros in the factor -- the whole
     16 384-walker ensemble against the oracle on the matrix-core form (variant 10, reduction shape 4: the default) and on the
     scalar-factor form (variant 9, reduction shape 8: MHX_EMCEE_MFMA=0)."""
     want_variant, want_L = (10, 4) if form == "matrix-core" else (9, 8)
-    monkeypatch.setenv("MHX_EMCEE_MFMA", "1" if form == "matrix-core" else "0")    # (default: matrix-core in fp64 at this size)
+    engine.setenv("MHX_EMCEE_MFMA", "1" if form == "matrix-core" else "0")    # (default: matrix-core in fp64 at this size)
     d, W, N = 50, 16384, 4
     Q, _ = np.linalg.qr(np.random.default_rng(50).normal(size=(d, d)))
     Sig = Q @ cases.sigma_ar1(d, 0.9) @ Q.T

@@ -243,7 +243,7 @@ def test_large_dimension_shapes_random_configurations(mhx, oracle, case, real):
 
 
 @pytest.mark.parametrize("case", range(24))
-def test_dense_factor_ensembles_random_configurations(mhx, oracle, case, real, monkeypatch):
+def test_dense_factor_ensembles_random_configurations(mhx, oracle, case, real, engine):
     """The scalar-factor form of the cooperative stretch move (round 4) over random dense factors: dimension 8 ... 68 (odd ones,
     multiples of 4 and of 16), odd and tiny ensembles (a single block, ragged last blocks, halves of different size), random
     waves per block / walkers per block / operand mode, thinning and a discarded prefix, a resumed call, both widths."""
@@ -264,7 +264,7 @@ def test_dense_factor_ensembles_random_configurations(mhx, oracle, case, real, m
     if "MHX_EMCEE_SCALAR" not in knobs:
         knobs["MHX_EMCEE_MFMA"] = str(int(rng.integers(0, 2)))   # the matrix-core form, d <= 64 (fp32: 128), or explicitly not
     for k, v in knobs.items():
-        monkeypatch.setenv(k, v)
+        engine.setenv(k, v)
     A = rng.normal(size=(d, d))
     Sig = A @ A.T / d + np.diag(0.2 + rng.random(d))               # a dense SPD matrix: no band
     seed, ens = int(rng.integers(1, 1 << 40)), int(rng.integers(0, 1 << 20))
@@ -306,7 +306,7 @@ def _banded_sigma(d, bw, rng):
 
 
 @pytest.mark.parametrize("case", range(24))
-def test_ensemble_sweep_launches_random_configurations(mhx, oracle, case, real, monkeypatch):
+def test_ensemble_sweep_launches_random_configurations(mhx, oracle, case, real, engine):
     """One launch per sweep (round 4) over random ensembles: banded factors on the lane-group form, dense ones on the scalar-factor or
     the matrix-core form, user-style targets on the lane-per-walker kernel; dimensions with and without padding, odd and tiny
     ensembles, random lanes per walker, thinning with a discarded prefix, a resumed call; and the same run as two half-step launches
@@ -328,18 +328,18 @@ def test_ensemble_sweep_launches_random_configurations(mhx, oracle, case, real, 
         A = rng.normal(size=(d, d))
         Sig = A @ A.T / d + np.diag(0.2 + rng.random(d))
         spec = mhx.CorrGaussian(Sig)
-        monkeypatch.setenv("MHX_EMCEE_MFMA", "1" if kind == "mfma" else "0")
+        engine.setenv("MHX_EMCEE_MFMA", "1" if kind == "mfma" else "0")
     else:
         spec = mhx.Banana(d, 0.03)
         lanes = 1
-        monkeypatch.setenv("MHX_EMCEE_PERSIST", "0")         # (small ensembles on this kernel would run as one persistent block)
+        engine.setenv("MHX_EMCEE_PERSIST", "0")         # (small ensembles on this kernel would run as one persistent block)
     seed, ens = int(rng.integers(1, 1 << 40)), int(rng.integers(0, 1 << 20))
     a = float(np.float32(1.5 + rng.random()))
     init = None if rng.integers(0, 2) else (rng.normal(size=(d, W)) * 0.5).astype(np.float32)
     prior = mhx.MvNormal(mhx.zeros(d), mhx.I)
 
     def go(fused):
-        monkeypatch.setenv("MHX_EMCEE_FUSED", "1" if fused else "0")
+        engine.setenv("MHX_EMCEE_FUSED", "1" if fused else "0")
         run = mhx.Run(mhx.DensityModel(spec), mhx.Ensemble(W, mhx.StretchProposal(prior, a)), seed=seed, first_chain=ens, reduce_lanes=lanes)
         run.init(init)
         run.sample(N, di, th, 0)

@@ -171,10 +171,11 @@ def test_jit_objects_persist_across_contexts(mhx, real, tmp_path, monkeypatch):
     assert hit4 == 0 and comp4 == comp1
 
 
-def test_a_failing_slab_drains_the_copies_and_releases_the_callers_buffer_once(mhx, real, monkeypatch):
+def test_a_failing_slab_drains_the_copies_and_releases_the_callers_buffer_once(mhx, real, tools_engine):
     """ADVICE r3 / VERDICT r3 #8: an error in the MIDDLE of mhx_run_sample_to_host (after the copies of earlier slabs were
     enqueued on the second stream) must not return while a DMA still targets the caller's buffer, must release the page-lock it took
-    exactly once, and must not leave a half-described tensor behind.  MHX_FAULT_SLAB=k injects the failure before slab k."""
+    exactly once, and must not leave a half-described tensor behind.  Option FAULT_SLAB = k of the TOOLS build (libmhx_tools.so; the
+    release library has no such hook) injects the failure before slab k."""
     d, nch, N = 5, 128, 12
     mk, _ = _runs(mhx, "rwmh", d, nch, 21)
     r, ref = mk(), mk()
@@ -183,10 +184,11 @@ def test_a_failing_slab_drains_the_copies_and_releases_the_callers_buffer_once(m
     assert reg0 == rel0
     out = np.full((N, d + 1, nch), np.nan, dtype=r.real)                # pageable: the call registers it
     acc = np.zeros((N, nch), dtype=np.uint8)
-    monkeypatch.setenv("MHX_FAULT_SLAB", "2")
+    tools_engine.set("FAULT_SLAB", "2")
     with pytest.raises(mhx.MhxError, match="injected failure at slab 2"):
         r.sample_to_host(N, 0, 1, 0, out=out, out_accepted=acc, slab_samples=3)
-    monkeypatch.delenv("MHX_FAULT_SLAB")
+    tools_engine.delenv("FAULT_SLAB")
+    assert r.stats()["tainted"] == 1                                    # a context that ever carried a hook stays marked
     reg1, rel1 = r.ctx.host_pin_counts()
     assert reg1 - reg0 == 2 and rel1 - rel0 == 2                        # samples + accepted: registered, then released, once each
     # the two slabs before the failure arrived completely (the return waited for their copies); nothing after them was written

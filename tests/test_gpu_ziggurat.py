@@ -136,52 +136,73 @@ def test_device_normals_pass_distribution_checks(mhx, f64):
 
 
 @pytest.mark.parametrize("every", [3, 7])
-def test_fixup_queue_windows(mhx, oracle, f64, monkeypatch, every):
+def test_fixup_queue_windows(mhx, oracle, f64, tools_engine, every):
     """More than 64 candidates of one wave-step in the fix-up queue (never seen in practice: a dozen fail) -- forced by the
-    MHX_ZIG_FORCE_FAIL test knob, which sends every n-th slot through the queue although its candidate is inside its rectangle;
-    the refinement re-derives the same normal, so the chains must still equal the oracle's bit for bit."""
-    monkeypatch.setenv("MHX_ZIG_FORCE_FAIL", str(every))
-    monkeypatch.setenv("MHX_NO_PREBUILT", "1")
+    ZIG_FORCE_FAIL test hook of the TOOLS build, which sends every n-th slot through the queue although its candidate is inside its
+    rectangle; the refinement re-derives the same normal, so the chains must still equal the oracle's bit for bit.  (A hook taints
+    its context: mhx_stats.tainted = 1, and `sample` builds a Chains from such a run only when told to.)"""
+    tools_engine.set("ZIG_FORCE_FAIL", str(every))
+    tools_engine.set("NO_PREBUILT", "1")
     for d, C, N, lanes in [(100, 70, 12, 2), (100, 33, 9, 4), (1000, 5, 6, 64), (13, 200, 10, 1)]:
         model = mhx.DensityModel(mhx.IsoGaussian(d))
         spl = mhx.RWMH(mhx.MvNormal(mhx.zeros(d), S * S * mhx.I))
-        chain = mhx.sample(model, spl, N, C, seed=77 + d, first_chain=2, reduce_lanes=lanes, normal_gen="ziggurat")
-        assert chain.stats["kernel_variant"] == 4 and chain.stats["normal_gen"] == 1
+        with pytest.raises(mhx.MhxError, match="tainted"):
+            mhx.sample(model, spl, 2, 4, seed=1, reduce_lanes=lanes, normal_gen="ziggurat")
+        chain = mhx.sample(model, spl, N, C, seed=77 + d, first_chain=2, reduce_lanes=lanes, normal_gen="ziggurat", allow_tainted=True)
+        assert chain.stats["kernel_variant"] == 4 and chain.stats["normal_gen"] == 1 and chain.stats["tainted"] == 1
         L = chain.stats["reduce_lanes"]
         ref = oracle.rwmh(oracle.iso_gauss(d, reduce_lanes=L), oracle.Proposal(oracle.PROP_ISO, S, normal_gen=1), oracle.schedule(N), 77 + d, 2, C)
         _same(chain.value, ref["samples"], "samples d=%d lanes=%d" % (d, lanes))
         _same(chain.accepted, ref["accepted"], "accepted")
 
 
-@pytest.mark.parametrize("defs", ["MHX_COOP_WIDE_REC=1", "MHX_COOP_WIDE_REC=1 MHX_WIDE_REC_RUN=0", "MHX_COOP_REC_RUN=0", "MHX_ZIG_SIGNACC=1",
-                                  "MHX_ZIG_FABS=1 MHX_ZIG_NIB=1", "MHX_ZIG_ANDOR=0 MHX_ZIG_FABS=0 MHX_ZIG_NIB=0", "MHX_REC_STORE_AUX=0"])
-def test_measured_knobs_of_the_cooperative_kernel_change_no_bit(mhx, oracle, f64, monkeypatch, defs):
-    """The kernel forms that were measured and kept as knobs (the record as 16-byte stores of two rows x two chains after a
-    lane transpose, row offsets hoisted or running, failure bits from the sign of |x| - x[layer + 1], the fast-path variants, plain
-    instead of non-temporal record stores) are data movement and instruction selection only: every one of them, compiled by hiprtc
-    through MHX_JIT_DEFS, yields the oracle's chains bit for bit -- even / odd chain counts, a last block with padding, two shapes."""
-    monkeypatch.setenv("MHX_JIT_DEFS", defs)
+def test_the_release_library_has_no_probes_and_reads_no_tuning_variable(mhx, oracle, f64, monkeypatch):
+    """libmhx.so: a probe / hook name is an unknown option, a run is never tainted, and the environment variables that steered the
+    kernels in earlier rounds do nothing (here: MHX_NO_PREBUILT=1 would have replaced the pre-built headline kernel, variant 3)."""
+    ctx = mhx.Context.default()
+    for name in ("ZIG_PROBE", "EMCEE_PROBE", "ZIG_FORCE_FAIL", "FAULT_SLAB", "JIT_DEFS", "EMCEE_STAMPS", "NOT_AN_OPTION"):
+        with pytest.raises(mhx.ArgumentError, match="unknown option"):
+            ctx.set_option(name, "1")
     monkeypatch.setenv("MHX_NO_PREBUILT", "1")
-    for d, C, N, lanes in [(100, 70, 9, 2), (100, 33, 7, 2), (98, 64, 6, 4), (1000, 6, 5, 64)]:
+    monkeypatch.setenv("MHX_ZIG_PROBE", "1")
+    d = 100
+    model = mhx.DensityModel(mhx.IsoGaussian(d))
+    spl = mhx.RWMH(mhx.MvNormal(mhx.zeros(d), S * S * mhx.I))
+    chain = mhx.sample(model, spl, 6, 64, seed=3, reduce_lanes=2, normal_gen="ziggurat")
+    assert chain.stats["kernel_variant"] == 3 and chain.stats["tainted"] == 0
+    ref = oracle.rwmh(oracle.iso_gauss(d, reduce_lanes=2), oracle.Proposal(oracle.PROP_ISO, S, normal_gen=1), oracle.schedule(6), 3, 0, 64)
+    _same(chain.value, ref["samples"], "samples")
+    ctx.set_option("NO_PREBUILT", "1")                      # the explicit form of the same wish
+    try:
+        assert ctx.get_option("NO_PREBUILT") == "1"
+        chain = mhx.sample(model, spl, 6, 64, seed=3, reduce_lanes=2, normal_gen="ziggurat")
+        assert chain.stats["kernel_variant"] == 4 and chain.stats["tainted"] == 0
+        _same(chain.value, ref["samples"], "samples, hiprtc-specialised")
+    finally:
+        ctx.set_option("NO_PREBUILT", None)
+
+
+def test_jit_defs_of_the_tools_build_reach_hiprtc_and_change_no_bit(mhx, oracle, f64, tools_engine, tmp_path, monkeypatch):
+    """Option JIT_DEFS of the tools build hands extra defines to every hiprtc compile (how the A/B scripts reach the kernels'
+    compile-time parameters): plain instead of non-temporal record stores are data movement only -- the oracle's chains bit for bit;
+    and a define that cannot compile must fail the run's creation (what makes the first half a test), in a fresh cache directory."""
+    tools_engine.set("JIT_DEFS", "MHX_REC_STORE_AUX=0")
+    tools_engine.set("NO_PREBUILT", "1")
+    for d, C, N, lanes in [(100, 70, 9, 2), (98, 64, 6, 4)]:
         model = mhx.DensityModel(mhx.IsoGaussian(d))
         spl = mhx.RWMH(mhx.MvNormal(mhx.zeros(d), S * S * mhx.I))
-        chain = mhx.sample(model, spl, N, C, seed=31 + d, first_chain=5, reduce_lanes=lanes, normal_gen="ziggurat")
-        assert chain.stats["kernel_variant"] == 4 and chain.stats["normal_gen"] == 1
+        chain = mhx.sample(model, spl, N, C, seed=31 + d, first_chain=5, reduce_lanes=lanes, normal_gen="ziggurat", allow_tainted=True)
+        assert chain.stats["kernel_variant"] == 4 and chain.stats["normal_gen"] == 1 and chain.stats["tainted"] == 1
         L = chain.stats["reduce_lanes"]
         ref = oracle.rwmh(oracle.iso_gauss(d, reduce_lanes=L), oracle.Proposal(oracle.PROP_ISO, S, normal_gen=1), oracle.schedule(N), 31 + d, 5, C)
-        _same(chain.value, ref["samples"], "samples d=%d lanes=%d defs=%s" % (d, lanes, defs))
+        _same(chain.value, ref["samples"], "samples d=%d lanes=%d" % (d, lanes))
         _same(chain.accepted, ref["accepted"], "accepted")
-
-
-def test_jit_defs_reach_hiprtc(mhx, f64, monkeypatch, tmp_path):
-    """(what makes the test above a test: a define that cannot compile must fail the run's creation, in a fresh cache directory)"""
     monkeypatch.setenv("MHX_CACHE_DIR", str(tmp_path / "jit"))
-    monkeypatch.setenv("MHX_JIT_DEFS", "MHX_COOP_REC_RUN=)")
-    monkeypatch.setenv("MHX_NO_PREBUILT", "1")
+    tools_engine.set("JIT_DEFS", "MHX_REC_STORE_AUX=)")
     model = mhx.DensityModel(mhx.IsoGaussian(100))
     spl = mhx.RWMH(mhx.MvNormal(mhx.zeros(100), S * S * mhx.I))
     with pytest.raises(Exception) as ei:
-        mhx.sample(model, spl, 4, 64, seed=1, reduce_lanes=2, normal_gen="ziggurat")
+        mhx.sample(model, spl, 4, 64, seed=1, reduce_lanes=2, normal_gen="ziggurat", allow_tainted=True)
     assert "hiprtc" in str(ei.value)
 
 
@@ -229,23 +250,3 @@ def test_ziggurat_register_kernel_draws_its_own_start(mhx, oracle, f64):
     ref = oracle.rwmh(ut, oracle.Proposal(oracle.PROP_ISO, s, normal_gen=1), oracle.schedule(30), 5, 0, C)
     _same(chain.value, ref["samples"], "samples")
     _same(chain.accepted, ref["accepted"], "accepted")
-
-
-def test_ziggurat_register_kernel_block_skip_knob_changes_no_bit(mhx, oracle, f64, monkeypatch):
-    """(MHX_REG_ZIG_SKIP = 1: the patch rounds skip blocks of 8 registers no lane's slot lies in -- measured slower, kept as a knob)"""
-    monkeypatch.setenv("MHX_JIT_DEFS", "MHX_REG_ZIG_SKIP=1")
-    d, C = 100, 70
-    rng = np.random.default_rng(4)
-    data = np.concatenate([rng.normal(size=d), 0.5 + rng.random(d)]).astype(np.float32)
-    model = mhx.DensityModel(mhx.HipLogDensity(user_targets.SHIFTED_GAUSS, d, data=data))
-    ut = user_targets.host_target(oracle, user_targets.SHIFTED_GAUSS, d, data=data)
-    s = float(np.float32(2.38 / d ** 0.5))
-    init = rng.normal(size=(d, C))
-    r = mhx.Run(model, mhx.RWMH(mhx.MvNormal(mhx.zeros(d), s * s * mhx.I)), nchains=C, seed=12, normal_gen="ziggurat")
-    r.init(init)
-    r.sample(25)
-    got, got_acc = r.samples()
-    assert r.stats()["kernel_variant"] == 2 and r.stats()["normal_gen"] == 1
-    ref = oracle.rwmh(ut, oracle.Proposal(oracle.PROP_ISO, s, normal_gen=1), oracle.schedule(25), 12, 0, C, init=init)
-    _same(got, ref["samples"], "samples")
-    _same(got_acc, ref["accepted"], "accepted")
