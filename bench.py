@@ -15,12 +15,18 @@ collective; scaling is weak.  The only collective -- acceptance totals + R-hat s
 ONE small all-reduce through the C ABI (mhx_comm_*: RCCL over xGMI).
 
 Launching.  `python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset) makes THIS process the launcher: it starts
-N ranks of itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / a free MASTER_PORT), one per GPU, and rank 0 prints
-the line.  Under torchrun (WORLD_SIZE set) the process is one rank.  A line never claims what did not run: --gpus must equal
-WORLD_SIZE, the box must have N devices (unless --allow-gloo, the one-GPU rehearsal), `n_gpus` is the number of DISTINCT devices
-the ranks opened, `n_ranks` the number of processes, and `config.collective` names the transport with the rank count RCCL itself
-reported (mhx_comm_rank).  `--dry-run` runs launcher, rendezvous and the host-side combining with no device and no engine
-(CPU rehearsal of the N-rank flow; `value` is null).
+N ranks of itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / a free MASTER_PORT), each bound to ITS device before
+HIP initialises (HIP_VISIBLE_DEVICES = the rank's entry of the visible list), and rank 0 prints the line.  Under torchrun
+(WORLD_SIZE set) the process is one rank of the launcher's and takes device LOCAL_RANK.  `--gpus N --single-process` is the
+third way: ONE process, N member contexts and N host threads behind the C ABI (mhx_group_*), the statistics summed on the host.
+A line never claims what did not run: --gpus must equal WORLD_SIZE, the box must have N devices (unless --allow-gloo, the one-GPU
+rehearsal), `n_gpus` is the number of DISTINCT PCI bus ids the ranks / members opened (ordinals depend on the visibility
+variables, bus ids do not), `n_ranks` the number of processes, and `config.collective` names the transport that really carried
+the small all-reduces.  A multi-GPU run must not end with NO line: the transports form a ladder -- RCCL behind the C ABI
+(mhx_comm_*, the product path: ncclCommInitRank and every collective under a deadline that names the rank), then
+torch.distributed's own nccl backend, then gloo -- every rung agreed on by all ranks, a failed rung reported in the line
+(`config.rccl_error`, `config.transport_errors`); `--require-rccl` turns the first fallback into an error instead.  `--dry-run`
+runs launcher, rendezvous, ladder and the host-side combining with no device and no engine (`value` is null).
 
 Prints ONE JSON line on rank 0, < 8 KB (the driver keeps an 8 KB tail): numbers only -- what each field means, the byte
 models and the workload texts are DESIGN.md section 7.  `roofline` prices the dominant kernel (bound "hbm": algorithmic bytes
@@ -195,9 +201,12 @@ MHX_LOGDENSITY(x, d, data, ndata)
         self.run.init(None)                                # x0 ~ proposal draw (src/mh-core.jl:83), on the device
         return self.run
 
-    def step(self):
+    def sched(self):
         # N = inner saved samples, the first one being the state after 1 transition: inner transitions
-        self.run.sample(self.inner, 1, 1, 0, save=True)
+        return (self.inner, 1, 1, 0, True)
+
+    def step(self):
+        self.run.sample(*self.sched()[:4], save=self.sched()[4])
         return self.run.stats()
 
     def units_per_step(self):
@@ -257,9 +266,8 @@ class C5(C2):
         self.run.init(x0)
         return self.run
 
-    def step(self):
-        self.run.sample(self.inner // 10, 10, 10, 0, save="moments")     # every 10th state folded into the moments
-        return self.run.stats()
+    def sched(self):
+        return (self.inner // 10, 10, 10, 0, "moments")                  # every 10th state folded into the moments
 
     def bytes_per_launch(self):
         """the state lives in registers for a launch: HBM sees one state round trip and one moments round trip per launch"""
@@ -322,8 +330,11 @@ MHX_LOGDENSITY(x, d, data, ndata)
         self.run.init(None)
         return self.run
 
+    def sched(self):
+        return (self.inner, 1, 1, 0, True)
+
     def step(self):
-        self.run.sample(self.inner, 1, 1, 0, save=True)
+        self.run.sample(*self.sched()[:4], save=self.sched()[4])
         return self.run.stats()
 
     def units_per_step(self):
@@ -385,9 +396,12 @@ class C4:
             self.run.sample(1, self.inner, 1, self.inner, save=False)   # a warm-up first: the timed steps run on adapted factors
         return self.run
 
-    def step(self):
+    def sched(self):
         # `inner` adapting transitions (step_warmup), or `inner` transitions with the factor frozen (RAM.jl:216-237)
-        self.run.sample(1, self.inner, 1, 0 if self.fixed else self.inner, save=False)
+        return (1, self.inner, 1, 0 if self.fixed else self.inner, False)
+
+    def step(self):
+        self.run.sample(*self.sched()[:4], save=self.sched()[4])
         return self.run.stats()
 
     def units_per_step(self):
@@ -435,8 +449,11 @@ class C1:
         self.run.init(np.array([0.0, 1.0]))
         return self.run
 
+    def sched(self):
+        return (self.inner, 1, 1, 0, True)
+
     def step(self):
-        self.run.sample(self.inner, 1, 1, 0, save=True)
+        self.run.sample(*self.sched()[:4], save=self.sched()[4])
         return self.run.stats()
 
     def units_per_step(self):
@@ -494,9 +511,9 @@ def cpu_baseline(wl, dtype, target_seconds=10.0, compact=False):
 
 
 class GlooSum:
-    """Fallback transport of the bench's three tiny host-side all-reduces (torch.distributed, gloo): same interface as
-    mhx.dist.Comm.allreduce_sum.  Only used when the RCCL communicator behind the C ABI cannot be created (--allow-gloo) and by
-    --dry-run."""
+    """Last rung of the transport ladder, and the transport of --dry-run: the bench's tiny host-side all-reduces over
+    torch.distributed gloo.  Same interface as mhx.dist.Comm.allreduce_sum."""
+    name = "gloo"
 
     def __init__(self, dist):
         self.dist = dist
@@ -508,53 +525,191 @@ class GlooSum:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return t.numpy()
 
+    def ranks(self):
+        return self.dist.get_world_size()
+
     def close(self):
         pass
 
 
-def rendezvous(rank, world):
+class TorchNcclSum:
+    """Second rung: torch.distributed's own nccl backend (the RCCL torch ships and initialises its own way) on device tensors --
+    tried when the communicator behind the C ABI could not be created on every rank."""
+    name = "torch.distributed nccl"
+
+    def __init__(self, dist, device, seconds):
+        import datetime
+        import torch
+        self.dist, self.torch = dist, torch
+        self.device = torch.device("cuda", device)
+        self.group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=max(10.0, seconds)))
+
+    def allreduce_sum(self, v):
+        import numpy as np
+        t = self.torch.from_numpy(np.ascontiguousarray(v, dtype=np.float64).copy()).to(self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t.cpu().numpy()
+
+    def ranks(self):
+        return self.dist.get_world_size(self.group)
+
+    def close(self):
+        pass
+
+
+class MhxCommSum:
+    """First rung, the product path: mhx_comm_* of the C ABI -- RCCL over xGMI, resolved by libmhx.so itself."""
+    name = "rccl(mhx_comm_*)"
+
+    def __init__(self, ctx, rank, world, uid, seconds):
+        import ctypes as C
+        import mhx._lib as L
+        from mhx.dist import Comm
+        self.comm = Comm.__new__(Comm)
+        self.comm.ctx, self.comm.rank, self.comm.world, self.comm.h = ctx, rank, world, C.c_void_p()
+        buf = (C.c_char * 128).from_buffer_copy(bytes(uid))
+        L.check(L.lib().mhx_comm_init_timed(ctx.h, rank, world, C.cast(buf, C.c_void_p), float(seconds), C.byref(self.comm.h)))
+        L.check(L.lib().mhx_comm_set_timeout(self.comm.h, float(seconds)))
+        self.rank, self.world = rank, world
+
+    def allreduce_sum(self, v):
+        return self.comm.allreduce_sum(v)
+
+    def ranks(self):
+        r, w = self.comm.rank_world()                  # what RCCL itself reports (ncclCommUserRank / ncclCommCount)
+        if w != self.world or r != self.rank:
+            raise RuntimeError("RCCL reports rank %d of %d, the launcher said %d of %d" % (r, w, self.rank, self.world))
+        return w
+
+    def close(self):
+        self.comm.close()
+
+
+def with_deadline(fn, seconds, what):
+    """fn() on a helper thread, abandoned after `seconds`: a transport that hangs must not take the line with it.  ctypes and torch
+    release the GIL inside their calls, so the wait below really times out.  Returns (value, None) or (None, error text)."""
+    import threading
+    box = {}
+
+    def work():
+        try:
+            box["v"] = fn()
+        except BaseException as e:                                # noqa: BLE001 -- the error text goes into the line
+            box["e"] = "%s: %s" % (type(e).__name__, str(e)[:300])
+    t = threading.Thread(target=work, daemon=True)
+    t.start()
+    t.join(seconds)
+    if t.is_alive():
+        return None, "%s: no answer within %.0f s (abandoned)" % (what, seconds)
+    if "e" in box:
+        return None, box["e"]
+    return box.get("v"), None
+
+
+ABANDONED = []          # transports that hung: their threads still sit in a library call, so the process leaves through os._exit
+
+
+def rendezvous(rank, world, seconds=300.0):
     """torch.distributed's own rendezvous (gloo on CPU; MASTER_ADDR / MASTER_PORT from the launcher): it carries the 128-byte RCCL
-    id from rank 0 to the others and is the --allow-gloo / --dry-run transport"""
+    id from rank 0 to the others, decides the ladder's rungs for all ranks together, and is the last rung itself.  `seconds`
+    bounds the wait for ranks that never arrive."""
+    import datetime
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
     if not dist.is_initialized():
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=seconds))
     return dist
 
 
-def make_collective(ctx, rank, world, allow_gloo=False):
-    """One process per GPU.  The bench's collectives -- barrier, max-over-ranks time, acceptance totals and R-hat sums -- go
-    through the C ABI (mhx_comm_*: RCCL over xGMI).  Returns (transport, text, ranks): `ranks` is what the transport itself
-    reports (mhx_comm_rank -> ncclCommCount).  If the RCCL communicator cannot be created on EVERY rank, all ranks fall back to
-    gloo for those small host-side all-reduces -- only with --allow-gloo, and the line says so."""
+def make_collective(ctx, rank, world, args, device=0):
+    """One process per GPU.  The bench's collectives -- barrier, max-over-ranks time, acceptance totals and R-hat sums -- as a
+    LADDER of transports, so that the first contact with an N-GPU node cannot end with no line at all:
+        1. rccl(mhx_comm_*)        the product path: RCCL behind the C ABI (ncclCommInitRank and every collective under a deadline)
+        2. torch.distributed nccl  torch's own RCCL, initialised torch's way, on device tensors
+        3. gloo                    host TCP; always there (it already carried the rendezvous)
+    A rung is taken only if EVERY rank built it and passed a test all-reduce within --transport-timeout (agreed over gloo with a MIN);
+    otherwise all ranks step down together.  Returns (transport, info): info = {collective, ranks_reported_by_transport,
+    rccl_error, transport_errors}.  --require-rccl: stepping down from rung 1 is an error.  ctx None = --dry-run (no device:
+    rungs 1 and 2 report that and the flow ends on gloo).  --fault-rccl-init fail|hang injects a failure into rung 1."""
     import numpy as np
     import torch
-    from mhx.dist import Comm
-    dist = rendezvous(rank, world)
-    box = [Comm.unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(box, src=0)
-    comm, err = None, ""
+    dist = rendezvous(rank, world, args.rendezvous_timeout)
+    T = float(args.transport_timeout)
+    fault = getattr(args, "fault_rccl_init", None)
+
+    def agree(ok):
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return t.item() >= 1.0
+
+    def gather_errors(err):
+        texts = [None] * world
+        dist.all_gather_object(texts, err)
+        return {"rank%d" % r: e for r, e in enumerate(texts) if e}
+
+    uid = [None]
+    if ctx is not None and rank == 0:
+        from mhx.dist import Comm
+        uid[0], e = with_deadline(Comm.unique_id, T, "mhx_comm_unique_id")
+    dist.broadcast_object_list(uid, src=0)
+
+    def rung_rccl():
+        if fault == "fail":
+            raise RuntimeError("mhx_comm_init: rank %d of %d: injected failure (--fault-rccl-init fail)" % (rank, world))
+        if fault == "hang":
+            time.sleep(1e6)
+        if ctx is None:
+            raise RuntimeError("dry run: no device")
+        if uid[0] is None:
+            raise RuntimeError("rank 0 could not create the RCCL unique id (librccl not loadable?)")
+        t = MhxCommSum(ctx, rank, world, uid[0], T)
+        t.allreduce_sum(np.zeros(1))
+        t.ranks()
+        return t
+
+    def rung_torch_nccl():
+        if ctx is None or not torch.cuda.is_available():
+            raise RuntimeError("dry run: no device")
+        t = TorchNcclSum(dist, device, T)
+        t.allreduce_sum(np.zeros(1))
+        return t
+
+    errors = {}
+    for name, build in (("rccl(mhx_comm_*)", rung_rccl), ("torch.distributed nccl", rung_torch_nccl)):
+        tr, err = with_deadline(build, T + 5.0, name)
+        if tr is None and err and "abandoned" in err:
+            ABANDONED.append(name)
+        ok = agree(tr is not None)
+        if ok:
+            info = {"collective": "%s, %d ranks" % (name, tr.ranks()), "ranks_reported_by_transport": tr.ranks(),
+                    "rccl_error": errors.get("rccl(mhx_comm_*)"), "transport_errors": errors or None}
+            return tr, info
+        errs = gather_errors(err or ("another rank failed" if tr is not None else "failed"))
+        errors[name] = errs
+        if tr is not None:
+            try:
+                tr.close()
+            except Exception:
+                pass
+        if name.startswith("rccl") and args.require_rccl:
+            raise RuntimeError("bench.py --gpus %d --require-rccl: the RCCL communicator behind the C ABI (mhx_comm_init) could not be "
+                               "created on every rank: %s" % (world, json.dumps(errs)))
+    tr = GlooSum(dist)
+    info = {"collective": "gloo, %d ranks (fallback: see rccl_error)" % tr.ranks(), "ranks_reported_by_transport": tr.ranks(),
+            "rccl_error": errors.get("rccl(mhx_comm_*)"), "transport_errors": errors or None}
+    return tr, info
+
+
+def pci_number(bus_id):
+    """"0000:05:00.0" -> an integer that identifies the device on this node (domain : bus : device . function)"""
     try:
-        comm = Comm(ctx, rank, world, box[0])
-        comm.allreduce_sum(np.zeros(1))
-    except Exception as e:                                       # e.g. no librccl, or two ranks on one device
-        comm, err = None, str(e)[:200]
-    ok = torch.tensor([1.0 if comm is not None else 0.0], dtype=torch.float64)
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN)                    # all ranks or none
-    if ok.item() >= 1.0:
-        r, w = comm.rank_world()
-        if w != world or r != rank:
-            raise RuntimeError("bench.py: RCCL reports rank %d of %d, the launcher said %d of %d" % (r, w, rank, world))
-        return comm, "rccl(mhx_comm_*), %d ranks" % w, w
-    if comm is not None:
-        comm.close()
-    if not allow_gloo:
-        # a multi-GPU line must not silently skip RCCL: without --allow-gloo the missing communicator is an error
-        raise RuntimeError("bench.py --gpus %d: the RCCL communicator behind the C ABI (mhx_comm_init) could not be created on every "
-                           "rank (%s); pass --allow-gloo to run the small host-side all-reduces over torch.distributed gloo instead"
-                           % (world, err or "another rank failed"))
-    return GlooSum(dist), "gloo, %d ranks (--allow-gloo: no RCCL communicator: %s)" % (dist.get_world_size(), err[:80]), dist.get_world_size()
+        dom, bus, rest = bus_id.split(":")
+        dev, fn = rest.split(".")
+        return (int(dom, 16) << 16) | (int(bus, 16) << 8) | (int(dev, 16) << 3) | int(fn, 16)
+    except Exception:
+        import zlib
+        return zlib.crc32(bus_id.encode()) | (1 << 40)
 
 
 def timed(wl, steps, warmup, barrier, spin=30):
@@ -753,9 +908,12 @@ def visible_devices():
 
 def launch_ranks(args):
     """This process is the launcher (WORLD_SIZE unset, --gpus N > 1): N children of the same command line, one per GPU, rank 0's
-    stdout is ours.  Exit code: the first non-zero child's.  A failing rank takes the others down (they would wait in a
-    collective for ever)."""
+    stdout is ours.  Each child is bound to ITS device before HIP initialises: HIP_VISIBLE_DEVICES = the r-th entry of the list
+    this process sees (--bind visible, the default; --bind ordinal leaves every device visible and the rank takes LOCAL_RANK like a
+    torchrun rank does).  Exit code: the first non-zero child's.  A failing rank takes the others down (they would wait in a
+    collective until its deadline)."""
     n = args.gpus
+    have = 0
     if not args.dry_run:
         have = visible_devices()
         if have < n and not args.allow_gloo:
@@ -766,9 +924,14 @@ def launch_ranks(args):
     env.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
                MHX_BENCH_LAUNCHED="1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC: what RCCL needs between processes on this driver
+    outer = [v for v in os.environ.get("HIP_VISIBLE_DEVICES", "").split(",") if v != ""]
     procs = []
     for r in range(n):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        if args.bind == "visible" and have > 0:
+            slot = r % have                                        # (several ranks per device only in the --allow-gloo rehearsal)
+            e["HIP_VISIBLE_DEVICES"] = outer[slot] if slot < len(outer) else str(slot)
+            e["MHX_BENCH_BOUND"] = "1"                             # the rank sees ONE device: ordinal 0
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rc, alive = 0, list(procs)
@@ -786,11 +949,21 @@ def launch_ranks(args):
     return rc
 
 
+def leave(code=0):
+    """end of a rank: through os._exit when a transport was abandoned in a hung library call (its thread cannot be joined)"""
+    sys.stdout.flush()
+    sys.stderr.flush()
+    if ABANDONED:
+        os._exit(code)
+    sys.exit(code)
+
+
 def dry_run(args, rank, world):
-    """--dry-run: the N-rank flow with no device and no engine -- rendezvous, barrier, max-over-ranks time and the summed
-    totals over gloo; each rank's "step" is a counter.  Proves on a CPU box that `--gpus N` really is N processes."""
+    """--dry-run: the N-rank flow with no device and no engine -- rendezvous, the transport ladder (it ends on gloo: there is no
+    device), barrier, max-over-ranks time and the summed totals; each rank's "step" is a counter.  Proves on a CPU box that
+    `--gpus N` really is N processes and that a failing / hanging RCCL init (--fault-rccl-init) still ends in a line."""
     import numpy as np
-    comm = GlooSum(rendezvous(rank, world)) if world > 1 else None
+    comm, info = (None, {}) if world == 1 else make_collective(None, rank, world, args)
 
     def barrier():
         if comm is not None:
@@ -813,16 +986,60 @@ def dry_run(args, rank, world):
         p[rank] = os.getpid()
         pids = [int(x) for x in comm.allreduce_sum(p)]
     if rank == 0:
+        cfg = {"workload": "dry run of the %d-rank flow" % world, "name": args.config,
+               "collective": info.get("collective", "none (1 rank)") + " (dry run)"}
+        for k in ("ranks_reported_by_transport", "rccl_error", "transport_errors"):
+            if info.get(k) is not None:
+                cfg[k] = info[k]
         print(json.dumps({"metric": "MH steps/sec (all chains) + ESS/sec", "value": None, "unit": "MH steps/s", "dry_run": True,
                           "n_gpus": 0, "n_ranks": ranks, "distinct_processes": len(set(pids)), "steps": args.steps, "warmup": args.warmup,
                           "units_all_ranks": total, "ms_per_step": dt * 1e3 / max(1, args.steps), "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "none (dry run: no device, no engine)",
-                          "config": {"workload": "dry run of the %d-rank flow" % world, "name": args.config,
-                                     "collective": "gloo, %d ranks (dry run)" % ranks}}), flush=True)
+                          "config": cfg}), flush=True)
     if comm is not None:
         barrier()
         comm.dist.destroy_process_group()
     return 0
+
+
+class GroupWorkload:
+    """--single-process: N member contexts of ONE process behind mhx_group_* (N host threads inside libmhx.so); member i builds the
+    workload of rank i, the group drives them side by side.  Same interface as a workload for timed()."""
+
+    def __init__(self, mhx, args, dtype, devices):
+        self.g = mhx.Group(devices, dtype)
+        for k, v in args.opt:
+            self.g.set_option(k, v)
+        self.members = []
+        for i, ctx in enumerate(self.g.ctxs):
+            w = WORKLOADS[args.config](args, dtype)
+            w.build(mhx, ctx, i)
+            self.members.append(w)
+        self.g.attach([w.run for w in self.members])
+        self.first = self.members[0]
+        self.name, self.d = self.first.name, self.first.d
+
+    def step(self):
+        sc = self.first.sched()
+        self.g.sample(*sc[:4], save=sc[4])
+        return self.g.stats()
+
+    def units_per_step(self):
+        return sum(w.units_per_step() for w in self.members)
+
+    def bytes_per_launch(self):
+        return self.first.bytes_per_launch()          # per member: the roofline prices ONE device's kernel
+
+    def describe(self):
+        return self.first.describe()
+
+
+def rhat_block(diag, d, chains, window, transport):
+    """configs[4]: the R-hat of the whole sharded run from the all-reduced (or host-summed) between / within sums"""
+    import numpy as np
+    rh = np.asarray(diag["rhat"][:d], dtype=np.float64)
+    return {"max": sig(float(np.nanmax(rh))), "median": sig(float(np.nanmedian(rh))), "chains": int(chains),
+            "draws_per_chain": int(diag["n_samples"]), "window": window, "reduced_over": transport}
 
 
 def main():
@@ -847,10 +1064,20 @@ def main():
     ap.add_argument("--normal-gen", choices=["auto", "ziggurat", "box-muller"], default="auto",
                     help="c2 / c5: how the RWMH kernel turns stream bits into standard normals (auto: ziggurat in fp64, Box-Muller in fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--allow-gloo", action="store_true", help="--gpus > 1: the one-GPU rehearsal -- fewer devices than ranks are "
-                    "accepted (ranks share devices; n_gpus says how many were really opened) and the host-side all-reduces fall back to "
-                    "torch.distributed gloo when the RCCL communicator cannot be created (default: both are errors)")
-    ap.add_argument("--dry-run", action="store_true", help="launcher + rendezvous + host-side combining only: no device, no engine")
+    ap.add_argument("--allow-gloo", action="store_true", help="--gpus > 1: the one-GPU rehearsal -- fewer devices than ranks / members are "
+                    "accepted (they share devices; n_gpus says how many were really opened, the line says `oversubscribed`)")
+    ap.add_argument("--require-rccl", action="store_true", help="--gpus > 1: no transport ladder -- if the RCCL communicator behind the C ABI "
+                    "cannot be created on every rank the run fails instead of stepping down to torch's nccl backend / gloo")
+    ap.add_argument("--single-process", action="store_true", help="--gpus N as ONE process: N member contexts and N host threads behind the "
+                    "C ABI (mhx_group_*), statistics summed on the host -- no launcher, no collective library")
+    ap.add_argument("--bind", choices=["visible", "ordinal"], default="visible", help="our own launcher: visible = each rank sees only its "
+                    "device (HIP_VISIBLE_DEVICES, set before HIP initialises); ordinal = all devices visible, device LOCAL_RANK")
+    ap.add_argument("--transport-timeout", type=float, default=120.0, help="seconds a rung of the transport ladder may take (init + test all-reduce)")
+    ap.add_argument("--rendezvous-timeout", type=float, default=300.0, help="seconds to wait for every rank at the rendezvous")
+    ap.add_argument("--fault-rccl-init", choices=["fail", "hang"], default=None, help="test hook of the BENCH (not of the library): the first "
+                    "rung of the ladder fails / never answers")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="explicit engine option (mhx_ctx_set_option), repeatable")
+    ap.add_argument("--dry-run", action="store_true", help="launcher + rendezvous + ladder + host-side combining only: no device, no engine")
     ap.add_argument("--no-other-configs", action="store_true", help="c2 at N=1: skip the C3 / C4 / C4-moving / C5 lines under `configs`")
     ap.add_argument("--no-e2e", action="store_true", help="c2 at N=1: skip the rate through the boundary (samples back on the host)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="size of the CPU-baseline sample of the headline config")
@@ -859,9 +1086,14 @@ def main():
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
+    args.opt = [tuple(o.split("=", 1)) if "=" in o else (o, "1") for o in args.opt]
 
-    if "WORLD_SIZE" not in os.environ:
-        if args.gpus > 1:
+    single = args.single_process and args.gpus > 1
+    if "WORLD_SIZE" not in os.environ or single:
+        if single and "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
+            sys.stderr.write("bench.py --single-process under a launcher with WORLD_SIZE=%s: refusing (one process is the point)\n" % os.environ["WORLD_SIZE"])
+            sys.exit(2)
+        if args.gpus > 1 and not single:
             sys.exit(launch_ranks(args))                          # this process is the launcher
         rank, local_rank, world = 0, 0, 1
     else:
@@ -872,7 +1104,8 @@ def main():
             sys.stderr.write("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; refusing to run\n" % (args.gpus, world))
             sys.exit(2)
     if args.dry_run:
-        sys.exit(dry_run(args, rank, world))
+        rc = dry_run(args, rank, world)
+        leave(rc)
 
     import numpy as np
     import torch
@@ -883,16 +1116,29 @@ def main():
     if ndev < 1:
         sys.stderr.write("bench.py: no GPU visible (the engine has no CPU path); --dry-run rehearses the launch without one\n")
         sys.exit(2)
-    if ndev < world and not args.allow_gloo:
+    bound = os.environ.get("MHX_BENCH_BOUND") == "1"             # our launcher made this rank's device the only visible one
+    need = args.gpus if single else (1 if bound else world)
+    if ndev < need and not args.allow_gloo:
         sys.stderr.write("bench.py --gpus %d: %d device(s) visible to rank %d; refusing (ranks would share a GPU). --allow-gloo accepts it "
                          "as a rehearsal\n" % (args.gpus, ndev, rank))
         sys.exit(2)
-    device = local_rank % ndev                                   # (several ranks on one device only in the --allow-gloo rehearsal)
+    device = 0 if bound else local_rank % ndev                   # (several ranks on one device only in the --allow-gloo rehearsal)
     torch.cuda.set_device(device)
     ctx = mhx.Context(device, args.dtype)
-    comm, collective, ranks_reported = None, None, 1
+    for k, v in args.opt:
+        ctx.set_option(k, v)
+    comm, info = None, {}
+    collective = None
     if world > 1 or os.environ.get("MHX_BENCH_FORCE_DIST"):      # the env knob exercises the collective path on 1 GPU
-        comm, collective, ranks_reported = make_collective(ctx, rank, world, args.allow_gloo)
+        try:
+            comm, info = make_collective(ctx, rank, world, args, device)
+            collective = info["collective"]
+        except Exception as e:
+            if args.require_rccl:
+                raise
+            # not even the rendezvous: this rank reports alone rather than not at all
+            info = {"collective": "none: %s" % str(e)[:200], "ranks_reported_by_transport": 1, "rendezvous_error": str(e)[:300]}
+            collective = info["collective"]
 
     def barrier():
         torch.cuda.synchronize()
@@ -900,73 +1146,108 @@ def main():
             comm.allreduce_sum(np.zeros(1))                      # every rank has arrived
             torch.cuda.synchronize()
 
-    # the devices the ranks REALLY opened: n_gpus of the line is their number, not the flag
-    n_gpus = 1
-    if comm is not None:
-        ids = np.zeros(world)
-        ids[rank] = 1 + device
-        n_gpus = len(set(int(round(v)) for v in comm.allreduce_sum(ids)))
-        if n_gpus != world and not args.allow_gloo:
-            sys.stderr.write("bench.py --gpus %d: the %d ranks opened %d distinct device(s)\n" % (args.gpus, world, n_gpus))
-            sys.exit(2)
-
-    wl = WORKLOADS[args.config](args, args.dtype)
-    wl.build(mhx, ctx, rank)
+    if single:
+        devs = [i % ndev for i in range(args.gpus)]
+        wl = GroupWorkload(mhx, args, args.dtype, devs)
+        bus = wl.g.pci_bus_ids()
+        n_gpus = len(set(bus))
+        collective = "single process: %d host threads behind mhx_group_*, host sum of the statistics" % args.gpus
+    else:
+        # the devices the ranks REALLY opened, by PCI bus id (ordinals depend on HIP_VISIBLE_DEVICES): n_gpus is their number
+        n_gpus = 1
+        if comm is not None:
+            ids = np.zeros(world)
+            ids[rank] = float(pci_number(ctx.pci_bus_id()))
+            n_gpus = len(set(int(round(v)) for v in comm.allreduce_sum(ids)))
+            if n_gpus != world and not args.allow_gloo:
+                sys.stderr.write("bench.py --gpus %d: the %d ranks opened %d distinct device(s)\n" % (args.gpus, world, n_gpus))
+                leave(2)
+        wl = WORKLOADS[args.config](args, args.dtype)
+        wl.build(mhx, ctx, rank)
     dt, kernel_ms, accepted, transitions, st = timed(wl, args.steps, args.warmup, barrier)
 
     # outside the timed region: diagnostics, the ESS window, the fp32 figure, the CPU baseline
     ess, diag = None, None
+    chains_all = None
     if args.config in ("c2", "c5"):
-        diag = wl.run.diagnostics(max_lag=0)
+        if single:
+            diag = wl.g.diagnostics(max_lag=0)                   # the members' sums added on the host
+            chains_all = diag["n_chains"]
+        else:
+            diag = wl.run.diagnostics(max_lag=0)
     if comm is not None:
         t = np.zeros(world)
         t[rank] = dt
         dt = float(comm.allreduce_sum(t).max())                  # MAX over ranks of the timed region
         if diag is not None:
-            diag = allreduce_stats(diag, accepted, transitions, comm=comm)       # ONE all-reduce: RCCL over xGMI through the C ABI
+            diag = allreduce_stats(diag, accepted, transitions, comm=comm)       # ONE all-reduce of 3(d+1)+3 doubles
             acc_rate = diag["acceptance_rate"]
+            chains_all = diag["n_chains"]
         else:
             v = comm.allreduce_sum(np.array([float(accepted), float(transitions)]))
             acc_rate = v[0] / v[1]
     else:
         acc_rate = accepted / float(transitions)
-    if args.config == "c2" and not args.no_ess and not args.c2_literal and not args.c2_user and rank == 0 and world == 1:
+    lone = world == 1 and not single
+    if args.config == "c2" and not args.no_ess and not args.c2_literal and not args.c2_user and rank == 0 and lone:
         try:
             ess = ess_window(mhx, wl, world)
         except Exception as e:                                   # never let a diagnostic break the bench line
             ess = {"error": str(e)[:160]}
 
     if rank == 0:
-        units = float(wl.units_per_step()) * args.steps * world
+        reporting = info.get("ranks_reported_by_transport", 1) if comm is None and world > 1 else world
+        units = float(wl.units_per_step()) * args.steps * (1 if single else reporting)
         value = units / dt
         out = {
             "metric": "MH steps/sec (all chains) + ESS/sec", "value": value, "unit": "MH steps/s",
             "n_gpus": n_gpus, "n_ranks": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": config_block(wl, args.config, st, collective),
+            "config": config_block(wl.first if single else wl, args.config, st, collective),
             "acceptance_rate": sig(acc_rate, 4),
             "roofline": roofline_block(wl, args.config, args.dtype, kernel_ms, args.steps, st),
         }
-        if comm is not None:
-            out["config"]["ranks_reported_by_transport"] = ranks_reported
-            if n_gpus != world:
+        if single:
+            out["n_members"] = args.gpus
+            out["config"]["members"] = "%d member contexts on devices %s (PCI %s)" % (args.gpus, devs, sorted(set(bus)))
+            if n_gpus != args.gpus:
+                out["oversubscribed"] = "%d members share %d device(s): a rehearsal of the flow, not a scaling point" % (args.gpus, n_gpus)
+        if world > 1:
+            for k in ("ranks_reported_by_transport", "rccl_error", "transport_errors", "rendezvous_error"):
+                if info.get(k) is not None:
+                    out["config"][k] = info[k]
+            out["config"]["binding"] = "HIP_VISIBLE_DEVICES per rank (set by the launcher before HIP initialised)" if bound else "all devices visible, device = LOCAL_RANK"
+            if comm is None:
+                out["ranks_in_value"] = 1
+            if n_gpus != world and comm is not None:
                 out["oversubscribed"] = "%d ranks share %d device(s): a rehearsal of the flow, not a scaling point" % (world, n_gpus)
+        if args.opt:
+            out["config"]["options"] = dict(args.opt)
+        if st.get("tainted"):
+            out["tainted"] = "a probe option of the tools build was set: NOT a valid measurement of the chains"
         if ess is not None:
             out["ess_per_sec"] = ess.get("ess_per_sec")
             out["ess"] = ess
         if diag is not None:
+            if args.config == "c5":
+                # configs[4]: the R-hat of the whole sharded run (262 144 chains at 8 x 32 768), reduced over the transport above
+                sc = (wl.first if single else wl).sched()
+                out["rhat"] = rhat_block(diag, wl.d, chains_all or diag["n_chains"],
+                                         "last timed launch: %d states per chain, %d transitions apart" % (sc[0], sc[2]), collective or "one rank")
             # the all-reduced between / within statistic of the LAST timed launch only (consecutive transitions, shorter than one
             # autocorrelation time at d = 100): it exercises the collective, it is not a convergence claim -- see ess.rhat_max_split
             out["rhat_last_launch"] = sig(float(np.nanmax(diag["rhat"][:wl.d])))
-        if world == 1 and args.config == "c2" and not args.no_e2e and not args.c2_literal and not args.c2_user:
+        if lone and args.config == "c2" and not args.no_e2e and not args.c2_literal and not args.c2_user:
             try:
                 out["e2e_host"] = e2e_host(mhx, wl)
             except Exception as e:
                 out["e2e_host"] = {"error": str(e)[:160]}
-        if world == 1 and not args.no_second_dtype and args.dtype == "f64":
+        if lone and not args.no_second_dtype and args.dtype == "f64":
             try:                                                  # the same workload on the fp32 engine: a second figure, never `value`
                 ctx32 = mhx.Context(device, "f32")
+                for k, v in args.opt:
+                    ctx32.set_option(k, v)
                 wl32 = WORKLOADS[args.config](args, "f32")
                 wl32.build(mhx, ctx32, rank)
                 n32 = max(5, args.steps // 2)
@@ -977,9 +1258,9 @@ def main():
                 wl32.run.close()
             except Exception as e:
                 out["f32"] = {"error": str(e)[:160]}
-        if world == 1 and not args.no_cpu_baseline:
+        if lone and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, args.dtype, args.cpu_seconds)
-        if world == 1 and args.config == "c2" and not args.no_other_configs and not args.c2_literal and not args.c2_user:
+        if lone and args.config == "c2" and not args.no_other_configs and not args.c2_literal and not args.c2_user:
             wl.run.close()                                        # 13.4 GB of samples: C4 needs the room
             out["configs"] = other_configs(mhx, ctx, args, barrier)
         line = json.dumps(out, separators=(",", ":"))
@@ -996,11 +1277,15 @@ def main():
             pass
         print(line, flush=True)
     if comm is not None:
-        barrier()
-        comm.close()
+        try:
+            barrier()
+            comm.close()
+        except Exception:
+            pass
         import torch.distributed as dist
-        if dist.is_initialized():
+        if dist.is_initialized() and not ABANDONED:
             dist.destroy_process_group()
+    leave(0)
 
 
 if __name__ == "__main__":

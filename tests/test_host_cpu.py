@@ -252,6 +252,73 @@ def test_bench_gpus_n_without_a_launcher_starts_n_ranks():
     assert "2 ranks" in line["config"]["collective"]
 
 
+@pytest.mark.parametrize("fault", ["fail", "hang"])
+def test_bench_transport_ladder_ends_in_a_line_when_rccl_init_fails_or_hangs(fault):
+    """the first contact with an N-GPU node must not end with NO line.  The bench's collectives are a ladder --
+    RCCL behind the C ABI, torch.distributed's nccl backend, gloo -- every rung under a deadline and agreed on by all ranks.  Here
+    rung 1 is made to fail / to never answer (--fault-rccl-init), rung 2 has no device (dry run): the flow ends on gloo, the line
+    is there, it says which transport carried it and why the others did not."""
+    rc, line, err = _run_bench(["--gpus", "2", "--dry-run", "--steps", "3", "--fault-rccl-init", fault, "--transport-timeout", "3"], timeout=240)
+    assert rc == 0, err
+    assert line is not None and line["n_ranks"] == 2 and line["distinct_processes"] == 2
+    cfg = line["config"]
+    assert cfg["collective"].startswith("gloo, 2 ranks") and cfg["ranks_reported_by_transport"] == 2
+    assert set(cfg["rccl_error"]) == {"rank0", "rank1"}
+    want = "injected failure" if fault == "fail" else "no answer within"
+    assert all(want in e for e in cfg["rccl_error"].values()), cfg["rccl_error"]
+    assert "torch.distributed nccl" in cfg["transport_errors"]
+
+
+def test_bench_require_rccl_turns_the_fallback_into_an_error():
+    rc, line, err = _run_bench(["--gpus", "2", "--dry-run", "--fault-rccl-init", "fail", "--require-rccl", "--transport-timeout", "3"], timeout=240)
+    assert rc != 0 and line is None and "--require-rccl" in err
+
+
+def test_bench_launcher_binds_each_rank_to_its_device_before_hip(tmp_path):
+    """launch_ranks: rank r gets HIP_VISIBLE_DEVICES = the r-th entry of the launcher's own list (so that HIP never sees the other
+    ranks' devices); --bind ordinal leaves the list alone.  Checked on the environment the children receive (no device needed)."""
+    import bench
+    import types
+    seen = []
+
+    class FakePopen:
+        def __init__(self, argv, env=None, stdout=None):
+            seen.append(env)
+
+        def poll(self):
+            return 0
+
+        def terminate(self):
+            pass
+    real_popen, real_vis = bench.subprocess.Popen, bench.visible_devices
+    bench.subprocess.Popen, bench.visible_devices = FakePopen, lambda: 4
+    old = os.environ.get("HIP_VISIBLE_DEVICES")
+    try:
+        os.environ["HIP_VISIBLE_DEVICES"] = "4,5,6,7"
+        args = types.SimpleNamespace(gpus=4, dry_run=False, allow_gloo=False, bind="visible")
+        assert bench.launch_ranks(args) == 0
+        assert [e["HIP_VISIBLE_DEVICES"] for e in seen] == ["4", "5", "6", "7"] and all(e["MHX_BENCH_BOUND"] == "1" for e in seen)
+        assert [e["RANK"] for e in seen] == ["0", "1", "2", "3"] and len({e["MASTER_PORT"] for e in seen}) == 1
+        del seen[:]
+        del os.environ["HIP_VISIBLE_DEVICES"]
+        assert bench.launch_ranks(args) == 0
+        assert [e["HIP_VISIBLE_DEVICES"] for e in seen] == ["0", "1", "2", "3"]
+        del seen[:]
+        args.bind = "ordinal"
+        assert bench.launch_ranks(args) == 0
+        assert all("HIP_VISIBLE_DEVICES" not in e and "MHX_BENCH_BOUND" not in e for e in seen)
+        del seen[:]
+        args.gpus = 8                                            # more ranks than devices: refused unless it is the rehearsal
+        assert bench.launch_ranks(args) == 2 and not seen
+    finally:
+        bench.subprocess.Popen, bench.visible_devices = real_popen, real_vis
+        if old is None:
+            os.environ.pop("HIP_VISIBLE_DEVICES", None)
+        else:
+            os.environ["HIP_VISIBLE_DEVICES"] = old
+    assert bench.pci_number("0000:05:00.0") != bench.pci_number("0000:15:00.0") and bench.pci_number("0000:05:00.0") == (5 << 8)
+
+
 def test_bench_under_a_launcher_is_one_rank_of_it():
     """the driver's form: python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2"""
     import subprocess
