@@ -65,7 +65,9 @@ end
 "a traced real number: node `i` of the graph being recorded"
 struct Traced <: Real
     i::Int
+    Traced(::Val{:node}, i::Int) = new(i)          # (no Traced(::Int): generic code that writes T(0) must get the LITERAL 0, see below)
 end
+tnode(i::Int) = Traced(Val(:node), i)
 
 # Python's float.hex(): sign, 0x1.<13 hex digits>p<signed exponent>; 0x0.0p+0; subnormals 0x0.<13 digits>p-1022
 function pyhex(v::Float64)
@@ -82,7 +84,7 @@ end
 
 lift(x::Traced) = x
 lift(x::Bool) = throw(TraceError("a condition is not a number"))
-lift(x::Real) = Traced(node!(graph(), (:c, pyhex(Float64(x)))))
+lift(x::Real) = tnode(node!(graph(), (:c, pyhex(Float64(x)))))
 
 Base.convert(::Type{Traced}, x::Traced) = x
 Base.convert(::Type{Traced}, x::Real) = lift(x)
@@ -99,20 +101,20 @@ Base.Float64(::Traced) = throw(TraceError("a traced number has no value while tr
 Base.show(io::IO, x::Traced) = print(io, "Traced(t", x.i, ")")
 
 # ---- arithmetic: ONE node per operation, operands lifted left to right (a literal is numbered when it is first used)
-bin(op::Symbol, a, b) = (x = lift(a); y = lift(b); Traced(node!(graph(), (op, x.i, y.i))))
+bin(op::Symbol, a, b) = (x = lift(a); y = lift(b); tnode(node!(graph(), (op, x.i, y.i))))
 for (f, op) in ((:+, :add), (:-, :sub), (:*, :mul), (:/, :div))
     @eval Base.$f(a::Traced, b::Traced) = bin($(QuoteNode(op)), a, b)
     @eval Base.$f(a::Traced, b::Real) = bin($(QuoteNode(op)), a, b)
     @eval Base.$f(a::Real, b::Traced) = bin($(QuoteNode(op)), a, b)
 end
-Base.:-(a::Traced) = Traced(node!(graph(), (:neg, a.i)))
+Base.:-(a::Traced) = tnode(node!(graph(), (:neg, a.i)))
 Base.:+(a::Traced) = a
 for f in (:log, :exp, :sqrt, :abs)
-    @eval Base.$f(a::Traced) = Traced(node!(graph(), ($(QuoteNode(f)), a.i)))
+    @eval Base.$f(a::Traced) = tnode(node!(graph(), ($(QuoteNode(f)), a.i)))
 end
 Base.abs2(a::Traced) = a * a
 Base.inv(a::Traced) = 1.0 / a
-Base.fma(a::Traced, b::Traced, c::Traced) = Traced(node!(graph(), (:fma, a.i, b.i, c.i)))
+Base.fma(a::Traced, b::Traced, c::Traced) = tnode(node!(graph(), (:fma, a.i, b.i, c.i)))
 Base.fma(a::Real, b::Real, c::Traced) = fma(lift(a), lift(b), c)
 Base.fma(a::Traced, b::Real, c::Real) = (x = a; y = lift(b); z = lift(c); fma(x, y, z))
 Base.fma(a::Real, b::Traced, c::Real) = (x = lift(a); y = b; z = lift(c); fma(x, y, z))
@@ -145,11 +147,11 @@ function decide(key::NodeKey)
     g.taken[key] = d
     return d
 end
-cmp(op::Symbol, a, b) = (x = lift(a); y = lift(b); decide((:cmp, op, x.i, y.i)))
+compare(op::Symbol, a, b) = (x = lift(a); y = lift(b); decide((:cmp, op, x.i, y.i)))
 for (f, op) in ((:<, :lt), (:<=, :le), (:>, :gt), (:>=, :ge), (:(==), :eq), (:!=, :ne))
-    @eval Base.$f(a::Traced, b::Traced) = cmp($(QuoteNode(op)), a, b)
-    @eval Base.$f(a::Traced, b::Real) = cmp($(QuoteNode(op)), a, b)
-    @eval Base.$f(a::Real, b::Traced) = cmp($(QuoteNode(op)), a, b)
+    @eval Base.$f(a::Traced, b::Traced) = compare($(QuoteNode(op)), a, b)
+    @eval Base.$f(a::Traced, b::Real) = compare($(QuoteNode(op)), a, b)
+    @eval Base.$f(a::Real, b::Traced) = compare($(QuoteNode(op)), a, b)
 end
 Base.isless(a::Traced, b::Traced) = a < b
 Base.isless(a::Traced, b::Real) = a < b
@@ -160,7 +162,7 @@ Base.isfinite(a::Traced) = abs(a) < Inf
 Base.iszero(a::Traced) = a == 0.0
 Base.signbit(a::Traced) = a < 0.0
 # min / max / ifelse as ONE select (no new path): cond ? a : b with both sides evaluated
-sel(key::NodeKey, a, b) = (x = lift(a); y = lift(b); Traced(node!(graph(), (:sel, key, x.i, y.i))))
+sel(key::NodeKey, a, b) = (x = lift(a); y = lift(b); tnode(node!(graph(), (:sel, key, x.i, y.i))))
 Base.min(a::Traced, b::Traced) = sel((:cmp, :lt, a.i, b.i), a, b)
 Base.max(a::Traced, b::Traced) = sel((:cmp, :gt, a.i, b.i), a, b)
 Base.min(a::Traced, b::Real) = min(a, lift(b))
@@ -271,7 +273,7 @@ function trace_logdensity(f, dim::Integer; max_paths::Integer = 64)
     CURRENT[] = g
     try
         node!(g, (:c, pyhex(0.0)))                                           # node 0, as in the Python tracer
-        θ = Traced[Traced(node!(g, (:x, k))) for k in 0:(dim - 1)]
+        θ = Traced[tnode(node!(g, (:x, k))) for k in 0:(dim - 1)]
         paths = NamedTuple{(:met, :dec, :out),Tuple{Vector{NodeKey},Vector{Bool},Int}}[]
         stack = Vector{Bool}[Bool[]]
         while !isempty(stack)
