@@ -595,7 +595,7 @@ def with_deadline(fn, seconds, what):
         try:
             box["v"] = fn()
         except BaseException as e:                                # noqa: BLE001 -- the error text goes into the line
-            box["e"] = "%s: %s" % (type(e).__name__, str(e)[:300])
+            box["e"] = ("%s: %s" % (type(e).__name__, " ".join(str(e).split())))[:220]
     t = threading.Thread(target=work, daemon=True)
     t.start()
     t.join(seconds)
@@ -683,7 +683,8 @@ def make_collective(ctx, rank, world, args, device=0):
         ok = agree(tr is not None)
         if ok:
             info = {"collective": "%s, %d ranks" % (name, tr.ranks()), "ranks_reported_by_transport": tr.ranks(),
-                    "rccl_error": errors.get("rccl(mhx_comm_*)"), "transport_errors": errors or None}
+                    "rccl_error": errors.get("rccl(mhx_comm_*)"),
+                    "transport_errors": {k: v for k, v in errors.items() if not k.startswith("rccl")} or None}
             return tr, info
         errs = gather_errors(err or ("another rank failed" if tr is not None else "failed"))
         errors[name] = errs
@@ -697,7 +698,8 @@ def make_collective(ctx, rank, world, args, device=0):
                                "created on every rank: %s" % (world, json.dumps(errs)))
     tr = GlooSum(dist)
     info = {"collective": "gloo, %d ranks (fallback: see rccl_error)" % tr.ranks(), "ranks_reported_by_transport": tr.ranks(),
-            "rccl_error": errors.get("rccl(mhx_comm_*)"), "transport_errors": errors or None}
+            "rccl_error": errors.get("rccl(mhx_comm_*)"),
+            "transport_errors": {k: v for k, v in errors.items() if not k.startswith("rccl")} or None}
     return tr, info
 
 
@@ -784,6 +786,15 @@ def pmc_of(wl, name, dtype):
     return tj if tj.get("units_per_launch") == wl.units_per_step() else {}
 
 
+def isa_mix_of(key, dtype):
+    """mean issue cycles per VALU instruction of the config's dominant kernel (tools/isa_mix.py: PMC class counts x the issue costs
+    tools/ubench/valu_rates.hip measured on this chip), or None when no count was taken"""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "isa_mix.json"))).get("%s_%s" % (key, dtype), {}).get("mean_cycles_per_valu_instruction")
+    except Exception:
+        return None
+
+
 def roofline_block(wl, key, dtype, kernel_ms, steps, st):
     """The dominant kernel against its bound.  HBM-bound configs: algorithmic bytes per step over the
     HIP-event time of the step's launches measured here.  C5 keeps its state in registers for a whole launch and is bound by VALU
@@ -796,14 +807,19 @@ def roofline_block(wl, key, dtype, kernel_ms, steps, st):
     tj = pmc_of(wl, key, dtype)
     traffic = tj.get("hbm_bytes_per_launch")
     valu_frac = tj["valu_insts_per_launch"] / launch_s / VALU_PEAK if tj.get("valu_insts_per_launch") else None
+    # the same instructions priced by their class (2 cycles is the cheapest class: fp64, 32-bit multiplies, v_bitop3, 64-bit mads
+    # cost more): issue cycles the launch NEEDED over the cycles it HAD -- counted, not assumed (tools/isa_mix.py)
+    cpi = isa_mix_of(key, dtype)
+    weighted = valu_frac * cpi / 2.0 if valu_frac is not None and cpi else None
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
            "traffic": traffic, "avg_launch_ms": launch_s * 1e3 / launches, "algorithmic_bytes_per_step": bytes_launch,
-           "valu_frac": sig(valu_frac, 4)}
+           "valu_frac": sig(valu_frac, 4), "valu_weighted_frac": sig(weighted, 4)}
     if wl.name == "c5" and valu_frac is not None:
         out = {"bound": "valu", "achieved": tj["valu_insts_per_launch"] / launch_s, "peak": VALU_PEAK, "unit": "wave-inst/s",
                "frac": valu_frac, "traffic": traffic, "avg_launch_ms": launch_s * 1e3 / launches,
                "valu_insts_per_step": tj["valu_insts_per_launch"], "algorithmic_bytes_per_step": bytes_launch,
-               "hbm_frac": sig(achieved / HBM_PEAK_GBS, 4)}
+               "hbm_frac": sig(achieved / HBM_PEAK_GBS, 4), "valu_weighted_frac": sig(weighted, 4),
+               "issue_cycles_per_valu_inst": sig(cpi, 4)}
     return out
 
 
@@ -834,8 +850,7 @@ def other_configs(mhx, ctx, args, barrier):
                    "launch_us": sig(rf["avg_launch_ms"] * 1e3, 4), "kernel": kernel_name(w, st), "lanes": st["reduce_lanes"]}
             if rf["bound"] == "valu":
                 blk["hbm_frac"] = rf["hbm_frac"]
-                # fp64, 32-bit multiplies and v_bitop3_b32 -- this kernel's instructions -- issue over 4 cycles, not 2 (r02a_valu_rates.log)
-                blk["frac_4cycle_class"] = sig(2.0 * rf["frac"], 4)
+                blk["valu_weighted_frac"] = rf.get("valu_weighted_frac")     # class-weighted issue bound (tools/isa_mix.py), None until counted
             if st.get("factor_band", -1) >= 0:
                 blk["band"] = st["factor_band"]
             w.run.close()

@@ -104,6 +104,20 @@ run_chains("rwmh_given_start", DensityModel(iso_gauss(3)), RWMH(MvNormal(zeros(3
 # the engine's ziggurat normals (MHX_FLAG_ZIGGURAT): 64 chains x 48 transitions x 8 normals = 2.5e4 draws, ~100 through the slow paths
 run_chains("rwmh_iso_ziggurat", DensityModel(iso_gauss(8)), RWMH(MvNormal(zeros(8), 0.6^2 * I)), 48, 15, 7, 64, 8; ziggurat = true)
 
+# README.md:25-40 AS WRITTEN -- a closure over data with a branch on a parameter (what MCMCHIP() traces and JIT-lowers; here the
+# reference runs it itself): the first 30 points of tests/golden/c1_normal_data.npy
+let data = parse.(Float64, split(strip(read(joinpath(@__DIR__, "..", "golden", "c1_normal_data_30.txt"), String))))
+    insupport(θ) = θ[2] >= 0
+    dist(θ) = Normal(θ[1], θ[2])
+    density(θ) = insupport(θ) ? sum(logpdf.(dist(θ), data)) : -Inf
+    run_chains("rwmh_readme", DensityModel(density), RWMH(MvNormal(zeros(2), I)), 64, 18, 0, 4, 2; initial_params = [0.0, 1.0])
+end
+# a USER log-density at d = 100 on the ziggurat normals (on the device: the register kernel's ziggurat form, one lane per chain)
+let d = 100, μ = [(k - 50.0) / 64.0 for k in 0:99], σ = [0.5 + (k % 8) / 8.0 for k in 0:99]
+    shifted(θ) = -0.5 * sum(abs2, (θ .- μ) ./ σ)
+    run_chains("rwmh_user_ziggurat", DensityModel(shifted), RWMH(MvNormal(zeros(d), 0.25^2 * I)), 24, 19, 5, 8, d; ziggurat = true)
+end
+
 # a drifting random walk (non-zero proposal mean: the Hastings ratio of src/proposal.jl:58-64,190-192 is not zero) and an independence
 # sampler (StaticMH: src/proposal.jl:9-11,66-83); Distributions' logpdf rounds differently from the engine's ratio, the accept-margin
 # logic of tests/test_julia_reference_traces.py absorbs that

@@ -34,6 +34,29 @@ def _rwmh_iso_ziggurat(O):
     return O.traced(O.rwmh, O.iso_gauss(8), O.Proposal(O.PROP_ISO, 0.6, normal_gen=1), O.schedule(48), 15, 7, 64)
 
 
+def _rwmh_readme(O):
+    """README.md:25-40 as written: DensityModel(density) over 30 data points (the first 30 of tests/golden/c1_normal_data.npy), RWMH(MvNormal(zeros(2), I))"""
+    import os
+    data = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c1_normal_data.npy"))[:30].astype(np.float64)
+    init = np.repeat(np.array([[0.0], [1.0]]), 4, axis=1)
+    return O.traced(O.rwmh, O.Target(O.TARGET_IID_NORMAL, 2, params=data), O.Proposal(O.PROP_ISO, 1.0), O.schedule(64), 18, 0, 4, init=init)
+
+
+def user_gauss_data(d=100):
+    """per-dimension mean / standard deviation of the user log-density case: exact binary fractions (the Julia script writes the same)"""
+    k = np.arange(d, dtype=np.float64)
+    return np.concatenate([(k - 50.0) / 64.0, 0.5 + (k % 8.0) / 8.0])
+
+
+def _rwmh_user_ziggurat(O):
+    """a USER log-density (DensityModel(f), not a catalogue target) at d = 100 with the ziggurat normals -- on the device this is the
+    register kernel's ziggurat form (round 4), one lane per chain: reduction shape 1, the plain ascending sum"""
+    import user_targets
+    d = 100
+    ut = user_targets.host_target(O, user_targets.SHIFTED_GAUSS, d, data=user_gauss_data(d))
+    return O.traced(O.rwmh, ut, O.Proposal(O.PROP_ISO, 0.25, normal_gen=1), O.schedule(24), 19, 5, 8)
+
+
 _MU = np.array([0.3, -0.2, 0.1, 0.25])
 
 
@@ -78,6 +101,7 @@ def _emcee_seq(O):
 
 JULIA_CASES = {
     "rwmh_iso": _rwmh_iso, "rwmh_dense_corr": _rwmh_dense_corr, "rwmh_funnel": _rwmh_funnel, "rwmh_banana": _rwmh_banana,
-    "rwmh_given_start": _rwmh_given_start, "rwmh_iso_ziggurat": _rwmh_iso_ziggurat, "rwmh_drift": _rwmh_drift, "rwmh_static": _rwmh_static, "ram": _ram, "ram_random_start": _ram_random_start, "ram_bounds": _ram_bounds,
+    "rwmh_given_start": _rwmh_given_start, "rwmh_iso_ziggurat": _rwmh_iso_ziggurat, "rwmh_readme": _rwmh_readme,
+    "rwmh_user_ziggurat": _rwmh_user_ziggurat, "rwmh_drift": _rwmh_drift, "rwmh_static": _rwmh_static, "ram": _ram, "ram_random_start": _ram_random_start, "ram_bounds": _ram_bounds,
     "mala_iso": _mala_iso, "mala_corr": _mala_corr, "emcee_seq": _emcee_seq,
 }
