@@ -12,6 +12,7 @@
 // Compile-time dimension (hiprtc, d <= 48): all five vectors are registers (mhx_mala_reg_body).
 #pragma once
 #include "mhx_targets.h"
+#include "mhx_rwmh_kernels.h"      // mhx_reg_zig_fill: the register-array ziggurat of MHX_FLAG_ZIGGURAT (fp64)
 
 MHX_NS_BEGIN
 
@@ -459,15 +460,34 @@ struct mhx_reg_rw {
 // state, its gradient and the step's noise are touched once per step each -- their first XR coordinates stay in registers, the tails
 // live in the block's LDS as [3][D - XR][lane] (one wave per block).  Carries the kernel from d = 24 / 48 (fp64 / fp32) to 64 / 128;
 // the run-time-dimension kernel it replaces there is 10-20 x slower (tools/bench_mala_user.py).  Same arithmetic, same chains.
-template <int D, int TK, int XR = D>
-MHX_DEV void mhx_mala_reg_body(const mhx_mala_args& a, const mhx_real* __restrict__ tparams, mhx_real* tails = nullptr)
+// ZIG (round 5, fp64; MHX_FLAG_ZIGGURAT on a MALA run): the step's noise by the table ziggurat instead of Box-Muller -- the same
+// register-array fill as the RWMH register kernel's (mhx_reg_zig_fill: fast path into the candidate's registers, the wave-step's
+// failures queued, refined side by side, handed back), so every lane of the one-wave block stays alive (idle lanes shadow the last
+// chain, stores guarded) and `zlds` holds [layer table][queue][results] in front of the tails.  The oracle's orc_mala(normal_gen = 1).
+template <int D, int TK, int XR = D, bool ZIG = false>
+MHX_DEV void mhx_mala_reg_body(const mhx_mala_args& a, const mhx_real* __restrict__ tparams, mhx_real* tails = nullptr,
+                               double* zlds = nullptr)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    static_assert(!ZIG || MHX_REAL64, "the ziggurat generator exists in the fp64 engine only");
+    const int c_raw = blockIdx.x * blockDim.x + threadIdx.x;
     constexpr int NT = D - XR;                                       // coordinates per vector in LDS
     mhx_real* xl = tails + threadIdx.x;                              // [NT][64], then g, then z
     mhx_real* gl = xl + NT * 64;
     mhx_real* zl = gl + NT * 64;
-    if (c >= a.nchains) return;
+    const bool valid = c_raw < a.nchains;
+    if (!ZIG && !valid) return;
+    const int c = valid ? c_raw : a.nchains - 1;                     // (ZIG: the queue and the hand-back are wave-wide)
+#if MHX_REAL64
+    [[maybe_unused]] const double* zt = zlds;
+    [[maybe_unused]] unsigned short* zq = (unsigned short*)(zlds + MHX_ZIG_TABLE_BYTES / 8);
+    [[maybe_unused]] double* zres = zlds + MHX_ZIG_TABLE_BYTES / 8 + 16;
+    [[maybe_unused]] mhx_u32 zsign = 0x80000000u;
+    if constexpr (ZIG) {
+        for (int e = (int)threadIdx.x; e <= MHX_ZIG_N; e += 64) zlds[e] = mhx_zig_x[e];
+        __syncthreads();
+        asm volatile("" : "+s"(zsign));
+    }
+#endif
     const mhx_u64 id = a.first_chain + (mhx_u64)c;
     const mhx_u32 id_lo = (mhx_u32)id, id_hi = (mhx_u32)(id >> 32);
     const mhx_philox_key ks = mhx_philox_schedule(a.seed);
@@ -498,6 +518,20 @@ MHX_DEV void mhx_mala_reg_body(const mhx_mala_args& a, const mhx_real* __restric
     for (int it = 0; it < a.nsteps; ++it) {
         const mhx_u32 step = a.step0 + (mhx_u32)it;
         mhx_real fwd = MHX_R(0.0);
+#if MHX_REAL64
+        if constexpr (ZIG) {
+            mhx_reg_zig_fill<D>(y, ks, id_lo, id_hi, step, MHX_STREAM_PROPOSAL, zt, zq, zres, (int)threadIdx.x, (long)blockIdx.x * 64,
+                                a.first_chain, a.nchains, zsign);
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                const mhx_real nk = y[k];
+                if (k < XR) z[k < XR ? k : 0] = nk; else zl[(k - XR) * 64] = nk;
+                y[k] = mhx_fma(a.sigma, nk, mhx_fma(a.h, getg(k), getx(k)));            // src/MALA.jl:70
+                fwd = mhx_fma(nk, nk, fwd);
+            }
+        } else
+#endif
+        {
 #pragma unroll
         for (int b = 0; b < nblk; ++b) {
             mhx_real n[4];
@@ -511,6 +545,7 @@ MHX_DEV void mhx_mala_reg_body(const mhx_mala_args& a, const mhx_real* __restric
                     fwd = mhx_fma(n[j], n[j], fwd);
                 }
             }
+        }
         }
         const mhx_real lpy = mhx_target_grad<TK>(TK, y, gy, D, tparams, a.ntparams, a.tconst);   // :73-75
         mhx_real bwd = MHX_R(0.0);
@@ -530,31 +565,35 @@ MHX_DEV void mhx_mala_reg_body(const mhx_mala_args& a, const mhx_real* __restric
         lp = acc ? lpy : lp;
         nacc += acc ? 1u : 0u;
         last = acc;
-        wave_acc += (mhx_u32)__popcll(__ballot(acc));
+        wave_acc += (mhx_u32)__popcll(__ballot(acc && valid));
         if (step == save_next) {
             mhx_real* row = a.samples + slot * (long)(D + 1) * ld + c;
-            {   // (buffer descriptor + running scalar row offset behind an opaque asm: MHX_COOP_REC_RUN in mhx_rwmh_kernels.h)
+            if (valid) {   // (buffer descriptor + running scalar row offset behind an opaque asm: MHX_COOP_REC_RUN in mhx_rwmh_kernels.h)
                 const mhx_srd srd = mhx_make_srd(a.samples + slot * (long)(D + 1) * ld, (mhx_u32)(D + 1) * (mhx_u32)ld * MHX_RB);
                 const mhx_u32 ldb = (mhx_u32)ld * MHX_RB, loff = (mhx_u32)c * MHX_RB;
                 mhx_u32 roff = 0u;
                 asm volatile("" : "+s"(roff));
 #pragma unroll
                 for (int k = 0; k < D; ++k) { mhx_srd_store<MHX_REC_STORE_AUX>(srd, loff, roff, getx(k)); roff += ldb; }
+                row[(long)D * ld] = lp;
+                a.accepted[slot * ld + c] = acc ? 1 : 0;
             }
-            row[(long)D * ld] = lp;
-            a.accepted[slot * ld + c] = acc ? 1 : 0;
             save_next += (mhx_u32)a.thinning;
             ++slot;
         }
     }
+    if (valid) {
 #pragma unroll
-    for (int k = 0; k < D; ++k) { a.x[(long)k * ld + c] = getx(k); a.gx[(long)k * ld + c] = getg(k); }
-    a.lp[c] = lp;
-    a.acc_count[c] = nacc;
-    a.last_acc[c] = last ? 1 : 0;
+        for (int k = 0; k < D; ++k) { a.x[(long)k * ld + c] = getx(k); a.gx[(long)k * ld + c] = getg(k); }
+        a.lp[c] = lp;
+        a.acc_count[c] = nacc;
+        a.last_acc[c] = last ? 1 : 0;
+    }
     if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u)
         atomicAdd(a.acc_total, (mhx_u64)wave_acc);
 }
+
+#define MHX_MALA_ZIG_LDS_BYTES(D, XR) ((size_t)3 * ((D) - (XR)) * 64 * 8 + MHX_ZIG_TABLE_BYTES_ANY + 128 + 512)
 
 // initial GradientTransition (src/MALA.jl:38-40): lp and gradient at the given initial_params
 template <int TK>
@@ -587,6 +626,18 @@ mhx_jit_mala_split(const mhx_mala_args a, const mhx_real* __restrict__ tparams)
 {
     extern __shared__ mhx_real mhx_mala_tails[];               // [3][MHX_JIT_DIM - MHX_JIT_XR][64]
     mhx_mala_reg_body<MHX_JIT_DIM, MHX_JIT_TK, MHX_JIT_XR>(a, tparams, mhx_mala_tails);
+}
+#endif
+#if MHX_REAL64 && defined(MHX_JIT_GEN) && MHX_JIT_GEN == 1 && MHX_JIT_DIM > 0
+// MHX_FLAG_ZIGGURAT: the register kernel with the ziggurat noise, one wave per block; LDS = [table][queue][results][tails]
+#ifndef MHX_JIT_XR
+#define MHX_JIT_XR MHX_JIT_DIM
+#endif
+extern "C" __global__ void __launch_bounds__(64)
+mhx_jit_mala_zig(const mhx_mala_args a, const mhx_real* __restrict__ tparams)
+{
+    extern __shared__ double mhx_mala_zig_lds[];               // MHX_MALA_ZIG_LDS_BYTES(MHX_JIT_DIM, MHX_JIT_XR)
+    mhx_mala_reg_body<MHX_JIT_DIM, MHX_JIT_TK, MHX_JIT_XR, true>(a, tparams, mhx_mala_zig_lds + MHX_ZIG_TABLE_BYTES / 8 + 16 + 64, mhx_mala_zig_lds);
 }
 #endif
 extern "C" __global__ void __launch_bounds__(256)

@@ -466,6 +466,132 @@ MHX_DEV void mhx_zig_fixup(const mhx_philox_key& ks, const double* __restrict__ 
 #endif
 
 #if MHX_REAL64
+// The D standard normals of (chain, step, stream) by the table ziggurat into a lane's REGISTER array y (lane per chain, every lane of
+// the wave alive): phase A writes every fast-path normal into y[n] and notes the failures in a per-lane bit mask; the failures of
+// the whole wave-step are queued, refined side by side by as many lanes (which leave the values in LDS by queue position), and every
+// owner walks its failures once more and takes the round's value where the slot number says so.  Used by the register kernels of
+// RWMH (mhx_rwmh_reg_zig_body) and MALA (mhx_mala_reg_body<.., ZIG>): the normals of mhx_zig_normal / orc_zig_normal.
+// zt: the layer table in LDS (offset 0), zq: 64 queue entries, zres: 64 refined values; chain_base: the chain of lane 0.
+template <int D>
+MHX_DEV void mhx_reg_zig_fill(double (&y)[D], const mhx_philox_key& ks, const mhx_u32 id_lo, const mhx_u32 id_hi, const mhx_u32 step,
+                              const mhx_u32 stream, const double* __restrict__ zt, unsigned short* __restrict__ zq,
+                              double* __restrict__ zres, const int lane, const long chain_base, const mhx_u64 first_chain,
+                              const int nchains, const mhx_u32 zsign)
+{
+    constexpr int NW = (D + 63) / 64;                          // words of the failure mask
+    // ---- phase A: normal n of the step from Philox block n >> 1 (words x, y / z, w), fast path; failures noted
+    // (the chain id behind an empty asm: otherwise hipcc hoists the id-only first round and a half of all D / 2 Philox calls out
+    // of the step loop -- 150 registers it does not have: they go to scratch memory and come back every step)
+    mhx_u32 idl = id_lo, idh = id_hi;
+    asm volatile("" : "+v"(idl), "+v"(idh));
+    mhx_u64 fmw[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) fmw[w] = 0ull;
+    // Software pipeline over the Philox blocks: the table look-ups of block p are in flight while the rounds of block p + 1 run
+    // (one wave per SIMD has nothing else to hide an LDS round trip behind; straight after each other the look-ups cost a
+    // quarter of the kernel: 100 x ~100 cycles per wave-step)
+    constexpr int NP = (D + 1) / 2;
+    mhx_u32x4 w4 = mhx_philox(ks, idl, idh, step, (stream << 28) | 0u);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        typedef double mhx_d2 __attribute__((ext_vector_type(2)));
+        mhx_d2 xe[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const mhx_u32 ly = (h ? w4.w : w4.y) & (mhx_u32)(MHX_ZIG_N - 1);
+            xe[h].x = zt[ly]; xe[h].y = zt[ly + 1];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mhx_u32x4 wn = w4;
+        if (p + 1 < NP) wn = mhx_philox(ks, idl, idh, step, (stream << 28) | (mhx_u32)(p + 1));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int n = 2 * p + h;
+            if (n < D) {
+                const mhx_u32 hi = h ? w4.z : w4.x, lo = h ? w4.w : w4.y;
+                const double ax = mhx_zig_ax(hi, lo, xe[h].x);
+                y[n] = mhx_zig_signed(ax, lo, zsign);
+                const bool fail = !(ax < xe[h].y);
+                fmw[n >> 6] |= (fail ? 1ull : 0ull) << (n & 63);
+            }
+        }
+        w4 = wn;
+    }
+    // ---- the wave-step's failures: queue, refine side by side, hand back
+    bool anyfail = false;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) anyfail = anyfail || fmw[w] != 0ull;
+    if (__ballot(anyfail)) {
+        int total = 0;
+        for (int win = 0; win == 0 || win < total; win += 64) {
+            int base = -win;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                mhx_u64 f = fmw[w];
+                for (;;) {
+                    const mhx_u64 m = __ballot(f != 0ull);
+                    if (m == 0ull) break;
+                    if (f != 0ull) {
+                        const int e = base + (int)__builtin_amdgcn_mbcnt_hi((mhx_u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((mhx_u32)m, 0u));
+                        const int sl = 64 * w + __ffsll((long long)f) - 1;
+                        if (e >= 0 && e < 64) zq[e] = (unsigned short)(lane | (sl << 6));
+                    }
+                    f &= f - 1ull;
+                    base += __popcll(m);
+                }
+            }
+            total = base + win;
+            MHX_WAVE_SYNC();
+            const int nent = total - win < 64 ? total - win : 64;
+            mhx_u32 ent = 0u;
+            double val = 0.0;
+            if (lane < nent) {
+                ent = zq[lane];
+                const int ol = (int)(ent & 63u);
+                const long oc_raw = chain_base + ol;
+                const mhx_u64 oid = first_chain + (mhx_u64)(oc_raw < nchains ? oc_raw : (long)nchains - 1);
+                val = mhx_zig_refine(ks, zt, (mhx_u32)oid, (mhx_u32)(oid >> 32), step, stream, ent >> 6);
+            }
+            if (lane < nent) zres[lane] = val;
+            MHX_WAVE_SYNC();
+            // back to the owners: the same walk as the queue's -- a lane's r-th failure of word w sits at the position it was
+            // given there -- and every register of the word takes the value where the slot number says so: straight-line
+            // compare + select per register and round (a wave-uniform branch per failure into one of D registers costs
+            // hipcc's allocator a copy of the whole candidate per iteration; a run-time index sends the array to scratch)
+            base = -win;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                mhx_u64 f = fmw[w];
+                for (;;) {
+                    const mhx_u64 m = __ballot(f != 0ull);
+                    if (m == 0ull) break;
+                    const int e = base + (int)__builtin_amdgcn_mbcnt_hi((mhx_u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((mhx_u32)m, 0u));
+                    const bool has = f != 0ull && e >= 0 && e < 64;
+                    int sls = has ? __ffsll((long long)f) - 1 : -1;
+                    asm volatile("" : "+v"(sls));          // (else hipcc splits the test into `has` AND a compare: 5 instructions per register for 3)
+                    const double pv = zres[has ? e : 0];
+                    // (skipping a block of 8 registers when no lane's slot lies in it was measured: 3.35 against 3.25 ms per launch at
+                    // c2_user -- the ballots and branches cost more than the skipped selects)
+#pragma unroll
+                    for (int blk = 0; blk < 8; ++blk) {
+                        if (64 * w + 8 * blk < D) {
+#pragma unroll
+                            for (int b = 8 * blk; b < 8 * blk + 8; ++b)
+                                if (64 * w + b < D) y[64 * w + b] = sls == b ? pv : y[64 * w + b];
+                        }
+                    }
+                    f &= f - 1ull;
+                    base += __popcll(m);
+                }
+            }
+            MHX_WAVE_SYNC();                               // (the next window writes the queue and the results again)
+        }
+    }
+}
+#endif
+
+#if MHX_REAL64
 // ---------------------------------------------------------------------------------------------
 // The register kernel (lane per chain, any target incl. a user's HIP source) with the ZIGGURAT generator (round 4, second
 // session).  Box-Muller is 3/5 of that kernel's instructions (~73 per normal against ~25 for Philox + table fast path); what kept
@@ -484,7 +610,6 @@ MHX_DEV void mhx_rwmh_reg_zig_body(const mhx_rwmh_args& a, const mhx_real* __res
                                    const mhx_real* __restrict__ pvec, double* __restrict__ lds)
 {
     static_assert(PK != MHX_PROP_DENSE, "ISO / DIAG proposals");
-    constexpr int NW = (D + 63) / 64;                          // words of the failure mask
     const int lane = (int)threadIdx.x;                         // one wave per block
     const long c_raw = (long)blockIdx.x * 64 + lane;
     const bool valid = c_raw < a.nchains;
@@ -522,115 +647,8 @@ MHX_DEV void mhx_rwmh_reg_zig_body(const mhx_rwmh_args& a, const mhx_real* __res
 
     for (int i = 0; i < a.nsteps; ++i) {
         const mhx_u32 step = a.step0 + (mhx_u32)i;
-        // ---- phase A: normal n of the step from Philox block n >> 1 (words x, y / z, w), fast path; failures noted
-        // (the chain id behind an empty asm: otherwise hipcc hoists the id-only first round and a half of all D / 2 Philox calls out
-        // of the step loop -- 150 registers it does not have: they go to scratch memory and come back every step)
-        mhx_u32 idl = id_lo, idh = id_hi;
-        asm volatile("" : "+v"(idl), "+v"(idh));
-        mhx_u64 fmw[NW];
-#pragma unroll
-        for (int w = 0; w < NW; ++w) fmw[w] = 0ull;
-        // Software pipeline over the Philox blocks: the table look-ups of block p are in flight while the rounds of block p + 1 run
-        // (one wave per SIMD has nothing else to hide an LDS round trip behind; straight after each other the look-ups cost a
-        // quarter of the kernel: 100 x ~100 cycles per wave-step)
-        constexpr int NP = (D + 1) / 2;
-        mhx_u32x4 w4 = mhx_philox(ks, idl, idh, step, (MHX_STREAM_PROPOSAL << 28) | 0u);
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            typedef double mhx_d2 __attribute__((ext_vector_type(2)));
-            mhx_d2 xe[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const mhx_u32 ly = (h ? w4.w : w4.y) & (mhx_u32)(MHX_ZIG_N - 1);
-                xe[h].x = zt[ly]; xe[h].y = zt[ly + 1];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            mhx_u32x4 wn = w4;
-            if (p + 1 < NP) wn = mhx_philox(ks, idl, idh, step, (MHX_STREAM_PROPOSAL << 28) | (mhx_u32)(p + 1));
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int n = 2 * p + h;
-                if (n < D) {
-                    const mhx_u32 hi = h ? w4.z : w4.x, lo = h ? w4.w : w4.y;
-                    const double ax = mhx_zig_ax(hi, lo, xe[h].x);
-                    y[n] = mhx_zig_signed(ax, lo, zsign);
-                    const bool fail = !(ax < xe[h].y);
-                    fmw[n >> 6] |= (fail ? 1ull : 0ull) << (n & 63);
-                }
-            }
-            w4 = wn;
-        }
-        // ---- the wave-step's failures: queue, refine side by side, hand back
-        bool anyfail = false;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) anyfail = anyfail || fmw[w] != 0ull;
-        if (__ballot(anyfail)) {
-            int total = 0;
-            for (int win = 0; win == 0 || win < total; win += 64) {
-                int base = -win;
-#pragma unroll
-                for (int w = 0; w < NW; ++w) {
-                    mhx_u64 f = fmw[w];
-                    for (;;) {
-                        const mhx_u64 m = __ballot(f != 0ull);
-                        if (m == 0ull) break;
-                        if (f != 0ull) {
-                            const int e = base + (int)__builtin_amdgcn_mbcnt_hi((mhx_u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((mhx_u32)m, 0u));
-                            const int sl = 64 * w + __ffsll((long long)f) - 1;
-                            if (e >= 0 && e < 64) zq[e] = (unsigned short)(lane | (sl << 6));
-                        }
-                        f &= f - 1ull;
-                        base += __popcll(m);
-                    }
-                }
-                total = base + win;
-                MHX_WAVE_SYNC();
-                const int nent = total - win < 64 ? total - win : 64;
-                mhx_u32 ent = 0u;
-                double val = 0.0;
-                if (lane < nent) {
-                    ent = zq[lane];
-                    const int ol = (int)(ent & 63u);
-                    const long oc_raw = (long)blockIdx.x * 64 + ol;
-                    const mhx_u64 oid = a.first_chain + (mhx_u64)(oc_raw < a.nchains ? oc_raw : (long)a.nchains - 1);
-                    val = mhx_zig_refine(ks, zt, (mhx_u32)oid, (mhx_u32)(oid >> 32), step, MHX_STREAM_PROPOSAL, ent >> 6);
-                }
-                if (lane < nent) zres[lane] = val;
-                MHX_WAVE_SYNC();
-                // back to the owners: the same walk as the queue's -- a lane's r-th failure of word w sits at the position it was
-                // given there -- and every register of the word takes the value where the slot number says so: straight-line
-                // compare + select per register and round (a wave-uniform branch per failure into one of D registers costs
-                // hipcc's allocator a copy of the whole candidate per iteration; a run-time index sends the array to scratch)
-                base = -win;
-#pragma unroll
-                for (int w = 0; w < NW; ++w) {
-                    mhx_u64 f = fmw[w];
-                    for (;;) {
-                        const mhx_u64 m = __ballot(f != 0ull);
-                        if (m == 0ull) break;
-                        const int e = base + (int)__builtin_amdgcn_mbcnt_hi((mhx_u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((mhx_u32)m, 0u));
-                        const bool has = f != 0ull && e >= 0 && e < 64;
-                        int sls = has ? __ffsll((long long)f) - 1 : -1;
-                        asm volatile("" : "+v"(sls));          // (else hipcc splits the test into `has` AND a compare: 5 instructions per register for 3)
-                        const double pv = zres[has ? e : 0];
-                        // (skipping a block of 8 registers when no lane's slot lies in it was measured: 3.35 against 3.25 ms per launch at
-                        // c2_user -- the ballots and branches cost more than the skipped selects)
-#pragma unroll
-                        for (int blk = 0; blk < 8; ++blk) {
-                            if (64 * w + 8 * blk < D) {
-#pragma unroll
-                                for (int b = 8 * blk; b < 8 * blk + 8; ++b)
-                                    if (64 * w + b < D) y[64 * w + b] = sls == b ? pv : y[64 * w + b];
-                            }
-                        }
-                        f &= f - 1ull;
-                        base += __popcll(m);
-                    }
-                }
-                MHX_WAVE_SYNC();                               // (the next window writes the queue and the results again)
-            }
-        }
+        // ---- the step's D standard normals into the candidate's registers (fast path, queue, refinement, hand-back)
+        mhx_reg_zig_fill<D>(y, ks, id_lo, id_hi, step, MHX_STREAM_PROPOSAL, zt, zq, zres, lane, (long)blockIdx.x * 64, a.first_chain, a.nchains, zsign);
         // ---- propose: y = x + s n   (src/proposal.jl:49-56)
 #pragma unroll
         for (int k = 0; k < D; ++k) y[k] = mhx_fma(PK == MHX_PROP_ISO ? a.pscale : pvec[k], y[k], getx(k));

@@ -1163,10 +1163,11 @@ real orc_target_grad(const orc_target *t, const real *x, real *g, orc_logdensity
  *   accept iff -randexp < lp(y) - lp(x) + logratio                           (:83-86)            */
 int orc_mala(const orc_target *t, orc_logdensity_grad_fn user, real sigma2, const orc_schedule *s,
              uint64_t seed, uint64_t first_chain, int nchains, const real *init,
-             real *samples, uint8_t *accepted, real *final_x, real *final_lp, uint32_t *accept_counts)
+             real *samples, uint8_t *accepted, real *final_x, real *final_lp, uint32_t *accept_counts, int normal_gen)
 {
     const int d = t->dim, C = nchains;
     if (!init) return -1;                                /* :37 "please specify initial parameters" */
+    /* normal_gen: 0 Box-Muller, 1 the table ziggurat (fp64) -- which standard normals the noise z is */
     int64_t nT, nA;
     orc_schedule_counts(s, &nT, &nA);
     const real sigma = SQRT(sigma2);
@@ -1186,7 +1187,7 @@ int orc_mala(const orc_target *t, orc_logdensity_grad_fn user, real sigma2, cons
         margin_flush(&mg, slot, C, c);
         for (int64_t tau = 1; tau <= nT; ++tau) {
             const uint32_t step = (uint32_t)tau;
-            orc_normals(seed, id, step, ORC_STREAM_PROPOSAL, d, z);
+            normals_gen(normal_gen, seed, id, step, ORC_STREAM_PROPOSAL, d, z);
             for (int k = 0; k < d; ++k) y[k] = FMA(sigma, z[k], FMA(h, gx[k], x[k]));
             const real fwd = lanes_sumsq(z, NULL, d, Lw);
             const real lpy = orc_target_grad(t, y, gy, user);

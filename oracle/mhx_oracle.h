@@ -151,7 +151,7 @@ real orc_target_grad(const orc_target *t, const real *x, real *g, orc_logdensity
 /* MALA(g -> MvNormal((sigma2/2) g, sigma2 I)): src/MALA.jl:54-93.  init [d][C] is required (:37). */
 int orc_mala(const orc_target *t, orc_logdensity_grad_fn user, real sigma2, const orc_schedule *s,
              uint64_t seed, uint64_t first_chain, int nchains, const real *init,
-             real *samples, uint8_t *accepted, real *final_x, real *final_lp, uint32_t *accept_counts);
+             real *samples, uint8_t *accepted, real *final_x, real *final_lp, uint32_t *accept_counts, int normal_gen /* 0 Box-Muller, 1 ziggurat (fp64) */);
 
 /* the d standard normals of (seed, chain, step, stream) by generator `gen` (0 Box-Muller, 1 ziggurat: fp64 build only) */
 void orc_normals_gen(int gen, uint64_t seed, uint64_t chain, uint32_t step, uint32_t stream, int d, real *out);

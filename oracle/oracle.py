@@ -419,7 +419,7 @@ def target_grad(target, x, user_grad_addr=None):
     return lp, g
 
 
-def mala(target, sigma2, sched, seed, first_chain, nchains, init, user_grad_addr=None, save=True):
+def mala(target, sigma2, sched, seed, first_chain, nchains, init, user_grad_addr=None, save=True, normal_gen=0):
     d, N, Cn = target.dim, sched.n_samples, nchains
     samples = np.empty((N, d + 1, Cn), dtype=real()) if save else None
     accepted = np.empty((N, Cn), dtype=np.uint8) if save else None
@@ -430,7 +430,8 @@ def mala(target, sigma2, sched, seed, first_chain, nchains, init, user_grad_addr
     assert init.shape == (d, Cn)
     ug = C.cast(user_grad_addr, _T("gfn")) if user_grad_addr else C.cast(None, _T("gfn"))
     rc = lib().orc_mala(C.byref(target.c), ug, _creal()(sigma2), C.byref(sched), C.c_uint64(seed),
-                        C.c_uint64(first_chain), Cn, _fp(init), _fp(samples), _u8p(accepted), _fp(fx), _fp(flp), _u32p(cnt))
+                        C.c_uint64(first_chain), Cn, _fp(init), _fp(samples), _u8p(accepted), _fp(fx), _fp(flp), _u32p(cnt),
+                        int(normal_gen))
     assert rc == 0
     return dict(samples=samples, accepted=accepted, final_x=fx, final_lp=flp, accept_counts=cnt)
 
