@@ -64,6 +64,12 @@ k_rwmh_reg(const mhx_rwmh_args a, const mhx_real* __restrict__ tparams, const mh
 {
     mhx_rwmh_reg_body<D, TK, PK>(a, tparams, pvec);
 }
+template <int PK>
+__global__ void __launch_bounds__(64)
+k_rwmh_wave(const mhx_rwmh_args a, const mhx_real* __restrict__ tparams, const mhx_real* __restrict__ pvec)
+{
+    mhx_rwmh_wave_body<PK>(a, tparams, pvec);
+}
 __global__ void __launch_bounds__(256)
 k_rwmh_generic(const mhx_rwmh_args a, const mhx_real* __restrict__ tparams, const mhx_real* __restrict__ pvec)
 {
@@ -947,6 +953,19 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
     const bool separable = tk == MHX_TARGET_ISO_GAUSS || tk == MHX_TARGET_BANANA || tk == MHX_TARGET_FUNNEL;
     // lanes per chain: cfg->reduce_lanes, or (auto) the smallest power of two that (a) keeps a lane's
     // blocks in registers (<= 13 blocks = 104 VGPRs of state) and (b) gives the chip >= 2 waves per SIMD
+    // A wave per chain (variant 11): the data-sum target of the README example with FEW chains -- the lanes split the likelihood's
+    // terms (reduction shape 64).  Asked for (reduce_lanes = 64), or by default while every chain can have a wave to itself (<= 2 per
+    // SIMD) and there are terms to split; the plain random walk, ISO / DIAG proposal, Box-Muller normals.
+    if (tk == MHX_TARGET_IID_NORMAL && d == 2 && pk != MHX_PROP_DENSE && walk == MHX_WALK_PLAIN &&
+        !(r->flags & (MHX_FLAG_GENERIC | MHX_FLAG_ZIGGURAT)) &&
+        (cfg->reduce_lanes == 64 || (cfg->reduce_lanes == 0 && t->nparams >= 8 && r->n <= 2048))) {
+        r->reg_fn = pk == MHX_PROP_ISO ? k_rwmh_wave<MHX_PROP_ISO> : k_rwmh_wave<MHX_PROP_DIAG>;
+        r->variant = 11;
+        r->coop_L = 64;
+    } else if (tk == MHX_TARGET_IID_NORMAL && cfg->reduce_lanes > 1) {
+        return mhx_fail(MHX_EINVAL, "mhx_rwmh_create: the data-sum target knows reduce_lanes 0, 1 and 64 (a wave per chain: plain walk, "
+                        "ISO / DIAG proposal, Box-Muller), got %d", cfg->reduce_lanes);
+    }
     int L = 1;
     bool coop_one_lane = false;                       // a walk with a Hastings ratio on ONE lane per chain: still the cooperative body
     if (separable && pk != MHX_PROP_DENSE && !(r->flags & MHX_FLAG_GENERIC) && !(walk && (r->flags & MHX_FLAG_NO_JIT))) {
@@ -1310,6 +1329,8 @@ static int rwmh_advance(mhx_run* r, uint64_t nsteps, uint32_t save_next, int sav
             void* params[] = {&a, &tp, &pv};
             HIP_TRY(hipModuleLaunchKernel(r->jit_step, grid, 1, 1, 64 * MHX_EMCEE_COOP_WAVES, 1, 1, (unsigned)r->dense_lds,
                                           ctx->stream, params, nullptr));
+        } else if (r->variant == 11) {                           // a wave per chain
+            hipLaunchKernelGGL(r->reg_fn, dim3((unsigned)r->n), dim3(64), 0, ctx->stream, a, tp, pv);
         } else if (r->variant == 1) {
             const unsigned grid = (unsigned)((r->n + 63) / 64);
             hipLaunchKernelGGL(r->reg_fn, dim3(grid), dim3(64), 0, ctx->stream, a, tp, pv);

@@ -1266,6 +1266,99 @@ MHX_DEV void mhx_moments_first_body(const mhx_real* __restrict__ x, const mhx_re
 }
 
 // JIT entry points: hiprtc compiles this header with the specialisation macros defined
+// ---------------------------------------------------------------------------------------------
+// A WAVE per chain (round 5; kernel_variant 11): the few-chain regime of the reference's own example -- README.md:25-40,
+// test/runtests.jl:76-94: ONE chain, 100 000 draws of theta = (mu, sigma) under sum(logpdf.(Normal(mu, sigma), data)).  A lane per chain
+// walks the data terms serially (2.4 us per transition: 23 x slower than one CPU thread); here the 64 lanes of a wave SPLIT THE TERMS
+// (lane l: terms l, l + 64, ... in ascending order, one IEEE division each), the partial sums meet in the fixed xor-butterfly -- the
+// spec's reduction shape 64, which the oracle takes for this target too -- and every lane carries the (tiny) state redundantly.  The
+// random numbers do not depend on the state (counter RNG), so they leave the sequential chain altogether: lane l draws the normals and
+// the accept uniform of step s0 + l for a batch of 64 steps at once, the chain then takes them by v_readlane; lane l also keeps the
+// state after ITS step and writes that step's record after the batch (one chain: 64 consecutive slots, contiguous).  What is left per
+// transition is the dependent chain itself: two fma, a division, six butterfly steps beside log(sigma), the compare.
+template <int PK>
+MHX_DEV void mhx_rwmh_wave_body(const mhx_rwmh_args& a, const mhx_real* __restrict__ tparams, const mhx_real* __restrict__ pvec)
+{
+    static_assert(PK != MHX_PROP_DENSE, "ISO / DIAG proposals");
+    const int lane = (int)threadIdx.x;                         // one wave per block, one chain per block
+    const long c = (long)blockIdx.x;
+    const mhx_u64 id = a.first_chain + (mhx_u64)c;
+    const mhx_u32 id_lo = (mhx_u32)id, id_hi = (mhx_u32)(id >> 32);
+    const mhx_philox_key ks = mhx_philox_schedule(a.seed);
+    const long ld = a.ld;
+    const int np = a.ntparams;
+    mhx_real x0 = a.x[c], x1 = a.x[ld + c], lp = a.lp[c];
+    mhx_u32 nacc = a.acc_count[c];
+    bool last = a.last_acc[c] != 0;
+    const mhx_real s0 = PK == MHX_PROP_ISO ? a.pscale : pvec[0], s1 = PK == MHX_PROP_ISO ? a.pscale : pvec[1];
+    const mhx_real t0 = lane < np ? tparams[lane] : MHX_R(0.0);                 // this lane's first term stays in a register
+    const mhx_real npf = (mhx_real)np;
+    mhx_u32 total_acc = 0u;
+    auto bcast = [](const mhx_real v, const int j) -> mhx_real {                   // lane j's value, for every lane (j is wave-uniform)
+#if MHX_REAL64
+        const mhx_u64 b = __builtin_bit_cast(mhx_u64, v);
+        const mhx_u32 lo = (mhx_u32)__builtin_amdgcn_readlane((int)(mhx_u32)b, j), hi = (mhx_u32)__builtin_amdgcn_readlane((int)(mhx_u32)(b >> 32), j);
+        return __builtin_bit_cast(double, (mhx_u64)lo | ((mhx_u64)hi << 32));
+#else
+        return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), j));
+#endif
+    };
+    for (int it0 = 0; it0 < a.nsteps; it0 += 64) {
+        const int nb = a.nsteps - it0 < 64 ? a.nsteps - it0 : 64;
+        // ---- the batch's draws, one step per lane (lanes >= nb draw for steps nobody takes)
+        const mhx_u32 mystep = a.step0 + (mhx_u32)(it0 + lane);
+        mhx_real n[4];
+        mhx_normal4(ks, id_lo, id_hi, mystep, MHX_STREAM_PROPOSAL, 0u, n);      // normals 0, 1 of the step (src/proposal.jl:49-56)
+        mhx_accept_cache ac;
+        ac.group = 0xffffffffu;
+        ac.w.x = ac.w.y = ac.w.z = ac.w.w = 0u;
+        const mhx_real mylogu = mhx_accept_logu(ks, id_lo, id_hi, mystep, ac);
+        mhx_real rx0 = x0, rx1 = x1, rlp = lp;
+        bool racc = false;
+        // ---- the chain
+        for (int j = 0; j < nb; ++j) {
+            const mhx_real y0 = mhx_fma(s0, bcast(n[0], j), x0), y1 = mhx_fma(s1, bcast(n[1], j), x1);
+            const mhx_real logu = bcast(mylogu, j);
+            // logdensity(model, candidate) (src/mh-core.jl:103): mhx_target_eval's IID_NORMAL expressions, the sum in shape 64
+            mhx_real acc = MHX_R(0.0);
+            if (lane < np) { const mhx_real z = (t0 - y0) / y1; acc = mhx_fma(z, z, acc); }
+            for (int i = lane + 64; i < np; i += 64) { const mhx_real z = (tparams[i] - y0) / y1; acc = mhx_fma(z, z, acc); }
+            acc = mhx_butterfly<64>(acc);
+            const mhx_real tt = mhx_log(y1) + MHX_HALF_LOG_2PI;
+            mhx_real lpy = mhx_fma(-MHX_R(0.5), acc, -(npf * tt));
+            lpy = (y1 > MHX_R(0.0)) ? lpy : -MHX_INF;                            // theta[2] >= 0 support, -Inf at sigma == 0; NaN: reject
+            const bool ok = logu < (lpy - lp);                                   // strict (src/mh-core.jl:108); NaN compares false
+            x0 = ok ? y0 : x0;
+            x1 = ok ? y1 : x1;
+            lp = ok ? lpy : lp;
+            nacc += ok ? 1u : 0u;
+            total_acc += ok ? 1u : 0u;
+            last = ok;
+            if (lane == j) { rx0 = x0; rx1 = x1; rlp = lp; racc = ok; }
+        }
+        // ---- the batch's records, one step per lane (ext/AdvancedMHMCMCChainsExt.jl:96-105 layout)
+        if (lane < nb && a.save_next != MHX_NO_SAVE && mystep >= a.save_next) {
+            const mhx_u32 since = mystep - a.save_next;
+            if (since % (mhx_u32)a.thinning == 0u) {
+                const long slot = (long)a.save_slot + (long)(since / (mhx_u32)a.thinning);
+                mhx_real* row = a.samples + slot * 3L * ld + c;
+                row[0] = rx0;
+                row[ld] = rx1;
+                row[2 * ld] = rlp;
+                a.accepted[slot * ld + c] = racc ? 1 : 0;
+            }
+        }
+    }
+    if (lane == 0) {
+        a.x[c] = x0;
+        a.x[ld + c] = x1;
+        a.lp[c] = lp;
+        a.acc_count[c] = nacc;
+        a.last_acc[c] = last ? 1 : 0;
+        atomicAdd(a.acc_total, (mhx_u64)total_acc);
+    }
+}
+
 #ifdef MHX_JIT_RWMH_REG
 #ifndef MHX_JIT_XR
 #define MHX_JIT_XR MHX_JIT_DIM

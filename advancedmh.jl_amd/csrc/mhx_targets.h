@@ -182,8 +182,25 @@ MHX_DEV mhx_real mhx_target_eval_lanes(int kind, const X& x, const int d, const 
 {
     const int k_ = (KIND == MHX_TARGET_DYNAMIC) ? kind : KIND;
     const bool separable = k_ == MHX_TARGET_ISO_GAUSS || k_ == MHX_TARGET_BANANA || k_ == MHX_TARGET_FUNNEL;
-    if (L <= 1 || !(separable || k_ == MHX_TARGET_CORR_GAUSS)) return mhx_target_eval<KIND>(kind, x, d, p, np, cst);
+    if (L <= 1 || !(separable || k_ == MHX_TARGET_CORR_GAUSS || k_ == MHX_TARGET_IID_NORMAL)) return mhx_target_eval<KIND>(kind, x, d, p, np, cst);
     mhx_real part[64];
+    if (k_ == MHX_TARGET_IID_NORMAL) {
+        // shape of the wave-per-chain kernel (mhx_rwmh_wave_body): lane l owns the data terms i = l, l+L, ...
+        const mhx_real mu = x[0], sigma = x[1];
+        if (!(sigma > MHX_R(0.0))) return -MHX_INF;
+        for (int l = 0; l < L; ++l) {
+            mhx_real q = MHX_R(0.0);
+            for (int i = l; i < np; i += L) { const mhx_real z = (p[i] - mu) / sigma; q = mhx_fma(z, z, q); }
+            part[l] = q;
+        }
+        for (int off = 1; off < L; off <<= 1) {
+            mhx_real nxt[64];
+            for (int l = 0; l < L; ++l) nxt[l] = part[l] + part[l ^ off];
+            for (int l = 0; l < L; ++l) part[l] = nxt[l];
+        }
+        const mhx_real tt = mhx_log(sigma) + MHX_HALF_LOG_2PI;
+        return mhx_fma(-MHX_R(0.5), part[0], -((mhx_real)np * tt));
+    }
     if (k_ == MHX_TARGET_CORR_GAUSS) {
         // shape of the cooperative ensemble kernel: lane l owns rows i = l, l+L, ... of A x
         for (int l = 0; l < L; ++l) {

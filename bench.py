@@ -759,7 +759,7 @@ def ess_window(mhx, wl, world):
 
 KERNELS = {0: "generic", 1: "prebuilt-register", 2: "hiprtc-register", 3: "prebuilt-cooperative", 4: "hiprtc-cooperative",
            5: "hiprtc-dense-cooperative", 6: "persistent-block-ensemble", 7: "sequential-ensemble-sweep", 8: "matrix-core",
-           9: "scalar-factor-ensemble", 10: "matrix-core-ensemble"}   # 6: one persistent block for a small ensemble
+           9: "scalar-factor-ensemble", 10: "matrix-core-ensemble", 11: "wave-per-chain"}   # 6: one persistent block for a small ensemble
 
 
 def kernel_name(wl, st):

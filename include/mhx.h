@@ -147,7 +147,8 @@ typedef struct {
                                q(x | y) - q(y | x) (src/proposal.jl:58-64,190-192) is then non-zero and is computed.
                                Runs on the generic kernel. */
     int32_t reduce_lanes;   /* lanes that share one chain (power of two <= 64) for the separable catalogue
-                               targets; 0 = let the engine choose from nchains and dim, 1 = one lane per chain.
+                               targets (MHX_TARGET_IID_NORMAL: 64 = a wave per chain, the few-chain kernel, which is also the
+                               engine's choice up to 2048 chains); 0 = let the engine choose from nchains and dim, 1 = one lane per chain.
                                The value in effect is reported in mhx_stats.reduce_lanes: it fixes the
                                summation order of the log-density and therefore the exact chain. */
 } mhx_rwmh_cfg;
@@ -325,7 +326,10 @@ typedef struct {
                                   shape = reduce_lanes = waves per block),
                                   10 matrix-core form of the stretch move (dense precision factor, dim <= 64 in fp64 / 128 in fp32:
                                   4 lanes per walker, A y of the 16 walkers of a wave on v_mfma_*_16x16x4, the factor's operands
-                                  fetched into registers from an image built once per run; reduction shape 4) */
+                                  fetched into registers from an image built once per run; reduction shape 4),
+                                  11 a WAVE per chain (RWMH on the data-sum target MHX_TARGET_IID_NORMAL with few chains -- the
+                                  reference's own README example, one chain: the 64 lanes split the likelihood's terms, the draws of
+                                  64 steps are made side by side off the chain's critical path; reduction shape 64) */
     int32_t launches;
     int32_t reduce_lanes;      /* lanes per chain in effect (1 unless a cooperative kernel runs) */
     int32_t dtype;             /* mhx_dtype of the run's context */

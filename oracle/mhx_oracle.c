@@ -505,6 +505,22 @@ real orc_target_eval(const orc_target *t, const real *x)
         }
         return FMA(-R(0.5), butterfly(p, L), target_const(t));
     }
+    if (t->reduce_lanes > 1 && t->kind == ORC_TARGET_IID_NORMAL) {
+        /* README.md:29-31 with the sum over the data in reduction shape L: lane l owns the terms i = l, l+L, ... in ascending order,
+         * the L partial sums meet in the butterfly (the wave-per-chain kernel: L = 64) */
+        const real mu = x[0], sigma = x[1];
+        if (!(sigma > R(0.0))) return -INFINITY;
+        const int L = t->reduce_lanes;
+        real p[64];
+        for (int l = 0; l < L; ++l) {
+            real q = R(0.0);
+            for (int i = l; i < t->nparams; i += L) { const real z = (t->params[i] - mu) / sigma; q = FMA(z, z, q); }
+            p[l] = q;
+        }
+        const real acc = butterfly(p, L);
+        const real tt = orc_log(sigma) + HALF_LOG_2PI;
+        return FMA(-R(0.5), acc, -((real)t->nparams * tt));
+    }
     if (t->reduce_lanes > 1 && (t->kind == ORC_TARGET_ISO_GAUSS || t->kind == ORC_TARGET_BANANA ||
                                 t->kind == ORC_TARGET_FUNNEL)) {
         const real q = split_sum_squares(t, x);

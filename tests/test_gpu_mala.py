@@ -194,7 +194,7 @@ def test_mala_user_gradient_register_kernel_with_tails_in_lds(mhx, oracle, d, C,
     _same(cnt, ref["accept_counts"], "accept counts")
 
 
-@pytest.mark.parametrize("d,C,target", [(5, 70, "iso"), (24, 33, "corr"), (40, 130, "iso"), (64, 64, "user")])
+@pytest.mark.parametrize("d,C,target", [(5, 70, "iso"), (12, 33, "corr"), (40, 130, "iso"), (64, 64, "user")])
 def test_mala_with_ziggurat_noise_on_the_register_kernel(mhx, oracle, d, C, target):
     """MHX_FLAG_ZIGGURAT on a MALA run (round 5; VERDICT r4 'missing' 6): the noise of the Langevin proposal by the table ziggurat --
     the register-array fill of the RWMH register kernel (fast path into registers, wave-wide queue, refinement, hand-back) -- bit for

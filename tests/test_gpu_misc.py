@@ -72,20 +72,25 @@ def test_rwmh_golden_traces_all_kernel_variants(mhx, name, flags_name, real):
     assert chain.stats["kernel_variant"] == want_variant
 
 
-def test_c1_readme_plumbing(mhx, oracle, real):
+@pytest.mark.parametrize("lanes,variant", [(0, 11), (1, 1)])
+def test_c1_readme_plumbing(mhx, oracle, real, lanes, variant):
     """BASELINE config 1 / README.md:25-40: Normal(mu, sigma) DensityModel, RWMH(MvNormal(zeros(2), I)),
-    100 000 steps, ONE chain -- GPU result identical to the CPU oracle and close to the data's moments."""
+    100 000 steps, ONE chain -- GPU result identical to the CPU oracle and close to the data's moments.  The engine's choice for a
+    single chain is the wave-per-chain kernel (variant 11, round 5: the lanes split the 30 likelihood terms, reduction shape 64);
+    reduce_lanes = 1 keeps the lane-per-chain register kernel (the plain ascending sum)."""
     data = np.load(os.path.join(GOLD, "c1_normal_data.npy"))[:30]
     model = mhx.DensityModel(mhx.IIDNormal(data))
     chain = mhx.sample(model, mhx.RWMH(mhx.MvNormal(mhx.zeros(2), mhx.I)), 100000, 1, seed=1234,
-                       initial_params=np.array([0.0, 1.0]), param_names=["μ", "σ"])
-    t = oracle.Target(oracle.TARGET_IID_NORMAL, 2, params=data)
+                       initial_params=np.array([0.0, 1.0]), param_names=["μ", "σ"], reduce_lanes=lanes)
+    L = chain.stats["reduce_lanes"]
+    assert chain.stats["kernel_variant"] == variant and L == (64 if variant == 11 else 1)
+    t = oracle.Target(oracle.TARGET_IID_NORMAL, 2, params=data, reduce_lanes=L)
     ref = oracle.rwmh(t, oracle.Proposal(oracle.PROP_ISO, 1.0), oracle.schedule(100000), 1234, 0, 1,
                       init=np.array([[0.0], [1.0]], dtype=np.float32))
     _same(chain.value, ref["samples"], "samples")
+    _same(chain.accepted, ref["accepted"], "accepted")
     assert chain.names == ["μ", "σ", "lp"]
     assert abs(chain.mean("μ") - data.mean()) < 0.1 and abs(chain.mean("σ") - data.std()) < 0.15
-    assert chain.stats["kernel_variant"] == 1                   # the pre-built (2, iid-normal, iso) register kernel
     d = chain.state.diagnostics(max_lag=2000, ess_chains=1)
     ess = d["ess_geyer"][:2]
     assert (ess > 1000).all() and (ess < 30000).all()           # README.md:59-63 shows ESS ~ 3.9e3 of 1e5 draws
