@@ -1077,7 +1077,7 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
         else if (cfg->reduce_lanes > 1) return rc;
         L = 1;                                                        // not the separable cooperative path below
         }
-    } else if (cfg->reduce_lanes > 1) {
+    } else if (cfg->reduce_lanes > 1 && r->variant != 11) {
         return mhx_fail(MHX_EINVAL, "reduce_lanes > 1 needs a separable catalogue target or the dense Gaussian target "
                                 "(dim <= 128, JIT), and an ISO/DIAG proposal");
     }

@@ -234,6 +234,19 @@ MHX_DEV double mhx_log(double x)
     if (ix < 0x0010000000000000ull) { x = x * 0x1p54; ix = mhx_d2u(x); eadj = -54; }
     return mhx_log_core(ix, eadj);
 }
+// the same function without a branch -- special cases by selects AFTER the arithmetic ran on (possibly meaningless) bits -- for kernels
+// that evaluate several logarithms side by side (mhx_rwmh_wave_body): early returns would serialise them.  Same value for every input.
+MHX_DEV double mhx_log_sel(const double x)
+{
+    const mhx_u64 ix0 = mhx_d2u(x);
+    const bool sub = ix0 < 0x0010000000000000ull;
+    const double xs = sub ? x * 0x1p54 : x;
+    double r = mhx_log_core(mhx_d2u(xs), sub ? -54 : 0);
+    r = ix0 >= 0x7ff0000000000000ull ? x : r;
+    r = (ix0 >> 63) ? MHX_NAN : r;
+    r = (ix0 << 1) == 0ull ? -MHX_INF : r;
+    return r;
+}
 
 MHX_DEV double mhx_exp(double x)
 {
@@ -539,21 +552,14 @@ MHX_DEV float mhx_log_pos(float x)
 }
 
 // full-range log (user log-densities, emcee's log z)
-MHX_DEV float mhx_log(float x)
+MHX_DEV float mhx_log_core(const mhx_u32 ix, const int eadj)
 {
-    mhx_u32 ix = mhx_f2u(x);
-    if ((ix << 1) == 0u) return -MHX_INF;
-    if (ix >> 31) return MHX_NAN;
-    if (ix >= 0x7f800000u) return x;
-    float adj = 0.0f;
-    if (ix < 0x00800000u) { x = x * 0x1p23f; adj = -23.0f; }
     // same polynomial as mhx_log_pos; the exponent correction is folded in before the conversion
-    ix = mhx_f2u(x);
     const mhx_u32 t = ix - 0x3f2aaaabu;
     const int e = (int)t >> 23;
     const float m = mhx_u2f(ix - ((mhx_u32)e << 23));
     const float f = m - 1.0f;
-    const float ef = (float)(e + (int)adj);
+    const float ef = (float)(e + eadj);
     float q = -0x1.04cba2p-3f;
     q = mhx_fma(q, f, 0x1.19bbe2p-3f);
     q = mhx_fma(q, f, -0x1.f483fap-4f);
@@ -567,6 +573,28 @@ MHX_DEV float mhx_log(float x)
     float r = mhx_fma(f2, q, f);
     r = mhx_fma(ef, MHX_LN2_LO, r);
     r = mhx_fma(ef, MHX_LN2_HI, r);
+    return r;
+}
+MHX_DEV float mhx_log(float x)
+{
+    mhx_u32 ix = mhx_f2u(x);
+    if ((ix << 1) == 0u) return -MHX_INF;
+    if (ix >> 31) return MHX_NAN;
+    if (ix >= 0x7f800000u) return x;
+    int eadj = 0;
+    if (ix < 0x00800000u) { x = x * 0x1p23f; eadj = -23; }
+    return mhx_log_core(mhx_f2u(x), eadj);
+}
+// the same function without a branch (see the fp64 twin): special cases by selects after the arithmetic
+MHX_DEV float mhx_log_sel(const float x)
+{
+    const mhx_u32 ix0 = mhx_f2u(x);
+    const bool sub = ix0 < 0x00800000u;
+    const float xs = sub ? x * 0x1p23f : x;
+    float r = mhx_log_core(mhx_f2u(xs), sub ? -23 : 0);
+    r = ix0 >= 0x7f800000u ? x : r;
+    r = (ix0 >> 31) ? MHX_NAN : r;
+    r = (ix0 << 1) == 0u ? -MHX_INF : r;
     return r;
 }
 

@@ -24,8 +24,14 @@
 MHX_NS_BEGIN
 
 #ifndef MHX_EMCEE_MFMA_WAVES
-#define MHX_EMCEE_MFMA_WAVES 1                    // waves per block (16 walkers each): the waves do not share anything
+#define MHX_EMCEE_MFMA_WAVES 1                    // waves per block (16 walkers each)
 #endif
+// Round 5: what the per-launch fetch of the operands costs was measured (tools/c3_mfma_probe.py, profiles/r05e_c3_mfma_probe.log: every
+// lane fetching its groups from the same 2 KB instead runs the C3 sweep in 8.47 us against 10.20) -- 19 KB per wave x 1024 waves =
+// 19 MB out of the L2s per sweep, 1.7 us of a 10-us launch.  With more than one wave per block the waves therefore SHARE the fetch:
+// wave w brings groups w, w + WAVES, ... into the block's LDS (plain loads issued behind the walker rows), one barrier, and every lane
+// takes its operands from there -- the L2 traffic of the image falls by the number of waves per block.  (One wave per block: straight
+// into registers as before, no LDS, no barrier.)
 
 // rows of (factor operands in registers) x b, two tiles at a time; q = sum of squares of this lane's rows in ascending order
 template <int D>
@@ -122,8 +128,33 @@ MHX_DEV void mhx_emcee_mfma_body(const mhx_emcee_args& a, const mhx_real* __rest
     }
     __builtin_amdgcn_sched_barrier(0);
     mhx_acc4 areg[NG];
+    if constexpr (MHX_EMCEE_MFMA_WAVES > 1) {
+        extern __shared__ mhx_acc4 mhx_emcee_mfma_opnd[];                        // [NG][64] acc4: the operand image, once per block
+        constexpr int NQ = (NG + MHX_EMCEE_MFMA_WAVES - 1) / MHX_EMCEE_MFMA_WAVES;
+        mhx_acc4 part[NQ];
 #pragma unroll
-    for (int q = 0; q < NG; ++q) areg[q] = ((const mhx_acc4*)img)[q * 64 + lane];
+        for (int u = 0; u < NQ; ++u) {
+            const int q = wave + u * MHX_EMCEE_MFMA_WAVES;
+            part[u] = ((const mhx_acc4*)img)[(q < NG ? q : NG - 1) * 64 + lane];
+        }
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            const int q = wave + u * MHX_EMCEE_MFMA_WAVES;
+            if (q < NG) mhx_emcee_mfma_opnd[q * 64 + lane] = part[u];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NG; ++q) areg[q] = mhx_emcee_mfma_opnd[q * 64 + lane];
+    } else {
+#pragma unroll
+        for (int q = 0; q < NG; ++q) areg[q] = ((const mhx_acc4*)img)[q * 64 + lane];
+    }
+#ifdef MHX_TOOLS_BUILD
+#if defined(MHX_EMCEE_MFMA_PROBE) && MHX_EMCEE_MFMA_PROBE == 1     // timing probe (tools build, JIT_DEFS): every group from the SAME 2 KB -- what the operand fetch costs
+#pragma unroll
+    for (int q = 0; q < NG; ++q) areg[q] = ((const mhx_acc4*)img)[lane];
+#endif
+#endif
     __builtin_amdgcn_sched_barrier(0);
     const mhx_real tt = mhx_fma(a.stretch - MHX_R(1.0), dr.u, MHX_R(1.0));
     const mhx_real z = (tt * tt) / a.stretch;                                    // src/emcee.jl:81

@@ -1275,7 +1275,8 @@ MHX_DEV void mhx_moments_first_body(const mhx_real* __restrict__ x, const mhx_re
 // random numbers do not depend on the state (counter RNG), so they leave the sequential chain altogether: lane l draws the normals and
 // the accept uniform of step s0 + l for a batch of 64 steps at once, the chain then takes them by v_readlane; lane l also keeps the
 // state after ITS step and writes that step's record after the batch (one chain: 64 consecutive slots, contiguous).  What is left per
-// transition is the dependent chain itself: two fma, a division, six butterfly steps beside log(sigma), the compare.
+// transition is the dependent chain itself -- two fma, a division, six butterfly steps beside log(sigma), the compare -- and that
+// chain runs K = 4 steps at a time speculatively (below): same decisions, same bits, a quarter of the latency while steps reject.
 template <int PK>
 MHX_DEV void mhx_rwmh_wave_body(const mhx_rwmh_args& a, const mhx_real* __restrict__ tparams, const mhx_real* __restrict__ pvec)
 {
@@ -1315,26 +1316,55 @@ MHX_DEV void mhx_rwmh_wave_body(const mhx_rwmh_args& a, const mhx_real* __restri
         const mhx_real mylogu = mhx_accept_logu(ks, id_lo, id_hi, mystep, ac);
         mhx_real rx0 = x0, rx1 = x1, rlp = lp;
         bool racc = false;
-        // ---- the chain
-        for (int j = 0; j < nb; ++j) {
-            const mhx_real y0 = mhx_fma(s0, bcast(n[0], j), x0), y1 = mhx_fma(s1, bcast(n[1], j), x1);
-            const mhx_real logu = bcast(mylogu, j);
-            // logdensity(model, candidate) (src/mh-core.jl:103): mhx_target_eval's IID_NORMAL expressions, the sum in shape 64
-            mhx_real acc = MHX_R(0.0);
-            if (lane < np) { const mhx_real z = (t0 - y0) / y1; acc = mhx_fma(z, z, acc); }
-            for (int i = lane + 64; i < np; i += 64) { const mhx_real z = (tparams[i] - y0) / y1; acc = mhx_fma(z, z, acc); }
-            acc = mhx_butterfly<64>(acc);
-            const mhx_real tt = mhx_log(y1) + MHX_HALF_LOG_2PI;
-            mhx_real lpy = mhx_fma(-MHX_R(0.5), acc, -(npf * tt));
-            lpy = (y1 > MHX_R(0.0)) ? lpy : -MHX_INF;                            // theta[2] >= 0 support, -Inf at sigma == 0; NaN: reject
-            const bool ok = logu < (lpy - lp);                                   // strict (src/mh-core.jl:108); NaN compares false
-            x0 = ok ? y0 : x0;
-            x1 = ok ? y1 : x1;
-            lp = ok ? lpy : lp;
-            nacc += ok ? 1u : 0u;
-            total_acc += ok ? 1u : 0u;
-            last = ok;
-            if (lane == j) { rx0 = x0; rx1 = x1; rlp = lp; racc = ok; }
+        // ---- the chain, K steps at a time.  The candidates of steps j .. j+K-1 are all formed from the CURRENT state and evaluated side
+        // by side (independent dependency chains: a wave alone on its SIMD has nothing else to fill the latencies with); the first
+        // of them that is accepted ends the round -- the steps before it were rejections from exactly this state, so their outcome
+        // is what the sequential loop computes; the ones after it are discarded and re-done from the new state.  Acceptance is low
+        // where this kernel runs (the README example: 6 %), so a round advances almost K steps for the latency of one.
+        constexpr int K = 4;
+        for (int j = 0; j < nb;) {
+            mhx_real y0[K], y1[K], lpy[K], logu[K], acc[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int jj = j + k < nb ? j + k : nb - 1;                      // (past the batch: a copy of its last step, never used)
+                y0[k] = mhx_fma(s0, bcast(n[0], jj), x0);
+                y1[k] = mhx_fma(s1, bcast(n[1], jj), x1);
+                logu[k] = bcast(mylogu, jj);
+                // logdensity(model, candidate) (src/mh-core.jl:103): mhx_target_eval's IID_NORMAL expressions, the sum in shape 64
+                acc[k] = MHX_R(0.0);
+                if (lane < np) { const mhx_real z = (t0 - y0[k]) / y1[k]; acc[k] = mhx_fma(z, z, acc[k]); }
+            }
+            for (int i = lane + 64; i < np; i += 64) {
+                const mhx_real ti = tparams[i];
+#pragma unroll
+                for (int k = 0; k < K; ++k) { const mhx_real z = (ti - y0[k]) / y1[k]; acc[k] = mhx_fma(z, z, acc[k]); }
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                acc[k] = mhx_butterfly<64>(acc[k]);
+                const mhx_real tt = mhx_log_sel(y1[k]) + MHX_HALF_LOG_2PI;       // (mhx_log's value, branch-free: the K logarithms interleave)
+                const mhx_real v = mhx_fma(-MHX_R(0.5), acc[k], -(npf * tt));
+                lpy[k] = (y1[k] > MHX_R(0.0)) ? v : -MHX_INF;                    // theta[2] >= 0 support, -Inf at sigma == 0; NaN: reject
+            }
+            // the first accepted step of the round (strict compare, src/mh-core.jl:108; NaN compares false), wave-uniform
+            int first = K;
+#pragma unroll
+            for (int k = K - 1; k >= 0; --k)
+                if (j + k < nb && logu[k] < (lpy[k] - lp)) first = k;
+            const int adv = first < K ? first + 1 : (nb - j < K ? nb - j : K);   // steps this round settles
+            // lanes j .. j+adv-2 (rejections) record the old state, lane j+adv-1 the new one if it was an acceptance
+            if (lane >= j && lane < j + adv) { rx0 = x0; rx1 = x1; rlp = lp; racc = false; }
+            if (first < K) {
+                mhx_real a0 = y0[0], a1 = y1[0], al = lpy[0];
+#pragma unroll
+                for (int k = 1; k < K; ++k) { a0 = first == k ? y0[k] : a0; a1 = first == k ? y1[k] : a1; al = first == k ? lpy[k] : al; }
+                x0 = a0; x1 = a1; lp = al;
+                nacc += 1u;
+                total_acc += 1u;
+                if (lane == j + first) { rx0 = x0; rx1 = x1; rlp = lp; racc = true; }
+            }
+            last = first < K;
+            j += adv;
         }
         // ---- the batch's records, one step per lane (ext/AdvancedMHMCMCChainsExt.jl:96-105 layout)
         if (lane < nb && a.save_next != MHX_NO_SAVE && mystep >= a.save_next) {

@@ -568,14 +568,17 @@ def test_a_large_dense_factor_falls_back_to_the_lane_group_form(mhx, oracle, rea
     _same(chain.value, ref["samples"], "samples")
 
 
-@pytest.mark.parametrize("d,W", [(50, 200), (8, 66), (17, 71), (33, 64), (64, 129), (24, 3), (50, 2), (12, 33), (100, 40), (128, 19)])
-def test_matrix_core_form_of_the_stretch_move(mhx, oracle, real, d, W, engine):
+@pytest.mark.parametrize("d,W,waves", [(50, 200, 1), (8, 66, 1), (17, 71, 4), (33, 64, 1), (64, 129, 2), (24, 3, 1), (50, 2, 4), (12, 33, 8), (100, 40, 1),
+                                       (128, 19, 1), (50, 300, 4), (40, 130, 8)])
+def test_matrix_core_form_of_the_stretch_move(mhx, oracle, real, d, W, waves, engine):
     """A dense precision factor on the matrix cores (variant 10): 4 lanes per walker, the candidate formed in the MFMA's B-operand
     layout, the factor's operand image built once per run and fetched into registers per launch -- no LDS, no barrier; reduction
     shape 4.  As one launch per sweep and as two half-step launches: the oracle's chain bit for bit (odd W, ensembles smaller than
     a wave, thinning with a discarded prefix, a continued call, the initial draw on the device)."""
     limit = 64 if real == "f64" else 128
     engine.setenv("MHX_EMCEE_MFMA", "1")               # (by default only large fp64 ensembles take this form)
+    # waves per block > 1 (round 5): the waves of a block share ONE fetch of the factor's operand image through LDS
+    engine.setenv("MHX_EMCEE_MFMA_WAVES", str(waves))
     Sig = _rotated(d, 0.9 if d <= 64 else 0.5)
     init = cases.emcee_init(d, W, 5)
     model = mhx.DensityModel(mhx.CorrGaussian(Sig))
