@@ -1292,7 +1292,8 @@ MHX_DEV void mhx_rwmh_wave_body(const mhx_rwmh_args& a, const mhx_real* __restri
     mhx_u32 nacc = a.acc_count[c];
     bool last = a.last_acc[c] != 0;
     const mhx_real s0 = PK == MHX_PROP_ISO ? a.pscale : pvec[0], s1 = PK == MHX_PROP_ISO ? a.pscale : pvec[1];
-    const mhx_real t0 = lane < np ? tparams[lane] : MHX_R(0.0);                 // this lane's first term stays in a register
+    const bool has_term = lane < np;
+    const mhx_real t0 = has_term ? tparams[lane] : MHX_R(0.0);                  // this lane's first term stays in a register
     const mhx_real npf = (mhx_real)np;
     mhx_u32 total_acc = 0u;
     auto bcast = [](const mhx_real v, const int j) -> mhx_real {                   // lane j's value, for every lane (j is wave-uniform)
@@ -1330,14 +1331,19 @@ MHX_DEV void mhx_rwmh_wave_body(const mhx_rwmh_args& a, const mhx_real* __restri
                 y0[k] = mhx_fma(s0, bcast(n[0], jj), x0);
                 y1[k] = mhx_fma(s1, bcast(n[1], jj), x1);
                 logu[k] = bcast(mylogu, jj);
-                // logdensity(model, candidate) (src/mh-core.jl:103): mhx_target_eval's IID_NORMAL expressions, the sum in shape 64
-                acc[k] = MHX_R(0.0);
-                if (lane < np) { const mhx_real z = (t0 - y0[k]) / y1[k]; acc[k] = mhx_fma(z, z, acc[k]); }
+                // logdensity(model, candidate) (src/mh-core.jl:103): mhx_target_eval's IID_NORMAL expressions, the sum in shape 64.
+                // (a SELECT, not a branch, for the lanes without a term: under `if (lane < np)` hipcc emits one exec-masked block per
+                // candidate and the K divisions run one after the other)
+                const mhx_real z = (t0 - y0[k]) / y1[k];
+                const mhx_real zz = mhx_fma(z, z, MHX_R(0.0));
+                acc[k] = has_term ? zz : MHX_R(0.0);
             }
-            for (int i = lane + 64; i < np; i += 64) {
-                const mhx_real ti = tparams[i];
+            if (np > 64) {                                                       // (wave-uniform) more terms than lanes
+                for (int i = lane + 64; i < np; i += 64) {
+                    const mhx_real ti = tparams[i];
 #pragma unroll
-                for (int k = 0; k < K; ++k) { const mhx_real z = (ti - y0[k]) / y1[k]; acc[k] = mhx_fma(z, z, acc[k]); }
+                    for (int k = 0; k < K; ++k) { const mhx_real z = (ti - y0[k]) / y1[k]; acc[k] = mhx_fma(z, z, acc[k]); }
+                }
             }
 #pragma unroll
             for (int k = 0; k < K; ++k) {
