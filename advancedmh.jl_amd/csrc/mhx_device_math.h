@@ -796,6 +796,18 @@ MHX_DEV mhx_real mhx_butterfly_add(const mhx_real q)
     return q + __shfl_xor(q, DIST, 64);
 #endif
 }
+// The value of lane ^ DIST for DIST = 1, 2, 4, 8 (DPP inside a row of 16 lanes); all lanes of the group must be active.
+template <int DIST>
+MHX_DEV mhx_real mhx_lane_xor(const mhx_real v)
+{
+#if MHX_REAL64
+    const mhx_u64 b = __builtin_bit_cast(mhx_u64, v);
+    const mhx_u32 lo = mhx_lane_xor_u32<DIST>((mhx_u32)b), hi = mhx_lane_xor_u32<DIST>((mhx_u32)(b >> 32));
+    return __builtin_bit_cast(double, (mhx_u64)lo | ((mhx_u64)hi << 32));
+#else
+    return __builtin_bit_cast(float, mhx_lane_xor_u32<DIST>(__builtin_bit_cast(mhx_u32, v)));
+#endif
+}
 // The value of lane ^ 1 (quad_perm:[1,0,3,2]); both lanes of a pair must be active.
 MHX_DEV mhx_real mhx_lane_swap1(const mhx_real v)
 {

@@ -1323,14 +1323,15 @@ MHX_DEV void mhx_rwmh_wave_body(const mhx_rwmh_args& a, const mhx_real* __restri
         // is what the sequential loop computes; the ones after it are discarded and re-done from the new state.  Acceptance is low
         // where this kernel runs (the README example: 6 %), so a round advances almost K steps for the latency of one.
         constexpr int K = 4;
+        const int kk = lane & 3;                                                 // the candidate whose SCALAR part this lane evaluates
+        const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
         for (int j = 0; j < nb;) {
-            mhx_real y0[K], y1[K], lpy[K], logu[K], acc[K];
+            mhx_real y0[K], y1[K], acc[K];
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const int jj = j + k < nb ? j + k : nb - 1;                      // (past the batch: a copy of its last step, never used)
                 y0[k] = mhx_fma(s0, bcast(n[0], jj), x0);
                 y1[k] = mhx_fma(s1, bcast(n[1], jj), x1);
-                logu[k] = bcast(mylogu, jj);
                 // logdensity(model, candidate) (src/mh-core.jl:103): mhx_target_eval's IID_NORMAL expressions, the sum in shape 64.
                 // (a SELECT, not a branch, for the lanes without a term: under `if (lane < np)` hipcc emits one exec-masked block per
                 // candidate and the K divisions run one after the other)
@@ -1345,26 +1346,38 @@ MHX_DEV void mhx_rwmh_wave_body(const mhx_rwmh_args& a, const mhx_real* __restri
                     for (int k = 0; k < K; ++k) { const mhx_real z = (ti - y0[k]) / y1[k]; acc[k] = mhx_fma(z, z, acc[k]); }
                 }
             }
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                acc[k] = mhx_butterfly<64>(acc[k]);
-                const mhx_real tt = mhx_log_sel(y1[k]) + MHX_HALF_LOG_2PI;       // (mhx_log's value, branch-free: the K logarithms interleave)
-                const mhx_real v = mhx_fma(-MHX_R(0.5), acc[k], -(npf * tt));
-                lpy[k] = (y1[k] > MHX_R(0.0)) ? v : -MHX_INF;                    // theta[2] >= 0 support, -Inf at sigma == 0; NaN: reject
-            }
-            // the first accepted step of the round (strict compare, src/mh-core.jl:108; NaN compares false), wave-uniform
-            int first = K;
-#pragma unroll
-            for (int k = K - 1; k >= 0; --k)
-                if (j + k < nb && logu[k] < (lpy[k] - lp)) first = k;
+            // The four butterflies as ONE, transposed: at offset 1 the even lane of a pair keeps candidate 0's (2's) sum and the odd
+            // lane candidate 1's (3's) -- each gives the partner the one it does not keep --, at offset 2 the pairs (0, 1) and (2, 3)
+            // merge the same way, offsets 4 .. 32 run on the one value left: 7 cross-lane steps instead of 24, and lane l ends with the
+            // total of candidate l & 3.  Every addition has the operands the plain butterfly of that candidate has at that lane (in
+            // either order: the same bits), so the totals are the shape-64 sums of the spec.  One wave alone on its SIMD issues an
+            // instruction every ~5 cycles whatever its class: what a round costs is its instruction count, hence this and the next step.
+            const mhx_real v01 = (b0 ? acc[1] : acc[0]) + mhx_lane_xor<1>(b0 ? acc[0] : acc[1]);
+            const mhx_real v23 = (b0 ? acc[3] : acc[2]) + mhx_lane_xor<1>(b0 ? acc[2] : acc[3]);
+            mhx_real tot = (b1 ? v23 : v01) + mhx_lane_xor<2>(b1 ? v01 : v23);
+            tot = mhx_butterfly_add<4>(tot);
+            tot = mhx_butterfly_add<8>(tot);
+            tot = mhx_butterfly_add<16>(tot);
+            tot = mhx_butterfly_add<32>(tot);
+            // ... and the scalar part of candidate l & 3 on lane l only (one logarithm per lane instead of four)
+            const int myj = j + kk;
+            const mhx_real my_y1 = kk == 0 ? y1[0] : (kk == 1 ? y1[1] : (kk == 2 ? y1[2] : y1[3]));
+            const mhx_real my_logu = __shfl(mylogu, myj < nb ? myj : nb - 1, 64);
+            const mhx_real tt = mhx_log_sel(my_y1) + MHX_HALF_LOG_2PI;           // (mhx_log's value, branch-free)
+            const mhx_real v = mhx_fma(-MHX_R(0.5), tot, -(npf * tt));
+            const mhx_real my_lpy = (my_y1 > MHX_R(0.0)) ? v : -MHX_INF;         // theta[2] >= 0 support, -Inf at sigma == 0; NaN: reject
+            // the first accepted step of the round (strict compare, src/mh-core.jl:108; NaN compares false): lanes 0 .. 3 speak for
+            // candidates 0 .. 3
+            const mhx_u32 okm = (mhx_u32)__ballot(myj < nb && my_logu < (my_lpy - lp)) & 0xfu;
+            const int first = okm ? (int)__builtin_ctz(okm) : K;                 // wave-uniform
             const int adv = first < K ? first + 1 : (nb - j < K ? nb - j : K);   // steps this round settles
             // lanes j .. j+adv-2 (rejections) record the old state, lane j+adv-1 the new one if it was an acceptance
             if (lane >= j && lane < j + adv) { rx0 = x0; rx1 = x1; rlp = lp; racc = false; }
             if (first < K) {
-                mhx_real a0 = y0[0], a1 = y1[0], al = lpy[0];
+                mhx_real a0 = y0[0], a1 = y1[0];
 #pragma unroll
-                for (int k = 1; k < K; ++k) { a0 = first == k ? y0[k] : a0; a1 = first == k ? y1[k] : a1; al = first == k ? lpy[k] : al; }
-                x0 = a0; x1 = a1; lp = al;
+                for (int k = 1; k < K; ++k) { a0 = first == k ? y0[k] : a0; a1 = first == k ? y1[k] : a1; }
+                x0 = a0; x1 = a1; lp = bcast(my_lpy, first);
                 nacc += 1u;
                 total_acc += 1u;
                 if (lane == j + first) { rx0 = x0; rx1 = x1; rlp = lp; racc = true; }
