@@ -1092,6 +1092,8 @@ def main():
     ap.add_argument("--fault-rccl-init", choices=["fail", "hang"], default=None, help="test hook of the BENCH (not of the library): the first "
                     "rung of the ladder fails / never answers")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="explicit engine option (mhx_ctx_set_option), repeatable")
+    ap.add_argument("--tools-lib", action="store_true", help="bind libmhx_tools.so (timing probes, fault injection: --opt EMCEE_PROBE=3 ...); "
+                    "a run with a probe option is tainted and the line says so")
     ap.add_argument("--dry-run", action="store_true", help="launcher + rendezvous + ladder + host-side combining only: no device, no engine")
     ap.add_argument("--no-other-configs", action="store_true", help="c2 at N=1: skip the C3 / C4 / C4-moving / C5 lines under `configs`")
     ap.add_argument("--no-e2e", action="store_true", help="c2 at N=1: skip the rate through the boundary (samples back on the host)")
@@ -1126,6 +1128,8 @@ def main():
     import torch
     import mhx
     from mhx.dist import allreduce_stats
+    if args.tools_lib:
+        mhx.use_library(mhx.TOOLS_LIB_PATH)
 
     ndev = torch.cuda.device_count()
     if ndev < 1:

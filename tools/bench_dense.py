@@ -12,6 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "advancedmh.jl_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import mhx  # noqa: E402
+import _opts
+_opts.bridge(mhx)                  # MHX_* variables of the command line -> explicit engine options (tools only)
 import cases  # noqa: E402
 
 C = int(os.environ.get("C", 65536))

@@ -11,6 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "advancedmh.jl_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import mhx  # noqa: E402
+import _opts
+_opts.bridge(mhx)                  # MHX_* variables of the command line -> explicit engine options (tools only)
 import user_targets  # noqa: E402
 
 for d in [int(x) for x in os.environ.get("DIMS", os.environ.get("D", "50")).split()]:

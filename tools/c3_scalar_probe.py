@@ -22,6 +22,8 @@ def sigma(d, rotated=True):
 
 def child(dt, mode, d, W):
     import mhx
+    import _opts
+    _opts.bridge(mhx)              # MHX_* variables of the command line -> explicit engine options (tools only)
     from oracle import oracle as O
     O.set_dtype(dt)
     Sig = sigma(d)

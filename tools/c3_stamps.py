@@ -12,7 +12,10 @@ import numpy as np
 os.environ["MHX_EMCEE_STAMPS"] = "1"
 fn = os.path.join(tempfile.gettempdir(), "mhx_stamps.bin")
 os.environ["MHX_EMCEE_STAMPS_FILE"] = fn
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import mhx
+import _opts
+_opts.bridge(mhx)                  # MHX_* variables of the command line -> explicit engine options (tools only)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 from c3_scalar_probe import sigma
 

@@ -9,7 +9,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DOMINANT = {"c2": ("rwmh_coop", "mhx_jit_rwmh_reg"), "c5": ("rwmh_coop",), "c3": ("mhx_jit_emcee_sweep", "emcee_half"), "c4": ("k_ram<",)}
+DOMINANT = {"c2": ("rwmh_coop", "mhx_jit_rwmh_reg"), "c5": ("rwmh_coop",), "c3": ("mhx_jit_emcee_sweep", "mhx_jit_emcee_mfma_sweep", "emcee_half"), "c4": ("k_ram<",)}
 
 
 def dominant(cfg, name):
@@ -25,6 +25,8 @@ def main(tags):
                 continue
             name = os.path.basename(d)                       # <tag>_<cfg>_<dtype>
             _, cfg, dt = name.rsplit("_", 2)
+            if cfg not in DOMINANT:                          # (another tool's directory under the same tag, e.g. r05_isa_c2)
+                continue
             sj = os.path.join(d, "summary.json")
             if not os.path.exists(sj):
                 continue
