@@ -340,6 +340,8 @@ tainted` -- how it ran (`mhx_stats`);  `n_chains, n_samples, sum_m, sum_m2, sum_
 chains).  For several processes: `v = pack_stats(st); allreduce_sum!(comm, v); unpack_stats(v, st)` gives the statistics of ALL
 chains (ONE all-reduce of 3(dim+1)+3 doubles over RCCL: the "global acceptance statistic and R-hat" of the design).
 """
+const HIPStats = NamedTuple
+
 function rhat_from_sums(sum_m, sum_m2, sum_v, C::Real, N::Real)
     W = sum_v ./ C
     Vm = max.((sum_m2 .- sum_m .* sum_m ./ C) ./ (C - 1), 0.0)
@@ -657,6 +659,6 @@ allreduce_sum!(comm::Ptr{Cvoid}, v::Vector{Float64}) =
     (check(ccall((:mhx_comm_allreduce_sum, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Csize_t), comm, v, length(v))); v)
 comm_destroy(comm::Ptr{Cvoid}) = ccall((:mhx_comm_destroy, libmhx), Cint, (Ptr{Cvoid},), comm)
 
-export MCMCHIP, HIPState, SampleTensor, LangevinProposal, IsoGaussian, CorrGaussian, IIDNormal, Banana, Funnel, HipSource, lower,
+export MCMCHIP, HIPState, HIPStats, SampleTensor, LangevinProposal, IsoGaussian, CorrGaussian, IIDNormal, Banana, Funnel, HipSource, lower,
        pack_stats, unpack_stats, allreduce_sum!, unique_id, comm_init, comm_destroy
 end # module
