@@ -1064,6 +1064,179 @@ int orc_ram(const orc_target *t, const orc_ram_cfg *cfg, const orc_schedule *s,
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* RAM with a DEFERRED factor: the same chain as orc_ram in exact arithmetic, another rounding.
+ * ram_adapt (src/RobustAdaptiveMetropolis.jl:153-173) updates  S S' <- S S' + sigma w w'  with  w = c S U,
+ * c^2 = eta |dalpha| / |U|^2, so  S_new = S M  with  M = chol(I + sigma c^2 U U')  -- lower triangular,
+ *     M_jj = a_j = sqrt(T_{j+1} / T_j),   M_ij = U_i g_j  (i > j),   g_j = sigma c^2 U_j / (T_j a_j),
+ *     T_j = 1 + sigma c^2 sum_{m<j} U_m^2
+ * and known from U and two scalars alone.  Up to K accepted updates stay PENDING as (a, g, u) triples:
+ *     proposal   x' = x + S_0 (M_1 (M_2 ... (M_m U)))          one read of the stored factor S_0, m prefix scans
+ *     flush      S_0 <- S_0 M_1 ... M_m                        one read + one write per K steps, column by column:
+ *                (S M)_rj = a_j S_rj + g_j sum_{i>j} S_ri u_i,  the suffix sum carried as  t_r - sum_{i<=j} S_ri u_i
+ *                with t = S u = the v of that step's proposal.
+ * Prefix sums over the <= 256 elements have the shape of the kernel's scan: 64 blocks of 4 consecutive elements
+ * (running fma inside a block), a Kogge-Stone scan over the 64 block totals.
+ * A flush happens when K updates are pending and after every transition listed in flush_at (ascending; the launch ends
+ * of the engine: the factor is whole in memory between launches).                                                      */
+#define DEFER_NB 64
+static void defer_scan_dot(const real *p, const real *q, int d, real *excl /* [257] */)
+{
+    real run[DEFER_NB][4], tot[DEFER_NB], nxt[DEFER_NB];
+    for (int b = 0; b < DEFER_NB; ++b) {
+        real r = R(0.0);
+        for (int e = 0; e < 4; ++e) {
+            const int j = 4 * b + e;
+            const real pj = j < d ? p[j] : R(0.0), qj = j < d ? q[j] : R(0.0);
+            r = e == 0 ? pj * qj : FMA(pj, qj, r);
+            run[b][e] = r;
+        }
+        tot[b] = r;
+    }
+    for (int s = 1; s < DEFER_NB; s <<= 1) {                 /* inclusive Kogge-Stone */
+        for (int b = 0; b < DEFER_NB; ++b) nxt[b] = b >= s ? tot[b - s] + tot[b] : tot[b];
+        memcpy(tot, nxt, sizeof tot);
+    }
+    for (int b = 0; b < DEFER_NB; ++b) {
+        const real E = b ? tot[b - 1] : R(0.0);
+        excl[4 * b] = E;
+        for (int e = 1; e < 4; ++e) excl[4 * b + e] = E + run[b][e - 1];
+    }
+    excl[4 * DEFER_NB] = tot[DEFER_NB - 1];
+}
+
+int orc_ram_deferred(const orc_target *t, const orc_ram_cfg *cfg, const orc_schedule *s,
+                     uint64_t seed, uint64_t first_chain, int nchains,
+                     const real *init, const real *S_in, real *S_out,
+                     real *samples, uint8_t *accepted, real *final_x, real *final_lp,
+                     uint32_t *accept_counts, uint8_t *status, real *diag_min, real *diag_max,
+                     int K, const int64_t *flush_at, int nflush)
+{
+    const int d = t->dim, C = nchains;
+    if (d > 4 * DEFER_NB || K < 1) return -1;
+    const size_t nS = (size_t)d * ((size_t)d + 1) / 2;
+    int64_t nT, nA;
+    orc_schedule_counts(s, &nT, &nA);
+    real *x = malloc(sizeof(real) * (size_t)d * 6);
+    real *y = x + d, *U = y + d, *v = U + d, *z = v + d, *dg = z + d;
+    real *S = malloc(sizeof(real) * nS);
+    real *pa = malloc(sizeof(real) * (size_t)K * d * 4);      /* pending a, g, u, t */
+    real *pg = pa + (size_t)K * d, *pu = pg + (size_t)K * d, *pt = pu + (size_t)K * d;
+    real PU[4 * DEFER_NB + 1], P[4 * DEFER_NB + 1], T[4 * DEFER_NB + 1];
+    const int default_bounds = (cfg->eig_lo == R(0.0) && isinf(cfg->eig_hi) && cfg->eig_hi > 0);
+    for (int c = 0; c < C; ++c) {
+        const uint64_t id = first_chain + (uint64_t)c;
+        uint8_t st = 0;
+        if (init) for (int k = 0; k < d; ++k) x[k] = init[(size_t)k * C + c];
+        else orc_normals(seed, id, 0, ORC_STREAM_INIT, d, x);
+        if (S_in) memcpy(S, S_in + (size_t)c * nS, sizeof(real) * nS);
+        else { memset(S, 0, sizeof(real) * nS); for (int i = 0; i < d; ++i) S[SIDX(i, i)] = R(1.0); }
+        for (int k = 0; k < d; ++k) dg[k] = S[SIDX(k, k)];        /* diag(S_0 M_1 ... M_m): the product of the diagonals */
+        real lp = orc_target_eval(t, x);
+        uint32_t nacc = 0;
+        if (diag_min) for (int k = 0; k < d; ++k) { diag_min[(size_t)k * C + c] = dg[k]; diag_max[(size_t)k * C + c] = dg[k]; }
+        real mg = (real)INFINITY;
+        real st_loga = R(0.0), st_eta = R(0.0);
+        int64_t slot = save_slot(s, 0);
+        if (slot >= 0) record(samples, accepted, slot, d, C, c, x, lp, 1);
+        margin_flush(&mg, slot, C, c);
+        if (slot >= 0 && g_logalpha) g_logalpha[(size_t)slot * C + c] = st_loga;
+        if (slot >= 0 && g_eta) g_eta[(size_t)slot * C + c] = st_eta;
+        int m = 0, fi = 0;
+        for (int64_t tau = 1; tau <= nT; ++tau) {
+            const uint32_t step = (uint32_t)tau;
+            orc_normals(seed, id, step, ORC_STREAM_PROPOSAL, d, U);
+            defer_scan_dot(U, U, d, PU);
+            const real nn = PU[4 * DEFER_NB];
+            memcpy(z, U, sizeof(real) * (size_t)d);
+            for (int i = m - 1; i >= 0; --i) {                      /* z = M_1 (... (M_m U)) */
+                const real *a = pa + (size_t)i * d, *g = pg + (size_t)i * d, *u = pu + (size_t)i * d;
+                defer_scan_dot(g, z, d, P);
+                for (int j = 0; j < d; ++j) z[j] = FMA(u[j], P[j], a[j] * z[j]);
+            }
+            for (int i = 0; i < d; ++i) {
+                real acc = R(0.0);
+                for (int j = 0; j <= i; ++j) acc = FMA(S[SIDX(i, j)], z[j], acc);
+                v[i] = acc;
+                y[i] = acc + x[i];
+            }
+            real lpy = orc_target_eval(t, y);
+            real diff = lpy - lp;
+            real loga = (diff != diff) ? diff : (diff < R(0.0) ? diff : R(0.0));
+            real logu = orc_accept_logu(seed, id, step);
+            int acc = logu < loga;
+            margin_note(&mg, logu, loga);
+            st_loga = loga;
+            if (tau <= nA) {
+                real da = orc_exp(loga) - cfg->alpha;
+                const real eta = (real)pow((double)step, -(double)cfg->gamma);
+                st_eta = eta;
+                if (da == da) {
+                    const real c2 = (eta * FABS(da)) / nn;
+                    const real sc = da > R(0.0) ? c2 : -c2;
+                    real *a = pa + (size_t)m * d, *g = pg + (size_t)m * d, *u = pu + (size_t)m * d, *tt = pt + (size_t)m * d;
+                    int ok = 1;
+                    for (int j = 0; j <= d; ++j) T[j] = FMA(sc, PU[j], R(1.0));
+                    for (int j = 0; j < d; ++j) if (!(T[j + 1] > R(0.0))) ok = 0;      /* the downdate left the PD cone */
+                    if (!ok) st |= 1;
+                    if (ok) {
+                        for (int j = 0; j < d; ++j) {
+                            a[j] = SQRT(T[j + 1] / T[j]);
+                            g[j] = (sc * U[j]) / (T[j] * a[j]);
+                            u[j] = U[j];
+                            tt[j] = v[j];
+                        }
+                        if (!default_bounds)
+                            for (int k = 0; k < d; ++k) {
+                                real e = dg[k] * a[k];
+                                if (!(cfg->eig_lo <= e && e <= cfg->eig_hi)) { ok = 0; break; }
+                            }
+                    }
+                    if (ok) { for (int k = 0; k < d; ++k) dg[k] = dg[k] * a[k]; ++m; }
+                } else {
+                    st |= 2;
+                }
+                if (diag_min) for (int k = 0; k < d; ++k) {
+                    real e = dg[k];
+                    if (e < diag_min[(size_t)k * C + c]) diag_min[(size_t)k * C + c] = e;
+                    if (e > diag_max[(size_t)k * C + c]) diag_max[(size_t)k * C + c] = e;
+                }
+            }
+            int forced = 0;
+            while (fi < nflush && flush_at[fi] < tau) ++fi;
+            if (fi < nflush && flush_at[fi] == tau) forced = 1;
+            if (tau == nT || tau == nA) forced = 1;
+            if (m == K || (forced && m > 0)) {                      /* S_0 <- S_0 M_1 ... M_m */
+                for (int r = 0; r < d; ++r)
+                    for (int j = 0; j <= r; ++j) {
+                        real cc = S[SIDX(r, j)];
+                        for (int i = 0; i < m; ++i) {
+                            const real a = pa[(size_t)i * d + j], g = pg[(size_t)i * d + j], u = pu[(size_t)i * d + j];
+                            real *tt = pt + (size_t)i * d;
+                            if (r == j) cc = a * cc;
+                            else { tt[r] = FMA(-u, cc, tt[r]); cc = FMA(g, tt[r], a * cc); }
+                        }
+                        S[SIDX(r, j)] = cc;
+                    }
+                m = 0;
+            }
+            if (acc) { memcpy(x, y, sizeof(real) * (size_t)d); lp = lpy; ++nacc; }
+            slot = save_slot(s, tau);
+            if (slot >= 0) record(samples, accepted, slot, d, C, c, x, lp, acc);
+            margin_flush(&mg, slot, C, c);
+            if (slot >= 0 && g_logalpha) g_logalpha[(size_t)slot * C + c] = st_loga;
+            if (slot >= 0 && g_eta) g_eta[(size_t)slot * C + c] = st_eta;
+        }
+        if (final_x) for (int k = 0; k < d; ++k) final_x[(size_t)k * C + c] = x[k];
+        if (final_lp) final_lp[c] = lp;
+        if (accept_counts) accept_counts[c] = nacc;
+        if (status) status[c] = st;
+        if (S_out) memcpy(S_out + (size_t)c * nS, S, sizeof(real) * nS);
+    }
+    free(x); free(S); free(pa);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* gradients of the catalogue targets (what ForwardDiff / LogDensityProblems.logdensity_and_gradient
  * supply to the reference's MALA, src/MALA.jl:73-75, ext/AdvancedMHForwardDiffExt.jl:13-17)     */
 real orc_target_grad(const orc_target *t, const real *x, real *g, orc_logdensity_grad_fn user)

@@ -390,6 +390,45 @@ def ram(target, sched, seed, first_chain, nchains, init=None, S_in=None, alpha=0
 
 
 
+def ram_flush_points(n_transitions, n_adapt=None, max_launch=4096):
+    """the transitions after which the engine's deferred-factor RAM kernel folds its pending updates into the stored factor
+    besides `K pending`: the ends of its launches (a sampling call is cut into launches of `max_launch` transitions,
+    csrc/mhx_api_ram.inc MHX_RAM_MAX_STEPS_PER_LAUNCH) -- the end of the warm-up and of the call are flush points by themselves"""
+    return list(range(max_launch, n_transitions, max_launch))
+
+
+def ram_deferred(target, sched, seed, first_chain, nchains, init=None, S_in=None, alpha=0.234, gamma=0.6,
+                 eig_lo=0.0, eig_hi=float("inf"), save=True, K=8, flush_at=None):
+    """the twin of MHX_FLAG_RAM_DEFERRED (orc_ram_deferred): `ram` in exact arithmetic, its own rounding"""
+    d, N, Cn = target.dim, sched.n_samples, nchains
+    nS = d * (d + 1) // 2
+    cfg = _T("RamCfg")(alpha, gamma, eig_lo, eig_hi)
+    samples = np.empty((N, d + 1, Cn), dtype=real()) if save else None
+    accepted = np.empty((N, Cn), dtype=np.uint8) if save else None
+    fx = np.empty((d, Cn), dtype=real())
+    flp = np.empty(Cn, dtype=real())
+    cnt = np.empty(Cn, dtype=np.uint32)
+    status = np.empty(Cn, dtype=np.uint8)
+    S_out = np.empty((Cn, nS), dtype=real())
+    dmin = np.empty((d, Cn), dtype=real())
+    dmax = np.empty((d, Cn), dtype=real())
+    if init is not None:
+        init = np.ascontiguousarray(init, dtype=real())
+    if S_in is not None:
+        S_in = np.ascontiguousarray(S_in, dtype=real())
+        assert S_in.shape == (Cn, nS)
+    fl = np.ascontiguousarray(flush_at if flush_at is not None else [], dtype=np.int64)
+    f = lib().orc_ram_deferred
+    f.restype = C.c_int
+    rc = f(C.byref(target.c), C.byref(cfg), C.byref(sched), C.c_uint64(seed),
+           C.c_uint64(first_chain), C.c_int(Cn), _fp(init), _fp(S_in), _fp(S_out), _fp(samples),
+           _u8p(accepted), _fp(fx), _fp(flp), _u32p(cnt), _u8p(status), _fp(dmin), _fp(dmax),
+           C.c_int(K), fl.ctypes.data_as(C.c_void_p), C.c_int(len(fl)))
+    assert rc == 0
+    return dict(samples=samples, accepted=accepted, final_x=fx, final_lp=flp, accept_counts=cnt,
+                status=status, S=S_out, diag_min=dmin, diag_max=dmax)
+
+
 def mt_rwmh(target, prop, sched, seed, first_chain, nchains, nthreads, save=True, init1=None):
     """bench.py's CPU baseline (oracle/mhx_oracle_mt.c): `nchains` independent chains on `nthreads` POSIX threads, each chain
     one orc_rwmh call with its own contiguous [N][d+1] record.  Returns (wall seconds, per-thread CPU seconds)."""
