@@ -229,7 +229,7 @@ static const opt_name k_opt_names[] = {
     {"EMCEE_REC_STORE", 0}, {"EMCEE_ROW_STORE", 0}, {"EMCEE_COOP_REC", 0},
 #ifdef MHX_TOOLS_BUILD
     {"ZIG_PROBE", 1}, {"ZIG_FORCE_FAIL", 1}, {"JIT_DEFS", 1}, {"EMCEE_PROBE", 1}, {"EMCEE_STAMPS", 1}, {"EMCEE_STAMPS_FILE", 1},
-    {"FAULT_SLAB", 1},
+    {"FAULT_SLAB", 1}, {"RAM_PROF", 1},
 #endif
 };
 static const opt_name* opt_find(const char* name)
@@ -691,6 +691,8 @@ struct mhx_run : mhx_handle_hdr {
     mhx_real *d_dmin = nullptr, *d_dmax = nullptr;  // [dim][n]
     mhx_real* d_eta = nullptr;                      // adaptation step sizes of the current launch
     mhx_real* d_loga = nullptr;                     // [n] log acceptance ratio of each chain's latest transition
+    mhx_real* d_defer = nullptr;                    // RAM, deferred-factor form: [n][MHX_RAM_DEFER_REALS] pending updates
+    int defer_R = 0;                                // rows per lane of that form's kernel (0: the sweep form)
     double last_eta = 0.0;                          // step size of the latest adapting transition (state.η; 0 before any)
     mhx_real* d_rec_loga = nullptr;                 // [n_saved][n] logα of every recorded transition of the last sampling call
     mhx_real* rec_loga_view = nullptr;              // where slot 0 of the current launches lands in it (slab-wise calls)
@@ -750,7 +752,7 @@ struct mhx_run : mhx_handle_hdr {
     {
         void* ptrs[] = {d_pvec, d_S, d_Ssel, d_status, d_dmin, d_dmax, d_eta, d_x, d_lp, d_ybuf,
                         d_acc, d_last, d_acc_total, d_samples, d_accepted, d_mom_mean, d_mom_m2, d_gx, d_gy, d_z, d_pmean, d_qx, d_xw, d_loga, d_mfma_img, d_rec_loga,
-                        d_watch_chains, d_watch, d_xw2, d_lp2};
+                        d_watch_chains, d_watch, d_xw2, d_lp2, d_defer};
         for (void* p : ptrs) if (p) (void)hipFree(p);
     }
 };

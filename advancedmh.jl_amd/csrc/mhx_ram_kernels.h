@@ -42,6 +42,8 @@ struct mhx_ram_args {
                               // callback would have seen after that step, test/RobustAdaptiveMetropolis.jl:11-28)
     const mhx_real* eta;         // [nsteps] adaptation step sizes iteration^-gamma of this launch
     const mhx_real* acol;        // CORR_GAUSS target: inv(chol(Sigma)) packed column-major lower
+    mhx_real* defer;             // deferred-factor form only: [nchains][MHX_RAM_DEFER_REALS] pending updates of each chain
+    int prof;                    // tools build, deferred-factor form: block 0 prints its cycles per phase
     mhx_u64 seed;
     mhx_u64 first_chain;
     int nchains;
@@ -574,12 +576,453 @@ MHX_DEV void mhx_ram_init_body(const mhx_ram_args& a, const mhx_real* __restrict
     a.loga[c] = MHX_R(0.0);         // RAM.jl:211: RobustAdaptiveMetropolisState(x, lp, S, zero(T), 0, 1, true)
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The DEFERRED-FACTOR form (MHX_FLAG_RAM_DEFERRED; arithmetic spec DESIGN.md 3.13, which also names the CPU twin the tests compare it with).
+// ram_adapt (RAM.jl:153-173) moves  S S' <- S S' + sigma w w',  w = c S U,  c^2 = eta |dalpha| / |U|^2:  S_new = S M  with
+// M = chol(I + sigma c^2 U U'), a lower-triangular factor known from U and two scalars alone
+//     M_jj = a_j = sqrt(T_{j+1} / T_j),   M_ij = U_i g_j (i > j),   g_j = sigma c^2 U_j / (T_j a_j),   T_j = 1 + sigma c^2 sum_{m<j} U_m^2.
+// Up to K accepted updates stay PENDING as (a, g, u) triples in a per-chain scratch (L2 / MALL resident):
+//     proposal   v = S_0 (M_1 (... (M_m U)))     ONE read of the stored factor, m prefix scans over d elements
+//     flush      S_0 <- S_0 M_1 ... M_m           one read + one write per K steps -- columns ascending through the same LDS ring,
+//                the K stages pipelined per column:  (S M)_rj = a_j S_rj + g_j (t_r - sum_{i<=j} S_ri u_i),  t = S u = the v of that
+//                step's proposal; the next step's mat-vec rides on the new columns as in the sweep above.
+// An adapting step moves (K + 1) / K reads + 1 / K writes of S instead of 1 + 1.  One chain per wave (G = 64), dim <= 256.
+// Element layout of the O(d) vectors ("layout 4"): lane b owns elements 4b .. 4b+3 = Philox block b of the step's noise; prefix sums
+// are a running fma inside the lane + a Kogge-Stone scan over the 64 lane totals.
+#ifndef MHX_RAM_DEFER_K
+#define MHX_RAM_DEFER_K 8
+#endif
+// per-chain scratch, in reals: [K slots][256 elements] (a, g, u, -) -- a slot is written in one coalesced piece (lane b: its four
+// elements, 128 B), read back the same way by the prefix applications, and gathered K x 64/K columns at a time by the fold --
+// then [K][R][64] the suffix vectors t
+#define MHX_RAM_DEFER_CF(K) ((K) * 256 * 4)
+#define MHX_RAM_DEFER_REALS(K, R) (MHX_RAM_DEFER_CF(K) + (K) * (R) * 64)
+// LDS of the fold's coefficient staging: two groups of 64 (a, g, u, -) entries = 64 / K columns each
+#define MHX_RAM_DEFER_STAGE 512
+
+MHX_DEV mhx_real mhx_shfl_up(const mhx_real x, const int s) { return __shfl_up(x, s, 64); }
+
+// exclusive prefix of p_j q_j at the lane's four elements, and the lane's inclusive total (== the exclusive prefix of element 4b+4)
+MHX_DEV void mhx_scan_dot4(const mhx_real (&p)[4], const mhx_real (&q)[4], const int lane, mhx_real (&ex)[4], mhx_real& incl)
+{
+    const mhx_real r0 = p[0] * q[0];
+    const mhx_real r1 = mhx_fma(p[1], q[1], r0);
+    const mhx_real r2 = mhx_fma(p[2], q[2], r1);
+    const mhx_real r3 = mhx_fma(p[3], q[3], r2);
+    mhx_real t = r3;
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) {
+        const mhx_real o = mhx_shfl_up(t, sft);
+        t = lane >= sft ? o + t : t;
+    }
+    mhx_real E = mhx_shfl_up(t, 1);
+    E = lane ? E : MHX_R(0.0);
+    incl = t;
+    ex[0] = E; ex[1] = E + r0; ex[2] = E + r1; ex[3] = E + r2;
+}
+
+// the K-stage column pipeline of a flush; s[k] = the running suffix vector of stage k (rows this lane owns)
+template <int R, int K>
+struct mhx_ram_flush_f {
+    const mhx_real* lds;      // wave-uniform
+    int ring;                 // mhx_real offset of the ring
+    int unext;                // mhx_real offset of next step's noise
+    mhx_srd srd;
+    mhx_u32 vbase;            // byte offset of row tg of the chain's new buffer
+    int tg;
+    int m;                    // pending updates (wave-uniform)
+    const mhx_f4* coef;       // [K][256] (a, g, u, -) of this chain
+    mhx_f4* stage;            // LDS, wave-uniform: [2][64] entries -- the coefficients of 64 / K columns per half, loaded a group ahead
+    mhx_f4 pre;               // this lane's entry of the next group
+    mhx_real s[K][R];
+    mhx_real vn[R];           // next step's S_new U'
+    static constexpr int CG = 64 / K;
+    MHX_DEV void prefetch(const int i) { pre = coef[(tg / CG) * 256 + i + (tg & (CG - 1))]; }   // entry tg of the group: slot tg / CG, column i + tg % CG
+    template <int IR>
+    MHX_DEV void col(const int il, const int i, const int roff, const int off)
+    {
+        if ((il & (CG - 1)) == 0) {                                  // wave-uniform: a new group of columns
+            // slots that hold no pending update are the identity (a = 1, g = u = 0: an exact no-op on the column and on s = 0)
+            if (tg / CG >= m) { pre.x = MHX_R(1.0); pre.y = MHX_R(0.0); pre.z = MHX_R(0.0); }
+            stage[((i / CG) & 1) * 64 + tg] = pre;
+            if (i + CG < 256) prefetch(i + CG);
+            MHX_WAVE_SYNC();
+        }
+        const mhx_real* cp = lds + (ring + tg + (roff - il));
+        const bool lo = tg >= il;
+        const bool ondiag = tg == il;
+        mhx_real c[R];
+        c[IR] = lo ? cp[0] : MHX_R(0.0);
+#pragma unroll
+        for (int r = IR + 1; r < R; ++r) c[r] = cp[64 * (r - IR)];
+        const mhx_f4* cf = stage + (((i / CG) & 1) * 64 + (i & (CG - 1)));                 // slot k of this column: cf[k CG]
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            {
+                const mhx_f4 q = cf[k * CG];
+                const mhx_real ak = q.x, gk = q.y, nu = -q.z;
+                {
+                    const mhx_real ac = ak * c[IR];
+                    s[k][IR] = mhx_fma(nu, c[IR], s[k][IR]);
+                    const mhx_real t = mhx_fma(gk, s[k][IR], ac);
+                    c[IR] = ondiag ? ac : t;
+                }
+#pragma unroll
+                for (int r = IR + 1; r < R; ++r) {
+                    const mhx_real ac = ak * c[r];
+                    s[k][r] = mhx_fma(nu, c[r], s[k][r]);
+                    c[r] = mhx_fma(gk, s[k][r], ac);
+                }
+            }
+        }
+        const mhx_real un = lds[unext + i];
+        const mhx_u32 voff = vbase + MHX_RB * (mhx_u32)(off - i);
+        if (lo) mhx_srd_store(srd, voff + MHX_RB * 64 * IR, 0u, c[IR]);
+        vn[IR] = mhx_fma(lo ? c[IR] : MHX_R(0.0), un, vn[IR]);
+#pragma unroll
+        for (int r = IR + 1; r < R; ++r) {
+            mhx_srd_store(srd, voff + MHX_RB * 64 * r, 0u, c[r]);
+            vn[r] = mhx_fma(c[r], un, vn[r]);
+        }
+    }
+};
+
+// the noise of `step` in layout 4 (lane b: Philox block b), its prefix sums of squares, and a copy in the chain's LDS vector
+struct mhx_ram_noise4 {
+    mhx_real u[4], pu[4], incl, nn;
+};
+MHX_DEV void mhx_ram_draw4(const mhx_philox_key& ks, mhx_u32 id_lo, mhx_u32 id_hi, mhx_u32 step, const int d, const int lane,
+                           mhx_ram_noise4& o)
+{
+    const int nblk = (d + 3) >> 2;
+    mhx_real n[4] = {MHX_R(0.0), MHX_R(0.0), MHX_R(0.0), MHX_R(0.0)};
+    if (lane < nblk) mhx_normal4(ks, id_lo, id_hi, step, MHX_STREAM_PROPOSAL, (mhx_u32)lane, n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o.u[e] = 4 * lane + e < d ? n[e] : MHX_R(0.0);
+    mhx_scan_dot4(o.u, o.u, lane, o.pu, o.incl);
+    o.nn = mhx_readlane(o.incl, 63);
+}
+
+template <int R, int K, int TK>
+#ifdef MHX_TOOLS_BUILD                                             // (tools build: block 0 prints its cycles per phase)
+#define MHX_RAM_DEFER_PROF 1
+#define MHX_PROF_T(k) do { const mhx_u64 now_ = __builtin_readcyclecounter(); prof_[k] += now_ - prof_t_; prof_t_ = now_; } while (0)
+#else
+#define MHX_PROF_T(k) do { } while (0)
+#endif
+MHX_DEV void mhx_ram_defer_body(const mhx_ram_args& a, const mhx_real* __restrict__ tparams, mhx_real* lds)
+{
+    constexpr int G = 64;
+    const int RINGS = mhx_ram_rings(MHX_RAM_RING(G, R), a.dim);
+    const int nb = gridDim.x;
+    const int per = (nb + 7) >> 3;
+    const long c = (long)(blockIdx.x & 7u) * per + (long)(blockIdx.x >> 3);
+    if (c >= a.nchains) return;
+    const int lane = threadIdx.x;
+    const int tg = lane;
+    const int d = a.dim;
+    const long ld = a.ld;
+    const long tri_pad = mhx_ram_tri_pad(d);
+    const mhx_u64 id = a.first_chain + (mhx_u64)c;
+    const mhx_u32 id_lo = (mhx_u32)id, id_hi = (mhx_u32)(id >> 32);
+    const mhx_philox_key ks = mhx_philox_schedule(a.seed);
+    const int ring = 0;
+    const int vec = RINGS;                       // the chain's one LDS vector: z, then the candidate / target scratch, then a, then U'
+    const mhx_srd srd = mhx_make_srd(a.S + c * 2 * tri_pad, (mhx_u32)(2 * tri_pad * MHX_RB));
+    const mhx_srd srd_a = mhx_make_srd(a.acol, (mhx_u32)(tri_pad * MHX_RB));
+    mhx_real* scratch = a.defer + c * (long)MHX_RAM_DEFER_REALS(K, R);
+    mhx_f4* coef = (mhx_f4*)scratch;                                   // [K][256] (a, g, u, -)
+    mhx_real* svec = scratch + MHX_RAM_DEFER_CF(K);                    // [K][R][64]
+    mhx_f4* stage = (mhx_f4*)(lds + RINGS + mhx_ram_mirror(d));
+    const bool has_blk = lane < ((d + 3) >> 2);                        // this lane's four elements hold part of the vector
+    const bool in_vec = 4 * lane < mhx_ram_mirror(d);                  // this lane's four elements lie inside the LDS vector
+
+    int sel = a.sel[c];
+    mhx_real x[R], dmn[R], dmx[R], dg[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int row = tg + G * r;
+        x[r] = row < d ? a.x[(long)row * ld + c] : MHX_R(0.0);
+        dmn[r] = row < d ? a.dmin[(long)c * d + row] : MHX_R(0.0);
+        dmx[r] = row < d ? a.dmax[(long)c * d + row] : MHX_R(0.0);
+        dg[r] = row < d ? a.S[(2 * c + sel) * tri_pad + mhx_ram_col_off(row, d)] : MHX_R(1.0);
+    }
+    mhx_real lp = a.lp[c];
+    mhx_u32 nacc = a.acc_count[c];
+    mhx_u32 wave_acc = 0;
+    bool last = a.last_acc[c] != 0;
+    unsigned st = a.status[c];
+    mhx_accept_cache ac;
+    ac.group = 0xffffffffu;
+    ac.w.x = ac.w.y = ac.w.z = ac.w.w = 0u;
+    mhx_u32 save_next = a.save_next;
+    long slot = a.save_slot;
+    mhx_real loga_last = a.loga[c];
+    bool have_v = false;
+    int m = 0;                                   // pending updates
+    mhx_real v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = MHX_R(0.0);
+    mhx_ram_noise4 nz;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) nz.u[e] = nz.pu[e] = MHX_R(0.0);
+    nz.incl = nz.nn = MHX_R(0.0);
+
+#ifdef MHX_TOOLS_BUILD
+    mhx_u64 prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    mhx_u64 prof_t_ = __builtin_readcyclecounter();
+#endif
+    for (int it = 0; it < a.nsteps; ++it) {
+        const mhx_u32 step = a.step0 + (mhx_u32)it;
+        const mhx_u32 scur = (mhx_u32)(sel * tri_pad * MHX_RB);
+        MHX_PROF_T(7);
+
+        // ---- U = randn(d), z = M_1 (... (M_m U)), v = S_0 z, x' = v + x
+        if (!have_v) {
+            // the pending factors, newest first, in batches of four: the loads of a batch are in flight together (and under the draw)
+            mhx_f4 qe[4][4];                                             // [slot of the batch][element]: (a, g, u, -)
+            const int top = m - 1;
+            if (m > 0) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // this wave's own stores of earlier steps
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { qe[t][e].x = MHX_R(1.0); qe[t][e].y = qe[t][e].z = qe[t][e].w = MHX_R(0.0); }
+                if (top - t >= 0 && has_blk) {
+                    const mhx_f4* q = coef + ((top - t) * 256 + 4 * lane);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) qe[t][e] = q[e];
+                }
+            }
+            mhx_ram_draw4(ks, id_lo, id_hi, step, d, lane, nz);
+            mhx_real z[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) z[e] = nz.u[e];
+            for (int base = top; base >= 0; base -= 4) {               // wave-uniform
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (base - t >= 0) {
+                        const mhx_real aa[4] = {qe[t][0].x, qe[t][1].x, qe[t][2].x, qe[t][3].x};
+                        const mhx_real gg[4] = {qe[t][0].y, qe[t][1].y, qe[t][2].y, qe[t][3].y};
+                        const mhx_real uu[4] = {qe[t][0].z, qe[t][1].z, qe[t][2].z, qe[t][3].z};
+                        mhx_real P[4], tot;
+                        mhx_scan_dot4(gg, z, lane, P, tot);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) z[e] = mhx_fma(uu[e], P[e], aa[e] * z[e]);
+                    }
+                }
+                if (base - 4 >= 0) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        if (base - 4 - t >= 0 && has_blk) {
+                            const mhx_f4* q = coef + ((base - 4 - t) * 256 + 4 * lane);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) qe[t][e] = q[e];
+                        }
+                    }
+                }
+            }
+            MHX_WAVE_SYNC();
+            if (in_vec) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) lds[vec + 4 * lane + e] = z[e];
+            }
+            MHX_PROF_T(0);
+            mhx_ram_matvec<G, R, false>(srd, scur, vec, d, lane, lds, v);
+            MHX_PROF_T(1);
+        }
+        const mhx_real eta = it < a.n_adapt ? a.eta[it] : MHX_R(0.0);      // asked for a whole log-density early
+        mhx_real y[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = tg + G * r;
+            y[r] = v[r] + x[r];
+            if (row < d) lds[vec + row] = y[r];
+        }
+        MHX_WAVE_SYNC();
+
+        // ---- lp' = logdensity(x')
+        mhx_real lpy;
+        const int kind = (TK == MHX_TARGET_DYNAMIC) ? a.target_kind : TK;
+        if (kind == MHX_TARGET_CORR_GAUSS) {
+            mhx_real wv[R];
+            mhx_ram_matvec<G, R, true>(srd_a, 0u, vec, d, lane, lds, wv);
+            MHX_WAVE_SYNC();
+#pragma unroll
+            for (int r = 0; r < R; ++r) if (tg + G * r < d) lds[vec + tg + G * r] = wv[r];
+            MHX_WAVE_SYNC();
+            mhx_real q = MHX_R(0.0);
+            for (int j = 0; j < d; ++j) { const mhx_real w = lds[vec + j]; q = mhx_fma(w, w, q); }
+            lpy = mhx_fma(-MHX_R(0.5), q, a.tconst);
+        } else {
+            mhx_lds_x yv;
+            yv.lds = lds; yv.off = vec;
+            lpy = mhx_target_eval<TK>(kind, yv, d, tparams, a.ntparams, a.tconst);
+        }
+
+        MHX_PROF_T(2);
+        // ---- accept
+        const mhx_real diff = lpy - lp;
+        const mhx_real loga = (diff != diff) ? diff : (diff < MHX_R(0.0) ? diff : MHX_R(0.0));
+        const mhx_real logu = mhx_accept_logu(ks, id_lo, id_hi, step, ac);
+        const bool acc = logu < loga;
+        loga_last = loga;
+
+        // ---- adapt: the update becomes pending
+        have_v = false;
+        if (it < a.n_adapt) {
+            const mhx_real da = mhx_exp(loga) - a.alpha;
+            const bool adapt = da == da;
+            if (!adapt) st |= 2u;
+            const mhx_real c2 = (eta * mhx_abs(da)) / nz.nn;
+            const mhx_real sc = da > MHX_R(0.0) ? c2 : -c2;
+            mhx_real aa[4], gg[4];
+            bool bad = false;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const mhx_real T0 = mhx_fma(sc, nz.pu[e], MHX_R(1.0));
+                const mhx_real T1 = mhx_fma(sc, e < 3 ? nz.pu[e < 3 ? e + 1 : 3] : nz.incl, MHX_R(1.0));
+                const bool in = 4 * lane + e < d;
+                if (in && !(T1 > MHX_R(0.0))) bad = true;
+                const mhx_real ae = mhx_sqrt(T1 / T0);
+                aa[e] = in ? ae : MHX_R(1.0);
+                gg[e] = in ? (sc * nz.u[e]) / (T0 * ae) : MHX_R(0.0);
+            }
+            bool ok = adapt && __ballot(bad) == 0ull;
+            if (adapt && !ok) st |= 1u;
+            // a in the row layout: through the LDS vector (the target is done with it)
+            MHX_WAVE_SYNC();
+            if (in_vec) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) lds[vec + 4 * lane + e] = aa[e];
+            }
+            MHX_WAVE_SYNC();
+            mhx_real nd[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) nd[r] = tg + G * r < d ? dg[r] * lds[vec + tg + G * r] : dg[r];
+            if (!a.default_bounds) {
+                bool out = false;
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (tg + G * r < d && !(a.eig_lo <= nd[r] && nd[r] <= a.eig_hi)) out = true;
+                if (__ballot(out) != 0ull) ok = false;
+            }
+            if (ok) {                                                    // wave-uniform
+                if (has_blk) {
+                    mhx_f4* q = coef + (m * 256 + 4 * lane);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        mhx_f4 c4;
+                        c4.x = aa[e]; c4.y = gg[e]; c4.z = nz.u[e]; c4.w = MHX_R(0.0);
+                        q[e] = c4;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    svec[(m * R + r) * 64 + tg] = v[r];
+                    dg[r] = nd[r];
+                    dmn[r] = nd[r] < dmn[r] ? nd[r] : dmn[r];
+                    dmx[r] = nd[r] > dmx[r] ? nd[r] : dmx[r];
+                }
+                ++m;                                                     // (the scratch is re-read by other lanes of this wave: fences at the reads)
+            }
+            MHX_PROF_T(3);
+            const bool at_end = it + 1 == a.n_adapt || it + 1 == a.nsteps;
+            if (m == K || (at_end && m > 0)) {
+                // ---- flush: S_0 <- S_0 M_1 ... M_m into the other buffer, the next step's mat-vec on the way
+                const bool fuse = it + 1 < a.nsteps;
+                MHX_WAVE_SYNC();
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                mhx_ram_noise4 nx;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) nx.u[e] = nx.pu[e] = MHX_R(0.0);
+                nx.incl = nx.nn = MHX_R(0.0);
+                if (fuse) mhx_ram_draw4(ks, id_lo, id_hi, step + 1u, d, lane, nx);
+                if (in_vec) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) lds[vec + 4 * lane + e] = nx.u[e];
+                }
+                mhx_ram_flush_f<R, K> fl;
+                fl.lds = lds; fl.ring = ring; fl.unext = vec; fl.srd = srd; fl.tg = tg; fl.m = m; fl.coef = coef; fl.stage = stage;
+                fl.prefetch(0);
+                fl.vbase = (mhx_u32)(((sel ^ 1) * tri_pad + tg) * MHX_RB);
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+#pragma unroll
+                    for (int r = 0; r < R; ++r) fl.s[k][r] = k < m ? svec[(k * R + r) * 64 + tg] : MHX_R(0.0);
+#pragma unroll
+                for (int r = 0; r < R; ++r) fl.vn[r] = MHX_R(0.0);
+                mhx_ram_stream<G, MHX_RAM_NV(R), MHX_RAM_MIRF(G, R)> stream;
+                stream.begin(srd, scur, d, tg, lds, ring);
+                mhx_ram_cols<G, R, 0>::run(stream, d, 0, fl);
+                sel ^= 1;
+                m = 0;
+                MHX_PROF_T(4);
+                if (fuse) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) v[r] = fl.vn[r];
+                    nz = nx;
+                    have_v = true;
+                }
+            }
+        }
+
+        // ---- state select
+#pragma unroll
+        for (int r = 0; r < R; ++r) x[r] = acc ? y[r] : x[r];
+        lp = acc ? lpy : lp;
+        nacc += acc ? 1u : 0u;
+        last = acc;
+        wave_acc += acc && tg == 0 ? 1u : 0u;
+        if (step == save_next) {
+            mhx_real* rowp = a.samples + slot * (long)(d + 1) * ld + c;
+#pragma unroll
+            for (int r = 0; r < R; ++r) if (tg + G * r < d) rowp[(long)(tg + G * r) * ld] = x[r];
+            if (tg == 0) {
+                rowp[(long)d * ld] = lp;
+                a.accepted[slot * ld + c] = acc ? 1 : 0;
+                if (a.rec_loga) a.rec_loga[slot * ld + c] = loga;
+            }
+            save_next += (mhx_u32)a.thinning;
+            ++slot;
+        }
+        MHX_WAVE_SYNC();
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int row = tg + G * r;
+        if (row < d) {
+            a.x[(long)row * ld + c] = x[r];
+            a.dmin[(long)c * d + row] = dmn[r];
+            a.dmax[(long)c * d + row] = dmx[r];
+        }
+    }
+    if (tg == 0) {
+        a.lp[c] = lp;
+        a.acc_count[c] = nacc;
+        a.last_acc[c] = last ? 1 : 0;
+        a.sel[c] = (unsigned char)sel;
+        a.status[c] = (unsigned char)st;
+        a.loga[c] = loga_last;
+        atomicAdd(a.acc_total, (mhx_u64)wave_acc);
+    }
+#ifdef MHX_TOOLS_BUILD
+    MHX_PROF_T(7);
+    if (blockIdx.x == 0 && lane == 0 && a.prof)
+        printf("defer prof (cycles, block 0, %d steps): draw+apply %llu  matvec %llu  target %llu  adapt %llu  fold %llu  other %llu\n", a.nsteps,
+               prof_[0], prof_[1], prof_[2], prof_[3], prof_[4], prof_[7]);
+#endif
+}
+
 #ifdef MHX_JIT_RAM
 extern "C" __global__ void __launch_bounds__(64)
 mhx_jit_ram(const mhx_ram_args a, const mhx_real* __restrict__ tparams)
 {
     extern __shared__ mhx_real mhx_ram_lds[];
+#ifdef MHX_JIT_DEFER_K
+    mhx_ram_defer_body<MHX_JIT_R, MHX_JIT_DEFER_K, MHX_JIT_TK>(a, tparams, mhx_ram_lds);
+#else
     mhx_ram_body<MHX_JIT_G, MHX_JIT_R, MHX_JIT_TK>(a, tparams, mhx_ram_lds);
+#endif
 }
 extern "C" __global__ void __launch_bounds__(256)
 mhx_jit_ram_init(const mhx_ram_args a, const mhx_real* __restrict__ tparams, const int draw)

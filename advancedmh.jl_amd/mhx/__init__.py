@@ -1,5 +1,5 @@
 """mhx -- Python host mirror of the AdvancedMH.jl API over libmhx.so (MI355X / gfx950 HIP kernels)."""
-from ._lib import (ArgumentError, Context, MhxError, PosDefException, FLAG_GENERIC, FLAG_NO_JIT, FLAG_EMCEE_SEQUENTIAL, FLAG_ZIGGURAT, FLAG_DENSE_FACTOR, LIB_PATH,
+from ._lib import (ArgumentError, Context, MhxError, PosDefException, FLAG_GENERIC, FLAG_NO_JIT, FLAG_EMCEE_SEQUENTIAL, FLAG_ZIGGURAT, FLAG_DENSE_FACTOR, FLAG_RAM_DEFERRED, LIB_PATH,
                    EXPORTS, MHX_EINVAL, MHX_ESTATE, Schedule, check, host_array, lib, get_default_dtype, set_default_dtype, use_library, TOOLS_LIB_PATH)
 from .dist import Group
 from .api import (I, Banana, Chains, CorrGaussian, DensityModel, Ensemble, Funnel, HipLogDensity, IIDNormal,

@@ -20,6 +20,7 @@ MHX_FLAG_STATIC_PROPOSAL = 4
 FLAG_EMCEE_SEQUENTIAL = 8
 FLAG_ZIGGURAT = 16
 FLAG_DENSE_FACTOR = 32
+FLAG_RAM_DEFERRED = 64
 
 
 class MhxError(RuntimeError):

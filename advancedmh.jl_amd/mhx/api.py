@@ -377,7 +377,10 @@ class RobustAdaptiveMetropolis:
     -- src/RobustAdaptiveMetropolis.jl:75-87."""
 
     def __init__(self, α=0.234, γ=0.6, S=None, eigenvalue_lower_bound=0.0, eigenvalue_upper_bound=float("inf"),
-                 alpha=None, gamma=None):
+                 alpha=None, gamma=None, deferred_factor=False):
+        """deferred_factor=True: MHX_FLAG_RAM_DEFERRED (dim <= 256) -- up to 8 rank-one updates stay pending as O(dim) triples and
+        are folded into S in one pass: the same chain in exact arithmetic, its own rounding (include/mhx.h)."""
+        self.deferred_factor = bool(deferred_factor)
         self.α = float(alpha if alpha is not None else α)
         self.γ = float(gamma if gamma is not None else γ)
         self.S = None if S is None else np.asarray(S, dtype=np.float64)
@@ -555,7 +558,7 @@ class Run:
                 # src/RobustAdaptiveMetropolis.jl:202-204
                 raise L.ArgumentError(L.MHX_EINVAL, "The provided `S` has the wrong dimensionality.")
             cfg = L.RamCfg(d, nchains, seed, first_chain, sampler.α, sampler.γ, sampler.eigenvalue_lower_bound,
-                           sampler.eigenvalue_upper_bound, flags)
+                           sampler.eigenvalue_upper_bound, flags | (L.FLAG_RAM_DEFERRED if sampler.deferred_factor else 0))
             L.check(lib.mhx_ram_create(self.ctx.h, model.handle(self.ctx), C.byref(cfg), C.byref(self.h)))
             self.n = nchains
             self.kind = "ram"

@@ -377,6 +377,7 @@ class C4:
         self.d, self.C, self.inner, self.dtype = args.dim or 200, args.chains or 32768, args.inner or 100, dtype
         self.moving = args.c4_moving
         self.fixed = getattr(args, "c4_fixed", False)      # "... + 500 fixed steps": S frozen after a warm-up
+        self.deferred = getattr(args, "c4_deferred", False)  # MHX_FLAG_RAM_DEFERRED: up to 8 updates pending, one fold per 8 steps
 
     def build(self, mhx, ctx, rank):
         import numpy as np
@@ -386,7 +387,8 @@ class C4:
         S0 = None
         if self.moving:           # a variant that moves: random start on the target's scale, S0 = 2.38/sqrt(d) I (about 0.17 I)
             S0 = (2.38 / d ** 0.5) * np.eye(d)
-        self.run = mhx.Run(model, mhx.RobustAdaptiveMetropolis(S=S0), nchains=self.C, seed=4, first_chain=rank * self.C, ctx=ctx)
+        self.run = mhx.Run(model, mhx.RobustAdaptiveMetropolis(S=S0, deferred_factor=self.deferred), nchains=self.C, seed=4,
+                           first_chain=rank * self.C, ctx=ctx)
         if self.moving:
             L = np.linalg.cholesky(self.Sig)
             self.run.init(L @ np.random.default_rng(11).normal(size=(d, self.C)))
@@ -412,11 +414,16 @@ class C4:
         B = RB[self.dtype]
         if self.fixed:
             return self.C * self.inner * (B * self.d * (self.d + 1) // 2 + 2 * B * self.d + 2 * B)
+        if self.deferred:
+            # its own byte model: per 8 adapting steps 7 reads of S (the proposals; the first one of a block rides on the previous
+            # fold's output) + 1 read + 1 write (the fold) = 9/8 passes per step -- NOT priced against the sweep form's 1 + 1
+            tri = B * self.d * (self.d + 1) // 2
+            return self.C * self.inner * (tri * 9 // 8 + 2 * B * self.d + 2 * B)
         return self.C * self.inner * (B * self.d * (self.d + 1) + 2 * B * self.d + 2 * B)
 
     def describe(self):
         return "RAM alpha=0.234 gamma=0.6, d=%d Gaussian kappa=1e3, %d chains/GPU (own factor each), %d %s transitions/launch, %s" % (
-            self.d, self.C, self.inner, "fixed-factor" if self.fixed else "adapting",
+            self.d, self.C, self.inner, "fixed-factor" if self.fixed else ("adapting (deferred factor, K=8)" if self.deferred else "adapting"),
             "random start, S0=2.38/sqrt(d) I" if self.moving else "x0=0, S0=I")
 
     def cpu_baseline(self, O, target_seconds):
@@ -763,6 +770,8 @@ KERNELS = {0: "generic", 1: "prebuilt-register", 2: "hiprtc-register", 3: "prebu
 
 
 def kernel_name(wl, st):
+    if wl.name == "c4" and getattr(wl, "deferred", False):
+        return "ram-deferred-factor"                               # k_ram_defer<R,K>: pending triples, one fold per K steps
     if wl.name == "c4":
         return "ram-streamed-factor"                               # k_ram<G,R,W>: lane groups, the factor streamed through an LDS ring
     return KERNELS.get(st["kernel_variant"], str(st["kernel_variant"]))
@@ -831,13 +840,14 @@ def other_configs(mhx, ctx, args, barrier):
     plan = [("c1", "c1", {}, 3, 1), ("c2_literal", "c2", {"c2_literal": True}, 20, 10), ("c2_user", "c2", {"c2_user": True}, 10, 5),
             ("c3", "c3", {}, 10, 10), ("c3_rotated", "c3", {"c3_rotated": True}, 10, 10), ("c3_user", "c3", {"c3_user": True}, 10, 10), ("c4", "c4", {}, 3, 2),
             ("c4_moving", "c4", {"c4_moving": True}, 3, 2), ("c4_fixed", "c4", {"c4_fixed": True}, 3, 2),
+            ("c4_deferred", "c4", {"c4_moving": True, "c4_deferred": True}, 3, 2),
             ("c5", "c5", {}, 10, 10), ("c5_banana", "c5", {"c5_banana": True}, 10, 10)]
     res = {}
     for key, name, over, steps, spin in plan:
         try:
             a = copy.copy(args)
             a.inner = a.chains = a.dim = a.lanes = 0
-            a.c4_moving = a.c4_fixed = a.c3_rotated = a.c5_banana = a.c2_literal = a.c2_user = a.c3_user = False
+            a.c4_moving = a.c4_fixed = a.c4_deferred = a.c3_rotated = a.c5_banana = a.c2_literal = a.c2_user = a.c3_user = False
             for k, v in over.items():
                 setattr(a, k, v)
             w = WORKLOADS[name](a, args.dtype)
@@ -1075,6 +1085,7 @@ def main():
     ap.add_argument("--c3-rotated", action="store_true", help="c3: the dense-rotated variant Sigma = Q (0.9^|i-j|) Q^T (no banded factor)")
     ap.add_argument("--c4-fixed", action="store_true", help="c4: the fixed-factor steps that follow the warm-up (1 read of S per step)")
     ap.add_argument("--c5-banana", action="store_true", help="c5: the banana target of SURVEY 8(d) (ii) instead of Neal's funnel")
+    ap.add_argument("--c4-deferred", action="store_true", help="c4: MHX_FLAG_RAM_DEFERRED (its own rounding and byte model: 10/8 passes over S per step)")
     ap.add_argument("--c4-moving", action="store_true", help="c4: random start and S0 = 2.38/sqrt(d) I instead of x0 = 0, S0 = I")
     ap.add_argument("--normal-gen", choices=["auto", "ziggurat", "box-muller"], default="auto",
                     help="c2 / c5: how the RWMH kernel turns stream bits into standard normals (auto: ziggurat in fp64, Box-Muller in fp32)")
@@ -1092,6 +1103,7 @@ def main():
     ap.add_argument("--fault-rccl-init", choices=["fail", "hang"], default=None, help="test hook of the BENCH (not of the library): the first "
                     "rung of the ladder fails / never answers")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="explicit engine option (mhx_ctx_set_option), repeatable")
+    ap.add_argument("--lib", default="", help="bind this build of the library (tools/build_variant.sh: A/B experiments on compile-time tuning macros)")
     ap.add_argument("--tools-lib", action="store_true", help="bind libmhx_tools.so (timing probes, fault injection: --opt EMCEE_PROBE=3 ...); "
                     "a run with a probe option is tainted and the line says so")
     ap.add_argument("--dry-run", action="store_true", help="launcher + rendezvous + ladder + host-side combining only: no device, no engine")
@@ -1130,6 +1142,8 @@ def main():
     from mhx.dist import allreduce_stats
     if args.tools_lib:
         mhx.use_library(mhx.TOOLS_LIB_PATH)
+    if args.lib:
+        mhx.use_library(args.lib)
 
     ndev = torch.cuda.device_count()
     if ndev < 1:

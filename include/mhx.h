@@ -170,6 +170,17 @@ typedef struct {
                                 within that kernel's dimension limit; reduce_lanes <= 1). */
 #define MHX_FLAG_DENSE_FACTOR 32 /* Ensemble runs: treat the precision factor of a dense-Gaussian target as dense even when it is
                                    banded (exact zeros below a band of width <= 8 are otherwise detected and skipped -- same bits) */
+#define MHX_FLAG_RAM_DEFERRED 64 /* RAM runs, dim <= 256: the DEFERRED-FACTOR form.  ram_adapt's rank-one step is S <- S chol(I +- c^2 U U')
+                                   (src/RobustAdaptiveMetropolis.jl:153-173 with w = c S U), a triangular factor known from U and two
+                                   scalars: up to 8 accepted updates stay pending as O(dim) triples -- proposals read the stored factor
+                                   once and apply the pending factors to the noise first -- and are folded into S in ONE read + write pass
+                                   (kernel variant 12): 9/8 reads + 1/8 writes of S per adapting step instead of 1 + 1.  The same Markov
+                                   chain in exact arithmetic, ANOTHER ROUNDING than the reference's sequential lowrankupdate! sweeps
+                                   (arithmetic spec 3.13; its own oracle twin, orc_ram_deferred): S S' agrees with the default form's to
+                                   ~1e-15 relative per step, accept decisions may differ where |log u - log alpha| is at rounding level.
+                                   Folds happen when 8 updates are pending, at the end of the warm-up and at the end of every launch (a
+                                   sampling call is cut into launches of 4096 transitions), so the factor is whole whenever the host can
+                                   see it; mhx_ram_watch_factors is refused (MHX_EINVAL). */
 #define MHX_FLAG_STATIC_PROPOSAL 4 /* RWMH runs only: the proposal is a StaticProposal (src/proposal.jl:9-11,66-83) --
                                       the candidate is a draw mean + L z that ignores the current state (independence
                                       sampler) and the ratio is logpdf(p, x) - logpdf(p, y) */
@@ -210,7 +221,7 @@ typedef struct {
     double alpha;            /* 0.234 */
     double gamma;            /* 0.6 */
     double eig_lo, eig_hi;   /* eigenvalue (diagonal) bounds, 0 and +inf */
-    int32_t flags;
+    int32_t flags;           /* MHX_FLAG_RAM_DEFERRED */
 } mhx_ram_cfg;
 
 int mhx_ram_create(mhx_ctx *ctx, const mhx_target *t, const mhx_ram_cfg *cfg, mhx_run **out);
@@ -329,7 +340,8 @@ typedef struct {
                                   fetched into registers from an image built once per run; reduction shape 4),
                                   11 a WAVE per chain (RWMH on the data-sum target MHX_TARGET_IID_NORMAL with few chains -- the
                                   reference's own README example, one chain: the 64 lanes split the likelihood's terms, the draws of
-                                  64 steps are made side by side off the chain's critical path; reduction shape 64) */
+                                  64 steps are made side by side off the chain's critical path; reduction shape 64),
+                                  12 RAM with a deferred factor (MHX_FLAG_RAM_DEFERRED) */
     int32_t launches;
     int32_t reduce_lanes;      /* lanes per chain in effect (1 unless a cooperative kernel runs) */
     int32_t dtype;             /* mhx_dtype of the run's context */
