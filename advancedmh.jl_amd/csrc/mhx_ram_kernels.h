@@ -577,7 +577,7 @@ MHX_DEV void mhx_ram_init_body(const mhx_ram_args& a, const mhx_real* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// The DEFERRED-FACTOR form (MHX_FLAG_RAM_DEFERRED; arithmetic spec DESIGN.md 3.13, which also names the CPU twin the tests compare it with).
+// The DEFERRED-FACTOR form (MHX_FLAG_RAM_DEFERRED; arithmetic spec DESIGN.md 3.12, which also names the CPU twin the tests compare it with).
 // ram_adapt (RAM.jl:153-173) moves  S S' <- S S' + sigma w w',  w = c S U,  c^2 = eta |dalpha| / |U|^2:  S_new = S M  with
 // M = chol(I + sigma c^2 U U'), a lower-triangular factor known from U and two scalars alone
 //     M_jj = a_j = sqrt(T_{j+1} / T_j),   M_ij = U_i g_j (i > j),   g_j = sigma c^2 U_j / (T_j a_j),   T_j = 1 + sigma c^2 sum_{m<j} U_m^2.

@@ -64,6 +64,7 @@ end
 const MHX_FLAG_STATIC_PROPOSAL = Int32(4)
 const MHX_FLAG_EMCEE_SEQUENTIAL = Int32(8)
 const MHX_FLAG_ZIGGURAT = Int32(16)
+const MHX_FLAG_RAM_DEFERRED = Int32(64)
 
 """
     LangevinProposal(σ²)
@@ -76,7 +77,8 @@ struct LangevinProposal; sigma2::Float64; end
 
 # --- the ensemble tag AbstractMCMC dispatches on -------------------------------------------------
 """
-    MCMCHIP(; device = 0, devices = nothing, first_chain = 0, T = Float64, sequential_ensemble = false, ziggurat = false)
+    MCMCHIP(; device = 0, devices = nothing, first_chain = 0, T = Float64, sequential_ensemble = false, ziggurat = false,
+            ram_deferred_factor = false)
 
 Run all chains of `sample(model, sampler, MCMCHIP(), N, nchains)` on one MI355X -- or, with `devices = 0:7`, on several from THIS
 process: what `sample(model, spl, MCMCThreads(), N, nchains)` is on the CPU (README.md:135-148, one task per chain) with one host
@@ -86,6 +88,8 @@ several processes that each take a shard via `first_chain`) are the unsharded ru
 `Float32`.  `sequential_ensemble = true` runs `Ensemble` with the reference's own Gauss-Seidel sweep (src/emcee.jl:39-58) instead
 of the parallel half-split.  `ziggurat = true` (Float64, RWMH with an isotropic / diagonal proposal, any log-density): standard
 normals by the engine's table ziggurat instead of Box-Muller (MHX_FLAG_ZIGGURAT -- what Julia's own `randn` is; a third faster).
+`ram_deferred_factor = true` (RobustAdaptiveMetropolis, dim <= 256): MHX_FLAG_RAM_DEFERRED -- up to 8 rank-one updates of `S` stay
+pending as O(dim) triples and are folded in one pass; the same chain in exact arithmetic, its own rounding, a third faster at d = 200.
 """
 Base.@kwdef struct MCMCHIP <: AbstractMCMC.AbstractMCMCEnsemble
     device::Int = 0
@@ -94,6 +98,7 @@ Base.@kwdef struct MCMCHIP <: AbstractMCMC.AbstractMCMCEnsemble
     T::DataType = Float64
     sequential_ensemble::Bool = false
     ziggurat::Bool = false
+    ram_deferred_factor::Bool = false
 end
 dtype_code(::Type{Float32}) = Cint(0)
 dtype_code(::Type{Float64}) = Cint(1)
@@ -433,7 +438,8 @@ function make_run(::Type{T}, ctx::Ptr{Cvoid}, tgt::Ptr{Cvoid}, d::Integer, sampl
         cfg = MalaCfg(d, n, seed, first, prop.sigma2, 0, 0)
         check(ccall((:mhx_mala_create, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{MalaCfg}, Ref{Ptr{Cvoid}}), ctx, tgt, cfg, run))
     elseif sampler isa AdvancedMH.RobustAdaptiveMetropolis
-        cfg = RamCfg(d, n, seed, first, sampler.α, sampler.γ, sampler.eigenvalue_lower_bound, sampler.eigenvalue_upper_bound, 0)
+        cfg = RamCfg(d, n, seed, first, sampler.α, sampler.γ, sampler.eigenvalue_lower_bound, sampler.eigenvalue_upper_bound,
+                     ens.ram_deferred_factor ? MHX_FLAG_RAM_DEFERRED : Int32(0))
         check(ccall((:mhx_ram_create, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{RamCfg}, Ref{Ptr{Cvoid}}), ctx, tgt, cfg, run))
         if sampler.S !== nothing
             if size(sampler.S) != (d, d)

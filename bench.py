@@ -36,7 +36,7 @@ same time against the issue peak); `cpu_baseline` is the CPU oracle (a port of t
 all measured after the timed region:
   `e2e_host`  the rate THROUGH the boundary -- samples back on the host (mhx_run_sample_to_host), save-all and thinned;
   `configs`   the other BASELINE.json configs and their SURVEY 8(d) variants (c1, c2_literal, c3, c3_rotated, c4,
-              c4_moving, c4_fixed, c5, c5_banana): {value, ms_per_step, acc, bound, frac, traffic_ratio, cpu, ...} each;
+              c4_moving, c4_fixed, c4_deferred, c5, c5_banana): {value, ms_per_step, acc, bound, frac, traffic_ratio, cpu, ...} each;
   `ess`       the ESS/sec window;  `f32` the fp32 engine on the same workload.
 """
 import argparse

@@ -176,7 +176,7 @@ typedef struct {
                                    once and apply the pending factors to the noise first -- and are folded into S in ONE read + write pass
                                    (kernel variant 12): 9/8 reads + 1/8 writes of S per adapting step instead of 1 + 1.  The same Markov
                                    chain in exact arithmetic, ANOTHER ROUNDING than the reference's sequential lowrankupdate! sweeps
-                                   (arithmetic spec 3.13; its own oracle twin, orc_ram_deferred): S S' agrees with the default form's to
+                                   (arithmetic spec 3.12; its own oracle twin, orc_ram_deferred): S S' agrees with the default form's to
                                    ~1e-15 relative per step, accept decisions may differ where |log u - log alpha| is at rounding level.
                                    Folds happen when 8 updates are pending, at the end of the warm-up and at the end of every launch (a
                                    sampling call is cut into launches of 4096 transitions), so the factor is whole whenever the host can

@@ -1064,7 +1064,7 @@ int orc_ram(const orc_target *t, const orc_ram_cfg *cfg, const orc_schedule *s,
 }
 
 /* ------------------------------------------------------------------------------------------ */
-/* RAM with a DEFERRED factor (DESIGN.md 3.13): the same chain as orc_ram in exact arithmetic, another rounding.
+/* RAM with a DEFERRED factor (DESIGN.md 3.12): the same chain as orc_ram in exact arithmetic, another rounding.
  * ram_adapt (src/RobustAdaptiveMetropolis.jl:153-173) updates  S S' <- S S' + sigma w w'  with  w = c S U,
  * c^2 = eta |dalpha| / |U|^2, so  S_new = S M  with  M = chol(I + sigma c^2 U U')  -- lower triangular,
  *     M_jj = a_j = sqrt(T_{j+1} / T_j),   M_ij = U_i g_j  (i > j),   g_j = sigma c^2 U_j / (T_j a_j),

@@ -143,7 +143,7 @@ int orc_ram(const orc_target *t, const orc_ram_cfg *cfg, const orc_schedule *s,
             real *samples, uint8_t *accepted, real *final_x, real *final_lp,
             uint32_t *accept_counts, uint8_t *status, real *diag_min, real *diag_max);
 
-/* RAM with a deferred factor (the twin of MHX_FLAG_RAM_DEFERRED, DESIGN.md 3.13): the chain of orc_ram in exact arithmetic,
+/* RAM with a deferred factor (the twin of MHX_FLAG_RAM_DEFERRED, DESIGN.md 3.12): the chain of orc_ram in exact arithmetic,
  * other rounding -- up to K accepted rank-1 updates stay pending as O(d) triples and are folded into the stored factor in one
  * pass; flush_at[nflush]: transitions (ascending) after which a flush is forced (the engine's launch ends). dim <= 256. */
 int orc_ram_deferred(const orc_target *t, const orc_ram_cfg *cfg, const orc_schedule *s,

@@ -1,5 +1,5 @@
 """GPU parity of the DEFERRED-FACTOR form of RobustAdaptiveMetropolis (MHX_FLAG_RAM_DEFERRED, kernel variant 12; arithmetic spec
-DESIGN.md 3.13) against its own oracle twin (oracle/mhx_oracle.c orc_ram_deferred), bit for bit; and against the reference-order
+DESIGN.md 3.12) against its own oracle twin (oracle/mhx_oracle.c orc_ram_deferred), bit for bit; and against the reference-order
 arithmetic (orc_ram = src/RobustAdaptiveMetropolis.jl:123-278 with the sequential lowrankupdate! sweep) within rounding."""
 import numpy as np
 import pytest
