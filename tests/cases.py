@@ -78,6 +78,19 @@ def case_ram_bounds(O):
                  gamma=0.51, eig_lo=0.9, eig_hi=1.1)
 
 
+def ram_deferred_setup(d=6, C=4):
+    """a start that moves from the first step: updates and downdates, short tail blocks, the warm-up's end inside the run"""
+    rng = np.random.default_rng(61)
+    return rng.normal(size=(d, C)), np.eye(d) * (2.38 / np.sqrt(d))
+
+
+def case_ram_deferred(O):
+    d, C = 6, 4
+    init, S0 = ram_deferred_setup(d, C)
+    return O.ram_deferred(O.corr_gauss_from_cov(sigma_ar1(d, 0.7)), O.schedule(40, 0, 1, 33), 33, 1, C, init=init,
+                          S_in=np.tile(O.pack_lower(S0), (C, 1)))
+
+
 TRACE_CASES = {
     "rwmh_iso": case_rwmh_iso,
     "rwmh_dense_corr": case_rwmh_dense_corr,
@@ -87,6 +100,7 @@ TRACE_CASES = {
     "emcee_seq": case_emcee_seq,
     "ram": case_ram,
     "ram_bounds": case_ram_bounds,
+    "ram_deferred": case_ram_deferred,
 }
 
 

@@ -65,6 +65,20 @@ def test_deferred_bit_exact(mhx, oracle, d, C, N, warm, real):
     _check(*out, ref)
 
 
+def test_deferred_golden_trace(mhx, real):
+    """the committed fixture of the twin (tests/golden/traces*.npz, case `ram_deferred` of tests/cases.py)"""
+    import os
+    tr = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "traces64.npz" if real == "f64" else "traces.npz"))
+    d, C = 6, 4
+    init, S0 = cases.ram_deferred_setup(d, C)
+    chain = mhx.sample(mhx.DensityModel(mhx.CorrGaussian(cases.sigma_ar1(d, 0.7))), mhx.RobustAdaptiveMetropolis(S=S0, deferred_factor=True),
+                       40, C, seed=33, first_chain=1, initial_params=init, num_warmup=33, discard_initial=0)
+    _same(chain.value, tr["ram_deferred/samples"], "samples")
+    _same(chain.accepted, tr["ram_deferred/accepted"], "accepted")
+    S, _ = chain.state.factor()
+    _same(S, tr["ram_deferred/S"], "S")
+
+
 def test_deferred_long_run_spans_several_launches(mhx, oracle, real):
     """9 000 transitions = three launches (a flush at the end of each); adaptation stops inside the second one"""
     d, C = 3, 5

@@ -202,3 +202,43 @@ def test_static_proposal_is_an_independence_sampler(oracle, real):
     flat = ref["samples"][:, :2, :].transpose(1, 0, 2).reshape(2, -1)
     assert np.abs(flat.mean(axis=1)).max() < 0.05
     assert np.abs(np.cov(flat) - Sig).max() < 0.08
+
+
+@pytest.mark.parametrize("d,K", [(5, 8), (13, 3), (70, 8), (200, 8), (256, 1)])
+def test_ram_deferred_twin_is_the_reference_order_chain_up_to_rounding(oracle, d, K):
+    """Arithmetic spec 3.12 (orc_ram_deferred, the twin of MHX_FLAG_RAM_DEFERRED) against item 9 (orc_ram: the reference's sequential
+    lowrankupdate! / lowrankdowndate! sweeps, src/RobustAdaptiveMetropolis.jl:153-173) on the same seeds, in fp64: S <- S chol(I +- c^2 U U')
+    IS the rank-one update, so the accept decisions are the same, the chains agree to round-off and S S' to a few ulp -- for any block
+    length K, with forced folds in the middle of a block."""
+    oracle.set_dtype("f64")
+    C, N = 3, 160
+    Sig = cases.sigma_ar1(d, 0.7)
+    rng = np.random.default_rng(d)
+    init, S0 = rng.normal(size=(d, C)), np.eye(d) * (2.38 / np.sqrt(d))
+    Sin = np.tile(oracle.pack_lower(S0), (C, 1))
+    sched = oracle.schedule(N, 0, 1, N - 21)
+    a = oracle.ram(oracle.corr_gauss_from_cov(Sig), sched, 31, 2, C, init=init, S_in=Sin)
+    b = oracle.ram_deferred(oracle.corr_gauss_from_cov(Sig), sched, 31, 2, C, init=init, S_in=Sin, K=K, flush_at=[5, 37, 38, 100])
+    assert 0.05 < a["accepted"][1:].mean() < 0.95
+    assert np.array_equal(a["accepted"], b["accepted"])
+    assert np.abs(a["samples"] - b["samples"]).max() < 1e-11
+    assert np.array_equal(a["status"], b["status"]) and not a["status"].any()
+    for c in range(C):
+        A, B = oracle.unpack_lower(a["S"][c], d), oracle.unpack_lower(b["S"][c], d)
+        assert np.linalg.norm(A @ A.T - B @ B.T) <= 2e-14 * np.linalg.norm(A @ A.T)
+        assert np.abs(a["diag_min"][:, c] - b["diag_min"][:, c]).max() <= 1e-13 * np.abs(a["diag_min"][:, c]).max()
+
+
+def test_ram_deferred_twin_respects_the_eigenvalue_bounds(oracle, real):
+    """a refused update is not pending: with bounds that bite the deferred factor never leaves them (test/RobustAdaptiveMetropolis.jl:57-69)"""
+    d, C, N = 5, 7, 60
+    rng = np.random.default_rng(3)
+    L = np.tril(rng.normal(size=(d, d)) * 0.2) + np.eye(d)
+    Sin = np.tile(oracle.pack_lower(L), (C, 1))
+    r = oracle.ram_deferred(oracle.iso_gauss(d), oracle.schedule(N, 0, 1, N), 77, 0, C, S_in=Sin, gamma=0.7, eig_lo=0.58, eig_hi=1.45)
+    free = oracle.ram_deferred(oracle.iso_gauss(d), oracle.schedule(N, 0, 1, N), 77, 0, C, S_in=Sin, gamma=0.7)
+    assert (r["diag_min"] >= 0.58).all() and (r["diag_max"] <= 1.45).all()
+    assert free["diag_min"].min() < 0.58 or free["diag_max"].max() > 1.45          # the bounds did refuse something
+    for c in range(C):
+        dg = np.diag(oracle.unpack_lower(r["S"][c], d))
+        assert (dg >= 0.58).all() and (dg <= 1.45).all()
