@@ -866,6 +866,13 @@ MHX_DEV void mhx_ram_defer_body(const mhx_ram_args& a, const mhx_real* __restric
         const mhx_real logu = mhx_accept_logu(ks, id_lo, id_hi, step, ac);
         const bool acc = logu < loga;
         loga_last = loga;
+        // ---- state select (before the update: the candidate dies here, not after the fold)
+#pragma unroll
+        for (int r = 0; r < R; ++r) x[r] = acc ? y[r] : x[r];
+        lp = acc ? lpy : lp;
+        nacc += acc ? 1u : 0u;
+        last = acc;
+        wave_acc += acc && tg == 0 ? 1u : 0u;
 
         // ---- adapt: the update becomes pending
         have_v = false;
@@ -966,13 +973,6 @@ MHX_DEV void mhx_ram_defer_body(const mhx_ram_args& a, const mhx_real* __restric
             }
         }
 
-        // ---- state select
-#pragma unroll
-        for (int r = 0; r < R; ++r) x[r] = acc ? y[r] : x[r];
-        lp = acc ? lpy : lp;
-        nacc += acc ? 1u : 0u;
-        last = acc;
-        wave_acc += acc && tg == 0 ? 1u : 0u;
         if (step == save_next) {
             mhx_real* rowp = a.samples + slot * (long)(d + 1) * ld + c;
 #pragma unroll
