@@ -303,6 +303,78 @@ def test_c4_known_answers_at_dimension_200(mhx, real):
     assert ad["iteration"] == 2001
 
 
+def test_c4_deferred_factor_known_answers_and_divergence_at_dimension_200(mhx, real):
+    """The deferred-factor form of RAM (MHX_FLAG_RAM_DEFERRED, arithmetic spec 3.12) has its own rounding, so it gets its own known
+    answers at configs[3]'s dimension -- the two of test_c4_known_answers_at_dimension_200:
+    (1) the log-det invariant of ram_adapt per chain -- exact for this form too: the diagonal of chol(I +- c^2 U U') multiplies to
+        sqrt(1 +- eta |dalpha|);
+    (2) the pull towards alpha over 32 768 chains;
+    and (3) the DIVERGENCE from the sequential form on the same seeds: chains whose accept decisions all agree over 160 adapting
+    transitions (a flipped decision sends a chain elsewhere for good), and for those the distance of the states and of S S'."""
+    import bench
+    import json
+    import os
+    d = 200
+    Sig = bench.sigma_illcond(d)
+    Lc = np.linalg.cholesky(Sig)
+    s0 = 2.38 / d ** 0.5
+    model = mhx.DensityModel(mhx.CorrGaussian(Sig))
+    C, N = 1024, 160
+    x0 = Lc @ np.random.default_rng(11).normal(size=(d, C))
+    out = {}
+    for form in ("deferred", "sequential"):
+        run = mhx.Run(model, mhx.RobustAdaptiveMetropolis(S=s0 * np.eye(d), deferred_factor=form == "deferred"), nchains=C, seed=4)
+        run.init(x0)
+        run.sample(N, 0, 1, N)
+        st = run.step_stats()
+        val, acc = run.samples()
+        S, status = run.factor()
+        assert run.stats()["kernel_variant"] == (12 if form == "deferred" else 0)
+        run.close()
+        assert (status == 0).all()
+        out[form] = (st, val, acc, S)
+    # (1)
+    st, val, acc, S = out["deferred"]
+    la = st["logα"].astype(np.float64)[1:]
+    eta = st["η"][1:]
+    want = 0.5 * np.log1p(eta[:, None] * (np.exp(la) - 0.234)).sum(axis=0)
+    diag_idx = np.cumsum(np.arange(1, d + 1)) - 1
+    got = np.log(S.astype(np.float64)[:, diag_idx]).sum(axis=1) - d * np.log(float(np.float32(s0) if real == "f32" else s0))
+    assert np.abs(got - want).max() < (2e-3 if real == "f32" else 1e-9), np.abs(got - want).max()
+    assert (want > 0).all()
+    # (3)
+    _, val2, acc2, S2 = out["sequential"]
+    same = (acc == acc2).all(axis=0)                             # [C]: every decision of the chain agrees
+    frac = same.mean()
+    il = np.tril_indices(d)
+    rel = 0.0
+    for c in np.flatnonzero(same)[:64]:
+        A = np.zeros((d, d)); A[il] = S[c]
+        B = np.zeros((d, d)); B[il] = S2[c]
+        rel = max(rel, np.linalg.norm(A @ A.T - B @ B.T) / np.linalg.norm(B @ B.T))
+    dx = np.abs(val[:, :d, same].astype(np.float64) - val2[:, :d, same].astype(np.float64)).max()
+    report = dict(dtype=real, chains=C, transitions=N - 1, chains_with_identical_decisions=float(frac), max_rel_SSt=float(rel), max_abs_dx=float(dx))
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "r05_c4_deferred_divergence_%s.json" % real), "w") as f:
+        json.dump(report, f)
+    if real == "f64":
+        assert frac == 1.0 and rel < 1e-12 and dx < 1e-9, report
+    else:
+        assert frac > 0.5 and rel < 1e-4, report                 # fp32: a log-density of O(100) leaves margins of 1e-5 to round-off
+    # (2)
+    C = 32768
+    run = mhx.Run(model, mhx.RobustAdaptiveMetropolis(S=s0 * np.eye(d), deferred_factor=True), nchains=C, seed=4)
+    run.init(Lc @ np.random.default_rng(11).normal(size=(d, C)))
+    marks = []
+    for n in (200, 800, 1000):
+        run.sample(1, n, 1, n, save=False)
+        marks.append(float(np.exp(run.adapt_state()["logα"].astype(np.float64)).mean()))
+    S, status = run.factor()
+    run.close()
+    assert (status == 0).all() and np.isfinite(S).all()
+    assert 0.66 > marks[0] > marks[1] > marks[2] > 0.60 and marks[0] - marks[2] > 0.008, marks
+
+
 def test_c3_ensemble_known_answer_at_scale(mhx, real):
     """configs[2] as a known answer: 16 384 walkers, 50-dim Gaussian with Sigma_ij = 0.9^|i-j|, initial walkers drawn on the
     device from N(0, I); after 20 000 sweeps of burn-in (the stretch move mixes slowly in 50 dimensions) the walkers of 20 sweeps 200 apart reproduce mean 0, unit variances and
