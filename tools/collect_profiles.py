@@ -9,7 +9,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DOMINANT = {"c2": ("rwmh_coop", "mhx_jit_rwmh_reg"), "c5": ("rwmh_coop",), "c3": ("mhx_jit_emcee_sweep", "mhx_jit_emcee_mfma_sweep", "emcee_half"), "c4": ("k_ram<", "k_ram_defer<")}
+DOMINANT = {"c2": ("rwmh_coop", "mhx_jit_rwmh_reg"), "c5": ("rwmh_coop",), "c3": ("mhx_jit_emcee_sweep", "mhx_jit_emcee_mfma_sweep", "emcee_half"), "c4": ("k_ram<", "k_ram_defer<"), "c1": ("k_rwmh_wave",)}
 
 
 def dominant(cfg, name):
