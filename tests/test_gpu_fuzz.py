@@ -128,6 +128,43 @@ def test_ram_random_configurations(mhx, oracle, case, real):
     _same(st, ref["status"], what)
 
 
+@pytest.mark.parametrize("case", range(30))
+def test_ram_deferred_factor_random_configurations(mhx, oracle, case, real):
+    """the deferred-factor form (MHX_FLAG_RAM_DEFERRED, spec 3.12) against its own twin: every rows-per-lane shape, blocks cut short by
+    the warm-up's end and by the end of the call, thinning and discards, bounds that refuse updates, both targets, a given factor"""
+    rng = np.random.default_rng(7000 + case + 100000 * SEED_OFFSET)
+    d = int(rng.choice([1, 2, 4, 9, 17, 33, 64, 65, 100, 129, 200, 256]))
+    C = int(rng.choice([1, 3, 4, 5, 9]))
+    N = int(rng.integers(2, 14))
+    th = int(rng.choice([1, 1, 2, 3]))
+    di = int(rng.integers(0, 12))
+    nT = di + (N - 1) * th
+    warm = int(rng.integers(0, nT + 2))
+    corr = bool(rng.integers(0, 2)) and d >= 2
+    Sig = cases.sigma_ar1(d, 0.6)
+    tgt, ot = (mhx.CorrGaussian(Sig), oracle.corr_gauss_from_cov(Sig)) if corr else (mhx.IsoGaussian(d), oracle.iso_gauss(d))
+    s0 = 2.38 / np.sqrt(d)
+    bounds = (0.0, float("inf")) if rng.integers(0, 2) else (0.9 * s0, 1.2 * s0)
+    gamma = float(np.float32(0.51 + 0.4 * rng.random()))
+    init = rng.normal(size=(d, C))
+    seed, first = int(rng.integers(1, 1 << 40)), int(rng.integers(0, 1 << 20))
+    S0 = np.eye(d) * s0
+    spl = mhx.RobustAdaptiveMetropolis(γ=gamma, S=S0, eigenvalue_lower_bound=bounds[0], eigenvalue_upper_bound=bounds[1], deferred_factor=True)
+    chain = mhx.sample(mhx.DensityModel(tgt), spl, N, C, seed=seed, first_chain=first, initial_params=init, num_warmup=warm,
+                       discard_initial=di, thinning=th)
+    ref = oracle.ram_deferred(ot, oracle.schedule(N, di, th, warm), seed, first, C, init=init, gamma=gamma, eig_lo=bounds[0], eig_hi=bounds[1],
+                              S_in=np.tile(oracle.pack_lower(S0), (C, 1)))
+    what = "case %d: d=%d C=%d corr=%s N=%d di=%d th=%d warm=%d bounds=%s" % (case, d, C, corr, N, di, th, warm, bounds)
+    _same(chain.value, ref["samples"], what)
+    _same(chain.accepted, ref["accepted"], what)
+    S, st = chain.state.factor()
+    _same(S, ref["S"], what)
+    _same(st, ref["status"], what)
+    lo, hi = chain.state.diag_range()
+    _same(lo, ref["diag_min"], what)
+    _same(hi, ref["diag_max"], what)
+
+
 @pytest.mark.parametrize("case", range(16))
 def test_mala_random_configurations(mhx, oracle, case, real):
     rng = np.random.default_rng(4000 + case + 100000 * SEED_OFFSET)
