@@ -91,6 +91,33 @@ def test_deferred_long_run_spans_several_launches(mhx, oracle, real):
     _check(*out, ref)
 
 
+@pytest.mark.parametrize("slab", [2, 3, -2])
+def test_deferred_through_the_host_return_path(mhx, oracle, real, slab):
+    """mhx_run_sample_to_host cuts the schedule into slabs of saved samples and every slab ends a launch -- a forced fold of the
+    pending updates (spec 3.12: the rounding depends on where launches end).  With the slab ends as the twin's fold points the record
+    that arrives on the host is the twin's, bit for bit; the device-resident call of the same schedule differs in the last bits."""
+    d, C = 70, 4
+    N, di, th, warm = 9, 5, 3, 26
+    Sig = cases.sigma_ar1(d, 0.7)
+    init, S0 = _moving_start(d, C, 5)
+    model = mhx.DensityModel(mhx.CorrGaussian(Sig))
+    spl = mhx.RobustAdaptiveMetropolis(S=S0, deferred_factor=True)
+    run = mhx.Run(model, spl, nchains=C, seed=19, first_chain=3)
+    run.init(init)
+    val, acc = run.sample_to_host(N, di, th, warm, slab_samples=slab)
+    S, _ = run.factor()
+    run.close()
+    K = abs(slab)
+    ends = [di + (min(i0 + K, N) - 1) * th for i0 in range(0, N, K)]          # the transition behind each slab's last sample
+    Sin = np.tile(oracle.pack_lower(S0), (C, 1))
+    ref = oracle.ram_deferred(oracle.corr_gauss_from_cov(Sig), oracle.schedule(N, di, th, warm), 19, 3, C, init=init, S_in=Sin, flush_at=ends)
+    _same(val, ref["samples"], "samples")
+    _same(acc, ref["accepted"], "accepted")
+    _same(S, ref["S"], "S")
+    one = oracle.ram_deferred(oracle.corr_gauss_from_cov(Sig), oracle.schedule(N, di, th, warm), 19, 3, C, init=init, S_in=Sin)
+    assert np.array_equal(one["accepted"], ref["accepted"]) and np.abs(one["S"] - ref["S"]).max() < (1e-4 if real == "f32" else 1e-12)
+
+
 def test_deferred_iso_target_thinning_and_bounds(mhx, oracle, real):
     """a separable target, thinning, eigenvalue bounds that refuse some updates (a refused update is not pending)"""
     d, C, N = 5, 7, 40
