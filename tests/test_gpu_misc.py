@@ -517,7 +517,7 @@ def test_readme_example_runs():
     assert "ess_bulk" in out.stdout and "sigma" in out.stdout
 
 
-@pytest.mark.parametrize("kind", ["rwmh_coop", "rwmh_dense", "rwmh_static", "emcee_coop", "emcee_user", "ram", "mala"])
+@pytest.mark.parametrize("kind", ["rwmh_coop", "rwmh_dense", "rwmh_static", "emcee_coop", "emcee_user", "ram", "ram_deferred", "mala"])
 def test_checkpoint_and_resume(mhx, kind, real):
     """mhx_run_save_state / mhx_run_load_state: a NEW run (created with another seed) that loads the blob continues the
     saved run bit for bit -- samples, accept flags, final state, RAM factors."""
@@ -538,13 +538,13 @@ def test_checkpoint_and_resume(mhx, kind, real):
         model = mhx.DensityModel(mhx.HipLogDensity(user_targets.SHIFTED_GAUSS, d, data=data))
         spl = mhx.Ensemble(C, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I)))
         init = cases.emcee_init(d, C, 3)
-    elif kind == "ram":
-        model, spl = mhx.DensityModel(mhx.CorrGaussian(Sig)), mhx.RobustAdaptiveMetropolis()
+    elif kind in ("ram", "ram_deferred"):                    # (the deferred form folds its pending updates at the end of every call: the blob is whole)
+        model, spl = mhx.DensityModel(mhx.CorrGaussian(Sig)), mhx.RobustAdaptiveMetropolis(deferred_factor=kind == "ram_deferred")
         init = np.zeros((d, C), dtype=np.float32)
     else:
         model, spl = mhx.DensityModel(mhx.CorrGaussian(Sig)), mhx.MALA(0.05)
         init = np.zeros((d, C), dtype=np.float32)
-    warm = 30 if kind == "ram" else 0                        # the warm-up spans the checkpoint
+    warm = 30 if kind.startswith("ram") else 0               # the warm-up spans the checkpoint
 
     def new_run(seed):
         return mhx.Run(model, spl, nchains=C, seed=seed, first_chain=4)
@@ -564,9 +564,13 @@ def test_checkpoint_and_resume(mhx, kind, real):
     _same(got_acc, want_acc, "accept flags")
     for u, v, what in zip(b.state(), want_state, ("x", "lp", "accept counts")):
         _same(u, v, what)
-    if kind == "ram":
+    if kind.startswith("ram"):
         _same(b.factor()[0], a.factor()[0], "factors")
         _same(b.diag_range()[0], a.diag_range()[0], "diag min")
+        other = mhx.Run(model, mhx.RobustAdaptiveMetropolis(deferred_factor=kind == "ram"), nchains=C, seed=1)
+        with pytest.raises(mhx.ArgumentError):               # the other form of RAM rounds differently: its blob is refused
+            other.load_state(blob)
+        other.close()
     with pytest.raises(mhx.ArgumentError):                   # a blob of another shape is refused
         other = mhx.Run(mhx.DensityModel(mhx.IsoGaussian(3)), mhx.RWMH(3), nchains=2, seed=1)
         other.load_state(blob)
