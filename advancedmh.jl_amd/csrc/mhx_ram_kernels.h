@@ -1014,7 +1014,12 @@ MHX_DEV void mhx_ram_defer_body(const mhx_ram_args& a, const mhx_real* __restric
 }
 
 #ifdef MHX_JIT_RAM
-extern "C" __global__ void __launch_bounds__(64)
+#ifdef MHX_JIT_DEFER_K
+#define MHX_JIT_RAM_BOUNDS __launch_bounds__(64, 2)      // the deferred-factor form is built for two waves per SIMD, like its pre-built kernels
+#else
+#define MHX_JIT_RAM_BOUNDS __launch_bounds__(64)
+#endif
+extern "C" __global__ void MHX_JIT_RAM_BOUNDS
 mhx_jit_ram(const mhx_ram_args a, const mhx_real* __restrict__ tparams)
 {
     extern __shared__ mhx_real mhx_ram_lds[];
