@@ -36,7 +36,7 @@ same time against the issue peak); `cpu_baseline` is the CPU oracle (a port of t
 all measured after the timed region:
   `e2e_host`  the rate THROUGH the boundary -- samples back on the host (mhx_run_sample_to_host), save-all and thinned;
   `configs`   the other BASELINE.json configs and their SURVEY 8(d) variants (c1, c2_literal, c3, c3_rotated, c4,
-              c4_moving, c4_fixed, c4_deferred, c5, c5_banana): {value, ms_per_step, acc, bound, frac, traffic_ratio, cpu, ...} each;
+              c4_moving, c4_fixed, c4_deferred, c5, c5_banana): {value, ms_per_step, acc, bound, frac, traffic_ratio, gen, cpu, ...} each;
   `ess`       the ESS/sec window;  `f32` the fp32 engine on the same workload.
 """
 import argparse
@@ -857,7 +857,9 @@ def other_configs(mhx, ctx, args, barrier):
             blk = {"value": sig(w.units_per_step() * steps / dt), "ms_per_step": sig(dt * 1e3 / steps), "acc": sig(acc / float(tr), 3),
                    "bound": rf["bound"], "frac": sig(rf["frac"], 4),
                    "traffic_ratio": sig(rf["traffic"] / rf["algorithmic_bytes_per_step"], 4) if rf.get("traffic") else None,
-                   "launch_us": sig(rf["avg_launch_ms"] * 1e3, 4), "kernel": kernel_name(w, st), "lanes": st["reduce_lanes"]}
+                   "launch_us": sig(rf["avg_launch_ms"] * 1e3, 4), "kernel": kernel_name(w, st), "lanes": st["reduce_lanes"],
+                   # which generator turned the stream bits into normals (mhx_stats.normal_gen; the stretch move draws none)
+                   "gen": "-" if name == "c3" else ("zig" if st.get("normal_gen") else "bm")}
             if rf["bound"] == "valu":
                 blk["hbm_frac"] = rf["hbm_frac"]
                 blk["valu_weighted_frac"] = rf.get("valu_weighted_frac")     # class-weighted issue bound (tools/isa_mix.py), None until counted
