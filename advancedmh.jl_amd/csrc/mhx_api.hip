@@ -64,11 +64,11 @@ k_rwmh_reg(const mhx_rwmh_args a, const mhx_real* __restrict__ tparams, const mh
 {
     mhx_rwmh_reg_body<D, TK, PK>(a, tparams, pvec);
 }
-template <int PK>
+template <int PK, int K>
 __global__ void __launch_bounds__(64)
 k_rwmh_wave(const mhx_rwmh_args a, const mhx_real* __restrict__ tparams, const mhx_real* __restrict__ pvec)
 {
-    mhx_rwmh_wave_body<PK>(a, tparams, pvec);
+    mhx_rwmh_wave_body<PK, K>(a, tparams, pvec);
 }
 __global__ void __launch_bounds__(256)
 k_rwmh_generic(const mhx_rwmh_args a, const mhx_real* __restrict__ tparams, const mhx_real* __restrict__ pvec)
@@ -223,7 +223,7 @@ int api_ctx_device(const mhx_ctx* ctx) { return ctx->device; }
 struct opt_name { const char* name; int probe; };
 static const opt_name k_opt_names[] = {
     {"NO_PREBUILT", 0}, {"NO_MFMA", 0}, {"MFMA_WAVES", 0}, {"REG_MAX_DIM", 0}, {"REG_XR", 0}, {"REG_UNROLL", 0}, {"COOP_WAVES", 0},
-    {"MALA_XR", 0}, {"RAM_G", 0}, {"RAM_LDS_PAD", 0},
+    {"MALA_XR", 0}, {"RAM_G", 0}, {"RAM_LDS_PAD", 0}, {"WAVE_K", 0},
     {"EMCEE_MFMA", 0}, {"EMCEE_MFMA_WAVES", 0}, {"EMCEE_SCALAR", 0}, {"EMCEE_SCAL_MODE", 0}, {"EMCEE_SCAL_WPB", 0}, {"EMCEE_SCAL_REC", 0},
     {"EMCEE_FUSED", 0}, {"EMCEE_PERSIST", 0}, {"EMCEE_PRELOAD", 0}, {"EMCEE_DEFER", 0}, {"EMCEE_SWEEP_DEFER", 0}, {"EMCEE_WAVES", 0},
     {"EMCEE_REC_STORE", 0}, {"EMCEE_ROW_STORE", 0}, {"EMCEE_COOP_REC", 0},
@@ -745,6 +745,8 @@ struct mhx_run : mhx_handle_hdr {
     bool emcee_scal = false;             // the scalar-factor form of the cooperative stretch move (variant 9): coop_L waves per block, 64 walkers
     int variant = 0;
     void (*reg_fn)(const mhx_rwmh_args, const mhx_real*, const mhx_real*) = nullptr;
+    void (*reg_fn8)(const mhx_rwmh_args, const mhx_real*, const mhx_real*) = nullptr;   // variant 11: the K = 8 build of the wave-per-chain kernel
+    int wave_k = 4;                      // variant 11: candidates per round of the next call (8 after a call that accepted < 1 step in 8)
     hipFunction_t jit_step = nullptr, jit_init = nullptr;
     mhx_stats stats{};
 
@@ -961,7 +963,8 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
     if (tk == MHX_TARGET_IID_NORMAL && d == 2 && pk != MHX_PROP_DENSE && walk == MHX_WALK_PLAIN &&
         !(r->flags & (MHX_FLAG_GENERIC | MHX_FLAG_ZIGGURAT)) &&
         (cfg->reduce_lanes == 64 || (cfg->reduce_lanes == 0 && t->nparams >= 8 && r->n <= 2048))) {
-        r->reg_fn = pk == MHX_PROP_ISO ? k_rwmh_wave<MHX_PROP_ISO> : k_rwmh_wave<MHX_PROP_DIAG>;
+        r->reg_fn = pk == MHX_PROP_ISO ? k_rwmh_wave<MHX_PROP_ISO, 4> : k_rwmh_wave<MHX_PROP_DIAG, 4>;
+        r->reg_fn8 = pk == MHX_PROP_ISO ? k_rwmh_wave<MHX_PROP_ISO, 8> : k_rwmh_wave<MHX_PROP_DIAG, 8>;
         r->variant = 11;
         r->coop_L = 64;
     } else if (tk == MHX_TARGET_IID_NORMAL && cfg->reduce_lanes > 1) {
@@ -1331,8 +1334,10 @@ static int rwmh_advance(mhx_run* r, uint64_t nsteps, uint32_t save_next, int sav
             void* params[] = {&a, &tp, &pv};
             HIP_TRY(hipModuleLaunchKernel(r->jit_step, grid, 1, 1, 64 * MHX_EMCEE_COOP_WAVES, 1, 1, (unsigned)r->dense_lds,
                                           ctx->stream, params, nullptr));
-        } else if (r->variant == 11) {                           // a wave per chain
-            hipLaunchKernelGGL(r->reg_fn, dim3((unsigned)r->n), dim3(64), 0, ctx->stream, a, tp, pv);
+        } else if (r->variant == 11) {                           // a wave per chain; candidates per round: by the last call's acceptance
+            const char* wk = opt(r->ctx, "WAVE_K");
+            const int k = wk ? atoi(wk) : r->wave_k;
+            hipLaunchKernelGGL(k == 8 ? r->reg_fn8 : r->reg_fn, dim3((unsigned)r->n), dim3(64), 0, ctx->stream, a, tp, pv);
         } else if (r->variant == 1) {
             const unsigned grid = (unsigned)((r->n + 63) / 64);
             hipLaunchKernelGGL(r->reg_fn, dim3(grid), dim3(64), 0, ctx->stream, a, tp, pv);
@@ -1526,6 +1531,8 @@ int api_run_sample(mhx_run* r, const mhx_schedule* s, int save_samples)
     r->stats.transitions = nT * (uint64_t)r->n;
     r->stats.accepted = acc_after - acc_before;
     r->stats.wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (r->variant == 11 && r->stats.transitions >= 64)          // (the same chain for either K: only the speed depends on it)
+        r->wave_k = 8.0 * (double)r->stats.accepted < (double)r->stats.transitions ? 8 : 4;
     return MHX_OK;
 }
 

@@ -1277,9 +1277,37 @@ MHX_DEV void mhx_moments_first_body(const mhx_real* __restrict__ x, const mhx_re
 // state after ITS step and writes that step's record after the batch (one chain: 64 consecutive slots, contiguous).  What is left per
 // transition is the dependent chain itself -- two fma, a division, six butterfly steps beside log(sigma), the compare -- and that
 // chain runs K = 4 steps at a time speculatively (below): same decisions, same bits, a quarter of the latency while steps reject.
-template <int PK>
+// N butterflies as ONE, transposed: at offset OFF the lane whose bit OFF is clear keeps the even member of every pair of running sums
+// and the other lane the odd one -- each hands its partner the member it does not keep -- so the N sums halve at each of log2 N
+// levels and lane l is left with the sum of candidate l & (N0 - 1) over its group of N0 lanes.  Every addition has the operands the
+// plain xor-butterfly of that candidate has at that lane (in either order: the same bits).
+template <int N, int OFF>
+MHX_DEV mhx_real mhx_wave_transposed(const mhx_real (&v)[N], const int lane)
+{
+    if constexpr (N == 1) {
+        return v[0];
+    } else {
+        const bool odd = (lane & OFF) != 0;
+        mhx_real w[N / 2];
+#pragma unroll
+        for (int m = 0; m < N / 2; ++m) w[m] = (odd ? v[2 * m + 1] : v[2 * m]) + mhx_lane_xor<OFF>(odd ? v[2 * m] : v[2 * m + 1]);
+        return mhx_wave_transposed<N / 2, 2 * OFF>(w, lane);
+    }
+}
+// ... and the plain butterfly over the remaining offsets OFF, 2 OFF, ..., 32
+template <int OFF>
+MHX_DEV mhx_real mhx_wave_butterfly_from(mhx_real q)
+{
+    if constexpr (OFF <= 32) return mhx_wave_butterfly_from<2 * OFF>(mhx_butterfly_add<OFF>(q));
+    else return q;
+}
+// K = candidates per round (4 or 8; the same chain for any K: a round settles the steps up to its first acceptance).  The host takes
+// 8 while the previous sampling call accepted fewer than one step in eight (a round then settles 6.5 steps at the README model's 6 %
+// against 3.65 with K = 4, for about 1.45 x the instructions), else 4.
+template <int PK, int K = 4>
 MHX_DEV void mhx_rwmh_wave_body(const mhx_rwmh_args& a, const mhx_real* __restrict__ tparams, const mhx_real* __restrict__ pvec)
 {
+    static_assert(K == 4 || K == 8, "candidates per round");
     static_assert(PK != MHX_PROP_DENSE, "ISO / DIAG proposals");
     const int lane = (int)threadIdx.x;                         // one wave per block, one chain per block
     const long c = (long)blockIdx.x;
@@ -1322,9 +1350,7 @@ MHX_DEV void mhx_rwmh_wave_body(const mhx_rwmh_args& a, const mhx_real* __restri
         // of them that is accepted ends the round -- the steps before it were rejections from exactly this state, so their outcome
         // is what the sequential loop computes; the ones after it are discarded and re-done from the new state.  Acceptance is low
         // where this kernel runs (the README example: 6 %), so a round advances almost K steps for the latency of one.
-        constexpr int K = 4;
-        const int kk = lane & 3;                                                 // the candidate whose SCALAR part this lane evaluates
-        const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
+        const int kk = lane & (K - 1);                                           // the candidate whose SCALAR part this lane evaluates
         for (int j = 0; j < nb;) {
             mhx_real y0[K], y1[K], acc[K];
 #pragma unroll
@@ -1352,23 +1378,19 @@ MHX_DEV void mhx_rwmh_wave_body(const mhx_rwmh_args& a, const mhx_real* __restri
             // total of candidate l & 3.  Every addition has the operands the plain butterfly of that candidate has at that lane (in
             // either order: the same bits), so the totals are the shape-64 sums of the spec.  One wave alone on its SIMD issues an
             // instruction every ~5 cycles whatever its class: what a round costs is its instruction count, hence this and the next step.
-            const mhx_real v01 = (b0 ? acc[1] : acc[0]) + mhx_lane_xor<1>(b0 ? acc[0] : acc[1]);
-            const mhx_real v23 = (b0 ? acc[3] : acc[2]) + mhx_lane_xor<1>(b0 ? acc[2] : acc[3]);
-            mhx_real tot = (b1 ? v23 : v01) + mhx_lane_xor<2>(b1 ? v01 : v23);
-            tot = mhx_butterfly_add<4>(tot);
-            tot = mhx_butterfly_add<8>(tot);
-            tot = mhx_butterfly_add<16>(tot);
-            tot = mhx_butterfly_add<32>(tot);
-            // ... and the scalar part of candidate l & 3 on lane l only (one logarithm per lane instead of four)
+            const mhx_real tot = mhx_wave_butterfly_from<K>(mhx_wave_transposed<K, 1>(acc, lane));
+            // ... and the scalar part of candidate l & (K - 1) on lane l only (one logarithm per lane instead of K)
             const int myj = j + kk;
-            const mhx_real my_y1 = kk == 0 ? y1[0] : (kk == 1 ? y1[1] : (kk == 2 ? y1[2] : y1[3]));
+            mhx_real my_y1 = y1[0];
+#pragma unroll
+            for (int k = 1; k < K; ++k) my_y1 = kk == k ? y1[k] : my_y1;
             const mhx_real my_logu = __shfl(mylogu, myj < nb ? myj : nb - 1, 64);
             const mhx_real tt = mhx_log_sel(my_y1) + MHX_HALF_LOG_2PI;           // (mhx_log's value, branch-free)
             const mhx_real v = mhx_fma(-MHX_R(0.5), tot, -(npf * tt));
             const mhx_real my_lpy = (my_y1 > MHX_R(0.0)) ? v : -MHX_INF;         // theta[2] >= 0 support, -Inf at sigma == 0; NaN: reject
-            // the first accepted step of the round (strict compare, src/mh-core.jl:108; NaN compares false): lanes 0 .. 3 speak for
-            // candidates 0 .. 3
-            const mhx_u32 okm = (mhx_u32)__ballot(myj < nb && my_logu < (my_lpy - lp)) & 0xfu;
+            // the first accepted step of the round (strict compare, src/mh-core.jl:108; NaN compares false): lanes 0 .. K-1 speak for
+            // candidates 0 .. K-1
+            const mhx_u32 okm = (mhx_u32)__ballot(myj < nb && my_logu < (my_lpy - lp)) & ((1u << K) - 1u);
             const int first = okm ? (int)__builtin_ctz(okm) : K;                 // wave-uniform
             const int adv = first < K ? first + 1 : (nb - j < K ? nb - j : K);   // steps this round settles
             // lanes j .. j+adv-2 (rejections) record the old state, lane j+adv-1 the new one if it was an acceptance

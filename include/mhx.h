@@ -74,8 +74,9 @@ int mhx_ctx_pci_bus_id(const mhx_ctx *ctx, char *buf, size_t len);
  *                   EMCEE_PRELOAD RAM_G
  *   tuning          COOP_WAVES MFMA_WAVES REG_MAX_DIM REG_XR REG_UNROLL MALA_XR EMCEE_WAVES EMCEE_MFMA_WAVES
  *                   EMCEE_SCAL_WPB EMCEE_SCAL_MODE EMCEE_SCAL_REC EMCEE_REC_STORE EMCEE_ROW_STORE EMCEE_COOP_REC RAM_LDS_PAD
+ *                   WAVE_K (4 | 8 speculative candidates per round of the wave-per-chain kernel; default: by the last call's acceptance)
  * value == NULL unsets.  An unknown name is MHX_EINVAL.  The tools build (libmhx_tools.so, `make tools`) additionally knows
- * timing probes and fault injection (ZIG_PROBE, EMCEE_PROBE, EMCEE_STAMPS, ZIG_FORCE_FAIL, FAULT_SLAB, JIT_DEFS): setting one
+ * timing probes and fault injection (ZIG_PROBE, EMCEE_PROBE, EMCEE_STAMPS, ZIG_FORCE_FAIL, FAULT_SLAB, JIT_DEFS, RAM_PROF): setting one
  * marks the context TAINTED -- mhx_stats.tainted = 1 for every run of it, and the host mirrors refuse to build a Chains from
  * such a run.  In libmhx.so those names do not exist. */
 int mhx_ctx_set_option(mhx_ctx *ctx, const char *name, const char *value);

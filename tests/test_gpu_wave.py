@@ -22,10 +22,14 @@ def _same(a, b, what):
 
 @pytest.mark.parametrize("np_,C,N,disc,thin,prop", [(30, 1, 200, 0, 1, "iso"), (8, 3, 70, 5, 3, "diag"), (64, 70, 130, 0, 2, "iso"),
                                                    (100, 5, 65, 1, 1, "diag"), (300, 2, 64, 63, 64, "iso"), (65, 33, 129, 7, 5, "iso")])
-def test_wave_per_chain_kernel_is_the_oracle_at_shape_64(mhx, oracle, real, np_, C, N, disc, thin, prop):
+@pytest.mark.parametrize("wave_k", [None, 4, 8])
+def test_wave_per_chain_kernel_is_the_oracle_at_shape_64(mhx, oracle, real, engine, np_, C, N, disc, thin, prop, wave_k):
     """terms that fill less than a wave, exactly a wave, several per lane; launches that are not multiples of the 64-step batch;
     discard / thinning (a record every 64th step: one lane of a batch writes); ISO and DIAG proposals; the state afterwards and a
-    second call that continues the chains"""
+    second call that continues the chains; 4 and 8 speculative candidates per round (option WAVE_K; None: the host's choice by the
+    previous call's acceptance -- the same chain either way)"""
+    if wave_k:
+        engine.set("WAVE_K", str(wave_k))
     data = np.load(os.path.join(GOLD, "c1_normal_data.npy"))[:np_]
     model = mhx.DensityModel(mhx.IIDNormal(data))
     if prop == "iso":
