@@ -887,7 +887,7 @@ MHX_DEV void mhx_ram_defer_body(const mhx_ram_args& a, const mhx_real* __restric
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const mhx_real T0 = mhx_fma(sc, nz.pu[e], MHX_R(1.0));
-                const mhx_real T1 = mhx_fma(sc, e < 3 ? nz.pu[e < 3 ? e + 1 : 3] : nz.incl, MHX_R(1.0));
+                const mhx_real T1 = mhx_fma(sc, e < 3 ? nz.pu[(e + 1) & 3] : nz.incl, MHX_R(1.0));    // the prefix of the NEXT element (lane's own total after its last)
                 const bool in = 4 * lane + e < d;
                 if (in && !(T1 > MHX_R(0.0))) bad = true;
                 const mhx_real ae = mhx_sqrt(T1 / T0);
