@@ -1276,7 +1276,7 @@ MHX_DEV void mhx_moments_first_body(const mhx_real* __restrict__ x, const mhx_re
 // the accept uniform of step s0 + l for a batch of 64 steps at once, the chain then takes them by v_readlane; lane l also keeps the
 // state after ITS step and writes that step's record after the batch (one chain: 64 consecutive slots, contiguous).  What is left per
 // transition is the dependent chain itself -- two fma, a division, six butterfly steps beside log(sigma), the compare -- and that
-// chain runs K = 4 steps at a time speculatively (below): same decisions, same bits, a quarter of the latency while steps reject.
+// chain runs K = 4 or 8 steps at a time speculatively (below): same decisions, same bits, 1 / K of the latency while steps reject.
 // N butterflies as ONE, transposed: at offset OFF the lane whose bit OFF is clear keeps the even member of every pair of running sums
 // and the other lane the odd one -- each hands its partner the member it does not keep -- so the N sums halve at each of log2 N
 // levels and lane l is left with the sum of candidate l & (N0 - 1) over its group of N0 lanes.  Every addition has the operands the
