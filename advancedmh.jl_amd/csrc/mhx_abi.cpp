@@ -230,6 +230,11 @@ extern "C" int mhx_run_get_samples(mhx_run* r, void* samples, uint8_t* accepted)
     NEED(r, "mhx_run_get_samples");
     return is64(r) ? mhx_f64::api_run_get_samples(R64(r), D(samples), accepted) : mhx_f32::api_run_get_samples(R32(r), F(samples), accepted);
 }
+extern "C" int mhx_run_host_stats(mhx_run* r, mhx_host_stats* out)
+{
+    NEED(r, "mhx_run_host_stats");
+    return is64(r) ? mhx_f64::api_run_host_stats(R64(r), out) : mhx_f32::api_run_host_stats(R32(r), out);
+}
 extern "C" int mhx_run_sample_to_host(mhx_run* r, const mhx_schedule* s, void* samples, uint8_t* accepted, int32_t slab_samples)
 {
     NEED(r, "mhx_run_sample_to_host");

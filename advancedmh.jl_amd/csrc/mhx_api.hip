@@ -36,6 +36,7 @@
 #else
 #include "mhx_jit_embed.inc"         // generated (embed_headers.py --release): the same text without its MHX_TOOLS_BUILD blocks
 #endif
+#include "mhx_host_expand.h"    // the host threads of the accept-compacted return path (pure host code, shared by both instantiations)
 #include "mhx_impl.h"           // the prototypes of this instantiation (api_*), shared with the dispatcher mhx_abi.cpp
 
 #define HIP_TRY(expr)                                                                              \
@@ -171,6 +172,21 @@ struct jit_module {
     std::map<std::string, hipFunction_t> fns;
 };
 
+// one of three buffer sets a compacted slab travels through (mhx_api_host.inc): device block -> page-locked staging -> host threads
+struct compact_pair {
+    unsigned char* dev_fixed = nullptr;  // header + masks + ranks + accept flags
+    size_t dev_fixed_cap = 0;
+    unsigned char* dev_pay = nullptr;    // the changed columns
+    size_t dev_pay_cap = 0;
+    unsigned char* host = nullptr;       // the block as the host threads read it (page-locked)
+    size_t host_cap = 0;
+    hipEvent_t c0 = nullptr, c1 = nullptr, scattered = nullptr;   // copy begin / end (timed), payload written
+    uint64_t seq = 0;                    // the expander job that reads `host`
+    bool used = false;
+    int device = 0;
+    double link_ms = 0.0;                // copy time of this pair's blocks in the current call (written by one expander thread)
+};
+
 struct mhx_ctx : mhx_handle_hdr {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -183,8 +199,23 @@ struct mhx_ctx : mhx_handle_hdr {
     long pins_registered = 0, pins_released = 0;    // caller buffers page-locked for the duration of a call / released again
     std::map<std::string, std::string> options;     // mhx_ctx_set_option: explicit engine options (never the environment)
     bool tainted = false;                           // a probe / fault-injection option of the tools build was set: results may be invalid
+    // the accept-compacted return path: three buffer sets, the pinned landing place of a block's header, the host threads
+    compact_pair cpair[3];
+    mhx_compact_hdr* hdr_pinned = nullptr;
+    mhx_expander* expander = nullptr;
+    int expander_threads = 0, expander_chunk = 0;   // the options the expander was created with
     ~mhx_ctx()
     {
+        if (expander) mhx_expander_destroy(expander);
+        for (compact_pair& P : cpair) {
+            if (P.dev_fixed) (void)hipFree(P.dev_fixed);
+            if (P.dev_pay) (void)hipFree(P.dev_pay);
+            if (P.host) (void)hipHostFree(P.host);
+            if (P.c0) (void)hipEventDestroy(P.c0);
+            if (P.c1) (void)hipEventDestroy(P.c1);
+            if (P.scattered) (void)hipEventDestroy(P.scattered);
+        }
+        if (hdr_pinned) (void)hipHostFree(hdr_pinned);
         for (int i = 0; i < 2; ++i) {
             if (slab_done[i]) (void)hipEventDestroy(slab_done[i]);
             if (slab_free[i]) (void)hipEventDestroy(slab_free[i]);
@@ -227,6 +258,7 @@ static const opt_name k_opt_names[] = {
     {"EMCEE_MFMA", 0}, {"EMCEE_MFMA_WAVES", 0}, {"EMCEE_SCALAR", 0}, {"EMCEE_SCAL_MODE", 0}, {"EMCEE_SCAL_WPB", 0}, {"EMCEE_SCAL_REC", 0},
     {"EMCEE_FUSED", 0}, {"EMCEE_PERSIST", 0}, {"EMCEE_PRELOAD", 0}, {"EMCEE_DEFER", 0}, {"EMCEE_SWEEP_DEFER", 0}, {"EMCEE_WAVES", 0},
     {"EMCEE_REC_STORE", 0}, {"EMCEE_ROW_STORE", 0}, {"EMCEE_COOP_REC", 0},
+    {"HOST_COMPACT", 0}, {"HOST_THREADS", 0}, {"HOST_CHUNK", 0},
 #ifdef MHX_TOOLS_BUILD
     {"ZIG_PROBE", 1}, {"ZIG_FORCE_FAIL", 1}, {"JIT_DEFS", 1}, {"EMCEE_PROBE", 1}, {"EMCEE_STAMPS", 1}, {"EMCEE_STAMPS_FILE", 1},
     {"FAULT_SLAB", 1}, {"RAM_PROF", 1},
@@ -749,6 +781,7 @@ struct mhx_run : mhx_handle_hdr {
     int wave_k = 4;                      // variant 11: candidates per round of the next call (8 after a call that accepted < 1 step in 8)
     hipFunction_t jit_step = nullptr, jit_init = nullptr;
     mhx_stats stats{};
+    mhx_host_stats host_stats{};         // what the last mhx_run_sample_to_host moved
 
     ~mhx_run()
     {
@@ -1707,6 +1740,13 @@ int api_run_stats(mhx_run* r, mhx_stats* out)
     *out = r->stats;
     out->tainted = r->ctx->tainted ? 1 : 0;
     out->reserved_ = 0;
+    return MHX_OK;
+}
+
+int api_run_host_stats(mhx_run* r, mhx_host_stats* out)
+{
+    if (!r || !out) return mhx_fail(MHX_EINVAL, "mhx_run_host_stats: NULL argument");
+    *out = r->host_stats;
     return MHX_OK;
 }
 

@@ -62,6 +62,7 @@ void mhx_jit_unlock();
     int api_run_save_state(mhx_run* r, void* blob, size_t bytes);                                                      \
     int api_run_load_state(mhx_run* r, const void* blob, size_t bytes);                                                \
     int api_run_stats(mhx_run* r, mhx_stats* out);                                                                     \
+    int api_run_host_stats(mhx_run* r, mhx_host_stats* out);                                                           \
     int api_run_destroy(mhx_run* r);                                                                                   \
     int api_run_diagnostics(mhx_run* r, const mhx_diag_cfg* cfg, double* sum_m, double* sum_m2, double* sum_v,         \
                             double* ess);                                                                              \

@@ -74,6 +74,22 @@ class Stats(C.Structure):
                 ("tainted", C.c_int32), ("reserved_", C.c_int32)]
 
 
+class HostStats(C.Structure):
+    """mhx_host_stats: what the last mhx_run_sample_to_host moved"""
+    _fields_ = [("tensor_bytes", C.c_uint64), ("wire_bytes", C.c_uint64), ("link_ms", C.c_double), ("expand_ms", C.c_double),
+                ("compact", C.c_int32), ("threads", C.c_int32), ("slabs", C.c_int32), ("ring", C.c_int32)]
+
+
+class CompactHdr(C.Structure):
+    """mhx_compact_hdr: the 64-byte header of an accept-compacted block"""
+    _fields_ = [("magic", C.c_uint32), ("elem_bytes", C.c_uint32), ("dim1", C.c_uint32), ("nchains", C.c_uint32),
+                ("first_sample", C.c_uint64), ("count", C.c_uint32), ("words", C.c_uint32), ("total_changed", C.c_uint64),
+                ("payload_offset", C.c_uint64), ("block_bytes", C.c_uint64), ("reserved_", C.c_uint64)]
+
+
+COMPACT_MAGIC = 0x4358484d
+
+
 class DiagCfg(C.Structure):
     _fields_ = [("max_lag", C.c_int32), ("ess_chains", C.c_int32), ("split", C.c_int32)]
 
@@ -93,6 +109,7 @@ EXPORTS = [
     "mhx_ctx_set_option", "mhx_ctx_get_option", "mhx_ctx_pci_bus_id", "mhx_run_shape", "mhx_comm_init_timed", "mhx_comm_set_timeout",
     "mhx_group_create", "mhx_group_destroy", "mhx_group_size", "mhx_group_ctx", "mhx_group_shard", "mhx_group_attach", "mhx_group_run",
     "mhx_group_init", "mhx_group_sample", "mhx_group_sample_to_host", "mhx_group_stats", "mhx_group_diagnostics", "mhx_group_ess_bulk_tail",
+    "mhx_compact_expand", "mhx_run_host_stats",
 ]
 
 MHX_F32, MHX_F64 = 0, 1
@@ -168,6 +185,8 @@ def lib():
         L.mhx_run_sample.argtypes = [vp, C.POINTER(Schedule), C.c_int]
         L.mhx_run_get_samples.argtypes = [vp, rp, u8p]
         L.mhx_run_sample_to_host.argtypes = [vp, C.POINTER(Schedule), rp, u8p, C.c_int32]
+        L.mhx_compact_expand.argtypes = [vp, C.c_size_t, rp, u8p, C.c_int64, C.c_int32]
+        L.mhx_run_host_stats.argtypes = [vp, C.POINTER(HostStats)]
         L.mhx_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
         L.mhx_host_free.argtypes = [vp]
         L.mhx_ctx_jit_counts.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]

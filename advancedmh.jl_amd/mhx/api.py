@@ -633,6 +633,13 @@ class Run:
         self._last_n = n_samples
         return out, acc
 
+    def host_stats(self):
+        """mhx_run_host_stats: what the last sample_to_host moved -- tensor / wire bytes, link and expand time, whether the
+        accept-compacted path ran and with how many host threads"""
+        st = L.HostStats()
+        L.check(L.lib().mhx_run_host_stats(self.h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in L.HostStats._fields_}
+
     def samples(self, want_accepted=True):
         n_saved = C.c_int64()
         L.check(L.lib().mhx_run_device_samples(self.h, None, None, C.byref(n_saved)))

@@ -887,15 +887,45 @@ def e2e_host(mhx, wl):
     buf = mhx.host_array((inner, d + 1, C), run.real)
     accb = mhx.host_array((inner, C), np.uint8)
     out["pinned_alloc_s"] = sig(time.perf_counter() - t0, 3)
-    run.sample_to_host(inner, 1, 1, 0, out=buf, out_accepted=accb)          # untimed: first touch of the slabs and streams
-    reps = 3
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        run.sample_to_host(inner, 1, 1, 0, out=buf, out_accepted=accb)
-    w = (time.perf_counter() - t0) / reps
-    nbytes = buf.nbytes + accb.nbytes
-    out["save_all"] = {"value": sig(C * inner / w), "wall_s": sig(w, 4), "host_GB": sig(nbytes / 1e9, 4), "link_GBps": sig(nbytes / w / 1e9, 4),
-                       "kernel_ms": sig(run.stats()["kernel_ms"], 4)}
+    def timed(label, out_buf, out_acc, reps=3):
+        run.sample_to_host(inner, 1, 1, 0, out=out_buf, out_accepted=out_acc)   # untimed: first touch of the slabs, staging and streams
+        t0 = time.perf_counter()
+        hs = None
+        for _ in range(reps):
+            run.sample_to_host(inner, 1, 1, 0, out=out_buf, out_accepted=out_acc)
+            h = run.host_stats()
+            hs = h if hs is None else {k: (hs[k] + h[k] if k in ("wire_bytes", "link_ms", "expand_ms") else h[k]) for k in h}
+        w = (time.perf_counter() - t0) / reps
+        nbytes = out_buf.nbytes + out_acc.nbytes
+        blk = {"value": sig(C * inner / w), "wall_s": sig(w, 4), "host_GB": sig(nbytes / 1e9, 4), "kernel_ms": sig(run.stats()["kernel_ms"], 4),
+               "compact": hs["compact"], "wire_GB": sig(hs["wire_bytes"] / reps / 1e9, 4)}
+        if hs["compact"]:
+            # link_GBps: the blocks over the time their copies held the link; host_expand_GBps: tensor bytes the host threads wrote
+            # over the time they were at it (first worker in to last worker out, per block); tensor_GBps: what the caller sees
+            blk.update({"link_GBps": sig(hs["wire_bytes"] / max(hs["link_ms"], 1e-9) / 1e6, 4),
+                        "host_expand_GBps": sig(nbytes * reps / max(hs["expand_ms"], 1e-9) / 1e6, 4),
+                        "tensor_GBps": sig(nbytes / w / 1e9, 4), "host_threads": hs["threads"], "slabs": hs["slabs"]})
+        else:
+            blk["link_GBps"] = sig(nbytes / w / 1e9, 4)
+        out[label] = blk
+    # save_all: the boundary's default for a save-all run -- accept-compacted blocks over the link, host threads rebuild the tensor
+    timed("save_all", buf, accb)
+    # ... into plain pageable memory (a numpy / Julia array, touched once before): nothing is page-locked on this path
+    try:
+        pb = np.empty((inner, d + 1, C), run.real)
+        pa = np.empty((inner, C), np.uint8)
+        pb[:] = 0
+        pa[:] = 0
+        timed("save_all_pageable", pb, pa, reps=2)
+        del pb, pa
+    except MemoryError as e:
+        out["save_all_pageable"] = {"error": str(e)[:80]}
+    # ... and the plain path (every row over the link, rounds 3-5): the PCIe link is the bound, B(d+1)+1 bytes per chain-step
+    run.ctx.set_option("HOST_COMPACT", "0")
+    try:
+        timed("save_all_plain", buf, accb, reps=2)
+    finally:
+        run.ctx.set_option("HOST_COMPACT", None)
     thin = max(1, int(round(40 * (d / 0.3) / 256)))
     n_draws = 256
     tb = mhx.host_array((n_draws, d + 1, C), run.real)

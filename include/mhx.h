@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MHX_VERSION 500 /* 0.5.0: mhx_group_* (many GPUs from one process), mhx_ctx_set_option (explicit engine options: the library no longer reads tuning variables from the environment), mhx_stats.tainted, mhx_comm_init_timed / deadlines on the collectives, mhx_ctx_pci_bus_id, mhx_run_shape; 0.4.0: mhx_ram_get_step_stats takes a capacity, watched factors, host pin accounting, kernel variant 9 (0.3.0: overlapped host return path, page-locked host buffers, persistent JIT cache) */
+#define MHX_VERSION 600 /* 0.6.0: the accept-compacted return path (mhx_compact_hdr, mhx_compact_expand, mhx_run_host_stats, options HOST_COMPACT / HOST_THREADS / HOST_CHUNK); 0.5.0: mhx_group_* (many GPUs from one process), mhx_ctx_set_option (explicit engine options: the library no longer reads tuning variables from the environment), mhx_stats.tainted, mhx_comm_init_timed / deadlines on the collectives, mhx_ctx_pci_bus_id, mhx_run_shape; 0.4.0: mhx_ram_get_step_stats takes a capacity, watched factors, host pin accounting, kernel variant 9 (0.3.0: overlapped host return path, page-locked host buffers, persistent JIT cache) */
 
 typedef enum {
     MHX_OK = 0,
@@ -75,6 +75,9 @@ int mhx_ctx_pci_bus_id(const mhx_ctx *ctx, char *buf, size_t len);
  *   tuning          COOP_WAVES MFMA_WAVES REG_MAX_DIM REG_XR REG_UNROLL MALA_XR EMCEE_WAVES EMCEE_MFMA_WAVES
  *                   EMCEE_SCAL_WPB EMCEE_SCAL_MODE EMCEE_SCAL_REC EMCEE_REC_STORE EMCEE_ROW_STORE EMCEE_COOP_REC RAM_LDS_PAD
  *                   WAVE_K (4 | 8 speculative candidates per round of the wave-per-chain kernel; default: by the last call's acceptance)
+ *   return path     HOST_COMPACT (1 / 0: the accept-compacted form of mhx_run_sample_to_host on / off; default: on for thinning == 1
+ *                   and >= 1024 chains) HOST_THREADS (host threads that expand; default: what the process may use) HOST_CHUNK (chains
+ *                   per unit of their work, a multiple of 64; default: so that a unit's state fits a core's L2)
  * value == NULL unsets.  An unknown name is MHX_EINVAL.  The tools build (libmhx_tools.so, `make tools`) additionally knows
  * timing probes and fault injection (ZIG_PROBE, EMCEE_PROBE, EMCEE_STAMPS, ZIG_FORCE_FAIL, FAULT_SLAB, JIT_DEFS, RAM_PROF): setting one
  * marks the context TAINTED -- mhx_stats.tainted = 1 for every run of it, and the host mirrors refuse to build a Chains from
@@ -306,6 +309,55 @@ int mhx_run_get_samples(mhx_run *run, void *samples, uint8_t *accepted);
  * buffers are complete on return.  Bit-identical to mhx_run_sample + mhx_run_get_samples.
  * mhx_stats.kernel_ms then spans the kernels including their waits for a free slab, wall_ms the whole call. */
 int mhx_run_sample_to_host(mhx_run *run, const mhx_schedule *sched, void *samples, uint8_t *accepted, int32_t slab_samples);
+
+/* The ACCEPT-COMPACTED form of that return path (0.6.0).  A rejected transition re-emits the previous Transition
+ * (src/mh-core.jl:109-114; src/emcee.jl:93-101; src/RobustAdaptiveMetropolis.jl:148-150), so at the acceptance rates these samplers
+ * are tuned to three quarters of a save-all tensor repeat the row above, byte for byte.  With thinning == 1 and >= 1024 chains
+ * (or context option HOST_COMPACT = 1; 0 switches it off) mhx_run_sample_to_host therefore moves, per slab, one BLOCK over the link:
+ * a bit per (sample, chain) -- "this chain's column [dim+1] differs from the sample before", found by comparing the bits of the two
+ * columns on the device, whatever the sampler -- and the columns of the chains whose bit is set; sample 0 of a call travels whole.
+ * Host threads inside the library (context option HOST_THREADS; default = what the process may use: affinity mask and cgroup CPU
+ * quota, at most 64) rebuild the caller's tensor from the blocks with non-temporal stores while the next slab is in flight.  The
+ * caller's buffers need not be page-locked on this path (the CPU writes them) and none is registered.  Bit-identical to the plain
+ * path by construction.  C2 in fp64: 13.4 GB of tensor per 250 transitions of 65 536 chains cross the link as 3.2 GB.
+ *
+ * A block:  mhx_compact_hdr | mask u64[count][words] | rank u32[count][words] (pad to 8) | accepted u8[count][nchains] (pad to 8)
+ *           | payload: for sample i  elem[dim1][m_i]   (m_i = set bits of mask[i][.]; row k holds parameter k of the changed
+ *           chains in chain order; parameter dim1-1 is lp)
+ * rank[i][w] = set bits of the block's masks before word (i, w) in (sample, word) order, so sample i's payload starts at element
+ * dim1 * rank[i][0] and chain c of it sits at  rank[i][c/64] - rank[i][0] + popcount(mask[i][c/64] & ((1 << c%64) - 1)). */
+#define MHX_COMPACT_MAGIC 0x4358484du /* "MHXC" */
+typedef struct {
+    uint32_t magic;
+    uint32_t elem_bytes;      /* 4 | 8: the run's dtype */
+    uint32_t dim1;            /* dim + 1 */
+    uint32_t nchains;
+    uint64_t first_sample;    /* row of the call's tensor the block starts at */
+    uint32_t count;           /* samples in the block */
+    uint32_t words;           /* (nchains + 63) / 64 */
+    uint64_t total_changed;   /* sum of m_i */
+    uint64_t payload_offset;  /* bytes from the start of the block */
+    uint64_t block_bytes;     /* payload_offset + total_changed * dim1 * elem_bytes */
+    uint64_t reserved_;
+} mhx_compact_hdr;            /* 64 bytes */
+/* Expand ONE block into the caller's whole tensor samples [n_samples][dim1][nchains] (and accepted [n_samples][nchains], or NULL);
+ * blocks of a call are expanded in order (a block reads the row above its first sample).  The block is validated (sizes, ranks
+ * against masks) before anything is written: MHX_EINVAL otherwise.  For hosts that move samples with their own transport -- the
+ * workers of Distributed.jl or MPI ranks ship blocks, not tensors.  threads <= 0: as above.  Needs no GPU. */
+int mhx_compact_expand(const void *block, size_t block_bytes, void *samples, uint8_t *accepted, int64_t n_samples, int32_t threads);
+
+/* What the last mhx_run_sample_to_host of the run moved, and how */
+typedef struct {
+    uint64_t tensor_bytes;    /* samples + accepted delivered to the caller */
+    uint64_t wire_bytes;      /* bytes of device-to-host copies behind them */
+    double link_ms;           /* time the copies occupied the link (stream events, summed over the slabs) */
+    double expand_ms;         /* compacted path: time the host threads spent on blocks (first worker in to last worker out, summed) */
+    int32_t compact;          /* 1: the accept-compacted path ran */
+    int32_t threads;          /* host threads that expanded */
+    int32_t slabs;
+    int32_t ring;             /* 1: two alternating device slabs (the device kept nothing) */
+} mhx_host_stats;
+int mhx_run_host_stats(mhx_run *run, mhx_host_stats *out);
 /* getparams / setparams!! (src/AdvancedMH.jl:146-157, src/RobustAdaptiveMetropolis.jl:116-121) */
 int mhx_run_get_state(mhx_run *run, void *x, void *lp, uint32_t *accept_counts);
 int mhx_run_set_state(mhx_run *run, const void *x /* lp is recomputed */);

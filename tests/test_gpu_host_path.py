@@ -44,7 +44,12 @@ def _runs(mhx, kind, d, C, seed):
 @pytest.mark.parametrize("slab", [0, 1, 3, -1, -3, -4])
 @pytest.mark.parametrize("sched", [(11, 0, 1, 0), (10, 7, 3, 0), (1, 0, 1, 0), (9, 5, 2, 12), (2, 0, 4, 3)])
 @pytest.mark.parametrize("kind", ["rwmh", "emcee", "ram", "mala"])
-def test_streamed_samples_equal_the_device_tensor(mhx, real, kind, sched, slab):
+@pytest.mark.parametrize("compact", ["1", "0"])
+def test_streamed_samples_equal_the_device_tensor(mhx, real, engine, kind, sched, slab, compact):
+    """compact = 1: the accept-compacted blocks + host threads (include/mhx.h: mhx_compact_hdr), forced at these small sizes and on
+    thinned schedules too (there a chain's column changes when ANY of the skipped transitions was accepted: the device compares
+    bits, it does not trust the accept flag); 0: the plain slab copies."""
+    engine.set("HOST_COMPACT", compact)
     d, nch = (6, 70) if kind != "emcee" else (5, 64)
     mk, init = _runs(mhx, kind, d, nch, 77)
     a, b = mk(), mk()
@@ -68,6 +73,9 @@ def test_streamed_samples_equal_the_device_tensor(mhx, real, kind, sched, slab):
     assert n_saved.value == (0 if ring else N)
     if not ring:
         _same(b.samples()[0], want, "device tensor after the streamed call")
+    hs = b.host_stats()
+    assert hs["compact"] == int(compact) and hs["ring"] == int(ring) and hs["tensor_bytes"] == got.nbytes + got_acc.nbytes
+    assert (hs["threads"] >= 1) == (compact == "1") and hs["slabs"] >= 1
     # both runs continue identically (the RNG counter advanced by the same number of transitions)
     a.sample(3, 1, 1, 0)
     g2, _ = b.sample_to_host(3, 1, 1, 0, slab_samples=-1)
@@ -177,6 +185,7 @@ def test_a_failing_slab_drains_the_copies_and_releases_the_callers_buffer_once(m
     exactly once, and must not leave a half-described tensor behind.  Option FAULT_SLAB = k of the TOOLS build (libmhx_tools.so; the
     release library has no such hook) injects the failure before slab k."""
     d, nch, N = 5, 128, 12
+    tools_engine.set("HOST_COMPACT", "0")                               # the plain path: slab copies into the caller's (registered) buffer
     mk, _ = _runs(mhx, "rwmh", d, nch, 21)
     r, ref = mk(), mk()
     r.init(None), ref.init(None)
@@ -212,3 +221,55 @@ def test_a_failing_slab_drains_the_copies_and_releases_the_callers_buffer_once(m
     s = mhx.Schedule(4, 0, 1, 0)
     buf = np.empty((4, d + 1, nch), dtype=r.real)
     assert mhx.lib().mhx_run_sample_to_host(r2.h, C.byref(s), buf.ctypes.data_as(C.c_void_p), None, -2 ** 31) == mhx.MHX_EINVAL
+
+
+def test_a_failing_slab_on_the_compacted_path_leaves_no_thread_writing(mhx, real, tools_engine):
+    """the same injected failure with the accept-compacted blocks: the call returns only after the host threads have finished the
+    blocks that were already queued (they write the caller's tensor), nothing is registered, and the context stays usable"""
+    d, nch, N = 5, 1100, 12
+    tools_engine.set("HOST_COMPACT", "1")
+    mk, _ = _runs(mhx, "rwmh", d, nch, 21)
+    r, ref = mk(), mk()
+    r.init(None), ref.init(None)
+    reg0, rel0 = r.ctx.host_pin_counts()
+    out = np.full((N, d + 1, nch), np.nan, dtype=r.real)
+    acc = np.zeros((N, nch), dtype=np.uint8)
+    tools_engine.set("FAULT_SLAB", "2")
+    with pytest.raises(mhx.MhxError, match="injected failure at slab 2"):
+        r.sample_to_host(N, 0, 1, 0, out=out, out_accepted=acc, slab_samples=3)
+    tools_engine.delenv("FAULT_SLAB")
+    assert r.ctx.host_pin_counts() == (reg0, rel0)                      # the CPU writes the tensor: no page-locking on this path
+    ref.sample(N, 0, 1, 0)
+    want, want_acc = ref.samples()
+    _same(out[:6], want[:6], "blocks 0 and 1")
+    _same(acc[:6], want_acc[:6], "their accept flags")
+    assert np.isnan(out[6:]).all()
+    r2 = mk()
+    r2.init(None)
+    got, _ = r2.sample_to_host(N, 0, 1, 0, slab_samples=3)
+    _same(got, want, "the next call")
+    assert r2.host_stats()["compact"] == 1
+
+
+@pytest.mark.parametrize("kind,d,nch,N", [("rwmh", 100, 4096, 40), ("emcee", 50, 2048, 30), ("ram", 20, 1500, 25), ("mala", 30, 1027, 20)])
+def test_compacted_path_is_the_default_for_save_all_runs_and_moves_less(mhx, real, kind, d, nch, N):
+    """no option set: thinning == 1 and >= 1024 chains take the compacted path; the wire carries about (acceptance x tensor) +
+    sample 0 + the masks; pageable and page-locked destinations, odd chain counts; equal to the plain path bit for bit"""
+    mk, init = _runs(mhx, kind, d, nch, 5)
+    a, b = mk(), mk()
+    a.init(init), b.init(init)
+    a.sample(N, 0, 1, N // 2 if kind == "ram" else 0)
+    want, want_acc = a.samples()
+    got, got_acc = b.sample_to_host(N, 0, 1, N // 2 if kind == "ram" else 0, pinned=(kind != "rwmh"))
+    _same(got, want, kind)
+    _same(got_acc, want_acc, "accepted")
+    hs = b.host_stats()
+    assert hs["compact"] == 1 and hs["threads"] >= 1
+    changed = (cases.bits(want[1:]) != cases.bits(want[:-1])).any(axis=1).mean()
+    bound = (changed + 1.5 / N) * want.nbytes + 16 * got_acc.size / 8 + got_acc.nbytes + 4096
+    assert hs["wire_bytes"] <= bound, (hs, changed)
+    if kind == "rwmh":
+        assert hs["wire_bytes"] < 0.5 * hs["tensor_bytes"]              # acceptance ~ 0.15 at this step size
+    # a thinned run of the same chains stays on the plain path
+    b.sample_to_host(5, 0, 3, 0)
+    assert b.host_stats()["compact"] == 0
