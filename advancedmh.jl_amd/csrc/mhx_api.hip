@@ -18,6 +18,7 @@
 #include <vector>
 
 #include <errno.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 

@@ -124,15 +124,29 @@ void row_scalar(T* cur, T* out, const uint64_t* mw, int nwords, int nc, const T*
         }
     }
     const size_t bytes = (size_t)nc * sizeof(T);
-    if (stream && bytes >= 64 && ((uintptr_t)out & 15) == 0) {
-        const size_t body = bytes & ~(size_t)15;
-        const __m128i* s = (const __m128i*)cur;
-        __m128i* d = (__m128i*)out;
-        for (size_t i = 0; i < body / 16; ++i) _mm_stream_si128(d + i, _mm_load_si128(s + i));
-        if (bytes > body) memcpy((char*)out + body, (const char*)cur + body, bytes - body);
+    if (stream && bytes >= 128) {
+        unsigned char* o = (unsigned char*)out;
+        const unsigned char* c = (const unsigned char*)cur;
+        const size_t head = (size_t)(-(intptr_t)(uintptr_t)o) & 15;
+        memcpy(o, c, head);
+        const size_t body = (bytes - head) & ~(size_t)15;
+        for (size_t i = 0; i < body; i += 16) _mm_stream_si128((__m128i*)(o + head + i), _mm_loadu_si128((const __m128i*)(c + head + i)));
+        memcpy(o + head + body, c + head + body, bytes - head - body);
     } else {
         memcpy(out, cur, bytes);
     }
+}
+
+// cur[0, bytes) -> out with non-temporal stores on out's own 64-byte lines (out at any alignment: numpy hands out 16-byte aligned
+// blocks); the partial lines at both ends go through the cache
+__attribute__((target("avx512f"))) void stream_bytes_avx512(unsigned char* out, const unsigned char* cur, size_t bytes)
+{
+    size_t head = (size_t)(-(intptr_t)(uintptr_t)out) & 63;
+    if (head > bytes) head = bytes;
+    memcpy(out, cur, head);
+    const size_t body = (bytes - head) & ~(size_t)63;
+    for (size_t i = 0; i < body; i += 64) _mm512_stream_si512((__m512i*)(out + head + i), _mm512_loadu_si512((const void*)(cur + head + i)));
+    memcpy(out + head + body, cur + head + body, bytes - head - body);
 }
 
 __attribute__((target("avx512f"))) void row_avx512_64(uint64_t* cur, uint64_t* out, const uint64_t* mw, int nwords, int nc, const uint64_t* src,
@@ -140,6 +154,22 @@ __attribute__((target("avx512f"))) void row_avx512_64(uint64_t* cur, uint64_t* o
 {
     const int full = nc / 64;            // words whose 64 chains all exist
     const bool nt = stream && ((uintptr_t)out & 63) == 0;
+    if (stream && !nt) {                 // merge in place, then stream the row on the destination's own lines
+        for (int w = 0; w < full; ++w) {
+            const uint64_t bits = mw[w];
+            if (!bits) continue;
+            double* c = (double*)(cur + 64 * w);
+            for (int g = 0; g < 8; ++g) {
+                const __mmask8 m = (__mmask8)(bits >> (8 * g));
+                if (!m) continue;
+                _mm512_store_pd(c + 8 * g, _mm512_mask_expandloadu_pd(_mm512_load_pd(c + 8 * g), m, src));
+                src += __builtin_popcount((unsigned)m);
+            }
+        }
+        stream_bytes_avx512((unsigned char*)out, (const unsigned char*)cur, (size_t)full * 64 * 8);
+        if (full < nwords) row_scalar<uint64_t>(cur + 64 * full, out + 64 * full, mw + full, nwords - full, nc - 64 * full, src, false);
+        return;
+    }
     for (int w = 0; w < full; ++w) {
         const uint64_t bits = mw[w];
         double* c = (double*)(cur + 64 * w);
@@ -170,6 +200,22 @@ __attribute__((target("avx512f"))) void row_avx512_32(uint32_t* cur, uint32_t* o
 {
     const int full = nc / 64;
     const bool nt = stream && ((uintptr_t)out & 63) == 0;
+    if (stream && !nt) {
+        for (int w = 0; w < full; ++w) {
+            const uint64_t bits = mw[w];
+            if (!bits) continue;
+            float* c = (float*)(cur + 64 * w);
+            for (int g = 0; g < 4; ++g) {
+                const __mmask16 m = (__mmask16)(bits >> (16 * g));
+                if (!m) continue;
+                _mm512_store_ps(c + 16 * g, _mm512_mask_expandloadu_ps(_mm512_load_ps(c + 16 * g), m, src));
+                src += __builtin_popcount((unsigned)m);
+            }
+        }
+        stream_bytes_avx512((unsigned char*)out, (const unsigned char*)cur, (size_t)full * 64 * 4);
+        if (full < nwords) row_scalar<uint32_t>(cur + 64 * full, out + 64 * full, mw + full, nwords - full, nc - 64 * full, src, false);
+        return;
+    }
     for (int w = 0; w < full; ++w) {
         const uint64_t bits = mw[w];
         float* c = (float*)(cur + 64 * w);

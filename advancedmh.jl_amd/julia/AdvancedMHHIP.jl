@@ -1,10 +1,12 @@
-# AdvancedMHHIP.jl -- thin `ccall` layer over libmhx.so (include/mhx.h, ABI 0.5) that plugs the MI355X engine
+# AdvancedMHHIP.jl -- thin `ccall` layer over libmhx.so (include/mhx.h, ABI 0.6) that plugs the MI355X engine
 # into AdvancedMH.jl through AbstractMCMC's ensemble dispatch:
 #
 #     model = DensityModel(density)                       # README.md:25-40, unchanged: the closure is traced and JIT-lowered
 #     chain = sample(model, RWMH(MvNormal(zeros(2), I)), MCMCHIP(), 100_000, 65_536;
 #                    param_names = ["μ", "σ"], chain_type = Chains)
 #     chain, stats = sample(model, spl, MCMCHIP(devices = 0:7), 1_000, 262_144; return_stats = true)   # 8 GPUs, ONE call
+#     sample(LogTargetDensity(), spl, MCMCHIP(), 100_000, 65_536)   # README.md:75-90: the LogDensityProblems form -- the ONLY form the
+#     sample(Gaussian(Σ), RobustAdaptiveMetropolis(), MCMCHIP(), N, nchains; num_warmup = N)   # reference's RAM takes (…RAM.jl:175-181)
 #
 # One `ccall` sequence runs all chains x all steps on the GPU(s) and returns the (iterations, params..., lp, chains) tensor that
 # ext/AdvancedMHMCMCChainsExt.jl:96-118 wraps.  The engine computes in Float64 by default -- the reference's arithmetic -- or
@@ -16,6 +18,7 @@
 module AdvancedMHHIP
 
 using AdvancedMH, AbstractMCMC, Distributions, LinearAlgebra, Random
+import LogDensityProblems
 import MCMCChains
 
 include("MHXTrace.jl")
@@ -162,6 +165,21 @@ struct IIDNormal <: DeviceLogDensity; data::Vector{Float64}; end          # READ
 struct Banana <: DeviceLogDensity; dim::Int; b::Float64; end
 struct Funnel <: DeviceLogDensity; dim::Int; end
 struct HipSource <: DeviceLogDensity; src::String; dim::Int; data::Vector{Float64}; end   # written against mhx_real / MHX_R()
+
+# The catalogue speaks the LogDensityProblems interface too (src/AdvancedMH.jl:76-77; the only model form the reference's
+# RobustAdaptiveMetropolis has methods for, src/RobustAdaptiveMetropolis.jl:175-181): `sample(CorrGaussian(Σ), spl, N)` is then the
+# reference's own CPU run of the very object `sample(CorrGaussian(Σ), spl, MCMCHIP(), N, nchains)` puts on the GPU.
+LogDensityProblems.capabilities(::Type{<:DeviceLogDensity}) = LogDensityProblems.LogDensityOrder{0}()
+LogDensityProblems.dimension(t::Union{IsoGaussian,Banana,Funnel,HipSource}) = t.dim
+LogDensityProblems.dimension(t::CorrGaussian) = size(t.Σ, 1)
+LogDensityProblems.dimension(::IIDNormal) = 2
+LogDensityProblems.logdensity(t::IsoGaussian, x) = logpdf(MvNormal(zeros(t.dim), I), x)
+LogDensityProblems.logdensity(t::CorrGaussian, x) = logpdf(MvNormal(zeros(size(t.Σ, 1)), t.Σ), x)
+LogDensityProblems.logdensity(t::IIDNormal, θ) = θ[2] >= 0 ? sum(logpdf.(Normal(θ[1], θ[2]), t.data)) : -Inf   # README.md:29-31
+LogDensityProblems.logdensity(t::Banana, x) =                             # N(0, diag(100, 1, ...)) twisted: x2 + b (x1^2 - 100)
+    logpdf(Normal(0, 10), x[1]) + logpdf(Normal(0, 1), x[2] + t.b * (x[1]^2 - 100)) + sum(logpdf.(Normal(0, 1), x[3:end]))
+LogDensityProblems.logdensity(t::Funnel, x) = logpdf(Normal(0, 3), x[1]) + sum(logpdf.(Normal(0, exp(x[1] / 2)), x[2:end]))
+LogDensityProblems.logdensity(::HipSource, x) = throw(ArgumentError("a HipSource log-density is evaluated on the device only"))
 
 """
     lower(f, dim) -> HipSource
@@ -324,7 +342,11 @@ Base.size(a::SampleTensor) = (size(a.raw, 3), size(a.raw, 2), size(a.raw, 1))
 Base.IndexStyle(::Type{<:SampleTensor}) = IndexCartesian()
 Base.@propagate_inbounds Base.getindex(a::SampleTensor, i::Int, j::Int, k::Int) = a.raw[k, j, i]
 Base.@propagate_inbounds Base.setindex!(a::SampleTensor, v, i::Int, j::Int, k::Int) = (a.raw[k, j, i] = v)
-function SampleTensor{T}(n::Integer, d1::Integer, N::Integer) where {T}
+# `pinned = false`: a plain Julia array.  A save-all run of >= 1024 chains comes back accept-compacted (include/mhx.h:
+# mhx_compact_hdr): host threads inside the library write the tensor, nothing is copied into it by DMA, and page-locking 13 GB
+# (0.55 s on the box) would cost four times what the whole return takes.
+function SampleTensor{T}(n::Integer, d1::Integer, N::Integer; pinned::Bool = true) where {T}
+    pinned || return SampleTensor{T}(Array{T,3}(undef, n, d1, N), nothing)
     p = Ref{Ptr{Cvoid}}(C_NULL)
     rc = ccall((:mhx_host_alloc, libmhx), Cint, (Csize_t, Ref{Ptr{Cvoid}}), n * d1 * N * sizeof(T), p)
     if rc != 0 || p[] == C_NULL                                   # a host that cannot page-lock that much: a Julia Array,
@@ -369,6 +391,14 @@ function run_stats(run::Ptr{Cvoid}, d::Integer, n::Integer, N::Integer)
     sum_m = zeros(d1); sum_m2 = zeros(d1); sum_v = zeros(d1)
     bulk = fill(NaN, d1); tail = fill(NaN, d1)
     split = N >= 4
+    # a tensor larger than the device's free memory was streamed through two slabs and the device kept nothing: the sums are then
+    # "not available" (NaN), not an error after a finished run (MHX_ESTATE = -6)
+    kept = Ref{Int64}(0)
+    check(ccall((:mhx_run_device_samples, libmhx), Cint, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Ref{Int64}), run, C_NULL, C_NULL, kept))
+    if kept[] < N
+        nan = fill(NaN, d1)
+        return stats_tuple(st[], nan, copy(nan), copy(nan), split ? 2n : n, split ? N ÷ 2 : N, bulk, tail)
+    end
     if N >= 2
         cfg = DiagCfg(0, 0, split ? 1 : 0)
         check(ccall((:mhx_run_diagnostics, libmhx), Cint, (Ptr{Cvoid}, Ref{DiagCfg}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
@@ -435,7 +465,7 @@ function make_run(::Type{T}, ctx::Ptr{Cvoid}, tgt::Ptr{Cvoid}, d::Integer, sampl
         prop = sampler.proposal.proposal
         prop isa LangevinProposal || throw(ArgumentError("the GPU path implements MALA(LangevinProposal(σ²)) only"))
         initial_params === nothing && error("please specify initial parameters")   # src/MALA.jl:37
-        cfg = MalaCfg(d, n, seed, first, prop.sigma2, 0, 0)
+        cfg = MalaCfg(d, n, seed, first, prop.sigma2, ens.ziggurat ? MHX_FLAG_ZIGGURAT : Int32(0), 0)
         check(ccall((:mhx_mala_create, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{MalaCfg}, Ref{Ptr{Cvoid}}), ctx, tgt, cfg, run))
     elseif sampler isa AdvancedMH.RobustAdaptiveMetropolis
         cfg = RamCfg(d, n, seed, first, sampler.α, sampler.γ, sampler.eigenvalue_lower_bound, sampler.eigenvalue_upper_bound,
@@ -507,9 +537,13 @@ function AbstractMCMC.sample(
         end
         sched = Schedule(N, discard_initial, thinning, num_warmup)
         # ONE call: the schedule runs while finished slabs of samples stream into the tensor on a second HIP stream
-        tensor = SampleTensor{T}(n, d + 1, N)
+        tensor = SampleTensor{T}(n, d + 1, N; pinned = !(thinning == 1 && n >= 1024))
         GC.@preserve tensor check(ccall((:mhx_run_sample_to_host, libmhx), Cint, (Ptr{Cvoid}, Ref{Schedule}, Ptr{Cvoid}, Ptr{UInt8}, Int32),
                                         run, sched, pointer(tensor.raw), C_NULL, 0))
+        rst = Ref{Stats}()
+        check(ccall((:mhx_run_stats, libmhx), Cint, (Ptr{Cvoid}, Ref{Stats}), run, rst))
+        rst[].tainted != 0 &&                      # whether or not statistics were asked for (include/mhx.h: mhx_stats.tainted)
+            error("the run's context carries a probe option of the tools build (libmhx_tools.so): its chains may be invalid")
         state = return_state ? save_state(T, run, n, d) : nothing
         stats = return_stats ? run_stats(run, d, n, N) : nothing
         if ram && haskey(kwargs, :sampler_stats)
@@ -526,9 +560,6 @@ function AbstractMCMC.sample(
                 Ss = [unpack(view(Sp, :, w, i)) for i in 1:N, w in 1:length(watch)]   # Ss[i, w] == state.S of chain watch[w] after saved step i
             end
             kwargs[:sampler_stats][] = (logα = permutedims(logα), η = η, S = Ss)
-        end
-        if return_stats && stats.tainted
-            error("the run's context carries a probe option of the tools build (libmhx_tools.so): its chains may be invalid")
         end
         # Float64: the tensor itself (it owns its block).  Float32 results are widened ONCE into a Julia array; the block goes now.
         vals = T === Float64 ? tensor : (w = Array{Float64,3}(tensor); tensor.blk === nothing || release!(tensor.blk); w)
@@ -580,14 +611,15 @@ function sample_group(rng, model, sampler, ens::MCMCHIP, N::Integer, nchains::In
             GC.@preserve inits check(ccall((:mhx_group_init, libmhx), Cint, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), g, ptrs))
         end
         sched = Schedule(N, discard_initial, thinning, num_warmup)
-        tensors = [SampleTensor{T}(n, d + 1, N) for n in counts]           # one page-locked block per member
+        tensors = [SampleTensor{T}(n, d + 1, N; pinned = !(thinning == 1 && n >= 1024)) for n in counts]   # one block per member
         outs = Ptr{Cvoid}[Ptr{Cvoid}(pointer(t.raw)) for t in tensors]
         GC.@preserve tensors check(ccall((:mhx_group_sample_to_host, libmhx), Cint, (Ptr{Cvoid}, Ref{Schedule}, Ptr{Ptr{Cvoid}}, Ptr{Ptr{UInt8}}, Int32),
                                          g, sched, outs, C_NULL, 0))
         stats = nothing
+        st = Ref{Stats}()
+        check(ccall((:mhx_group_stats, libmhx), Cint, (Ptr{Cvoid}, Ref{Stats}), g, st))
+        st[].tainted != 0 && error("a member context carries a probe option of the tools build: the chains may be invalid")
         if return_stats                                                    # over ALL chains: the members' sums added on the host
-            st = Ref{Stats}()
-            check(ccall((:mhx_group_stats, libmhx), Cint, (Ptr{Cvoid}, Ref{Stats}), g, st))
             d1 = d + 1
             sum_m = zeros(d1); sum_m2 = zeros(d1); sum_v = zeros(d1); nch = Ref{Int64}(0)
             bulk = fill(NaN, d1); tail = fill(NaN, d1)
@@ -606,7 +638,6 @@ function sample_group(rng, model, sampler, ens::MCMCHIP, N::Integer, nchains::In
                 bulk .= abs.(bulk); tail .= abs.(tail)
             end
             stats = stats_tuple(st[], sum_m, sum_m2, sum_v, Int(nch[]), split ? N ÷ 2 : N, bulk, tail)
-            stats.tainted && error("a member context carries a probe option of the tools build: the chains may be invalid")
         end
         names = param_symbols(param_names, d)
         if chain_type === :shards                                           # the members' tensors as they are: no copy at all
@@ -637,8 +668,22 @@ function AbstractMCMC.sample(rng::Random.AbstractRNG, model::AdvancedMH.DensityM
     return AbstractMCMC.sample(rng, lowered, sampler, ens, N, nchains; initial_params, kwargs...)
 end
 
+# --- the LogDensityProblems form (src/AdvancedMH.jl:56,76-77; README.md:75-90; the only form RobustAdaptiveMetropolis takes:
+# src/RobustAdaptiveMetropolis.jl:175-181,216-222,247-253, test/RobustAdaptiveMetropolis.jl:30-56).  AbstractMCMC wraps an object
+# that implements the interface into `LogDensityModel` before dispatching on the ensemble, so `sample(ℓ, spl, MCMCHIP(), N, nchains)`
+# lands here too.  The dimension comes from the problem itself; a catalogue target goes to its built-in kernel, anything else is
+# traced through `LogDensityProblems.logdensity(ℓ, θ::Vector{Traced})` -- the same lowering as a closure's.  (MALA needs a gradient on
+# the device: the traced source of this round's Julia tracer has none, so the engine refuses as src/MALA.jl:42-52 does.)
+function AbstractMCMC.sample(rng::Random.AbstractRNG, model::AbstractMCMC.LogDensityModel, sampler::AdvancedMH.MHSampler,
+                             ens::MCMCHIP, N::Integer, nchains::Integer; kwargs...)
+    ℓ = model.logdensity
+    dev = ℓ isa DeviceLogDensity ? ℓ : lower(θ -> LogDensityProblems.logdensity(ℓ, θ), LogDensityProblems.dimension(ℓ))
+    return AbstractMCMC.sample(rng, AdvancedMH.DensityModel(dev), sampler, ens, N, nchains; kwargs...)
+end
+
 # convenience: default rng, and the ensemble samplers' nchains-free form
-AbstractMCMC.sample(model::AdvancedMH.DensityModel, sampler::AdvancedMH.MHSampler, ens::MCMCHIP, N::Integer, nchains::Integer = 1; kwargs...) =
+AbstractMCMC.sample(model::Union{AdvancedMH.DensityModel,AbstractMCMC.LogDensityModel}, sampler::AdvancedMH.MHSampler, ens::MCMCHIP, N::Integer,
+                    nchains::Integer = 1; kwargs...) =
     AbstractMCMC.sample(Random.default_rng(), model, sampler, ens, N, nchains; kwargs...)
 
 # --- collectives of a sharded run (RCCL over xGMI behind the C ABI; one Julia process per GPU, e.g. Distributed.jl) -----

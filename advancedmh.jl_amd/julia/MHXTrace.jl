@@ -156,6 +156,8 @@ end
 Base.isless(a::Traced, b::Traced) = a < b
 Base.isless(a::Traced, b::Real) = a < b
 Base.isless(a::Real, b::Traced) = a < b
+Base.isless(a::Traced, b::AbstractFloat) = a < b         # (Base has isless(::Real, ::AbstractFloat) and its mirror: without these two
+Base.isless(a::AbstractFloat, b::Traced) = a < b         #  `isless(θ[1], 0.0)` is an ambiguity error instead of a decision)
 Base.isnan(a::Traced) = a != a
 Base.isinf(a::Traced) = abs(a) == Inf
 Base.isfinite(a::Traced) = abs(a) < Inf

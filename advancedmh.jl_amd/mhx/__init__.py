@@ -3,7 +3,7 @@ from ._lib import (ArgumentError, Context, MhxError, PosDefException, FLAG_GENER
                    EXPORTS, MHX_EINVAL, MHX_ESTATE, Schedule, check, host_array, lib, get_default_dtype, set_default_dtype, use_library, TOOLS_LIB_PATH)
 from .dist import Group
 from .api import (I, Banana, Chains, CorrGaussian, DensityModel, Ensemble, Funnel, HipLogDensity, IIDNormal,
-                  InverseGamma, IsoGaussian, MALA, MCMCDistributed, MCMCHIP, MCMCSerial, MCMCThreads, MetropolisHastings, MvNormal, Normal, RandomWalkProposal,
+                  InverseGamma, IsoGaussian, LogDensityModel, MALA, MCMCDistributed, MCMCHIP, MCMCSerial, MCMCThreads, MetropolisHastings, MvNormal, Normal, RandomWalkProposal,
                   RobustAdaptiveMetropolis, Run, RWMH, StaticMH, StaticProposal, StructArray, combine_diagnostics, StretchProposal,
                   SymmetricRandomWalkProposal, Transition, bundle_samples,
                   logdensity, pack_lower, sample, unpack_lower, zeros)

@@ -256,6 +256,29 @@ class DensityModel:
         return self._handles[ctx]
 
 
+def _is_logdensity_problem(obj):
+    """an object that implements the LogDensityProblems interface: dimension() and logdensity(theta)"""
+    return callable(getattr(obj, "dimension", None)) and callable(getattr(obj, "logdensity", None))
+
+
+class LogDensityModel(DensityModel):
+    """AbstractMCMC.LogDensityModel(problem) -- the LogDensityProblems form of a model (src/AdvancedMH.jl:56,76-77; README.md:75-90),
+    and the ONLY form the reference's RobustAdaptiveMetropolis takes (src/RobustAdaptiveMetropolis.jl:175-181,
+    test/RobustAdaptiveMetropolis.jl:1-9,30-56).  `problem` has  dimension() -> d  and  logdensity(theta) -> lp  (the methods
+    LogDensityProblems.dimension / .logdensity of the Julia object): the dimension comes from the problem, the log-density is traced
+    through problem.logdensity exactly as a closure's is.  A catalogue log-density is its own problem.  `sample(problem, sampler, ...)`
+    wraps by itself, as AbstractMCMC does."""
+
+    def __init__(self, problem, gradient=True):
+        if isinstance(problem, _TargetSpec):
+            super().__init__(problem)
+        elif _is_logdensity_problem(problem):
+            super().__init__(lambda theta: problem.logdensity(theta), dim=int(problem.dimension()), gradient=gradient)
+        else:
+            raise L.ArgumentError(L.MHX_EINVAL, "LogDensityModel: %r does not implement dimension() / logdensity(theta)" % (problem,))
+        self.problem = problem
+
+
 def logdensity(model, x, ctx=None, dtype=None):
     """logdensity(model, params) for one point (d,) or a batch (d, n) -- src/AdvancedMH.jl:74."""
     if isinstance(x, Transition):
@@ -603,13 +626,18 @@ class Run:
         self._last_n = n_samples if mode == 1 else 0
 
     def sample_to_host(self, n_samples, discard_initial=0, thinning=1, num_warmup=0, want_accepted=True, out=None,
-                       out_accepted=None, slab_samples=0, pinned=True):
+                       out_accepted=None, slab_samples=0, pinned=None):
         """mhx_run_sample_to_host: the whole schedule with the samples streamed to the host while the chains keep running
         (two device slabs; what `sample` returns is a host tensor, ext/AdvancedMHMCMCChainsExt.jl:12-39).  Returns
-        (samples [N][dim+1][n], accepted [N][n] or None).  `pinned`: allocate the results page-locked (mhx_host_alloc);
-        `out` / `out_accepted`: caller-provided arrays (any host memory: registered for the call when not page-locked)."""
+        (samples [N][dim+1][n], accepted [N][n] or None).  `pinned`: allocate the results page-locked (mhx_host_alloc); None = only
+        where a DMA writes them -- a save-all run of >= 1024 chains comes back accept-compacted (include/mhx.h: mhx_compact_hdr),
+        host threads write the tensor, and page-locking it would cost more than the whole return (0.55 s for C2's 13 GB);
+        `out` / `out_accepted`: caller-provided arrays (any host memory: registered for the call when a DMA targets them)."""
         s = L.Schedule(n_samples, discard_initial, thinning, num_warmup)
         shape = (n_samples, self.dim + 1, self.n)
+        if pinned is None:
+            oc = self.ctx.get_option("HOST_COMPACT")
+            pinned = not (int(oc) != 0 if oc else (thinning == 1 and self.n >= 1024))
 
         def result(shp, dt):
             # page-locked when asked for and available; a host that cannot lock that much (ulimit -l, fragmented memory) gets
@@ -852,6 +880,8 @@ def sample(model, sampler, N, nchains=1, *more, initial_params=None, discard_ini
         raise L.ArgumentError(L.MHX_EINVAL, "sample: too many positional arguments")
     if discard_initial is None:
         discard_initial = num_warmup
+    if not isinstance(model, DensityModel) and (_is_logdensity_problem(model) or isinstance(model, _TargetSpec)):
+        model = LogDensityModel(model)              # sample(problem, sampler, N): AbstractMCMC wraps what implements the interface
     run = Run(model, sampler, nchains=nchains, seed=seed, first_chain=first_chain, ctx=ctx, flags=flags,
               reduce_lanes=reduce_lanes, dtype=dtype, normal_gen=normal_gen)
     run.init(initial_params)

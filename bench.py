@@ -920,6 +920,20 @@ def e2e_host(mhx, wl):
         del pb, pa
     except MemoryError as e:
         out["save_all_pageable"] = {"error": str(e)[:80]}
+    # ... into a tensor allocated INSIDE the timed region, as a one-shot `sample` call does: the kernel's zeroing of 13 GB of fresh
+    # pages is part of it (the library asks for huge pages on the range; the expanding threads fault them in)
+    try:
+        t0 = time.perf_counter()
+        fb = np.empty((inner, d + 1, C), run.real)
+        fa = np.empty((inner, C), np.uint8)
+        run.sample_to_host(inner, 1, 1, 0, out=fb, out_accepted=fa)
+        w = time.perf_counter() - t0
+        hs = run.host_stats()
+        out["save_all_fresh"] = {"value": sig(C * inner / w), "wall_s": sig(w, 4), "compact": hs["compact"],
+                                 "host_expand_GBps": sig((fb.nbytes + fa.nbytes) / max(hs["expand_ms"], 1e-9) / 1e6, 4)}
+        del fb, fa
+    except MemoryError as e:
+        out["save_all_fresh"] = {"error": str(e)[:80]}
     # ... and the plain path (every row over the link, rounds 3-5): the PCIe link is the bound, B(d+1)+1 bytes per chain-step
     run.ctx.set_option("HOST_COMPACT", "0")
     try:

@@ -244,3 +244,9 @@ def trace_logdensity(f, dim, max_paths=64):
         return emit(g, build(g, paths, 0)), len(paths)
     finally:
         CURRENT[0] = old
+
+
+def trace_logdensity_problem(problem, max_paths=64):
+    """AdvancedMHHIP.jl's method for AbstractMCMC.LogDensityModel: the dimension from LogDensityProblems.dimension(l), the log-density
+    traced through  theta -> LogDensityProblems.logdensity(l, theta)  -- `problem` has dimension() and logdensity(theta)."""
+    return trace_logdensity(lambda theta: problem.logdensity(theta), int(problem.dimension()), max_paths)

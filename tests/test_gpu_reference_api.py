@@ -80,3 +80,53 @@ def test_mala_closure_form_runs_the_same_chain(mhx, real):
     a = mhx.sample(model, mhx.MALA(lambda g: mhx.MvNormal(0.5 * s2 * g, s2 * mhx.I)), 50, 8, initial_params=init, seed=4)
     b = mhx.sample(model, mhx.MALA(s2), 50, 8, initial_params=init, seed=4)
     assert np.array_equal(a.value, b.value) and a.accepted[1:].mean() > 0.2
+
+
+class Gaussian:
+    """test/RobustAdaptiveMetropolis.jl:1-9: a LogDensityProblems object -- `dimension`, `logdensity` -- for a zero-mean Gaussian with
+    Σ = [σ² ρ; ρ σ²].  (The log-density is written out: forward substitution with L = chol(Σ).)"""
+
+    def __init__(self, s2):
+        self.l11 = math.sqrt(s2)
+        self.l21 = (s2 / 2) / self.l11
+        self.l22 = math.sqrt(s2 - self.l21 * self.l21)
+        self.c = math.log(self.l11) + math.log(self.l22) + LOG2PI
+
+    def dimension(self):
+        return 2
+
+    def logdensity(self, x):
+        z1 = x[0] / self.l11
+        z2 = (x[1] - self.l21 * z1) / self.l22
+        return -(z1 * z1 + z2 * z2) / 2 - self.c
+
+
+@pytest.mark.parametrize("s2", [10.0, 0.01])
+def test_ram_takes_the_logdensityproblems_form(mhx, oracle, real, s2):
+    """test/RobustAdaptiveMetropolis.jl:30-69 as the reference writes it: `sample(model, sampler, num_warmup; num_warmup,
+    discard_initial = 0, initial_params = zeros(2), callback)` with `model` a LogDensityProblems OBJECT -- the only form the
+    reference's RobustAdaptiveMetropolis has `step` methods for (src/RobustAdaptiveMetropolis.jl:175-181).  The dimension comes from
+    the problem, the log-density is traced through problem.logdensity; the chains are the oracle's on the emitted source bit for bit,
+    every recorded state.S keeps its diagonal (its eigenvalues) inside the bounds and saturates at the bound the target pushes to."""
+    import cases
+    import user_targets
+    model = Gaussian(s2)
+    spl = mhx.RobustAdaptiveMetropolis(γ=0.51, eigenvalue_lower_bound=0.9, eigenvalue_upper_bound=1.1)
+    num_warmup, C = 1000, 64
+    chain = mhx.sample(model, spl, num_warmup, C, num_warmup=num_warmup, discard_initial=0, initial_params=np.zeros(2), seed=11)
+    assert chain.value.shape == (num_warmup, 3, C) and chain.names == ["param_1", "param_2", "lp"]
+    lo, hi = chain.state.diag_range()
+    assert (lo >= 0.9).all() and (hi <= 1.1).all()
+    assert np.abs((hi if s2 > 0.5 else lo) - (1.1 if s2 > 0.5 else 0.9)).max() < 0.05
+    wrapped = mhx.LogDensityModel(model)                                   # what `sample` made of it (AbstractMCMC wraps the same way)
+    assert wrapped.dim == 2
+    ut = user_targets.host_target(oracle, wrapped.traced.source, 2, data=wrapped.traced.data)
+    N = 120
+    ref = oracle.ram(ut, oracle.schedule(N, 0, 1, N), 11, 0, C, init=np.zeros((2, C), dtype=cases.R()), gamma=0.51, eig_lo=0.9, eig_hi=1.1)
+    bad = np.argwhere(cases.bits(chain.value[:N]) != cases.bits(ref["samples"]))
+    assert len(bad) == 0, bad[:3]
+    # the explicit wrapper and a catalogue target (its own problem) go the same way
+    again = mhx.sample(wrapped, spl, 50, C, num_warmup=50, discard_initial=0, initial_params=np.zeros(2), seed=11)
+    assert np.array_equal(cases.bits(again.value), cases.bits(chain.value[:50]))
+    cat = mhx.sample(mhx.CorrGaussian(np.array([[s2, s2 / 2], [s2 / 2, s2]])), spl, 20, 8, num_warmup=20, initial_params=np.zeros(2))
+    assert cat.value.shape == (20, 3, 8)

@@ -154,3 +154,87 @@ def test_julia_tracer_file_mirrors_the_model():
     # Python's float.hex() is the literal format: the Julia pyhex must produce these for the same doubles
     assert (1.5).hex() == "0x1.8000000000000p+0" and (0.0).hex() == "0x0.0p+0" and (-0.5).hex() == "-0x1.0000000000000p-1"
     assert (5e-324).hex() == "0x0.0000000000001p-1022"
+
+
+# ---- the LogDensityProblems form: src/AdvancedMH.jl:56,76-77, README.md:75-90, the only model form the reference's
+# RobustAdaptiveMetropolis has methods for (src/RobustAdaptiveMetropolis.jl:175-181, test/RobustAdaptiveMetropolis.jl:1-9,30-56)
+class LogTargetDensity:
+    """README.md:80-88: `LogDensityProblems.logdensity(p::LogTargetDensity, θ) = density(θ)`, `dimension(p) = 2`"""
+
+    def __init__(self, density):
+        self.density = density
+
+    def dimension(self):
+        return 2
+
+    def logdensity(self, theta):
+        return self.density(theta)
+
+
+class Gaussian2:
+    """test/RobustAdaptiveMetropolis.jl:1-9,33-40: a zero-mean Gaussian with Σ = [σ² ρ; ρ σ²], ρ = σ²/2, as a LogDensityProblems
+    object.  The log-density is written out (z = L \\ x by forward substitution, L = chol(Σ) on the host) so that the traced text
+    does not depend on how a library orders its operations; `sq` / `lg` are the square root / logarithm of whoever traces."""
+
+    def __init__(self, s2, sq, lg):
+        rho = s2 / 2
+        self.l11 = math.sqrt(s2)
+        self.l21 = rho / self.l11
+        self.l22 = math.sqrt(s2 - self.l21 * self.l21)
+        self.lg11, self.lg22 = math.log(self.l11), math.log(self.l22)     # (tests/julia/check_tracer.jl passes these very doubles)
+
+    def dimension(self):
+        return 2
+
+    def logdensity(self, x):
+        z1 = x[0] / self.l11
+        z2 = (x[1] - self.l21 * z1) / self.l22
+        return -(z1 * z1 + z2 * z2) / 2 - self.lg11 - self.lg22 - J.LOG2PI
+
+
+def test_logdensityproblems_form_lowers_to_the_same_source_as_the_closure():
+    """`sample(LogTargetDensity(), spl, MCMCHIP(), N, nchains)` must reach the kernels `sample(DensityModel(density), ...)` reaches:
+    the glue's LogDensityModel method traces θ -> LogDensityProblems.logdensity(ℓ, θ) with the dimension the problem reports; the
+    emitted text -- the key of the hiprtc module -- is the closure's, character for character (fixture tests/golden/traced_readme.hip)."""
+    from mhx import trace as T
+    import mhx
+    readme, _ = _twins()
+    want = _fixture("traced_readme.hip")
+    got_jl, npaths = J.trace_logdensity_problem(LogTargetDensity(readme_julia))
+    assert got_jl == want and npaths == 2
+    m = mhx.LogDensityModel(LogTargetDensity(readme), gradient=False)     # the Python mirror's form of the same model
+    assert m.traced.source == want and m.dim == 2
+    with pytest.raises(mhx.ArgumentError):
+        mhx.LogDensityModel(lambda theta: 0.0)                            # a bare closure is a DensityModel, not a problem
+
+
+def test_gaussian_problem_of_the_ram_test_has_a_pinned_source():
+    """test/RobustAdaptiveMetropolis.jl's model (σ² = 10 and 0.01): model of the Julia tracer == Python tracer == the committed
+    fixture; evaluated, it is logpdf(MvNormal(zeros(2), Σ), x)"""
+    from mhx import trace as T
+    import mhx
+    import scipy.stats as st
+    for s2, fx in ((10.0, "traced_ldp_gauss2_s10.hip"), (0.01, "traced_ldp_gauss2_s001.hip")):
+        want = _fixture(fx)
+        got_jl, npaths = J.trace_logdensity_problem(Gaussian2(s2, J.sqrt, J.log))
+        m = mhx.LogDensityModel(Gaussian2(s2, T.sqrt, T.log), gradient=False)
+        assert npaths == 1 and got_jl == want, fx
+        assert m.traced.source == want, fx
+        Sig = np.array([[s2, s2 / 2], [s2 / 2, s2]])
+        for x in ([0.3, -1.1], [2.0, 0.5]):
+            assert abs(m.traced.evaluate(x) - st.multivariate_normal([0, 0], Sig).logpdf(x)) < 1e-12 * max(1.0, 1 / s2)
+
+
+def test_julia_glue_has_the_logdensitymodel_method():
+    """what can be held without Julia: the method exists with the dispatch signature AbstractMCMC's ensemble call uses, takes its
+    dimension from LogDensityProblems.dimension, traces through LogDensityProblems.logdensity, and forwards every keyword"""
+    jl = open(os.path.join(HERE, "..", "advancedmh.jl_amd", "julia", "AdvancedMHHIP.jl")).read()
+    m = re.search(r"function AbstractMCMC\.sample\(rng::Random\.AbstractRNG, model::AbstractMCMC\.LogDensityModel, sampler::AdvancedMH\.MHSampler,\s*"
+                  r"ens::MCMCHIP, N::Integer, nchains::Integer; kwargs\.\.\.\)(.*?)\nend\n", jl, flags=re.S)
+    assert m, "no sample(rng, ::LogDensityModel, ::MHSampler, ::MCMCHIP, N, nchains; kwargs...) method"
+    body = m.group(1)
+    assert "LogDensityProblems.dimension(ℓ)" in body and "LogDensityProblems.logdensity(ℓ, θ)" in body
+    assert "ℓ isa DeviceLogDensity ? ℓ" in body                           # a catalogue target keeps its built-in kernel
+    assert re.search(r"AbstractMCMC\.sample\(rng, AdvancedMH\.DensityModel\(dev\), sampler, ens, N, nchains; kwargs\.\.\.\)", body)
+    assert "import LogDensityProblems" in jl
+    assert "LogDensityProblems.capabilities(::Type{<:DeviceLogDensity})" in jl   # LogDensityModel(ℓ) refuses an object without it

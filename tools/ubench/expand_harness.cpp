@@ -8,12 +8,13 @@
 #include <cstring>
 #include <random>
 #include <vector>
+#include <sys/mman.h>
 extern "C" int mhx_compact_expand(const void*, size_t, void*, uint8_t*, int64_t, int32_t);
 size_t mhx_compact_payload_offset(uint32_t count, uint32_t words, uint32_t nchains);
 int main(int argc, char** argv)
 {
     const int T = argc > 1 ? atoi(argv[1]) : 1;
-    const uint32_t n = 65536, d1 = 101, cnt = 5, nblocks = 4, words = n / 64;
+    const uint32_t n = 65536, d1 = 101, cnt = 5, nblocks = argc > 2 ? (uint32_t)atoi(argv[2]) : 4, words = n / 64;
     const size_t N = (size_t)cnt * nblocks;
     std::mt19937_64 g(1);
     std::vector<std::vector<unsigned char>> blocks;
@@ -38,7 +39,8 @@ int main(int argc, char** argv)
         blocks.push_back(std::move(blk));
     }
     double* out = (double*)aligned_alloc(4096, N * d1 * n * 8);
-    memset(out, 0, N * d1 * n * 8);
+    if (argc > 3 && atoi(argv[3])) madvise(out, N * d1 * n * 8, MADV_HUGEPAGE);
+    if (!(argc > 4 && atoi(argv[4]))) memset(out, 0, N * d1 * n * 8);      // argv[4] = 1: first touch happens inside the expansion
     for (int rep = 0; rep < 3; ++rep) {
         auto t0 = std::chrono::steady_clock::now();
         for (auto& b : blocks) if (mhx_compact_expand(b.data(), b.size(), out, nullptr, (int64_t)N, T)) { printf("fail\n"); return 1; }
