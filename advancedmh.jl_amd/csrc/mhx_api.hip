@@ -696,7 +696,8 @@ struct mhx_run : mhx_handle_hdr {
     mhx_ctx* ctx = nullptr;
     const mhx_target* target = nullptr;
     int kind = RUN_RWMH;
-    int dim = 0, n = 0;                  // n = chains / walkers
+    int dim = 0, n = 0;                  // n = chains / walkers (an Ensemble run: all walkers of all its ensembles)
+    int ens_w = 0, n_ens = 1;            // Ensemble runs: walkers per ensemble, ensembles (ids first_id .. first_id + n_ens - 1)
     uint64_t seed = 0, first_id = 0;
     int flags = 0;
     bool initialised = false;
@@ -1652,6 +1653,8 @@ struct ckpt_header {
     double last_eta;           // RAM: step size of the latest adapting transition
 };
 static const uint32_t k_ckpt_magic = 0x5848484du;          // "MHXX"
+// the static-proposal bit and, for Ensemble runs, how many ensembles the walkers form (2 x 8 walkers are not 1 x 16)
+static int32_t ckpt_flags(const mhx_run* r) { return (r->flags & MHX_FLAG_STATIC_PROPOSAL) | (r->n_ens > 1 ? r->n_ens << 8 : 0); }
 struct ckpt_part { void* dev; size_t bytes; };
 // the device arrays that make up the state, in blob order
 static std::vector<ckpt_part> ckpt_parts(mhx_run* r)
@@ -1690,7 +1693,7 @@ int api_run_save_state(mhx_run* r, void* blob, size_t bytes)
     HIP_TRY(hipSetDevice(r->ctx->device));
     if (r->kind == RUN_EMCEE) { int rc = emcee_sync_state(r, 1); if (rc) return rc; }      // walker-major -> ABI layout
     HIP_TRY(hipStreamSynchronize(r->ctx->stream));
-    ckpt_header h = {k_ckpt_magic, 2u, (int32_t)r->kind, r->dim, r->n, r->flags & MHX_FLAG_STATIC_PROPOSAL, r->tau, r->seed, r->first_id,
+    ckpt_header h = {k_ckpt_magic, 2u, (int32_t)r->kind, r->dim, r->n, ckpt_flags(r), r->tau, r->seed, r->first_id,
                      r->target->kind, r->prop_kind, r->variant, r->coop_L, (uint64_t)(need - sizeof(ckpt_header)), r->last_eta};
     char* out = (char*)blob;
     memcpy(out, &h, sizeof h);
@@ -1713,12 +1716,12 @@ int api_run_load_state(mhx_run* r, const void* blob, size_t bytes)
     if (h.kind != (int32_t)r->kind || h.dim != r->dim || h.n != r->n || bytes != need || h.payload_bytes != need - sizeof h)
         return mhx_fail(MHX_EINVAL, "mhx_run_load_state: the blob is a state of sampler kind %d, dim %d, %d chains (%zu bytes); "
                                 "this run is kind %d, dim %d, %d chains (%zu bytes)", h.kind, h.dim, h.n, bytes, (int)r->kind, r->dim, r->n, need);
-    if (h.flags != (r->flags & MHX_FLAG_STATIC_PROPOSAL) || h.target_kind != r->target->kind || h.prop_kind != r->prop_kind ||
+    if (h.flags != ckpt_flags(r) || h.target_kind != r->target->kind || h.prop_kind != r->prop_kind ||
         h.variant != r->variant || h.coop_L != r->coop_L)
         return mhx_fail(MHX_EINVAL, "mhx_run_load_state: the blob was saved by a different configuration (target kind %d, proposal kind %d, "
                                 "static %d, kernel variant %d, %d lane(s) per chain; this run: %d, %d, %d, %d, %d) -- the continuation "
                                 "would not be the saved chain", h.target_kind, h.prop_kind, h.flags, h.variant, h.coop_L,
-                    r->target->kind, r->prop_kind, r->flags & MHX_FLAG_STATIC_PROPOSAL, r->variant, r->coop_L);
+                    r->target->kind, r->prop_kind, ckpt_flags(r), r->variant, r->coop_L);
     HIP_TRY(hipSetDevice(r->ctx->device));
     const char* in = (const char*)blob + sizeof h;
     for (const auto& p : ckpt_parts(r)) {

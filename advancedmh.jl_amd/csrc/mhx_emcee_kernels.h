@@ -62,6 +62,12 @@ struct mhx_emcee_args {
     int nsweeps;              // sweeps of this launch
     mhx_u32 save_next;        // first sweep whose state is recorded (0xffffffff: none), then every `thinning`-th
     int thinning;
+    // MANY ensembles in one launch (mhx_emcee_cfg.n_ensembles; README.md:135-148: `sample(model, Ensemble(..), MCMCThreads(), N,
+    // nchains)` runs nchains independent ensembles): blockIdx.y is the ensemble.  Ensemble e's walkers are columns e W .. e W + W - 1
+    // of every [..][E W] array (x, samples, accepted: leading dimension ld = E W), rows e W .. of the walker-major state, and its
+    // Philox counters carry ensemble_id + e -- the kernels see ONE ensemble through mhx_emcee_pick.
+    int ld;                   // E * nwalkers
+    int ybuf_ens;             // reals between two ensembles' pieces of ybuf
 };
 
 // Pitch (in reals) of a walker's row in the walker-major state: round4(dim) reals.  MHX_XW_LINE = 128 (a build-time knob) rounds rows
@@ -83,6 +89,27 @@ MHX_HD constexpr int mhx_xw_pitch(const int d)
 #define MHX_PROP_DENSE 2
 #endif
 
+// the argument block of ensemble blockIdx.y (wave-uniform: scalar arithmetic on the kernel arguments)
+MHX_DEV mhx_emcee_args mhx_emcee_pick(const mhx_emcee_args& a)
+{
+    mhx_emcee_args b = a;
+    const long e = (long)blockIdx.y;
+    if (e) {
+        const long w = e * (long)a.nwalkers, wp = w * mhx_xw_pitch(a.dim);
+        b.x += w;
+        if (a.xw) b.xw += wp;
+        if (a.xw_out) b.xw_out += wp;
+        b.lp += w;
+        if (a.lp_out) b.lp_out += w;
+        b.acc_count += w;
+        b.last_acc += w;
+        if (a.samples) { b.samples += w; b.accepted += w; }
+        if (a.ybuf) b.ybuf += e * (long)a.ybuf_ens;
+        b.ensemble_id += (mhx_u64)e;
+    }
+    return b;
+}
+
 typedef mhx_real mhx_e4 __attribute__((ext_vector_type(4)));
 
 // D > 0: compile-time dimension, candidate in registers; the walkers are read from the walker-major copy
@@ -102,7 +129,7 @@ MHX_DEV void mhx_emcee_half_body(const mhx_emcee_args& a, const mhx_real* __rest
     const int ostart = a.half ? 0 : halfW;
     const int osize = a.half ? halfW : W - halfW;
     const int d = D > 0 ? D : a.dim;
-    const long ld = W;
+    const long ld = a.ld;
 
     const mhx_philox_key ks = mhx_philox_schedule(a.seed);
     const mhx_emcee_draws dr = mhx_emcee_draw(ks, (mhx_u32)i, (mhx_u32)a.ensemble_id, a.sweep);
@@ -192,7 +219,7 @@ MHX_DEV void mhx_emcee_sweep_reg_body(const mhx_emcee_args& a, const mhx_real* _
     const int t = blk * (int)blockDim.x + (int)threadIdx.x;
     if (t >= cnt) return;
     const int i = (second ? halfW : 0) + t;
-    const long ld = W;
+    const long ld = a.ld;
     constexpr int XP = (D + 3) & ~3;
     // the walker's own row, lp and flag do not wait for the draws: their loads go out first (left where they are used, they were issued
     // behind the Philox rounds and, in the second half, behind the partner's whole evaluation)
@@ -302,7 +329,7 @@ MHX_DEV void mhx_emcee_persist_body(const mhx_emcee_args& a, const mhx_real* __r
     const int t = (int)threadIdx.x;
     const bool owner = t < W;
     const int i = owner ? t : W - 1;
-    const long ld = W;
+    const long ld = a.ld;
     const mhx_philox_key ks = mhx_philox_schedule(a.seed);
     mhx_real x[XP], y[XP];
     const mhx_real* xrow_g = a.xw + (long)i * mhx_xw_pitch(D);
@@ -378,7 +405,7 @@ MHX_DEV void mhx_emcee_init_body(const mhx_emcee_args& a, const mhx_real* __rest
     if (i >= a.nwalkers) return;
     if (draw) {
         const mhx_philox_key ks = mhx_philox_schedule(a.seed);
-        const long ld = a.nwalkers;
+        const long ld = a.ld;
         const int d = a.dim;
         mhx_real* xs = a.x + i;
         const int nblk = (d + 3) >> 2;
@@ -407,7 +434,7 @@ MHX_DEV void mhx_emcee_init_body(const mhx_emcee_args& a, const mhx_real* __rest
     }
     mhx_strided_x xv;
     xv.base = a.x + i;
-    xv.ld = a.nwalkers;
+    xv.ld = a.ld;
     a.lp[i] = mhx_target_eval_lanes<TK>(a.target_kind, xv, a.dim, tparams, a.ntparams, a.tconst, a.reduce_lanes);
     a.acc_count[i] = 0u;
     a.last_acc[i] = 0;
@@ -682,7 +709,7 @@ MHX_DEV void mhx_emcee_coop_body(const mhx_emcee_args& a, const mhx_real* __rest
     const int i = lo + (valid ? t_raw : cnt - 1);
     const int ostart = a.half ? 0 : halfW;
     const int osize = a.half ? halfW : W - halfW;
-    const long ld = W;
+    const long ld = a.ld;
 
     MHX_TP(1, (mhx_real)i);                                               // launch + arguments
     // the walker's own row does not wait for the draw (the partner's does): its loads go out first
@@ -876,7 +903,7 @@ MHX_DEV void mhx_emcee_coop_sweep_body(const mhx_emcee_args& a, const mhx_real* 
     const int t_raw = (blk * MHX_EMCEE_COOP_WAVES + wave) * CPW + cw;
     const bool valid = t_raw < cnt;
     const int i = (second ? halfW : 0) + (valid ? t_raw : cnt - 1);
-    const long ld = W;
+    const long ld = a.ld;
     const mhx_e4 zero4 = {MHX_R(0.0), MHX_R(0.0), MHX_R(0.0), MHX_R(0.0)};
 
     mhx_e4 xs[NQL], ysl[NQL];
@@ -1306,7 +1333,7 @@ MHX_DEV void mhx_emcee_scal_body(const mhx_emcee_args& a, const mhx_real* __rest
     const int i = lo + (valid ? t_raw : cnt - 1);
     const int ostart = a.half ? 0 : halfW;
     const int osize = a.half ? halfW : W - halfW;
-    const long ld = W;
+    const long ld = a.ld;
     MHX_TP(1, (mhx_real)i);
     mhx_e4 xs[NQL], xjs[NQL], ysl[NQL];
     mhx_e4* xrow_i = (mhx_e4*)(a.xw + (long)i * mhx_xw_pitch(D));
@@ -1491,7 +1518,7 @@ MHX_DEV void mhx_emcee_scal_sweep_body(const mhx_emcee_args& a, const mhx_real* 
     const int lo = second ? halfW : 0;
     const int i = lo + (valid ? t_raw : cnt - 1);
     const int r0 = second ? ws : 3 * HB + ws;                                // this walker's first candidate row
-    const long ld = W;
+    const long ld = a.ld;
     const mhx_e4 zero4 = {MHX_R(0.0), MHX_R(0.0), MHX_R(0.0), MHX_R(0.0)};
     // ---- phase 1 (LM lanes per walker): every address is a function of the counters -- own row, partner's row, and (second
     // half) the partner's partner's row go out before anything has come back; then this wave's pieces of the factor
@@ -1664,7 +1691,7 @@ MHX_DEV void mhx_emcee_seq_body(const mhx_emcee_args& a, const mhx_real* __restr
 {
     const int lane = threadIdx.x & 63;
     const int W = a.nwalkers, d = a.dim;
-    const long ld = W;
+    const long ld = a.ld;
     const mhx_philox_key ks = mhx_philox_schedule(a.seed);
     mhx_u32 save_next = a.save_next;
     long slot = a.save_slot;
@@ -1707,7 +1734,7 @@ MHX_DEV void mhx_emcee_seq_body(const mhx_emcee_args& a, const mhx_real* __restr
         }
         if (rec) {
             mhx_real* row = a.samples + slot * (long)(d + 1) * ld;
-            for (long e = lane; e < (long)d * W; e += 64) row[e] = a.x[e];
+            for (long e = lane; e < (long)d * W; e += 64) { const long k = e / W, i = e - k * W; row[k * ld + i] = a.x[k * ld + i]; }
             for (int i = lane; i < W; i += 64) { row[(long)d * ld + i] = a.lp[i]; a.accepted[slot * ld + i] = a.last_acc[i]; }
             save_next += (mhx_u32)a.thinning;
             ++slot;
@@ -1744,8 +1771,9 @@ mhx_jit_emcee_half(mhx_real* const xw, mhx_real* const lp, const mhx_u64 seed, c
     a.xw = xw; a.lp = lp; a.seed = seed; a.ensemble_id = ensemble_id; a.sweep = sweep; a.half = half; a.nwalkers = nwalkers;
     a.t_begin = t_begin; a.t_count = t_count;
 #else
-mhx_jit_emcee_half(const mhx_emcee_args a, const mhx_real* __restrict__ tparams)
+mhx_jit_emcee_half(const mhx_emcee_args a_, const mhx_real* __restrict__ tparams)
 {
+    const mhx_emcee_args a = mhx_emcee_pick(a_);
 #endif
 #if MHX_JIT_SCAL
     // the scalar-factor form: MHX_JIT_L waves per block = row classes = reduction shape; dynamic LDS = y rows + partial sums
@@ -1766,8 +1794,9 @@ mhx_jit_emcee_half(const mhx_emcee_args a, const mhx_real* __restrict__ tparams)
 #if MHX_JIT_SCAL && MHX_EMCEE_SCAL_MODE == 1 && MHX_EMCEE_SCAL_WPB == 32
 // one launch per sweep (scalar-factor form, mixed blocks): LDS = [64] candidate rows, [NW][64] partial sums, [2][WPB] lp and flag
 extern "C" __global__ void __launch_bounds__(64 * MHX_JIT_L)
-mhx_jit_emcee_sweep(const mhx_emcee_args a, const mhx_real* __restrict__ tparams)
+mhx_jit_emcee_sweep(const mhx_emcee_args a_, const mhx_real* __restrict__ tparams)
 {
+    const mhx_emcee_args a = mhx_emcee_pick(a_);
     extern __shared__ mhx_e4 mhx_emcee_lds[];
     mhx_emcee_scal_sweep_body<MHX_JIT_DIM, MHX_JIT_L>(a, tparams, (mhx_real*)mhx_emcee_lds);
 }
@@ -1776,37 +1805,42 @@ mhx_jit_emcee_sweep(const mhx_emcee_args a, const mhx_real* __restrict__ tparams
 #ifdef MHX_JIT_PERSIST_THREADS
 // a small ensemble as one persistent block (lane per walker, any target): dynamic LDS = [W][round4(D) + 1] reals
 extern "C" __global__ void __launch_bounds__(MHX_JIT_PERSIST_THREADS)
-mhx_jit_emcee_persist(const mhx_emcee_args a, const mhx_real* __restrict__ tparams)
+mhx_jit_emcee_persist(const mhx_emcee_args a_, const mhx_real* __restrict__ tparams)
 {
+    const mhx_emcee_args a = mhx_emcee_pick(a_);
     extern __shared__ mhx_e4 mhx_emcee_lds[];
     mhx_emcee_persist_body<MHX_JIT_DIM, MHX_JIT_TK>(a, tparams, (mhx_real*)mhx_emcee_lds);
 }
 #endif
 // one launch per sweep (lane per walker, any target)
 extern "C" __global__ void __launch_bounds__(64)
-mhx_jit_emcee_sweep(const mhx_emcee_args a, const mhx_real* __restrict__ tparams)
+mhx_jit_emcee_sweep(const mhx_emcee_args a_, const mhx_real* __restrict__ tparams)
 {
+    const mhx_emcee_args a = mhx_emcee_pick(a_);
     mhx_emcee_sweep_reg_body<MHX_JIT_DIM, MHX_JIT_TK>(a, tparams);
 }
 #endif
 #if !MHX_JIT_SCAL && MHX_JIT_L > 1
 // one launch per sweep (lane-group form): three candidate rows per walker in LDS, then the factor image
 extern "C" __global__ void __launch_bounds__(64 * MHX_EMCEE_COOP_WAVES)
-mhx_jit_emcee_sweep(const mhx_emcee_args a, const mhx_real* __restrict__ tparams)
+mhx_jit_emcee_sweep(const mhx_emcee_args a_, const mhx_real* __restrict__ tparams)
 {
+    const mhx_emcee_args a = mhx_emcee_pick(a_);
     extern __shared__ mhx_e4 mhx_emcee_lds[];
     constexpr int YS4 = 3 * MHX_EMCEE_COOP_WAVES * (64 / MHX_JIT_L) * mhx_emcee_geom<MHX_JIT_DIM, MHX_JIT_L>::DP4 / 4;
     mhx_emcee_coop_sweep_body<MHX_JIT_DIM, MHX_JIT_L, MHX_JIT_BW>(a, tparams, (mhx_real*)mhx_emcee_lds, mhx_emcee_lds + YS4);
 }
 #endif
 extern "C" __global__ void __launch_bounds__(256)
-mhx_jit_emcee_init(const mhx_emcee_args a, const mhx_real* __restrict__ tparams, const int draw)
+mhx_jit_emcee_init(const mhx_emcee_args a_, const mhx_real* __restrict__ tparams, const int draw)
 {
+    const mhx_emcee_args a = mhx_emcee_pick(a_);
     mhx_emcee_init_body<MHX_JIT_TK>(a, tparams, draw);
 }
 extern "C" __global__ void __launch_bounds__(64)
-mhx_jit_emcee_seq(const mhx_emcee_args a, const mhx_real* __restrict__ tparams)
+mhx_jit_emcee_seq(const mhx_emcee_args a_, const mhx_real* __restrict__ tparams)
 {
+    const mhx_emcee_args a = mhx_emcee_pick(a_);
     mhx_emcee_seq_body<MHX_JIT_TK>(a, tparams);
 }
 #endif

@@ -96,7 +96,7 @@ MHX_DEV void mhx_emcee_mfma_body(const mhx_emcee_args& a, const mhx_real* __rest
     const bool valid = t_raw < cnt && (SWEEP || t_raw < a.t_begin + a.t_count);
     const int lo = second ? halfW : 0;
     const int i = lo + (valid ? t_raw : cnt - 1);
-    const long ld = W;
+    const long ld = a.ld;
     constexpr int PITCH = mhx_xw_pitch(D);
     // ---- the chain of latencies first: own row, draws, partner row(s); then this lane's operands of the factor
     mhx_real xs[NS], xj[NS], y0[NS];
@@ -228,13 +228,15 @@ MHX_DEV void mhx_emcee_mfma_body(const mhx_emcee_args& a, const mhx_real* __rest
 
 #ifdef MHX_JIT_EMCEE_MFMA
 extern "C" __global__ void __launch_bounds__(64 * MHX_EMCEE_MFMA_WAVES)
-mhx_jit_emcee_mfma_half(const mhx_emcee_args a, const mhx_real* __restrict__ img)
+mhx_jit_emcee_mfma_half(const mhx_emcee_args a_, const mhx_real* __restrict__ img)
 {
+    const mhx_emcee_args a = mhx_emcee_pick(a_);
     mhx_emcee_mfma_body<MHX_JIT_DIM, false>(a, img);
 }
 extern "C" __global__ void __launch_bounds__(64 * MHX_EMCEE_MFMA_WAVES)
-mhx_jit_emcee_mfma_sweep(const mhx_emcee_args a, const mhx_real* __restrict__ img)
+mhx_jit_emcee_mfma_sweep(const mhx_emcee_args a_, const mhx_real* __restrict__ img)
 {
+    const mhx_emcee_args a = mhx_emcee_pick(a_);
     mhx_emcee_mfma_body<MHX_JIT_DIM, true>(a, img);
 }
 #endif

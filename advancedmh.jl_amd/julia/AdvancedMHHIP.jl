@@ -48,6 +48,7 @@ end
 struct EmceeCfg
     dim::Int32; nwalkers::Int32; seed::UInt64; ensemble_id::UInt64; stretch::Cdouble; flags::Int32; reduce_lanes::Int32
     init_kind::Int32; init_scale::Cdouble; init_vec::Ptr{Cvoid}; init_mean::Ptr{Cvoid}
+    n_ensembles::Int32
 end
 struct MalaCfg
     dim::Int32; nchains::Int32; seed::UInt64; first_chain::UInt64; sigma2::Cdouble; flags::Int32; reduce_lanes::Int32
@@ -442,20 +443,23 @@ function make_run(::Type{T}, ctx::Ptr{Cvoid}, tgt::Ptr{Cvoid}, d::Integer, sampl
             check(ccall((:mhx_rwmh_create, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{RwmhCfg}, Ref{Ptr{Cvoid}}), ctx, tgt, cfg, run))
         end
     elseif sampler isa AdvancedMH.Ensemble
-        n = sampler.n_walkers
+        # `sample(model, Ensemble(W, ..), MCMCThreads(), N, nchains)` runs nchains ENSEMBLES (README.md:135-148): all of them in this
+        # run (mhx_emcee_cfg.n_ensembles), ids first .. first + nchains - 1, their walkers side by side in the chain axis
+        nens = max(Int(n), 1)
+        n = sampler.n_walkers * nens
         prior = sampler.proposal.proposal                               # what StretchProposal wraps: the prior of the initial walkers
         flags = ens.sequential_ensemble ? MHX_FLAG_EMCEE_SEQUENTIAL : Int32(0)
         if prior isa Union{MvNormal, Normal, AbstractVector{<:Normal}}  # drawn on the device (src/emcee.jl:29-34)
             kind, scale, vec = proposal_spec(T, prior)
             μ = T.(proposal_mean(prior))
             GC.@preserve vec μ begin
-                cfg = EmceeCfg(d, n, seed, first, sampler.proposal.stretch_length, flags, 0,
-                               kind, scale, ptr_or_null(vec), all(iszero, μ) ? Ptr{Cvoid}(C_NULL) : Ptr{Cvoid}(pointer(μ)))
+                cfg = EmceeCfg(d, sampler.n_walkers, seed, first, sampler.proposal.stretch_length, flags, 0,
+                               kind, scale, ptr_or_null(vec), all(iszero, μ) ? Ptr{Cvoid}(C_NULL) : Ptr{Cvoid}(pointer(μ)), nens)
                 check(ccall((:mhx_emcee_create, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{EmceeCfg}, Ref{Ptr{Cvoid}}), ctx, tgt, cfg, run))
             end
         else                                                            # any other Distribution: W host draws, handed over
-            cfg = EmceeCfg(d, n, seed, first, sampler.proposal.stretch_length, flags, 0,
-                           Int32(-1), 1.0, Ptr{Cvoid}(C_NULL), Ptr{Cvoid}(C_NULL))
+            cfg = EmceeCfg(d, sampler.n_walkers, seed, first, sampler.proposal.stretch_length, flags, 0,
+                           Int32(-1), 1.0, Ptr{Cvoid}(C_NULL), Ptr{Cvoid}(C_NULL), nens)
             check(ccall((:mhx_emcee_create, libmhx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{EmceeCfg}, Ref{Ptr{Cvoid}}), ctx, tgt, cfg, run))
             if initial_params === nothing
                 initial_params = reduce(hcat, [prior isa AbstractVector ? map(p -> rand(rng, p), prior) : rand(rng, prior) for _ in 1:n])
@@ -595,9 +599,10 @@ function sample_group(rng, model, sampler, ens::MCMCHIP, N::Integer, nchains::In
             tgt, d = target(T, ctx[], model.logdensity)
             push!(tgts, tgt)
             first = Ref{UInt64}(0); cnt = Ref{Int32}(0)
-            check(ccall((:mhx_group_shard, libmhx), Cint, (Ptr{Cvoid}, Int64, Int32, Ref{UInt64}, Ref{Int32}), g, nchains, i, first, cnt))
-            # chains: member i takes global ids first_chain + [first, first + cnt); an Ensemble: one ensemble per member, ids first_chain + i
-            id0 = sampler isa AdvancedMH.Ensemble ? ens.first_chain + i : ens.first_chain + Int(first[])
+            units = sampler isa AdvancedMH.Ensemble ? max(nchains, m) : nchains      # ensembles (at least one per member) or chains
+            check(ccall((:mhx_group_shard, libmhx), Cint, (Ptr{Cvoid}, Int64, Int32, Ref{UInt64}, Ref{Int32}), g, units, i, first, cnt))
+            # member i takes global ids first_chain + [first, first + cnt): of chains, or of whole ensembles
+            id0 = ens.first_chain + Int(first[])
             run, n, ip = make_run(T, ctx[], tgt, d, sampler, ens, rng, seed, id0, Int(cnt[]), initial_params)
             push!(runs, run); push!(counts, n)
             push!(inits, sampler isa AdvancedMH.Ensemble ? initial_matrix(T, ip, n) : initial_matrix(T, ip, n, lo))

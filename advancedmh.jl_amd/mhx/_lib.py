@@ -53,7 +53,8 @@ class RwmhCfg(C.Structure):
 class EmceeCfg(C.Structure):
     _fields_ = [("dim", C.c_int32), ("nwalkers", C.c_int32), ("seed", C.c_uint64), ("ensemble_id", C.c_uint64),
                 ("stretch", C.c_double), ("flags", C.c_int32), ("reduce_lanes", C.c_int32),
-                ("init_kind", C.c_int32), ("init_scale", C.c_double), ("init_vec", C.c_void_p), ("init_mean", C.c_void_p)]
+                ("init_kind", C.c_int32), ("init_scale", C.c_double), ("init_vec", C.c_void_p), ("init_mean", C.c_void_p),
+                ("n_ensembles", C.c_int32)]
 
 
 class RamCfg(C.Structure):

@@ -566,10 +566,13 @@ class Run:
                 self._keep += [ivec, imean]
             else:
                 self._prior = None
+            # `sample(model, Ensemble(W, ..), MCMCThreads(), N, nchains)` runs nchains ENSEMBLES (README.md:135-148): here all of
+            # them in one run, ids first_chain .. first_chain + nchains - 1, walkers side by side in the chain axis
+            self.n_ensembles = max(1, int(nchains))
             cfg = L.EmceeCfg(d, sampler.n_walkers, seed, first_chain, sampler.proposal.stretch_length, flags, reduce_lanes,
-                             ik, isc, L.rptr(ivec), L.rptr(imean))
+                             ik, isc, L.rptr(ivec), L.rptr(imean), self.n_ensembles)
             L.check(lib.mhx_emcee_create(self.ctx.h, model.handle(self.ctx), C.byref(cfg), C.byref(self.h)))
-            self.n = sampler.n_walkers
+            self.n = sampler.n_walkers * self.n_ensembles
             self.kind = "emcee"
         elif isinstance(sampler, MALA):
             cfg = L.MalaCfg(d, nchains, seed, first_chain, sampler.resolve(d), flags, reduce_lanes)

@@ -66,12 +66,15 @@ class Group:
         return [c.pci_bus_id() for c in self.ctxs]
 
     def create(self, model, sampler, nchains=1, seed=0, first_chain=0, **kw):
-        """One Run per member: chains [first_chain + shard) by global id (an Ensemble: one ensemble per member, ids first_chain + i)."""
+        """One Run per member: chains [first_chain + shard) by global id (an Ensemble: whole ensembles by global id, at least one per member)."""
         from .api import Ensemble, Run
         self.close_runs()
         for i, ctx in enumerate(self.ctxs):
             if isinstance(sampler, Ensemble):
-                self.runs.append(Run(model, sampler, seed=seed, first_chain=first_chain + i, ctx=ctx, **kw))
+                # nchains ENSEMBLES (README.md:135-148) dealt to the members by global id, at least one each; a member runs its
+                # ensembles in one launch (mhx_emcee_cfg.n_ensembles)
+                f, n = self.shard(max(nchains, len(self.ctxs)), i)
+                self.runs.append(Run(model, sampler, nchains=n, seed=seed, first_chain=first_chain + f, ctx=ctx, **kw))
             else:
                 f, n = self.shard(nchains, i)
                 self.runs.append(Run(model, sampler, nchains=n, seed=seed, first_chain=first_chain + f, ctx=ctx, **kw))

@@ -210,6 +210,13 @@ typedef struct {
     double init_scale;      /* ISO: sigma */
     const void *init_vec;   /* DIAG: sigma_k [dim]; DENSE: chol(Sigma) packed lower [dim(dim+1)/2] */
     const void *init_mean;  /* mu [dim] or NULL */
+    int32_t n_ensembles;    /* 0.6.0: E independent ensembles in ONE run -- `sample(model, Ensemble(W, ..), MCMCThreads(), N, nchains)`
+                               (README.md:135-148) runs nchains ENSEMBLES, and emcee is run at sizes (test/emcee.jl:24: 1000 walkers) that
+                               leave the chip idle one at a time.  0 / 1 = one.  Ensemble e carries id ensemble_id + e in its RNG counters
+                               and is bit for bit the run of that id alone; its walkers are columns e W .. e W + W - 1 of every
+                               [..][E W] array (x, samples, accepted; mhx_run_shape reports E W chains).  Every launch takes E as a second
+                               grid dimension; an ensemble of <= 1024 walkers (kernel variant 6) is one persistent block, so E of them
+                               occupy E CUs.  The sharded-ensemble building blocks below (mhx_emcee_half_step ...) need E = 1. */
 } mhx_emcee_cfg;
 
 int mhx_emcee_create(mhx_ctx *ctx, const mhx_target *t, const mhx_emcee_cfg *cfg, mhx_run **out);
