@@ -2,6 +2,7 @@
 // belongs to (namespace mhx_f32: mhx_real = float, namespace mhx_f64: mhx_real = double; mhx_impl.h).  The first word
 // of every handle is its mhx_dtype.  No device code here.
 #include "mhx_impl.h"
+#include "mhx_host_expand.h"    // mhx_numa_*: placement of page-locked result memory
 
 #include <hip/hip_runtime_api.h>   // hipHostMalloc / hipHostFree only (mhx_host_alloc): no device code here
 
@@ -108,7 +109,15 @@ extern "C" int mhx_host_alloc(size_t bytes, void** out)
     if (!out) return mhx_fail(MHX_EINVAL, "mhx_host_alloc: out is NULL");
     *out = nullptr;
     if (!bytes) return MHX_OK;
-    hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    // on the memory node of the calling thread's current device: what fills a result tensor -- the GPU's DMA engine, or the host
+    // threads that expand accept-compacted blocks, which keep to that node -- then works on local memory
+    int dev = 0, node = -1;
+    char bus[32] = {0};
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetPCIBusId(bus, (int)sizeof bus, dev) == hipSuccess) node = mhx_numa_node_of_pci(bus);
+    else (void)hipGetLastError();
+    if (node >= 0) mhx_numa_prefer(node);
+    hipError_t e = hipHostMalloc(out, bytes, node >= 0 ? hipHostMallocNumaUser : hipHostMallocDefault);
+    if (node >= 0) mhx_numa_default();
     if (e != hipSuccess) {
         *out = nullptr;
         return mhx_fail(MHX_ENOMEM, "mhx_host_alloc: %zu page-locked bytes: %s", bytes, hipGetErrorString(e));

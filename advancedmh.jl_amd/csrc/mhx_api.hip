@@ -204,7 +204,7 @@ struct mhx_ctx : mhx_handle_hdr {
     compact_pair cpair[3];
     mhx_compact_hdr* hdr_pinned = nullptr;
     mhx_expander* expander = nullptr;
-    int expander_threads = 0, expander_chunk = 0;   // the options the expander was created with
+    int expander_threads = 0, expander_chunk = 0, expander_numa = -1;   // the options / memory node the expander was created with
     ~mhx_ctx()
     {
         if (expander) mhx_expander_destroy(expander);
@@ -259,7 +259,7 @@ static const opt_name k_opt_names[] = {
     {"EMCEE_MFMA", 0}, {"EMCEE_MFMA_WAVES", 0}, {"EMCEE_SCALAR", 0}, {"EMCEE_SCAL_MODE", 0}, {"EMCEE_SCAL_WPB", 0}, {"EMCEE_SCAL_REC", 0},
     {"EMCEE_FUSED", 0}, {"EMCEE_PERSIST", 0}, {"EMCEE_PRELOAD", 0}, {"EMCEE_DEFER", 0}, {"EMCEE_SWEEP_DEFER", 0}, {"EMCEE_WAVES", 0},
     {"EMCEE_REC_STORE", 0}, {"EMCEE_ROW_STORE", 0}, {"EMCEE_COOP_REC", 0},
-    {"HOST_COMPACT", 0}, {"HOST_THREADS", 0}, {"HOST_CHUNK", 0},
+    {"HOST_COMPACT", 0}, {"HOST_THREADS", 0}, {"HOST_CHUNK", 0}, {"HOST_NUMA", 0},
 #ifdef MHX_TOOLS_BUILD
     {"ZIG_PROBE", 1}, {"ZIG_FORCE_FAIL", 1}, {"JIT_DEFS", 1}, {"EMCEE_PROBE", 1}, {"EMCEE_STAMPS", 1}, {"EMCEE_STAMPS_FILE", 1},
     {"FAULT_SLAB", 1}, {"RAM_PROF", 1},

@@ -26,7 +26,10 @@
 
 #include <emmintrin.h>
 #include <immintrin.h>
+#include <pthread.h>
 #include <sched.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 namespace {
 
@@ -278,6 +281,65 @@ void expand_chunk(const block_view& v, T* samples, uint8_t* accepted, uint32_t c
 
 }  // namespace
 
+// ---- NUMA placement (mhx_host_expand.h) -----------------------------------------------------------------------------------
+int mhx_numa_node_of_pci(const char* bus_id)
+{
+    if (!bus_id || !*bus_id) return -1;
+    char path[256], id[64];
+    size_t n = 0;
+    for (; bus_id[n] && n + 1 < sizeof id; ++n) id[n] = (char)((bus_id[n] >= 'A' && bus_id[n] <= 'F') ? bus_id[n] + 32 : bus_id[n]);   // sysfs spells hex in lower case
+    id[n] = 0;
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", id);
+    int node = -1;
+    if (FILE* f = fopen(path, "r")) {
+        if (fscanf(f, "%d", &node) != 1) node = -1;
+        fclose(f);
+    }
+    if (node < 0) return -1;
+    if (FILE* f = fopen("/sys/devices/system/node/node1/cpulist", "r")) fclose(f); else return -1;      // a single node: nothing to place
+    return node;
+}
+void mhx_numa_prefer(int node)
+{
+#ifdef SYS_set_mempolicy
+    if (node < 0 || node >= 1024) return;
+    unsigned long mask[16] = {0};
+    mask[node / 64] = 1ul << (node % 64);
+    (void)syscall(SYS_set_mempolicy, 1 /* MPOL_PREFERRED */, mask, 1025ul);
+#else
+    (void)node;
+#endif
+}
+void mhx_numa_default(void)
+{
+#ifdef SYS_set_mempolicy
+    (void)syscall(SYS_set_mempolicy, 0 /* MPOL_DEFAULT */, nullptr, 0ul);
+#endif
+}
+// the CPUs of `node` this process may run on ("0-63,128-191"); false when there are none (a cpuset elsewhere: stay unpinned)
+static bool node_cpus(int node, cpu_set_t* out)
+{
+    char path[128];
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    FILE* f = fopen(path, "r");
+    if (!f) return false;
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) { fclose(f); return false; }
+    CPU_ZERO(out);
+    int a = 0, b = 0, got = 0;
+    char sep = 0;
+    while (fscanf(f, "%d", &a) == 1) {
+        b = a;
+        if (fscanf(f, "%c", &sep) == 1 && sep == '-') { if (fscanf(f, "%d", &b) != 1) break; if (fscanf(f, "%c", &sep) != 1) sep = 0; }
+        for (int c = a; c <= b && c < CPU_SETSIZE; ++c)
+            if (CPU_ISSET(c, &allowed)) { CPU_SET(c, out); ++got; }
+        if (sep != ',') break;
+    }
+    fclose(f);
+    return got > 0;
+}
+
 int mhx_host_usable_cpus(void)
 {
     int n = (int)std::thread::hardware_concurrency();
@@ -301,13 +363,18 @@ size_t mhx_compact_payload_offset(uint32_t count, uint32_t words, uint32_t nchai
 // ---------------------------------------------------------------------------------------------------------------------------
 class mhx_expander {
 public:
-    mhx_expander(int threads, int chunk) : chunk_(chunk)
+    mhx_expander(int threads, int chunk, int numa_node = -1) : chunk_(chunk)
     {
         if (threads <= 0) threads = mhx_host_usable_cpus();
         if (threads > 64) threads = 64;
         nthreads_ = threads;
         scratch_.resize((size_t)threads);
-        for (int t = 0; t < threads; ++t) workers_.emplace_back([this, t] { work(t); });
+        pin_ = numa_node >= 0 && node_cpus(numa_node, &cpus_);
+        for (int t = 0; t < threads; ++t)
+            workers_.emplace_back([this, t] {
+                if (pin_) (void)pthread_setaffinity_np(pthread_self(), sizeof cpus_, &cpus_);   // the node's CPUs, not one each: the kernel balances
+                work(t);
+            });
     }
     ~mhx_expander()
     {
@@ -474,6 +541,8 @@ private:
     }
 
     int nthreads_ = 1, chunk_ = 0;
+    bool pin_ = false;
+    cpu_set_t cpus_;
     std::vector<std::thread> workers_;
     std::vector<scratch> scratch_;
     std::mutex mu_;
@@ -486,7 +555,7 @@ private:
     double busy_s_ = 0.0;
 };
 
-mhx_expander* mhx_expander_create(int threads, int chunk_chains) { return new mhx_expander(threads, chunk_chains); }
+mhx_expander* mhx_expander_create(int threads, int chunk_chains, int numa_node) { return new mhx_expander(threads, chunk_chains, numa_node); }
 void mhx_expander_destroy(mhx_expander* e) { delete e; }
 int mhx_expander_threads(const mhx_expander* e) { return e->threads(); }
 uint64_t mhx_expander_submit(mhx_expander* e, const mhx_expand_job& job) { return e->submit(job); }
@@ -507,7 +576,7 @@ extern "C" int mhx_compact_expand(const void* block, size_t block_bytes, void* s
     // sizes first (view_block), so that the arrays the checks walk lie inside the buffer
     if (h.count && h.words && mhx_compact_payload_offset(h.count, h.words, h.nchains) > block_bytes)
         return mhx_fail(MHX_EINVAL, "mhx_compact_expand: the block's arrays do not fit into %zu bytes", block_bytes);
-    mhx_expander e(threads, 0);
+    mhx_expander e(threads, 0, -1);
     mhx_expand_job j;
     j.block = block;
     j.samples = samples;

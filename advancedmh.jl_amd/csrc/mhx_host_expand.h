@@ -24,8 +24,16 @@ struct mhx_expand_job {
 };
 
 class mhx_expander;
-// threads <= 0: as many as the process may use (affinity mask, cgroup CPU quota), at most 64
-mhx_expander* mhx_expander_create(int threads, int chunk_chains /* 0 = choose */);
+// threads <= 0: as many as the process may use (affinity mask, cgroup CPU quota), at most 64.  numa_node >= 0: the workers keep to
+// the CPUs of that memory node (the GPU's: the blocks they read were written there by its DMA engine) where the process may run on any
+mhx_expander* mhx_expander_create(int threads, int chunk_chains /* 0 = choose */, int numa_node /* -1 = anywhere */);
+
+// ---- NUMA placement without libnuma (raw set_mempolicy; every call is a hint that may fail silently)
+// memory node of a PCI device "dddd:bb:dd.f" (sysfs numa_node), -1 when unknown or the machine has one node
+int mhx_numa_node_of_pci(const char* bus_id);
+// the calling thread's NEW pages come from `node` if it has room (MPOL_PREFERRED) / from wherever the thread runs (default) again
+void mhx_numa_prefer(int node);
+void mhx_numa_default(void);
 void mhx_expander_destroy(mhx_expander* e);
 int mhx_expander_threads(const mhx_expander* e);
 // queue a slab; jobs are expanded strictly in order (slab c + 1 reads the last row slab c wrote).  Returns its sequence number.

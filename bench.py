@@ -293,6 +293,12 @@ class C3:
 
     def __init__(self, args, dtype):
         self.d, self.W, self.inner, self.dtype = args.dim or 50, args.chains or 16384, args.inner or 500, dtype
+        self.E = 1
+        if getattr(args, "c3_small", False):
+            # the sizes emcee is run at (test/emcee.jl:24: 1 000 walkers), as MANY ensembles in one run -- what
+            # `sample(model, Ensemble(1000, ..), MCMCThreads(), N, nchains)` is (README.md:135-148); --ensembles 1 = one ensemble alone
+            self.d, self.W = args.dim or 5, args.chains or 1000
+            self.E = max(1, getattr(args, "ensembles", 0) or 256)
         self.lanes = args.lanes
         self.rotated = getattr(args, "c3_rotated", False)
         self.user = getattr(args, "c3_user", False)       # the AR(1) target as a user log-density in HIP source (DensityModel(f)): lane per walker
@@ -326,7 +332,8 @@ MHX_LOGDENSITY(x, d, data, ndata)
         else:
             model = mhx.DensityModel(mhx.CorrGaussian(self.Sig))
         spl = mhx.Ensemble(self.W, mhx.StretchProposal(mhx.MvNormal(mhx.zeros(d), mhx.I)))
-        self.run = mhx.Run(model, spl, seed=3, first_chain=rank, ctx=ctx, reduce_lanes=self.lanes)   # one ensemble per GPU (replicas)
+        # one ensemble per GPU (replicas), or E of them in one run (ids rank E .. rank E + E - 1)
+        self.run = mhx.Run(model, spl, nchains=self.E, seed=3, first_chain=rank * self.E, ctx=ctx, reduce_lanes=self.lanes)
         self.run.init(None)
         return self.run
 
@@ -338,19 +345,25 @@ MHX_LOGDENSITY(x, d, data, ndata)
         return self.run.stats()
 
     def units_per_step(self):
-        return self.W * self.inner
+        return self.W * self.E * self.inner
 
     def bytes_per_launch(self):
         """per move read x_i, x_j, write x_i, lp r/w (3Bd + 2B) + record B(d+1)+1"""
         B = RB[self.dtype]
-        return self.W * self.inner * (3 * B * self.d + 2 * B + B * (self.d + 1) + 1)
+        if hasattr(self, "run") and self.run.stats().get("kernel_variant") == 6:
+            # a persistent block per ensemble: walkers stay in registers / LDS for the whole launch -- the record is all that moves
+            return self.W * self.E * (self.inner * (B * (self.d + 1) + 1) + 2 * (B * self.d + 2 * B))
+        return self.W * self.E * self.inner * (3 * B * self.d + 2 * B + B * (self.d + 1) + 1)
 
     def describe(self):
         st = self.run.stats() if hasattr(self, "run") else {}
         band = st.get("factor_band", -1)
         per_sweep = "one launch per sweep" if 0 < st.get("launches", 0) <= self.inner else "two launches per sweep"
-        return "emcee stretch a=2, d=%d Gaussian %s, %d walkers (one ensemble/GPU), %d sweeps/step, save-all, half-split sweep (%s), %s" % (
-            self.d, "Q(0.9^|i-j|)Q^T" if self.rotated else "0.9^|i-j|", self.W, self.inner, per_sweep,
+        if st.get("kernel_variant") == 6:
+            per_sweep = "a persistent block per ensemble: one launch per step"
+        return "emcee stretch a=2, d=%d Gaussian %s, %d walkers (%s), %d sweeps/step, save-all, half-split sweep (%s), %s" % (
+            self.d, "Q(0.9^|i-j|)Q^T" if self.rotated else "0.9^|i-j|", self.W, "one ensemble/GPU" if self.E == 1 else "%d ensembles in one run" % self.E,
+            self.inner, per_sweep,
             "user log-density (HIP source, hiprtc)" if self.user else "factor " + ("band %d" % band if band >= 0 else "dense"))
 
     def cpu_baseline(self, O, target_seconds):
@@ -832,13 +845,48 @@ def roofline_block(wl, key, dtype, kernel_ms, steps, st):
     return out
 
 
+def c3_latency_floor(mhx, ctx, w, st):
+    """What bounds C3 is not bandwidth (26.6 MB per sweep live in the 256 MiB Infinity Cache) but the launch's DEPENDENT CHAIN:
+    kernel boundary -> partner draw -> row gather -> A y -> accept -> state and record stores visible to the next launch.  The floor
+    is measured, not modelled: the SAME kernel form on the same target with 256 walkers (one or two blocks per half, every CU but a
+    few idle) -- a sweep of it is the chain with no throughput term.  frac = that time / the time of a full-size sweep."""
+    import numpy as np
+    fused = st["launches"] <= w.inner
+    opts = {"EMCEE_MFMA": "1" if st["kernel_variant"] == 10 else "0", "EMCEE_PERSIST": "0", "EMCEE_FUSED": "1" if fused else "0"}
+    old = {k: ctx.get_option(k) for k in opts}
+    try:
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        a = type("A", (), {})()
+        a.dim, a.chains, a.inner, a.lanes = w.d, 256, w.inner, w.lanes
+        a.c3_rotated, a.c3_user, a.c3_small = w.rotated, w.user, False
+        f = C3(a, w.dtype)
+        f.build(mhx, ctx, 0)
+        f.run.sample(*f.sched()[:4], save=True)
+        ms = []
+        for _ in range(5):
+            f.run.sample(*f.sched()[:4], save=True)
+            ms.append(f.run.stats()["kernel_ms"])
+        fs = f.run.stats()
+        f.run.close()
+        if fs["kernel_variant"] != st["kernel_variant"] or fs["reduce_lanes"] != st["reduce_lanes"]:
+            return None
+        return float(np.median(ms)) * 1e3 / w.inner               # microseconds per sweep
+    finally:
+        for k, v in old.items():
+            ctx.set_option(k, v or None)
+
+
 def other_configs(mhx, ctx, args, barrier):
     """The other BASELINE.json configs in the same driver run (N = 1, rank 0, after the headline's timed region), one compact
     block each: value, ms_per_step, acceptance, bound / frac of the dominant kernel, PMC traffic over algorithmic bytes, launch
     time, and the CPU baseline (2 s samples).  What each key is: DESIGN.md section 7."""
     import copy
     plan = [("c1", "c1", {}, 3, 1), ("c2_literal", "c2", {"c2_literal": True}, 20, 10), ("c2_user", "c2", {"c2_user": True}, 10, 5),
-            ("c3", "c3", {}, 10, 10), ("c3_rotated", "c3", {"c3_rotated": True}, 10, 10), ("c3_user", "c3", {"c3_user": True}, 10, 10), ("c4", "c4", {}, 3, 2),
+            ("c3", "c3", {}, 10, 10), ("c3_rotated", "c3", {"c3_rotated": True}, 10, 10), ("c3_user", "c3", {"c3_user": True}, 10, 10),
+            # emcee at the sizes it is used at: 256 ensembles x 1000 walkers in one run (a persistent block per ensemble), and one alone
+            ("c3_small", "c3", {"c3_small": True}, 5, 3), ("c3_small_one", "c3", {"c3_small": True, "ensembles": 1}, 5, 3),
+            ("c4", "c4", {}, 3, 2),
             ("c4_moving", "c4", {"c4_moving": True}, 3, 2), ("c4_fixed", "c4", {"c4_fixed": True}, 3, 2),
             ("c4_deferred", "c4", {"c4_moving": True, "c4_deferred": True}, 3, 2),
             ("c5", "c5", {}, 10, 10), ("c5_banana", "c5", {"c5_banana": True}, 10, 10)]
@@ -847,7 +895,8 @@ def other_configs(mhx, ctx, args, barrier):
         try:
             a = copy.copy(args)
             a.inner = a.chains = a.dim = a.lanes = 0
-            a.c4_moving = a.c4_fixed = a.c4_deferred = a.c3_rotated = a.c5_banana = a.c2_literal = a.c2_user = a.c3_user = False
+            a.c4_moving = a.c4_fixed = a.c4_deferred = a.c3_rotated = a.c5_banana = a.c2_literal = a.c2_user = a.c3_user = a.c3_small = False
+            a.ensembles = 0
             for k, v in over.items():
                 setattr(a, k, v)
             w = WORKLOADS[name](a, args.dtype)
@@ -865,6 +914,15 @@ def other_configs(mhx, ctx, args, barrier):
                 blk["valu_weighted_frac"] = rf.get("valu_weighted_frac")     # class-weighted issue bound (tools/isa_mix.py), None until counted
             if st.get("factor_band", -1) >= 0:
                 blk["band"] = st["factor_band"]
+            if name == "c3" and w.E == 1:
+                # the honest ruler for one ensemble per launch: the dependent chain (c3_latency_floor), not HBM
+                fl = c3_latency_floor(mhx, ctx, w, st)
+                if fl:
+                    sweep_us = dt * 1e6 / (steps * w.inner)
+                    blk.update({"bound": "latency", "hbm_frac": blk["frac"], "floor_us": sig(fl, 4), "sweep_us": sig(sweep_us, 4),
+                                "frac": sig(fl / sweep_us, 4)})
+            elif name == "c3":
+                blk["ensembles"] = w.E
             w.run.close()
             if not args.no_cpu_baseline:
                 blk["cpu"] = cpu_baseline(w, args.dtype, 2.0, compact=True)
@@ -1128,6 +1186,8 @@ def main():
                     "instead of the tuned 2.38/sqrt(d)")
     ap.add_argument("--c2-user", action="store_true", help="c2: the target as a user log-density in HIP source (DensityModel(f), JIT-lowered, one lane per chain)")
     ap.add_argument("--c3-user", action="store_true", help="c3: the AR(1) target as a user log-density in HIP source (lane per walker, any-target kernel)")
+    ap.add_argument("--c3-small", action="store_true", help="c3: d = 5, 1 000 walkers (test/emcee.jl:24) x --ensembles ensembles in ONE run (mhx_emcee_cfg.n_ensembles)")
+    ap.add_argument("--ensembles", type=int, default=0, help="c3 --c3-small: ensembles in the run (default 256)")
     ap.add_argument("--c3-rotated", action="store_true", help="c3: the dense-rotated variant Sigma = Q (0.9^|i-j|) Q^T (no banded factor)")
     ap.add_argument("--c4-fixed", action="store_true", help="c4: the fixed-factor steps that follow the warm-up (1 read of S per step)")
     ap.add_argument("--c5-banana", action="store_true", help="c5: the banana target of SURVEY 8(d) (ii) instead of Neal's funnel")

@@ -77,7 +77,8 @@ int mhx_ctx_pci_bus_id(const mhx_ctx *ctx, char *buf, size_t len);
  *                   WAVE_K (4 | 8 speculative candidates per round of the wave-per-chain kernel; default: by the last call's acceptance)
  *   return path     HOST_COMPACT (1 / 0: the accept-compacted form of mhx_run_sample_to_host on / off; default: on for thinning == 1
  *                   and >= 1024 chains) HOST_THREADS (host threads that expand; default: what the process may use) HOST_CHUNK (chains
- *                   per unit of their work, a multiple of 64; default: so that a unit's state fits a core's L2)
+ *                   per unit of their work, a multiple of 64; default: so that a unit's state fits a core's L2) HOST_NUMA (0: do not
+ *                   place the staging memory and the expanding threads on the GPU's memory node)
  * value == NULL unsets.  An unknown name is MHX_EINVAL.  The tools build (libmhx_tools.so, `make tools`) additionally knows
  * timing probes and fault injection (ZIG_PROBE, EMCEE_PROBE, EMCEE_STAMPS, ZIG_FORCE_FAIL, FAULT_SLAB, JIT_DEFS, RAM_PROF): setting one
  * marks the context TAINTED -- mhx_stats.tainted = 1 for every run of it, and the host mirrors refuse to build a Chains from

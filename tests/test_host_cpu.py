@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol(mhx):
     for name in declared:
         assert hasattr(lib, name), "libmhx.so does not export %s" % name
     assert sorted(mhx.EXPORTS) == declared
-    assert lib.mhx_version() == 500
+    assert lib.mhx_version() == 600
 
 
 def test_no_gpu_fails_loudly_not_silently(mhx):
