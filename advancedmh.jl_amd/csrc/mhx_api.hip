@@ -259,7 +259,7 @@ static const opt_name k_opt_names[] = {
     {"EMCEE_MFMA", 0}, {"EMCEE_MFMA_WAVES", 0}, {"EMCEE_SCALAR", 0}, {"EMCEE_SCAL_MODE", 0}, {"EMCEE_SCAL_WPB", 0}, {"EMCEE_SCAL_REC", 0},
     {"EMCEE_FUSED", 0}, {"EMCEE_PERSIST", 0}, {"EMCEE_PRELOAD", 0}, {"EMCEE_DEFER", 0}, {"EMCEE_SWEEP_DEFER", 0}, {"EMCEE_WAVES", 0},
     {"EMCEE_REC_STORE", 0}, {"EMCEE_ROW_STORE", 0}, {"EMCEE_COOP_REC", 0},
-    {"HOST_COMPACT", 0}, {"HOST_THREADS", 0}, {"HOST_CHUNK", 0}, {"HOST_NUMA", 0},
+    {"HOST_COMPACT", 0}, {"HOST_THREADS", 0}, {"HOST_CHUNK", 0}, {"HOST_NUMA", 0}, {"TOTAL_CHAINS", 0},
 #ifdef MHX_TOOLS_BUILD
     {"ZIG_PROBE", 1}, {"ZIG_FORCE_FAIL", 1}, {"JIT_DEFS", 1}, {"EMCEE_PROBE", 1}, {"EMCEE_STAMPS", 1}, {"EMCEE_STAMPS_FILE", 1},
     {"FAULT_SLAB", 1}, {"RAM_PROF", 1},
@@ -285,6 +285,17 @@ static const char* opt(const mhx_ctx* ctx, const char* name)
     auto it = ctx->options.find(name);
     return it == ctx->options.end() ? nullptr : it->second.c_str();
 }
+// The chains of the WHOLE run a shard belongs to (option TOTAL_CHAINS; mhx_group_shard sets it on the member's context, a process
+// of a multi-process run sets it itself): the kernel form -- and with it the summation order of the log-density -- is chosen for
+// that count, so that a shard takes the form the unsharded run takes and stays bit for bit its part of it (the
+// wave-per-chain kernel was picked from the LOCAL count: 8 x 1024 chains ran shape 64 where 8192 run shape 1).
+static long chains_of_whole_run(const mhx_ctx* ctx, long local)
+{
+    const char* v = opt(ctx, "TOTAL_CHAINS");
+    const long all = v ? atol(v) : 0;
+    return all > local ? all : local;
+}
+
 int api_ctx_set_option(mhx_ctx* ctx, const char* name, const char* value)
 {
     const opt_name* o = opt_find(name);
@@ -997,7 +1008,7 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
     // SIMD) and there are terms to split; the plain random walk, ISO / DIAG proposal, Box-Muller normals.
     if (tk == MHX_TARGET_IID_NORMAL && d == 2 && pk != MHX_PROP_DENSE && walk == MHX_WALK_PLAIN &&
         !(r->flags & (MHX_FLAG_GENERIC | MHX_FLAG_ZIGGURAT)) &&
-        (cfg->reduce_lanes == 64 || (cfg->reduce_lanes == 0 && t->nparams >= 8 && r->n <= 2048))) {
+        (cfg->reduce_lanes == 64 || (cfg->reduce_lanes == 0 && t->nparams >= 8 && chains_of_whole_run(ctx, r->n) <= 2048))) {
         r->reg_fn = pk == MHX_PROP_ISO ? k_rwmh_wave<MHX_PROP_ISO, 4> : k_rwmh_wave<MHX_PROP_DIAG, 4>;
         r->reg_fn8 = pk == MHX_PROP_ISO ? k_rwmh_wave<MHX_PROP_ISO, 8> : k_rwmh_wave<MHX_PROP_DIAG, 8>;
         r->variant = 11;
@@ -1019,7 +1030,7 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
             // blocks still fit a lane (C2 in fp64: 4 lanes x 7 = 28 slots for 25 blocks -> 2 lanes x 13 = 26: +4 %)
             while (L > 1 && (nblk + L / 2 - 1) / (L / 2) <= MHX_COOP_NBL_MAX &&
                    (long)(L / 2) * ((nblk + L / 2 - 1) / (L / 2)) * 105 < (long)L * ((nblk + L - 1) / L) * 100) L /= 2;
-            while (L < 64 && 2 * L <= nblk && (long)r->n * L / 64 < 2048) L *= 2;
+            while (L < 64 && 2 * L <= nblk && chains_of_whole_run(ctx, r->n) * L / 64 < 2048) L *= 2;
             if ((nblk + L - 1) / L > MHX_COOP_NBL_MAX) L = 1;      // not even a whole wave holds the chain: state in HBM
         }
         // (the ziggurat generator lives in the cooperative body: a chain on ONE lane still runs it there)

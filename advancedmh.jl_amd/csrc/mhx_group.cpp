@@ -8,6 +8,9 @@
 // entry points of mhx.h: a group drives member runs exactly like N processes would.
 #include "mhx_impl.h"
 
+#include <algorithm>
+#include "mhx_host_expand.h"    // mhx_host_usable_cpus
+
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
@@ -120,6 +123,13 @@ extern "C" int mhx_group_create(const int32_t* devices, int32_t n, int dtype, mh
         for (auto& m : g->mem) (void)mhx_ctx_destroy(m->ctx);
         return mhx_fail(rc, "mhx_group_create: member %d: %s", (int)g->mem.size(), err.c_str());
     }
+    // the members return their samples at the same time: the host threads that expand accept-compacted blocks are shared out
+    // (each member's own pool would otherwise be sized for the whole machine: n x 16 threads on a quota of 16 CPUs)
+    if (n > 1) {
+        char buf[16];
+        snprintf(buf, sizeof buf, "%d", std::max(1, mhx_host_usable_cpus() / (int)n));
+        for (auto& m : g->mem) (void)mhx_ctx_set_option(m->ctx, "HOST_THREADS", buf);
+    }
     for (auto& m : g->mem) m->th = std::thread(worker, m.get());
     *out = g.release();
     return MHX_OK;
@@ -169,7 +179,11 @@ extern "C" int mhx_group_shard(const mhx_group* g, int64_t nchains_total, int32_
     const int64_t base = nchains_total / w, rem = nchains_total % w;
     if (first_chain) *first_chain = (uint64_t)(i * base + (i < rem ? i : rem));
     if (nchains) *nchains = (int32_t)(base + (i < rem ? 1 : 0));
-    return MHX_OK;
+    // the member's runs are parts of a run of nchains_total chains: the engine picks the kernel form (the summation order) for THAT
+    // count, so the union of the members is the unsharded run bit for bit whatever the shard sizes (option TOTAL_CHAINS)
+    char buf[32];
+    snprintf(buf, sizeof buf, "%lld", (long long)nchains_total);
+    return mhx_ctx_set_option(g->mem[(size_t)i]->ctx, "TOTAL_CHAINS", buf);
 }
 
 extern "C" int mhx_group_attach(mhx_group* g, mhx_run* const* runs)

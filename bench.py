@@ -1302,6 +1302,10 @@ def main():
                 sys.stderr.write("bench.py --gpus %d: the %d ranks opened %d distinct device(s)\n" % (args.gpus, world, n_gpus))
                 leave(2)
         wl = WORKLOADS[args.config](args, args.dtype)
+        if world > 1 and getattr(wl, "C", 0):
+            # a rank's chains are a shard of world x C: the engine picks the kernel form (the summation order) for the whole run's
+            # count, so the ranks' union is the unsharded run bit for bit (include/mhx.h: option TOTAL_CHAINS)
+            ctx.set_option("TOTAL_CHAINS", wl.C * world)
         wl.build(mhx, ctx, rank)
     dt, kernel_ms, accepted, transitions, st = timed(wl, args.steps, args.warmup, barrier)
 

@@ -79,6 +79,10 @@ int mhx_ctx_pci_bus_id(const mhx_ctx *ctx, char *buf, size_t len);
  *                   and >= 1024 chains) HOST_THREADS (host threads that expand; default: what the process may use) HOST_CHUNK (chains
  *                   per unit of their work, a multiple of 64; default: so that a unit's state fits a core's L2) HOST_NUMA (0: do not
  *                   place the staging memory and the expanding threads on the GPU's memory node)
+ *   sharding        TOTAL_CHAINS (the chains of the WHOLE run this context's runs are shards of: where the engine picks a kernel
+ *                   form -- hence a summation order -- from the chain count (reduce_lanes = 0), it picks for that count, so a shard
+ *                   runs what the unsharded run runs; mhx_group_shard sets it on the member's context, a process of a
+ *                   multi-process run sets it itself)
  * value == NULL unsets.  An unknown name is MHX_EINVAL.  The tools build (libmhx_tools.so, `make tools`) additionally knows
  * timing probes and fault injection (ZIG_PROBE, EMCEE_PROBE, EMCEE_STAMPS, ZIG_FORCE_FAIL, FAULT_SLAB, JIT_DEFS, RAM_PROF): setting one
  * marks the context TAINTED -- mhx_stats.tainted = 1 for every run of it, and the host mirrors refuse to build a Chains from
@@ -522,7 +526,8 @@ int mhx_group_create(const int32_t *devices, int32_t n, int dtype /* mhx_dtype *
 int mhx_group_destroy(mhx_group *g);
 int mhx_group_size(const mhx_group *g, int32_t *n);
 int mhx_group_ctx(mhx_group *g, int32_t i, mhx_ctx **ctx);      /* borrowed: valid until mhx_group_destroy */
-/* member i's contiguous block of `nchains_total` global chain ids (sizes differ by at most one) */
+/* member i's contiguous block of `nchains_total` global chain ids (sizes differ by at most one); also tells member i's context that
+ * its runs are shards of a run of nchains_total chains (option TOTAL_CHAINS: the kernel form is picked for the whole run) */
 int mhx_group_shard(const mhx_group *g, int64_t nchains_total, int32_t i, uint64_t *first_chain, int32_t *nchains);
 int mhx_group_attach(mhx_group *g, mhx_run *const *runs /* [n]: runs[i] was created on mhx_group_ctx(g, i); equal dim */);
 int mhx_group_run(mhx_group *g, int32_t i, mhx_run **run);

@@ -134,3 +134,38 @@ def test_a_failing_member_is_named(mhx, real):
     g.close()
     with pytest.raises(mhx.MhxError):
         mhx.Group([0, 99])                                 # no such device: nothing leaks, the error names the member
+
+
+def test_a_shard_takes_the_kernel_form_of_the_whole_run(mhx, real):
+    """where the engine picks the kernel form from the chain count (reduce_lanes = 0), a shard must pick what the
+    UNSHARDED run picks -- the README's data-sum model runs a wave per chain (reduction shape 64) up to 2048 chains and a lane per
+    chain (shape 1) beyond: 4 members x 1024 chains of a 4096-chain run used to take shape 64 and differ from the whole in the last
+    bits.  mhx_group_shard tells the member's context the whole run's count (option TOTAL_CHAINS); a lone process does it itself."""
+    data = np.random.default_rng(1234).normal(size=30)
+    model = mhx.DensityModel(mhx.IIDNormal(data))
+    spl = mhx.RWMH(mhx.MvNormal(mhx.zeros(2), 0.25 * mhx.I))
+    C, N = 4096, 12
+    init = np.array([0.0, 1.0])
+    whole = mhx.Run(model, spl, nchains=C, seed=7)
+    whole.init(init)
+    want, _ = whole.sample_to_host(N, 0, 1, 0)
+    assert whole.stats()["reduce_lanes"] == 1 and whole.stats()["kernel_variant"] != 11
+    g = mhx.Group([0] * 4)
+    g.create(model, spl, nchains=C, seed=7)
+    g.init(init)
+    vals, _ = g.sample_to_host(N, 0, 1, 0)
+    assert all(r.stats()["reduce_lanes"] == 1 for r in g.runs)
+    _same(np.concatenate(vals, axis=2), want, "4 x 1024 chains of the data-sum model vs the 4096-chain run")
+    # a process that holds one shard of a multi-process run says so itself
+    ctx = mhx.Context(0, real)
+    ctx.set_option("TOTAL_CHAINS", C)
+    part = mhx.Run(model, spl, nchains=1024, seed=7, first_chain=1024, ctx=ctx)
+    part.init(init)
+    v, _ = part.sample_to_host(N, 0, 1, 0)
+    _same(v, want[:, :, 1024:2048], "shard 1 of 4 with TOTAL_CHAINS set")
+    # ... and without the hint the small run keeps its own (faster) form: a wave per chain
+    lone = mhx.Run(model, spl, nchains=1024, seed=7, first_chain=1024)
+    lone.init(init)
+    lone.sample(2)
+    assert lone.stats()["kernel_variant"] == 11 and lone.stats()["reduce_lanes"] == 64
+    g.close()
