@@ -597,8 +597,11 @@ MHX_DEV void mhx_ram_init_body(const mhx_ram_args& a, const mhx_real* __restrict
 // then [K][R][64] the suffix vectors t
 #define MHX_RAM_DEFER_CF(K) ((K) * 256 * 4)
 #define MHX_RAM_DEFER_REALS(K, R) (MHX_RAM_DEFER_CF(K) + (K) * (R) * 64)
-// LDS of the fold's coefficient staging: two groups of 64 (a, g, u, -) entries = 64 / K columns each
-#define MHX_RAM_DEFER_STAGE 512
+// LDS of the fold's coefficient staging: two groups of 64 (a, g, u, -) entries = 64 / K columns each, then what is kept of a pending
+// update between its step and the fold: the step's number and the signed scale sigma c^2 (2 x 8 reals; round 6: the update's
+// O(d) coefficients are REGENERATED from these two -- U from the Philox counter, T_j from its prefix sums -- instead of being
+// written to the per-chain scratch at every step and read back at every proposal: 39 -> 17 KB of scratch traffic per step at d = 200)
+#define MHX_RAM_DEFER_STAGE (512 + 16)
 
 MHX_DEV mhx_real mhx_shfl_up(const mhx_real x, const int s) { return __shfl_up(x, s, 64); }
 
@@ -703,6 +706,27 @@ MHX_DEV void mhx_ram_draw4(const mhx_philox_key& ks, mhx_u32 id_lo, mhx_u32 id_h
     o.nn = mhx_readlane(o.incl, 63);
 }
 
+// The coefficients of a pending update at this lane's four elements, from the step that made it and its signed scale alone:
+// U = the step's noise again (counter-based: the same bits), T_j = 1 + sc sum_{m<j} U_m^2 from the same scan, then
+// a_j = sqrt(T_{j+1} / T_j), g_j = sc U_j / (T_j a_j) -- the very expressions of the adapt phase below, so the values are the ones
+// that were stored until round 5.
+MHX_DEV void mhx_ram_defer_regen(const mhx_philox_key& ks, const mhx_u32 id_lo, const mhx_u32 id_hi, const mhx_u32 step, const mhx_real sc,
+                                 const int d, const int lane, mhx_real (&aa)[4], mhx_real (&gg)[4], mhx_real (&uu)[4])
+{
+    mhx_ram_noise4 q;
+    mhx_ram_draw4(ks, id_lo, id_hi, step, d, lane, q);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const mhx_real T0 = mhx_fma(sc, q.pu[e], MHX_R(1.0));
+        const mhx_real T1 = mhx_fma(sc, e < 3 ? q.pu[(e + 1) & 3] : q.incl, MHX_R(1.0));
+        const bool in = 4 * lane + e < d;
+        const mhx_real ae = mhx_sqrt(T1 / T0);
+        aa[e] = in ? ae : MHX_R(1.0);
+        gg[e] = in ? (sc * q.u[e]) / (T0 * ae) : MHX_R(0.0);
+        uu[e] = q.u[e];
+    }
+}
+
 template <int R, int K, int TK>
 #ifdef MHX_TOOLS_BUILD                                             // (tools build: block 0 prints its cycles per phase)
 #define MHX_RAM_DEFER_PROF 1
@@ -734,6 +758,8 @@ MHX_DEV void mhx_ram_defer_body(const mhx_ram_args& a, const mhx_real* __restric
     mhx_f4* coef = (mhx_f4*)scratch;                                   // [K][256] (a, g, u, -)
     mhx_real* svec = scratch + MHX_RAM_DEFER_CF(K);                    // [K][R][64]
     mhx_f4* stage = (mhx_f4*)(lds + RINGS + mhx_ram_mirror(d));
+    mhx_real* const psc = lds + RINGS + mhx_ram_mirror(d) + 512;        // [K] signed scale of pending update k
+    mhx_u32* const pstep = (mhx_u32*)(psc + 8);                         // [K] the step that made it
     const bool has_blk = lane < ((d + 3) >> 2);                        // this lane's four elements hold part of the vector
     const bool in_vec = 4 * lane < mhx_ram_mirror(d);                  // this lane's four elements lie inside the LDS vector
 
@@ -779,47 +805,19 @@ MHX_DEV void mhx_ram_defer_body(const mhx_ram_args& a, const mhx_real* __restric
 
         // ---- U = randn(d), z = M_1 (... (M_m U)), v = S_0 z, x' = v + x
         if (!have_v) {
-            // the pending factors, newest first, in batches of four: the loads of a batch are in flight together (and under the draw)
-            mhx_f4 qe[4][4];                                             // [slot of the batch][element]: (a, g, u, -)
-            const int top = m - 1;
-            if (m > 0) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // this wave's own stores of earlier steps
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { qe[t][e].x = MHX_R(1.0); qe[t][e].y = qe[t][e].z = qe[t][e].w = MHX_R(0.0); }
-                if (top - t >= 0 && has_blk) {
-                    const mhx_f4* q = coef + ((top - t) * 256 + 4 * lane);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) qe[t][e] = q[e];
-                }
-            }
+            // the pending factors, newest first, each REGENERATED at this lane's four elements (mhx_ram_defer_regen): a Philox
+            // block, a scan and a dozen slow operations per update -- a few hundred cycles of a step that waits ~10^5 on HBM
             mhx_ram_draw4(ks, id_lo, id_hi, step, d, lane, nz);
             mhx_real z[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) z[e] = nz.u[e];
-            for (int base = top; base >= 0; base -= 4) {               // wave-uniform
+            for (int k = m - 1; k >= 0; --k) {                          // wave-uniform
+                mhx_real aa[4], gg[4], uu[4];
+                mhx_ram_defer_regen(ks, id_lo, id_hi, pstep[k], psc[k], d, lane, aa, gg, uu);
+                mhx_real P[4], tot;
+                mhx_scan_dot4(gg, z, lane, P, tot);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    if (base - t >= 0) {
-                        const mhx_real aa[4] = {qe[t][0].x, qe[t][1].x, qe[t][2].x, qe[t][3].x};
-                        const mhx_real gg[4] = {qe[t][0].y, qe[t][1].y, qe[t][2].y, qe[t][3].y};
-                        const mhx_real uu[4] = {qe[t][0].z, qe[t][1].z, qe[t][2].z, qe[t][3].z};
-                        mhx_real P[4], tot;
-                        mhx_scan_dot4(gg, z, lane, P, tot);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) z[e] = mhx_fma(uu[e], P[e], aa[e] * z[e]);
-                    }
-                }
-                if (base - 4 >= 0) {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        if (base - 4 - t >= 0 && has_blk) {
-                            const mhx_f4* q = coef + ((base - 4 - t) * 256 + 4 * lane);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) qe[t][e] = q[e];
-                        }
-                    }
-                }
+                for (int e = 0; e < 4; ++e) z[e] = mhx_fma(uu[e], P[e], aa[e] * z[e]);
             }
             MHX_WAVE_SYNC();
             if (in_vec) {
@@ -914,15 +912,7 @@ MHX_DEV void mhx_ram_defer_body(const mhx_ram_args& a, const mhx_real* __restric
                 if (__ballot(out) != 0ull) ok = false;
             }
             if (ok) {                                                    // wave-uniform
-                if (has_blk) {
-                    mhx_f4* q = coef + (m * 256 + 4 * lane);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        mhx_f4 c4;
-                        c4.x = aa[e]; c4.y = gg[e]; c4.z = nz.u[e]; c4.w = MHX_R(0.0);
-                        q[e] = c4;
-                    }
-                }
+                if (lane == 0) { psc[m] = sc; pstep[m] = step; }         // all that is kept of the update (read after the wave syncs below)
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     svec[(m * R + r) * 64 + tg] = v[r];
@@ -937,6 +927,22 @@ MHX_DEV void mhx_ram_defer_body(const mhx_ram_args& a, const mhx_real* __restric
             if (m == K || (at_end && m > 0)) {
                 // ---- flush: S_0 <- S_0 M_1 ... M_m into the other buffer, the next step's mat-vec on the way
                 const bool fuse = it + 1 < a.nsteps;
+                MHX_WAVE_SYNC();
+                // the fold reads the coefficients TRANSPOSED (lane = (update, column of the group)): they go through the chain's
+                // scratch once per fold -- each lane writes its four elements of every pending update, regenerated
+                for (int k = 0; k < m; ++k) {                            // wave-uniform
+                    mhx_real ra[4], rg[4], ru[4];
+                    mhx_ram_defer_regen(ks, id_lo, id_hi, pstep[k], psc[k], d, lane, ra, rg, ru);
+                    if (has_blk) {
+                        mhx_f4* q = coef + (k * 256 + 4 * lane);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            mhx_f4 c4;
+                            c4.x = ra[e]; c4.y = rg[e]; c4.z = ru[e]; c4.w = MHX_R(0.0);
+                            q[e] = c4;
+                        }
+                    }
+                }
                 MHX_WAVE_SYNC();
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                 mhx_ram_noise4 nx;

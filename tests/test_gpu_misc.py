@@ -547,7 +547,8 @@ def test_checkpoint_and_resume(mhx, kind, real):
     warm = 30 if kind.startswith("ram") else 0               # the warm-up spans the checkpoint
 
     def new_run(seed):
-        return mhx.Run(model, spl, nchains=C, seed=seed, first_chain=4)
+        # (an Ensemble run: nchains counts ENSEMBLES, README.md:135-148 -- one here)
+        return mhx.Run(model, spl, nchains=1 if kind.startswith("emcee") else C, seed=seed, first_chain=4)
 
     a = new_run(11)
     a.init(init)
