@@ -11,6 +11,25 @@ for p in (ROOT, os.path.join(ROOT, "advancedmh.jl_amd")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "soak: the long tail of the parameter products (random configurations, knob x width x shape); "
+                                       "skipped unless the mark expression names it: -m 'gpu and soak' (or MHX_SOAK=1)")
+
+
+def soak_tail(values, keep):
+    """the first `keep` values in the default tier, the rest in the soak tier (the default `-m gpu` run must leave
+    the driver's time limit a wide margin on a slow lease; every SURVEY section-8 row keeps its full-size test in the default tier)"""
+    values = list(values)
+    return values[:keep] + [pytest.param(*(v if isinstance(v, tuple) else (v,)), marks=pytest.mark.soak) for v in values[keep:]]
+
+
+def pytest_collection_modifyitems(config, items):
+    expr = config.getoption("-m") or ""
+    if "soak" in expr or os.environ.get("MHX_SOAK"):
+        return
+    skip = pytest.mark.skip(reason="soak tier: run with -m 'gpu and soak' (or MHX_SOAK=1)")
+    for it in items:
+        if "soak" in it.keywords:
+            it.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import cases
+from conftest import soak_tail
 import user_targets
 
 pytestmark = pytest.mark.gpu
@@ -532,8 +533,8 @@ def test_scalar_factor_form_runs_a_dense_factor_bit_exact(mhx, oracle, real, d, 
     _same(got_acc, ref["accepted"], "accepted, slab-streamed")
 
 
-@pytest.mark.parametrize("knobs", [{"MHX_EMCEE_SCALAR": "4"}, {"MHX_EMCEE_SCALAR": "16"}, {"MHX_EMCEE_SCAL_WPB": "64"}, {"MHX_EMCEE_SCAL_WPB": "16"},
-                                   {"MHX_EMCEE_SCAL_MODE": "0"}, {"MHX_EMCEE_SCAL_REC": "0"}, {"MHX_EMCEE_SCALAR": "0"}])
+@pytest.mark.parametrize("knobs", soak_tail([{"MHX_EMCEE_SCALAR": "4"}, {"MHX_EMCEE_SCAL_MODE": "0"}, {"MHX_EMCEE_SCALAR": "0"}, {"MHX_EMCEE_SCALAR": "16"},
+                                             {"MHX_EMCEE_SCAL_WPB": "64"}, {"MHX_EMCEE_SCAL_WPB": "16"}, {"MHX_EMCEE_SCAL_REC": "0"}], 3))
 def test_scalar_factor_form_every_shape_and_the_lane_group_form_agree_with_the_oracle(mhx, oracle, real, knobs, engine):
     """The tuning knobs of the scalar-factor form (waves per block = reduction shape 4 / 16, walkers per block, SGPR operands instead
     of the DPP broadcast, the record straight from the move mapping) and MHX_EMCEE_SCALAR=0 (the lane-group form with its LDS image):
@@ -568,8 +569,8 @@ def test_a_large_dense_factor_falls_back_to_the_lane_group_form(mhx, oracle, rea
     _same(chain.value, ref["samples"], "samples")
 
 
-@pytest.mark.parametrize("d,W,waves", [(50, 200, 1), (8, 66, 1), (17, 71, 4), (33, 64, 1), (64, 129, 2), (24, 3, 1), (50, 2, 4), (12, 33, 8), (100, 40, 1),
-                                       (128, 19, 1), (50, 300, 4), (40, 130, 8)])
+@pytest.mark.parametrize("d,W,waves", soak_tail([(50, 200, 1), (17, 71, 4), (64, 129, 2), (24, 3, 1), (100, 40, 1), (8, 66, 1), (33, 64, 1), (50, 2, 4),
+                                                 (12, 33, 8), (128, 19, 1), (50, 300, 4), (40, 130, 8)], 5))
 def test_matrix_core_form_of_the_stretch_move(mhx, oracle, real, d, W, waves, engine):
     """A dense precision factor on the matrix cores (variant 10): 4 lanes per walker, the candidate formed in the MFMA's B-operand
     layout, the factor's operand image built once per run and fetched into registers per launch -- no LDS, no barrier; reduction
@@ -618,8 +619,8 @@ def test_matrix_core_form_of_the_stretch_move(mhx, oracle, real, d, W, waves, en
     _same(got_acc, ref["accepted"], "accepted, slab-streamed")
 
 
-@pytest.mark.parametrize("d,W,kind", [(2, 1000, "user"), (10, 64, "user"), (7, 37, "user"), (50, 200, "user"), (24, 1024, "user"), (3, 2, "user"),
-                                      (2, 131, "iid"), (30, 66, "banana"), (10, 1025, "user")])
+@pytest.mark.parametrize("d,W,kind", soak_tail([(2, 1000, "user"), (7, 37, "user"), (24, 1024, "user"), (2, 131, "iid"), (10, 1025, "user"), (10, 64, "user"),
+                                                (50, 200, "user"), (3, 2, "user"), (30, 66, "banana")], 5))
 def test_small_ensemble_as_one_persistent_block(mhx, oracle, d, W, kind, real, engine):
     """An ensemble of at most 1024 walkers on the lane-per-walker kernel runs a whole sampling call as ONE launch of one persistent
     block (variant 6): thread = walker, rows in LDS for the partners, block barriers between the half-steps.  Same tensor, state and

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 import cases
+from conftest import soak_tail
 
 pytestmark = pytest.mark.gpu
 
@@ -27,7 +28,7 @@ def _schedule(rng):
     return N, di, th
 
 
-@pytest.mark.parametrize("case", range(60))
+@pytest.mark.parametrize("case", soak_tail(range(60), 20))
 def test_rwmh_random_configurations(mhx, oracle, case, real):
     rng = np.random.default_rng(1000 + case + 100000 * SEED_OFFSET)
     d = int(rng.choice([1, 2, 3, 5, 8, 13, 17, 31, 40, 66, 97]))
@@ -78,7 +79,7 @@ def test_rwmh_random_configurations(mhx, oracle, case, real):
     _same(cnt, ref["accept_counts"], what)
 
 
-@pytest.mark.parametrize("case", range(25))
+@pytest.mark.parametrize("case", soak_tail(range(25), 9))
 def test_emcee_random_configurations(mhx, oracle, case, real):
     rng = np.random.default_rng(2000 + case + 100000 * SEED_OFFSET)
     d = int(rng.choice([1, 2, 3, 6, 11, 20, 33, 64, 90]))
@@ -103,7 +104,7 @@ def test_emcee_random_configurations(mhx, oracle, case, real):
     _same(lp, ref["final_lp"], what)
 
 
-@pytest.mark.parametrize("case", range(25))
+@pytest.mark.parametrize("case", soak_tail(range(25), 9))
 def test_ram_random_configurations(mhx, oracle, case, real):
     rng = np.random.default_rng(3000 + case + 100000 * SEED_OFFSET)
     d = int(rng.choice([1, 2, 4, 9, 16, 17, 33, 47, 65, 100]))
@@ -128,7 +129,7 @@ def test_ram_random_configurations(mhx, oracle, case, real):
     _same(st, ref["status"], what)
 
 
-@pytest.mark.parametrize("case", range(30))
+@pytest.mark.parametrize("case", soak_tail(range(30), 10))
 def test_ram_deferred_factor_random_configurations(mhx, oracle, case, real):
     """the deferred-factor form (MHX_FLAG_RAM_DEFERRED, spec 3.12) against its own twin: every rows-per-lane shape, blocks cut short by
     the warm-up's end and by the end of the call, thinning and discards, bounds that refuse updates, both targets, a given factor"""
@@ -165,7 +166,7 @@ def test_ram_deferred_factor_random_configurations(mhx, oracle, case, real):
     _same(hi, ref["diag_max"], what)
 
 
-@pytest.mark.parametrize("case", range(16))
+@pytest.mark.parametrize("case", soak_tail(range(16), 6))
 def test_mala_random_configurations(mhx, oracle, case, real):
     rng = np.random.default_rng(4000 + case + 100000 * SEED_OFFSET)
     d = int(rng.choice([1, 2, 3, 7, 16, 33, 70]))
@@ -236,7 +237,7 @@ def test_dimensions_beyond_the_specialised_kernels(mhx, oracle, real):
     same(ch.value, oracle.mala(oracle.iso_gauss(d, reduce_lanes=ch.stats["reduce_lanes"]), 0.01, oracle.schedule(4), 6, 0, C, init)["samples"], "mala d=500")
 
 
-@pytest.mark.parametrize("case", range(16))
+@pytest.mark.parametrize("case", soak_tail(range(16), 6))
 def test_large_dimension_shapes_random_configurations(mhx, oracle, case, real):
     """One or two chains per wave (d = 130 ... 1000): state, moments and the per-step record move through LDS as whole row
     segments when all chains of a block exist, element-wise otherwise -- odd chain counts exercise both in one run; both
@@ -279,7 +280,7 @@ def test_large_dimension_shapes_random_configurations(mhx, oracle, case, real):
     run.close()
 
 
-@pytest.mark.parametrize("case", range(24))
+@pytest.mark.parametrize("case", soak_tail(range(24), 8))
 def test_dense_factor_ensembles_random_configurations(mhx, oracle, case, real, engine):
     """The scalar-factor form of the cooperative stretch move (round 4) over random dense factors: dimension 8 ... 68 (odd ones,
     multiples of 4 and of 16), odd and tiny ensembles (a single block, ragged last blocks, halves of different size), random
@@ -342,7 +343,7 @@ def _banded_sigma(d, bw, rng):
     return np.linalg.inv(A.T @ A)
 
 
-@pytest.mark.parametrize("case", range(24))
+@pytest.mark.parametrize("case", soak_tail(range(24), 8))
 def test_ensemble_sweep_launches_random_configurations(mhx, oracle, case, real, engine):
     """One launch per sweep (round 4) over random ensembles: banded factors on the lane-group form, dense ones on the scalar-factor or
     the matrix-core form, user-style targets on the lane-per-walker kernel; dimensions with and without padding, odd and tiny

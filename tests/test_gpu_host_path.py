@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import cases
+from conftest import soak_tail
 
 pytestmark = pytest.mark.gpu
 
@@ -41,10 +42,11 @@ def _runs(mhx, kind, d, C, seed):
     return mk, init
 
 
-@pytest.mark.parametrize("slab", [0, 1, 3, -1, -3, -4])
+# every slab layout on the compacted path (240 combinations with the schedules, samplers and widths); the plain path keeps the two
+# layouts that differ in kind (whole tensor on the device / two alternating slabs) in the default tier, the rest in the soak tier
+@pytest.mark.parametrize("compact,slab", soak_tail([("1", s) for s in (0, 1, 3, -1, -3, -4)] + [("0", 0), ("0", -3), ("0", 1), ("0", 3), ("0", -1), ("0", -4)], 8))
 @pytest.mark.parametrize("sched", [(11, 0, 1, 0), (10, 7, 3, 0), (1, 0, 1, 0), (9, 5, 2, 12), (2, 0, 4, 3)])
 @pytest.mark.parametrize("kind", ["rwmh", "emcee", "ram", "mala"])
-@pytest.mark.parametrize("compact", ["1", "0"])
 def test_streamed_samples_equal_the_device_tensor(mhx, real, engine, kind, sched, slab, compact):
     """compact = 1: the accept-compacted blocks + host threads (include/mhx.h: mhx_compact_hdr), forced at these small sizes and on
     thinned schedules too (there a chain's column changes when ANY of the skipped transitions was accepted: the device compares

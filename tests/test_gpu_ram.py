@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import cases
+from conftest import soak_tail
 
 pytestmark = pytest.mark.gpu
 
@@ -133,7 +134,7 @@ def test_ram_doctest_covariance(mhx, real):
 
 # one dimension per pre-built kernel shape (lanes per chain x rows per lane): 16x{1,2,4}, 32x{3..8},
 # 64x{5,6,7,8,12,16}; odd chain counts leave idle lane groups in the last wave
-@pytest.mark.parametrize("d", [16, 30, 50, 64, 90, 128, 150, 190, 224, 250, 300, 380, 448, 500, 700, 1000])
+@pytest.mark.parametrize("d", soak_tail([16, 64, 128, 224, 300, 448, 1000, 30, 50, 90, 150, 190, 250, 380, 500, 700], 7))
 def test_ram_every_kernel_shape(mhx, oracle, d, real):
     C, N, warm = 5, 5, 4
     Sig = cases.sigma_ar1(d, 0.6)
