@@ -923,6 +923,24 @@ def other_configs(mhx, ctx, args, barrier):
                                 "frac": sig(fl / sweep_us, 4)})
             elif name == "c3":
                 blk["ensembles"] = w.E
+            if key == "c3":
+                # the same sweeps with every walker's state back on the host (what `sample` returns): the accept-compacted return
+                # path at the stretch move's acceptance -- moves/s through the boundary, tensor and wire bytes per step
+                try:
+                    import numpy as np
+                    hb = mhx.host_array((w.inner, w.d + 1, w.W * w.E), w.run.real)
+                    ha = mhx.host_array((w.inner, w.W * w.E), np.uint8)
+                    w.run.sample_to_host(w.inner, 1, 1, 0, out=hb, out_accepted=ha)
+                    t0 = time.perf_counter()
+                    for _ in range(3):
+                        w.run.sample_to_host(w.inner, 1, 1, 0, out=hb, out_accepted=ha)
+                    wt = (time.perf_counter() - t0) / 3
+                    hs = w.run.host_stats()
+                    blk["e2e_save_all"] = {"value": sig(w.units_per_step() / wt), "host_GB": sig((hb.nbytes + ha.nbytes) / 1e9, 4),
+                                           "wire_GB": sig(hs["wire_bytes"] / 1e9, 4), "compact": hs["compact"]}
+                    del hb, ha
+                except Exception as e:
+                    blk["e2e_save_all"] = {"error": str(e)[:80]}
             w.run.close()
             if not args.no_cpu_baseline:
                 blk["cpu"] = cpu_baseline(w, args.dtype, 2.0, compact=True)

@@ -11,6 +11,7 @@ for p in (ROOT, os.path.join(ROOT, "advancedmh.jl_amd")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "soak_f32: the fp32 instance of this test belongs to the soak tier")
     config.addinivalue_line("markers", "soak: the long tail of the parameter products (random configurations, knob x width x shape); "
                                        "skipped unless the mark expression names it: -m 'gpu and soak' (or MHX_SOAK=1)")
 
@@ -28,7 +29,9 @@ def pytest_collection_modifyitems(config, items):
         return
     skip = pytest.mark.skip(reason="soak tier: run with -m 'gpu and soak' (or MHX_SOAK=1)")
     for it in items:
-        if "soak" in it.keywords:
+        # soak_f32: the fp32 instance of a slow test goes to the soak tier (fp64 is the reference's arithmetic and stays)
+        f32_only = "soak_f32" in it.keywords and getattr(getattr(it, "callspec", None), "params", {}).get("real") == "f32"
+        if "soak" in it.keywords or f32_only:
             it.add_marker(skip)
 
 

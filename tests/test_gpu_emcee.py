@@ -312,6 +312,7 @@ def _lanes_of(mhx, model, W):
     return L
 
 
+@pytest.mark.soak_f32
 def test_sharded_ensemble_over_rccl_single_rank(mhx, oracle, real):
     """The collective path of ShardedEnsemble through the C ABI (mhx_comm_*: RCCL) with the one rank this box has: the
     moved slice is packed, all-gathered and unpacked on the run's stream after every half-step."""
@@ -405,8 +406,8 @@ def test_one_launch_per_sweep_is_the_same_chain_as_two_half_steps(mhx, oracle, r
     _same(f[0][1], ref["accepted"], "accepted vs oracle")
 
 
-@pytest.mark.parametrize("d,W,knobs", [(50, 200, {}), (17, 71, {}), (64, 129, {}), (33, 64, {"MHX_EMCEE_SCALAR": "4"}),
-                                       (16, 66, {"MHX_EMCEE_SCALAR": "16"}), (24, 3, {}), (50, 2, {}), (12, 33, {})])
+@pytest.mark.parametrize("d,W,knobs", soak_tail([(50, 200, {}), (17, 71, {}), (64, 129, {}), (33, 64, {"MHX_EMCEE_SCALAR": "4"}),
+                                       (16, 66, {"MHX_EMCEE_SCALAR": "16"}), (24, 3, {}), (50, 2, {}), (12, 33, {})], 4))
 def test_scalar_factor_form_one_launch_per_sweep(mhx, oracle, real, d, W, knobs, engine):
     """The scalar-factor form (dense factor) with both halves in one launch: mixed blocks of 16 walkers of each half, the second
     half's carry three candidate rows each through phase 2 (64 rows: every lane busy).  Same tensor as two half-step launches and

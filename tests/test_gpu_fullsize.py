@@ -254,6 +254,7 @@ def test_ram_adaptation_reaches_its_target_over_many_chains(mhx, real):
     assert ad["iteration"] == 7001 and abs(ad["η"] - 7000.0 ** -0.6) < 1e-6 * ad["η"]
 
 
+@pytest.mark.soak_f32
 def test_c4_known_answers_at_dimension_200(mhx, real):
     """configs[3] at ITS dimension (the adaptation's known answer ran at d = 8 only).  Two answers at d = 200, kappa = 1e3,
     from the start that moves (x0 ~ target, S0 = 2.38/sqrt(d) I):
@@ -303,6 +304,7 @@ def test_c4_known_answers_at_dimension_200(mhx, real):
     assert ad["iteration"] == 2001
 
 
+@pytest.mark.soak_f32
 def test_c4_deferred_factor_known_answers_and_divergence_at_dimension_200(mhx, real):
     """The deferred-factor form of RAM (MHX_FLAG_RAM_DEFERRED, arithmetic spec 3.12) has its own rounding, so it gets its own known
     answers at configs[3]'s dimension -- the two of test_c4_known_answers_at_dimension_200:

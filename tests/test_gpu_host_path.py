@@ -181,6 +181,7 @@ def test_jit_objects_persist_across_contexts(mhx, real, tmp_path, monkeypatch):
     assert hit4 == 0 and comp4 == comp1
 
 
+@pytest.mark.soak_f32
 def test_a_failing_slab_drains_the_copies_and_releases_the_callers_buffer_once(mhx, real, tools_engine):
     """ADVICE r3 / VERDICT r3 #8: an error in the MIDDLE of mhx_run_sample_to_host (after the copies of earlier slabs were
     enqueued on the second stream) must not return while a DMA still targets the caller's buffer, must release the page-lock it took

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import cases
+from conftest import soak_tail
 import user_targets
 
 pytestmark = pytest.mark.gpu
@@ -99,7 +100,7 @@ def test_mala_cooperative_kernel_bit_exact(mhx, oracle, name, d, lanes, real):
     run2.close()
 
 
-@pytest.mark.parametrize("d,C,lanes", [(16, 70, 4), (40, 33, 0), (100, 70, 0), (100, 17, 4), (61, 16, 0), (128, 40, 0), (21, 130, 4), (150, 20, 0), (200, 33, 0), (330, 9, 0), (256, 20, 0), (512, 9, 4)])
+@pytest.mark.parametrize("d,C,lanes", soak_tail([(16, 70, 4), (40, 33, 0), (100, 70, 0), (100, 17, 4), (61, 16, 0), (128, 40, 0), (21, 130, 4), (150, 20, 0), (200, 33, 0), (330, 9, 0), (256, 20, 0), (512, 9, 4)], 5))
 def test_mala_dense_target_matrix_core_kernel(mhx, oracle, d, C, lanes, real):
     """MALA on the dense Gaussian target (mhx_mala_mfma_kernels.h): w = A y and grad = -A^T w as two triangular GEMMs over the
     16 chains of a wave (v_mfma_*_16x16x4), 4 lanes per chain; the three sums of a step in the reduction shape 4.  Default above
@@ -173,7 +174,7 @@ def test_mala_reference_tests(mhx, oracle, real):
     assert (x2 == 1).all() and np.allclose(lp2, lp2[0])
 
 
-@pytest.mark.parametrize("d,C", [(7, 70), (24, 130), (25, 66), (40, 64), (64, 33), (100, 10), (128, 5), (129, 4)])
+@pytest.mark.parametrize("d,C", soak_tail([(7, 70), (24, 130), (25, 66), (40, 64), (64, 33), (100, 10), (128, 5), (129, 4)], 4))
 def test_mala_user_gradient_register_kernel_with_tails_in_lds(mhx, oracle, d, C, real):
     """A user log-density with its gradient (HIP source) on the register kernel: up to 24 (fp32: 48) dimensions all five vectors are
     registers; above that, to 64 (128), only the candidate and its gradient are -- state, gradient and noise keep their tails in LDS --
@@ -194,7 +195,7 @@ def test_mala_user_gradient_register_kernel_with_tails_in_lds(mhx, oracle, d, C,
     _same(cnt, ref["accept_counts"], "accept counts")
 
 
-@pytest.mark.parametrize("d,C,target", [(5, 70, "iso"), (12, 33, "corr"), (40, 130, "iso"), (64, 64, "user")])
+@pytest.mark.parametrize("d,C,target", soak_tail([(5, 70, "iso"), (12, 33, "corr"), (40, 130, "iso"), (64, 64, "user")], 2))
 def test_mala_with_ziggurat_noise_on_the_register_kernel(mhx, oracle, d, C, target):
     """MHX_FLAG_ZIGGURAT on a MALA run (round 5; VERDICT r4 'missing' 6): the noise of the Langevin proposal by the table ziggurat --
     the register-array fill of the RWMH register kernel (fast path into registers, wave-wide queue, refinement, hand-back) -- bit for

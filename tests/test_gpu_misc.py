@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import cases
+from conftest import soak_tail
 import user_targets
 
 pytestmark = pytest.mark.gpu
@@ -313,7 +314,7 @@ def test_drifting_random_walk_hastings_ratio(mhx, oracle, kind, real):
 
 
 @pytest.mark.parametrize("target", ["iso", "banana", "funnel"])
-@pytest.mark.parametrize("walk", ["drift_iso", "drift_diag", "static_iso", "static_diag_mean"])
+@pytest.mark.parametrize("walk", soak_tail(["drift_iso", "drift_diag", "static_iso", "static_diag_mean"], 2))
 @pytest.mark.parametrize("lanes", [0, 1, 4])
 def test_walks_with_a_hastings_ratio_on_the_cooperative_kernel(mhx, oracle, target, walk, lanes, real):
     """Drifting random walks (src/proposal.jl:58-64,190-192) and static proposals (:9-11,66-83) on the separable catalogue

@@ -72,6 +72,7 @@ def test_scalar_parameter_closure(mhx, real):
     assert chain_b.range() == range(26, 26 + 4 * 10_000, 4) and abs(chain_b.mean("μ") - DATA.mean()) < 0.1
 
 
+@pytest.mark.soak_f32
 def test_mala_closure_form_runs_the_same_chain(mhx, real):
     """test/runtests.jl:291: MALA(x -> MvNormal((σ² / 2) .* x, σ² * I)) is MALA(σ²) of the engine."""
     model = mhx.DensityModel(density, dim=2)

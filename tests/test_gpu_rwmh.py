@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 import cases
+from conftest import soak_tail
 import user_targets
 
 pytestmark = pytest.mark.gpu
@@ -91,14 +92,14 @@ def test_parallel_sampling_call_forms(mhx, real):
     assert np.array_equal(c.value, b.value[:100])
 
 
-@pytest.mark.parametrize("d,C,lanes,prop", [(100, 70, 0, "iso"), (128, 33, 16, "diag"), (70, 9, 8, "iso"), (5, 37, 2, "diag"),
+@pytest.mark.parametrize("d,C,lanes,prop", soak_tail([(100, 70, 0, "iso"), (128, 33, 16, "diag"), (70, 9, 8, "iso"), (5, 37, 2, "diag"),
                                             (50, 40, 4, "iso"), (99, 17, 32, "diag"), (100, 21, 0, "dense"), (37, 66, 4, "dense"),
                                             (96, 5, 8, "dense"), (100, 13, 0, "dense_iso_target"), (18, 130, 0, "dense_iso_target"),
                                             (200, 9, 0, "iso"), (256, 5, 0, "diag"), (130, 7, 0, "dense"), (160, 6, 0, "dense_iso_target"),
                                             (16, 100, 0, "iso"), (17, 35, 4, "dense"), (31, 64, 0, "diag"), (64, 16, 4, "dense"),
                                             (100, 65, 4, "diag"), (176, 20, 0, "iso"), (100, 300, 8, "iso"), (50, 33, 2, "dense"),
                                             (300, 20, 0, "iso"), (200, 70, 4, "dense"), (250, 17, 0, "diag"), (384, 9, 0, "dense_iso_target"),
-                                            (448, 9, 0, "diag"), (300, 9, 0, "dense"), (272, 12, 4, "dense_iso_target")])
+                                            (448, 9, 0, "diag"), (300, 9, 0, "dense"), (272, 12, 4, "dense_iso_target")], 12))
 def test_dense_gaussian_target_cooperative_kernel(mhx, oracle, d, C, lanes, prop, real):
     """RWMH on the dense Gaussian target with L lanes per chain (mhx_rwmh_dense_kernels.h): the default above 64
     dimensions, on request below; ISO and DIAG proposals, random initial states, a schedule with discard and
@@ -179,8 +180,8 @@ def test_negative_zero_initial_coordinates(mhx, oracle, real, lanes):
     assert not np.signbit(run.state()[0][init == 0]).any()
 
 
-@pytest.mark.parametrize("d,C,prop", [(65, 130, "iso"), (100, 70, "diag"), (128, 64, "iso"), (160, 33, "diag"), (200, 65, "iso"), (320, 10, "diag"),
-                                      (64, 66, "iso"), (96, 5, "dense"), (40, 9, "dense")])
+@pytest.mark.parametrize("d,C,prop", soak_tail([(65, 130, "iso"), (100, 70, "diag"), (128, 64, "iso"), (160, 33, "diag"), (200, 65, "iso"), (320, 10, "diag"),
+                                      (64, 66, "iso"), (96, 5, "dense"), (40, 9, "dense")], 4))
 def test_user_log_density_register_kernel_with_the_state_tail_in_lds(mhx, oracle, real, d, C, prop):
     """A user log-density needs the whole candidate in one lane's registers; above 64 (fp32: 128) dimensions the state keeps only
     its head there and its tail in LDS -- the register kernel then reaches d = 160 in fp64 (320 in fp32) instead of handing an
