@@ -135,14 +135,12 @@ static const prebuilt_coop k_prebuilt_coop[] = {
      k_rwmh_coop<MHX_C5_L, MHX_C5_NBL, MHX_TARGET_FUNNEL, MHX_PROP_ISO, true>},
     {MHX_C5_L, MHX_C5_NBL, MHX_TARGET_BANANA, MHX_PROP_ISO, k_rwmh_coop<MHX_C5_L, MHX_C5_NBL, MHX_TARGET_BANANA, MHX_PROP_ISO, false>,
      k_rwmh_coop<MHX_C5_L, MHX_C5_NBL, MHX_TARGET_BANANA, MHX_PROP_ISO, true>},
-#if MHX_REAL64
-    // the same shapes with the ziggurat generator (MHX_FLAG_ZIGGURAT)
+    // the same shapes with the ziggurat generator (MHX_FLAG_ZIGGURAT; both widths since round 6)
     {MHX_C2_L, MHX_C2_NBL, MHX_TARGET_ISO_GAUSS, MHX_PROP_ISO,
      k_rwmh_coop<MHX_C2_L, MHX_C2_NBL, MHX_TARGET_ISO_GAUSS, MHX_PROP_ISO, false, MHX_GEN_ZIGGURAT>, nullptr, MHX_GEN_ZIGGURAT},
     {MHX_C5_L, MHX_C5_NBL, MHX_TARGET_FUNNEL, MHX_PROP_ISO,
      k_rwmh_coop<MHX_C5_L, MHX_C5_NBL, MHX_TARGET_FUNNEL, MHX_PROP_ISO, false, MHX_GEN_ZIGGURAT>,
      k_rwmh_coop<MHX_C5_L, MHX_C5_NBL, MHX_TARGET_FUNNEL, MHX_PROP_ISO, true, MHX_GEN_ZIGGURAT>, MHX_GEN_ZIGGURAT},
-#endif
 };
 
 // sum of a u32 array into a u64 (one atomic per block)
@@ -993,8 +991,8 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
     // ---- kernel choice
     r->variant = 0;
     const int tk = t->kind, pk = r->prop_kind;
-    if ((cfg->flags & MHX_FLAG_ZIGGURAT) && !MHX_REAL64)
-        return mhx_fail(MHX_EINVAL, "MHX_FLAG_ZIGGURAT: the ziggurat normal generator exists in fp64 contexts only");
+    // (fp32, round 6: the ziggurat exists on the cooperative kernel -- 256 layers, one Philox word per normal; the register kernel's form
+    // and MALA's are fp64: the check at the end of this function refuses a run whose kernel has no ziggurat form)
     if ((cfg->flags & MHX_FLAG_ZIGGURAT) && d >= (1 << 20))      // the retry blocks are numbered (normal index << 8 | attempt) in 28 bits
         return mhx_fail(MHX_EINVAL, "MHX_FLAG_ZIGGURAT: dim must be below 2^20");
     int regmax = pk == MHX_PROP_DENSE ? MHX_REG_MAX_DIM_DENSE : MHX_REG_MAX_DIM;
@@ -1141,23 +1139,19 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
         const char* waves_env = opt(ctx, "COOP_WAVES");
         const int waves_override = waves_env ? atoi(waves_env) : 0;
         const bool zig = (cfg->flags & MHX_FLAG_ZIGGURAT) != 0;
-#if MHX_REAL64
         if (zig && MHX_ZIG_LDS_BYTES(NBL) > MHX_LDS_PER_BLOCK)
             return mhx_fail(MHX_EINVAL, "MHX_FLAG_ZIGGURAT: %d blocks per lane need %d bytes of LDS per block (limit %d); use more lanes per chain",
                             NBL, (int)MHX_ZIG_LDS_BYTES(NBL), (int)MHX_LDS_PER_BLOCK);
-#endif
         if (!(no_prebuilt && atoi(no_prebuilt)) && !waves_override && !walk)
             for (const auto& pb : k_prebuilt_coop)
                 if (pb.L == L && pb.NBL == NBL && pb.TK == tk && pb.PK == pk && pb.gen == (zig ? MHX_GEN_ZIGGURAT : MHX_GEN_BOX_MULLER)) {
                     r->reg_fn = pb.fn; r->reg_fn_mom = pb.fn_mom; r->variant = 3; r->normal_gen = pb.gen;
-#if MHX_REAL64
                     if (zig) {
                         r->coop_lds = MHX_ZIG_LDS_BYTES(NBL);
                         for (auto f : {pb.fn, pb.fn_mom})
                             if (f && hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->coop_lds) != hipSuccess)
                                 return mhx_fail(MHX_EHIP, "cooperative kernel (ziggurat): %zu bytes of LDS refused", r->coop_lds);
                     }
-#endif
                 }
         if (!r->variant && !(r->flags & MHX_FLAG_NO_JIT)) {
             jit_module* m = nullptr;
@@ -1183,13 +1177,11 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
 #endif
             rc = jit_compile(ctx, key + "/mom=0", jit_source(t, "mhx_rwmh_kernels.h"), defs, &m);
             if (rc == MHX_OK) rc = jit_function(m, "mhx_jit_rwmh_coop", &r->jit_step);
-#if MHX_REAL64
             if (rc == MHX_OK && zig) {
                 r->coop_lds = MHX_ZIG_LDS_BYTES(NBL);
                 if (hipFuncSetAttribute((const void*)r->jit_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->coop_lds) != hipSuccess)
                     rc = mhx_fail(MHX_EHIP, "cooperative kernel (ziggurat): %zu bytes of LDS refused", r->coop_lds);
             }
-#endif
             if (rc == MHX_OK) { r->variant = 4; r->normal_gen = zig ? MHX_GEN_ZIGGURAT : MHX_GEN_BOX_MULLER; }
             else if (cfg->reduce_lanes > 1 || zig) return rc;      // the caller asked for this shape explicitly
         }
@@ -1267,8 +1259,8 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
     }
     if ((cfg->flags & MHX_FLAG_ZIGGURAT) && r->normal_gen != MHX_GEN_ZIGGURAT)
         return mhx_fail(MHX_EINVAL, "MHX_FLAG_ZIGGURAT: this run's kernel (variant %d) has no ziggurat form -- it exists on the cooperative "
-                                    "kernel (separable catalogue target) and on the register kernel (any target within its dimension limit) of "
-                                    "fp64 contexts, ISO / DIAG proposal, JIT allowed", r->variant);
+                                    "kernel (separable catalogue target; fp64 and fp32) and on the register kernel (any target within its "
+                                    "dimension limit; fp64), ISO / DIAG proposal, JIT allowed", r->variant);
     // candidate scratch of the state-in-HBM kernel; a static proposal whitens the state into it whatever kernel steps the chain
     if (r->variant == 0 || r->d_qx) HIP_TRY(hipMalloc(&r->d_ybuf, (size_t)d * (size_t)r->n * sizeof(mhx_real)));
     *out = r.release();

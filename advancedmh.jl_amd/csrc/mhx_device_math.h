@@ -48,9 +48,7 @@ typedef float mhx_real;
 
 typedef unsigned int mhx_u32;
 typedef unsigned long long mhx_u64;
-#if MHX_REAL64
-#include "mhx_zig_table.h"     // generated (tools/gen_zig_table.py): the layer table of the ziggurat normal generator
-#endif
+#include "mhx_zig_table.h"     // generated (tools/gen_zig_table.py): the layer tables of the ziggurat normal generator (fp64: MHX_ZIG_*, fp32: MHX_ZIG32_*)
 MHX_NS_BEGIN
 
 // signature of a user log-density in HIP source form (see include/mhx.h, mhx_target_from_hip_source)
@@ -689,13 +687,109 @@ MHX_DEV void mhx_normal4(const mhx_philox_key& ks, mhx_u32 id_lo, mhx_u32 id_hi,
     mhx_normal_pair(w.x, w.y, n[0], n[1]);
     mhx_normal_pair(w.z, w.w, n[2], n[3]);
 }
+// ---------------------------------------------------------------------------------------------
+// The ZIGGURAT normal generator in fp32 (round 6; DESIGN.md section 3.11, fp32 form; the fp64 form is above): 256 equal-area layers,
+// table x[0..256] (mhx_zig_table.h: MHX_ZIG32_*), ONE 32-bit word per normal -- Philox block p of (id, step, stream) serves normals
+// 4p .. 4p+3 from its words x, y, z, w (the block a Box-Muller step spends on the same four normals):
+//   layer = bits 0..7;  sign = bit 31;  u = k 2^-23 in [0, 1) with the 23-bit k = bits 8..30 (the float 1 + u is 0x3f800000 | k);
+//   |x| = u x[layer];  accept at once when |x| < x[layer + 1]  (98.5 % of the draws);
+// otherwise rejection attempts t = 1, 2, ... from Philox block (n << 8 | t) of stream | 4: layer 0: the tail beyond r -- xx =
+// -log(U(word x))/r, yy = -log(U(word z)), accept r + xx iff 2 yy >= xx^2; else the wedge -- accept x iff f1 + U(word z) (f0 - f1) < 1;
+// on rejection word x of the same block is the next candidate.  Inside the kernels the macros MHX_ZIG_N / _R / _NEG_RINV mean the
+// table of the engine's own width.
+#define MHX_STREAM_RETRY 4u
 #define MHX_GEN_BOX_MULLER 0
 #define MHX_GEN_ZIGGURAT 1
-// (the ziggurat generator exists in the fp64 engine only)
-MHX_DEV void mhx_normal4_gen(const int, const mhx_philox_key& ks, mhx_u32 id_lo, mhx_u32 id_hi, mhx_u32 step,
+#undef MHX_ZIG_N
+#undef MHX_ZIG_LOG2N
+#undef MHX_ZIG_R
+#undef MHX_ZIG_NEG_RINV
+#define MHX_ZIG_N MHX_ZIG32_N
+#define MHX_ZIG_LOG2N 8
+#define MHX_ZIG_R MHX_ZIG32_R
+#define MHX_ZIG_NEG_RINV MHX_ZIG32_NEG_RINV
+__device__ const float mhx_zig_x[MHX_ZIG_N + 1] = MHX_ZIG32_TABLE;
+
+// u x_l in ONE operation: with m = 1 + u (exact) the fma m x_l - x_l rounds u x_l once -- the rounded product of the spec
+MHX_DEV float mhx_zig_ax(const mhx_u32 w, const float xl)
+{
+    return mhx_fma(mhx_u2f(0x3f800000u | ((w >> 8) & 0x7fffffu)), xl, -xl);
+}
+// |x| with the candidate's sign (bit 31 of its word); `sign` = 0x80000000 from a scalar register (v_and_or_b32 takes no literal)
+MHX_DEV float mhx_zig_signed(const float ax, const mhx_u32 w, const mhx_u32 sign = 0x80000000u)
+{
+    return mhx_u2f(mhx_f2u(ax) | (w & sign));
+}
+MHX_DEV bool mhx_zig_try(const float* __restrict__ zt, const mhx_u32 w, float& x, mhx_u32& layer)
+{
+    layer = w & (mhx_u32)(MHX_ZIG_N - 1);
+    const float ax = mhx_zig_ax(w, zt[layer]);
+    x = mhx_zig_signed(ax, w);
+    return ax < zt[layer + 1];
+}
+// the normal behind a candidate (x, layer) that left its rectangle: rejection attempts t0, t0 + 1, ...
+MHX_DEV float mhx_zig_slow(const mhx_philox_key& ks, const float* __restrict__ zt, const mhx_u32 id_lo, const mhx_u32 id_hi,
+                           const mhx_u32 step, const mhx_u32 stream, const mhx_u32 n, float x, mhx_u32 layer, const mhx_u32 t0 = 1u)
+{
+    for (mhx_u32 t = t0;; ++t) {
+        const mhx_u32x4 v = mhx_philox(ks, id_lo, id_hi, step, ((stream | MHX_STREAM_RETRY) << 28) | ((n << 8) | (t & 255u)));
+        if (layer == 0u) {
+            const float xx = mhx_log_pos(mhx_u01_open(v.x)) * MHX_ZIG_NEG_RINV;
+            const float yy = -mhx_log_pos(mhx_u01_open(v.z));
+            if (yy + yy >= xx * xx) return mhx_u2f(mhx_f2u(MHX_ZIG_R + xx) | (mhx_f2u(x) & 0x80000000u));
+        } else {
+            const float xl = zt[layer], xl1 = zt[layer + 1], xsq = x * x;
+            const float f0 = mhx_exp(-0.5f * (xl * xl - xsq)), f1 = mhx_exp(-0.5f * (xl1 * xl1 - xsq));
+            if (mhx_fma(mhx_u01_half(v.z), f0 - f1, f1) < 1.0f) return x;
+            if (mhx_zig_try(zt, v.x, x, layer)) return x;
+        }
+    }
+}
+// the same normal laid out for latency (the fix-up pass): the failed candidate's block and the block of attempt 1 drawn together,
+// the table entries of both candidates fetched together, the common case -- a wedge settled by attempt 1 -- straight through
+MHX_DEV float mhx_zig_refine(const mhx_philox_key& ks, const float* __restrict__ zt, const mhx_u32 id_lo, const mhx_u32 id_hi,
+                             const mhx_u32 step, const mhx_u32 stream, const mhx_u32 n)
+{
+    const mhx_u32x4 w4 = mhx_philox(ks, id_lo, id_hi, step, (stream << 28) | (n >> 2));
+    const mhx_u32x4 v = mhx_philox(ks, id_lo, id_hi, step, ((stream | MHX_STREAM_RETRY) << 28) | ((n << 8) | 1u));
+    const mhx_u32 j = n & 3u;
+    const mhx_u32 w = j == 0u ? w4.x : (j == 1u ? w4.y : (j == 2u ? w4.z : w4.w));
+    mhx_u32 layer = w & (mhx_u32)(MHX_ZIG_N - 1);
+    const mhx_u32 layer2 = v.x & (mhx_u32)(MHX_ZIG_N - 1);
+    const float xl = zt[layer], xl1 = zt[layer + 1];
+    const float xn = zt[layer2], xn1 = zt[layer2 + 1];
+    const float ax = mhx_zig_ax(w, xl);
+    float x = mhx_zig_signed(ax, w);
+    if (ax < xl1) return x;                                        // (not a failed candidate after all: callers only send failures)
+    if (layer == 0u) return mhx_zig_slow(ks, zt, id_lo, id_hi, step, stream, n, x, layer, 1u);
+    const float xsq = x * x;
+    const float f0 = mhx_exp(-0.5f * (xl * xl - xsq)), f1 = mhx_exp(-0.5f * (xl1 * xl1 - xsq));
+    if (mhx_fma(mhx_u01_half(v.z), f0 - f1, f1) < 1.0f) return x;
+    const float ax2 = mhx_zig_ax(v.x, xn);
+    x = mhx_zig_signed(ax2, v.x);
+    if (ax2 < xn1) return x;
+    return mhx_zig_slow(ks, zt, id_lo, id_hi, step, stream, n, x, layer2, 2u);
+}
+// normal number n (0-based) of (id, step, stream), straight from the table in global memory: the kernels off the hot path
+MHX_DEV float mhx_zig_normal(const mhx_philox_key& ks, const mhx_u32 id_lo, const mhx_u32 id_hi, const mhx_u32 step,
+                             const mhx_u32 stream, const mhx_u32 n)
+{
+    const mhx_u32x4 w4 = mhx_philox(ks, id_lo, id_hi, step, (stream << 28) | (n >> 2));
+    const mhx_u32 j = n & 3u;
+    float x; mhx_u32 layer;
+    if (mhx_zig_try(mhx_zig_x, j == 0u ? w4.x : (j == 1u ? w4.y : (j == 2u ? w4.z : w4.w)), x, layer)) return x;
+    return mhx_zig_slow(ks, mhx_zig_x, id_lo, id_hi, step, stream, n, x, layer);
+}
+// the 4 normals 4b..4b+3 by either generator (lane-per-chain kernels: initial draws, generic paths)
+MHX_DEV void mhx_normal4_gen(const int gen, const mhx_philox_key& ks, mhx_u32 id_lo, mhx_u32 id_hi, mhx_u32 step,
                              mhx_u32 stream, mhx_u32 block, float n[4])
 {
-    mhx_normal4(ks, id_lo, id_hi, step, stream, block, n);
+    if (gen == MHX_GEN_ZIGGURAT) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) n[j] = mhx_zig_normal(ks, id_lo, id_hi, step, stream, 4u * block + (mhx_u32)j);
+    } else {
+        mhx_normal4(ks, id_lo, id_hi, step, stream, block, n);
+    }
 }
 
 // log of the accept uniform of `step`: one Philox block serves 4 consecutive steps.

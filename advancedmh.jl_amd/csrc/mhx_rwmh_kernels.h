@@ -389,24 +389,30 @@ MHX_DEV void mhx_rwmh_whiten_body(const mhx_rwmh_args& a, const mhx_real* __rest
 #define MHX_WALK_PLAIN  0
 #define MHX_WALK_DRIFT  1
 #define MHX_WALK_STATIC 2
-#define MHX_ZIG_TABLE_BYTES_ANY (((1024 + 1) * 8 + 15) / 16 * 16)      // == MHX_ZIG_TABLE_BYTES (fp64 builds; checked there)
-#if MHX_REAL64
-// Dynamic LDS of the cooperative kernel with the ziggurat generator (GEN = MHX_GEN_ZIGGURAT), 256-thread blocks:
-//   [0, 8208)                       the layer table x[0..N]
-//   then per wave  NBL*4*64 doubles the step's normals, [pair of slots][lane][2] (a lane writes / reads 16 bytes, conflict-free)
+// Dynamic LDS of the cooperative kernel with the ziggurat generator (GEN = MHX_GEN_ZIGGURAT), 256-thread blocks (sizes in the engine's
+// own width: fp64 1024 layers and 8-byte normals, fp32 -- round 6 -- 256 layers and 4-byte normals):
+//   [0, table bytes)                the layer table x[0..N]
+//   then per wave  NBL*4*64 reals   the step's normals -- fp64: [pair of slots][lane][2], fp32: [block][lane][4]: a lane writes / reads
+//                                   16 bytes, conflict-free
 //                  64 u16           the queue of the candidates that left their rectangles: owner lane | slot << 6
 //                  KS x 64 u64      the lanes' masks of failed slots, one per step of the group
 // KS (round 4): the normals of KS consecutive steps are generated back to back and their failed candidates finished in ONE pass --
 // the fix-up pass costs a wave what it costs whether it repairs 4 candidates or 40 (the queue, two wave syncs, one walk through the
 // rejection code), and at d = 1000 (a wave per chain, 16 slots per lane: 4 failures per wave-step) it was a third of the kernel.
 // KS is the largest group (<= 4) whose slabs leave the LDS for as many blocks per CU as the launch bound asks for.
-#define MHX_ZIG_TABLE_BYTES (((MHX_ZIG_N + 1) * 8 + 15) / 16 * 16)
-#define MHX_ZIG_SLAB_BYTES(NBL) ((NBL) * 4 * 64 * 8)
+#define MHX_ZIG_TABLE_BYTES (((MHX_ZIG_N + 1) * (int)sizeof(mhx_real) + 15) / 16 * 16)
+#define MHX_ZIG_TABLE_BYTES_ANY MHX_ZIG_TABLE_BYTES
+#define MHX_ZIG_SLAB_BYTES(NBL) ((NBL) * 4 * 64 * (int)sizeof(mhx_real))
 #define MHX_ZIG_KS_FIT(NBL) ((163840 / MHX_COOP_WAVES(NBL) - MHX_ZIG_TABLE_BYTES - 512) / (4 * (MHX_ZIG_SLAB_BYTES(NBL) + 512 + 32)))
 #define MHX_ZIG_KS(NBL) (MHX_ZIG_KS_FIT(NBL) < 1 ? 1 : (MHX_ZIG_KS_FIT(NBL) > 4 ? 4 : MHX_ZIG_KS_FIT(NBL)))
 #define MHX_ZIG_WAVE_BYTES(NBL) (MHX_ZIG_KS(NBL) * (MHX_ZIG_SLAB_BYTES(NBL) + 512) + 128)
 #define MHX_ZIG_LDS_BYTES(NBL) (MHX_ZIG_TABLE_BYTES + 4 * MHX_ZIG_WAVE_BYTES(NBL))
-static_assert(MHX_ZIG_TABLE_BYTES == MHX_ZIG_TABLE_BYTES_ANY, "ziggurat table size");
+// where slot sl (= 4 i + j: block i of the lane, normal j of the block) of lane `ln` lives in a step's slab of normals
+#if MHX_REAL64
+#define MHX_ZIG_SLAB_AT(sl, ln) (((((sl) >> 1) * 64 + (ln)) << 1) + ((sl) & 1))
+#else
+#define MHX_ZIG_SLAB_AT(sl, ln) (((((sl) >> 2) * 64 + (ln)) << 2) + ((sl) & 3))
+#endif
 
 // The candidates of this wave-step that left their rectangles (0.4 % of the draws: a dozen per wave-step at d = 100), gathered
 // from all lanes into one queue and finished by as many lanes side by side -- ONE pass of the slow path per wave-step instead of
@@ -417,7 +423,7 @@ static_assert(MHX_ZIG_TABLE_BYTES == MHX_ZIG_TABLE_BYTES_ANY, "ziggurat table si
 // (Measured and removed in round 5, profiles/r04y_fastpath_ab.log: the failure bits from the SIGN of |x| - x[layer + 1] shifted in by
 // one v_alignbit_b32 per candidate -- 47 instructions fewer per wave-step and SLOWER, one dependent chain per candidate.)
 template <int L>
-MHX_DEV void mhx_zig_fixup(const mhx_philox_key& ks, const double* __restrict__ zt, double* __restrict__ zn,
+MHX_DEV void mhx_zig_fixup(const mhx_philox_key& ks, const mhx_real* __restrict__ zt, mhx_real* __restrict__ zn,
                            unsigned short* __restrict__ zq, const mhx_u64* __restrict__ zfm, const int ng, const int slabd,
                            const int lane, const long wave,
                            const mhx_u64 first_chain, const int nchains, const mhx_u32 step0, const mhx_u32 stream,
@@ -452,18 +458,17 @@ MHX_DEV void mhx_zig_fixup(const mhx_philox_key& ks, const double* __restrict__ 
             const int ent = zq[lane];
             const int ol = ent & 63, sl = (ent >> 6) & 63, sg = ent >> 12;
             const mhx_u32 step = step0 + (mhx_u32)sg;
-            double* const zns = zn + sg * slabd;
+            mhx_real* const zns = zn + sg * slabd;
             const long oc_raw = wave * CPW + (ol & (CPW - 1));
             const mhx_u64 oid = first_chain + (mhx_u64)(oc_raw < nchains ? oc_raw : (long)nchains - 1);
             const mhx_u32 b = (mhx_u32)(ol / CPW + L * (sl >> 2));
             const mhx_u32 n = 4u * b + (mhx_u32)(sl & 3);
             // nothing but the slot number was kept: the failed candidate is re-derived from its Philox block
-            zns[(((sl >> 1) * 64 + ol) << 1) + (sl & 1)] = mhx_zig_refine(ks, zt, (mhx_u32)oid, (mhx_u32)(oid >> 32), step, stream, n);
+            zns[MHX_ZIG_SLAB_AT(sl, ol)] = mhx_zig_refine(ks, zt, (mhx_u32)oid, (mhx_u32)(oid >> 32), step, stream, n);
         }
         MHX_WAVE_SYNC();
     }
 }
-#endif
 
 #if MHX_REAL64
 // The D standard normals of (chain, step, stream) by the table ziggurat into a lane's REGISTER array y (lane per chain, every lane of
@@ -706,13 +711,23 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
     constexpr bool ZKEEP = MHX_REAL64 && WALK == MHX_WALK_PLAIN && PK == MHX_PROP_ISO;   // (fp32: a select is one instruction already)
     // (re-reading the normals from LDS at the accept instead of keeping them in registers: C2 4.76e9 against 5.11e9 steps/s, removed --
     // profiles/r04i_zreload_ab.log)
-    static_assert(!ZIG || MHX_REAL64, "the ziggurat generator exists in the fp64 engine only");
     extern __shared__ double mhx_coop_lds[];
+    constexpr int KS = ZIG ? MHX_ZIG_KS(NBL) : 1;                   // steps per fix-up group
 #if MHX_REAL64
     typedef double mhx_d2 __attribute__((ext_vector_type(2)));
-    constexpr int KS = ZIG ? MHX_ZIG_KS(NBL) : 1;                   // steps per fix-up group
 #else
-    constexpr int KS = 1;
+    // the fp32 form (round 6): same layout in 4-byte reals -- table, then per wave the slab [block][lane][4], the queue, the masks
+    typedef float mhx_f2v __attribute__((ext_vector_type(2)));
+    typedef float mhx_f4v __attribute__((ext_vector_type(4)));
+    const float* zt = (const float*)mhx_coop_lds;
+    constexpr int SLABD = NBL * 4 * 64;                            // floats of one step's normals
+    float* zn0 = (float*)((char*)mhx_coop_lds + MHX_ZIG_TABLE_BYTES + (threadIdx.x >> 6) * MHX_ZIG_WAVE_BYTES(NBL));
+    unsigned short* zq = (unsigned short*)(zn0 + KS * SLABD);
+    mhx_u64* zfm = (mhx_u64*)((char*)(zn0 + KS * SLABD) + 128);
+    if (ZIG) {
+        for (int e = threadIdx.x; e <= MHX_ZIG_N; e += blockDim.x) ((float*)mhx_coop_lds)[e] = mhx_zig_x[e];
+        __syncthreads();
+    }
 #endif
 #if MHX_REAL64
     const double* zt = mhx_coop_lds;
@@ -983,6 +998,78 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
             mhx_zig_fixup<L>(ks, zt, zn0, zq, zfm, ng, SLABD, lane, wave, a.first_chain, a.nchains, a.step0 + (mhx_u32)it0, MHX_STREAM_PROPOSAL,
                              KS == 1, fm1);
     }
+#else
+    if (ZIG) {
+        // the fp32 form of the same three phases: ONE Philox call per block of four normals (a word each), the table pair of a
+        // candidate as one ds_read2_b32, the block's four normals to the slab as one 16-byte write
+        bool anyfail = false;
+        mhx_u64 fm1 = 0ull;
+#pragma unroll 1
+        for (int sg = 0; sg < ng; ++sg) {
+            const mhx_u32 step = a.step0 + (mhx_u32)(it0 + sg);
+            float* const zn = zn0 + sg * SLABD;
+            mhx_u64 fm = 0ull;
+            mhx_u32 kw[4];
+            auto draw = [&](const int i, mhx_u32 (&w)[4]) {
+                if (i < NBL) {
+                    const mhx_u32x4 w4 = mhx_philox(ks, id_lo, id_hi, step, (MHX_STREAM_PROPOSAL << 28) | (mhx_u32)(l + L * i));
+                    w[0] = w4.x; w[1] = w4.y; w[2] = w4.z; w[3] = w4.w;
+                } else {
+                    w[0] = w[1] = w[2] = w[3] = 0u;
+                }
+            };
+            draw(0, kw);
+            mhx_u32 zsign = 0x80000000u;                            // (opaque: see mhx_zig_signed)
+            asm volatile("" : "+s"(zsign));
+#pragma unroll
+            for (int i = 0; i < NBL; ++i) {
+                mhx_f2v xe[4];                                      // x[layer], x[layer + 1] of the block's candidates
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const mhx_u32 ly = kw[e] & (mhx_u32)(MHX_ZIG_N - 1);
+                    xe[e].x = zt[ly]; xe[e].y = zt[ly + 1];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mhx_u32 nw[4];
+                if (i + 1 < NBL) draw(i + 1, nw);                   // the next block's Philox rounds run while the look-ups are in flight
+                __builtin_amdgcn_sched_barrier(0);
+                mhx_f4v v4;
+                float nn[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float ax = mhx_zig_ax(kw[j], xe[j].x);
+                    nn[j] = mhx_zig_signed(ax, kw[j], zsign);
+                    bool fail = !(ax < xe[j].y);
+#ifdef MHX_TOOLS_BUILD
+#ifdef MHX_ZIG_FORCE_FAIL
+                    fail = fail || ((4 * i + j + lane) % (MHX_ZIG_FORCE_FAIL) == 0);
+#endif
+#endif
+                    if (i == NBL - 1) fail = fail && (k_last + j < d);   // padding dimensions past the end of the vector need no normal
+                    fm |= (fail ? 1ull : 0ull) << (4 * i + j);
+                }
+                v4.x = nn[0]; v4.y = nn[1]; v4.z = nn[2]; v4.w = nn[3];
+                *(mhx_f4v*)(zn + ((i * 64 + lane) << 2)) = v4;
+                if (i + 1 < NBL) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) kw[e] = nw[e];
+                }
+            }
+            if (KS > 1) zfm[sg * 64 + lane] = fm;
+            fm1 = fm;
+            anyfail = anyfail || fm != 0ull;
+        }
+#ifdef MHX_TOOLS_BUILD
+#ifndef MHX_ZIG_PROBE
+#define MHX_ZIG_PROBE 0
+#endif
+        if (MHX_ZIG_PROBE != 1 && __ballot(anyfail))
+#else
+        if (__ballot(anyfail))
+#endif
+            mhx_zig_fixup<L>(ks, zt, zn0, zq, zfm, ng, SLABD, lane, wave, a.first_chain, a.nchains, a.step0 + (mhx_u32)it0, MHX_STREAM_PROPOSAL,
+                             KS == 1, fm1);
+    }
 #endif
 #pragma unroll 1
     for (int sg = 0; sg < ng; ++sg) {
@@ -1003,16 +1090,23 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
                 y[i][0] = v0.x; y[i][1] = v0.y; y[i][2] = v1.x; y[i][3] = v1.y;
             }
         }
+#else
+        if (ZIG) {
+            const float* const zn_c = zn0 + sg * SLABD;
+#pragma unroll
+            for (int i = 0; i < NBL; ++i) {
+                const mhx_f4v v = *(const mhx_f4v*)(zn_c + ((i * 64 + lane) << 2));
+                y[i][0] = v.x; y[i][1] = v.y; y[i][2] = v.z; y[i][3] = v.w;
+            }
+        }
 #endif
 #pragma unroll
         for (int i = 0; i < NBL; ++i) {
             const int b = l + L * i;
             mhx_real n[4];
-#if MHX_REAL64
             if (ZIG) {
                 n[0] = y[i][0]; n[1] = y[i][1]; n[2] = y[i][2]; n[3] = y[i][3];
             } else
-#endif
             mhx_normal4(ks, id_lo, id_hi, step, MHX_STREAM_PROPOSAL, (mhx_u32)b, n);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {

@@ -63,13 +63,14 @@ RB = {"f32": 4, "f64": 8}
 GEN_TEXT = {None: "Box-Muller", "box-muller": "Box-Muller", "ziggurat": "ziggurat"}
 
 
-def pick_gen(args, dtype):
-    """RWMH on the cooperative kernel: the ziggurat generator in fp64 (what Julia's own randn is), Box-Muller in fp32 (the fp64
-    engine alone has the ziggurat); --normal-gen overrides."""
+def pick_gen(args, dtype, coop=True):
+    """RWMH: the ziggurat generator (what Julia's own randn is) wherever the kernel has the form -- fp64: the cooperative and the
+    register kernel; fp32 (round 6): the cooperative kernel; Box-Muller otherwise; --normal-gen overrides."""
     g = getattr(args, "normal_gen", "auto")
+    has = dtype == "f64" or coop
     if g == "auto":
-        return "ziggurat" if dtype == "f64" else None
-    return None if g == "box-muller" or dtype != "f64" else g
+        return "ziggurat" if has else None
+    return None if g == "box-muller" or not has else g
 
 
 def sigma_ar1(d, rho):
@@ -179,7 +180,7 @@ class C2:
         self.lanes = args.lanes
         self.literal = getattr(args, "c2_literal", False)
         self.user = getattr(args, "c2_user", False)       # the same target as a user log-density in HIP source: DensityModel(f), JIT-lowered
-        self.gen = pick_gen(args, dtype)                  # (the register kernel of a user log-density has its ziggurat form too)
+        self.gen = pick_gen(args, dtype, coop=not self.user)   # (the register kernel of a user log-density has its ziggurat form in fp64)
 
     USER_SOURCE = """
 MHX_LOGDENSITY(x, d, data, ndata)

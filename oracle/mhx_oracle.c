@@ -367,7 +367,7 @@ static void emcee_draws(uint64_t seed, uint64_t ens, int i, uint32_t sweep, uint
 #endif
 
 /* ------------------------------------------------------------------------------------------ */
-/* normal generators.  gen 0: Box-Muller (orc_normals).  gen 1 (fp64 only): the table ZIGGURAT of spec 3.11 --
+/* normal generators.  gen 0: Box-Muller (orc_normals).  gen 1: the table ZIGGURAT of spec 3.11 (fp64 here, the fp32 form below) --
  * ORC_ZIG_N equal-area layers under exp(-x^2/2) (mhx_zig_table.h, generated by tools/gen_zig_table.py), 64 bits per normal:
  * Philox block p of (chain, step, stream) serves normals 2p (words hi = 0, lo = 1) and 2p+1 (words 2, 3); layer = lo mod N,
  * sign = bit 31 of lo, u = k 2^-52 with k = (bits 11..30 of lo) : hi, |x| = u x[layer], accepted at once iff |x| < x[layer+1]; otherwise rejection
@@ -410,16 +410,53 @@ double orc_zig_normal(uint64_t seed, uint64_t chain, uint32_t step, uint32_t str
 }
 #endif
 
+#if !ORC_F64
+/* The fp32 ziggurat (round 6; spec 3.11, fp32 form): MHX_ZIG32_N = 256 layers, ONE 32-bit word per normal -- Philox block p of
+ * (chain, step, stream) serves normals 4p .. 4p+3 from its words 0 .. 3; layer = bits 0..7, sign = bit 31, u = k 2^-23 with the 23-bit
+ * k = bits 8..30, |x| = u x[layer], accepted at once iff |x| < x[layer+1] (98.5 %); otherwise rejection attempts t = 1, 2, ... from block
+ * (n << 8 | t) of stream | 4: layer 0 = the tail beyond r (uniforms from words 0 and 2), else the wedge test (uniform from word 2)
+ * with the next candidate from word 0 of the same block on rejection. */
+#include "mhx_zig_table.h"
+static const float zig_x[MHX_ZIG32_N + 1] = MHX_ZIG32_TABLE;
+
+static int zig_try(uint32_t w, float *x, uint32_t *layer)
+{
+    *layer = w & (uint32_t)(MHX_ZIG32_N - 1);                          /* bits 0..7 */
+    const float u = (float)((w >> 8) & 0x7fffffu) * 0x1p-23f;           /* [0, 1), exact */
+    const float ax = u * zig_x[*layer];
+    *x = (w >> 31) ? -ax : ax;                                          /* bit 31 is the sign */
+    return ax < zig_x[*layer + 1];
+}
+
+float orc_zig_normal(uint64_t seed, uint64_t chain, uint32_t step, uint32_t stream, uint32_t n)
+{
+    uint32_t w[4], layer;
+    float x;
+    philox_at(seed, chain, step, stream, n >> 2, w);
+    if (zig_try(w[n & 3u], &x, &layer)) return x;
+    for (uint32_t t = 1;; ++t) {
+        philox_at(seed, chain, step, stream | 4u, (n << 8) | (t & 255u), w);
+        if (layer == 0u) {
+            const float xx = orc_log(orc_u01_open(w[0])) * MHX_ZIG32_NEG_RINV;
+            const float yy = -orc_log(orc_u01_open(w[2]));
+            if (yy + yy >= xx * xx) return signbit(x) ? -(MHX_ZIG32_R + xx) : (MHX_ZIG32_R + xx);
+        } else {
+            const float xl = zig_x[layer], xl1 = zig_x[layer + 1], xsq = x * x;
+            const float f0 = orc_exp(-0.5f * (xl * xl - xsq)), f1 = orc_exp(-0.5f * (xl1 * xl1 - xsq));
+            if (fmaf(orc_u01_half(w[2]), f0 - f1, f1) < 1.0f) return x;
+            if (zig_try(w[0], &x, &layer)) return x;
+        }
+    }
+}
+#endif
+
 void orc_normals_gen(int gen, uint64_t seed, uint64_t chain, uint32_t step, uint32_t stream, int d, real *out);
 static void normals_gen(int gen, uint64_t seed, uint64_t chain, uint32_t step, uint32_t stream, int d, real *out)
 {
-#if ORC_F64
     if (gen == 1) {
         for (int k = 0; k < d; ++k) out[k] = orc_zig_normal(seed, chain, step, stream, (uint32_t)k);
         return;
     }
-#endif
-    (void)gen;
     orc_normals(seed, chain, step, stream, d, out);
 }
 void orc_normals_gen(int gen, uint64_t seed, uint64_t chain, uint32_t step, uint32_t stream, int d, real *out)

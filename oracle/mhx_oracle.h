@@ -163,12 +163,11 @@ int orc_mala(const orc_target *t, orc_logdensity_grad_fn user, real sigma2, cons
              uint64_t seed, uint64_t first_chain, int nchains, const real *init,
              real *samples, uint8_t *accepted, real *final_x, real *final_lp, uint32_t *accept_counts, int normal_gen /* 0 Box-Muller, 1 ziggurat (fp64) */);
 
-/* the d standard normals of (seed, chain, step, stream) by generator `gen` (0 Box-Muller, 1 ziggurat: fp64 build only) */
+/* the d standard normals of (seed, chain, step, stream) by generator `gen` (0 Box-Muller, 1 ziggurat) */
 void orc_normals_gen(int gen, uint64_t seed, uint64_t chain, uint32_t step, uint32_t stream, int d, real *out);
-#if ORC_F64
-/* standard normal number n (0-based) of (seed, chain, step, stream) by the ziggurat generator (spec 3.11) */
-double orc_zig_normal(uint64_t seed, uint64_t chain, uint32_t step, uint32_t stream, uint32_t n);
-#endif
+/* standard normal number n (0-based) of (seed, chain, step, stream) by the ziggurat generator (spec 3.11: 1024 layers and 64 bits per
+ * normal in the fp64 build, 256 layers and 32 bits in the fp32 build) */
+real orc_zig_normal(uint64_t seed, uint64_t chain, uint32_t step, uint32_t stream, uint32_t n);
 
 /* Trace sink for tests (thread-local; all three optional, [n_samples][nchains], NULL switches off):
  * margin = smallest |logu - logalpha| over the transitions that led to a saved slot; logalpha / eta = RAM's state.logalpha

@@ -201,8 +201,8 @@ def normals(seed, chain, step, stream, d):
 
 
 def zig_normals(seed, chain, step, stream, d):
-    """d standard normals of (seed, chain, step, stream) by the ziggurat generator (fp64 build)"""
-    out = np.empty(d, dtype=np.float64)
+    """d standard normals of (seed, chain, step, stream) by the ziggurat generator (the build's own form: 64 / 32 bits per normal)"""
+    out = np.empty(d, dtype=real())
     lib().orc_normals_gen(1, C.c_uint64(seed), C.c_uint64(chain), C.c_uint32(step), C.c_uint32(stream), d, _fp(out))
     return out
 
@@ -290,9 +290,8 @@ def unpack_lower(p, d):
 
 class Proposal:
     def __init__(self, kind, scale=1.0, vec=None, mean=None, static=False, normal_gen=0):
-        """normal_gen: 0 Box-Muller, 1 the table ziggurat (fp64 build only; what MHX_FLAG_ZIGGURAT selects on the device)"""
-        if normal_gen and _DT != "f64":
-            raise ValueError("the ziggurat generator exists in the fp64 build only")
+        """normal_gen: 0 Box-Muller, 1 the table ziggurat (what MHX_FLAG_ZIGGURAT selects on the device; 64 bits per normal in the
+        fp64 build, 32 in the fp32 build)"""
         self.vec = None if vec is None else np.ascontiguousarray(vec, dtype=real())
         self.mean = None if mean is None else np.ascontiguousarray(mean, dtype=real())
         self.c = _T("Proposal")(kind, float(scale), _fp(self.vec), _fp(self.mean), 1 if static else 0, int(normal_gen))

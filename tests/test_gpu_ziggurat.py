@@ -1,4 +1,5 @@
-"""GPU parity of the ZIGGURAT normal generator (MHX_FLAG_ZIGGURAT, arithmetic spec 3.11; fp64 engine): the cooperative RWMH
+"""GPU parity of the ZIGGURAT normal generator (MHX_FLAG_ZIGGURAT, arithmetic spec 3.11; fp64 engine, and since round 6 the fp32
+engine's cooperative kernel): the cooperative RWMH
 kernel -- fast path for every lane, the rare candidates that leave their rectangles gathered per wave-step and finished by as many
 lanes side by side -- against the oracle's one-normal-at-a-time restatement (oracle.Proposal(normal_gen=1)), bit for bit.
 Reference behaviour under test: src/mh-core.jl:76-117 with `randn` replaced by the spec's generator (Julia's own randn is a
@@ -31,9 +32,20 @@ def f64(mhx, oracle):
     oracle.set_dtype(old_o)
 
 
+@pytest.fixture(params=["f64", "f32"])
+def width(request, mhx, oracle):
+    """the cooperative kernel's ziggurat exists in both widths since round 6 (fp32: 256 layers, one Philox word per normal)"""
+    old_m, old_o = mhx.get_default_dtype(), oracle.get_dtype()
+    mhx.set_default_dtype(request.param)
+    oracle.set_dtype(request.param)
+    yield request.param
+    mhx.set_default_dtype(old_m)
+    oracle.set_dtype(old_o)
+
+
 @pytest.mark.parametrize("lanes", [0, 1, 2, 4, 8])
 @pytest.mark.parametrize("d,C,N", [(100, 130, 60), (7, 64, 40), (33, 257, 25), (2, 5, 64), (52, 1000, 12)])
-def test_iso_gauss_ziggurat_bit_exact(mhx, oracle, f64, d, C, N, lanes):
+def test_iso_gauss_ziggurat_bit_exact(mhx, oracle, width, d, C, N, lanes):
     if lanes > 1 and lanes > (d + 3) // 4:
         pytest.skip("more lanes than Philox blocks")
     if lanes and -(-((d + 3) // 4) // lanes) > 13:
@@ -56,7 +68,7 @@ def test_iso_gauss_ziggurat_bit_exact(mhx, oracle, f64, d, C, N, lanes):
     assert bm.stats["normal_gen"] == 0 and not np.array_equal(bm.value[:3], chain.value[:3])
 
 
-def test_c2_shape_hits_the_prebuilt_ziggurat_kernel_and_the_slow_paths(mhx, oracle, f64):
+def test_c2_shape_hits_the_prebuilt_ziggurat_kernel_and_the_slow_paths(mhx, oracle, width):
     """65 536-chain shape of the headline on a subset of chains, long enough that every branch of the generator is taken many
     times (wedges: 0.4 % of the draws; tails beyond r = 4.04: 5e-5): 256 chains x 400 transitions x 100 normals = 1e7 draws."""
     d, C, N = 100, 256, 401
@@ -71,7 +83,7 @@ def test_c2_shape_hits_the_prebuilt_ziggurat_kernel_and_the_slow_paths(mhx, orac
 
 
 @pytest.mark.parametrize("target", ["funnel", "banana"])
-def test_separable_targets_diag_proposal_and_moments(mhx, oracle, f64, target):
+def test_separable_targets_diag_proposal_and_moments(mhx, oracle, width, target):
     d, C, N = 1000, 96, 9
     tm = mhx.Funnel(d) if target == "funnel" else mhx.Banana(d, 0.03)
     ot = oracle.Target(oracle.TARGET_FUNNEL, d) if target == "funnel" else oracle.Target(oracle.TARGET_BANANA, d, params=[0.03])
@@ -91,7 +103,7 @@ def test_separable_targets_diag_proposal_and_moments(mhx, oracle, f64, target):
     assert np.isfinite(dg["mean"]).all()
 
 
-def test_walks_with_a_hastings_ratio(mhx, oracle, f64):
+def test_walks_with_a_hastings_ratio(mhx, oracle, width):
     d, C, N = 20, 70, 30
     mu = np.linspace(-0.05, 0.05, d)
     model = mhx.DensityModel(mhx.IsoGaussian(d))
@@ -113,30 +125,36 @@ def test_where_the_ziggurat_does_not_exist(mhx, f64):
     spl = mhx.RWMH(mhx.MvNormal(mhx.zeros(d), 0.04 * mhx.I))
     with pytest.raises(mhx.ArgumentError, match="ziggurat"):                 # dense Gaussian target: matrix-core / dense kernels
         mhx.Run(mhx.DensityModel(mhx.CorrGaussian(cases.sigma_ar1(d, 0.5))), spl, nchains=64, normal_gen="ziggurat")
-    with pytest.raises(mhx.ArgumentError, match="fp64"):                      # fp32 context
-        mhx.Run(mhx.DensityModel(mhx.IsoGaussian(d)), spl, nchains=64, normal_gen="ziggurat", dtype="f32")
+    # fp32: the cooperative kernel has the form (round 6), the register kernel (a user's source) does not
+    ok = mhx.Run(mhx.DensityModel(mhx.IsoGaussian(d)), spl, nchains=64, normal_gen="ziggurat", dtype="f32")
+    ok.init(None)
+    ok.sample(3)
+    assert ok.stats()["normal_gen"] == 1 and ok.stats()["dtype"] == "f32"
+    with pytest.raises(mhx.ArgumentError, match="ziggurat"):
+        mhx.Run(mhx.DensityModel(mhx.HipLogDensity(user_targets.SHIFTED_GAUSS, d, data=np.zeros(2 * d, np.float32) + 1)), spl, nchains=64,
+                normal_gen="ziggurat", dtype="f32")
     with pytest.raises(mhx.ArgumentError):                                    # forced generic kernel
         mhx.Run(mhx.DensityModel(mhx.IsoGaussian(d)), spl, nchains=64, normal_gen="ziggurat", flags=mhx.FLAG_GENERIC)
 
 
-def test_device_normals_pass_distribution_checks(mhx, f64):
+def test_device_normals_pass_distribution_checks(mhx, width):
     """The device's own draws (the initial draw of 4096 chains x d = 1000 from N(0, I): 4.1e6 normals) against the normal law."""
     import scipy.stats as st
     d, C = 1000, 4096
     run = mhx.Run(mhx.DensityModel(mhx.IsoGaussian(d)), mhx.RWMH(mhx.MvNormal(mhx.zeros(d), mhx.I)), nchains=C, seed=77, normal_gen="ziggurat")
     run.init(None)
-    x = run.state()[0].ravel()
+    x = run.state()[0].ravel().astype(np.float64)
     n = x.size
     assert abs(x.mean()) < 5 / np.sqrt(n) and abs(x.var() - 1) < 5 * np.sqrt(2.0 / n)
     assert abs((x ** 4).mean() - 3) < 5 * np.sqrt(96.0 / n)
     assert st.kstest(x[::7], "norm").pvalue > 1e-4
-    for t in (2.0, 3.0, 4.0388498461095045):
+    for t in (2.0, 3.0, 4.0388498461095045 if width == "f64" else 3.65415288536):
         e = n * 2 * st.norm.sf(t)
         assert abs((np.abs(x) > t).sum() - e) < 5 * np.sqrt(e) + 1, t
 
 
 @pytest.mark.parametrize("every", [3, 7])
-def test_fixup_queue_windows(mhx, oracle, f64, tools_engine, every):
+def test_fixup_queue_windows(mhx, oracle, width, tools_engine, every):
     """More than 64 candidates of one wave-step in the fix-up queue (never seen in practice: a dozen fail) -- forced by the
     ZIG_FORCE_FAIL test hook of the TOOLS build, which sends every n-th slot through the queue although its candidate is inside its
     rectangle; the refinement re-derives the same normal, so the chains must still equal the oracle's bit for bit.  (A hook taints

@@ -220,6 +220,7 @@ def _zig_table(path):
     txt = open(path).read()
     n = int(re.search(r"#define MHX_ZIG_N (\d+)", txt).group(1))
     body = txt[txt.index("#define MHX_ZIG_TABLE"):]
+    body = body[:body.index("}")]                                            # (the fp32 table follows in the same file)
     vals = [float.fromhex(t) for t in re.findall(r"-?0x[0-9a-f.]+p[+-]?\d+", body)]
     r = float.fromhex(re.search(r"#define MHX_ZIG_R (\S+)", txt).group(1))
     nri = float.fromhex(re.search(r"#define MHX_ZIG_NEG_RINV (\S+)", txt).group(1))
@@ -280,9 +281,56 @@ def test_ziggurat_stream_layout(oracle64):
     cand = x0 + s * z                                                       # s = 1/2: the product is exact, one rounding like the fma
     got = r["samples"][1, :d, 0]
     assert np.array_equal(got, cand if r["accepted"][1, 0] else x0)
-    with pytest.raises(ValueError):
-        O.set_dtype("f32")
-        try:
-            O.Proposal(O.PROP_ISO, s, normal_gen=1)
-        finally:
-            O.set_dtype("f64")
+
+
+def _zig32_table(path):
+    import re
+    txt = open(path).read()
+    n = int(re.search(r"#define MHX_ZIG32_N (\d+)", txt).group(1))
+    body = txt[txt.index("#define MHX_ZIG32_TABLE"):]
+    vals = [float.fromhex(t) for t in re.findall(r"-?0x[0-9a-f.]+p[+-]?\d+", body)]
+    r = float.fromhex(re.search(r"#define MHX_ZIG32_R (\S+?)f\b", txt).group(1))
+    nri = float.fromhex(re.search(r"#define MHX_ZIG32_NEG_RINV (\S+?)f\b", txt).group(1))
+    return n, np.array(vals), r, nri
+
+
+def test_fp32_ziggurat_table_normals_and_stream_layout(oracle):
+    """round 6: the fp32 form of spec 3.11 -- 256 equal-area layers (floats correctly rounded from the 60-digit recursion), ONE 32-bit
+    word per normal: normal n of a step comes from word n & 3 of Philox block n >> 2 of its stream and, on rejection, from blocks
+    (n << 8 | t) of stream | 4 only.  The draws are standard normal; rwmh with normal_gen = 1 uses exactly these."""
+    import os
+    O = oracle
+    old = O.get_dtype()
+    O.set_dtype("f32")
+    try:
+        n, x, r, nri = _zig32_table(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "mhx_zig_table.h"))
+        assert n == 256 and x.size == n + 1 and x[1] == r and x[n] == 0.0 and (np.diff(x) < 0).all()
+        assert all(float(np.float32(v)) == v for v in x) and abs(nri + 1.0 / r) < 1e-7
+        mp = pytest.importorskip("mpmath")
+        mp.mp.dps = 30
+        f = lambda t: mp.exp(-mp.mpf(t) ** 2 / 2)
+        v = mp.mpf(r) * f(r) + mp.sqrt(mp.pi / 2) * mp.erfc(mp.mpf(r) / mp.sqrt(2))
+        for i in (1, 2, 17, 128, 250, n - 1):                                # equal areas, to the floats' rounding
+            assert abs(mp.mpf(x[i]) * (f(x[i + 1]) - f(x[i])) / v - 1) < 2e-5, i
+        z = np.concatenate([O.zig_normals(20260929, c, 5, O.STREAM_PROPOSAL, 500000) for c in range(8)]).astype(np.float64)
+        m = z.size
+        assert z.dtype == np.float64 and abs(z.mean()) < 4.5 / np.sqrt(m) and abs(z.var() - 1) < 4.5 * np.sqrt(2.0 / m)
+        assert abs((z ** 3).mean()) < 4.5 * np.sqrt(15.0 / m) and abs((z ** 4).mean() - 3) < 4.5 * np.sqrt(96.0 / m)
+        assert stats.kstest(z[::3], "norm").pvalue > 1e-3
+        for t in (1.0, 2.0, 3.0, r, 4.2):                                    # body, wedges and the tail beyond r
+            e = m * 2 * stats.norm.sf(t)
+            assert abs((np.abs(z) > t).sum() - e) < 4.5 * np.sqrt(e) + 1, (t, (np.abs(z) > t).sum(), e)
+        assert np.isfinite(z).all() and abs((z > 0).mean() - 0.5) < 4.5 * 0.5 / np.sqrt(m)
+        a = O.zig_normals(3, 9, 2, O.STREAM_PROPOSAL, 40)
+        b = O.zig_normals(3, 9, 2, O.STREAM_PROPOSAL, 1000)
+        assert a.dtype == np.float32 and np.array_equal(a, b[:40])
+        # the fast path, restated: word j of block p -> layer, sign, 23-bit uniform
+        d, sc = 6, 0.5
+        rr = O.rwmh(O.iso_gauss(d), O.Proposal(O.PROP_ISO, sc, normal_gen=1), O.schedule(2), 3, 9, 1)
+        x0 = np.float32(sc) * O.zig_normals(3, 9, 0, O.STREAM_INIT, d)
+        assert np.array_equal(rr["samples"][0, :d, 0], x0)
+        zz = O.zig_normals(3, 9, 1, O.STREAM_PROPOSAL, d)
+        cand = x0 + np.float32(sc) * zz
+        assert np.array_equal(rr["samples"][1, :d, 0], cand if rr["accepted"][1, 0] else x0)
+    finally:
+        O.set_dtype(old)
