@@ -167,14 +167,16 @@ typedef struct {
 #define MHX_FLAG_EMCEE_SEQUENTIAL 8 /* Ensemble runs only: the reference's sweep (src/emcee.jl:39-58) -- walkers move one after
                                       another and pair with already-updated walkers (Gauss-Seidel), one wavefront, for
                                       fidelity checks at the reference's test sizes; the default is the parallel half-split */
-#define MHX_FLAG_ZIGGURAT 16 /* RWMH and (round 5) MALA runs, fp64 contexts: standard normals by the table ZIGGURAT of the arithmetic spec (DESIGN.md
-                                section 3.11: 1024 equal-area layers, 64 bits per normal, exact rejection sampling) instead of
+#define MHX_FLAG_ZIGGURAT 16 /* RWMH and (round 5) MALA runs: standard normals by the table ZIGGURAT of the arithmetic spec (DESIGN.md
+                                section 3.11: fp64 contexts 1024 equal-area layers and 64 bits per normal; fp32 contexts -- 0.6.0, the
+                                cooperative RWMH kernel only -- 256 layers and 32 bits per normal; exact rejection sampling) instead of
                                 Box-Muller -- a third fewer instructions per transition on the cooperative kernel (separable
                                 catalogue targets) and on the register kernel (any target within its dimension limit, a user's
                                 HIP source included), ISO / DIAG proposals.  It selects the STREAM of normals, so the chain differs
                                 from the Box-Muller chain of the same seed (both target the same law); the value in effect is
                                 reported in mhx_stats.normal_gen and fixes the chain bit for bit.  MHX_EINVAL where the run's
-                                kernel has no ziggurat form (fp32, dense factors, the matrix-core and state-in-HBM kernels).  MALA: the
+                                kernel has no ziggurat form (dense factors, the matrix-core and state-in-HBM kernels; in fp32 also the
+                                register kernel and MALA).  MALA: the
                                 noise z of the Langevin proposal, on the lane-per-chain register kernel (any target with a gradient
                                 within that kernel's dimension limit; reduce_lanes <= 1). */
 #define MHX_FLAG_DENSE_FACTOR 32 /* Ensemble runs: treat the precision factor of a dense-Gaussian target as dense even when it is

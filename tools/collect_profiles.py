@@ -9,7 +9,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DOMINANT = {"c2": ("rwmh_coop", "mhx_jit_rwmh_reg"), "c5": ("rwmh_coop",), "c3": ("mhx_jit_emcee_sweep", "mhx_jit_emcee_mfma_sweep", "emcee_half"), "c4": ("k_ram<", "k_ram_defer<"), "c1": ("k_rwmh_wave",)}
+DOMINANT = {"c2": ("rwmh_coop", "mhx_jit_rwmh_reg"), "c5": ("rwmh_coop",), "c3": ("mhx_jit_emcee_sweep", "mhx_jit_emcee_mfma_sweep", "mhx_jit_emcee_persist", "emcee_half"), "c4": ("k_ram<", "k_ram_defer<"), "c1": ("k_rwmh_wave",)}
 
 
 def dominant(cfg, name):
@@ -60,7 +60,7 @@ def main(tags):
                 "source": "profiles/%s_summary.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_*, separate passes)" % name,
             }
             # variants of a config profiled under their own tag: r04rot_c3_f64 -> c3_rotated_f64, r04ban_c5_f64 -> c5_banana_f64, ...
-            variant = {"rot": "_rotated", "ban": "_banana", "mov": "_moving", "fix": "_fixed", "lit": "_literal", "usr": "_user", "def": "_deferred"}.get(tag[-3:], "")
+            variant = {"rot": "_rotated", "ban": "_banana", "mov": "_moving", "fix": "_fixed", "lit": "_literal", "usr": "_user", "def": "_deferred", "sml": "_small"}.get(tag[-3:], "")
             traffic["%s%s_%s" % (cfg, variant, dt)] = entry
             print(name, "-> traffic[%s%s_%s]: hbm %.4g B, valu %.4g per step; trace %.4g ns vs HIP events %.4g ns per dispatch" % (
                 cfg, variant, dt, entry["hbm_bytes_per_launch"], entry["valu_insts_per_launch"], entry["trace_avg_ns_per_dispatch"] or 0,
