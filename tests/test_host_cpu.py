@@ -351,10 +351,10 @@ def test_bench_refuses_to_claim_ranks_or_gpus_it_does_not_have():
 
 def test_bench_line_fits_the_drivers_tail():
     """The driver keeps an 8 KB tail of stdout: the whole line has to fit.  Checked on the last full line a GPU box printed
-    (profiles/r0[45]*_bench_full.json, committed) and on the worst case the compact blocks can reach."""
+    (profiles/r0[456]*_bench_full.json, committed) and on the worst case the compact blocks can reach."""
     import glob
     import bench
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[45]*_bench_full.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[456]*_bench_full.json")))
     for f in files:
         text = open(f).read().strip().splitlines()[-1]
         assert len(text) < 8000, (f, len(text))
@@ -362,6 +362,10 @@ def test_bench_line_fits_the_drivers_tail():
         for k in ("c1", "c2_literal", "c3", "c3_rotated", "c4", "c4_moving", "c4_fixed", "c5", "c5_banana"):
             assert k in line["configs"], (f, k)
             assert "error" not in line["configs"][k], (f, k, line["configs"][k])
+        if os.path.basename(f).startswith("r06"):                # round 6: the boundary's own figure and the many-ensemble config ride in the line
+            sa = line["e2e_host"]["save_all"]
+            assert sa["compact"] == 1 and sa["value"] >= 1.0e8 and "host_expand_GBps" in sa and "link_GBps" in sa, sa
+            assert line["configs"]["c3_small"]["ensembles"] == 256 and line["configs"]["c3"]["bound"] == "latency"
     # a compact block with every optional key and full-width numbers stays small: 9 of them + the top level < 8000
     blk = {"value": 1.2345e9, "ms_per_step": 123.45, "acc": 0.234, "bound": "valu", "frac": 0.4321, "traffic_ratio": 1.2345,
            "launch_us": 12345.0, "kernel": "sequential-ensemble-sweep", "lanes": 64, "hbm_frac": 0.0171, "band": 1,
