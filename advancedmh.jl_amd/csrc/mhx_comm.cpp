@@ -30,6 +30,7 @@ struct rccl_api {
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;        // optional: what the communicator itself reports
     ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;                    // optional: release a communicator whose collective hangs
     bool ok = false;
 };
 
@@ -54,6 +55,7 @@ void load_rccl()
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
     g_rccl.CommCount = (decltype(g_rccl.CommCount))sym("ncclCommCount");
     g_rccl.CommUserRank = (decltype(g_rccl.CommUserRank))sym("ncclCommUserRank");
+    g_rccl.CommAbort = (decltype(g_rccl.CommAbort))sym("ncclCommAbort");
     g_rccl.ok = g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.CommDestroy && g_rccl.AllReduce && g_rccl.AllGather &&
                 g_rccl.GetErrorString;
 }
@@ -72,7 +74,9 @@ struct mhx_comm {
     ncclComm_t comm = nullptr;
     hipStream_t stream = nullptr;
     double* d_buf = nullptr;       // staging of the stats all-reduce
-    size_t cap = 0;
+    double* h_buf = nullptr;       // ... and its host side (page-locked, owned here: a copy still queued after a missed
+    size_t cap = 0;                //     deadline lands in memory that outlives the caller's array)
+    bool poisoned = false;         // a collective missed its deadline: its stream still holds it, nothing more is queued behind it
     void* d_stage = nullptr;       // staging of the walker all-gather: [world][stride] bytes
     size_t stage_cap = 0;
     double op_timeout_s = MHX_COMM_INIT_TIMEOUT_S;   // deadline of one blocking collective (mhx_comm_set_timeout)
@@ -109,6 +113,7 @@ struct init_job {
     std::mutex mu;
     std::condition_variable cv;
     bool done = false;
+    bool abandoned = false;             // the caller's deadline passed: a communicator that still arrives is the helper's to release
     ncclResult_t res = ncclSuccess;
     hipError_t dev = hipSuccess;
     ncclComm_t comm = nullptr;
@@ -147,15 +152,22 @@ extern "C" int mhx_comm_init_timed(mhx_ctx* ctx, int rank, int world, const void
         if (fault && !strcmp(fault, "hang")) for (;;) std::this_thread::sleep_for(std::chrono::seconds(3600));
 #endif
         if (e == hipSuccess) r = g_rccl.CommInitRank(&comm, world, id, rank);
-        std::lock_guard<std::mutex> lk(job->mu);
+        std::unique_lock<std::mutex> lk(job->mu);
+        if (job->abandoned) {                            // nobody is waiting any more: do not leak what arrived late
+            lk.unlock();
+            if (comm && r == ncclSuccess) (void)(g_rccl.CommAbort ? g_rccl.CommAbort(comm) : g_rccl.CommDestroy(comm));
+            return;
+        }
         job->dev = e; job->res = r; job->comm = comm; job->done = true;
         job->cv.notify_all();
     }).detach();
     {
         std::unique_lock<std::mutex> lk(job->mu);
-        if (!job->cv.wait_for(lk, std::chrono::duration<double>(timeout_s), [&] { return job->done; }))
+        if (!job->cv.wait_for(lk, std::chrono::duration<double>(timeout_s), [&] { return job->done; })) {
+            job->abandoned = true;
             return mhx_fail(MHX_EHIP, "mhx_comm_init: rank %d of %d (device %d): ncclCommInitRank did not return within %.0f s "
                             "(a rank that never arrived, a stale id, or a fabric that cannot connect the ranks)", rank, world, device, timeout_s);
+        }
     }
     if (job->dev != hipSuccess) return mhx_fail(MHX_EHIP, "mhx_comm_init: rank %d: hipSetDevice(%d): %s", rank, device, hipGetErrorString(job->dev));
     if (job->res != ncclSuccess)
@@ -179,8 +191,16 @@ extern "C" int mhx_comm_destroy(mhx_comm* c)
 {
     if (!c) return MHX_OK;
     (void)hipSetDevice(c->device);
+    if (c->poisoned) {
+        // a collective no peer joined is still on the stream: destroying the communicator or freeing what the queued copies
+        // touch would block or fault.  Abort what RCCL holds if it can, leave the small staging buffers to the process.
+        if (c->comm && g_rccl.ok && g_rccl.CommAbort) (void)g_rccl.CommAbort(c->comm);
+        delete c;
+        return MHX_OK;
+    }
     if (c->comm && g_rccl.ok) (void)g_rccl.CommDestroy(c->comm);
     if (c->d_buf) (void)hipFree(c->d_buf);
+    if (c->h_buf) (void)hipHostFree(c->h_buf);
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -214,16 +234,22 @@ extern "C" int mhx_comm_allreduce_sum(mhx_comm* c, double* inout, size_t n)
 {
     if (!c || (!inout && n)) return mhx_fail(MHX_EINVAL, "mhx_comm_allreduce_sum: NULL argument");
     if (!n) return MHX_OK;
+    if (c->poisoned)
+        return mhx_fail(MHX_ESTATE, "mhx_comm_allreduce_sum: rank %d of %d: an earlier collective on this communicator missed its deadline; "
+                        "destroy it and build a new one", c->rank, c->world);
     HIP_TRY(hipSetDevice(c->device));
     if (c->cap < n) {
         if (c->d_buf) (void)hipFree(c->d_buf);
-        c->d_buf = nullptr; c->cap = 0;
+        if (c->h_buf) (void)hipHostFree(c->h_buf);
+        c->d_buf = nullptr; c->h_buf = nullptr; c->cap = 0;
         HIP_TRY(hipMalloc(&c->d_buf, n * sizeof(double)));
+        HIP_TRY(hipHostMalloc((void**)&c->h_buf, n * sizeof(double), hipHostMallocDefault));
         c->cap = n;
     }
-    HIP_TRY(hipMemcpyAsync(c->d_buf, inout, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    memcpy(c->h_buf, inout, n * sizeof(double));
+    HIP_TRY(hipMemcpyAsync(c->d_buf, c->h_buf, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     RCCL_TRY(g_rccl.AllReduce(c->d_buf, c->d_buf, n, ncclDouble, ncclSum, c->comm, c->stream));
-    HIP_TRY(hipMemcpyAsync(inout, c->d_buf, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_buf, c->d_buf, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     // a collective a peer never joins does not fail, it waits: poll with a deadline instead of hipStreamSynchronize
     const auto t0 = std::chrono::steady_clock::now();
     for (long spins = 0;; ++spins) {
@@ -232,12 +258,15 @@ extern "C" int mhx_comm_allreduce_sum(mhx_comm* c, double* inout, size_t n)
         if (q != hipErrorNotReady) return mhx_fail(MHX_EHIP, "mhx_comm_allreduce_sum: %s", hipGetErrorString(q));
         if (spins > 2000) {
             const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            if (waited > c->op_timeout_s)
+            if (waited > c->op_timeout_s) {
+                c->poisoned = true;                       // the caller's array is untouched; the queued copy writes into h_buf
                 return mhx_fail(MHX_EHIP, "mhx_comm_allreduce_sum: rank %d of %d: the all-reduce of %zu doubles did not complete within %.0f s "
                                 "(a peer never joined it)", c->rank, c->world, n, c->op_timeout_s);
+            }
             std::this_thread::sleep_for(std::chrono::microseconds(50));
         }
     }
+    memcpy(inout, c->h_buf, n * sizeof(double));
     return MHX_OK;
 }
 
