@@ -690,9 +690,12 @@ MHX_DEV void mhx_normal4(const mhx_philox_key& ks, mhx_u32 id_lo, mhx_u32 id_hi,
 // ---------------------------------------------------------------------------------------------
 // The ZIGGURAT normal generator in fp32 (round 6; DESIGN.md section 3.11, fp32 form; the fp64 form is above): 256 equal-area layers,
 // table x[0..256] (mhx_zig_table.h: MHX_ZIG32_*), ONE 32-bit word per normal -- Philox block p of (id, step, stream) serves normals
-// 4p .. 4p+3 from its words x, y, z, w (the block a Box-Muller step spends on the same four normals):
-//   layer = bits 0..7;  sign = bit 31;  u = k 2^-23 in [0, 1) with the 23-bit k = bits 8..30 (the float 1 + u is 0x3f800000 | k);
-//   |x| = u x[layer];  accept at once when |x| < x[layer + 1]  (98.5 % of the draws);
+// 4p .. 4p+3 from its words x, y, z, w (the block a Box-Muller step spends on the same four normals).  The word, laid out so that
+// every field is used where it lies:
+//   k = bits 0..22: u = k 2^-23 in [0, 1), the float 1 + u is 0x3f800000 | k -- the mantissa in place, no shift;
+//   layer = bits 23..30;  sign = bit 31: the nine bits (w >> 23) index a table of SIGNED pairs (+-x[layer], x[layer + 1]), so the
+//   candidate x = u (+-x[layer]) comes out of one fma with its sign and the test |x| < x[layer + 1] (98.5 % of the draws pass) takes
+//   the magnitude as an operand modifier: and_or, shift, and, fma, compare per normal;
 // otherwise rejection attempts t = 1, 2, ... from Philox block (n << 8 | t) of stream | 4: layer 0: the tail beyond r -- xx =
 // -log(U(word x))/r, yy = -log(U(word z)), accept r + xx iff 2 yy >= xx^2; else the wedge -- accept x iff f1 + U(word z) (f0 - f1) < 1;
 // on rejection word x of the same block is the next candidate.  Inside the kernels the macros MHX_ZIG_N / _R / _NEG_RINV mean the
@@ -709,25 +712,40 @@ MHX_DEV void mhx_normal4(const mhx_philox_key& ks, mhx_u32 id_lo, mhx_u32 id_hi,
 #define MHX_ZIG_R MHX_ZIG32_R
 #define MHX_ZIG_NEG_RINV MHX_ZIG32_NEG_RINV
 __device__ const float mhx_zig_x[MHX_ZIG_N + 1] = MHX_ZIG32_TABLE;
+// The table as the kernels keep it in LDS: 2 x 256 pairs (sign s, layer l) -> { s ? -x[l] : x[l], x[l + 1] }, 8 bytes each, the pair of
+// a candidate at byte (w >> 20) & 0xff8.  Entry e of the flat float array:
+#define MHX_ZIG_PAIR_FLOATS (4 * MHX_ZIG_N)
+MHX_DEV float mhx_zig_pair_entry(const int e)
+{
+    const int l = (e >> 1) & (MHX_ZIG_N - 1);
+    return (e & 1) ? mhx_zig_x[l + 1] : ((e >> 1) >= MHX_ZIG_N ? -mhx_zig_x[l] : mhx_zig_x[l]);
+}
+// table access of the helpers below: TS = 1 the plain table x[0..N] (global memory), TS = 2 the positive half of the pair table (LDS)
+template <int TS> MHX_DEV float mhx_zig_lo(const float* __restrict__ zt, const mhx_u32 layer) { return zt[TS * layer]; }
+template <int TS> MHX_DEV float mhx_zig_hi(const float* __restrict__ zt, const mhx_u32 layer) { return zt[TS * layer + 1]; }
 
+MHX_DEV mhx_u32 mhx_zig_layer(const mhx_u32 w) { return (w >> 23) & (mhx_u32)(MHX_ZIG_N - 1); }
 // u x_l in ONE operation: with m = 1 + u (exact) the fma m x_l - x_l rounds u x_l once -- the rounded product of the spec
+// (x_l with either sign: the fma is odd in it)
 MHX_DEV float mhx_zig_ax(const mhx_u32 w, const float xl)
 {
-    return mhx_fma(mhx_u2f(0x3f800000u | ((w >> 8) & 0x7fffffu)), xl, -xl);
+    return mhx_fma(mhx_u2f(0x3f800000u | (w & 0x7fffffu)), xl, -xl);
 }
-// |x| with the candidate's sign (bit 31 of its word); `sign` = 0x80000000 from a scalar register (v_and_or_b32 takes no literal)
+// |x| with the candidate's sign (bit 31 of its word)
 MHX_DEV float mhx_zig_signed(const float ax, const mhx_u32 w, const mhx_u32 sign = 0x80000000u)
 {
     return mhx_u2f(mhx_f2u(ax) | (w & sign));
 }
+template <int TS>
 MHX_DEV bool mhx_zig_try(const float* __restrict__ zt, const mhx_u32 w, float& x, mhx_u32& layer)
 {
-    layer = w & (mhx_u32)(MHX_ZIG_N - 1);
-    const float ax = mhx_zig_ax(w, zt[layer]);
+    layer = mhx_zig_layer(w);
+    const float ax = mhx_zig_ax(w, mhx_zig_lo<TS>(zt, layer));
     x = mhx_zig_signed(ax, w);
-    return ax < zt[layer + 1];
+    return ax < mhx_zig_hi<TS>(zt, layer);
 }
 // the normal behind a candidate (x, layer) that left its rectangle: rejection attempts t0, t0 + 1, ...
+template <int TS>
 MHX_DEV float mhx_zig_slow(const mhx_philox_key& ks, const float* __restrict__ zt, const mhx_u32 id_lo, const mhx_u32 id_hi,
                            const mhx_u32 step, const mhx_u32 stream, const mhx_u32 n, float x, mhx_u32 layer, const mhx_u32 t0 = 1u)
 {
@@ -738,15 +756,16 @@ MHX_DEV float mhx_zig_slow(const mhx_philox_key& ks, const float* __restrict__ z
             const float yy = -mhx_log_pos(mhx_u01_open(v.z));
             if (yy + yy >= xx * xx) return mhx_u2f(mhx_f2u(MHX_ZIG_R + xx) | (mhx_f2u(x) & 0x80000000u));
         } else {
-            const float xl = zt[layer], xl1 = zt[layer + 1], xsq = x * x;
+            const float xl = mhx_zig_lo<TS>(zt, layer), xl1 = mhx_zig_hi<TS>(zt, layer), xsq = x * x;
             const float f0 = mhx_exp(-0.5f * (xl * xl - xsq)), f1 = mhx_exp(-0.5f * (xl1 * xl1 - xsq));
             if (mhx_fma(mhx_u01_half(v.z), f0 - f1, f1) < 1.0f) return x;
-            if (mhx_zig_try(zt, v.x, x, layer)) return x;
+            if (mhx_zig_try<TS>(zt, v.x, x, layer)) return x;
         }
     }
 }
-// the same normal laid out for latency (the fix-up pass): the failed candidate's block and the block of attempt 1 drawn together,
-// the table entries of both candidates fetched together, the common case -- a wedge settled by attempt 1 -- straight through
+// the same normal laid out for latency (the fix-up pass; zt = the pair table in LDS): the failed candidate's block and the block of
+// attempt 1 drawn together, the table entries of both candidates fetched together, the common case -- a wedge settled by attempt 1 --
+// straight through
 MHX_DEV float mhx_zig_refine(const mhx_philox_key& ks, const float* __restrict__ zt, const mhx_u32 id_lo, const mhx_u32 id_hi,
                              const mhx_u32 step, const mhx_u32 stream, const mhx_u32 n)
 {
@@ -754,21 +773,21 @@ MHX_DEV float mhx_zig_refine(const mhx_philox_key& ks, const float* __restrict__
     const mhx_u32x4 v = mhx_philox(ks, id_lo, id_hi, step, ((stream | MHX_STREAM_RETRY) << 28) | ((n << 8) | 1u));
     const mhx_u32 j = n & 3u;
     const mhx_u32 w = j == 0u ? w4.x : (j == 1u ? w4.y : (j == 2u ? w4.z : w4.w));
-    mhx_u32 layer = w & (mhx_u32)(MHX_ZIG_N - 1);
-    const mhx_u32 layer2 = v.x & (mhx_u32)(MHX_ZIG_N - 1);
-    const float xl = zt[layer], xl1 = zt[layer + 1];
-    const float xn = zt[layer2], xn1 = zt[layer2 + 1];
+    mhx_u32 layer = mhx_zig_layer(w);
+    const mhx_u32 layer2 = mhx_zig_layer(v.x);
+    const float xl = mhx_zig_lo<2>(zt, layer), xl1 = mhx_zig_hi<2>(zt, layer);
+    const float xn = mhx_zig_lo<2>(zt, layer2), xn1 = mhx_zig_hi<2>(zt, layer2);
     const float ax = mhx_zig_ax(w, xl);
     float x = mhx_zig_signed(ax, w);
     if (ax < xl1) return x;                                        // (not a failed candidate after all: callers only send failures)
-    if (layer == 0u) return mhx_zig_slow(ks, zt, id_lo, id_hi, step, stream, n, x, layer, 1u);
+    if (layer == 0u) return mhx_zig_slow<2>(ks, zt, id_lo, id_hi, step, stream, n, x, layer, 1u);
     const float xsq = x * x;
     const float f0 = mhx_exp(-0.5f * (xl * xl - xsq)), f1 = mhx_exp(-0.5f * (xl1 * xl1 - xsq));
     if (mhx_fma(mhx_u01_half(v.z), f0 - f1, f1) < 1.0f) return x;
     const float ax2 = mhx_zig_ax(v.x, xn);
     x = mhx_zig_signed(ax2, v.x);
     if (ax2 < xn1) return x;
-    return mhx_zig_slow(ks, zt, id_lo, id_hi, step, stream, n, x, layer2, 2u);
+    return mhx_zig_slow<2>(ks, zt, id_lo, id_hi, step, stream, n, x, layer2, 2u);
 }
 // normal number n (0-based) of (id, step, stream), straight from the table in global memory: the kernels off the hot path
 MHX_DEV float mhx_zig_normal(const mhx_philox_key& ks, const mhx_u32 id_lo, const mhx_u32 id_hi, const mhx_u32 step,
@@ -777,8 +796,8 @@ MHX_DEV float mhx_zig_normal(const mhx_philox_key& ks, const mhx_u32 id_lo, cons
     const mhx_u32x4 w4 = mhx_philox(ks, id_lo, id_hi, step, (stream << 28) | (n >> 2));
     const mhx_u32 j = n & 3u;
     float x; mhx_u32 layer;
-    if (mhx_zig_try(mhx_zig_x, j == 0u ? w4.x : (j == 1u ? w4.y : (j == 2u ? w4.z : w4.w)), x, layer)) return x;
-    return mhx_zig_slow(ks, mhx_zig_x, id_lo, id_hi, step, stream, n, x, layer);
+    if (mhx_zig_try<1>(mhx_zig_x, j == 0u ? w4.x : (j == 1u ? w4.y : (j == 2u ? w4.z : w4.w)), x, layer)) return x;
+    return mhx_zig_slow<1>(ks, mhx_zig_x, id_lo, id_hi, step, stream, n, x, layer);
 }
 // the 4 normals 4b..4b+3 by either generator (lane-per-chain kernels: initial draws, generic paths)
 MHX_DEV void mhx_normal4_gen(const int gen, const mhx_philox_key& ks, mhx_u32 id_lo, mhx_u32 id_hi, mhx_u32 step,

@@ -391,7 +391,7 @@ MHX_DEV void mhx_rwmh_whiten_body(const mhx_rwmh_args& a, const mhx_real* __rest
 #define MHX_WALK_STATIC 2
 // Dynamic LDS of the cooperative kernel with the ziggurat generator (GEN = MHX_GEN_ZIGGURAT), 256-thread blocks (sizes in the engine's
 // own width: fp64 1024 layers and 8-byte normals, fp32 -- round 6 -- 256 layers and 4-byte normals):
-//   [0, table bytes)                the layer table x[0..N]
+//   [0, table bytes)                the layer table: fp64 x[0..N]; fp32 the signed pairs (+-x[l], x[l + 1]) a candidate's nine top bits index
 //   then per wave  NBL*4*64 reals   the step's normals -- fp64: [pair of slots][lane][2], fp32: [block][lane][4]: a lane writes / reads
 //                                   16 bytes, conflict-free
 //                  64 u16           the queue of the candidates that left their rectangles: owner lane | slot << 6
@@ -400,7 +400,11 @@ MHX_DEV void mhx_rwmh_whiten_body(const mhx_rwmh_args& a, const mhx_real* __rest
 // the fix-up pass costs a wave what it costs whether it repairs 4 candidates or 40 (the queue, two wave syncs, one walk through the
 // rejection code), and at d = 1000 (a wave per chain, 16 slots per lane: 4 failures per wave-step) it was a third of the kernel.
 // KS is the largest group (<= 4) whose slabs leave the LDS for as many blocks per CU as the launch bound asks for.
+#if MHX_REAL64
 #define MHX_ZIG_TABLE_BYTES (((MHX_ZIG_N + 1) * (int)sizeof(mhx_real) + 15) / 16 * 16)
+#else
+#define MHX_ZIG_TABLE_BYTES (MHX_ZIG_PAIR_FLOATS * 4)       // the signed pair table (mhx_device_math.h): 2 x 256 x 8 bytes
+#endif
 #define MHX_ZIG_TABLE_BYTES_ANY MHX_ZIG_TABLE_BYTES
 #define MHX_ZIG_SLAB_BYTES(NBL) ((NBL) * 4 * 64 * (int)sizeof(mhx_real))
 #define MHX_ZIG_KS_FIT(NBL) ((163840 / MHX_COOP_WAVES(NBL) - MHX_ZIG_TABLE_BYTES - 512) / (4 * (MHX_ZIG_SLAB_BYTES(NBL) + 512 + 32)))
@@ -427,8 +431,10 @@ MHX_DEV void mhx_zig_fixup(const mhx_philox_key& ks, const mhx_real* __restrict_
                            unsigned short* __restrict__ zq, const mhx_u64* __restrict__ zfm, const int ng, const int slabd,
                            const int lane, const long wave,
                            const mhx_u64 first_chain, const int nchains, const mhx_u32 step0, const mhx_u32 stream,
-                           const bool fm_in_reg = false, const mhx_u64 fm_reg = 0ull)
+                           const bool fm_in_reg = false, const mhx_u64 fm_reg = 0ull, const int rev_top = -1)
 {
+    // rev_top >= 0 (the fp32 kernel's masks): bit p of a mask is slot 4 i + j with j = p >> 4, i = rev_top - (p & 15) -- four
+    // 16-bit fields, one per word of a Philox block, each shifted up by one per block; rev_top < 0: bit p is slot p
     constexpr int CPW = 64 / L;
     // Queue positions without a prefix sum over the lanes: round k takes the k-th failure of every lane that has one; the
     // lanes of a round are ranked by mbcnt over the round's ballot, the rounds follow each other in the queue.  (Nearly all
@@ -444,7 +450,8 @@ MHX_DEV void mhx_zig_fixup(const mhx_philox_key& ks, const mhx_real* __restrict_
                 if (m == 0ull) break;
                 if (f != 0ull) {
                     const int e = base + (int)__builtin_amdgcn_mbcnt_hi((mhx_u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((mhx_u32)m, 0u));
-                    const int sl = __ffsll((long long)f) - 1;
+                    const int p = __ffsll((long long)f) - 1;
+                    const int sl = rev_top < 0 ? p : 4 * (rev_top - (p & 15)) + (p >> 4);
                     if (e >= 0 && e < 64) zq[e] = (unsigned short)(lane | (sl << 6) | (s << 12));
                 }
                 f &= f - 1ull;
@@ -719,13 +726,17 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
     // the fp32 form (round 6): same layout in 4-byte reals -- table, then per wave the slab [block][lane][4], the queue, the masks
     typedef float mhx_f2v __attribute__((ext_vector_type(2)));
     typedef float mhx_f4v __attribute__((ext_vector_type(4)));
+    // a candidate's table pair is read at its LDS byte address itself -- the table opens the kernel's LDS (no static LDS in this
+    // kernel: checked below); through the generic pointer hipcc adds the array's base, a literal 0 it learns too late to fold
+    typedef const __attribute__((address_space(3))) mhx_f2v* mhx_lds_f2v;
     const float* zt = (const float*)mhx_coop_lds;
+    if (ZIG && (mhx_u32)(mhx_u64)mhx_coop_lds != 0u) __builtin_trap();
     constexpr int SLABD = NBL * 4 * 64;                            // floats of one step's normals
     float* zn0 = (float*)((char*)mhx_coop_lds + MHX_ZIG_TABLE_BYTES + (threadIdx.x >> 6) * MHX_ZIG_WAVE_BYTES(NBL));
     unsigned short* zq = (unsigned short*)(zn0 + KS * SLABD);
     mhx_u64* zfm = (mhx_u64*)((char*)(zn0 + KS * SLABD) + 128);
     if (ZIG) {
-        for (int e = threadIdx.x; e <= MHX_ZIG_N; e += blockDim.x) ((float*)mhx_coop_lds)[e] = mhx_zig_x[e];
+        for (int e = threadIdx.x; e < MHX_ZIG_PAIR_FLOATS; e += blockDim.x) ((float*)mhx_coop_lds)[e] = mhx_zig_pair_entry(e);
         __syncthreads();
     }
 #endif
@@ -1000,15 +1011,23 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
     }
 #else
     if (ZIG) {
-        // the fp32 form of the same three phases: ONE Philox call per block of four normals (a word each), the table pair of a
-        // candidate as one ds_read2_b32, the block's four normals to the slab as one 16-byte write
+        // the fp32 form of the same three phases: ONE Philox call per block of four normals (a word each); a candidate's nine top bits
+        // fetch its signed table pair as one 8-byte read, its mantissa is used where it lies, the sign comes with the table entry and
+        // the compare's carry is shifted into the mask of failures by one add-with-carry: and_or, shift, and, fma, compare, addc per
+        // normal (9 before the word was laid out for it); the block's four normals go to the slab as one 16-byte write.
+        // Masks: one 32-bit word per word j of the Philox blocks, block i at bit NBL - 1 - i (mhx_zig_fixup: rev_top).
+        static_assert(NBL <= 16, "a 16-bit field of failure bits per Philox word");
         bool anyfail = false;
         mhx_u64 fm1 = 0ull;
+        mhx_u64 pad_ok = ~0ull;                                     // padding dimensions past the end of the vector need no normal
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (k_last + j >= d) pad_ok &= ~(1ull << (16 * j));
 #pragma unroll 1
         for (int sg = 0; sg < ng; ++sg) {
             const mhx_u32 step = a.step0 + (mhx_u32)(it0 + sg);
             float* const zn = zn0 + sg * SLABD;
-            mhx_u64 fm = 0ull;
+            mhx_u32 m4[4] = {0u, 0u, 0u, 0u};
             mhx_u32 kw[4];
             auto draw = [&](const int i, mhx_u32 (&w)[4]) {
                 if (i < NBL) {
@@ -1019,16 +1038,11 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
                 }
             };
             draw(0, kw);
-            mhx_u32 zsign = 0x80000000u;                            // (opaque: see mhx_zig_signed)
-            asm volatile("" : "+s"(zsign));
 #pragma unroll
             for (int i = 0; i < NBL; ++i) {
-                mhx_f2v xe[4];                                      // x[layer], x[layer + 1] of the block's candidates
+                mhx_f2v xe[4];                                      // +-x[layer], x[layer + 1] of the block's candidates
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const mhx_u32 ly = kw[e] & (mhx_u32)(MHX_ZIG_N - 1);
-                    xe[e].x = zt[ly]; xe[e].y = zt[ly + 1];
-                }
+                for (int e = 0; e < 4; ++e) xe[e] = *(mhx_lds_f2v)((kw[e] >> 20) & 0xff8u);     // (LDS byte address: the table is at 0)
                 __builtin_amdgcn_sched_barrier(0);
                 mhx_u32 nw[4];
                 if (i + 1 < NBL) draw(i + 1, nw);                   // the next block's Philox rounds run while the look-ups are in flight
@@ -1037,16 +1051,16 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
                 float nn[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float ax = mhx_zig_ax(kw[j], xe[j].x);
-                    nn[j] = mhx_zig_signed(ax, kw[j], zsign);
-                    bool fail = !(ax < xe[j].y);
+                    nn[j] = mhx_zig_ax(kw[j], xe[j].x);             // signed: the table entry carries the sign
+                    // (the compare's carry shifted in: `m = m + m + vcc`)
+#define MHX_ZIG_NOTE(m, x, hi) asm("v_cmp_nlt_f32 vcc, |%1|, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(x), "v"(hi) : "vcc")
 #ifdef MHX_TOOLS_BUILD
 #ifdef MHX_ZIG_FORCE_FAIL
-                    fail = fail || ((4 * i + j + lane) % (MHX_ZIG_FORCE_FAIL) == 0);
+#undef MHX_ZIG_NOTE
+#define MHX_ZIG_NOTE(m, x, hi) m = ((m) << 1) | ((!(__builtin_fabsf(x) < (hi)) || ((4 * i + j + lane) % (MHX_ZIG_FORCE_FAIL) == 0)) ? 1u : 0u)
 #endif
 #endif
-                    if (i == NBL - 1) fail = fail && (k_last + j < d);   // padding dimensions past the end of the vector need no normal
-                    fm |= (fail ? 1ull : 0ull) << (4 * i + j);
+                    MHX_ZIG_NOTE(m4[j], nn[j], xe[j].y);
                 }
                 v4.x = nn[0]; v4.y = nn[1]; v4.z = nn[2]; v4.w = nn[3];
                 *(mhx_f4v*)(zn + ((i * 64 + lane) << 2)) = v4;
@@ -1055,6 +1069,7 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
                     for (int e = 0; e < 4; ++e) kw[e] = nw[e];
                 }
             }
+            const mhx_u64 fm = ((mhx_u64)(m4[0] | (m4[1] << 16)) | ((mhx_u64)(m4[2] | (m4[3] << 16)) << 32)) & pad_ok;
             if (KS > 1) zfm[sg * 64 + lane] = fm;
             fm1 = fm;
             anyfail = anyfail || fm != 0ull;
@@ -1068,7 +1083,7 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
         if (__ballot(anyfail))
 #endif
             mhx_zig_fixup<L>(ks, zt, zn0, zq, zfm, ng, SLABD, lane, wave, a.first_chain, a.nchains, a.step0 + (mhx_u32)it0, MHX_STREAM_PROPOSAL,
-                             KS == 1, fm1);
+                             KS == 1, fm1, NBL - 1);
     }
 #endif
 #pragma unroll 1

@@ -412,8 +412,9 @@ double orc_zig_normal(uint64_t seed, uint64_t chain, uint32_t step, uint32_t str
 
 #if !ORC_F64
 /* The fp32 ziggurat (round 6; spec 3.11, fp32 form): MHX_ZIG32_N = 256 layers, ONE 32-bit word per normal -- Philox block p of
- * (chain, step, stream) serves normals 4p .. 4p+3 from its words 0 .. 3; layer = bits 0..7, sign = bit 31, u = k 2^-23 with the 23-bit
- * k = bits 8..30, |x| = u x[layer], accepted at once iff |x| < x[layer+1] (98.5 %); otherwise rejection attempts t = 1, 2, ... from block
+ * (chain, step, stream) serves normals 4p .. 4p+3 from its words 0 .. 3; u = k 2^-23 with the 23-bit k = bits 0..22 (a float's
+ * mantissa where it lies), layer = bits 23..30, sign = bit 31, |x| = u x[layer], accepted at once iff |x| < x[layer+1] (98.5 %);
+ * otherwise rejection attempts t = 1, 2, ... from block
  * (n << 8 | t) of stream | 4: layer 0 = the tail beyond r (uniforms from words 0 and 2), else the wedge test (uniform from word 2)
  * with the next candidate from word 0 of the same block on rejection. */
 #include "mhx_zig_table.h"
@@ -421,8 +422,8 @@ static const float zig_x[MHX_ZIG32_N + 1] = MHX_ZIG32_TABLE;
 
 static int zig_try(uint32_t w, float *x, uint32_t *layer)
 {
-    *layer = w & (uint32_t)(MHX_ZIG32_N - 1);                          /* bits 0..7 */
-    const float u = (float)((w >> 8) & 0x7fffffu) * 0x1p-23f;           /* [0, 1), exact */
+    *layer = (w >> 23) & (uint32_t)(MHX_ZIG32_N - 1);                  /* bits 23..30 */
+    const float u = (float)(w & 0x7fffffu) * 0x1p-23f;                  /* bits 0..22: [0, 1), exact */
     const float ax = u * zig_x[*layer];
     *x = (w >> 31) ? -ax : ax;                                          /* bit 31 is the sign */
     return ax < zig_x[*layer + 1];
