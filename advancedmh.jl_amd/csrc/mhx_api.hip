@@ -252,7 +252,7 @@ int api_ctx_device(const mhx_ctx* ctx) { return ctx->device; }
 // taint the context; the release library does not even carry their names.
 struct opt_name { const char* name; int probe; };
 static const opt_name k_opt_names[] = {
-    {"NO_PREBUILT", 0}, {"NO_MFMA", 0}, {"MFMA_WAVES", 0}, {"REG_MAX_DIM", 0}, {"REG_XR", 0}, {"REG_UNROLL", 0}, {"COOP_WAVES", 0},
+    {"NO_PREBUILT", 0}, {"NO_MFMA", 0}, {"MFMA_WAVES", 0}, {"REG_MAX_DIM", 0}, {"REG_XR", 0}, {"REG_UNROLL", 0}, {"REG_WAVES", 0}, {"REG_ZSLAB", 0}, {"COOP_WAVES", 0},
     {"MALA_XR", 0}, {"RAM_G", 0}, {"RAM_LDS_PAD", 0}, {"WAVE_K", 0},
     {"EMCEE_MFMA", 0}, {"EMCEE_MFMA_WAVES", 0}, {"EMCEE_SCALAR", 0}, {"EMCEE_SCAL_MODE", 0}, {"EMCEE_SCAL_WPB", 0}, {"EMCEE_SCAL_REC", 0},
     {"EMCEE_FUSED", 0}, {"EMCEE_PERSIST", 0}, {"EMCEE_PRELOAD", 0}, {"EMCEE_DEFER", 0}, {"EMCEE_SWEEP_DEFER", 0}, {"EMCEE_WAVES", 0},
@@ -991,8 +991,8 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
     // ---- kernel choice
     r->variant = 0;
     const int tk = t->kind, pk = r->prop_kind;
-    // (fp32, round 6: the ziggurat exists on the cooperative kernel -- 256 layers, one Philox word per normal; the register kernel's form
-    // and MALA's are fp64: the check at the end of this function refuses a run whose kernel has no ziggurat form)
+    // (fp32, round 6: 256 layers, one Philox word per normal -- on the cooperative kernel, the register kernel and MALA's register kernel
+    // like fp64; the check at the end of this function refuses a run whose kernel has no ziggurat form)
     if ((cfg->flags & MHX_FLAG_ZIGGURAT) && d >= (1 << 20))      // the retry blocks are numbered (normal index << 8 | attempt) in 28 bits
         return mhx_fail(MHX_EINVAL, "MHX_FLAG_ZIGGURAT: dim must be below 2^20");
     int regmax = pk == MHX_PROP_DENSE ? MHX_REG_MAX_DIM_DENSE : MHX_REG_MAX_DIM;
@@ -1228,21 +1228,29 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
             const char* ut = opt(ctx, "REG_UNROLL");
             std::vector<std::string> xo;
             if (!ut || atoi(ut) > 0) xo = {"-mllvm", std::string("-amdgpu-unroll-threshold-private=") + (ut ? ut : "100000")};
-            // MHX_FLAG_ZIGGURAT (fp64, ISO / DIAG proposal): the register kernel's ziggurat form (mhx_rwmh_reg_zig_body) -- any target,
+            // MHX_FLAG_ZIGGURAT (ISO / DIAG proposal; both widths since round 6): the register kernel's ziggurat form (mhx_rwmh_reg_zig_body) -- any target,
             // a user's HIP source included
-            const bool zig_reg = MHX_REAL64 && (cfg->flags & MHX_FLAG_ZIGGURAT) && pk != MHX_PROP_DENSE;
+            const bool zig_reg = (cfg->flags & MHX_FLAG_ZIGGURAT) && pk != MHX_PROP_DENSE;
+            // waves per SIMD the kernel's register budget is cut for (REG_WAVES; measured on the fp32 ziggurat form: no gain from 2)
+            int rwaves = 1;
+            if (const char* we = opt(ctx, "REG_WAVES")) rwaves = std::max(1, std::min(4, atoi(we)));
+            // fp32: the step's normals through an LDS slab instead of the hand-back walk, where four one-wave blocks of it fit a CU
+            // (option REG_ZSLAB = 0 / 1 overrides)
+            bool zslab = !MHX_REAL64 && zig_reg && 4 * (MHX_REG_ZIG_LDS_BYTES(d, xr) + MHX_REG_ZIG_SLAB_BYTES(d)) <= 163840;
+            if (const char* ze = opt(ctx, "REG_ZSLAB")) zslab = !MHX_REAL64 && zig_reg && atoi(ze) != 0;
             const std::string key = "rwmh_reg/d=" + std::to_string(d) + "/tk=" + std::to_string(tk) + "/pk=" +
                                     std::to_string(pk) + "/xr=" + std::to_string(xr) + (ut ? std::string("/ut=") + ut : std::string()) +
-                                    (zig_reg ? "/gen=1" : "") + "/" + t->user_key;
+                                    (zig_reg ? "/gen=1" : "") + (zslab ? "/slab" : "") + (rwaves > 1 ? "/w=" + std::to_string(rwaves) : std::string()) +
+                                    "/" + t->user_key;
             std::vector<std::string> rdefs = {"MHX_JIT_RWMH_REG=1", "MHX_JIT_DIM=" + std::to_string(d),
                                               "MHX_JIT_TK=" + std::to_string(tk), "MHX_JIT_PK=" + std::to_string(pk), "MHX_JIT_XR=" + std::to_string(xr)};
             if (zig_reg) rdefs.push_back("MHX_JIT_GEN=1");
+            if (zslab) rdefs.push_back("MHX_JIT_ZSLAB=1");
+            if (rwaves > 1) rdefs.push_back("MHX_JIT_REG_WAVES=" + std::to_string(rwaves));
             rc = jit_compile(ctx, key, jit_source(t, "mhx_rwmh_kernels.h"), rdefs, &m, xo);
             if (rc == MHX_OK) rc = jit_function(m, "mhx_jit_rwmh_reg", &r->jit_step);
             r->reg_lds = (size_t)(d - xr) * 64 * sizeof(mhx_real);
-#if MHX_REAL64
-            if (zig_reg) r->reg_lds = MHX_REG_ZIG_LDS_BYTES(d, xr);
-#endif
+            if (zig_reg) r->reg_lds = MHX_REG_ZIG_LDS_BYTES(d, xr) + (zslab ? MHX_REG_ZIG_SLAB_BYTES(d) : 0);
             if (rc == MHX_OK && r->reg_lds > 65536 &&
                 hipFuncSetAttribute((const void*)r->jit_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->reg_lds) != hipSuccess)
                 rc = mhx_fail(MHX_EHIP, "register kernel: %zu bytes of LDS refused", r->reg_lds);
@@ -1259,8 +1267,8 @@ int api_rwmh_create(mhx_ctx* ctx, const mhx_target* t, const mhx_rwmh_cfg* cfg, 
     }
     if ((cfg->flags & MHX_FLAG_ZIGGURAT) && r->normal_gen != MHX_GEN_ZIGGURAT)
         return mhx_fail(MHX_EINVAL, "MHX_FLAG_ZIGGURAT: this run's kernel (variant %d) has no ziggurat form -- it exists on the cooperative "
-                                    "kernel (separable catalogue target; fp64 and fp32) and on the register kernel (any target within its "
-                                    "dimension limit; fp64), ISO / DIAG proposal, JIT allowed", r->variant);
+                                    "kernel (separable catalogue target) and on the register kernel (any target within its "
+                                    "dimension limit), ISO / DIAG proposal, JIT allowed", r->variant);
     // candidate scratch of the state-in-HBM kernel; a static proposal whitens the state into it whatever kernel steps the chain
     if (r->variant == 0 || r->d_qx) HIP_TRY(hipMalloc(&r->d_ybuf, (size_t)d * (size_t)r->n * sizeof(mhx_real)));
     *out = r.release();

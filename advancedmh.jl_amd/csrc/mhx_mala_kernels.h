@@ -12,7 +12,7 @@
 // Compile-time dimension (hiprtc, d <= 48): all five vectors are registers (mhx_mala_reg_body).
 #pragma once
 #include "mhx_targets.h"
-#include "mhx_rwmh_kernels.h"      // mhx_reg_zig_fill: the register-array ziggurat of MHX_FLAG_ZIGGURAT (fp64)
+#include "mhx_rwmh_kernels.h"      // mhx_reg_zig_fill: the register-array ziggurat of MHX_FLAG_ZIGGURAT
 
 MHX_NS_BEGIN
 
@@ -460,7 +460,7 @@ struct mhx_reg_rw {
 // state, its gradient and the step's noise are touched once per step each -- their first XR coordinates stay in registers, the tails
 // live in the block's LDS as [3][D - XR][lane] (one wave per block).  Carries the kernel from d = 24 / 48 (fp64 / fp32) to 64 / 128;
 // the run-time-dimension kernel it replaces there is 10-20 x slower (tools/bench_mala_user.py).  Same arithmetic, same chains.
-// ZIG (round 5, fp64; MHX_FLAG_ZIGGURAT on a MALA run): the step's noise by the table ziggurat instead of Box-Muller -- the same
+// ZIG (round 5; fp32 since round 6; MHX_FLAG_ZIGGURAT on a MALA run): the step's noise by the table ziggurat instead of Box-Muller -- the same
 // register-array fill as the RWMH register kernel's (mhx_reg_zig_fill: fast path into the candidate's registers, the wave-step's
 // failures queued, refined side by side, handed back), so every lane of the one-wave block stays alive (idle lanes shadow the last
 // chain, stores guarded) and `zlds` holds [layer table][queue][results] in front of the tails.  The oracle's orc_mala(normal_gen = 1).
@@ -468,7 +468,6 @@ template <int D, int TK, int XR = D, bool ZIG = false>
 MHX_DEV void mhx_mala_reg_body(const mhx_mala_args& a, const mhx_real* __restrict__ tparams, mhx_real* tails = nullptr,
                                double* zlds = nullptr)
 {
-    static_assert(!ZIG || MHX_REAL64, "the ziggurat generator exists in the fp64 engine only");
     const int c_raw = blockIdx.x * blockDim.x + threadIdx.x;
     constexpr int NT = D - XR;                                       // coordinates per vector in LDS
     mhx_real* xl = tails + threadIdx.x;                              // [NT][64], then g, then z
@@ -477,17 +476,20 @@ MHX_DEV void mhx_mala_reg_body(const mhx_mala_args& a, const mhx_real* __restric
     const bool valid = c_raw < a.nchains;
     if (!ZIG && !valid) return;
     const int c = valid ? c_raw : a.nchains - 1;                     // (ZIG: the queue and the hand-back are wave-wide)
-#if MHX_REAL64
-    [[maybe_unused]] const double* zt = zlds;
-    [[maybe_unused]] unsigned short* zq = (unsigned short*)(zlds + MHX_ZIG_TABLE_BYTES / 8);
-    [[maybe_unused]] double* zres = zlds + MHX_ZIG_TABLE_BYTES / 8 + 16;
+    [[maybe_unused]] mhx_real* const zt = (mhx_real*)zlds;
+    [[maybe_unused]] unsigned short* zq = (unsigned short*)((char*)zlds + MHX_ZIG_TABLE_BYTES);
+    [[maybe_unused]] mhx_real* zres = (mhx_real*)((char*)zlds + MHX_ZIG_TABLE_BYTES + 128);
     [[maybe_unused]] mhx_u32 zsign = 0x80000000u;
     if constexpr (ZIG) {
-        for (int e = (int)threadIdx.x; e <= MHX_ZIG_N; e += 64) zlds[e] = mhx_zig_x[e];
+#if MHX_REAL64
+        for (int e = (int)threadIdx.x; e <= MHX_ZIG_N; e += 64) zt[e] = mhx_zig_x[e];
+#else
+        if ((mhx_u32)(mhx_u64)zlds != 0u) __builtin_trap();       // (MHX_ZIG_PAIR_OF addresses the table at LDS byte 0)
+        for (int e = (int)threadIdx.x; e < MHX_ZIG_PAIR_FLOATS; e += 64) zt[e] = mhx_zig_pair_entry(e);
+#endif
         __syncthreads();
         asm volatile("" : "+s"(zsign));
     }
-#endif
     const mhx_u64 id = a.first_chain + (mhx_u64)c;
     const mhx_u32 id_lo = (mhx_u32)id, id_hi = (mhx_u32)(id >> 32);
     const mhx_philox_key ks = mhx_philox_schedule(a.seed);
@@ -518,7 +520,6 @@ MHX_DEV void mhx_mala_reg_body(const mhx_mala_args& a, const mhx_real* __restric
     for (int it = 0; it < a.nsteps; ++it) {
         const mhx_u32 step = a.step0 + (mhx_u32)it;
         mhx_real fwd = MHX_R(0.0);
-#if MHX_REAL64
         if constexpr (ZIG) {
             mhx_reg_zig_fill<D>(y, ks, id_lo, id_hi, step, MHX_STREAM_PROPOSAL, zt, zq, zres, (int)threadIdx.x, (long)blockIdx.x * 64,
                                 a.first_chain, a.nchains, zsign);
@@ -530,7 +531,6 @@ MHX_DEV void mhx_mala_reg_body(const mhx_mala_args& a, const mhx_real* __restric
                 fwd = mhx_fma(nk, nk, fwd);
             }
         } else
-#endif
         {
 #pragma unroll
         for (int b = 0; b < nblk; ++b) {
@@ -593,7 +593,7 @@ MHX_DEV void mhx_mala_reg_body(const mhx_mala_args& a, const mhx_real* __restric
         atomicAdd(a.acc_total, (mhx_u64)wave_acc);
 }
 
-#define MHX_MALA_ZIG_LDS_BYTES(D, XR) ((size_t)3 * ((D) - (XR)) * 64 * 8 + MHX_ZIG_TABLE_BYTES_ANY + 128 + 512)
+#define MHX_MALA_ZIG_LDS_BYTES(D, XR) ((size_t)3 * ((D) - (XR)) * 64 * sizeof(mhx_real) + MHX_REG_ZIG_HDR_BYTES)
 
 // initial GradientTransition (src/MALA.jl:38-40): lp and gradient at the given initial_params
 template <int TK>
@@ -628,7 +628,7 @@ mhx_jit_mala_split(const mhx_mala_args a, const mhx_real* __restrict__ tparams)
     mhx_mala_reg_body<MHX_JIT_DIM, MHX_JIT_TK, MHX_JIT_XR>(a, tparams, mhx_mala_tails);
 }
 #endif
-#if MHX_REAL64 && defined(MHX_JIT_GEN) && MHX_JIT_GEN == 1 && MHX_JIT_DIM > 0
+#if defined(MHX_JIT_GEN) && MHX_JIT_GEN == 1 && MHX_JIT_DIM > 0
 // MHX_FLAG_ZIGGURAT: the register kernel with the ziggurat noise, one wave per block; LDS = [table][queue][results][tails]
 #ifndef MHX_JIT_XR
 #define MHX_JIT_XR MHX_JIT_DIM
@@ -637,7 +637,7 @@ extern "C" __global__ void __launch_bounds__(64)
 mhx_jit_mala_zig(const mhx_mala_args a, const mhx_real* __restrict__ tparams)
 {
     extern __shared__ double mhx_mala_zig_lds[];               // MHX_MALA_ZIG_LDS_BYTES(MHX_JIT_DIM, MHX_JIT_XR)
-    mhx_mala_reg_body<MHX_JIT_DIM, MHX_JIT_TK, MHX_JIT_XR, true>(a, tparams, mhx_mala_zig_lds + MHX_ZIG_TABLE_BYTES / 8 + 16 + 64, mhx_mala_zig_lds);
+    mhx_mala_reg_body<MHX_JIT_DIM, MHX_JIT_TK, MHX_JIT_XR, true>(a, tparams, (mhx_real*)((char*)mhx_mala_zig_lds + MHX_REG_ZIG_HDR_BYTES), mhx_mala_zig_lds);
 }
 #endif
 extern "C" __global__ void __launch_bounds__(256)

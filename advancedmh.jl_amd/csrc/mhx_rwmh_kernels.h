@@ -418,6 +418,24 @@ MHX_DEV void mhx_rwmh_whiten_body(const mhx_rwmh_args& a, const mhx_real* __rest
 #define MHX_ZIG_SLAB_AT(sl, ln) (((((sl) >> 2) * 64 + (ln)) << 2) + ((sl) & 3))
 #endif
 
+#if !MHX_REAL64
+// fp32: "candidate x left its rectangle" noted by shifting the compare's carry into a mask word: `m = m + m + (|x| >= hi)` -- two
+// instructions (compare with the magnitude as an operand modifier, add-with-carry); the bit of the FIRST candidate noted ends up highest
+#define MHX_ZIG_NOTE(m, x, hi, slot) asm("v_cmp_nlt_f32 vcc, |%1|, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(x), "v"(hi) : "vcc")
+#ifdef MHX_TOOLS_BUILD
+#ifdef MHX_ZIG_FORCE_FAIL
+#undef MHX_ZIG_NOTE
+#define MHX_ZIG_NOTE(m, x, hi, slot) m = ((m) << 1) | ((!(__builtin_fabsf(x) < (hi)) || (((slot) + lane) % (MHX_ZIG_FORCE_FAIL) == 0)) ? 1u : 0u)
+#endif
+#endif
+// a candidate's table pair read at its LDS byte address itself: the signed pair table OPENS the kernel's LDS (no static LDS in the
+// kernels that use it; each checks).  Through a generic pointer hipcc adds the array's base, a literal 0 it learns too late to fold.
+typedef float mhx_f2v __attribute__((ext_vector_type(2)));
+typedef float mhx_f4v __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) mhx_f2v* mhx_lds_f2v;
+#define MHX_ZIG_PAIR_OF(w) (*(mhx_lds_f2v)(((w) >> 20) & 0xff8u))
+#endif
+
 // The candidates of this wave-step that left their rectangles (0.4 % of the draws: a dozen per wave-step at d = 100), gathered
 // from all lanes into one queue and finished by as many lanes side by side -- ONE pass of the slow path per wave-step instead of
 // one per failing block.  fm: the lane's failed slots (slot s = 4 i + j at bit s).  A fixer lane re-derives the failed candidate from
@@ -477,22 +495,29 @@ MHX_DEV void mhx_zig_fixup(const mhx_philox_key& ks, const mhx_real* __restrict_
     }
 }
 
-#if MHX_REAL64
 // The D standard normals of (chain, step, stream) by the table ziggurat into a lane's REGISTER array y (lane per chain, every lane of
 // the wave alive): phase A writes every fast-path normal into y[n] and notes the failures in a per-lane bit mask; the failures of
 // the whole wave-step are queued, refined side by side by as many lanes (which leave the values in LDS by queue position), and every
 // owner walks its failures once more and takes the round's value where the slot number says so.  Used by the register kernels of
-// RWMH (mhx_rwmh_reg_zig_body) and MALA (mhx_mala_reg_body<.., ZIG>): the normals of mhx_zig_normal / orc_zig_normal.
+// RWMH (mhx_rwmh_reg_zig_body) and MALA (mhx_mala_reg_body<.., ZIG>): the normals of mhx_zig_normal / orc_zig_normal.  Both widths
+// (fp32 since round 6: a Philox block serves four normals, the signed pair table, failures noted by add-with-carry).
 // zt: the layer table in LDS (offset 0), zq: 64 queue entries, zres: 64 refined values; chain_base: the chain of lane 0.
-template <int D>
-MHX_DEV void mhx_reg_zig_fill(double (&y)[D], const mhx_philox_key& ks, const mhx_u32 id_lo, const mhx_u32 id_hi, const mhx_u32 step,
-                              const mhx_u32 stream, const double* __restrict__ zt, unsigned short* __restrict__ zq,
-                              double* __restrict__ zres, const int lane, const long chain_base, const mhx_u64 first_chain,
-                              const int nchains, const mhx_u32 zsign)
+#define MHX_REG_ZIG_HDR_BYTES (MHX_ZIG_TABLE_BYTES + 128 + 64 * (int)sizeof(mhx_real))      // [table][queue][results]
+// SLAB (fp32, where the LDS has room for [blocks][64][4] floats per wave): the step's normals meet in a slab as in the cooperative
+// kernel -- the fast path writes a Philox block's four normals as one 16-byte store, a refined value is dropped into its owner's
+// place, and the lane reads its column back when the queue is empty -- instead of the hand-back walk (compare + select per register
+// and round: at fp32's failure rate, 1.5 % of 6 400 candidates = two queue windows of five rounds, it cost more than the fast path).
+#define MHX_REG_ZIG_SLAB_BYTES(D) ((size_t)(((D) + 3) / 4) * 64 * 4 * sizeof(mhx_real))
+template <int D, bool SLAB = false>
+MHX_DEV void mhx_reg_zig_fill(mhx_real (&y)[D], const mhx_philox_key& ks, const mhx_u32 id_lo, const mhx_u32 id_hi, const mhx_u32 step,
+                              const mhx_u32 stream, const mhx_real* __restrict__ zt, unsigned short* __restrict__ zq,
+                              mhx_real* __restrict__ zres, const int lane, const long chain_base, const mhx_u64 first_chain,
+                              const int nchains, const mhx_u32 zsign, mhx_real* __restrict__ zslab = nullptr)
 {
+    static_assert(!SLAB || !MHX_REAL64, "the slab form is fp32's");
     constexpr int NW = (D + 63) / 64;                          // words of the failure mask
-    // ---- phase A: normal n of the step from Philox block n >> 1 (words x, y / z, w), fast path; failures noted
-    // (the chain id behind an empty asm: otherwise hipcc hoists the id-only first round and a half of all D / 2 Philox calls out
+    // ---- phase A: the fast path; failures noted
+    // (the chain id behind an empty asm: otherwise hipcc hoists the id-only first round and a half of all Philox calls out
     // of the step loop -- 150 registers it does not have: they go to scratch memory and come back every step)
     mhx_u32 idl = id_lo, idh = id_hi;
     asm volatile("" : "+v"(idl), "+v"(idh));
@@ -502,6 +527,8 @@ MHX_DEV void mhx_reg_zig_fill(double (&y)[D], const mhx_philox_key& ks, const mh
     // Software pipeline over the Philox blocks: the table look-ups of block p are in flight while the rounds of block p + 1 run
     // (one wave per SIMD has nothing else to hide an LDS round trip behind; straight after each other the look-ups cost a
     // quarter of the kernel: 100 x ~100 cycles per wave-step)
+#if MHX_REAL64
+    // normal n of the step from Philox block n >> 1 (words x, y / z, w)
     constexpr int NP = (D + 1) / 2;
     mhx_u32x4 w4 = mhx_philox(ks, idl, idh, step, (stream << 28) | 0u);
 #pragma unroll
@@ -530,6 +557,48 @@ MHX_DEV void mhx_reg_zig_fill(double (&y)[D], const mhx_philox_key& ks, const mh
         }
         w4 = wn;
     }
+#else
+    // normal n of the step from word n & 3 of Philox block n >> 2; 32 consecutive slots share a mask word (first slot highest)
+    constexpr int NP = (D + 3) / 4, NM = (D + 31) / 32;
+    mhx_u32 m32[NM];
+#pragma unroll
+    for (int w = 0; w < NM; ++w) m32[w] = 0u;
+    mhx_u32x4 w4 = mhx_philox(ks, idl, idh, step, (stream << 28) | 0u);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const mhx_u32 kw[4] = {w4.x, w4.y, w4.z, w4.w};
+        mhx_f2v xe[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xe[e] = MHX_ZIG_PAIR_OF(kw[e]);
+        __builtin_amdgcn_sched_barrier(0);
+        mhx_u32x4 wn = w4;
+        if (p + 1 < NP) wn = mhx_philox(ks, idl, idh, step, (stream << 28) | (mhx_u32)(p + 1));
+        __builtin_amdgcn_sched_barrier(0);
+        float nn[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = 4 * p + j;
+            if (n < D) {
+                nn[j] = mhx_zig_ax(kw[j], xe[j].x);            // signed: the table entry carries the sign
+                MHX_ZIG_NOTE(m32[n >> 5], nn[j], xe[j].y, n);
+                if (!SLAB) y[n] = nn[j];
+            }
+        }
+        if (SLAB) {
+            mhx_f4v v4;
+            v4.x = nn[0]; v4.y = nn[1]; v4.z = nn[2]; v4.w = nn[3];
+            *(mhx_f4v*)(zslab + ((p * 64 + lane) << 2)) = v4;
+        }
+        w4 = wn;
+    }
+#pragma unroll
+    for (int w = 0; w < NM; ++w) {                             // slot n at bit n & 63 of word n >> 6, as the walks below expect
+        const int cnt = D - 32 * w < 32 ? D - 32 * w : 32;
+        const mhx_u32 nat = __builtin_bitreverse32(m32[w]) >> (32 - cnt);
+        fmw[w >> 1] |= (mhx_u64)nat << (32 * (w & 1));
+    }
+    (void)zsign;
+#endif
     // ---- the wave-step's failures: queue, refine side by side, hand back
     bool anyfail = false;
 #pragma unroll
@@ -557,13 +626,19 @@ MHX_DEV void mhx_reg_zig_fill(double (&y)[D], const mhx_philox_key& ks, const mh
             MHX_WAVE_SYNC();
             const int nent = total - win < 64 ? total - win : 64;
             mhx_u32 ent = 0u;
-            double val = 0.0;
+            mhx_real val = MHX_R(0.0);
             if (lane < nent) {
                 ent = zq[lane];
                 const int ol = (int)(ent & 63u);
                 const long oc_raw = chain_base + ol;
                 const mhx_u64 oid = first_chain + (mhx_u64)(oc_raw < nchains ? oc_raw : (long)nchains - 1);
                 val = mhx_zig_refine(ks, zt, (mhx_u32)oid, (mhx_u32)(oid >> 32), step, stream, ent >> 6);
+            }
+            if (SLAB) {
+                // into the owner's place of the slab; the next window (if any) rewrites the queue
+                if (lane < nent) zslab[((((ent >> 6) >> 2) * 64 + (ent & 63u)) << 2) + ((ent >> 6) & 3u)] = val;
+                MHX_WAVE_SYNC();
+                continue;
             }
             if (lane < nent) zres[lane] = val;
             MHX_WAVE_SYNC();
@@ -582,7 +657,7 @@ MHX_DEV void mhx_reg_zig_fill(double (&y)[D], const mhx_philox_key& ks, const mh
                     const bool has = f != 0ull && e >= 0 && e < 64;
                     int sls = has ? __ffsll((long long)f) - 1 : -1;
                     asm volatile("" : "+v"(sls));          // (else hipcc splits the test into `has` AND a compare: 5 instructions per register for 3)
-                    const double pv = zres[has ? e : 0];
+                    const mhx_real pv = zres[has ? e : 0];
                     // (skipping a block of 8 registers when no lane's slot lies in it was measured: 3.35 against 3.25 ms per launch at
                     // c2_user -- the ballots and branches cost more than the skipped selects)
 #pragma unroll
@@ -600,10 +675,21 @@ MHX_DEV void mhx_reg_zig_fill(double (&y)[D], const mhx_philox_key& ks, const mh
             MHX_WAVE_SYNC();                               // (the next window writes the queue and the results again)
         }
     }
-}
+#if !MHX_REAL64
+    if (SLAB) {
+        MHX_WAVE_SYNC();
+#pragma unroll
+        for (int p = 0; p < (D + 3) / 4; ++p) {
+            const mhx_f4v v = *(const mhx_f4v*)(zslab + ((p * 64 + lane) << 2));
+            if (4 * p < D) y[4 * p] = v.x;
+            if (4 * p + 1 < D) y[4 * p + 1] = v.y;
+            if (4 * p + 2 < D) y[4 * p + 2] = v.z;
+            if (4 * p + 3 < D) y[4 * p + 3] = v.w;
+        }
+    }
 #endif
+}
 
-#if MHX_REAL64
 // ---------------------------------------------------------------------------------------------
 // The register kernel (lane per chain, any target incl. a user's HIP source) with the ZIGGURAT generator (round 4, second
 // session).  Box-Muller is 3/5 of that kernel's instructions (~73 per normal against ~25 for Philox + table fast path); what kept
@@ -616,36 +702,43 @@ MHX_DEV void mhx_reg_zig_fill(double (&y)[D], const mhx_philox_key& ks, const mh
 // chain would be 51 KB per wave).  Every lane stays alive (idle lanes shadow the last chain) because the queue and the
 // patch are wave-wide.  LDS of the one-wave block: [layer table][queue][results][state tail (D - XR) x 64].  Same normals as
 // mhx_zig_normal, hence the oracle's chains at reduction shape 1.
-#define MHX_REG_ZIG_LDS_BYTES(D, XR) ((size_t)((D) - (XR)) * 64 * 8 + MHX_ZIG_TABLE_BYTES + 128 + 512)
-template <int D, int TK, int PK, int XR = D>
+// (fp32, round 6: the same kernel in 4-byte reals over the signed pair table.)
+#define MHX_REG_ZIG_LDS_BYTES(D, XR) ((size_t)((D) - (XR)) * 64 * sizeof(mhx_real) + MHX_REG_ZIG_HDR_BYTES)
+template <int D, int TK, int PK, int XR = D, bool SLAB = false>
 MHX_DEV void mhx_rwmh_reg_zig_body(const mhx_rwmh_args& a, const mhx_real* __restrict__ tparams,
-                                   const mhx_real* __restrict__ pvec, double* __restrict__ lds)
+                                   const mhx_real* __restrict__ pvec, double* __restrict__ lds_)
 {
     static_assert(PK != MHX_PROP_DENSE, "ISO / DIAG proposals");
     const int lane = (int)threadIdx.x;                         // one wave per block
     const long c_raw = (long)blockIdx.x * 64 + lane;
     const bool valid = c_raw < a.nchains;
     const long c = valid ? c_raw : (long)a.nchains - 1;        // idle lanes shadow the last chain (loads only)
-    double* const zt = lds;                                    // (the table at offset 0: its look-up addresses need no base)
-    unsigned short* const zq = (unsigned short*)(zt + MHX_ZIG_TABLE_BYTES / 8);      // 64 entries
-    double* const zres = zt + MHX_ZIG_TABLE_BYTES / 8 + 16;                           // 64 refined normals
-    double* const xl = zres + 64 + lane;                       // this lane's column of the [D - XR][64] state tail
+    mhx_real* const zt = (mhx_real*)lds_;                      // (the table at offset 0: its look-up addresses need no base)
+    unsigned short* const zq = (unsigned short*)((char*)lds_ + MHX_ZIG_TABLE_BYTES);  // 64 entries
+    mhx_real* const zres = (mhx_real*)((char*)lds_ + MHX_ZIG_TABLE_BYTES + 128);      // 64 refined normals
+    mhx_real* const xl = zres + 64 + lane;                     // this lane's column of the [D - XR][64] state tail
+    mhx_real* const zslab = zres + 64 + (D - XR) * 64;         // (SLAB) the step's normals [block][lane][4], 16-byte aligned
+#if MHX_REAL64
     for (int e = lane; e <= MHX_ZIG_N; e += 64) zt[e] = mhx_zig_x[e];
+#else
+    if ((mhx_u32)(mhx_u64)lds_ != 0u) __builtin_trap();        // (MHX_ZIG_PAIR_OF addresses the table at LDS byte 0)
+    for (int e = lane; e < MHX_ZIG_PAIR_FLOATS; e += 64) zt[e] = mhx_zig_pair_entry(e);
+#endif
     __syncthreads();
     const mhx_u64 id = a.first_chain + (mhx_u64)c;
     const mhx_u32 id_lo = (mhx_u32)id, id_hi = (mhx_u32)(id >> 32);
     const mhx_philox_key ks = mhx_philox_schedule(a.seed);
     const long ld = a.ld;
 
-    double x[XR > 0 ? XR : 1], y[D];
-    auto getx = [&](const int k) -> double { return k < XR ? x[k < XR ? k : 0] : xl[(k - XR) * 64]; };
+    mhx_real x[XR > 0 ? XR : 1], y[D];
+    auto getx = [&](const int k) -> mhx_real { return k < XR ? x[k < XR ? k : 0] : xl[(k - XR) * 64]; };
     const mhx_u32 cu = (mhx_u32)c * MHX_RB;
 #pragma unroll
     for (int k = 0; k < D; ++k) {
-        const double v = mhx_ld_off(a.x + (long)k * ld, cu);
+        const mhx_real v = mhx_ld_off(a.x + (long)k * ld, cu);
         if (k < XR) x[k < XR ? k : 0] = v; else xl[(k - XR) * 64] = v;
     }
-    double lp = a.lp[c];
+    mhx_real lp = a.lp[c];
     mhx_u32 nacc = a.acc_count[c];
     mhx_u32 wave_acc = 0;
     bool last = a.last_acc[c] != 0;
@@ -660,13 +753,13 @@ MHX_DEV void mhx_rwmh_reg_zig_body(const mhx_rwmh_args& a, const mhx_real* __res
     for (int i = 0; i < a.nsteps; ++i) {
         const mhx_u32 step = a.step0 + (mhx_u32)i;
         // ---- the step's D standard normals into the candidate's registers (fast path, queue, refinement, hand-back)
-        mhx_reg_zig_fill<D>(y, ks, id_lo, id_hi, step, MHX_STREAM_PROPOSAL, zt, zq, zres, lane, (long)blockIdx.x * 64, a.first_chain, a.nchains, zsign);
+        mhx_reg_zig_fill<D, SLAB>(y, ks, id_lo, id_hi, step, MHX_STREAM_PROPOSAL, zt, zq, zres, lane, (long)blockIdx.x * 64, a.first_chain, a.nchains, zsign, zslab);
         // ---- propose: y = x + s n   (src/proposal.jl:49-56)
 #pragma unroll
         for (int k = 0; k < D; ++k) y[k] = mhx_fma(PK == MHX_PROP_ISO ? a.pscale : pvec[k], y[k], getx(k));
         // ---- log-density of the candidate and the accept test (src/mh-core.jl:103-108)
-        const double lpy = mhx_target_eval<TK>(TK, y, D, tparams, a.ntparams, a.tconst);
-        const double logu = mhx_accept_logu(ks, id_lo, id_hi, step, ac);
+        const mhx_real lpy = mhx_target_eval<TK>(TK, y, D, tparams, a.ntparams, a.tconst);
+        const mhx_real logu = mhx_accept_logu(ks, id_lo, id_hi, step, ac);
         const bool acc = logu < (lpy - lp);          // strict; NaN compares false => reject
         // (the accepted lanes MOVE the candidate over the state under their execute mask: where the state's registers are AGPRs
         // -- d = 100: all 60 of them -- a select costs read + 2 v_cndmask + write per real, the move one write per word)
@@ -707,7 +800,7 @@ MHX_DEV void mhx_rwmh_reg_zig_body(const mhx_rwmh_args& a, const mhx_real* __res
     }
     if (lane == 0) atomicAdd(a.acc_total, (mhx_u64)wave_acc);
 }
-#endif
+
 
 template <int L, int NBL, int TK, int PK, bool MOM, int WALK = MHX_WALK_PLAIN, int GEN = MHX_GEN_BOX_MULLER>
 MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restrict__ tparams,
@@ -724,11 +817,6 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
     typedef double mhx_d2 __attribute__((ext_vector_type(2)));
 #else
     // the fp32 form (round 6): same layout in 4-byte reals -- table, then per wave the slab [block][lane][4], the queue, the masks
-    typedef float mhx_f2v __attribute__((ext_vector_type(2)));
-    typedef float mhx_f4v __attribute__((ext_vector_type(4)));
-    // a candidate's table pair is read at its LDS byte address itself -- the table opens the kernel's LDS (no static LDS in this
-    // kernel: checked below); through the generic pointer hipcc adds the array's base, a literal 0 it learns too late to fold
-    typedef const __attribute__((address_space(3))) mhx_f2v* mhx_lds_f2v;
     const float* zt = (const float*)mhx_coop_lds;
     if (ZIG && (mhx_u32)(mhx_u64)mhx_coop_lds != 0u) __builtin_trap();
     constexpr int SLABD = NBL * 4 * 64;                            // floats of one step's normals
@@ -1042,7 +1130,7 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
             for (int i = 0; i < NBL; ++i) {
                 mhx_f2v xe[4];                                      // +-x[layer], x[layer + 1] of the block's candidates
 #pragma unroll
-                for (int e = 0; e < 4; ++e) xe[e] = *(mhx_lds_f2v)((kw[e] >> 20) & 0xff8u);     // (LDS byte address: the table is at 0)
+                for (int e = 0; e < 4; ++e) xe[e] = MHX_ZIG_PAIR_OF(kw[e]);
                 __builtin_amdgcn_sched_barrier(0);
                 mhx_u32 nw[4];
                 if (i + 1 < NBL) draw(i + 1, nw);                   // the next block's Philox rounds run while the look-ups are in flight
@@ -1052,15 +1140,7 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     nn[j] = mhx_zig_ax(kw[j], xe[j].x);             // signed: the table entry carries the sign
-                    // (the compare's carry shifted in: `m = m + m + vcc`)
-#define MHX_ZIG_NOTE(m, x, hi) asm("v_cmp_nlt_f32 vcc, |%1|, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(x), "v"(hi) : "vcc")
-#ifdef MHX_TOOLS_BUILD
-#ifdef MHX_ZIG_FORCE_FAIL
-#undef MHX_ZIG_NOTE
-#define MHX_ZIG_NOTE(m, x, hi) m = ((m) << 1) | ((!(__builtin_fabsf(x) < (hi)) || ((4 * i + j + lane) % (MHX_ZIG_FORCE_FAIL) == 0)) ? 1u : 0u)
-#endif
-#endif
-                    MHX_ZIG_NOTE(m4[j], nn[j], xe[j].y);
+                    MHX_ZIG_NOTE(m4[j], nn[j], xe[j].y, 4 * i + j);
                 }
                 v4.x = nn[0]; v4.y = nn[1]; v4.z = nn[2]; v4.w = nn[3];
                 *(mhx_f4v*)(zn + ((i * 64 + lane) << 2)) = v4;
@@ -1543,12 +1623,18 @@ MHX_DEV void mhx_rwmh_wave_body(const mhx_rwmh_args& a, const mhx_real* __restri
 #ifndef MHX_JIT_XR
 #define MHX_JIT_XR MHX_JIT_DIM
 #endif
-extern "C" __global__ void __launch_bounds__(64)
+#ifndef MHX_JIT_REG_WAVES
+#define MHX_JIT_REG_WAVES 1       // waves per SIMD the register budget is cut for (the host asks for 2 where the arrays leave room)
+#endif
+extern "C" __global__ void __launch_bounds__(64, MHX_JIT_REG_WAVES)
 mhx_jit_rwmh_reg(const mhx_rwmh_args a, const mhx_real* __restrict__ tparams, const mhx_real* __restrict__ pvec)
 {
 #if defined(MHX_JIT_GEN) && MHX_JIT_GEN == 1
     extern __shared__ double mhx_reg_zig_lds[];                // MHX_REG_ZIG_LDS_BYTES(MHX_JIT_DIM, MHX_JIT_XR)
-    mhx_rwmh_reg_zig_body<MHX_JIT_DIM, MHX_JIT_TK, MHX_JIT_PK, MHX_JIT_XR>(a, tparams, pvec, mhx_reg_zig_lds);
+#ifndef MHX_JIT_ZSLAB
+#define MHX_JIT_ZSLAB 0
+#endif
+    mhx_rwmh_reg_zig_body<MHX_JIT_DIM, MHX_JIT_TK, MHX_JIT_PK, MHX_JIT_XR, (MHX_JIT_ZSLAB != 0)>(a, tparams, pvec, mhx_reg_zig_lds);
 #elif MHX_JIT_XR < MHX_JIT_DIM
     extern __shared__ mhx_real mhx_reg_state_tail[];           // [MHX_JIT_DIM - MHX_JIT_XR][64]
     mhx_rwmh_reg_body<MHX_JIT_DIM, MHX_JIT_TK, MHX_JIT_PK, MHX_JIT_XR>(a, tparams, pvec, mhx_reg_state_tail);

@@ -64,13 +64,13 @@ GEN_TEXT = {None: "Box-Muller", "box-muller": "Box-Muller", "ziggurat": "ziggura
 
 
 def pick_gen(args, dtype, coop=True):
-    """RWMH: the ziggurat generator (what Julia's own randn is) wherever the kernel has the form -- fp64: the cooperative and the
-    register kernel; fp32 (round 6): the cooperative kernel; Box-Muller otherwise; --normal-gen overrides."""
+    """RWMH: the ziggurat generator (what Julia's own randn is) -- the cooperative and the register kernel have the form in both
+    widths (fp32 since round 6); on the fp32 REGISTER kernel Box-Muller is still the faster stream by 5 % (profiles/r06_zig32_ab.txt)
+    and stays the default there; --normal-gen overrides."""
     g = getattr(args, "normal_gen", "auto")
-    has = dtype == "f64" or coop
     if g == "auto":
-        return "ziggurat" if has else None
-    return None if g == "box-muller" or not has else g
+        return "ziggurat" if dtype == "f64" or coop else None
+    return None if g == "box-muller" else g
 
 
 def sigma_ar1(d, rho):
@@ -180,7 +180,7 @@ class C2:
         self.lanes = args.lanes
         self.literal = getattr(args, "c2_literal", False)
         self.user = getattr(args, "c2_user", False)       # the same target as a user log-density in HIP source: DensityModel(f), JIT-lowered
-        self.gen = pick_gen(args, dtype, coop=not self.user)   # (the register kernel of a user log-density has its ziggurat form in fp64)
+        self.gen = pick_gen(args, dtype, coop=not self.user)
 
     USER_SOURCE = """
 MHX_LOGDENSITY(x, d, data, ndata)

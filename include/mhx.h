@@ -72,7 +72,7 @@ int mhx_ctx_pci_bus_id(const mhx_ctx *ctx, char *buf, size_t len);
  * in tests/): they exist so that every form can be reached at every size, and for A/B measurements.
  *   kernel form     NO_PREBUILT NO_MFMA EMCEE_MFMA EMCEE_SCALAR EMCEE_FUSED EMCEE_PERSIST EMCEE_DEFER EMCEE_SWEEP_DEFER
  *                   EMCEE_PRELOAD RAM_G
- *   tuning          COOP_WAVES MFMA_WAVES REG_MAX_DIM REG_XR REG_UNROLL MALA_XR EMCEE_WAVES EMCEE_MFMA_WAVES
+ *   tuning          COOP_WAVES MFMA_WAVES REG_MAX_DIM REG_XR REG_UNROLL REG_WAVES REG_ZSLAB MALA_XR EMCEE_WAVES EMCEE_MFMA_WAVES
  *                   EMCEE_SCAL_WPB EMCEE_SCAL_MODE EMCEE_SCAL_REC EMCEE_REC_STORE EMCEE_ROW_STORE EMCEE_COOP_REC RAM_LDS_PAD
  *                   WAVE_K (4 | 8 speculative candidates per round of the wave-per-chain kernel; default: by the last call's acceptance)
  *   return path     HOST_COMPACT (1 / 0: the accept-compacted form of mhx_run_sample_to_host on / off; default: on for thinning == 1
@@ -168,15 +168,14 @@ typedef struct {
                                       another and pair with already-updated walkers (Gauss-Seidel), one wavefront, for
                                       fidelity checks at the reference's test sizes; the default is the parallel half-split */
 #define MHX_FLAG_ZIGGURAT 16 /* RWMH and (round 5) MALA runs: standard normals by the table ZIGGURAT of the arithmetic spec (DESIGN.md
-                                section 3.11: fp64 contexts 1024 equal-area layers and 64 bits per normal; fp32 contexts -- 0.6.0, the
-                                cooperative RWMH kernel only -- 256 layers and 32 bits per normal; exact rejection sampling) instead of
+                                section 3.11: fp64 contexts 1024 equal-area layers and 64 bits per normal; fp32 contexts -- since 0.6.0 --
+                                256 layers and 32 bits per normal; exact rejection sampling) instead of
                                 Box-Muller -- a third fewer instructions per transition on the cooperative kernel (separable
                                 catalogue targets) and on the register kernel (any target within its dimension limit, a user's
                                 HIP source included), ISO / DIAG proposals.  It selects the STREAM of normals, so the chain differs
                                 from the Box-Muller chain of the same seed (both target the same law); the value in effect is
                                 reported in mhx_stats.normal_gen and fixes the chain bit for bit.  MHX_EINVAL where the run's
-                                kernel has no ziggurat form (dense factors, the matrix-core and state-in-HBM kernels; in fp32 also the
-                                register kernel and MALA).  MALA: the
+                                kernel has no ziggurat form (dense factors, the matrix-core and state-in-HBM kernels).  MALA: the
                                 noise z of the Langevin proposal, on the lane-per-chain register kernel (any target with a gradient
                                 within that kernel's dimension limit; reduce_lanes <= 1). */
 #define MHX_FLAG_DENSE_FACTOR 32 /* Ensemble runs: treat the precision factor of a dense-Gaussian target as dense even when it is

@@ -62,8 +62,9 @@ def test_rwmh_random_configurations(mhx, oracle, case, real):
     spl = mhx.StaticMH(dist) if static else mhx.RWMH(dist)
     init = None if rng.integers(0, 2) else (rng.normal(size=(d, C)) * 0.5).astype(np.float32)
     seed, first = int(rng.integers(1, 1 << 40)), int(rng.integers(0, 1 << 33))
-    # the ziggurat generator (fp64, separable targets, ISO / DIAG proposals: the cooperative kernel) on a third of the eligible cases
-    zig = real == "f64" and tname != "corr" and pname != "dense" and bool(rng.integers(0, 3) == 0)
+    # the ziggurat generator (separable targets, ISO / DIAG proposals: the cooperative kernel; fp32 too since round 6) on a third of the
+    # eligible cases
+    zig = tname != "corr" and pname != "dense" and bool(rng.integers(0, 3) == 0)
     chain = mhx.sample(mhx.DensityModel(tgt), spl, N, C, seed=seed, first_chain=first, initial_params=init,
                        discard_initial=di, thinning=th, normal_gen="ziggurat" if zig else None)
     L = chain.stats["reduce_lanes"]

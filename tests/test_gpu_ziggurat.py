@@ -34,7 +34,7 @@ def f64(mhx, oracle):
 
 @pytest.fixture(params=["f64", "f32"])
 def width(request, mhx, oracle):
-    """the cooperative kernel's ziggurat exists in both widths since round 6 (fp32: 256 layers, one Philox word per normal)"""
+    """the ziggurat exists in both widths since round 6 (fp32: 256 layers, one Philox word per normal)"""
     old_m, old_o = mhx.get_default_dtype(), oracle.get_dtype()
     mhx.set_default_dtype(request.param)
     oracle.set_dtype(request.param)
@@ -125,14 +125,15 @@ def test_where_the_ziggurat_does_not_exist(mhx, f64):
     spl = mhx.RWMH(mhx.MvNormal(mhx.zeros(d), 0.04 * mhx.I))
     with pytest.raises(mhx.ArgumentError, match="ziggurat"):                 # dense Gaussian target: matrix-core / dense kernels
         mhx.Run(mhx.DensityModel(mhx.CorrGaussian(cases.sigma_ar1(d, 0.5))), spl, nchains=64, normal_gen="ziggurat")
-    # fp32: the cooperative kernel has the form (round 6), the register kernel (a user's source) does not
-    ok = mhx.Run(mhx.DensityModel(mhx.IsoGaussian(d)), spl, nchains=64, normal_gen="ziggurat", dtype="f32")
-    ok.init(None)
-    ok.sample(3)
-    assert ok.stats()["normal_gen"] == 1 and ok.stats()["dtype"] == "f32"
-    with pytest.raises(mhx.ArgumentError, match="ziggurat"):
-        mhx.Run(mhx.DensityModel(mhx.HipLogDensity(user_targets.SHIFTED_GAUSS, d, data=np.zeros(2 * d, np.float32) + 1)), spl, nchains=64,
-                normal_gen="ziggurat", dtype="f32")
+    # fp32 (round 6): the cooperative kernel and the register kernel (a user's source) have the form as in fp64
+    for model in (mhx.DensityModel(mhx.IsoGaussian(d)),
+                  mhx.DensityModel(mhx.HipLogDensity(user_targets.SHIFTED_GAUSS, d, data=np.zeros(2 * d, np.float32) + 1))):
+        ok = mhx.Run(model, spl, nchains=64, normal_gen="ziggurat", dtype="f32")
+        ok.init(None)
+        ok.sample(3)
+        assert ok.stats()["normal_gen"] == 1 and ok.stats()["dtype"] == "f32"
+    with pytest.raises(mhx.ArgumentError, match="ziggurat"):                 # ... and the dense target is refused there too
+        mhx.Run(mhx.DensityModel(mhx.CorrGaussian(cases.sigma_ar1(d, 0.5))), spl, nchains=64, normal_gen="ziggurat", dtype="f32")
     with pytest.raises(mhx.ArgumentError):                                    # forced generic kernel
         mhx.Run(mhx.DensityModel(mhx.IsoGaussian(d)), spl, nchains=64, normal_gen="ziggurat", flags=mhx.FLAG_GENERIC)
 
@@ -225,11 +226,12 @@ def test_jit_defs_of_the_tools_build_reach_hiprtc_and_change_no_bit(mhx, oracle,
 
 
 @pytest.mark.parametrize("d,C,prop", [(5, 70, "iso"), (64, 33, "diag"), (100, 130, "iso"), (100, 64, "diag"), (130, 40, "iso"), (160, 65, "iso")])
-def test_ziggurat_on_the_register_kernel_with_a_user_log_density(mhx, oracle, f64, d, C, prop):
+def test_ziggurat_on_the_register_kernel_with_a_user_log_density(mhx, oracle, width, d, C, prop):
     """normal_gen="ziggurat" on the lane-per-chain register kernel (any target; here a user's HIP source): fast-path normals straight
     into the candidate's registers, the wave-step's failures queued, refined side by side and handed back to their owners' registers.
     Same chains as the oracle at reduction shape 1 -- chains that do not fill a wave (idle lanes shadow the last chain), the state's
-    tail in LDS above 64 dimensions, one / two / three words of failure mask, thinning with a discarded prefix, the state after."""
+    tail in LDS above 64 dimensions, one / two / three words of failure mask, thinning with a discarded prefix, the state after.
+    Both widths since round 6 (fp32: a Philox block serves four normals, the signed pair table, failures noted by add-with-carry)."""
     rng = np.random.default_rng(1000 + d)
     data = np.concatenate([rng.normal(size=d), 0.5 + rng.random(d)]).astype(np.float32)
     model = mhx.DensityModel(mhx.HipLogDensity(user_targets.SHIFTED_GAUSS, d, data=data))
@@ -256,7 +258,7 @@ def test_ziggurat_on_the_register_kernel_with_a_user_log_density(mhx, oracle, f6
     _same(cnt, ref["accept_counts"], "accept counts")
 
 
-def test_ziggurat_register_kernel_draws_its_own_start(mhx, oracle, f64):
+def test_ziggurat_register_kernel_draws_its_own_start(mhx, oracle, width):
     """(no initial_params: the start is a bare proposal draw by the same generator, src/proposal.jl:41-47)"""
     d, C = 24, 100
     data = np.concatenate([np.zeros(d), np.ones(d)]).astype(np.float32)
