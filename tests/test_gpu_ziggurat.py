@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import cases
+from conftest import soak_tail
 import user_targets
 
 pytestmark = pytest.mark.gpu
@@ -225,7 +226,7 @@ def test_jit_defs_of_the_tools_build_reach_hiprtc_and_change_no_bit(mhx, oracle,
     assert "hiprtc" in str(ei.value)
 
 
-@pytest.mark.parametrize("d,C,prop", [(5, 70, "iso"), (64, 33, "diag"), (100, 130, "iso"), (100, 64, "diag"), (130, 40, "iso"), (160, 65, "iso")])
+@pytest.mark.parametrize("d,C,prop", soak_tail([(5, 70, "iso"), (100, 130, "iso"), (130, 40, "iso"), (64, 33, "diag"), (100, 64, "diag"), (160, 65, "iso")], 3))
 def test_ziggurat_on_the_register_kernel_with_a_user_log_density(mhx, oracle, width, d, C, prop):
     """normal_gen="ziggurat" on the lane-per-chain register kernel (any target; here a user's HIP source): fast-path normals straight
     into the candidate's registers, the wave-step's failures queued, refined side by side and handed back to their owners' registers.
