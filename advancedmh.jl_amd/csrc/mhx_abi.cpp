@@ -94,6 +94,15 @@ extern "C" int mhx_ctx_jit_counts(const mhx_ctx* ctx, int64_t* compiles, int64_t
     if (cache_hits) *cache_hits = b;
     return MHX_OK;
 }
+extern "C" int mhx_ctx_jit_compiler(const mhx_ctx* ctx, char* compiler, size_t len, int64_t* ext_compiles)
+{
+    if (!ctx) return mhx_fail(MHX_EINVAL, "mhx_ctx_jit_compiler: ctx is NULL");
+    long n = 0;
+    return is64(ctx) ? mhx_f64::api_ctx_jit_compiler(reinterpret_cast<const mhx_f64::mhx_ctx*>(ctx), compiler, len, ext_compiles ? &n : nullptr) ||
+                           (ext_compiles ? (*ext_compiles = n, 0) : 0)
+                     : mhx_f32::api_ctx_jit_compiler(reinterpret_cast<const mhx_f32::mhx_ctx*>(ctx), compiler, len, ext_compiles ? &n : nullptr) ||
+                           (ext_compiles ? (*ext_compiles = n, 0) : 0);
+}
 extern "C" int mhx_ctx_host_pin_counts(const mhx_ctx* ctx, int64_t* registered, int64_t* released)
 {
     if (!ctx) return mhx_fail(MHX_EINVAL, "mhx_ctx_host_pin_counts: ctx is NULL");

@@ -37,6 +37,7 @@
 #else
 #include "mhx_jit_embed.inc"         // generated (embed_headers.py --release): the same text without its MHX_TOOLS_BUILD blocks
 #endif
+#include "mhx_jit_ext.h"        // run-time kernels through the installation's clang++ (pure host code)
 #include "mhx_host_expand.h"    // the host threads of the accept-compacted return path (pure host code, shared by both instantiations)
 #include "mhx_impl.h"           // the prototypes of this instantiation (api_*), shared with the dispatcher mhx_abi.cpp
 
@@ -191,7 +192,8 @@ struct mhx_ctx : mhx_handle_hdr {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::map<std::string, std::unique_ptr<jit_module>> jit;
-    long jit_compiles = 0, jit_cache_hits = 0;      // hiprtc compilations / code objects taken from the on-disk cache
+    long jit_compiles = 0, jit_cache_hits = 0;      // compilations / code objects taken from the on-disk cache
+    long jit_ext_compiles = 0;                      // ... of the compilations, by the installation's clang++ (mhx_jit_ext.h)
     // the return path of mhx_run_sample_to_host: a second stream for the D2H copies + the slab hand-over events
     hipStream_t copy_stream = nullptr;
     hipEvent_t slab_done[2] = {nullptr, nullptr}, slab_free[2] = {nullptr, nullptr};
@@ -257,7 +259,7 @@ static const opt_name k_opt_names[] = {
     {"EMCEE_MFMA", 0}, {"EMCEE_MFMA_WAVES", 0}, {"EMCEE_SCALAR", 0}, {"EMCEE_SCAL_MODE", 0}, {"EMCEE_SCAL_WPB", 0}, {"EMCEE_SCAL_REC", 0},
     {"EMCEE_FUSED", 0}, {"EMCEE_PERSIST", 0}, {"EMCEE_PRELOAD", 0}, {"EMCEE_DEFER", 0}, {"EMCEE_SWEEP_DEFER", 0}, {"EMCEE_WAVES", 0},
     {"EMCEE_REC_STORE", 0}, {"EMCEE_ROW_STORE", 0}, {"EMCEE_COOP_REC", 0},
-    {"HOST_COMPACT", 0}, {"HOST_THREADS", 0}, {"HOST_CHUNK", 0}, {"HOST_NUMA", 0}, {"TOTAL_CHAINS", 0},
+    {"HOST_COMPACT", 0}, {"HOST_THREADS", 0}, {"HOST_CHUNK", 0}, {"HOST_NUMA", 0}, {"TOTAL_CHAINS", 0}, {"JIT_COMPILER", 0},
 #ifdef MHX_TOOLS_BUILD
     {"ZIG_PROBE", 1}, {"ZIG_FORCE_FAIL", 1}, {"JIT_DEFS", 1}, {"EMCEE_PROBE", 1}, {"EMCEE_STAMPS", 1}, {"EMCEE_STAMPS_FILE", 1},
     {"FAULT_SLAB", 1}, {"RAM_PROF", 1},
@@ -336,6 +338,19 @@ int api_ctx_jit_counts(const mhx_ctx* ctx, long* compiles, long* cache_hits)
     return MHX_OK;
 }
 
+int api_ctx_jit_compiler(const mhx_ctx* ctx, char* compiler, size_t len, long* ext_compiles)
+{
+    if (compiler && len) {
+        const char* jc = nullptr;
+        auto it = ctx->options.find("JIT_COMPILER");
+        if (it != ctx->options.end()) jc = it->second.c_str();
+        const std::string id = (jc && !strcmp(jc, "hiprtc")) ? std::string() : mhx_jit_ext_identity();
+        snprintf(compiler, len, "%s", id.c_str());
+    }
+    if (ext_compiles) *ext_compiles = ctx->jit_ext_compiles;
+    return MHX_OK;
+}
+
 int api_ctx_destroy(mhx_ctx* ctx)
 {
     if (!ctx) return MHX_OK;
@@ -368,11 +383,13 @@ static std::string jit_cache_dir()
     if (mkdir(dir.c_str(), 0755) != 0 && errno != EEXIST) return "";
     return dir;
 }
-static std::string jit_cache_name(const std::string& source, const std::vector<std::string>& opts, const char* const* hdr_src, int nhdr)
+static std::string jit_cache_name(const std::string& source, const std::vector<std::string>& opts, const char* const* hdr_src, int nhdr,
+                                  const std::string& compiler_id)
 {
     unsigned long long h1 = 1469598103934665603ull, h2 = 0x9e3779b97f4a7c15ull;
     auto mix = [&](const void* d, size_t n) { h1 = fnv64(d, n, h1); h2 = fnv64(d, n, h2 ^ (unsigned long long)n); };
     mix(source.data(), source.size());
+    mix(compiler_id.data(), compiler_id.size());
     for (auto& o : opts) { mix(o.data(), o.size()); mix("\0", 1); }
     for (int i = 0; i < nhdr; ++i) mix(hdr_src[i], strlen(hdr_src[i]));
     int vmaj = 0, vmin = 0, rt = 0;
@@ -444,8 +461,13 @@ static int jit_compile(mhx_ctx* ctx, const std::string& key_in, const std::strin
             p = e;
         }
     for (auto& o : extra_opts) opts.push_back(o);
+    // Which compiler: the installation's clang++ where there is one (mhx_jit_ext.h: hiprtc is whichever copy the process loaded first,
+    // a PyTorch wheel's older one inside Python), hiprtc otherwise or when option JIT_COMPILER says "hiprtc"; "clang" = no fall-back
+    const char* jc = opt(ctx, "JIT_COMPILER");
+    const bool want_ext = !(jc && !strcmp(jc, "hiprtc")) && !mhx_jit_ext_identity().empty();
+    if (jc && !strcmp(jc, "clang") && !want_ext) return mhx_fail(MHX_EJIT, "JIT_COMPILER=clang: no clang++ found (MHX_JIT_CLANG, ROCM_PATH, /opt/rocm)");
     const std::string cdir = jit_cache_dir();
-    const std::string cname = cdir.empty() ? std::string() : jit_cache_name(source, opts, hdr_src, 11);
+    const std::string cname = cdir.empty() ? std::string() : jit_cache_name(source, opts, hdr_src, 11, want_ext ? mhx_jit_ext_identity() : std::string());
     std::vector<char> code;
     bool from_cache = !cdir.empty() && jit_cache_read(cdir + "/" + cname, &code);
     if (from_cache) {
@@ -459,6 +481,30 @@ static int jit_compile(mhx_ctx* ctx, const std::string& key_in, const std::strin
         (void)hipGetLastError();            // a stale / foreign object: fall through and compile
         from_cache = false;
     }
+    if (want_ext) {
+        std::string xlog;
+        if (mhx_jit_ext_compile(source, hdr_src, hdr_name, 11, opts, &code, &xlog)) {
+            std::unique_ptr<jit_module> m(new jit_module);
+            const hipError_t e = hipModuleLoadData(&m->mod, code.data());
+            if (e == hipSuccess) {
+                ctx->jit_compiles++;
+                ctx->jit_ext_compiles++;
+                if (!cdir.empty()) jit_cache_write(cdir, cname, code);
+                *out = m.get();
+                ctx->jit[key] = std::move(m);
+                return MHX_OK;
+            }
+            (void)hipGetLastError();
+            xlog = std::string("hipModuleLoadData: ") + hipGetErrorString(e);
+        }
+        if (jc && !strcmp(jc, "clang")) {
+            if (xlog.size() > 1800) xlog.resize(1800);
+            return mhx_fail(MHX_EJIT, "JIT_COMPILER=clang: %s", xlog.c_str());
+        }
+        // (a source that does not compile fails here too: hiprtc's log is the one the caller gets)
+    }
+    // the object this path produces is keyed without the offline compiler's identity
+    const std::string cname_rtc = (cdir.empty() || !want_ext) ? cname : jit_cache_name(source, opts, hdr_src, 11, std::string());
     hiprtcProgram prog = nullptr;
     hiprtcResult r = hiprtcCreateProgram(&prog, source.c_str(), "mhx_jit.hip", 11, hdr_src, hdr_name);
     if (r != HIPRTC_SUCCESS) return mhx_fail(MHX_EJIT, "hiprtcCreateProgram: %s", hiprtcGetErrorString(r));
@@ -483,7 +529,7 @@ static int jit_compile(mhx_ctx* ctx, const std::string& key_in, const std::strin
     std::unique_ptr<jit_module> m(new jit_module);
     hipError_t e = hipModuleLoadData(&m->mod, code.data());
     if (e != hipSuccess) return mhx_fail(MHX_EJIT, "hipModuleLoadData: %s", hipGetErrorString(e));
-    if (!cdir.empty()) jit_cache_write(cdir, cname, code);
+    if (!cdir.empty()) jit_cache_write(cdir, cname_rtc, code);
     *out = m.get();
     ctx->jit[key] = std::move(m);
     return MHX_OK;

@@ -33,6 +33,7 @@ void mhx_jit_unlock();
     int api_ctx_pci_bus_id(const mhx_ctx* ctx, char* buf, size_t len);                                                 \
     int api_run_shape(const mhx_run* r, int32_t* dim, int32_t* nchains);                                               \
     int api_ctx_jit_counts(const mhx_ctx* ctx, long* compiles, long* cache_hits);                                      \
+    int api_ctx_jit_compiler(const mhx_ctx* ctx, char* compiler, size_t len, long* ext_compiles);                      \
     int api_ctx_host_pin_counts(const mhx_ctx* ctx, long* registered, long* released);                                  \
     int api_target_builtin(mhx_ctx* ctx, int kind, int dim, const REAL* params, size_t nparams, mhx_target** out);     \
     int api_target_from_hip_source(mhx_ctx* ctx, const char* src, int dim, const REAL* data, size_t ndata,             \

@@ -418,6 +418,19 @@ MHX_DEV void mhx_rwmh_whiten_body(const mhx_rwmh_args& a, const mhx_real* __rest
 #define MHX_ZIG_SLAB_AT(sl, ln) (((((sl) >> 2) * 64 + (ln)) << 2) + ((sl) & 3))
 #endif
 
+#if MHX_REAL64
+// (experiment, MHX_ZADDC: the fp64 fast path noting its failures like the fp32 one -- compare + add-with-carry into four mask words)
+#ifndef MHX_ZADDC
+#define MHX_ZADDC 1
+#endif
+#define MHX_ZIG_NOTE64(m, ax, hi, slot) asm("v_cmp_nlt_f64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(ax), "v"(hi) : "vcc")
+#ifdef MHX_TOOLS_BUILD
+#ifdef MHX_ZIG_FORCE_FAIL
+#undef MHX_ZIG_NOTE64
+#define MHX_ZIG_NOTE64(m, ax, hi, slot) m = ((m) << 1) | ((!((ax) < (hi)) || (((slot) + lane) % (MHX_ZIG_FORCE_FAIL) == 0)) ? 1u : 0u)
+#endif
+#endif
+#endif
 #if !MHX_REAL64
 // fp32: "candidate x left its rectangle" noted by shifting the compare's carry into a mask word: `m = m + m + (|x| >= hi)` -- two
 // instructions (compare with the magnitude as an operand modifier, add-with-carry); the bit of the FIRST candidate noted ends up highest
@@ -433,7 +446,7 @@ MHX_DEV void mhx_rwmh_whiten_body(const mhx_rwmh_args& a, const mhx_real* __rest
 typedef float mhx_f2v __attribute__((ext_vector_type(2)));
 typedef float mhx_f4v __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(3))) mhx_f2v* mhx_lds_f2v;
-#define MHX_ZIG_PAIR_OF(w) (*(mhx_lds_f2v)(((w) >> 20) & 0xff8u))
+#define MHX_ZIG_PAIR_OF(w) (*(mhx_lds_f2v)(size_t)(((w) >> 20) & 0xff8u))
 #endif
 
 // The candidates of this wave-step that left their rectangles (0.4 % of the draws: a dozen per wave-step at d = 100), gathered
@@ -997,6 +1010,8 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
             // phase A: every slot's candidate by the fast path -- table look-up, multiply, compare -- into LDS; the slots that
             // left their rectangles are noted in `fm` and finished by mhx_zig_fixup before the candidate state is formed
             mhx_u64 fm = 0ull;
+            constexpr bool ZADDC = MHX_ZADDC != 0 && NBL > 4 && NBL <= 16;
+            mhx_u32 m4[4] = {0u, 0u, 0u, 0u};
             // Software pipeline over the lane's blocks: the table look-ups of block i are in flight while the Philox rounds of
             // block i + 1 run (one wave per SIMD has no other wave to hide an LDS round trip behind): per block -- issue the 4
             // look-ups (layers known since the previous stage), Philox of the next block, then consume.
@@ -1056,6 +1071,7 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
                             nn[j] = mhx_zig_signed(ax, klo[4 * bb + j], zsign);
                             // (|x| of the signed value: a source modifier of the compare, and `ax` dies at the sign merge -- the merge
                             // then happens in place instead of into a register that a v_mov brings back for the 16-byte LDS write)
+                            if (ZADDC) { MHX_ZIG_NOTE64(m4[j], ax, xe[4 * bb + j].y, 4 * i + j); continue; }
                             bool fail = ZFABS ? !(__builtin_fabs(nn[j]) < xe[4 * bb + j].y) : !(ax < xe[4 * bb + j].y);
 #ifdef MHX_TOOLS_BUILD
 #ifdef MHX_ZIG_FORCE_FAIL       // test hook of the tools build (option ZIG_FORCE_FAIL): every n-th slot is sent through the fix-up although
@@ -1081,11 +1097,18 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
                     for (int e = 0; e < 4 * GB; ++e) { khi[e] = nhi[e]; klo[e] = nlo[e]; }
                 }
             }
+            if (ZADDC) {
+                fm = (mhx_u64)(m4[0] | (m4[1] << 16)) | ((mhx_u64)(m4[2] | (m4[3] << 16)) << 32);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (k_last + j >= d) fm &= ~(1ull << (16 * j));      // padding dimensions past the end of the vector need no normal
+            }
             if (KS > 1) zfm[sg * 64 + lane] = fm;
             fm1 = fm;
             anyfail = anyfail || fm != 0ull;
             }
         }
+        constexpr bool ZADDC_ = MHX_ZADDC != 0 && NBL > 4 && NBL <= 16;
 #ifdef MHX_TOOLS_BUILD
 #ifndef MHX_ZIG_PROBE
 #define MHX_ZIG_PROBE 0        // timing probe of the tools build (option ZIG_PROBE): 1 = skip the fix-up (WRONG normals)
@@ -1095,7 +1118,7 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
         if (__ballot(anyfail))
 #endif
             mhx_zig_fixup<L>(ks, zt, zn0, zq, zfm, ng, SLABD, lane, wave, a.first_chain, a.nchains, a.step0 + (mhx_u32)it0, MHX_STREAM_PROPOSAL,
-                             KS == 1, fm1);
+                             KS == 1, fm1, ZADDC_ ? NBL - 1 : -1);
     }
 #else
     if (ZIG) {

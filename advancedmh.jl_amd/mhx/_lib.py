@@ -106,7 +106,7 @@ EXPORTS = [
     "mhx_ctx_dtype", "mhx_ctx_device", "mhx_ram_set_factor_all", "mhx_ram_get_adapt_state", "mhx_emcee_exchange_plan", "mhx_emcee_exchange_pack",
     "mhx_emcee_exchange_unpack", "mhx_comm_unique_id", "mhx_comm_init", "mhx_comm_destroy", "mhx_comm_rank",
     "mhx_comm_allreduce_sum", "mhx_comm_slice", "mhx_comm_allgather_walkers",
-    "mhx_ram_get_step_stats", "mhx_ram_watch_factors", "mhx_ram_get_watched_factors", "mhx_run_sample_to_host", "mhx_host_alloc", "mhx_host_free", "mhx_ctx_jit_counts", "mhx_ctx_host_pin_counts",
+    "mhx_ram_get_step_stats", "mhx_ram_watch_factors", "mhx_ram_get_watched_factors", "mhx_run_sample_to_host", "mhx_host_alloc", "mhx_host_free", "mhx_ctx_jit_counts", "mhx_ctx_jit_compiler", "mhx_ctx_host_pin_counts",
     "mhx_ctx_set_option", "mhx_ctx_get_option", "mhx_ctx_pci_bus_id", "mhx_run_shape", "mhx_comm_init_timed", "mhx_comm_set_timeout",
     "mhx_group_create", "mhx_group_destroy", "mhx_group_size", "mhx_group_ctx", "mhx_group_shard", "mhx_group_attach", "mhx_group_run",
     "mhx_group_init", "mhx_group_sample", "mhx_group_sample_to_host", "mhx_group_stats", "mhx_group_diagnostics", "mhx_group_ess_bulk_tail",
@@ -191,6 +191,7 @@ def lib():
         L.mhx_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
         L.mhx_host_free.argtypes = [vp]
         L.mhx_ctx_jit_counts.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.mhx_ctx_jit_compiler.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int64)]
         L.mhx_ctx_host_pin_counts.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.mhx_run_get_state.argtypes = [vp, rp, rp, u32p]
         L.mhx_run_set_state.argtypes = [vp, rp]
@@ -357,6 +358,12 @@ class Context:
         a, b = C.c_int64(), C.c_int64()
         check(lib().mhx_ctx_jit_counts(self.h, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
+
+    def jit_compiler(self):
+        """(identity of the installation's clang++ that builds the run-time kernels, "" = hiprtc only; compilations it did so far)"""
+        buf, n = C.create_string_buffer(512), C.c_int64()
+        check(lib().mhx_ctx_jit_compiler(self.h, buf, 512, C.byref(n)))
+        return buf.value.decode(), int(n.value)
 
     def host_pin_counts(self):
         """(caller buffers page-locked for a mhx_run_sample_to_host call, released again) so far: equal between calls"""

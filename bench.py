@@ -1386,6 +1386,11 @@ def main():
                 out["oversubscribed"] = "%d ranks share %d device(s): a rehearsal of the flow, not a scaling point" % (world, n_gpus)
         if args.opt:
             out["config"]["options"] = dict(args.opt)
+        try:                                               # who builds the run-time kernels: the installation's clang++, or hiprtc
+            cid, next_ = ctx.jit_compiler()                # (inside Python: the PyTorch wheel's older copy of it; include/mhx.h)
+            out["config"]["jit_compiler"] = (os.path.basename(cid.split(":")[1]) + " of " + cid.split(":")[1].split("/lib/llvm")[0]) if cid else "hiprtc"
+        except Exception:
+            pass
         if st.get("tainted"):
             out["tainted"] = "a probe option of the tools build was set: NOT a valid measurement of the chains"
         if ess is not None:

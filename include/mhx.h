@@ -79,6 +79,7 @@ int mhx_ctx_pci_bus_id(const mhx_ctx *ctx, char *buf, size_t len);
  *                   and >= 1024 chains) HOST_THREADS (host threads that expand; default: what the process may use) HOST_CHUNK (chains
  *                   per unit of their work, a multiple of 64; default: so that a unit's state fits a core's L2) HOST_NUMA (0: do not
  *                   place the staging memory and the expanding threads on the GPU's memory node)
+ *   run-time kernels JIT_COMPILER ("hiprtc" | "clang" | unset = clang++ of the installation when found, else hiprtc; mhx_ctx_jit_compiler)
  *   sharding        TOTAL_CHAINS (the chains of the WHOLE run this context's runs are shards of: where the engine picks a kernel
  *                   form -- hence a summation order -- from the chain count (reduce_lanes = 0), it picks for that count, so a shard
  *                   runs what the unsharded run runs; mhx_group_shard sets it on the member's context, a process of a
@@ -90,10 +91,17 @@ int mhx_ctx_pci_bus_id(const mhx_ctx *ctx, char *buf, size_t len);
 int mhx_ctx_set_option(mhx_ctx *ctx, const char *name, const char *value);
 /* the value in effect ("" when unset) copied to buf; MHX_EINVAL for an unknown name */
 int mhx_ctx_get_option(const mhx_ctx *ctx, const char *name, char *buf, size_t len);
-/* hiprtc specialisations of this context so far: compiled by hiprtc / loaded from the on-disk code-object cache
- * ($MHX_CACHE_DIR, default ~/.cache/mhx; key = hash(source, device headers, options, hiprtc + runtime version);
+/* run-time specialisations of this context so far: compiled / loaded from the on-disk code-object cache
+ * ($MHX_CACHE_DIR, default ~/.cache/mhx; key = hash(source, device headers, options, compiler + runtime version);
  * MHX_CACHE_DIR="" or MHX_NO_JIT_CACHE=1 switches the cache off).  Either pointer may be NULL. */
 int mhx_ctx_jit_counts(const mhx_ctx *ctx, int64_t *compiles, int64_t *cache_hits);
+/* WHICH compiler builds them (0.6.0).  The installation's own clang++ where one is found -- $MHX_JIT_CLANG (a path; "0" = none),
+ * $ROCM_PATH/lib/llvm/bin/clang++, /opt/rocm/lib/llvm/bin/clang++ -- run as a child process on the same source, headers and options;
+ * the hiprtc library otherwise, when that fails, or when option JIT_COMPILER = "hiprtc" ("clang" = no fall-back).  Why: hiprtc is
+ * whichever libhiprtc.so.7 / libamd_comgr.so.3 the PROCESS loaded first -- inside Python after `import torch` the wheel's bundled,
+ * older compiler, whose cooperative RWMH kernel runs 7 % behind the one hipcc builds from the same text.  `compiler` receives
+ * "clang++:<path>:<size>:<mtime>" or "" (none found: hiprtc only), ext_compiles how many of mhx_ctx_jit_counts' compilations it did. */
+int mhx_ctx_jit_compiler(const mhx_ctx *ctx, char *compiler, size_t len, int64_t *ext_compiles);
 
 /* Page-locked host memory for result tensors (the `Chains` array of ext/AdvancedMHMCMCChainsExt.jl:12-39 lives on the
  * host): device-to-host copies into it run at the link rate and asynchronously.  Any other host buffer works too --
