@@ -1010,7 +1010,7 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
             // phase A: every slot's candidate by the fast path -- table look-up, multiply, compare -- into LDS; the slots that
             // left their rectangles are noted in `fm` and finished by mhx_zig_fixup before the candidate state is formed
             mhx_u64 fm = 0ull;
-            constexpr bool ZADDC = MHX_ZADDC != 0 && NBL > 4 && NBL <= 16;
+            constexpr bool ZADDC = (MHX_ZADDC == 2 || (MHX_ZADDC == 1 && NBL > 4)) && NBL <= 16;
             mhx_u32 m4[4] = {0u, 0u, 0u, 0u};
             // Software pipeline over the lane's blocks: the table look-ups of block i are in flight while the Philox rounds of
             // block i + 1 run (one wave per SIMD has no other wave to hide an LDS round trip behind): per block -- issue the 4
@@ -1108,7 +1108,7 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
             anyfail = anyfail || fm != 0ull;
             }
         }
-        constexpr bool ZADDC_ = MHX_ZADDC != 0 && NBL > 4 && NBL <= 16;
+        constexpr bool ZADDC_ = (MHX_ZADDC == 2 || (MHX_ZADDC == 1 && NBL > 4)) && NBL <= 16;
 #ifdef MHX_TOOLS_BUILD
 #ifndef MHX_ZIG_PROBE
 #define MHX_ZIG_PROBE 0        // timing probe of the tools build (option ZIG_PROBE): 1 = skip the fix-up (WRONG normals)
