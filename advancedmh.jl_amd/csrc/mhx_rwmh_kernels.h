@@ -1154,10 +1154,13 @@ MHX_DEV void mhx_rwmh_coop_body(const mhx_rwmh_args& a, const mhx_real* __restri
                 mhx_f2v xe[4];                                      // +-x[layer], x[layer + 1] of the block's candidates
 #pragma unroll
                 for (int e = 0; e < 4; ++e) xe[e] = MHX_ZIG_PAIR_OF(kw[e]);
-                __builtin_amdgcn_sched_barrier(0);
+#ifndef MHX_ZIG32_FENCE
+#define MHX_ZIG32_FENCE 3       // bit 0: the look-ups are issued before the next block's Philox rounds; bit 1: those before this block's fast path
+#endif
+                if (MHX_ZIG32_FENCE & 1) __builtin_amdgcn_sched_barrier(0);
                 mhx_u32 nw[4];
                 if (i + 1 < NBL) draw(i + 1, nw);                   // the next block's Philox rounds run while the look-ups are in flight
-                __builtin_amdgcn_sched_barrier(0);
+                if (MHX_ZIG32_FENCE & 2) __builtin_amdgcn_sched_barrier(0);
                 mhx_f4v v4;
                 float nn[4];
 #pragma unroll

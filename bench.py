@@ -1422,6 +1422,10 @@ def main():
                 out["f32"] = {"value": sig(wl32.units_per_step() * n32 / dt32), "ms_per_step": sig(dt32 * 1e3 / n32),
                               "acc": sig(a32 / float(t32), 3), "lanes": st32["reduce_lanes"],
                               "frac": sig(wl32.bytes_per_launch() / (k32 * 1e-3 / n32) / 1e9 / HBM_PEAK_GBS, 4)}
+                rf32 = roofline_block(wl32, args.config, "f32", k32, n32, st32)      # (PMC counts of the fp32 kernel, where taken)
+                for k in ("valu_frac", "valu_weighted_frac"):
+                    if rf32.get(k) is not None:
+                        out["f32"][k] = rf32[k]
                 wl32.run.close()
             except Exception as e:
                 out["f32"] = {"error": str(e)[:160]}

@@ -138,16 +138,36 @@ def disassemble(obj, kernel_re):
     return found, hist
 
 
+def disassemble_hsaco(path, kernel_re):
+    """the same histogram from a loadable code object (a run-time kernel kept by the JIT cache)"""
+    txt = subprocess.check_output([LLVM + "/llvm-objdump", "-d", path], text=True)
+    cur, hist, found = None, Counter(), None
+    for ln in txt.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.+)>:$", ln)
+        if m:
+            cur = m.group(1)
+            if re.search(kernel_re, cur) and found is None:
+                found = cur
+            continue
+        if cur is not None and cur == found:
+            t = ln.strip().split()
+            if t and re.match(r"^[vsdbgt]_|^buffer_|^global_|^flat_|^ds_|^scratch_", t[0]):
+                hist[t[0]] += 1
+    assert found, "no kernel matches %r in %s" % (kernel_re, path)
+    return found, hist
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--object", required=True)
+    ap.add_argument("--object")
+    ap.add_argument("--hsaco", help="a code object of the JIT cache instead of --object (run-time kernels)")
     ap.add_argument("--kernel", required=True, help="regex on the (mangled) kernel symbol")
     ap.add_argument("--pmc", help="summary.json of tools/summarize_profile.py over the pmc_valu* passes (tools/isa_mix_run.sh)")
     ap.add_argument("--pmc-kernel", help="regex on the kernel name in the PMC summary (default: derived from --kernel)")
     ap.add_argument("--launch-ms", type=float, help="average launch duration (HIP events / rocprofv3 trace)")
     ap.add_argument("--out")
     a = ap.parse_args()
-    sym, hist = disassemble(a.object, a.kernel)
+    sym, hist = disassemble_hsaco(a.hsaco, a.kernel) if a.hsaco else disassemble(a.object, a.kernel)
     valu = Counter({k: v for k, v in hist.items() if k.startswith("v_")})
     cyc = group_cycles()
     static_groups = Counter()
