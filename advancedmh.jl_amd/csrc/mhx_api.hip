@@ -344,6 +344,7 @@ int api_ctx_jit_compiler(const mhx_ctx* ctx, char* compiler, size_t len, long* e
         const char* jc = nullptr;
         auto it = ctx->options.find("JIT_COMPILER");
         if (it != ctx->options.end()) jc = it->second.c_str();
+        if (!jc) { jc = getenv("MHX_JIT_COMPILER"); if (jc && !*jc) jc = nullptr; }
         const std::string id = (jc && !strcmp(jc, "hiprtc")) ? std::string() : mhx_jit_ext_identity();
         snprintf(compiler, len, "%s", id.c_str());
     }
@@ -464,12 +465,15 @@ static int jit_compile(mhx_ctx* ctx, const std::string& key_in, const std::strin
     // Which compiler: the installation's clang++ where there is one (mhx_jit_ext.h: hiprtc is whichever copy the process loaded first,
     // a PyTorch wheel's older one inside Python), hiprtc otherwise or when option JIT_COMPILER says "hiprtc"; "clang" = no fall-back
     const char* jc = opt(ctx, "JIT_COMPILER");
+    if (!jc) { jc = getenv("MHX_JIT_COMPILER"); if (jc && !*jc) jc = nullptr; }     // (the process-wide default of the option)
     const bool want_ext = !(jc && !strcmp(jc, "hiprtc")) && !mhx_jit_ext_identity().empty();
     if (jc && !strcmp(jc, "clang") && !want_ext) return mhx_fail(MHX_EJIT, "JIT_COMPILER=clang: no clang++ found (MHX_JIT_CLANG, ROCM_PATH, /opt/rocm)");
     const std::string cdir = jit_cache_dir();
     const std::string cname = cdir.empty() ? std::string() : jit_cache_name(source, opts, hdr_src, 11, want_ext ? mhx_jit_ext_identity() : std::string());
+    // (where the offline compiler is preferred but failed on this source before, hiprtc's object is there under its own name)
+    const std::string cname_rtc = (cdir.empty() || !want_ext) ? cname : jit_cache_name(source, opts, hdr_src, 11, std::string());
     std::vector<char> code;
-    bool from_cache = !cdir.empty() && jit_cache_read(cdir + "/" + cname, &code);
+    bool from_cache = !cdir.empty() && (jit_cache_read(cdir + "/" + cname, &code) || (want_ext && jit_cache_read(cdir + "/" + cname_rtc, &code)));
     if (from_cache) {
         std::unique_ptr<jit_module> m(new jit_module);
         if (hipModuleLoadData(&m->mod, code.data()) == hipSuccess) {
@@ -501,10 +505,10 @@ static int jit_compile(mhx_ctx* ctx, const std::string& key_in, const std::strin
             if (xlog.size() > 1800) xlog.resize(1800);
             return mhx_fail(MHX_EJIT, "JIT_COMPILER=clang: %s", xlog.c_str());
         }
-        // (a source that does not compile fails here too: hiprtc's log is the one the caller gets)
+        // (a source that does not compile fails here too: hiprtc's log is the one the caller gets; MHX_JIT_VERBOSE=1 shows this one)
+        if (const char* v = getenv("MHX_JIT_VERBOSE")) if (*v && *v != '0')
+            fprintf(stderr, "mhx: the offline compiler failed on %s, hiprtc takes over: %.1500s\n", key.c_str(), xlog.c_str());
     }
-    // the object this path produces is keyed without the offline compiler's identity
-    const std::string cname_rtc = (cdir.empty() || !want_ext) ? cname : jit_cache_name(source, opts, hdr_src, 11, std::string());
     hiprtcProgram prog = nullptr;
     hiprtcResult r = hiprtcCreateProgram(&prog, source.c_str(), "mhx_jit.hip", 11, hdr_src, hdr_name);
     if (r != HIPRTC_SUCCESS) return mhx_fail(MHX_EJIT, "hiprtcCreateProgram: %s", hiprtcGetErrorString(r));

@@ -20,8 +20,8 @@
 
 // The engine is compiled twice from these headers: mhx_real = float (MHX_REAL64 = 0) and mhx_real = double (MHX_REAL64 = 1:
 // the reference computes in Float64 end to end -- Distributions' rand / logpdf, src/RobustAdaptiveMetropolis.jl:187-196).
-// The two pre-built instantiations live in their own namespaces inside libmhx.so; hiprtc gets -DMHX_REAL64=... and no
-// namespace (one module per specialisation).
+// The two pre-built instantiations live in their own namespaces inside libmhx.so; a run-time build gets -DMHX_REAL64=... and no
+// namespace (one module per specialisation; a user's source sits in front of the kernels' header, outside any namespace).
 #ifndef MHX_REAL64
 #define MHX_REAL64 0
 #endif
@@ -35,7 +35,7 @@ typedef float mhx_real;
 #define MHX_NS mhx_f32
 #endif
 #define MHX_RB ((unsigned)sizeof(mhx_real))              // bytes per real
-#ifdef __HIPCC_RTC__
+#if defined(__HIPCC_RTC__) || defined(MHX_JIT_BUILD)      // (MHX_JIT_BUILD: the same run-time source through the installation's clang++)
 #define MHX_NS_BEGIN
 #define MHX_NS_END
 #else

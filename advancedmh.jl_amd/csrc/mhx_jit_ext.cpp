@@ -99,7 +99,8 @@ bool mhx_jit_ext_compile(const std::string& source, const char* const* hdr_src, 
     ok = ok && write_file(src, source.data(), source.size());
     int status = -1;
     if (ok) {
-        std::vector<std::string> args = {c.path, "-x", "hip", "--offload-device-only", "--no-gpu-bundle-output", "-I" + dir};
+        // MHX_JIT_BUILD: what __HIPCC_RTC__ tells the headers under hiprtc -- a run-time module, no namespace around the engine
+        std::vector<std::string> args = {c.path, "-x", "hip", "--offload-device-only", "--no-gpu-bundle-output", "-DMHX_JIT_BUILD=1", "-I" + dir};
         if (!c.root.empty()) args.push_back("--rocm-path=" + c.root);
         for (const std::string& o : opts) args.push_back(o);
         args.push_back("-o"); args.push_back(obj); args.push_back(src);

@@ -1389,6 +1389,8 @@ def main():
         try:                                               # who builds the run-time kernels: the installation's clang++, or hiprtc
             cid, next_ = ctx.jit_compiler()                # (inside Python: the PyTorch wheel's older copy of it; include/mhx.h)
             out["config"]["jit_compiler"] = (os.path.basename(cid.split(":")[1]) + " of " + cid.split(":")[1].split("/lib/llvm")[0]) if cid else "hiprtc"
+            comp, hits = ctx.jit_counts()
+            out["config"]["jit"] = {"compiled": comp, "by_clang": next_, "from_cache": hits}
         except Exception:
             pass
         if st.get("tainted"):

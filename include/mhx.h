@@ -66,7 +66,7 @@ int mhx_ctx_destroy(mhx_ctx *ctx);
 int mhx_ctx_pci_bus_id(const mhx_ctx *ctx, char *buf, size_t len);
 
 /* Engine options: explicit, per context, set BEFORE the runs they steer are created.  The library reads nothing but
- * MHX_CACHE_DIR / MHX_NO_JIT_CACHE / XDG_CACHE_HOME / HOME (where compiled kernels are kept) and MHX_RCCL_LIB from the environment;
+ * MHX_CACHE_DIR / MHX_NO_JIT_CACHE / XDG_CACHE_HOME / HOME (where compiled kernels are kept), MHX_JIT_COMPILER / MHX_JIT_CLANG / ROCM_PATH / MHX_JIT_VERBOSE (who compiles them) and MHX_RCCL_LIB from the environment;
  * which kernel form runs is chosen from (dim, chains, dtype) unless an option says otherwise, and mhx_stats reports the form.
  * Every option below yields the SAME chain law and, for a given reduction shape, the same bits (each form is held to the oracle
  * in tests/): they exist so that every form can be reached at every size, and for A/B measurements.
@@ -97,7 +97,9 @@ int mhx_ctx_get_option(const mhx_ctx *ctx, const char *name, char *buf, size_t l
 int mhx_ctx_jit_counts(const mhx_ctx *ctx, int64_t *compiles, int64_t *cache_hits);
 /* WHICH compiler builds them (0.6.0).  The installation's own clang++ where one is found -- $MHX_JIT_CLANG (a path; "0" = none),
  * $ROCM_PATH/lib/llvm/bin/clang++, /opt/rocm/lib/llvm/bin/clang++ -- run as a child process on the same source, headers and options;
- * the hiprtc library otherwise, when that fails, or when option JIT_COMPILER = "hiprtc" ("clang" = no fall-back).  Why: hiprtc is
+ * the hiprtc library otherwise, when that fails, or when option JIT_COMPILER = "hiprtc" ("clang" = no fall-back; $MHX_JIT_COMPILER is
+ * the process-wide default of the option: a child process costs ~0.5 s more per kernel than hiprtc in-process, which a test suite that
+ * compiles hundreds of small kernels may not want to pay).  Why: hiprtc is
  * whichever libhiprtc.so.7 / libamd_comgr.so.3 the PROCESS loaded first -- inside Python after `import torch` the wheel's bundled,
  * older compiler, whose cooperative RWMH kernel runs 7 % behind the one hipcc builds from the same text.  `compiler` receives
  * "clang++:<path>:<size>:<mtime>" or "" (none found: hiprtc only), ext_compiles how many of mhx_ctx_jit_counts' compilations it did. */

@@ -16,6 +16,22 @@ def pytest_configure(config):
                                        "skipped unless the mark expression names it: -m 'gpu and soak' (or MHX_SOAK=1)")
 
 
+    # Which compiler builds the run-time kernels (include/mhx.h: mhx_ctx_jit_compiler): the product's default is the installation's
+    # clang++ as a child process -- 0.5 s more per kernel than hiprtc in-process, 150 s over the few hundred small kernels of the
+    # default tier (profiles/r06_gpu_suite_time.txt).  The default tier therefore compiles with hiprtc (same source, same options, same
+    # bits: test_run_time_kernels_by_either_compiler_give_the_same_chains) EXCEPT the full-size tests of the bench's own configurations
+    # (tests/test_gpu_fullsize.py) and the compiler test; the soak tier runs everything under the product's default.
+    expr = config.getoption("-m") or ""
+    if not ("soak" in expr or os.environ.get("MHX_SOAK")):
+        os.environ.setdefault("MHX_JIT_COMPILER", "hiprtc")
+
+
+@pytest.fixture
+def product_jit(monkeypatch):
+    """the product's own choice of compiler for the run-time kernels (see pytest_configure)"""
+    monkeypatch.delenv("MHX_JIT_COMPILER", raising=False)
+
+
 def soak_tail(values, keep):
     """the first `keep` values in the default tier, the rest in the soak tier (the default `-m gpu` run must leave
     the driver's time limit a wide margin on a slow lease; every SURVEY section-8 row keeps its full-size test in the default tier)"""

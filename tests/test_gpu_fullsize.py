@@ -10,6 +10,11 @@ import cases
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _the_products_compiler(product_jit):
+    """the bench's own configurations: their run-time kernels by the compiler the product picks (tests/conftest.py)"""
+
+
 def _same(a, b, what):
     a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
     assert a.shape == b.shape, what

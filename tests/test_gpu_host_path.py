@@ -181,6 +181,60 @@ def test_jit_objects_persist_across_contexts(mhx, real, tmp_path, monkeypatch):
     assert hit4 == 0 and comp4 == comp1
 
 
+def test_run_time_kernels_by_either_compiler_give_the_same_chains(mhx, oracle, real, tmp_path, monkeypatch, product_jit):
+    """round 6: the run-time kernels are built by the installation's clang++ (a child process) where there is one, by the hiprtc
+    library otherwise (include/mhx.h: mhx_ctx_jit_compiler, option JIT_COMPILER).  Either way the same source under the same
+    options: the same chains bit for bit (and the oracle's); the two compilers' objects live under different cache names; a source
+    that does not compile is reported with hiprtc's log whichever compiler was tried first."""
+    monkeypatch.setenv("MHX_CACHE_DIR", str(tmp_path / "jit"))
+    old = oracle.get_dtype()
+    oracle.set_dtype(real)
+    try:
+        d, nch, N = 37, 70, 12                              # (no pre-built shape: the cooperative kernel is specialised)
+        s = float(np.float32(0.3))
+        got, nfiles = {}, {}
+        for jc in (None, "hiprtc"):
+            ctx = mhx.Context(0, real)
+            ctx.set_option("JIT_COMPILER", jc)
+            cid, _ = ctx.jit_compiler()
+            if jc == "hiprtc":
+                assert cid == ""
+            r = mhx.Run(mhx.DensityModel(mhx.IsoGaussian(d)), mhx.RWMH(mhx.MvNormal(mhx.zeros(d), s * s * mhx.I)), nchains=nch, seed=11, first_chain=2,
+                        reduce_lanes=2, ctx=ctx)
+            r.init(None)
+            r.sample(N)
+            got[jc] = (r.samples()[0].copy(), r.stats()["reduce_lanes"])
+            comp, _ = ctx.jit_counts()
+            _, ext = ctx.jit_compiler()
+            assert comp >= 1 and (ext == comp if (jc is None and cid) else ext == 0), (jc, cid, comp, ext)
+            r.close()
+            nfiles[jc] = len(os.listdir(tmp_path / "jit"))
+        _same(got[None][0], got["hiprtc"][0], "clang++ / hiprtc")
+        L = got[None][1]
+        ref = oracle.rwmh(oracle.iso_gauss(d, reduce_lanes=L), oracle.Proposal(oracle.PROP_ISO, s), oracle.schedule(N), 11, 2, nch)
+        _same(got[None][0], ref["samples"], "oracle")
+        ctx = mhx.Context(0, real)
+        have_clang = ctx.jit_compiler()[0] != ""
+        if have_clang:
+            assert nfiles["hiprtc"] > nfiles[None], "the two compilers' objects must not share cache names"
+        # a user's source goes the same way (it sits in front of the kernels' header, outside any namespace)
+        uctx = mhx.Context(0, real)
+        ur = mhx.Run(mhx.DensityModel(mhx.HipLogDensity(USER_SRC % ("0.25", "0.25"), 6)), mhx.RWMH(mhx.MvNormal(mhx.zeros(6), 0.25 * mhx.I)),
+                     nchains=64, seed=3, ctx=uctx)
+        ur.init(None)
+        ur.sample(4)
+        ur.close()
+        if have_clang:
+            assert uctx.jit_compiler()[1] == uctx.jit_counts()[0] >= 1, (uctx.jit_compiler(), uctx.jit_counts())
+        # a source that does not compile: hiprtc's log reaches the caller
+        with pytest.raises(Exception) as ei:
+            bad = mhx.DensityModel(mhx.HipLogDensity("MHX_LOGDENSITY(x, d, data, ndata) { return not_a_symbol; }", 4))
+            mhx.Run(bad, mhx.RWMH(mhx.MvNormal(mhx.zeros(4), 0.25 * mhx.I)), nchains=64, seed=1, ctx=ctx).init(None)
+        assert "hiprtc" in str(ei.value) and "not_a_symbol" in str(ei.value)
+    finally:
+        oracle.set_dtype(old)
+
+
 @pytest.mark.soak_f32
 def test_a_failing_slab_drains_the_copies_and_releases_the_callers_buffer_once(mhx, real, tools_engine):
     """ADVICE r3 / VERDICT r3 #8: an error in the MIDDLE of mhx_run_sample_to_host (after the copies of earlier slabs were
