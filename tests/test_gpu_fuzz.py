@@ -194,6 +194,7 @@ def test_mala_random_configurations(mhx, oracle, case, real):
     _same(chain.accepted, ref["accepted"], what)
 
 
+@pytest.mark.soak_f32
 def test_dimensions_beyond_the_specialised_kernels(mhx, oracle, real):
     """Sizes past every specialised kernel's range fall back to the cooperative / run-time-dimension / generic kernels
     and stay bit-exact: RWMH d = 4000 (64 lanes per chain), emcee d = 300 (isotropic and dense target), RAM d = 1024,

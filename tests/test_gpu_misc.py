@@ -416,6 +416,7 @@ def test_static_proposal_survives_setparams(mhx, oracle, real):
     run.close()
 
 
+@pytest.mark.soak_f32
 def test_runs_release_their_device_memory(mhx, real):
     """create / init / sample / diagnostics / destroy cycles over every sampler leave the free-memory count unchanged."""
     import ctypes as C

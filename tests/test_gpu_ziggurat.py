@@ -155,7 +155,7 @@ def test_device_normals_pass_distribution_checks(mhx, width):
         assert abs((np.abs(x) > t).sum() - e) < 5 * np.sqrt(e) + 1, t
 
 
-@pytest.mark.parametrize("every", [3, 7])
+@pytest.mark.parametrize("every", soak_tail([3, 7], 1))
 def test_fixup_queue_windows(mhx, oracle, width, tools_engine, every):
     """More than 64 candidates of one wave-step in the fix-up queue (never seen in practice: a dozen fail) -- forced by the
     ZIG_FORCE_FAIL test hook of the TOOLS build, which sends every n-th slot through the queue although its candidate is inside its
