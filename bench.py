@@ -1389,8 +1389,6 @@ def main():
         try:                                               # who builds the run-time kernels: the installation's clang++, or hiprtc
             cid, next_ = ctx.jit_compiler()                # (inside Python: the PyTorch wheel's older copy of it; include/mhx.h)
             out["config"]["jit_compiler"] = (os.path.basename(cid.split(":")[1]) + " of " + cid.split(":")[1].split("/lib/llvm")[0]) if cid else "hiprtc"
-            comp, hits = ctx.jit_counts()
-            out["config"]["jit"] = {"compiled": comp, "by_clang": next_, "from_cache": hits}
         except Exception:
             pass
         if st.get("tainted"):
@@ -1436,6 +1434,11 @@ def main():
         if lone and args.config == "c2" and not args.no_other_configs and not args.c2_literal and not args.c2_user:
             wl.run.close()                                        # 13.4 GB of samples: C4 needs the room
             out["configs"] = other_configs(mhx, ctx, args, barrier)
+        try:                                                      # run-time kernels of the whole run: built here / by clang++ / from the disk cache
+            comp, hits = ctx.jit_counts()
+            out["config"]["jit"] = {"compiled": comp, "by_clang": ctx.jit_compiler()[1], "from_cache": hits}
+        except Exception:
+            pass
         line = json.dumps(out, separators=(",", ":"))
         if len(line) >= 8000:                                     # the driver keeps an 8 KB tail: drop detail before the contract keys go
             for k in ("ess", "e2e_host"):
