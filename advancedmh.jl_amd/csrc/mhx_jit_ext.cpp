@@ -117,8 +117,10 @@ bool mhx_jit_ext_compile(const std::string& source, const char* const* hdr_src, 
         posix_spawn_file_actions_destroy(&fa);
         if (rc != 0) { ok = false; if (log) *log = std::string("posix_spawn: ") + strerror(rc); }
         else {
-            while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {}
-            ok = WIFEXITED(status) && WEXITSTATUS(status) == 0;
+            int w;
+            while ((w = waitpid(pid, &status, 0)) < 0 && errno == EINTR) {}
+            // (a host that ignores SIGCHLD reaps the child itself: ECHILD -- the object file then says how it went)
+            ok = w < 0 ? errno == ECHILD : (WIFEXITED(status) && WEXITSTATUS(status) == 0);
         }
     }
     if (ok) {
