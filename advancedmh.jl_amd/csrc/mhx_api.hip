@@ -261,7 +261,7 @@ static const opt_name k_opt_names[] = {
     {"EMCEE_REC_STORE", 0}, {"EMCEE_ROW_STORE", 0}, {"EMCEE_COOP_REC", 0},
     {"HOST_COMPACT", 0}, {"HOST_THREADS", 0}, {"HOST_CHUNK", 0}, {"HOST_NUMA", 0}, {"TOTAL_CHAINS", 0}, {"JIT_COMPILER", 0},
 #ifdef MHX_TOOLS_BUILD
-    {"ZIG_PROBE", 1}, {"ZIG_FORCE_FAIL", 1}, {"JIT_DEFS", 1}, {"EMCEE_PROBE", 1}, {"EMCEE_STAMPS", 1}, {"EMCEE_STAMPS_FILE", 1},
+    {"ZIG_PROBE", 1}, {"ZIG_FORCE_FAIL", 1}, {"JIT_DEFS", 1}, {"JIT_FLAGS", 1}, {"EMCEE_PROBE", 1}, {"EMCEE_STAMPS", 1}, {"EMCEE_STAMPS_FILE", 1},
     {"FAULT_SLAB", 1}, {"RAM_PROF", 1},
 #endif
 };
@@ -437,7 +437,8 @@ static int jit_compile(mhx_ctx* ctx, const std::string& key_in, const std::strin
     // kernel's LDS layout behind the host's back), and the release library has no such door.
     const char* xdefs = MHX_PROBE_OPT(ctx, "JIT_DEFS");
     struct jit_guard { jit_guard() { mhx_jit_lock(); } ~jit_guard() { mhx_jit_unlock(); } } one_at_a_time;
-    const std::string key = (xdefs && *xdefs) ? key_in + "/xd=" + xdefs : key_in;
+    const char* xflags = MHX_PROBE_OPT(ctx, "JIT_FLAGS");      // (tools build: raw compiler options, blank-separated, for A/B of code generation)
+    const std::string key = ((xdefs && *xdefs) ? key_in + "/xd=" + xdefs : key_in) + ((xflags && *xflags) ? std::string("/xf=") + xflags : std::string());
     auto it = ctx->jit.find(key);
     if (it != ctx->jit.end()) { *out = it->second.get(); return MHX_OK; }
     const char* hdr_src[] = {k_src_mhx_zig_table_h, k_src_mhx_device_math_h, k_src_mhx_targets_h, k_src_mhx_rwmh_kernels_h,
@@ -462,6 +463,14 @@ static int jit_compile(mhx_ctx* ctx, const std::string& key_in, const std::strin
             p = e;
         }
     for (auto& o : extra_opts) opts.push_back(o);
+    if (xflags)
+        for (const char* p = xflags; *p;) {
+            while (*p == ' ') ++p;
+            const char* e = p;
+            while (*e && *e != ' ') ++e;
+            if (e > p) opts.push_back(std::string(p, e));
+            p = e;
+        }
     // Which compiler: the installation's clang++ where there is one (mhx_jit_ext.h: hiprtc is whichever copy the process loaded first,
     // a PyTorch wheel's older one inside Python), hiprtc otherwise or when option JIT_COMPILER says "hiprtc"; "clang" = no fall-back
     const char* jc = opt(ctx, "JIT_COMPILER");

@@ -85,7 +85,7 @@ int mhx_ctx_pci_bus_id(const mhx_ctx *ctx, char *buf, size_t len);
  *                   runs what the unsharded run runs; mhx_group_shard sets it on the member's context, a process of a
  *                   multi-process run sets it itself)
  * value == NULL unsets.  An unknown name is MHX_EINVAL.  The tools build (libmhx_tools.so, `make tools`) additionally knows
- * timing probes and fault injection (ZIG_PROBE, EMCEE_PROBE, EMCEE_STAMPS, ZIG_FORCE_FAIL, FAULT_SLAB, JIT_DEFS, RAM_PROF): setting one
+ * timing probes and fault injection (ZIG_PROBE, EMCEE_PROBE, EMCEE_STAMPS, ZIG_FORCE_FAIL, FAULT_SLAB, JIT_DEFS, JIT_FLAGS, RAM_PROF): setting one
  * marks the context TAINTED -- mhx_stats.tainted = 1 for every run of it, and the host mirrors refuse to build a Chains from
  * such a run.  In libmhx.so those names do not exist. */
 int mhx_ctx_set_option(mhx_ctx *ctx, const char *name, const char *value);

@@ -3,7 +3,7 @@ them (include/mhx.h: mhx_ctx_set_option).  `bridge(mhx)` turns the variables a t
 default contexts -- binding the TOOLS build first when one of them is a probe (whose runs are then marked tainted)."""
 import os
 
-PROBES = ("ZIG_PROBE", "EMCEE_PROBE", "EMCEE_STAMPS", "EMCEE_STAMPS_FILE", "ZIG_FORCE_FAIL", "FAULT_SLAB", "JIT_DEFS")
+PROBES = ("ZIG_PROBE", "EMCEE_PROBE", "EMCEE_STAMPS", "EMCEE_STAMPS_FILE", "ZIG_FORCE_FAIL", "FAULT_SLAB", "JIT_DEFS", "JIT_FLAGS")
 NOT_OPTIONS = ("LIB", "DTYPE", "CACHE_DIR", "NO_JIT_CACHE", "RCCL_LIB", "FUZZ_SEED", "BENCH_LAUNCHED", "BENCH_BOUND", "BENCH_FORCE_DIST", "STORE_PORT", "DEVICE", "GEN")
 
 

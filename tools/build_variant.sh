@@ -8,6 +8,6 @@ make -s all
 mkdir -p ../abvar
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wall -Wno-unused-function -Wno-pass-failed -Wno-array-bounds"
 hipcc $FLAGS -DMHX_REAL64=1 "$@" -c -o ../abvar/mhx_api_f64_$name.o mhx_api.hip
-hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-Bsymbolic -o ../abvar/libmhx_$name.so mhx_api_f32.o ../abvar/mhx_api_f64_$name.o mhx_abi.o mhx_comm.o mhx_group.o mhx_host_expand.o -lhiprtc -ldl -lpthread
+hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-Bsymbolic -o ../abvar/libmhx_$name.so mhx_api_f32.o ../abvar/mhx_api_f64_$name.o mhx_abi.o mhx_comm.o mhx_group.o mhx_host_expand.o mhx_jit_ext.o -lhiprtc -ldl -lpthread
 rm -f ../abvar/mhx_api_f64_$name.o
 echo built ../abvar/libmhx_$name.so
